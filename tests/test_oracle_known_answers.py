@@ -1,0 +1,154 @@
+"""Hand-derivable known answers that pin the oracle.  CPU only."""
+import numpy as np
+import pytest
+
+from hiertcn_amd.args import hier_tcn_args, make_args
+from oracle import hiertcn_oracle as O
+
+
+def test_param_count_matches_reference_graph():
+    # the number model.py:182 would print for --model_type hier --model_low_type tcn at defaults
+    args = hier_tcn_args()
+    p = O.init_params(args, seed=0)
+    assert O.count_params(p) == 5_750_698
+    assert p["hier/emb/kernel"].shape == (20778, 128)
+    assert p["hier/tcn/emb/kernel"].shape == (128 + 256, 128)
+    assert p["hier/tcn/temporal_conv_net/tblock_1/conv1/kernel"].shape == (5, 128, 128)
+    assert p["hier/multi_rnn_cell/cell_0/gru_cell/gates/kernel"].shape == (256, 256)
+    assert np.all(p["hier/multi_rnn_cell/cell_0/gru_cell/gates/bias"] == 1.0)
+
+
+def test_single_level_tcn_shapes_have_downsample_only_on_block4():
+    args = make_args([], model_type="tcn")
+    assert args.tcn_channel == [128, 128, 128, 128, 256, 256]  # args.py:310-311
+    p = O.init_params(args, seed=0, model="tcn")
+    ds = [k for k in p if k.endswith("/dense/kernel") and "tblock" in k]
+    assert ds == ["tcn/temporal_conv_net/tblock_4/dense/kernel"]  # customized_tcn_cell.py:102-106
+
+
+def test_causal_conv_snippet_is_causal():
+    # mirrors the commented snippet customized_tcn_cell.py:52-67: CausalConv1D(1,3,dilation=2)
+    x = np.array([1, 2, 300, 4, 5], np.float64)[None, :, None]
+    W = np.array([0.5, -1.0, 2.0])[:, None, None]
+    o = O.causal_conv1d(x, W, np.zeros(1), 2)[0, :, 0]
+    # o[t] = W0*x[t-4] + W1*x[t-2] + W2*x[t]
+    exp = [2 * 1, 2 * 2, 2 * 300 - 1 * 1, 2 * 4 - 1 * 2, 2 * 5 - 300 + 0.5 * 1]
+    assert np.allclose(o, exp)
+    # the spike at t=2 must not leak to t<2
+    x2 = x.copy(); x2[0, 2, 0] = 0
+    o2 = O.causal_conv1d(x2, W, np.zeros(1), 2)[0, :, 0]
+    assert np.array_equal(o[:2], o2[:2])
+
+
+def test_tcn_spike_does_not_leak_backwards():
+    # mirrors customized_tcn_cell.py:163-180
+    args = hier_tcn_args(tcn_channel=[8, 8, 8], kernel_size=3, item_num=50, hidden_dim=4, emb_dim=8)
+    p = O.init_params(args, seed=3)
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal((1, 10, 8 + 8))
+    h0 = O.tcn_hidden(args, x, p, "hier/tcn", O.EXACT64)
+    x[0, 5] += 100.0
+    h1 = O.tcn_hidden(args, x, p, "hier/tcn", O.EXACT64)
+    assert np.array_equal(h0[0, :5], h1[0, :5])
+    assert not np.allclose(h0[0, 5:], h1[0, 5:])
+
+
+def test_identity_conv_block():
+    # K=1-equivalent: only the last tap is non-zero and equals I -> conv(x)=x ; block = relu(relu(x)+x)
+    C = 6
+    W = np.zeros((5, C, C)); W[4] = np.eye(C)
+    p = {"b/conv1/kernel": W, "b/conv1/bias": np.zeros(C)}
+    x = np.random.default_rng(1).standard_normal((2, 7, C))
+    out = O.temporal_block(x, p, "b", 2, O.EXACT64)
+    assert np.allclose(out, np.maximum(np.maximum(x, 0) + x, 0))
+
+
+def test_gru_zero_weights():
+    # zero kernels, gate bias 1, cand bias 0 -> h' = sigma(1)*h + (1-sigma(1))*tanh(0)
+    H = 5
+    h = np.random.default_rng(2).standard_normal((3, H))
+    out = O.gru_cell(np.zeros((3, 4)), h, np.zeros((4 + H, 2 * H)), np.ones(2 * H), np.zeros((4 + H, H)), np.zeros(H))
+    s1 = 1 / (1 + np.exp(-1.0))
+    assert np.allclose(out, s1 * h)
+
+
+def test_gru_gate_order_r_first():
+    # make only the FIRST half of the gates (r) tiny -> candidate ignores h; u=sigmoid(0)=0.5
+    H = 2
+    Wg = np.zeros((1 + H, 2 * H)); bg = np.array([-50.0, -50.0, 0.0, 0.0])
+    Wc = np.zeros((1 + H, H)); Wc[1:, :] = 10 * np.eye(H)  # candidate sees r*h only
+    h = np.array([[1.0, -2.0]])
+    out = O.gru_cell(np.zeros((1, 1)), h, Wg, bg, Wc, np.zeros(H))
+    # r ~ 0 -> c = tanh(0) = 0 ; h' = 0.5*h
+    assert np.allclose(out, 0.5 * h, atol=1e-12)
+
+
+def test_null_id_is_zero_embedding_and_pool_has_bias():
+    E = np.arange(12, dtype=np.float64).reshape(4, 3) + 1
+    e = O.embed_ids(np.array([[0, 2, 3]]), E)
+    assert np.array_equal(e[0, 0], np.zeros(3)) and np.array_equal(e[0, 1], E[2])
+    p = {"hier/emb/kernel": E, "hier/emb/bias": np.array([10.0, 20.0, 30.0])}
+    pooled = O.session_mean_pool(np.array([[2, 3, 0, 0]]), p)
+    assert np.allclose(pooled[0], (E[2] + E[3]) / 2 + [10, 20, 30])  # model_hier.py:83-85
+
+
+def test_all_masked_rows_rank_zero_and_topk_is_iota():
+    pred = np.random.default_rng(0).standard_normal((2, 3, 11))
+    y = np.array([[0, 0, 0], [4, 0, 7]])
+    m = O.masked_loss_and_metrics(pred, y)
+    assert np.all(m["ranks"][0] == 0) and np.all(m["ce"][0] == 0)
+    idx, ranks = O.calc_metric_topk(pred, y)
+    assert np.array_equal(idx[0, 0], np.arange(11))  # all-zero row: ties -> lower index first
+    # fast and slow rank definitions agree on rows without ties
+    assert np.array_equal(ranks[1, [0, 2]], m["ranks"][1, [0, 2]])
+
+
+def test_rank_is_strict_greater_and_includes_null_candidate():
+    z = np.array([[[5.0, 1.0, 3.0, 3.0, 0.0]]])
+    m = O.masked_loss_and_metrics(z, np.array([[2]]))
+    assert m["ranks"][0, 0] == 1  # only index 0 (the null id) is strictly greater; tie at 3 not counted
+    assert np.isclose(m["recall1"], 0.0) and np.isclose(m["recall5"], 1.0)
+    assert np.isclose(m["mrr"], 0.5 / (1 + 1e-6))
+    ce = np.log(np.exp(z[0, 0]).sum()) - 3.0
+    assert np.isclose(m["loss"], ce / (1 + 1e-6))
+
+
+def test_loss_mean_of_lane_means():
+    rng = np.random.default_rng(5)
+    pred = rng.standard_normal((3, 4, 9))
+    y = np.array([[1, 2, 0, 0], [0, 0, 0, 0], [3, 4, 5, 6]])
+    m = O.masked_loss_and_metrics(pred, y)
+    ce = m["ce"]
+    exp = (ce[0].sum() / (2 + 1e-6) + ce[2].sum() / (4 + 1e-6)) / 2  # user_count = 2 (model.py:113)
+    assert np.isclose(m["loss"], exp)
+
+
+def test_model_hier_state_reset_and_slot_independence():
+    args = hier_tcn_args(item_num=40, hidden_dim=8, emb_dim=8, tcn_channel=[8, 8], num_layer=2)
+    p = O.init_params(args, seed=1)
+    rng = np.random.default_rng(0)
+    B, S, L = 3, 4, 5
+    x = [rng.integers(1, 40, (B, L)) for _ in range(S)]
+    for xi in x:
+        xi[:, 0] = 0
+    y = [rng.integers(1, 40, (B, L)) for _ in range(S)]
+    mask = [np.ones((B, 1)) for _ in range(S)]
+    mask[1][0, 0] = 0.0  # lane 0's user ends at slot 1
+    st0 = rng.standard_normal((B, 16))
+    pred, st = O.model_hier(args, x, y, mask, st0, p)
+    assert pred.shape == (B, S * L, 40) and st.shape == (B, 16)
+    # slot 2 of lane 0 must equal a fresh run from a zero state
+    pred2, _ = O.model_hier(args, [x[2][:1]], [y[2][:1]], [mask[2][:1]], np.zeros((1, 16)), p)
+    assert np.allclose(pred[0, 2 * L:3 * L], pred2[0])
+    # first prediction of a session depends only on the carried state (x[:,0] is the null id)
+    x_alt = [xi.copy() for xi in x]
+    x_alt[0][:, 1:] = rng.integers(1, 40, (B, L - 1))
+    pred3, _ = O.model_hier(args, x_alt, y, mask, st0, p)
+    assert np.allclose(pred[:, 0], pred3[:, 0])
+
+
+def test_round_bf16_matches_torch():
+    torch = pytest.importorskip("torch")
+    x = np.random.default_rng(0).standard_normal(10000).astype(np.float32) * 37
+    ref = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
+    assert np.array_equal(O.round_bf16(x), ref)
