@@ -1,0 +1,95 @@
+"""ctypes binding of libhiertcn_gfx950.so (include/hiertcn.h).  There is NO fallback: if the
+library is missing or does not export the ABI, importing the compute path raises."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
+
+MAX_BLOCKS = 8
+MAX_LAYERS = 4
+MAX_TOPK = 16
+ABI_VERSION = 1
+
+c_f32p = C.POINTER(C.c_float)
+c_i32p = C.POINTER(C.c_int32)
+c_u16p = C.POINTER(C.c_uint16)
+c_f64p = C.POINTER(C.c_double)
+
+
+class Config(C.Structure):
+    _fields_ = [("item_num", C.c_int32), ("emb_dim", C.c_int32), ("hidden_dim", C.c_int32),
+                ("num_layer", C.c_int32), ("kernel_size", C.c_int32), ("n_blocks", C.c_int32),
+                ("channels", C.c_int32 * MAX_BLOCKS), ("hier", C.c_int32)]
+
+
+class Weights(C.Structure):
+    _fields_ = [("emb_kernel", C.c_void_p), ("emb_bias", C.c_void_p), ("proj_kernel", C.c_void_p),
+                ("conv_kernel", C.c_void_p * MAX_BLOCKS), ("conv_bias", C.c_void_p * MAX_BLOCKS),
+                ("res_kernel", C.c_void_p * MAX_BLOCKS), ("res_bias", C.c_void_p * MAX_BLOCKS),
+                ("out_kernel", C.c_void_p), ("out_bias", C.c_void_p),
+                ("gru_gate_kernel", C.c_void_p * MAX_LAYERS), ("gru_gate_bias", C.c_void_p * MAX_LAYERS),
+                ("gru_cand_kernel", C.c_void_p * MAX_LAYERS), ("gru_cand_bias", C.c_void_p * MAX_LAYERS)]
+
+
+class ScoreOut(C.Structure):
+    _fields_ = [("rank", C.c_void_p), ("ce", C.c_void_p), ("target", C.c_void_p),
+                ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p), ("topk", C.c_int32)]
+
+
+# every symbol include/hiertcn.h declares: (restype, argtypes)
+SYMBOLS = {
+    "hiertcn_abi_version": (C.c_int, []),
+    "hiertcn_last_error": (C.c_char_p, []),
+    "hiertcn_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config)]),
+    "hiertcn_destroy": (C.c_int, [C.c_void_p]),
+    "hiertcn_get_config": (C.c_int, [C.c_void_p, C.POINTER(Config)]),
+    "hiertcn_set_weights": (C.c_int, [C.c_void_p, C.POINTER(Weights), C.c_void_p]),
+    "hiertcn_session_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_gru_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hiertcn_tcn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_score_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ScoreOut), C.c_void_p]),
+    "hiertcn_score_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
+    "hiertcn_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "hiertcn_forward_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                        C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(ScoreOut), C.c_void_p]),
+    "hiertcn_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
+    "hiertcn_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
+}
+
+_lib = None
+
+
+class HierTCNError(RuntimeError):
+    pass
+
+
+def load():
+    """Load the shared library (once).  Raises if it is absent: the product path never falls
+    back to a CPU implementation."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HierTCNError(
+            f"{LIB_PATH} not found: build it with `python -m hiertcn_amd.build` "
+            "(or __graft_entry__.build()).  There is no CPU fallback for the compute path.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the export is missing
+        fn.restype = res
+        fn.argtypes = args
+    if lib.hiertcn_abi_version() != ABI_VERSION:
+        raise HierTCNError(f"ABI mismatch: library {lib.hiertcn_abi_version()} vs binding {ABI_VERSION}")
+    _lib = lib
+    return lib
+
+
+def check(rc: int):
+    if rc != 0:
+        msg = load().hiertcn_last_error()
+        raise HierTCNError(f"hiertcn call failed ({rc}): {msg.decode() if msg else '?'}")

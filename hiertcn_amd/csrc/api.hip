@@ -1,0 +1,347 @@
+// C-ABI of libhiertcn_gfx950.so (include/hiertcn.h).  Host-side glue only: argument checks,
+// the per-device context that owns the converted weights, and stream-ordered kernel launches.
+// Nothing here allocates or synchronises on the hot path.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                                   \
+  do {                                                                                                  \
+    hipError_t e_ = (expr);                                                                             \
+    if (e_ != hipSuccess) return fail(HIERTCN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct hiertcn_ctx {
+  hiertcn_config_t cfg;
+  ModelDev m;
+  int device;
+  bool weights_set;
+  std::vector<void*> allocs;
+  double* metric_scratch;
+  // timing hook
+  bool timing;
+  std::vector<hipEvent_t> ev_begin, ev_end;
+  size_t ev_used;
+};
+
+template <typename T>
+static hipError_t dev_alloc(hiertcn_ctx* c, T** out, size_t count) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, count * sizeof(T) ? count * sizeof(T) : sizeof(T));
+  if (e != hipSuccess) return e;
+  c->allocs.push_back(p);
+  *out = reinterpret_cast<T*>(p);
+  return hipSuccess;
+}
+
+extern "C" {
+
+int hiertcn_abi_version(void) { return HIERTCN_ABI_VERSION; }
+const char* hiertcn_last_error(void) { return g_err; }
+
+int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
+  if (!out || !cfg) return fail(HIERTCN_ERR_INVALID, "null argument");
+  const int E = cfg->emb_dim;
+  if (cfg->item_num < 2) return fail(HIERTCN_ERR_INVALID, "item_num must be >= 2 (row 0 is the null id)");
+  if (!(E == 64 || E == 128 || E == 256))
+    return fail(HIERTCN_ERR_INVALID, "emb_dim %d unsupported: the fused gfx950 kernels are built for 64, 128, 256 (zero-pad other widths on the host)", E);
+  if (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS) return fail(HIERTCN_ERR_INVALID, "n_blocks out of range");
+  for (int i = 0; i < cfg->n_blocks; i++)
+    if (cfg->channels[i] != E)
+      return fail(HIERTCN_ERR_INVALID, "tcn_channel[%d]=%d: the fused low-level kernel needs every channel count == emb_dim (%d)", i,
+                  cfg->channels[i], E);
+  if (cfg->kernel_size < 1 || cfg->kernel_size > 8) return fail(HIERTCN_ERR_INVALID, "kernel_size out of range");
+  if (cfg->hier) {
+    if (cfg->num_layer < 1 || cfg->num_layer > HIERTCN_MAX_LAYERS) return fail(HIERTCN_ERR_INVALID, "num_layer out of range");
+    if (cfg->hidden_dim < 4 || (cfg->hidden_dim & 3)) return fail(HIERTCN_ERR_INVALID, "hidden_dim must be a positive multiple of 4");
+  }
+  const int halo = (cfg->kernel_size - 1) * (1 << (cfg->n_blocks - 1));
+  const size_t tcn_lds = (size_t)4 * (((halo + 7) & ~7) + 32) * 2 * E;
+  if (tcn_lds > 160 * 1024) return fail(HIERTCN_ERR_INVALID, "receptive-field halo %d rows does not fit the fused kernel's LDS slab", halo);
+
+  hiertcn_ctx* c = new hiertcn_ctx();
+  c->cfg = *cfg;
+  c->weights_set = false;
+  c->timing = false;
+  c->ev_used = 0;
+  c->metric_scratch = nullptr;
+  if (hipGetDevice(&c->device) != hipSuccess) {
+    delete c;
+    return fail(HIERTCN_ERR_HIP, "hipGetDevice failed (no GPU?)");
+  }
+  ModelDev& m = c->m;
+  memset(&m, 0, sizeof(m));
+  m.N = cfg->item_num;
+  m.NP = (cfg->item_num + 63) & ~63;
+  m.E = E;
+  m.hier = cfg->hier ? 1 : 0;
+  m.H = m.hier ? cfg->hidden_dim : 0;
+  m.nl = m.hier ? cfg->num_layer : 0;
+  m.HT = m.H * m.nl;
+  m.K = cfg->kernel_size;
+  m.n_blocks = cfg->n_blocks;
+  for (int i = 0; i < m.n_blocks; i++) m.C[i] = cfg->channels[i];
+  m.Clast = m.C[m.n_blocks - 1];
+
+#define ALLOC_OR_FAIL(ptr, count)                                  \
+  do {                                                             \
+    hipError_t e_ = dev_alloc(c, &(ptr), (size_t)(count));         \
+    if (e_ != hipSuccess) {                                        \
+      int rc_ = fail(HIERTCN_ERR_HIP, "hipMalloc(%s) failed: %s", #ptr, hipGetErrorString(e_)); \
+      hiertcn_destroy(c);                                          \
+      return rc_;                                                  \
+    }                                                              \
+  } while (0)
+
+  ALLOC_OR_FAIL(m.emb, (size_t)m.N * E);
+  ALLOC_OR_FAIL(m.outT, (size_t)m.NP * m.Clast);
+  ALLOC_OR_FAIL(m.out_bias, (size_t)m.NP);
+  for (int i = 0; i < m.n_blocks; i++) {
+    ALLOC_OR_FAIL(m.convT[i], (size_t)m.K * E * E);
+    ALLOC_OR_FAIL(m.conv_bias[i], (size_t)E);
+  }
+  if (m.hier) {
+    ALLOC_OR_FAIL(m.emb_bias, (size_t)E);
+    ALLOC_OR_FAIL(m.projT, (size_t)E * E);
+    ALLOC_OR_FAIL(m.projS, (size_t)m.HT * E);
+    for (int l = 0; l < m.nl; l++) {
+      const int in = (l == 0) ? E : m.H;
+      ALLOC_OR_FAIL(m.gru_wg[l], (size_t)(in + m.H) * 2 * m.H);
+      ALLOC_OR_FAIL(m.gru_bg[l], (size_t)2 * m.H);
+      ALLOC_OR_FAIL(m.gru_wc[l], (size_t)(in + m.H) * m.H);
+      ALLOC_OR_FAIL(m.gru_bc[l], (size_t)m.H);
+    }
+  }
+  ALLOC_OR_FAIL(c->metric_scratch, (size_t)8 * HIERTCN_METRIC_BLOCKS_MAX);
+#undef ALLOC_OR_FAIL
+  *out = c;
+  return HIERTCN_OK;
+}
+
+int hiertcn_destroy(hiertcn_handle_t h) {
+  if (!h) return HIERTCN_OK;
+  for (void* p : h->allocs) (void)hipFree(p);
+  for (hipEvent_t e : h->ev_begin) (void)hipEventDestroy(e);
+  for (hipEvent_t e : h->ev_end) (void)hipEventDestroy(e);
+  delete h;
+  return HIERTCN_OK;
+}
+
+int hiertcn_get_config(hiertcn_handle_t h, hiertcn_config_t* out) {
+  if (!h || !out) return fail(HIERTCN_ERR_INVALID, "null argument");
+  *out = h->cfg;
+  return HIERTCN_OK;
+}
+
+int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* stream) {
+  if (!h || !w) return fail(HIERTCN_ERR_INVALID, "null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  ModelDev& m = h->m;
+  const int E = m.E;
+  if (!w->emb_kernel || !w->out_kernel || !w->out_bias) return fail(HIERTCN_ERR_INVALID, "emb_kernel/out_kernel/out_bias are required");
+  // item table: [N][E] fp32 -> bf16, row 0 zeroed (model.py:59)
+  HIP_TRY(launch_rows_to_bf16(w->emb_kernel, m.emb, m.N, E, 1, st));
+  // scoring kernel: [C][N] -> [NP][C] bf16 (item-major rows = MFMA A operand); bias padded with -inf so
+  // that padding items never outrank anything and add exp(-inf) = 0 to the softmax denominator
+  HIP_TRY(launch_transpose_to_bf16(w->out_kernel, m.outT, m.Clast, m.N, m.NP, st));
+  HIP_TRY(launch_copy_pad_f32(w->out_bias, m.out_bias, m.N, m.NP, -INFINITY, st));
+  for (int i = 0; i < m.n_blocks; i++) {
+    if (!w->conv_kernel[i] || !w->conv_bias[i]) return fail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
+    if (w->res_kernel[i]) return fail(HIERTCN_ERR_INVALID, "down-sample residual (block %d) is not supported by the fused kernel", i);
+    for (int j = 0; j < m.K; j++)  // tap j: [Cin][Cout] -> [Cout][Cin]
+      HIP_TRY(launch_transpose_to_bf16(w->conv_kernel[i] + (size_t)j * E * E, m.convT[i] + (size_t)j * E * E, E, E, E, st));
+    HIP_TRY(launch_copy_pad_f32(w->conv_bias[i], m.conv_bias[i], E, E, 0.f, st));
+  }
+  if (m.hier) {
+    if (!w->emb_bias || !w->proj_kernel) return fail(HIERTCN_ERR_INVALID, "emb_bias/proj_kernel are required for hier models");
+    HIP_TRY(launch_copy_pad_f32(w->emb_bias, m.emb_bias, E, E, 0.f, st));
+    HIP_TRY(launch_transpose_to_bf16(w->proj_kernel, m.projT, E, E, E, st));  // rows [0,E): item half, bf16, cout-major
+    HIP_TRY(launch_copy_pad_f32(w->proj_kernel + (size_t)E * E, m.projS, (int64_t)m.HT * E, (int64_t)m.HT * E, 0.f, st));  // state half, fp32
+    for (int l = 0; l < m.nl; l++) {
+      if (!w->gru_gate_kernel[l] || !w->gru_gate_bias[l] || !w->gru_cand_kernel[l] || !w->gru_cand_bias[l])
+        return fail(HIERTCN_ERR_INVALID, "GRU layer %d weights missing", l);
+      const int in = (l == 0) ? E : m.H;
+      const int64_t ng = (int64_t)(in + m.H) * 2 * m.H, nc = (int64_t)(in + m.H) * m.H;
+      HIP_TRY(launch_copy_pad_f32(w->gru_gate_kernel[l], m.gru_wg[l], ng, ng, 0.f, st));
+      HIP_TRY(launch_copy_pad_f32(w->gru_gate_bias[l], m.gru_bg[l], 2 * m.H, 2 * m.H, 0.f, st));
+      HIP_TRY(launch_copy_pad_f32(w->gru_cand_kernel[l], m.gru_wc[l], nc, nc, 0.f, st));
+      HIP_TRY(launch_copy_pad_f32(w->gru_cand_bias[l], m.gru_bc[l], m.H, m.H, 0.f, st));
+    }
+  }
+  h->weights_set = true;
+  return HIERTCN_OK;
+}
+
+#define CHECK_READY(h)                                                        \
+  do {                                                                        \
+    if (!(h)) return fail(HIERTCN_ERR_INVALID, "null handle");                \
+    if (!(h)->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_set_weights has not been called"); \
+  } while (0)
+
+int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_sessions, int32_t L, float* pooled, void* stream) {
+  CHECK_READY(h);
+  if (!h->m.hier) return fail(HIERTCN_ERR_STATE, "session_pool is a model_hier operation");
+  if (!y_ids || !pooled || n_sessions < 0 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask, const float* state_in, int32_t B, int32_t S,
+                     float* sproj, float* state_out, float* state_before, void* stream) {
+  CHECK_READY(h);
+  if (!h->m.hier) return fail(HIERTCN_ERR_STATE, "gru_scan is a model_hier operation");
+  if (!pooled || !mask || !state_in || !sproj || !state_out || B < 0 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, state_before, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* sproj, int64_t n_sessions, int32_t L,
+                        uint16_t* hidden, void* stream) {
+  CHECK_READY(h);
+  if (!x_ids || !hidden || n_sessions < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (L < 1 || L > 32) return fail(HIERTCN_ERR_INVALID, "L=%d: the fused low-level kernel handles 1..32 steps per session", L);
+  if (h->m.hier && !sproj) return fail(HIERTCN_ERR_INVALID, "sproj is required for hier models (run hiertcn_gru_scan first)");
+  HIP_TRY(launch_tcn_forward(h->m, x_ids, h->m.hier ? sproj : nullptr, n_sessions, L, hidden, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                       hipStream_t st) {
+  size_t slot = 0;
+  const bool timing = h->timing;
+  if (timing) {
+    if (h->ev_used == h->ev_begin.size()) {
+      hipEvent_t a, b;
+      HIP_TRY(hipEventCreate(&a));
+      HIP_TRY(hipEventCreate(&b));
+      h->ev_begin.push_back(a);
+      h->ev_end.push_back(b);
+    }
+    slot = h->ev_used++;
+    HIP_TRY(hipEventRecord(h->ev_begin[slot], st));
+  }
+  HIP_TRY(launch_score(h->m, hidden, y, R, out, nullptr, st));
+  if (timing) HIP_TRY(hipEventRecord(h->ev_end[slot], st));
+  return HIERTCN_OK;
+}
+
+int hiertcn_score_fused(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y_ids, int64_t R, const hiertcn_score_out_t* out,
+                        void* stream) {
+  CHECK_READY(h);
+  if (!hidden || !y_ids || !out || R < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (out->topk != 0) return fail(HIERTCN_ERR_INVALID, "topk is not implemented in this build");
+  return score_timed(h, hidden, y_ids, R, out, reinterpret_cast<hipStream_t>(stream));
+}
+
+int hiertcn_score_logits(hiertcn_handle_t h, const uint16_t* hidden, int64_t R, float* logits, void* stream) {
+  CHECK_READY(h);
+  if (!hidden || !logits || R < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  HIP_TRY(launch_score(h->m, hidden, nullptr, R, nullptr, logits, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, const int32_t* y_ids, int32_t B, int32_t T, double* out8,
+                    void* stream) {
+  if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
+  if (!rank || !ce || !y_ids || !out8 || B < 1 || T < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  HIP_TRY(launch_metrics_scratch(h->m, rank, ce, y_ids, B, T, out8, h->metric_scratch, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+// workspace layout of hiertcn_forward_eval (all sub-buffers 256-byte aligned)
+struct EvalWs {
+  size_t pooled, sproj, hidden, rank, ce, total;
+};
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
+  EvalWs w;
+  size_t off = 0;
+  w.pooled = off; off += al256((size_t)B * S * m.E * sizeof(float));
+  w.sproj = off;  off += al256((size_t)B * S * m.E * sizeof(float));
+  w.hidden = off; off += al256((size_t)B * S * L * m.Clast * sizeof(uint16_t));
+  w.rank = off;   off += al256((size_t)B * S * L * sizeof(int32_t));
+  w.ce = off;     off += al256((size_t)B * S * L * sizeof(float));
+  w.total = off;
+  return w;
+}
+
+size_t hiertcn_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t L) {
+  if (!h || B < 0 || S < 0 || L < 0) return 0;
+  return eval_ws(h->m, B, S, L).total;
+}
+
+int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
+                         int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out,
+                         double* metrics8, const hiertcn_score_out_t* score_out, void* stream) {
+  CHECK_READY(h);
+  if (!h->m.hier) return fail(HIERTCN_ERR_STATE, "forward_eval is the model_hier evaluation step");
+  if (!x_ids || !y_ids || !mask || !state_in || !workspace || !state_out || B < 1 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (L < 1 || L > 32) return fail(HIERTCN_ERR_INVALID, "L=%d: the fused low-level kernel handles 1..32 steps per session", L);
+  const EvalWs w = eval_ws(h->m, B, S, L);
+  if (workspace_bytes < w.total) return fail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.total);
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+  float* pooled = reinterpret_cast<float*>(ws + w.pooled);
+  float* sproj = reinterpret_cast<float*>(ws + w.sproj);
+  uint16_t* hidden = reinterpret_cast<uint16_t*>(ws + w.hidden);
+  hiertcn_score_out_t so;
+  memset(&so, 0, sizeof(so));
+  if (score_out) so = *score_out;
+  if (so.topk != 0) return fail(HIERTCN_ERR_INVALID, "topk is not implemented in this build");
+  if (!so.rank) so.rank = reinterpret_cast<int32_t*>(ws + w.rank);
+  if (!so.ce) so.ce = reinterpret_cast<float*>(ws + w.ce);
+  const int64_t n_sessions = (int64_t)B * S;
+  const int64_t R = n_sessions * L;
+  // scan first (it never reads the low level's output: model_hier.py:83-93), then every
+  // (user, session) low-level problem is independent.
+  HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
+  HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, st));
+  HIP_TRY(launch_tcn_forward(h->m, x_ids, sproj, n_sessions, L, hidden, st));
+  int rc = score_timed(h, hidden, y_ids, R, &so, st);
+  if (rc != HIERTCN_OK) return rc;
+  if (metrics8) {
+    if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+    HIP_TRY(launch_metrics_scratch(h->m, so.rank, so.ce, y_ids, B, S * L, metrics8, h->metric_scratch, st));
+  }
+  return HIERTCN_OK;
+}
+
+int hiertcn_timing_enable(hiertcn_handle_t h, int32_t on) {
+  if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
+  h->timing = on != 0;
+  return HIERTCN_OK;
+}
+
+int hiertcn_timing_read(hiertcn_handle_t h, double* score_ms_avg, int64_t* launches, int32_t reset) {
+  if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
+  double total = 0.0;
+  for (size_t i = 0; i < h->ev_used; i++) {
+    HIP_TRY(hipEventSynchronize(h->ev_end[i]));
+    float ms = 0.f;
+    HIP_TRY(hipEventElapsedTime(&ms, h->ev_begin[i], h->ev_end[i]));
+    total += ms;
+  }
+  if (score_ms_avg) *score_ms_avg = h->ev_used ? total / (double)h->ev_used : 0.0;
+  if (launches) *launches = (int64_t)h->ev_used;
+  if (reset) h->ev_used = 0;
+  return HIERTCN_OK;
+}
+
+}  // extern "C"

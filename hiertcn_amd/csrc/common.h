@@ -1,0 +1,75 @@
+// Shared device/host helpers for the gfx950 HierTCN kernels.  CDNA4 only: wave64, MFMA
+// 32x32x16 bf16, 160 KiB LDS.  No portability layer on purpose.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/hiertcn.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+#define LOG2E_F 1.4426950408889634f
+#define LN2_F 0.6931471805599453f
+
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+__device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
+  return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
+}
+
+// MFMA 32x32x16 bf16 (cdna_hip_programming.md 3): lane l (r=l&31, h=l>>5) holds
+//   A[row r][k=8h+j], B[k=8h+j][col r], j=0..7;  D[row=(reg&3)+8*(reg>>2)+4h][col=r].
+__device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+// accumulator register -> row inside the 32x32 tile (for lane half h)
+__device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }
+
+// Internal (converted) weights + shape, shared by all kernels.
+struct ModelDev {
+  int N, NP;       // items, items padded to a multiple of 64
+  int E;           // embedding width == projection width C0
+  int H, nl, HT;   // GRU hidden, layers, H*nl
+  int K;           // conv taps
+  int n_blocks;
+  int C[HIERTCN_MAX_BLOCKS];
+  int Clast;
+  int hier;
+  // bf16 tensors (uint16 bit patterns)
+  uint16_t* emb;        // [N][E], row 0 zeroed
+  uint16_t* projT;      // [E(out)][E(in)]   = transpose(Wp[:E])          (hier only)
+  uint16_t* convT[HIERTCN_MAX_BLOCKS];  // [K][Cout][Cin]
+  uint16_t* resT[HIERTCN_MAX_BLOCKS];   // [Cout][Cin] or null
+  uint16_t* outT;       // [NP][Clast], rows >= N zero
+  // fp32 tensors
+  float* emb_bias;      // [E]
+  float* projS;         // [HT][E]  = Wp[E:]                               (hier only)
+  float* conv_bias[HIERTCN_MAX_BLOCKS];
+  float* res_bias[HIERTCN_MAX_BLOCKS];
+  float* out_bias;      // [NP], entries >= N are -inf
+  float* gru_wg[HIERTCN_MAX_LAYERS];
+  float* gru_bg[HIERTCN_MAX_LAYERS];
+  float* gru_wc[HIERTCN_MAX_LAYERS];
+  float* gru_bc[HIERTCN_MAX_LAYERS];
+};
+
+// launchers implemented in the kernel files (all asynchronous on `st`)
+hipError_t launch_rows_to_bf16(const float* src, uint16_t* dst, int64_t rows, int cols, int zero_row0, hipStream_t st);
+hipError_t launch_transpose_to_bf16(const float* src, uint16_t* dst, int64_t rows, int64_t cols, int64_t dst_rows_padded, hipStream_t st);
+hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t npad, float padval, hipStream_t st);
+hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
+hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
+                           float* sproj, float* state_out, float* state_before, hipStream_t st);
+hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
+                              uint16_t* hidden, hipStream_t st);
+hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                        float* logits, hipStream_t st);
+hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,
+                                  double* out8, double* scratch, hipStream_t st);
+#define HIERTCN_METRIC_BLOCKS_MAX 16384  // 256 lanes per block -> up to 4.19 M lanes per call

@@ -1,0 +1,75 @@
+// Lane (user) aggregation of the per-step scoring outputs: model.py:111-117 (loss) and
+// loss.py:189-219 (recall@1/5/10, reciprocal rank, rank fraction): per-lane mean over the lane's
+// valid steps (denominator activity_count + 1e-6, model.py:114), summed over lanes.  The division
+// by user_count (model.py:117, loss.py:215-219) is left to the caller so that partial sums from
+// several GPUs can be all-reduced first.
+//
+// Deterministic: every lane's sum is accumulated in step order by one thread; lanes are combined
+// by a fixed-shape tree.  HBM-bound: 12 bytes per step.
+#include "common.h"
+
+#define MT_THREADS 256
+
+__global__ __launch_bounds__(MT_THREADS) void k_lane_metrics(const int32_t* __restrict__ rank, const float* __restrict__ ce,
+                                                             const int32_t* __restrict__ y, int B, int T, int N,
+                                                             double* __restrict__ partial /*[gridDim.x][8]*/) {
+  __shared__ double red[MT_THREADS / 64][8];
+  const int b = blockIdx.x * MT_THREADS + threadIdx.x;
+  double v[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) v[k] = 0.0;
+  if (b < B) {
+    float loss = 0.f, r1 = 0.f, r5 = 0.f, r10 = 0.f, rr = 0.f, rf = 0.f;
+    int act = 0;
+    const int64_t base = (int64_t)b * T;
+    for (int t = 0; t < T; t++) {
+      if (y[base + t] > 0) {
+        const float rk = (float)rank[base + t];
+        act++;
+        loss += ce[base + t];
+        r1 += (rk <= 0.f) ? 1.f : 0.f;
+        r5 += (rk <= 4.f) ? 1.f : 0.f;
+        r10 += (rk <= 9.f) ? 1.f : 0.f;
+        rr += 1.0f / (1.0f + rk);
+        rf += rk / (float)N;
+      }
+    }
+    if (act > 0) {
+      const float den = (float)act + 1e-6f;  // model.py:114 (fp32 in the reference graph)
+      v[0] = loss / den; v[1] = r1 / den; v[2] = r5 / den; v[3] = r10 / den; v[4] = rr / den; v[5] = rf / den;
+      v[6] = 1.0;
+      v[7] = (double)act;
+    }
+  }
+  // wave tree, then fixed-order combine of the 4 waves
+#pragma unroll
+  for (int k = 0; k < 8; k++) {
+    double x = v[k];
+    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double s = 0.0;
+    for (int w = 0; w < MT_THREADS / 64; w++) s += red[w][threadIdx.x];
+    partial[(int64_t)blockIdx.x * 8 + threadIdx.x] = s;
+  }
+}
+
+__global__ void k_metrics_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out8) {
+  if (threadIdx.x < 8) {
+    double s = 0.0;
+    for (int i = 0; i < nblocks; i++) s += partial[(int64_t)i * 8 + threadIdx.x];
+    out8[threadIdx.x] = s;
+  }
+}
+
+// `partial` scratch lives behind out8: the caller passes a buffer of 8 * (1 + ceil(B/256)) doubles
+// through the handle's metric scratch (see api.hip).
+hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,
+                                  double* out8, double* scratch, hipStream_t st) {
+  const int nblocks = (B + MT_THREADS - 1) / MT_THREADS;
+  hipLaunchKernelGGL(k_lane_metrics, dim3(nblocks), dim3(MT_THREADS), 0, st, rank, ce, y, B, T, m.N, scratch);
+  hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(64), 0, st, scratch, nblocks, out8);
+  return hipGetLastError();
+}

@@ -1,0 +1,192 @@
+// Low level of HierTCN, fused: item-embedding gather (model.py:59-61 + model_hier.py:50), input
+// projection (model_hier.py:54-55 -> model_tcn.py:35) and the dilated causal conv stack
+// (customized_tcn_cell.py:46-49,109-127,147-161; conv arithmetic
+// customized_convolution_layer.py:171-198) for G sessions per workgroup, entirely in LDS.
+//
+// LDS image: per session a slab of (PAD + 32) rows x C bf16 channels; the first PAD rows are the
+// zero left-padding of the causal conv (customized_tcn_cell.py:47-48) and are never written, the
+// next 32 rows are the time steps (L <= 32).  Each layer is computed in place: MFMA accumulators
+// hold the layer's output while every wave still reads the layer's input, then one barrier, then
+// the bf16 write-back.  16-byte chunks of a row are XOR-swizzled by the row index so that the
+// ds_read_b128 of 32 consecutive rows is bank-conflict free (cdna_hip_programming.md T2).
+//
+// MFMA orientation: A = weights [cout][cin] (internal layout, transposed at set_weights),
+// B = activations^T, D[row = cout][col = time step].  A lane then owns ONE time step and four
+// runs of 4 consecutive output channels -> 8-byte packed bf16 stores and residual loads.
+#include "common.h"
+
+#define TCN_G 4          // sessions per workgroup
+#define TCN_THREADS 512  // 8 waves
+
+template <int C>
+struct TcnGeom {
+  static constexpr int NCB = C / 32;        // output-channel blocks
+  static constexpr int WPC = 8 / NCB;       // waves sharing one channel block
+  static constexpr int RPW = TCN_G / WPC;   // sessions (row blocks) per wave
+  static constexpr int KS = C / 16;         // MFMA k-steps
+  static constexpr int CH = C / 8;          // 16-byte chunks per row
+  static constexpr int SWZ = (CH < 16 ? CH : 16) - 1;
+  static_assert(NCB >= 1 && NCB <= 8 && (8 % NCB) == 0 && (TCN_G % WPC) == 0, "unsupported channel count");
+};
+
+struct TcnParams {
+  const uint16_t* emb;                         // [N][C] bf16, row 0 zero
+  const uint16_t* projT;                       // [C][C] bf16 (cout-major) or null (single level: no projection)
+  const uint16_t* convT[HIERTCN_MAX_BLOCKS];   // [K][C][C]
+  const float* conv_bias[HIERTCN_MAX_BLOCKS];  // [C]
+  int n_blocks, K, pad;
+};
+
+template <int C>
+__device__ __forceinline__ int lds_off(int row, int chunk) {
+  // byte offset of 16-byte chunk `chunk` of slab row `row`
+  return row * (2 * C) + ((chunk ^ (row & TcnGeom<C>::SWZ)) << 4);
+}
+
+template <int C>
+__global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const int32_t* __restrict__ x,
+                                                           const float* __restrict__ sproj, int64_t n_sessions, int L,
+                                                           uint16_t* __restrict__ hidden) {
+  using G = TcnGeom<C>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int ROWS = p.pad + 32;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t sess0 = (int64_t)blockIdx.x * TCN_G;
+
+  // ---- phase 0: zero halo rows, gather embedding rows (16 B per lane) -------------------------
+  for (int i = tid; i < TCN_G * ROWS * G::CH; i += TCN_THREADS) {
+    const int row = i / G::CH, ch = i % G::CH;
+    const int g = row / ROWS, r = row % ROWS;
+    uint4 v = make_uint4(0, 0, 0, 0);
+    const int t = r - p.pad;
+    const int64_t sess = sess0 + g;
+    if (t >= 0 && t < L && sess < n_sessions) {
+      const int id = x[sess * L + t];
+      v = *reinterpret_cast<const uint4*>(p.emb + (int64_t)id * C + ch * 8);  // row 0 is stored as zeros
+    }
+    *reinterpret_cast<uint4*>(smem + lds_off<C>(row, ch)) = v;
+  }
+  __syncthreads();
+
+  const int cb = wave / G::WPC;                 // output-channel block of this wave
+  const int g0 = (wave % G::WPC) * G::RPW;      // first session (row block) of this wave
+  const int arow = cb * 32 + lr;                // weight row (output channel) this lane feeds as A
+
+  // One layer = (taps x k-steps) MFMAs per row block; layer < 0 is the input projection.
+  const int n_layers = p.n_blocks + (p.projT ? 1 : 0);
+  for (int li = 0; li < n_layers; li++) {
+    const bool is_proj = (p.projT != nullptr) && (li == 0);
+    const int blk = li - (p.projT ? 1 : 0);
+    const int dil = is_proj ? 0 : (1 << blk);
+    const int taps = is_proj ? 1 : p.K;
+    const uint16_t* W = is_proj ? p.projT : p.convT[blk];
+
+    f32x16 acc[G::RPW];
+#pragma unroll
+    for (int r = 0; r < G::RPW; r++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        f32x4 init = {0.f, 0.f, 0.f, 0.f};
+        const int c0 = cb * 32 + 8 * q + 4 * lh;  // 4 consecutive output channels of this register quad
+        if (is_proj) {
+          const int64_t sess = sess0 + g0 + r;
+          if (sproj != nullptr && sess < n_sessions) init = *reinterpret_cast<const f32x4*>(sproj + sess * C + c0);
+        } else {
+          init = *reinterpret_cast<const f32x4*>(p.conv_bias[blk] + c0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) acc[r][4 * q + j] = init[j];
+      }
+    }
+
+    for (int j = 0; j < taps; j++) {
+      const int shift = is_proj ? 0 : (p.K - 1 - j) * dil;  // o[t] += x[t - (K-1-j)*dil] . W[j]
+      const uint16_t* Wj = W + (int64_t)j * C * C + (int64_t)arow * C + 8 * lh;
+#pragma unroll 4
+      for (int s = 0; s < G::KS; s++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(Wj + 16 * s);
+#pragma unroll
+        for (int r = 0; r < G::RPW; r++) {
+          const int row = (g0 + r) * ROWS + p.pad + lr - shift;
+          const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));
+          acc[r] = mfma32(a, b, acc[r]);
+        }
+      }
+    }
+
+    // epilogue in registers: projection -> identity; block -> relu(relu(conv+b) + x)
+    uint2 outv[G::RPW][4];
+#pragma unroll
+    for (int r = 0; r < G::RPW; r++) {
+      const int row = (g0 + r) * ROWS + p.pad + lr;
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        float v[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = acc[r][4 * q + j];
+        if (!is_proj) {
+          const uint2 res = *reinterpret_cast<const uint2*>(smem + lds_off<C>(row, cb * 4 + q) + 8 * lh);
+          const float r0 = bf2f((uint16_t)(res.x & 0xffff)), r1 = bf2f((uint16_t)(res.x >> 16));
+          const float r2 = bf2f((uint16_t)(res.y & 0xffff)), r3 = bf2f((uint16_t)(res.y >> 16));
+          v[0] = fmaxf(fmaxf(v[0], 0.f) + r0, 0.f);
+          v[1] = fmaxf(fmaxf(v[1], 0.f) + r1, 0.f);
+          v[2] = fmaxf(fmaxf(v[2], 0.f) + r2, 0.f);
+          v[3] = fmaxf(fmaxf(v[3], 0.f) + r3, 0.f);
+        }
+        outv[r][q].x = pack2bf(v[0], v[1]);
+        outv[r][q].y = pack2bf(v[2], v[3]);
+      }
+    }
+    __syncthreads();  // every wave has finished reading this layer's input
+#pragma unroll
+    for (int r = 0; r < G::RPW; r++) {
+      const int row = (g0 + r) * ROWS + p.pad + lr;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        *reinterpret_cast<uint2*>(smem + lds_off<C>(row, cb * 4 + q) + 8 * lh) = outv[r][q];
+    }
+    __syncthreads();
+  }
+
+  // ---- write the valid rows out, 16 B per lane, rows compacted to [session][t < L] -----------
+  for (int i = tid; i < TCN_G * 32 * G::CH; i += TCN_THREADS) {
+    const int ch = i % G::CH, rt = i / G::CH;
+    const int g = rt >> 5, t = rt & 31;
+    const int64_t sess = sess0 + g;
+    if (t < L && sess < n_sessions) {
+      const uint4 v = *reinterpret_cast<const uint4*>(smem + lds_off<C>(g * ROWS + p.pad + t, ch));
+      *reinterpret_cast<uint4*>(hidden + (sess * L + t) * C + ch * 8) = v;
+    }
+  }
+}
+
+template <int C>
+static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
+                               uint16_t* hidden, hipStream_t st) {
+  size_t lds = (size_t)TCN_G * (p.pad + 32) * 2 * C;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  unsigned blocks = (unsigned)((n_sessions + TCN_G - 1) / TCN_G);
+  hipLaunchKernelGGL(k_tcn_fused<C>, dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
+  return hipGetLastError();
+}
+
+hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
+                              uint16_t* hidden, hipStream_t st) {
+  if (n_sessions <= 0) return hipSuccess;
+  TcnParams p;
+  p.emb = m.emb;
+  p.projT = m.hier ? m.projT : nullptr;
+  for (int i = 0; i < HIERTCN_MAX_BLOCKS; i++) { p.convT[i] = m.convT[i]; p.conv_bias[i] = m.conv_bias[i]; }
+  p.n_blocks = m.n_blocks; p.K = m.K;
+  int halo = (m.K - 1) * (1 << (m.n_blocks - 1));
+  p.pad = (halo + 7) & ~7;
+  switch (m.E) {
+    case 64: return launch_tcn_c<64>(p, x, sproj, n_sessions, L, hidden, st);
+    case 128: return launch_tcn_c<128>(p, x, sproj, n_sessions, L, hidden, st);
+    case 256: return launch_tcn_c<256>(p, x, sproj, n_sessions, L, hidden, st);
+    default: return hipErrorInvalidValue;
+  }
+}

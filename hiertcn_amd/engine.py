@@ -1,0 +1,268 @@
+"""Device-side engine: a thin, typed wrapper over the C-ABI (include/hiertcn.h).
+
+PyTorch is used here for device memory, streams and (elsewhere) torch.distributed only; every
+computation on the hot path is a hand-written HIP kernel reached through ctypes.  Tensors are
+passed as raw device pointers; the engine checks dtype / device / contiguity / shape so that a
+bad call fails in Python rather than as a GPU fault.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HierTCNError, check
+
+METRIC_KEYS = ("loss", "recall1", "recall5", "recall10", "mrr", "rank_frac", "user_count", "valid_steps")
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _req(t: torch.Tensor, dtype, name: str, shape=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a torch.Tensor")
+    if not t.is_cuda:
+        raise HierTCNError(f"{name}: must live on the GPU (got {t.device})")
+    if t.dtype != dtype:
+        raise HierTCNError(f"{name}: dtype {t.dtype}, expected {dtype}")
+    if not t.is_contiguous():
+        raise HierTCNError(f"{name}: must be contiguous")
+    if shape is not None and tuple(t.shape) != tuple(shape):
+        raise HierTCNError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+    return t
+
+
+def config_from_args(args, hier: bool = True) -> _lib.Config:
+    """args.py attribute names -> hiertcn_config_t."""
+    cfg = _lib.Config()
+    cfg.item_num = int(args.item_num)
+    cfg.emb_dim = int(getattr(args, "emb_dim", 128))
+    cfg.hidden_dim = int(args.hidden_dim)
+    cfg.num_layer = int(args.num_layer)
+    cfg.kernel_size = int(args.kernel_size)
+    ch = [int(c) for c in args.tcn_channel]
+    if len(ch) > _lib.MAX_BLOCKS:
+        raise HierTCNError("too many TCN blocks")
+    cfg.n_blocks = len(ch)
+    for i, c in enumerate(ch):
+        cfg.channels[i] = c
+    cfg.hier = 1 if hier else 0
+    return cfg
+
+
+class Engine:
+    """One handle on the current CUDA(HIP) device."""
+
+    def __init__(self, args, hier: bool = True, device: Optional[torch.device] = None):
+        self.lib = _lib.load()
+        if not torch.cuda.is_available():
+            raise HierTCNError("no GPU visible: the HierTCN compute path is HIP-only (no CPU fallback)")
+        self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
+        self.hier = hier
+        self.cfg = config_from_args(args, hier)
+        self.N = int(self.cfg.item_num)
+        self.E = int(self.cfg.emb_dim)
+        self.H = int(self.cfg.hidden_dim) if hier else 0
+        self.nl = int(self.cfg.num_layer) if hier else 0
+        self.HT = self.H * self.nl
+        self.C = int(self.cfg.channels[self.cfg.n_blocks - 1])
+        self._h = C.c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
+        self._ws: Optional[torch.Tensor] = None
+        self._weights_set = False
+
+    # ---------------------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None) is not None and self._h.value:
+            self.lib.hiertcn_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _stream():
+        return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    # ---------------------------------------------------------------------------------------
+    def set_weights(self, params: Dict[str, "np.ndarray | torch.Tensor"], root: Optional[str] = None):
+        """params: TF-named tensors in the reference layout; numpy or torch, any
+        float dtype; uploaded as fp32 and converted on the device by hiertcn_set_weights."""
+        root = root or ("hier" if self.hier else "tcn")
+        tcn = f"{root}/tcn" if self.hier else root
+        keep = []
+
+        def dev(name, shape=None, optional=False):
+            if name not in params:
+                if optional:
+                    return None
+                raise HierTCNError(f"missing parameter {name}")
+            v = params[name]
+            t = torch.as_tensor(np.asarray(v, dtype=np.float32) if not isinstance(v, torch.Tensor) else v)
+            t = t.to(device=self.device, dtype=torch.float32).contiguous()
+            if shape is not None and tuple(t.shape) != tuple(shape):
+                raise HierTCNError(f"{name}: shape {tuple(t.shape)}, expected {tuple(shape)}")
+            keep.append(t)
+            return t.data_ptr()
+
+        E, N, H, K = self.E, self.N, self.H, int(self.cfg.kernel_size)
+        w = _lib.Weights()
+        w.emb_kernel = dev(f"{root}/emb/kernel", (N, E))
+        if self.hier:
+            w.emb_bias = dev(f"{root}/emb/bias", (E,))
+            w.proj_kernel = dev(f"{tcn}/emb/kernel", (E + self.HT, E))
+        cin = E
+        for i in range(self.cfg.n_blocks):
+            cout = int(self.cfg.channels[i])
+            pre = f"{tcn}/temporal_conv_net/tblock_{i}"
+            w.conv_kernel[i] = dev(f"{pre}/conv1/kernel", (K, cin, cout))
+            w.conv_bias[i] = dev(f"{pre}/conv1/bias", (cout,))
+            rk = dev(f"{pre}/dense/kernel", (cin, cout), optional=True)
+            if rk is not None:
+                w.res_kernel[i] = rk
+                w.res_bias[i] = dev(f"{pre}/dense/bias", (cout,))
+            cin = cout
+        w.out_kernel = dev(f"{tcn}/dense/kernel", (cin, N))
+        w.out_bias = dev(f"{tcn}/dense/bias", (N,))
+        if self.hier:
+            inp = E
+            for l in range(self.nl):
+                pre = f"{root}/multi_rnn_cell/cell_{l}/gru_cell"
+                w.gru_gate_kernel[l] = dev(f"{pre}/gates/kernel", (inp + H, 2 * H))
+                w.gru_gate_bias[l] = dev(f"{pre}/gates/bias", (2 * H,))
+                w.gru_cand_kernel[l] = dev(f"{pre}/candidate/kernel", (inp + H, H))
+                w.gru_cand_bias[l] = dev(f"{pre}/candidate/bias", (H,))
+                inp = H
+        with torch.cuda.device(self.device):
+            check(self.lib.hiertcn_set_weights(self._h, C.byref(w), self._stream()))
+            torch.cuda.current_stream().synchronize()  # the fp32 staging copies die with `keep`
+        self._weights_set = True
+
+    # ---------------------------------------------------------------------------------------
+    def session_pool(self, y_ids: torch.Tensor) -> torch.Tensor:
+        """y_ids [n_sessions, L] int32 -> [n_sessions, E] fp32   (model_hier.py:83-85)."""
+        _req(y_ids, torch.int32, "y_ids")
+        n, L = y_ids.shape
+        out = torch.empty((n, self.E), dtype=torch.float32, device=self.device)
+        check(self.lib.hiertcn_session_pool(self._h, _ptr(y_ids), n, L, _ptr(out), self._stream()))
+        return out
+
+    def gru_scan(self, pooled: torch.Tensor, mask: torch.Tensor, state_in: torch.Tensor, want_state_before=False):
+        """pooled [B,S,E], mask [B,S], state_in [B,H*nl] -> (sproj [B,S,E], state_out, state_before|None)."""
+        B, S, _ = pooled.shape
+        _req(pooled, torch.float32, "pooled", (B, S, self.E))
+        _req(mask, torch.float32, "mask", (B, S))
+        _req(state_in, torch.float32, "state_in", (B, self.HT))
+        sproj = torch.empty((B, S, self.E), dtype=torch.float32, device=self.device)
+        state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
+        sb = torch.empty((B, S, self.HT), dtype=torch.float32, device=self.device) if want_state_before else None
+        check(self.lib.hiertcn_gru_scan(self._h, _ptr(pooled), _ptr(mask), _ptr(state_in), B, S, _ptr(sproj),
+                                        _ptr(state_out), _ptr(sb), self._stream()))
+        return sproj, state_out, sb
+
+    def tcn_forward(self, x_ids: torch.Tensor, sproj: Optional[torch.Tensor]) -> torch.Tensor:
+        """x_ids [n_sessions, L] int32, sproj [n_sessions, E] fp32 -> hidden [n_sessions*L, C] bf16."""
+        _req(x_ids, torch.int32, "x_ids")
+        n, L = x_ids.shape
+        if sproj is not None:
+            _req(sproj, torch.float32, "sproj", (n, self.E))
+        hidden = torch.empty((n * L, self.C), dtype=torch.bfloat16, device=self.device)
+        check(self.lib.hiertcn_tcn_forward(self._h, _ptr(x_ids), _ptr(sproj), n, L, _ptr(hidden), self._stream()))
+        return hidden
+
+    def score_fused(self, hidden: torch.Tensor, y_ids: torch.Tensor, want_target=False):
+        """hidden [R, C] bf16, y_ids [R] int32 -> dict(rank int32 [R], ce fp32 [R], target?)."""
+        R = hidden.shape[0]
+        _req(hidden, torch.bfloat16, "hidden", (R, self.C))
+        y = y_ids.reshape(-1)
+        _req(y, torch.int32, "y_ids", (R,))
+        rank = torch.empty(R, dtype=torch.int32, device=self.device)
+        ce = torch.empty(R, dtype=torch.float32, device=self.device)
+        tgt = torch.empty(R, dtype=torch.float32, device=self.device) if want_target else None
+        so = _lib.ScoreOut(rank=rank.data_ptr(), ce=ce.data_ptr(), target=tgt.data_ptr() if tgt is not None else None,
+                           topk_idx=None, topk_val=None, topk=0)
+        check(self.lib.hiertcn_score_fused(self._h, _ptr(hidden), _ptr(y), R, C.byref(so), self._stream()))
+        out = dict(rank=rank, ce=ce)
+        if tgt is not None:
+            out["target"] = tgt
+        return out
+
+    def score_logits(self, hidden: torch.Tensor) -> torch.Tensor:
+        """parity/debug: materialised logits [R, N] fp32 (model_tcn.py:41, before the model.py:105 mask)."""
+        R = hidden.shape[0]
+        _req(hidden, torch.bfloat16, "hidden", (R, self.C))
+        logits = torch.empty((R, self.N), dtype=torch.float32, device=self.device)
+        check(self.lib.hiertcn_score_logits(self._h, _ptr(hidden), R, _ptr(logits), self._stream()))
+        return logits
+
+    def metrics(self, rank: torch.Tensor, ce: torch.Tensor, y_ids: torch.Tensor, B: int, T: int) -> torch.Tensor:
+        """-> 8 doubles on the device: lane-mean SUMS + user_count + valid steps (hiertcn.h)."""
+        _req(rank, torch.int32, "rank")
+        _req(ce, torch.float32, "ce")
+        y = y_ids.reshape(-1)
+        _req(y, torch.int32, "y_ids", (B * T,))
+        out = torch.empty(8, dtype=torch.float64, device=self.device)
+        check(self.lib.hiertcn_metrics(self._h, _ptr(rank), _ptr(ce), _ptr(y), B, T, _ptr(out), self._stream()))
+        return out
+
+    # ---------------------------------------------------------------------------------------
+    def workspace(self, B: int, S: int, L: int) -> torch.Tensor:
+        need = int(self.lib.hiertcn_workspace_bytes(self._h, B, S, L))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._ws
+
+    def forward_eval(self, x_ids, y_ids, mask, state_in, want_rows=False, state_out=None, metrics8=None):
+        """One evaluation step on a packed batch: x_ids, y_ids [B,S,L] int32; mask [B,S] fp32;
+        state_in [B,H*nl] fp32.  Returns dict(state, metrics8 (device, 8 doubles)[, rank, ce])."""
+        B, S, L = x_ids.shape
+        _req(x_ids, torch.int32, "x_ids", (B, S, L))
+        _req(y_ids, torch.int32, "y_ids", (B, S, L))
+        _req(mask, torch.float32, "mask", (B, S))
+        _req(state_in, torch.float32, "state_in", (B, self.HT))
+        ws = self.workspace(B, S, L)
+        if state_out is None:
+            state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
+        if metrics8 is None:
+            metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
+        so = None
+        out = dict(state=state_out, metrics8=metrics8)
+        if want_rows:
+            rank = torch.empty(B * S * L, dtype=torch.int32, device=self.device)
+            ce = torch.empty(B * S * L, dtype=torch.float32, device=self.device)
+            so = _lib.ScoreOut(rank=rank.data_ptr(), ce=ce.data_ptr(), target=None, topk_idx=None, topk_val=None, topk=0)
+            out["rank"] = rank.view(B, S * L)
+            out["ce"] = ce.view(B, S * L)
+        check(self.lib.hiertcn_forward_eval(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
+                                            _ptr(ws), ws.numel(), _ptr(state_out), _ptr(metrics8),
+                                            C.byref(so) if so is not None else None, self._stream()))
+        return out
+
+    # ---------------------------------------------------------------------------------------
+    def timing_enable(self, on: bool = True):
+        check(self.lib.hiertcn_timing_enable(self._h, 1 if on else 0))
+
+    def timing_read(self, reset: bool = True):
+        ms = C.c_double(0.0)
+        n = C.c_int64(0)
+        check(self.lib.hiertcn_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        return ms.value, n.value
+
+
+def metrics_dict(m8) -> Dict[str, float]:
+    """8 doubles (host or device) -> the reference's batch metrics (model.py:117, loss.py:215-219)."""
+    v = m8.detach().cpu().numpy() if isinstance(m8, torch.Tensor) else np.asarray(m8)
+    users = v[6]
+    d = {k: float(v[i] / users) if users > 0 else float("nan") for i, k in enumerate(METRIC_KEYS[:6])}
+    d["user_count"] = float(users)
+    d["valid_steps"] = float(v[7])
+    return d

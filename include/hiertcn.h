@@ -1,0 +1,178 @@
+/*
+ * hiertcn.h -- C-ABI of the MI355X-native HierTCN forward + scoring path.
+ *
+ * This is the drop-in boundary: every entry point stands where one piece of
+ * the reference's TF-1.x graph stood.  Citations are file:line under the reference tree.
+ *
+ *   reference                                                   this library
+ *   ---------------------------------------------------------   ---------------------------
+ *   tf variables created by model_hier / model_tcn              hiertcn_set_weights
+ *   model_hier.py:83-85  (session mean-pool + 'emb' with bias)  hiertcn_session_pool
+ *   model_hier.py:36-37,91,93 + customed_gru_cell.py:309-337,   hiertcn_gru_scan
+ *       1050-1073 (MultiRNNCell of GRUCells, mask reset) and the
+ *       state half of model_hier.py:54-55 -> model_tcn.py:35
+ *   model.py:59-61 + model_hier.py:50 (one-hot "lookup"),        hiertcn_tcn_forward
+ *       model_tcn.py:35-36, customized_tcn_cell.py:46-49,109-127,
+ *       147-161, customized_convolution_layer.py:171-198
+ *   model_tcn.py:41 (scoring dense) + model.py:105 (mask) +      hiertcn_score_fused
+ *       loss.py:20-21 (cross entropy) + loss.py:179 (count-greater
+ *       rank) + loss.py:120 (top_k, optional)
+ *   model_tcn.py:41 alone (materialised logits, parity/debug)    hiertcn_score_logits
+ *   model.py:111-117 + loss.py:189-219 (lane means)              hiertcn_metrics
+ *   one sess.run of the eval fetch list run_hier_xing.py:145-149 hiertcn_forward_eval
+ *
+ * Conventions
+ *   - plain C, no exceptions, no torch types.  Every pointer is a DEVICE pointer owned by the
+ *     caller unless it says "host".  Nothing is allocated or synchronised on the hot path; all
+ *     work is enqueued on the caller's hipStream_t (passed as void*).
+ *   - returns 0 on success; otherwise a negative hiertcn_status and a thread-local message
+ *     retrievable with hiertcn_last_error().
+ *   - one handle per device; a handle is not thread-safe, different handles are independent.
+ *   - ids are int32, 0 = null/padding (model.py:59: one_hot(id)*sign(id) -> zero embedding, and
+ *     model.py:62: mask_y = sign(y_id)).  Batch layout is user-major:
+ *       x_ids, y_ids [B][S][L] ; mask [B][S] ; state [B][H*nl] ; rows r = (b*S+s)*L+t.
+ *   - "bf16" buffers are uint16_t holding IEEE bfloat16 bit patterns.
+ */
+#ifndef HIERTCN_H_
+#define HIERTCN_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HIERTCN_ABI_VERSION 1
+#define HIERTCN_MAX_BLOCKS 8
+#define HIERTCN_MAX_LAYERS 4
+#define HIERTCN_MAX_TOPK 16
+
+typedef struct hiertcn_ctx* hiertcn_handle_t;
+
+enum hiertcn_status {
+  HIERTCN_OK = 0,
+  HIERTCN_ERR_INVALID = -1,     /* bad argument / unsupported shape */
+  HIERTCN_ERR_HIP = -2,         /* a HIP runtime call failed */
+  HIERTCN_ERR_STATE = -3,       /* weights not set, handle destroyed, ... */
+  HIERTCN_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+/* Model shape = the reference's args that size the graph (args.py:47-58) plus emb_dim, which the
+ * reference hard-codes to 128 (model_hier.py:50,85; model_tcn.py:35). */
+typedef struct {
+  int32_t item_num;                      /* N, args.item_num (row 0 = null id)            */
+  int32_t emb_dim;                       /* E = C0: 'emb' units                            */
+  int32_t hidden_dim;                    /* H, args.hidden_dim (ignored when hier == 0)    */
+  int32_t num_layer;                     /* nl, args.num_layer                             */
+  int32_t kernel_size;                   /* K, args.kernel_size                            */
+  int32_t n_blocks;                      /* len(args.tcn_channel)                          */
+  int32_t channels[HIERTCN_MAX_BLOCKS];  /* args.tcn_channel                               */
+  int32_t hier;                          /* 1: model_hier low level; 0: single-level model_tcn */
+} hiertcn_config_t;
+
+/* Device pointers to fp32 tensors in the REFERENCE's variable layout:
+ *   emb_kernel      [N][E]              hier/emb/kernel (or tcn/emb/kernel when hier == 0)
+ *   emb_bias        [E]                 hier/emb/bias                (hier only)
+ *   proj_kernel     [E+H*nl][E]         hier/tcn/emb/kernel          (hier only)
+ *   conv_kernel[i]  [K][Cin][Cout]      .../tblock_i/conv1/kernel
+ *   conv_bias[i]    [Cout]              .../tblock_i/conv1/bias
+ *   res_kernel[i]   [Cin][Cout] or NULL .../tblock_i/dense/kernel    (only when Cin != Cout)
+ *   res_bias[i]     [Cout] or NULL
+ *   out_kernel      [C_last][N]         .../tcn/dense/kernel
+ *   out_bias        [N]                 .../tcn/dense/bias
+ *   gru_*_kernel[l] [in_l+H][2H] / [in_l+H][H], gru_*_bias[l] [2H] / [H]   (hier only)
+ * hiertcn_set_weights converts them (device-side) to the internal layouts and
+ * keeps its own copies; the caller's buffers may be freed once the stream has drained. */
+typedef struct {
+  const float* emb_kernel;
+  const float* emb_bias;
+  const float* proj_kernel;
+  const float* conv_kernel[HIERTCN_MAX_BLOCKS];
+  const float* conv_bias[HIERTCN_MAX_BLOCKS];
+  const float* res_kernel[HIERTCN_MAX_BLOCKS];
+  const float* res_bias[HIERTCN_MAX_BLOCKS];
+  const float* out_kernel;
+  const float* out_bias;
+  const float* gru_gate_kernel[HIERTCN_MAX_LAYERS];
+  const float* gru_gate_bias[HIERTCN_MAX_LAYERS];
+  const float* gru_cand_kernel[HIERTCN_MAX_LAYERS];
+  const float* gru_cand_bias[HIERTCN_MAX_LAYERS];
+} hiertcn_weights_t;
+
+/* Outputs of one evaluation step (all optional except where noted; NULL = not wanted). */
+typedef struct {
+  int32_t* rank;       /* [R]  loss.py:179 count of candidates strictly greater than the target; 0 on masked rows */
+  float* ce;           /* [R]  loss.py:21 cross entropy  (LSE - target logit); 0 on masked rows      */
+  float* target;       /* [R]  the target logit z[y]                                                  */
+  int32_t* topk_idx;   /* [R][topk]  loss.py:120 order: value descending, ties -> lower index        */
+  float* topk_val;     /* [R][topk]                                                                   */
+  int32_t topk;        /* 0..HIERTCN_MAX_TOPK                                                         */
+} hiertcn_score_out_t;
+
+int hiertcn_abi_version(void);
+const char* hiertcn_last_error(void);
+
+/* create on the CURRENT hip device; allocates the internal weight copies (sized from cfg). */
+int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg);
+int hiertcn_destroy(hiertcn_handle_t h);
+int hiertcn_get_config(hiertcn_handle_t h, hiertcn_config_t* out);
+
+int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* stream);
+
+/* model_hier.py:83-85.  y_ids [n_sessions][L] -> pooled [n_sessions][E] fp32. */
+int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_sessions, int32_t L,
+                         float* pooled, void* stream);
+
+/* model_hier.py:91-93 scanned over the S slots for every lane, plus the state half of the low
+ * level's input projection (model_hier.py:54-55 -> model_tcn.py:35: [e, state].Wp = e.Wp[:E] +
+ * state.Wp[E:]).  pooled [B][S][E], mask [B][S], state_in [B][H*nl] ->
+ *   sproj        [B][S][E]     state_before_slot_s . Wp[E:]        (consumed by hiertcn_tcn_forward)
+ *   state_out    [B][H*nl]     state after the last slot
+ *   state_before [B][S][H*nl]  optional (NULL): the state each slot's low level saw */
+int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask, const float* state_in,
+                     int32_t B, int32_t S, float* sproj, float* state_out, float* state_before,
+                     void* stream);
+
+/* model.py:59-61 + model_hier.py:50 + model_tcn.py:35-36: ids -> last TCN activations.
+ * x_ids [n_sessions][L]; sproj [n_sessions][E] or NULL (single-level) ->
+ * hidden [n_sessions*L][C_last] bf16. */
+int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* sproj, int64_t n_sessions,
+                        int32_t L, uint16_t* hidden, void* stream);
+
+/* model_tcn.py:41 + model.py:105 + loss.py:21,179(,120) fused: logits are never written. */
+int hiertcn_score_fused(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y_ids, int64_t R,
+                        const hiertcn_score_out_t* out, void* stream);
+
+/* parity/debug: materialise logits [R][N] fp32 (pre-mask, i.e. model_tcn.py:41's output). */
+int hiertcn_score_logits(hiertcn_handle_t h, const uint16_t* hidden, int64_t R, float* logits, void* stream);
+
+/* model.py:111-117 + loss.py:189-219.  rank, ce, y_ids are [B][T] (T = S*L); out8 (device, 8
+ * doubles) = SUMS over lanes of the per-lane means, ready for a cross-rank all-reduce:
+ *   [0] loss  [1] recall@1  [2] recall@5  [3] recall@10  [4] reciprocal rank  [5] rank/N
+ *   [6] user_count (lanes with >= 1 valid step)  [7] valid steps
+ * batch metric = out8[k] / out8[6]. */
+int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, const int32_t* y_ids,
+                    int32_t B, int32_t T, double* out8, void* stream);
+
+/* Bytes of scratch hiertcn_forward_eval needs for a [B][S][L] batch. */
+size_t hiertcn_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t L);
+
+/* One evaluation step = the fetch list of run_hier_xing.py:145-149 without `pred`:
+ * pool -> gru scan -> tcn -> fused scoring -> lane metrics, all enqueued on `stream`.
+ * score_out may be NULL (then rank/ce live in the workspace only). */
+int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask,
+                         const float* state_in, int32_t B, int32_t S, int32_t L, void* workspace,
+                         size_t workspace_bytes, float* state_out, double* metrics8,
+                         const hiertcn_score_out_t* score_out, void* stream);
+
+/* Measurement hook for bench.py: average duration in milliseconds of the scoring kernel over the
+ * launches made since the last reset, measured with HIP events recorded on the launch stream.
+ * Disabled (0 cost) unless enabled. */
+int hiertcn_timing_enable(hiertcn_handle_t h, int32_t on);
+int hiertcn_timing_read(hiertcn_handle_t h, double* score_ms_avg, int64_t* launches, int32_t reset);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HIERTCN_H_ */

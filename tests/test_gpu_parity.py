@@ -1,0 +1,166 @@
+"""Parity of the HIP path against the CPU oracle on the same seeded inputs (run with -m gpu).
+
+Tolerances (stated per north star): integer outputs (ranks) bit-exact against a count over the
+HIP path's own materialised logits; fp32 logits within 1e-3 of the oracle; fp32 state within 1e-5.
+"""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from oracle import hiertcn_oracle as O  # noqa: E402
+from tests.gpu_common import as_lists, make_batch, make_params, small_args  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.cuda().contiguous()
+
+
+@pytest.fixture(scope="module", params=[(64, 1000), (128, 2053), (256, 777)])
+def setup(request):
+    from hiertcn_amd.engine import Engine
+    d, N = request.param
+    args = small_args(N=N, d=d, H=32 if d == 64 else 64)
+    p = make_params(args)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    pr = O.round_params_bf16(p, E=d)  # what the device actually stores
+    rng = np.random.default_rng(d)
+    B, S, L = 9, 4, 11
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, args.hidden_dim * args.num_layer))).astype(np.float32)
+    yield dict(args=args, p=p, pr=pr, eng=eng, x=x, y=y, mask=mask, st0=st0, B=B, S=S, L=L, N=N, d=d)
+    eng.close()
+
+
+def oracle_scan(s):
+    """the scan of model_hier.py:83-93 alone, returning pooled, state_before per slot, final state"""
+    args, pr = s["args"], s["pr"]
+    H, nl = args.hidden_dim, args.num_layer
+    st = s["st0"].astype(np.float64)
+    pooled, before = [], []
+    for i in range(s["S"]):
+        before.append(st.copy())
+        pl = O.session_mean_pool(s["y"][:, i], pr)
+        pooled.append(pl)
+        _, st = O.multi_rnn_cell(pl, st, pr, H, nl)
+        st = st * s["mask"][:, i:i + 1]
+    return np.stack(pooled, 1), np.stack(before, 1), st
+
+
+def test_session_pool(setup):
+    s = setup
+    B, S, L = s["B"], s["S"], s["L"]
+    got = s["eng"].session_pool(dev(s["y"].reshape(B * S, L))).cpu().numpy().reshape(B, S, -1)
+    ref, _, _ = oracle_scan(s)
+    assert np.abs(got - ref).max() < 1e-5
+
+
+def test_gru_scan(setup):
+    s = setup
+    d = s["d"]
+    pooled, before, final = oracle_scan(s)
+    sproj, st_out, sb = s["eng"].gru_scan(dev(pooled, torch.float32), dev(s["mask"]), dev(s["st0"]), want_state_before=True)
+    assert np.abs(st_out.cpu().numpy() - final).max() < 1e-5
+    assert np.abs(sb.cpu().numpy() - before).max() < 1e-5
+    ref_sproj = before @ s["pr"]["hier/tcn/emb/kernel"][d:].astype(np.float64)
+    assert np.abs(sproj.cpu().numpy() - ref_sproj).max() < 1e-5
+
+
+def oracle_hidden(s, num):
+    xl, yl, ml = as_lists(s["x"], s["y"], s["mask"])
+    h, st = O.model_hier(s["args"], xl, yl, ml, s["st0"], s["pr"], num, return_hidden=True)
+    return h.reshape(s["B"], s["S"], s["L"], -1), st
+
+
+def gpu_hidden(s):
+    B, S, L = s["B"], s["S"], s["L"]
+    eng = s["eng"]
+    pooled = eng.session_pool(dev(s["y"].reshape(B * S, L))).view(B, S, -1)
+    sproj, st_out, _ = eng.gru_scan(pooled, dev(s["mask"]), dev(s["st0"]))
+    hid = eng.tcn_forward(dev(s["x"].reshape(B * S, L)), sproj.view(B * S, -1))
+    return hid, st_out
+
+
+def test_tcn_hidden(setup):
+    s = setup
+    hid, _ = gpu_hidden(s)
+    got = hid.float().cpu().numpy().reshape(s["B"], s["S"], s["L"], -1)
+    ref, _ = oracle_hidden(s, O.MIRROR)
+    diff = np.abs(got - ref)
+    scale = np.abs(ref).max()
+    # same rounding points as the oracle: disagreement is a rare 1-ulp bf16 flip (2^-8 relative)
+    assert diff.max() <= scale * 2.0 ** -7, (diff.max(), scale)
+    assert diff.mean() <= scale * 1e-4
+    exact, _ = oracle_hidden(s, O.EXACT64)
+    assert np.abs(got - exact).max() <= scale * 0.03  # bf16 storage vs the exact restatement
+
+
+def test_logits_and_fused_scoring(setup):
+    s = setup
+    eng = s["eng"]
+    hid, _ = gpu_hidden(s)
+    R = hid.shape[0]
+    logits = eng.score_logits(hid).cpu().numpy()
+    W = s["pr"]["hier/tcn/dense/kernel"].astype(np.float64)
+    b = s["pr"]["hier/tcn/dense/bias"].astype(np.float64)
+    ref = hid.float().cpu().numpy().astype(np.float64) @ W + b
+    assert np.abs(logits - ref).max() < 1e-5  # fp32 accumulation only
+
+    y = s["y"].reshape(-1)
+    out = eng.score_fused(hid, dev(y), want_target=True)
+    rank = out["rank"].cpu().numpy()
+    ce = out["ce"].cpu().numpy()
+    tgt = out["target"].cpu().numpy()
+    valid = y > 0
+    rows = np.arange(R)
+    # the fused target is BITWISE the logit the main loop produces for column y
+    assert np.array_equal(tgt[valid], logits[rows[valid], y[valid]])
+    # integer output: bit-exact against a count over the HIP path's own logits (loss.py:179)
+    cnt = (logits > logits[rows, y][:, None]).sum(1)
+    assert np.array_equal(rank[valid], cnt[valid])
+    assert np.all(rank[~valid] == 0) and np.all(ce[~valid] == 0)
+    lse = O.log_sum_exp(logits.astype(np.float64))
+    assert np.abs(ce[valid] - (lse - logits[rows, y])[valid]).max() < 2e-5
+
+
+def test_forward_eval_matches_oracle(setup):
+    s = setup
+    eng = s["eng"]
+    B, S, L, N = s["B"], s["S"], s["L"], s["N"]
+    out = eng.forward_eval(dev(s["x"]), dev(s["y"]), dev(s["mask"]), dev(s["st0"]), want_rows=True)
+    from hiertcn_amd.engine import metrics_dict
+    m = metrics_dict(out["metrics8"])
+    xl, yl, ml = as_lists(s["x"], s["y"], s["mask"])
+    # exact fp64 restatement on the stored (bf16-rounded) weights: logits within 1e-3
+    pred, st = O.model_hier(s["args"], xl, yl, ml, s["st0"], s["pr"], O.EXACT64)
+    hid, st_gpu = gpu_hidden(s)
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+    ymask = (s["y"].reshape(B, S * L) > 0)
+    assert np.abs(logits - pred)[ymask].max() < 1e-3
+    assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
+    # metrics against the mirror-rounded oracle
+    predm, _ = O.model_hier(s["args"], xl, yl, ml, s["st0"], s["pr"], O.MIRROR)
+    ref = O.masked_loss_and_metrics(predm, s["y"].reshape(B, S * L), N)
+    assert abs(m["loss"] - ref["loss"]) < 1e-3
+    assert m["user_count"] == np.sign((s["y"].reshape(B, -1) > 0).sum(1)).sum()
+    # ranks: equal to the oracle's wherever no oracle logit lies within tol of the target
+    tol = 2e-3
+    tgt = np.take_along_axis(predm, s["y"].reshape(B, S * L, 1).astype(np.int64), -1)
+    lo = (predm > tgt + tol).sum(-1)
+    hi = (predm > tgt - tol).sum(-1)
+    rk = out["rank"].cpu().numpy()
+    assert np.all((rk >= lo)[ymask]) and np.all((rk <= hi)[ymask])
+    for k in ("recall1", "recall5", "recall10", "mrr", "rank_frac"):
+        assert abs(m[k] - ref[k]) < 2e-2, (k, m[k], ref[k])
+    # and the lane aggregation itself is exact given the HIP path's own ranks / ce
+    y2 = s["y"].reshape(B, S * L)
+    act = (y2 > 0).sum(1)
+    users = (act > 0).sum()
+    r10 = ((((rk <= 9) & (y2 > 0)).sum(1) / (act + 1e-6))[act > 0]).sum() / users
+    assert abs(m["recall10"] - r10) < 1e-6
