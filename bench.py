@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""Headline benchmark: HierTCN forward + full-catalogue scoring, sessions/sec on XING-shaped
+synthetic data (BASELINE.json configs[2]: 200k users x 20 sessions x 30 steps, 300k items, d=256,
+bf16 storage / fp32 accumulate), user-batch data parallel over N GPUs.
+
+    python bench.py --gpus 1 --steps 6 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" = one evaluation pass (session pool -> GRU scan -> fused TCN -> fused scoring with loss /
+rank epilogue -> lane metrics [-> RCCL all-reduce of the 8 metric sums when N > 1]) over one batch
+of `--users-per-step` users per GPU, ids already resident in HBM.  Weak scaling: every rank
+walks its own shard of the 200k users.  Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+MFMA_PEAK_TFLOPS = 2500.0  # MI355X dense bf16 (MI355X_MICROARCH.md, chip-level parameters)
+U_TOTAL, S_SESS, L_STEPS, N_ITEMS, DIM = 200_000, 20, 30, 300_000, 256
+
+
+def zipf_sampler(n_items: int, a: float = 1.1):
+    """Zipf(a) over a fixed random permutation of the items 1..N-1."""
+    w = 1.0 / np.arange(1, n_items, dtype=np.float64) ** a
+    cdf = np.cumsum(w / w.sum())
+    perm = (np.random.default_rng(0).permutation(n_items - 1) + 1).astype(np.int32)
+
+    def draw(rng, shape):
+        k = np.searchsorted(cdf, rng.random(shape))
+        return perm[np.minimum(k, n_items - 2)]
+
+    return draw
+
+
+def make_users(draw, first_user: int, n_users: int, ragged: bool):
+    """ids for users [first_user, first_user+n_users): deterministic per 256-user block so the data
+    of a user does not depend on the GPU count."""
+    blocks = []
+    u = first_user
+    while u < first_user + n_users:
+        blk = u // 256
+        rng = np.random.default_rng([0, blk])
+        ids = draw(rng, (256, S_SESS, L_STEPS))
+        if ragged:
+            lens = np.random.default_rng([1, blk]).integers(1, L_STEPS + 1, (256, S_SESS))
+            ids = ids * (np.arange(L_STEPS)[None, None, :] < lens[..., None])
+        lo = u - blk * 256
+        hi = min(256, first_user + n_users - blk * 256)
+        blocks.append(ids[lo:hi])
+        u = blk * 256 + hi
+    y = np.concatenate(blocks, 0).astype(np.int32)
+    x = np.zeros_like(y)
+    x[:, :, 1:] = y[:, :, :-1]  # the loader's shift (data_loader.py:260-261); x[:, :, 0] is the null id
+    mask = np.ones((n_users, S_SESS), np.float32)
+    mask[:, -1] = 0.0  # a user's last session resets the state (data_loader.py:186-187)
+    return x, y, mask
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=6)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--users-per-step", type=int, default=2048, help="users per step PER GPU")
+    ap.add_argument("--ragged", action="store_true", help="session lengths ~ U{1..30} instead of full")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
+    a = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        a.gpus = world
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine, metrics_dict
+    from hiertcn_amd.params import init_params
+
+    args = hier_tcn_args(item_num=N_ITEMS, emb_dim=DIM, hidden_dim=DIM, num_layer=2, tcn_channel=[DIM, DIM], kernel_size=5,
+                         max_activity_len=L_STEPS, max_session_num=S_SESS, batch_size=a.users_per_step)
+    t_setup = time.perf_counter()
+    params = init_params(args, seed=2)  # glorot-uniform / GRU gate bias 1.0, default_rng(2)
+    eng = Engine(args, hier=True)
+    eng.set_weights(params)
+
+    B = a.users_per_step
+    n_steps_total = a.warmup + a.steps
+    shard = U_TOTAL // max(world, 1)
+    draw = zipf_sampler(N_ITEMS)
+    batches = []
+    for i in range(n_steps_total):
+        first = rank * shard + (i * B) % max(shard - B, 1)
+        x, y, mask = make_users(draw, first, B, a.ragged)
+        batches.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda()))
+    state0 = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")  # run_hier_xing.py:241
+    state_out = torch.empty_like(state0)
+    m8 = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(n_steps_total)]
+    eng.workspace(B, S_SESS, L_STEPS)
+    torch.cuda.synchronize()
+    t_setup = time.perf_counter() - t_setup
+
+    def step(i):
+        xb, yb, mb = batches[i]
+        eng.forward_eval(xb, yb, mb, state0, state_out=state_out, metrics8=m8[i])
+        if world > 1:
+            dist.all_reduce(m8[i])  # RCCL: the only collective of the evaluation path (8 doubles)
+
+    for i in range(a.warmup):
+        step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.timing_enable(True)
+    eng.timing_read(reset=True)
+    t0 = time.perf_counter()
+    for i in range(a.warmup, n_steps_total):
+        step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    score_ms, launches = eng.timing_read(reset=True)
+    eng.timing_enable(False)
+
+    sessions_per_step = B * S_SESS * world
+    value = sessions_per_step * a.steps / dt
+    rows_per_launch = B * S_SESS * L_STEPS
+    flops_per_launch = 2.0 * rows_per_launch * DIM * N_ITEMS  # algorithmic: rows x 2 C N
+    achieved = flops_per_launch / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
+    last = metrics_dict(m8[-1])
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        # the checker, timed on this host's cores on a bounded sample of the SAME workload
+        from oracle.cpu_baseline import time_cpu_baseline
+        xb, yb, mb = batches[a.warmup]
+        n_cpu = min(B, 256)
+        r = time_cpu_baseline(args, params, xb[:n_cpu].cpu().numpy(), yb[:n_cpu].cpu().numpy(), mb[:n_cpu].cpu().numpy(),
+                              lanes=32, budget_s=a.cpu_budget)
+        cpu = dict(value=round(r["value"], 3), unit="sessions/s", cores=r["cores"], kind="port", sample=r["sample"],
+                   seconds=round(r["seconds"], 2))
+
+    if rank == 0:
+        out = {
+            "metric": "sessions/sec (XING-shape synth) at 1/2/4/8 MI355X; recall@10 parity",
+            "value": round(value, 2),
+            "unit": "sessions/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "cfg3-synth: 200k users x 20 sessions x 30 steps, 300k-item catalogue, d=256 (E=C=H), "
+                            "2 TCN blocks K=5, 2-layer GRU; eval step = pool+GRU scan+TCN+fused scoring(loss+rank)+lane metrics",
+                "users_per_step_per_gpu": B,
+                "sessions_per_step": sessions_per_step,
+                "ragged": bool(a.ragged),
+                "parallelism": f"user-batch dp{world}",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "k_score<256,false> (fused scoring GEMM + loss/rank epilogue)",
+                "achieved": round(achieved, 2),
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "traffic": None,
+                "launch_ms": round(score_ms, 4),
+                "launches_timed": int(launches),
+                "flops_per_launch": flops_per_launch,
+            },
+            "cpu_baseline": cpu,
+            "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
+            "setup_s": round(t_setup, 1),
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -74,6 +74,9 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
+    # torch first: its wheel bundles the HIP runtime (libamdhip64.so.7); loading it before our
+    # library makes both resolve to ONE runtime, which sharing streams and device pointers needs.
+    import torch  # noqa: F401
     if not os.path.exists(LIB_PATH):
         raise HierTCNError(
             f"{LIB_PATH} not found: build it with `python -m hiertcn_amd.build` "

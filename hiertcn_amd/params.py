@@ -1,0 +1,74 @@
+"""Parameter store of the hot path: TF-1.x variable names and shapes of the reference graph
+(SURVEY.md 8(a)), and the initialisers the reference relies on.
+
+  glorot-uniform for every kernel  ([TF-sem] default of tf.layers / add_variable(initializer=None),
+                                    customized_dense_layer.py:133-135, customized_convolution_layer.py:137-141;
+                                    for conv kernels fan = K*C)
+  zeros for every bias             (customized_dense_layer.py:101, customized_convolution_layer.py:95,150)
+  1.0 for the GRU gate bias        (customed_gru_cell.py:312-314), 0 for the candidate bias (:333)
+"""
+from __future__ import annotations
+
+from typing import Dict
+
+import numpy as np
+
+
+def _glorot(rng, shape, fan_in, fan_out):
+    lim = np.sqrt(6.0 / (fan_in + fan_out))
+    return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+
+def param_shapes(args, model: str = "hier") -> Dict[str, tuple]:
+    N = int(args.item_num)
+    E = int(getattr(args, "emb_dim", 128))
+    H, nl, K = int(args.hidden_dim), int(args.num_layer), int(args.kernel_size)
+    ch = [int(c) for c in args.tcn_channel]
+    s: Dict[str, tuple] = {}
+    if model == "hier":
+        root = "hier/tcn"
+        s["hier/emb/kernel"] = (N, E)
+        s["hier/emb/bias"] = (E,)  # created by the y-path dense only (model_hier.py:85 vs :50)
+        s["hier/tcn/emb/kernel"] = (E + H * nl, E)
+    else:
+        root = "tcn"
+        s["tcn/emb/kernel"] = (N, E)
+    cin = E
+    for i, cout in enumerate(ch):
+        pre = f"{root}/temporal_conv_net/tblock_{i}"
+        s[f"{pre}/conv1/kernel"] = (K, cin, cout)
+        s[f"{pre}/conv1/bias"] = (cout,)
+        if cin != cout:
+            s[f"{pre}/dense/kernel"] = (cin, cout)
+            s[f"{pre}/dense/bias"] = (cout,)
+        cin = cout
+    s[f"{root}/dense/kernel"] = (cin, N)
+    s[f"{root}/dense/bias"] = (N,)
+    if model == "hier":
+        inp = E
+        for l in range(nl):
+            pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
+            s[f"{pre}/gates/kernel"] = (inp + H, 2 * H)
+            s[f"{pre}/gates/bias"] = (2 * H,)
+            s[f"{pre}/candidate/kernel"] = (inp + H, H)
+            s[f"{pre}/candidate/bias"] = (H,)
+            inp = H
+    return s
+
+
+def init_params(args, seed: int = 2, model: str = "hier") -> Dict[str, np.ndarray]:
+    """numpy.random.default_rng(seed), tensors drawn in param_shapes() order."""
+    rng = np.random.default_rng(seed)
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in param_shapes(args, model).items():
+        if name.endswith("/bias"):
+            out[name] = (np.ones if name.endswith("gates/bias") else np.zeros)(shape, np.float32)
+        elif len(shape) == 3:  # conv [K, Cin, Cout]
+            out[name] = _glorot(rng, shape, shape[0] * shape[1], shape[0] * shape[2])
+        else:
+            out[name] = _glorot(rng, shape, shape[0], shape[1])
+    return out
+
+
+def count_params(params) -> int:
+    return int(sum(int(np.prod(v.shape)) for v in params.values()))

@@ -1,0 +1,48 @@
+"""Pins oracle/cpu_baseline.py (torch-CPU, the timed 'reference CPU path') and
+hiertcn_amd/params.py (product-side initialiser) to the NumPy oracle."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+
+from hiertcn_amd import params as P  # noqa: E402
+from hiertcn_amd.args import hier_tcn_args, make_args  # noqa: E402
+from oracle import hiertcn_oracle as O  # noqa: E402
+from oracle.cpu_baseline import CpuHierTCN, time_cpu_baseline  # noqa: E402
+from tests.gpu_common import as_lists, make_batch, make_params  # noqa: E402
+
+
+def test_product_init_matches_oracle_init():
+    args = hier_tcn_args(item_num=301, emb_dim=32, hidden_dim=16, tcn_channel=[32, 32])
+    a, b = P.init_params(args, seed=2), O.init_params(args, seed=2)
+    assert list(a) == list(b)
+    for k in a:
+        assert np.array_equal(a[k], b[k]), k
+    assert P.count_params(P.init_params(hier_tcn_args(), seed=0)) == 5_750_698
+    t = make_args([], model_type="tcn")
+    assert list(P.init_params(t, 0, "tcn")) == list(O.init_params(t, 0, "tcn"))
+
+
+def test_cpu_baseline_matches_oracle():
+    args = hier_tcn_args(item_num=211, emb_dim=16, hidden_dim=8, tcn_channel=[16, 16])
+    p = make_params(args)
+    rng = np.random.default_rng(3)
+    B, S, L = 6, 3, 7
+    x, y, mask = make_batch(rng, B, S, L, 211)
+    st0 = rng.standard_normal((B, 16)).astype(np.float32)
+    m, st = CpuHierTCN(args, p).eval_batch(torch.from_numpy(x.astype(np.int64)), torch.from_numpy(y.astype(np.int64)),
+                                           torch.from_numpy(mask), torch.from_numpy(st0))
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, st_ref = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64)
+    ref = O.masked_loss_and_metrics(pred, y.reshape(B, S * L), 211)
+    assert np.abs(st.numpy() - st_ref).max() < 1e-5
+    for k in ("loss", "recall1", "recall5", "recall10", "mrr", "rank_frac"):
+        assert abs(m[k] - float(ref[k])) < 1e-4, k
+
+
+def test_time_cpu_baseline_runs_bounded():
+    args = hier_tcn_args(item_num=500, emb_dim=16, hidden_dim=8, tcn_channel=[16, 16])
+    p = make_params(args)
+    x, y, mask = make_batch(np.random.default_rng(0), 64, 2, 5, 500, ragged=False)
+    r = time_cpu_baseline(args, p, x, y, mask, lanes=32, budget_s=0.01)
+    assert r["sessions"] == 64 and r["value"] > 0 and r["cores"] >= 1

