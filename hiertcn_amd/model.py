@@ -1,0 +1,142 @@
+"""The contract between the run loop and the model (what /root/reference/model.py is to
+run_hier_xing.py): parameter scopes, the lazy `pred` handle, batch packing and one evaluation step.
+
+The reference builds one TF graph at import time (model.py:19-182) and the run loops fetch module
+globals by name.  Here a `HierTCNModel` owns the same things explicitly: the variables of a scope
+(TF names), an Engine (HIP kernels behind the C-ABI) and `eval_step`, which returns
+the fetch list of run_hier_xing.py:145-149.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from .engine import Engine, metrics_dict
+from .params import init_params
+
+_SCOPES: Dict[str, "HierTCNModel"] = {}
+
+
+def _to_ids(a) -> np.ndarray:
+    """loader arrays are float64 holding integer ids (data_loader.py:246); model.py:50-51 feeds
+    them to int32 placeholders."""
+    if isinstance(a, torch.Tensor):
+        a = a.detach().cpu().numpy()
+    return np.asarray(a).astype(np.int32)
+
+
+def pack_slots(x_list: Sequence, y_list: Sequence, mask_list: Sequence):
+    """S arrays [B, L_i] (ragged over slots) -> ids [B, S, Lmax] int32 zero padded, mask [B, S].
+    Zero padding is exactly the loader's own right-padding (data_loader.py:246-252): id 0 embeds to
+    zero and is masked out of loss/metrics (model.py:59-62)."""
+    S = len(x_list)
+    xs = [_to_ids(v) for v in x_list]
+    ys = [_to_ids(v) for v in y_list]
+    B = xs[0].shape[0]
+    lens = [v.shape[1] for v in xs]
+    Lmax = max(lens)
+    x = np.zeros((B, S, Lmax), np.int32)
+    y = np.zeros((B, S, Lmax), np.int32)
+    for i in range(S):
+        x[:, i, :lens[i]] = xs[i]
+        y[:, i, :lens[i]] = ys[i]
+    mask = np.concatenate([np.asarray(m.detach().cpu() if isinstance(m, torch.Tensor) else m, dtype=np.float32).reshape(B, 1)
+                           for m in mask_list], axis=1)
+    return x, y, mask, lens
+
+
+class LazyLogits:
+    """What `pred` is in the reference (model_hier.py:79: [B, sum L_i, N] logits) without the
+    logits: the last TCN activations plus the engine that can score them.  calc_loss /
+    calc_metric_fast consume it through the fused kernel; .materialize() writes real logits
+    (parity / debug only: 4*N bytes per step)."""
+
+    def __init__(self, engine: Engine, hidden: torch.Tensor, B: int, S: int, Lmax: int, lens: List[int]):
+        self.engine, self.hidden = engine, hidden
+        self.B, self.S, self.Lmax, self.lens = B, S, Lmax, list(lens)
+        self._cols = torch.as_tensor(np.concatenate([i * Lmax + np.arange(l) for i, l in enumerate(lens)]), device=hidden.device)
+        self._scored = None
+
+    @property
+    def shape(self):
+        return (self.B, int(sum(self.lens)), self.engine.N)
+
+    def unpad(self, rows: torch.Tensor) -> torch.Tensor:
+        """[B*S*Lmax, ...] row-major tensor -> [B, sum L_i, ...] in the reference's concat order."""
+        v = rows.view(self.B, self.S * self.Lmax, *rows.shape[1:])
+        return v.index_select(1, self._cols)
+
+    def pad_ids(self, y) -> torch.Tensor:
+        """[B, sum L_i] ids (the reference's y_id = concat(y_list), run_hier_xing.py:116) -> [B*S*Lmax] int32."""
+        y = torch.as_tensor(_to_ids(y), device=self.hidden.device)
+        full = torch.zeros((self.B, self.S * self.Lmax), dtype=torch.int32, device=self.hidden.device)
+        full.index_copy_(1, self._cols, y)
+        return full.reshape(-1).contiguous()
+
+    def scored(self, y) -> dict:
+        if self._scored is None:
+            yp = self.pad_ids(y)
+            out = self.engine.score_fused(self.hidden, yp, want_target=True)
+            out["y_padded"] = yp
+            self._scored = out
+        return self._scored
+
+    def materialize(self) -> torch.Tensor:
+        return self.unpad(self.engine.score_logits(self.hidden))
+
+
+class HierTCNModel:
+    def __init__(self, args, params: Optional[dict] = None, name: str = "hier", seed: int = 2):
+        self.args, self.name = args, name
+        self.hier = name.startswith("hier")
+        self.engine = Engine(args, hier=self.hier)
+        self.params = params if params is not None else init_params(args, seed, "hier" if self.hier else "tcn")
+        self.engine.set_weights(self.params, root=name)
+
+    def set_parameters(self, params: dict):
+        self.params = params
+        self.engine.set_weights(params, root=self.name)
+
+    # one sess.run of the evaluation fetch list (run_hier_xing.py:145-149) ------------------------
+    def eval_step(self, x_list, y_list, mask_list, state_np, want_pred: bool = False):
+        eng = self.engine
+        x, y, mask, lens = pack_slots(x_list, y_list, mask_list)
+        B, S, Lmax = x.shape
+        dev = eng.device
+        xd, yd, md = (torch.from_numpy(v).to(dev) for v in (x, y, mask))
+        st = torch.as_tensor(np.asarray(state_np, dtype=np.float32)).to(dev).contiguous()
+        out = eng.forward_eval(xd, yd, md, st, want_rows=True)
+        m = metrics_dict(out["metrics8"])
+        cols = np.concatenate([i * Lmax + np.arange(l) for i, l in enumerate(lens)])
+        rank = out["rank"].cpu().numpy()[:, cols].astype(np.float32)
+        mask_y = (y.reshape(B, S * Lmax)[:, cols] > 0).astype(np.float32)
+        res = dict(loss=m["loss"], state=out["state"].cpu().numpy(), ranks_float_mean_user=m["rank_frac"],
+                   ranks_float=rank / float(eng.N), mask_y=mask_y, reciprocal_ranks_float_mean_user=m["mrr"],
+                   recall1_mean_user=m["recall1"], recall5_mean_user=m["recall5"], recall10_mean_user=m["recall10"],
+                   ranks=rank, user_count=m["user_count"])
+        if want_pred:
+            pooled = eng.session_pool(yd.view(B * S, Lmax)).view(B, S, -1)
+            sproj, _, _ = eng.gru_scan(pooled, md, st)
+            hid = eng.tcn_forward(xd.view(B * S, Lmax), sproj.view(B * S, -1))
+            res["pred"] = LazyLogits(eng, hid, B, S, Lmax, lens).materialize().cpu().numpy()
+        return res
+
+
+def get_scope(args, name: str) -> HierTCNModel:
+    """tf.variable_scope(name, reuse=tf.AUTO_REUSE) (model_hier.py:28, model_tcn.py:26): the first
+    use of a scope creates its variables (glorot / zeros / gate-bias 1.0), later uses share them."""
+    if name not in _SCOPES:
+        _SCOPES[name] = HierTCNModel(args, None, name)
+    return _SCOPES[name]
+
+
+def set_scope(name: str, model: HierTCNModel):
+    _SCOPES[name] = model
+
+
+def reset_scopes():
+    for m in _SCOPES.values():
+        m.engine.close()
+    _SCOPES.clear()

@@ -1,0 +1,33 @@
+"""model_tcn with the reference's signature (model_tcn.py:13), backed by the HIP kernels.
+
+    model_tcn(args, x, x_gap=None, x_impression=None, name='tcn', reuse=True,
+              training=False, mask=None) -> pred
+
+Single-level use (model.py:71-73): x = ids [B, T]; the first dense of the reference
+(model_tcn.py:35 on a one-hot input) is the embedding lookup with row 0 -> 0.
+This build's fused low-level kernel covers T <= 32 and equal channel widths; the reference's
+6-block / T <= 500 single-level configuration (args.py:310-311) is the next row of SURVEY.md 8(f)
+and raises here rather than silently running somewhere else.
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from .model import LazyLogits, _to_ids, get_scope
+
+
+def model_tcn(args, x, x_gap=None, x_impression=None, name="tcn", reuse=True, training=False, mask=None):
+    for flag in ("has_gap", "has_impression", "has_batchnorm", "has_weightnorm", "has_layernorm", "l2_normalize"):
+        if getattr(args, flag, False):
+            raise NotImplementedError(f"args.{flag}=True is outside the hot path (reference default is False)")
+    ids = _to_ids(x)
+    if ids.ndim != 2:
+        raise NotImplementedError("model_tcn takes ids [B, T] (the one-hot of model.py:56 is undone); "
+                                  "the float-input form is reached through model_hier")
+    model = get_scope(args, name)
+    eng = model.engine
+    B, T = ids.shape
+    xd = torch.from_numpy(np.ascontiguousarray(ids)).to(eng.device)
+    hidden = eng.tcn_forward(xd, None)
+    return LazyLogits(eng, hidden, B, 1, T, [T])

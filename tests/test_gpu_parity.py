@@ -142,13 +142,15 @@ def test_forward_eval_matches_oracle(setup):
     hid, st_gpu = gpu_hidden(s)
     logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
     ymask = (s["y"].reshape(B, S * L) > 0)
-    # north star: fp32 logits within 1e-3 at its logit scale (|z| <= 1 at N=300k glorot); bf16 storage is
-    # a RELATIVE 2^-9 error, so the bound is scaled by the logit magnitude when the small-N test weights
-    # produce larger logits
-    assert np.abs(logits - pred)[ymask].max() < 1e-3 * max(1.0, np.abs(pred).max())
+    # bf16 STORAGE of weights/activations is a relative 2^-9 perturbation per rounding point, so against the
+    # exact fp64 restatement the error scales with the logit magnitude (the small-N glorot test weights are
+    # ~17x larger than at the north star's N=300k; test_logits_within_1e-3_at_north_star_scale covers that)
+    assert np.abs(logits - pred)[ymask].max() < 4e-3 * max(1.0, np.abs(pred).max())
     assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
     # metrics against the mirror-rounded oracle
     predm, _ = O.model_hier(s["args"], xl, yl, ml, s["st0"], s["pr"], O.MIRROR)
+    # against the oracle that rounds at the same points: 1e-3 absolute (north star's logit tolerance)
+    assert np.abs(logits - predm)[ymask].max() < 1e-3
     ref = O.masked_loss_and_metrics(predm, s["y"].reshape(B, S * L), N)
     assert abs(m["loss"] - ref["loss"]) < 1e-3
     assert m["user_count"] == np.sign((s["y"].reshape(B, -1) > 0).sum(1)).sum()
@@ -167,3 +169,34 @@ def test_forward_eval_matches_oracle(setup):
     users = (act > 0).sum()
     r10 = ((((rk <= 9) & (y2 > 0)).sum(1) / (act + 1e-6))[act > 0]).sum() / users
     assert abs(m["recall10"] - r10) < 1e-6
+
+
+def test_logits_within_1e_3_at_north_star_scale():
+    """North-star tolerance on the EXACT restatement: fp32 logits within 1e-3 when the scoring weights have
+    the magnitude they have at the headline catalogue size (glorot limit sqrt(6/(256+300000)))."""
+    from hiertcn_amd.engine import Engine
+    d, N = 256, 1500
+    args = small_args(N=N, d=d, H=64)
+    p = make_params(args)
+    p["hier/tcn/dense/kernel"] = (p["hier/tcn/dense/kernel"] * np.sqrt((d + N) / (d + 300000.0))).astype(np.float32)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    pr = O.round_params_bf16(p, E=d)
+    rng = np.random.default_rng(11)
+    B, S, L = 5, 3, 20
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=False)
+    st0 = (0.3 * rng.standard_normal((B, 128))).astype(np.float32)
+    s = dict(eng=eng, x=x, y=y, mask=mask, st0=st0, B=B, S=S, L=L)
+    hid, _ = gpu_hidden(s)
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, _ = O.model_hier(args, xl, yl, ml, st0, pr, O.EXACT64)
+    assert np.abs(logits - pred).max() < 1e-3
+    # and top-10 indices identical wherever the oracle's 10th/11th gap exceeds the tolerance (SURVEY.md 7)
+    top_ref = O.top_k_indices(pred, 11)
+    vals = np.take_along_axis(pred, top_ref, -1)
+    safe = np.all(vals[..., :-1] - vals[..., 1:] > 2e-3, axis=-1)
+    top_gpu = O.top_k_indices(logits.astype(np.float64), 10)
+    assert safe.sum() > 0
+    assert np.array_equal(top_gpu[safe], top_ref[..., :10][safe])
+    eng.close()
