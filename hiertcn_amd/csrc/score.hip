@@ -29,29 +29,35 @@ struct ScGeom {
   static_assert((SC_STAGE * CH) % SC_THREADS == 0, "stage must split evenly");
 };
 
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void gbl_void;
+
 struct RowState {
   float t;    // target logit
-  float m2;   // running max * log2(e)
-  float m;    // running max
-  float s;    // sum of exp(z - m)
+  float m2;   // reference point of the running softmax sum, in log2 units (>= max logit * log2(e) - SC_DEFER)
+  float s;    // sum of 2^(z*log2(e) - m2)
   int cnt;    // #{z > t}
 };
 
+#define SC_DEFER 8.0f  // rescale only when a logit exceeds the reference by 2^8 (T13): exact in fp32, rarely taken
+
 __device__ __forceinline__ void epilogue(const f32x16& v, RowState& st) {
-  float tm = fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3]));
-  tm = fmaxf(tm, fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
-  tm = fmaxf(tm, fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])));
-  tm = fmaxf(tm, fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15])));
-  if (__any(tm > st.m)) {  // wave-uniform, rare once the running max has settled
-    const float mn = fmaxf(st.m, tm);
-    st.s *= __builtin_amdgcn_exp2f((st.m - mn) * LOG2E_F);
-    st.m = mn;
-    st.m2 = mn * LOG2E_F;
+  float x[16];
+#pragma unroll
+  for (int i = 0; i < 16; i++) x[i] = fmaf(v[i], LOG2E_F, -st.m2);  // fma results are canonical: no v_max canonicalisation below
+  float xm = fmaxf(fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])), fmaxf(fmaxf(x[4], x[5]), fmaxf(x[6], x[7])));
+  xm = fmaxf(xm, fmaxf(fmaxf(fmaxf(x[8], x[9]), fmaxf(x[10], x[11])), fmaxf(fmaxf(x[12], x[13]), fmaxf(x[14], x[15]))));
+  if (__any(xm > SC_DEFER)) {  // wave-uniform, rare once the reference has settled
+    const float d = fmaxf(xm, 0.f);
+    st.s *= __builtin_amdgcn_exp2f(-d);
+    st.m2 += d;
+#pragma unroll
+    for (int i = 0; i < 16; i++) x[i] -= d;
   }
 #pragma unroll
   for (int i = 0; i < 16; i++) {
     st.cnt += (v[i] > st.t) ? 1 : 0;
-    st.s += __builtin_amdgcn_exp2f(fmaf(v[i], LOG2E_F, -st.m2));
+    st.s += __builtin_amdgcn_exp2f(x[i]);
   }
 }
 
@@ -63,11 +69,16 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
                                                          float* __restrict__ o_tgt, float* __restrict__ logits) {
   using G = ScGeom<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages + 2 x 64 bias floats
-  float* sbias = reinterpret_cast<float*>(smem + 2 * G::STAGE_BYTES);
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * 64;
+  // Waves w and w+4 share a SIMD.  Waves 4-7 run half a tile behind waves 0-3 (they defer the epilogue of a
+  // stage's second item block past the barrier), so that on every SIMD one wave's MFMA burst runs beside the
+  // other's VALU epilogue instead of both bursts colliding after each barrier (MI355X_MICROARCH.md, two waves
+  // per SIMD, item 9).
+  const bool late = !LOGITS && wave >= 4;
 
   // ---- this wave's 64 steps as the B operand, resident for the whole kernel -------------------
   uint4 hf[2][G::KS];
@@ -110,100 +121,113 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       const float other = __shfl_xor(d, 32);
       const float t = (((lr >> 2) & 1) == lh) ? d : other;
       st[cbk].t = t;
-      st[cbk].m = t;
       st[cbk].m2 = t * LOG2E_F;
       st[cbk].s = 0.f;
       st[cbk].cnt = 0;
     }
   }
 
-  // ---- stream the item table ------------------------------------------------------------------
+  // ---- stream the item table: LDS-DMA (global_load_lds, 16 B per lane, 1 KiB per wave instruction) -------
+  // The LDS image is lane-linear per instruction, so the bank swizzle is applied to the SOURCE address
+  // (cdna_hip_programming.md rule 21): LDS slot (row, c) holds global chunk c ^ (row & SWZ) of that row.
   const int n_stages = NP / SC_STAGE;
-  uint4 pre[G::CHUNKS_PER_THREAD];
-  float pre_b = 0.f;
-  auto stage_load = [&](int stg) {
-    const uint16_t* src = outT + (int64_t)stg * SC_STAGE * C;
+  constexpr int PIECES = G::STAGE_BYTES / 1024;  // wave instructions per stage
+  constexpr int PPW = PIECES / 8;                // per wave
+  static_assert(PIECES % 8 == 0, "stage must split over 8 waves");
+  auto stage_issue = [&](int stg, int buf) {
 #pragma unroll
-    for (int i = 0; i < G::CHUNKS_PER_THREAD; i++) {
-      const int id = tid + i * SC_THREADS;
-      pre[i] = *reinterpret_cast<const uint4*>(src + (int64_t)id * 8);
+    for (int i = 0; i < PPW; i++) {
+      const int piece = wave * PPW + i;
+      const int off = piece * 1024 + lane * 16;          // byte offset inside the stage image
+      const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
+      const uint16_t* src = outT + ((int64_t)stg * SC_STAGE + row) * C + ((slot ^ (row & G::SWZ)) << 3);
+      __builtin_amdgcn_global_load_lds((gbl_void*)src, (lds_void*)(smem + buf * G::STAGE_BYTES + piece * 1024), 16, 0, 0);
     }
-    if (tid < SC_STAGE) pre_b = out_bias[stg * SC_STAGE + tid];
+    if (wave == 0 && lane < SC_STAGE / 4)
+      __builtin_amdgcn_global_load_lds((gbl_void*)(out_bias + (int64_t)stg * SC_STAGE + lane * 4),
+                                       (lds_void*)(smem + 2 * G::STAGE_BYTES + buf * SC_STAGE * 4), 16, 0, 0);
   };
-  auto stage_write = [&](int buf) {
-    unsigned char* dst = smem + buf * G::STAGE_BYTES;
+  const float* sbias = reinterpret_cast<const float*>(smem + 2 * G::STAGE_BYTES);
+
+  f32x16 acc0, acc1;
+  auto mfma_tile = [&](int buf, int ib) {
 #pragma unroll
-    for (int i = 0; i < G::CHUNKS_PER_THREAD; i++) {
-      const int id = tid + i * SC_THREADS;
-      const int row = id / G::CH, ch = id % G::CH;
-      *reinterpret_cast<uint4*>(dst + row * (2 * C) + ((ch ^ (row & G::SWZ)) << 4)) = pre[i];
+    for (int q = 0; q < 4; q++) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + buf * SC_STAGE + ib * 32 + 8 * q + 4 * lh);
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        acc0[4 * q + j] = b4[j];
+        acc1[4 * q + j] = b4[j];
+      }
     }
-    if (tid < SC_STAGE) sbias[buf * SC_STAGE + tid] = pre_b;
+    const unsigned char* arow = smem + buf * G::STAGE_BYTES + (ib * 32 + lr) * (2 * C);
+#pragma unroll
+    for (int s = 0; s < G::KS; s++) {
+      const uint4 a = *reinterpret_cast<const uint4*>(arow + (((2 * s + lh) ^ (lr & G::SWZ)) << 4));
+      acc0 = mfma32(a, hf[0][s], acc0);
+      acc1 = mfma32(a, hf[1][s], acc1);
+    }
+  };
+  auto store_logits = [&](int stg, int ib) {
+    const int item0 = stg * SC_STAGE + ib * 32 + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int it = item0 + 8 * q;
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        if (it + j < N) {
+          if (myrow[0] < R) logits[myrow[0] * N + it + j] = acc0[4 * q + j];
+          if (myrow[1] < R) logits[myrow[1] * N + it + j] = acc1[4 * q + j];
+        }
+      }
+    }
   };
 
-  stage_load(0);
-  stage_write(0);
-  __syncthreads();
+  stage_issue(0, 0);
+  __syncthreads();  // (hipcc drains vmcnt(0) here because an LDS-DMA is in flight)
 
   for (int stg = 0; stg < n_stages; stg++) {
     const int buf = stg & 1;
-    if (stg + 1 < n_stages) stage_load(stg + 1);  // global loads in flight under the MFMAs (T14)
-    const unsigned char* tile = smem + buf * G::STAGE_BYTES;
-#pragma unroll
-    for (int ib = 0; ib < 2; ib++) {
-      f32x16 acc0, acc1;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + buf * SC_STAGE + ib * 32 + 8 * q + 4 * lh);
-#pragma unroll
-        for (int j = 0; j < 4; j++) {
-          acc0[4 * q + j] = b4[j];
-          acc1[4 * q + j] = b4[j];
-        }
-      }
-      const unsigned char* arow = tile + (ib * 32 + lr) * (2 * C);
-#pragma unroll
-      for (int s = 0; s < G::KS; s++) {
-        const uint4 a = *reinterpret_cast<const uint4*>(arow + (((2 * s + lh) ^ (lr & G::SWZ)) << 4));
-        acc0 = mfma32(a, hf[0][s], acc0);
-        acc1 = mfma32(a, hf[1][s], acc1);
-      }
-      if (LOGITS) {
-        const int item0 = stg * SC_STAGE + ib * 32 + 4 * lh;
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          const int it = item0 + 8 * q;
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            if (it + j < N) {
-              if (myrow[0] < R) logits[myrow[0] * N + it + j] = acc0[4 * q + j];
-              if (myrow[1] < R) logits[myrow[1] * N + it + j] = acc1[4 * q + j];
-            }
-          }
-        }
-      } else {
-        epilogue(acc0, st[0]);
-        epilogue(acc1, st[1]);
-      }
+    // buf^1 was last read (by MFMA operand / bias reads) before the barrier that ended stage stg-1
+    if (stg + 1 < n_stages) stage_issue(stg + 1, buf ^ 1);
+    if (late && stg > 0) {  // deferred epilogue of the previous stage's second item block
+      epilogue(acc0, st[0]);
+      epilogue(acc1, st[1]);
     }
-    if (stg + 1 < n_stages) stage_write(buf ^ 1);
+    mfma_tile(buf, 0);
+    if (LOGITS) {
+      store_logits(stg, 0);
+    } else {
+      epilogue(acc0, st[0]);
+      epilogue(acc1, st[1]);
+    }
+    mfma_tile(buf, 1);
+    if (LOGITS) {
+      store_logits(stg, 1);
+    } else if (!late) {
+      epilogue(acc0, st[0]);
+      epilogue(acc1, st[1]);
+    }
     __syncthreads();
+  }
+  if (late) {
+    epilogue(acc0, st[0]);
+    epilogue(acc1, st[1]);
   }
 
   if (!LOGITS) {
 #pragma unroll
     for (int cbk = 0; cbk < 2; cbk++) {
       // merge the two half-waves (same step, disjoint item subsets)
-      const float m_o = __shfl_xor(st[cbk].m, 32);
+      const float m_o = __shfl_xor(st[cbk].m2, 32);
       const float s_o = __shfl_xor(st[cbk].s, 32);
       const int c_o = __shfl_xor(st[cbk].cnt, 32);
-      const float M = fmaxf(st[cbk].m, m_o);
-      const float S = st[cbk].s * __builtin_amdgcn_exp2f((st[cbk].m - M) * LOG2E_F) +
-                      s_o * __builtin_amdgcn_exp2f((m_o - M) * LOG2E_F);
+      const float M2 = fmaxf(st[cbk].m2, m_o);
+      const float S = st[cbk].s * __builtin_amdgcn_exp2f(st[cbk].m2 - M2) + s_o * __builtin_amdgcn_exp2f(m_o - M2);
       const int cnt = st[cbk].cnt + c_o;
       if (lh == 0 && myrow[cbk] < R) {
         const bool valid = myy[cbk] > 0;
-        const float lse = M + logf(S);
+        const float lse = (M2 + log2f(S)) * LN2_F;
         if (o_rank) o_rank[myrow[cbk]] = valid ? cnt : 0;
         if (o_ce) o_ce[myrow[cbk]] = valid ? (lse - st[cbk].t) : 0.f;
         if (o_tgt) o_tgt[myrow[cbk]] = valid ? st[cbk].t : 0.f;
