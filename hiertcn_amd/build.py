@@ -43,7 +43,10 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
 
     def cc(job):
         s, o = job
-        cmd = [hipcc, *FLAGS, *extra_flags, "-c", s, "-o", o]
+        # score.hip: logits are finite or -inf by construction; without NaN-honouring fmaxf needs no
+        # canonicalising v_max on MFMA results (cdna_hip_programming.md, attention 'Pitfalls')
+        per_file = ["-fno-honor-nans"] if s.endswith("score.hip") else []
+        cmd = [hipcc, *FLAGS, *per_file, *extra_flags, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("hipcc failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))

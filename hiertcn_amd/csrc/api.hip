@@ -68,7 +68,9 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
   if (cfg->kernel_size < 1 || cfg->kernel_size > 8) return fail(HIERTCN_ERR_INVALID, "kernel_size out of range");
   if (cfg->hier) {
     if (cfg->num_layer < 1 || cfg->num_layer > HIERTCN_MAX_LAYERS) return fail(HIERTCN_ERR_INVALID, "num_layer out of range");
-    if (cfg->hidden_dim < 4 || (cfg->hidden_dim & 3)) return fail(HIERTCN_ERR_INVALID, "hidden_dim must be a positive multiple of 4");
+    if (cfg->hidden_dim < 8 || (cfg->hidden_dim & 7)) return fail(HIERTCN_ERR_INVALID, "hidden_dim must be a positive multiple of 8");
+    if (cfg->hidden_dim * cfg->num_layer > 1024 || cfg->hidden_dim + (E > cfg->hidden_dim ? E : cfg->hidden_dim) > 1024)
+      return fail(HIERTCN_ERR_INVALID, "GRU reduction width above 1024 is not built");
   }
   const int halo = (cfg->kernel_size - 1) * (1 << (cfg->n_blocks - 1));
   const size_t tcn_lds = (size_t)4 * (((halo + 7) & ~7) + 32) * 2 * E;
@@ -171,15 +173,14 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
     if (!w->emb_bias || !w->proj_kernel) return fail(HIERTCN_ERR_INVALID, "emb_bias/proj_kernel are required for hier models");
     HIP_TRY(launch_copy_pad_f32(w->emb_bias, m.emb_bias, E, E, 0.f, st));
     HIP_TRY(launch_transpose_to_bf16(w->proj_kernel, m.projT, E, E, E, st));  // rows [0,E): item half, bf16, cout-major
-    HIP_TRY(launch_copy_pad_f32(w->proj_kernel + (size_t)E * E, m.projS, (int64_t)m.HT * E, (int64_t)m.HT * E, 0.f, st));  // state half, fp32
+    HIP_TRY(launch_transpose_f32(w->proj_kernel + (size_t)E * E, m.projS, m.HT, E, st));  // state half, fp32, [E][HT]
     for (int l = 0; l < m.nl; l++) {
       if (!w->gru_gate_kernel[l] || !w->gru_gate_bias[l] || !w->gru_cand_kernel[l] || !w->gru_cand_bias[l])
         return fail(HIERTCN_ERR_INVALID, "GRU layer %d weights missing", l);
       const int in = (l == 0) ? E : m.H;
-      const int64_t ng = (int64_t)(in + m.H) * 2 * m.H, nc = (int64_t)(in + m.H) * m.H;
-      HIP_TRY(launch_copy_pad_f32(w->gru_gate_kernel[l], m.gru_wg[l], ng, ng, 0.f, st));
+      HIP_TRY(launch_transpose_f32(w->gru_gate_kernel[l], m.gru_wg[l], in + m.H, 2 * m.H, st));
       HIP_TRY(launch_copy_pad_f32(w->gru_gate_bias[l], m.gru_bg[l], 2 * m.H, 2 * m.H, 0.f, st));
-      HIP_TRY(launch_copy_pad_f32(w->gru_cand_kernel[l], m.gru_wc[l], nc, nc, 0.f, st));
+      HIP_TRY(launch_transpose_f32(w->gru_cand_kernel[l], m.gru_wc[l], in + m.H, m.H, st));
       HIP_TRY(launch_copy_pad_f32(w->gru_cand_bias[l], m.gru_bc[l], m.H, m.H, 0.f, st));
     }
   }

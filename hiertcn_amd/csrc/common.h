@@ -49,19 +49,20 @@ struct ModelDev {
   uint16_t* outT;       // [NP][Clast], rows >= N zero
   // fp32 tensors
   float* emb_bias;      // [E]
-  float* projS;         // [HT][E]  = Wp[E:]                               (hier only)
+  float* projS;         // [E][HT]  = transpose(Wp[E:]), fp32                  (hier only)
   float* conv_bias[HIERTCN_MAX_BLOCKS];
   float* res_bias[HIERTCN_MAX_BLOCKS];
   float* out_bias;      // [NP], entries >= N are -inf
-  float* gru_wg[HIERTCN_MAX_LAYERS];
+  float* gru_wg[HIERTCN_MAX_LAYERS];  // [2H][in+H]  (transposed: output-major)
   float* gru_bg[HIERTCN_MAX_LAYERS];
-  float* gru_wc[HIERTCN_MAX_LAYERS];
+  float* gru_wc[HIERTCN_MAX_LAYERS];  // [H][in+H]
   float* gru_bc[HIERTCN_MAX_LAYERS];
 };
 
 // launchers implemented in the kernel files (all asynchronous on `st`)
 hipError_t launch_rows_to_bf16(const float* src, uint16_t* dst, int64_t rows, int cols, int zero_row0, hipStream_t st);
 hipError_t launch_transpose_to_bf16(const float* src, uint16_t* dst, int64_t rows, int64_t cols, int64_t dst_rows_padded, hipStream_t st);
+hipError_t launch_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, hipStream_t st);
 hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t npad, float padval, hipStream_t st);
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,

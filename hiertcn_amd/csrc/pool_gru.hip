@@ -68,54 +68,113 @@ hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_se
 }
 
 // ---------------------------------------------------------------------------------------------
-// GRU scan.  One workgroup owns UB lanes (users) and walks their S slots; the carried state, the
-// slot input and the gate activations live in LDS; weights stream from L2 (every workgroup reads
-// the same ~3.5 MB).  Thread j owns output column j of each small GEMM, so weight reads are
-// coalesced along the output dimension and activations are LDS broadcasts.
+// GRU scan.  One workgroup owns UB = 8 lanes (users) and walks their S slots; the carried state,
+// the concatenated cell input [in | h] and the gate activations live in LDS.  Weights are stored
+// TRANSPOSED ([out][in], set_weights) and stream from L2: a wave computes a block of 8 output
+// columns x 8 users with its 64 lanes spread along the REDUCTION axis, so every weight load is a
+// fully coalesced 1 KiB wave access and activations are conflict-free LDS reads; the 64 partial
+// sums per lane are then folded across the wavefront with v_permlane32_swap and
+// five xor-shuffle steps, leaving exactly one (user, column) total on each lane, where the
+// gate non-linearity is applied.
 // ---------------------------------------------------------------------------------------------
 #define GRU_UB 8
-#define GRU_THREADS 256
+#define GRU_THREADS 512
+#define GRU_WAVES (GRU_THREADS / 64)
 
-// acc[u] += sum_k x[u][k] * W[k][col]   for k in [0,K), x rows `xs` floats apart in LDS.
-__device__ __forceinline__ void gemv_cols(float (&acc)[GRU_UB], const float* __restrict__ x, int xs, const float* __restrict__ W,
-                                          int ldw, int col, int K) {
-  for (int k = 0; k < K; k += 4) {
-    const float w0 = W[(int64_t)(k + 0) * ldw + col];
-    const float w1 = W[(int64_t)(k + 1) * ldw + col];
-    const float w2 = W[(int64_t)(k + 2) * ldw + col];
-    const float w3 = W[(int64_t)(k + 3) * ldw + col];
+__device__ __forceinline__ float swap_add32(float a, float b) {
+  // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) mis-lowers `r[0] + r[1]` of the builtin's
+  // two results to `r[0] + r[0]` once the SLP vectoriser packs neighbouring sums (scripts/fold_test2.hip).
+  // The two v_nop are the VALU-write -> v_permlane-read wait states (cdna_hip_programming.md T21).
+  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+  return a + b;
+}
+
+// Fold 64 per-lane values across the 64 lanes: afterwards every lane holds the wave-wide total of exactly one
+// of the 64 indices.  WHICH index a lane ends up with is a fixed permutation of the lane id that depends only on
+// the exchange pattern; the kernel measures it once (fold_owner) instead of assuming it.
+__device__ __forceinline__ float fold64(float (&p)[64], int lane) {
 #pragma unroll
-    for (int u = 0; u < GRU_UB; u++) {
-      const float4 xv = *reinterpret_cast<const float4*>(x + u * xs + k);
-      acc[u] = fmaf(xv.x, w0, acc[u]);
-      acc[u] = fmaf(xv.y, w1, acc[u]);
-      acc[u] = fmaf(xv.z, w2, acc[u]);
-      acc[u] = fmaf(xv.w, w3, acc[u]);
+  for (int i = 0; i < 32; i++) p[i] = swap_add32(p[i], p[i + 32]);
+#pragma unroll
+  for (int half = 16; half >= 1; half >>= 1) {
+    const bool hi = (lane & half) != 0;
+#pragma unroll
+    for (int i = 0; i < half; i++) {
+      const float send = hi ? p[i] : p[i + half];
+      const float keep = hi ? p[i + half] : p[i];
+      p[i] = keep + __shfl_xor(send, half);
     }
+  }
+  return p[0];
+}
+__device__ __forceinline__ int fold_owner(int lane) {
+  float p[64];
+#pragma unroll
+  for (int i = 0; i < 64; i++) p[i] = (lane == 0) ? (float)(i + 1) : 0.f;  // only lane 0 contributes: total of index i is i+1
+  return (int)fold64(p, lane) - 1;
+}
+
+// out[u][c] = sum_k x[u][k] * Wt[c][k] for u < 8, c < ncols (ncols % 8 == 0), K % 4 == 0, K <= 256*NK4.
+// x: LDS, rows `xs` floats apart.  epi(u, c, total) runs on the lane that owns index u*8 + (c & 7) (`own`).
+template <int NK4, typename Epi>
+__device__ __forceinline__ void gru_gemm(const float* x, int xs, const float* __restrict__ Wt, int K, int ncols, int wave,
+                                         int lane, int own, Epi epi) {
+  const int nblk = ncols >> 3;
+  for (int cb = wave; cb < nblk; cb += GRU_WAVES) {
+    float p[64];
+#pragma unroll
+    for (int i = 0; i < 64; i++) p[i] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NK4; i++) {
+      const int k = 4 * (lane + 64 * i);
+      if (k < K) {
+        float4 xv[GRU_UB];
+#pragma unroll
+        for (int u = 0; u < GRU_UB; u++) xv[u] = *reinterpret_cast<const float4*>(x + u * xs + k);
+#pragma unroll
+        for (int c = 0; c < 8; c++) {
+          const float4 w = *reinterpret_cast<const float4*>(Wt + (int64_t)(cb * 8 + c) * K + k);
+#pragma unroll
+          for (int u = 0; u < GRU_UB; u++) {
+            float a = p[u * 8 + c];
+            a = fmaf(xv[u].x, w.x, a);
+            a = fmaf(xv[u].y, w.y, a);
+            a = fmaf(xv[u].z, w.z, a);
+            a = fmaf(xv[u].w, w.w, a);
+            p[u * 8 + c] = a;
+          }
+        }
+      }
+    }
+    const float total = fold64(p, lane);
+    epi(own >> 3, cb * 8 + (own & 7), total);
   }
 }
 
 struct GruParams {
-  const float* wg[HIERTCN_MAX_LAYERS];
+  const float* wgT[HIERTCN_MAX_LAYERS];  // [2H][in+H]
   const float* bg[HIERTCN_MAX_LAYERS];
-  const float* wc[HIERTCN_MAX_LAYERS];
+  const float* wcT[HIERTCN_MAX_LAYERS];  // [H][in+H]
   const float* bc[HIERTCN_MAX_LAYERS];
-  const float* projS;  // [HT][E]
-  int E, H, nl, HT;
+  const float* projST;  // [E][HT]
+  int E, H, nl, HT, Kmax;
 };
 
+template <int NK4>
 __global__ __launch_bounds__(GRU_THREADS) void k_gru_scan(GruParams p, const float* __restrict__ pooled,
                                                           const float* __restrict__ mask, const float* __restrict__ state_in,
                                                           int B, int S, float* __restrict__ sproj, float* __restrict__ state_out,
                                                           float* __restrict__ state_before) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int E = p.E, H = p.H, HT = p.HT;
-  float* st = lds;                      // [UB][HT]   carried state
-  float* xin = st + GRU_UB * HT;        // [UB][E]    slot input (pooled embedding)
-  float* gates = xin + GRU_UB * E;      // [UB][2H]   sigmoid(r), sigmoid(u)
-  float* rh = gates + GRU_UB * 2 * H;   // [UB][H]    r * h
+  const int E = p.E, H = p.H, HT = p.HT, Kmax = p.Kmax;
+  float* st = lds;                      // [UB][HT]    carried state
+  float* xcat = st + GRU_UB * HT;       // [UB][Kmax]  [in | h] then [in | r*h]
+  float* gates = xcat + GRU_UB * Kmax;  // [UB][2H]    sigmoid(r), sigmoid(u)
   const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int b0 = blockIdx.x * GRU_UB;
+  const int own = fold_owner(lane);  // which (user, column-in-block) total this lane receives from fold64
 
   for (int i = tid; i < GRU_UB * HT; i += GRU_THREADS) {
     int u = i / HT, k = i % HT;
@@ -124,72 +183,51 @@ __global__ __launch_bounds__(GRU_THREADS) void k_gru_scan(GruParams p, const flo
   __syncthreads();
 
   for (int s = 0; s < S; s++) {
-    // slot input
-    for (int i = tid; i < GRU_UB * E; i += GRU_THREADS) {
-      int u = i / E, k = i % E;
-      xin[i] = (b0 + u < B) ? pooled[((int64_t)(b0 + u) * S + s) * E + k] : 0.f;
-    }
-    // the state this slot's low level sees, and its projection state . Wp[E:]
+    // the state this slot's low level sees, and its projection state . Wp[E:]  (model_hier.py:54-55 -> model_tcn.py:35)
     if (state_before) {
       for (int i = tid; i < GRU_UB * HT; i += GRU_THREADS) {
         int u = i / HT, k = i % HT;
         if (b0 + u < B) state_before[((int64_t)(b0 + u) * S + s) * HT + k] = st[i];
       }
     }
-    for (int col = tid; col < E; col += GRU_THREADS) {
-      float acc[GRU_UB];
-#pragma unroll
-      for (int u = 0; u < GRU_UB; u++) acc[u] = 0.f;
-      gemv_cols(acc, st, HT, p.projS, E, col, HT);
-#pragma unroll
-      for (int u = 0; u < GRU_UB; u++)
-        if (b0 + u < B) sproj[((int64_t)(b0 + u) * S + s) * E + col] = acc[u];
-    }
-    __syncthreads();
+    gru_gemm<NK4>(st, HT, p.projST, HT, E, wave, lane, own, [&](int u, int c, float v) {
+      if (b0 + u < B) sproj[((int64_t)(b0 + u) * S + s) * E + c] = v;
+    });
 
     for (int l = 0; l < p.nl; l++) {
-      const float* in = (l == 0) ? xin : (st + (l - 1) * H);
-      const int in_s = (l == 0) ? E : HT;
       const int in_dim = (l == 0) ? E : H;
+      const int K = in_dim + H;
       float* hl = st + l * H;  // rows HT apart
+      // xcat = [in | h_l]
+      for (int i = tid; i < GRU_UB * K; i += GRU_THREADS) {
+        const int u = i / K, k = i % K;
+        float v;
+        if (k < in_dim)
+          v = (l == 0) ? ((b0 + u < B) ? pooled[((int64_t)(b0 + u) * S + s) * E + k] : 0.f) : st[u * HT + (l - 1) * H + k];
+        else
+          v = hl[u * HT + (k - in_dim)];
+        xcat[u * Kmax + k] = v;
+      }
+      __syncthreads();
       // gates = sigmoid([in, h] . Wg + bg)      (customed_gru_cell.py:323)
-      for (int col = tid; col < 2 * H; col += GRU_THREADS) {
-        float acc[GRU_UB];
-        const float b = p.bg[l][col];
-#pragma unroll
-        for (int u = 0; u < GRU_UB; u++) acc[u] = b;
-        gemv_cols(acc, in, in_s, p.wg[l], 2 * H, col, in_dim);
-        gemv_cols(acc, hl, HT, p.wg[l] + (int64_t)in_dim * 2 * H, 2 * H, col, H);
-#pragma unroll
-        for (int u = 0; u < GRU_UB; u++) gates[u * 2 * H + col] = 1.0f / (1.0f + expf(-acc[u]));
-      }
+      gru_gemm<NK4>(xcat, Kmax, p.wgT[l], K, 2 * H, wave, lane, own, [&](int u, int c, float v) {
+        gates[u * 2 * H + c] = 1.0f / (1.0f + expf(-(v + p.bg[l][c])));
+      });
       __syncthreads();
-      // r_state = r * h                         (:324-326; r is the FIRST half)
+      // r_state = r * h                         (:324-326; r is the FIRST half), written over the h half of xcat
       for (int i = tid; i < GRU_UB * H; i += GRU_THREADS) {
-        int u = i / H, k = i % H;
-        rh[i] = gates[u * 2 * H + k] * hl[u * HT + k];
+        const int u = i / H, k = i % H;
+        xcat[u * Kmax + in_dim + k] = gates[u * 2 * H + k] * hl[u * HT + k];
       }
       __syncthreads();
-      // c = tanh([in, r*h] . Wc + bc) ; h' = u*h + (1-u)*c      (:335-336)
-      for (int col = tid; col < H; col += GRU_THREADS) {
-        float acc[GRU_UB];
-        const float b = p.bc[l][col];
-#pragma unroll
-        for (int u = 0; u < GRU_UB; u++) acc[u] = b;
-        gemv_cols(acc, in, in_s, p.wc[l], H, col, in_dim);
-        gemv_cols(acc, rh, H, p.wc[l] + (int64_t)in_dim * H, H, col, H);
-#pragma unroll
-        for (int u = 0; u < GRU_UB; u++) {
-          const float c = tanhf(acc[u]);
-          const float ug = gates[u * 2 * H + H + col];
-          const float hold = hl[u * HT + col];
-          acc[u] = ug * hold + (1.0f - ug) * c;
-        }
-        // nobody else reads st[., l*H + col] in this phase (the GEMMs above read `in` and `rh`),
-        // so the new h can be committed in place; it is layer l+1's input (:1069).
-#pragma unroll
-        for (int u = 0; u < GRU_UB; u++) hl[u * HT + col] = acc[u];
-      }
+      // c = tanh([in, r*h] . Wc + bc) ; h' = u*h + (1-u)*c      (:335-336).  Only the owning lane touches
+      // st[u][l*H + c] in this phase (the GEMM reads xcat), so h' is committed in place; it is layer l+1's input.
+      gru_gemm<NK4>(xcat, Kmax, p.wcT[l], K, H, wave, lane, own, [&](int u, int c, float v) {
+        const float cand = tanhf(v + p.bc[l][c]);
+        const float ug = gates[u * 2 * H + H + c];
+        const float hold = hl[u * HT + c];
+        hl[u * HT + c] = ug * hold + (1.0f - ug) * cand;
+      });
       __syncthreads();
     }
     // state *= mask[i]                          (model_hier.py:93)
@@ -211,14 +249,29 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
   if (B <= 0) return hipSuccess;
   GruParams p;
   for (int l = 0; l < HIERTCN_MAX_LAYERS; l++) {
-    p.wg[l] = m.gru_wg[l]; p.bg[l] = m.gru_bg[l]; p.wc[l] = m.gru_wc[l]; p.bc[l] = m.gru_bc[l];
+    p.wgT[l] = m.gru_wg[l]; p.bg[l] = m.gru_bg[l]; p.wcT[l] = m.gru_wc[l]; p.bc[l] = m.gru_bc[l];
   }
-  p.projS = m.projS; p.E = m.E; p.H = m.H; p.nl = m.nl; p.HT = m.HT;
-  size_t lds = sizeof(float) * GRU_UB * (size_t)(m.HT + m.E + 2 * m.H + m.H);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
+  p.projST = m.projS; p.E = m.E; p.H = m.H; p.nl = m.nl; p.HT = m.HT;
+  int kmax = (m.E > m.H ? m.E : m.H) + m.H;
+  if (m.HT > kmax) kmax = m.HT;
+  p.Kmax = kmax;
+  const int nk4 = (kmax / 4 + 63) / 64;
+  size_t lds = sizeof(float) * GRU_UB * (size_t)(m.HT + kmax + 2 * m.H);
   unsigned blocks = (unsigned)((B + GRU_UB - 1) / GRU_UB);
-  hipLaunchKernelGGL(k_gru_scan, dim3(blocks), dim3(GRU_THREADS), lds, st, p, pooled, mask, state_in, B, S, sproj, state_out,
-                     state_before);
+#define GRU_LAUNCH(NK)                                                                                                         \
+  do {                                                                                                                         \
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
+    if (e != hipSuccess) return e;                                                                                             \
+    hipLaunchKernelGGL(k_gru_scan<NK>, dim3(blocks), dim3(GRU_THREADS), lds, st, p, pooled, mask, state_in, B, S, sproj, state_out, \
+                       state_before);                                                                                          \
+  } while (0)
+  switch (nk4) {
+    case 1: GRU_LAUNCH(1); break;
+    case 2: GRU_LAUNCH(2); break;
+    case 3: GRU_LAUNCH(3); break;
+    case 4: GRU_LAUNCH(4); break;
+    default: return hipErrorInvalidValue;
+  }
+#undef GRU_LAUNCH
   return hipGetLastError();
 }

@@ -76,3 +76,25 @@ hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t 
   hipLaunchKernelGGL(k_copy_pad_f32, dim3(blocks), dim3(256), 0, st, src, dst, n, npad, padval);
   return hipGetLastError();
 }
+
+// src [rows][cols] fp32 -> dst [cols][rows] fp32 (GRU-side weights: [in][out] -> [out][in])
+__global__ void k_transpose_f32(const float* __restrict__ src, float* __restrict__ dst, int64_t rows, int64_t cols) {
+  __shared__ float tile[32][33];
+  const int64_t c0 = (int64_t)blockIdx.x * 32, r0 = (int64_t)blockIdx.y * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  for (int i = ty; i < 32; i += 8) {
+    int64_t r = r0 + i, c = c0 + tx;
+    tile[i][tx] = (r < rows && c < cols) ? src[r * cols + c] : 0.f;
+  }
+  __syncthreads();
+  for (int i = ty; i < 32; i += 8) {
+    int64_t c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst[c * rows + r] = tile[tx][i];
+  }
+}
+
+hipError_t launch_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, hipStream_t st) {
+  dim3 grid((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32));
+  hipLaunchKernelGGL(k_transpose_f32, grid, dim3(256), 0, st, src, dst, rows, cols);
+  return hipGetLastError();
+}

@@ -32,6 +32,16 @@ struct ScGeom {
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
+// diagnostic cycle stamp (separate STAMP build only; cdna_hip_programming.md 7 'In-kernel stamps')
+__device__ __forceinline__ unsigned long long stamp() {
+  unsigned long long t;
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  __builtin_amdgcn_sched_barrier(0);
+  return t;
+}
+#define SC_NSTAMP 8
+
 struct RowState {
   float t;    // target logit
   float m2;   // reference point of the running softmax sum, in log2 units (>= max logit * log2(e) - SC_DEFER)
@@ -41,7 +51,20 @@ struct RowState {
 
 #define SC_DEFER 8.0f  // rescale only when a logit exceeds the reference by 2^8 (T13): exact in fp32, rarely taken
 
+// MODE: 0 = full (production); 1 = rank only; 2 = no epilogue (accumulators kept alive).  Modes 1/2 exist for
+// the ablation runs recorded in profiles/ (HIERTCN_SCORE_VARIANT); they produce wrong loss values by design.
+template <int MODE>
 __device__ __forceinline__ void epilogue(const f32x16& v, RowState& st) {
+  if (MODE == 2) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) asm volatile("" ::"v"(v[i]));
+    return;
+  }
+  if (MODE == 1) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) st.cnt += (v[i] > st.t) ? 1 : 0;
+    return;
+  }
   float x[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) x[i] = fmaf(v[i], LOG2E_F, -st.m2);  // fma results are canonical: no v_max canonicalisation below
@@ -54,19 +77,32 @@ __device__ __forceinline__ void epilogue(const f32x16& v, RowState& st) {
 #pragma unroll
     for (int i = 0; i < 16; i++) x[i] -= d;
   }
+  // four independent partial sums / counters: a single accumulation chain is latency-bound (one wave
+  // issues a dependent VALU op only every ~6.6 cycles instead of 4)
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  int c0 = 0, c1 = 0, c2 = 0, c3 = 0;
 #pragma unroll
-  for (int i = 0; i < 16; i++) {
-    st.cnt += (v[i] > st.t) ? 1 : 0;
-    st.s += __builtin_amdgcn_exp2f(x[i]);
+  for (int i = 0; i < 16; i += 4) {
+    s0 += __builtin_amdgcn_exp2f(x[i]);
+    s1 += __builtin_amdgcn_exp2f(x[i + 1]);
+    s2 += __builtin_amdgcn_exp2f(x[i + 2]);
+    s3 += __builtin_amdgcn_exp2f(x[i + 3]);
+    c0 += (v[i] > st.t) ? 1 : 0;
+    c1 += (v[i + 1] > st.t) ? 1 : 0;
+    c2 += (v[i + 2] > st.t) ? 1 : 0;
+    c3 += (v[i + 3] > st.t) ? 1 : 0;
   }
+  st.s += (s0 + s1) + (s2 + s3);
+  st.cnt += (c0 + c1) + (c2 + c3);
 }
 
-template <int C, bool LOGITS>
+template <int C, bool LOGITS, int MODE, bool STAMP = false>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
                                                          int64_t R, const uint16_t* __restrict__ outT,
                                                          const float* __restrict__ out_bias, int N, int NP,
                                                          int32_t* __restrict__ o_rank, float* __restrict__ o_ce,
-                                                         float* __restrict__ o_tgt, float* __restrict__ logits) {
+                                                         float* __restrict__ o_tgt, float* __restrict__ logits, int stagger,
+                                                         unsigned long long* __restrict__ stamps = nullptr) {
   using G = ScGeom<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages + 2 x 64 bias floats
   const int tid = threadIdx.x;
@@ -78,7 +114,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
   // stage's second item block past the barrier), so that on every SIMD one wave's MFMA burst runs beside the
   // other's VALU epilogue instead of both bursts colliding after each barrier (MI355X_MICROARCH.md, two waves
   // per SIMD, item 9).
-  const bool late = !LOGITS && wave >= 4;
+  const bool late = !LOGITS && stagger && wave >= 4;
 
   // ---- this wave's 64 steps as the B operand, resident for the whole kernel -------------------
   uint4 hf[2][G::KS];
@@ -186,33 +222,56 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
   stage_issue(0, 0);
   __syncthreads();  // (hipcc drains vmcnt(0) here because an LDS-DMA is in flight)
 
+  unsigned long long tsum[SC_NSTAMP];
+#pragma unroll
+  for (int i = 0; i < SC_NSTAMP; i++) tsum[i] = 0;
+#define STAMP_AT(i)                         \
+  if (STAMP) {                              \
+    const unsigned long long tn_ = stamp(); \
+    tsum[i] += tn_ - tprev;                 \
+    tprev = tn_;                            \
+  }
+  unsigned long long tprev = STAMP ? stamp() : 0;
   for (int stg = 0; stg < n_stages; stg++) {
     const int buf = stg & 1;
     // buf^1 was last read (by MFMA operand / bias reads) before the barrier that ended stage stg-1
     if (stg + 1 < n_stages) stage_issue(stg + 1, buf ^ 1);
+    STAMP_AT(0)
     if (late && stg > 0) {  // deferred epilogue of the previous stage's second item block
-      epilogue(acc0, st[0]);
-      epilogue(acc1, st[1]);
+      epilogue<MODE>(acc0, st[0]);
+      epilogue<MODE>(acc1, st[1]);
     }
+    STAMP_AT(1)
     mfma_tile(buf, 0);
+    STAMP_AT(2)
     if (LOGITS) {
       store_logits(stg, 0);
     } else {
-      epilogue(acc0, st[0]);
-      epilogue(acc1, st[1]);
+      epilogue<MODE>(acc0, st[0]);
+      epilogue<MODE>(acc1, st[1]);
     }
+    STAMP_AT(3)
     mfma_tile(buf, 1);
+    STAMP_AT(4)
     if (LOGITS) {
       store_logits(stg, 1);
     } else if (!late) {
-      epilogue(acc0, st[0]);
-      epilogue(acc1, st[1]);
+      epilogue<MODE>(acc0, st[0]);
+      epilogue<MODE>(acc1, st[1]);
     }
+    STAMP_AT(5)
+    if (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    STAMP_AT(6)
     __syncthreads();
+    STAMP_AT(7)
+  }
+  if (STAMP && lane == 0) {
+#pragma unroll
+    for (int i = 0; i < SC_NSTAMP; i++) stamps[((int64_t)blockIdx.x * 8 + wave) * SC_NSTAMP + i] = tsum[i];
   }
   if (late) {
-    epilogue(acc0, st[0]);
-    epilogue(acc1, st[1]);
+    epilogue<MODE>(acc0, st[0]);
+    epilogue<MODE>(acc1, st[1]);
   }
 
   if (!LOGITS) {
@@ -236,25 +295,290 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
   }
 }
 
+// =============================================================================================
+// Production kernel: software-pipelined.  Inside ONE wave the MFMAs of item tile t+1 are issued
+// between the VALU epilogue instructions of tile t (two accumulator sets), because on gfx950 a
+// wave's own VALU work hides in the ~24 free issue cycles of each 32-cycle MFMA, while two
+// co-resident waves that alternate "all MFMA" and "all VALU" phases mostly time-slice the SIMD
+// (measured: profiles/r1_score_ablation.md).  Three LDS stages of 64 items; the LDS-DMA for stage
+// s+2 is issued one full iteration before its first use; one barrier per stage.
+// =============================================================================================
+struct RowState2 {
+  float t;     // target logit
+  float m2;    // softmax reference in log2 units
+  float s;     // sum of 2^(z*log2(e) - m2)
+  int c;       // count of z > t
+};
+
 template <int C>
-static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
-                                 const hiertcn_score_out_t* out, float* logits, hipStream_t st) {
+__global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
+                                                              int64_t R, const uint16_t* __restrict__ outT,
+                                                              const float* __restrict__ out_bias, int N, int NP,
+                                                              int32_t* __restrict__ o_rank, float* __restrict__ o_ce,
+                                                              float* __restrict__ o_tgt) {
+  using G = ScGeom<C>;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 stages + 3 x 64 bias floats
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * 64;
+
+  uint4 hf[2][G::KS];
+  int myy[2];
+#pragma unroll
+  for (int cbk = 0; cbk < 2; cbk++) {
+    int64_t r = row0 + cbk * 32 + lr;
+    const int64_t rc = (r < R) ? r : (R - 1);
+    int yy = (r >= R) ? 0 : y[rc];
+    myy[cbk] = (yy > 0 && yy < N) ? yy : 0;
+    const uint16_t* hp = hidden + rc * C + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < G::KS; s++) hf[cbk][s] = *reinterpret_cast<const uint4*>(hp + 16 * s);
+  }
+
+  RowState2 st[2];
+#pragma unroll
+  for (int cbk = 0; cbk < 2; cbk++) {  // target logits: same MFMA sequence as the main loop (see file header)
+    f32x16 acc;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) {
+      const int yi = __shfl(myy[cbk], acc_row(reg, lh));
+      acc[reg] = out_bias[yi];
+    }
+    const uint16_t* ap = outT + (int64_t)myy[cbk] * C + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < G::KS; s++) {
+      const uint4 a = *reinterpret_cast<const uint4*>(ap + 16 * s);
+      acc = mfma32(a, hf[cbk][s], acc);
+    }
+    const int dreg = (lr & 3) + 4 * (lr >> 3);
+    float d = acc[0];
+#pragma unroll
+    for (int reg = 1; reg < 16; reg++) d = (dreg == reg) ? acc[reg] : d;
+    const float other = __shfl_xor(d, 32);
+    const float t = (((lr >> 2) & 1) == lh) ? d : other;
+    st[cbk].t = t;
+    st[cbk].m2 = t * LOG2E_F;
+    st[cbk].s = 0.f;
+    st[cbk].c = 0;
+  }
+
+  const int n_stages = NP / SC_STAGE;
+  constexpr int PIECES = G::STAGE_BYTES / 1024;
+  constexpr int PPW = PIECES / 8;
+  constexpr int BIAS_OFF = 3 * G::STAGE_BYTES;
+  // LDS-DMA issued through inline asm: hipcc then neither drains it (vmcnt(0)) in front of the next ds_read -- it
+  // cannot prove that the DMA and the read touch different stages -- nor waits for it at the barrier; the
+  // wait is placed by hand, one full iteration after the issue (cdna_hip_programming.md 5.7 'LDS-DMA recipe').
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  auto glds16 = [&](const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+  };
+  auto stage_issue = [&](int stg, int buf) {
+#pragma unroll
+    for (int i = 0; i < PPW; i++) {
+      const int piece = wave * PPW + i;
+      const int off = piece * 1024 + lane * 16;
+      const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
+      const uint16_t* src = outT + ((int64_t)stg * SC_STAGE + row) * C + ((slot ^ (row & G::SWZ)) << 3);
+      glds16(src, lds_base + buf * G::STAGE_BYTES + piece * 1024);
+    }
+    if (wave == 0 && lane < SC_STAGE / 4)
+      glds16(out_bias + (int64_t)stg * SC_STAGE + lane * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
+  };
+  const float* sbias = reinterpret_cast<const float*>(smem + BIAS_OFF);
+
+  // per-tile pre-pass of the epilogue: running-reference check on the raw logits (rare rescale, T13)
+  auto pre = [&](const f32x16& v, RowState2& rs) {
+    float tm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+    tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
+    const float xm = fmaf(tm, LOG2E_F, -rs.m2);
+    if (__any(xm > SC_DEFER)) {
+      const float d = fmaxf(xm, 0.f);
+      const float sc = __builtin_amdgcn_exp2f(-d);
+      rs.s *= sc;
+      rs.m2 += d;
+    }
+  };
+  // one value of the epilogue (placed between two MFMAs)
+  // The empty asm statements are ordering anchors: hipcc otherwise hoists these (pure) VALU ops out from between
+  // the MFMAs, where they are free, into one block of their own, where they are not.
+  auto one = [&](float v, RowState2& rs) {
+    asm volatile("" : "+v"(v));
+    rs.s += __builtin_amdgcn_exp2f(fmaf(v, LOG2E_F, -rs.m2));
+    rs.c += (v > rs.t) ? 1 : 0;
+    asm volatile("" : "+v"(rs.s), "+v"(rs.c));
+  };
+  // LDS byte offset of this lane's A fragment for k-step 0 of item row (ib*32 + lr); k-step s is `^ (s << 5)`:
+  // ((2s + lh) ^ sw) << 4 == ((lh ^ sw) << 4) ^ (s << 5), so one VGPR and one v_xor replace 16 address registers
+  const int a_k0 = lr * (2 * C) + ((lh ^ (lr & G::SWZ)) << 4);
+  auto bias_init = [&](f32x16& a0, int buf, int ib) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + buf * SC_STAGE + ib * 32 + 8 * q + 4 * lh);
+#pragma unroll
+      for (int j = 0; j < 4; j++) a0[4 * q + j] = b4[j];
+    }
+  };
+  // One pipeline step: the 16 MFMAs of (item block ib of stage buffer buf) x (step block CBX) into x, with the
+  // epilogue of the previous tile y (step block CBY) issued between them, one value per MFMA.
+  // Both step blocks re-read the item fragments from LDS (1 ds_read_b128 per MFMA = 128 B/clk/CU, half the
+  // LDS peak) -- the price of needing only two accumulator tiles.
+#define SC_PHASE(x, CBX, y, CBY, buf_, ib_, do_mfma)                                         \
+  do {                                                                                       \
+    pre(y, st[CBY]);                                                                         \
+    if (do_mfma) {                                                                           \
+      const unsigned char* tile_ = smem + (buf_) * G::STAGE_BYTES + (ib_) * 32 * (2 * C);    \
+      uint4 af_[3];                                                                          \
+      af_[0] = *reinterpret_cast<const uint4*>(tile_ + a_k0);                                \
+      af_[1] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ 32));                         \
+      bias_init(x, buf_, ib_);                                                               \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      _Pragma("unroll") for (int s = 0; s < G::KS; s++) {                                    \
+        if (s + 2 < G::KS) af_[(s + 2) % 3] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + 2) << 5))); \
+        x = mfma32(af_[s % 3], hf[CBX][s], x);                                               \
+        one(y[s & 15], st[CBY]);                                                             \
+        __builtin_amdgcn_sched_barrier(0); /* keep exactly this order: hipcc otherwise clusters the MFMAs */ \
+      }                                                                                      \
+      _Pragma("unroll") for (int s = G::KS; s < 16; s++) one(y[s], st[CBY]);                 \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int s = 0; s < 16; s++) one(y[s], st[CBY]);                     \
+    }                                                                                        \
+  } while (0)
+
+  f32x16 accA, accB;
+  stage_issue(0, 0);
+  if (n_stages > 1) stage_issue(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {  // tile (stage 0, ib 0, step block 0) has nothing to overlap with
+    bias_init(accA, 0, 0);
+#pragma unroll
+    for (int s = 0; s < G::KS; s++) {
+      const uint4 a = *reinterpret_cast<const uint4*>(smem + (a_k0 ^ (s << 5)));
+      accA = mfma32(a, hf[0][s], accA);
+    }
+  }
+  int buf = 0;  // stg % 3
+  for (int stg = 0; stg < n_stages; stg++) {
+    const int buf1 = (buf == 2) ? 0 : buf + 1;
+    const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
+    // buf2 held stage stg-1: its last readers finished before the barrier that ended iteration stg-1
+    if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
+    SC_PHASE(accB, 1, accA, 0, buf, 0, true);                   // MFMA (stg, ib0, cb1)   || epilogue (stg, ib0, cb0)
+    SC_PHASE(accA, 0, accB, 1, buf, 1, true);                   // MFMA (stg, ib1, cb0)   || epilogue (stg, ib0, cb1)
+    SC_PHASE(accB, 1, accA, 0, buf, 1, true);                   // MFMA (stg, ib1, cb1)   || epilogue (stg, ib1, cb0)
+    SC_PHASE(accA, 0, accB, 1, buf1, 0, stg + 1 < n_stages);    // MFMA (stg+1, ib0, cb0) || epilogue (stg, ib1, cb1)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage stg+2 (issued a whole iteration ago)
+    __syncthreads();                                   // ... and everyone else's; buf is free again
+    buf = buf1;
+  }
+#undef SC_PHASE
+
+#pragma unroll
+  for (int cbk = 0; cbk < 2; cbk++) {
+    const float s_own = st[cbk].s;
+    const int c_own = st[cbk].c;
+    const int64_t myr = row0 + cbk * 32 + lr;
+    const float m_o = __shfl_xor(st[cbk].m2, 32);
+    const float s_o = __shfl_xor(s_own, 32);
+    const int c_o = __shfl_xor(c_own, 32);
+    const float M2 = fmaxf(st[cbk].m2, m_o);
+    const float S = s_own * __builtin_amdgcn_exp2f(st[cbk].m2 - M2) + s_o * __builtin_amdgcn_exp2f(m_o - M2);
+    const int cnt = c_own + c_o;
+    if (lh == 0 && myr < R) {
+      const bool valid = myy[cbk] > 0;
+      const float lse = (M2 + log2f(S)) * LN2_F;
+      if (o_rank) o_rank[myr] = valid ? cnt : 0;
+      if (o_ce) o_ce[myr] = valid ? (lse - st[cbk].t) : 0.f;
+      if (o_tgt) o_tgt[myr] = valid ? st[cbk].t : 0.f;
+    }
+  }
+}
+
+template <int C>
+static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
+                                    const hiertcn_score_out_t* out, hipStream_t st) {
+  using G = ScGeom<C>;
+  const size_t lds = 3 * G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
+  const unsigned blocks = (unsigned)((R + 511) / 512);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_score_pipe<C>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+                     out->rank, out->ce, out->target);
+  return hipGetLastError();
+}
+
+#include <stdio.h>
+#include <stdlib.h>
+
+#include <vector>
+
+template <int C, bool LOGITS, int MODE>
+static hipError_t launch_score_v(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
+                                 const hiertcn_score_out_t* out, float* logits, int stagger, hipStream_t st) {
   using G = ScGeom<C>;
   const size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
   const unsigned blocks = (unsigned)((R + 511) / 512);
-  hipError_t e;
-  if (logits) {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_score<C, true>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                       (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, logits);
-  } else {
-    e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_score<C, false>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                       out->rank, out->ce, out->target, (float*)nullptr);
-  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<C, LOGITS, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_score<C, LOGITS, MODE>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+                     out ? out->rank : nullptr, out ? out->ce : nullptr, out ? out->target : nullptr, logits, stagger);
   return hipGetLastError();
+}
+
+template <int C>
+static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
+                                 const hiertcn_score_out_t* out, float* logits, hipStream_t st) {
+  if (logits) return launch_score_v<C, true, 0>(m, hidden, y, R, nullptr, logits, 0, st);
+  if (getenv("HIERTCN_SCORE_STAMPS")) {  // diagnostic build: per-phase cycle sums of the first workgroups, printed to stderr
+    using G = ScGeom<C>;
+    const int stagger_d = getenv("HIERTCN_SCORE_VARIANT") && getenv("HIERTCN_SCORE_VARIANT")[1] == '0' ? 0 : 1;
+    const size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
+    const unsigned blocks = (unsigned)((R + 511) / 512);
+    unsigned long long* d = nullptr;
+    const size_t n = (size_t)blocks * 8 * SC_NSTAMP;
+    if (hipMalloc(&d, n * 8) != hipSuccess) return hipErrorOutOfMemory;
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_score<C, false, 0, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipLaunchKernelGGL((k_score<C, false, 0, true>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N,
+                       m.NP, out->rank, out->ce, out->target, (float*)nullptr, stagger_d, d);
+    (void)hipStreamSynchronize(st);
+    std::vector<unsigned long long> hbuf(n);
+    (void)hipMemcpy(hbuf.data(), d, n * 8, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    const char* names[SC_NSTAMP] = {"issue", "defer-epi", "mfma0", "epi0", "mfma1", "epi1", "vmcnt", "barrier"};
+    const double ns = (double)(m.NP / SC_STAGE);
+    for (unsigned b = 0; b < blocks && b < 600; b += 257) {
+      for (int w = 0; w < 8; w++) {
+        fprintf(stderr, "[stamps] wg %u wave %d:", b, w);
+        double tot = 0;
+        for (int i = 0; i < SC_NSTAMP; i++) {
+          const double v = hbuf[((size_t)b * 8 + w) * SC_NSTAMP + i] / ns;
+          tot += v;
+          fprintf(stderr, " %s=%.0f", names[i], v);
+        }
+        fprintf(stderr, " total=%.0f cyc/stage\n", tot);
+      }
+    }
+    return hipGetLastError();
+  }
+  // ablation switch for profiling runs only: "<mode><stagger>", e.g. "20" = no epilogue, no stagger
+  static const char* var = getenv("HIERTCN_SCORE_VARIANT");
+  if (!var || !var[0]) return launch_score_pipe<C>(m, hidden, y, R, out, st);
+  int mode = 0, stagger = 1;
+  if (var && var[0]) {
+    mode = var[0] - '0';
+    if (var[1]) stagger = var[1] - '0';
+  }
+  if (mode == 1) return launch_score_v<C, false, 1>(m, hidden, y, R, out, nullptr, stagger, st);
+  if (mode == 2) return launch_score_v<C, false, 2>(m, hidden, y, R, out, nullptr, stagger, st);
+  return launch_score_v<C, false, 0>(m, hidden, y, R, out, nullptr, stagger, st);
 }
 
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
