@@ -48,8 +48,9 @@ SYMBOLS = {
     "hiertcn_get_config": (C.c_int, [C.c_void_p, C.POINTER(Config)]),
     "hiertcn_set_weights": (C.c_int, [C.c_void_p, C.POINTER(Weights), C.c_void_p]),
     "hiertcn_session_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_gru_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "hiertcn_gru_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
-                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
+                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hiertcn_tcn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hiertcn_score_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ScoreOut), C.c_void_p]),
     "hiertcn_score_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),

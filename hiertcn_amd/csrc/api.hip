@@ -68,9 +68,8 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
   if (cfg->kernel_size < 1 || cfg->kernel_size > 8) return fail(HIERTCN_ERR_INVALID, "kernel_size out of range");
   if (cfg->hier) {
     if (cfg->num_layer < 1 || cfg->num_layer > HIERTCN_MAX_LAYERS) return fail(HIERTCN_ERR_INVALID, "num_layer out of range");
-    if (cfg->hidden_dim < 8 || (cfg->hidden_dim & 7)) return fail(HIERTCN_ERR_INVALID, "hidden_dim must be a positive multiple of 8");
-    if (cfg->hidden_dim * cfg->num_layer > 1024 || cfg->hidden_dim + (E > cfg->hidden_dim ? E : cfg->hidden_dim) > 1024)
-      return fail(HIERTCN_ERR_INVALID, "GRU reduction width above 1024 is not built");
+    if (cfg->hidden_dim < 32 || (cfg->hidden_dim & 31))
+      return fail(HIERTCN_ERR_INVALID, "hidden_dim must be a positive multiple of 32 (one MFMA tile of GRU columns)");
   }
   const int halo = (cfg->kernel_size - 1) * (1 << (cfg->n_blocks - 1));
   const size_t tcn_lds = (size_t)4 * (((halo + 7) & ~7) + 32) * 2 * E;
@@ -202,12 +201,20 @@ int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_ses
   return HIERTCN_OK;
 }
 
+size_t hiertcn_gru_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S) {
+  if (!h || !h->m.hier || B < 0 || S < 0) return 0;
+  return gru_workspace_bytes(h->m, B, S);
+}
+
 int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask, const float* state_in, int32_t B, int32_t S,
-                     float* sproj, float* state_out, float* state_before, void* stream) {
+                     float* sproj, float* state_out, float* state_before, void* workspace, size_t workspace_bytes, void* stream) {
   CHECK_READY(h);
   if (!h->m.hier) return fail(HIERTCN_ERR_STATE, "gru_scan is a model_hier operation");
-  if (!pooled || !mask || !state_in || !sproj || !state_out || B < 0 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, state_before, reinterpret_cast<hipStream_t>(stream)));
+  if (!pooled || !mask || !state_in || !sproj || !state_out || !workspace || B < 0 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (workspace_bytes < gru_workspace_bytes(h->m, B, S)) return fail(HIERTCN_ERR_WORKSPACE, "gru workspace too small");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 15) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 16-byte aligned");
+  HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, state_before, reinterpret_cast<float*>(workspace),
+                          reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
 
@@ -267,7 +274,7 @@ int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, co
 
 // workspace layout of hiertcn_forward_eval (all sub-buffers 256-byte aligned)
 struct EvalWs {
-  size_t pooled, sproj, hidden, rank, ce, total;
+  size_t pooled, sproj, hidden, rank, ce, gru, total;
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
@@ -278,6 +285,7 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
   w.hidden = off; off += al256((size_t)B * S * L * m.Clast * sizeof(uint16_t));
   w.rank = off;   off += al256((size_t)B * S * L * sizeof(int32_t));
   w.ce = off;     off += al256((size_t)B * S * L * sizeof(float));
+  w.gru = off;    off += al256(gru_workspace_bytes(m, (int)B, (int)S));
   w.total = off;
   return w;
 }
@@ -313,7 +321,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   // scan first (it never reads the low level's output: model_hier.py:83-93), then every
   // (user, session) low-level problem is independent.
   HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
-  HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, st));
+  HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
   HIP_TRY(launch_tcn_forward(h->m, x_ids, sproj, n_sessions, L, hidden, st));
   int rc = score_timed(h, hidden, y_ids, R, &so, st);
   if (rc != HIERTCN_OK) return rc;

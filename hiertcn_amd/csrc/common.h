@@ -65,8 +65,9 @@ hipError_t launch_transpose_to_bf16(const float* src, uint16_t* dst, int64_t row
 hipError_t launch_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, hipStream_t st);
 hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t npad, float padval, hipStream_t st);
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
+size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
-                           float* sproj, float* state_out, float* state_before, hipStream_t st);
+                           float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st);
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
                               uint16_t* hidden, hipStream_t st);
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,

@@ -5,6 +5,8 @@
 //
 // Both kernels are fp32 end to end (the recurrence is the only true sequential dependency of
 // the path and < 0.1 % of its FLOPs; rounding the carried state would compound over sessions).
+#include <string.h>
+
 #include "common.h"
 
 // ---------------------------------------------------------------------------------------------
@@ -68,210 +70,193 @@ hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_se
 }
 
 // ---------------------------------------------------------------------------------------------
-// GRU scan.  One workgroup owns UB = 8 lanes (users) and walks their S slots; the carried state,
-// the concatenated cell input [in | h] and the gate activations live in LDS.  Weights are stored
-// TRANSPOSED ([out][in], set_weights) and stream from L2: a wave computes a block of 8 output
-// columns x 8 users with its 64 lanes spread along the REDUCTION axis, so every weight load is a
-// fully coalesced 1 KiB wave access and activations are conflict-free LDS reads; the 64 partial
-// sums per lane are then folded across the wavefront with v_permlane32_swap and
-// five xor-shuffle steps, leaving exactly one (user, column) total on each lane, where the
-// gate non-linearity is applied.
+// GRU scan = a stream of small exact-fp32 MFMA GEMMs, one pair per (slot, layer):
+//     gates GEMM :  sigmoid([in | h] . Wg + bg)            -> gates, r*h
+//     cand  GEMM :  tanh([in | r*h] . Wc + bc), h' = u*h + (1-u)*c -> next layer input, masked next state
+// over ALL lanes of the batch at once (M = B rows), so every launch fills the chip and each weight
+// matrix is read from L2 once per launch instead of once per 8 lanes.  v_mfma_f32_32x32x2_f32 is
+// bit-for-bit an fp32 fma chain (cdna_hip_programming.md 3, 'FP32-input MFMA'), so the carried state
+// stays fp32-exact.  The state of every slot is kept ([B][S+1][HT]) and the state half of the low
+// level's input projection (model_hier.py:54-55 -> model_tcn.py:35) is ONE GEMM over all slots at
+// the end.  Two earlier designs (lanes-per-workgroup with VALU dot products: 7.5 ms; lanes along K
+// with a wavefront shuffle fold: 11.0 ms at cfg-3) are in the git history; this one is launch-
+// latency bound at ~90 launches per batch.
 // ---------------------------------------------------------------------------------------------
-#define GRU_UB 8
-#define GRU_THREADS 512
-#define GRU_WAVES (GRU_THREADS / 64)
+enum { EPI_STORE = 0, EPI_GATES = 1, EPI_CAND = 2 };
 
-__device__ __forceinline__ float swap_add32(float a, float b) {
-  // inline asm, not __builtin_amdgcn_permlane32_swap: hipcc (ROCm 7.2) mis-lowers `r[0] + r[1]` of the builtin's
-  // two results to `r[0] + r[0]` once the SLP vectoriser packs neighbouring sums (scripts/fold_test2.hip).
-  // The two v_nop are the VALU-write -> v_permlane-read wait states (cdna_hip_programming.md T21).
-  asm volatile("v_nop\n\tv_nop\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
-  return a + b;
-}
-
-// Fold 64 per-lane values across the 64 lanes: afterwards every lane holds the wave-wide total of exactly one
-// of the 64 indices.  WHICH index a lane ends up with is a fixed permutation of the lane id that depends only on
-// the exchange pattern; the kernel measures it once (fold_owner) instead of assuming it.
-__device__ __forceinline__ float fold64(float (&p)[64], int lane) {
-#pragma unroll
-  for (int i = 0; i < 32; i++) p[i] = swap_add32(p[i], p[i + 32]);
-#pragma unroll
-  for (int half = 16; half >= 1; half >>= 1) {
-    const bool hi = (lane & half) != 0;
-#pragma unroll
-    for (int i = 0; i < half; i++) {
-      const float send = hi ? p[i] : p[i + half];
-      const float keep = hi ? p[i + half] : p[i];
-      p[i] = keep + __shfl_xor(send, half);
-    }
-  }
-  return p[0];
-}
-__device__ __forceinline__ int fold_owner(int lane) {
-  float p[64];
-#pragma unroll
-  for (int i = 0; i < 64; i++) p[i] = (lane == 0) ? (float)(i + 1) : 0.f;  // only lane 0 contributes: total of index i is i+1
-  return (int)fold64(p, lane) - 1;
-}
-
-// out[u][c] = sum_k x[u][k] * Wt[c][k] for u < 8, c < ncols (ncols % 8 == 0), K % 4 == 0, K <= 256*NK4.
-// x: LDS, rows `xs` floats apart.  epi(u, c, total) runs on the lane that owns index u*8 + (c & 7) (`own`).
-template <int NK4, typename Epi>
-__device__ __forceinline__ void gru_gemm(const float* x, int xs, const float* __restrict__ Wt, int K, int ncols, int wave,
-                                         int lane, int own, Epi epi) {
-  const int nblk = ncols >> 3;
-  for (int cb = wave; cb < nblk; cb += GRU_WAVES) {
-    float p[64];
-#pragma unroll
-    for (int i = 0; i < 64; i++) p[i] = 0.f;
-#pragma unroll
-    for (int i = 0; i < NK4; i++) {
-      const int k = 4 * (lane + 64 * i);
-      if (k < K) {
-        float4 xv[GRU_UB];
-#pragma unroll
-        for (int u = 0; u < GRU_UB; u++) xv[u] = *reinterpret_cast<const float4*>(x + u * xs + k);
-#pragma unroll
-        for (int c = 0; c < 8; c++) {
-          const float4 w = *reinterpret_cast<const float4*>(Wt + (int64_t)(cb * 8 + c) * K + k);
-#pragma unroll
-          for (int u = 0; u < GRU_UB; u++) {
-            float a = p[u * 8 + c];
-            a = fmaf(xv[u].x, w.x, a);
-            a = fmaf(xv[u].y, w.y, a);
-            a = fmaf(xv[u].z, w.z, a);
-            a = fmaf(xv[u].w, w.w, a);
-            p[u * 8 + c] = a;
-          }
-        }
-      }
-    }
-    const float total = fold64(p, lane);
-    epi(own >> 3, cb * 8 + (own & 7), total);
-  }
-}
-
-struct GruParams {
-  const float* wgT[HIERTCN_MAX_LAYERS];  // [2H][in+H]
-  const float* bg[HIERTCN_MAX_LAYERS];
-  const float* wcT[HIERTCN_MAX_LAYERS];  // [H][in+H]
-  const float* bc[HIERTCN_MAX_LAYERS];
-  const float* projST;  // [E][HT]
-  int E, H, nl, HT, Kmax;
+struct GemmArgs {
+  const float* A1; int lda1; int K1;   // activations, first K1 columns
+  const float* A2; int lda2; int K2;   // activations, next K2 columns (may be null when K2 == 0)
+  const float* Wt;                     // [N][K1+K2]  (output-major)
+  const float* bias;                   // [N] or null
+  int M, N;
+  float* out; int ldo;                 // STORE: C ; GATES: gates [M][2H] ; CAND: next layer input [M][H]
+  float* out2; int ldo2;               // GATES: r*h [M][H] ; CAND: masked next-state slice
+  const float* h; int ldh;             // GATES / CAND: the layer's old h slice
+  const float* gates; int ldg;         // CAND
+  const float* mask; int ldm;          // CAND: mask[m * ldm]
+  int H;
+  int rowmap_S;                        // STORE: >0 -> row m = b*(S+1)+s maps to out row b*S+s, s == S skipped
 };
 
-template <int NK4>
-__global__ __launch_bounds__(GRU_THREADS) void k_gru_scan(GruParams p, const float* __restrict__ pooled,
-                                                          const float* __restrict__ mask, const float* __restrict__ state_in,
-                                                          int B, int S, float* __restrict__ sproj, float* __restrict__ state_out,
-                                                          float* __restrict__ state_before) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
-  const int E = p.E, H = p.H, HT = p.HT, Kmax = p.Kmax;
-  float* st = lds;                      // [UB][HT]    carried state
-  float* xcat = st + GRU_UB * HT;       // [UB][Kmax]  [in | h] then [in | r*h]
-  float* gates = xcat + GRU_UB * Kmax;  // [UB][2H]    sigmoid(r), sigmoid(u)
-  const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int b0 = blockIdx.x * GRU_UB;
-  const int own = fold_owner(lane);  // which (user, column-in-block) total this lane receives from fold64
+typedef float f32x16v __attribute__((ext_vector_type(16)));
 
-  for (int i = tid; i < GRU_UB * HT; i += GRU_THREADS) {
-    int u = i / HT, k = i % HT;
-    st[i] = (b0 + u < B) ? state_in[(int64_t)(b0 + u) * HT + k] : 0.f;
+template <int EPI>
+__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int tiles_n = g.N >> 5;
+  const int t = blockIdx.x * 4 + wave;
+  const int tm = t / tiles_n, tn = t - tm * tiles_n;
+  if (tm * 32 >= g.M) return;
+  const int K = g.K1 + g.K2;
+  int mrow = tm * 32 + lr;
+  const bool mvalid = mrow < g.M;
+  if (!mvalid) mrow = g.M - 1;
+  // A operand = weights (rows = output columns n), B operand = activations^T (cols = lanes/users):
+  // D[row = n][col = user]; per 8 k's one float4 per lane on each side, k order (j, half) -> k0 + 4*half + j.
+  const float* wp = g.Wt + (int64_t)(tn * 32 + lr) * K + 4 * lh;
+  const float* x1 = g.A1 + (int64_t)mrow * g.lda1 + 4 * lh;
+  f32x16v acc;
+#pragma unroll
+  for (int i = 0; i < 16; i++) acc[i] = 0.f;
+  const int n1 = g.K1 >> 3;
+#pragma unroll 4
+  for (int i = 0; i < n1; i++) {
+    const float4 a = *reinterpret_cast<const float4*>(wp + 8 * i);
+    const float4 b = *reinterpret_cast<const float4*>(x1 + 8 * i);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
   }
-  __syncthreads();
+  if (g.K2 > 0) {
+    const float* x2 = g.A2 + (int64_t)mrow * g.lda2 + 4 * lh;
+    const float* wp2 = wp + g.K1;
+    const int n2 = g.K2 >> 3;
+#pragma unroll 4
+    for (int i = 0; i < n2; i++) {
+      const float4 a = *reinterpret_cast<const float4*>(wp2 + 8 * i);
+      const float4 b = *reinterpret_cast<const float4*>(x2 + 8 * i);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
+    }
+  }
+  if (!mvalid) return;
+  const int m = tm * 32 + lr;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int n0 = tn * 32 + 8 * q + 4 * lh;  // 4 consecutive output columns
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = acc[4 * q + j] + (g.bias ? g.bias[n0 + j] : 0.f);
+    if (EPI == EPI_STORE) {
+      int64_t orow = m;
+      if (g.rowmap_S > 0) {
+        const int b = m / (g.rowmap_S + 1), sl = m - b * (g.rowmap_S + 1);
+        if (sl == g.rowmap_S) continue;
+        orow = (int64_t)b * g.rowmap_S + sl;
+      }
+      *reinterpret_cast<float4*>(g.out + orow * g.ldo + n0) = make_float4(v[0], v[1], v[2], v[3]);
+    } else if (EPI == EPI_GATES) {
+      float s4[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) s4[j] = 1.0f / (1.0f + expf(-v[j]));  // customed_gru_cell.py:323
+      *reinterpret_cast<float4*>(g.out + (int64_t)m * g.ldo + n0) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+      if (n0 < g.H) {  // r is the FIRST half (:324); r_state = r * h (:326)
+        const float4 hv = *reinterpret_cast<const float4*>(g.h + (int64_t)m * g.ldh + n0);
+        *reinterpret_cast<float4*>(g.out2 + (int64_t)m * g.ldo2 + n0) =
+            make_float4(s4[0] * hv.x, s4[1] * hv.y, s4[2] * hv.z, s4[3] * hv.w);
+      }
+    } else {  // EPI_CAND: c = tanh(.), h' = u*h + (1-u)*c (:335-336); state *= mask (model_hier.py:93)
+      const float4 hv = *reinterpret_cast<const float4*>(g.h + (int64_t)m * g.ldh + n0);
+      const float4 uv = *reinterpret_cast<const float4*>(g.gates + (int64_t)m * g.ldg + g.H + n0);
+      const float mk = g.mask[(int64_t)m * g.ldm];
+      float hn[4];
+      hn[0] = uv.x * hv.x + (1.0f - uv.x) * tanhf(v[0]);
+      hn[1] = uv.y * hv.y + (1.0f - uv.y) * tanhf(v[1]);
+      hn[2] = uv.z * hv.z + (1.0f - uv.z) * tanhf(v[2]);
+      hn[3] = uv.w * hv.w + (1.0f - uv.w) * tanhf(v[3]);
+      *reinterpret_cast<float4*>(g.out + (int64_t)m * g.ldo + n0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      *reinterpret_cast<float4*>(g.out2 + (int64_t)m * g.ldo2 + n0) = make_float4(hn[0] * mk, hn[1] * mk, hn[2] * mk, hn[3] * mk);
+    }
+  }
+}
 
-  for (int s = 0; s < S; s++) {
-    // the state this slot's low level sees, and its projection state . Wp[E:]  (model_hier.py:54-55 -> model_tcn.py:35)
-    if (state_before) {
-      for (int i = tid; i < GRU_UB * HT; i += GRU_THREADS) {
-        int u = i / HT, k = i % HT;
-        if (b0 + u < B) state_before[((int64_t)(b0 + u) * S + s) * HT + k] = st[i];
-      }
-    }
-    gru_gemm<NK4>(st, HT, p.projST, HT, E, wave, lane, own, [&](int u, int c, float v) {
-      if (b0 + u < B) sproj[((int64_t)(b0 + u) * S + s) * E + c] = v;
-    });
+template <int EPI>
+static hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
+  const int tiles = ((g.M + 31) / 32) * (g.N / 32);
+  hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, g);
+  return hipGetLastError();
+}
 
-    for (int l = 0; l < p.nl; l++) {
-      const int in_dim = (l == 0) ? E : H;
-      const int K = in_dim + H;
-      float* hl = st + l * H;  // rows HT apart
-      // xcat = [in | h_l]
-      for (int i = tid; i < GRU_UB * K; i += GRU_THREADS) {
-        const int u = i / K, k = i % K;
-        float v;
-        if (k < in_dim)
-          v = (l == 0) ? ((b0 + u < B) ? pooled[((int64_t)(b0 + u) * S + s) * E + k] : 0.f) : st[u * HT + (l - 1) * H + k];
-        else
-          v = hl[u * HT + (k - in_dim)];
-        xcat[u * Kmax + k] = v;
-      }
-      __syncthreads();
-      // gates = sigmoid([in, h] . Wg + bg)      (customed_gru_cell.py:323)
-      gru_gemm<NK4>(xcat, Kmax, p.wgT[l], K, 2 * H, wave, lane, own, [&](int u, int c, float v) {
-        gates[u * 2 * H + c] = 1.0f / (1.0f + expf(-(v + p.bg[l][c])));
-      });
-      __syncthreads();
-      // r_state = r * h                         (:324-326; r is the FIRST half), written over the h half of xcat
-      for (int i = tid; i < GRU_UB * H; i += GRU_THREADS) {
-        const int u = i / H, k = i % H;
-        xcat[u * Kmax + in_dim + k] = gates[u * 2 * H + k] * hl[u * HT + k];
-      }
-      __syncthreads();
-      // c = tanh([in, r*h] . Wc + bc) ; h' = u*h + (1-u)*c      (:335-336).  Only the owning lane touches
-      // st[u][l*H + c] in this phase (the GEMM reads xcat), so h' is committed in place; it is layer l+1's input.
-      gru_gemm<NK4>(xcat, Kmax, p.wcT[l], K, H, wave, lane, own, [&](int u, int c, float v) {
-        const float cand = tanhf(v + p.bc[l][c]);
-        const float ug = gates[u * 2 * H + H + c];
-        const float hold = hl[u * HT + c];
-        hl[u * HT + c] = ug * hold + (1.0f - ug) * cand;
-      });
-      __syncthreads();
-    }
-    // state *= mask[i]                          (model_hier.py:93)
-    for (int i = tid; i < GRU_UB * HT; i += GRU_THREADS) {
-      int u = i / HT;
-      const float mk = (b0 + u < B) ? mask[(int64_t)(b0 + u) * S + s] : 0.f;
-      st[i] *= mk;
-    }
-    __syncthreads();
-  }
-  for (int i = tid; i < GRU_UB * HT; i += GRU_THREADS) {
-    int u = i / HT, k = i % HT;
-    if (b0 + u < B) state_out[(int64_t)(b0 + u) * HT + k] = st[i];
-  }
+__global__ void k_state_rows(const float* __restrict__ src, int64_t src_stride, float* __restrict__ dst, int64_t dst_stride,
+                             int rows, int cols) {
+  // dst[r][c] = src[r][c] for row strides that differ (state_in -> history slot 0, history -> state_out / state_before)
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)rows * cols) return;
+  const int64_t r = i / cols, c = i - r * cols;
+  dst[r * dst_stride + c] = src[r * src_stride + c];
+}
+static hipError_t copy_rows(const float* src, int64_t ss, float* dst, int64_t ds, int rows, int cols, hipStream_t st) {
+  const int64_t n = (int64_t)rows * cols;
+  hipLaunchKernelGGL(k_state_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, ss, dst, ds, rows, cols);
+  return hipGetLastError();
+}
+
+size_t gru_workspace_bytes(const ModelDev& m, int B, int S) {
+  // history [B][S+1][HT] + gates [B][2H] + rh [B][H] + per-layer unmasked outputs [nl][B][H]
+  return sizeof(float) * ((size_t)B * (S + 1) * m.HT + (size_t)B * 2 * m.H + (size_t)B * m.H + (size_t)m.nl * B * m.H);
 }
 
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
-                           float* sproj, float* state_out, float* state_before, hipStream_t st) {
+                           float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st) {
   if (B <= 0) return hipSuccess;
-  GruParams p;
-  for (int l = 0; l < HIERTCN_MAX_LAYERS; l++) {
-    p.wgT[l] = m.gru_wg[l]; p.bg[l] = m.gru_bg[l]; p.wcT[l] = m.gru_wc[l]; p.bc[l] = m.gru_bc[l];
+  const int E = m.E, H = m.H, HT = m.HT;
+  float* hist = ws;                                  // [B][S+1][HT]
+  float* gates = hist + (size_t)B * (S + 1) * HT;    // [B][2H]
+  float* rh = gates + (size_t)B * 2 * H;             // [B][H]
+  float* hcur = rh + (size_t)B * H;                  // [nl][B][H]
+  const int64_t hs = (int64_t)(S + 1) * HT;          // row stride of the history
+  hipError_t e = copy_rows(state_in, HT, hist, hs, B, HT, st);
+  if (e != hipSuccess) return e;
+  for (int s = 0; s < S; s++) {
+    for (int l = 0; l < m.nl; l++) {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      const float* in = (l == 0) ? pooled + (size_t)s * E : hcur + (size_t)(l - 1) * B * H;
+      const int ldin = (l == 0) ? S * E : H;
+      const int in_dim = (l == 0) ? E : H;
+      const float* hold = hist + (size_t)s * HT + (size_t)l * H;
+      g.M = B; g.H = H;
+      g.A1 = in; g.lda1 = ldin; g.K1 = in_dim;
+      g.A2 = hold; g.lda2 = (int)hs; g.K2 = H;
+      g.Wt = m.gru_wg[l]; g.bias = m.gru_bg[l]; g.N = 2 * H;
+      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = (int)hs;
+      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
+      g.A2 = rh; g.lda2 = H;
+      g.Wt = m.gru_wc[l]; g.bias = m.gru_bc[l]; g.N = H;
+      g.out = hcur + (size_t)l * B * H; g.ldo = H;
+      g.out2 = hist + (size_t)(s + 1) * HT + (size_t)l * H; g.ldo2 = (int)hs;
+      g.gates = gates; g.ldg = 2 * H;
+      g.mask = mask + s; g.ldm = S;
+      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    }
   }
-  p.projST = m.projS; p.E = m.E; p.H = m.H; p.nl = m.nl; p.HT = m.HT;
-  int kmax = (m.E > m.H ? m.E : m.H) + m.H;
-  if (m.HT > kmax) kmax = m.HT;
-  p.Kmax = kmax;
-  const int nk4 = (kmax / 4 + 63) / 64;
-  size_t lds = sizeof(float) * GRU_UB * (size_t)(m.HT + kmax + 2 * m.H);
-  unsigned blocks = (unsigned)((B + GRU_UB - 1) / GRU_UB);
-#define GRU_LAUNCH(NK)                                                                                                         \
-  do {                                                                                                                         \
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_scan<NK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds); \
-    if (e != hipSuccess) return e;                                                                                             \
-    hipLaunchKernelGGL(k_gru_scan<NK>, dim3(blocks), dim3(GRU_THREADS), lds, st, p, pooled, mask, state_in, B, S, sproj, state_out, \
-                       state_before);                                                                                          \
-  } while (0)
-  switch (nk4) {
-    case 1: GRU_LAUNCH(1); break;
-    case 2: GRU_LAUNCH(2); break;
-    case 3: GRU_LAUNCH(3); break;
-    case 4: GRU_LAUNCH(4); break;
-    default: return hipErrorInvalidValue;
+  {  // state half of the input projection for every slot at once: [B*(S+1), HT] x [HT, E]
+    GemmArgs g;
+    memset(&g, 0, sizeof(g));
+    g.M = B * (S + 1); g.N = E; g.A1 = hist; g.lda1 = HT; g.K1 = HT; g.K2 = 0;
+    g.Wt = m.projS; g.bias = nullptr; g.out = sproj; g.ldo = E; g.rowmap_S = S;
+    if ((e = launch_gemm<EPI_STORE>(g, st)) != hipSuccess) return e;
   }
-#undef GRU_LAUNCH
-  return hipGetLastError();
+  if ((e = copy_rows(hist + (size_t)S * HT, hs, state_out, HT, B, HT, st)) != hipSuccess) return e;
+  if (state_before) {
+    for (int s = 0; s < S; s++)
+      if ((e = copy_rows(hist + (size_t)s * HT, hs, state_before + (size_t)s * HT, (int64_t)S * HT, B, HT, st)) != hipSuccess) return e;
+  }
+  return hipSuccess;
 }

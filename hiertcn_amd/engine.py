@@ -75,6 +75,7 @@ class Engine:
         with torch.cuda.device(self.device):
             check(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
         self._ws: Optional[torch.Tensor] = None
+        self._gru_ws: Optional[torch.Tensor] = None
         self._weights_set = False
 
     # ---------------------------------------------------------------------------------------
@@ -165,8 +166,11 @@ class Engine:
         sproj = torch.empty((B, S, self.E), dtype=torch.float32, device=self.device)
         state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
         sb = torch.empty((B, S, self.HT), dtype=torch.float32, device=self.device) if want_state_before else None
+        need = int(self.lib.hiertcn_gru_workspace_bytes(self._h, B, S))
+        if self._gru_ws is None or self._gru_ws.numel() < need:
+            self._gru_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         check(self.lib.hiertcn_gru_scan(self._h, _ptr(pooled), _ptr(mask), _ptr(state_in), B, S, _ptr(sproj),
-                                        _ptr(state_out), _ptr(sb), self._stream()))
+                                        _ptr(state_out), _ptr(sb), _ptr(self._gru_ws), self._gru_ws.numel(), self._stream()))
         return sproj, state_out, sb
 
     def tcn_forward(self, x_ids: torch.Tensor, sproj: Optional[torch.Tensor]) -> torch.Tensor:

@@ -129,10 +129,12 @@ int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_ses
  * state.Wp[E:]).  pooled [B][S][E], mask [B][S], state_in [B][H*nl] ->
  *   sproj        [B][S][E]     state_before_slot_s . Wp[E:]        (consumed by hiertcn_tcn_forward)
  *   state_out    [B][H*nl]     state after the last slot
- *   state_before [B][S][H*nl]  optional (NULL): the state each slot's low level saw */
+ *   state_before [B][S][H*nl]  optional (NULL): the state each slot's low level saw
+ *   workspace    hiertcn_gru_workspace_bytes(h, B, S) bytes of scratch, 256-byte aligned (state history) */
+size_t hiertcn_gru_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S);
 int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask, const float* state_in,
                      int32_t B, int32_t S, float* sproj, float* state_out, float* state_before,
-                     void* stream);
+                     void* workspace, size_t workspace_bytes, void* stream);
 
 /* model.py:59-61 + model_hier.py:50 + model_tcn.py:35-36: ids -> last TCN activations.
  * x_ids [n_sessions][L]; sproj [n_sessions][E] or NULL (single-level) ->
