@@ -1,0 +1,215 @@
+"""Batch packers for the XING path: the loader protocol the run loops consume
+(`get_batch()`, `.done`, `.viewer_table`; run_hier_xing.py:114-115,177) plus a packed form that
+feeds the HIP path directly.
+
+Stands where /root/reference/data_loader.py stands:
+  Dataloader_single_level_model_xing  :31-106   pad each user's whole history to the batch max
+  Dataloader_hier_model_xing          :115-272  B lane queues of sessions, S slots per batch
+and reproduces their batches bit for bit (tests/test_data_loader.py against fixtures captured
+from the reference loader).  The organisation is different: every user is cut into sessions ONCE,
+up front, with array passes (session boundaries, truncation to max_activity_len, last-session
+mask); a lane queue then holds session *numbers*, not Python lists of events, and a batch is
+assembled by fancy indexing.  `get_packed_batch()` emits ids [B][S][Lmax] int32 + mask [B][S]
+(the layout of include/hiertcn.h) without building the float64 per-slot arrays at all.
+"""
+from __future__ import annotations
+
+from collections import deque
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .data_prepare import load_xing
+
+DATA_PATH = "dataset/interactions.csv"  # data_loader.py:54,140 (relative to the working directory)
+
+
+def _split(viewer_table: np.ndarray, split: str) -> np.ndarray:
+    """data_loader.py:55-60,141-146: first 80 % of the users train, next 10 % validate, last 10 % test."""
+    n = viewer_table.shape[0]
+    if split == "train":
+        return viewer_table[0:int(n * 0.8), :]
+    if split == "validate":
+        return viewer_table[int(n * 0.8):int(n * 0.9), :]
+    if split == "test":
+        return viewer_table[int(n * 0.9):, :]
+    return viewer_table
+
+
+class _UserWalk:
+    """The user order of one pass over a split (data_loader.py:70-75,159-170): arange, or a fresh
+    numpy global-RNG permutation per pass when args.shuffle."""
+
+    def __init__(self, n_users: int, shuffle: bool):
+        self.n, self.shuffle = n_users, shuffle
+        self.refresh()
+
+    def refresh(self):
+        self.index = np.random.permutation(self.n) if self.shuffle else np.arange(self.n)
+        self.index_pointer = 0
+
+
+class Dataloader_single_level_model_xing:
+    """get_batch() -> (x, y, info): x, y float64 [B, T], info [B, T, 5]; T = longest history in the
+    batch; rows past the last user of a short final batch stay zero (data_loader.py:78-106)."""
+
+    def __init__(self, args, type: str = "train", data: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+        self.args = args
+        self.done = False
+        vt, self.viewer_data = data if data is not None else load_xing(DATA_PATH, max_activity=int(args.max_seq_len))
+        self.viewer_table = _split(vt, type)
+        self._ids = self.viewer_data[:, 1].astype(np.int64)
+        self._walk = _UserWalk(self.viewer_table.shape[0], bool(args.shuffle))
+
+    def refresh(self):
+        self._walk.refresh()
+
+    def _rows(self):
+        B = int(self.args.batch_size)
+        w = self._walk
+        users = w.index[w.index_pointer:w.index_pointer + B]
+        start = self.viewer_table[users, 0].astype(np.int64)
+        count = self.viewer_table[users, 1].astype(np.int64)
+        T = int(count.max())
+        t = np.arange(T)[None, :]
+        valid = t < count[:, None]
+        src = np.where(valid, start[:, None] + t, 0)
+        self.done = False
+        w.index_pointer += B
+        if w.index_pointer >= w.index.shape[0]:
+            w.refresh()
+            self.done = True
+        return B, T, valid, src
+
+    def get_batch(self):
+        B, T, valid, src = self._rows()
+        n = valid.shape[0]
+        seq = np.zeros((B, T + 1))
+        seq[:n, 1:] = np.where(valid, self._ids[src], 0)
+        info = np.zeros((B, T, 5))
+        info[:n] = np.where(valid[..., None], self.viewer_data[src], 0.0)
+        return seq[:, :-1], seq[:, 1:], info
+
+    def get_packed_batch(self):
+        """-> x, y int32 [B, T] (the single-level model's placeholders, model.py:42-43)."""
+        B, T, valid, src = self._rows()
+        n = valid.shape[0]
+        y = np.zeros((B, T), np.int32)
+        y[:n] = np.where(valid, self._ids[src], 0)
+        x = np.zeros_like(y)
+        x[:, 1:] = y[:, :-1]
+        return x, y
+
+
+class Dataloader_hier_model_xing:
+    """B lane queues of sessions (data_loader.py:115-272).
+
+    A user's sessions go to the currently shortest lane (first minimum, :203); users keep being
+    enqueued -- at least one per batch -- until every lane holds MORE than S sessions (:229); a
+    batch pops one session per lane for each of the S slots (:233-265).  `done` reports that the
+    user index wrapped while filling (:214-216, :227), not that the queues drained."""
+
+    def __init__(self, args, type: str = "train", data: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+        self.args = args
+        self.done = False
+        vt, self.viewer_data = data if data is not None else load_xing(DATA_PATH, max_activity=int(args.max_seq_len))
+        self.viewer_table = _split(vt, type)
+        self._ids = self.viewer_data[:, 1].astype(np.int64)
+        self._cut_sessions()
+        self._walk = _UserWalk(self.viewer_table.shape[0], bool(args.shuffle))
+        B = int(args.batch_size)
+        self._lanes: List[deque] = [deque() for _ in range(B)]
+        self.queue_len = np.zeros(B)
+
+    # -- one array pass over the event table ------------------------------------------------------
+    def _cut_sessions(self):
+        """Session table: first event row, kept length (truncated to max_activity_len, :198) and
+        mask (1 except a user's last session, :186-187) of every session; a user's sessions are the
+        consecutive entries whose first row lies inside the user's [start, start + count)."""
+        vd = self.viewer_data
+        n = vd.shape[0]
+        boundary = np.ones(n, bool)
+        boundary[1:] = (vd[1:, 4] != vd[:-1, 4]) | (vd[1:, 0] != vd[:-1, 0])
+        begins = np.flatnonzero(boundary)
+        ends = np.append(begins[1:], n)
+        last_of_user = np.ones(begins.shape[0], bool)
+        last_of_user[:-1] = vd[begins[1:], 0] != vd[begins[:-1], 0]
+        self._s_begin = begins
+        self._s_len = np.minimum(ends - begins, int(self.args.max_activity_len))
+        self._s_mask = np.where(last_of_user, 0.0, 1.0)
+        start = self.viewer_table[:, 0].astype(np.int64)
+        count = self.viewer_table[:, 1].astype(np.int64)
+        self._u_first = np.searchsorted(begins, start, side="left")
+        self._u_nsess = np.searchsorted(begins, start + count, side="left") - self._u_first
+
+    def refresh(self, i=None):
+        self._walk.refresh()
+
+    # -- queue mechanics ---------------------------------------------------------------------------
+    def enqueue(self) -> bool:
+        w = self._walk
+        u = int(w.index[w.index_pointer])
+        first, n = int(self._u_first[u]), int(self._u_nsess[u])
+        lane = int(np.argmin(self.queue_len))
+        self._lanes[lane].extend(range(first, first + n))
+        self.queue_len[lane] += n
+        w.index_pointer += 1
+        if w.index_pointer >= w.index.shape[0]:
+            w.refresh()
+            return True
+        return False
+
+    def enqueue_loop(self) -> bool:
+        stop = False
+        while True:
+            stop = self.enqueue() or stop
+            if np.amin(self.queue_len) > int(self.args.max_session_num):
+                return stop
+
+    def _pop_slots(self) -> np.ndarray:
+        """-> session numbers [B, S] of the next batch."""
+        S = int(self.args.max_session_num)
+        out = np.array([[lane.popleft() for _ in range(S)] for lane in self._lanes], dtype=np.int64)
+        self.queue_len -= S
+        return out
+
+    def dequeue(self):
+        """The reference's per-slot float64 arrays (data_loader.py:233-265)."""
+        sess = self._pop_slots()
+        B, S = sess.shape
+        x_out, y_out, mask_out, info_out = [], [], [], []
+        for i in range(S):
+            sid = sess[:, i]
+            L = int(self._s_len[sid].max())
+            t = np.arange(L)[None, :]
+            valid = t < self._s_len[sid][:, None]
+            src = np.where(valid, self._s_begin[sid][:, None] + t, 0)
+            seq = np.zeros((B, L + 1))
+            seq[:, 1:] = np.where(valid, self._ids[src], 0)
+            x_out.append(seq[:, :-1])
+            y_out.append(seq[:, 1:])
+            info_out.append(np.where(valid[..., None], self.viewer_data[src], 0.0))
+            mask_out.append(self._s_mask[sid][:, None].copy())
+        return x_out, y_out, mask_out, info_out
+
+    def get_batch(self):
+        self.done = self.enqueue_loop()
+        return self.dequeue()
+
+    def get_packed_batch(self):
+        """-> x, y int32 [B, S, Lmax], mask float32 [B, S], lens (per-slot max length, i.e. the L_i
+        of the reference's ragged slot arrays; needed only to un-pad `pred`-shaped outputs)."""
+        self.done = self.enqueue_loop()
+        sess = self._pop_slots()
+        slen = self._s_len[sess]                                   # [B, S]
+        Lmax = int(slen.max())
+        t = np.arange(Lmax)[None, None, :]
+        valid = t < slen[..., None]
+        src = np.where(valid, self._s_begin[sess][..., None] + t, 0)
+        y = np.where(valid, self._ids[src], 0).astype(np.int32)
+        x = np.zeros_like(y)
+        x[:, :, 1:] = y[:, :, :-1]
+        slot_len = slen.max(axis=0)                                # the reference's per-slot widths L_i
+        x *= t < slot_len[None, :, None]                           # nothing exists past a slot's own width
+        mask = self._s_mask[sess].astype(np.float32)
+        return x, y, mask, [int(v) for v in slot_len]

@@ -1,0 +1,91 @@
+"""The native ingestion + packers against vectors captured from the REFERENCE's own
+data_prepare.py / data_loader.py (tests/golden/make_loader_fixtures.py): bit-for-bit."""
+import os
+
+import numpy as np
+import pytest
+
+from hiertcn_amd.args import hier_tcn_args
+from hiertcn_amd.data_loader import Dataloader_hier_model_xing, Dataloader_single_level_model_xing
+from hiertcn_amd.data_prepare import load_xing
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSV = os.path.join(HERE, "golden", "interactions_synth.csv")
+
+
+@pytest.fixture(scope="module")
+def fx():
+    return np.load(os.path.join(HERE, "golden", "loader_fixtures.npz"))
+
+
+@pytest.fixture(scope="module")
+def data():
+    return load_xing(CSV)
+
+
+def test_load_xing_matches_reference(fx, data):
+    vt, vd = data
+    assert vd.dtype == np.float64 and vd.shape[1] == 5
+    np.testing.assert_array_equal(vt.astype(np.float64), fx["viewer_table"])
+    np.testing.assert_array_equal(vd, fx["viewer_data"])
+    # the filters of data_prepare.py:21,32,47 did something on this input
+    assert (vd[:, 2] != 4).all() and vt[:, 1].min() >= 10 and vt[:, 1].max() <= 500
+    assert vd[:, 1].min() == 1 and len(np.unique(vd[:, 1])) == int(vd[:, 1].max())
+
+
+@pytest.mark.parametrize("split", ["train", "test"])
+def test_hier_loader_matches_reference(fx, data, split):
+    B, S, max_act, _, n_train, n_test, _ = [int(v) for v in fx["meta"]]
+    args = hier_tcn_args(batch_size=B, max_session_num=S, max_activity_len=max_act)
+    ld = Dataloader_hier_model_xing(args, split, data=data)
+    np.testing.assert_array_equal(ld.viewer_table.astype(np.float64), fx[f"hier_{split}_table"])
+    dones = []
+    for b in range(n_train if split == "train" else n_test):
+        x, y, m, info = ld.get_batch()
+        dones.append(ld.done)
+        assert len(x) == len(y) == len(m) == len(info) == S
+        for s in range(S):
+            for got, key in ((x[s], "x"), (y[s], "y"), (m[s], "m"), (info[s], "i")):
+                want = fx[f"hier_{split}_b{b}_{key}{s}"]
+                assert got.dtype == want.dtype == np.float64 and got.shape == want.shape, (b, s, key)
+                np.testing.assert_array_equal(got, want, err_msg=f"batch {b} slot {s} {key}")
+    np.testing.assert_array_equal(np.array(dones), fx[f"hier_{split}_done"])
+    if split == "test":
+        assert any(dones), "the fixture must cover the wrap-around / done path"
+
+
+def test_packed_batch_equals_slot_lists(fx, data):
+    """get_packed_batch() is the same batch as get_batch(), already in the C-ABI layout."""
+    B, S, max_act = [int(v) for v in fx["meta"][:3]]
+    args = hier_tcn_args(batch_size=B, max_session_num=S, max_activity_len=max_act)
+    a = Dataloader_hier_model_xing(args, "train", data=data)
+    b = Dataloader_hier_model_xing(args, "train", data=data)
+    for _ in range(10):
+        xl, yl, ml, _ = a.get_batch()
+        x, y, mask, lens = b.get_packed_batch()
+        assert a.done == b.done and x.dtype == np.int32 and mask.dtype == np.float32
+        assert lens == [v.shape[1] for v in xl] and x.shape == (B, S, max(lens))
+        for s in range(S):
+            L = lens[s]
+            np.testing.assert_array_equal(x[:, s, :L], xl[s])
+            np.testing.assert_array_equal(y[:, s, :L], yl[s])
+            assert not x[:, s, L:].any() and not y[:, s, L:].any()
+            np.testing.assert_array_equal(mask[:, s:s + 1], ml[s])
+
+
+def test_single_level_loader_matches_reference(fx, data):
+    Bs, n = int(fx["meta"][3]), int(fx["meta"][6])
+    args = hier_tcn_args(batch_size=Bs)
+    ld = Dataloader_single_level_model_xing(args, "train", data=data)
+    ld2 = Dataloader_single_level_model_xing(args, "train", data=data)
+    dones = []
+    for b in range(n):
+        x, y, info = ld.get_batch()
+        dones.append(ld.done)
+        np.testing.assert_array_equal(x, fx[f"single_b{b}_x"])
+        np.testing.assert_array_equal(y, fx[f"single_b{b}_y"])
+        np.testing.assert_array_equal(info, fx[f"single_b{b}_i"])
+        xp, yp = ld2.get_packed_batch()
+        np.testing.assert_array_equal(xp, x.astype(np.int32))
+        np.testing.assert_array_equal(yp, y.astype(np.int32))
+    np.testing.assert_array_equal(np.array(dones), fx["single_done"])
