@@ -101,11 +101,17 @@ class HierTCNModel:
 
     # one sess.run of the evaluation fetch list (run_hier_xing.py:145-149) ------------------------
     def eval_step(self, x_list, y_list, mask_list, state_np, want_pred: bool = False):
-        eng = self.engine
+        """Slot lists as the loader emits them (S arrays [B, L_i]) -> the fetch list."""
         x, y, mask, lens = pack_slots(x_list, y_list, mask_list)
+        return self.eval_step_packed(x, y, mask, lens, state_np, want_pred)
+
+    def eval_step_packed(self, x, y, mask, lens, state_np, want_pred: bool = False):
+        """x, y int32 [B, S, Lmax]; mask float32 [B, S]; lens = the slot widths L_i.  Per-step
+        outputs come back in the reference's concat order [B, sum L_i] (model_hier.py:79)."""
+        eng = self.engine
         B, S, Lmax = x.shape
         dev = eng.device
-        xd, yd, md = (torch.from_numpy(v).to(dev) for v in (x, y, mask))
+        xd, yd, md = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, y, mask))
         st = torch.as_tensor(np.asarray(state_np, dtype=np.float32)).to(dev).contiguous()
         out = eng.forward_eval(xd, yd, md, st, want_rows=True)
         m = metrics_dict(out["metrics8"])
@@ -122,6 +128,11 @@ class HierTCNModel:
             hid = eng.tcn_forward(xd.view(B * S, Lmax), sproj.view(B * S, -1))
             res["pred"] = LazyLogits(eng, hid, B, S, Lmax, lens).materialize().cpu().numpy()
         return res
+
+    def train_step(self, x_list, y_list, mask_list, state_np, lr):
+        """train_op of model.py:139-141 (Adam on every variable).  SURVEY.md 8(f) rank 1: not built."""
+        raise NotImplementedError("the training step (backward + TF-form Adam) is not built yet; "
+                                  "run with args.train = False (the reference's own default, args.py:193)")
 
 
 def get_scope(args, name: str) -> HierTCNModel:

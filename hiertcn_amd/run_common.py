@@ -1,0 +1,82 @@
+"""Pieces shared by the hier and single-level run loops: the epoch accumulator behind
+`results.txt`, the scalar event log that stands in for the TensorBoard FileWriter, and the
+learning-rate schedule.
+
+Reference: run_hier_xing.py:96-106,152-201 / run_nn_xing.py:20-27,50-95 (the six running sums, the
+every-20-batches and final blocks of results.txt), run_hier_xing.py:233-235,311-314 (three
+FileWriters receiving hand-built `loss_epoch`-style scalars), :265-269 (lr / 5 at epochs 60, 120).
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from typing import Dict, Optional
+
+# (key in a step's result dict, tag written to results.txt / the event log)
+SCALARS = (("loss", "loss_epoch"), ("ranks_float_mean_user", "ranks_float_epoch_mean"),
+           ("reciprocal_ranks_float_mean_user", "reciprocal_ranks_float_epoch_mean"),
+           ("recall1_mean_user", "recall1_epoch_mean"), ("recall5_mean_user", "recall5_epoch_mean"),
+           ("recall10_mean_user", "recall10_epoch_mean"))
+
+
+class EpochMeter:
+    """Mean over batches of the per-batch (lane-mean) scalars -- the reference's epoch metric is a
+    mean of means and therefore depends on the batching."""
+
+    def __init__(self, results_path: Optional[str], final_header: bool):
+        self.sums = {k: 0.0 for k, _ in SCALARS}
+        self.batch_count = 0
+        self.results_path = results_path
+        self.final_header = final_header  # evaluate_hier writes a 'final' line (:198), evaluate_nn does not (:91)
+
+    def add(self, step: Dict[str, float]):
+        for k, _ in SCALARS:
+            self.sums[k] += float(step[k])
+        self.batch_count += 1
+        if self.batch_count % 20 == 0:  # :170
+            self._write(self.means(), head="batch count {}:".format(self.batch_count))
+
+    def means(self) -> Dict[str, float]:
+        n = max(self.batch_count, 1)
+        return {tag: self.sums[k] / n for k, tag in SCALARS}
+
+    def finish(self) -> Dict[str, float]:
+        m = self.means()
+        self._write(m, head="final\n" if self.final_header else "")
+        return m
+
+    def _write(self, m: Dict[str, float], head: str):
+        if not self.results_path:
+            return
+        os.makedirs(os.path.dirname(self.results_path), exist_ok=True)
+        t = [tag for _, tag in SCALARS]
+        with open(self.results_path, "a") as f:
+            f.write(head)
+            f.write("{} {}, {} {}\n".format(t[0], m[t[0]], t[1], m[t[1]]))
+            f.write("{} {}, {} {}\n".format(t[2], m[t[2]], t[3], m[t[3]]))
+            f.write("{} {}, {} {}\n".format(t[4], m[t[4]], t[5], m[t[5]]))
+
+
+class ScalarLog:
+    """One directory per split, like tf.summary.FileWriter(args.log_path + 'train/'): scalars are
+    appended to `scalars.jsonl` as {"step", "tag", "value", "wall"}.  Creating it creates the
+    directory, which is what makes `<log_path>/<prefix>/results.txt` writable in the reference."""
+
+    def __init__(self, logdir: str):
+        self.logdir = logdir
+        os.makedirs(logdir, exist_ok=True)
+        self._path = os.path.join(logdir, "scalars.jsonl")
+
+    def add_summary(self, summary: Dict[str, float], step: int):
+        with open(self._path, "a") as f:
+            for tag, value in summary.items():
+                f.write(json.dumps({"step": int(step), "tag": tag, "value": float(value), "wall": time.time()}) + "\n")
+
+
+def scheduled_lr(args, epoch: int):
+    """run_hier_xing.py:265-269 / run_nn_xing.py: divide by 5 when epoch 60 and 120 START
+    (mutates args.learning_rate, as the reference does)."""
+    if args.lr_schedule and epoch in (60, 120):
+        args.learning_rate /= 5
+    return args.learning_rate

@@ -1,0 +1,124 @@
+"""run_hier / evaluate_hier with the reference's control flow (run_hier_xing.py:83-207, 210-350);
+the TF session is replaced by a model handle (hiertcn_amd.model.HierTCNModel or anything with the
+same `eval_step` / `train_step`).
+
+What one evaluation batch does (run_hier_xing.py:112-165): loader.get_batch() -> feed the S slot
+arrays, masks, y_id = concat(y) and the carried state -> fetch loss, state, the five lane-mean
+metrics, ranks_float and mask_y -> accumulate; results.txt every 20 batches and at the end; stop
+when loader.done.  The carried state belongs to the loader it was produced with and survives across
+evaluations and epochs (:241-243,332,343).
+"""
+from __future__ import annotations
+
+import time
+from typing import Sequence
+
+import numpy as np
+
+from .run_common import EpochMeter, ScalarLog, scheduled_lr
+
+
+def ranks_analysis(ranks_float_np, batch_x_list: Sequence, batch_mask_y, ranks_temp, ranks_temp_count):
+    """Per-position-in-session rank profile (run_hier_xing.py:11-31): position `i` of every slot
+    that is at least i+1 wide contributes its column sums.  Vectorised over slots."""
+    widths = np.array([np.shape(x)[1] for x in batch_x_list])
+    first = np.concatenate([[0], np.cumsum(widths)[:-1]])
+    col_rank = np.asarray(ranks_float_np).sum(axis=0)
+    col_cnt = np.asarray(batch_mask_y).sum(axis=0)
+    for w, f in zip(widths, first):
+        ranks_temp[:w] += col_rank[f:f + w]
+        ranks_temp_count[:w] += col_cnt[f:f + w]
+    return ranks_temp, ranks_temp_count
+
+
+def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=None, prefix="test", warm_start=None):
+    """-> (summary, summary_val, time_load, time_run, state_np), the tuple of run_hier_xing.py:207.
+    `sess` is the model handle.  `summary` is a dict tag -> value (the reference builds a
+    tf.Summary with the same tags, :189-196); `summary_val` is the last batch's step dict."""
+    if warm_start if warm_start is not None else getattr(args, "warm_start", False):
+        raise NotImplementedError("warm-start masks (model.py:102-103) are outside the hot path")
+    model = sess
+    time_load = time_run = 0.0
+    meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) else None, final_header=True)
+    ranks_temp = np.zeros(args.max_activity_len + 1)
+    ranks_temp_count = np.zeros(args.max_activity_len + 1)
+    step = None
+    packed = hasattr(loader, "get_packed_batch") and hasattr(model, "eval_step_packed")
+    while True:  # :112
+        t1 = time.time()
+        if packed:   # same batch, already in the C-ABI layout (tests/test_data_loader.py)
+            x, y, mask, widths = loader.get_packed_batch()
+            t2 = time.time()
+            step = model.eval_step_packed(x, y, mask, widths, state_np)
+            slot_shapes = [np.empty((0, w)) for w in widths]
+        else:
+            batch_x_list, batch_y_list, batch_mask_list, _info = loader.get_batch()
+            t2 = time.time()
+            step = model.eval_step(batch_x_list, batch_y_list, batch_mask_list, state_np)
+            slot_shapes = batch_x_list
+        state_np = step["state"]  # :147 -- carried into the next batch
+        meter.add(step)
+        ranks_temp, ranks_temp_count = ranks_analysis(step["ranks_float"], slot_shapes, step["mask_y"], ranks_temp, ranks_temp_count)
+        t3 = time.time()
+        time_load += t2 - t1
+        time_run += t3 - t2
+        if loader.done:  # :177
+            break
+    summary = meter.finish()
+    summary_val = {k: v for k, v in step.items() if np.ndim(v) == 0}
+    summary_val["ranks_by_position"] = ranks_temp / (ranks_temp_count + 1e-6)  # :183
+    return summary, summary_val, time_load, time_run, state_np
+
+
+def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, sess=None):
+    """run_hier_xing.py:210-350.  `sess` = model handle; when None a HierTCNModel is created for
+    `args` (glorot / zeros / gate-bias-1 initialisation, i.e. `sess.run(init)`, :219) and, with
+    args.load, restored from args.load_path (:220-229).  Returns the model handle."""
+    from . import checkpoint
+    from .model import HierTCNModel
+
+    model = sess if sess is not None else HierTCNModel(args)
+    epoch = 0
+    if args.load:  # :220-229
+        fname = args.load_path + str(args.load_epoch) + ".ckpt"
+        try:
+            model.set_parameters(checkpoint.load(fname))
+            print("Model restored: {}".format(fname))
+            epoch = args.load_epoch + 1
+        except Exception:
+            print("No ckpt found: {}, train from scratch".format(fname))
+            epoch = 0
+    train_writer = ScalarLog(args.log_path + "train/")
+    validate_writer = ScalarLog(args.log_path + "validate/")
+    test_writer = ScalarLog(args.log_path + "test/")
+    HT = args.hidden_dim * args.num_layer
+    state_np = np.zeros((args.batch_size, HT))           # :241-243: one carried state per loader
+    state_np_validate = np.zeros((args.batch_size, HT))
+    state_np_test = np.zeros((args.batch_size, HT))
+    while epoch <= args.epoch_max:  # :261
+        if args.train:
+            lr = scheduled_lr(args, epoch)
+            training_loss_epoch = 0.0
+            for _ in range(args.epoch_batches_train):  # :275
+                batch_x_list, batch_y_list, batch_mask_list, _info = loader_train.get_batch()
+                out = model.train_step(batch_x_list, batch_y_list, batch_mask_list, state_np, lr)
+                state_np = out["state"]
+                training_loss_epoch += float(out["loss"])
+            training_loss_epoch /= args.epoch_batches_train
+            train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
+            if args.save and epoch % args.save_epoch == 0 and epoch != 0:  # :317-321
+                fname = args.save_path + str(epoch) + ".ckpt"
+                checkpoint.save(fname, model.params, extra={"state_np": state_np})
+                print("Model saved in path: %s" % fname)
+        if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:  # :324
+            if args.validate:
+                summary, _, _, _, state_np_validate = evaluate_hier(args, loader_validate, state_np_validate, model, prefix="validate")
+                validate_writer.add_summary(summary, epoch)
+            if args.test:
+                summary, _, t_load, t_run, state_np_test = evaluate_hier(args, loader_test, state_np_test, model, prefix="test")
+                test_writer.add_summary(summary, epoch)
+                print("Step {}: test load {:.2f}s, test run {:.2f}s, {}".format(epoch, t_load, t_run, args.name))
+            if not args.train:
+                break  # :349 evaluate once
+        epoch += 1
+    return model

@@ -42,3 +42,21 @@ def make_batch(rng, B, S, L, N, ragged=True, zipf=False):
 def as_lists(x, y, mask):
     S = x.shape[1]
     return [x[:, s] for s in range(S)], [y[:, s] for s in range(S)], [mask[:, s:s + 1] for s in range(S)]
+
+
+class OracleSession:
+    """A model handle for the run loops backed by the CPU oracle (test infrastructure only): the
+    same `eval_step` fetch list as hiertcn_amd.model.HierTCNModel, computed by oracle.model_hier +
+    oracle.masked_loss_and_metrics."""
+
+    def __init__(self, args, params, num=None):
+        self.args, self.params, self.num = args, params, num or O.EXACT64
+
+    def eval_step(self, x_list, y_list, mask_list, state_np):
+        pred, state = O.model_hier(self.args, x_list, y_list, mask_list, np.asarray(state_np, np.float64), self.params, self.num)
+        y_id = np.concatenate([np.asarray(v).astype(np.int64) for v in y_list], axis=1)
+        m = O.masked_loss_and_metrics(pred, y_id, int(self.args.item_num))
+        return dict(loss=float(m["loss"]), state=state, ranks_float_mean_user=float(m["rank_frac"]),
+                    ranks_float=m["ranks_float"], mask_y=(y_id > 0).astype(np.float64),
+                    reciprocal_ranks_float_mean_user=float(m["mrr"]), recall1_mean_user=float(m["recall1"]),
+                    recall5_mean_user=float(m["recall5"]), recall10_mean_user=float(m["recall10"]), ranks=m["ranks"])

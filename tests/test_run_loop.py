@@ -1,0 +1,126 @@
+"""run_hier / evaluate_hier control flow (run_hier_xing.py:83-207,210-350) on the synthetic XING
+CSV, with the CPU oracle as the model handle: batching, state carry, mean-of-means aggregation,
+results.txt text, eval-once-when-not-training."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+from hiertcn_amd import checkpoint
+from hiertcn_amd.args import hier_tcn_args
+from hiertcn_amd.data_loader import Dataloader_hier_model_xing
+from hiertcn_amd.data_prepare import load_xing
+from hiertcn_amd.run_hier_xing import evaluate_hier, ranks_analysis, run_hier
+from oracle import hiertcn_oracle as O
+from tests.gpu_common import OracleSession, make_params
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSV = os.path.join(HERE, "golden", "interactions_synth.csv")
+
+
+@pytest.fixture(scope="module")
+def data():
+    return load_xing(CSV)
+
+
+def _args(tmp_path, data, **kw):
+    n_items = int(data[1][:, 1].max()) + 1
+    a = hier_tcn_args(item_num=n_items, emb_dim=16, hidden_dim=8, num_layer=2, tcn_channel=[16, 16], kernel_size=3,
+                      batch_size=4, max_session_num=3, max_activity_len=6, **kw)
+    a.log_path = str(tmp_path) + "/log/"
+    a.save_path = str(tmp_path) + "/model/"
+    return a
+
+
+def test_evaluate_hier_aggregation_and_results_file(tmp_path, data):
+    args = _args(tmp_path, data)
+    params = make_params(args)
+    sess = OracleSession(args, params)
+    os.makedirs(args.log_path + "test/")
+    ld = Dataloader_hier_model_xing(args, "test", data=data)
+    st0 = np.zeros((4, 16))
+    summary, summary_val, t_load, t_run, st = evaluate_hier(args, ld, st0, sess, prefix="test")
+    # independent replay: same batches through oracle.evaluate_hier
+    ld2 = Dataloader_hier_model_xing(args, "test", data=data)
+    batches = []
+    while True:
+        x, y, m, _ = ld2.get_batch()
+        batches.append((x, y, m))
+        if ld2.done:
+            break
+    ref, per_batch, st_ref = O.evaluate_hier(args, batches, np.zeros((4, 16)), params)
+    assert len(batches) == 5  # the fixture's `done` pattern: wrap in the 5th batch
+    assert summary["loss_epoch"] == pytest.approx(ref["loss"], rel=1e-12)
+    assert summary["recall10_epoch_mean"] == pytest.approx(ref["recall10"], rel=1e-12)
+    assert summary["reciprocal_ranks_float_epoch_mean"] == pytest.approx(ref["mrr"], rel=1e-12)
+    assert summary["ranks_float_epoch_mean"] == pytest.approx(ref["rank_frac"], rel=1e-12)
+    np.testing.assert_allclose(st, st_ref, rtol=0, atol=0)
+    txt = open(args.log_path + "test/results.txt").read().splitlines()
+    assert txt[0] == "final"
+    assert re.fullmatch(r"loss_epoch \S+, ranks_float_epoch_mean \S+", txt[1])
+    assert re.fullmatch(r"reciprocal_ranks_float_epoch_mean \S+, recall1_epoch_mean \S+", txt[2])
+    assert re.fullmatch(r"recall5_epoch_mean \S+, recall10_epoch_mean \S+", txt[3])
+    assert float(txt[1].split()[1].rstrip(",")) == pytest.approx(ref["loss"])
+
+
+def test_results_file_every_20_batches(tmp_path, data):
+    args = _args(tmp_path, data)
+
+    class Loader:  # never-ending stub with the loader protocol; done on the 41st batch
+        def __init__(self):
+            self.inner = Dataloader_hier_model_xing(args, "train", data=data)
+            self.n, self.done, self.viewer_table = 0, False, self.inner.viewer_table
+
+        def get_batch(self):
+            self.n += 1
+            out = self.inner.get_batch()
+            self.done = self.n >= 41
+            return out
+
+    os.makedirs(args.log_path + "validate/")
+    evaluate_hier(args, Loader(), np.zeros((4, 16)), OracleSession(args, make_params(args)), prefix="validate")
+    txt = open(args.log_path + "validate/results.txt").read()
+    assert txt.count("batch count 20:loss_epoch") == 1 and txt.count("batch count 40:loss_epoch") == 1
+    assert txt.count("final\n") == 1
+
+
+def test_ranks_analysis_matches_loop_definition():
+    rng = np.random.default_rng(0)
+    widths = [3, 5, 2]
+    xs = [np.zeros((4, w)) for w in widths]
+    rf = rng.random((4, sum(widths)))
+    mk = (rng.random((4, sum(widths))) > 0.3).astype(float)
+    got, got_n = ranks_analysis(rf, xs, mk, np.zeros(7), np.zeros(7))
+    want, want_n = np.zeros(7), np.zeros(7)
+    first = 0
+    for w in widths:   # run_hier_xing.py:21-30, slot by slot
+        for i in range(w):
+            want[i] += rf[:, first + i].sum()
+            want_n[i] += mk[:, first + i].sum()
+        first += w
+    np.testing.assert_allclose(got, want)
+    np.testing.assert_allclose(got_n, want_n)
+
+
+def test_run_hier_eval_only_runs_once_and_keeps_per_loader_state(tmp_path, data):
+    args = _args(tmp_path, data)
+    args.train, args.validate, args.test = False, True, True
+    sess = OracleSession(args, make_params(args))
+    lv = Dataloader_hier_model_xing(args, "validate", data=data)
+    lt = Dataloader_hier_model_xing(args, "test", data=data)
+    run_hier(args, None, lv, lt, sess=sess)
+    for split in ("validate", "test"):
+        assert open(args.log_path + split + "/results.txt").read().count("final") == 1
+        assert os.path.exists(args.log_path + split + "/scalars.jsonl")
+    assert os.path.isdir(args.log_path + "train/")
+
+
+def test_checkpoint_roundtrip_with_carried_state(tmp_path, data):
+    args = _args(tmp_path, data)
+    p = make_params(args)
+    f = checkpoint.save(args.save_path + "20.ckpt", p, extra={"state_np": np.ones((4, 16))})
+    assert f.endswith("20.ckpt.npz") and os.path.exists(f)
+    q, extra = checkpoint.load(args.save_path + "20.ckpt", with_extra=True)
+    assert set(q) == set(p) and all(np.array_equal(q[k], p[k]) for k in p)
+    assert "hier/multi_rnn_cell/cell_1/gru_cell/gates/kernel" in q and extra["state_np"].shape == (4, 16)
