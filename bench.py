@@ -81,17 +81,16 @@ def main():
     import torch
     import torch.distributed as dist
 
+    from hiertcn_amd.distributed import all_reduce_metrics, init_from_env, max_over_ranks, user_shard
+
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+    rank, world, local_rank = init_from_env("nccl", torch.device("cuda", local_rank))  # "nccl" = RCCL on ROCm
 
     from hiertcn_amd.args import hier_tcn_args
     from hiertcn_amd.engine import Engine, metrics_dict
@@ -106,11 +105,11 @@ def main():
 
     B = a.users_per_step
     n_steps_total = a.warmup + a.steps
-    shard = U_TOTAL // max(world, 1)
+    shard_first, shard = user_shard(U_TOTAL, rank, world)  # this rank's users of the 200k
     draw = zipf_sampler(N_ITEMS)
     batches = []
     for i in range(n_steps_total):
-        first = rank * shard + (i * B) % max(shard - B, 1)
+        first = shard_first + (i * B) % max(shard - B, 1)
         x, y, mask = make_users(draw, first, B, a.ragged)
         batches.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda()))
     state0 = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")  # run_hier_xing.py:241
@@ -123,8 +122,7 @@ def main():
     def step(i):
         xb, yb, mb = batches[i]
         eng.forward_eval(xb, yb, mb, state0, state_out=state_out, metrics8=m8[i])
-        if world > 1:
-            dist.all_reduce(m8[i])  # RCCL: the only collective of the evaluation path (8 doubles)
+        all_reduce_metrics(m8[i])  # RCCL: the only collective of the evaluation path (8 doubles); no-op at N=1
 
     for i in range(a.warmup):
         step(i)
@@ -141,10 +139,7 @@ def main():
         dist.barrier()
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
+    dt = max_over_ranks(dt, "cuda")
     score_ms, launches = eng.timing_read(reset=True)
     eng.timing_enable(False)
 
