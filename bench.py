@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--users-per-step", type=int, default=2048, help="users per step PER GPU")
+    ap.add_argument("--users-per-step", type=int, default=4096, help="users per step PER GPU (4096 users = 4800 workgroups = 18.75 rounds of 256 CUs: 1.3 % tail)")
     ap.add_argument("--ragged", action="store_true", help="session lengths ~ U{1..30} instead of full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")

@@ -308,9 +308,15 @@ struct RowState2 {
   float m2;    // softmax reference in log2 units
   float s;     // sum of 2^(z*log2(e) - m2)
   int c;       // count of z > t
+  float xp, ep, ssave;  // PMODE 5: software-pipeline registers (pending exponent, pending term) and the tile checkpoint of s
 };
 
-template <int C>
+// PMODE (HIERTCN_PIPE_VARIANT): 0 full, reference checked before every tile (v3); 1 count only; 2 no epilogue;
+// 3 softmax sum only; 4 full without the reference check (1-4: ablation builds, wrong outputs by design);
+// 5 full, epilogue software-pipelined across values (the fma / exp / add of one logit sit in three consecutive
+// MFMA gaps, so no VALU op waits on the one before it) and the reference moved only when the running sum
+// overflows (checked once per tile; the tile is then redone from its checkpoint with a new reference).
+template <int C, int PMODE = 0>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
                                                               int64_t R, const uint16_t* __restrict__ outT,
                                                               const float* __restrict__ out_bias, int N, int NP,
@@ -362,6 +368,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     st[cbk].m2 = t * LOG2E_F;
     st[cbk].s = 0.f;
     st[cbk].c = 0;
+    st[cbk].xp = st[cbk].ep = st[cbk].ssave = 0.f;
   }
 
   const int n_stages = NP / SC_STAGE;
@@ -395,7 +402,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   const float* sbias = reinterpret_cast<const float*>(smem + BIAS_OFF);
 
   // per-tile pre-pass of the epilogue: running-reference check on the raw logits (rare rescale, T13)
+  constexpr bool PIPED = PMODE >= 5;
+  constexpr int RING = PMODE == 6 ? 4 : 3;  // LDS fragment ring: a ds_read is issued RING-1 MFMAs ahead of its use
   auto pre = [&](const f32x16& v, RowState2& rs) {
+    if (PMODE == 1 || PMODE == 2 || PMODE == 4) return;
+    if (PIPED) {
+      rs.ssave = rs.s;
+      asm volatile("" : "+v"(rs.ssave));
+      return;
+    }
     float tm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
     tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
     const float xm = fmaf(tm, LOG2E_F, -rs.m2);
@@ -409,10 +424,39 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // one value of the epilogue (placed between two MFMAs)
   // The empty asm statements are ordering anchors: hipcc otherwise hoists these (pure) VALU ops out from between
   // the MFMAs, where they are free, into one block of their own, where they are not.
+  // PMODE 5: value i of a tile.  s += e(i-2); e(i-1) = 2^x(i-1); x(i) = v*log2(e) - m2; c += v > t.
+  auto val5 = [&](int i, float v, RowState2& rs) {
+    const bool gt = v > rs.t;
+    if (i >= 2) rs.s += rs.ep;
+    if (i >= 1) rs.ep = __builtin_amdgcn_exp2f(rs.xp);
+    rs.xp = fmaf(v, LOG2E_F, -rs.m2);
+    rs.c += gt ? 1 : 0;
+    asm volatile("" : "+v"(rs.s), "+v"(rs.c), "+v"(rs.ep), "+v"(rs.xp));
+  };
+  // PMODE 5: end of a tile: drain the two pending values, then the overflow check (wave-uniform branch, rare).
+  auto post5 = [&](const f32x16& v, RowState2& rs) {
+    rs.s += rs.ep;
+    rs.s += __builtin_amdgcn_exp2f(rs.xp);
+    if (__any(!(rs.s < 1.0e38f))) {
+      // redo this tile from the checkpoint with a reference that bounds every term and the carried sum by 1
+      float tm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+      tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
+      const bool bad = !(rs.s < 1.0e38f);
+      float d = fmaxf(ceilf(fmaf(tm, LOG2E_F, -rs.m2)), 0.f);
+      d = fmaxf(d, (float)__builtin_amdgcn_frexp_expf(rs.ssave));   // ssave * 2^-d <= 1 (frexp_exp(0) = 0)
+      d = bad ? d : 0.f;                                             // lanes that did not overflow keep their reference
+      rs.m2 += d;
+      float acc = rs.ssave * __builtin_amdgcn_exp2f(-d);             // exact: d is an integer
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc += __builtin_amdgcn_exp2f(fmaf(v[i], LOG2E_F, -rs.m2));
+      rs.s = acc;
+    }
+  };
   auto one = [&](float v, RowState2& rs) {
     asm volatile("" : "+v"(v));
-    rs.s += __builtin_amdgcn_exp2f(fmaf(v, LOG2E_F, -rs.m2));
-    rs.c += (v > rs.t) ? 1 : 0;
+    if (PMODE == 2) return;
+    if (PMODE != 1) rs.s += __builtin_amdgcn_exp2f(fmaf(v, LOG2E_F, -rs.m2));
+    if (PMODE != 3) rs.c += (v > rs.t) ? 1 : 0;
     asm volatile("" : "+v"(rs.s), "+v"(rs.c));
   };
   // LDS byte offset of this lane's A fragment for k-step 0 of item row (ib*32 + lr); k-step s is `^ (s << 5)`:
@@ -435,21 +479,23 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     pre(y, st[CBY]);                                                                         \
     if (do_mfma) {                                                                           \
       const unsigned char* tile_ = smem + (buf_) * G::STAGE_BYTES + (ib_) * 32 * (2 * C);    \
-      uint4 af_[3];                                                                          \
-      af_[0] = *reinterpret_cast<const uint4*>(tile_ + a_k0);                                \
-      af_[1] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ 32));                         \
+      uint4 af_[RING];                                                                       \
+      _Pragma("unroll") for (int s = 0; s < RING - 1; s++)                                   \
+        af_[s] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ (s << 5)));                 \
       bias_init(x, buf_, ib_);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                     \
       _Pragma("unroll") for (int s = 0; s < G::KS; s++) {                                    \
-        if (s + 2 < G::KS) af_[(s + 2) % 3] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + 2) << 5))); \
-        x = mfma32(af_[s % 3], hf[CBX][s], x);                                               \
-        one(y[s & 15], st[CBY]);                                                             \
+        if (s + RING - 1 < G::KS)                                                            \
+          af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + RING - 1) << 5))); \
+        x = mfma32(af_[s % RING], hf[CBX][s], x);                                            \
+        if (PIPED) val5(s & 15, y[s & 15], st[CBY]); else one(y[s & 15], st[CBY]);           \
         __builtin_amdgcn_sched_barrier(0); /* keep exactly this order: hipcc otherwise clusters the MFMAs */ \
       }                                                                                      \
-      _Pragma("unroll") for (int s = G::KS; s < 16; s++) one(y[s], st[CBY]);                 \
+      _Pragma("unroll") for (int s = G::KS; s < 16; s++) { if (PIPED) val5(s, y[s], st[CBY]); else one(y[s], st[CBY]); } \
     } else {                                                                                 \
-      _Pragma("unroll") for (int s = 0; s < 16; s++) one(y[s], st[CBY]);                     \
+      _Pragma("unroll") for (int s = 0; s < 16; s++) { if (PIPED) val5(s, y[s], st[CBY]); else one(y[s], st[CBY]); } \
     }                                                                                        \
+    if (PIPED) post5(y, st[CBY]);                                                            \
   } while (0)
 
   f32x16 accA, accB;
@@ -486,11 +532,12 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const float s_own = st[cbk].s;
     const int c_own = st[cbk].c;
     const int64_t myr = row0 + cbk * 32 + lr;
-    const float m_o = __shfl_xor(st[cbk].m2, 32);
-    const float s_o = __shfl_xor(s_own, 32);
+    // each half's log2-sum-exp2 first (s may be as large as 1e38 in PMODE 5), then the two-term merge
+    const float l_own = st[cbk].m2 + log2f(s_own);
+    const float l_o = __shfl_xor(l_own, 32);
     const int c_o = __shfl_xor(c_own, 32);
-    const float M2 = fmaxf(st[cbk].m2, m_o);
-    const float S = s_own * __builtin_amdgcn_exp2f(st[cbk].m2 - M2) + s_o * __builtin_amdgcn_exp2f(m_o - M2);
+    const float M2 = fmaxf(l_own, l_o);
+    const float S = __builtin_amdgcn_exp2f(l_own - M2) + __builtin_amdgcn_exp2f(l_o - M2);
     const int cnt = c_own + c_o;
     if (lh == 0 && myr < R) {
       const bool valid = myy[cbk] > 0;
@@ -502,15 +549,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   }
 }
 
-template <int C>
+template <int C, int PMODE = 0>
 static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
                                     const hiertcn_score_out_t* out, hipStream_t st) {
   using G = ScGeom<C>;
   const size_t lds = 3 * G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
   const unsigned blocks = (unsigned)((R + 511) / 512);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_score_pipe<C>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+  hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                      out->rank, out->ce, out->target);
   return hipGetLastError();
 }
@@ -570,7 +617,19 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   }
   // ablation switch for profiling runs only: "<mode><stagger>", e.g. "20" = no epilogue, no stagger
   static const char* var = getenv("HIERTCN_SCORE_VARIANT");
-  if (!var || !var[0]) return launch_score_pipe<C>(m, hidden, y, R, out, st);
+  static const char* pvar = getenv("HIERTCN_PIPE_VARIANT");
+  if (pvar && pvar[0] == '0') return launch_score_pipe<C, 0>(m, hidden, y, R, out, st);  // v3, for A/B runs
+  if (pvar && pvar[0] == '6') return launch_score_pipe<C, 6>(m, hidden, y, R, out, st);
+  if (C == 256 && pvar && pvar[0]) {
+    switch (pvar[0]) {
+      case '1': return launch_score_pipe<256, 1>(m, hidden, y, R, out, st);
+      case '2': return launch_score_pipe<256, 2>(m, hidden, y, R, out, st);
+      case '3': return launch_score_pipe<256, 3>(m, hidden, y, R, out, st);
+      case '4': return launch_score_pipe<256, 4>(m, hidden, y, R, out, st);
+      default: break;
+    }
+  }
+  if (!var || !var[0]) return launch_score_pipe<C, 5>(m, hidden, y, R, out, st);  // production
   int mode = 0, stagger = 1;
   if (var && var[0]) {
     mode = var[0] - '0';

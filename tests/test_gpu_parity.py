@@ -200,3 +200,47 @@ def test_logits_within_1e_3_at_north_star_scale():
     assert safe.sum() > 0
     assert np.array_equal(top_gpu[safe], top_ref[..., :10][safe])
     eng.close()
+
+
+@pytest.mark.parametrize("case", ["single_term", "sum_of_terms", "late_spike"])
+def test_fused_lse_reference_move_is_exercised(case):
+    """The softmax-sum reference of the fused epilogue moves only when the running sum overflows fp32
+    (score.hip, post5).  Random bounded inputs never take that branch, so force it (cdna_hip_programming.md
+    rule 26): logits far above the target logit, as one spike, as many moderately large terms whose SUM
+    overflows, and as a spike that arrives after the sum has grown.  Reference: fp64 log-sum-exp over the
+    HIP path's own materialised logits; tolerance 1e-4 absolute on ce values of magnitude ~1e2."""
+    from hiertcn_amd.engine import Engine
+    d, N, R = 64, 1500, 200
+    args = small_args(N=N, d=d, H=32)
+    p = make_params(args)
+    rng = np.random.default_rng(11)
+    u = np.zeros(d, np.float32)
+    u[:8] = 1.0
+    W = (0.01 * rng.standard_normal((d, N))).astype(np.float32)
+    y = rng.integers(1, N // 2, R).astype(np.int32)
+    W[:, 1:N // 2] += -8.0 * u[:, None] / 8.0          # every candidate target sits ~ -8*|h.u| below zero
+    if case == "single_term":
+        W[:, N - 5] += 8.0 * u / 8.0                   # one item ~ +8*|h.u|
+    elif case == "sum_of_terms":
+        W[:, N // 2:N // 2 + 600] += 5.2 * u[:, None] / 8.0   # 600 items whose terms are ~2^(13.2*|h.u|*1.44) each
+    else:
+        W[:, N // 2:N // 2 + 300] += 4.0 * u[:, None] / 8.0
+        W[:, N - 3] += 9.0 * u / 8.0                   # the last 64-item stage holds the largest logit
+    p["hier/tcn/dense/kernel"] = W
+    p["hier/tcn/dense/bias"] = np.zeros(N, np.float32)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    hid = np.zeros((R, d), np.float32)
+    hid[:, :8] = 7.5 * (1.0 + 0.1 * rng.random((R, 8)))  # h.u ~ 63: target ~ -63*8/8... logit gaps of 100+ nats
+    hid_t = torch.as_tensor(hid).cuda().to(torch.bfloat16).contiguous()
+    logits = eng.score_logits(hid_t).cpu().numpy().astype(np.float64)
+    out = eng.score_fused(hid_t, dev(y), want_target=True)
+    ce, rank = out["ce"].cpu().numpy(), out["rank"].cpu().numpy()
+    rows = np.arange(R)
+    gap_log2 = (logits.max(1) - logits[rows, y]) * np.log2(np.e)
+    assert gap_log2.min() > 130, "the input must push 2^x past fp32 range or the branch is not taken"
+    ref = O.log_sum_exp(logits) - logits[rows, y]
+    assert np.isfinite(ce).all()
+    assert np.abs(ce - ref).max() < 1e-4 * max(1.0, np.abs(ref).max() / 100), np.abs(ce - ref).max()
+    assert np.array_equal(rank, (logits > logits[rows, y][:, None]).sum(1))
+    eng.close()
