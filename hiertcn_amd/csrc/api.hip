@@ -248,11 +248,19 @@ static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t
   return HIERTCN_OK;
 }
 
+static int check_topk(const hiertcn_ctx* h, const hiertcn_score_out_t* o) {
+  if (o->topk < 0 || o->topk > HIERTCN_MAX_TOPK) return fail(HIERTCN_ERR_INVALID, "topk %d out of range 0..%d", o->topk, HIERTCN_MAX_TOPK);
+  if (o->topk > 0 && (!o->topk_idx || !o->topk_val)) return fail(HIERTCN_ERR_INVALID, "topk > 0 needs topk_idx and topk_val");
+  if (o->topk > h->m.N) return fail(HIERTCN_ERR_INVALID, "topk %d exceeds item_num %d", o->topk, h->m.N);
+  if (o->topk > 0 && (!o->rank || !o->ce)) return fail(HIERTCN_ERR_INVALID, "the top-k kernel also writes rank and ce: both are required");
+  return HIERTCN_OK;
+}
+
 int hiertcn_score_fused(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y_ids, int64_t R, const hiertcn_score_out_t* out,
                         void* stream) {
   CHECK_READY(h);
   if (!hidden || !y_ids || !out || R < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  if (out->topk != 0) return fail(HIERTCN_ERR_INVALID, "topk is not implemented in this build");
+  if (int rc = check_topk(h, out)) return rc;
   return score_timed(h, hidden, y_ids, R, out, reinterpret_cast<hipStream_t>(stream));
 }
 
@@ -313,9 +321,9 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   hiertcn_score_out_t so;
   memset(&so, 0, sizeof(so));
   if (score_out) so = *score_out;
-  if (so.topk != 0) return fail(HIERTCN_ERR_INVALID, "topk is not implemented in this build");
   if (!so.rank) so.rank = reinterpret_cast<int32_t*>(ws + w.rank);
   if (!so.ce) so.ce = reinterpret_cast<float*>(ws + w.ce);
+  if (int rc = check_topk(h, &so)) return rc;
   const int64_t n_sessions = (int64_t)B * S;
   const int64_t R = n_sessions * L;
   // scan first (it never reads the low level's output: model_hier.py:83-93), then every

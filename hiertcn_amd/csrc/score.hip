@@ -96,32 +96,81 @@ __device__ __forceinline__ void epilogue(const f32x16& v, RowState& st) {
   st.cnt += (c0 + c1) + (c2 + c3);
 }
 
-template <int C, bool LOGITS, int MODE, bool STAMP = false>
+// Running top-KT list of one lane (one step, half of the items): values descending, equal values in arrival
+// (= index) order, which is the order tf.nn.top_k returns (loss.py:120: ties -> lower index first).
+template <int KT>
+struct TopList {
+  float v[KT];
+  int i[KT];
+};
+
+// insert (val, idx) below the last entry and bubble it up; strict '>' keeps equal values in arrival order
+template <int KT>
+__device__ __forceinline__ void top_insert(TopList<KT>& L, float val, int idx) {
+  const bool take = val > L.v[KT - 1];
+  L.v[KT - 1] = take ? val : L.v[KT - 1];
+  L.i[KT - 1] = take ? idx : L.i[KT - 1];
+#pragma unroll
+  for (int k = KT - 1; k > 0; k--) {
+    const bool up = L.v[k] > L.v[k - 1];
+    const float hv = up ? L.v[k] : L.v[k - 1], lv = up ? L.v[k - 1] : L.v[k];
+    const int hi = up ? L.i[k] : L.i[k - 1], li = up ? L.i[k - 1] : L.i[k];
+    L.v[k - 1] = hv; L.v[k] = lv;
+    L.i[k - 1] = hi; L.i[k] = li;
+  }
+}
+
+// one 32-item x 32-step accumulator tile against the lane's list; item index of register r is item0 + 8*(r>>2) + (r&3)
+template <int KT>
+__device__ __forceinline__ void top_tile(TopList<KT>& L, const f32x16& v, int item0) {
+  float tm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+  tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
+  if (!__any(tm > L.v[KT - 1])) return;  // wave-uniform: no lane of this wave has a candidate in this tile
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    if (__any(v[r] > L.v[KT - 1])) top_insert<KT>(L, v[r], item0 + 8 * (r >> 2) + (r & 3));
+  }
+}
+
+// NB = step blocks of 32 rows per wave: 2 everywhere except the top-k build, whose per-lane lists would not fit
+// the 256-VGPR budget of a 512-thread workgroup beside two resident step blocks.
+template <int C, bool LOGITS, int MODE, bool STAMP = false, int KT = 0, int NB = 2>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
                                                          int64_t R, const uint16_t* __restrict__ outT,
                                                          const float* __restrict__ out_bias, int N, int NP,
                                                          int32_t* __restrict__ o_rank, float* __restrict__ o_ce,
                                                          float* __restrict__ o_tgt, float* __restrict__ logits, int stagger,
-                                                         unsigned long long* __restrict__ stamps = nullptr) {
+                                                         unsigned long long* __restrict__ stamps = nullptr,
+                                                         int32_t* __restrict__ o_topi = nullptr, float* __restrict__ o_topv = nullptr,
+                                                         int topk = 0) {
   using G = ScGeom<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages + 2 x 64 bias floats
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * 64;
+  const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * (32 * NB);
   // Waves w and w+4 share a SIMD.  Waves 4-7 run half a tile behind waves 0-3 (they defer the epilogue of a
   // stage's second item block past the barrier), so that on every SIMD one wave's MFMA burst runs beside the
   // other's VALU epilogue instead of both bursts colliding after each barrier (MI355X_MICROARCH.md, two waves
   // per SIMD, item 9).
-  const bool late = !LOGITS && stagger && wave >= 4;
+  const bool late = !LOGITS && KT == 0 && stagger && wave >= 4;
+  constexpr int KTA = KT > 0 ? KT : 1;
+  TopList<KTA> top[NB];
+  if (KT > 0) {
+#pragma unroll
+    for (int cbk = 0; cbk < NB; cbk++) {
+#pragma unroll
+      for (int k = 0; k < KTA; k++) { top[cbk].v[k] = -INFINITY; top[cbk].i[k] = 0x7fffffff; }
+    }
+  }
 
   // ---- this wave's 64 steps as the B operand, resident for the whole kernel -------------------
-  uint4 hf[2][G::KS];
-  int64_t myrow[2];
-  int myy[2];
+  uint4 hf[NB][G::KS];
+  int64_t myrow[NB];
+  int myy[NB];
 #pragma unroll
-  for (int cbk = 0; cbk < 2; cbk++) {
+  for (int cbk = 0; cbk < NB; cbk++) {
     int64_t r = row0 + cbk * 32 + lr;
     myrow[cbk] = r;
     const int64_t rc = (r < R) ? r : (R - 1);
@@ -132,11 +181,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     for (int s = 0; s < G::KS; s++) hf[cbk][s] = *reinterpret_cast<const uint4*>(hp + 16 * s);
   }
 
-  RowState st[2];
+  RowState st[NB];
   if (!LOGITS) {
     // ---- target logits: D[i][j] = bo[y_i] + Wo^T[y_i] . h_j, keep the diagonal ----------------
 #pragma unroll
-    for (int cbk = 0; cbk < 2; cbk++) {
+    for (int cbk = 0; cbk < NB; cbk++) {
       f32x16 acc;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) {
@@ -193,7 +242,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         acc0[4 * q + j] = b4[j];
-        acc1[4 * q + j] = b4[j];
+        if (NB == 2) acc1[4 * q + j] = b4[j];
       }
     }
     const unsigned char* arow = smem + buf * G::STAGE_BYTES + (ib * 32 + lr) * (2 * C);
@@ -201,7 +250,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     for (int s = 0; s < G::KS; s++) {
       const uint4 a = *reinterpret_cast<const uint4*>(arow + (((2 * s + lh) ^ (lr & G::SWZ)) << 4));
       acc0 = mfma32(a, hf[0][s], acc0);
-      acc1 = mfma32(a, hf[1][s], acc1);
+      if (NB == 2) acc1 = mfma32(a, hf[NB - 1][s], acc1);
     }
   };
   auto store_logits = [&](int stg, int ib) {
@@ -213,7 +262,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       for (int j = 0; j < 4; j++) {
         if (it + j < N) {
           if (myrow[0] < R) logits[myrow[0] * N + it + j] = acc0[4 * q + j];
-          if (myrow[1] < R) logits[myrow[1] * N + it + j] = acc1[4 * q + j];
+          if (NB == 2 && myrow[NB - 1] < R) logits[myrow[NB - 1] * N + it + j] = acc1[4 * q + j];
         }
       }
     }
@@ -239,7 +288,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     STAMP_AT(0)
     if (late && stg > 0) {  // deferred epilogue of the previous stage's second item block
       epilogue<MODE>(acc0, st[0]);
-      epilogue<MODE>(acc1, st[1]);
+      if (NB == 2) epilogue<MODE>(acc1, st[NB - 1]);
     }
     STAMP_AT(1)
     mfma_tile(buf, 0);
@@ -248,7 +297,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       store_logits(stg, 0);
     } else {
       epilogue<MODE>(acc0, st[0]);
-      epilogue<MODE>(acc1, st[1]);
+      if (NB == 2) epilogue<MODE>(acc1, st[NB - 1]);
+      if (KT > 0) {
+        top_tile<KTA>(top[0], acc0, stg * SC_STAGE + 4 * lh);
+        if (NB == 2) top_tile<KTA>(top[NB - 1], acc1, stg * SC_STAGE + 4 * lh);
+      }
     }
     STAMP_AT(3)
     mfma_tile(buf, 1);
@@ -257,7 +310,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       store_logits(stg, 1);
     } else if (!late) {
       epilogue<MODE>(acc0, st[0]);
-      epilogue<MODE>(acc1, st[1]);
+      if (NB == 2) epilogue<MODE>(acc1, st[NB - 1]);
+      if (KT > 0) {
+        top_tile<KTA>(top[0], acc0, stg * SC_STAGE + 32 + 4 * lh);
+        if (NB == 2) top_tile<KTA>(top[NB - 1], acc1, stg * SC_STAGE + 32 + 4 * lh);
+      }
     }
     STAMP_AT(5)
     if (STAMP) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -271,12 +328,12 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
   }
   if (late) {
     epilogue<MODE>(acc0, st[0]);
-    epilogue<MODE>(acc1, st[1]);
+    if (NB == 2) epilogue<MODE>(acc1, st[NB - 1]);
   }
 
   if (!LOGITS) {
 #pragma unroll
-    for (int cbk = 0; cbk < 2; cbk++) {
+    for (int cbk = 0; cbk < NB; cbk++) {
       // merge the two half-waves (same step, disjoint item subsets)
       const float m_o = __shfl_xor(st[cbk].m2, 32);
       const float s_o = __shfl_xor(st[cbk].s, 32);
@@ -290,6 +347,35 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
         if (o_rank) o_rank[myrow[cbk]] = valid ? cnt : 0;
         if (o_ce) o_ce[myrow[cbk]] = valid ? (lse - st[cbk].t) : 0.f;
         if (o_tgt) o_tgt[myrow[cbk]] = valid ? st[cbk].t : 0.f;
+      }
+    }
+    if (KT > 0) {
+      // The two half-waves hold disjoint item subsets of the same step: merge the two sorted lists
+      // (value descending, then index ascending) in LDS, which the item stream no longer needs.
+      float* lv = reinterpret_cast<float*>(smem);                       // [512 lanes][KT]
+      int* li = reinterpret_cast<int*>(smem + SC_THREADS * KTA * 4);    // [512 lanes][KT]
+#pragma unroll
+      for (int cbk = 0; cbk < NB; cbk++) {
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < KTA; k++) { lv[tid * KTA + k] = top[cbk].v[k]; li[tid * KTA + k] = top[cbk].i[k]; }
+        __syncthreads();
+        if (lh == 0 && myrow[cbk] < R) {
+          const bool valid = myy[cbk] > 0;
+          const float* av = lv + tid * KTA; const int* ai = li + tid * KTA;
+          const float* bv = lv + (tid + 32) * KTA; const int* bi = li + (tid + 32) * KTA;
+          int pa = 0, pb = 0;
+          for (int k = 0; k < topk; k++) {
+            // masked rows are all-zero logit rows (model.py:105): every value ties at 0 -> indices 0..k-1
+            const float va = pa < KTA ? av[pa] : -INFINITY, vb = pb < KTA ? bv[pb] : -INFINITY;
+            const int ia = pa < KTA ? ai[pa] : 0x7fffffff, ib = pb < KTA ? bi[pb] : 0x7fffffff;
+            const bool ta = (va > vb) || (va == vb && ia < ib);
+            o_topi[myrow[cbk] * topk + k] = valid ? (ta ? ia : ib) : k;
+            o_topv[myrow[cbk] * topk + k] = valid ? (ta ? va : vb) : 0.f;
+            pa += ta ? 1 : 0;
+            pb += ta ? 0 : 1;
+          }
+        }
       }
     }
   }
@@ -580,10 +666,28 @@ static hipError_t launch_score_v(const ModelDev& m, const uint16_t* hidden, cons
   return hipGetLastError();
 }
 
+template <int C, int KT>
+static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
+                                    const hiertcn_score_out_t* out, hipStream_t st) {
+  using G = ScGeom<C>;
+  size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
+  const size_t merge = (size_t)SC_THREADS * KT * 8;
+  if (merge > lds) lds = merge;
+  const unsigned blocks = (unsigned)((R + 255) / 256);  // NB = 1: 8 waves x 32 rows
+  auto kern = k_score<C, false, 0, false, KT, 1>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out->rank, out->ce,
+                     out->target, (float*)nullptr, 0, (unsigned long long*)nullptr, out->topk_idx, out->topk_val, (int)out->topk);
+  return hipGetLastError();
+}
+
 template <int C>
 static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
                                  const hiertcn_score_out_t* out, float* logits, hipStream_t st) {
   if (logits) return launch_score_v<C, true, 0>(m, hidden, y, R, nullptr, logits, 0, st);
+  if (out && out->topk > 0)  // loss.py:120 ranked indices beside rank / ce: the list kernel (slower epilogue)
+    return out->topk <= 8 ? launch_score_topk<C, 8>(m, hidden, y, R, out, st) : launch_score_topk<C, 16>(m, hidden, y, R, out, st);
   if (getenv("HIERTCN_SCORE_STAMPS")) {  // diagnostic build: per-phase cycle sums of the first workgroups, printed to stderr
     using G = ScGeom<C>;
     const int stagger_d = getenv("HIERTCN_SCORE_VARIANT") && getenv("HIERTCN_SCORE_VARIANT")[1] == '0' ? 0 : 1;

@@ -183,8 +183,9 @@ class Engine:
         check(self.lib.hiertcn_tcn_forward(self._h, _ptr(x_ids), _ptr(sproj), n, L, _ptr(hidden), self._stream()))
         return hidden
 
-    def score_fused(self, hidden: torch.Tensor, y_ids: torch.Tensor, want_target=False):
-        """hidden [R, C] bf16, y_ids [R] int32 -> dict(rank int32 [R], ce fp32 [R], target?)."""
+    def score_fused(self, hidden: torch.Tensor, y_ids: torch.Tensor, want_target=False, topk: int = 0):
+        """hidden [R, C] bf16, y_ids [R] int32 -> dict(rank int32 [R], ce fp32 [R], target?,
+        topk_idx int32 [R, topk], topk_val fp32 [R, topk] when topk > 0 (loss.py:120 order))."""
         R = hidden.shape[0]
         _req(hidden, torch.bfloat16, "hidden", (R, self.C))
         y = y_ids.reshape(-1)
@@ -192,12 +193,17 @@ class Engine:
         rank = torch.empty(R, dtype=torch.int32, device=self.device)
         ce = torch.empty(R, dtype=torch.float32, device=self.device)
         tgt = torch.empty(R, dtype=torch.float32, device=self.device) if want_target else None
+        ti = torch.empty((R, topk), dtype=torch.int32, device=self.device) if topk > 0 else None
+        tv = torch.empty((R, topk), dtype=torch.float32, device=self.device) if topk > 0 else None
         so = _lib.ScoreOut(rank=rank.data_ptr(), ce=ce.data_ptr(), target=tgt.data_ptr() if tgt is not None else None,
-                           topk_idx=None, topk_val=None, topk=0)
+                           topk_idx=ti.data_ptr() if ti is not None else None,
+                           topk_val=tv.data_ptr() if tv is not None else None, topk=int(topk))
         check(self.lib.hiertcn_score_fused(self._h, _ptr(hidden), _ptr(y), R, C.byref(so), self._stream()))
         out = dict(rank=rank, ce=ce)
         if tgt is not None:
             out["target"] = tgt
+        if topk > 0:
+            out["topk_idx"], out["topk_val"] = ti, tv
         return out
 
     def score_logits(self, hidden: torch.Tensor) -> torch.Tensor:
@@ -225,9 +231,9 @@ class Engine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward_eval(self, x_ids, y_ids, mask, state_in, want_rows=False, state_out=None, metrics8=None):
+    def forward_eval(self, x_ids, y_ids, mask, state_in, want_rows=False, state_out=None, metrics8=None, topk: int = 0):
         """One evaluation step on a packed batch: x_ids, y_ids [B,S,L] int32; mask [B,S] fp32;
-        state_in [B,H*nl] fp32.  Returns dict(state, metrics8 (device, 8 doubles)[, rank, ce])."""
+        state_in [B,H*nl] fp32.  Returns dict(state, metrics8 (device, 8 doubles)[, rank, ce][, topk_idx, topk_val])."""
         B, S, L = x_ids.shape
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
@@ -240,12 +246,18 @@ class Engine:
             metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
         so = None
         out = dict(state=state_out, metrics8=metrics8)
-        if want_rows:
+        if want_rows or topk > 0:
             rank = torch.empty(B * S * L, dtype=torch.int32, device=self.device)
             ce = torch.empty(B * S * L, dtype=torch.float32, device=self.device)
-            so = _lib.ScoreOut(rank=rank.data_ptr(), ce=ce.data_ptr(), target=None, topk_idx=None, topk_val=None, topk=0)
+            ti = torch.empty((B * S * L, topk), dtype=torch.int32, device=self.device) if topk > 0 else None
+            tv = torch.empty((B * S * L, topk), dtype=torch.float32, device=self.device) if topk > 0 else None
+            so = _lib.ScoreOut(rank=rank.data_ptr(), ce=ce.data_ptr(), target=None, topk_idx=ti.data_ptr() if topk > 0 else None,
+                               topk_val=tv.data_ptr() if topk > 0 else None, topk=int(topk))
             out["rank"] = rank.view(B, S * L)
             out["ce"] = ce.view(B, S * L)
+            if topk > 0:
+                out["topk_idx"] = ti.view(B, S * L, topk)
+                out["topk_val"] = tv.view(B, S * L, topk)
         check(self.lib.hiertcn_forward_eval(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
                                             _ptr(ws), ws.numel(), _ptr(state_out), _ptr(metrics8),
                                             C.byref(so) if so is not None else None, self._stream()))

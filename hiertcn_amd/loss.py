@@ -58,9 +58,19 @@ def calc_metric_fast(score, mask_y, activity_count, user_count, y):
     return user_mean(r1), user_mean(r5), user_mean(r10), user_mean(rr), user_mean(ranks_float), ranks_float, ranks
 
 
+def calc_metric_topk(score, y_id, k: int = 10):
+    """The ranked candidate list of loss.py:120 cut at k <= 16, from the fused kernel (no logits):
+    -> (ranks_indices [B, T, k] int32, ranks_values [B, T, k] fp32).  Value descending, ties -> lower
+    index first ([TF-sem] tf.nn.top_k); masked rows are all-zero rows (model.py:105) -> indices 0..k-1."""
+    _need_lazy(score)
+    sc = score.scored(y_id, topk=int(k))
+    return score.unpad(sc["topk_idx"][:, :k]), score.unpad(sc["topk_val"][:, :k])
+
+
 def calc_metric(score, mask_y, activity_count, user_count, y_id=None):
     """loss.py:108-160, the slow variant (commented out at model.py:128-129): a FULL top_k(k=N)
-    over materialised logits -- parity/debug only, O(N log N) per step and 4N bytes per step of HBM.
+    over materialised logits -- parity/debug only, O(N log N) per step and 4N bytes per step of HBM
+    (the ranked top-k for k <= 16 comes from the fused kernel: calc_metric_topk).
     Ties -> lower index first ([TF-sem] tf.nn.top_k), masked rows are all-zero rows (model.py:105).
     Returns the tuple of loss.py:160."""
     _need_lazy(score)

@@ -75,11 +75,12 @@ class LazyLogits:
         full.index_copy_(1, self._cols, y)
         return full.reshape(-1).contiguous()
 
-    def scored(self, y) -> dict:
-        if self._scored is None:
+    def scored(self, y, topk: int = 0) -> dict:
+        if self._scored is None or (topk > 0 and self._scored.get("topk", 0) < topk):
             yp = self.pad_ids(y)
-            out = self.engine.score_fused(self.hidden, yp, want_target=True)
+            out = self.engine.score_fused(self.hidden, yp, want_target=True, topk=topk)
             out["y_padded"] = yp
+            out["topk"] = topk
             self._scored = out
         return self._scored
 

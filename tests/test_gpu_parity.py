@@ -244,3 +244,51 @@ def test_fused_lse_reference_move_is_exercised(case):
     assert np.abs(ce - ref).max() < 1e-4 * max(1.0, np.abs(ref).max() / 100), np.abs(ce - ref).max()
     assert np.array_equal(rank, (logits > logits[rows, y][:, None]).sum(1))
     eng.close()
+
+
+@pytest.mark.parametrize("k", [5, 10, 16])
+def test_fused_topk_is_bit_exact(setup, k):
+    """Ranked top-k indices (loss.py:120: value descending, ties -> lower index first) from the fused
+    list kernel vs a stable sort of the HIP path's own materialised logits: identical index lists,
+    identical values; masked rows -> 0..k-1 (they are all-zero rows, model.py:105).  Exact ties are
+    forced by duplicating item columns."""
+    from hiertcn_amd.engine import Engine
+    s = setup
+    p = dict(s["p"])
+    W = p["hier/tcn/dense/kernel"].copy()
+    b = p["hier/tcn/dense/bias"].copy()
+    N = s["N"]
+    rng = np.random.default_rng(k)
+    for _ in range(40):   # duplicates: item j gets the column and bias of item i (exactly equal logits for every step)
+        i, j = rng.integers(0, N, 2)
+        W[:, j], b[j] = W[:, i], b[i]
+    for boost, (i, j) in zip((3.0, 2.5), rng.integers(0, N, (2, 2))):   # and two duplicate pairs that lead every list
+        b[i] = boost
+        W[:, j], b[j] = W[:, i], b[i]
+    p["hier/tcn/dense/kernel"], p["hier/tcn/dense/bias"] = W, b
+    eng = Engine(s["args"], hier=True)
+    eng.set_weights(p)
+    hid, _ = gpu_hidden(s)
+    R = hid.shape[0]
+    logits = eng.score_logits(hid).cpu().numpy()
+    y = s["y"].reshape(-1)
+    out = eng.score_fused(hid, dev(y), topk=k)
+    ti, tv = out["topk_idx"].cpu().numpy(), out["topk_val"].cpu().numpy()
+    valid = y > 0
+    want = O.top_k_indices(logits, k)                       # stable argsort of -logits
+    assert np.array_equal(ti[valid], want[valid])
+    assert np.array_equal(tv[valid], np.take_along_axis(logits, want, 1)[valid])
+    assert (np.take_along_axis(logits, want, 1)[valid][:, :-1] == np.take_along_axis(logits, want, 1)[valid][:, 1:]).any(), "no tie in any list"
+    assert np.array_equal(ti[~valid], np.broadcast_to(np.arange(k), ((~valid).sum(), k))) and not tv[~valid].any()
+    # rank / ce of the list kernel agree with the production kernel's
+    ref = eng.score_fused(hid, dev(y))
+    assert np.array_equal(out["rank"].cpu().numpy(), ref["rank"].cpu().numpy())
+    assert np.abs(out["ce"].cpu().numpy() - ref["ce"].cpu().numpy()).max() < 2e-5
+    # the target's position in the list is its rank whenever rank < k (loss.py:124 vs :179 agree absent ties above)
+    rank = ref["rank"].cpu().numpy()
+    hit = valid & (rank < k)
+    pos = (ti == y[:, None]).argmax(1)
+    tgt_val = logits[np.arange(R), y]
+    n_equal_before = ((logits == tgt_val[:, None]) & (np.arange(N)[None, :] < y[:, None])).sum(1)
+    assert np.array_equal(pos[hit & (rank + n_equal_before < k)], (rank + n_equal_before)[hit & (rank + n_equal_before < k)])
+    eng.close()
