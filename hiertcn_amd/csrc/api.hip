@@ -58,22 +58,26 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
   if (!out || !cfg) return fail(HIERTCN_ERR_INVALID, "null argument");
   const int E = cfg->emb_dim;
   if (cfg->item_num < 2) return fail(HIERTCN_ERR_INVALID, "item_num must be >= 2 (row 0 is the null id)");
-  if (!(E == 64 || E == 128 || E == 256))
-    return fail(HIERTCN_ERR_INVALID, "emb_dim %d unsupported: the fused gfx950 kernels are built for 64, 128, 256 (zero-pad other widths on the host)", E);
+  if (E < 32 || (E & 31) || E > 1024)
+    return fail(HIERTCN_ERR_INVALID, "emb_dim %d unsupported: widths are multiples of 32 (one MFMA tile), zero-pad other widths on the host", E);
   if (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS) return fail(HIERTCN_ERR_INVALID, "n_blocks out of range");
-  for (int i = 0; i < cfg->n_blocks; i++)
-    if (cfg->channels[i] != E)
-      return fail(HIERTCN_ERR_INVALID, "tcn_channel[%d]=%d: the fused low-level kernel needs every channel count == emb_dim (%d)", i,
-                  cfg->channels[i], E);
+  bool uniform = (E == 64 || E == 128 || E == 256);
+  for (int i = 0; i < cfg->n_blocks; i++) {
+    const int ci = cfg->channels[i];
+    if (ci < 32 || (ci & 31) || ci > 1024) return fail(HIERTCN_ERR_INVALID, "tcn_channel[%d]=%d: widths are multiples of 32 up to 1024", i, ci);
+    uniform = uniform && ci == E;
+  }
+  const int clast = cfg->channels[cfg->n_blocks - 1];
+  if (!(clast == 64 || clast == 128 || clast == 256))
+    return fail(HIERTCN_ERR_INVALID, "last tcn_channel %d unsupported: the scoring kernel is built for 64, 128, 256", clast);
   if (cfg->kernel_size < 1 || cfg->kernel_size > 8) return fail(HIERTCN_ERR_INVALID, "kernel_size out of range");
   if (cfg->hier) {
+    if (!(E == 64 || E == 128 || E == 256 || E == 512))
+      return fail(HIERTCN_ERR_INVALID, "emb_dim %d: the session mean-pool kernel is built for 64, 128, 256, 512", E);
     if (cfg->num_layer < 1 || cfg->num_layer > HIERTCN_MAX_LAYERS) return fail(HIERTCN_ERR_INVALID, "num_layer out of range");
     if (cfg->hidden_dim < 32 || (cfg->hidden_dim & 31))
       return fail(HIERTCN_ERR_INVALID, "hidden_dim must be a positive multiple of 32 (one MFMA tile of GRU columns)");
   }
-  const int halo = (cfg->kernel_size - 1) * (1 << (cfg->n_blocks - 1));
-  const size_t tcn_lds = (size_t)4 * (((halo + 7) & ~7) + 32) * 2 * E;
-  if (tcn_lds > 160 * 1024) return fail(HIERTCN_ERR_INVALID, "receptive-field halo %d rows does not fit the fused kernel's LDS slab", halo);
 
   hiertcn_ctx* c = new hiertcn_ctx();
   c->cfg = *cfg;
@@ -98,6 +102,7 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
   m.n_blocks = cfg->n_blocks;
   for (int i = 0; i < m.n_blocks; i++) m.C[i] = cfg->channels[i];
   m.Clast = m.C[m.n_blocks - 1];
+  m.fused_tcn = uniform ? 1 : 0;
 
 #define ALLOC_OR_FAIL(ptr, count)                                  \
   do {                                                             \
@@ -112,9 +117,13 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
   ALLOC_OR_FAIL(m.emb, (size_t)m.N * E);
   ALLOC_OR_FAIL(m.outT, (size_t)m.NP * m.Clast);
   ALLOC_OR_FAIL(m.out_bias, (size_t)m.NP);
-  for (int i = 0; i < m.n_blocks; i++) {
-    ALLOC_OR_FAIL(m.convT[i], (size_t)m.K * E * E);
-    ALLOC_OR_FAIL(m.conv_bias[i], (size_t)E);
+  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+    ALLOC_OR_FAIL(m.convT[i], (size_t)m.K * cin * m.C[i]);
+    ALLOC_OR_FAIL(m.conv_bias[i], (size_t)m.C[i]);
+    if (cin != m.C[i]) {  // customized_tcn_cell.py:102-106: a biased Dense down-sample on the residual path
+      ALLOC_OR_FAIL(m.resT[i], (size_t)cin * m.C[i]);
+      ALLOC_OR_FAIL(m.res_bias[i], (size_t)m.C[i]);
+    }
   }
   if (m.hier) {
     ALLOC_OR_FAIL(m.emb_bias, (size_t)E);
@@ -161,12 +170,19 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
   // that padding items never outrank anything and add exp(-inf) = 0 to the softmax denominator
   HIP_TRY(launch_transpose_to_bf16(w->out_kernel, m.outT, m.Clast, m.N, m.NP, st));
   HIP_TRY(launch_copy_pad_f32(w->out_bias, m.out_bias, m.N, m.NP, -INFINITY, st));
-  for (int i = 0; i < m.n_blocks; i++) {
+  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+    const int cout = m.C[i];
     if (!w->conv_kernel[i] || !w->conv_bias[i]) return fail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
-    if (w->res_kernel[i]) return fail(HIERTCN_ERR_INVALID, "down-sample residual (block %d) is not supported by the fused kernel", i);
+    if ((cin != cout) != (w->res_kernel[i] != nullptr))
+      return fail(HIERTCN_ERR_INVALID, "block %d: a down-sample residual exists exactly when Cin != Cout (customized_tcn_cell.py:102-106)", i);
     for (int j = 0; j < m.K; j++)  // tap j: [Cin][Cout] -> [Cout][Cin]
-      HIP_TRY(launch_transpose_to_bf16(w->conv_kernel[i] + (size_t)j * E * E, m.convT[i] + (size_t)j * E * E, E, E, E, st));
-    HIP_TRY(launch_copy_pad_f32(w->conv_bias[i], m.conv_bias[i], E, E, 0.f, st));
+      HIP_TRY(launch_transpose_to_bf16(w->conv_kernel[i] + (size_t)j * cin * cout, m.convT[i] + (size_t)j * cin * cout, cin, cout, cout, st));
+    HIP_TRY(launch_copy_pad_f32(w->conv_bias[i], m.conv_bias[i], cout, cout, 0.f, st));
+    if (w->res_kernel[i]) {
+      if (!w->res_bias[i]) return fail(HIERTCN_ERR_INVALID, "res_bias[%d] missing", i);
+      HIP_TRY(launch_transpose_to_bf16(w->res_kernel[i], m.resT[i], cin, cout, cout, st));
+      HIP_TRY(launch_copy_pad_f32(w->res_bias[i], m.res_bias[i], cout, cout, 0.f, st));
+    }
   }
   if (m.hier) {
     if (!w->emb_bias || !w->proj_kernel) return fail(HIERTCN_ERR_INVALID, "emb_bias/proj_kernel are required for hier models");
@@ -218,13 +234,23 @@ int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask,
   return HIERTCN_OK;
 }
 
+size_t hiertcn_tcn_workspace_bytes(hiertcn_handle_t h, int64_t n_sessions, int32_t L) {
+  if (!h || n_sessions < 0 || L < 1) return 0;
+  return tcn_workspace_bytes(h->m, n_sessions, L);
+}
+
 int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* sproj, int64_t n_sessions, int32_t L,
-                        uint16_t* hidden, void* stream) {
+                        uint16_t* hidden, void* workspace, size_t workspace_bytes, void* stream) {
   CHECK_READY(h);
   if (!x_ids || !hidden || n_sessions < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  if (L < 1 || L > 32) return fail(HIERTCN_ERR_INVALID, "L=%d: the fused low-level kernel handles 1..32 steps per session", L);
+  if (L < 1 || L > 4096) return fail(HIERTCN_ERR_INVALID, "L=%d out of range 1..4096", L);
   if (h->m.hier && !sproj) return fail(HIERTCN_ERR_INVALID, "sproj is required for hier models (run hiertcn_gru_scan first)");
-  HIP_TRY(launch_tcn_forward(h->m, x_ids, h->m.hier ? sproj : nullptr, n_sessions, L, hidden, reinterpret_cast<hipStream_t>(stream)));
+  const size_t need = tcn_workspace_bytes(h->m, n_sessions, L);
+  if (need > 0) {
+    if (!workspace || workspace_bytes < need) return fail(HIERTCN_ERR_WORKSPACE, "tcn workspace %zu < required %zu bytes", workspace_bytes, need);
+    if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
+  }
+  HIP_TRY(launch_tcn_forward(h->m, x_ids, h->m.hier ? sproj : nullptr, n_sessions, L, hidden, workspace, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
 
@@ -282,7 +308,7 @@ int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, co
 
 // workspace layout of hiertcn_forward_eval (all sub-buffers 256-byte aligned)
 struct EvalWs {
-  size_t pooled, sproj, hidden, rank, ce, gru, total;
+  size_t pooled, sproj, hidden, rank, ce, gru, tcn, total;
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
@@ -293,7 +319,8 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
   w.hidden = off; off += al256((size_t)B * S * L * m.Clast * sizeof(uint16_t));
   w.rank = off;   off += al256((size_t)B * S * L * sizeof(int32_t));
   w.ce = off;     off += al256((size_t)B * S * L * sizeof(float));
-  w.gru = off;    off += al256(gru_workspace_bytes(m, (int)B, (int)S));
+  w.gru = off;    off += al256(m.hier ? gru_workspace_bytes(m, (int)B, (int)S) : 0);
+  w.tcn = off;    off += al256(tcn_workspace_bytes(m, B * S, (int)L));
   w.total = off;
   return w;
 }
@@ -307,9 +334,11 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
                          int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out,
                          double* metrics8, const hiertcn_score_out_t* score_out, void* stream) {
   CHECK_READY(h);
-  if (!h->m.hier) return fail(HIERTCN_ERR_STATE, "forward_eval is the model_hier evaluation step");
-  if (!x_ids || !y_ids || !mask || !state_in || !workspace || !state_out || B < 1 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  if (L < 1 || L > 32) return fail(HIERTCN_ERR_INVALID, "L=%d: the fused low-level kernel handles 1..32 steps per session", L);
+  const bool hier = h->m.hier != 0;
+  if (!x_ids || !y_ids || !workspace || B < 1 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
+  if (!hier && S != 1) return fail(HIERTCN_ERR_INVALID, "single-level model_tcn: one sequence per lane (S must be 1, L = T)");
+  if (L < 1 || L > 4096) return fail(HIERTCN_ERR_INVALID, "L=%d out of range 1..4096", L);
   const EvalWs w = eval_ws(h->m, B, S, L);
   if (workspace_bytes < w.total) return fail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.total);
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
@@ -328,9 +357,11 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   const int64_t R = n_sessions * L;
   // scan first (it never reads the low level's output: model_hier.py:83-93), then every
   // (user, session) low-level problem is independent.
-  HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
-  HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
-  HIP_TRY(launch_tcn_forward(h->m, x_ids, sproj, n_sessions, L, hidden, st));
+  if (hier) {
+    HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
+    HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
+  }
+  HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, hidden, ws + w.tcn, st));
   int rc = score_timed(h, hidden, y_ids, R, &so, st);
   if (rc != HIERTCN_OK) return rc;
   if (metrics8) {

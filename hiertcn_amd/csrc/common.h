@@ -41,6 +41,7 @@ struct ModelDev {
   int C[HIERTCN_MAX_BLOCKS];
   int Clast;
   int hier;
+  int fused_tcn;   // 1: every width == E in {64,128,256} and no down-sample residual -> tcn.hip's fused kernel applies (L <= 32)
   // bf16 tensors (uint16 bit patterns)
   uint16_t* emb;        // [N][E], row 0 zeroed
   uint16_t* projT;      // [E(out)][E(in)]   = transpose(Wp[:E])          (hier only)
@@ -68,8 +69,12 @@ hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_se
 size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
                            float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st);
+size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
-                              uint16_t* hidden, hipStream_t st);
+                              uint16_t* hidden, void* workspace, hipStream_t st);
+size_t tcn_layers_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
+hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L, uint16_t* hidden,
+                             void* workspace, hipStream_t st);
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                         float* logits, hipStream_t st);
 hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,

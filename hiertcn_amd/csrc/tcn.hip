@@ -173,9 +173,23 @@ static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float
   return hipGetLastError();
 }
 
+#include <stdlib.h>
+static bool use_fused(const ModelDev& m, int L) {
+  static const bool force_layers = getenv("HIERTCN_FORCE_LAYERED") != nullptr;  // tests: both paths must agree bitwise
+  if (force_layers) return false;
+  const int halo = (m.K - 1) * (1 << (m.n_blocks - 1));
+  const size_t lds = (size_t)TCN_G * (((halo + 7) & ~7) + 32) * 2 * m.E;
+  return m.fused_tcn && L <= 32 && lds <= 160 * 1024;
+}
+
+size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) {
+  return use_fused(m, L) ? 0 : tcn_layers_workspace_bytes(m, n_sessions, L);
+}
+
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
-                              uint16_t* hidden, hipStream_t st) {
+                              uint16_t* hidden, void* workspace, hipStream_t st) {
   if (n_sessions <= 0) return hipSuccess;
+  if (!use_fused(m, L)) return launch_tcn_layers(m, x, sproj, n_sessions, L, hidden, workspace, st);
   TcnParams p;
   p.emb = m.emb;
   p.projT = m.hier ? m.projT : nullptr;

@@ -1,0 +1,174 @@
+// Layer-at-a-time low level for the shapes the fused kernel (tcn.hip) does not take: the single-level
+// model_tcn (model.py:71-73, model_tcn.py:13-44: T <= 500 steps per user, six blocks with dilations
+// 1..32 and channels [128,128,128,128,256,256] -> a biased Dense residual where Cin != Cout,
+// customized_tcn_cell.py:102-106,123-124) and any model_hier configuration with L > 32 or unequal
+// widths.  Activations live in HBM/L2 as bf16 rows [sequence * L + t][C] between layers (two
+// ping-pong buffers): with a receptive field of 1 + (K-1)(2^n - 1) = 253 steps for six blocks a
+// single fused LDS slab would recompute a 252-step halo per 32-step tile.
+//
+// One wave = one 32 (output channels) x 32 (time steps) tile.  A = weights [tap][cout][cin] rows,
+// B = activation rows shifted by (K-1-j)*dil steps (zero operand left of the sequence start,
+// customized_tcn_cell.py:47-48), D[row = cout][col = t]; taps outermost, k-steps inner -- the SAME
+// accumulation order as the fused kernel, so both produce bitwise identical activations.
+#include "common.h"
+
+struct LayerArgs {
+  const uint16_t* in;      // [n_seq * L][Cin]
+  uint16_t* out;           // [n_seq * L][Cout]
+  const uint16_t* W;       // [taps][Cout][Cin]
+  const float* bias;       // [Cout] or null
+  const float* seq_init;   // [n_seq][Cout] fp32 accumulator start per sequence (projection: state . Wp[E:]) or null
+  const uint16_t* Wres;    // [Cout][Cin] or null
+  const float* bres;       // [Cout] or null
+  int Cin, Cout, taps, dil, L;
+  int64_t n_seq;
+  int linear;              // 1: out = conv (the 'emb' projection, model_tcn.py:35); 0: relu(relu(conv + b) + res)
+};
+
+__global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int ncb = a.Cout >> 5;
+  const int ntt = (a.L + 31) >> 5;
+  const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
+  const int cb = (int)(tile % ncb);
+  const int64_t rest = tile / ncb;
+  const int tt = (int)(rest % ntt);
+  const int64_t seq = rest / ntt;
+  if (seq >= a.n_seq) return;
+  const int t = tt * 32 + lr;
+  const int64_t row0 = seq * a.L;
+  const int ks = a.Cin >> 4;
+
+  f32x16 acc, racc;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int c0 = cb * 32 + 8 * q + 4 * lh;
+    f32x4 init = {0.f, 0.f, 0.f, 0.f}, rinit = {0.f, 0.f, 0.f, 0.f};
+    if (a.seq_init) init = *reinterpret_cast<const f32x4*>(a.seq_init + seq * a.Cout + c0);
+    if (a.bias) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
+#pragma unroll
+      for (int j = 0; j < 4; j++) init[j] += b4[j];
+    }
+    if (a.bres) rinit = *reinterpret_cast<const f32x4*>(a.bres + c0);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { acc[4 * q + j] = init[j]; racc[4 * q + j] = rinit[j]; }
+  }
+
+  const uint4 zero = make_uint4(0, 0, 0, 0);
+  for (int j = 0; j < a.taps; j++) {
+    const int tsrc = t - (a.taps - 1 - j) * a.dil;   // o[t] += x[t - (K-1-j)*dil] . W[j]
+    const bool ok = tsrc >= 0 && t < a.L;
+    const uint16_t* brow = a.in + (row0 + (ok ? tsrc : 0)) * a.Cin + 8 * lh;
+    const uint16_t* arow = a.W + ((int64_t)j * a.Cout + cb * 32 + lr) * a.Cin + 8 * lh;
+#pragma unroll 4
+    for (int s = 0; s < ks; s++) {
+      const uint4 av = *reinterpret_cast<const uint4*>(arow + 16 * s);
+      const uint4 bv = ok ? *reinterpret_cast<const uint4*>(brow + 16 * s) : zero;
+      acc = mfma32(av, bv, acc);
+    }
+  }
+  if (!a.linear && a.Wres) {   // res(x) = x . Wr + br  (customized_tcn_cell.py:106,124)
+    const bool ok = t < a.L;
+    const uint16_t* brow = a.in + (row0 + (ok ? t : 0)) * a.Cin + 8 * lh;
+    const uint16_t* arow = a.Wres + ((int64_t)cb * 32 + lr) * a.Cin + 8 * lh;
+#pragma unroll 4
+    for (int s = 0; s < ks; s++) {
+      const uint4 av = *reinterpret_cast<const uint4*>(arow + 16 * s);
+      const uint4 bv = ok ? *reinterpret_cast<const uint4*>(brow + 16 * s) : zero;
+      racc = mfma32(av, bv, racc);
+    }
+  }
+  if (t >= a.L) return;
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int c0 = cb * 32 + 8 * q + 4 * lh;
+    float v[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) v[j] = acc[4 * q + j];
+    if (!a.linear) {
+      float r[4];
+      if (a.Wres) {
+#pragma unroll
+        for (int j = 0; j < 4; j++) r[j] = racc[4 * q + j];
+      } else {   // identity residual (Cin == Cout)
+        const uint2 res = *reinterpret_cast<const uint2*>(a.in + (row0 + t) * a.Cin + c0);
+        r[0] = bf2f((uint16_t)(res.x & 0xffff)); r[1] = bf2f((uint16_t)(res.x >> 16));
+        r[2] = bf2f((uint16_t)(res.y & 0xffff)); r[3] = bf2f((uint16_t)(res.y >> 16));
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) v[j] = fmaxf(fmaxf(v[j], 0.f) + r[j], 0.f);
+    }
+    uint2 o;
+    o.x = pack2bf(v[0], v[1]);
+    o.y = pack2bf(v[2], v[3]);
+    *reinterpret_cast<uint2*>(a.out + (row0 + t) * a.Cout + c0) = o;
+  }
+}
+
+// ids [R] -> rows [R][E] bf16: the one-hot "lookup" of model.py:56-61 + model_tcn.py:35 / model_hier.py:50
+// (row 0 of the table is stored as zeros).  HBM/L2-bound gather, 16 B per lane.
+__global__ __launch_bounds__(256) void k_embed_rows(const uint16_t* __restrict__ emb, const int32_t* __restrict__ ids, int64_t R, int E,
+                                                    uint16_t* __restrict__ out) {
+  const int ch = E >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch);
+  const int id = ids[r];
+  *reinterpret_cast<uint4*>(out + r * E + c * 8) = *reinterpret_cast<const uint4*>(emb + (int64_t)id * E + c * 8);
+}
+
+static int max_width(const ModelDev& m) {
+  int w = m.E;
+  for (int i = 0; i < m.n_blocks; i++) w = m.C[i] > w ? m.C[i] : w;
+  return w;
+}
+
+size_t tcn_layers_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) {
+  // two ping-pong activation buffers, each 256-byte aligned
+  const size_t one = (((size_t)n_sessions * L * max_width(m) * sizeof(uint16_t)) + 255) & ~(size_t)255;
+  return 2 * one;
+}
+
+static hipError_t launch_layer(const LayerArgs& a, hipStream_t st) {
+  const int64_t tiles = a.n_seq * ((a.L + 31) / 32) * (a.Cout / 32);
+  hipLaunchKernelGGL(k_tcn_layer, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L, uint16_t* hidden,
+                             void* workspace, hipStream_t st) {
+  const int64_t R = n_sessions * L;
+  const size_t one = tcn_layers_workspace_bytes(m, n_sessions, L) / 2;
+  uint16_t* buf[2] = {reinterpret_cast<uint16_t*>(workspace), reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(workspace) + one)};
+  int cur = 0;
+  {
+    const int64_t n = R * (m.E / 8);
+    hipLaunchKernelGGL(k_embed_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.emb, x, R, m.E, buf[cur]);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  int cin = m.E;
+  if (m.hier) {   // [e, state] . Wp = e . Wp[:E] + state . Wp[E:]  (model_hier.py:54-55 -> model_tcn.py:35), no bias, no activation
+    LayerArgs a = {};
+    a.in = buf[cur]; a.out = buf[cur ^ 1]; a.W = m.projT; a.seq_init = sproj;
+    a.Cin = m.E; a.Cout = m.E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sessions; a.linear = 1;
+    hipError_t e = launch_layer(a, st);
+    if (e != hipSuccess) return e;
+    cur ^= 1;
+  }
+  for (int i = 0; i < m.n_blocks; i++) {
+    LayerArgs a = {};
+    a.in = buf[cur];
+    a.out = (i == m.n_blocks - 1) ? hidden : buf[cur ^ 1];
+    a.W = m.convT[i]; a.bias = m.conv_bias[i]; a.Wres = m.resT[i]; a.bres = m.res_bias[i];
+    a.Cin = cin; a.Cout = m.C[i]; a.taps = m.K; a.dil = 1 << i; a.L = L; a.n_seq = n_sessions; a.linear = 0;
+    hipError_t e = launch_layer(a, st);
+    if (e != hipSuccess) return e;
+    cur ^= 1;
+    cin = m.C[i];
+  }
+  return hipSuccess;
+}

@@ -76,6 +76,7 @@ class Engine:
             check(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
         self._ws: Optional[torch.Tensor] = None
         self._gru_ws: Optional[torch.Tensor] = None
+        self._tcn_ws: Optional[torch.Tensor] = None
         self._weights_set = False
 
     # ---------------------------------------------------------------------------------------
@@ -180,7 +181,12 @@ class Engine:
         if sproj is not None:
             _req(sproj, torch.float32, "sproj", (n, self.E))
         hidden = torch.empty((n * L, self.C), dtype=torch.bfloat16, device=self.device)
-        check(self.lib.hiertcn_tcn_forward(self._h, _ptr(x_ids), _ptr(sproj), n, L, _ptr(hidden), self._stream()))
+        need = int(self.lib.hiertcn_tcn_workspace_bytes(self._h, n, L))  # 0 when the fused kernel applies
+        if need and (self._tcn_ws is None or self._tcn_ws.numel() < need):
+            self._tcn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._tcn_ws if need else None
+        check(self.lib.hiertcn_tcn_forward(self._h, _ptr(x_ids), _ptr(sproj), n, L, _ptr(hidden), _ptr(ws),
+                                           ws.numel() if ws is not None else 0, self._stream()))
         return hidden
 
     def score_fused(self, hidden: torch.Tensor, y_ids: torch.Tensor, want_target=False, topk: int = 0):
@@ -237,10 +243,15 @@ class Engine:
         B, S, L = x_ids.shape
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
-        _req(mask, torch.float32, "mask", (B, S))
-        _req(state_in, torch.float32, "state_in", (B, self.HT))
+        if self.hier:
+            _req(mask, torch.float32, "mask", (B, S))
+            _req(state_in, torch.float32, "state_in", (B, self.HT))
+        else:  # single-level model_tcn: one sequence per lane, no carried state (run_nn_xing.py:36-41)
+            if S != 1:
+                raise HierTCNError("single-level model: x_ids is [B, 1, T]")
+            mask = state_in = None
         ws = self.workspace(B, S, L)
-        if state_out is None:
+        if state_out is None and self.hier:
             state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
         if metrics8 is None:
             metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)

@@ -16,7 +16,7 @@ import torch
 from .engine import Engine, metrics_dict
 from .params import init_params
 
-_SCOPES: Dict[str, "HierTCNModel"] = {}
+_SCOPES: Dict[str, object] = {}
 
 
 def _to_ids(a) -> np.ndarray:
@@ -136,11 +136,54 @@ class HierTCNModel:
                                   "run with args.train = False (the reference's own default, args.py:193)")
 
 
-def get_scope(args, name: str) -> HierTCNModel:
+class TcnModel:
+    """The single-level model (model.py:56-57,71-73; run with --model_type tcn): ids [B, T] ->
+    embedding (tcn/emb/kernel) -> TemporalConvNet -> scoring, no carried state.  Widths that are not a
+    multiple of 32 (BASELINE.json config 1: d = 100) are zero-padded on upload (params.pad_widths)."""
+
+    def __init__(self, args, params: Optional[dict] = None, name: str = "tcn", seed: int = 2):
+        from .params import pad_widths
+        self.args, self.name, self.hier = args, name, False
+        self.params = params if params is not None else init_params(args, seed, "tcn")
+        renamed = {("tcn" + k[len(name):] if k.startswith(name + "/") else k): v for k, v in self.params.items()}
+        self._dev_args, dev_params = pad_widths(args, renamed, "tcn")
+        self.engine = Engine(self._dev_args, hier=False)
+        self.engine.set_weights(dev_params, root="tcn")
+
+    def set_parameters(self, params: dict):
+        from .params import pad_widths
+        self.params = params
+        renamed = {("tcn" + k[len(self.name):] if k.startswith(self.name + "/") else k): v for k, v in params.items()}
+        self.engine.set_weights(pad_widths(self.args, renamed, "tcn")[1], root="tcn")
+
+    def eval_step(self, x, y, want_pred: bool = False):
+        """One sess.run of evaluate_nn's fetch list (run_nn_xing.py:43-47): x, y [B, T] ids."""
+        eng = self.engine
+        xi, yi = _to_ids(x), _to_ids(y)
+        B, T = xi.shape
+        xd = torch.from_numpy(np.ascontiguousarray(xi)).to(eng.device).view(B, 1, T)
+        yd = torch.from_numpy(np.ascontiguousarray(yi)).to(eng.device).view(B, 1, T)
+        out = eng.forward_eval(xd, yd, None, None, want_rows=True)
+        m = metrics_dict(out["metrics8"])
+        rank = out["rank"].cpu().numpy().astype(np.float32)
+        res = dict(loss=m["loss"], ranks_float_mean_user=m["rank_frac"], ranks_float=rank / float(eng.N),
+                   mask_y=(yi > 0).astype(np.float32), reciprocal_ranks_float_mean_user=m["mrr"],
+                   recall1_mean_user=m["recall1"], recall5_mean_user=m["recall5"], recall10_mean_user=m["recall10"],
+                   ranks=rank, user_count=m["user_count"])
+        if want_pred:
+            hid = eng.tcn_forward(xd.view(B, T), None)
+            res["pred"] = eng.score_logits(hid).view(B, T, -1).cpu().numpy()
+        return res
+
+    def train_step(self, x, y, lr):
+        raise NotImplementedError("the training step (backward + TF-form Adam) is not built yet; run with args.train = False")
+
+
+def get_scope(args, name: str):
     """tf.variable_scope(name, reuse=tf.AUTO_REUSE) (model_hier.py:28, model_tcn.py:26): the first
     use of a scope creates its variables (glorot / zeros / gate-bias 1.0), later uses share them."""
     if name not in _SCOPES:
-        _SCOPES[name] = HierTCNModel(args, None, name)
+        _SCOPES[name] = HierTCNModel(args, None, name) if name.startswith("hier") else TcnModel(args, None, name)
     return _SCOPES[name]
 
 

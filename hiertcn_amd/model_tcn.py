@@ -5,9 +5,9 @@
 
 Single-level use (model.py:71-73): x = ids [B, T]; the first dense of the reference
 (model_tcn.py:35 on a one-hot input) is the embedding lookup with row 0 -> 0.
-This build's fused low-level kernel covers T <= 32 and equal channel widths; the reference's
-6-block / T <= 500 single-level configuration (args.py:310-311) is the next row of SURVEY.md 8(f)
-and raises here rather than silently running somewhere else.
+The reference's single-level configuration (args.py:310-311: six blocks, channels
+[128,128,128,128,256,256], T <= 500, a Dense down-sample on the residual of block 4) runs on the
+layer-at-a-time kernels (csrc/tcn_layers.hip); short equal-width stacks take the fused kernel.
 """
 from __future__ import annotations
 

@@ -72,3 +72,38 @@ def init_params(args, seed: int = 2, model: str = "hier") -> Dict[str, np.ndarra
 
 def count_params(params) -> int:
     return int(sum(int(np.prod(v.shape)) for v in params.values()))
+
+
+def pad_widths(args, params: Dict[str, np.ndarray], model: str = "hier", multiple: int = 32):
+    """Zero-pad the channel axes (emb_dim, tcn_channel) up to a multiple of one MFMA tile, e.g. the
+    d=100 single-level configuration of BASELINE.json -> 128.  Padded channels are exactly zero
+    everywhere (zero embedding columns, zero kernel rows/columns, zero biases; relu(0) = 0 and a zero
+    row of the scoring kernel adds nothing), so every logit is unchanged.  Returns (args', params')
+    with the same TF names.  hidden_dim (GRU) is not padded: its gate arithmetic is not zero-preserving
+    (sigmoid(0) = 0.5), choose a multiple of 32."""
+    import copy
+
+    def up(c):
+        return -(-int(c) // multiple) * multiple
+
+    a = copy.copy(args)
+    E0, E1 = int(getattr(args, "emb_dim", 128)), up(getattr(args, "emb_dim", 128))
+    ch0 = [int(c) for c in args.tcn_channel]
+    ch1 = [up(c) for c in ch0]
+    a.emb_dim, a.tcn_channel = E1, ch1
+    want = param_shapes(a, model)
+    have = param_shapes(args, model)
+    if set(want) != set(have):   # padding must not change which blocks have a down-sample residual
+        raise ValueError(f"padding {ch0} -> {ch1} with emb {E0} -> {E1} changes the variable set: {sorted(set(want) ^ set(have))}")
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in want.items():
+        src = np.asarray(params[name], dtype=np.float32)
+        if name.endswith("tcn/emb/kernel") and model == "hier":   # [E + H*nl, E]: item rows then state rows
+            dst = np.zeros(shape, np.float32)
+            dst[:E0, :E0] = src[:E0]
+            dst[E1:, :E0] = src[E0:]
+        else:
+            dst = np.zeros(shape, np.float32)
+            dst[tuple(slice(0, n) for n in src.shape)] = src
+        out[name] = dst
+    return a, out

@@ -1,0 +1,78 @@
+"""run_nn / evaluate_nn with the reference's control flow (run_nn_xing.py:10-98,101-192) for the
+single-level models; the TF session is replaced by a model handle (hiertcn_amd.model.TcnModel or
+anything with `eval_step(x, y)` / `train_step(x, y, lr)`).  No state is carried between batches.
+"""
+from __future__ import annotations
+
+import time
+
+from .run_common import EpochMeter, ScalarLog, scheduled_lr
+
+
+def evaluate_nn(args, loader, sess, prefix="test", warm_start=None):
+    """-> (summary, summary_val, time_load, time_run), the tuple of run_nn_xing.py:98."""
+    if warm_start if warm_start is not None else getattr(args, "warm_start", False):
+        raise NotImplementedError("warm-start masks (model.py:102-103) are outside the hot path")
+    model = sess
+    time_load = time_run = 0.0
+    meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) else None, final_header=False)
+    step = None
+    while True:  # :31
+        t1 = time.time()
+        batch_x, batch_y, _info = loader.get_batch()
+        t2 = time.time()
+        step = model.eval_step(batch_x, batch_y)
+        meter.add(step)
+        t3 = time.time()
+        time_load += t2 - t1
+        time_run += t3 - t2
+        if loader.done:  # :72
+            break
+    summary = meter.finish()
+    return summary, {k: v for k, v in step.items() if isinstance(v, float)}, time_load, time_run
+
+
+def run_nn(args, loader_train, loader_validate, loader_test, warm_start=None, sess=None):
+    """run_nn_xing.py:101-192: same epoch / lr / save / test cadence as run_hier, no carried state."""
+    from . import checkpoint
+    from .model import TcnModel
+
+    model = sess if sess is not None else TcnModel(args)
+    epoch = 0
+    if args.load:
+        fname = args.load_path + str(args.load_epoch) + ".ckpt"
+        try:
+            model.set_parameters(checkpoint.load(fname))
+            print("Model restored: {}".format(fname))
+            epoch = args.load_epoch + 1
+        except Exception:
+            print("No ckpt found: {}, train from scratch".format(fname))
+            epoch = 0
+    train_writer = ScalarLog(args.log_path + "train/")
+    validate_writer = ScalarLog(args.log_path + "validate/")
+    test_writer = ScalarLog(args.log_path + "test/")
+    while epoch <= args.epoch_max:
+        if args.train:
+            lr = scheduled_lr(args, epoch)
+            training_loss_epoch = 0.0
+            for _ in range(args.epoch_batches_train):
+                batch_x, batch_y, _info = loader_train.get_batch()
+                training_loss_epoch += float(model.train_step(batch_x, batch_y, lr)["loss"])
+            training_loss_epoch /= args.epoch_batches_train
+            train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
+            if args.save and epoch % args.save_epoch == 0 and epoch != 0:
+                fname = args.save_path + str(epoch) + ".ckpt"
+                checkpoint.save(fname, model.params)
+                print("Model saved in path: %s" % fname)
+        if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:
+            if args.validate:
+                summary, _, _, _ = evaluate_nn(args, loader_validate, model, prefix="validate")
+                validate_writer.add_summary(summary, epoch)
+            if args.test:
+                summary, _, t_load, t_run = evaluate_nn(args, loader_test, model, prefix="test")
+                test_writer.add_summary(summary, epoch)
+                print("Step {}: test load {:.2f}s, test run {:.2f}s, {}".format(epoch, t_load, t_run, args.name))
+            if not args.train:
+                break
+        epoch += 1
+    return model

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 1
+#define HIERTCN_ABI_VERSION 2
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -138,9 +138,15 @@ int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask,
 
 /* model.py:59-61 + model_hier.py:50 + model_tcn.py:35-36: ids -> last TCN activations.
  * x_ids [n_sessions][L]; sproj [n_sessions][E] or NULL (single-level) ->
- * hidden [n_sessions*L][C_last] bf16. */
+ * hidden [n_sessions*L][C_last] bf16.
+ * Two device paths, same results: the fused kernel (every width == emb_dim in {64,128,256}, L <= 32:
+ * gather + projection + all blocks in LDS; needs no workspace) and the layer-at-a-time path (any
+ * L <= 4096, per-block widths in multiples of 32, Dense down-sample residual where Cin != Cout --
+ * the single-level model_tcn of model.py:71-73 with T <= 500 and channels [128,128,128,128,256,256]),
+ * which needs hiertcn_tcn_workspace_bytes() bytes of 256-byte aligned scratch. */
+size_t hiertcn_tcn_workspace_bytes(hiertcn_handle_t h, int64_t n_sessions, int32_t L);
 int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* sproj, int64_t n_sessions,
-                        int32_t L, uint16_t* hidden, void* stream);
+                        int32_t L, uint16_t* hidden, void* workspace, size_t workspace_bytes, void* stream);
 
 /* model_tcn.py:41 + model.py:105 + loss.py:21,179(,120) fused: logits are never written. */
 int hiertcn_score_fused(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y_ids, int64_t R,
@@ -162,7 +168,9 @@ size_t hiertcn_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t
 
 /* One evaluation step = the fetch list of run_hier_xing.py:145-149 without `pred`:
  * pool -> gru scan -> tcn -> fused scoring -> lane metrics, all enqueued on `stream`.
- * score_out may be NULL (then rank/ce live in the workspace only). */
+ * score_out may be NULL (then rank/ce live in the workspace only).
+ * Single-level handles (hier == 0; run_nn_xing.py:43-47's fetch list): S must be 1, L = T, x_ids/y_ids
+ * [B][1][T]; mask, state_in, state_out are ignored and may be NULL. */
 int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask,
                          const float* state_in, int32_t B, int32_t S, int32_t L, void* workspace,
                          size_t workspace_bytes, float* state_out, double* metrics8,
