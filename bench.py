@@ -150,6 +150,18 @@ def main():
     achieved = flops_per_launch / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
     last = metrics_dict(m8[-1])
 
+    # HBM/fabric bytes per scoring launch come from a separate rocprofv3 --pmc run of this same command
+    # (bench.py cannot read PMC counters itself); used only when that run had the same rows per launch.
+    traffic, traffic_src = None, None
+    try:
+        with open(os.path.join(ROOT, "profiles", "score_traffic.json")) as f:
+            tj = json.load(f)
+        if int(tj["rows_per_launch"]) == rows_per_launch and not a.ragged:
+            traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
+            traffic_src = tj["source"]
+    except (OSError, KeyError, ValueError):
+        pass
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the checker, timed on this host's cores on a bounded sample of the SAME workload
@@ -185,12 +197,15 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_score<256,false> (fused scoring GEMM + loss/rank epilogue)",
+                "kernel": "k_score_pipe<256,5> (fused scoring GEMM + loss/rank epilogue)",
                 "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch through the L2's memory-side port (Infinity-Cache hits included)",
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": rows_per_launch * (2 * DIM + 4 + 8) + 2 * DIM * N_ITEMS + 4 * N_ITEMS,
                 "launch_ms": round(score_ms, 4),
                 "launches_timed": int(launches),
                 "flops_per_launch": flops_per_launch,
