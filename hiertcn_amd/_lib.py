@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 2
+ABI_VERSION = 3
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -54,6 +54,13 @@ SYMBOLS = {
     "hiertcn_tcn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "hiertcn_tcn_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                        C.c_void_p]),
+    "hiertcn_train_enable": (C.c_int, [C.c_void_p]),
+    "hiertcn_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
+    "hiertcn_train_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
+                                                  C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hiertcn_grad_arena": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "hiertcn_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hiertcn_export_weights": (C.c_int, [C.c_void_p, C.POINTER(Weights), C.c_int32, C.c_void_p]),
     "hiertcn_score_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ScoreOut), C.c_void_p]),
     "hiertcn_score_logits": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]),
     "hiertcn_metrics": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),

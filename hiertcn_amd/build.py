@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhiertcn_gfx950.so")
-SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "metrics.hip"]
+SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "metrics.hip", "train.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function",
          "-fno-gpu-rdc", "-D__HIP_PLATFORM_AMD__"]
 
@@ -33,7 +33,7 @@ def _stale(target, deps):
 def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -59,7 +59,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or _stale(LIB, objs):
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
+        # rocBLAS: plain GEMMs of the training backward pass only (csrc/train.hip)
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (r.stdout, r.stderr))

@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "common.h"
+#include "train.h"
 
 static thread_local char g_err[512] = "";
 
@@ -33,6 +34,7 @@ struct hiertcn_ctx {
   bool weights_set;
   std::vector<void*> allocs;
   double* metric_scratch;
+  TrainCtx train;
   // timing hook
   bool timing;
   std::vector<hipEvent_t> ev_begin, ev_end;
@@ -145,6 +147,7 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
 
 int hiertcn_destroy(hiertcn_handle_t h) {
   if (!h) return HIERTCN_OK;
+  train_destroy(h->train);
   for (void* p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev_begin) (void)hipEventDestroy(e);
   for (hipEvent_t e : h->ev_end) (void)hipEventDestroy(e);
@@ -199,6 +202,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
       HIP_TRY(launch_copy_pad_f32(w->gru_cand_bias[l], m.gru_bc[l], m.H, m.H, 0.f, st));
     }
   }
+  if (h->train.enabled) HIP_TRY(train_fill_masters(m, h->train, w, st));
   h->weights_set = true;
   return HIERTCN_OK;
 }
@@ -368,6 +372,58 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
     if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
     HIP_TRY(launch_metrics_scratch(h->m, so.rank, so.ce, y_ids, B, S * L, metrics8, h->metric_scratch, st));
   }
+  return HIERTCN_OK;
+}
+
+// ---- training ----------------------------------------------------------------------
+int hiertcn_train_enable(hiertcn_handle_t h) {
+  if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
+  if (h->train.enabled) return HIERTCN_OK;
+  if (h->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_train_enable must precede hiertcn_set_weights (the fp32 masters are filled there)");
+  if (!h->m.hier) return fail(HIERTCN_ERR_INVALID, "training is built for model_hier only");
+  HIP_TRY(train_enable(h->m, h->train));
+  return HIERTCN_OK;
+}
+
+size_t hiertcn_train_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t L) {
+  if (!h || B < 1 || S < 1 || L < 1) return 0;
+  return train_workspace_bytes(h->m, B, S, L);
+}
+
+int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
+                                   int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out,
+                                   double* metrics8, void* stream) {
+  CHECK_READY(h);
+  if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
+  if (!x_ids || !y_ids || !mask || !state_in || !workspace || !state_out || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
+  if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, state_in, B, S, L, workspace, state_out, metrics8, h->metric_scratch,
+                             reinterpret_cast<hipStream_t>(stream)) != 0)
+    return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
+  return HIERTCN_OK;
+}
+
+int hiertcn_grad_arena(hiertcn_handle_t h, float** grad, size_t* count) {
+  if (!h || !h->train.enabled || !grad || !count) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
+  *grad = h->train.grad();
+  *count = h->train.total;
+  return HIERTCN_OK;
+}
+
+int hiertcn_adam_step(hiertcn_handle_t h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  CHECK_READY(h);
+  if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
+  HIP_TRY(train_adam(h->m, h->train, lr, beta1, beta2, eps, grad_scale, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+int hiertcn_export_weights(hiertcn_handle_t h, const hiertcn_weights_t* dst, int32_t which, void* stream) {
+  CHECK_READY(h);
+  if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
+  if (!dst || which < 0 || which > 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  HIP_TRY(train_export(h->m, h->train, dst, which, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
 

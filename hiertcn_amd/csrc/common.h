@@ -67,16 +67,36 @@ hipError_t launch_transpose_f32(const float* src, float* dst, int64_t rows, int6
 hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t npad, float padval, hipStream_t st);
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
 size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
+size_t gru_save_floats(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
-                           float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st);
+                           float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st, float* save = nullptr);
 size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
                               uint16_t* hidden, void* workspace, hipStream_t st);
+// one layer of the layer-at-a-time low level (tcn_layers.hip)
+struct LayerArgs {
+  const uint16_t* in;      // [n_seq * L][Cin]
+  uint16_t* out;           // [n_seq * L][Cout]
+  const uint16_t* W;       // [taps][Cout][Cin]
+  const float* bias;       // [Cout] or null
+  const float* seq_init;   // [n_seq][Cout] fp32 accumulator start per sequence (projection: state . Wp[E:]) or null
+  const uint16_t* Wres;    // [Cout][Cin] or null
+  const float* bres;       // [Cout] or null
+  int Cin, Cout, taps, dil, L;
+  int64_t n_seq;
+  uint16_t* c_out;         // optional [n_seq * L][Cout]: relu(conv + b) before the residual add (kept for training)
+  int linear;              // 1: out = conv (the 'emb' projection, model_tcn.py:35); 0: relu(relu(conv + b) + res)
+};
+
+hipError_t launch_tcn_layer(const LayerArgs& a, hipStream_t st);
+hipError_t launch_embed_rows(const ModelDev& m, const int32_t* ids, int64_t R, uint16_t* out, hipStream_t st);
 size_t tcn_layers_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
 hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L, uint16_t* hidden,
                              void* workspace, hipStream_t st);
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                         float* logits, hipStream_t st);
+hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse, const float* w,
+                                   int stg_begin, int stg_end, uint16_t* gout, hipStream_t st);
 hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,
                                   double* out8, double* scratch, hipStream_t st);
 #define HIERTCN_METRIC_BLOCKS_MAX 16384  // 256 lanes per block -> up to 4.19 M lanes per call

@@ -95,6 +95,7 @@ struct GemmArgs {
   const float* h; int ldh;             // GATES / CAND: the layer's old h slice
   const float* gates; int ldg;         // CAND
   const float* mask; int ldm;          // CAND: mask[m * ldm]
+  float* cand_out; int ldc;            // CAND, optional: the candidate c = tanh(.) (kept for the backward pass)
   int H;
   int rowmap_S;                        // STORE: >0 -> row m = b*(S+1)+s maps to out row b*S+s, s == S skipped
 };
@@ -176,10 +177,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
       const float4 uv = *reinterpret_cast<const float4*>(g.gates + (int64_t)m * g.ldg + g.H + n0);
       const float mk = g.mask[(int64_t)m * g.ldm];
       float hn[4];
-      hn[0] = uv.x * hv.x + (1.0f - uv.x) * tanhf(v[0]);
-      hn[1] = uv.y * hv.y + (1.0f - uv.y) * tanhf(v[1]);
-      hn[2] = uv.z * hv.z + (1.0f - uv.z) * tanhf(v[2]);
-      hn[3] = uv.w * hv.w + (1.0f - uv.w) * tanhf(v[3]);
+      const float c0 = tanhf(v[0]), c1 = tanhf(v[1]), c2 = tanhf(v[2]), c3 = tanhf(v[3]);
+      if (g.cand_out) *reinterpret_cast<float4*>(g.cand_out + (int64_t)m * g.ldc + n0) = make_float4(c0, c1, c2, c3);
+      hn[0] = uv.x * hv.x + (1.0f - uv.x) * c0;
+      hn[1] = uv.y * hv.y + (1.0f - uv.y) * c1;
+      hn[2] = uv.z * hv.z + (1.0f - uv.z) * c2;
+      hn[3] = uv.w * hv.w + (1.0f - uv.w) * c3;
       *reinterpret_cast<float4*>(g.out + (int64_t)m * g.ldo + n0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
       *reinterpret_cast<float4*>(g.out2 + (int64_t)m * g.ldo2 + n0) = make_float4(hn[0] * mk, hn[1] * mk, hn[2] * mk, hn[3] * mk);
     }
@@ -212,14 +215,20 @@ size_t gru_workspace_bytes(const ModelDev& m, int B, int S) {
   return sizeof(float) * ((size_t)B * (S + 1) * m.HT + (size_t)B * 2 * m.H + (size_t)B * m.H + (size_t)m.nl * B * m.H);
 }
 
+size_t gru_save_floats(const ModelDev& m, int B, int S) {
+  // per (slot, layer): gates [B][2H] + r*h [B][H] + candidate [B][H] + unmasked output [B][H]
+  return (size_t)S * m.nl * B * 5 * m.H;
+}
+
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
-                           float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st) {
+                           float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st, float* save) {
   if (B <= 0) return hipSuccess;
   const int E = m.E, H = m.H, HT = m.HT;
   float* hist = ws;                                  // [B][S+1][HT]
   float* gates = hist + (size_t)B * (S + 1) * HT;    // [B][2H]
   float* rh = gates + (size_t)B * 2 * H;             // [B][H]
   float* hcur = rh + (size_t)B * H;                  // [nl][B][H]
+  const size_t cell = (size_t)B * 5 * H;             // one (slot, layer) record of `save`
   const int64_t hs = (int64_t)(S + 1) * HT;          // row stride of the history
   hipError_t e = copy_rows(state_in, HT, hist, hs, B, HT, st);
   if (e != hipSuccess) return e;
@@ -227,10 +236,17 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
     for (int l = 0; l < m.nl; l++) {
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      const float* in = (l == 0) ? pooled + (size_t)s * E : hcur + (size_t)(l - 1) * B * H;
+      const float* in = (l == 0) ? pooled + (size_t)s * E
+                        : (save ? save + ((size_t)s * m.nl + (l - 1)) * cell + (size_t)B * 4 * H : hcur + (size_t)(l - 1) * B * H);
       const int ldin = (l == 0) ? S * E : H;
       const int in_dim = (l == 0) ? E : H;
       const float* hold = hist + (size_t)s * HT + (size_t)l * H;
+      float* hout = hcur + (size_t)l * B * H;
+      if (save) {  // training: every (slot, layer) keeps its own gates / r*h / candidate / output (GruSaved in train.hip)
+        float* rec = save + ((size_t)s * m.nl + l) * cell;
+        gates = rec; rh = rec + (size_t)B * 2 * H; g.cand_out = rec + (size_t)B * 3 * H; g.ldc = H;
+        hout = rec + (size_t)B * 4 * H;
+      }
       g.M = B; g.H = H;
       g.A1 = in; g.lda1 = ldin; g.K1 = in_dim;
       g.A2 = hold; g.lda2 = (int)hs; g.K2 = H;
@@ -239,7 +255,7 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
       if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
       g.A2 = rh; g.lda2 = H;
       g.Wt = m.gru_wc[l]; g.bias = m.gru_bc[l]; g.N = H;
-      g.out = hcur + (size_t)l * B * H; g.ldo = H;
+      g.out = hout; g.ldo = H;
       g.out2 = hist + (size_t)(s + 1) * HT + (size_t)l * H; g.ldo2 = (int)hs;
       g.gates = gates; g.ldg = 2 * H;
       g.mask = mask + s; g.ldm = S;

@@ -142,7 +142,12 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
                                                          float* __restrict__ o_tgt, float* __restrict__ logits, int stagger,
                                                          unsigned long long* __restrict__ stamps = nullptr,
                                                          int32_t* __restrict__ o_topi = nullptr, float* __restrict__ o_topv = nullptr,
-                                                         int topk = 0) {
+                                                         int topk = 0, const float* __restrict__ g_lse = nullptr,
+                                                         const float* __restrict__ g_w = nullptr, int stg_begin = 0, int stg_end = -1) {
+  // LOGITS && MODE == 9: gradient build (training).  Instead of fp32 logits the kernel writes, for the stages
+  // [stg_begin, stg_end) only, G[r][n] = w_r * (exp(z_rn - lse_r) - [n == y_r]) as bf16 into `logits` viewed as
+  // uint16_t [R][(stg_end - stg_begin) * 64]: d loss / d z of model.py:111-117 + loss.py:21, never held for all N at once.
+  constexpr bool GRAD = LOGITS && MODE == 9;
   using G = ScGeom<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 2 stages + 2 x 64 bias floats
   const int tid = threadIdx.x;
@@ -174,11 +179,18 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     int64_t r = row0 + cbk * 32 + lr;
     myrow[cbk] = r;
     const int64_t rc = (r < R) ? r : (R - 1);
-    int yy = (LOGITS || r >= R) ? 0 : y[rc];
+    int yy = ((LOGITS && !GRAD) || r >= R) ? 0 : y[rc];
     myy[cbk] = (yy > 0 && yy < N) ? yy : 0;
     const uint16_t* hp = hidden + rc * C + 8 * lh;
 #pragma unroll
     for (int s = 0; s < G::KS; s++) hf[cbk][s] = *reinterpret_cast<const uint4*>(hp + 16 * s);
+  }
+  float my_lse[NB], my_w[NB];
+#pragma unroll
+  for (int cbk = 0; cbk < NB; cbk++) {
+    const bool live = GRAD && myrow[cbk] < R && myy[cbk] > 0;
+    my_lse[cbk] = live ? g_lse[myrow[cbk]] : 0.f;
+    my_w[cbk] = live ? g_w[myrow[cbk]] : 0.f;
   }
 
   RowState st[NB];
@@ -268,7 +280,34 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     }
   };
 
-  stage_issue(0, 0);
+  auto store_grad = [&](int stg, int ib) {
+    uint16_t* gout = reinterpret_cast<uint16_t*>(logits);
+    const int64_t NC = (int64_t)(stg_end - stg_begin) * SC_STAGE;
+    const int item0 = stg * SC_STAGE + ib * 32 + 4 * lh;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int it = item0 + 8 * q;
+#pragma unroll
+      for (int cbk = 0; cbk < NB; cbk++) {
+        if (myrow[cbk] >= R) continue;
+        const f32x16& a = (cbk == 0) ? acc0 : acc1;
+        float g[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) {
+          const float p = __expf(a[4 * q + j] - my_lse[cbk]);      // softmax probability (pad items: exp(-inf) = 0)
+          g[j] = my_w[cbk] != 0.f ? my_w[cbk] * (p - ((it + j == myy[cbk]) ? 1.f : 0.f)) : 0.f;
+        }
+        uint2 o;
+        o.x = pack2bf(g[0], g[1]);
+        o.y = pack2bf(g[2], g[3]);
+        *reinterpret_cast<uint2*>(gout + myrow[cbk] * NC + (it - stg_begin * SC_STAGE)) = o;
+      }
+    }
+  };
+  const int stg_last = (GRAD && stg_end >= 0) ? stg_end : n_stages;
+  const int stg_first = GRAD ? stg_begin : 0;
+
+  stage_issue(stg_first, 0);
   __syncthreads();  // (hipcc drains vmcnt(0) here because an LDS-DMA is in flight)
 
   unsigned long long tsum[SC_NSTAMP];
@@ -281,10 +320,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     tprev = tn_;                            \
   }
   unsigned long long tprev = STAMP ? stamp() : 0;
-  for (int stg = 0; stg < n_stages; stg++) {
-    const int buf = stg & 1;
+  for (int stg = stg_first; stg < stg_last; stg++) {
+    const int buf = (stg - stg_first) & 1;
     // buf^1 was last read (by MFMA operand / bias reads) before the barrier that ended stage stg-1
-    if (stg + 1 < n_stages) stage_issue(stg + 1, buf ^ 1);
+    if (stg + 1 < stg_last) stage_issue(stg + 1, buf ^ 1);
     STAMP_AT(0)
     if (late && stg > 0) {  // deferred epilogue of the previous stage's second item block
       epilogue<MODE>(acc0, st[0]);
@@ -293,7 +332,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     STAMP_AT(1)
     mfma_tile(buf, 0);
     STAMP_AT(2)
-    if (LOGITS) {
+    if (GRAD) {
+      store_grad(stg, 0);
+    } else if (LOGITS) {
       store_logits(stg, 0);
     } else {
       epilogue<MODE>(acc0, st[0]);
@@ -306,7 +347,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
     STAMP_AT(3)
     mfma_tile(buf, 1);
     STAMP_AT(4)
-    if (LOGITS) {
+    if (GRAD) {
+      store_grad(stg, 1);
+    } else if (LOGITS) {
       store_logits(stg, 1);
     } else if (!late) {
       epilogue<MODE>(acc0, st[0]);
@@ -678,7 +721,8 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out->rank, out->ce,
-                     out->target, (float*)nullptr, 0, (unsigned long long*)nullptr, out->topk_idx, out->topk_val, (int)out->topk);
+                     out->target, (float*)nullptr, 0, (unsigned long long*)nullptr, out->topk_idx, out->topk_val, (int)out->topk,
+                     (const float*)nullptr, (const float*)nullptr, 0, -1);
   return hipGetLastError();
 }
 
@@ -742,6 +786,33 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   if (mode == 1) return launch_score_v<C, false, 1>(m, hidden, y, R, out, nullptr, stagger, st);
   if (mode == 2) return launch_score_v<C, false, 2>(m, hidden, y, R, out, nullptr, stagger, st);
   return launch_score_v<C, false, 0>(m, hidden, y, R, out, nullptr, stagger, st);
+}
+
+template <int C>
+static hipError_t launch_score_grad_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse,
+                                      const float* w, int stg_begin, int stg_end, uint16_t* gout, hipStream_t st) {
+  using G = ScGeom<C>;
+  const size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
+  const unsigned blocks = (unsigned)((R + 511) / 512);
+  auto kern = k_score<C, true, 9>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, (int32_t*)nullptr,
+                     (float*)nullptr, (float*)nullptr, reinterpret_cast<float*>(gout), 0, (unsigned long long*)nullptr, (int32_t*)nullptr,
+                     (float*)nullptr, 0, lse, w, stg_begin, stg_end);
+  return hipGetLastError();
+}
+
+// d loss / d logits for the items [stg_begin*64, stg_end*64) as bf16 [R][(stg_end-stg_begin)*64] (training backward)
+hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse, const float* w,
+                                   int stg_begin, int stg_end, uint16_t* gout, hipStream_t st) {
+  if (R <= 0 || stg_end <= stg_begin) return hipSuccess;
+  switch (m.Clast) {
+    case 64: return launch_score_grad_c<64>(m, hidden, y, R, lse, w, stg_begin, stg_end, gout, st);
+    case 128: return launch_score_grad_c<128>(m, hidden, y, R, lse, w, stg_begin, stg_end, gout, st);
+    case 256: return launch_score_grad_c<256>(m, hidden, y, R, lse, w, stg_begin, stg_end, gout, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,

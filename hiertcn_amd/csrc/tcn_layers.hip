@@ -12,19 +12,6 @@
 // accumulation order as the fused kernel, so both produce bitwise identical activations.
 #include "common.h"
 
-struct LayerArgs {
-  const uint16_t* in;      // [n_seq * L][Cin]
-  uint16_t* out;           // [n_seq * L][Cout]
-  const uint16_t* W;       // [taps][Cout][Cin]
-  const float* bias;       // [Cout] or null
-  const float* seq_init;   // [n_seq][Cout] fp32 accumulator start per sequence (projection: state . Wp[E:]) or null
-  const uint16_t* Wres;    // [Cout][Cin] or null
-  const float* bres;       // [Cout] or null
-  int Cin, Cout, taps, dil, L;
-  int64_t n_seq;
-  int linear;              // 1: out = conv (the 'emb' projection, model_tcn.py:35); 0: relu(relu(conv + b) + res)
-};
-
 __global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -97,6 +84,12 @@ __global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
         r[0] = bf2f((uint16_t)(res.x & 0xffff)); r[1] = bf2f((uint16_t)(res.x >> 16));
         r[2] = bf2f((uint16_t)(res.y & 0xffff)); r[3] = bf2f((uint16_t)(res.y >> 16));
       }
+      if (a.c_out) {   // training: keep relu(conv + b) -- the backward pass needs its sign pattern
+        uint2 co;
+        co.x = pack2bf(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+        co.y = pack2bf(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+        *reinterpret_cast<uint2*>(a.c_out + (row0 + t) * a.Cout + c0) = co;
+      }
 #pragma unroll
       for (int j = 0; j < 4; j++) v[j] = fmaxf(fmaxf(v[j], 0.f) + r[j], 0.f);
     }
@@ -120,6 +113,12 @@ __global__ __launch_bounds__(256) void k_embed_rows(const uint16_t* __restrict__
   *reinterpret_cast<uint4*>(out + r * E + c * 8) = *reinterpret_cast<const uint4*>(emb + (int64_t)id * E + c * 8);
 }
 
+hipError_t launch_embed_rows(const ModelDev& m, const int32_t* ids, int64_t R, uint16_t* out, hipStream_t st) {
+  const int64_t n = R * (m.E / 8);
+  hipLaunchKernelGGL(k_embed_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.emb, ids, R, m.E, out);
+  return hipGetLastError();
+}
+
 static int max_width(const ModelDev& m) {
   int w = m.E;
   for (int i = 0; i < m.n_blocks; i++) w = m.C[i] > w ? m.C[i] : w;
@@ -132,7 +131,7 @@ size_t tcn_layers_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) 
   return 2 * one;
 }
 
-static hipError_t launch_layer(const LayerArgs& a, hipStream_t st) {
+hipError_t launch_tcn_layer(const LayerArgs& a, hipStream_t st) {
   const int64_t tiles = a.n_seq * ((a.L + 31) / 32) * (a.Cout / 32);
   hipLaunchKernelGGL(k_tcn_layer, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
   return hipGetLastError();
@@ -155,7 +154,7 @@ hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* s
     LayerArgs a = {};
     a.in = buf[cur]; a.out = buf[cur ^ 1]; a.W = m.projT; a.seq_init = sproj;
     a.Cin = m.E; a.Cout = m.E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sessions; a.linear = 1;
-    hipError_t e = launch_layer(a, st);
+    hipError_t e = launch_tcn_layer(a, st);
     if (e != hipSuccess) return e;
     cur ^= 1;
   }
@@ -165,7 +164,7 @@ hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* s
     a.out = (i == m.n_blocks - 1) ? hidden : buf[cur ^ 1];
     a.W = m.convT[i]; a.bias = m.conv_bias[i]; a.Wres = m.resT[i]; a.bres = m.res_bias[i];
     a.Cin = cin; a.Cout = m.C[i]; a.taps = m.K; a.dil = 1 << i; a.L = L; a.n_seq = n_sessions; a.linear = 0;
-    hipError_t e = launch_layer(a, st);
+    hipError_t e = launch_tcn_layer(a, st);
     if (e != hipSuccess) return e;
     cur ^= 1;
     cin = m.C[i];

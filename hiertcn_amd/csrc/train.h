@@ -1,0 +1,43 @@
+// Training state of one handle: fp32 master weights, gradients and the two Adam
+// moments of every variable, kept in the INTERNAL layouts of ModelDev (Adam is elementwise, so the layout
+// is free; exporting to the reference's TF layouts is a transpose per tensor).
+#pragma once
+#include "common.h"
+
+struct TrainSeg {
+  size_t off = 0, n = 0;  // in floats, inside each of the four arenas
+};
+
+struct TrainCtx {
+  bool enabled = false;
+  float* arena = nullptr;  // [4][total]: master | grad | m | v
+  size_t total = 0;
+  TrainSeg emb, emb_bias, projT, projS, outT, out_bias;
+  TrainSeg convT[HIERTCN_MAX_BLOCKS], conv_bias[HIERTCN_MAX_BLOCKS];
+  TrainSeg wg[HIERTCN_MAX_LAYERS], bg[HIERTCN_MAX_LAYERS], wc[HIERTCN_MAX_LAYERS], bc[HIERTCN_MAX_LAYERS];
+  void* blas = nullptr;  // rocblas_handle
+  int64_t step = 0;      // Adam time step t
+  float* master() const { return arena; }
+  float* grad() const { return arena + total; }
+  float* mom1() const { return arena + 2 * total; }
+  float* mom2() const { return arena + 3 * total; }
+};
+
+const char* train_last_error();
+// lays out the segments (no allocation); returns total floats per arena
+size_t train_layout(const ModelDev& m, TrainCtx& t);
+// allocates the arenas + the rocBLAS handle and points ModelDev's fp32 tensors INTO the master arena
+hipError_t train_enable(ModelDev& m, TrainCtx& t);
+void train_destroy(TrainCtx& t);
+// fp32 masters of the bf16-stored tensors, from the reference-layout sources (called by hiertcn_set_weights)
+hipError_t train_fill_masters(const ModelDev& m, TrainCtx& t, const hiertcn_weights_t* w, hipStream_t st);
+// bf16 device copies (item table, projection, conv kernels, scoring kernel) re-derived from the masters
+hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t st);
+size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L);
+// forward (training mode: activations kept) + loss + backward of every variable into t.grad(); returns 0 or -1 (train_last_error)
+int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y, const float* mask, const float* state_in, int B,
+                           int S, int L, void* ws, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st);
+// TF-1.x AdamOptimizer (model.py:139): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v updates; theta -= lr_t*m/(sqrt(v)+eps)
+hipError_t train_adam(const ModelDev& m, TrainCtx& t, float lr, float beta1, float beta2, float eps, float grad_scale, hipStream_t st);
+// which = 0: masters, 1: gradients -> fp32 tensors in the reference layouts (device destinations)
+hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weights_t* dst, int which, hipStream_t st);

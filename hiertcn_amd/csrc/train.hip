@@ -1,0 +1,686 @@
+// Training step of the HierTCN path: model.py:102-117 (masked lane-mean cross
+// entropy) differentiated through model_tcn.py:41 (scoring), customized_tcn_cell.py:109-127 (blocks),
+// model_tcn.py:35 / model_hier.py:50,54-55 (projection, item embedding), model_hier.py:83-93 (session mean-pool,
+// GRU across the S in-batch slots, mask reset) and applied with TF-1.x Adam (model.py:139-141).  No gradient
+// crosses the batch boundary: state_in is data (run_hier_xing.py:291,301).
+//
+// First build, correctness first.  The d-logits matrix [rows, N] is never held whole: the scoring kernel
+// re-computes it 64-item stage by stage and writes bf16 chunks G[rows, NC]; the two products per chunk
+// (d hidden += G . Wo_chunk^T, d Wo_chunk = hidden^T . G) and every other backward matrix product are PLAIN
+// GEMMs and go to rocBLAS (bf16 inputs / fp32 accumulate for the low level, fp32 for the GRU); the pieces
+// around them (masks of the relus, causal shifts, scatter-adds into the item table, gate derivatives, Adam)
+// are hand-written, bandwidth-bound kernels.  Gradients pass straight through the bf16 roundings of the
+// forward pass.  Restrictions of this build: model_hier with equal widths (no Dense down-sample residual).
+#include <rocblas/rocblas.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "train.h"
+
+static thread_local char g_terr[512] = "";
+const char* train_last_error() { return g_terr; }
+static int tfail(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_terr, sizeof(g_terr), fmt, ap);
+  va_end(ap);
+  return -1;
+}
+#define T_HIP(expr)                                                                                      \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return tfail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+#define T_BLAS(expr)                                                                          \
+  do {                                                                                        \
+    rocblas_status s_ = (expr);                                                               \
+    if (s_ != rocblas_status_success) return tfail("%s failed: rocblas_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
+  } while (0)
+
+static size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+size_t train_layout(const ModelDev& m, TrainCtx& t) {
+  size_t off = 0;
+  auto seg = [&](TrainSeg& s, size_t n) { s.off = off; s.n = n; off += al64(n); };
+  seg(t.emb, (size_t)m.N * m.E);
+  seg(t.outT, (size_t)m.NP * m.Clast);
+  seg(t.out_bias, (size_t)m.NP);
+  seg(t.emb_bias, (size_t)m.E);
+  seg(t.projT, (size_t)m.E * m.E);
+  seg(t.projS, (size_t)m.E * m.HT);
+  for (int i = 0, cin = m.E; i < m.n_blocks; cin = m.C[i], i++) {
+    seg(t.convT[i], (size_t)m.K * m.C[i] * cin);
+    seg(t.conv_bias[i], (size_t)m.C[i]);
+  }
+  for (int l = 0; l < m.nl; l++) {
+    const int in = (l == 0) ? m.E : m.H;
+    seg(t.wg[l], (size_t)(in + m.H) * 2 * m.H);
+    seg(t.bg[l], (size_t)2 * m.H);
+    seg(t.wc[l], (size_t)(in + m.H) * m.H);
+    seg(t.bc[l], (size_t)m.H);
+  }
+  t.total = off;
+  return off;
+}
+
+hipError_t train_enable(ModelDev& m, TrainCtx& t) {
+  train_layout(m, t);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.arena), 4 * t.total * sizeof(float));
+  if (e != hipSuccess) return e;
+  if ((e = hipMemset(t.arena, 0, 4 * t.total * sizeof(float))) != hipSuccess) return e;
+  rocblas_handle hdl = nullptr;
+  if (rocblas_create_handle(&hdl) != rocblas_status_success) return hipErrorUnknown;
+  rocblas_set_pointer_mode(hdl, rocblas_pointer_mode_host);
+  t.blas = hdl;
+  // the fp32-stored tensors ARE their masters from now on (the conversion kernels of set_weights write into the arena)
+  float* M = t.master();
+  m.out_bias = M + t.out_bias.off;
+  m.emb_bias = M + t.emb_bias.off;
+  m.projS = M + t.projS.off;
+  for (int i = 0; i < m.n_blocks; i++) m.conv_bias[i] = M + t.conv_bias[i].off;
+  for (int l = 0; l < m.nl; l++) {
+    m.gru_wg[l] = M + t.wg[l].off; m.gru_bg[l] = M + t.bg[l].off;
+    m.gru_wc[l] = M + t.wc[l].off; m.gru_bc[l] = M + t.bc[l].off;
+  }
+  t.enabled = true;
+  t.step = 0;
+  return hipSuccess;
+}
+
+void train_destroy(TrainCtx& t) {
+  if (t.blas) rocblas_destroy_handle(reinterpret_cast<rocblas_handle>(t.blas));
+  if (t.arena) (void)hipFree(t.arena);
+  t.blas = nullptr; t.arena = nullptr; t.enabled = false;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// small kernels
+// ---------------------------------------------------------------------------------------------------------
+__global__ void k_cast_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t n, int64_t zero_first) {
+  int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  const int64_t stride = (int64_t)gridDim.x * blockDim.x * 4;
+  for (; i < n; i += stride) {
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (i + j < n) dst[i + j] = (i + j < zero_first) ? (uint16_t)0 : f2bf(src[i + j]);
+  }
+}
+static hipError_t cast_bf16(const float* src, uint16_t* dst, int64_t n, int64_t zero_first, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  int64_t blocks = (n / 4 + 255) / 256;
+  if (blocks > 8192) blocks = 8192;
+  if (blocks < 1) blocks = 1;
+  hipLaunchKernelGGL(k_cast_bf16, dim3((unsigned)blocks), dim3(256), 0, st, src, dst, n, zero_first);
+  return hipGetLastError();
+}
+
+hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t st) {
+  const float* M = t.master();
+  hipError_t e;
+  if ((e = cast_bf16(M + t.emb.off, m.emb, (int64_t)t.emb.n, m.E, st)) != hipSuccess) return e;  // row 0 = null id -> zeros (model.py:59)
+  if ((e = cast_bf16(M + t.outT.off, m.outT, (int64_t)t.outT.n, 0, st)) != hipSuccess) return e;
+  if (m.hier && (e = cast_bf16(M + t.projT.off, m.projT, (int64_t)t.projT.n, 0, st)) != hipSuccess) return e;
+  for (int i = 0; i < m.n_blocks; i++)
+    if ((e = cast_bf16(M + t.convT[i].off, m.convT[i], (int64_t)t.convT[i].n, 0, st)) != hipSuccess) return e;
+  return hipSuccess;
+}
+
+hipError_t train_fill_masters(const ModelDev& m, TrainCtx& t, const hiertcn_weights_t* w, hipStream_t st) {
+  float* M = t.master();
+  hipError_t e;
+  const int E = m.E;
+  if ((e = hipMemcpyAsync(M + t.emb.off, w->emb_kernel, t.emb.n * sizeof(float), hipMemcpyDeviceToDevice, st)) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(M + t.outT.off, 0, t.outT.n * sizeof(float), st)) != hipSuccess) return e;
+  if ((e = launch_transpose_f32(w->out_kernel, M + t.outT.off, m.Clast, m.N, st)) != hipSuccess) return e;  // [C][N] -> [N][C]
+  if (m.hier && (e = launch_transpose_f32(w->proj_kernel, M + t.projT.off, E, E, st)) != hipSuccess) return e;  // rows [0,E) -> [Eout][Ein]
+  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+    const int cout = m.C[i];
+    for (int j = 0; j < m.K; j++)
+      if ((e = launch_transpose_f32(w->conv_kernel[i] + (size_t)j * cin * cout, M + t.convT[i].off + (size_t)j * cin * cout, cin, cout, st)) !=
+          hipSuccess)
+        return e;
+  }
+  t.step = 0;
+  if ((e = hipMemsetAsync(t.mom1(), 0, 2 * t.total * sizeof(float), st)) != hipSuccess) return e;  // m and v
+  return hipSuccess;
+}
+
+// act[b] = number of valid steps of lane b; users += 1 for every lane with at least one (model.py:112-113)
+__global__ __launch_bounds__(256) void k_lane_act(const int32_t* __restrict__ y, int T, float* __restrict__ act, float* __restrict__ users) {
+  __shared__ int red[256];
+  const int b = blockIdx.x;
+  int c = 0;
+  for (int t = threadIdx.x; t < T; t += 256) c += y[(int64_t)b * T + t] > 0 ? 1 : 0;
+  red[threadIdx.x] = c;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    act[b] = (float)red[0];
+    if (red[0] > 0) atomicAdd(users, 1.0f);
+  }
+}
+
+// w[r] = d loss / d ce[r] = mask / ((act_b + 1e-6) * users) (model.py:111-117);  lse[r] = ce[r] + target[r]
+__global__ void k_row_weights(const int32_t* __restrict__ y, const float* __restrict__ act, const float* __restrict__ users,
+                              const float* __restrict__ ce, const float* __restrict__ tgt, int64_t R, int T, float* __restrict__ w,
+                              float* __restrict__ lse) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  const bool valid = y[r] > 0;
+  const float u = users[0];
+  w[r] = (valid && u > 0.f) ? 1.0f / ((act[r / T] + 1e-6f) * u) : 0.f;
+  lse[r] = valid ? ce[r] + tgt[r] : 0.f;
+}
+
+// out[c] += sum over rows of bf16 src[r][c]  (d bias of the scoring layer from a G chunk)
+__global__ __launch_bounds__(256) void k_colsum_bf16(const uint16_t* __restrict__ src, int64_t rows, int64_t ld, int cols,
+                                                     float* __restrict__ out) {
+  __shared__ float red[8][64];
+  const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;  // 32 column pairs x 8 row lanes
+  const int c0 = blockIdx.x * 64 + cx * 2;
+  const int64_t r0 = (int64_t)blockIdx.y * 4096;
+  const int64_t r1 = (r0 + 4096 < rows) ? r0 + 4096 : rows;
+  float s0 = 0.f, s1 = 0.f;
+  if (c0 < cols) {
+    for (int64_t r = r0 + ry; r < r1; r += 8) {
+      const uint32_t v = *reinterpret_cast<const uint32_t*>(src + r * ld + c0);
+      s0 += bf2f((uint16_t)(v & 0xffff));
+      s1 += bf2f((uint16_t)(v >> 16));
+    }
+  }
+  red[ry][cx * 2] = s0;
+  red[ry][cx * 2 + 1] = s1;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; i++) s += red[i][threadIdx.x];
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c < cols) atomicAdd(out + c, s);
+  }
+}
+
+// out[c] += sum over rows of fp32 src[r * ld + c]
+__global__ __launch_bounds__(256) void k_colsum_f32(const float* __restrict__ src, int64_t rows, int64_t ld, int cols, float* __restrict__ out) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ry = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  const int64_t r0 = (int64_t)blockIdx.y * 2048;
+  const int64_t r1 = (r0 + 2048 < rows) ? r0 + 2048 : rows;
+  float s = 0.f;
+  if (c < cols)
+    for (int64_t r = r0 + ry; r < r1; r += 4) s += src[r * ld + c];
+  red[ry][threadIdx.x & 63] = s;
+  __syncthreads();
+  if (threadIdx.x < 64 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+static hipError_t colsum_f32(const float* src, int64_t rows, int64_t ld, int cols, float* out, hipStream_t st) {
+  hipLaunchKernelGGL(k_colsum_f32, dim3((cols + 63) / 64, (unsigned)((rows + 2047) / 2048)), dim3(256), 0, st, src, rows, ld, cols, out);
+  return hipGetLastError();
+}
+
+// TemporalBlock backward, pointwise part (customized_tcn_cell.py:120-127): out = relu(c + res), c = relu(conv + b)
+//   ds = da * [out > 0]   (grad of the pre-activation sum; also the grad of the identity residual)
+//   dc = ds * [c > 0]     (grad of conv + b)
+__global__ void k_block_bwd(const float* __restrict__ da, const uint16_t* __restrict__ aout, const uint16_t* __restrict__ cact, int64_t n,
+                            float* __restrict__ ds, uint16_t* __restrict__ dc) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float4 g = *reinterpret_cast<const float4*>(da + i);
+  const uint2 ao = *reinterpret_cast<const uint2*>(aout + i);
+  const uint2 co = *reinterpret_cast<const uint2*>(cact + i);
+  const float gs[4] = {g.x, g.y, g.z, g.w};
+  const uint16_t a4[4] = {(uint16_t)(ao.x & 0xffff), (uint16_t)(ao.x >> 16), (uint16_t)(ao.y & 0xffff), (uint16_t)(ao.y >> 16)};
+  const uint16_t c4[4] = {(uint16_t)(co.x & 0xffff), (uint16_t)(co.x >> 16), (uint16_t)(co.y & 0xffff), (uint16_t)(co.y >> 16)};
+  float s4[4], d4[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    s4[j] = bf2f(a4[j]) > 0.f ? gs[j] : 0.f;
+    d4[j] = bf2f(c4[j]) > 0.f ? s4[j] : 0.f;
+  }
+  *reinterpret_cast<float4*>(ds + i) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+  uint2 o;
+  o.x = pack2bf(d4[0], d4[1]);
+  o.y = pack2bf(d4[2], d4[3]);
+  *reinterpret_cast<uint2*>(dc + i) = o;
+}
+
+// dst[seq][t][:] = src[seq][t - shift][:] when 0 <= t - shift < L, else 0  (causal shift forward, anti-causal for shift < 0)
+__global__ void k_shift_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t n_rows, int L, int C, int shift) {
+  const int ch = C >> 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_rows * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch);
+  const int t = (int)(r % L);
+  const int ts = t - shift;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (ts >= 0 && ts < L) v = *reinterpret_cast<const uint4*>(src + (r - shift) * C + c * 8);
+  *reinterpret_cast<uint4*>(dst + r * C + c * 8) = v;
+}
+
+// table[ids[r]][:] += rows[r][:] (fp32 atomics; id 0 = null id has no embedding: model.py:59)
+__global__ void k_scatter_add_rows(float* __restrict__ table, const int32_t* __restrict__ ids, const float* __restrict__ rows, int64_t R, int E) {
+  const int ch = E >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= R * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch) * 4;
+  const int id = ids[r];
+  if (id <= 0) return;
+  const float4 v = *reinterpret_cast<const float4*>(rows + r * E + c);
+  float* d = table + (int64_t)id * E + c;
+  atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+}
+
+// dst[(b*(S+1) + s)][e] = sum_t src[((b*S + s)*L + t)][e]; row s == S of every lane = 0  (d sproj, laid out like the state history)
+__global__ void k_segment_sum(const float* __restrict__ src, int B, int S, int L, int E, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * (S + 1) * E) return;
+  const int e = (int)(i % E);
+  const int64_t bs = i / E;
+  const int s = (int)(bs % (S + 1));
+  const int64_t b = bs / (S + 1);
+  float acc = 0.f;
+  if (s < S) {
+    const float* p = src + ((b * S + s) * L) * (int64_t)E + e;
+    for (int t = 0; t < L; t++) acc += p[(int64_t)t * E];
+  }
+  dst[i] = acc;
+}
+
+// session mean-pool backward (model_hier.py:83-85): table[y[sess][t]] += dpooled[sess] / cnt for valid t
+__global__ __launch_bounds__(256) void k_pool_bwd(float* __restrict__ table, const int32_t* __restrict__ y, const float* __restrict__ dpooled,
+                                                  int64_t n_sessions, int L, int E) {
+  const int64_t sess = blockIdx.x;
+  if (sess >= n_sessions) return;
+  int cnt = 0;
+  for (int t = 0; t < L; t++) cnt += y[sess * L + t] > 0 ? 1 : 0;
+  if (cnt == 0) return;
+  const float inv = 1.0f / (float)cnt;
+  for (int e = threadIdx.x; e < E; e += 256) {
+    const float g = dpooled[sess * E + e] * inv;
+    for (int t = 0; t < L; t++) {
+      const int id = y[sess * L + t];
+      if (id > 0) atomicAdd(table + (int64_t)id * E + e, g);
+    }
+  }
+}
+
+// ---- GRU backward, elementwise pieces (customed_gru_cell.py:323-337 differentiated) ----------------------
+// dhp: grad of the cell's (unmasked) output h' [B][H] (row stride ldd); extra: optional second grad term added to it.
+// gates [B][2H] = (r, u); cand c; h = old state slice (row stride ldh).
+//   dac = dh' (1-u) (1-c^2);  dag[:, H:] = dh' (h - c) u (1-u);  dhpart = dh' u
+__global__ void k_gru_bwd_a(const float* __restrict__ dhp, int ldd, const float* __restrict__ extra, const float* __restrict__ h, int ldh,
+                            const float* __restrict__ gates, const float* __restrict__ cand, int B, int H, float* __restrict__ dac,
+                            float* __restrict__ dag, float* __restrict__ dhpart) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * H) return;
+  const int64_t b = i / H;
+  const int k = (int)(i - b * H);
+  const float d = dhp[b * ldd + k] + (extra ? extra[i] : 0.f);
+  const float u = gates[b * 2 * H + H + k], c = cand[i], hv = h[b * ldh + k];
+  dac[i] = d * (1.f - u) * (1.f - c * c);
+  dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  dhpart[i] = d * u;
+}
+// drh = dcat_c[:, in:] (grad of r*h);  dag[:, :H] = drh h r (1-r);  dhpart += drh r
+__global__ void k_gru_bwd_b(const float* __restrict__ dcat_c, int K, int in, const float* __restrict__ h, int ldh,
+                            const float* __restrict__ gates, int B, int H, float* __restrict__ dag, float* __restrict__ dhpart) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * H) return;
+  const int64_t b = i / H;
+  const int k = (int)(i - b * H);
+  const float drh = dcat_c[b * K + in + k];
+  const float r = gates[b * 2 * H + k], hv = h[b * ldh + k];
+  dag[b * 2 * H + k] = drh * hv * r * (1.f - r);
+  dhpart[i] += drh * r;
+}
+// din = dcat_c[:, :in] + dcat_g[:, :in] -> dst_in (row stride ldi);  dh = dhpart + dcat_g[:, in:] -> dst_h (row stride ldo)
+__global__ void k_gru_bwd_c(const float* __restrict__ dcat_c, const float* __restrict__ dcat_g, int K, int in, const float* __restrict__ dhpart,
+                            int B, int H, float* __restrict__ dst_in, int ldi, float* __restrict__ dst_h, int ldo) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = in > H ? in : H;
+  if (i >= (int64_t)B * W) return;
+  const int64_t b = i / W;
+  const int k = (int)(i - b * W);
+  if (k < in) dst_in[b * ldi + k] = dcat_c[b * K + k] + dcat_g[b * K + k];
+  if (k < H) dst_h[b * ldo + k] = dhpart[b * H + k] + dcat_g[b * K + in + k];
+}
+// grad of the unmasked cell outputs of slot s: (carried + state-projection path) * mask  (model_hier.py:93)
+__global__ void k_gru_out_grad(const float* __restrict__ carried, const float* __restrict__ dsb, int64_t ld_dsb, const float* __restrict__ mask,
+                               int ldm, int B, int HT, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * HT) return;
+  const int64_t b = i / HT;
+  const int k = (int)(i - b * HT);
+  out[i] = (carried[i] + dsb[b * ld_dsb + k]) * mask[b * ldm];
+}
+
+__global__ void k_adam(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m1, float* __restrict__ m2, size_t n, float lr_t,
+                       float b1, float b2, float eps, float gscale) {
+  size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t stride = (size_t)gridDim.x * blockDim.x;
+  for (; i < n; i += stride) {
+    const float gv = g[i] * gscale;
+    const float a = b1 * m1[i] + (1.f - b1) * gv;
+    const float v = b2 * m2[i] + (1.f - b2) * gv * gv;
+    m1[i] = a;
+    m2[i] = v;
+    const float upd = lr_t * a / (sqrtf(v) + eps);
+    if (upd != 0.f) p[i] -= upd;   // (keeps -inf pad biases -inf: -inf - 0 would also be fine, NaN from inf*0 never arises)
+  }
+}
+
+hipError_t train_adam(const ModelDev& m, TrainCtx& t, float lr, float beta1, float beta2, float eps, float grad_scale, hipStream_t st) {
+  t.step += 1;
+  const double tt = (double)t.step;
+  const float lr_t = (float)(lr * sqrt(1.0 - pow((double)beta2, tt)) / (1.0 - pow((double)beta1, tt)));
+  size_t blocks = (t.total + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, t.master(), t.grad(), t.mom1(), t.mom2(), t.total, lr_t, beta1, beta2, eps,
+                     grad_scale);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return train_refresh_bf16(m, t, st);
+}
+
+hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weights_t* d, int which, hipStream_t st) {
+  const float* A = which == 0 ? t.master() : t.grad();
+  hipError_t e;
+  const int E = m.E, H = m.H;
+  auto cp = [&](const float* dst, const TrainSeg& s, size_t n) -> hipError_t {
+    return dst ? hipMemcpyAsync(const_cast<float*>(dst), A + s.off, n * sizeof(float), hipMemcpyDeviceToDevice, st) : hipSuccess;
+  };
+  auto tr = [&](const float* dst, const float* src, int64_t rows, int64_t cols) -> hipError_t {  // src [rows][cols] -> dst [cols][rows]
+    return dst ? launch_transpose_f32(src, const_cast<float*>(dst), rows, cols, st) : hipSuccess;
+  };
+  if ((e = cp(d->emb_kernel, t.emb, t.emb.n)) != hipSuccess) return e;
+  if ((e = tr(d->out_kernel, A + t.outT.off, m.N, m.Clast)) != hipSuccess) return e;   // [N][C] -> [C][N]
+  if ((e = cp(d->out_bias, t.out_bias, (size_t)m.N)) != hipSuccess) return e;
+  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+    const int cout = m.C[i];
+    for (int j = 0; j < m.K; j++)
+      if (d->conv_kernel[i] &&
+          (e = tr(d->conv_kernel[i] + (size_t)j * cin * cout, A + t.convT[i].off + (size_t)j * cin * cout, cout, cin)) != hipSuccess)
+        return e;
+    if ((e = cp(d->conv_bias[i], t.conv_bias[i], (size_t)cout)) != hipSuccess) return e;
+  }
+  if (m.hier) {
+    if ((e = cp(d->emb_bias, t.emb_bias, (size_t)E)) != hipSuccess) return e;
+    if (d->proj_kernel) {
+      if ((e = tr(d->proj_kernel, A + t.projT.off, E, E)) != hipSuccess) return e;                          // rows [0,E)
+      if ((e = tr(d->proj_kernel + (size_t)E * E, A + t.projS.off, E, m.HT)) != hipSuccess) return e;       // [E][HT] -> [HT][E]
+    }
+    for (int l = 0; l < m.nl; l++) {
+      const int K = ((l == 0) ? E : H) + H;
+      if ((e = tr(d->gru_gate_kernel[l], A + t.wg[l].off, 2 * H, K)) != hipSuccess) return e;
+      if ((e = cp(d->gru_gate_bias[l], t.bg[l], (size_t)2 * H)) != hipSuccess) return e;
+      if ((e = tr(d->gru_cand_kernel[l], A + t.wc[l].off, H, K)) != hipSuccess) return e;
+      if ((e = cp(d->gru_cand_bias[l], t.bc[l], (size_t)H)) != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// workspace
+// ---------------------------------------------------------------------------------------------------------
+struct TrainWs {
+  size_t pooled, sproj, gru_ws, gru_save, act[2 * HIERTCN_MAX_BLOCKS + 2], rank, ce, tgt, lse, w, lane_act, users;
+  size_t dA, dB, dsf, dcb, shb, dub, gchunk, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
+  size_t total;
+  int nc_stages;  // stages (of 64 items) per G chunk
+};
+
+static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
+  TrainWs w;
+  memset(&w, 0, sizeof(w));
+  size_t off = 0;
+  auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
+  const size_t R = (size_t)B * S * L, C = (size_t)m.E, HT = (size_t)m.HT, H = (size_t)m.H;
+  w.pooled = take((size_t)B * S * C * 4);
+  w.sproj = take((size_t)B * S * C * 4);
+  w.gru_ws = take(gru_workspace_bytes(m, B, S));
+  w.gru_save = take(gru_save_floats(m, B, S) * 4);
+  // activations kept for the backward pass: [0] embedded inputs, [1] projection output a^0, then per block: c_k, a^k
+  for (int i = 0; i < 2 + 2 * m.n_blocks; i++) w.act[i] = take(R * C * 2);
+  w.rank = take(R * 4); w.ce = take(R * 4); w.tgt = take(R * 4); w.lse = take(R * 4); w.w = take(R * 4);
+  w.lane_act = take((size_t)B * 4);
+  w.users = take(256);
+  w.dA = take(R * C * 4); w.dB = take(R * C * 4); w.dsf = take(R * C * 4);
+  w.dcb = take(R * C * 2); w.shb = take(R * C * 2); w.dub = take(R * C * 2);
+  // G chunk: at most ~4 GiB of bf16, at least one 64-item stage
+  const size_t budget = (size_t)4 << 30;
+  size_t st = budget / (R * 64 * 2);
+  const size_t nst = (size_t)m.NP / 64;
+  if (st < 1) st = 1;
+  if (st > nst) st = nst;
+  if (st > 128) st = 128;
+  w.nc_stages = (int)st;
+  w.gchunk = take(R * st * 64 * 2);
+  w.dsp_ext = take((size_t)B * (S + 1) * C * 4);
+  w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
+  w.dpooled = take((size_t)B * S * C * 4);
+  w.dstate[0] = take((size_t)B * HT * 4); w.dstate[1] = take((size_t)B * HT * 4);
+  w.dhp = take((size_t)B * HT * 4);
+  w.dac = take((size_t)B * H * 4); w.dag = take((size_t)B * 2 * H * 4); w.dhpart = take((size_t)B * H * 4);
+  const size_t Kmax = (C > H ? C : H) + H;
+  w.dcat_c = take((size_t)B * Kmax * 4); w.dcat_g = take((size_t)B * Kmax * 4); w.din_up = take((size_t)B * H * 4);
+  w.total = off;
+  return w;
+}
+
+size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L) { return train_ws(m, B, S, L).total; }
+
+// row-major helpers over rocBLAS (column-major):  C[M][N] (ldc) (+)= A[M][K] (lda) . B[K][N] (ldb), any operand optionally transposed
+// expressed directly in the column-major call: see the derivations next to each call site.
+static rocblas_status gemm_bf16(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const void* A, int lda,
+                                const void* B, int ldb, float beta, float* Cc, int ldc) {
+  const float one = 1.f;
+  return rocblas_gemm_ex(h, ta, tb, m, n, k, &one, A, rocblas_datatype_bf16_r, lda, B, rocblas_datatype_bf16_r, ldb, &beta, Cc,
+                         rocblas_datatype_f32_r, ldc, Cc, rocblas_datatype_f32_r, ldc, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+}
+static rocblas_status gemm_f32(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* A, int lda,
+                               const float* B, int ldb, float beta, float* Cc, int ldc) {
+  const float one = 1.f;
+  return rocblas_sgemm(h, ta, tb, m, n, k, &one, A, lda, B, ldb, &beta, Cc, ldc);
+}
+#define OPN rocblas_operation_none
+#define OPT rocblas_operation_transpose
+
+int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y, const float* mask, const float* state_in, int B,
+                           int S, int L, void* wsp, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st) {
+  if (!t.enabled) return tfail("training is not enabled on this handle (hiertcn_train_enable before hiertcn_set_weights)");
+  if (!m.hier) return tfail("train step: only model_hier is built");
+  for (int i = 0; i < m.n_blocks; i++)
+    if (m.C[i] != m.E || m.resT[i]) return tfail("train step: equal widths / identity residual only in this build");
+  rocblas_handle bl = reinterpret_cast<rocblas_handle>(t.blas);
+  T_BLAS(rocblas_set_stream(bl, st));
+  const TrainWs w = train_ws(m, B, S, L);
+  unsigned char* ws = reinterpret_cast<unsigned char*>(wsp);
+  const int E = m.E, C = m.E, H = m.H, HT = m.HT, nb = m.n_blocks;
+  const int64_t n_sess = (int64_t)B * S, R = n_sess * L;
+  if (R * (int64_t)C >= ((int64_t)1 << 31)) return tfail("train step: B*S*L*C must stay below 2^31 (rocBLAS 32-bit dims); use a smaller batch");
+  float* G = t.grad();
+  T_HIP(hipMemsetAsync(G, 0, t.total * sizeof(float), st));
+#define F32(o) reinterpret_cast<float*>(ws + (o))
+#define BF(o) reinterpret_cast<uint16_t*>(ws + (o))
+
+  // ================= forward (activations kept) ==========================================================
+  float* pooled = F32(w.pooled);
+  float* sproj = F32(w.sproj);
+  float* hist = F32(w.gru_ws);   // [B][S+1][HT] at the head of the GRU workspace (pool_gru.hip)
+  float* gsave = F32(w.gru_save);
+  T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
+  T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
+  uint16_t* a_emb = BF(w.act[0]);
+  uint16_t* a0 = BF(w.act[1]);
+  T_HIP(launch_embed_rows(m, x, R, a_emb, st));
+  {
+    LayerArgs a = {};
+    a.in = a_emb; a.out = a0; a.W = m.projT; a.seq_init = sproj;
+    a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
+    T_HIP(launch_tcn_layer(a, st));
+  }
+  for (int i = 0; i < nb; i++) {
+    LayerArgs a = {};
+    a.in = BF(w.act[1 + 2 * i]);   // a^{i}: act[1], act[3], ...
+    a.c_out = BF(w.act[2 + 2 * i]);
+    a.out = BF(w.act[3 + 2 * i]);
+    a.W = m.convT[i]; a.bias = m.conv_bias[i];
+    a.Cin = C; a.Cout = C; a.taps = m.K; a.dil = 1 << i; a.L = L; a.n_seq = n_sess; a.linear = 0;
+    T_HIP(launch_tcn_layer(a, st));
+  }
+  const uint16_t* hidden = BF(w.act[1 + 2 * nb]);
+  hiertcn_score_out_t so;
+  memset(&so, 0, sizeof(so));
+  so.rank = reinterpret_cast<int32_t*>(ws + w.rank); so.ce = F32(w.ce); so.target = F32(w.tgt);
+  T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st));
+  if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
+
+  // ================= d loss / d logits, scoring layer =====================================================
+  float* users = F32(w.users);
+  T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
+  hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
+  hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users, so.ce, so.target, R, S * L,
+                     F32(w.w), F32(w.lse));
+  T_HIP(hipGetLastError());
+  float* dH = F32(w.dA);   // [R][C] fp32
+  T_HIP(hipMemsetAsync(dH, 0, (size_t)R * C * 4, st));
+  uint16_t* Gc = BF(w.gchunk);
+  const int n_stages = m.NP / 64;
+  for (int s0 = 0; s0 < n_stages; s0 += w.nc_stages) {
+    const int s1 = (s0 + w.nc_stages < n_stages) ? s0 + w.nc_stages : n_stages;
+    const int NC = (s1 - s0) * 64;
+    T_HIP(launch_score_grad_chunk(m, hidden, y, R, F32(w.lse), F32(w.w), s0, s1, Gc, st));
+    // d bo[n] = sum_r G[r][n]
+    hipLaunchKernelGGL(k_colsum_bf16, dim3(NC / 64, (unsigned)((R + 4095) / 4096)), dim3(256), 0, st, Gc, R, (int64_t)NC, NC,
+                       G + t.out_bias.off + (size_t)s0 * 64);
+    T_HIP(hipGetLastError());
+    // dH[R][C] += G[R][NC] . outT_chunk[NC][C]   == col-major: dH^T[C x R] += outT_chunk^T[C x NC] . G^T[NC x R]
+    T_BLAS(gemm_bf16(bl, OPN, OPN, C, (int)R, NC, m.outT + (size_t)s0 * 64 * C, C, Gc, NC, 1.f, dH, C));
+    // d outT_chunk[NC][C] = G^T[NC x R] . hidden[R][C]   == col-major [C x NC] = hidden^T[C x R] . (G^T[NC x R])^T
+    T_BLAS(gemm_bf16(bl, OPN, OPT, C, NC, (int)R, hidden, C, Gc, NC, 0.f, G + t.outT.off + (size_t)s0 * 64 * C, C));
+  }
+
+  // ================= TemporalBlocks, last to first =========================================================
+  float* da = dH;              // grad of a^k, fp32 [R][C]
+  float* dprev = F32(w.dB);    // grad of a^{k-1}
+  float* dsf = F32(w.dsf);
+  uint16_t* dcb = BF(w.dcb);
+  uint16_t* shb = BF(w.shb);
+  const int64_t nRC = R * C;
+  for (int i = nb - 1; i >= 0; i--) {
+    const uint16_t* a_in = BF(w.act[1 + 2 * i]);
+    const uint16_t* c_act = BF(w.act[2 + 2 * i]);
+    const uint16_t* a_out = BF(w.act[3 + 2 * i]);
+    const int dil = 1 << i;
+    hipLaunchKernelGGL(k_block_bwd, dim3((unsigned)((nRC / 4 + 255) / 256)), dim3(256), 0, st, da, a_out, c_act, nRC, dsf, dcb);
+    T_HIP(hipGetLastError());
+    // conv bias: sum over rows of dc
+    hipLaunchKernelGGL(k_colsum_bf16, dim3(C / 64 > 0 ? C / 64 : 1, (unsigned)((R + 4095) / 4096)), dim3(256), 0, st, dcb, R, (int64_t)C, C,
+                       G + t.conv_bias[i].off);
+    T_HIP(hipGetLastError());
+    // identity residual: d a^{k-1} starts as ds
+    T_HIP(hipMemcpyAsync(dprev, dsf, (size_t)nRC * 4, hipMemcpyDeviceToDevice, st));
+    for (int j = 0; j < m.K; j++) {
+      const int shift = (m.K - 1 - j) * dil;   // o[t] += a_in[t - shift] . W_j
+      const uint16_t* Wj = m.convT[i] + (size_t)j * C * C;   // [Cout][Cin]
+      // d W_j^T [Cout][Cin] = dc^T[Cout x R] . Xs[R][Cin], Xs[t] = a_in[t - shift]   == col-major [Cin x Cout] = Xs^T[Cin x R] . (dc^T[Cout x R])^T
+      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (C / 8) + 255) / 256)), dim3(256), 0, st, a_in, shb, R, L, C, shift);
+      T_HIP(hipGetLastError());
+      T_BLAS(gemm_bf16(bl, OPN, OPT, C, C, (int)R, shb, C, dcb, C, 0.f, G + t.convT[i].off + (size_t)j * C * C, C));
+      // d a_in[tau] += dc[tau + shift] . W_j^T: rows [R][Cout] . [Cout][Cin]   == col-major [Cin x R] += W_j(col-major [Cin x Cout]) . dcs^T[Cout x R]
+      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (C / 8) + 255) / 256)), dim3(256), 0, st, dcb, shb, R, L, C, -shift);
+      T_HIP(hipGetLastError());
+      T_BLAS(gemm_bf16(bl, OPN, OPN, C, (int)R, C, Wj, C, shb, C, 1.f, dprev, C));
+    }
+    float* tmp = da; da = dprev; dprev = tmp;
+  }
+  // ================= projection u = e . Wp[:E] + sproj (model_hier.py:54-55 -> model_tcn.py:35) ============
+  uint16_t* dub = BF(w.dub);
+  T_HIP(cast_bf16(da, dub, nRC, 0, st));
+  // d projT[Eout][Ein] = du^T[Eout x R] . e[R][Ein]   == col-major [Ein x Eout] = e^T[Ein x R] . (du^T)^T
+  T_BLAS(gemm_bf16(bl, OPN, OPT, E, E, (int)R, a_emb, E, dub, E, 0.f, G + t.projT.off, E));
+  // d e[R][Ein] = du[R][Eout] . projT[Eout][Ein]   == col-major [Ein x R] = projT(col-major [Ein x Eout]) . du^T[Eout x R]
+  T_BLAS(gemm_bf16(bl, OPN, OPN, E, (int)R, E, m.projT, E, dub, E, 0.f, dprev, E));
+  hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R * (E / 4) + 255) / 256)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E);
+  T_HIP(hipGetLastError());
+  // d sproj, laid out [B][S+1][E] like the state history (slot S = 0)
+  float* dsp = F32(w.dsp_ext);
+  hipLaunchKernelGGL(k_segment_sum, dim3((unsigned)(((int64_t)B * (S + 1) * E + 255) / 256)), dim3(256), 0, st, da, B, S, L, E, dsp);
+  T_HIP(hipGetLastError());
+  const int Mext = B * (S + 1);
+  // d projS[E][HT] = dsproj^T[E x M] . state_before[M][HT]   == col-major [HT x E] = hist^T[HT x M] . (dsp^T[E x M])^T
+  T_BLAS(gemm_f32(bl, OPN, OPT, HT, E, Mext, hist, HT, dsp, E, 0.f, G + t.projS.off, HT));
+  // d state_before[M][HT] = dsproj[M][E] . projS[E][HT]   == col-major [HT x M] = projS(col-major [HT x E]) . dsp^T[E x M]
+  float* dsb = F32(w.dsb_ext);
+  T_BLAS(gemm_f32(bl, OPN, OPN, HT, Mext, E, m.projS, HT, dsp, E, 0.f, dsb, HT));
+
+  // ================= GRU through the S slots, last to first (customed_gru_cell.py:323-337, model_hier.py:91-93) =====
+  float* dcar = F32(w.dstate[0]);
+  float* dnext = F32(w.dstate[1]);
+  T_HIP(hipMemsetAsync(dcar, 0, (size_t)B * HT * 4, st));
+  float* dhp = F32(w.dhp);
+  float* dac = F32(w.dac);
+  float* dag = F32(w.dag);
+  float* dhpart = F32(w.dhpart);
+  float* dcat_c = F32(w.dcat_c);
+  float* dcat_g = F32(w.dcat_g);
+  float* din_up = F32(w.din_up);
+  float* dpooled = F32(w.dpooled);
+  const int64_t hs = (int64_t)(S + 1) * HT;
+  const size_t cell = (size_t)B * 5 * H;
+  const unsigned gBH = (unsigned)(((int64_t)B * H + 255) / 256);
+  for (int s = S - 1; s >= 0; s--) {
+    hipLaunchKernelGGL(k_gru_out_grad, dim3((unsigned)(((int64_t)B * HT + 255) / 256)), dim3(256), 0, st, dcar, dsb + (size_t)(s + 1) * HT, hs,
+                       mask + s, S, B, HT, dhp);
+    T_HIP(hipGetLastError());
+    for (int l = m.nl - 1; l >= 0; l--) {
+      const int in = (l == 0) ? E : H;
+      const int K = in + H;
+      const float* rec = gsave + ((size_t)s * m.nl + l) * cell;
+      const float* gates = rec;
+      const float* rh = rec + (size_t)B * 2 * H;
+      const float* cand = rec + (size_t)B * 3 * H;
+      const float* hold = hist + (size_t)s * HT + (size_t)l * H;   // row stride hs
+      const float* inp = (l == 0) ? pooled + (size_t)s * E : gsave + ((size_t)s * m.nl + (l - 1)) * cell + (size_t)B * 4 * H;
+      const int ldin = (l == 0) ? S * E : H;
+      hipLaunchKernelGGL(k_gru_bwd_a, dim3(gBH), dim3(256), 0, st, dhp + (size_t)l * H, HT, (l < m.nl - 1) ? din_up : nullptr, hold, (int)hs,
+                         gates, cand, B, H, dac, dag, dhpart);
+      T_HIP(hipGetLastError());
+      // d[in | r*h] [B][K] = dac[B][H] . wc[H][K]   == col-major [K x B] = wc(col-major [K x H]) . dac^T[H x B]
+      T_BLAS(gemm_f32(bl, OPN, OPN, K, B, H, m.gru_wc[l], K, dac, H, 0.f, dcat_c, K));
+      // d wc[H][K] += dac^T[H x B] . [in | r*h][B][K]   == col-major [K x H], rows [0,in) from `in`, rows [in,K) from r*h
+      T_BLAS(gemm_f32(bl, OPN, OPT, in, H, B, inp, ldin, dac, H, 1.f, G + t.wc[l].off, K));
+      T_BLAS(gemm_f32(bl, OPN, OPT, H, H, B, rh, H, dac, H, 1.f, G + t.wc[l].off + in, K));
+      T_HIP(colsum_f32(dac, B, H, H, G + t.bc[l].off, st));
+      hipLaunchKernelGGL(k_gru_bwd_b, dim3(gBH), dim3(256), 0, st, dcat_c, K, in, hold, (int)hs, gates, B, H, dag, dhpart);
+      T_HIP(hipGetLastError());
+      // d[in | h] [B][K] = dag[B][2H] . wg[2H][K]
+      T_BLAS(gemm_f32(bl, OPN, OPN, K, B, 2 * H, m.gru_wg[l], K, dag, 2 * H, 0.f, dcat_g, K));
+      T_BLAS(gemm_f32(bl, OPN, OPT, in, 2 * H, B, inp, ldin, dag, 2 * H, 1.f, G + t.wg[l].off, K));
+      T_BLAS(gemm_f32(bl, OPN, OPT, H, 2 * H, B, hold, (int)hs, dag, 2 * H, 1.f, G + t.wg[l].off + in, K));
+      T_HIP(colsum_f32(dag, B, 2 * H, 2 * H, G + t.bg[l].off, st));
+      float* dst_in = (l == 0) ? dpooled + (size_t)s * E : din_up;
+      const int ldi = (l == 0) ? S * E : H;
+      const int Wd = in > H ? in : H;
+      hipLaunchKernelGGL(k_gru_bwd_c, dim3((unsigned)(((int64_t)B * Wd + 255) / 256)), dim3(256), 0, st, dcat_c, dcat_g, K, in, dhpart, B, H, dst_in,
+                         ldi, dnext + (size_t)l * H, HT);
+      T_HIP(hipGetLastError());
+    }
+    float* tmp = dcar; dcar = dnext; dnext = tmp;
+  }
+  // ================= session mean-pool + 'emb' bias (model_hier.py:83-85) ================================
+  T_HIP(colsum_f32(dpooled, n_sess, E, E, G + t.emb_bias.off, st));
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)n_sess), dim3(256), 0, st, G + t.emb.off, y, dpooled, n_sess, L, E);
+  T_HIP(hipGetLastError());
+#undef F32
+#undef BF
+  return 0;
+}

@@ -58,13 +58,14 @@ def config_from_args(args, hier: bool = True) -> _lib.Config:
 class Engine:
     """One handle on the current CUDA(HIP) device."""
 
-    def __init__(self, args, hier: bool = True, device: Optional[torch.device] = None):
+    def __init__(self, args, hier: bool = True, device: Optional[torch.device] = None, train: bool = False):
         self.lib = _lib.load()
         if not torch.cuda.is_available():
             raise HierTCNError("no GPU visible: the HierTCN compute path is HIP-only (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.hier = hier
         self.cfg = config_from_args(args, hier)
+        self._args_for_shapes = args
         self.N = int(self.cfg.item_num)
         self.E = int(self.cfg.emb_dim)
         self.H = int(self.cfg.hidden_dim) if hier else 0
@@ -74,6 +75,11 @@ class Engine:
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             check(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
+        self.train = bool(train)
+        if self.train:   # fp32 masters / gradients / Adam moments; must precede set_weights
+            with torch.cuda.device(self.device):
+                check(self.lib.hiertcn_train_enable(self._h))
+        self._train_ws: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._gru_ws: Optional[torch.Tensor] = None
         self._tcn_ws: Optional[torch.Tensor] = None
@@ -272,6 +278,66 @@ class Engine:
         check(self.lib.hiertcn_forward_eval(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
                                             _ptr(ws), ws.numel(), _ptr(state_out), _ptr(metrics8),
                                             C.byref(so) if so is not None else None, self._stream()))
+        return out
+
+    # -- training (hiertcn.h "training step") ------------------------------------------------------
+    def train_forward_backward(self, x_ids, y_ids, mask, state_in, state_out=None, metrics8=None):
+        """Forward + loss + gradients of every variable (into the handle's gradient arena).
+        Returns dict(state, metrics8)."""
+        B, S, L = x_ids.shape
+        _req(x_ids, torch.int32, "x_ids", (B, S, L))
+        _req(y_ids, torch.int32, "y_ids", (B, S, L))
+        _req(mask, torch.float32, "mask", (B, S))
+        _req(state_in, torch.float32, "state_in", (B, self.HT))
+        need = int(self.lib.hiertcn_train_workspace_bytes(self._h, B, S, L))
+        if self._train_ws is None or self._train_ws.numel() < need:
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        if state_out is None:
+            state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
+        if metrics8 is None:
+            metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
+        check(self.lib.hiertcn_train_forward_backward(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
+                                                      _ptr(self._train_ws), self._train_ws.numel(), _ptr(state_out), _ptr(metrics8),
+                                                      self._stream()))
+        return dict(state=state_out, metrics8=metrics8)
+
+    def grad_arena(self) -> torch.Tensor:
+        """The flat fp32 gradient buffer as a torch view (no copy): the all-reduce target of data-parallel training."""
+        ptr = C.c_void_p()
+        n = C.c_size_t()
+        check(self.lib.hiertcn_grad_arena(self._h, C.byref(ptr), C.byref(n)))
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f4", "data": (int(ptr.value), False), "version": 2}
+
+        return torch.as_tensor(_Raw(), device=self.device)
+
+    def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0):
+        """tf.train.AdamOptimizer(lr) defaults (model.py:139)."""
+        check(self.lib.hiertcn_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), self._stream()))
+
+    def export(self, which: str = "weights", root: Optional[str] = None) -> Dict[str, np.ndarray]:
+        """Masters ('weights') or gradients ('grads') as {TF variable name: fp32 ndarray in the reference layout}."""
+        from .params import param_shapes
+        root = root or "hier"
+        shapes = param_shapes(self._args_for_shapes, "hier")
+        bufs = {k: torch.zeros(v, dtype=torch.float32, device=self.device) for k, v in shapes.items()}
+        w = _lib.Weights()
+        tcn = f"{root}/tcn"
+        g = lambda k: bufs[k].data_ptr()  # noqa: E731
+        w.emb_kernel, w.emb_bias, w.proj_kernel = g("hier/emb/kernel"), g("hier/emb/bias"), g("hier/tcn/emb/kernel")
+        for i in range(self.cfg.n_blocks):
+            pre = f"hier/tcn/temporal_conv_net/tblock_{i}"
+            w.conv_kernel[i], w.conv_bias[i] = g(f"{pre}/conv1/kernel"), g(f"{pre}/conv1/bias")
+        w.out_kernel, w.out_bias = g("hier/tcn/dense/kernel"), g("hier/tcn/dense/bias")
+        for l in range(self.nl):
+            pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
+            w.gru_gate_kernel[l], w.gru_gate_bias[l] = g(f"{pre}/gates/kernel"), g(f"{pre}/gates/bias")
+            w.gru_cand_kernel[l], w.gru_cand_bias[l] = g(f"{pre}/candidate/kernel"), g(f"{pre}/candidate/bias")
+        check(self.lib.hiertcn_export_weights(self._h, C.byref(w), 0 if which == "weights" else 1, self._stream()))
+        torch.cuda.current_stream().synchronize()
+        out = {(root + k[4:] if k.startswith("hier") else k): v.cpu().numpy() for k, v in bufs.items()}
+        del tcn
         return out
 
     # ---------------------------------------------------------------------------------------

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 2
+#define HIERTCN_ABI_VERSION 3
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -175,6 +175,27 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
                          const float* state_in, int32_t B, int32_t S, int32_t L, void* workspace,
                          size_t workspace_bytes, float* state_out, double* metrics8,
                          const hiertcn_score_out_t* score_out, void* stream);
+
+/* ---- training step (model.py:135-141: Adam on the masked lane-mean cross entropy of model.py:102-117) ----------
+ * hiertcn_train_enable   before hiertcn_set_weights: allocates fp32 masters / gradients / Adam moments for every
+ *                        variable (4 x parameter count floats) and a rocBLAS handle.
+ * hiertcn_train_forward_backward   one `sess.run([train_op minus the apply, loss, state])` of run_hier_xing.py:301:
+ *                        forward with activations kept in `workspace`, loss into metrics8 (as hiertcn_metrics), gradients
+ *                        of every variable into the gradient arena.  No gradient crosses the batch boundary (state_in is data).
+ * hiertcn_grad_arena     the flat fp32 gradient buffer (device) -- the RCCL all-reduce target of data-parallel runs.
+ * hiertcn_adam_step      TF-1.x AdamOptimizer update (lr_t = lr*sqrt(1-b2^t)/(1-b1^t); theta -= lr_t*m/(sqrt(v)+eps)) of the
+ *                        masters from grad * grad_scale, then refreshes the bf16 device copies.
+ * hiertcn_export_weights which = 0: masters, 1: gradients -> fp32 device tensors in the REFERENCE layouts (`dst` holds
+ *                        destination pointers; NULL members are skipped) -- checkpoints and tests.
+ * This build: model_hier, equal widths (identity residual). */
+int hiertcn_train_enable(hiertcn_handle_t h);
+size_t hiertcn_train_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t L);
+int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask,
+                                   const float* state_in, int32_t B, int32_t S, int32_t L, void* workspace,
+                                   size_t workspace_bytes, float* state_out, double* metrics8, void* stream);
+int hiertcn_grad_arena(hiertcn_handle_t h, float** grad, size_t* count);
+int hiertcn_adam_step(hiertcn_handle_t h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int hiertcn_export_weights(hiertcn_handle_t h, const hiertcn_weights_t* dst, int32_t which, void* stream);
 
 /* Measurement hook for bench.py: average duration in milliseconds of the scoring kernel over the
  * launches made since the last reset, measured with HIP events recorded on the launch stream.

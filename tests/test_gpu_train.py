@@ -1,0 +1,158 @@
+"""-m gpu: the training step (model.py:102-117 loss, model.py:139-141 Adam) of the HIP path against an
+independent PyTorch-CPU fp64 formulation differentiated by autograd (a floating-point kernel: the torch
+reference is the checker here, as for the forward pass in tests/test_oracle_vs_torch.py).
+
+Tolerances: the device multiplies bf16 operands (weights, activations, d-logits) with fp32 accumulation
+and passes gradients straight through the forward roundings, the reference is fp64 on the bf16-rounded
+weights: per-tensor relative L2 error < 3e-2 and cosine > 0.999; Adam arithmetic itself (given the
+device's own gradients) to 1e-6."""
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+import torch.nn.functional as F  # noqa: E402
+
+from oracle import hiertcn_oracle as O  # noqa: E402
+from tests.gpu_common import make_batch, make_params, small_args  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def ste_bf16(a):
+    """Round to bf16 in the forward pass, identity in the backward pass: the device keeps its activations in
+    bf16 and passes gradients straight through the roundings."""
+    return a + (a.detach().to(torch.float32).to(torch.bfloat16).to(torch.float64) - a.detach())
+
+
+def torch_loss(args, P, x, y, mask, state):
+    """model_hier.py:39-93 + model.py:102-117 on torch tensors (P: name -> tensor), activations rounded where
+    the device rounds them (after the projection and after every block)."""
+    B, S, L = x.shape
+    H, nl, N = args.hidden_dim, args.num_layer, args.item_num
+    st = torch.as_tensor(state, dtype=torch.float64)
+    E = P["hier/emb/kernel"]
+    xt, yt = torch.as_tensor(x, dtype=torch.int64), torch.as_tensor(y, dtype=torch.int64)
+    mk = torch.as_tensor(mask, dtype=torch.float64)
+    logits = []
+    for s in range(S):
+        e = F.embedding(xt[:, s], E) * (xt[:, s] > 0)[..., None]
+        u = torch.cat([e, st[:, None, :].expand(-1, L, -1)], -1) @ P["hier/tcn/emb/kernel"]
+        a = ste_bf16(u).transpose(1, 2)
+        for i in range(len(args.tcn_channel)):
+            pre = f"hier/tcn/temporal_conv_net/tblock_{i}"
+            W = P[f"{pre}/conv1/kernel"].permute(2, 1, 0)
+            d, K = 2 ** i, W.shape[-1]
+            c = torch.relu(F.conv1d(F.pad(a, ((K - 1) * d, 0)), W, P[f"{pre}/conv1/bias"], dilation=d))
+            a = ste_bf16(torch.relu(c + a))
+        logits.append(a.transpose(1, 2) @ P["hier/tcn/dense/kernel"] + P["hier/tcn/dense/bias"])
+        ey = F.embedding(yt[:, s], E) * (yt[:, s] > 0)[..., None]
+        cur = ey.sum(1) / (yt[:, s] > 0).sum(1, keepdim=True) + P["hier/emb/bias"]
+        new = []
+        for l in range(nl):
+            pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
+            h = st[:, l * H:(l + 1) * H]
+            g = torch.sigmoid(torch.cat([cur, h], 1) @ P[f"{pre}/gates/kernel"] + P[f"{pre}/gates/bias"])
+            r, uu = g.chunk(2, 1)
+            c = torch.tanh(torch.cat([cur, r * h], 1) @ P[f"{pre}/candidate/kernel"] + P[f"{pre}/candidate/bias"])
+            cur = uu * h + (1 - uu) * c
+            new.append(cur)
+        st = torch.cat(new, 1) * mk[:, s:s + 1]
+    z = torch.cat(logits, 1)
+    yy = yt.reshape(B, S * L)
+    m = (yy > 0).double()
+    z = z * m[..., None]
+    ce = F.cross_entropy(z.reshape(-1, N), yy.reshape(-1), reduction="none").reshape(B, -1) * m
+    act = m.sum(1)
+    users = (act > 0).double().sum()
+    return ((ce.sum(1) / (act + 1e-6)).sum() / users), st
+
+
+@pytest.fixture(scope="module", params=[(64, 700, 32), (128, 1500, 64)])
+def trained(request):
+    from hiertcn_amd.engine import Engine, metrics_dict
+    d, N, H = request.param
+    args = small_args(N=N, d=d, H=H)
+    p = make_params(args)
+    eng = Engine(args, hier=True, train=True)
+    eng.set_weights(p)
+    rng = np.random.default_rng(d)
+    B, S, L = 7, 4, 9
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, H * args.num_layer))).astype(np.float32)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda().contiguous()  # noqa: E731
+    out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    torch.cuda.synchronize()
+    grads = eng.export("grads")
+    loss = metrics_dict(out["metrics8"])["loss"]
+    pr = O.round_params_bf16(p, E=d)
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in pr.items()}
+    ref_loss, ref_state = torch_loss(args, P, x, y, mask, st0)
+    ref_loss.backward()
+    ref = {k: v.grad.numpy() for k, v in P.items()}
+    yield dict(args=args, p=p, eng=eng, grads=grads, ref=ref, loss=loss, ref_loss=float(ref_loss.detach()), state=out["state"].cpu().numpy(),
+               ref_state=ref_state.detach().numpy(), batch=(x, y, mask, st0), dev=dev)
+    eng.close()
+
+
+def test_loss_and_state_match(trained):
+    t = trained
+    assert abs(t["loss"] - t["ref_loss"]) < 2e-3
+    assert np.abs(t["state"] - t["ref_state"]).max() < 1e-3
+
+
+def test_every_gradient_matches_autograd(trained):
+    t = trained
+    assert set(t["grads"]) == set(t["ref"])
+    report = []
+    for k in sorted(t["ref"]):
+        g, r = t["grads"][k].astype(np.float64), t["ref"][k]
+        assert g.shape == r.shape, k
+        nr = np.linalg.norm(r)
+        rel = np.linalg.norm(g - r) / max(nr, 1e-30)
+        cos = float((g * r).sum() / max(np.linalg.norm(g) * nr, 1e-30))
+        report.append((k, rel, cos, nr))
+    bad = [(k, rel, cos) for k, rel, cos, nr in report if nr > 1e-9 and (rel > 3e-2 or cos < 0.999)]
+    assert not bad, "\n".join(f"{k}: rel {rel:.3e} cos {cos:.5f}" for k, rel, cos in bad) + "\nall:\n" + "\n".join(
+        f"{k}: rel {rel:.3e} cos {cos:.5f} |ref| {nr:.3e}" for k, rel, cos, nr in report)
+    # the null id never receives a gradient (model.py:59)
+    assert not t["grads"]["hier/emb/kernel"][0].any()
+
+
+def test_adam_is_tf_adam(trained):
+    """Two steps on the same batch; the reference update is computed in NumPy from the device's own gradients:
+    lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2; theta -= lr_t m/(sqrt(v)+eps)."""
+    t = trained
+    eng, dev = t["eng"], t["dev"]
+    x, y, mask, st0 = t["batch"]
+    lr, b1, b2, eps = 1e-2, 0.9, 0.999, 1e-8
+    w = {k: v.astype(np.float64) for k, v in eng.export("weights").items()}
+    for k in t["p"]:   # the masters hold the fp32 parameters as given (not their bf16 roundings)
+        assert np.array_equal(w[k].astype(np.float32), np.asarray(t["p"][k], np.float32)), k
+    m1 = {k: np.zeros_like(v) for k, v in w.items()}
+    m2 = {k: np.zeros_like(v) for k, v in w.items()}
+    losses = []
+    from hiertcn_amd.engine import metrics_dict
+    for step in (1, 2, 3):
+        out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+        losses.append(metrics_dict(out["metrics8"])["loss"])
+        g = {k: v.astype(np.float64) for k, v in eng.export("grads").items()}
+        eng.adam_step(lr, b1, b2, eps)
+        got = eng.export("weights")
+        lr_t = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        for k in w:
+            m1[k] = b1 * m1[k] + (1 - b1) * g[k]
+            m2[k] = b2 * m2[k] + (1 - b2) * g[k] ** 2
+            w[k] = w[k] - lr_t * m1[k] / (np.sqrt(m2[k]) + eps)
+            assert np.abs(got[k] - w[k]).max() < 2e-6 * max(1.0, np.abs(w[k]).max()), (k, step)
+            w[k] = got[k].astype(np.float64)   # follow the device's fp32 state so that rounding does not accumulate
+    assert losses[2] < losses[0], losses   # three Adam steps on one batch lower its loss
+
+
+def test_gradient_all_reduce_view_is_the_arena(trained):
+    eng = trained["eng"]
+    g = eng.grad_arena()
+    assert g.dtype == torch.float32 and g.is_cuda and g.numel() > 0
+    total = sum(v.size for v in trained["grads"].values())
+    assert g.numel() >= total    # segments are padded to 64 floats
+    s = float(g.double().abs().sum())
+    assert np.isfinite(s) and s > 0
