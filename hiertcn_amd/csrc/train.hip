@@ -14,6 +14,7 @@
 #include <rocblas/rocblas.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "train.h"
@@ -461,6 +462,10 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   if (st < 1) st = 1;
   if (st > nst) st = nst;
   if (st > 128) st = 128;
+  if (const char* ov = getenv("HIERTCN_TRAIN_CHUNK_STAGES")) {  // tests: force several chunks on a small catalogue
+    const long v = atol(ov);
+    if (v >= 1 && (size_t)v < st) st = (size_t)v;
+  }
   w.nc_stages = (int)st;
   w.gchunk = take(R * st * 64 * 2);
   w.dsp_ext = take((size_t)B * (S + 1) * C * 4);

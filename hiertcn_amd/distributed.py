@@ -53,3 +53,17 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def all_reduce_gradients(flat: torch.Tensor, bucket_bytes: int = 256 << 20) -> int:
+    """Sum the flat fp32 gradient arena over ranks, in place, in buckets (so that a bucket's RCCL all-reduce can
+    overlap the next bucket's launch; the arena is dominated by the two [N, d] item tables -- 2 x 307 MB at
+    cfg-3).  Returns the world size: the caller divides by it (equal user counts per rank: weak scaling), which
+    makes the update the gradient of the GLOBAL batch's lane-mean loss (model.py:116-117)."""
+    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+        return 1
+    n = max(1, bucket_bytes // 4)
+    works = [dist.all_reduce(flat[i:i + n], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), n)]
+    for wk in works:
+        wk.wait()
+    return dist.get_world_size()

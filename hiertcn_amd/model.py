@@ -89,15 +89,27 @@ class LazyLogits:
 
 
 class HierTCNModel:
-    def __init__(self, args, params: Optional[dict] = None, name: str = "hier", seed: int = 2):
+    def __init__(self, args, params: Optional[dict] = None, name: str = "hier", seed: int = 2, train: Optional[bool] = None):
         self.args, self.name = args, name
         self.hier = name.startswith("hier")
-        self.engine = Engine(args, hier=self.hier)
-        self.params = params if params is not None else init_params(args, seed, "hier" if self.hier else "tcn")
-        self.engine.set_weights(self.params, root=name)
+        self.trainable = bool(getattr(args, "train", False)) if train is None else bool(train)
+        self.engine = Engine(args, hier=self.hier, train=self.trainable)
+        self._params = params if params is not None else init_params(args, seed, "hier" if self.hier else "tcn")
+        self.engine.set_weights(self._params, root=name)
+
+    @property
+    def params(self) -> dict:
+        """TF-named fp32 variables.  A trainable model reads them back from the device masters."""
+        if self.trainable:
+            self._params = self.engine.export("weights", root=self.name)
+        return self._params
+
+    @params.setter
+    def params(self, value: dict):
+        self._params = value
 
     def set_parameters(self, params: dict):
-        self.params = params
+        self._params = params
         self.engine.set_weights(params, root=self.name)
 
     # one sess.run of the evaluation fetch list (run_hier_xing.py:145-149) ------------------------
@@ -131,9 +143,25 @@ class HierTCNModel:
         return res
 
     def train_step(self, x_list, y_list, mask_list, state_np, lr):
-        """train_op of model.py:139-141 (Adam on every variable).  SURVEY.md 8(f) rank 1: not built."""
-        raise NotImplementedError("the training step (backward + TF-form Adam) is not built yet; "
-                                  "run with args.train = False (the reference's own default, args.py:193)")
+        """One sess.run([train_op, loss, state]) of run_hier_xing.py:301: forward, masked lane-mean cross
+        entropy (model.py:102-117), gradients of every variable, [RCCL all-reduce of the gradient arena
+        when a process group is up], TF-form Adam (model.py:139-141).  Returns dict(loss, state)."""
+        if not self.trainable:
+            raise RuntimeError("this model was created without training state (args.train = False)")
+        x, y, mask, _lens = pack_slots(x_list, y_list, mask_list)
+        return self.train_step_packed(x, y, mask, state_np, lr)
+
+    def train_step_packed(self, x, y, mask, state_np, lr):
+        from .distributed import all_reduce_gradients
+        eng = self.engine
+        dev = eng.device
+        xd, yd, md = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, y, mask))
+        st = torch.as_tensor(np.asarray(state_np, dtype=np.float32)).to(dev).contiguous()
+        out = eng.train_forward_backward(xd, yd, md, st)
+        world = all_reduce_gradients(eng.grad_arena())
+        eng.adam_step(float(lr), grad_scale=1.0 / world)
+        m = metrics_dict(out["metrics8"])
+        return dict(loss=m["loss"], state=out["state"].cpu().numpy(), user_count=m["user_count"])
 
 
 class TcnModel:

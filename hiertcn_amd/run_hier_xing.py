@@ -108,7 +108,7 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
             train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
             if args.save and epoch % args.save_epoch == 0 and epoch != 0:  # :317-321
                 fname = args.save_path + str(epoch) + ".ckpt"
-                checkpoint.save(fname, model.params, extra={"state_np": state_np})
+                checkpoint.save(fname, model.params, extra={"state_np": state_np})  # .params reads the device masters back
                 print("Model saved in path: %s" % fname)
         if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:  # :324
             if args.validate:

@@ -85,3 +85,23 @@ def test_two_rank_metric_all_reduce_equals_single_process(tmp_path):
     assert got[0] / got[6] == np.float64(m["loss"]) or abs(got[0] / got[6] - m["loss"]) < 1e-12
     assert abs(got[3] / got[6] - m["recall10"]) < 1e-12
     assert np.load(tmp_path / "t.npy")[0] == 2.0   # MAX over ranks of the per-rank time
+
+
+def _grad_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hiertcn_amd.distributed import all_reduce_gradients, init_from_env
+    import torch.distributed as dist
+    init_from_env("gloo")
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)      # stands for the flat gradient arena
+    w = all_reduce_gradients(g, bucket_bytes=4 * 96)              # 96-float buckets: 11 async all-reduces, a ragged last one
+    if rank == 0:
+        np.save(os.path.join(out_dir, "g.npy"), g.numpy())
+        np.save(os.path.join(out_dir, "w.npy"), np.array([w]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_bucketed_gradient_all_reduce(tmp_path):
+    mp.spawn(_grad_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    assert np.load(tmp_path / "w.npy")[0] == 2
+    np.testing.assert_array_equal(np.load(tmp_path / "g.npy"), np.arange(1000, dtype=np.float32) * 3)

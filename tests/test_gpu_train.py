@@ -156,3 +156,78 @@ def test_gradient_all_reduce_view_is_the_arena(trained):
     assert g.numel() >= total    # segments are padded to 64 floats
     s = float(g.double().abs().sum())
     assert np.isfinite(s) and s > 0
+
+
+def test_chunked_dlogits_equal_single_chunk():
+    """The d-logits matrix is produced in item chunks; forcing 3-stage (192-item) chunks on a 700-item catalogue
+    must give the same gradients as one chunk (only the fp32 summation order of d hidden changes)."""
+    import os
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = r'''
+import sys, numpy as np, torch
+sys.path.insert(0, %r)
+from tests.gpu_common import make_batch, make_params, small_args
+from hiertcn_amd.engine import Engine
+args = small_args(N=700, d=64, H=32)
+eng = Engine(args, hier=True, train=True); eng.set_weights(make_params(args))
+x, y, mask = make_batch(np.random.default_rng(3), 5, 3, 8, 700)
+dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda().contiguous()
+eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(np.zeros((5, 64), np.float32)))
+g = eng.export("grads")
+np.savez(sys.argv[1], **{k.replace("/", "."): v for k, v in g.items()})
+''' % root
+    with tempfile.TemporaryDirectory() as tmp:
+        outs = []
+        for i, env in enumerate(({}, {"HIERTCN_TRAIN_CHUNK_STAGES": "3"})):
+            f = os.path.join(tmp, f"g{i}.npz")
+            subprocess.run([sys.executable, "-c", code, f], check=True, env={**os.environ, **env})
+            outs.append(dict(np.load(f)))
+    assert set(outs[0]) == set(outs[1])
+    for k in outs[0]:
+        a, b = outs[0][k].astype(np.float64), outs[1][k].astype(np.float64)
+        assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(a), 1e-12), k
+
+
+def test_run_hier_trains_saves_and_restores(tmp_path):
+    """run_hier with args.train on the synthetic XING CSV: epochs 0..2 of 6 batches, lr 1e-2, checkpoint at epoch 2,
+    evaluation at epoch 2; the loss falls, the checkpoint restores into a fresh model that evaluates identically."""
+    import os
+    from hiertcn_amd import checkpoint
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.data_loader import Dataloader_hier_model_xing
+    from hiertcn_amd.data_prepare import load_xing
+    from hiertcn_amd.model import HierTCNModel
+    from hiertcn_amd.run_hier_xing import evaluate_hier, run_hier
+    data = load_xing(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interactions_synth.csv"))
+    n_items = int(data[1][:, 1].max()) + 1
+    args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=5,
+                         batch_size=4, max_session_num=3, max_activity_len=6)
+    args.log_path, args.save_path = str(tmp_path) + "/log/", str(tmp_path) + "/model/"
+    args.train, args.validate, args.test, args.save = True, False, True, True
+    args.epoch_max, args.epoch_batches_train, args.save_epoch, args.test_epoch, args.learning_rate = 2, 6, 2, 2, 1e-2
+    mk = lambda split: Dataloader_hier_model_xing(args, split, data=data)  # noqa: E731
+    model = HierTCNModel(args)
+    st0 = np.zeros((4, 64))
+    os.makedirs(args.log_path + "before/")
+    before, *_ = evaluate_hier(args, mk("test"), st0, model, prefix="before")
+    run_hier(args, mk("train"), mk("validate"), mk("test"), sess=model)
+    txt = open(args.log_path + "test/results.txt").read()
+    after_loss = float(txt.split("final\n")[1].split()[1].rstrip(","))
+    assert after_loss < before["loss_epoch"] - 0.05, (before["loss_epoch"], after_loss)
+    import json
+    tr = [json.loads(l) for l in open(args.log_path + "train/scalars.jsonl")]
+    assert [r["step"] for r in tr] == [0, 1, 2] and tr[2]["value"] < tr[0]["value"]
+    ck = args.save_path + "2.ckpt"
+    params, extra = checkpoint.load(ck, with_extra=True)
+    assert extra["state_np"].shape == (4, 64)
+    fresh = HierTCNModel(args, params, train=False)
+    os.makedirs(args.log_path + "a/")
+    os.makedirs(args.log_path + "b/")
+    ra, *_ = evaluate_hier(args, mk("test"), st0, model, prefix="a")
+    rb, *_ = evaluate_hier(args, mk("test"), st0, fresh, prefix="b")
+    assert ra == rb
+    model.engine.close()
+    fresh.engine.close()
