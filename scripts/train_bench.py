@@ -1,0 +1,32 @@
+"""Training-step throughput on the cfg-3 synthetic shape (secondary measurement; bench.py's headline is the eval pass).
+usage: python scripts/train_bench.py [users_per_step] [steps]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import bench
+from hiertcn_amd.args import hier_tcn_args
+from hiertcn_amd.engine import Engine, metrics_dict
+from hiertcn_amd.params import init_params
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+N, d, S, L = bench.N_ITEMS, bench.DIM, bench.S_SESS, bench.L_STEPS
+args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L,
+                     max_session_num=S, batch_size=B)
+eng = Engine(args, hier=True, train=True)
+eng.set_weights(init_params(args, seed=2))
+draw = bench.zipf_sampler(N)
+x, y, mask = bench.make_users(draw, 0, B, False)
+xd, yd, md = (torch.from_numpy(v).cuda() for v in (x, y, mask))
+st0 = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")
+losses = []
+for i in range(steps + 1):
+    if i == 1:
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+    out = eng.train_forward_backward(xd, yd, md, st0)
+    eng.adam_step(1e-2)
+    losses.append(out["metrics8"].clone())
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / steps
+print("train step: users %d, %.1f ms/step, %.0f sessions/s; loss %s" % (
+    B, dt * 1e3, B * S / dt, [round(metrics_dict(m)["loss"], 4) for m in losses]), flush=True)
