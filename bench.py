@@ -146,7 +146,9 @@ def main():
     sessions_per_step = B * S_SESS * world
     value = sessions_per_step * a.steps / dt
     rows_per_launch = B * S_SESS * L_STEPS
-    flops_per_launch = 2.0 * rows_per_launch * DIM * N_ITEMS  # algorithmic: rows x 2 C N
+    # rows that carry a target (= all rows unless --ragged): padded steps are not scored at all (row compaction)
+    scored_rows = float(torch.stack(m8[a.warmup:]).cpu()[:, 7].mean()) / world if a.steps > 0 else float(rows_per_launch)
+    flops_per_launch = 2.0 * scored_rows * DIM * N_ITEMS  # algorithmic: scored rows x 2 C N
     achieved = flops_per_launch / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
     last = metrics_dict(m8[-1])
 
@@ -209,6 +211,7 @@ def main():
                 "launch_ms": round(score_ms, 4),
                 "launches_timed": int(launches),
                 "flops_per_launch": flops_per_launch,
+                "scored_rows_per_launch": scored_rows,
             },
             "cpu_baseline": cpu,
             "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},

@@ -259,7 +259,7 @@ int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* s
 }
 
 static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
-                       hipStream_t st) {
+                       hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr) {
   size_t slot = 0;
   const bool timing = h->timing;
   if (timing) {
@@ -273,7 +273,7 @@ static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t
     slot = h->ev_used++;
     HIP_TRY(hipEventRecord(h->ev_begin[slot], st));
   }
-  HIP_TRY(launch_score(h->m, hidden, y, R, out, nullptr, st));
+  HIP_TRY(launch_score(h->m, hidden, y, R, out, nullptr, st, row_map, n_rows_dev));
   if (timing) HIP_TRY(hipEventRecord(h->ev_end[slot], st));
   return HIERTCN_OK;
 }
@@ -312,7 +312,7 @@ int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, co
 
 // workspace layout of hiertcn_forward_eval (all sub-buffers 256-byte aligned)
 struct EvalWs {
-  size_t pooled, sproj, hidden, rank, ce, gru, tcn, total;
+  size_t pooled, sproj, hidden, rank, ce, gru, tcn, map, nvalid, cscratch, total;
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
@@ -325,6 +325,9 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
   w.ce = off;     off += al256((size_t)B * S * L * sizeof(float));
   w.gru = off;    off += al256(m.hier ? gru_workspace_bytes(m, (int)B, (int)S) : 0);
   w.tcn = off;    off += al256(tcn_workspace_bytes(m, B * S, (int)L));
+  w.map = off;    off += al256((size_t)B * S * L * sizeof(int32_t));           // ragged batches: rows that carry a target
+  w.nvalid = off; off += al256(sizeof(int32_t));
+  w.cscratch = off; off += al256(((size_t)B * S * L / 1024 + 2) * sizeof(int32_t));
   w.total = off;
   return w;
 }
@@ -366,7 +369,19 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
     HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
   }
   HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, hidden, ws + w.tcn, st));
-  int rc = score_timed(h, hidden, y_ids, R, &so, st);
+  // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): zero the outputs, list the rows that do
+  // carry a target and score only those (a ragged XING batch is mostly padding: slot width = longest session of the slot).
+  int32_t* row_map = nullptr;
+  int32_t* n_valid = nullptr;
+  if (so.topk == 0) {   // (the top-k list kernel takes dense rows)
+    row_map = reinterpret_cast<int32_t*>(ws + w.map);
+    n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
+    HIP_TRY(launch_compact_rows(y_ids, R, row_map, n_valid, reinterpret_cast<int32_t*>(ws + w.cscratch), st));
+    HIP_TRY(hipMemsetAsync(so.rank, 0, (size_t)R * sizeof(int32_t), st));
+    HIP_TRY(hipMemsetAsync(so.ce, 0, (size_t)R * sizeof(float), st));
+    if (so.target) HIP_TRY(hipMemsetAsync(so.target, 0, (size_t)R * sizeof(float), st));
+  }
+  int rc = score_timed(h, hidden, y_ids, R, &so, st, row_map, n_valid);
   if (rc != HIERTCN_OK) return rc;
   if (metrics8) {
     if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");

@@ -73,3 +73,76 @@ hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const 
   hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(64), 0, st, scratch, nblocks, out8);
   return hipGetLastError();
 }
+
+
+// ---------------------------------------------------------------------------------------------
+// Row compaction for ragged batches: the ascending list of rows that carry a target (y > 0).
+// Three tiny launches (per-1024-row counts, a single-workgroup scan, the write pass); order is
+// deterministic, so is everything computed through the list.
+// ---------------------------------------------------------------------------------------------
+#define CP_ROWS 1024
+__global__ __launch_bounds__(256) void k_valid_counts(const int32_t* __restrict__ y, int64_t R, int32_t* __restrict__ counts) {
+  __shared__ int red[4];
+  const int64_t r0 = (int64_t)blockIdx.x * CP_ROWS + threadIdx.x * 4;
+  int c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) c += (r0 + j < R && y[r0 + j] > 0) ? 1 : 0;
+  for (int off = 32; off > 0; off >>= 1) c += __shfl_xor(c, off);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = c;
+  __syncthreads();
+  if (threadIdx.x == 0) counts[blockIdx.x] = red[0] + red[1] + red[2] + red[3];
+}
+// exclusive scan of counts[0..n) in place (one workgroup; n <= a few thousand), total -> n_valid
+__global__ __launch_bounds__(1024) void k_scan_counts(int32_t* __restrict__ counts, int n, int32_t* __restrict__ n_valid) {
+  __shared__ int part[1024];
+  const int per = (n + 1023) / 1024;
+  const int lo = threadIdx.x * per, hi = (lo + per < n) ? lo + per : n;
+  int s = 0;
+  for (int i = lo; i < hi; i++) s += counts[i];
+  part[threadIdx.x] = s;
+  __syncthreads();
+  for (int off = 1; off < 1024; off <<= 1) {   // Hillis-Steele inclusive scan of the 1024 partials
+    const int v = (threadIdx.x >= off) ? part[threadIdx.x - off] : 0;
+    __syncthreads();
+    part[threadIdx.x] += v;
+    __syncthreads();
+  }
+  int run = part[threadIdx.x] - s;   // exclusive prefix of this thread's slice
+  for (int i = lo; i < hi; i++) {
+    const int c = counts[i];
+    counts[i] = run;
+    run += c;
+  }
+  if (threadIdx.x == 1023) n_valid[0] = part[1023];
+}
+__global__ __launch_bounds__(256) void k_write_map(const int32_t* __restrict__ y, int64_t R, const int32_t* __restrict__ offsets,
+                                                  int32_t* __restrict__ map) {
+  __shared__ int wsum[4];
+  const int64_t r0 = (int64_t)blockIdx.x * CP_ROWS + threadIdx.x * 4;
+  int f[4], c = 0;
+#pragma unroll
+  for (int j = 0; j < 4; j++) { f[j] = (r0 + j < R && y[r0 + j] > 0) ? 1 : 0; c += f[j]; }
+  // exclusive scan of c over the 256 threads: inside each wave by shuffles, then across the 4 waves
+  int incl = c;
+  const int lane = threadIdx.x & 63;
+  for (int off = 1; off < 64; off <<= 1) {
+    const int v = __shfl_up(incl, off);
+    if (lane >= off) incl += v;
+  }
+  if (lane == 63) wsum[threadIdx.x >> 6] = incl;
+  __syncthreads();
+  int base = offsets[blockIdx.x];
+  for (int w = 0; w < (int)(threadIdx.x >> 6); w++) base += wsum[w];
+  int pos = base + incl - c;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    if (f[j]) map[pos++] = (int32_t)(r0 + j);
+}
+
+hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_t* n_valid, int32_t* scratch, hipStream_t st) {
+  const int nblk = (int)((R + CP_ROWS - 1) / CP_ROWS);
+  hipLaunchKernelGGL(k_valid_counts, dim3(nblk), dim3(256), 0, st, y, R, scratch);
+  hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, scratch, nblk, n_valid);
+  hipLaunchKernelGGL(k_write_map, dim3(nblk), dim3(256), 0, st, y, R, scratch, map);
+  return hipGetLastError();
+}

@@ -450,7 +450,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
                                                               int64_t R, const uint16_t* __restrict__ outT,
                                                               const float* __restrict__ out_bias, int N, int NP,
                                                               int32_t* __restrict__ o_rank, float* __restrict__ o_ce,
-                                                              float* __restrict__ o_tgt) {
+                                                              float* __restrict__ o_tgt, const int32_t* __restrict__ row_map,
+                                                              const int32_t* __restrict__ n_rows_dev) {
+  // Ragged batches: `row_map` (optional) lists the rows that have a target (y > 0) in ascending order and
+  // n_rows_dev[0] is their count (both produced on the device, hiertcn_forward_eval); compact position p then
+  // stands for row row_map[p], workgroups past the count exit at once, and padded steps cost no MFMA at all.
+  // Every row's arithmetic is independent of its position, so results are bit-identical to the dense launch.
+  const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
+  if ((int64_t)blockIdx.x * SC_THREADS >= Rv) return;
   using G = ScGeom<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 stages + 3 x 64 bias floats
   const int tid = threadIdx.x;
@@ -461,11 +468,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 
   uint4 hf[2][G::KS];
   int myy[2];
+  int64_t mysrc[2];
 #pragma unroll
   for (int cbk = 0; cbk < 2; cbk++) {
     int64_t r = row0 + cbk * 32 + lr;
-    const int64_t rc = (r < R) ? r : (R - 1);
-    int yy = (r >= R) ? 0 : y[rc];
+    const int64_t rp = (r < Rv) ? r : (Rv - 1);
+    const int64_t rc = row_map ? (int64_t)row_map[rp] : rp;
+    mysrc[cbk] = rc;
+    int yy = (r >= Rv) ? 0 : y[rc];
     myy[cbk] = (yy > 0 && yy < N) ? yy : 0;
     const uint16_t* hp = hidden + rc * C + 8 * lh;
 #pragma unroll
@@ -668,26 +678,28 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const float M2 = fmaxf(l_own, l_o);
     const float S = __builtin_amdgcn_exp2f(l_own - M2) + __builtin_amdgcn_exp2f(l_o - M2);
     const int cnt = c_own + c_o;
-    if (lh == 0 && myr < R) {
+    if (lh == 0 && myr < Rv) {
       const bool valid = myy[cbk] > 0;
       const float lse = (M2 + log2f(S)) * LN2_F;
-      if (o_rank) o_rank[myr] = valid ? cnt : 0;
-      if (o_ce) o_ce[myr] = valid ? (lse - st[cbk].t) : 0.f;
-      if (o_tgt) o_tgt[myr] = valid ? st[cbk].t : 0.f;
+      const int64_t dst = mysrc[cbk];
+      if (o_rank) o_rank[dst] = valid ? cnt : 0;
+      if (o_ce) o_ce[dst] = valid ? (lse - st[cbk].t) : 0.f;
+      if (o_tgt) o_tgt[dst] = valid ? st[cbk].t : 0.f;
     }
   }
 }
 
 template <int C, int PMODE = 0>
 static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
-                                    const hiertcn_score_out_t* out, hipStream_t st) {
+                                    const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
+                                    const int32_t* n_rows_dev = nullptr) {
   using G = ScGeom<C>;
   const size_t lds = 3 * G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
   const unsigned blocks = (unsigned)((R + 511) / 512);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                     out->rank, out->ce, out->target);
+                     out->rank, out->ce, out->target, row_map, n_rows_dev);
   return hipGetLastError();
 }
 
@@ -728,7 +740,8 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
 
 template <int C>
 static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
-                                 const hiertcn_score_out_t* out, float* logits, hipStream_t st) {
+                                 const hiertcn_score_out_t* out, float* logits, hipStream_t st, const int32_t* row_map,
+                                 const int32_t* n_rows_dev) {
   if (logits) return launch_score_v<C, true, 0>(m, hidden, y, R, nullptr, logits, 0, st);
   if (out && out->topk > 0)  // loss.py:120 ranked indices beside rank / ce: the list kernel (slower epilogue)
     return out->topk <= 8 ? launch_score_topk<C, 8>(m, hidden, y, R, out, st) : launch_score_topk<C, 16>(m, hidden, y, R, out, st);
@@ -777,7 +790,7 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
       default: break;
     }
   }
-  if (!var || !var[0]) return launch_score_pipe<C, 5>(m, hidden, y, R, out, st);  // production
+  if (!var || !var[0]) return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev);  // production
   int mode = 0, stagger = 1;
   if (var && var[0]) {
     mode = var[0] - '0';
@@ -816,12 +829,12 @@ hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, co
 }
 
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
-                        float* logits, hipStream_t st) {
+                        float* logits, hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev) {
   if (R <= 0) return hipSuccess;
   switch (m.Clast) {
-    case 64: return launch_score_c<64>(m, hidden, y, R, out, logits, st);
-    case 128: return launch_score_c<128>(m, hidden, y, R, out, logits, st);
-    case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st);
+    case 64: return launch_score_c<64>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev);
+    case 128: return launch_score_c<128>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev);
+    case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev);
     default: return hipErrorInvalidValue;
   }
 }
