@@ -259,7 +259,7 @@ int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* s
 }
 
 static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
-                       hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr) {
+                       hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr, float* split_scratch = nullptr) {
   size_t slot = 0;
   const bool timing = h->timing;
   if (timing) {
@@ -273,7 +273,7 @@ static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t
     slot = h->ev_used++;
     HIP_TRY(hipEventRecord(h->ev_begin[slot], st));
   }
-  HIP_TRY(launch_score(h->m, hidden, y, R, out, nullptr, st, row_map, n_rows_dev));
+  HIP_TRY(launch_score(h->m, hidden, y, R, out, nullptr, st, row_map, n_rows_dev, split_scratch));
   if (timing) HIP_TRY(hipEventRecord(h->ev_end[slot], st));
   return HIERTCN_OK;
 }
@@ -312,7 +312,7 @@ int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, co
 
 // workspace layout of hiertcn_forward_eval (all sub-buffers 256-byte aligned)
 struct EvalWs {
-  size_t pooled, sproj, hidden, rank, ce, gru, tcn, map, nvalid, cscratch, total;
+  size_t pooled, sproj, hidden, rank, ce, tgt, gru, tcn, map, nvalid, cscratch, split, total;
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
 static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
@@ -328,6 +328,8 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
   w.map = off;    off += al256((size_t)B * S * L * sizeof(int32_t));           // ragged batches: rows that carry a target
   w.nvalid = off; off += al256(sizeof(int32_t));
   w.cscratch = off; off += al256(((size_t)B * S * L / 1024 + 2) * sizeof(int32_t));
+  w.tgt = off;    off += al256((size_t)B * S * L * sizeof(float));
+  w.split = off;  off += al256((size_t)score_split_parts(B * S * L, m.NP) * 2 * B * S * L * sizeof(float));   // small batches only (parts > 1)
   w.total = off;
   return w;
 }
@@ -381,7 +383,13 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
     HIP_TRY(hipMemsetAsync(so.ce, 0, (size_t)R * sizeof(float), st));
     if (so.target) HIP_TRY(hipMemsetAsync(so.target, 0, (size_t)R * sizeof(float), st));
   }
-  int rc = score_timed(h, hidden, y_ids, R, &so, st, row_map, n_valid);
+  float* split = nullptr;
+  if (so.topk == 0 && score_split_parts(R, h->m.NP) > 1) {
+    split = reinterpret_cast<float*>(ws + w.split);
+    if (!so.target) so.target = reinterpret_cast<float*>(ws + w.tgt);   // the merge needs the target logit
+    HIP_TRY(hipMemsetAsync(so.target, 0, (size_t)R * sizeof(float), st));
+  }
+  int rc = score_timed(h, hidden, y_ids, R, &so, st, row_map, n_valid, split);
   if (rc != HIERTCN_OK) return rc;
   if (metrics8) {
     if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");

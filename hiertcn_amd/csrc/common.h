@@ -95,7 +95,10 @@ hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* s
                              void* workspace, hipStream_t st);
 // row_map / n_rows_dev (optional, production kernel only): score only the rows listed in row_map[0 .. n_rows_dev[0])
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
-                        float* logits, hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr);
+                        float* logits, hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr,
+                        float* split_scratch = nullptr);
+// small batches: number of catalogue parts the production kernel splits into (1 = none); scratch = parts * 2 * R floats
+int score_split_parts(int64_t R, int NP);
 // ascending list of the rows with y > 0 (device-side, 3 small kernels): map [R], n_valid [1], scratch [(R+1023)/1024 + 1] ints
 hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_t* n_valid, int32_t* scratch, hipStream_t st);
 hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse, const float* w,

@@ -29,6 +29,18 @@ struct ScGeom {
   static_assert((SC_STAGE * CH) % SC_THREADS == 0, "stage must split evenly");
 };
 
+// Catalogue parts for a small batch: enough (row tile, part) workgroups to cover the 256 CUs about once, at least 16
+// stages (1024 items) per part, at most 32 parts.  1 = no split (large batches fill the chip with row tiles alone).
+int score_split_parts(int64_t R, int NP) {
+  const int64_t tiles = (R + SC_THREADS - 1) / SC_THREADS;
+  if (tiles >= 128) return 1;
+  int64_t parts = (256 + tiles - 1) / tiles;
+  const int64_t by_len = (NP / SC_STAGE) / 16;
+  if (parts > by_len) parts = by_len;
+  if (parts > 32) parts = 32;
+  return parts < 1 ? 1 : (int)parts;
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -451,7 +463,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
                                                               const float* __restrict__ out_bias, int N, int NP,
                                                               int32_t* __restrict__ o_rank, float* __restrict__ o_ce,
                                                               float* __restrict__ o_tgt, const int32_t* __restrict__ row_map,
-                                                              const int32_t* __restrict__ n_rows_dev) {
+                                                              const int32_t* __restrict__ n_rows_dev, int part_stages,
+                                                              float* __restrict__ partials) {
+  // Small batches: gridDim.y > 1 splits the CATALOGUE -- workgroup (x, p) walks stages [p*part_stages, (p+1)*part_stages)
+  // for row tile x and writes (count, log2-sum-exp2) per row into `partials` [gridDim.y][2][R]; k_score_merge adds them
+  // up.  A 6,400-row XING batch (32 lanes) otherwise occupies 13 of the 256 CUs for a whole pass over the table.
   // Ragged batches: `row_map` (optional) lists the rows that have a target (y > 0) in ascending order and
   // n_rows_dev[0] is their count (both produced on the device, hiertcn_forward_eval); compact position p then
   // stands for row row_map[p], workgroups past the count exit at once, and padded steps cost no MFMA at all.
@@ -510,7 +526,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     st[cbk].xp = st[cbk].ep = st[cbk].ssave = 0.f;
   }
 
-  const int n_stages = NP / SC_STAGE;
+  const int n_all = NP / SC_STAGE;
+  const int stg_lo = partials ? (int)blockIdx.y * part_stages : 0;
+  const int stg_hi0 = partials ? stg_lo + part_stages : n_all;
+  const int n_stages = ((stg_hi0 < n_all) ? stg_hi0 : n_all) - stg_lo;   // stages of THIS workgroup (may be <= 0 for a tail part)
   constexpr int PIECES = G::STAGE_BYTES / 1024;
   constexpr int PPW = PIECES / 8;
   constexpr int BIAS_OFF = 3 * G::STAGE_BYTES;
@@ -526,7 +545,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
                  : "v"(gsrc), "s"(dst)
                  : "memory");
   };
-  auto stage_issue = [&](int stg, int buf) {
+  auto stage_issue = [&](int stg_rel, int buf) {
+    const int stg = stg_lo + stg_rel;
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
       const int piece = wave * PPW + i;
@@ -638,11 +658,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   } while (0)
 
   f32x16 accA, accB;
-  stage_issue(0, 0);
+  if (n_stages > 0) stage_issue(0, 0);
   if (n_stages > 1) stage_issue(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  {  // tile (stage 0, ib 0, step block 0) has nothing to overlap with
+  if (n_stages > 0) {  // tile (stage 0, ib 0, step block 0) has nothing to overlap with
     bias_init(accA, 0, 0);
 #pragma unroll
     for (int s = 0; s < G::KS; s++) {
@@ -678,6 +698,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const float M2 = fmaxf(l_own, l_o);
     const float S = __builtin_amdgcn_exp2f(l_own - M2) + __builtin_amdgcn_exp2f(l_o - M2);
     const int cnt = c_own + c_o;
+    if (partials) {
+      if (lh == 0 && myr < Rv) {
+        float* pp = partials + (int64_t)blockIdx.y * 2 * R;
+        pp[myr] = __int_as_float(cnt);
+        pp[R + myr] = (n_stages > 0) ? M2 + log2f(S) : -INFINITY;   // log2 of this part's sum of 2^(z log2 e)
+        if (blockIdx.y == 0 && o_tgt) o_tgt[mysrc[cbk]] = (myy[cbk] > 0) ? st[cbk].t : 0.f;
+      }
+      continue;
+    }
     if (lh == 0 && myr < Rv) {
       const bool valid = myy[cbk] > 0;
       const float lse = (M2 + log2f(S)) * LN2_F;
@@ -689,17 +718,48 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   }
 }
 
+// adds up the catalogue parts of k_score_pipe (small-batch split): rank = sum of counts, lse = log-sum-exp over parts
+__global__ void k_score_merge(const float* __restrict__ partials, int parts, int64_t R, const int32_t* __restrict__ row_map,
+                              const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ y, const float* __restrict__ tgt,
+                              int32_t* __restrict__ o_rank, float* __restrict__ o_ce) {
+  const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
+  if (p >= Rv) return;
+  const int64_t row = row_map ? (int64_t)row_map[p] : p;
+  int cnt = 0;
+  float M = -INFINITY;
+  for (int k = 0; k < parts; k++) {
+    cnt += __float_as_int(partials[(int64_t)k * 2 * R + p]);
+    M = fmaxf(M, partials[(int64_t)k * 2 * R + R + p]);
+  }
+  float S = 0.f;
+  for (int k = 0; k < parts; k++) S += __builtin_amdgcn_exp2f(partials[(int64_t)k * 2 * R + R + p] - M);
+  const bool valid = y[row] > 0;
+  o_rank[row] = valid ? cnt : 0;
+  o_ce[row] = valid ? (M + log2f(S)) * LN2_F - tgt[row] : 0.f;
+}
+
 template <int C, int PMODE = 0>
 static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
                                     const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
-                                    const int32_t* n_rows_dev = nullptr) {
+                                    const int32_t* n_rows_dev = nullptr, float* split_scratch = nullptr) {
   using G = ScGeom<C>;
   const size_t lds = 3 * G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
   const unsigned blocks = (unsigned)((R + 511) / 512);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  const int parts = score_split_parts(R, m.NP);
+  if (PMODE == 5 && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
+    const int n_all = m.NP / SC_STAGE;
+    const int part_stages = (n_all + parts - 1) / parts;
+    hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+                       out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch);
+    hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
+                       out->target, out->rank, out->ce);
+    return hipGetLastError();
+  }
   hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                     out->rank, out->ce, out->target, row_map, n_rows_dev);
+                     out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr);
   return hipGetLastError();
 }
 
@@ -741,7 +801,7 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
 template <int C>
 static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
                                  const hiertcn_score_out_t* out, float* logits, hipStream_t st, const int32_t* row_map,
-                                 const int32_t* n_rows_dev) {
+                                 const int32_t* n_rows_dev, float* split_scratch) {
   if (logits) return launch_score_v<C, true, 0>(m, hidden, y, R, nullptr, logits, 0, st);
   if (out && out->topk > 0)  // loss.py:120 ranked indices beside rank / ce: the list kernel (slower epilogue)
     return out->topk <= 8 ? launch_score_topk<C, 8>(m, hidden, y, R, out, st) : launch_score_topk<C, 16>(m, hidden, y, R, out, st);
@@ -790,7 +850,7 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
       default: break;
     }
   }
-  if (!var || !var[0]) return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev);  // production
+  if (!var || !var[0]) return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);  // production
   int mode = 0, stagger = 1;
   if (var && var[0]) {
     mode = var[0] - '0';
@@ -829,12 +889,12 @@ hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, co
 }
 
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
-                        float* logits, hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev) {
+                        float* logits, hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev, float* split_scratch) {
   if (R <= 0) return hipSuccess;
   switch (m.Clast) {
-    case 64: return launch_score_c<64>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev);
-    case 128: return launch_score_c<128>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev);
-    case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev);
+    case 64: return launch_score_c<64>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
+    case 128: return launch_score_c<128>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
+    case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
     default: return hipErrorInvalidValue;
   }
 }

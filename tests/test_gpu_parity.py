@@ -351,8 +351,9 @@ def test_full_catalogue_properties_at_north_star_size():
 
 
 def test_ragged_batch_compaction_is_bit_identical(setup):
-    """hiertcn_forward_eval scores only the rows that carry a target (device-side row list); per-row outputs must
-    equal the dense launch of the same kernel bit for bit, padded rows must be exactly rank 0 / ce 0."""
+    """hiertcn_forward_eval scores only the rows that carry a target (device-side row list) and, for a batch this
+    small, splits the catalogue over workgroups (partial counts / log-sum-exps merged by k_score_merge): ranks must
+    equal the dense single-pass launch exactly, ce to fp32 summation order (2e-5), padded rows exactly rank 0 / ce 0."""
     s = setup
     eng = s["eng"]
     B, S, L = s["B"], s["S"], s["L"]
@@ -362,8 +363,8 @@ def test_ragged_batch_compaction_is_bit_identical(setup):
     out = eng.forward_eval(dev(s["x"]), dev(s["y"]), dev(s["mask"]), dev(s["st0"]), want_rows=True)
     assert (y == 0).sum() > 0.2 * y.size, "the batch must be ragged"
     assert np.array_equal(out["rank"].cpu().numpy().reshape(-1), dense["rank"].cpu().numpy())
-    assert np.array_equal(out["ce"].cpu().numpy().reshape(-1), dense["ce"].cpu().numpy())
-    assert not out["rank"].cpu().numpy().reshape(-1)[y == 0].any()
+    assert np.abs(out["ce"].cpu().numpy().reshape(-1) - dense["ce"].cpu().numpy()).max() < 2e-5
+    assert not out["rank"].cpu().numpy().reshape(-1)[y == 0].any() and not out["ce"].cpu().numpy().reshape(-1)[y == 0].any()
     # all rows padded: nothing to score, every output zero, metrics NaN-free zeros
     z = np.zeros_like(s["y"])
     o0 = eng.forward_eval(dev(z), dev(z), dev(s["mask"]), dev(s["st0"]), want_rows=True)
