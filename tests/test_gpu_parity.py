@@ -369,3 +369,37 @@ def test_ragged_batch_compaction_is_bit_identical(setup):
     z = np.zeros_like(s["y"])
     o0 = eng.forward_eval(dev(z), dev(z), dev(s["mask"]), dev(s["st0"]), want_rows=True)
     assert not o0["rank"].cpu().numpy().any() and not o0["ce"].cpu().numpy().any()
+
+
+@pytest.mark.parametrize("B,S,L,N,d,H", [(1, 1, 1, 65, 64, 32),      # one lane, one slot, one step
+                                         (3, 2, 32, 200, 64, 32),     # L = 32: the fused low level's limit
+                                         (2, 2, 33, 300, 64, 32),     # L = 33: model_hier on the layer-at-a-time path
+                                         (5, 1, 7, 64, 128, 64),      # N = 64: exactly one scoring stage
+                                         (2, 3, 5, 2, 64, 32),        # N = 2: the null id and one item
+                                         (40, 2, 20, 1000, 256, 64)]) # more lanes than one metrics wave
+def test_edge_shapes_against_oracle(B, S, L, N, d, H):
+    from hiertcn_amd.engine import Engine, metrics_dict
+    args = small_args(N=N, d=d, H=H, S=S, L=L, B=B)
+    p = make_params(args)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    pr = O.round_params_bf16(p, E=d)
+    rng = np.random.default_rng(B * 1000 + L)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.2 * rng.standard_normal((B, H * args.num_layer))).astype(np.float32)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+    m = metrics_dict(out["metrics8"])
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, st = O.model_hier(args, xl, yl, ml, st0, pr, O.MIRROR)
+    ref = O.masked_loss_and_metrics(pred, y.reshape(B, S * L), N)
+    assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
+    assert abs(m["loss"] - ref["loss"]) < 1e-3
+    assert m["user_count"] == float((y.reshape(B, -1) > 0).any(1).sum())
+    # ranks: inside the oracle's bracket for a 2e-3 logit tolerance (exact wherever no other logit is that close)
+    z = pred * (y.reshape(B, S * L, 1) > 0)
+    zt = np.take_along_axis(z, y.reshape(B, S * L, 1).astype(np.int64), -1)
+    lo, hi = (z > zt + 2e-3).sum(-1), (z > zt - 2e-3).sum(-1) - 1
+    r = out["rank"].cpu().numpy().reshape(B, S * L)
+    v = y.reshape(B, S * L) > 0
+    assert np.all(lo[v] <= r[v]) and np.all(r[v] <= np.maximum(hi, lo)[v]) and not r[~v].any()
+    eng.close()
