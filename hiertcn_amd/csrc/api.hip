@@ -305,7 +305,7 @@ int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, co
                     void* stream) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (!rank || !ce || !y_ids || !out8 || B < 1 || T < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
   HIP_TRY(launch_metrics_scratch(h->m, rank, ce, y_ids, B, T, out8, h->metric_scratch, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
@@ -392,7 +392,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   int rc = score_timed(h, hidden, y_ids, R, &so, st, row_map, n_valid, split);
   if (rc != HIERTCN_OK) return rc;
   if (metrics8) {
-    if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+    if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
     HIP_TRY(launch_metrics_scratch(h->m, so.rank, so.ce, y_ids, B, S * L, metrics8, h->metric_scratch, st));
   }
   return HIERTCN_OK;
@@ -421,7 +421,7 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
   if (!x_ids || !y_ids || !mask || !state_in || !workspace || !state_out || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
-  if ((B + 255) / 256 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
   if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, state_in, B, S, L, workspace, state_out, metrics8, h->metric_scratch,
                              reinterpret_cast<hipStream_t>(stream)) != 0)
     return fail(HIERTCN_ERR_HIP, "%s", train_last_error());

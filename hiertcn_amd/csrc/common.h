@@ -105,4 +105,4 @@ hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, co
                                    int stg_begin, int stg_end, uint16_t* gout, hipStream_t st);
 hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,
                                   double* out8, double* scratch, hipStream_t st);
-#define HIERTCN_METRIC_BLOCKS_MAX 16384  // 256 lanes per block -> up to 4.19 M lanes per call
+#define HIERTCN_METRIC_BLOCKS_MAX 65536  // 4 lanes per block -> up to 262,144 lanes per call

@@ -10,19 +10,20 @@
 
 #define MT_THREADS 256
 
+// One wave per lane (user): the wave's 64 threads stride over the lane's T steps (coalesced 12 B per step), per-thread
+// partial sums are combined by a fixed shuffle tree, the 4 lanes of a workgroup by a fixed-order loop.
 __global__ __launch_bounds__(MT_THREADS) void k_lane_metrics(const int32_t* __restrict__ rank, const float* __restrict__ ce,
                                                              const int32_t* __restrict__ y, int B, int T, int N,
                                                              double* __restrict__ partial /*[gridDim.x][8]*/) {
   __shared__ double red[MT_THREADS / 64][8];
-  const int b = blockIdx.x * MT_THREADS + threadIdx.x;
-  double v[8];
-#pragma unroll
-  for (int k = 0; k < 8; k++) v[k] = 0.0;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * (MT_THREADS / 64) + wave;
+  float loss = 0.f, r1 = 0.f, r5 = 0.f, r10 = 0.f, rr = 0.f, rf = 0.f;
+  int act = 0;
   if (b < B) {
-    float loss = 0.f, r1 = 0.f, r5 = 0.f, r10 = 0.f, rr = 0.f, rf = 0.f;
-    int act = 0;
     const int64_t base = (int64_t)b * T;
-    for (int t = 0; t < T; t++) {
+    const float invN = 1.0f / (float)N;
+    for (int t = lane; t < T; t += 64) {
       if (y[base + t] > 0) {
         const float rk = (float)rank[base + t];
         act++;
@@ -31,22 +32,24 @@ __global__ __launch_bounds__(MT_THREADS) void k_lane_metrics(const int32_t* __re
         r5 += (rk <= 4.f) ? 1.f : 0.f;
         r10 += (rk <= 9.f) ? 1.f : 0.f;
         rr += 1.0f / (1.0f + rk);
-        rf += rk / (float)N;
+        rf += rk * invN;
       }
     }
+  }
+  for (int off = 32; off > 0; off >>= 1) {
+    loss += __shfl_down(loss, off); r1 += __shfl_down(r1, off); r5 += __shfl_down(r5, off); r10 += __shfl_down(r10, off);
+    rr += __shfl_down(rr, off); rf += __shfl_down(rf, off); act += __shfl_down(act, off);
+  }
+  if (lane == 0) {
+    double v[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (act > 0) {
       const float den = (float)act + 1e-6f;  // model.py:114 (fp32 in the reference graph)
       v[0] = loss / den; v[1] = r1 / den; v[2] = r5 / den; v[3] = r10 / den; v[4] = rr / den; v[5] = rf / den;
       v[6] = 1.0;
       v[7] = (double)act;
     }
-  }
-  // wave tree, then fixed-order combine of the 4 waves
 #pragma unroll
-  for (int k = 0; k < 8; k++) {
-    double x = v[k];
-    for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][k] = x;
+    for (int k = 0; k < 8; k++) red[wave][k] = v[k];
   }
   __syncthreads();
   if (threadIdx.x < 8) {
@@ -56,21 +59,22 @@ __global__ __launch_bounds__(MT_THREADS) void k_lane_metrics(const int32_t* __re
   }
 }
 
-__global__ void k_metrics_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out8) {
-  if (threadIdx.x < 8) {
-    double s = 0.0;
-    for (int i = 0; i < nblocks; i++) s += partial[(int64_t)i * 8 + threadIdx.x];
-    out8[threadIdx.x] = s;
-  }
+// 8 columns x 32 threads: strided partial sums, then a fixed shuffle tree per column
+__global__ __launch_bounds__(256) void k_metrics_final(const double* __restrict__ partial, int nblocks, double* __restrict__ out8) {
+  const int col = threadIdx.x >> 5, j = threadIdx.x & 31;
+  double s = 0.0;
+  for (int i = j; i < nblocks; i += 32) s += partial[(int64_t)i * 8 + col];
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+  if (j == 0) out8[col] = s;
 }
 
 // `partial` scratch lives behind out8: the caller passes a buffer of 8 * (1 + ceil(B/256)) doubles
 // through the handle's metric scratch (see api.hip).
 hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,
                                   double* out8, double* scratch, hipStream_t st) {
-  const int nblocks = (B + MT_THREADS - 1) / MT_THREADS;
+  const int nblocks = (B + MT_THREADS / 64 - 1) / (MT_THREADS / 64);   // 4 lanes per workgroup
   hipLaunchKernelGGL(k_lane_metrics, dim3(nblocks), dim3(MT_THREADS), 0, st, rank, ce, y, B, T, m.N, scratch);
-  hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(64), 0, st, scratch, nblocks, out8);
+  hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(256), 0, st, scratch, nblocks, out8);
   return hipGetLastError();
 }
 
