@@ -403,7 +403,6 @@ int hiertcn_train_enable(hiertcn_handle_t h) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (h->train.enabled) return HIERTCN_OK;
   if (h->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_train_enable must precede hiertcn_set_weights (the fp32 masters are filled there)");
-  if (!h->m.hier) return fail(HIERTCN_ERR_INVALID, "training is built for model_hier only");
   HIP_TRY(train_enable(h->m, h->train));
   return HIERTCN_OK;
 }
@@ -418,7 +417,8 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
                                    double* metrics8, void* stream) {
   CHECK_READY(h);
   if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
-  if (!x_ids || !y_ids || !mask || !state_in || !workspace || !state_out || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (h->m.hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
   if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");

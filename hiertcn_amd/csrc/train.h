@@ -13,7 +13,7 @@ struct TrainCtx {
   float* arena = nullptr;  // [4][total]: master | grad | m | v
   size_t total = 0;
   TrainSeg emb, emb_bias, projT, projS, outT, out_bias;
-  TrainSeg convT[HIERTCN_MAX_BLOCKS], conv_bias[HIERTCN_MAX_BLOCKS];
+  TrainSeg convT[HIERTCN_MAX_BLOCKS], conv_bias[HIERTCN_MAX_BLOCKS], resT[HIERTCN_MAX_BLOCKS], res_bias[HIERTCN_MAX_BLOCKS];
   TrainSeg wg[HIERTCN_MAX_LAYERS], bg[HIERTCN_MAX_LAYERS], wc[HIERTCN_MAX_LAYERS], bc[HIERTCN_MAX_LAYERS];
   void* blas = nullptr;  // rocblas_handle
   int64_t step = 0;      // Adam time step t

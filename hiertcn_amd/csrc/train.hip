@@ -10,7 +10,7 @@
 // GEMMs and go to rocBLAS (bf16 inputs / fp32 accumulate for the low level, fp32 for the GRU); the pieces
 // around them (masks of the relus, causal shifts, scatter-adds into the item table, gate derivatives, Adam)
 // are hand-written, bandwidth-bound kernels.  Gradients pass straight through the bf16 roundings of the
-// forward pass.  Restrictions of this build: model_hier with equal widths (no Dense down-sample residual).
+// forward pass.  Both model_hier and the single-level model_tcn (per-block widths, Dense down-sample residual).
 #include <rocblas/rocblas.h>
 #include <stdarg.h>
 #include <stdio.h>
@@ -47,12 +47,18 @@ size_t train_layout(const ModelDev& m, TrainCtx& t) {
   seg(t.emb, (size_t)m.N * m.E);
   seg(t.outT, (size_t)m.NP * m.Clast);
   seg(t.out_bias, (size_t)m.NP);
-  seg(t.emb_bias, (size_t)m.E);
-  seg(t.projT, (size_t)m.E * m.E);
-  seg(t.projS, (size_t)m.E * m.HT);
+  if (m.hier) {
+    seg(t.emb_bias, (size_t)m.E);
+    seg(t.projT, (size_t)m.E * m.E);
+    seg(t.projS, (size_t)m.E * m.HT);
+  }
   for (int i = 0, cin = m.E; i < m.n_blocks; cin = m.C[i], i++) {
     seg(t.convT[i], (size_t)m.K * m.C[i] * cin);
     seg(t.conv_bias[i], (size_t)m.C[i]);
+    if (cin != m.C[i]) {
+      seg(t.resT[i], (size_t)m.C[i] * cin);
+      seg(t.res_bias[i], (size_t)m.C[i]);
+    }
   }
   for (int l = 0; l < m.nl; l++) {
     const int in = (l == 0) ? m.E : m.H;
@@ -77,9 +83,14 @@ hipError_t train_enable(ModelDev& m, TrainCtx& t) {
   // the fp32-stored tensors ARE their masters from now on (the conversion kernels of set_weights write into the arena)
   float* M = t.master();
   m.out_bias = M + t.out_bias.off;
-  m.emb_bias = M + t.emb_bias.off;
-  m.projS = M + t.projS.off;
-  for (int i = 0; i < m.n_blocks; i++) m.conv_bias[i] = M + t.conv_bias[i].off;
+  if (m.hier) {
+    m.emb_bias = M + t.emb_bias.off;
+    m.projS = M + t.projS.off;
+  }
+  for (int i = 0; i < m.n_blocks; i++) {
+    m.conv_bias[i] = M + t.conv_bias[i].off;
+    if (t.resT[i].n) m.res_bias[i] = M + t.res_bias[i].off;
+  }
   for (int l = 0; l < m.nl; l++) {
     m.gru_wg[l] = M + t.wg[l].off; m.gru_bg[l] = M + t.bg[l].off;
     m.gru_wc[l] = M + t.wc[l].off; m.gru_bc[l] = M + t.bc[l].off;
@@ -122,8 +133,10 @@ hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t 
   if ((e = cast_bf16(M + t.emb.off, m.emb, (int64_t)t.emb.n, m.E, st)) != hipSuccess) return e;  // row 0 = null id -> zeros (model.py:59)
   if ((e = cast_bf16(M + t.outT.off, m.outT, (int64_t)t.outT.n, 0, st)) != hipSuccess) return e;
   if (m.hier && (e = cast_bf16(M + t.projT.off, m.projT, (int64_t)t.projT.n, 0, st)) != hipSuccess) return e;
-  for (int i = 0; i < m.n_blocks; i++)
+  for (int i = 0; i < m.n_blocks; i++) {
     if ((e = cast_bf16(M + t.convT[i].off, m.convT[i], (int64_t)t.convT[i].n, 0, st)) != hipSuccess) return e;
+    if (t.resT[i].n && (e = cast_bf16(M + t.resT[i].off, m.resT[i], (int64_t)t.resT[i].n, 0, st)) != hipSuccess) return e;
+  }
   return hipSuccess;
 }
 
@@ -141,6 +154,7 @@ hipError_t train_fill_masters(const ModelDev& m, TrainCtx& t, const hiertcn_weig
       if ((e = launch_transpose_f32(w->conv_kernel[i] + (size_t)j * cin * cout, M + t.convT[i].off + (size_t)j * cin * cout, cin, cout, st)) !=
           hipSuccess)
         return e;
+    if (t.resT[i].n && (e = launch_transpose_f32(w->res_kernel[i], M + t.resT[i].off, cin, cout, st)) != hipSuccess) return e;  // [Cin][Cout] -> [Cout][Cin]
   }
   t.step = 0;
   if ((e = hipMemsetAsync(t.mom1(), 0, 2 * t.total * sizeof(float), st)) != hipSuccess) return e;  // m and v
@@ -410,6 +424,10 @@ hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weig
           (e = tr(d->conv_kernel[i] + (size_t)j * cin * cout, A + t.convT[i].off + (size_t)j * cin * cout, cout, cin)) != hipSuccess)
         return e;
     if ((e = cp(d->conv_bias[i], t.conv_bias[i], (size_t)cout)) != hipSuccess) return e;
+    if (t.resT[i].n) {
+      if ((e = tr(d->res_kernel[i], A + t.resT[i].off, cout, cin)) != hipSuccess) return e;
+      if ((e = cp(d->res_bias[i], t.res_bias[i], (size_t)cout)) != hipSuccess) return e;
+    }
   }
   if (m.hier) {
     if ((e = cp(d->emb_bias, t.emb_bias, (size_t)E)) != hipSuccess) return e;
@@ -443,11 +461,13 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   memset(&w, 0, sizeof(w));
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
-  const size_t R = (size_t)B * S * L, C = (size_t)m.E, HT = (size_t)m.HT, H = (size_t)m.H;
-  w.pooled = take((size_t)B * S * C * 4);
-  w.sproj = take((size_t)B * S * C * 4);
-  w.gru_ws = take(gru_workspace_bytes(m, B, S));
-  w.gru_save = take(gru_save_floats(m, B, S) * 4);
+  const size_t R = (size_t)B * S * L, E = (size_t)m.E, HT = (size_t)m.HT, H = (size_t)m.H;
+  size_t C = E;   // widest activation
+  for (int i = 0; i < m.n_blocks; i++) C = (size_t)m.C[i] > C ? (size_t)m.C[i] : C;
+  w.pooled = take((size_t)B * S * E * 4);
+  w.sproj = take((size_t)B * S * E * 4);
+  w.gru_ws = take(m.hier ? gru_workspace_bytes(m, B, S) : 0);
+  w.gru_save = take(m.hier ? gru_save_floats(m, B, S) * 4 : 0);
   // activations kept for the backward pass: [0] embedded inputs, [1] projection output a^0, then per block: c_k, a^k
   for (int i = 0; i < 2 + 2 * m.n_blocks; i++) w.act[i] = take(R * C * 2);
   w.rank = take(R * 4); w.ce = take(R * 4); w.tgt = take(R * 4); w.lse = take(R * 4); w.w = take(R * 4);
@@ -468,13 +488,13 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   }
   w.nc_stages = (int)st;
   w.gchunk = take(R * st * 64 * 2);
-  w.dsp_ext = take((size_t)B * (S + 1) * C * 4);
+  w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
   w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
-  w.dpooled = take((size_t)B * S * C * 4);
+  w.dpooled = take((size_t)B * S * E * 4);
   w.dstate[0] = take((size_t)B * HT * 4); w.dstate[1] = take((size_t)B * HT * 4);
   w.dhp = take((size_t)B * HT * 4);
   w.dac = take((size_t)B * H * 4); w.dag = take((size_t)B * 2 * H * 4); w.dhpart = take((size_t)B * H * 4);
-  const size_t Kmax = (C > H ? C : H) + H;
+  const size_t Kmax = (E > H ? E : H) + H;
   w.dcat_c = take((size_t)B * Kmax * 4); w.dcat_g = take((size_t)B * Kmax * 4); w.din_up = take((size_t)B * H * 4);
   w.total = off;
   return w;
@@ -501,16 +521,16 @@ static rocblas_status gemm_f32(rocblas_handle h, rocblas_operation ta, rocblas_o
 int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y, const float* mask, const float* state_in, int B,
                            int S, int L, void* wsp, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st) {
   if (!t.enabled) return tfail("training is not enabled on this handle (hiertcn_train_enable before hiertcn_set_weights)");
-  if (!m.hier) return tfail("train step: only model_hier is built");
-  for (int i = 0; i < m.n_blocks; i++)
-    if (m.C[i] != m.E || m.resT[i]) return tfail("train step: equal widths / identity residual only in this build");
   rocblas_handle bl = reinterpret_cast<rocblas_handle>(t.blas);
   T_BLAS(rocblas_set_stream(bl, st));
   const TrainWs w = train_ws(m, B, S, L);
   unsigned char* ws = reinterpret_cast<unsigned char*>(wsp);
-  const int E = m.E, C = m.E, H = m.H, HT = m.HT, nb = m.n_blocks;
+  const int E = m.E, H = m.H, HT = m.HT, nb = m.n_blocks, CL = m.Clast;
+  int Cmax = E;
+  for (int i = 0; i < nb; i++) Cmax = m.C[i] > Cmax ? m.C[i] : Cmax;
   const int64_t n_sess = (int64_t)B * S, R = n_sess * L;
-  if (R * (int64_t)C >= ((int64_t)1 << 31)) return tfail("train step: B*S*L*C must stay below 2^31 (rocBLAS 32-bit dims); use a smaller batch");
+  if (R * (int64_t)Cmax >= ((int64_t)1 << 31)) return tfail("train step: B*S*L*C must stay below 2^31 (rocBLAS 32-bit dims); use a smaller batch");
+  if (!m.hier && S != 1) return tfail("train step: the single-level model takes one sequence per lane (S = 1)");
   float* G = t.grad();
   T_HIP(hipMemsetAsync(G, 0, t.total * sizeof(float), st));
 #define F32(o) reinterpret_cast<float*>(ws + (o))
@@ -521,27 +541,28 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   float* sproj = F32(w.sproj);
   float* hist = F32(w.gru_ws);   // [B][S+1][HT] at the head of the GRU workspace (pool_gru.hip)
   float* gsave = F32(w.gru_save);
-  T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
-  T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
   uint16_t* a_emb = BF(w.act[0]);
-  uint16_t* a0 = BF(w.act[1]);
+  uint16_t* a0 = m.hier ? BF(w.act[1]) : a_emb;   // input of block 0: the projection's output, or the embedded ids themselves
   T_HIP(launch_embed_rows(m, x, R, a_emb, st));
-  {
+  if (m.hier) {
+    T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
+    T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
     LayerArgs a = {};
     a.in = a_emb; a.out = a0; a.W = m.projT; a.seq_init = sproj;
     a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
     T_HIP(launch_tcn_layer(a, st));
   }
-  for (int i = 0; i < nb; i++) {
+  auto a_of = [&](int k) -> uint16_t* { return k == 0 ? a0 : BF(w.act[1 + 2 * k]); };   // a^k: output of block k-1
+  for (int i = 0, cin = E; i < nb; cin = m.C[i], i++) {
     LayerArgs a = {};
-    a.in = BF(w.act[1 + 2 * i]);   // a^{i}: act[1], act[3], ...
+    a.in = a_of(i);
     a.c_out = BF(w.act[2 + 2 * i]);
-    a.out = BF(w.act[3 + 2 * i]);
-    a.W = m.convT[i]; a.bias = m.conv_bias[i];
-    a.Cin = C; a.Cout = C; a.taps = m.K; a.dil = 1 << i; a.L = L; a.n_seq = n_sess; a.linear = 0;
+    a.out = a_of(i + 1);
+    a.W = m.convT[i]; a.bias = m.conv_bias[i]; a.Wres = m.resT[i]; a.bres = m.res_bias[i];
+    a.Cin = cin; a.Cout = m.C[i]; a.taps = m.K; a.dil = 1 << i; a.L = L; a.n_seq = n_sess; a.linear = 0;
     T_HIP(launch_tcn_layer(a, st));
   }
-  const uint16_t* hidden = BF(w.act[1 + 2 * nb]);
+  const uint16_t* hidden = a_of(nb);
   hiertcn_score_out_t so;
   memset(&so, 0, sizeof(so));
   so.rank = reinterpret_cast<int32_t*>(ws + w.rank); so.ce = F32(w.ce); so.target = F32(w.tgt);
@@ -555,8 +576,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users, so.ce, so.target, R, S * L,
                      F32(w.w), F32(w.lse));
   T_HIP(hipGetLastError());
-  float* dH = F32(w.dA);   // [R][C] fp32
-  T_HIP(hipMemsetAsync(dH, 0, (size_t)R * C * 4, st));
+  float* dH = F32(w.dA);   // [R][C_last] fp32
+  T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
   uint16_t* Gc = BF(w.gchunk);
   const int n_stages = m.NP / 64;
   for (int s0 = 0; s0 < n_stages; s0 += w.nc_stages) {
@@ -568,47 +589,69 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
                        G + t.out_bias.off + (size_t)s0 * 64);
     T_HIP(hipGetLastError());
     // dH[R][C] += G[R][NC] . outT_chunk[NC][C]   == col-major: dH^T[C x R] += outT_chunk^T[C x NC] . G^T[NC x R]
-    T_BLAS(gemm_bf16(bl, OPN, OPN, C, (int)R, NC, m.outT + (size_t)s0 * 64 * C, C, Gc, NC, 1.f, dH, C));
+    T_BLAS(gemm_bf16(bl, OPN, OPN, CL, (int)R, NC, m.outT + (size_t)s0 * 64 * CL, CL, Gc, NC, 1.f, dH, CL));
     // d outT_chunk[NC][C] = G^T[NC x R] . hidden[R][C]   == col-major [C x NC] = hidden^T[C x R] . (G^T[NC x R])^T
-    T_BLAS(gemm_bf16(bl, OPN, OPT, C, NC, (int)R, hidden, C, Gc, NC, 0.f, G + t.outT.off + (size_t)s0 * 64 * C, C));
+    T_BLAS(gemm_bf16(bl, OPN, OPT, CL, NC, (int)R, hidden, CL, Gc, NC, 0.f, G + t.outT.off + (size_t)s0 * 64 * CL, CL));
   }
 
   // ================= TemporalBlocks, last to first =========================================================
-  float* da = dH;              // grad of a^k, fp32 [R][C]
-  float* dprev = F32(w.dB);    // grad of a^{k-1}
+  float* da = dH;              // grad of a^{k+1}, fp32 [R][Cout]
+  float* dprev = F32(w.dB);    // grad of a^k
   float* dsf = F32(w.dsf);
   uint16_t* dcb = BF(w.dcb);
   uint16_t* shb = BF(w.shb);
-  const int64_t nRC = R * C;
+  uint16_t* dub = BF(w.dub);
   for (int i = nb - 1; i >= 0; i--) {
-    const uint16_t* a_in = BF(w.act[1 + 2 * i]);
+    const int cin = (i == 0) ? E : m.C[i - 1], cout = m.C[i];
+    const uint16_t* a_in = a_of(i);
     const uint16_t* c_act = BF(w.act[2 + 2 * i]);
-    const uint16_t* a_out = BF(w.act[3 + 2 * i]);
+    const uint16_t* a_out = a_of(i + 1);
     const int dil = 1 << i;
-    hipLaunchKernelGGL(k_block_bwd, dim3((unsigned)((nRC / 4 + 255) / 256)), dim3(256), 0, st, da, a_out, c_act, nRC, dsf, dcb);
+    const int64_t nOut = R * cout;
+    hipLaunchKernelGGL(k_block_bwd, dim3((unsigned)((nOut / 4 + 255) / 256)), dim3(256), 0, st, da, a_out, c_act, nOut, dsf, dcb);
     T_HIP(hipGetLastError());
     // conv bias: sum over rows of dc
-    hipLaunchKernelGGL(k_colsum_bf16, dim3(C / 64 > 0 ? C / 64 : 1, (unsigned)((R + 4095) / 4096)), dim3(256), 0, st, dcb, R, (int64_t)C, C,
+    hipLaunchKernelGGL(k_colsum_bf16, dim3((cout + 63) / 64, (unsigned)((R + 4095) / 4096)), dim3(256), 0, st, dcb, R, (int64_t)cout, cout,
                        G + t.conv_bias[i].off);
     T_HIP(hipGetLastError());
-    // identity residual: d a^{k-1} starts as ds
-    T_HIP(hipMemcpyAsync(dprev, dsf, (size_t)nRC * 4, hipMemcpyDeviceToDevice, st));
+    if (m.resT[i]) {
+      // Dense down-sample on the residual path (customized_tcn_cell.py:102-106,123-124): res = a_in . Wr + br
+      T_HIP(cast_bf16(dsf, dub, nOut, 0, st));
+      T_HIP(colsum_f32(dsf, R, cout, cout, G + t.res_bias[i].off, st));
+      // d resT[Cout][Cin] = ds^T[Cout x R] . a_in[R][Cin]   == col-major [Cin x Cout] = a_in^T[Cin x R] . (ds^T)^T
+      T_BLAS(gemm_bf16(bl, OPN, OPT, cin, cout, (int)R, a_in, cin, dub, cout, 0.f, G + t.resT[i].off, cin));
+      // d a_in[R][Cin] = ds[R][Cout] . resT[Cout][Cin]   == col-major [Cin x R] = resT(col-major [Cin x Cout]) . ds^T[Cout x R]
+      T_BLAS(gemm_bf16(bl, OPN, OPN, cin, (int)R, cout, m.resT[i], cin, dub, cout, 0.f, dprev, cin));
+    } else {
+      // identity residual: d a_in starts as ds
+      T_HIP(hipMemcpyAsync(dprev, dsf, (size_t)nOut * 4, hipMemcpyDeviceToDevice, st));
+    }
     for (int j = 0; j < m.K; j++) {
       const int shift = (m.K - 1 - j) * dil;   // o[t] += a_in[t - shift] . W_j
-      const uint16_t* Wj = m.convT[i] + (size_t)j * C * C;   // [Cout][Cin]
+      const uint16_t* Wj = m.convT[i] + (size_t)j * cin * cout;   // [Cout][Cin]
       // d W_j^T [Cout][Cin] = dc^T[Cout x R] . Xs[R][Cin], Xs[t] = a_in[t - shift]   == col-major [Cin x Cout] = Xs^T[Cin x R] . (dc^T[Cout x R])^T
-      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (C / 8) + 255) / 256)), dim3(256), 0, st, a_in, shb, R, L, C, shift);
+      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (cin / 8) + 255) / 256)), dim3(256), 0, st, a_in, shb, R, L, cin, shift);
       T_HIP(hipGetLastError());
-      T_BLAS(gemm_bf16(bl, OPN, OPT, C, C, (int)R, shb, C, dcb, C, 0.f, G + t.convT[i].off + (size_t)j * C * C, C));
+      T_BLAS(gemm_bf16(bl, OPN, OPT, cin, cout, (int)R, shb, cin, dcb, cout, 0.f, G + t.convT[i].off + (size_t)j * cin * cout, cin));
       // d a_in[tau] += dc[tau + shift] . W_j^T: rows [R][Cout] . [Cout][Cin]   == col-major [Cin x R] += W_j(col-major [Cin x Cout]) . dcs^T[Cout x R]
-      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (C / 8) + 255) / 256)), dim3(256), 0, st, dcb, shb, R, L, C, -shift);
+      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (cout / 8) + 255) / 256)), dim3(256), 0, st, dcb, shb, R, L, cout, -shift);
       T_HIP(hipGetLastError());
-      T_BLAS(gemm_bf16(bl, OPN, OPN, C, (int)R, C, Wj, C, shb, C, 1.f, dprev, C));
+      T_BLAS(gemm_bf16(bl, OPN, OPN, cin, (int)R, cout, Wj, cin, shb, cout, 1.f, dprev, cin));
     }
     float* tmp = da; da = dprev; dprev = tmp;
   }
+  if (!m.hier) {
+    // single-level model_tcn (model.py:56-57,71-73): block 0 reads the embedded ids directly
+    hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R * (E / 4) + 255) / 256)), dim3(256), 0, st, G + t.emb.off, x, da, R, E);
+    T_HIP(hipGetLastError());
+#undef F32
+#undef BF
+    return 0;
+  }
+  const int64_t nRC = R * E;
+#define F32(o) reinterpret_cast<float*>(ws + (o))
+#define BF(o) reinterpret_cast<uint16_t*>(ws + (o))
   // ================= projection u = e . Wp[:E] + sproj (model_hier.py:54-55 -> model_tcn.py:35) ============
-  uint16_t* dub = BF(w.dub);
   T_HIP(cast_bf16(da, dub, nRC, 0, st));
   // d projT[Eout][Ein] = du^T[Eout x R] . e[R][Ein]   == col-major [Ein x Eout] = e^T[Ein x R] . (du^T)^T
   T_BLAS(gemm_bf16(bl, OPN, OPT, E, E, (int)R, a_emb, E, dub, E, 0.f, G + t.projT.off, E));

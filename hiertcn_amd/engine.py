@@ -281,19 +281,22 @@ class Engine:
         return out
 
     # -- training (hiertcn.h "training step") ------------------------------------------------------
-    def train_forward_backward(self, x_ids, y_ids, mask, state_in, state_out=None, metrics8=None):
+    def train_forward_backward(self, x_ids, y_ids, mask=None, state_in=None, state_out=None, metrics8=None):
         """Forward + loss + gradients of every variable (into the handle's gradient arena).
-        Returns dict(state, metrics8)."""
+        Returns dict(state, metrics8).  Single-level handles: x_ids / y_ids [B, 1, T], no mask / state."""
         B, S, L = x_ids.shape
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
-        _req(mask, torch.float32, "mask", (B, S))
-        _req(state_in, torch.float32, "state_in", (B, self.HT))
+        if self.hier:
+            _req(mask, torch.float32, "mask", (B, S))
+            _req(state_in, torch.float32, "state_in", (B, self.HT))
+            if state_out is None:
+                state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
+        else:
+            mask = state_in = state_out = None
         need = int(self.lib.hiertcn_train_workspace_bytes(self._h, B, S, L))
         if self._train_ws is None or self._train_ws.numel() < need:
             self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        if state_out is None:
-            state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
         if metrics8 is None:
             metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
         check(self.lib.hiertcn_train_forward_backward(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
@@ -319,26 +322,29 @@ class Engine:
     def export(self, which: str = "weights", root: Optional[str] = None) -> Dict[str, np.ndarray]:
         """Masters ('weights') or gradients ('grads') as {TF variable name: fp32 ndarray in the reference layout}."""
         from .params import param_shapes
-        root = root or "hier"
-        shapes = param_shapes(self._args_for_shapes, "hier")
+        kind = "hier" if self.hier else "tcn"
+        root = root or kind
+        shapes = param_shapes(self._args_for_shapes, kind)
         bufs = {k: torch.zeros(v, dtype=torch.float32, device=self.device) for k, v in shapes.items()}
         w = _lib.Weights()
-        tcn = f"{root}/tcn"
+        tcn = "hier/tcn" if self.hier else "tcn"
         g = lambda k: bufs[k].data_ptr()  # noqa: E731
-        w.emb_kernel, w.emb_bias, w.proj_kernel = g("hier/emb/kernel"), g("hier/emb/bias"), g("hier/tcn/emb/kernel")
+        w.emb_kernel = g(f"{kind}/emb/kernel")
+        if self.hier:
+            w.emb_bias, w.proj_kernel = g("hier/emb/bias"), g("hier/tcn/emb/kernel")
         for i in range(self.cfg.n_blocks):
-            pre = f"hier/tcn/temporal_conv_net/tblock_{i}"
+            pre = f"{tcn}/temporal_conv_net/tblock_{i}"
             w.conv_kernel[i], w.conv_bias[i] = g(f"{pre}/conv1/kernel"), g(f"{pre}/conv1/bias")
-        w.out_kernel, w.out_bias = g("hier/tcn/dense/kernel"), g("hier/tcn/dense/bias")
+            if f"{pre}/dense/kernel" in bufs:
+                w.res_kernel[i], w.res_bias[i] = g(f"{pre}/dense/kernel"), g(f"{pre}/dense/bias")
+        w.out_kernel, w.out_bias = g(f"{tcn}/dense/kernel"), g(f"{tcn}/dense/bias")
         for l in range(self.nl):
             pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
             w.gru_gate_kernel[l], w.gru_gate_bias[l] = g(f"{pre}/gates/kernel"), g(f"{pre}/gates/bias")
             w.gru_cand_kernel[l], w.gru_cand_bias[l] = g(f"{pre}/candidate/kernel"), g(f"{pre}/candidate/bias")
         check(self.lib.hiertcn_export_weights(self._h, C.byref(w), 0 if which == "weights" else 1, self._stream()))
         torch.cuda.current_stream().synchronize()
-        out = {(root + k[4:] if k.startswith("hier") else k): v.cpu().numpy() for k, v in bufs.items()}
-        del tcn
-        return out
+        return {(root + k[len(kind):] if k.startswith(kind) else k): v.cpu().numpy() for k, v in bufs.items()}
 
     # ---------------------------------------------------------------------------------------
     def timing_enable(self, on: bool = True):

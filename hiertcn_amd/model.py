@@ -169,18 +169,32 @@ class TcnModel:
     embedding (tcn/emb/kernel) -> TemporalConvNet -> scoring, no carried state.  Widths that are not a
     multiple of 32 (BASELINE.json config 1: d = 100) are zero-padded on upload (params.pad_widths)."""
 
-    def __init__(self, args, params: Optional[dict] = None, name: str = "tcn", seed: int = 2):
+    def __init__(self, args, params: Optional[dict] = None, name: str = "tcn", seed: int = 2, train: Optional[bool] = None):
         from .params import pad_widths
         self.args, self.name, self.hier = args, name, False
-        self.params = params if params is not None else init_params(args, seed, "tcn")
-        renamed = {("tcn" + k[len(name):] if k.startswith(name + "/") else k): v for k, v in self.params.items()}
+        self.trainable = bool(getattr(args, "train", False)) if train is None else bool(train)
+        self._params = params if params is not None else init_params(args, seed, "tcn")
+        renamed = {("tcn" + k[len(name):] if k.startswith(name + "/") else k): v for k, v in self._params.items()}
         self._dev_args, dev_params = pad_widths(args, renamed, "tcn")
-        self.engine = Engine(self._dev_args, hier=False)
+        if self.trainable and (self._dev_args.emb_dim != int(getattr(args, "emb_dim", 128)) or
+                               list(self._dev_args.tcn_channel) != [int(c) for c in args.tcn_channel]):
+            raise NotImplementedError("training a width-padded model is not built: use widths that are multiples of 32")
+        self.engine = Engine(self._dev_args, hier=False, train=self.trainable)
         self.engine.set_weights(dev_params, root="tcn")
+
+    @property
+    def params(self) -> dict:
+        if self.trainable:
+            self._params = self.engine.export("weights", root=self.name)
+        return self._params
+
+    @params.setter
+    def params(self, value: dict):
+        self._params = value
 
     def set_parameters(self, params: dict):
         from .params import pad_widths
-        self.params = params
+        self._params = params
         renamed = {("tcn" + k[len(self.name):] if k.startswith(self.name + "/") else k): v for k, v in params.items()}
         self.engine.set_weights(pad_widths(self.args, renamed, "tcn")[1], root="tcn")
 
@@ -204,7 +218,20 @@ class TcnModel:
         return res
 
     def train_step(self, x, y, lr):
-        raise NotImplementedError("the training step (backward + TF-form Adam) is not built yet; run with args.train = False")
+        """One sess.run([train_op, loss]) of run_nn_xing.py: forward, loss, gradients, [all-reduce], TF-form Adam."""
+        from .distributed import all_reduce_gradients
+        if not self.trainable:
+            raise RuntimeError("this model was created without training state (args.train = False)")
+        eng = self.engine
+        xi, yi = _to_ids(x), _to_ids(y)
+        B, T = xi.shape
+        xd = torch.from_numpy(np.ascontiguousarray(xi)).to(eng.device).view(B, 1, T)
+        yd = torch.from_numpy(np.ascontiguousarray(yi)).to(eng.device).view(B, 1, T)
+        out = eng.train_forward_backward(xd, yd)
+        world = all_reduce_gradients(eng.grad_arena())
+        eng.adam_step(float(lr), grad_scale=1.0 / world)
+        m = metrics_dict(out["metrics8"])
+        return dict(loss=m["loss"], user_count=m["user_count"])
 
 
 def get_scope(args, name: str):

@@ -187,7 +187,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
  *                        masters from grad * grad_scale, then refreshes the bf16 device copies.
  * hiertcn_export_weights which = 0: masters, 1: gradients -> fp32 device tensors in the REFERENCE layouts (`dst` holds
  *                        destination pointers; NULL members are skipped) -- checkpoints and tests.
- * This build: model_hier, equal widths (identity residual). */
+ * Both model kinds (hier == 1: x/y [B][S][L]; hier == 0: [B][1][T], mask/state NULL), per-block widths, Dense residual. */
 int hiertcn_train_enable(hiertcn_handle_t h);
 size_t hiertcn_train_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t L);
 int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask,

@@ -231,3 +231,70 @@ def test_run_hier_trains_saves_and_restores(tmp_path):
     assert ra == rb
     model.engine.close()
     fresh.engine.close()
+
+
+def torch_tcn_loss(args, P, x, y):
+    """Single-level model (model.py:56-57,71-73,102-117): ids -> 'emb' -> TemporalConvNet (Dense down-sample where
+    Cin != Cout, customized_tcn_cell.py:102-106) -> scoring -> masked lane-mean cross entropy."""
+    B, T = x.shape
+    N = args.item_num
+    xt, yt = torch.as_tensor(x, dtype=torch.int64), torch.as_tensor(y, dtype=torch.int64)
+    a = (F.embedding(xt, P["tcn/emb/kernel"]) * (xt > 0)[..., None]).transpose(1, 2)   # bf16-stored table: already exact
+    for i in range(len(args.tcn_channel)):
+        pre = f"tcn/temporal_conv_net/tblock_{i}"
+        W = P[f"{pre}/conv1/kernel"].permute(2, 1, 0)
+        d, K = 2 ** i, W.shape[-1]
+        c = torch.relu(F.conv1d(F.pad(a, ((K - 1) * d, 0)), W, P[f"{pre}/conv1/bias"], dilation=d))
+        if f"{pre}/dense/kernel" in P:
+            r = (a.transpose(1, 2) @ P[f"{pre}/dense/kernel"] + P[f"{pre}/dense/bias"]).transpose(1, 2)
+        else:
+            r = a
+        a = ste_bf16(torch.relu(c + r))
+    z = a.transpose(1, 2) @ P["tcn/dense/kernel"] + P["tcn/dense/bias"]
+    m = (yt > 0).double()
+    z = z * m[..., None]
+    ce = F.cross_entropy(z.reshape(-1, N), yt.reshape(-1), reduction="none").reshape(B, -1) * m
+    act = m.sum(1)
+    return (ce.sum(1) / (act + 1e-6)).sum() / (act > 0).double().sum()
+
+
+def test_single_level_training_with_downsample_residual():
+    """model_tcn with unequal widths ([64, 64, 128, 128]: a Dense residual on block 2), T = 70: gradients vs autograd,
+    then TcnModel.train_step lowers the loss."""
+    from hiertcn_amd.args import make_args
+    from hiertcn_amd.engine import Engine, metrics_dict
+    from hiertcn_amd.model import TcnModel
+    from hiertcn_amd.params import init_params
+    N = 600
+    a = make_args([], model_type="hier", item_num=N, emb_dim=64, tcn_channel=[64, 64, 128, 128], kernel_size=3)
+    a.model_type = "tcn"
+    rng = np.random.default_rng(5)
+    p = init_params(a, 2, "tcn")
+    p = {k: (v + 0.05 * rng.standard_normal(v.shape).astype(np.float32)) if k.endswith("/bias") else v for k, v in p.items()}
+    B, T = 5, 70
+    lens = rng.integers(5, T + 1, B)
+    y = (rng.integers(1, N, (B, T)) * (np.arange(T)[None, :] < lens[:, None])).astype(np.int32)
+    x = np.zeros_like(y)
+    x[:, 1:] = y[:, :-1]
+    eng = Engine(a, hier=False, train=True)
+    eng.set_weights(p)
+    dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).cuda().contiguous()  # noqa: E731
+    out = eng.train_forward_backward(dev(x).view(B, 1, T), dev(y).view(B, 1, T))
+    grads = eng.export("grads")
+    pr = O.round_params_bf16(p, E=64)
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in pr.items()}
+    ref_loss = torch_tcn_loss(a, P, x, y)
+    ref_loss.backward()
+    assert abs(metrics_dict(out["metrics8"])["loss"] - float(ref_loss.detach())) < 2e-3
+    assert set(grads) == set(P) and "tcn/temporal_conv_net/tblock_2/dense/kernel" in grads
+    for k in sorted(P):
+        g, r = grads[k].astype(np.float64), P[k].grad.numpy()
+        rel = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
+        cos = float((g * r).sum() / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
+        assert rel < 3e-2 and cos > 0.999, (k, rel, cos)
+    eng.close()
+    model = TcnModel(a, p, train=True)
+    losses = [model.train_step(x, y, 1e-2)["loss"] for _ in range(4)]
+    assert losses[-1] < losses[0], losses
+    assert set(model.params) == set(p)
+    model.engine.close()
