@@ -59,6 +59,8 @@ SYMBOLS = {
     "hiertcn_train_forward_backward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                                   C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hiertcn_grad_arena": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "hiertcn_train_arena": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "hiertcn_adam_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hiertcn_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hiertcn_export_weights": (C.c_int, [C.c_void_p, C.POINTER(Weights), C.c_int32, C.c_void_p]),
     "hiertcn_score_fused": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(ScoreOut), C.c_void_p]),

@@ -435,6 +435,20 @@ int hiertcn_grad_arena(hiertcn_handle_t h, float** grad, size_t* count) {
   return HIERTCN_OK;
 }
 
+int hiertcn_train_arena(hiertcn_handle_t h, int32_t which, float** ptr, size_t* count) {
+  if (!h || !h->train.enabled || !ptr || !count || which < 0 || which > 3) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle / bad argument");
+  *ptr = h->train.arena + (size_t)which * h->train.total;
+  *count = h->train.total;
+  return HIERTCN_OK;
+}
+
+int hiertcn_adam_time(hiertcn_handle_t h, int64_t* get, const int64_t* set) {
+  if (!h || !h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
+  if (set) h->train.step = *set;
+  if (get) *get = h->train.step;
+  return HIERTCN_OK;
+}
+
 int hiertcn_adam_step(hiertcn_handle_t h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   CHECK_READY(h);
   if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");

@@ -315,6 +315,31 @@ class Engine:
 
         return torch.as_tensor(_Raw(), device=self.device)
 
+    def _arena(self, which: int) -> torch.Tensor:
+        ptr, n = C.c_void_p(), C.c_size_t()
+        check(self.lib.hiertcn_train_arena(self._h, which, C.byref(ptr), C.byref(n)))
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f4", "data": (int(ptr.value), False), "version": 2}
+
+        return torch.as_tensor(_Raw(), device=self.device)
+
+    def optimizer_state(self) -> Dict[str, np.ndarray]:
+        """Adam slots (flat, internal layout: valid for this model config only) + time step, for checkpoints."""
+        t = C.c_int64(0)
+        check(self.lib.hiertcn_adam_time(self._h, C.byref(t), None))
+        torch.cuda.current_stream().synchronize()
+        return {"adam_m": self._arena(2).cpu().numpy(), "adam_v": self._arena(3).cpu().numpy(), "adam_t": np.array([t.value], np.int64)}
+
+    def load_optimizer_state(self, state: Dict[str, np.ndarray]):
+        m, v = self._arena(2), self._arena(3)
+        if state["adam_m"].size != m.numel():
+            raise HierTCNError("optimizer state belongs to a different model configuration")
+        m.copy_(torch.from_numpy(np.ascontiguousarray(state["adam_m"], dtype=np.float32)).to(self.device))
+        v.copy_(torch.from_numpy(np.ascontiguousarray(state["adam_v"], dtype=np.float32)).to(self.device))
+        t = C.c_int64(int(np.asarray(state["adam_t"]).reshape(-1)[0]))
+        check(self.lib.hiertcn_adam_time(self._h, None, C.byref(t)))
+
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0):
         """tf.train.AdamOptimizer(lr) defaults (model.py:139)."""
         check(self.lib.hiertcn_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), self._stream()))

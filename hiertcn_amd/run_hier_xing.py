@@ -79,10 +79,16 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
 
     model = sess if sess is not None else HierTCNModel(args)
     epoch = 0
+    state_restored = None
     if args.load:  # :220-229
         fname = args.load_path + str(args.load_epoch) + ".ckpt"
         try:
-            model.set_parameters(checkpoint.load(fname))
+            params, extra = checkpoint.load(fname, with_extra=True)
+            model.set_parameters(params)
+            if getattr(model, "trainable", False) and "adam_m" in extra:   # optimizer slots, as tf.train.Saver keeps them
+                model.engine.load_optimizer_state(extra)
+            if "state_np" in extra:
+                state_restored = extra["state_np"]
             print("Model restored: {}".format(fname))
             epoch = args.load_epoch + 1
         except Exception:
@@ -93,6 +99,8 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
     test_writer = ScalarLog(args.log_path + "test/")
     HT = args.hidden_dim * args.num_layer
     state_np = np.zeros((args.batch_size, HT))           # :241-243: one carried state per loader
+    if state_restored is not None and state_restored.shape == state_np.shape:
+        state_np = state_restored                        # (the reference re-zeroes it on restart; the checkpoint carries it here)
     state_np_validate = np.zeros((args.batch_size, HT))
     state_np_test = np.zeros((args.batch_size, HT))
     while epoch <= args.epoch_max:  # :261
@@ -108,7 +116,10 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
             train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
             if args.save and epoch % args.save_epoch == 0 and epoch != 0:  # :317-321
                 fname = args.save_path + str(epoch) + ".ckpt"
-                checkpoint.save(fname, model.params, extra={"state_np": state_np})  # .params reads the device masters back
+                extra = {"state_np": state_np}
+                if getattr(model, "trainable", False):
+                    extra.update(model.engine.optimizer_state())
+                checkpoint.save(fname, model.params, extra=extra)  # .params reads the device masters back
                 print("Model saved in path: %s" % fname)
         if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:  # :324
             if args.validate:

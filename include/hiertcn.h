@@ -194,6 +194,10 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
                                    const float* state_in, int32_t B, int32_t S, int32_t L, void* workspace,
                                    size_t workspace_bytes, float* state_out, double* metrics8, void* stream);
 int hiertcn_grad_arena(hiertcn_handle_t h, float** grad, size_t* count);
+/* which = 0 masters, 1 gradients, 2 Adam m, 3 Adam v: the flat fp32 arenas (internal layouts; valid for this config
+ * only) -- lets a checkpoint carry the optimizer slots as tf.train.Saver does; hiertcn_adam_time reads / sets t. */
+int hiertcn_train_arena(hiertcn_handle_t h, int32_t which, float** ptr, size_t* count);
+int hiertcn_adam_time(hiertcn_handle_t h, int64_t* get, const int64_t* set);
 int hiertcn_adam_step(hiertcn_handle_t h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int hiertcn_export_weights(hiertcn_handle_t h, const hiertcn_weights_t* dst, int32_t which, void* stream);
 

@@ -298,3 +298,27 @@ def test_single_level_training_with_downsample_residual():
     assert losses[-1] < losses[0], losses
     assert set(model.params) == set(p)
     model.engine.close()
+
+
+def test_optimizer_state_round_trip(trained):
+    """Adam slots + time step survive save/restore: a restored model's next update equals the original's."""
+    from hiertcn_amd.engine import Engine
+    t = trained
+    eng, dev = t["eng"], t["dev"]
+    x, y, mask, st0 = t["batch"]
+    eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    eng.adam_step(1e-2)
+    w_mid, opt = eng.export("weights"), eng.optimizer_state()
+    assert int(opt["adam_t"][0]) >= 1 and np.abs(opt["adam_v"]).sum() > 0
+    eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    eng.adam_step(1e-2)
+    want = eng.export("weights")
+    other = Engine(t["args"], hier=True, train=True)
+    other.set_weights(w_mid)
+    other.load_optimizer_state(opt)
+    other.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    other.adam_step(1e-2)
+    got = other.export("weights")
+    for k in want:
+        assert np.abs(got[k] - want[k]).max() <= 1e-6 * max(1.0, np.abs(want[k]).max()), k
+    other.close()
