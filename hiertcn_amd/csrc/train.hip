@@ -191,6 +191,29 @@ __global__ void k_row_weights(const int32_t* __restrict__ y, const float* __rest
   lse[r] = valid ? ce[r] + tgt[r] : 0.f;
 }
 
+// compact row p = row map[p]: hidden row, target id, weight and log-sum-exp gathered into dense arrays
+__global__ void k_gather_scored(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y, const float* __restrict__ w,
+                                const float* __restrict__ lse, const int32_t* __restrict__ map, int64_t Rv, int C, uint16_t* __restrict__ hc,
+                                int32_t* __restrict__ yc, float* __restrict__ wc, float* __restrict__ lc) {
+  const int ch = C >> 3;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Rv * ch) return;
+  const int64_t p = i / ch;
+  const int c = (int)(i - p * ch);
+  const int64_t r = map[p];
+  *reinterpret_cast<uint4*>(hc + p * C + c * 8) = *reinterpret_cast<const uint4*>(hidden + r * C + c * 8);
+  if (c == 0) { yc[p] = y[r]; wc[p] = w[r]; lc[p] = lse[r]; }
+}
+// dst[map[p]][:] = src[p][:]  (dst zeroed beforehand: padded steps have no gradient)
+__global__ void k_scatter_rows_f32(const float* __restrict__ src, const int32_t* __restrict__ map, int64_t Rv, int C, float* __restrict__ dst) {
+  const int ch = C >> 2;
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Rv * ch) return;
+  const int64_t p = i / ch;
+  const int c = (int)(i - p * ch) * 4;
+  *reinterpret_cast<float4*>(dst + (int64_t)map[p] * C + c) = *reinterpret_cast<const float4*>(src + p * C + c);
+}
+
 // out[c] += sum over rows of bf16 src[r][c]  (d bias of the scoring layer from a G chunk)
 __global__ __launch_bounds__(256) void k_colsum_bf16(const uint16_t* __restrict__ src, int64_t rows, int64_t ld, int cols,
                                                      float* __restrict__ out) {
@@ -451,7 +474,7 @@ hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weig
 // ---------------------------------------------------------------------------------------------------------
 struct TrainWs {
   size_t pooled, sproj, gru_ws, gru_save, act[2 * HIERTCN_MAX_BLOCKS + 2], rank, ce, tgt, lse, w, lane_act, users;
-  size_t dA, dB, dsf, dcb, shb, dub, gchunk, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
+  size_t dA, dB, dsf, dcb, shb, dub, gchunk, map, nvalid, cscratch, hc, yc, wc, lc, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
   size_t total;
   int nc_stages;  // stages (of 64 items) per G chunk
 };
@@ -488,6 +511,8 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   }
   w.nc_stages = (int)st;
   w.gchunk = take(R * st * 64 * 2);
+  w.map = take(R * 4); w.nvalid = take(256); w.cscratch = take((R / 1024 + 2) * 4);
+  w.hc = take(R * C * 2); w.yc = take(R * 4); w.wc = take(R * 4); w.lc = take(R * 4);
   w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
   w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
   w.dpooled = take((size_t)B * S * E * 4);
@@ -566,8 +591,20 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   hiertcn_score_out_t so;
   memset(&so, 0, sizeof(so));
   so.rank = reinterpret_cast<int32_t*>(ws + w.rank); so.ce = F32(w.ce); so.target = F32(w.tgt);
-  T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st));
+  // Only the rows that carry a target are scored and differentiated (a ragged batch is mostly padding): the device builds
+  // their ascending list; its length comes back to the host once per step because it sizes the rocBLAS calls below.
+  int32_t* rmap = reinterpret_cast<int32_t*>(ws + w.map);
+  int32_t* nvalid_d = reinterpret_cast<int32_t*>(ws + w.nvalid);
+  T_HIP(launch_compact_rows(y, R, rmap, nvalid_d, reinterpret_cast<int32_t*>(ws + w.cscratch), st));
+  T_HIP(hipMemsetAsync(so.rank, 0, (size_t)R * 4, st));
+  T_HIP(hipMemsetAsync(so.ce, 0, (size_t)R * 4, st));
+  T_HIP(hipMemsetAsync(so.target, 0, (size_t)R * 4, st));
+  T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st, rmap, nvalid_d));
   if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
+  int32_t nvalid_h = 0;
+  T_HIP(hipMemcpyAsync(&nvalid_h, nvalid_d, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  T_HIP(hipStreamSynchronize(st));
+  const int64_t Rv = nvalid_h;
 
   // ================= d loss / d logits, scoring layer =====================================================
   float* users = F32(w.users);
@@ -578,20 +615,31 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   T_HIP(hipGetLastError());
   float* dH = F32(w.dA);   // [R][C_last] fp32
   T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
-  uint16_t* Gc = BF(w.gchunk);
-  const int n_stages = m.NP / 64;
-  for (int s0 = 0; s0 < n_stages; s0 += w.nc_stages) {
-    const int s1 = (s0 + w.nc_stages < n_stages) ? s0 + w.nc_stages : n_stages;
-    const int NC = (s1 - s0) * 64;
-    T_HIP(launch_score_grad_chunk(m, hidden, y, R, F32(w.lse), F32(w.w), s0, s1, Gc, st));
-    // d bo[n] = sum_r G[r][n]
-    hipLaunchKernelGGL(k_colsum_bf16, dim3(NC / 64, (unsigned)((R + 4095) / 4096)), dim3(256), 0, st, Gc, R, (int64_t)NC, NC,
-                       G + t.out_bias.off + (size_t)s0 * 64);
+  if (Rv > 0) {
+    uint16_t* hc = BF(w.hc);
+    int32_t* yc = reinterpret_cast<int32_t*>(ws + w.yc);
+    float* dHc = F32(w.dsf);   // [Rv][C_last] fp32 (the block loop's scratch, free until then)
+    hipLaunchKernelGGL(k_gather_scored, dim3((unsigned)((Rv * (CL / 8) + 255) / 256)), dim3(256), 0, st, hidden, y, F32(w.w), F32(w.lse), rmap, Rv, CL,
+                       hc, yc, F32(w.wc), F32(w.lc));
     T_HIP(hipGetLastError());
-    // dH[R][C] += G[R][NC] . outT_chunk[NC][C]   == col-major: dH^T[C x R] += outT_chunk^T[C x NC] . G^T[NC x R]
-    T_BLAS(gemm_bf16(bl, OPN, OPN, CL, (int)R, NC, m.outT + (size_t)s0 * 64 * CL, CL, Gc, NC, 1.f, dH, CL));
-    // d outT_chunk[NC][C] = G^T[NC x R] . hidden[R][C]   == col-major [C x NC] = hidden^T[C x R] . (G^T[NC x R])^T
-    T_BLAS(gemm_bf16(bl, OPN, OPT, CL, NC, (int)R, hidden, CL, Gc, NC, 0.f, G + t.outT.off + (size_t)s0 * 64 * CL, CL));
+    T_HIP(hipMemsetAsync(dHc, 0, (size_t)Rv * CL * 4, st));
+    uint16_t* Gc = BF(w.gchunk);
+    const int n_stages = m.NP / 64;
+    for (int s0 = 0; s0 < n_stages; s0 += w.nc_stages) {
+      const int s1 = (s0 + w.nc_stages < n_stages) ? s0 + w.nc_stages : n_stages;
+      const int NC = (s1 - s0) * 64;
+      T_HIP(launch_score_grad_chunk(m, hc, yc, Rv, F32(w.lc), F32(w.wc), s0, s1, Gc, st));
+      // d bo[n] = sum_r G[r][n]
+      hipLaunchKernelGGL(k_colsum_bf16, dim3(NC / 64, (unsigned)((Rv + 4095) / 4096)), dim3(256), 0, st, Gc, Rv, (int64_t)NC, NC,
+                         G + t.out_bias.off + (size_t)s0 * 64);
+      T_HIP(hipGetLastError());
+      // dH[Rv][C] += G[Rv][NC] . outT_chunk[NC][C]   == col-major: dH^T[C x Rv] += outT_chunk^T[C x NC] . G^T[NC x Rv]
+      T_BLAS(gemm_bf16(bl, OPN, OPN, CL, (int)Rv, NC, m.outT + (size_t)s0 * 64 * CL, CL, Gc, NC, 1.f, dHc, CL));
+      // d outT_chunk[NC][C] = G^T[NC x Rv] . hidden[Rv][C]   == col-major [C x NC] = hidden^T[C x Rv] . (G^T[NC x Rv])^T
+      T_BLAS(gemm_bf16(bl, OPN, OPT, CL, NC, (int)Rv, hc, CL, Gc, NC, 0.f, G + t.outT.off + (size_t)s0 * 64 * CL, CL));
+    }
+    hipLaunchKernelGGL(k_scatter_rows_f32, dim3((unsigned)((Rv * (CL / 4) + 255) / 256)), dim3(256), 0, st, dHc, rmap, Rv, CL, dH);
+    T_HIP(hipGetLastError());
   }
 
   // ================= TemporalBlocks, last to first =========================================================

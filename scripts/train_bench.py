@@ -1,5 +1,5 @@
 """Training-step throughput on the cfg-3 synthetic shape (secondary measurement; bench.py's headline is the eval pass).
-usage: python scripts/train_bench.py [users_per_step] [steps]"""
+usage: python scripts/train_bench.py [users_per_step] [steps] [ragged]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -10,13 +10,14 @@ from hiertcn_amd.params import init_params
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
+ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
 N, d, S, L = bench.N_ITEMS, bench.DIM, bench.S_SESS, bench.L_STEPS
 args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L,
                      max_session_num=S, batch_size=B)
 eng = Engine(args, hier=True, train=True)
 eng.set_weights(init_params(args, seed=2))
 draw = bench.zipf_sampler(N)
-x, y, mask = bench.make_users(draw, 0, B, False)
+x, y, mask = bench.make_users(draw, 0, B, ragged)
 xd, yd, md = (torch.from_numpy(v).cuda() for v in (x, y, mask))
 st0 = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")
 losses = []
@@ -28,5 +29,5 @@ for i in range(steps + 1):
     losses.append(out["metrics8"].clone())
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
-print("train step: users %d, %.1f ms/step, %.0f sessions/s; loss %s" % (
-    B, dt * 1e3, B * S / dt, [round(metrics_dict(m)["loss"], 4) for m in losses]), flush=True)
+print("train step%s: users %d, %.1f ms/step, %.0f sessions/s; loss %s" % (
+    " (ragged)" if ragged else "", B, dt * 1e3, B * S / dt, [round(metrics_dict(m)["loss"], 4) for m in losses]), flush=True)
