@@ -102,13 +102,18 @@ struct GemmArgs {
 
 typedef float f32x16v __attribute__((ext_vector_type(16)));
 
-template <int EPI>
+// SPLITK (small batches: fewer tiles than CUs): the four waves of a workgroup share ONE tile and take every fourth
+// 8-deep k-step each, then add their accumulators through LDS -- a 32-lane XING batch otherwise runs each of its 40
+// dependent GRU GEMMs as a single 256-MFMA chain per wave (20 us per launch, 80 % of the batch's time).
+template <int EPI, bool SPLITK = false>
 __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int tiles_n = g.N >> 5;
-  const int t = blockIdx.x * 4 + wave;
+  const int t = SPLITK ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
+  constexpr int KSTEP = SPLITK ? 4 : 1;
+  const int k_first = SPLITK ? wave : 0;
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
   if (tm * 32 >= g.M) return;
   const int K = g.K1 + g.K2;
@@ -124,7 +129,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
   const int n1 = g.K1 >> 3;
 #pragma unroll 4
-  for (int i = 0; i < n1; i++) {
+  for (int i = k_first; i < n1; i += KSTEP) {
     const float4 a = *reinterpret_cast<const float4*>(wp + 8 * i);
     const float4 b = *reinterpret_cast<const float4*>(x1 + 8 * i);
     acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -137,7 +142,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     const float* wp2 = wp + g.K1;
     const int n2 = g.K2 >> 3;
 #pragma unroll 4
-    for (int i = 0; i < n2; i++) {
+    for (int i = k_first; i < n2; i += KSTEP) {
       const float4 a = *reinterpret_cast<const float4*>(wp2 + 8 * i);
       const float4 b = *reinterpret_cast<const float4*>(x2 + 8 * i);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
@@ -145,6 +150,17 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
+  }
+  if (SPLITK) {   // fixed-order sum of the four partial tiles (deterministic)
+    __shared__ float part[3][16][64];
+    if (wave > 0) {
+#pragma unroll
+      for (int i = 0; i < 16; i++) part[wave - 1][i][lane] = acc[i];
+    }
+    __syncthreads();
+    if (wave > 0) return;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = ((acc[i] + part[0][i][lane]) + part[1][i][lane]) + part[2][i][lane];
   }
   if (!mvalid) return;
   const int m = tm * 32 + lr;
@@ -192,7 +208,10 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
 template <int EPI>
 static hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
   const int tiles = ((g.M + 31) / 32) * (g.N / 32);
-  hipLaunchKernelGGL(k_gemm_f32<EPI>, dim3((tiles + 3) / 4), dim3(256), 0, st, g);
+  if (tiles <= 128)
+    hipLaunchKernelGGL((k_gemm_f32<EPI, true>), dim3(tiles), dim3(256), 0, st, g);
+  else
+    hipLaunchKernelGGL((k_gemm_f32<EPI, false>), dim3((tiles + 3) / 4), dim3(256), 0, st, g);
   return hipGetLastError();
 }
 
