@@ -7,7 +7,16 @@ import numpy as np, torch
 from hiertcn_amd.args import hier_tcn_args
 from hiertcn_amd.engine import Engine
 from hiertcn_amd.params import init_params
-from tests.gpu_common import make_batch
+
+
+
+def make_batch(rng, B, S, L, N):
+    """ragged ids [B,S,L] (x = y shifted by one step, data_loader.py:246-261) and the last-session mask"""
+    ids = rng.integers(1, N, (B, S, L)) * (np.arange(L)[None, None, :] < rng.integers(1, L + 1, (B, S))[..., None])
+    x = np.zeros_like(ids)
+    x[:, :, 1:] = ids[:, :, :-1]
+    return x.astype(np.int32), ids.astype(np.int32), (rng.random((B, S)) > 0.15).astype(np.float32)
+
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
@@ -18,7 +27,7 @@ eng.set_weights(init_params(args, seed=2))
 rng = np.random.default_rng(0)
 batches = []
 for _ in range(8):
-    x, y, mask = make_batch(rng, B, S, L, N, ragged=True)
+    x, y, mask = make_batch(rng, B, S, L, N)
     batches.append(tuple(torch.as_tensor(v).cuda().contiguous() for v in (x, y, mask)))
 st = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")
 st2 = torch.empty_like(st)
