@@ -464,7 +464,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
                                                               int32_t* __restrict__ o_rank, float* __restrict__ o_ce,
                                                               float* __restrict__ o_tgt, const int32_t* __restrict__ row_map,
                                                               const int32_t* __restrict__ n_rows_dev, int part_stages,
-                                                              float* __restrict__ partials) {
+                                                              float* __restrict__ partials, int* __restrict__ walk_pos) {
   // Small batches: gridDim.y > 1 splits the CATALOGUE -- workgroup (x, p) walks stages [p*part_stages, (p+1)*part_stages)
   // for row tile x and writes (count, log2-sum-exp2) per row into `partials` [gridDim.y][2][R]; k_score_merge adds them
   // up.  A 6,400-row XING batch (32 lanes) otherwise occupies 13 of the 256 CUs for a whole pass over the table.
@@ -545,8 +545,24 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
                  : "v"(gsrc), "s"(dst)
                  : "memory");
   };
+  // walk_pos: a workgroup may start anywhere in the table and wrap around (count and softmax sum do not depend on the
+  // item order beyond fp32 rounding).  Workgroups dealt to one XCD (blockIdx % 8: observed round-robin placement, a
+  // speed hint, never correctness) start where their already-running neighbours are, so that late starters re-use the
+  // neighbours' lines in that XCD's 4 MiB L2 instead of pulling the 150 MB table through the fabric again: measured
+  // 161 -> 32 GB per launch at the L2's memory-side port, L2 hit rate 76 -> 96 % (profiles/r1_score_ablation.md).
+  // Price: the low bits of `ce` depend on the start offset (ranks never do); HIERTCN_FIXED_WALK=1 pins it to 0.
+  int s0 = 0;
+  if (walk_pos && !partials) {
+    s0 = __hip_atomic_load(walk_pos + (blockIdx.x & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s0 = __builtin_amdgcn_readfirstlane(s0);
+    s0 = (s0 >= 0 && s0 < n_stages) ? s0 : 0;
+  }
   auto stage_issue = [&](int stg_rel, int buf) {
-    const int stg = stg_lo + stg_rel;
+    int stg = s0 + stg_rel;
+    stg -= (stg >= n_stages) ? n_stages : 0;
+    if (walk_pos && !partials && wave == 0 && lane == 0 && (stg_rel & 7) == 0)
+      __hip_atomic_store(walk_pos + (blockIdx.x & 7) * 32, stg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    stg += stg_lo;
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
       const int piece = wave * PPW + i;
@@ -739,6 +755,8 @@ __global__ void k_score_merge(const float* __restrict__ partials, int parts, int
   o_ce[row] = valid ? (M + log2f(S)) * LN2_F - tgt[row] : 0.f;
 }
 
+__device__ int g_walk_pos[8 * 32];
+
 template <int C, int PMODE = 0>
 static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
                                     const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
@@ -748,18 +766,24 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
   const unsigned blocks = (unsigned)((R + 511) / 512);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
+  static int* walk = nullptr;
+  static bool walk_init = false;
+  if (!walk_init) {
+    walk_init = true;
+    if (!getenv("HIERTCN_FIXED_WALK")) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&walk), HIP_SYMBOL(g_walk_pos));
+  }
   const int parts = score_split_parts(R, m.NP);
   if (PMODE == 5 && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;
     hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                       out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch);
+                       out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
                        out->target, out->rank, out->ce);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                     out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr);
+                     out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk);
   return hipGetLastError();
 }
 

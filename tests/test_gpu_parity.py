@@ -333,7 +333,8 @@ def test_full_catalogue_properties_at_north_star_size():
     # (4) the same rows scored alone
     alone = eng.score_fused(hid[:64].contiguous(), dev(y[:64]))
     assert np.array_equal(alone["rank"].cpu().numpy(), prod["rank"].cpu().numpy()[:64])
-    assert np.array_equal(alone["ce"].cpu().numpy(), prod["ce"].cpu().numpy()[:64])
+    # (ce: equal up to the fp32 summation order of the item walk, which starts where the XCD's other workgroups are)
+    assert np.abs(alone["ce"].cpu().numpy() - prod["ce"].cpu().numpy()[:64]).max() < 2e-5
     # (3) boost ONE item: the rows that target it go to rank 0 / ce ~ 0, every other valid row's rank grows by exactly 1
     p2 = dict(p)
     b = p["hier/tcn/dense/bias"].copy()

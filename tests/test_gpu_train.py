@@ -320,5 +320,7 @@ def test_optimizer_state_round_trip(trained):
     other.adam_step(1e-2)
     got = other.export("weights")
     for k in want:
-        assert np.abs(got[k] - want[k]).max() <= 1e-6 * max(1.0, np.abs(want[k]).max()), k
+        # (not bitwise: fp32 atomics in the scatter-adds and the item-walk start of the scoring kernel reorder sums)
+        # without the restored slots the two updates differ by ~lr = 1e-2 per element
+        assert np.abs(got[k] - want[k]).max() <= 1e-4 * max(1.0, np.abs(want[k]).max()), (k, np.abs(got[k] - want[k]).max())
     other.close()
