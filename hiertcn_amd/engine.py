@@ -280,6 +280,13 @@ class Engine:
                                             C.byref(so) if so is not None else None, self._stream()))
         return out
 
+    # -- hipGraph replay of the evaluation step (launch-bound at the reference's batch sizes) ------------------------
+    def capture_eval_graph(self, B: int, S: int, L: int):
+        """Captures hiertcn_forward_eval for one batch shape into a hipGraph (torch.cuda.CUDAGraph on ROCm) and returns
+        an EvalGraph: copy ids / mask / state into its static buffers (or write them there directly), `replay()`,
+        read `state_out` / `metrics8`.  A 32-lane XING batch is ~60 dependent launches; replay removes their host cost."""
+        return EvalGraph(self, B, S, L)
+
     # -- training (hiertcn.h "training step") ------------------------------------------------------
     def train_forward_backward(self, x_ids, y_ids, mask=None, state_in=None, state_out=None, metrics8=None):
         """Forward + loss + gradients of every variable (into the handle's gradient arena).
@@ -380,6 +387,39 @@ class Engine:
         n = C.c_int64(0)
         check(self.lib.hiertcn_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
+
+
+class EvalGraph:
+    """Static-shape evaluation step as a replayable graph.  Buffers: x, y int32 [B,S,L]; mask fp32 [B,S]; state_in /
+    state_out fp32 [B, H*nl]; metrics8 fp64 [8].  `chain_state()` copies state_out into state_in on the device (the carried
+    state of run_hier_xing.py:132,147 never visits the host)."""
+
+    def __init__(self, eng: "Engine", B: int, S: int, L: int):
+        self.eng, self.shape = eng, (B, S, L)
+        dev = eng.device
+        self.x = torch.zeros((B, S, L), dtype=torch.int32, device=dev)
+        self.y = torch.zeros((B, S, L), dtype=torch.int32, device=dev)
+        self.mask = torch.zeros((B, S), dtype=torch.float32, device=dev)
+        self.state_in = torch.zeros((B, eng.HT), dtype=torch.float32, device=dev)
+        self.state_out = torch.zeros((B, eng.HT), dtype=torch.float32, device=dev)
+        self.metrics8 = torch.zeros(8, dtype=torch.float64, device=dev)
+        eng.workspace(B, S, L)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # warm-up outside the capture: lazy module / attribute initialisation happens here
+            for _ in range(2):
+                eng.forward_eval(self.x, self.y, self.mask, self.state_in, state_out=self.state_out, metrics8=self.metrics8)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            eng.forward_eval(self.x, self.y, self.mask, self.state_in, state_out=self.state_out, metrics8=self.metrics8)
+
+    def replay(self):
+        self.graph.replay()
+
+    def chain_state(self):
+        self.state_in.copy_(self.state_out, non_blocking=True)
 
 
 def metrics_dict(m8) -> Dict[str, float]:

@@ -39,3 +39,14 @@ for i in range(n):
     eng.forward_eval(*batches[i % 8], st, state_out=st2, metrics8=m8)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
 print("cfg2: lanes %d: %.3f ms per batch, %.0f sessions/s" % (B, dt * 1e3, B * S / dt), flush=True)
+# the same step replayed from a hipGraph, carried state chained on the device
+g = eng.capture_eval_graph(B, S, L)
+for i in range(10):
+    g.x.copy_(batches[i % 8][0]); g.y.copy_(batches[i % 8][1]); g.mask.copy_(batches[i % 8][2]); g.replay(); g.chain_state()
+torch.cuda.synchronize(); t0 = time.perf_counter()
+for i in range(n):
+    xb, yb, mb = batches[i % 8]
+    g.x.copy_(xb, non_blocking=True); g.y.copy_(yb, non_blocking=True); g.mask.copy_(mb, non_blocking=True)
+    g.replay(); g.chain_state()
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / n
+print("cfg2: lanes %d, hipGraph replay: %.3f ms per batch, %.0f sessions/s" % (B, dt * 1e3, B * S / dt), flush=True)

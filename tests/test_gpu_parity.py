@@ -404,3 +404,27 @@ def test_edge_shapes_against_oracle(B, S, L, N, d, H):
     v = y.reshape(B, S * L) > 0
     assert np.all(lo[v] <= r[v]) and np.all(r[v] <= np.maximum(hi, lo)[v]) and not r[~v].any()
     eng.close()
+
+
+def test_eval_graph_replay_matches_direct_call(setup):
+    """hiertcn_forward_eval captured into a hipGraph: replays give the direct call's metrics and state, with the carried
+    state chained on the device across two batches."""
+    s = setup
+    eng = s["eng"]
+    B, S, L = s["B"], s["S"], s["L"]
+    g = eng.capture_eval_graph(B, S, L)
+    rng = np.random.default_rng(1)
+    st = dev(s["st0"])
+    g.state_in.copy_(st)
+    for _ in range(2):
+        x, y, mask = make_batch(rng, B, S, L, s["N"])
+        ref = eng.forward_eval(dev(x), dev(y), dev(mask), st)
+        g.x.copy_(dev(x)); g.y.copy_(dev(y)); g.mask.copy_(dev(mask))
+        g.replay()
+        torch.cuda.synchronize()
+        assert np.array_equal(g.state_out.cpu().numpy(), ref["state"].cpu().numpy())
+        a, b = g.metrics8.cpu().numpy(), ref["metrics8"].cpu().numpy()
+        assert np.array_equal(a[1:4], b[1:4]) and np.array_equal(a[6:], b[6:])      # recall sums, user count, valid steps: exact
+        assert np.allclose(a, b, rtol=1e-6, atol=1e-9)                               # loss / mrr sums: fp32 summation order of ce
+        st = ref["state"]
+        g.chain_state()
