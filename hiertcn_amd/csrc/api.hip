@@ -70,8 +70,8 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
     uniform = uniform && ci == E;
   }
   const int clast = cfg->channels[cfg->n_blocks - 1];
-  if (!(clast == 64 || clast == 128 || clast == 256))
-    return fail(HIERTCN_ERR_INVALID, "last tcn_channel %d unsupported: the scoring kernel is built for 64, 128, 256", clast);
+  if (!(clast == 64 || clast == 128 || clast == 256 || clast == 512))
+    return fail(HIERTCN_ERR_INVALID, "last tcn_channel %d unsupported: the scoring kernel is built for 64, 128, 256, 512", clast);
   if (cfg->kernel_size < 1 || cfg->kernel_size > 8) return fail(HIERTCN_ERR_INVALID, "kernel_size out of range");
   if (cfg->hier) {
     if (!(E == 64 || E == 128 || E == 256 || E == 512))

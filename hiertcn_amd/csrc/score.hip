@@ -885,6 +885,10 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   return launch_score_v<C, false, 0>(m, hidden, y, R, out, nullptr, stagger, st);
 }
 
+template <bool LOGITS, int MODE, int KT>
+static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                                   float* logits, const float* lse, const float* w, int stg_begin, int stg_end, hipStream_t st);
+
 template <int C>
 static hipError_t launch_score_grad_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse,
                                       const float* w, int stg_begin, int stg_end, uint16_t* gout, hipStream_t st) {
@@ -908,8 +912,28 @@ hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, co
     case 64: return launch_score_grad_c<64>(m, hidden, y, R, lse, w, stg_begin, stg_end, gout, st);
     case 128: return launch_score_grad_c<128>(m, hidden, y, R, lse, w, stg_begin, stg_end, gout, st);
     case 256: return launch_score_grad_c<256>(m, hidden, y, R, lse, w, stg_begin, stg_end, gout, st);
+    case 512:
+      return launch_score_512<true, 9, 0>(m, hidden, y, R, nullptr, reinterpret_cast<float*>(gout), lse, w, stg_begin, stg_end, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+// d = 512 (BASELINE.json configs[3]: the scoring-GEMM stress shape): 64 rows x 512 channels of resident B operand
+// would take 256 VGPRs, so every flavour (fused, top-k, logits, gradient chunk) runs the two-stage kernel with ONE
+// 32-step block per wave (128 VGPRs of B operand, 2 x 64 KB LDS stages, 32 MFMAs per 16 logits of epilogue).
+template <bool LOGITS, int MODE, int KT>
+static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                                   float* logits, const float* lse, const float* w, int stg_begin, int stg_end, hipStream_t st) {
+  using G = ScGeom<512>;
+  size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
+  const unsigned blocks = (unsigned)((R + 255) / 256);
+  auto kern = k_score<512, LOGITS, MODE, false, KT, 1>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out ? out->rank : nullptr,
+                     out ? out->ce : nullptr, out ? out->target : nullptr, logits, 0, (unsigned long long*)nullptr,
+                     out ? out->topk_idx : nullptr, out ? out->topk_val : nullptr, out ? (int)out->topk : 0, lse, w, stg_begin, stg_end);
+  return hipGetLastError();
 }
 
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
@@ -919,6 +943,11 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
     case 64: return launch_score_c<64>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
     case 128: return launch_score_c<128>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
     case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
+    case 512:   // (dense rows: callers zero-fill nothing here, the kernel writes rank 0 / ce 0 on masked rows itself)
+      if (logits) return launch_score_512<true, 0, 0>(m, hidden, y, R, nullptr, logits, nullptr, nullptr, 0, -1, st);
+      if (out && out->topk > 8) return launch_score_512<false, 0, 16>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
+      if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
+      return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -139,6 +139,8 @@ int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask,
 /* model.py:59-61 + model_hier.py:50 + model_tcn.py:35-36: ids -> last TCN activations.
  * x_ids [n_sessions][L]; sproj [n_sessions][E] or NULL (single-level) ->
  * hidden [n_sessions*L][C_last] bf16.
+ * (widths: emb_dim and tcn_channel are multiples of 32; the last channel count, which the scoring kernels are built
+ *  for, is one of 64, 128, 256, 512.)
  * Two device paths, same results: the fused kernel (every width == emb_dim in {64,128,256}, L <= 32:
  * gather + projection + all blocks in LDS; needs no workspace) and the layer-at-a-time path (any
  * L <= 4096, per-block widths in multiples of 32, Dense down-sample residual where Cin != Cout --

@@ -9,7 +9,7 @@ from hiertcn_amd.params import init_params
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 2048 * 600
 Ns = [int(v) for v in sys.argv[2:]] or [300000, 65536, 8192]
-d = 256
+d = int(os.environ.get("D", "256"))
 for N in Ns:
     args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, tcn_channel=[d, d])
     p = init_params(args, 2)

@@ -21,7 +21,7 @@ def dev(a, dtype=None):
     return t.cuda().contiguous()
 
 
-@pytest.fixture(scope="module", params=[(64, 1000), (128, 2053), (256, 777)])
+@pytest.fixture(scope="module", params=[(64, 1000), (128, 2053), (256, 777), (512, 1100)])
 def setup(request):
     from hiertcn_amd.engine import Engine
     d, N = request.param

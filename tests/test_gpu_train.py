@@ -67,7 +67,7 @@ def torch_loss(args, P, x, y, mask, state):
     return ((ce.sum(1) / (act + 1e-6)).sum() / users), st
 
 
-@pytest.fixture(scope="module", params=[(64, 700, 32), (128, 1500, 64)])
+@pytest.fixture(scope="module", params=[(64, 700, 32), (128, 1500, 64), (512, 900, 64)])
 def trained(request):
     from hiertcn_amd.engine import Engine, metrics_dict
     d, N, H = request.param
