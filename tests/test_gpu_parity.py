@@ -428,3 +428,38 @@ def test_eval_graph_replay_matches_direct_call(setup):
         assert np.allclose(a, b, rtol=1e-6, atol=1e-9)                               # loss / mrr sums: fp32 summation order of ce
         st = ref["state"]
         g.chain_state()
+
+
+@pytest.mark.parametrize("K,channels,d", [(1, [64], 64), (3, [64, 64, 64], 64), (5, [128, 128, 128, 128], 128), (8, [64, 64], 64),
+                                          (5, [128, 256], 128), (3, [64, 128, 128], 64)])
+def test_kernel_size_depth_and_width_variants(K, channels, d):
+    """model_hier over kernel sizes 1..8, 1..4 blocks (halo up to 32 rows in the fused slab) and unequal widths
+    (a Dense down-sample residual inside model_hier: the layer-at-a-time path) against the oracle."""
+    from hiertcn_amd.engine import Engine, metrics_dict
+    N, H, B, S, L = 400, 32, 4, 2, 17
+    args = small_args(N=N, d=d, H=H, S=S, L=L, B=B, K=K, blocks=len(channels))
+    args.tcn_channel = list(channels)
+    p = O.init_params(args, seed=3)
+    rng = np.random.default_rng(K)
+    for k in p:
+        if k.endswith("/bias") and "gates" not in k:
+            p[k] = (p[k] + 0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    pr = O.round_params_bf16(p, E=d)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.2 * rng.standard_normal((B, H * args.num_layer))).astype(np.float32)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+    m = metrics_dict(out["metrics8"])
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, st = O.model_hier(args, xl, yl, ml, st0, pr, O.MIRROR)
+    ref = O.masked_loss_and_metrics(pred, y.reshape(B, S * L), N)
+    assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
+    assert abs(m["loss"] - ref["loss"]) < 1e-3
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+    err = np.abs(logits - pred)
+    assert np.quantile(err, 0.999) < 1e-3 and err.max() < 4e-3
+    eng.close()
