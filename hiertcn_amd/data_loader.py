@@ -14,7 +14,7 @@ assembled by fancy indexing.  `get_packed_batch()` emits ids [B][S][Lmax] int32 
 """
 from __future__ import annotations
 
-from collections import deque
+import heapq
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -118,8 +118,13 @@ class Dataloader_hier_model_xing:
         self._cut_sessions()
         self._walk = _UserWalk(self.viewer_table.shape[0], bool(args.shuffle))
         B = int(args.batch_size)
-        self._lanes: List[deque] = [deque() for _ in range(B)]
+        self._lanes: List[list] = [[] for _ in range(B)]   # session numbers queued per lane; _heads = first unread entry
+        self._heads = [0] * B
         self.queue_len = np.zeros(B)
+        # (sessions queued, lane) ordered like np.argmin(queue_len) picks: shortest lane, lowest index on ties.  Lengths in
+        # the heap are relative to _popped (every batch takes S from every lane, which keeps the order).
+        self._heap = [(0, b) for b in range(B)]
+        self._popped = 0
 
     # -- one array pass over the event table ------------------------------------------------------
     def _cut_sessions(self):
@@ -150,8 +155,9 @@ class Dataloader_hier_model_xing:
         w = self._walk
         u = int(w.index[w.index_pointer])
         first, n = int(self._u_first[u]), int(self._u_nsess[u])
-        lane = int(np.argmin(self.queue_len))
+        qlen, lane = heapq.heappop(self._heap)      # == np.argmin(self.queue_len), data_loader.py:203
         self._lanes[lane].extend(range(first, first + n))
+        heapq.heappush(self._heap, (qlen + n, lane))
         self.queue_len[lane] += n
         w.index_pointer += 1
         if w.index_pointer >= w.index.shape[0]:
@@ -163,14 +169,21 @@ class Dataloader_hier_model_xing:
         stop = False
         while True:
             stop = self.enqueue() or stop
-            if np.amin(self.queue_len) > int(self.args.max_session_num):
+            if self._heap[0][0] - self._popped > int(self.args.max_session_num):   # == np.amin(self.queue_len) > S (:229)
                 return stop
 
     def _pop_slots(self) -> np.ndarray:
         """-> session numbers [B, S] of the next batch."""
         S = int(self.args.max_session_num)
-        out = np.array([[lane.popleft() for _ in range(S)] for lane in self._lanes], dtype=np.int64)
+        out = np.array([lane[h:h + S] for lane, h in zip(self._lanes, self._heads)], dtype=np.int64)
+        for b, lane in enumerate(self._lanes):
+            h = self._heads[b] + S
+            if h > 4096:          # drop the consumed prefix now and then
+                del lane[:h]
+                h = 0
+            self._heads[b] = h
         self.queue_len -= S
+        self._popped += S
         return out
 
     def dequeue(self):
