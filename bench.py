@@ -164,6 +164,28 @@ def main():
     except (OSError, KeyError, ValueError):
         pass
 
+    # a plain library GEMM on the same box, same data kind (random bf16), as a second yardstick beside the datasheet peak
+    # ("the ratio against a measured hipBLASLt GEMM peak on the same box"); measurement only, not product path
+    gemm_ref = None
+    if rank == 0:
+        try:
+            n = 8192
+            ga = torch.randn((n, n), device="cuda", dtype=torch.bfloat16)
+            gb = torch.randn((n, n), device="cuda", dtype=torch.bfloat16)
+            for _ in range(3):
+                gc = ga @ gb
+            torch.cuda.synchronize()
+            tg = time.perf_counter()
+            for _ in range(10):
+                gc = ga @ gb
+            torch.cuda.synchronize()
+            tg = (time.perf_counter() - tg) / 10
+            gemm_ref = {"what": "torch.mm bf16 8192^3, random normal operands (hipBLASLt/rocBLAS via PyTorch)",
+                        "tflops": round(2.0 * n ** 3 / tg / 1e12, 1)}
+            del ga, gb, gc
+        except Exception as e:  # noqa: BLE001  (a yardstick, never fatal)
+            gemm_ref = {"error": str(e)[:200]}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the checker, timed on this host's cores on a bounded sample of the SAME workload
@@ -204,6 +226,8 @@ def main():
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "library_gemm_reference": gemm_ref,
+                "frac_of_library_gemm": (round(achieved / gemm_ref["tflops"], 4) if gemm_ref and gemm_ref.get("tflops") else None),
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch through the L2's memory-side port (Infinity-Cache hits included)",
                 "traffic_source": traffic_src,
