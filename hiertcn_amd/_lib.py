@@ -42,6 +42,7 @@ class ScoreOut(C.Structure):
 # every symbol include/hiertcn.h declares: (restype, argtypes)
 SYMBOLS = {
     "hiertcn_abi_version": (C.c_int, []),
+    "hiertcn_storage_dtype": (C.c_int, []),
     "hiertcn_last_error": (C.c_char_p, []),
     "hiertcn_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(Config)]),
     "hiertcn_destroy": (C.c_int, [C.c_void_p]),
@@ -74,37 +75,49 @@ SYMBOLS = {
 }
 
 _lib = None
+_lib_f16 = None
+LIB_PATH_F16 = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhiertcn_gfx950_f16.so")
 
 
 class HierTCNError(RuntimeError):
     pass
 
 
-def load():
-    """Load the shared library (once).  Raises if it is absent: the product path never falls
-    back to a CPU implementation."""
-    global _lib
+def load(f16: bool = False):
+    """Load the shared library (once per storage variant).  Raises if it is absent: the product path never falls
+    back to a CPU implementation.  f16=True loads the IEEE-half build (inference only)."""
+    global _lib, _lib_f16
+    if f16:
+        if _lib_f16 is None:
+            _lib_f16 = _open(LIB_PATH_F16, 1)
+        return _lib_f16
     if _lib is not None:
         return _lib
+    _lib = _open(LIB_PATH, 0)
+    return _lib
+
+
+def _open(path, want_dtype):
     # torch first: its wheel bundles the HIP runtime (libamdhip64.so.7); loading it before our
     # library makes both resolve to ONE runtime, which sharing streams and device pointers needs.
     import torch  # noqa: F401
-    if not os.path.exists(LIB_PATH):
+    if not os.path.exists(path):
         raise HierTCNError(
-            f"{LIB_PATH} not found: build it with `python -m hiertcn_amd.build` "
+            f"{path} not found: build it with `python -m hiertcn_amd.build` "
             "(or __graft_entry__.build()).  There is no CPU fallback for the compute path.")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the export is missing
         fn.restype = res
         fn.argtypes = args
     if lib.hiertcn_abi_version() != ABI_VERSION:
         raise HierTCNError(f"ABI mismatch: library {lib.hiertcn_abi_version()} vs binding {ABI_VERSION}")
-    _lib = lib
+    if lib.hiertcn_storage_dtype() != want_dtype:
+        raise HierTCNError(f"{path}: storage dtype {lib.hiertcn_storage_dtype()}, expected {want_dtype}")
     return lib
 
 
-def check(rc: int):
+def check(rc: int, lib=None):
     if rc != 0:
-        msg = load().hiertcn_last_error()
+        msg = (lib or load()).hiertcn_last_error()
         raise HierTCNError(f"hiertcn call failed ({rc}): {msg.decode() if msg else '?'}")

@@ -30,7 +30,19 @@ def _stale(target, deps):
     return any(os.path.getmtime(d) > t for d in deps)
 
 
-def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str:
+LIB_F16 = os.path.join(HERE, "libhiertcn_gfx950_f16.so")
+
+
+def build_all(force: bool = False, verbose: bool = False):
+    """Both storage variants: bfloat16 (default, training + inference) and IEEE half (-DHIERTCN_F16, inference)."""
+    return build_lib(force, verbose), build_lib(force, verbose, f16=True)
+
+
+def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: bool = False) -> str:
+    OBJ = os.path.join(HERE, "build", "f16") if f16 else os.path.join(HERE, "build")  # noqa: N806
+    LIB = LIB_F16 if f16 else globals()["LIB"]  # noqa: N806
+    if f16:
+        extra_flags = tuple(extra_flags) + ("-DHIERTCN_F16=1",)
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
@@ -68,4 +80,4 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=()) -> str
 
 
 if __name__ == "__main__":
-    print(build_lib(force="--force" in sys.argv, verbose=True))
+    print(*build_all(force="--force" in sys.argv, verbose=True))

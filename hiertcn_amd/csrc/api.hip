@@ -54,6 +54,13 @@ static hipError_t dev_alloc(hiertcn_ctx* c, T** out, size_t count) {
 extern "C" {
 
 int hiertcn_abi_version(void) { return HIERTCN_ABI_VERSION; }
+int hiertcn_storage_dtype(void) {
+#ifdef HIERTCN_F16
+  return 1;
+#else
+  return 0;
+#endif
+}
 const char* hiertcn_last_error(void) { return g_err; }
 
 int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {

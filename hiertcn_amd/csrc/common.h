@@ -14,11 +14,23 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 #define LOG2E_F 1.4426950408889634f
 #define LN2_F 0.6931471805599453f
 
+// Storage type of the 16-bit tensors (item tables, conv kernels, activations).  The default build stores bfloat16;
+// building with -DHIERTCN_F16 (libhiertcn_gfx950_f16.so, BASELINE.json configs[3]: "fp16 MFMA") stores IEEE half and
+// switches the MFMA to its f16 form -- same rate, 3 more mantissa bits, 5 exponent bits.  The helper names keep "bf".
+#ifdef HIERTCN_F16
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ uint16_t f2bf(float f) {
+  _Float16 b = (_Float16)f;  // v_cvt_f16_f32: round-to-nearest-even
+  return __builtin_bit_cast(uint16_t, b);
+}
+__device__ __forceinline__ float bf2f(uint16_t u) { return (float)__builtin_bit_cast(_Float16, u); }
+#else
 __device__ __forceinline__ uint16_t f2bf(float f) {
   __bf16 b = (__bf16)f;  // v_cvt_pk_bf16_f32: round-to-nearest-even
   return __builtin_bit_cast(uint16_t, b);
 }
 __device__ __forceinline__ float bf2f(uint16_t u) { return __builtin_bit_cast(float, (uint32_t)u << 16); }
+#endif
 __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
   return (uint32_t)f2bf(lo) | ((uint32_t)f2bf(hi) << 16);
 }
@@ -26,7 +38,11 @@ __device__ __forceinline__ uint32_t pack2bf(float lo, float hi) {
 // MFMA 32x32x16 bf16 (cdna_hip_programming.md 3): lane l (r=l&31, h=l>>5) holds
 //   A[row r][k=8h+j], B[k=8h+j][col r], j=0..7;  D[row=(reg&3)+8*(reg>>2)+4h][col=r].
 __device__ __forceinline__ f32x16 mfma32(uint4 a, uint4 b, f32x16 c) {
+#ifdef HIERTCN_F16
+  return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+#else
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+#endif
 }
 // accumulator register -> row inside the 32x32 tile (for lane half h)
 __device__ __forceinline__ int acc_row(int reg, int h) { return (reg & 3) + 8 * (reg >> 2) + 4 * h; }

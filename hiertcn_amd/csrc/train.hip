@@ -39,6 +39,12 @@ static int tfail(const char* fmt, ...) {
     if (s_ != rocblas_status_success) return tfail("%s failed: rocblas_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
   } while (0)
 
+#ifdef HIERTCN_F16
+#define HIERTCN_BLAS_16 rocblas_datatype_f16_r
+#else
+#define HIERTCN_BLAS_16 rocblas_datatype_bf16_r
+#endif
+
 static size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 size_t train_layout(const ModelDev& m, TrainCtx& t) {
@@ -72,6 +78,10 @@ size_t train_layout(const ModelDev& m, TrainCtx& t) {
 }
 
 hipError_t train_enable(ModelDev& m, TrainCtx& t) {
+#ifdef HIERTCN_F16
+  // d-logits of ~1e-10 underflow in half precision; the f16 build is an inference build (no loss scaling here)
+  return hipErrorNotSupported;
+#endif
   train_layout(m, t);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.arena), 4 * t.total * sizeof(float));
   if (e != hipSuccess) return e;
@@ -532,7 +542,7 @@ size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L) { return tr
 static rocblas_status gemm_bf16(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const void* A, int lda,
                                 const void* B, int ldb, float beta, float* Cc, int ldc) {
   const float one = 1.f;
-  return rocblas_gemm_ex(h, ta, tb, m, n, k, &one, A, rocblas_datatype_bf16_r, lda, B, rocblas_datatype_bf16_r, ldb, &beta, Cc,
+  return rocblas_gemm_ex(h, ta, tb, m, n, k, &one, A, HIERTCN_BLAS_16, lda, B, HIERTCN_BLAS_16, ldb, &beta, Cc,
                          rocblas_datatype_f32_r, ldc, Cc, rocblas_datatype_f32_r, ldc, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
 }
 static rocblas_status gemm_f32(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* A, int lda,

@@ -58,8 +58,16 @@ def config_from_args(args, hier: bool = True) -> _lib.Config:
 class Engine:
     """One handle on the current CUDA(HIP) device."""
 
-    def __init__(self, args, hier: bool = True, device: Optional[torch.device] = None, train: bool = False):
-        self.lib = _lib.load()
+    def __init__(self, args, hier: bool = True, device: Optional[torch.device] = None, train: bool = False,
+                 dtype: Optional[str] = None):
+        """dtype: storage type of the 16-bit tensors: 'bf16' (default; args.storage_dtype overrides) or 'fp16' (the
+        libhiertcn_gfx950_f16.so build: BASELINE.json configs[3], inference only)."""
+        dtype = dtype or getattr(args, "storage_dtype", "bf16")
+        if dtype not in ("bf16", "fp16"):
+            raise HierTCNError(f"storage dtype {dtype!r}: 'bf16' or 'fp16'")
+        self.f16 = dtype == "fp16"
+        self.act_dtype = torch.float16 if self.f16 else torch.bfloat16
+        self.lib = _lib.load(f16=self.f16)
         if not torch.cuda.is_available():
             raise HierTCNError("no GPU visible: the HierTCN compute path is HIP-only (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -74,16 +82,19 @@ class Engine:
         self.C = int(self.cfg.channels[self.cfg.n_blocks - 1])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
+            self._ck(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
         self.train = bool(train)
         if self.train:   # fp32 masters / gradients / Adam moments; must precede set_weights
             with torch.cuda.device(self.device):
-                check(self.lib.hiertcn_train_enable(self._h))
+                self._ck(self.lib.hiertcn_train_enable(self._h))
         self._train_ws: Optional[torch.Tensor] = None
         self._ws: Optional[torch.Tensor] = None
         self._gru_ws: Optional[torch.Tensor] = None
         self._tcn_ws: Optional[torch.Tensor] = None
         self._weights_set = False
+
+    def _ck(self, rc: int):
+        check(rc, self.lib)
 
     # ---------------------------------------------------------------------------------------
     def close(self):
@@ -151,7 +162,7 @@ class Engine:
                 w.gru_cand_bias[l] = dev(f"{pre}/candidate/bias", (H,))
                 inp = H
         with torch.cuda.device(self.device):
-            check(self.lib.hiertcn_set_weights(self._h, C.byref(w), self._stream()))
+            self._ck(self.lib.hiertcn_set_weights(self._h, C.byref(w), self._stream()))
             torch.cuda.current_stream().synchronize()  # the fp32 staging copies die with `keep`
         self._weights_set = True
 
@@ -161,7 +172,7 @@ class Engine:
         _req(y_ids, torch.int32, "y_ids")
         n, L = y_ids.shape
         out = torch.empty((n, self.E), dtype=torch.float32, device=self.device)
-        check(self.lib.hiertcn_session_pool(self._h, _ptr(y_ids), n, L, _ptr(out), self._stream()))
+        self._ck(self.lib.hiertcn_session_pool(self._h, _ptr(y_ids), n, L, _ptr(out), self._stream()))
         return out
 
     def gru_scan(self, pooled: torch.Tensor, mask: torch.Tensor, state_in: torch.Tensor, want_state_before=False):
@@ -176,7 +187,7 @@ class Engine:
         need = int(self.lib.hiertcn_gru_workspace_bytes(self._h, B, S))
         if self._gru_ws is None or self._gru_ws.numel() < need:
             self._gru_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        check(self.lib.hiertcn_gru_scan(self._h, _ptr(pooled), _ptr(mask), _ptr(state_in), B, S, _ptr(sproj),
+        self._ck(self.lib.hiertcn_gru_scan(self._h, _ptr(pooled), _ptr(mask), _ptr(state_in), B, S, _ptr(sproj),
                                         _ptr(state_out), _ptr(sb), _ptr(self._gru_ws), self._gru_ws.numel(), self._stream()))
         return sproj, state_out, sb
 
@@ -186,12 +197,12 @@ class Engine:
         n, L = x_ids.shape
         if sproj is not None:
             _req(sproj, torch.float32, "sproj", (n, self.E))
-        hidden = torch.empty((n * L, self.C), dtype=torch.bfloat16, device=self.device)
+        hidden = torch.empty((n * L, self.C), dtype=self.act_dtype, device=self.device)
         need = int(self.lib.hiertcn_tcn_workspace_bytes(self._h, n, L))  # 0 when the fused kernel applies
         if need and (self._tcn_ws is None or self._tcn_ws.numel() < need):
             self._tcn_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         ws = self._tcn_ws if need else None
-        check(self.lib.hiertcn_tcn_forward(self._h, _ptr(x_ids), _ptr(sproj), n, L, _ptr(hidden), _ptr(ws),
+        self._ck(self.lib.hiertcn_tcn_forward(self._h, _ptr(x_ids), _ptr(sproj), n, L, _ptr(hidden), _ptr(ws),
                                            ws.numel() if ws is not None else 0, self._stream()))
         return hidden
 
@@ -199,7 +210,7 @@ class Engine:
         """hidden [R, C] bf16, y_ids [R] int32 -> dict(rank int32 [R], ce fp32 [R], target?,
         topk_idx int32 [R, topk], topk_val fp32 [R, topk] when topk > 0 (loss.py:120 order))."""
         R = hidden.shape[0]
-        _req(hidden, torch.bfloat16, "hidden", (R, self.C))
+        _req(hidden, self.act_dtype, "hidden", (R, self.C))
         y = y_ids.reshape(-1)
         _req(y, torch.int32, "y_ids", (R,))
         rank = torch.empty(R, dtype=torch.int32, device=self.device)
@@ -210,7 +221,7 @@ class Engine:
         so = _lib.ScoreOut(rank=rank.data_ptr(), ce=ce.data_ptr(), target=tgt.data_ptr() if tgt is not None else None,
                            topk_idx=ti.data_ptr() if ti is not None else None,
                            topk_val=tv.data_ptr() if tv is not None else None, topk=int(topk))
-        check(self.lib.hiertcn_score_fused(self._h, _ptr(hidden), _ptr(y), R, C.byref(so), self._stream()))
+        self._ck(self.lib.hiertcn_score_fused(self._h, _ptr(hidden), _ptr(y), R, C.byref(so), self._stream()))
         out = dict(rank=rank, ce=ce)
         if tgt is not None:
             out["target"] = tgt
@@ -221,9 +232,9 @@ class Engine:
     def score_logits(self, hidden: torch.Tensor) -> torch.Tensor:
         """parity/debug: materialised logits [R, N] fp32 (model_tcn.py:41, before the model.py:105 mask)."""
         R = hidden.shape[0]
-        _req(hidden, torch.bfloat16, "hidden", (R, self.C))
+        _req(hidden, self.act_dtype, "hidden", (R, self.C))
         logits = torch.empty((R, self.N), dtype=torch.float32, device=self.device)
-        check(self.lib.hiertcn_score_logits(self._h, _ptr(hidden), R, _ptr(logits), self._stream()))
+        self._ck(self.lib.hiertcn_score_logits(self._h, _ptr(hidden), R, _ptr(logits), self._stream()))
         return logits
 
     def metrics(self, rank: torch.Tensor, ce: torch.Tensor, y_ids: torch.Tensor, B: int, T: int) -> torch.Tensor:
@@ -233,7 +244,7 @@ class Engine:
         y = y_ids.reshape(-1)
         _req(y, torch.int32, "y_ids", (B * T,))
         out = torch.empty(8, dtype=torch.float64, device=self.device)
-        check(self.lib.hiertcn_metrics(self._h, _ptr(rank), _ptr(ce), _ptr(y), B, T, _ptr(out), self._stream()))
+        self._ck(self.lib.hiertcn_metrics(self._h, _ptr(rank), _ptr(ce), _ptr(y), B, T, _ptr(out), self._stream()))
         return out
 
     # ---------------------------------------------------------------------------------------
@@ -275,7 +286,7 @@ class Engine:
             if topk > 0:
                 out["topk_idx"] = ti.view(B, S * L, topk)
                 out["topk_val"] = tv.view(B, S * L, topk)
-        check(self.lib.hiertcn_forward_eval(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
+        self._ck(self.lib.hiertcn_forward_eval(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
                                             _ptr(ws), ws.numel(), _ptr(state_out), _ptr(metrics8),
                                             C.byref(so) if so is not None else None, self._stream()))
         return out
@@ -306,7 +317,7 @@ class Engine:
             self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         if metrics8 is None:
             metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
-        check(self.lib.hiertcn_train_forward_backward(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
+        self._ck(self.lib.hiertcn_train_forward_backward(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
                                                       _ptr(self._train_ws), self._train_ws.numel(), _ptr(state_out), _ptr(metrics8),
                                                       self._stream()))
         return dict(state=state_out, metrics8=metrics8)
@@ -315,7 +326,7 @@ class Engine:
         """The flat fp32 gradient buffer as a torch view (no copy): the all-reduce target of data-parallel training."""
         ptr = C.c_void_p()
         n = C.c_size_t()
-        check(self.lib.hiertcn_grad_arena(self._h, C.byref(ptr), C.byref(n)))
+        self._ck(self.lib.hiertcn_grad_arena(self._h, C.byref(ptr), C.byref(n)))
 
         class _Raw:
             __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f4", "data": (int(ptr.value), False), "version": 2}
@@ -324,7 +335,7 @@ class Engine:
 
     def _arena(self, which: int) -> torch.Tensor:
         ptr, n = C.c_void_p(), C.c_size_t()
-        check(self.lib.hiertcn_train_arena(self._h, which, C.byref(ptr), C.byref(n)))
+        self._ck(self.lib.hiertcn_train_arena(self._h, which, C.byref(ptr), C.byref(n)))
 
         class _Raw:
             __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f4", "data": (int(ptr.value), False), "version": 2}
@@ -334,7 +345,7 @@ class Engine:
     def optimizer_state(self) -> Dict[str, np.ndarray]:
         """Adam slots (flat, internal layout: valid for this model config only) + time step, for checkpoints."""
         t = C.c_int64(0)
-        check(self.lib.hiertcn_adam_time(self._h, C.byref(t), None))
+        self._ck(self.lib.hiertcn_adam_time(self._h, C.byref(t), None))
         torch.cuda.current_stream().synchronize()
         return {"adam_m": self._arena(2).cpu().numpy(), "adam_v": self._arena(3).cpu().numpy(), "adam_t": np.array([t.value], np.int64)}
 
@@ -345,11 +356,11 @@ class Engine:
         m.copy_(torch.from_numpy(np.ascontiguousarray(state["adam_m"], dtype=np.float32)).to(self.device))
         v.copy_(torch.from_numpy(np.ascontiguousarray(state["adam_v"], dtype=np.float32)).to(self.device))
         t = C.c_int64(int(np.asarray(state["adam_t"]).reshape(-1)[0]))
-        check(self.lib.hiertcn_adam_time(self._h, None, C.byref(t)))
+        self._ck(self.lib.hiertcn_adam_time(self._h, None, C.byref(t)))
 
     def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0):
         """tf.train.AdamOptimizer(lr) defaults (model.py:139)."""
-        check(self.lib.hiertcn_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), self._stream()))
+        self._ck(self.lib.hiertcn_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), float(grad_scale), self._stream()))
 
     def export(self, which: str = "weights", root: Optional[str] = None) -> Dict[str, np.ndarray]:
         """Masters ('weights') or gradients ('grads') as {TF variable name: fp32 ndarray in the reference layout}."""
@@ -374,18 +385,18 @@ class Engine:
             pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
             w.gru_gate_kernel[l], w.gru_gate_bias[l] = g(f"{pre}/gates/kernel"), g(f"{pre}/gates/bias")
             w.gru_cand_kernel[l], w.gru_cand_bias[l] = g(f"{pre}/candidate/kernel"), g(f"{pre}/candidate/bias")
-        check(self.lib.hiertcn_export_weights(self._h, C.byref(w), 0 if which == "weights" else 1, self._stream()))
+        self._ck(self.lib.hiertcn_export_weights(self._h, C.byref(w), 0 if which == "weights" else 1, self._stream()))
         torch.cuda.current_stream().synchronize()
         return {(root + k[len(kind):] if k.startswith(kind) else k): v.cpu().numpy() for k, v in bufs.items()}
 
     # ---------------------------------------------------------------------------------------
     def timing_enable(self, on: bool = True):
-        check(self.lib.hiertcn_timing_enable(self._h, 1 if on else 0))
+        self._ck(self.lib.hiertcn_timing_enable(self._h, 1 if on else 0))
 
     def timing_read(self, reset: bool = True):
         ms = C.c_double(0.0)
         n = C.c_int64(0)
-        check(self.lib.hiertcn_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
+        self._ck(self.lib.hiertcn_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
 
 

@@ -111,6 +111,8 @@ typedef struct {
 } hiertcn_score_out_t;
 
 int hiertcn_abi_version(void);
+/* 0: the 16-bit tensors are bfloat16 (libhiertcn_gfx950.so); 1: IEEE half (libhiertcn_gfx950_f16.so, inference only) */
+int hiertcn_storage_dtype(void);
 const char* hiertcn_last_error(void);
 
 /* create on the CURRENT hip device; allocates the internal weight copies (sized from cfg). */

@@ -44,6 +44,11 @@ def round_bf16(x):
     return out
 
 
+def round_f16(x):
+    """Round-to-nearest-even fp32 -> IEEE half -> fp32 (the storage rounding of the HIERTCN_F16 build)."""
+    return np.asarray(x, dtype=np.float32).astype(np.float16).astype(np.float32)
+
+
 class Numerics:
     """Where the oracle rounds.  mode='exact': nothing is rounded, everything in `dtype`
     (the literal restatement).  mode='bf16_mirror': activations are rounded to bf16 at exactly
@@ -52,19 +57,22 @@ class Numerics:
     (round_params_bf16)."""
 
     def __init__(self, mode="exact", dtype=np.float64):
-        assert mode in ("exact", "bf16_mirror")
+        assert mode in ("exact", "bf16_mirror", "f16_mirror")
         self.mode = mode
         self.dtype = dtype
 
     def act(self, x):
         if self.mode == "bf16_mirror":
             return round_bf16(x).astype(self.dtype)
+        if self.mode == "f16_mirror":
+            return round_f16(x).astype(self.dtype)
         return x
 
 
 EXACT64 = Numerics("exact", np.float64)
 EXACT32 = Numerics("exact", np.float32)
 MIRROR = Numerics("bf16_mirror", np.float64)
+MIRROR_F16 = Numerics("f16_mirror", np.float64)
 
 def is_bf16_stored(name: str) -> bool:
     """Tensors the HIP path stores in bf16: the item table, the input projection (rows [0:E) of
@@ -78,10 +86,12 @@ def is_bf16_stored(name: str) -> bool:
     return True
 
 
-def round_params_bf16(params: dict, E: int | None = None) -> dict:
-    """Return a copy of `params` whose bf16-stored tensors hold bf16-representable values.
+def round_params_bf16(params: dict, E: int | None = None, rnd=None) -> dict:
+    """Return a copy of `params` whose bf16-stored tensors hold bf16-representable values (or, with
+    rnd=round_f16, half-representable ones: the HIERTCN_F16 build).
     The state half of */tcn/emb/kernel (rows E:) stays fp32: the HIP path consumes it in the
     fp32 GRU-side kernel (hiertcn_gru_scan)."""
+    round_bf16 = rnd or globals()["round_bf16"]  # noqa: F811
     out = {}
     for k, v in params.items():
         v = np.asarray(v, dtype=np.float32)

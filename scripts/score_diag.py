@@ -13,9 +13,9 @@ d = int(os.environ.get("D", "256"))
 for N in Ns:
     args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, tcn_channel=[d, d])
     p = init_params(args, 2)
-    eng = Engine(args)
+    eng = Engine(args, dtype=os.environ.get("DTYPE", "bf16"))
     eng.set_weights(p)
-    hid = (torch.randn(rows, d, device="cuda") * 0.5).to(torch.bfloat16)
+    hid = (torch.randn(rows, d, device="cuda") * 0.5).to(eng.act_dtype)
     y = torch.randint(1, N, (rows,), device="cuda", dtype=torch.int32)
     eng.score_fused(hid, y)
     torch.cuda.synchronize()

@@ -56,3 +56,11 @@ def test_no_silent_cpu_fallback():
     from hiertcn_amd.engine import Engine
     with pytest.raises(HierTCNError):
         Engine(hier_tcn_args(item_num=100, emb_dim=64, hidden_dim=32, tcn_channel=[64, 64]))
+
+
+def test_both_storage_variants_load_and_report_their_dtype():
+    """libhiertcn_gfx950.so stores bfloat16, libhiertcn_gfx950_f16.so IEEE half; same exports (no compute without a GPU)."""
+    from hiertcn_amd import _lib
+    a, b = _lib.load(), _lib.load(f16=True)
+    assert a.hiertcn_storage_dtype() == 0 and b.hiertcn_storage_dtype() == 1
+    assert a.hiertcn_abi_version() == b.hiertcn_abi_version()

@@ -463,3 +463,43 @@ def test_kernel_size_depth_and_width_variants(K, channels, d):
     err = np.abs(logits - pred)
     assert np.quantile(err, 0.999) < 1e-3 and err.max() < 4e-3
     eng.close()
+
+
+def test_fp16_storage_build_matches_its_mirror_oracle():
+    """libhiertcn_gfx950_f16.so (-DHIERTCN_F16: IEEE-half tables and activations, f16 MFMA; BASELINE.json configs[3]
+    names fp16): the same forward + scoring against the oracle rounding to half at the same points.  Training is
+    refused on this build (d-logits underflow in half precision)."""
+    from hiertcn_amd._lib import HierTCNError
+    from hiertcn_amd.engine import Engine, metrics_dict
+    N, d, H, B, S, L = 900, 128, 64, 6, 3, 10
+    args = small_args(N=N, d=d, H=H, S=S, L=L, B=B)
+    p = make_params(args)
+    eng = Engine(args, hier=True, dtype="fp16")
+    assert eng.lib.hiertcn_storage_dtype() == 1
+    eng.set_weights(p)
+    pr = O.round_params_bf16(p, E=d, rnd=O.round_f16)
+    rng = np.random.default_rng(12)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.2 * rng.standard_normal((B, H * args.num_layer))).astype(np.float32)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+    m = metrics_dict(out["metrics8"])
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, st = O.model_hier(args, xl, yl, ml, st0, pr, O.MIRROR_F16)
+    ref = O.masked_loss_and_metrics(pred, y.reshape(B, S * L), N)
+    assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
+    assert abs(m["loss"] - ref["loss"]) < 1e-3
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+    assert hid.dtype == torch.float16
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+    assert np.abs(logits - pred).max() < 1e-3          # half keeps 3 more mantissa bits than bf16: flips are 8x smaller
+    fused = eng.score_fused(hid, dev(y.reshape(-1)), topk=10)
+    flat = logits.reshape(-1, N)
+    yy = y.reshape(-1)
+    v = yy > 0
+    assert np.array_equal(fused["rank"].cpu().numpy()[v], (flat > flat[np.arange(len(yy)), yy][:, None]).sum(1)[v])
+    assert np.array_equal(fused["topk_idx"].cpu().numpy()[v], O.top_k_indices(flat, 10)[v])
+    eng.close()
+    with pytest.raises(HierTCNError):
+        Engine(args, hier=True, dtype="fp16", train=True)
