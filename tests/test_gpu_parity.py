@@ -503,3 +503,28 @@ def test_fp16_storage_build_matches_its_mirror_oracle():
     eng.close()
     with pytest.raises(HierTCNError):
         Engine(args, hier=True, dtype="fp16", train=True)
+
+
+@pytest.mark.parametrize("R,N,d", [(20_000, 50_000, 256), (3_000, 20_778, 128)])
+def test_race_screen_repeated_launches_agree(R, N, d):
+    """The scoring kernels hand LDS stages between waves with LDS-DMA + counted waits + barriers; a misplaced wait shows
+    up as rare wrong tiles that come and go (cdna_hip_programming.md, 'Read a staged buffer one phase AFTER the wait
+    that retires it').  Screen: 25 launches of every flavour on one input must give identical integer outputs."""
+    from hiertcn_amd.engine import Engine
+    args = small_args(N=N, d=d, H=64)
+    eng = Engine(args, hier=True)
+    eng.set_weights(make_params(args, seed=7))
+    rng = np.random.default_rng(R)
+    hid = torch.as_tensor((0.5 * rng.standard_normal((R, d))).astype(np.float32)).cuda().to(torch.bfloat16).contiguous()
+    y = dev(rng.integers(1, N, R).astype(np.int32))
+    first = eng.score_fused(hid, y, topk=10)
+    r0, c0, t0 = first["rank"].clone(), first["ce"].clone(), first["topk_idx"].clone()
+    g0 = eng.score_fused(hid, y)
+    assert torch.equal(g0["rank"], r0)
+    for i in range(25):
+        a = eng.score_fused(hid, y) if i % 2 else eng.score_fused(hid, y, topk=10)
+        assert torch.equal(a["rank"], r0), i
+        assert float((a["ce"] - c0).abs().max()) < 2e-5, i
+        if "topk_idx" in a:
+            assert torch.equal(a["topk_idx"], t0), i
+    eng.close()
