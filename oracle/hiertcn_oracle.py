@@ -96,7 +96,7 @@ def round_params_bf16(params: dict, E: int | None = None, rnd=None) -> dict:
     for k, v in params.items():
         v = np.asarray(v, dtype=np.float32)
         if is_bf16_stored(k):
-            if k.endswith("tcn/emb/kernel") and k.startswith("hier/") and E is not None:
+            if (k.endswith("tcn/emb/kernel") or k.endswith("gru/emb/kernel")) and k.startswith("hier/") and E is not None:
                 w = v.copy()
                 w[:E] = round_bf16(v[:E])
                 out[k] = w
@@ -129,6 +129,24 @@ def init_params(args, seed=2, model="hier", emb_dim=None):
     H, nl, K = int(args.hidden_dim), int(args.num_layer), int(args.kernel_size)
     ch = [int(c) for c in args.tcn_channel]
     p = {}
+    if model == "hier" and getattr(args, "model_low_type", "tcn") == "gru":
+        # HierGRU (model_hier.py:68 -> model_gru.py:16-63): 'emb' projection, MultiRNNCell of GRUCells under
+        # dynamic_rnn's scope 'rnn' [TF-sem], scoring dense on the top layer's outputs
+        p["hier/emb/kernel"] = _glorot(rng, (N, E), N, E)
+        p["hier/emb/bias"] = np.zeros(E, np.float32)
+        p["hier/gru/emb/kernel"] = _glorot(rng, (E + H * nl, E), E + H * nl, E)
+        for scope, first_in in (("hier/gru/rnn", E), ("hier", E)):
+            inp = first_in
+            for l in range(nl):
+                pre = f"{scope}/multi_rnn_cell/cell_{l}/gru_cell"
+                p[f"{pre}/gates/kernel"] = _glorot(rng, (inp + H, 2 * H), inp + H, 2 * H)
+                p[f"{pre}/gates/bias"] = np.ones(2 * H, np.float32)
+                p[f"{pre}/candidate/kernel"] = _glorot(rng, (inp + H, H), inp + H, H)
+                p[f"{pre}/candidate/bias"] = np.zeros(H, np.float32)
+                inp = H
+        p["hier/gru/dense/kernel"] = _glorot(rng, (H, N), H, N)
+        p["hier/gru/dense/bias"] = np.zeros(N, np.float32)
+        return p
     if model == "hier":
         root = "hier/tcn"
         p["hier/emb/kernel"] = _glorot(rng, (N, E), N, E)
@@ -265,18 +283,50 @@ def gru_cell(inp, h, Wg, bg, Wc, bc):
     return u * h + (1 - u) * c
 
 
-def multi_rnn_cell(inp, state, params, H, nl):
+def multi_rnn_cell(inp, state, params, H, nl, scope="hier"):
     """customed_gru_cell.py:1050-1073 with state_is_tuple=False: layer l reads
     state[:, l*H:(l+1)*H]; the new state is the concat of the per-layer h'."""
     cur = inp
     new = []
     for l in range(nl):
-        pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
+        pre = f"{scope}/multi_rnn_cell/cell_{l}/gru_cell"
         h = state[:, l * H : (l + 1) * H]
         cur = gru_cell(cur, h, params[f"{pre}/gates/kernel"], params[f"{pre}/gates/bias"],
                        params[f"{pre}/candidate/kernel"], params[f"{pre}/candidate/bias"])
         new.append(cur)
     return cur, np.concatenate(new, 1)
+
+
+def seq_length(x):
+    """model_gru.py:109-118: the number of time steps whose feature vector is not all-zero -- a COUNT, used by
+    dynamic_rnn as a prefix length (:51).  Inside model_hier it is taken on the projected [e, state] rows, so a padded
+    step counts whenever the carried state is non-zero, and with a zero state (a user's first session) the leading
+    null-id step does not: such a session of n events gets length n-1 and its last real step outputs zeros."""
+    used = np.sign(np.abs(x).max(2))
+    return used.sum(1).astype(np.int64)
+
+
+def model_gru_low(args, xs, params, root="hier/gru", num: Numerics = EXACT64, return_hidden=False):
+    """model_gru.py:16-63 as the low level of model_hier (model_hier.py:68): xs [B, L, E + H*nl] float.
+    'emb' projection without bias (:46); MultiRNNCell of GRUCells run by dynamic_rnn from a zero state with
+    sequence_length = length(projected x) (:47-53) -- [TF-sem] past a row's length the output is zero and the state is
+    carried through unchanged; scoring dense on the outputs (:57)."""
+    dt = num.dtype
+    H, nl = int(args.hidden_dim), int(args.num_layer)
+    u = num.act(dense(xs.astype(dt), params[f"{root}/emb/kernel"]))
+    length = seq_length(u)
+    B, L, _ = u.shape
+    state = np.zeros((B, H * nl), dt)
+    outs = np.zeros((B, L, H), dt)
+    for t in range(L):
+        active = (t < length)[:, None]
+        cur, new_state = multi_rnn_cell(u[:, t], state, params, H, nl, scope=f"{root}/rnn")
+        state = np.where(active, new_state, state)
+        outs[:, t] = np.where(active, cur, 0.0)
+    outs = num.act(outs)
+    if return_hidden:
+        return outs
+    return dense(outs, params[f"{root}/dense/kernel"], params[f"{root}/dense/bias"])
 
 
 def session_mean_pool(y_ids, params, dtype=np.float64):
@@ -293,7 +343,7 @@ def session_mean_pool(y_ids, params, dtype=np.float64):
 
 
 def model_hier(args, x, y, mask, state, params, num: Numerics = EXACT64, return_hidden=False):
-    """model_hier.py:21-94 with model_low_type == 'tcn' and the default-off branches
+    """model_hier.py:21-94 with model_low_type 'tcn' (HierTCN) or 'gru' (HierGRU) and the default-off branches
     (gap, noise, impression, batchnorm) excluded.
     x, y: lists of S integer id arrays [B, L_i] (the one-hot of model.py:59-61 is undone: ids in,
     row-0-is-zero semantics kept); mask: list of [B,1]; state [B, H*nl].
@@ -308,11 +358,14 @@ def model_hier(args, x, y, mask, state, params, num: Numerics = EXACT64, return_
         e = embed_ids(xi, params["hier/emb/kernel"], dt)  # :50
         feat = np.repeat(state[:, None, :], xi.shape[1], axis=1)  # :54
         xs = np.concatenate([e, feat], axis=-1)  # :55
-        h = tcn_hidden(args, xs, params, "hier/tcn", num)  # :63 -> model_tcn.py:35-36
-        if return_hidden:
-            preds.append(h)
+        if getattr(args, "model_low_type", "tcn") == "gru":  # :67-68 (the reference's default low level: HierGRU)
+            preds.append(model_gru_low(args, xs, params, "hier/gru", num, return_hidden))
         else:
-            preds.append(dense(h, params["hier/tcn/dense/kernel"], params["hier/tcn/dense/bias"]))
+            h = tcn_hidden(args, xs, params, "hier/tcn", num)  # :63 -> model_tcn.py:35-36
+            if return_hidden:
+                preds.append(h)
+            else:
+                preds.append(dense(h, params["hier/tcn/dense/kernel"], params["hier/tcn/dense/bias"]))
         y_slice = session_mean_pool(y[i], params, dt)  # :83-85
         _, state = multi_rnn_cell(y_slice, state, params, H, nl)  # :91
         state = state * np.asarray(mask[i], dt)  # :93

@@ -152,3 +152,34 @@ def test_round_bf16_matches_torch():
     x = np.random.default_rng(0).standard_normal(10000).astype(np.float32) * 37
     ref = torch.from_numpy(x).to(torch.bfloat16).to(torch.float32).numpy()
     assert np.array_equal(O.round_bf16(x), ref)
+
+
+def test_hiergru_low_level_length_quirk_and_zero_weight_answer():
+    """HierGRU (model_hier.py:67-68 -> model_gru.py:16-63).  (1) `length` counts non-zero projected steps and
+    dynamic_rnn uses the count as a prefix length (model_gru.py:51,109-118): with a zero carried state the leading null-id
+    step is all-zero, so a first session of n events runs n-1 steps and its n-th step outputs zeros -> logits = bias.
+    (2) With all GRU kernels zero and the gate bias 1 the top layer's output at step t (from a zero state) is
+    h_t = sigma(1) h_{t-1} + (1 - sigma(1)) tanh(0) = 0 -> logits = bias everywhere."""
+    from hiertcn_amd.args import hier_tcn_args
+    a = hier_tcn_args(item_num=40, emb_dim=8, hidden_dim=6, num_layer=2, model_low_type="gru")
+    p = O.init_params(a, 3)
+    p["hier/gru/dense/bias"] = np.arange(40, dtype=np.float32) * 0.01
+    x = [np.array([[0, 3, 4, 0, 0], [0, 7, 9, 2, 5]])]
+    y = [np.array([[3, 4, 6, 0, 0], [7, 9, 2, 5, 1]])]
+    pred, st = O.model_hier(a, x, y, [np.ones((2, 1))], np.zeros((2, 12)), p)
+    b = p["hier/gru/dense/bias"]
+    assert np.allclose(pred[0, 2], b) and not np.allclose(pred[0, 1], b)      # lane 0: 3 events, length 2
+    assert np.allclose(pred[1, 4], b) and not np.allclose(pred[1, 3], b)      # lane 1: 5 events, length 4
+    # a non-zero carried state makes every step of the slot "used": no zeroed output
+    pred2, _ = O.model_hier(a, x, y, [np.ones((2, 1))], 0.3 * np.ones((2, 12)), p)
+    assert not np.allclose(pred2[0, 4], b)
+    q = dict(p)
+    for k in q:
+        if "hier/gru/rnn" in k and k.endswith("kernel"):
+            q[k] = np.zeros_like(q[k])
+    pred3, _ = O.model_hier(a, x, y, [np.ones((2, 1))], 0.3 * np.ones((2, 12)), q)
+    assert np.allclose(pred3, b[None, None, :])
+    # parameter count: E + b_emb + Wp + 2 x (2-layer GRU) + scoring
+    E, H, N = 8, 6, 40
+    gru = lambda i: (i + H) * 2 * H + 2 * H + (i + H) * H + H  # noqa: E731
+    assert O.count_params(p) == N * E + E + (E + 2 * H) * E + 2 * (gru(E) + gru(H)) + H * N + N

@@ -154,3 +154,59 @@ def test_bf16_mirror_close_to_exact():
     b, sb = O.model_hier(args, x, y, mask, st0, p, O.MIRROR)
     assert np.abs(a - b).max() < 1e-3
     assert np.allclose(sa, sb)  # the GRU side is fp32/fp64 in both
+
+
+def test_hiergru_agrees_with_torch_formulation():
+    """HierGRU low level: NumPy oracle vs a torch formulation built on torch.nn.GRUCell-free primitives with explicit
+    length masks (torch.where), incl. the count-as-prefix-length quirk of model_gru.py:109-118."""
+    args = hier_tcn_args(item_num=61, hidden_dim=10, emb_dim=12, num_layer=2, model_low_type="gru")
+    p = O.init_params(args, seed=5)
+    rng = np.random.default_rng(5)
+    for k in p:
+        if k.endswith("/bias"):
+            p[k] = p[k] + rng.standard_normal(p[k].shape).astype(np.float32) * 0.1
+    B, S, L = 3, 3, 5
+    x, y, mask = make_batch(rng, B, S, L, 61)
+    st0 = np.zeros((B, 20))
+    st0[1] = rng.standard_normal(20)          # lane 1 starts with a carried state, lanes 0 and 2 from zero
+    pred, st = O.model_hier(args, x, y, mask, st0, p)
+    H, nl = 10, 2
+    Etab = T(p["hier/emb/kernel"]).clone()
+    state = T(st0)
+    outs = []
+    for i in range(S):
+        xi = torch.from_numpy(x[i].astype(np.int64))
+        yi = torch.from_numpy(y[i].astype(np.int64))
+        e = F.embedding(xi, Etab) * (xi > 0)[..., None]
+        u = torch.cat([e, state[:, None, :].expand(-1, L, -1)], -1) @ T(p["hier/gru/emb/kernel"])
+        length = (u.abs().amax(2) > 0).sum(1)
+        h = torch.zeros(B, H * nl, dtype=torch.float64)
+        steps = []
+        for t in range(L):
+            cur, new = u[:, t], []
+            for l in range(nl):
+                pre = f"hier/gru/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+                hl = h[:, l * H:(l + 1) * H]
+                g = torch.sigmoid(torch.cat([cur, hl], 1) @ T(p[f"{pre}/gates/kernel"]) + T(p[f"{pre}/gates/bias"]))
+                r, uu = g[:, :H], g[:, H:]
+                c = torch.tanh(torch.cat([cur, r * hl], 1) @ T(p[f"{pre}/candidate/kernel"]) + T(p[f"{pre}/candidate/bias"]))
+                cur = uu * hl + (1 - uu) * c
+                new.append(cur)
+            act = (t < length)[:, None]
+            h = torch.where(act, torch.cat(new, 1), h)
+            steps.append(torch.where(act, cur, torch.zeros_like(cur)))
+        outs.append(torch.stack(steps, 1) @ T(p["hier/gru/dense/kernel"]) + T(p["hier/gru/dense/bias"]))
+        ey = F.embedding(yi, Etab) * (yi > 0)[..., None]
+        cur = ey.sum(1) / (yi > 0).sum(1, keepdim=True) + T(p["hier/emb/bias"])
+        new = []
+        for l in range(nl):
+            pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
+            hl = state[:, l * H:(l + 1) * H]
+            g = torch.sigmoid(torch.cat([cur, hl], 1) @ T(p[f"{pre}/gates/kernel"]) + T(p[f"{pre}/gates/bias"]))
+            r, uu = g.chunk(2, 1)
+            c = torch.tanh(torch.cat([cur, r * hl], 1) @ T(p[f"{pre}/candidate/kernel"]) + T(p[f"{pre}/candidate/bias"]))
+            cur = uu * hl + (1 - uu) * c
+            new.append(cur)
+        state = torch.cat(new, 1) * T(mask[i])
+    assert np.allclose(pred, torch.cat(outs, 1).numpy(), atol=1e-10)
+    assert np.allclose(st, state.numpy(), atol=1e-10)
