@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -22,7 +22,7 @@ c_f64p = C.POINTER(C.c_double)
 class Config(C.Structure):
     _fields_ = [("item_num", C.c_int32), ("emb_dim", C.c_int32), ("hidden_dim", C.c_int32),
                 ("num_layer", C.c_int32), ("kernel_size", C.c_int32), ("n_blocks", C.c_int32),
-                ("channels", C.c_int32 * MAX_BLOCKS), ("hier", C.c_int32)]
+                ("channels", C.c_int32 * MAX_BLOCKS), ("hier", C.c_int32), ("low_type", C.c_int32)]
 
 
 class Weights(C.Structure):
@@ -31,7 +31,9 @@ class Weights(C.Structure):
                 ("res_kernel", C.c_void_p * MAX_BLOCKS), ("res_bias", C.c_void_p * MAX_BLOCKS),
                 ("out_kernel", C.c_void_p), ("out_bias", C.c_void_p),
                 ("gru_gate_kernel", C.c_void_p * MAX_LAYERS), ("gru_gate_bias", C.c_void_p * MAX_LAYERS),
-                ("gru_cand_kernel", C.c_void_p * MAX_LAYERS), ("gru_cand_bias", C.c_void_p * MAX_LAYERS)]
+                ("gru_cand_kernel", C.c_void_p * MAX_LAYERS), ("gru_cand_bias", C.c_void_p * MAX_LAYERS),
+                ("low_gate_kernel", C.c_void_p * MAX_LAYERS), ("low_gate_bias", C.c_void_p * MAX_LAYERS),
+                ("low_cand_kernel", C.c_void_p * MAX_LAYERS), ("low_cand_bias", C.c_void_p * MAX_LAYERS)]
 
 
 class ScoreOut(C.Structure):

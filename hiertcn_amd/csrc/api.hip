@@ -63,12 +63,22 @@ int hiertcn_storage_dtype(void) {
 }
 const char* hiertcn_last_error(void) { return g_err; }
 
-int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
-  if (!out || !cfg) return fail(HIERTCN_ERR_INVALID, "null argument");
+int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
+  if (!out || !cfg_in) return fail(HIERTCN_ERR_INVALID, "null argument");
+  hiertcn_config_t cfg_local = *cfg_in;
+  const hiertcn_config_t* cfg = &cfg_local;
   const int E = cfg->emb_dim;
   if (cfg->item_num < 2) return fail(HIERTCN_ERR_INVALID, "item_num must be >= 2 (row 0 is the null id)");
   if (E < 32 || (E & 31) || E > 1024)
     return fail(HIERTCN_ERR_INVALID, "emb_dim %d unsupported: widths are multiples of 32 (one MFMA tile), zero-pad other widths on the host", E);
+  const bool low_gru = cfg->hier && cfg->low_type == 1;
+  if (cfg->low_type != 0 && !low_gru) return fail(HIERTCN_ERR_INVALID, "low_type %d: 0 (tcn) or, for hier models, 1 (gru)", cfg->low_type);
+  if (low_gru) {
+    if (!(cfg->hidden_dim == 64 || cfg->hidden_dim == 128 || cfg->hidden_dim == 256 || cfg->hidden_dim == 512))
+      return fail(HIERTCN_ERR_INVALID, "HierGRU: hidden_dim %d feeds the scoring kernel, which is built for 64, 128, 256, 512", cfg->hidden_dim);
+    // the TemporalConvNet fields do not apply: normalise them so that the shared checks / sizes below see one "block" of H channels
+    cfg_local.n_blocks = 1; cfg_local.channels[0] = cfg->hidden_dim; cfg_local.kernel_size = 1;
+  }
   if (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS) return fail(HIERTCN_ERR_INVALID, "n_blocks out of range");
   bool uniform = (E == 64 || E == 128 || E == 256);
   for (int i = 0; i < cfg->n_blocks; i++) {
@@ -111,7 +121,8 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
   m.n_blocks = cfg->n_blocks;
   for (int i = 0; i < m.n_blocks; i++) m.C[i] = cfg->channels[i];
   m.Clast = m.C[m.n_blocks - 1];
-  m.fused_tcn = uniform ? 1 : 0;
+  m.low_gru = low_gru ? 1 : 0;
+  m.fused_tcn = (uniform && !low_gru) ? 1 : 0;
 
 #define ALLOC_OR_FAIL(ptr, count)                                  \
   do {                                                             \
@@ -126,7 +137,7 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
   ALLOC_OR_FAIL(m.emb, (size_t)m.N * E);
   ALLOC_OR_FAIL(m.outT, (size_t)m.NP * m.Clast);
   ALLOC_OR_FAIL(m.out_bias, (size_t)m.NP);
-  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+  for (int i = 0, cin = E; i < m.n_blocks && !low_gru; cin = m.C[i], i++) {
     ALLOC_OR_FAIL(m.convT[i], (size_t)m.K * cin * m.C[i]);
     ALLOC_OR_FAIL(m.conv_bias[i], (size_t)m.C[i]);
     if (cin != m.C[i]) {  // customized_tcn_cell.py:102-106: a biased Dense down-sample on the residual path
@@ -144,6 +155,12 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg) {
       ALLOC_OR_FAIL(m.gru_bg[l], (size_t)2 * m.H);
       ALLOC_OR_FAIL(m.gru_wc[l], (size_t)(in + m.H) * m.H);
       ALLOC_OR_FAIL(m.gru_bc[l], (size_t)m.H);
+      if (low_gru) {
+        ALLOC_OR_FAIL(m.lgru_wg[l], (size_t)(in + m.H) * 2 * m.H);
+        ALLOC_OR_FAIL(m.lgru_bg[l], (size_t)2 * m.H);
+        ALLOC_OR_FAIL(m.lgru_wc[l], (size_t)(in + m.H) * m.H);
+        ALLOC_OR_FAIL(m.lgru_bc[l], (size_t)m.H);
+      }
     }
   }
   ALLOC_OR_FAIL(c->metric_scratch, (size_t)8 * HIERTCN_METRIC_BLOCKS_MAX);
@@ -180,7 +197,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
   // that padding items never outrank anything and add exp(-inf) = 0 to the softmax denominator
   HIP_TRY(launch_transpose_to_bf16(w->out_kernel, m.outT, m.Clast, m.N, m.NP, st));
   HIP_TRY(launch_copy_pad_f32(w->out_bias, m.out_bias, m.N, m.NP, -INFINITY, st));
-  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+  for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
     const int cout = m.C[i];
     if (!w->conv_kernel[i] || !w->conv_bias[i]) return fail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
     if ((cin != cout) != (w->res_kernel[i] != nullptr))
@@ -207,6 +224,14 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
       HIP_TRY(launch_copy_pad_f32(w->gru_gate_bias[l], m.gru_bg[l], 2 * m.H, 2 * m.H, 0.f, st));
       HIP_TRY(launch_transpose_f32(w->gru_cand_kernel[l], m.gru_wc[l], in + m.H, m.H, st));
       HIP_TRY(launch_copy_pad_f32(w->gru_cand_bias[l], m.gru_bc[l], m.H, m.H, 0.f, st));
+      if (m.low_gru) {
+        if (!w->low_gate_kernel[l] || !w->low_gate_bias[l] || !w->low_cand_kernel[l] || !w->low_cand_bias[l])
+          return fail(HIERTCN_ERR_INVALID, "HierGRU: low-level GRU layer %d weights missing", l);
+        HIP_TRY(launch_transpose_f32(w->low_gate_kernel[l], m.lgru_wg[l], in + m.H, 2 * m.H, st));
+        HIP_TRY(launch_copy_pad_f32(w->low_gate_bias[l], m.lgru_bg[l], 2 * m.H, 2 * m.H, 0.f, st));
+        HIP_TRY(launch_transpose_f32(w->low_cand_kernel[l], m.lgru_wc[l], in + m.H, m.H, st));
+        HIP_TRY(launch_copy_pad_f32(w->low_cand_bias[l], m.lgru_bc[l], m.H, m.H, 0.f, st));
+      }
     }
   }
   if (h->train.enabled) HIP_TRY(train_fill_masters(m, h->train, w, st));
@@ -409,6 +434,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
 int hiertcn_train_enable(hiertcn_handle_t h) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (h->train.enabled) return HIERTCN_OK;
+  if (h->m.low_gru) return fail(HIERTCN_ERR_INVALID, "training is not built for the HierGRU low level");
   if (h->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_train_enable must precede hiertcn_set_weights (the fp32 masters are filled there)");
   HIP_TRY(train_enable(h->m, h->train));
   return HIERTCN_OK;

@@ -57,6 +57,7 @@ struct ModelDev {
   int C[HIERTCN_MAX_BLOCKS];
   int Clast;
   int hier;
+  int low_gru;     // 1: HierGRU -- the low level is model_gru.py's GRU stack instead of the TemporalConvNet (hier only)
   int fused_tcn;   // 1: every width == E in {64,128,256} and no down-sample residual -> tcn.hip's fused kernel applies (L <= 32)
   // bf16 tensors (uint16 bit patterns)
   uint16_t* emb;        // [N][E], row 0 zeroed
@@ -74,6 +75,10 @@ struct ModelDev {
   float* gru_bg[HIERTCN_MAX_LAYERS];
   float* gru_wc[HIERTCN_MAX_LAYERS];  // [H][in+H]
   float* gru_bc[HIERTCN_MAX_LAYERS];
+  float* lgru_wg[HIERTCN_MAX_LAYERS]; // low-level GRU stack of HierGRU (same layouts), low_gru only
+  float* lgru_bg[HIERTCN_MAX_LAYERS];
+  float* lgru_wc[HIERTCN_MAX_LAYERS];
+  float* lgru_bc[HIERTCN_MAX_LAYERS];
 };
 
 // launchers implemented in the kernel files (all asynchronous on `st`)
@@ -86,6 +91,9 @@ size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 size_t gru_save_floats(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
                            float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st, float* save = nullptr);
+size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L);
+hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
+                          hipStream_t st);
 size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
                               uint16_t* hidden, void* workspace, hipStream_t st);

@@ -96,6 +96,9 @@ struct GemmArgs {
   const float* gates; int ldg;         // CAND
   const float* mask; int ldm;          // CAND: mask[m * ldm]
   float* cand_out; int ldc;            // CAND, optional: the candidate c = tanh(.) (kept for the backward pass)
+  const int32_t* seq_len; int tstep;   // CAND, optional (low-level GRU under dynamic_rnn): row m is active iff tstep < seq_len[m];
+                                       //   inactive rows keep their old state, and their output row is zero
+  uint16_t* hid_out; int64_t ldho;     // CAND, optional: the layer's output as a 16-bit row (scoring operand), zero when inactive
   int H;
   int rowmap_S;                        // STORE: >0 -> row m = b*(S+1)+s maps to out row b*S+s, s == S skipped
 };
@@ -191,7 +194,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
     } else {  // EPI_CAND: c = tanh(.), h' = u*h + (1-u)*c (:335-336); state *= mask (model_hier.py:93)
       const float4 hv = *reinterpret_cast<const float4*>(g.h + (int64_t)m * g.ldh + n0);
       const float4 uv = *reinterpret_cast<const float4*>(g.gates + (int64_t)m * g.ldg + g.H + n0);
-      const float mk = g.mask[(int64_t)m * g.ldm];
+      const float mk = g.mask ? g.mask[(int64_t)m * g.ldm] : 1.0f;
       float hn[4];
       const float c0 = tanhf(v[0]), c1 = tanhf(v[1]), c2 = tanhf(v[2]), c3 = tanhf(v[3]);
       if (g.cand_out) *reinterpret_cast<float4*>(g.cand_out + (int64_t)m * g.ldc + n0) = make_float4(c0, c1, c2, c3);
@@ -200,6 +203,18 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
       hn[2] = uv.z * hv.z + (1.0f - uv.z) * c2;
       hn[3] = uv.w * hv.w + (1.0f - uv.w) * c3;
       *reinterpret_cast<float4*>(g.out + (int64_t)m * g.ldo + n0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      if (g.seq_len) {   // [TF-sem] dynamic_rnn past a row's sequence_length: state copied through, output zero (model_gru.py:47-53)
+        const bool active = g.tstep < g.seq_len[m];
+        *reinterpret_cast<float4*>(g.out2 + (int64_t)m * g.ldo2 + n0) =
+            active ? make_float4(hn[0], hn[1], hn[2], hn[3]) : make_float4(hv.x, hv.y, hv.z, hv.w);
+        if (g.hid_out) {
+          uint2 o;
+          o.x = active ? pack2bf(hn[0], hn[1]) : 0u;
+          o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
+          *reinterpret_cast<uint2*>(g.hid_out + (int64_t)m * g.ldho + n0) = o;
+        }
+        continue;
+      }
       *reinterpret_cast<float4*>(g.out2 + (int64_t)m * g.ldo2 + n0) = make_float4(hn[0] * mk, hn[1] * mk, hn[2] * mk, hn[3] * mk);
     }
   }
@@ -292,6 +307,100 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
   if (state_before) {
     for (int s = 0; s < S; s++)
       if ((e = copy_rows(hist + (size_t)s * HT, hs, state_before + (size_t)s * HT, (int64_t)S * HT, B, HT, st)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// HierGRU low level (model_hier.py:67-68 -> model_gru.py:16-63): the projected session rows run through a
+// MultiRNNCell of GRUCells under dynamic_rnn, from a zero state, for `length` steps per session, where
+// length = the NUMBER of non-zero projected rows of the session (model_gru.py:109-118, used as a prefix
+// length).  Same exact-fp32 MFMA GEMM stream as the high level, M = all sessions of the batch, one
+// (gates, candidate) pair per (step, layer); the top layer's outputs are written as the scoring
+// kernel's 16-bit operand rows [session * L + t][H].
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_rows_f32_and_len(const uint16_t* __restrict__ u, int64_t n_sess, int L, int E, float* __restrict__ uf,
+                                                          int32_t* __restrict__ seq_len) {
+  // one wave per session: widen the projected rows to fp32 (the GEMM operand) and count the rows that are not all-zero
+  const int lane = threadIdx.x & 63;
+  const int64_t sess = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sess >= n_sess) return;
+  int cnt = 0;
+  for (int t = 0; t < L; t++) {
+    const int64_t r = sess * L + t;
+    int nz = 0;
+    for (int c = lane; c < E; c += 64) {
+      const float v = bf2f(u[r * E + c]);
+      uf[r * E + c] = v;
+      nz |= (v != 0.f) ? 1 : 0;
+    }
+    cnt += __any(nz) ? 1 : 0;
+  }
+  if (lane == 0) seq_len[sess] = cnt;
+}
+
+size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
+  // u (16-bit) + u (fp32) + lengths + two state buffers + gates + r*h + per-layer outputs
+  const size_t R = (size_t)n_sess * L;
+  size_t b = 0;
+  auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
+  b += al(R * m.E * 2) + al(R * m.E * 4) + al((size_t)n_sess * 4);
+  b += 2 * al((size_t)n_sess * m.HT * 4) + al((size_t)n_sess * 2 * m.H * 4) + al((size_t)n_sess * m.H * 4) + al((size_t)m.nl * n_sess * m.H * 4);
+  return b + al(R * m.E * 2);   // + the embedded rows
+}
+
+hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
+                          hipStream_t st) {
+  if (n_sess <= 0) return hipSuccess;
+  const int E = m.E, H = m.H, HT = m.HT;
+  const int64_t R = n_sess * L;
+  unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+  auto take = [&](size_t bytes) { unsigned char* p = w; w += (bytes + 255) & ~(size_t)255; return p; };
+  uint16_t* a_emb = reinterpret_cast<uint16_t*>(take((size_t)R * E * 2));
+  uint16_t* u16 = reinterpret_cast<uint16_t*>(take((size_t)R * E * 2));
+  float* uf = reinterpret_cast<float*>(take((size_t)R * E * 4));
+  int32_t* seq_len = reinterpret_cast<int32_t*>(take((size_t)n_sess * 4));
+  float* state[2] = {reinterpret_cast<float*>(take((size_t)n_sess * HT * 4)), reinterpret_cast<float*>(take((size_t)n_sess * HT * 4))};
+  float* gates = reinterpret_cast<float*>(take((size_t)n_sess * 2 * H * 4));
+  float* rh = reinterpret_cast<float*>(take((size_t)n_sess * H * 4));
+  float* hcur = reinterpret_cast<float*>(take((size_t)m.nl * n_sess * H * 4));
+  hipError_t e;
+  if ((e = launch_embed_rows(m, x, R, a_emb, st)) != hipSuccess) return e;
+  {  // 'emb' projection of [e, state] (model_gru.py:46), rounded to the 16-bit storage type like the TCN's input
+    LayerArgs a = {};
+    a.in = a_emb; a.out = u16; a.W = m.projT; a.seq_init = sproj;
+    a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
+    if ((e = launch_tcn_layer(a, st)) != hipSuccess) return e;
+  }
+  hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, u16, n_sess, L, E, uf, seq_len);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(state[0], 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state (model_gru.py:52: initial_state=None)
+  int cur = 0;
+  for (int t = 0; t < L; t++) {
+    for (int l = 0; l < m.nl; l++) {
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      const float* in = (l == 0) ? uf + (size_t)t * E : hcur + (size_t)(l - 1) * n_sess * H;
+      const int ldin = (l == 0) ? L * E : H;
+      const int in_dim = (l == 0) ? E : H;
+      const float* hold = state[cur] + (size_t)l * H;
+      g.M = (int)n_sess; g.H = H;
+      g.A1 = in; g.lda1 = ldin; g.K1 = in_dim;
+      g.A2 = hold; g.lda2 = HT; g.K2 = H;
+      g.Wt = m.lgru_wg[l]; g.bias = m.lgru_bg[l]; g.N = 2 * H;
+      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
+      g.A2 = rh; g.lda2 = H;
+      g.Wt = m.lgru_wc[l]; g.bias = m.lgru_bc[l]; g.N = H;
+      g.out = hcur + (size_t)l * n_sess * H; g.ldo = H;
+      g.out2 = state[cur ^ 1] + (size_t)l * H; g.ldo2 = HT;
+      g.gates = gates; g.ldg = 2 * H;
+      g.seq_len = seq_len; g.tstep = t;
+      if (l == m.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
+      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    }
+    cur ^= 1;
   }
   return hipSuccess;
 }

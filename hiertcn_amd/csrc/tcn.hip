@@ -183,12 +183,14 @@ static bool use_fused(const ModelDev& m, int L) {
 }
 
 size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) {
+  if (m.low_gru) return low_gru_workspace_bytes(m, n_sessions, L);
   return use_fused(m, L) ? 0 : tcn_layers_workspace_bytes(m, n_sessions, L);
 }
 
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
                               uint16_t* hidden, void* workspace, hipStream_t st) {
   if (n_sessions <= 0) return hipSuccess;
+  if (m.low_gru) return launch_low_gru(m, x, sproj, n_sessions, L, hidden, workspace, st);
   if (!use_fused(m, L)) return launch_tcn_layers(m, x, sproj, n_sessions, L, hidden, workspace, st);
   TcnParams p;
   p.emb = m.emb;

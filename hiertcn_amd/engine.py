@@ -52,6 +52,10 @@ def config_from_args(args, hier: bool = True) -> _lib.Config:
     for i, c in enumerate(ch):
         cfg.channels[i] = c
     cfg.hier = 1 if hier else 0
+    low = getattr(args, "model_low_type", "tcn") if hier else "tcn"
+    if low not in ("tcn", "gru"):
+        raise HierTCNError(f"model_low_type {low!r}: 'tcn' (HierTCN) and 'gru' (HierGRU) are built")
+    cfg.low_type = 1 if low == "gru" else 0
     return cfg
 
 
@@ -79,7 +83,8 @@ class Engine:
         self.H = int(self.cfg.hidden_dim) if hier else 0
         self.nl = int(self.cfg.num_layer) if hier else 0
         self.HT = self.H * self.nl
-        self.C = int(self.cfg.channels[self.cfg.n_blocks - 1])
+        self.low_gru = bool(self.cfg.low_type == 1)
+        self.C = self.H if self.low_gru else int(self.cfg.channels[self.cfg.n_blocks - 1])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             self._ck(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
@@ -117,7 +122,7 @@ class Engine:
         """params: TF-named tensors in the reference layout; numpy or torch, any
         float dtype; uploaded as fp32 and converted on the device by hiertcn_set_weights."""
         root = root or ("hier" if self.hier else "tcn")
-        tcn = f"{root}/tcn" if self.hier else root
+        tcn = (f"{root}/gru" if self.low_gru else f"{root}/tcn") if self.hier else root
         keep = []
 
         def dev(name, shape=None, optional=False):
@@ -139,8 +144,8 @@ class Engine:
         if self.hier:
             w.emb_bias = dev(f"{root}/emb/bias", (E,))
             w.proj_kernel = dev(f"{tcn}/emb/kernel", (E + self.HT, E))
-        cin = E
-        for i in range(self.cfg.n_blocks):
+        cin = H if self.low_gru else E
+        for i in range(0 if self.low_gru else self.cfg.n_blocks):
             cout = int(self.cfg.channels[i])
             pre = f"{tcn}/temporal_conv_net/tblock_{i}"
             w.conv_kernel[i] = dev(f"{pre}/conv1/kernel", (K, cin, cout))
@@ -160,6 +165,12 @@ class Engine:
                 w.gru_gate_bias[l] = dev(f"{pre}/gates/bias", (2 * H,))
                 w.gru_cand_kernel[l] = dev(f"{pre}/candidate/kernel", (inp + H, H))
                 w.gru_cand_bias[l] = dev(f"{pre}/candidate/bias", (H,))
+                if self.low_gru:   # dynamic_rnn's scope 'rnn' under model_gru's 'gru' (model_gru.py:47)
+                    lo = f"{tcn}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+                    w.low_gate_kernel[l] = dev(f"{lo}/gates/kernel", (inp + H, 2 * H))
+                    w.low_gate_bias[l] = dev(f"{lo}/gates/bias", (2 * H,))
+                    w.low_cand_kernel[l] = dev(f"{lo}/candidate/kernel", (inp + H, H))
+                    w.low_cand_bias[l] = dev(f"{lo}/candidate/bias", (H,))
                 inp = H
         with torch.cuda.device(self.device):
             self._ck(self.lib.hiertcn_set_weights(self._h, C.byref(w), self._stream()))

@@ -23,8 +23,8 @@ from .model import LazyLogits, get_scope, pack_slots
 
 
 def _check_args(args):
-    if getattr(args, "model_low_type", "tcn") != "tcn":
-        raise NotImplementedError(f"model_low_type={args.model_low_type!r}: only the HierTCN low level ('tcn') is built")
+    if getattr(args, "model_low_type", "tcn") not in ("tcn", "gru"):
+        raise NotImplementedError(f"model_low_type={args.model_low_type!r}: 'tcn' (HierTCN) and 'gru' (HierGRU) are built")
     for flag in ("has_gap", "has_impression", "has_batchnorm", "has_weightnorm", "has_layernorm", "l2_normalize"):
         if getattr(args, flag, False):
             raise NotImplementedError(f"args.{flag}=True is outside the hot path (reference default is False)")

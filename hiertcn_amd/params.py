@@ -25,6 +25,23 @@ def param_shapes(args, model: str = "hier") -> Dict[str, tuple]:
     H, nl, K = int(args.hidden_dim), int(args.num_layer), int(args.kernel_size)
     ch = [int(c) for c in args.tcn_channel]
     s: Dict[str, tuple] = {}
+    if model == "hier" and getattr(args, "model_low_type", "tcn") == "gru":
+        # HierGRU (the reference's default low level, args.py:40; model_hier.py:67-68 -> model_gru.py:16-63)
+        s["hier/emb/kernel"] = (N, E)
+        s["hier/emb/bias"] = (E,)
+        s["hier/gru/emb/kernel"] = (E + H * nl, E)
+        for scope in ("hier/gru/rnn", "hier"):
+            inp = E
+            for l in range(nl):
+                pre = f"{scope}/multi_rnn_cell/cell_{l}/gru_cell"
+                s[f"{pre}/gates/kernel"] = (inp + H, 2 * H)
+                s[f"{pre}/gates/bias"] = (2 * H,)
+                s[f"{pre}/candidate/kernel"] = (inp + H, H)
+                s[f"{pre}/candidate/bias"] = (H,)
+                inp = H
+        s["hier/gru/dense/kernel"] = (H, N)
+        s["hier/gru/dense/bias"] = (N,)
+        return s
     if model == "hier":
         root = "hier/tcn"
         s["hier/emb/kernel"] = (N, E)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 3
+#define HIERTCN_ABI_VERSION 4
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -69,6 +69,9 @@ typedef struct {
   int32_t n_blocks;                      /* len(args.tcn_channel)                          */
   int32_t channels[HIERTCN_MAX_BLOCKS];  /* args.tcn_channel                               */
   int32_t hier;                          /* 1: model_hier low level; 0: single-level model_tcn */
+  int32_t low_type;                      /* args.model_low_type (hier only): 0 'tcn' = HierTCN; 1 'gru' = HierGRU, the reference's
+                                          * default (args.py:40; model_hier.py:67-68 -> model_gru.py:16-63): n_blocks / channels /
+                                          * kernel_size are ignored, the scoring layer reads hidden_dim channels */
 } hiertcn_config_t;
 
 /* Device pointers to fp32 tensors in the REFERENCE's variable layout:
@@ -98,6 +101,12 @@ typedef struct {
   const float* gru_gate_bias[HIERTCN_MAX_LAYERS];
   const float* gru_cand_kernel[HIERTCN_MAX_LAYERS];
   const float* gru_cand_bias[HIERTCN_MAX_LAYERS];
+  /* HierGRU only (low_type == 1): hier/gru/rnn/multi_rnn_cell/cell_{l}/gru_cell/{gates,candidate}/{kernel,bias};
+   * proj_kernel is then hier/gru/emb/kernel, out_kernel / out_bias hier/gru/dense/{kernel [H][N], bias} */
+  const float* low_gate_kernel[HIERTCN_MAX_LAYERS];
+  const float* low_gate_bias[HIERTCN_MAX_LAYERS];
+  const float* low_cand_kernel[HIERTCN_MAX_LAYERS];
+  const float* low_cand_bias[HIERTCN_MAX_LAYERS];
 } hiertcn_weights_t;
 
 /* Outputs of one evaluation step (all optional except where noted; NULL = not wanted). */
