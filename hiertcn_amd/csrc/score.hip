@@ -450,6 +450,8 @@ struct RowState2 {
   float s;     // sum of 2^(z*log2(e) - m2)
   int c;       // count of z > t
   float xp, ep, ssave;  // PMODE 5: software-pipeline registers (pending exponent, pending term) and the tile checkpoint of s
+  f32x2 s2, xp2, ep2;   // PMODE 7/8: the same pipeline on PAIRS of logits (v_pk_fma_f32 / v_pk_add_f32: two values per issue slot)
+  unsigned bits;        // PMODE 7: sign bits of (t - z) of the current tile, one per logit (popcount at the end of the tile)
 };
 
 // PMODE (HIERTCN_PIPE_VARIANT): 0 full, reference checked before every tile (v3); 1 count only; 2 no epilogue;
@@ -457,6 +459,9 @@ struct RowState2 {
 // 5 full, epilogue software-pipelined across values (the fma / exp / add of one logit sit in three consecutive
 // MFMA gaps, so no VALU op waits on the one before it) and the reference moved only when the running sum
 // overflows (checked once per tile; the tile is then redone from its checkpoint with a new reference).
+// 7: as 5 on pairs of logits with the packed fp32 ops (fma and sum cost half an issue slot per logit) and the count taken
+// from the sign of (t - z) shifted into a bit register (v_pk_add + v_alignbit, popcount once per tile) instead of
+// v_cmp + v_addc; 8: packed sum, compare/add-carry count.
 template <int C, int PMODE = 0>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
                                                               int64_t R, const uint16_t* __restrict__ outT,
@@ -524,6 +529,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     st[cbk].s = 0.f;
     st[cbk].c = 0;
     st[cbk].xp = st[cbk].ep = st[cbk].ssave = 0.f;
+    st[cbk].s2 = st[cbk].xp2 = st[cbk].ep2 = f32x2{0.f, 0.f};
+    st[cbk].bits = 0u;
+    if (PMODE == 7 || PMODE == 9) st[cbk].t = t + 0.0f;   // -0 -> +0: then (t - z) is negative exactly when z > t (no -0 result possible)
   }
 
   const int n_all = NP / SC_STAGE;
@@ -578,9 +586,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 
   // per-tile pre-pass of the epilogue: running-reference check on the raw logits (rare rescale, T13)
   constexpr bool PIPED = PMODE >= 5;
+  constexpr bool PACKED = PMODE >= 7;
   constexpr int RING = PMODE == 6 ? 4 : 3;  // LDS fragment ring: a ds_read is issued RING-1 MFMAs ahead of its use
   auto pre = [&](const f32x16& v, RowState2& rs) {
     if (PMODE == 1 || PMODE == 2 || PMODE == 4) return;
+    if (PACKED) {
+      rs.ssave = rs.s2.x + rs.s2.y;
+      asm volatile("" : "+v"(rs.ssave));
+      return;
+    }
     if (PIPED) {
       rs.ssave = rs.s;
       asm volatile("" : "+v"(rs.ssave));
@@ -607,6 +621,69 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     rs.xp = fmaf(v, LOG2E_F, -rs.m2);
     rs.c += gt ? 1 : 0;
     asm volatile("" : "+v"(rs.s), "+v"(rs.c), "+v"(rs.ep), "+v"(rs.xp));
+  };
+  // PMODE 7/8: gap i of a tile handles pair j = i/2.  Even gap: s2 += e2(j-2); e(j-1).lo = 2^x(j-1).lo; d2 = t - v2(j).
+  // Odd gap: e(j-1).hi = 2^x(j-1).hi; x2(j) = v2(j)*log2(e) - m2.  Every gap: one sign bit into rs.bits.
+  // PMODE 9 = 7 with the packed ops written in asm: hipcc (SIPreEmitPeephole) splits v_pk_*_f32 that sit behind an MFMA back
+  // into two scalar ops on gfx950, so 7 as compiled is only partly packed.
+  auto pk_add = [&](f32x2 a, f32x2 b) { f32x2 r; asm volatile("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; };
+  auto val7 = [&](int i, const f32x16& v, RowState2& rs, f32x2& d2) {
+    const int j = i >> 1;
+    const f32x2 v2 = {v[2 * j], v[2 * j + 1]};
+    if (PMODE == 9) {
+      const f32x2 tm = {rs.t, rs.m2};
+      const f32x2 l2 = {LOG2E_F, LOG2E_F};
+      if ((i & 1) == 0) {
+        if (j >= 2) rs.s2 = pk_add(rs.s2, rs.ep2);
+        if (j >= 1) rs.ep2.x = __builtin_amdgcn_exp2f(rs.xp2.x);
+        asm volatile("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(d2) : "v"(tm), "v"(v2));
+        rs.bits = (i == 0) ? (__float_as_uint(d2.x) >> 31) : __builtin_amdgcn_alignbit(rs.bits, __float_as_uint(d2.x), 31);
+      } else {
+        if (j >= 1) rs.ep2.y = __builtin_amdgcn_exp2f(rs.xp2.y);
+        asm volatile("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,1] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+                     : "=v"(rs.xp2) : "v"(v2), "s"(l2), "v"(tm));
+        rs.bits = __builtin_amdgcn_alignbit(rs.bits, __float_as_uint(d2.y), 31);
+      }
+      asm volatile("" : "+v"(rs.s2), "+v"(rs.c), "+v"(rs.ep2), "+v"(rs.xp2), "+v"(rs.bits), "+v"(d2));
+      return;
+    }
+    if ((i & 1) == 0) {
+      if (j >= 2) rs.s2 += rs.ep2;
+      if (j >= 1) rs.ep2.x = __builtin_amdgcn_exp2f(rs.xp2.x);
+      if (PMODE == 7) {
+        d2 = f32x2{rs.t, rs.t} - v2;
+        rs.bits = (i == 0) ? (__float_as_uint(d2.x) >> 31) : __builtin_amdgcn_alignbit(rs.bits, __float_as_uint(d2.x), 31);
+      } else {
+        rs.c += (v2.x > rs.t) ? 1 : 0;
+      }
+    } else {
+      if (j >= 1) rs.ep2.y = __builtin_amdgcn_exp2f(rs.xp2.y);
+      rs.xp2 = __builtin_elementwise_fma(v2, f32x2{LOG2E_F, LOG2E_F}, f32x2{-rs.m2, -rs.m2});
+      if (PMODE == 7) rs.bits = __builtin_amdgcn_alignbit(rs.bits, __float_as_uint(d2.y), 31);
+      else rs.c += (v2.y > rs.t) ? 1 : 0;
+    }
+    asm volatile("" : "+v"(rs.s2), "+v"(rs.c), "+v"(rs.ep2), "+v"(rs.xp2), "+v"(rs.bits), "+v"(d2));
+  };
+  auto post7 = [&](const f32x16& v, RowState2& rs) {
+    rs.s2 += rs.ep2;
+    rs.ep2.x = __builtin_amdgcn_exp2f(rs.xp2.x);
+    rs.ep2.y = __builtin_amdgcn_exp2f(rs.xp2.y);
+    rs.s2 += rs.ep2;
+    if (PMODE == 7 || PMODE == 9) rs.c += __builtin_popcount(rs.bits);
+    const float tot = rs.s2.x + rs.s2.y;
+    if (__any(!(tot < 1.0e38f))) {
+      float tm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
+      tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
+      const bool bad = !(tot < 1.0e38f);
+      float d = fmaxf(ceilf(fmaf(tm, LOG2E_F, -rs.m2)), 0.f);
+      d = fmaxf(d, (float)__builtin_amdgcn_frexp_expf(rs.ssave));
+      d = bad ? d : 0.f;
+      rs.m2 += d;
+      float acc = rs.ssave * __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+      for (int i = 0; i < 16; i++) acc += __builtin_amdgcn_exp2f(fmaf(v[i], LOG2E_F, -rs.m2));
+      rs.s2 = f32x2{acc, 0.f};
+    }
   };
   // PMODE 5: end of a tile: drain the two pending values, then the overflow check (wave-uniform branch, rare).
   auto post5 = [&](const f32x16& v, RowState2& rs) {
@@ -651,6 +728,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // LDS peak) -- the price of needing only two accumulator tiles.
 #define SC_PHASE(x, CBX, y, CBY, buf_, ib_, do_mfma)                                         \
   do {                                                                                       \
+    f32x2 d2_ = {0.f, 0.f};                                                                  \
     pre(y, st[CBY]);                                                                         \
     if (do_mfma) {                                                                           \
       const unsigned char* tile_ = smem + (buf_) * G::STAGE_BYTES + (ib_) * 32 * (2 * C);    \
@@ -663,14 +741,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
         if (s + RING - 1 < G::KS)                                                            \
           af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + RING - 1) << 5))); \
         x = mfma32(af_[s % RING], hf[CBX][s], x);                                            \
-        if (PIPED) val5(s & 15, y[s & 15], st[CBY]); else one(y[s & 15], st[CBY]);           \
+        if (PACKED) val7(s & 15, y, st[CBY], d2_); else if (PIPED) val5(s & 15, y[s & 15], st[CBY]); else one(y[s & 15], st[CBY]); \
         __builtin_amdgcn_sched_barrier(0); /* keep exactly this order: hipcc otherwise clusters the MFMAs */ \
       }                                                                                      \
-      _Pragma("unroll") for (int s = G::KS; s < 16; s++) { if (PIPED) val5(s, y[s], st[CBY]); else one(y[s], st[CBY]); } \
+      _Pragma("unroll") for (int s = G::KS; s < 16; s++) { if (PACKED) val7(s, y, st[CBY], d2_); else if (PIPED) val5(s, y[s], st[CBY]); else one(y[s], st[CBY]); } \
     } else {                                                                                 \
-      _Pragma("unroll") for (int s = 0; s < 16; s++) { if (PIPED) val5(s, y[s], st[CBY]); else one(y[s], st[CBY]); } \
+      _Pragma("unroll") for (int s = 0; s < 16; s++) { if (PACKED) val7(s, y, st[CBY], d2_); else if (PIPED) val5(s, y[s], st[CBY]); else one(y[s], st[CBY]); } \
     }                                                                                        \
-    if (PIPED) post5(y, st[CBY]);                                                            \
+    if (PACKED) post7(y, st[CBY]); else if (PIPED) post5(y, st[CBY]);                        \
   } while (0)
 
   f32x16 accA, accB;
@@ -704,7 +782,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 
 #pragma unroll
   for (int cbk = 0; cbk < 2; cbk++) {
-    const float s_own = st[cbk].s;
+    const float s_own = PACKED ? st[cbk].s2.x + st[cbk].s2.y : st[cbk].s;
     const int c_own = st[cbk].c;
     const int64_t myr = row0 + cbk * 32 + lr;
     // each half's log2-sum-exp2 first (s may be as large as 1e38 in PMODE 5), then the two-term merge
@@ -773,7 +851,7 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
     if (!getenv("HIERTCN_FIXED_WALK")) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&walk), HIP_SYMBOL(g_walk_pos));
   }
   const int parts = score_split_parts(R, m.NP);
-  if (PMODE == 5 && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
+  if ((PMODE == 5 || PMODE >= 7) && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;
     hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
@@ -865,6 +943,9 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   static const char* pvar = getenv("HIERTCN_PIPE_VARIANT");
   if (pvar && pvar[0] == '0') return launch_score_pipe<C, 0>(m, hidden, y, R, out, st);  // v3, for A/B runs
   if (pvar && pvar[0] == '6') return launch_score_pipe<C, 6>(m, hidden, y, R, out, st);
+  if (pvar && pvar[0] == '7') return launch_score_pipe<C, 7>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (pvar && pvar[0] == '8') return launch_score_pipe<C, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (pvar && pvar[0] == '9') return launch_score_pipe<C, 9>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0]) {
     switch (pvar[0]) {
       case '1': return launch_score_pipe<256, 1>(m, hidden, y, R, out, st);

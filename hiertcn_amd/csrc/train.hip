@@ -508,13 +508,19 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.users = take(256);
   w.dA = take(R * C * 4); w.dB = take(R * C * 4); w.dsf = take(R * C * 4);
   w.dcb = take(R * C * 2); w.shb = take(R * C * 2); w.dub = take(R * C * 2);
-  // G chunk: at most ~4 GiB of bf16, at least one 64-item stage
-  const size_t budget = (size_t)4 << 30;
+  // G chunk: at most 16 GiB of bf16 (the two products per chunk run 12 % faster than with 4 GiB chunks: fewer, larger
+  // GEMMs -- profiles/r1_train_notes.md), at least one 64-item stage
+  size_t budget = (size_t)16 << 30;
+  size_t st_cap = 4096;
+  if (const char* gb = getenv("HIERTCN_TRAIN_CHUNK_GIB")) {  // experiments: larger chunks (288 GB of HBM allow it)
+    const long v = atol(gb);
+    if (v >= 1 && v <= 128) budget = (size_t)v << 30;
+  }
   size_t st = budget / (R * 64 * 2);
   const size_t nst = (size_t)m.NP / 64;
   if (st < 1) st = 1;
   if (st > nst) st = nst;
-  if (st > 128) st = 128;
+  if (st > st_cap) st = st_cap;
   if (const char* ov = getenv("HIERTCN_TRAIN_CHUNK_STAGES")) {  // tests: force several chunks on a small catalogue
     const long v = atol(ov);
     if (v >= 1 && (size_t)v < st) st = (size_t)v;

@@ -11,7 +11,7 @@ state  : [B, hidden_dim*num_layer]
 returns: pred_all  a LazyLogits standing for the [B, sum L_i, N] logits of model_hier.py:79
          state     torch.float32 [B, hidden_dim*num_layer] on the GPU (model_hier.py:93-94)
 
-Only the default-graph branches are implemented: model_low_type == 'tcn', no gap decay, no
+Only the default-graph branches are implemented: model_low_type 'tcn' or 'gru' (model_hier.py:64-68), no gap decay, no
 impressions, no noise, no batch/weight/layer norm; anything else raises.
 """
 from __future__ import annotations

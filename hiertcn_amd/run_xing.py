@@ -3,7 +3,8 @@
     python -m hiertcn_amd.run_xing --model_type hier --model_low_type tcn [flags of args.py]
 
 uniquify the log directory, build the three loaders from dataset/interactions.csv, dispatch on
-model_type.  Only the hot-path models are built: 'hier' (with model_low_type 'tcn') and 'tcn'.
+model_type.  Only the hot-path models are built: 'hier' (model_low_type 'tcn' = HierTCN, trainable; 'gru' = HierGRU,
+evaluation only) and 'tcn'.
 """
 from __future__ import annotations
 
