@@ -92,6 +92,12 @@ size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 size_t gru_save_floats(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
                            float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st, float* save = nullptr);
+// score_grad.hip: item-stationary d-logits kernel of the training backward (row chunks)
+bool dlogits_supported(const ModelDev& m);
+int64_t dlogits_ld(const ModelDev& m);
+hipError_t launch_dlogits_rowbias(const float* wc, const float* lc, int64_t Rv, int64_t Rpad, float* rb, hipStream_t st);
+hipError_t launch_dlogits_rows(const ModelDev& m, const uint16_t* hc, const float* rb, const int32_t* yc, const float* wc, const float* lc,
+                               const float* tgt, const int32_t* map, int64_t r0, int64_t r1, uint16_t* gout, float* dbias, hipStream_t st);
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L);
 hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
                           hipStream_t st);

@@ -16,18 +16,7 @@
 // n == y, as in the reference where both come from one tensor (loss.py:179).
 #include "common.h"
 
-#define SC_THREADS 512
-#define SC_STAGE 64  // items per LDS stage (two 32-item MFMA row blocks)
-
-template <int C>
-struct ScGeom {
-  static constexpr int KS = C / 16;
-  static constexpr int CH = C / 8;
-  static constexpr int SWZ = (CH < 16 ? CH : 16) - 1;
-  static constexpr int STAGE_BYTES = SC_STAGE * 2 * C;
-  static constexpr int CHUNKS_PER_THREAD = (SC_STAGE * CH) / SC_THREADS;  // 16-byte chunks each thread stages
-  static_assert((SC_STAGE * CH) % SC_THREADS == 0, "stage must split evenly");
-};
+#include "score_geom.h"
 
 // Catalogue parts for a small batch: enough (row tile, part) workgroups to cover the 256 CUs about once, at least 16
 // stages (1024 items) per part, at most 32 parts.  1 = no split (large batches fill the chip with row tiles alone).

@@ -486,7 +486,9 @@ struct TrainWs {
   size_t pooled, sproj, gru_ws, gru_save, act[2 * HIERTCN_MAX_BLOCKS + 2], rank, ce, tgt, lse, w, lane_act, users;
   size_t dA, dB, dsf, dcb, shb, dub, gchunk, map, nvalid, cscratch, hc, yc, wc, lc, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
   size_t total;
-  int nc_stages;  // stages (of 64 items) per G chunk
+  size_t rb;      // ln w - lse per compact row (+ one padding stage of -inf), k_dlogits
+  int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
+  int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
 };
 
 static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
@@ -526,9 +528,25 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     if (v >= 1 && (size_t)v < st) st = (size_t)v;
   }
   w.nc_stages = (int)st;
-  w.gchunk = take(R * st * 64 * 2);
+  size_t gbytes = R * st * 64 * 2;
+  if (dlogits_supported(m)) {
+    // row-chunked path: G[rows of the chunk, padded to 64][all items, padded to 512]
+    const size_t ldg = (size_t)dlogits_ld(m);
+    size_t rs = budget / (ldg * 2 * 64);
+    const size_t rst = (R + 63) / 64;
+    if (rs < 1) rs = 1;
+    if (rs > rst) rs = rst;
+    if (const char* ov = getenv("HIERTCN_TRAIN_CHUNK_STAGES")) {
+      const long v = atol(ov);
+      if (v >= 1 && (size_t)v < rs) rs = (size_t)v;
+    }
+    w.rc_stages = (int)rs;
+    gbytes = rs * 64 * ldg * 2;
+  }
+  w.gchunk = take(gbytes);
   w.map = take(R * 4); w.nvalid = take(256); w.cscratch = take((R / 1024 + 2) * 4);
-  w.hc = take(R * C * 2); w.yc = take(R * 4); w.wc = take(R * 4); w.lc = take(R * 4);
+  w.hc = take((R + 64) * C * 2); w.yc = take(R * 4); w.wc = take(R * 4); w.lc = take(R * 4);
+  w.rb = take((R + 64) * 4);
   w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
   w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
   w.dpooled = take((size_t)B * S * E * 4);
@@ -641,6 +659,24 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(hipMemsetAsync(dHc, 0, (size_t)Rv * CL * 4, st));
     uint16_t* Gc = BF(w.gchunk);
     const int n_stages = m.NP / 64;
+    if (dlogits_supported(m)) {
+      // Row chunks (score_grad.hip): G[chunk rows][all items] from the item-stationary kernel, which also leaves d bo behind;
+      // then the two plain products of the chunk.
+      const int64_t ldg = dlogits_ld(m);
+      const int64_t Rpad = (Rv + 63) & ~(int64_t)63;
+      T_HIP(hipMemsetAsync(hc + Rv * CL, 0, (size_t)(Rpad - Rv) * CL * 2, st));   // the padding rows of the last stage are read as operands
+      T_HIP(launch_dlogits_rowbias(F32(w.wc), F32(w.lc), Rv, Rpad, F32(w.rb), st));
+      const int64_t rows_per = (int64_t)w.rc_stages * 64;
+      for (int64_t r0 = 0; r0 < Rv; r0 += rows_per) {
+        const int64_t r1 = (r0 + rows_per < Rv) ? r0 + rows_per : Rv;
+        const int rows = (int)(r1 - r0);
+        T_HIP(launch_dlogits_rows(m, hc, F32(w.rb), yc, F32(w.wc), F32(w.lc), so.target, rmap, r0, r1, Gc, G + t.out_bias.off, st));
+        // dH[rows][C] = G[rows][NP] . outT[NP][C]   == col-major: dH^T[C x rows] = outT^T[C x NP] . G^T[NP x rows] (ld = ldg)
+        T_BLAS(gemm_bf16(bl, OPN, OPN, CL, rows, m.NP, m.outT, CL, Gc, (int)ldg, 0.f, dHc + r0 * CL, CL));
+        // d outT[NP][C] += G^T[NP x rows] . hidden[rows][C]   == col-major [C x NP] += hidden^T[C x rows] . (G^T[NP x rows])^T
+        T_BLAS(gemm_bf16(bl, OPN, OPT, CL, m.NP, rows, hc + r0 * CL, CL, Gc, (int)ldg, r0 == 0 ? 0.f : 1.f, G + t.outT.off, CL));
+      }
+    } else
     for (int s0 = 0; s0 < n_stages; s0 += w.nc_stages) {
       const int s1 = (s0 + w.nc_stages < n_stages) ? s0 + w.nc_stages : n_stages;
       const int NC = (s1 - s0) * 64;

@@ -159,8 +159,8 @@ def test_gradient_all_reduce_view_is_the_arena(trained):
 
 
 def test_chunked_dlogits_equal_single_chunk():
-    """The d-logits matrix is produced in item chunks; forcing 3-stage (192-item) chunks on a 700-item catalogue
-    must give the same gradients as one chunk (only the fp32 summation order of d hidden changes)."""
+    """The d-logits matrix is produced in chunks of rows (64-row stages; C_last = 512: chunks of items); forcing one-stage
+    chunks -- 64 rows, then a ragged tail -- must give the same gradients as one chunk (only fp32 summation orders change)."""
     import os
     import subprocess
     import sys
@@ -181,7 +181,7 @@ np.savez(sys.argv[1], **{k.replace("/", "."): v for k, v in g.items()})
 ''' % root
     with tempfile.TemporaryDirectory() as tmp:
         outs = []
-        for i, env in enumerate(({}, {"HIERTCN_TRAIN_CHUNK_STAGES": "3"})):
+        for i, env in enumerate(({}, {"HIERTCN_TRAIN_CHUNK_STAGES": "1"})):
             f = os.path.join(tmp, f"g{i}.npz")
             subprocess.run([sys.executable, "-c", code, f], check=True, env={**os.environ, **env})
             outs.append(dict(np.load(f)))
