@@ -324,3 +324,58 @@ def test_optimizer_state_round_trip(trained):
         # without the restored slots the two updates differ by ~lr = 1e-2 per element
         assert np.abs(got[k] - want[k]).max() <= 1e-4 * max(1.0, np.abs(want[k]).max()), (k, np.abs(got[k] - want[k]).max())
     other.close()
+
+
+def test_scoring_backward_properties_at_north_star_size():
+    """N = 300,000, d = 256 (BASELINE.json configs[2] catalogue), 33,600 rows (about 30,200 scored) = two row chunks of the 16 GiB d-logits budget.
+    Size-independent properties of the scoring layer's backward: (a) every row of softmax - onehot sums to zero, so the
+    bias gradient sums to zero; (b) for sampled items the bias gradient and the kernel-gradient column equal a direct
+    evaluation from the HIP path's own hidden rows and log-sum-exp (d-logits rounded to bf16 as the device rounds them)."""
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine
+    from hiertcn_amd.params import init_params
+    N, d, S, L, B = 300_000, 256, 20, 30, 56    # ~30,200 scored rows > the 28,608 rows of one 16 GiB chunk
+    args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L,
+                         max_session_num=S, batch_size=B)
+    p = init_params(args, seed=2)
+    rng = np.random.default_rng(11)
+    p["hier/tcn/dense/bias"] = (0.5 * rng.standard_normal(N)).astype(np.float32)
+    eng = Engine(args, hier=True, train=True)
+    eng.set_weights(p)
+    ids = np.minimum(1 + (rng.pareto(1.1, (B, S, L)) * 50).astype(np.int64), N - 1)
+    ids[:, :, 20:] *= (rng.random((B, S, 1)) > 0.3)          # some sessions shorter
+    x = np.zeros_like(ids); x[:, :, 1:] = ids[:, :, :-1]
+    dev = lambda a, t=None: torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0", dtype=t)  # noqa: E731
+    xd, yd = dev(x, torch.int32), dev(ids, torch.int32)
+    mask = dev((rng.random((B, S)) > 0.1).astype(np.float32))
+    st0 = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda:0")
+    eng.train_forward_backward(xd, yd, mask, st0)
+    g = eng.export("grads")
+    db = g["hier/tcn/dense/bias"].astype(np.float64)
+    assert abs(db.sum()) <= 1e-4 * np.abs(db).sum()
+
+    # the HIP path's own hidden rows / lse (evaluation entry points of the same handle)
+    pooled = eng.session_pool(yd.view(B * S, L)).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, mask, st0)
+    hid = eng.tcn_forward(xd.view(B * S, L), sproj.view(B * S, -1))
+    yv = yd.view(-1).long()
+    sc = eng.score_fused(hid, yd.view(-1), want_target=True)
+    valid = yv > 0
+    lse = (sc["ce"] + sc["target"]).double()
+    act = valid.view(B, -1).sum(1).double()
+    users = (act > 0).sum().double()
+    w = (1.0 / ((act + 1e-6) * users)).repeat_interleave(S * L) * valid
+    top = torch.bincount(yv[valid]).argsort(descending=True)[:4].cpu().numpy()
+    J = np.unique(np.concatenate([top, rng.integers(1, N, 12), [0]]))
+    Wj = dev(p["hier/tcn/dense/kernel"][:, J]).bfloat16().double()
+    bj = dev(p["hier/tcn/dense/bias"][J]).double()
+    H = hid.double()
+    z = H @ Wj + bj
+    gj = w[:, None] * (torch.exp(z - lse[:, None]) - (yv[:, None] == dev(J)[None, :]).double())
+    gj[~valid] = 0
+    db_ref = gj.sum(0).cpu().numpy()
+    assert np.abs(db[J] - db_ref).max() <= 2e-3 * np.abs(db_ref).max() + 1e-9
+    dW_ref = (H.T @ gj.float().bfloat16().double()).cpu().numpy()          # [d, |J|]
+    dW = g["hier/tcn/dense/kernel"][:, J].astype(np.float64)
+    assert np.linalg.norm(dW - dW_ref) <= 5e-3 * np.linalg.norm(dW_ref), np.linalg.norm(dW - dW_ref) / np.linalg.norm(dW_ref)
+    eng.close()
