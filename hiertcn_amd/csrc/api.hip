@@ -434,7 +434,6 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
 int hiertcn_train_enable(hiertcn_handle_t h) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (h->train.enabled) return HIERTCN_OK;
-  if (h->m.low_gru) return fail(HIERTCN_ERR_INVALID, "training is not built for the HierGRU low level");
   if (h->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_train_enable must precede hiertcn_set_weights (the fp32 masters are filled there)");
   HIP_TRY(train_enable(h->m, h->train));
   return HIERTCN_OK;

@@ -99,6 +99,20 @@ hipError_t launch_dlogits_rowbias(const float* wc, const float* lc, int64_t Rv, 
 hipError_t launch_dlogits_rows(const ModelDev& m, const uint16_t* hc, const float* rb, const int32_t* yc, const float* wc, const float* lc,
                                const float* tgt, const int32_t* map, int64_t r0, int64_t r1, uint16_t* gout, float* dbias, hipStream_t st);
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L);
+// buffers of the HierGRU low level: evaluation keeps two states and one record per layer, training all of them
+struct LowGruBufs {
+  uint16_t* a_emb;    // [R][E] embedded ids
+  uint16_t* u16;      // [R][E] projected [e, state] rows, storage type
+  float* uf;          // [R][E] the same as fp32 (the GRU's input)
+  int32_t* seq_len;   // [n_sess]
+  float* states;      // [n_states][n_sess][HT]; state before step t = buffer t % n_states
+  int n_states;       // 2 (ping-pong) or L + 1
+  float* rec;         // per layer (keep_all: per step and layer): gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
+  int keep_all;
+};
+size_t low_gru_save_floats(const ModelDev& m, int64_t n_sess, int L);
+hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden,
+                               const LowGruBufs& b, hipStream_t st);
 hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
                           hipStream_t st);
 size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);

@@ -341,50 +341,49 @@ __global__ __launch_bounds__(256) void k_rows_f32_and_len(const uint16_t* __rest
 }
 
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
-  // u (16-bit) + u (fp32) + lengths + two state buffers + gates + r*h + per-layer outputs
+  // embedded rows + u (16-bit) + u (fp32) + lengths + two state buffers + one (gates | r*h | cand | out) record per layer
   const size_t R = (size_t)n_sess * L;
-  size_t b = 0;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
-  b += al(R * m.E * 2) + al(R * m.E * 4) + al((size_t)n_sess * 4);
-  b += 2 * al((size_t)n_sess * m.HT * 4) + al((size_t)n_sess * 2 * m.H * 4) + al((size_t)n_sess * m.H * 4) + al((size_t)m.nl * n_sess * m.H * 4);
-  return b + al(R * m.E * 2);   // + the embedded rows
+  return 2 * al(R * m.E * 2) + al(R * m.E * 4) + al((size_t)n_sess * 4) + 2 * al((size_t)n_sess * m.HT * 4) +
+         al((size_t)m.nl * n_sess * 5 * m.H * 4);
 }
 
-hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
-                          hipStream_t st) {
+// training keeps everything the backward pass needs: L+1 states and one record per (step, layer)
+size_t low_gru_save_floats(const ModelDev& m, int64_t n_sess, int L) {
+  return (size_t)(L + 1) * n_sess * m.HT + (size_t)L * m.nl * n_sess * 5 * m.H;
+}
+
+hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden,
+                               const LowGruBufs& b, hipStream_t st) {
   if (n_sess <= 0) return hipSuccess;
   const int E = m.E, H = m.H, HT = m.HT;
   const int64_t R = n_sess * L;
-  unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
-  auto take = [&](size_t bytes) { unsigned char* p = w; w += (bytes + 255) & ~(size_t)255; return p; };
-  uint16_t* a_emb = reinterpret_cast<uint16_t*>(take((size_t)R * E * 2));
-  uint16_t* u16 = reinterpret_cast<uint16_t*>(take((size_t)R * E * 2));
-  float* uf = reinterpret_cast<float*>(take((size_t)R * E * 4));
-  int32_t* seq_len = reinterpret_cast<int32_t*>(take((size_t)n_sess * 4));
-  float* state[2] = {reinterpret_cast<float*>(take((size_t)n_sess * HT * 4)), reinterpret_cast<float*>(take((size_t)n_sess * HT * 4))};
-  float* gates = reinterpret_cast<float*>(take((size_t)n_sess * 2 * H * 4));
-  float* rh = reinterpret_cast<float*>(take((size_t)n_sess * H * 4));
-  float* hcur = reinterpret_cast<float*>(take((size_t)m.nl * n_sess * H * 4));
+  const size_t cell = (size_t)n_sess * 5 * H;   // gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
   hipError_t e;
-  if ((e = launch_embed_rows(m, x, R, a_emb, st)) != hipSuccess) return e;
+  if ((e = launch_embed_rows(m, x, R, b.a_emb, st)) != hipSuccess) return e;
   {  // 'emb' projection of [e, state] (model_gru.py:46), rounded to the 16-bit storage type like the TCN's input
     LayerArgs a = {};
-    a.in = a_emb; a.out = u16; a.W = m.projT; a.seq_init = sproj;
+    a.in = b.a_emb; a.out = b.u16; a.W = m.projT; a.seq_init = sproj;
     a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
     if ((e = launch_tcn_layer(a, st)) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, u16, n_sess, L, E, uf, seq_len);
+  hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
   if ((e = hipGetLastError()) != hipSuccess) return e;
-  if ((e = hipMemsetAsync(state[0], 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state (model_gru.py:52: initial_state=None)
-  int cur = 0;
+  if ((e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state (model_gru.py:52: initial_state=None)
   for (int t = 0; t < L; t++) {
+    const float* s_old = b.states + (size_t)(t % b.n_states) * n_sess * HT;
+    float* s_new = b.states + (size_t)((t + 1) % b.n_states) * n_sess * HT;
     for (int l = 0; l < m.nl; l++) {
+      float* rec = b.rec + (b.keep_all ? ((size_t)t * m.nl + l) : (size_t)l) * cell;
+      const float* below = (l == 0) ? nullptr : b.rec + (b.keep_all ? ((size_t)t * m.nl + l - 1) : (size_t)(l - 1)) * cell + (size_t)n_sess * 4 * H;
       GemmArgs g;
       memset(&g, 0, sizeof(g));
-      const float* in = (l == 0) ? uf + (size_t)t * E : hcur + (size_t)(l - 1) * n_sess * H;
+      const float* in = (l == 0) ? b.uf + (size_t)t * E : below;
       const int ldin = (l == 0) ? L * E : H;
       const int in_dim = (l == 0) ? E : H;
-      const float* hold = state[cur] + (size_t)l * H;
+      const float* hold = s_old + (size_t)l * H;
+      float* gates = rec;
+      float* rh = rec + (size_t)n_sess * 2 * H;
       g.M = (int)n_sess; g.H = H;
       g.A1 = in; g.lda1 = ldin; g.K1 = in_dim;
       g.A2 = hold; g.lda2 = HT; g.K2 = H;
@@ -393,14 +392,32 @@ hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* spro
       if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
       g.A2 = rh; g.lda2 = H;
       g.Wt = m.lgru_wc[l]; g.bias = m.lgru_bc[l]; g.N = H;
-      g.out = hcur + (size_t)l * n_sess * H; g.ldo = H;
-      g.out2 = state[cur ^ 1] + (size_t)l * H; g.ldo2 = HT;
+      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
+      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
+      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
       g.gates = gates; g.ldg = 2 * H;
-      g.seq_len = seq_len; g.tstep = t;
+      g.seq_len = b.seq_len; g.tstep = t;
       if (l == m.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
       if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
     }
-    cur ^= 1;
   }
   return hipSuccess;
+}
+
+hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
+                          hipStream_t st) {
+  if (n_sess <= 0) return hipSuccess;
+  const int64_t R = n_sess * L;
+  unsigned char* w = reinterpret_cast<unsigned char*>(workspace);
+  auto take = [&](size_t bytes) { unsigned char* p = w; w += (bytes + 255) & ~(size_t)255; return p; };
+  LowGruBufs b;
+  b.a_emb = reinterpret_cast<uint16_t*>(take((size_t)R * m.E * 2));
+  b.u16 = reinterpret_cast<uint16_t*>(take((size_t)R * m.E * 2));
+  b.uf = reinterpret_cast<float*>(take((size_t)R * m.E * 4));
+  b.seq_len = reinterpret_cast<int32_t*>(take((size_t)n_sess * 4));
+  b.states = reinterpret_cast<float*>(take(2 * (((size_t)n_sess * m.HT * 4 + 255) & ~(size_t)255)));
+  b.n_states = 2;
+  b.rec = reinterpret_cast<float*>(take((size_t)m.nl * n_sess * 5 * m.H * 4));
+  b.keep_all = 0;
+  return launch_low_gru_bufs(m, x, sproj, n_sess, L, hidden, b, st);
 }

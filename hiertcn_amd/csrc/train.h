@@ -15,6 +15,7 @@ struct TrainCtx {
   TrainSeg emb, emb_bias, projT, projS, outT, out_bias;
   TrainSeg convT[HIERTCN_MAX_BLOCKS], conv_bias[HIERTCN_MAX_BLOCKS], resT[HIERTCN_MAX_BLOCKS], res_bias[HIERTCN_MAX_BLOCKS];
   TrainSeg wg[HIERTCN_MAX_LAYERS], bg[HIERTCN_MAX_LAYERS], wc[HIERTCN_MAX_LAYERS], bc[HIERTCN_MAX_LAYERS];
+  TrainSeg lwg[HIERTCN_MAX_LAYERS], lbg[HIERTCN_MAX_LAYERS], lwc[HIERTCN_MAX_LAYERS], lbc[HIERTCN_MAX_LAYERS];   // HierGRU low level
   void* blas = nullptr;  // rocblas_handle
   int64_t step = 0;      // Adam time step t
   float* master() const { return arena; }

@@ -58,7 +58,7 @@ size_t train_layout(const ModelDev& m, TrainCtx& t) {
     seg(t.projT, (size_t)m.E * m.E);
     seg(t.projS, (size_t)m.E * m.HT);
   }
-  for (int i = 0, cin = m.E; i < m.n_blocks; cin = m.C[i], i++) {
+  for (int i = 0, cin = m.E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
     seg(t.convT[i], (size_t)m.K * m.C[i] * cin);
     seg(t.conv_bias[i], (size_t)m.C[i]);
     if (cin != m.C[i]) {
@@ -72,6 +72,13 @@ size_t train_layout(const ModelDev& m, TrainCtx& t) {
     seg(t.bg[l], (size_t)2 * m.H);
     seg(t.wc[l], (size_t)(in + m.H) * m.H);
     seg(t.bc[l], (size_t)m.H);
+  }
+  for (int l = 0; l < m.nl && m.low_gru; l++) {
+    const int in = (l == 0) ? m.E : m.H;
+    seg(t.lwg[l], (size_t)(in + m.H) * 2 * m.H);
+    seg(t.lbg[l], (size_t)2 * m.H);
+    seg(t.lwc[l], (size_t)(in + m.H) * m.H);
+    seg(t.lbc[l], (size_t)m.H);
   }
   t.total = off;
   return off;
@@ -97,13 +104,17 @@ hipError_t train_enable(ModelDev& m, TrainCtx& t) {
     m.emb_bias = M + t.emb_bias.off;
     m.projS = M + t.projS.off;
   }
-  for (int i = 0; i < m.n_blocks; i++) {
+  for (int i = 0; i < m.n_blocks && !m.low_gru; i++) {
     m.conv_bias[i] = M + t.conv_bias[i].off;
     if (t.resT[i].n) m.res_bias[i] = M + t.res_bias[i].off;
   }
   for (int l = 0; l < m.nl; l++) {
     m.gru_wg[l] = M + t.wg[l].off; m.gru_bg[l] = M + t.bg[l].off;
     m.gru_wc[l] = M + t.wc[l].off; m.gru_bc[l] = M + t.bc[l].off;
+    if (m.low_gru) {
+      m.lgru_wg[l] = M + t.lwg[l].off; m.lgru_bg[l] = M + t.lbg[l].off;
+      m.lgru_wc[l] = M + t.lwc[l].off; m.lgru_bc[l] = M + t.lbc[l].off;
+    }
   }
   t.enabled = true;
   t.step = 0;
@@ -143,7 +154,7 @@ hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t 
   if ((e = cast_bf16(M + t.emb.off, m.emb, (int64_t)t.emb.n, m.E, st)) != hipSuccess) return e;  // row 0 = null id -> zeros (model.py:59)
   if ((e = cast_bf16(M + t.outT.off, m.outT, (int64_t)t.outT.n, 0, st)) != hipSuccess) return e;
   if (m.hier && (e = cast_bf16(M + t.projT.off, m.projT, (int64_t)t.projT.n, 0, st)) != hipSuccess) return e;
-  for (int i = 0; i < m.n_blocks; i++) {
+  for (int i = 0; i < m.n_blocks && !m.low_gru; i++) {
     if ((e = cast_bf16(M + t.convT[i].off, m.convT[i], (int64_t)t.convT[i].n, 0, st)) != hipSuccess) return e;
     if (t.resT[i].n && (e = cast_bf16(M + t.resT[i].off, m.resT[i], (int64_t)t.resT[i].n, 0, st)) != hipSuccess) return e;
   }
@@ -158,7 +169,7 @@ hipError_t train_fill_masters(const ModelDev& m, TrainCtx& t, const hiertcn_weig
   if ((e = hipMemsetAsync(M + t.outT.off, 0, t.outT.n * sizeof(float), st)) != hipSuccess) return e;
   if ((e = launch_transpose_f32(w->out_kernel, M + t.outT.off, m.Clast, m.N, st)) != hipSuccess) return e;  // [C][N] -> [N][C]
   if (m.hier && (e = launch_transpose_f32(w->proj_kernel, M + t.projT.off, E, E, st)) != hipSuccess) return e;  // rows [0,E) -> [Eout][Ein]
-  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+  for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
     const int cout = m.C[i];
     for (int j = 0; j < m.K; j++)
       if ((e = launch_transpose_f32(w->conv_kernel[i] + (size_t)j * cin * cout, M + t.convT[i].off + (size_t)j * cin * cout, cin, cout, st)) !=
@@ -399,6 +410,35 @@ __global__ void k_gru_bwd_c(const float* __restrict__ dcat_c, const float* __res
   if (k < in) dst_in[b * ldi + k] = dcat_c[b * K + k] + dcat_g[b * K + k];
   if (k < H) dst_h[b * ldo + k] = dhpart[b * H + k] + dcat_g[b * K + in + k];
 }
+// HierGRU low level under dynamic_rnn (model_gru.py:47-53): a row past its sequence_length neither produced an output nor moved
+// its state at this step -- no gradient enters the cell (d = 0) and the carried state gradient passes through unchanged.
+__global__ void k_lgru_bwd_a(const float* __restrict__ dcar, int ldd, const float* __restrict__ dout, int64_t ld_dout,
+                             const int32_t* __restrict__ seq_len, int tstep, const float* __restrict__ h, int ldh,
+                             const float* __restrict__ gates, const float* __restrict__ cand, int M, int H, float* __restrict__ dac,
+                             float* __restrict__ dag, float* __restrict__ dhpart) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * H) return;
+  const int64_t b = i / H;
+  const int k = (int)(i - b * H);
+  const bool active = tstep < seq_len[b];
+  const float d = active ? dcar[b * ldd + k] + dout[b * ld_dout + k] : 0.f;
+  const float u = gates[b * 2 * H + H + k], c = cand[i], hv = h[b * ldh + k];
+  dac[i] = d * (1.f - u) * (1.f - c * c);
+  dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  dhpart[i] = d * u;
+}
+__global__ void k_lgru_bwd_c(const float* __restrict__ dcat_c, const float* __restrict__ dcat_g, int K, int in, const float* __restrict__ dhpart,
+                             int M, int H, float* __restrict__ dst_in, int64_t ldi, float* __restrict__ dst_h, int ldo,
+                             const float* __restrict__ dcar, const int32_t* __restrict__ seq_len, int tstep) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int W = in > H ? in : H;
+  if (i >= (int64_t)M * W) return;
+  const int64_t b = i / W;
+  const int k = (int)(i - b * W);
+  const bool active = tstep < seq_len[b];
+  if (k < in) dst_in[b * ldi + k] = dcat_c[b * K + k] + dcat_g[b * K + k];   // zero for an inactive row (its dac / dag rows are zero)
+  if (k < H) dst_h[b * ldo + k] = active ? dhpart[b * H + k] + dcat_g[b * K + in + k] : dcar[b * ldo + k];
+}
 // grad of the unmasked cell outputs of slot s: (carried + state-projection path) * mask  (model_hier.py:93)
 __global__ void k_gru_out_grad(const float* __restrict__ carried, const float* __restrict__ dsb, int64_t ld_dsb, const float* __restrict__ mask,
                                int ldm, int B, int HT, float* __restrict__ out) {
@@ -450,7 +490,7 @@ hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weig
   if ((e = cp(d->emb_kernel, t.emb, t.emb.n)) != hipSuccess) return e;
   if ((e = tr(d->out_kernel, A + t.outT.off, m.N, m.Clast)) != hipSuccess) return e;   // [N][C] -> [C][N]
   if ((e = cp(d->out_bias, t.out_bias, (size_t)m.N)) != hipSuccess) return e;
-  for (int i = 0, cin = E; i < m.n_blocks; cin = m.C[i], i++) {
+  for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
     const int cout = m.C[i];
     for (int j = 0; j < m.K; j++)
       if (d->conv_kernel[i] &&
@@ -474,6 +514,12 @@ hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weig
       if ((e = cp(d->gru_gate_bias[l], t.bg[l], (size_t)2 * H)) != hipSuccess) return e;
       if ((e = tr(d->gru_cand_kernel[l], A + t.wc[l].off, H, K)) != hipSuccess) return e;
       if ((e = cp(d->gru_cand_bias[l], t.bc[l], (size_t)H)) != hipSuccess) return e;
+      if (m.low_gru) {
+        if ((e = tr(d->low_gate_kernel[l], A + t.lwg[l].off, 2 * H, K)) != hipSuccess) return e;
+        if ((e = cp(d->low_gate_bias[l], t.lbg[l], (size_t)2 * H)) != hipSuccess) return e;
+        if ((e = tr(d->low_cand_kernel[l], A + t.lwc[l].off, H, K)) != hipSuccess) return e;
+        if ((e = cp(d->low_cand_bias[l], t.lbc[l], (size_t)H)) != hipSuccess) return e;
+      }
     }
   }
   return hipSuccess;
@@ -486,6 +532,7 @@ struct TrainWs {
   size_t pooled, sproj, gru_ws, gru_save, act[2 * HIERTCN_MAX_BLOCKS + 2], rank, ce, tgt, lse, w, lane_act, users;
   size_t dA, dB, dsf, dcb, shb, dub, gchunk, map, nvalid, cscratch, hc, yc, wc, lc, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
   size_t total;
+  size_t lg_uf, lg_len, lg_save, lg_dcar[2], lg_dac, lg_dag, lg_dhpart, lg_dcat_c, lg_dcat_g, lg_din_up;   // HierGRU low level
   size_t rb;      // ln w - lse per compact row (+ one padding stage of -inf), k_dlogits
   int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
   int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
@@ -555,6 +602,14 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.dac = take((size_t)B * H * 4); w.dag = take((size_t)B * 2 * H * 4); w.dhpart = take((size_t)B * H * 4);
   const size_t Kmax = (E > H ? E : H) + H;
   w.dcat_c = take((size_t)B * Kmax * 4); w.dcat_g = take((size_t)B * Kmax * 4); w.din_up = take((size_t)B * H * 4);
+  if (m.low_gru) {
+    const size_t M = (size_t)B * S;
+    w.lg_uf = take(R * E * 4); w.lg_len = take(M * 4);
+    w.lg_save = take(low_gru_save_floats(m, (int64_t)M, L) * 4);
+    w.lg_dcar[0] = take(M * HT * 4); w.lg_dcar[1] = take(M * HT * 4);
+    w.lg_dac = take(M * H * 4); w.lg_dag = take(M * 2 * H * 4); w.lg_dhpart = take(M * H * 4);
+    w.lg_dcat_c = take(M * Kmax * 4); w.lg_dcat_g = take(M * Kmax * 4); w.lg_din_up = take(M * H * 4);
+  }
   w.total = off;
   return w;
 }
@@ -602,17 +657,27 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   float* gsave = F32(w.gru_save);
   uint16_t* a_emb = BF(w.act[0]);
   uint16_t* a0 = m.hier ? BF(w.act[1]) : a_emb;   // input of block 0: the projection's output, or the embedded ids themselves
-  T_HIP(launch_embed_rows(m, x, R, a_emb, st));
+  if (!m.low_gru) T_HIP(launch_embed_rows(m, x, R, a_emb, st));
   if (m.hier) {
     T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
-    LayerArgs a = {};
-    a.in = a_emb; a.out = a0; a.W = m.projT; a.seq_init = sproj;
-    a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
-    T_HIP(launch_tcn_layer(a, st));
+    if (!m.low_gru) {
+      LayerArgs a = {};
+      a.in = a_emb; a.out = a0; a.W = m.projT; a.seq_init = sproj;
+      a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
+      T_HIP(launch_tcn_layer(a, st));
+    }
+  }
+  LowGruBufs lb;
+  memset(&lb, 0, sizeof(lb));
+  if (m.low_gru) {   // HierGRU: embedding + projection + the GRU stack over the L steps, every state and gate kept (model_gru.py:46-55)
+    lb.a_emb = a_emb; lb.u16 = a0; lb.uf = F32(w.lg_uf); lb.seq_len = reinterpret_cast<int32_t*>(ws + w.lg_len);
+    lb.states = F32(w.lg_save); lb.n_states = L + 1;
+    lb.rec = lb.states + (size_t)(L + 1) * n_sess * HT; lb.keep_all = 1;
+    T_HIP(launch_low_gru_bufs(m, x, sproj, n_sess, L, BF(w.act[2]), lb, st));
   }
   auto a_of = [&](int k) -> uint16_t* { return k == 0 ? a0 : BF(w.act[1 + 2 * k]); };   // a^k: output of block k-1
-  for (int i = 0, cin = E; i < nb; cin = m.C[i], i++) {
+  for (int i = 0, cin = E; i < nb && !m.low_gru; cin = m.C[i], i++) {
     LayerArgs a = {};
     a.in = a_of(i);
     a.c_out = BF(w.act[2 + 2 * i]);
@@ -621,7 +686,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     a.Cin = cin; a.Cout = m.C[i]; a.taps = m.K; a.dil = 1 << i; a.L = L; a.n_seq = n_sess; a.linear = 0;
     T_HIP(launch_tcn_layer(a, st));
   }
-  const uint16_t* hidden = a_of(nb);
+  const uint16_t* hidden = m.low_gru ? BF(w.act[2]) : a_of(nb);
   hiertcn_score_out_t so;
   memset(&so, 0, sizeof(so));
   so.rank = reinterpret_cast<int32_t*>(ws + w.rank); so.ce = F32(w.ce); so.target = F32(w.tgt);
@@ -701,7 +766,61 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   uint16_t* dcb = BF(w.dcb);
   uint16_t* shb = BF(w.shb);
   uint16_t* dub = BF(w.dub);
-  for (int i = nb - 1; i >= 0; i--) {
+  if (m.low_gru) {
+    // ============ HierGRU low level: BPTT over the L steps of every session (model_gru.py:47-55), last step first ============
+    const int M = (int)n_sess;
+    const float* lst = lb.states;
+    const float* lrec = lb.rec;
+    const size_t lcell = (size_t)n_sess * 5 * H;
+    float* du = dsf;                       // d u [R][E]: grad of the projected [e, state] rows
+    float* lcar = F32(w.lg_dcar[0]);
+    float* lnext = F32(w.lg_dcar[1]);
+    T_HIP(hipMemsetAsync(lcar, 0, (size_t)M * HT * 4, st));   // the low level's final state is dropped (model_gru.py:47)
+    float* dac = F32(w.lg_dac);
+    float* dag = F32(w.lg_dag);
+    float* dhpart = F32(w.lg_dhpart);
+    float* dcat_c = F32(w.lg_dcat_c);
+    float* dcat_g = F32(w.lg_dcat_g);
+    float* din_up = F32(w.lg_din_up);
+    const unsigned gMH = (unsigned)(((int64_t)M * H + 255) / 256);
+    for (int tt = L - 1; tt >= 0; tt--) {
+      for (int l = m.nl - 1; l >= 0; l--) {
+        const int in = (l == 0) ? E : H;
+        const int K = in + H;
+        const float* rec = lrec + ((size_t)tt * m.nl + l) * lcell;
+        const float* gates = rec;
+        const float* rh = rec + (size_t)M * 2 * H;
+        const float* cand = rec + (size_t)M * 3 * H;
+        const float* hold = lst + (size_t)tt * n_sess * HT + (size_t)l * H;   // row stride HT
+        const float* inp = (l == 0) ? lb.uf + (size_t)tt * E : lrec + ((size_t)tt * m.nl + l - 1) * lcell + (size_t)M * 4 * H;
+        const int ldin = (l == 0) ? L * E : H;
+        const float* dout = (l == m.nl - 1) ? dH + (size_t)tt * H : din_up;
+        const int64_t ld_dout = (l == m.nl - 1) ? (int64_t)L * H : H;
+        hipLaunchKernelGGL(k_lgru_bwd_a, dim3(gMH), dim3(256), 0, st, lcar + (size_t)l * H, HT, dout, ld_dout, lb.seq_len, tt, hold, HT, gates, cand,
+                           M, H, dac, dag, dhpart);
+        T_HIP(hipGetLastError());
+        T_BLAS(gemm_f32(bl, OPN, OPN, K, M, H, m.lgru_wc[l], K, dac, H, 0.f, dcat_c, K));
+        T_BLAS(gemm_f32(bl, OPN, OPT, in, H, M, inp, ldin, dac, H, 1.f, G + t.lwc[l].off, K));
+        T_BLAS(gemm_f32(bl, OPN, OPT, H, H, M, rh, H, dac, H, 1.f, G + t.lwc[l].off + in, K));
+        T_HIP(colsum_f32(dac, M, H, H, G + t.lbc[l].off, st));
+        hipLaunchKernelGGL(k_gru_bwd_b, dim3(gMH), dim3(256), 0, st, dcat_c, K, in, hold, HT, gates, M, H, dag, dhpart);
+        T_HIP(hipGetLastError());
+        T_BLAS(gemm_f32(bl, OPN, OPN, K, M, 2 * H, m.lgru_wg[l], K, dag, 2 * H, 0.f, dcat_g, K));
+        T_BLAS(gemm_f32(bl, OPN, OPT, in, 2 * H, M, inp, ldin, dag, 2 * H, 1.f, G + t.lwg[l].off, K));
+        T_BLAS(gemm_f32(bl, OPN, OPT, H, 2 * H, M, hold, HT, dag, 2 * H, 1.f, G + t.lwg[l].off + in, K));
+        T_HIP(colsum_f32(dag, M, 2 * H, 2 * H, G + t.lbg[l].off, st));
+        float* dst_in = (l == 0) ? du + (size_t)tt * E : din_up;
+        const int64_t ldi = (l == 0) ? (int64_t)L * E : H;
+        const int Wd = in > H ? in : H;
+        hipLaunchKernelGGL(k_lgru_bwd_c, dim3((unsigned)(((int64_t)M * Wd + 255) / 256)), dim3(256), 0, st, dcat_c, dcat_g, K, in, dhpart, M, H,
+                           dst_in, ldi, lnext + (size_t)l * H, HT, lcar + (size_t)l * H, lb.seq_len, tt);
+        T_HIP(hipGetLastError());
+      }
+      float* tmp = lcar; lcar = lnext; lnext = tmp;
+    }
+    da = du;
+  }
+  for (int i = nb - 1; i >= 0 && !m.low_gru; i--) {
     const int cin = (i == 0) ? E : m.C[i - 1], cout = m.C[i];
     const uint16_t* a_in = a_of(i);
     const uint16_t* c_act = BF(w.act[2 + 2 * i]);

@@ -381,12 +381,12 @@ class Engine:
         shapes = param_shapes(self._args_for_shapes, kind)
         bufs = {k: torch.zeros(v, dtype=torch.float32, device=self.device) for k, v in shapes.items()}
         w = _lib.Weights()
-        tcn = "hier/tcn" if self.hier else "tcn"
+        tcn = ("hier/gru" if self.low_gru else "hier/tcn") if self.hier else "tcn"
         g = lambda k: bufs[k].data_ptr()  # noqa: E731
         w.emb_kernel = g(f"{kind}/emb/kernel")
         if self.hier:
-            w.emb_bias, w.proj_kernel = g("hier/emb/bias"), g("hier/tcn/emb/kernel")
-        for i in range(self.cfg.n_blocks):
+            w.emb_bias, w.proj_kernel = g("hier/emb/bias"), g(f"{tcn}/emb/kernel")
+        for i in range(0 if self.low_gru else self.cfg.n_blocks):
             pre = f"{tcn}/temporal_conv_net/tblock_{i}"
             w.conv_kernel[i], w.conv_bias[i] = g(f"{pre}/conv1/kernel"), g(f"{pre}/conv1/bias")
             if f"{pre}/dense/kernel" in bufs:
@@ -396,6 +396,10 @@ class Engine:
             pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
             w.gru_gate_kernel[l], w.gru_gate_bias[l] = g(f"{pre}/gates/kernel"), g(f"{pre}/gates/bias")
             w.gru_cand_kernel[l], w.gru_cand_bias[l] = g(f"{pre}/candidate/kernel"), g(f"{pre}/candidate/bias")
+            if self.low_gru:
+                lo = f"{tcn}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+                w.low_gate_kernel[l], w.low_gate_bias[l] = g(f"{lo}/gates/kernel"), g(f"{lo}/gates/bias")
+                w.low_cand_kernel[l], w.low_cand_bias[l] = g(f"{lo}/candidate/kernel"), g(f"{lo}/candidate/bias")
         self._ck(self.lib.hiertcn_export_weights(self._h, C.byref(w), 0 if which == "weights" else 1, self._stream()))
         torch.cuda.current_stream().synchronize()
         return {(root + k[len(kind):] if k.startswith(kind) else k): v.cpu().numpy() for k, v in bufs.items()}

@@ -97,10 +97,8 @@ def test_hiergru_forward_eval_matches_oracle(setup):
         assert abs(m[k] - ref[k]) < 2e-2, (k, m[k], ref[k])
 
 
-def test_hiergru_model_hier_surface_and_training_refusal(setup):
-    """model_hier(args, ...) with the reference's default model_low_type goes through the same surface; training of
-    the GRU low level is not built and must say so instead of silently training something else."""
-    from hiertcn_amd.engine import Engine, HierTCNError
+def test_hiergru_model_hier_surface(setup):
+    """model_hier(args, ...) with the reference's default model_low_type goes through the same surface."""
     from hiertcn_amd.model import HierTCNModel
     s = setup
     model = HierTCNModel(s["args"], params=s["p"])
@@ -110,5 +108,101 @@ def test_hiergru_model_hier_surface_and_training_refusal(setup):
     ref = O.masked_loss_and_metrics(predm, s["y"].reshape(s["B"], -1), s["N"])
     assert abs(r["loss"] - ref["loss"]) < 1e-3
     assert np.abs(np.asarray(r["state"]) - st).max() < 1e-5
-    with pytest.raises(HierTCNError):
-        Engine(s["args"], hier=True, train=True)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training step of HierGRU against autograd (same contract as tests/test_gpu_train.py)
+# ---------------------------------------------------------------------------------------------------------------------
+def torch_loss_gru(args, P, x, y, mask, state):
+    """model_hier.py:39-93 with the model_gru.py:16-63 low level + model.py:102-117, on torch fp64 tensors; activations are
+    rounded (straight-through) where the device rounds them: the projected rows and the GRU outputs fed to scoring."""
+    import torch.nn.functional as F
+    from tests.test_gpu_train import ste_bf16
+    B, S, L = x.shape
+    H, nl, N = args.hidden_dim, args.num_layer, args.item_num
+    st = torch.as_tensor(state, dtype=torch.float64)
+    E = P["hier/emb/kernel"]
+    xt, yt = torch.as_tensor(x, dtype=torch.int64), torch.as_tensor(y, dtype=torch.int64)
+    mk = torch.as_tensor(mask, dtype=torch.float64)
+
+    def cell(scope, l, cur, h):
+        pre = f"{scope}/multi_rnn_cell/cell_{l}/gru_cell"
+        g = torch.sigmoid(torch.cat([cur, h], 1) @ P[f"{pre}/gates/kernel"] + P[f"{pre}/gates/bias"])
+        r, uu = g.chunk(2, 1)
+        c = torch.tanh(torch.cat([cur, r * h], 1) @ P[f"{pre}/candidate/kernel"] + P[f"{pre}/candidate/bias"])
+        return uu * h + (1 - uu) * c
+
+    logits = []
+    for s in range(S):
+        e = F.embedding(xt[:, s], E) * (xt[:, s] > 0)[..., None]
+        u = ste_bf16(torch.cat([e, st[:, None, :].expand(-1, L, -1)], -1) @ P["hier/gru/emb/kernel"])
+        length = (u.detach().abs().amax(2) > 0).sum(1)          # model_gru.py:109-118: a count, used as a prefix length
+        hs = torch.zeros((B, H * nl), dtype=torch.float64)
+        outs = []
+        for t in range(L):
+            active = (t < length)[:, None]
+            cur, new = u[:, t], []
+            for l in range(nl):
+                cur = cell("hier/gru/rnn", l, cur, hs[:, l * H:(l + 1) * H])
+                new.append(cur)
+            hs = torch.where(active, torch.cat(new, 1), hs)
+            outs.append(torch.where(active, cur, torch.zeros_like(cur)))
+        a = ste_bf16(torch.stack(outs, 1))
+        logits.append(a @ P["hier/gru/dense/kernel"] + P["hier/gru/dense/bias"])
+        ey = F.embedding(yt[:, s], E) * (yt[:, s] > 0)[..., None]
+        cur = ey.sum(1) / (yt[:, s] > 0).sum(1, keepdim=True) + P["hier/emb/bias"]
+        new = []
+        for l in range(nl):
+            cur = cell("hier", l, cur, st[:, l * H:(l + 1) * H])
+            new.append(cur)
+        st = torch.cat(new, 1) * mk[:, s:s + 1]
+    z = torch.cat(logits, 1)
+    yy = yt.reshape(B, S * L)
+    m = (yy > 0).double()
+    z = z * m[..., None]
+    ce = F.cross_entropy(z.reshape(-1, N), yy.reshape(-1), reduction="none").reshape(B, -1) * m
+    act = m.sum(1)
+    users = (act > 0).double().sum()
+    return ((ce.sum(1) / (act + 1e-6)).sum() / users), st
+
+
+@pytest.mark.parametrize("d,H,N,nl", [(64, 64, 700, 2), (128, 64, 1500, 1)])
+def test_hiergru_training_step_matches_autograd(d, H, N, nl):
+    from hiertcn_amd.engine import Engine, metrics_dict
+    args = gru_args(N=N, d=d, H=H, nl=nl)
+    p = make_params(args)
+    eng = Engine(args, hier=True, train=True)
+    eng.set_weights(p)
+    rng = np.random.default_rng(d + 7)
+    B, S, L = 6, 3, 8
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, H * nl))).astype(np.float32)
+    st0[:2] = 0.0
+    out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    grads = eng.export("grads")
+    loss = metrics_dict(out["metrics8"])["loss"]
+    pr = O.round_params_bf16(p, E=d)
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in pr.items()}
+    ref_loss, ref_state = torch_loss_gru(args, P, x, y, mask, st0)
+    ref_loss.backward()
+    assert abs(loss - float(ref_loss.detach())) < 2e-3
+    assert np.abs(out["state"].cpu().numpy() - ref_state.detach().numpy()).max() < 1e-3
+    assert set(grads) == set(P)
+    bad, report = [], []
+    for k in sorted(P):
+        g, r = grads[k].astype(np.float64), P[k].grad.numpy()
+        nr = np.linalg.norm(r)
+        rel = np.linalg.norm(g - r) / max(nr, 1e-30)
+        cos = float((g * r).sum() / max(np.linalg.norm(g) * nr, 1e-30))
+        report.append(f"{k}: rel {rel:.3e} cos {cos:.5f} |ref| {nr:.3e}")
+        if nr > 1e-9 and (rel > 3e-2 or cos < 0.999):
+            bad.append(k)
+    assert not bad, "\n".join(report)
+    # three Adam steps on the batch lower its loss, and the masters come back under the reference's variable names
+    l0 = loss
+    for _ in range(3):
+        eng.adam_step(1e-2)
+        out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    assert metrics_dict(out["metrics8"])["loss"] < l0
+    assert set(eng.export("weights")) == set(p)
+    eng.close()
