@@ -191,9 +191,11 @@ np.savez(sys.argv[1], **{k.replace("/", "."): v for k, v in g.items()})
         assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(a), 1e-12), k
 
 
-def test_run_hier_trains_saves_and_restores(tmp_path):
-    """run_hier with args.train on the synthetic XING CSV: epochs 0..2 of 6 batches, lr 1e-2, checkpoint at epoch 2,
-    evaluation at epoch 2; the loss falls, the checkpoint restores into a fresh model that evaluates identically."""
+@pytest.mark.parametrize("low,H", [("tcn", 32), ("gru", 64)])
+def test_run_hier_trains_saves_and_restores(tmp_path, low, H):
+    """run_hier with args.train on the synthetic XING CSV (HierTCN and the reference's default HierGRU): epochs 0..2 of 6
+    batches, lr 1e-2, checkpoint at epoch 2, evaluation at epoch 2; the loss falls, the checkpoint restores into a fresh
+    model that evaluates identically."""
     import os
     from hiertcn_amd import checkpoint
     from hiertcn_amd.args import hier_tcn_args
@@ -203,14 +205,15 @@ def test_run_hier_trains_saves_and_restores(tmp_path):
     from hiertcn_amd.run_hier_xing import evaluate_hier, run_hier
     data = load_xing(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interactions_synth.csv"))
     n_items = int(data[1][:, 1].max()) + 1
-    args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=5,
+    args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=H, num_layer=2, tcn_channel=[64, 64], kernel_size=5,
                          batch_size=4, max_session_num=3, max_activity_len=6)
+    args.model_low_type = low
     args.log_path, args.save_path = str(tmp_path) + "/log/", str(tmp_path) + "/model/"
     args.train, args.validate, args.test, args.save = True, False, True, True
     args.epoch_max, args.epoch_batches_train, args.save_epoch, args.test_epoch, args.learning_rate = 2, 6, 2, 2, 1e-2
     mk = lambda split: Dataloader_hier_model_xing(args, split, data=data)  # noqa: E731
     model = HierTCNModel(args)
-    st0 = np.zeros((4, 64))
+    st0 = np.zeros((4, 2 * H))
     os.makedirs(args.log_path + "before/")
     before, *_ = evaluate_hier(args, mk("test"), st0, model, prefix="before")
     run_hier(args, mk("train"), mk("validate"), mk("test"), sess=model)
@@ -222,7 +225,8 @@ def test_run_hier_trains_saves_and_restores(tmp_path):
     assert [r["step"] for r in tr] == [0, 1, 2] and tr[2]["value"] < tr[0]["value"]
     ck = args.save_path + "2.ckpt"
     params, extra = checkpoint.load(ck, with_extra=True)
-    assert extra["state_np"].shape == (4, 64)
+    assert extra["state_np"].shape == (4, 2 * H)
+    assert ("hier/gru/dense/kernel" in params) == (low == "gru")
     fresh = HierTCNModel(args, params, train=False)
     os.makedirs(args.log_path + "a/")
     os.makedirs(args.log_path + "b/")
