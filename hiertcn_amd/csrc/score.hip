@@ -451,7 +451,9 @@ struct RowState2 {
 // 7: as 5 on pairs of logits with the packed fp32 ops (fma and sum cost half an issue slot per logit) and the count taken
 // from the sign of (t - z) shifted into a bit register (v_pk_add + v_alignbit, popcount once per tile) instead of
 // v_cmp + v_addc; 8: packed sum, compare/add-carry count.
-template <int C, int PMODE = 0>
+// NB = 32-step blocks per wave, NSTG = LDS stages: <2, 3> for C <= 256; <1, 2> for C = 512, where 64 rows of resident B operand
+// would take all 256 VGPRs and three 64 KB stages do not fit the 160 KB of LDS.
+template <int C, int PMODE = 0, int NB = 2, int NSTG = 3>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
                                                               int64_t R, const uint16_t* __restrict__ outT,
                                                               const float* __restrict__ out_bias, int N, int NP,
@@ -467,20 +469,21 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // stands for row row_map[p], workgroups past the count exit at once, and padded steps cost no MFMA at all.
   // Every row's arithmetic is independent of its position, so results are bit-identical to the dense launch.
   const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
-  if ((int64_t)blockIdx.x * SC_THREADS >= Rv) return;
+  static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2), "two pipeline shapes are written out below");
+  if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 stages + 3 x 64 bias floats
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NSTG stages + NSTG x 64 bias floats
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * 64;
+  const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * (32 * NB);
 
-  uint4 hf[2][G::KS];
-  int myy[2];
-  int64_t mysrc[2];
+  uint4 hf[NB][G::KS];
+  int myy[NB];
+  int64_t mysrc[NB];
 #pragma unroll
-  for (int cbk = 0; cbk < 2; cbk++) {
+  for (int cbk = 0; cbk < NB; cbk++) {
     int64_t r = row0 + cbk * 32 + lr;
     const int64_t rp = (r < Rv) ? r : (Rv - 1);
     const int64_t rc = row_map ? (int64_t)row_map[rp] : rp;
@@ -492,9 +495,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     for (int s = 0; s < G::KS; s++) hf[cbk][s] = *reinterpret_cast<const uint4*>(hp + 16 * s);
   }
 
-  RowState2 st[2];
+  RowState2 st[NB];
 #pragma unroll
-  for (int cbk = 0; cbk < 2; cbk++) {  // target logits: same MFMA sequence as the main loop (see file header)
+  for (int cbk = 0; cbk < NB; cbk++) {  // target logits: same MFMA sequence as the main loop (see file header)
     f32x16 acc;
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) {
@@ -529,7 +532,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   const int n_stages = ((stg_hi0 < n_all) ? stg_hi0 : n_all) - stg_lo;   // stages of THIS workgroup (may be <= 0 for a tail part)
   constexpr int PIECES = G::STAGE_BYTES / 1024;
   constexpr int PPW = PIECES / 8;
-  constexpr int BIAS_OFF = 3 * G::STAGE_BYTES;
+  constexpr int BIAS_OFF = NSTG * G::STAGE_BYTES;
   // LDS-DMA issued through inline asm: hipcc then neither drains it (vmcnt(0)) in front of the next ds_read -- it
   // cannot prove that the DMA and the read touch different stages -- nor waits for it at the barrier; the
   // wait is placed by hand, one full iteration after the issue (cdna_hip_programming.md 5.7 'LDS-DMA recipe').
@@ -576,6 +579,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // per-tile pre-pass of the epilogue: running-reference check on the raw logits (rare rescale, T13)
   constexpr bool PIPED = PMODE >= 5;
   constexpr bool PACKED = PMODE >= 7;
+  constexpr int GPV = G::KS > 16 ? G::KS / 16 : 1;   // MFMA gaps per epilogue value
   constexpr int RING = PMODE == 6 ? 4 : 3;  // LDS fragment ring: a ds_read is issued RING-1 MFMAs ahead of its use
   auto pre = [&](const f32x16& v, RowState2& rs) {
     if (PMODE == 1 || PMODE == 2 || PMODE == 4) return;
@@ -718,6 +722,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 #define SC_PHASE(x, CBX, y, CBY, buf_, ib_, do_mfma)                                         \
   do {                                                                                       \
     f32x2 d2_ = {0.f, 0.f};                                                                  \
+    int constexpr_i_ = 0;                                                                    \
     pre(y, st[CBY]);                                                                         \
     if (do_mfma) {                                                                           \
       const unsigned char* tile_ = smem + (buf_) * G::STAGE_BYTES + (ib_) * 32 * (2 * C);    \
@@ -730,7 +735,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
         if (s + RING - 1 < G::KS)                                                            \
           af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + RING - 1) << 5))); \
         x = mfma32(af_[s % RING], hf[CBX][s], x);                                            \
-        if (PACKED) val7(s & 15, y, st[CBY], d2_); else if (PIPED) val5(s & 15, y[s & 15], st[CBY]); else one(y[s & 15], st[CBY]); \
+        if (s % GPV == 0) {   /* KS > 16 (C = 512): one value per GPV gaps */                \
+          constexpr_i_ = s / GPV;                                                            \
+          if (PACKED) val7(constexpr_i_, y, st[CBY], d2_); else if (PIPED) val5(constexpr_i_, y[constexpr_i_], st[CBY]); else one(y[constexpr_i_], st[CBY]); \
+        }                                                                                    \
         __builtin_amdgcn_sched_barrier(0); /* keep exactly this order: hipcc otherwise clusters the MFMAs */ \
       }                                                                                      \
       _Pragma("unroll") for (int s = G::KS; s < 16; s++) { if (PACKED) val7(s, y, st[CBY], d2_); else if (PIPED) val5(s, y[s], st[CBY]); else one(y[s], st[CBY]); } \
@@ -741,36 +749,64 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   } while (0)
 
   f32x16 accA, accB;
-  if (n_stages > 0) stage_issue(0, 0);
-  if (n_stages > 1) stage_issue(1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  if (n_stages > 0) {  // tile (stage 0, ib 0, step block 0) has nothing to overlap with
-    bias_init(accA, 0, 0);
-#pragma unroll
-    for (int s = 0; s < G::KS; s++) {
-      const uint4 a = *reinterpret_cast<const uint4*>(smem + (a_k0 ^ (s << 5)));
-      accA = mfma32(a, hf[0][s], accA);
+  if constexpr (NB == 2) {
+    f32x16 accA, accB;
+    if (n_stages > 0) stage_issue(0, 0);
+    if (n_stages > 1) stage_issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (n_stages > 0) {  // tile (stage 0, ib 0, step block 0) has nothing to overlap with
+      bias_init(accA, 0, 0);
+  #pragma unroll
+      for (int s = 0; s < G::KS; s++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + (a_k0 ^ (s << 5)));
+        accA = mfma32(a, hf[0][s], accA);
+      }
     }
-  }
-  int buf = 0;  // stg % 3
-  for (int stg = 0; stg < n_stages; stg++) {
-    const int buf1 = (buf == 2) ? 0 : buf + 1;
-    const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
-    // buf2 held stage stg-1: its last readers finished before the barrier that ended iteration stg-1
-    if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
-    SC_PHASE(accB, 1, accA, 0, buf, 0, true);                   // MFMA (stg, ib0, cb1)   || epilogue (stg, ib0, cb0)
-    SC_PHASE(accA, 0, accB, 1, buf, 1, true);                   // MFMA (stg, ib1, cb0)   || epilogue (stg, ib0, cb1)
-    SC_PHASE(accB, 1, accA, 0, buf, 1, true);                   // MFMA (stg, ib1, cb1)   || epilogue (stg, ib1, cb0)
-    SC_PHASE(accA, 0, accB, 1, buf1, 0, stg + 1 < n_stages);    // MFMA (stg+1, ib0, cb0) || epilogue (stg, ib1, cb1)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage stg+2 (issued a whole iteration ago)
-    __syncthreads();                                   // ... and everyone else's; buf is free again
-    buf = buf1;
+    int buf = 0;  // stg % 3
+    for (int stg = 0; stg < n_stages; stg++) {
+      const int buf1 = (buf == 2) ? 0 : buf + 1;
+      const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
+      // buf2 held stage stg-1: its last readers finished before the barrier that ended iteration stg-1
+      if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
+      SC_PHASE(accB, 1, accA, 0, buf, 0, true);                   // MFMA (stg, ib0, cb1)   || epilogue (stg, ib0, cb0)
+      SC_PHASE(accA, 0, accB, 1, buf, 1, true);                   // MFMA (stg, ib1, cb0)   || epilogue (stg, ib0, cb1)
+      SC_PHASE(accB, 1, accA, 0, buf, 1, true);                   // MFMA (stg, ib1, cb1)   || epilogue (stg, ib1, cb0)
+      SC_PHASE(accA, 0, accB, 1, buf1, 0, stg + 1 < n_stages);    // MFMA (stg+1, ib0, cb0) || epilogue (stg, ib1, cb1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's pieces of stage stg+2 (issued a whole iteration ago)
+      __syncthreads();                                   // ... and everyone else's; buf is free again
+      buf = buf1;
+    }
+  } else {
+    // One step block per wave, two LDS stages.  Stage stg+1 is needed by the second phase of iteration stg, so the barrier sits
+    // between the two phases: by then every wave has finished reading stage stg (the first phase was its last reader) and has
+    // waited for its own pieces of stage stg+1; the buffer of stage stg is refilled with stage stg+2 right behind the barrier,
+    // a whole iteration (64 MFMAs) before its first use.
+    if (n_stages > 0) stage_issue(0, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (n_stages > 1) stage_issue(1, 1);
+    if (n_stages > 0) {
+      bias_init(accA, 0, 0);
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + (a_k0 ^ (s << 5)));
+        accA = mfma32(a, hf[0][s], accA);
+      }
+    }
+    for (int stg = 0; stg < n_stages; stg++) {
+      const int buf = stg & 1;
+      SC_PHASE(accB, 0, accA, 0, buf, 1, true);                        // MFMA (stg, ib1)   || epilogue (stg, ib0)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (stg + 2 < n_stages) stage_issue(stg + 2, buf);
+      SC_PHASE(accA, 0, accB, 0, buf ^ 1, 0, stg + 1 < n_stages);      // MFMA (stg+1, ib0) || epilogue (stg, ib1)
+    }
   }
 #undef SC_PHASE
 
 #pragma unroll
-  for (int cbk = 0; cbk < 2; cbk++) {
+  for (int cbk = 0; cbk < NB; cbk++) {
     const float s_own = PACKED ? st[cbk].s2.x + st[cbk].s2.y : st[cbk].s;
     const int c_own = st[cbk].c;
     const int64_t myr = row0 + cbk * 32 + lr;
@@ -824,14 +860,14 @@ __global__ void k_score_merge(const float* __restrict__ partials, int parts, int
 
 __device__ int g_walk_pos[8 * 32];
 
-template <int C, int PMODE = 0>
+template <int C, int PMODE = 0, int NB = 2, int NSTG = 3>
 static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
                                     const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
                                     const int32_t* n_rows_dev = nullptr, float* split_scratch = nullptr) {
   using G = ScGeom<C>;
-  const size_t lds = 3 * G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
-  const unsigned blocks = (unsigned)((R + 511) / 512);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const size_t lds = NSTG * G::STAGE_BYTES + NSTG * SC_STAGE * sizeof(float);
+  const unsigned blocks = (unsigned)((R + 256 * NB - 1) / (256 * NB));
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE, NB, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   static int* walk = nullptr;
   static bool walk_init = false;
@@ -843,13 +879,13 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
   if ((PMODE == 5 || PMODE >= 7) && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;
-    hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+    hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                        out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
                        out->target, out->rank, out->ce);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((k_score_pipe<C, PMODE>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+  hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                      out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk);
   return hipGetLastError();
 }
@@ -1017,7 +1053,8 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
       if (logits) return launch_score_512<true, 0, 0>(m, hidden, y, R, nullptr, logits, nullptr, nullptr, 0, -1, st);
       if (out && out->topk > 8) return launch_score_512<false, 0, 16>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
       if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
-      return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
+      if (getenv("HIERTCN_SCORE512_V1")) return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);   // A/B
+      return launch_score_pipe<512, 5, 1, 2>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     default: return hipErrorInvalidValue;
   }
 }

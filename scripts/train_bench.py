@@ -1,5 +1,5 @@
 """Training-step throughput on the cfg-3 synthetic shape (secondary measurement; bench.py's headline is the eval pass).
-usage: python scripts/train_bench.py [users_per_step] [steps] [ragged]"""
+usage: [LOW=gru] python scripts/train_bench.py [users_per_step] [steps] [ragged]     (LOW=gru: HierGRU low level)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -14,6 +14,7 @@ ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
 N, d, S, L = bench.N_ITEMS, bench.DIM, bench.S_SESS, bench.L_STEPS
 args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L,
                      max_session_num=S, batch_size=B)
+args.model_low_type = os.environ.get("LOW", "tcn")
 eng = Engine(args, hier=True, train=True)
 eng.set_weights(init_params(args, seed=2))
 draw = bench.zipf_sampler(N)
@@ -29,5 +30,12 @@ for i in range(steps + 1):
     losses.append(out["metrics8"].clone())
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
+if os.environ.get("EVAL"):
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(steps):
+        eng.forward_eval(xd, yd, md, st0)
+    torch.cuda.synchronize()
+    de = (time.perf_counter() - t0) / steps
+    print("eval step (%s): users %d, %.1f ms/step, %.0f sessions/s" % (args.model_low_type, B, de * 1e3, B * S / de), flush=True)
 print("train step%s: users %d, %.1f ms/step, %.0f sessions/s; loss %s" % (
     " (ragged)" if ragged else "", B, dt * 1e3, B * S / dt, [round(metrics_dict(m)["loss"], 4) for m in losses]), flush=True)
