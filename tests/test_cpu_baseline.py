@@ -21,6 +21,15 @@ def test_product_init_matches_oracle_init():
     assert P.count_params(P.init_params(hier_tcn_args(), seed=0)) == 5_750_698
     t = make_args([], model_type="tcn")
     assert list(P.init_params(t, 0, "tcn")) == list(O.init_params(t, 0, "tcn"))
+    # HierGRU, the reference's default low level (args.py:40): same variable names / shapes / values on both sides, and the
+    # trainable-parameter count of its default graph: E 2,659,584 + b_emb 128 + gru/emb 49,152 + low GRU 197,376 + high GRU
+    # 197,376 + scoring dense 2,680,362
+    g = make_args([], model_type="hier")
+    assert g.model_low_type == "gru"
+    a, b = P.init_params(g, seed=2), O.init_params(g, seed=2)
+    assert sorted(a) == sorted(b) and all(np.array_equal(a[k], b[k]) for k in a)
+    assert P.count_params(a) == 5_783_978
+    assert a["hier/gru/rnn/multi_rnn_cell/cell_1/gru_cell/candidate/kernel"].shape == (256, 128)
 
 
 def test_cpu_baseline_matches_oracle():
