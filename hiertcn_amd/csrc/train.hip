@@ -533,6 +533,7 @@ struct TrainWs {
   size_t dA, dB, dsf, dcb, shb, dub, gchunk, map, nvalid, cscratch, hc, yc, wc, lc, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
   size_t total;
   size_t lg_uf, lg_len, lg_save, lg_dcar[2], lg_dac, lg_dag, lg_dhpart, lg_dcat_c, lg_dcat_g, lg_din_up;   // HierGRU low level
+  size_t splitk;  // partial outputs of the split-K weight-gradient GEMMs
   size_t rb;      // ln w - lse per compact row (+ one padding stage of -inf), k_dlogits
   int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
   int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
@@ -594,6 +595,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.map = take(R * 4); w.nvalid = take(256); w.cscratch = take((R / 1024 + 2) * 4);
   w.hc = take((R + 64) * C * 2); w.yc = take(R * 4); w.wc = take(R * 4); w.lc = take(R * 4);
   w.rb = take((R + 64) * 4);
+  w.splitk = take((size_t)32 * C * C * 4);
   w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
   w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
   w.dpooled = take((size_t)B * S * E * 4);
@@ -623,6 +625,40 @@ static rocblas_status gemm_bf16(rocblas_handle h, rocblas_operation ta, rocblas_
   const float one = 1.f;
   return rocblas_gemm_ex(h, ta, tb, m, n, k, &one, A, HIERTCN_BLAS_16, lda, B, HIERTCN_BLAS_16, ldb, &beta, Cc,
                          rocblas_datatype_f32_r, ldc, Cc, rocblas_datatype_f32_r, ldc, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+}
+// Weight gradients of the conv / projection layers: [Cin x Cout] outputs with K = all rows of the batch.  One such GEMM has
+// 16 output tiles and leaves 240 CUs idle (rocBLAS: MT64x64, 988 us at cfg-3), so K is cut into P slices run as one strided
+// batch into P partial outputs, which k_sum_parts adds up (P * 256 KB of scratch).
+__global__ void k_sum_parts(const float* __restrict__ parts, int P, int64_t n, float* __restrict__ out) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float s = 0.f;
+  for (int p = 0; p < P; p++) s += parts[(int64_t)p * n + i];
+  out[i] = s;
+}
+static int splitk_parts(int64_t k) {
+  for (int p = 32; p > 1; p >>= 1)
+    if (k % p == 0 && k / p >= 2048) return p;
+  return 1;
+}
+// C[m x n] (ldc == m) = A[m x k] . B[n x k]^T, column-major, both operands K-contiguous by column: the (OPN, OPT) weight-gradient form
+static rocblas_status gemm_bf16_wgrad(rocblas_handle h, int m, int n, int k, const void* A, int lda, const void* B, int ldb, float* Cc,
+                                      float* scratch, hipStream_t st) {
+  const int P = scratch ? splitk_parts(k) : 1;
+  const float one = 1.f, zero = 0.f;
+  if (P == 1)
+    return rocblas_gemm_ex(h, rocblas_operation_none, rocblas_operation_transpose, m, n, k, &one, A, HIERTCN_BLAS_16, lda, B, HIERTCN_BLAS_16, ldb,
+                           &zero, Cc, rocblas_datatype_f32_r, m, Cc, rocblas_datatype_f32_r, m, rocblas_datatype_f32_r,
+                           rocblas_gemm_algo_standard, 0, 0);
+  const int kp = k / P;
+  rocblas_status rs = rocblas_gemm_strided_batched_ex(
+      h, rocblas_operation_none, rocblas_operation_transpose, m, n, kp, &one, A, HIERTCN_BLAS_16, lda, (rocblas_stride)kp * lda, B, HIERTCN_BLAS_16,
+      ldb, (rocblas_stride)kp * ldb, &zero, scratch, rocblas_datatype_f32_r, m, (rocblas_stride)m * n, scratch, rocblas_datatype_f32_r, m,
+      (rocblas_stride)m * n, P, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
+  if (rs != rocblas_status_success) return rs;
+  const int64_t nn = (int64_t)m * n;
+  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, scratch, P, nn, Cc);
+  return hipGetLastError() == hipSuccess ? rocblas_status_success : rocblas_status_internal_error;
 }
 static rocblas_status gemm_f32(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* A, int lda,
                                const float* B, int ldb, float beta, float* Cc, int ldc) {
@@ -838,7 +874,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       T_HIP(cast_bf16(dsf, dub, nOut, 0, st));
       T_HIP(colsum_f32(dsf, R, cout, cout, G + t.res_bias[i].off, st));
       // d resT[Cout][Cin] = ds^T[Cout x R] . a_in[R][Cin]   == col-major [Cin x Cout] = a_in^T[Cin x R] . (ds^T)^T
-      T_BLAS(gemm_bf16(bl, OPN, OPT, cin, cout, (int)R, a_in, cin, dub, cout, 0.f, G + t.resT[i].off, cin));
+      T_BLAS(gemm_bf16_wgrad(bl, cin, cout, (int)R, a_in, cin, dub, cout, G + t.resT[i].off, F32(w.splitk), st));
       // d a_in[R][Cin] = ds[R][Cout] . resT[Cout][Cin]   == col-major [Cin x R] = resT(col-major [Cin x Cout]) . ds^T[Cout x R]
       T_BLAS(gemm_bf16(bl, OPN, OPN, cin, (int)R, cout, m.resT[i], cin, dub, cout, 0.f, dprev, cin));
     } else {
@@ -851,7 +887,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       // d W_j^T [Cout][Cin] = dc^T[Cout x R] . Xs[R][Cin], Xs[t] = a_in[t - shift]   == col-major [Cin x Cout] = Xs^T[Cin x R] . (dc^T[Cout x R])^T
       hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (cin / 8) + 255) / 256)), dim3(256), 0, st, a_in, shb, R, L, cin, shift);
       T_HIP(hipGetLastError());
-      T_BLAS(gemm_bf16(bl, OPN, OPT, cin, cout, (int)R, shb, cin, dcb, cout, 0.f, G + t.convT[i].off + (size_t)j * cin * cout, cin));
+      T_BLAS(gemm_bf16_wgrad(bl, cin, cout, (int)R, shb, cin, dcb, cout, G + t.convT[i].off + (size_t)j * cin * cout, F32(w.splitk), st));
       // d a_in[tau] += dc[tau + shift] . W_j^T: rows [R][Cout] . [Cout][Cin]   == col-major [Cin x R] += W_j(col-major [Cin x Cout]) . dcs^T[Cout x R]
       hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (cout / 8) + 255) / 256)), dim3(256), 0, st, dcb, shb, R, L, cout, -shift);
       T_HIP(hipGetLastError());
@@ -873,7 +909,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // ================= projection u = e . Wp[:E] + sproj (model_hier.py:54-55 -> model_tcn.py:35) ============
   T_HIP(cast_bf16(da, dub, nRC, 0, st));
   // d projT[Eout][Ein] = du^T[Eout x R] . e[R][Ein]   == col-major [Ein x Eout] = e^T[Ein x R] . (du^T)^T
-  T_BLAS(gemm_bf16(bl, OPN, OPT, E, E, (int)R, a_emb, E, dub, E, 0.f, G + t.projT.off, E));
+  T_BLAS(gemm_bf16_wgrad(bl, E, E, (int)R, a_emb, E, dub, E, G + t.projT.off, F32(w.splitk), st));
   // d e[R][Ein] = du[R][Eout] . projT[Eout][Ein]   == col-major [Ein x R] = projT(col-major [Ein x Eout]) . du^T[Eout x R]
   T_BLAS(gemm_bf16(bl, OPN, OPN, E, (int)R, E, m.projT, E, dub, E, 0.f, dprev, E));
   hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R * (E / 4) + 255) / 256)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E);
