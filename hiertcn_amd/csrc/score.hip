@@ -577,12 +577,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   const float* sbias = reinterpret_cast<const float*>(smem + BIAS_OFF);
 
   // per-tile pre-pass of the epilogue: running-reference check on the raw logits (rare rescale, T13)
-  constexpr bool PIPED = PMODE >= 5;
-  constexpr bool PACKED = PMODE >= 7;
+  constexpr bool NOLDS = PMODE == 10 || PMODE == 11;   // timing experiments (wrong results): one A fragment per tile instead of one per MFMA
+  constexpr bool PIPED = PMODE >= 5 && PMODE != 10;    // 10: no epilogue either; 11: production epilogue
+  constexpr bool PACKED = PMODE >= 7 && PMODE <= 9;
   constexpr int GPV = G::KS > 16 ? G::KS / 16 : 1;   // MFMA gaps per epilogue value
   constexpr int RING = PMODE == 6 ? 4 : 3;  // LDS fragment ring: a ds_read is issued RING-1 MFMAs ahead of its use
   auto pre = [&](const f32x16& v, RowState2& rs) {
-    if (PMODE == 1 || PMODE == 2 || PMODE == 4) return;
+    if (PMODE == 1 || PMODE == 2 || PMODE == 4 || PMODE == 10) return;
     if (PACKED) {
       rs.ssave = rs.s2.x + rs.s2.y;
       asm volatile("" : "+v"(rs.ssave));
@@ -699,7 +700,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   };
   auto one = [&](float v, RowState2& rs) {
     asm volatile("" : "+v"(v));
-    if (PMODE == 2) return;
+    if (PMODE == 2 || PMODE == 10) return;
     if (PMODE != 1) rs.s += __builtin_amdgcn_exp2f(fmaf(v, LOG2E_F, -rs.m2));
     if (PMODE != 3) rs.c += (v > rs.t) ? 1 : 0;
     asm volatile("" : "+v"(rs.s), "+v"(rs.c));
@@ -732,9 +733,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       bias_init(x, buf_, ib_);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                     \
       _Pragma("unroll") for (int s = 0; s < G::KS; s++) {                                    \
-        if (s + RING - 1 < G::KS)                                                            \
+        if (s + RING - 1 < G::KS && !NOLDS)                                                  \
           af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + RING - 1) << 5))); \
-        x = mfma32(af_[s % RING], hf[CBX][s], x);                                            \
+        x = mfma32(af_[NOLDS ? 0 : s % RING], hf[CBX][s], x);                                \
         if (s % GPV == 0) {   /* KS > 16 (C = 512): one value per GPV gaps */                \
           constexpr_i_ = s / GPV;                                                            \
           if (PACKED) val7(constexpr_i_, y, st[CBY], d2_); else if (PIPED) val5(constexpr_i_, y[constexpr_i_], st[CBY]); else one(y[constexpr_i_], st[CBY]); \
@@ -971,6 +972,8 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   if (pvar && pvar[0] == '7') return launch_score_pipe<C, 7>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (pvar && pvar[0] == '8') return launch_score_pipe<C, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (pvar && pvar[0] == '9') return launch_score_pipe<C, 9>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (C == 256 && pvar && pvar[0] == 'a') return launch_score_pipe<256, 10>(m, hidden, y, R, out, st);
+  if (C == 256 && pvar && pvar[0] == 'b') return launch_score_pipe<256, 11>(m, hidden, y, R, out, st);
   if (C == 256 && pvar && pvar[0]) {
     switch (pvar[0]) {
       case '1': return launch_score_pipe<256, 1>(m, hidden, y, R, out, st);
