@@ -453,7 +453,13 @@ struct RowState2 {
 // v_cmp + v_addc; 8: packed sum, compare/add-carry count.
 // NB = 32-step blocks per wave, NSTG = LDS stages: <2, 3> for C <= 256; <1, 2> for C = 512, where 64 rows of resident B operand
 // would take all 256 VGPRs and three 64 KB stages do not fit the 160 KB of LDS.
-template <int C, int PMODE = 0, int NB = 2, int NSTG = 3>
+// PAD (C >= 256): the LDS image of a stage is padded per 1 KB LDS-DMA piece instead of XOR-swizzled per row, so that the A fragment of
+// k-step s sits at (lane base + 32 s) -- an immediate offset -- instead of (lane base ^ 32 s): one address register instead of sixteen.
+// C = 256: a piece holds two rows; pitch 1024 + 32 and chunk' = chunk ^ (row & 1) put row r of a 16-lane read group in bank group
+// r mod 16.  C = 512: one row per piece, pitch 1024 + 16.
+// FIXUP: launched behind a DUAL kernel (which has no room for the overflow redo): a row tile is re-done, with the per-tile redo,
+// only if the fast kernel left a non-finite ce in it (running sum past fp32); every other workgroup exits after one vote.
+template <int C, int PMODE = 0, int NB = 2, int NSTG = 3, bool PAD = false, bool FIXUP = false>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
                                                               int64_t R, const uint16_t* __restrict__ outT,
                                                               const float* __restrict__ out_bias, int N, int NP,
@@ -472,6 +478,16 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2), "two pipeline shapes are written out below");
   if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
+  constexpr bool DUAL = PMODE == 12 || PMODE == 13;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
+  if constexpr (FIXUP) {
+    const int64_t r = (int64_t)blockIdx.x * (256 * NB) + threadIdx.x;
+    int bad = 0;
+    if ((int)threadIdx.x < 256 * NB && r < Rv) {
+      const int64_t src = row_map ? (int64_t)row_map[r] : r;
+      bad = (__float_as_uint(o_ce[src]) & 0x7f800000u) == 0x7f800000u ? 1 : 0;   // inf or NaN, whatever the fast-math flags assume
+    }
+    if (!__syncthreads_or(bad)) return;
+  }
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // NSTG stages + NSTG x 64 bias floats
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -532,7 +548,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   const int n_stages = ((stg_hi0 < n_all) ? stg_hi0 : n_all) - stg_lo;   // stages of THIS workgroup (may be <= 0 for a tail part)
   constexpr int PIECES = G::STAGE_BYTES / 1024;
   constexpr int PPW = PIECES / 8;
-  constexpr int BIAS_OFF = NSTG * G::STAGE_BYTES;
+  constexpr bool PADL = PAD && C >= 256;
+  constexpr int PITCH = PADL ? 1024 + (C == 256 ? 32 : 16) : 1024;   // LDS bytes per 1 KB piece
+  constexpr int STAGE_LDS = PIECES * PITCH;
+  constexpr int TILE_LDS = STAGE_LDS / 2;                             // one 32-item block
+  constexpr int BIAS_OFF = NSTG * STAGE_LDS;
   // LDS-DMA issued through inline asm: hipcc then neither drains it (vmcnt(0)) in front of the next ds_read -- it
   // cannot prove that the DMA and the read touch different stages -- nor waits for it at the barrier; the
   // wait is placed by hand, one full iteration after the issue (cdna_hip_programming.md 5.7 'LDS-DMA recipe').
@@ -563,13 +583,38 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     if (walk_pos && !partials && wave == 0 && lane == 0 && (stg_rel & 7) == 0)
       __hip_atomic_store(walk_pos + (blockIdx.x & 7) * 32, stg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stg += stg_lo;
+    if constexpr (DUAL) {
+      // register diet: per-lane 32-bit offsets recomputed at every issue (a handful of VALU ops per 64 MFMAs) instead of eight
+      // loop-invariant 64-bit pointers, and the stage's base address in an SGPR pair
+      int ln = lane;
+      asm volatile("" : "+v"(ln));   // not loop-invariant as far as hipcc can tell
+      const uint16_t* sbase = outT + (int64_t)stg * SC_STAGE * C;
+#pragma unroll
+      for (int i = 0; i < PPW; i++) {
+        const int piece = wave * PPW + i;
+        const int off = piece * 1024 + ln * 16;
+        const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
+        const int sw = PADL ? (C == 256 ? (row & 1) : 0) : (row & G::SWZ);
+        const unsigned voff = (unsigned)(row * (2 * C) + ((slot ^ sw) << 4));
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_LDS + piece * PITCH);
+        unsigned keep;
+        asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                     : "=&s"(keep)
+                     : "v"(voff), "s"(sbase), "s"(dst)
+                     : "memory");
+      }
+      if (wave == 0 && ln < SC_STAGE / 4)
+        glds16(out_bias + (int64_t)stg * SC_STAGE + ln * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
+      return;
+    }
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
       const int piece = wave * PPW + i;
       const int off = piece * 1024 + lane * 16;
       const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
-      const uint16_t* src = outT + ((int64_t)stg * SC_STAGE + row) * C + ((slot ^ (row & G::SWZ)) << 3);
-      glds16(src, lds_base + buf * G::STAGE_BYTES + piece * 1024);
+      const int sw = PADL ? (C == 256 ? (row & 1) : 0) : (row & G::SWZ);
+      const uint16_t* src = outT + ((int64_t)stg * SC_STAGE + row) * C + ((slot ^ sw) << 3);
+      glds16(src, lds_base + buf * STAGE_LDS + piece * PITCH);
     }
     if (wave == 0 && lane < SC_STAGE / 4)
       glds16(out_bias + (int64_t)stg * SC_STAGE + lane * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
@@ -581,7 +626,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   constexpr bool PIPED = PMODE >= 5 && PMODE != 10;    // 10: no epilogue either; 11: production epilogue
   constexpr bool PACKED = PMODE >= 7 && PMODE <= 9;
   constexpr int GPV = G::KS > 16 ? G::KS / 16 : 1;   // MFMA gaps per epilogue value
-  constexpr int RING = PMODE == 6 ? 4 : 3;  // LDS fragment ring: a ds_read is issued RING-1 MFMAs ahead of its use
+  constexpr int RING = PMODE == 6 ? 4 : (PMODE == 12 ? 2 : 3);  // LDS fragment ring: a ds_read is issued RING-1 MFMAs ahead of its use
   auto pre = [&](const f32x16& v, RowState2& rs) {
     if (PMODE == 1 || PMODE == 2 || PMODE == 4 || PMODE == 10) return;
     if (PACKED) {
@@ -683,7 +728,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   auto post5 = [&](const f32x16& v, RowState2& rs) {
     rs.s += rs.ep;
     rs.s += __builtin_amdgcn_exp2f(rs.xp);
-    if (__any(!(rs.s < 1.0e38f))) {
+    if (!DUAL && __any(!(rs.s < 1.0e38f))) {
       // redo this tile from the checkpoint with a reference that bounds every term and the carried sum by 1
       float tm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
       tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
@@ -707,7 +752,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   };
   // LDS byte offset of this lane's A fragment for k-step 0 of item row (ib*32 + lr); k-step s is `^ (s << 5)`:
   // ((2s + lh) ^ sw) << 4 == ((lh ^ sw) << 4) ^ (s << 5), so one VGPR and one v_xor replace 16 address registers
-  const int a_k0 = lr * (2 * C) + ((lh ^ (lr & G::SWZ)) << 4);
+  const int a_k0 = PADL ? (C == 256 ? (lr >> 1) * PITCH + (lr & 1) * 512 + ((lh ^ (lr & 1)) << 4) : lr * PITCH + (lh << 4))
+                        : lr * (2 * C) + ((lh ^ (lr & G::SWZ)) << 4);
+#define SC_FRAG(s_) (PADL ? (a_k0 + ((s_) << 5)) : (a_k0 ^ ((s_) << 5)))
   auto bias_init = [&](f32x16& a0, int buf, int ib) {
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -726,15 +773,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     int constexpr_i_ = 0;                                                                    \
     pre(y, st[CBY]);                                                                         \
     if (do_mfma) {                                                                           \
-      const unsigned char* tile_ = smem + (buf_) * G::STAGE_BYTES + (ib_) * 32 * (2 * C);    \
+      const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;             \
       uint4 af_[RING];                                                                       \
       _Pragma("unroll") for (int s = 0; s < RING - 1; s++)                                   \
-        af_[s] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ (s << 5)));                 \
+        af_[s] = *reinterpret_cast<const uint4*>(tile_ + SC_FRAG(s));                        \
       bias_init(x, buf_, ib_);                                                               \
       __builtin_amdgcn_sched_barrier(0);                                                     \
       _Pragma("unroll") for (int s = 0; s < G::KS; s++) {                                    \
         if (s + RING - 1 < G::KS && !NOLDS)                                                  \
-          af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + RING - 1) << 5))); \
+          af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + SC_FRAG(s + RING - 1)); \
         x = mfma32(af_[NOLDS ? 0 : s % RING], hf[CBX][s], x);                                \
         if (s % GPV == 0) {   /* KS > 16 (C = 512): one value per GPV gaps */                \
           constexpr_i_ = s / GPV;                                                            \
@@ -749,8 +796,67 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     if (PACKED) post7(y, st[CBY]); else if (PIPED) post5(y, st[CBY]);                        \
   } while (0)
 
+  // DUAL: the 32 MFMAs of (item block ib) x (both step blocks) share each A fragment (0.5 ds_read_b128 per MFMA); the epilogue of the
+  // previous item block's two tiles runs in the 32 gaps, the two rows' chains alternating.
+#define SC_PHASE2(x0, x1, y0, y1, buf_, ib_, do_mfma)                                        \
+  do {                                                                                       \
+    pre(y0, st[0]);                                                                          \
+    pre(y1, st[1]);                                                                          \
+    if (do_mfma) {                                                                           \
+      const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;             \
+      uint4 af_[RING];                                                                       \
+      _Pragma("unroll") for (int s = 0; s < RING - 1; s++)                                   \
+        af_[s] = *reinterpret_cast<const uint4*>(tile_ + SC_FRAG(s));                        \
+      bias_init(x0, buf_, ib_);                                                              \
+      bias_init(x1, buf_, ib_);                                                              \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      _Pragma("unroll") for (int s = 0; s < G::KS; s++) {                                    \
+        if (s + RING - 1 < G::KS)                                                            \
+          af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + SC_FRAG(s + RING - 1)); \
+        x0 = mfma32(af_[s % RING], hf[0][s], x0);                                            \
+        val5(s, y0[s], st[0]);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+        x1 = mfma32(af_[s % RING], hf[1][s], x1);                                            \
+        val5(s, y1[s], st[1]);                                                               \
+        __builtin_amdgcn_sched_barrier(0);                                                   \
+      }                                                                                      \
+      _Pragma("unroll") for (int s = G::KS; s < 16; s++) { val5(s, y0[s], st[0]); val5(s, y1[s], st[1]); } \
+    } else {                                                                                 \
+      _Pragma("unroll") for (int s = 0; s < 16; s++) { val5(s, y0[s], st[0]); val5(s, y1[s], st[1]); } \
+    }                                                                                        \
+    post5(y0, st[0]);                                                                        \
+    post5(y1, st[1]);                                                                        \
+  } while (0)
+
   f32x16 accA, accB;
-  if constexpr (NB == 2) {
+  if constexpr (NB == 2 && DUAL) {
+    f32x16 xa0, xa1, xb0, xb1;
+    if (n_stages > 0) stage_issue(0, 0);
+    if (n_stages > 1) stage_issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (n_stages > 0) {
+      bias_init(xa0, 0, 0);
+      bias_init(xa1, 0, 0);
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + SC_FRAG(s));
+        xa0 = mfma32(a, hf[0][s], xa0);
+        xa1 = mfma32(a, hf[1][s], xa1);
+      }
+    }
+    int buf = 0;
+    for (int stg = 0; stg < n_stages; stg++) {
+      const int buf1 = (buf == 2) ? 0 : buf + 1;
+      const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
+      if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
+      SC_PHASE2(xb0, xb1, xa0, xa1, buf, 1, true);                    // MFMA (stg, ib1)   || epilogue (stg, ib0)
+      SC_PHASE2(xa0, xa1, xb0, xb1, buf1, 0, stg + 1 < n_stages);     // MFMA (stg+1, ib0) || epilogue (stg, ib1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      buf = buf1;
+    }
+  } else if constexpr (NB == 2) {
     f32x16 accA, accB;
     if (n_stages > 0) stage_issue(0, 0);
     if (n_stages > 1) stage_issue(1, 1);
@@ -760,7 +866,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       bias_init(accA, 0, 0);
   #pragma unroll
       for (int s = 0; s < G::KS; s++) {
-        const uint4 a = *reinterpret_cast<const uint4*>(smem + (a_k0 ^ (s << 5)));
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + SC_FRAG(s));
         accA = mfma32(a, hf[0][s], accA);
       }
     }
@@ -791,7 +897,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       bias_init(accA, 0, 0);
 #pragma unroll
       for (int s = 0; s < G::KS; s++) {
-        const uint4 a = *reinterpret_cast<const uint4*>(smem + (a_k0 ^ (s << 5)));
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + SC_FRAG(s));
         accA = mfma32(a, hf[0][s], accA);
       }
     }
@@ -805,6 +911,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     }
   }
 #undef SC_PHASE
+#undef SC_PHASE2
+#undef SC_FRAG
 
 #pragma unroll
   for (int cbk = 0; cbk < NB; cbk++) {
@@ -815,6 +923,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const float l_own = st[cbk].m2 + log2f(s_own);
     const float l_o = __shfl_xor(l_own, 32);
     const int c_o = __shfl_xor(c_own, 32);
+    const float s_other = __shfl_xor(s_own, 32);
     const float M2 = fmaxf(l_own, l_o);
     const float S = __builtin_amdgcn_exp2f(l_own - M2) + __builtin_amdgcn_exp2f(l_o - M2);
     const int cnt = c_own + c_o;
@@ -829,7 +938,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     }
     if (lh == 0 && myr < Rv) {
       const bool valid = myy[cbk] > 0;
-      const float lse = (M2 + log2f(S)) * LN2_F;
+      float lse = (M2 + log2f(S)) * LN2_F;
+      // DUAL has no overflow redo: a running sum past fp32 is handed to the fix-up launch as an all-ones exponent in ce
+      if (DUAL && ((__float_as_uint(s_own) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(s_other) & 0x7f800000u) == 0x7f800000u))
+        lse = INFINITY;
       const int64_t dst = mysrc[cbk];
       if (o_rank) o_rank[dst] = valid ? cnt : 0;
       if (o_ce) o_ce[dst] = valid ? (lse - st[cbk].t) : 0.f;
@@ -861,14 +973,29 @@ __global__ void k_score_merge(const float* __restrict__ partials, int parts, int
 
 __device__ int g_walk_pos[8 * 32];
 
-template <int C, int PMODE = 0, int NB = 2, int NSTG = 3>
+template <int C, int NB, int NSTG, bool PAD>
+static hipError_t launch_score_fixup(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                                     hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev, int* walk) {
+  using G = ScGeom<C>;
+  const size_t pitch = (PAD && C >= 256) ? 1024 + (C == 256 ? 32 : 16) : 1024;
+  const size_t lds = NSTG * (G::STAGE_BYTES / 1024) * pitch + NSTG * SC_STAGE * sizeof(float);
+  auto kern = k_score_pipe<C, 5, NB, NSTG, PAD, true>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)((R + 256 * NB - 1) / (256 * NB))), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N,
+                     m.NP, out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk);
+  return hipGetLastError();
+}
+
+template <int C, int PMODE = 0, int NB = 2, int NSTG = 3, bool PAD = false>
 static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
                                     const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
                                     const int32_t* n_rows_dev = nullptr, float* split_scratch = nullptr) {
   using G = ScGeom<C>;
-  const size_t lds = NSTG * G::STAGE_BYTES + NSTG * SC_STAGE * sizeof(float);
+  const size_t pitch = (PAD && C >= 256) ? 1024 + (C == 256 ? 32 : 16) : 1024;
+  const size_t lds = NSTG * (G::STAGE_BYTES / 1024) * pitch + NSTG * SC_STAGE * sizeof(float);
   const unsigned blocks = (unsigned)((R + 256 * NB - 1) / (256 * NB));
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE, NB, NSTG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   static int* walk = nullptr;
   static bool walk_init = false;
@@ -880,14 +1007,16 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
   if ((PMODE == 5 || PMODE >= 7) && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;
-    hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+    hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                        out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
                        out->target, out->rank, out->ce);
+    if (PMODE == 12) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
     return hipGetLastError();
   }
-  hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+  hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                      out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk);
+  if (PMODE == 12 && out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
   return hipGetLastError();
 }
 
@@ -967,11 +1096,15 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   // ablation switch for profiling runs only: "<mode><stagger>", e.g. "20" = no epilogue, no stagger
   static const char* var = getenv("HIERTCN_SCORE_VARIANT");
   static const char* pvar = getenv("HIERTCN_PIPE_VARIANT");
+  if (pvar && pvar[0] == '5') return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // previous production, for A/B runs
   if (pvar && pvar[0] == '0') return launch_score_pipe<C, 0>(m, hidden, y, R, out, st);  // v3, for A/B runs
   if (pvar && pvar[0] == '6') return launch_score_pipe<C, 6>(m, hidden, y, R, out, st);
   if (pvar && pvar[0] == '7') return launch_score_pipe<C, 7>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (pvar && pvar[0] == '8') return launch_score_pipe<C, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (pvar && pvar[0] == '9') return launch_score_pipe<C, 9>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (C == 256 && pvar && pvar[0] == 'c') return launch_score_pipe<256, 12, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (C == 256 && pvar && pvar[0] == 'd') return launch_score_pipe<256, 13, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (C == 256 && pvar && pvar[0] == 'e') return launch_score_pipe<256, 5, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'a') return launch_score_pipe<256, 10>(m, hidden, y, R, out, st);
   if (C == 256 && pvar && pvar[0] == 'b') return launch_score_pipe<256, 11>(m, hidden, y, R, out, st);
   if (C == 256 && pvar && pvar[0]) {
@@ -983,7 +1116,12 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
       default: break;
     }
   }
-  if (!var || !var[0]) return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);  // production
+  if (!var || !var[0]) {   // production
+    if constexpr (C == 256)   // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
+      return launch_score_pipe<256, 12, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+    else
+      return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  }
   int mode = 0, stagger = 1;
   if (var && var[0]) {
     mode = var[0] - '0';
@@ -1057,7 +1195,8 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
       if (out && out->topk > 8) return launch_score_512<false, 0, 16>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
       if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
       if (getenv("HIERTCN_SCORE512_V1")) return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);   // A/B
-      return launch_score_pipe<512, 5, 1, 2>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+      if (getenv("HIERTCN_SCORE512_XOR")) return launch_score_pipe<512, 5, 1, 2>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // A/B
+      return launch_score_pipe<512, 5, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     default: return hipErrorInvalidValue;
   }
 }
