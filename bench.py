@@ -221,7 +221,7 @@ def main():
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": "k_score_pipe<256,12,2,3,pad> (fused scoring GEMM + loss/rank epilogue; + its fix-up launch)",
+                "kernel": "k_score_pipe<256,14,2,3,pad> (fused scoring GEMM + loss/rank epilogue; + its fix-up launch)",
                 "achieved": round(achieved, 2),
                 "peak": MFMA_PEAK_TFLOPS,
                 "unit": "TFLOP/s",

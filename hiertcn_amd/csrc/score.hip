@@ -478,7 +478,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2), "two pipeline shapes are written out below");
   if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
-  constexpr bool DUAL = PMODE == 12 || PMODE == 13;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
+  constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
+  constexpr bool SEAMLESS = PMODE == 14;   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
   if constexpr (FIXUP) {
     const int64_t r = (int64_t)blockIdx.x * (256 * NB) + threadIdx.x;
     int bad = 0;
@@ -828,8 +829,71 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     post5(y1, st[1]);                                                                        \
   } while (0)
 
+  // SEAMLESS: as SC_PHASE2, but nothing waits at a tile boundary.  The accumulators of the NEXT phase are the ones this phase's
+  // epilogue is draining (y0, y1), and a value is dead once its gap has passed (no per-tile redo in DUAL), so the next tile's bias
+  // is read straight into registers 4q..4q+3 right after gap 4q+3; the A-fragment ring runs on across the boundary (the read issued
+  // at the last k-step is the next tile's first fragment).
+#define SC_PHASE3(x0, x1, y0, y1, buf_, ib_, do_mfma, nbuf_, nib_)                            \
+  do {                                                                                       \
+    const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;               \
+    const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nib_) * TILE_LDS;            \
+    const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nib_) * 32 + 4 * lh;                 \
+    _Pragma("unroll") for (int s = 0; s < 16; s++) {                                         \
+      if (do_mfma) {                                                                         \
+        ring_[(s + 1) & 1] = *reinterpret_cast<const uint4*>((s + 1 < 16) ? tile_ + SC_FRAG(s + 1) : ntile_ + SC_FRAG(0)); \
+        x0 = mfma32(ring_[s & 1], hf[0][s], x0);                                             \
+      }                                                                                      \
+      val5(s, y0[s], st[0]);                                                                 \
+      if ((s & 3) == 3) {                                                                    \
+        const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 2));           \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) y0[(s & ~3) + j] = b4_[j];             \
+      }                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      if (do_mfma) x1 = mfma32(ring_[s & 1], hf[1][s], x1);                                  \
+      val5(s, y1[s], st[1]);                                                                 \
+      if ((s & 3) == 3) {                                                                    \
+        const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 2));           \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) y1[(s & ~3) + j] = b4_[j];             \
+      }                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+    }                                                                                        \
+    post5(y0, st[0]);                                                                        \
+    post5(y1, st[1]);                                                                        \
+  } while (0)
+
   f32x16 accA, accB;
-  if constexpr (NB == 2 && DUAL) {
+  if constexpr (NB == 2 && SEAMLESS && C == 256) {
+    f32x16 xa0, xa1, xb0, xb1;
+    uint4 ring_[2];
+    if (n_stages > 0) stage_issue(0, 0);
+    if (n_stages > 1) stage_issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (n_stages > 0) {
+      bias_init(xa0, 0, 0);
+      bias_init(xa1, 0, 0);
+      bias_init(xb0, 0, 1);
+      bias_init(xb1, 0, 1);
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + SC_FRAG(s));
+        xa0 = mfma32(a, hf[0][s], xa0);
+        xa1 = mfma32(a, hf[1][s], xa1);
+      }
+      ring_[0] = *reinterpret_cast<const uint4*>(smem + TILE_LDS + SC_FRAG(0));   // first fragment of (stage 0, ib1)
+    }
+    int buf = 0;
+    for (int stg = 0; stg < n_stages; stg++) {
+      const int buf1 = (buf == 2) ? 0 : buf + 1;
+      const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
+      if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
+      SC_PHASE3(xb0, xb1, xa0, xa1, buf, 1, true, buf1, 0);                    // MFMA (stg, ib1)   || epilogue (stg, ib0); xa <- bias (stg+1, ib0)
+      SC_PHASE3(xa0, xa1, xb0, xb1, buf1, 0, stg + 1 < n_stages, buf1, 1);     // MFMA (stg+1, ib0) || epilogue (stg, ib1); xb <- bias (stg+1, ib1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      buf = buf1;
+    }
+  } else if constexpr (NB == 2 && DUAL) {
     f32x16 xa0, xa1, xb0, xb1;
     if (n_stages > 0) stage_issue(0, 0);
     if (n_stages > 1) stage_issue(1, 1);
@@ -912,6 +976,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   }
 #undef SC_PHASE
 #undef SC_PHASE2
+#undef SC_PHASE3
 #undef SC_FRAG
 
 #pragma unroll
@@ -1011,12 +1076,12 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
                        out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
                        out->target, out->rank, out->ce);
-    if (PMODE == 12) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+    if (PMODE == 12 || PMODE == 14) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                      out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk);
-  if (PMODE == 12 && out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+  if ((PMODE == 12 || PMODE == 14) && out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
   return hipGetLastError();
 }
 
@@ -1104,6 +1169,7 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   if (pvar && pvar[0] == '9') return launch_score_pipe<C, 9>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'c') return launch_score_pipe<256, 12, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'd') return launch_score_pipe<256, 13, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (C == 256 && pvar && pvar[0] == 'f') return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'e') return launch_score_pipe<256, 5, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'a') return launch_score_pipe<256, 10>(m, hidden, y, R, out, st);
   if (C == 256 && pvar && pvar[0] == 'b') return launch_score_pipe<256, 11>(m, hidden, y, R, out, st);
@@ -1118,7 +1184,7 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   }
   if (!var || !var[0]) {   // production
     if constexpr (C == 256)   // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
-      return launch_score_pipe<256, 12, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+      return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     else
       return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   }
