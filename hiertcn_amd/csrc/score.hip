@@ -1185,8 +1185,8 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   if (!var || !var[0]) {   // production
     if constexpr (C == 256)   // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
       return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
-    else
-      return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+    else   // C = 64 / 128: the four-tile shape on the XOR-swizzled image (+2..3 % over PMODE 5; registers are not the problem here)
+      return launch_score_pipe<C, 12>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   }
   int mode = 0, stagger = 1;
   if (var && var[0]) {
