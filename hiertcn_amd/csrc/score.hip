@@ -833,13 +833,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // epilogue is draining (y0, y1), and a value is dead once its gap has passed (no per-tile redo in DUAL), so the next tile's bias
   // is read straight into registers 4q..4q+3 right after gap 4q+3; the A-fragment ring runs on across the boundary (the read issued
   // at the last k-step is the next tile's first fragment).
-#define SC_PHASE3(x0, x1, y0, y1, buf_, ib_, do_mfma, nbuf_, nib_)                            \
+#define SC_PHASE3(x0, x1, y0, y1, buf_, ib_, MF, nbuf_, nib_)                                 \
   do {                                                                                       \
     const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;               \
     const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nib_) * TILE_LDS;            \
     const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nib_) * 32 + 4 * lh;                 \
     _Pragma("unroll") for (int s = 0; s < 16; s++) {                                         \
-      if (do_mfma) {                                                                         \
+      if (MF) {   /* compile-time */                                                         \
         ring_[(s + 1) & 1] = *reinterpret_cast<const uint4*>((s + 1 < 16) ? tile_ + SC_FRAG(s + 1) : ntile_ + SC_FRAG(0)); \
         x0 = mfma32(ring_[s & 1], hf[0][s], x0);                                             \
       }                                                                                      \
@@ -849,7 +849,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
         _Pragma("unroll") for (int j = 0; j < 4; j++) y0[(s & ~3) + j] = b4_[j];             \
       }                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                     \
-      if (do_mfma) x1 = mfma32(ring_[s & 1], hf[1][s], x1);                                  \
+      if (MF) x1 = mfma32(ring_[s & 1], hf[1][s], x1);                                       \
       val5(s, y1[s], st[1]);                                                                 \
       if ((s & 3) == 3) {                                                                    \
         const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 2));           \
@@ -883,15 +883,19 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       ring_[0] = *reinterpret_cast<const uint4*>(smem + TILE_LDS + SC_FRAG(0));   // first fragment of (stage 0, ib1)
     }
     int buf = 0;
-    for (int stg = 0; stg < n_stages; stg++) {
+    for (int stg = 0; stg + 1 < n_stages; stg++) {   // the last stage is peeled: no run-time "is there a next tile" inside the phases
       const int buf1 = (buf == 2) ? 0 : buf + 1;
       const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
       if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
-      SC_PHASE3(xb0, xb1, xa0, xa1, buf, 1, true, buf1, 0);                    // MFMA (stg, ib1)   || epilogue (stg, ib0); xa <- bias (stg+1, ib0)
-      SC_PHASE3(xa0, xa1, xb0, xb1, buf1, 0, stg + 1 < n_stages, buf1, 1);     // MFMA (stg+1, ib0) || epilogue (stg, ib1); xb <- bias (stg+1, ib1)
+      SC_PHASE3(xb0, xb1, xa0, xa1, buf, 1, true, buf1, 0);       // MFMA (stg, ib1)   || epilogue (stg, ib0); xa <- bias (stg+1, ib0)
+      SC_PHASE3(xa0, xa1, xb0, xb1, buf1, 0, true, buf1, 1);      // MFMA (stg+1, ib0) || epilogue (stg, ib1); xb <- bias (stg+1, ib1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       buf = buf1;
+    }
+    if (n_stages > 0) {
+      SC_PHASE3(xb0, xb1, xa0, xa1, buf, 1, true, buf, 1);        // (the "next tile" reads land in dead registers)
+      SC_PHASE3(xa0, xa1, xb0, xb1, buf, 1, false, buf, 1);       // epilogue of the last tile only
     }
   } else if constexpr (NB == 2 && DUAL) {
     f32x16 xa0, xa1, xb0, xb1;
