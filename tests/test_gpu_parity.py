@@ -380,7 +380,10 @@ def test_ragged_batch_compaction_is_bit_identical(setup):
                                          (2, 2, 33, 300, 64, 32),     # L = 33: model_hier on the layer-at-a-time path
                                          (5, 1, 7, 64, 128, 64),      # N = 64: exactly one scoring stage
                                          (2, 3, 5, 2, 64, 32),        # N = 2: the null id and one item
-                                         (40, 2, 20, 1000, 256, 64)]) # more lanes than one metrics wave
+                                         (40, 2, 20, 1000, 256, 64),  # more lanes than one metrics wave
+                                         (3, 2, 9, 40, 256, 64),      # d = 256 (four-tile seamless kernel), ONE scoring stage: only the peeled tail runs
+                                         (3, 2, 9, 100, 256, 64),     # ... two stages: one trip of the loop + the tail
+                                         (30, 3, 12, 190, 256, 64)])  # ... three stages, two 512-row tiles (the second partly filled)
 def test_edge_shapes_against_oracle(B, S, L, N, d, H):
     from hiertcn_amd.engine import Engine, metrics_dict
     args = small_args(N=N, d=d, H=H, S=S, L=L, B=B)
