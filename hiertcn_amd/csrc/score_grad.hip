@@ -15,6 +15,11 @@
 // target logit the forward pass saved -- bitwise the value the row's own MFMA chain would give (score.hip file header).
 #include "score_geom.h"
 
+// v2 of the kernel body (v1: two accumulator tiles, XOR-swizzled image, 114 ms per cfg-3 step): the four-tile seamless shape of the
+// forward kernel (score.hip, SC_PHASE3).  One A fragment (32 hidden rows x 16 k) read from LDS feeds the MFMAs of BOTH item blocks,
+// so the two halves of every packed dword (items 2n, 2n+1) come out of the same phase; the next row block's (ln w - lse) scalars are
+// read straight into the drained accumulator registers and the fragment ring runs on across the tile boundary.  C = 256: padded LDS
+// image (fragment k-steps at immediate offsets); C = 64 / 128: XOR-swizzled image.
 template <int C>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __restrict__ hrows, const float* __restrict__ rowbias, int n_stages,
                                                            const uint16_t* __restrict__ outT, const float* __restrict__ out_bias, int N, int NP,
@@ -41,49 +46,56 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __res
 
   constexpr int PIECES = G::STAGE_BYTES / 1024;
   constexpr int PPW = PIECES / 8;
-  constexpr int BIAS_OFF = 3 * G::STAGE_BYTES;
-  constexpr int RING = 3;
+  constexpr bool PADL = C == 256;
+  constexpr int PITCH = PADL ? 1024 + 32 : 1024;
+  constexpr int STAGE_LDS = PIECES * PITCH;
+  constexpr int TILE_LDS = STAGE_LDS / 2;
+  constexpr int BIAS_OFF = 3 * STAGE_LDS;
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
-  auto glds16 = [&](const void* gsrc, unsigned lds_dst) {   // LDS-DMA by hand (score.hip: why asm)
-    unsigned keep;
-    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep)
-                 : "v"(gsrc), "s"(dst)
-                 : "memory");
-  };
-  auto stage_issue = [&](int stg, int buf) {
+  auto stage_issue = [&](int stg, int buf) {   // LDS-DMA by hand (score.hip: why asm); SGPR stage base + 32-bit lane offset
+    int ln = lane;
+    asm volatile("" : "+v"(ln));   // keeps the offsets out of loop-invariant registers
+    const uint16_t* sbase = hrows + (int64_t)stg * SC_STAGE * C;
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
       const int piece = wave * PPW + i;
-      const int off = piece * 1024 + lane * 16;
+      const int off = piece * 1024 + ln * 16;
       const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
-      const uint16_t* src = hrows + ((int64_t)stg * SC_STAGE + row) * C + ((slot ^ (row & G::SWZ)) << 3);
-      glds16(src, lds_base + buf * G::STAGE_BYTES + piece * 1024);
+      const int sw = PADL ? (row & 1) : (row & G::SWZ);
+      const unsigned voff = (unsigned)(row * (2 * C) + ((slot ^ sw) << 4));
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_LDS + piece * PITCH);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(voff), "s"(sbase), "s"(dst)
+                   : "memory");
     }
-    if (wave == 0 && lane < SC_STAGE / 4)
-      glds16(rowbias + (int64_t)stg * SC_STAGE + lane * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
+    if (wave == 0 && ln < SC_STAGE / 4) {
+      const float* src = rowbias + (int64_t)stg * SC_STAGE + ln * 4;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + BIAS_OFF + buf * SC_STAGE * 4);
+      unsigned keep;
+      asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                   : "=&s"(keep)
+                   : "v"(src), "s"(dst)
+                   : "memory");
+    }
   };
   const float* sbias = reinterpret_cast<const float*>(smem + BIAS_OFF);
-  const int a_k0 = lr * (2 * C) + ((lh ^ (lr & G::SWZ)) << 4);
-  auto bias_init = [&](f32x16& a0, int buf, int ib) {   // accumulator row r starts from ln w_r - lse_r
+  const int a_k0 = PADL ? (lr >> 1) * PITCH + (lr & 1) * 512 + ((lh ^ (lr & 1)) << 4) : lr * (2 * C) + ((lh ^ (lr & G::SWZ)) << 4);
+#define DL_FRAG(s_) (PADL ? (a_k0 + ((s_) << 5)) : (a_k0 ^ ((s_) << 5)))
+  auto bias_init = [&](f32x16& a0, int buf, int rb) {   // accumulator row r starts from ln w_r - lse_r
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + buf * SC_STAGE + ib * 32 + 8 * q + 4 * lh);
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + buf * SC_STAGE + rb * 32 + 8 * q + 4 * lh);
 #pragma unroll
       for (int j = 0; j < 4; j++) a0[4 * q + j] = b4[j];
     }
   };
 
-  float cs[2] = {0.f, 0.f};   // column sums of this lane's two items over the rows of its half-wave
-  float xp = 0.f;             // pipeline: pending exponent
-  float g0[16];               // block-0 values of the current row block, waiting for their block-1 neighbours
-  float e1[2] = {0.f, 0.f};
-#pragma unroll
-  for (int i = 0; i < 16; i++) g0[i] = 0.f;
+  float cs0 = 0.f, cs1 = 0.f;   // column sums of this lane's two items over the rows of its half-wave
+  float xp0 = 0.f, xp1 = 0.f, e0 = 0.f, e1 = 0.f;   // pipeline: pending exponents / terms of the current value pair
   const unsigned voff = (unsigned)(((int64_t)4 * lh * ldg + item_base + 2 * lr) * 2);   // bytes, < 2^32 (ldg < 2^27)
-
-  // value k of a tile sits in accumulator register k = row (k & 3) + 8 * (k >> 2) + 4 * lh of the 32-row block
+  // value k of a tile sits in accumulator register k = row (k & 3) + 8 * (k >> 2) + 4 * lh of the 32-row block;
   // (uniform row pointer in an SGPR pair) + (per-lane 32-bit byte offset): no VALU address arithmetic per store
   auto put = [&](uint16_t* gtile, int k, uint32_t dw) {
     const uint16_t* rowp = gtile + (int64_t)((k & 3) + 8 * (k >> 2)) * ldg;
@@ -94,87 +106,82 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __res
     const f32x2 v = {lo, hi};
     return __builtin_bit_cast(uint32_t, __builtin_convertvector(v, bf16x2_t));
   };
-  // gap i of a tile: value i-2 is consumed (column sum; block 1: packed with its block-0 neighbour and stored),
-  // value i-1 goes through v_exp, value i through the fma
-  auto val = [&](int i, const f32x16& v, int cb, uint16_t* gtile) {
-    if (cb == 0) {
-      if (i >= 2) cs[0] += g0[i - 2];
-      if (i >= 1) g0[i - 1] = __builtin_amdgcn_exp2f(xp);
-      xp = fmaf(v[i], LOG2E_F, b2[0]);
-      asm volatile("" : "+v"(xp), "+v"(cs[0]));
-    } else {
-      if (i >= 2) {
-        cs[1] += e1[i & 1];
-        put(gtile, i - 2, pack2(g0[i - 2], e1[i & 1]));
-      }
-      if (i >= 1) e1[(i - 1) & 1] = __builtin_amdgcn_exp2f(xp);
-      xp = fmaf(v[i], LOG2E_F, b2[1]);
-      asm volatile("" : "+v"(xp), "+v"(cs[1]), "+v"(e1[0]), "+v"(e1[1]));
+  // value pair i over the two MFMA gaps of k-step i: gap A consumes pair i-1 (column sums, pack, store) and starts pair i (fma),
+  // gap B runs pair i through v_exp
+  auto gap_a = [&](int i, float v0, float v1, uint16_t* gtile) {
+    if (i >= 1) {
+      cs0 += e0;
+      cs1 += e1;
+      put(gtile, i - 1, pack2(e0, e1));
     }
+    xp0 = fmaf(v0, LOG2E_F, b2[0]);
+    xp1 = fmaf(v1, LOG2E_F, b2[1]);
+    asm volatile("" : "+v"(xp0), "+v"(xp1), "+v"(cs0), "+v"(cs1));
   };
-  auto post = [&](int cb, uint16_t* gtile) {
-    if (cb == 0) {
-      cs[0] += g0[14];
-      g0[15] = __builtin_amdgcn_exp2f(xp);
-      cs[0] += g0[15];
-    } else {
-      cs[1] += e1[0];
-      put(gtile, 14, pack2(g0[14], e1[0]));
-      e1[1] = __builtin_amdgcn_exp2f(xp);
-      cs[1] += e1[1];
-      put(gtile, 15, pack2(g0[15], e1[1]));
-    }
+  auto gap_b = [&]() {
+    e0 = __builtin_amdgcn_exp2f(xp0);
+    e1 = __builtin_amdgcn_exp2f(xp1);
+    asm volatile("" : "+v"(e0), "+v"(e1));
+  };
+  auto post = [&](uint16_t* gtile) {
+    cs0 += e0;
+    cs1 += e1;
+    put(gtile, 15, pack2(e0, e1));
   };
 
-  // One pipeline step: the MFMAs of (row block ib of stage buffer buf) x (item block CBX) into x, with the epilogue of the
-  // previous tile y (item block CBY, rows starting at srow) in the gaps.
-#define DL_PHASE(x, CBX, y, CBY, buf_, ib_, do_mfma, srow)                                   \
+  // One phase: the 32 MFMAs of (row block rb of stage buffer buf) x (both item blocks) into (x0, x1); in the gaps the previous row
+  // block's tiles (y0, y1; rows from srow) become G, and (y0, y1) are refilled with the next row block's row scalars.
+#define DL_PHASE(x0, x1, y0, y1, buf_, rb_, MF, nbuf_, nrb_, srow)                           \
   do {                                                                                       \
     uint16_t* gtile_ = gout + (int64_t)(srow) * ldg;                                         \
-    if (do_mfma) {                                                                           \
-      const unsigned char* tile_ = smem + (buf_) * G::STAGE_BYTES + (ib_) * 32 * (2 * C);    \
-      uint4 af_[RING];                                                                       \
-      _Pragma("unroll") for (int s = 0; s < RING - 1; s++)                                   \
-        af_[s] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ (s << 5)));                 \
-      bias_init(x, buf_, ib_);                                                               \
-      __builtin_amdgcn_sched_barrier(0);                                                     \
-      _Pragma("unroll") for (int s = 0; s < G::KS; s++) {                                    \
-        if (s + RING - 1 < G::KS)                                                            \
-          af_[(s + RING - 1) % RING] = *reinterpret_cast<const uint4*>(tile_ + (a_k0 ^ ((s + RING - 1) << 5))); \
-        x = mfma32(af_[s % RING], hf[CBX][s], x);                                            \
-        val(s & 15, y, CBY, gtile_);                                                         \
-        __builtin_amdgcn_sched_barrier(0);                                                   \
+    const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (rb_) * TILE_LDS;               \
+    const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nrb_) * TILE_LDS;            \
+    const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nrb_) * 32 + 4 * lh;                 \
+    _Pragma("unroll") for (int s = 0; s < 16; s++) {                                         \
+      if (MF && s < G::KS) {                                                                 \
+        ring_[(s + 1) & 1] = *reinterpret_cast<const uint4*>((s + 1 < G::KS) ? tile_ + DL_FRAG(s + 1) : ntile_ + DL_FRAG(0)); \
+        x0 = mfma32(ring_[s & 1], hf[0][s], x0);                                             \
       }                                                                                      \
-      _Pragma("unroll") for (int s = G::KS; s < 16; s++) val(s, y, CBY, gtile_);             \
-    } else {                                                                                 \
-      _Pragma("unroll") for (int s = 0; s < 16; s++) val(s, y, CBY, gtile_);                 \
+      gap_a(s, y0[s], y1[s], gtile_);                                                        \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+      if (MF && s < G::KS) x1 = mfma32(ring_[s & 1], hf[1][s], x1);                          \
+      gap_b();                                                                               \
+      if ((s & 3) == 3) {   /* values 4q..4q+3 of both tiles are dead: next row block's scalars */ \
+        const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 2));           \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) { y0[(s & ~3) + j] = b4_[j]; y1[(s & ~3) + j] = b4_[j]; } \
+      }                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
     }                                                                                        \
-    post(CBY, gtile_);                                                                       \
+    post(gtile_);                                                                            \
   } while (0)
 
-  f32x16 accA, accB;
+  f32x16 xa0, xa1, xb0, xb1;
+  uint4 ring_[2];
   if (n_stages > 0) stage_issue(0, 0);
   if (n_stages > 1) stage_issue(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (n_stages > 0) {
-    bias_init(accA, 0, 0);
+    bias_init(xa0, 0, 0);
+    bias_init(xa1, 0, 0);
+    bias_init(xb0, 0, 1);
+    bias_init(xb1, 0, 1);
 #pragma unroll
     for (int s = 0; s < G::KS; s++) {
-      const uint4 a = *reinterpret_cast<const uint4*>(smem + (a_k0 ^ (s << 5)));
-      accA = mfma32(a, hf[0][s], accA);
+      const uint4 a = *reinterpret_cast<const uint4*>(smem + DL_FRAG(s));
+      xa0 = mfma32(a, hf[0][s], xa0);
+      xa1 = mfma32(a, hf[1][s], xa1);
     }
+    ring_[0] = *reinterpret_cast<const uint4*>(smem + TILE_LDS + DL_FRAG(0));   // first fragment of (stage 0, rows 32..63)
   }
   int buf = 0;
-  for (int stg = 0; stg < n_stages; stg++) {
+  for (int stg = 0; stg + 1 < n_stages; stg++) {   // the last stage is peeled: "is there a next tile" stays a compile-time flag
     const int buf1 = (buf == 2) ? 0 : buf + 1;
     const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
     const int r0 = stg * SC_STAGE;
     if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
-    DL_PHASE(accB, 1, accA, 0, buf, 0, true, r0);                         // MFMA (stg, rows0, items1)   || epilogue (stg, rows0, items0)
-    DL_PHASE(accA, 0, accB, 1, buf, 1, true, r0);                         // MFMA (stg, rows1, items0)   || epilogue (stg, rows0, items1) + stores
-    DL_PHASE(accB, 1, accA, 0, buf, 1, true, r0 + 32);                    // MFMA (stg, rows1, items1)   || epilogue (stg, rows1, items0)
-    DL_PHASE(accA, 0, accB, 1, buf1, 0, stg + 1 < n_stages, r0 + 32);     // MFMA (stg+1, rows0, items0) || epilogue (stg, rows1, items1) + stores
+    DL_PHASE(xb0, xb1, xa0, xa1, buf, 1, true, buf1, 0, r0);          // MFMA (stg, rows1)   || G of (stg, rows0);  xa <- scalars (stg+1, rows0)
+    DL_PHASE(xa0, xa1, xb0, xb1, buf1, 0, true, buf1, 1, r0 + 32);    // MFMA (stg+1, rows0) || G of (stg, rows1);  xb <- scalars (stg+1, rows1)
     // vmcnt counts in issue order on gfx9-family parts (loads and stores share the counter): the LDS-DMA of stage stg+2 was issued
     // before this iteration's 32 stores, so "at most 32 outstanding" means it has landed while the stores may still be in flight
     asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
@@ -182,13 +189,19 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __res
     asm volatile("" ::: "memory");
     buf = buf1;
   }
+  if (n_stages > 0) {
+    const int r0 = (n_stages - 1) * SC_STAGE;
+    DL_PHASE(xb0, xb1, xa0, xa1, buf, 1, true, buf, 1, r0);           // (the "next tile" reads land in dead registers)
+    DL_PHASE(xa0, xa1, xb0, xb1, buf, 1, false, buf, 1, r0 + 32);     // G of the last row block only
+  }
 #undef DL_PHASE
+#undef DL_FRAG
 
-#pragma unroll
-  for (int b = 0; b < 2; b++) {
-    const float tot = cs[b] + __shfl_xor(cs[b], 32);
-    const int it = item_base + 2 * lr + b;
-    if (lh == 0 && it < N) dbias[it] += tot;   // one owner per item and launch; launches of a step are stream-ordered
+  {
+    const float t0 = cs0 + __shfl_xor(cs0, 32), t1 = cs1 + __shfl_xor(cs1, 32);
+    const int it = item_base + 2 * lr;
+    if (lh == 0 && it < N) dbias[it] += t0;   // one owner per item and launch; launches of a step are stream-ordered
+    if (lh == 0 && it + 1 < N) dbias[it + 1] += t1;
   }
 }
 
@@ -217,7 +230,8 @@ template <int C>
 static hipError_t launch_dlogits_c(const ModelDev& m, const uint16_t* hrows, const float* rowbias, int n_stages, uint16_t* gout, int64_t ldg,
                                    float* dbias, hipStream_t st) {
   using G = ScGeom<C>;
-  const size_t lds = 3 * G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
+  const size_t pitch = C == 256 ? 1024 + 32 : 1024;
+  const size_t lds = 3 * (G::STAGE_BYTES / 1024) * pitch + 3 * SC_STAGE * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlogits<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const unsigned blocks = (unsigned)((m.NP + 511) / 512);

@@ -26,7 +26,7 @@ for i in range(steps + 1):
     if i == 1:
         torch.cuda.synchronize(); t0 = time.perf_counter()
     out = eng.train_forward_backward(xd, yd, md, st0)
-    eng.adam_step(1e-2)
+    eng.adam_step(float(os.environ.get("LR", "1e-3")))
     losses.append(out["metrics8"].clone())
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / steps
