@@ -534,7 +534,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const float other = __shfl_xor(d, 32);
     const float t = (((lr >> 2) & 1) == lh) ? d : other;
     st[cbk].t = t;
-    st[cbk].m2 = t * LOG2E_F;
+    // Reference of the softmax sum, log2 units: the target logit plus 64.  Terms are 2^(z log2e - m2), so the running sum overflows
+    // fp32 only when some logit sits more than (128 + 64) ln 2 = 133 nats above the target (88 without the headroom) -- the
+    // overflow path (per-tile redo / the fix-up launch) is for pathological rows -- and a term underflows only 43 nats BELOW the
+    // target, where it is < 2^-62 of the target's own term.  The shift is an exact integer; lse = (m2 + log2 s) ln 2 as before.
+    st[cbk].m2 = t * LOG2E_F + 64.0f;
     st[cbk].s = 0.f;
     st[cbk].c = 0;
     st[cbk].xp = st[cbk].ep = st[cbk].ssave = 0.f;
