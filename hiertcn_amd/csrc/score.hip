@@ -843,8 +843,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nib_) * TILE_LDS;            \
     const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nib_) * 32 + 4 * lh;                 \
     _Pragma("unroll") for (int s = 0; s < 16; s++) {                                         \
-      if (MF) {   /* compile-time */                                                         \
-        ring_[(s + 1) & 1] = *reinterpret_cast<const uint4*>((s + 1 < 16) ? tile_ + SC_FRAG(s + 1) : ntile_ + SC_FRAG(0)); \
+      if (MF && s < G::KS) {   /* compile-time; C < 256: fewer k-steps than values, the rest of the epilogue trails */ \
+        ring_[(s + 1) & 1] = *reinterpret_cast<const uint4*>((s + 1 < G::KS) ? tile_ + SC_FRAG(s + 1) : ntile_ + SC_FRAG(0)); \
         x0 = mfma32(ring_[s & 1], hf[0][s], x0);                                             \
       }                                                                                      \
       val5(s, y0[s], st[0]);                                                                 \
@@ -853,7 +853,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
         _Pragma("unroll") for (int j = 0; j < 4; j++) y0[(s & ~3) + j] = b4_[j];             \
       }                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                     \
-      if (MF) x1 = mfma32(ring_[s & 1], hf[1][s], x1);                                       \
+      if (MF && s < G::KS) x1 = mfma32(ring_[s & 1], hf[1][s], x1);                          \
       val5(s, y1[s], st[1]);                                                                 \
       if ((s & 3) == 3) {                                                                    \
         const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 2));           \
@@ -866,7 +866,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   } while (0)
 
   f32x16 accA, accB;
-  if constexpr (NB == 2 && SEAMLESS && C == 256) {
+  if constexpr (NB == 2 && SEAMLESS && C <= 256) {
     f32x16 xa0, xa1, xb0, xb1;
     uint4 ring_[2];
     if (n_stages > 0) stage_issue(0, 0);
@@ -1193,8 +1193,10 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   if (!var || !var[0]) {   // production
     if constexpr (C == 256)   // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
       return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
-    else   // C = 64 / 128: the four-tile shape on the XOR-swizzled image (+2..3 % over PMODE 5; registers are not the problem here)
+    else if (getenv("HIERTCN_SMALL_C_DUAL"))   // A/B
       return launch_score_pipe<C, 12>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+    else   // C = 64 / 128: the same four-tile seamless shape on the XOR-swizzled image (registers are not the problem here)
+      return launch_score_pipe<C, 14>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   }
   int mode = 0, stagger = 1;
   if (var && var[0]) {
