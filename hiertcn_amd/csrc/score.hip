@@ -582,6 +582,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     s0 = __builtin_amdgcn_readfirstlane(s0);
     s0 = (s0 >= 0 && s0 < n_stages) ? s0 : 0;
   }
+  unsigned dma_voff[PPW];   // DUAL: byte offset of this lane's 16 B of piece i inside a stage of outT (source-side swizzle applied)
+#pragma unroll
+  for (int i = 0; i < PPW; i++) {
+    const int off = (wave * PPW + i) * 1024 + lane * 16;
+    const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
+    const int sw = PADL ? (C == 256 ? (row & 1) : 0) : (row & G::SWZ);
+    dma_voff[i] = (unsigned)(row * (2 * C) + ((slot ^ sw) << 4));
+  }
   auto stage_issue = [&](int stg_rel, int buf) {
     int stg = s0 + stg_rel;
     stg -= (stg >= n_stages) ? n_stages : 0;
@@ -589,27 +597,19 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       __hip_atomic_store(walk_pos + (blockIdx.x & 7) * 32, stg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stg += stg_lo;
     if constexpr (DUAL) {
-      // register diet: per-lane 32-bit offsets recomputed at every issue (a handful of VALU ops per 64 MFMAs) instead of eight
-      // loop-invariant 64-bit pointers, and the stage's base address in an SGPR pair
-      int ln = lane;
-      asm volatile("" : "+v"(ln));   // not loop-invariant as far as hipcc can tell
+      // SGPR stage base + per-piece 32-bit lane offsets (dma_voff, computed once): no 64-bit per-lane pointers, no address VALU per stage
       const uint16_t* sbase = outT + (int64_t)stg * SC_STAGE * C;
 #pragma unroll
       for (int i = 0; i < PPW; i++) {
-        const int piece = wave * PPW + i;
-        const int off = piece * 1024 + ln * 16;
-        const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
-        const int sw = PADL ? (C == 256 ? (row & 1) : 0) : (row & G::SWZ);
-        const unsigned voff = (unsigned)(row * (2 * C) + ((slot ^ sw) << 4));
-        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_LDS + piece * PITCH);
+        const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_LDS + (wave * PPW + i) * PITCH);
         unsigned keep;
         asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                      : "=&s"(keep)
-                     : "v"(voff), "s"(sbase), "s"(dst)
+                     : "v"(dma_voff[i]), "s"(sbase), "s"(dst)
                      : "memory");
       }
-      if (wave == 0 && ln < SC_STAGE / 4)
-        glds16(out_bias + (int64_t)stg * SC_STAGE + ln * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
+      if (wave == 0 && lane < SC_STAGE / 4)
+        glds16(out_bias + (int64_t)stg * SC_STAGE + lane * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
       return;
     }
 #pragma unroll
