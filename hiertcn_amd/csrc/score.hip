@@ -582,7 +582,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     s0 = __builtin_amdgcn_readfirstlane(s0);
     s0 = (s0 >= 0 && s0 < n_stages) ? s0 : 0;
   }
-  unsigned dma_voff[PPW];   // DUAL: byte offset of this lane's 16 B of piece i inside a stage of outT (source-side swizzle applied)
+  unsigned dma_voff[PPW];   // byte offset of this lane's 16 B of piece i inside a stage of outT (source-side swizzle applied)
 #pragma unroll
   for (int i = 0; i < PPW; i++) {
     const int off = (wave * PPW + i) * 1024 + lane * 16;
@@ -596,7 +596,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     if (walk_pos && !partials && wave == 0 && lane == 0 && (stg_rel & 7) == 0)
       __hip_atomic_store(walk_pos + (blockIdx.x & 7) * 32, stg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     stg += stg_lo;
-    if constexpr (DUAL) {
+    {
       // SGPR stage base + per-piece 32-bit lane offsets (dma_voff, computed once): no 64-bit per-lane pointers, no address VALU per stage
       const uint16_t* sbase = outT + (int64_t)stg * SC_STAGE * C;
 #pragma unroll
@@ -610,19 +610,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       }
       if (wave == 0 && lane < SC_STAGE / 4)
         glds16(out_bias + (int64_t)stg * SC_STAGE + lane * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
-      return;
     }
-#pragma unroll
-    for (int i = 0; i < PPW; i++) {
-      const int piece = wave * PPW + i;
-      const int off = piece * 1024 + lane * 16;
-      const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
-      const int sw = PADL ? (C == 256 ? (row & 1) : 0) : (row & G::SWZ);
-      const uint16_t* src = outT + ((int64_t)stg * SC_STAGE + row) * C + ((slot ^ sw) << 3);
-      glds16(src, lds_base + buf * STAGE_LDS + piece * PITCH);
-    }
-    if (wave == 0 && lane < SC_STAGE / 4)
-      glds16(out_bias + (int64_t)stg * SC_STAGE + lane * 4, lds_base + BIAS_OFF + buf * SC_STAGE * 4);
   };
   const float* sbias = reinterpret_cast<const float*>(smem + BIAS_OFF);
 

@@ -52,26 +52,27 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __res
   constexpr int TILE_LDS = STAGE_LDS / 2;
   constexpr int BIAS_OFF = 3 * STAGE_LDS;
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  unsigned dma_voff[PPW];   // byte offset of this lane's 16 B of piece i inside a 64-row stage (source-side swizzle applied), computed once
+#pragma unroll
+  for (int i = 0; i < PPW; i++) {
+    const int off = (wave * PPW + i) * 1024 + lane * 16;
+    const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
+    const int sw = PADL ? (row & 1) : (row & G::SWZ);
+    dma_voff[i] = (unsigned)(row * (2 * C) + ((slot ^ sw) << 4));
+  }
   auto stage_issue = [&](int stg, int buf) {   // LDS-DMA by hand (score.hip: why asm); SGPR stage base + 32-bit lane offset
-    int ln = lane;
-    asm volatile("" : "+v"(ln));   // keeps the offsets out of loop-invariant registers
     const uint16_t* sbase = hrows + (int64_t)stg * SC_STAGE * C;
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
-      const int piece = wave * PPW + i;
-      const int off = piece * 1024 + ln * 16;
-      const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
-      const int sw = PADL ? (row & 1) : (row & G::SWZ);
-      const unsigned voff = (unsigned)(row * (2 * C) + ((slot ^ sw) << 4));
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_LDS + piece * PITCH);
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_LDS + (wave * PPW + i) * PITCH);
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
-                   : "v"(voff), "s"(sbase), "s"(dst)
+                   : "v"(dma_voff[i]), "s"(sbase), "s"(dst)
                    : "memory");
     }
-    if (wave == 0 && ln < SC_STAGE / 4) {
-      const float* src = rowbias + (int64_t)stg * SC_STAGE + ln * 4;
+    if (wave == 0 && lane < SC_STAGE / 4) {
+      const float* src = rowbias + (int64_t)stg * SC_STAGE + lane * 4;
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + BIAS_OFF + buf * SC_STAGE * 4);
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
