@@ -478,8 +478,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2), "two pipeline shapes are written out below");
   if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
-  constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
-  constexpr bool SEAMLESS = PMODE == 14;   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
+  constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14 || PMODE == 16;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
+  constexpr bool SEAMLESS = PMODE == 14 || PMODE == 16;   // 16: timing experiment, no stage barrier (racy by design)   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
   if constexpr (FIXUP) {
     const int64_t r = (int64_t)blockIdx.x * (256 * NB) + threadIdx.x;
     int bad = 0;
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       SC_PHASE3(xb0, xb1, xa0, xa1, buf, 1, true, buf1, 0);       // MFMA (stg, ib1)   || epilogue (stg, ib0); xa <- bias (stg+1, ib0)
       SC_PHASE3(xa0, xa1, xb0, xb1, buf1, 0, true, buf1, 1);      // MFMA (stg+1, ib0) || epilogue (stg, ib1); xb <- bias (stg+1, ib1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (PMODE != 16) __syncthreads();
       buf = buf1;
     }
     if (n_stages > 0) {
@@ -1165,6 +1165,7 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   if (pvar && pvar[0] == '9') return launch_score_pipe<C, 9>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'c') return launch_score_pipe<256, 12, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'd') return launch_score_pipe<256, 13, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if (C == 256 && pvar && pvar[0] == 'h') return launch_score_pipe<256, 16, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'f') return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'e') return launch_score_pipe<256, 5, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if (C == 256 && pvar && pvar[0] == 'a') return launch_score_pipe<256, 10>(m, hidden, y, R, out, st);
