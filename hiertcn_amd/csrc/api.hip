@@ -407,13 +407,15 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   // carry a target and score only those (a ragged XING batch is mostly padding: slot width = longest session of the slot).
   int32_t* row_map = nullptr;
   int32_t* n_valid = nullptr;
-  if (so.topk == 0) {   // (the top-k list kernel takes dense rows)
+  {
     row_map = reinterpret_cast<int32_t*>(ws + w.map);
     n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
     HIP_TRY(launch_compact_rows(y_ids, R, row_map, n_valid, reinterpret_cast<int32_t*>(ws + w.cscratch), st));
     HIP_TRY(hipMemsetAsync(so.rank, 0, (size_t)R * sizeof(int32_t), st));
     HIP_TRY(hipMemsetAsync(so.ce, 0, (size_t)R * sizeof(float), st));
     if (so.target) HIP_TRY(hipMemsetAsync(so.target, 0, (size_t)R * sizeof(float), st));
+    // a masked row is an all-zero logit row (model.py:105): its ranked list is 0..k-1 with values 0 (loss.py:120 on ties)
+    if (so.topk > 0) HIP_TRY(launch_topk_fill(so.topk_idx, so.topk_val, R, so.topk, st));
   }
   float* split = nullptr;
   if (so.topk == 0 && score_split_parts(R, h->m.NP) > 1) {

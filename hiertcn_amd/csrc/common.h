@@ -92,6 +92,7 @@ size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 size_t gru_save_floats(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
                            float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st, float* save = nullptr);
+hipError_t launch_topk_fill(int32_t* idx, float* val, int64_t R, int k, hipStream_t st);
 // score_grad.hip: item-stationary d-logits kernel of the training backward (row chunks)
 bool dlogits_supported(const ModelDev& m);
 int64_t dlogits_ld(const ModelDev& m);

@@ -150,3 +150,17 @@ hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_
   hipLaunchKernelGGL(k_write_map, dim3(nblk), dim3(256), 0, st, y, R, scratch, map);
   return hipGetLastError();
 }
+
+// ranked lists of masked rows: indices 0..k-1, values 0 (the scoring kernel then overwrites the rows that carry a target)
+__global__ void k_topk_fill(int32_t* __restrict__ idx, float* __restrict__ val, int64_t n, int k) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  idx[i] = (int32_t)(i % k);
+  val[i] = 0.f;
+}
+hipError_t launch_topk_fill(int32_t* idx, float* val, int64_t R, int k, hipStream_t st) {
+  const int64_t n = R * k;
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_topk_fill, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, idx, val, n, k);
+  return hipGetLastError();
+}

@@ -144,7 +144,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
                                                          unsigned long long* __restrict__ stamps = nullptr,
                                                          int32_t* __restrict__ o_topi = nullptr, float* __restrict__ o_topv = nullptr,
                                                          int topk = 0, const float* __restrict__ g_lse = nullptr,
-                                                         const float* __restrict__ g_w = nullptr, int stg_begin = 0, int stg_end = -1) {
+                                                         const float* __restrict__ g_w = nullptr, int stg_begin = 0, int stg_end = -1,
+                                                         const int32_t* __restrict__ row_map = nullptr,
+                                                         const int32_t* __restrict__ n_rows_dev = nullptr) {
+  // row_map / n_rows_dev (fused and top-k flavours): compact position p stands for row row_map[p], as in k_score_pipe.
+  const int64_t Rin = R;
+  if (n_rows_dev) R = (int64_t)n_rows_dev[0];
+  if ((int64_t)blockIdx.x * (256 * NB) >= R && Rin > 0) return;
   // LOGITS && MODE == 9: gradient build (training).  Instead of fp32 logits the kernel writes, for the stages
   // [stg_begin, stg_end) only, G[r][n] = w_r * (exp(z_rn - lse_r) - [n == y_r]) as bf16 into `logits` viewed as
   // uint16_t [R][(stg_end - stg_begin) * 64]: d loss / d z of model.py:111-117 + loss.py:21, never held for all N at once.
@@ -178,8 +184,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
 #pragma unroll
   for (int cbk = 0; cbk < NB; cbk++) {
     int64_t r = row0 + cbk * 32 + lr;
-    myrow[cbk] = r;
-    const int64_t rc = (r < R) ? r : (R - 1);
+    const int64_t rp = (r < R) ? r : (R - 1);
+    const int64_t rc = row_map ? (int64_t)row_map[rp] : rp;
+    myrow[cbk] = (r < R) ? rc : Rin;   // output / input row; Rin = "no row" (fails every `< R` test below, R <= Rin)
     int yy = ((LOGITS && !GRAD) || r >= R) ? 0 : y[rc];
     myy[cbk] = (yy > 0 && yy < N) ? yy : 0;
     const uint16_t* hp = hidden + rc * C + 8 * lh;
@@ -189,7 +196,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
   float my_lse[NB], my_w[NB];
 #pragma unroll
   for (int cbk = 0; cbk < NB; cbk++) {
-    const bool live = GRAD && myrow[cbk] < R && myy[cbk] > 0;
+    const bool live = GRAD && myrow[cbk] < Rin && myy[cbk] > 0;
     my_lse[cbk] = live ? g_lse[myrow[cbk]] : 0.f;
     my_w[cbk] = live ? g_w[myrow[cbk]] : 0.f;
   }
@@ -274,8 +281,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
 #pragma unroll
       for (int j = 0; j < 4; j++) {
         if (it + j < N) {
-          if (myrow[0] < R) logits[myrow[0] * N + it + j] = acc0[4 * q + j];
-          if (NB == 2 && myrow[NB - 1] < R) logits[myrow[NB - 1] * N + it + j] = acc1[4 * q + j];
+          if (myrow[0] < Rin) logits[myrow[0] * N + it + j] = acc0[4 * q + j];
+          if (NB == 2 && myrow[NB - 1] < Rin) logits[myrow[NB - 1] * N + it + j] = acc1[4 * q + j];
         }
       }
     }
@@ -290,7 +297,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       const int it = item0 + 8 * q;
 #pragma unroll
       for (int cbk = 0; cbk < NB; cbk++) {
-        if (myrow[cbk] >= R) continue;
+        if (myrow[cbk] >= Rin) continue;
         const f32x16& a = (cbk == 0) ? acc0 : acc1;
         float g[4];
 #pragma unroll
@@ -385,7 +392,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       const float M2 = fmaxf(st[cbk].m2, m_o);
       const float S = st[cbk].s * __builtin_amdgcn_exp2f(st[cbk].m2 - M2) + s_o * __builtin_amdgcn_exp2f(m_o - M2);
       const int cnt = st[cbk].cnt + c_o;
-      if (lh == 0 && myrow[cbk] < R) {
+      if (lh == 0 && myrow[cbk] < Rin) {
         const bool valid = myy[cbk] > 0;
         const float lse = (M2 + log2f(S)) * LN2_F;
         if (o_rank) o_rank[myrow[cbk]] = valid ? cnt : 0;
@@ -404,7 +411,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
 #pragma unroll
         for (int k = 0; k < KTA; k++) { lv[tid * KTA + k] = top[cbk].v[k]; li[tid * KTA + k] = top[cbk].i[k]; }
         __syncthreads();
-        if (lh == 0 && myrow[cbk] < R) {
+        if (lh == 0 && myrow[cbk] < Rin) {
           const bool valid = myy[cbk] > 0;
           const float* av = lv + tid * KTA; const int* ai = li + tid * KTA;
           const float* bv = lv + (tid + 32) * KTA; const int* bi = li + (tid + 32) * KTA;
@@ -1101,7 +1108,8 @@ static hipError_t launch_score_v(const ModelDev& m, const uint16_t* hidden, cons
 
 template <int C, int KT>
 static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R,
-                                    const hiertcn_score_out_t* out, hipStream_t st) {
+                                    const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
+                                    const int32_t* n_rows_dev = nullptr) {
   using G = ScGeom<C>;
   size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
   const size_t merge = (size_t)SC_THREADS * KT * 8;
@@ -1112,7 +1120,7 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out->rank, out->ce,
                      out->target, (float*)nullptr, 0, (unsigned long long*)nullptr, out->topk_idx, out->topk_val, (int)out->topk,
-                     (const float*)nullptr, (const float*)nullptr, 0, -1);
+                     (const float*)nullptr, (const float*)nullptr, 0, -1, row_map, n_rows_dev);
   return hipGetLastError();
 }
 
@@ -1122,7 +1130,8 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
                                  const int32_t* n_rows_dev, float* split_scratch) {
   if (logits) return launch_score_v<C, true, 0>(m, hidden, y, R, nullptr, logits, 0, st);
   if (out && out->topk > 0)  // loss.py:120 ranked indices beside rank / ce: the list kernel (slower epilogue)
-    return out->topk <= 8 ? launch_score_topk<C, 8>(m, hidden, y, R, out, st) : launch_score_topk<C, 16>(m, hidden, y, R, out, st);
+    return out->topk <= 8 ? launch_score_topk<C, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev)
+                          : launch_score_topk<C, 16>(m, hidden, y, R, out, st, row_map, n_rows_dev);
   if (getenv("HIERTCN_SCORE_STAMPS")) {  // diagnostic build: per-phase cycle sums of the first workgroups, printed to stderr
     using G = ScGeom<C>;
     const int stagger_d = getenv("HIERTCN_SCORE_VARIANT") && getenv("HIERTCN_SCORE_VARIANT")[1] == '0' ? 0 : 1;
@@ -1199,7 +1208,8 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
 
 template <bool LOGITS, int MODE, int KT>
 static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
-                                   float* logits, const float* lse, const float* w, int stg_begin, int stg_end, hipStream_t st);
+                                   float* logits, const float* lse, const float* w, int stg_begin, int stg_end, hipStream_t st,
+                                   const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr);
 
 template <int C>
 static hipError_t launch_score_grad_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse,
@@ -1212,7 +1222,7 @@ static hipError_t launch_score_grad_c(const ModelDev& m, const uint16_t* hidden,
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, (int32_t*)nullptr,
                      (float*)nullptr, (float*)nullptr, reinterpret_cast<float*>(gout), 0, (unsigned long long*)nullptr, (int32_t*)nullptr,
-                     (float*)nullptr, 0, lse, w, stg_begin, stg_end);
+                     (float*)nullptr, 0, lse, w, stg_begin, stg_end, (const int32_t*)nullptr, (const int32_t*)nullptr);
   return hipGetLastError();
 }
 
@@ -1235,7 +1245,8 @@ hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, co
 // 32-step block per wave (128 VGPRs of B operand, 2 x 64 KB LDS stages, 32 MFMAs per 16 logits of epilogue).
 template <bool LOGITS, int MODE, int KT>
 static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
-                                   float* logits, const float* lse, const float* w, int stg_begin, int stg_end, hipStream_t st) {
+                                   float* logits, const float* lse, const float* w, int stg_begin, int stg_end, hipStream_t st,
+                                   const int32_t* row_map, const int32_t* n_rows_dev) {
   using G = ScGeom<512>;
   size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
   const unsigned blocks = (unsigned)((R + 255) / 256);
@@ -1244,7 +1255,8 @@ static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, co
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out ? out->rank : nullptr,
                      out ? out->ce : nullptr, out ? out->target : nullptr, logits, 0, (unsigned long long*)nullptr,
-                     out ? out->topk_idx : nullptr, out ? out->topk_val : nullptr, out ? (int)out->topk : 0, lse, w, stg_begin, stg_end);
+                     out ? out->topk_idx : nullptr, out ? out->topk_val : nullptr, out ? (int)out->topk : 0, lse, w, stg_begin, stg_end,
+                     row_map, n_rows_dev);
   return hipGetLastError();
 }
 
@@ -1257,8 +1269,8 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
     case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
     case 512:   // (dense rows: callers zero-fill nothing here, the kernel writes rank 0 / ce 0 on masked rows itself)
       if (logits) return launch_score_512<true, 0, 0>(m, hidden, y, R, nullptr, logits, nullptr, nullptr, 0, -1, st);
-      if (out && out->topk > 8) return launch_score_512<false, 0, 16>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
-      if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
+      if (out && out->topk > 8) return launch_score_512<false, 0, 16>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st, row_map, n_rows_dev);
+      if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st, row_map, n_rows_dev);
       if (getenv("HIERTCN_SCORE512_V1")) return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);   // A/B
       if (getenv("HIERTCN_SCORE512_XOR")) return launch_score_pipe<512, 5, 1, 2>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // A/B
       return launch_score_pipe<512, 5, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);

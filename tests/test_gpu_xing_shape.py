@@ -68,4 +68,7 @@ def test_xing_shape_logits_recall_and_topk_against_oracle():
     # and on ALL scored rows the device's list is the exact top-10 of the device's own logits (bit-exact integer output)
     own = O.top_k_indices(logits.reshape(-1, N), K).reshape(B, S * L, K)
     assert np.array_equal(ti[valid], own[valid])
+    # masked rows (never visited by the kernel: the rows are compacted) carry the all-zero row's list 0..K-1 (model.py:105, loss.py:120)
+    assert np.array_equal(ti[~valid], np.broadcast_to(np.arange(K), ti[~valid].shape))
+    assert not out["topk_val"].cpu().numpy().reshape(B, S * L, K)[~valid].any()
     eng.close()
