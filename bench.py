@@ -89,8 +89,12 @@ def main():
         if world == 1 and a.gpus > 1:
             raise SystemExit("--gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         a.gpus = world
-    torch.cuda.set_device(local_rank)
-    rank, world, local_rank = init_from_env("nccl", torch.device("cuda", local_rank))  # "nccl" = RCCL on ROCm
+    # HIERTCN_BENCH_BACKEND=gloo: smoke-test of the N > 1 code path on a box with fewer GPUs than ranks (ranks share devices,
+    # the 8 metric sums go through the host); the measured configuration is always one rank per GPU over RCCL
+    backend = os.environ.get("HIERTCN_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    rank, world, local_rank = init_from_env(backend, torch.device("cuda", dev_index))  # "nccl" = RCCL on ROCm
 
     from hiertcn_amd.args import hier_tcn_args
     from hiertcn_amd.engine import Engine, metrics_dict

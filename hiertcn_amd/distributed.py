@@ -43,7 +43,12 @@ def all_reduce_metrics(m8: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks of the 8 accumulators; afterwards out[k] / out[6] is the metric
     over the GLOBAL batch (a mean over all lanes of all ranks, model.py:116-117 / loss.py:215-219)."""
     if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-        dist.all_reduce(m8, op=dist.ReduceOp.SUM)
+        if m8.is_cuda and dist.get_backend() == "gloo":   # (tests / smoke runs: gloo reduces host tensors)
+            host = m8.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM)
+            m8.copy_(host)
+        else:
+            dist.all_reduce(m8, op=dist.ReduceOp.SUM)
     return m8
 
 
