@@ -43,6 +43,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
     LIB = LIB_F16 if f16 else globals()["LIB"]  # noqa: N806
     if f16:
         extra_flags = tuple(extra_flags) + ("-DHIERTCN_F16=1",)
+    if os.environ.get("HIERTCN_ABLATION"):   # ablation / timing kernel flavours (scripts/pipe_ablate.sh); never in the shipped build
+        extra_flags = tuple(extra_flags) + ("-DHIERTCN_ABLATION=1",)
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "score_geom.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]

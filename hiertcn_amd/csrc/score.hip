@@ -1132,6 +1132,9 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   if (out && out->topk > 0)  // loss.py:120 ranked indices beside rank / ce: the list kernel (slower epilogue)
     return out->topk <= 8 ? launch_score_topk<C, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev)
                           : launch_score_topk<C, 16>(m, hidden, y, R, out, st, row_map, n_rows_dev);
+#ifdef HIERTCN_ABLATION
+  // Ablation / timing flavours (profiles/r1_score_ablation.md; several give wrong results by design).  Only in libraries built with
+  // -DHIERTCN_ABLATION=1 (HIERTCN_ABLATION=1 python -m hiertcn_amd.build): the production library holds production kernels only.
   if (getenv("HIERTCN_SCORE_STAMPS")) {  // diagnostic build: per-phase cycle sums of the first workgroups, printed to stderr
     using G = ScGeom<C>;
     const int stagger_d = getenv("HIERTCN_SCORE_VARIANT") && getenv("HIERTCN_SCORE_VARIANT")[1] == '0' ? 0 : 1;
@@ -1188,22 +1191,22 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
       default: break;
     }
   }
-  if (!var || !var[0]) {   // production
-    if constexpr (C == 256)   // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
-      return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
-    else if (getenv("HIERTCN_SMALL_C_DUAL"))   // A/B
-      return launch_score_pipe<C, 12>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
-    else   // C = 64 / 128: the same four-tile seamless shape on the XOR-swizzled image (registers are not the problem here)
-      return launch_score_pipe<C, 14>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
-  }
-  int mode = 0, stagger = 1;
   if (var && var[0]) {
+    int mode = 0, stagger = 1;
     mode = var[0] - '0';
     if (var[1]) stagger = var[1] - '0';
+    if (mode == 1) return launch_score_v<C, false, 1>(m, hidden, y, R, out, nullptr, stagger, st);
+    if (mode == 2) return launch_score_v<C, false, 2>(m, hidden, y, R, out, nullptr, stagger, st);
+    return launch_score_v<C, false, 0>(m, hidden, y, R, out, nullptr, stagger, st);
   }
-  if (mode == 1) return launch_score_v<C, false, 1>(m, hidden, y, R, out, nullptr, stagger, st);
-  if (mode == 2) return launch_score_v<C, false, 2>(m, hidden, y, R, out, nullptr, stagger, st);
-  return launch_score_v<C, false, 0>(m, hidden, y, R, out, nullptr, stagger, st);
+#endif
+  // production
+  if (getenv("HIERTCN_PIPE_VARIANT") && getenv("HIERTCN_PIPE_VARIANT")[0] == '5')   // the two-tile kernel (also the FIXUP flavour), kept for A/B runs
+    return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  if constexpr (C == 256)   // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
+    return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  else   // C = 64 / 128: the same four-tile seamless shape on the XOR-swizzled image (registers are not the problem here)
+    return launch_score_pipe<C, 14>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
 }
 
 template <bool LOGITS, int MODE, int KT>
