@@ -1,0 +1,60 @@
+"""-m gpu: seeded random shapes through the whole evaluation path (hiertcn_forward_eval) against the CPU oracle -- widths, catalogue
+sizes that are not multiples of any tile, one-row batches, L on both sides of the fused low level's limit, 1..3 blocks, K = 1..6,
+HierTCN and HierGRU.  Catches shape-dependent slips the fixed fixtures cannot (tail workgroups, padding stages, peeled loops)."""
+import copy
+
+import numpy as np
+import pytest
+
+from oracle import hiertcn_oracle as O
+from tests.gpu_common import as_lists, make_batch, make_params, small_args
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _cases(n=24, seed=20261002):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        d = int(rng.choice([64, 128, 256]))
+        low = "gru" if i % 4 == 3 else "tcn"
+        H = int(rng.choice([64, 128])) if low == "gru" else int(rng.choice([32, 64]))
+        out.append(dict(d=d, H=H, low=low, N=int(rng.integers(2, 3000)), B=int(rng.integers(1, 41)), S=int(rng.integers(1, 5)),
+                        L=int(rng.integers(1, 34)), K=int(rng.integers(1, 7)), blocks=int(rng.integers(1, 4)), nl=int(rng.integers(1, 3)),
+                        seed=int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("c", _cases(), ids=lambda c: "{low}-d{d}-N{N}-B{B}-S{S}-L{L}-K{K}-b{blocks}".format(**c))
+def test_random_shape_forward_eval_matches_oracle(c):
+    from hiertcn_amd.engine import Engine, metrics_dict
+    args = copy.copy(small_args(N=c["N"], d=c["d"], H=c["H"], nl=c["nl"], blocks=c["blocks"], K=c["K"], L=c["L"], S=c["S"], B=c["B"]))
+    args.model_low_type = c["low"]
+    p = make_params(args, seed=c["seed"] % 1000)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    pr = O.round_params_bf16(p, E=c["d"])
+    rng = np.random.default_rng(c["seed"])
+    B, S, L, N = c["B"], c["S"], c["L"], c["N"]
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.25 * rng.standard_normal((B, c["H"] * c["nl"]))).astype(np.float32)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")  # noqa: E731
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+    m = metrics_dict(out["metrics8"])
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, st = O.model_hier(args, xl, yl, ml, st0, pr, O.MIRROR)
+    yy = y.reshape(B, S * L)
+    ref = O.masked_loss_and_metrics(pred, yy, N)
+    assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
+    assert abs(m["loss"] - ref["loss"]) < 1e-3, (m["loss"], ref["loss"])
+    assert m["user_count"] == float((yy > 0).any(1).sum())
+    z = pred * (yy[..., None] > 0)
+    zt = np.take_along_axis(z, yy[..., None].astype(np.int64), -1)
+    lo, hi = (z > zt + 2e-3).sum(-1), (z > zt - 2e-3).sum(-1) - 1
+    r = out["rank"].cpu().numpy().reshape(B, S * L)
+    v = yy > 0
+    assert np.all(lo[v] <= r[v]) and np.all(r[v] <= np.maximum(hi, lo)[v]) and not r[~v].any()
+    ce = out["ce"].cpu().numpy().reshape(B, S * L)
+    assert np.abs(ce - np.asarray(ref["ce"]))[v].max() < 2e-3 if v.any() else True
+    eng.close()
