@@ -58,3 +58,53 @@ def test_random_shape_forward_eval_matches_oracle(c):
     ce = out["ce"].cpu().numpy().reshape(B, S * L)
     assert np.abs(ce - np.asarray(ref["ce"]))[v].max() < 2e-3 if v.any() else True
     eng.close()
+
+
+def _train_cases(n=10, seed=4242):
+    rng = np.random.default_rng(seed)
+    out = []
+    for i in range(n):
+        low = "gru" if i % 3 == 2 else "tcn"
+        d = int(rng.choice([64, 128, 256]))
+        out.append(dict(d=d, H=int(rng.choice([64, 128])) if low == "gru" else int(rng.choice([32, 64])), low=low, N=int(rng.integers(40, 1500)),
+                        B=int(rng.integers(1, 9)), S=int(rng.integers(1, 4)), L=int(rng.integers(2, 13)), K=int(rng.integers(1, 6)),
+                        blocks=int(rng.integers(1, 4)), nl=int(rng.integers(1, 3)), seed=int(rng.integers(1 << 30))))
+    return out
+
+
+@pytest.mark.parametrize("c", _train_cases(), ids=lambda c: "{low}-d{d}-N{N}-B{B}-S{S}-L{L}-K{K}-b{blocks}-nl{nl}".format(**c))
+def test_random_shape_training_step_matches_autograd(c):
+    """Every gradient of one training step against autograd on the torch fp64 restatements (tests/test_gpu_train.py,
+    tests/test_gpu_hiergru.py), same tolerances: relative L2 < 3e-2, cosine > 0.999."""
+    from hiertcn_amd.engine import Engine, metrics_dict
+    from tests.test_gpu_hiergru import torch_loss_gru
+    from tests.test_gpu_train import torch_loss
+    args = copy.copy(small_args(N=c["N"], d=c["d"], H=c["H"], nl=c["nl"], blocks=c["blocks"], K=c["K"], L=c["L"], S=c["S"], B=c["B"]))
+    args.model_low_type = c["low"]
+    p = make_params(args, seed=c["seed"] % 1000)
+    eng = Engine(args, hier=True, train=True)
+    eng.set_weights(p)
+    rng = np.random.default_rng(c["seed"])
+    B, S, L, N = c["B"], c["S"], c["L"], c["N"]
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.25 * rng.standard_normal((B, c["H"] * c["nl"]))).astype(np.float32)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")  # noqa: E731
+    out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    grads = eng.export("grads")
+    pr = O.round_params_bf16(p, E=c["d"])
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in pr.items()}
+    ref_loss, _ = (torch_loss_gru if c["low"] == "gru" else torch_loss)(args, P, x, y, mask, st0)
+    ref_loss.backward()
+    assert abs(metrics_dict(out["metrics8"])["loss"] - float(ref_loss.detach())) < 2e-3
+    assert set(grads) == set(P)
+    bad, report = [], []
+    for k in sorted(P):
+        g, r = grads[k].astype(np.float64), (P[k].grad.numpy() if P[k].grad is not None else np.zeros(P[k].shape))
+        nr = np.linalg.norm(r)
+        rel = np.linalg.norm(g - r) / max(nr, 1e-30)
+        cos = float((g * r).sum() / max(np.linalg.norm(g) * nr, 1e-30))
+        report.append(f"{k}: rel {rel:.3e} cos {cos:.5f} |ref| {nr:.3e} |got| {np.linalg.norm(g):.3e}")
+        if (nr > 1e-9 and (rel > 3e-2 or cos < 0.999)) or (nr <= 1e-9 and np.linalg.norm(g) > 1e-7):
+            bad.append(k)
+    assert not bad, "\n".join(report)
+    eng.close()
