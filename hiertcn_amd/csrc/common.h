@@ -117,8 +117,15 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
 hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
                           hipStream_t st);
 size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
+// activations the training backward needs, written by the fused low-level kernel on the way (all [n_sessions * L][C], any may be null)
+struct TcnSaves {
+  uint16_t* emb;
+  uint16_t* a[HIERTCN_MAX_BLOCKS + 1];   // a[0]: projection output (hier), a[k + 1]: output of block k
+  uint16_t* c[HIERTCN_MAX_BLOCKS];       // relu(conv + b) of block k
+};
+bool tcn_fused_applies(const ModelDev& m, int L);
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
-                              uint16_t* hidden, void* workspace, hipStream_t st);
+                              uint16_t* hidden, void* workspace, hipStream_t st, const TcnSaves* sv = nullptr);
 // one layer of the layer-at-a-time low level (tcn_layers.hip)
 struct LayerArgs {
   const uint16_t* in;      // [n_seq * L][Cin]

@@ -35,6 +35,11 @@ struct TcnParams {
   const uint16_t* convT[HIERTCN_MAX_BLOCKS];   // [K][C][C]
   const float* conv_bias[HIERTCN_MAX_BLOCKS];  // [C]
   int n_blocks, K, pad;
+  // training (optional, all [n_sessions * L][C]): what the backward pass needs -- the embedded rows, every layer's output
+  // (save_a[0] = projection output or, single level, unused; save_a[k + 1] = output of block k) and relu(conv + b) of every block
+  uint16_t* save_emb;
+  uint16_t* save_a[HIERTCN_MAX_BLOCKS + 1];
+  uint16_t* save_c[HIERTCN_MAX_BLOCKS];
 };
 
 template <int C>
@@ -65,6 +70,7 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
     if (t >= 0 && t < L && sess < n_sessions) {
       const int id = x[sess * L + t];
       v = *reinterpret_cast<const uint4*>(p.emb + (int64_t)id * C + ch * 8);  // row 0 is stored as zeros
+      if (p.save_emb) *reinterpret_cast<uint4*>(p.save_emb + (sess * L + t) * C + ch * 8) = v;
     }
     *reinterpret_cast<uint4*>(smem + lds_off<C>(row, ch)) = v;
   }
@@ -127,6 +133,15 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
 #pragma unroll
         for (int j = 0; j < 4; j++) v[j] = acc[r][4 * q + j];
         if (!is_proj) {
+          if (p.save_c[blk]) {   // training: relu(conv + b) before the residual add (its sign pattern gates the backward pass)
+            const int64_t sess = sess0 + g0 + r;
+            if (lr < L && sess < n_sessions) {
+              uint2 co;
+              co.x = pack2bf(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+              co.y = pack2bf(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+              *reinterpret_cast<uint2*>(p.save_c[blk] + (sess * L + lr) * C + cb * 32 + 8 * q + 4 * lh) = co;
+            }
+          }
           const uint2 res = *reinterpret_cast<const uint2*>(smem + lds_off<C>(row, cb * 4 + q) + 8 * lh);
           const float r0 = bf2f((uint16_t)(res.x & 0xffff)), r1 = bf2f((uint16_t)(res.x >> 16));
           const float r2 = bf2f((uint16_t)(res.y & 0xffff)), r3 = bf2f((uint16_t)(res.y >> 16));
@@ -148,6 +163,16 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
         *reinterpret_cast<uint2*>(smem + lds_off<C>(row, cb * 4 + q) + 8 * lh) = outv[r][q];
     }
     __syncthreads();
+    uint16_t* sv = p.save_a[is_proj ? 0 : blk + 1];
+    if (sv) {   // training: this layer's output, 16 B per lane (the next layer's first barrier also covers these reads)
+      for (int i = tid; i < TCN_G * 32 * G::CH; i += TCN_THREADS) {
+        const int ch = i % G::CH, rt = i / G::CH;
+        const int g = rt >> 5, t = rt & 31;
+        const int64_t sess = sess0 + g;
+        if (t < L && sess < n_sessions)
+          *reinterpret_cast<uint4*>(sv + (sess * L + t) * C + ch * 8) = *reinterpret_cast<const uint4*>(smem + lds_off<C>(g * ROWS + p.pad + t, ch));
+      }
+    }
   }
 
   // ---- write the valid rows out, 16 B per lane, rows compacted to [session][t < L] -----------
@@ -174,6 +199,7 @@ static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float
 }
 
 #include <stdlib.h>
+#include <string.h>
 static bool use_fused(const ModelDev& m, int L) {
   static const bool force_layers = getenv("HIERTCN_FORCE_LAYERED") != nullptr;  // tests: both paths must agree bitwise
   if (force_layers) return false;
@@ -187,12 +213,20 @@ size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) {
   return use_fused(m, L) ? 0 : tcn_layers_workspace_bytes(m, n_sessions, L);
 }
 
+bool tcn_fused_applies(const ModelDev& m, int L) { return !m.low_gru && use_fused(m, L); }
+
 hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
-                              uint16_t* hidden, void* workspace, hipStream_t st) {
+                              uint16_t* hidden, void* workspace, hipStream_t st, const TcnSaves* sv) {
   if (n_sessions <= 0) return hipSuccess;
   if (m.low_gru) return launch_low_gru(m, x, sproj, n_sessions, L, hidden, workspace, st);
-  if (!use_fused(m, L)) return launch_tcn_layers(m, x, sproj, n_sessions, L, hidden, workspace, st);
+  if (!use_fused(m, L)) return sv ? hipErrorInvalidValue : launch_tcn_layers(m, x, sproj, n_sessions, L, hidden, workspace, st);
   TcnParams p;
+  memset(&p, 0, sizeof(p));
+  if (sv) {
+    p.save_emb = sv->emb;
+    for (int i = 0; i <= HIERTCN_MAX_BLOCKS; i++) p.save_a[i] = sv->a[i];
+    for (int i = 0; i < HIERTCN_MAX_BLOCKS; i++) p.save_c[i] = sv->c[i];
+  }
   p.emb = m.emb;
   p.projT = m.hier ? m.projT : nullptr;
   for (int i = 0; i < HIERTCN_MAX_BLOCKS; i++) { p.convT[i] = m.convT[i]; p.conv_bias[i] = m.conv_bias[i]; }

@@ -693,11 +693,14 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   float* gsave = F32(w.gru_save);
   uint16_t* a_emb = BF(w.act[0]);
   uint16_t* a0 = m.hier ? BF(w.act[1]) : a_emb;   // input of block 0: the projection's output, or the embedded ids themselves
-  if (!m.low_gru) T_HIP(launch_embed_rows(m, x, R, a_emb, st));
+  // equal widths and L <= 32: the fused low-level kernel of the evaluation path, writing the kept activations on its way
+  // (bitwise the layer-at-a-time kernels' values; HIERTCN_FORCE_LAYERED=1 takes those instead)
+  const bool fused_fw = tcn_fused_applies(m, L);
+  if (!m.low_gru && !fused_fw) T_HIP(launch_embed_rows(m, x, R, a_emb, st));
   if (m.hier) {
     T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
-    if (!m.low_gru) {
+    if (!m.low_gru && !fused_fw) {
       LayerArgs a = {};
       a.in = a_emb; a.out = a0; a.W = m.projT; a.seq_init = sproj;
       a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
@@ -713,7 +716,18 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(launch_low_gru_bufs(m, x, sproj, n_sess, L, BF(w.act[2]), lb, st));
   }
   auto a_of = [&](int k) -> uint16_t* { return k == 0 ? a0 : BF(w.act[1 + 2 * k]); };   // a^k: output of block k-1
-  for (int i = 0, cin = E; i < nb && !m.low_gru; cin = m.C[i], i++) {
+  if (fused_fw) {
+    TcnSaves sv;
+    memset(&sv, 0, sizeof(sv));
+    sv.emb = a_emb;
+    if (m.hier) sv.a[0] = a0;
+    for (int i = 0; i < nb; i++) {
+      sv.c[i] = BF(w.act[2 + 2 * i]);
+      if (i + 1 < nb) sv.a[i + 1] = a_of(i + 1);   // (the last block's output is the kernel's own result)
+    }
+    T_HIP(launch_tcn_forward(m, x, m.hier ? sproj : nullptr, n_sess, L, a_of(nb), nullptr, st, &sv));
+  }
+  for (int i = 0, cin = E; i < nb && !m.low_gru && !fused_fw; cin = m.C[i], i++) {
     LayerArgs a = {};
     a.in = a_of(i);
     a.c_out = BF(w.act[2 + 2 * i]);

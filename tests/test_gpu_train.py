@@ -181,14 +181,16 @@ np.savez(sys.argv[1], **{k.replace("/", "."): v for k, v in g.items()})
 ''' % root
     with tempfile.TemporaryDirectory() as tmp:
         outs = []
-        for i, env in enumerate(({}, {"HIERTCN_TRAIN_CHUNK_STAGES": "1"})):
+        # (third run: the layer-at-a-time low level instead of the fused kernel that writes the kept activations on its way)
+        for i, env in enumerate(({}, {"HIERTCN_TRAIN_CHUNK_STAGES": "1"}, {"HIERTCN_FORCE_LAYERED": "1"})):
             f = os.path.join(tmp, f"g{i}.npz")
             subprocess.run([sys.executable, "-c", code, f], check=True, env={**os.environ, **env})
             outs.append(dict(np.load(f)))
-    assert set(outs[0]) == set(outs[1])
-    for k in outs[0]:
-        a, b = outs[0][k].astype(np.float64), outs[1][k].astype(np.float64)
-        assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(a), 1e-12), k
+    for other in outs[1:]:
+        assert set(outs[0]) == set(other)
+        for k in outs[0]:
+            a, b = outs[0][k].astype(np.float64), other[k].astype(np.float64)
+            assert np.linalg.norm(a - b) <= 1e-5 * max(np.linalg.norm(a), 1e-12), k
 
 
 @pytest.mark.parametrize("low,H", [("tcn", 32), ("gru", 64)])
