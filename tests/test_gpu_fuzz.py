@@ -1,6 +1,7 @@
 """-m gpu: seeded random shapes through the whole evaluation path (hiertcn_forward_eval) against the CPU oracle -- widths, catalogue
 sizes that are not multiples of any tile, one-row batches, L on both sides of the fused low level's limit, 1..3 blocks, K = 1..6,
-HierTCN and HierGRU.  Catches shape-dependent slips the fixed fixtures cannot (tail workgroups, padding stages, peeled loops)."""
+HierTCN and HierGRU.  Catches shape-dependent slips the fixed fixtures cannot (tail workgroups, padding stages, peeled loops).
+The committed counts keep the suite short; one-off runs of 400 evaluation and 150 training shapes (other seeds) passed on MI355X."""
 import copy
 
 import numpy as np
