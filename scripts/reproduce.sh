@@ -1,0 +1,21 @@
+# Every number quoted in DESIGN.md / README.md, one command each (run on an MI355X box from the repo root; ~6 minutes).
+set -u
+python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" | tail -1
+echo "== headline (bench.py defaults: 4096 users/step, cfg-3 shape)"; python3 bench.py 2>/dev/null | tail -1 | python3 -c "
+import sys, json
+b = json.loads(sys.stdin.read()); r = b['roofline']
+print(f\"{b['value']:.0f} sessions/s, {b['ms_per_step']:.1f} ms/step; scoring {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of peak, {r['frac_of_library_gemm']:.2f} x library GEMM; cpu {b['cpu_baseline']['value']:.1f} sessions/s on {b['cpu_baseline']['cores']} cores\")"
+echo "== ragged sessions (lengths ~ U{1..30})"; python3 bench.py --ragged --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
+import sys, json; b = json.loads(sys.stdin.read()); print(f\"{b['value']:.0f} sessions/s\")"
+echo "== reference batching (32 lanes x 10 x <=20, XING catalogue)"; python3 scripts/cfg2_bench.py 2>&1 | tail -2
+echo "== scoring kernel alone, d = 256 / 128 / 64 (2,457,600 rows x 300,000 items)"
+for d in 256 128 64; do D=$d python3 scripts/score_diag.py 2457600 300000 2>&1 | tail -1 | sed "s/^/d=$d: /"; done
+echo "== d = 512, N = 1,000,000 (bf16, then the IEEE-half build)"
+D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
+DTYPE=fp16 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
+echo "== ranked top-k flavour"; python3 scripts/topk_bench.py 2>&1 | tail -3
+echo "== training step (1024 users), dense / ragged / HierGRU"
+python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
+python3 scripts/train_bench.py 1024 3 ragged 2>&1 | tail -1
+LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
+echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3
