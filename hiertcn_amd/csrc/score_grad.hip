@@ -100,7 +100,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __res
   // (uniform row pointer in an SGPR pair) + (per-lane 32-bit byte offset): no VALU address arithmetic per store
   auto put = [&](uint16_t* gtile, int k, uint32_t dw) {
     const uint16_t* rowp = gtile + (int64_t)((k & 3) + 8 * (k >> 2)) * ldg;
-    asm volatile("global_store_dword %0, %1, %2" : : "v"(voff), "v"(dw), "s"(rowp));
+    asm volatile("global_store_dword %0, %1, %2 nt" : : "v"(voff), "v"(dw), "s"(rowp));   // nt: G is written once, 17 GB per chunk
   };
   auto pack2 = [&](float lo, float hi) -> uint32_t {   // one v_cvt_pk_bf16_f32
     typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
