@@ -322,18 +322,19 @@ __global__ void k_shift_rows(const uint16_t* __restrict__ src, uint16_t* __restr
   *reinterpret_cast<uint4*>(dst + r * C + c * 8) = v;
 }
 
-// table[ids[r]][:] += rows[r][:] (fp32 atomics; id 0 = null id has no embedding: model.py:59)
-__global__ void k_scatter_add_rows(float* __restrict__ table, const int32_t* __restrict__ ids, const float* __restrict__ rows, int64_t R, int E) {
-  const int ch = E >> 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= R * ch) return;
-  const int64_t r = i / ch;
-  const int c = (int)(i - r * ch) * 4;
+// table[ids[r]][:] += rows[r][:] (fp32 atomics; id 0 = null id has no embedding: model.py:59).  One wave per row, lane e
+// takes channels e, e + 64, ...: every atomic instruction of the wave covers 256 contiguous bytes of the destination row
+// (a thread-per-float4 layout issues four strided atomics per lane and takes 4 x as long on the Zipf-distributed ids).
+__global__ __launch_bounds__(256) void k_scatter_add_rows(float* __restrict__ table, const int32_t* __restrict__ ids, const float* __restrict__ rows,
+                                                          int64_t R, int E) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
   const int id = ids[r];
   if (id <= 0) return;
-  const float4 v = *reinterpret_cast<const float4*>(rows + r * E + c);
-  float* d = table + (int64_t)id * E + c;
-  atomicAdd(d, v.x); atomicAdd(d + 1, v.y); atomicAdd(d + 2, v.z); atomicAdd(d + 3, v.w);
+  const float* src = rows + r * E;
+  float* d = table + (int64_t)id * E;
+  for (int e = lane; e < E; e += 64) atomicAdd(d + e, src[e]);
 }
 
 // dst[(b*(S+1) + s)][e] = sum_t src[((b*S + s)*L + t)][e]; row s == S of every lane = 0  (d sproj, laid out like the state history)
@@ -911,7 +912,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   }
   if (!m.hier) {
     // single-level model_tcn (model.py:56-57,71-73): block 0 reads the embedded ids directly
-    hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R * (E / 4) + 255) / 256)), dim3(256), 0, st, G + t.emb.off, x, da, R, E);
+    hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, da, R, E);
     T_HIP(hipGetLastError());
 #undef F32
 #undef BF
@@ -926,7 +927,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   T_BLAS(gemm_bf16_wgrad(bl, E, E, (int)R, a_emb, E, dub, E, G + t.projT.off, F32(w.splitk), st));
   // d e[R][Ein] = du[R][Eout] . projT[Eout][Ein]   == col-major [Ein x R] = projT(col-major [Ein x Eout]) . du^T[Eout x R]
   T_BLAS(gemm_bf16(bl, OPN, OPN, E, (int)R, E, m.projT, E, dub, E, 0.f, dprev, E));
-  hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R * (E / 4) + 255) / 256)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E);
+  hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E);
   T_HIP(hipGetLastError());
   // d sproj, laid out [B][S+1][E] like the state history (slot S = 0)
   float* dsp = F32(w.dsp_ext);
