@@ -583,10 +583,16 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // neighbours' lines in that XCD's 4 MiB L2 instead of pulling the 150 MB table through the fabric again: measured
   // 161 -> 32 GB per launch at the L2's memory-side port, L2 hit rate 76 -> 96 % (profiles/r1_score_ablation.md).
   // Price: the low bits of `ce` depend on the start offset (ranks never do); HIERTCN_FIXED_WALK=1 pins it to 0.
+  // ONE read per workgroup, shared through LDS: the position word moves while the workgroup starts, and eight waves that each read
+  // it for themselves can disagree -- they would then fill one LDS stage with pieces of two different item stages (items counted
+  // twice or not at all: ranks off by a few; found by scripts/soak_score.py at full size, not by the small race screen).
   int s0 = 0;
   if (walk_pos && !partials) {
-    s0 = __hip_atomic_load(walk_pos + (blockIdx.x & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    s0 = __builtin_amdgcn_readfirstlane(s0);
+    int* s0_sh = reinterpret_cast<int*>(smem);   // (the stage buffers are not in use yet)
+    if (tid == 0) *s0_sh = __hip_atomic_load(walk_pos + (blockIdx.x & 7) * 32, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    s0 = __builtin_amdgcn_readfirstlane(*s0_sh);
+    __syncthreads();                             // everyone has read it before the first LDS-DMA may overwrite the word
     s0 = (s0 >= 0 && s0 < n_stages) ? s0 : 0;
   }
   unsigned dma_voff[PPW];   // byte offset of this lane's 16 B of piece i inside a stage of outT (source-side swizzle applied)

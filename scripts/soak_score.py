@@ -1,0 +1,24 @@
+import sys, time
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+from hiertcn_amd.args import hier_tcn_args
+from hiertcn_amd.engine import Engine
+from hiertcn_amd.params import init_params
+for d, N, rows in ((256, 300000, 2457600), (128, 300000, 1228800), (512, 200000, 614400), (64, 100000, 1228800)):
+    args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, tcn_channel=[d, d])
+    eng = Engine(args); eng.set_weights(init_params(args, 2))
+    hid = (torch.randn(rows, d, device="cuda") * 0.5).to(eng.act_dtype)
+    y = torch.randint(1, N, (rows,), device="cuda", dtype=torch.int32)
+    ref = eng.score_fused(hid, y, want_target=True)
+    r0, c0, t0 = ref["rank"].clone(), ref["ce"].clone(), ref["target"].clone()
+    bad = 0
+    for i in range(12):
+        out = eng.score_fused(hid, y, want_target=True)
+        nr = int((out["rank"] != r0).sum()); nt = int((out["target"] != t0).sum()); dc = (out["ce"] - c0).abs().max().item()
+        if nr or nt or dc > 2e-5:
+            bad += 1
+            if bad <= 3:
+                idx = (out["rank"] != r0).nonzero().flatten()[:5].tolist()
+                print(f"   launch {i}: rank diffs {nr}, target diffs {nt}, max |dce| {dc:.3e}; rows {idx}: {[(int(out['rank'][j]), int(r0[j])) for j in idx]}", flush=True)
+    print(f"d={d} N={N} rows={rows}: {bad} mismatching launches of 12; ce spread ok", flush=True)
+    eng.close()

@@ -535,3 +535,33 @@ def test_race_screen_repeated_launches_agree(R, N, d):
         if "topk_idx" in a:
             assert torch.equal(a["topk_idx"], t0), i
     eng.close()
+
+
+@pytest.mark.parametrize("d,N,R", [(256, 60_000, 1_228_800), (128, 60_000, 1_228_800), (512, 40_000, 614_400)])
+def test_ranks_do_not_depend_on_the_item_walk_at_scale(d, N, R):
+    """Thousands of workgroups in flight, each entering the item table where its XCD's neighbours are (score.hip, walk_pos): the
+    integer outputs must not depend on that start (ce may, in its low bits).  A launch this size is needed: the start word moves
+    while a workgroup starts, and waves that each read it for themselves once disagreed -- ranks off by a few in most rows at
+    2.4 M rows, invisible at the 20,000 rows of the small race screen."""
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine
+    from hiertcn_amd.params import init_params
+    args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, tcn_channel=[d, d])
+    eng = Engine(args)
+    eng.set_weights(init_params(args, 2))
+    g = torch.Generator(device="cuda").manual_seed(5)
+    hid = (torch.randn(R, d, device="cuda", generator=g) * 0.5).to(eng.act_dtype)
+    y = torch.randint(1, N, (R,), device="cuda", dtype=torch.int32, generator=g)
+    ref = eng.score_fused(hid, y, want_target=True)
+    r0, c0, t0 = ref["rank"].clone(), ref["ce"].clone(), ref["target"].clone()
+    for _ in range(6):
+        out = eng.score_fused(hid, y, want_target=True)
+        assert torch.equal(out["rank"], r0)
+        assert torch.equal(out["target"], t0)
+        assert (out["ce"] - c0).abs().max().item() < 1e-4
+    # and against a count over materialised logits on a sample of rows
+    idx = torch.randint(0, R, (256,), device="cuda", generator=g)
+    logits = eng.score_logits(hid[idx].contiguous())
+    tgt = logits.gather(1, y[idx].long()[:, None])
+    assert torch.equal((logits > tgt).sum(1).int(), r0[idx])
+    eng.close()
