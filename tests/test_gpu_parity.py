@@ -565,3 +565,43 @@ def test_ranks_do_not_depend_on_the_item_walk_at_scale(d, N, R):
     tgt = logits.gather(1, y[idx].long()[:, None])
     assert torch.equal((logits > tgt).sum(1).int(), r0[idx])
     eng.close()
+
+
+@pytest.mark.parametrize("ragged", [False, True])
+def test_forward_eval_at_scale_is_self_consistent(ragged):
+    """1024 lanes x 20 x 30 (614,400 rows), N = 60,000, d = 256 through hiertcn_forward_eval: the lane aggregation (8 sums), the row
+    compaction of a ragged batch and the scoring outputs must agree with each other at a size where thousands of workgroups run."""
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine, metrics_dict
+    from hiertcn_amd.params import init_params
+    B, S, L, N, d = 1024, 20, 30, 60_000, 256
+    args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, tcn_channel=[d, d], max_activity_len=L, max_session_num=S, batch_size=B)
+    eng = Engine(args)
+    eng.set_weights(init_params(args, 2))
+    rng = np.random.default_rng(77)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=ragged, zipf=True)
+    st0 = np.zeros((B, eng.HT), np.float32)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+    m = metrics_dict(out["metrics8"])
+    rk = out["rank"].double().view(B, S * L)
+    ce = out["ce"].double().view(B, S * L)
+    yv = (dev(y).view(B, S * L) > 0).double()
+    act = yv.sum(1)
+    users = (act > 0).sum()
+    mean = lambda v: float((((v * yv).sum(1) / (act + 1e-6))[act > 0]).sum() / users)  # noqa: E731
+    # (1e-7: the + 1e-6 of model.py:114 is below fp32 resolution at 600 valid steps; fp32 and fp64 evaluations differ by that much)
+    assert abs(m["loss"] - mean(ce)) < 1e-7 * max(1.0, abs(m["loss"]))
+    assert abs(m["recall10"] - mean((rk <= 9).double())) < 1e-7
+    assert abs(m["mrr"] - mean(1.0 / (1.0 + rk))) < 1e-7
+    assert m["user_count"] == float(users)
+    assert not out["rank"].view(B, S * L)[yv == 0].any() and not out["ce"].view(B, S * L)[yv == 0].any()
+    # the rows' ranks are counts over the HIP path's own logits (sampled rows: the logits are 240 KB per row)
+    pooled = eng.session_pool(dev(y).view(B * S, L)).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    hid = eng.tcn_forward(dev(x).view(B * S, L), sproj.view(B * S, -1))
+    yy = dev(y).view(-1)
+    idx = torch.nonzero(yy > 0).flatten()[:: max(1, int((yy > 0).sum()) // 300)][:300]
+    logits = eng.score_logits(hid[idx].contiguous())
+    tgt = logits.gather(1, yy[idx].long()[:, None])
+    assert torch.equal((logits > tgt).sum(1).int(), out["rank"].view(-1)[idx])
+    eng.close()
