@@ -19,3 +19,4 @@ python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 python3 scripts/train_bench.py 1024 3 ragged 2>&1 | tail -1
 LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
 echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3
+echo "== repeated full-size launches agree (ranks, target logits bitwise; ce to 5e-5)"; python3 scripts/soak_score.py 2>&1 | grep mismatching
