@@ -605,3 +605,23 @@ def test_forward_eval_at_scale_is_self_consistent(ragged):
     tgt = logits.gather(1, yy[idx].long()[:, None])
     assert torch.equal((logits > tgt).sum(1).int(), out["rank"].view(-1)[idx])
     eng.close()
+
+
+def test_side_stream_calls_match_default_stream(setup):
+    """Every C-ABI call enqueues on the caller's stream (include/hiertcn.h): the same evaluation and training-free scoring calls issued
+    on a non-default stream give the default stream's results (event timing and the fix-up launch follow the stream too)."""
+    s = setup
+    eng = s["eng"]
+    args = (dev(s["x"]), dev(s["y"]), dev(s["mask"]), dev(s["st0"]))
+    ref = eng.forward_eval(*args, want_rows=True)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        out = eng.forward_eval(*args, want_rows=True)
+        top = eng.forward_eval(*args, topk=5)
+    side.synchronize()
+    assert torch.equal(out["rank"], ref["rank"])
+    assert (out["ce"] - ref["ce"]).abs().max().item() < 2e-5
+    assert torch.equal(out["state"], ref["state"])
+    assert (out["metrics8"] - ref["metrics8"]).abs().max().item() < 1e-6
+    assert top["topk_idx"].shape[-1] == 5
