@@ -22,3 +22,22 @@ for d, N, rows in ((256, 300000, 2457600), (128, 300000, 1228800), (512, 200000,
                 print(f"   launch {i}: rank diffs {nr}, target diffs {nt}, max |dce| {dc:.3e}; rows {idx}: {[(int(out['rank'][j]), int(r0[j])) for j in idx]}", flush=True)
     print(f"d={d} N={N} rows={rows}: {bad} mismatching launches of 12; ce spread ok", flush=True)
     eng.close()
+
+# exhaustive: every row of a large launch against a count / log-sum-exp over the HIP path's own materialised logits
+d, N, rows = 256, 300000, 1228800
+args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, tcn_channel=[d, d])
+eng = Engine(args); eng.set_weights(init_params(args, 2))
+hid = (torch.randn(rows, d, device="cuda") * 0.5).to(eng.act_dtype)
+y = torch.randint(1, N, (rows,), device="cuda", dtype=torch.int32)
+out = eng.score_fused(hid, y, want_target=True)
+bad_rank = bad_tgt = 0
+worst_ce = 0.0
+for i in range(0, rows, 8192):
+    z = eng.score_logits(hid[i:i + 8192].contiguous())
+    t = z.gather(1, y[i:i + 8192].long()[:, None])
+    bad_rank += int(((z > t).sum(1).int() != out["rank"][i:i + 8192]).sum())
+    bad_tgt += int((t[:, 0] != out["target"][i:i + 8192]).sum())
+    lse = torch.logsumexp(z.double(), 1)
+    worst_ce = max(worst_ce, float(((lse - t[:, 0].double()) - out["ce"][i:i + 8192].double()).abs().max()))
+    del z
+print(f"exhaustive d={d} N={N} rows={rows}: rank mismatches {bad_rank}, target mismatches {bad_tgt}, worst |ce - (lse - t)| {worst_ce:.3e}", flush=True)
