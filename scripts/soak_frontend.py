@@ -1,0 +1,22 @@
+import os, sys
+sys.path.insert(0, "/root/repo")
+import numpy as np, torch
+import bench
+from hiertcn_amd.args import hier_tcn_args
+from hiertcn_amd.engine import Engine
+from hiertcn_amd.params import init_params
+B = 4096
+N, d, S, L = 60000, bench.DIM, bench.S_SESS, bench.L_STEPS
+args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L, max_session_num=S, batch_size=B)
+eng = Engine(args, hier=True); eng.set_weights(init_params(args, seed=2))
+rng = np.random.default_rng(0)
+ids = rng.integers(1, N, (B, S, L)).astype(np.int32)
+x = np.zeros_like(ids); x[:, :, 1:] = ids[:, :, :-1]
+mask = (rng.random((B, S)) > 0.1).astype(np.float32)
+xd, yd, md = (torch.from_numpy(v).cuda() for v in (x, ids, mask))
+st0 = (0.1 * torch.randn((B, eng.HT), device="cuda", generator=torch.Generator(device="cuda").manual_seed(1))).float()
+pooled = eng.session_pool(yd.view(B * S, L)).view(B, S, -1)
+sproj, st_out, _ = eng.gru_scan(pooled, md, st0)
+hid = eng.tcn_forward(xd.view(B * S, L), sproj.view(B * S, -1))
+h = hid.view(torch.int16).to(torch.int64)
+print("pooled", float(pooled.double().sum()), "state", float(st_out.double().sum()), "hidden-bits", int(h.sum()), int((h * (torch.arange(h.numel(), device="cuda").view_as(h) % 1009)).sum()))
