@@ -20,3 +20,16 @@ sproj, st_out, _ = eng.gru_scan(pooled, md, st0)
 hid = eng.tcn_forward(xd.view(B * S, L), sproj.view(B * S, -1))
 h = hid.view(torch.int16).to(torch.int64)
 print("pooled", float(pooled.double().sum()), "state", float(st_out.double().sum()), "hidden-bits", int(h.sum()), int((h * (torch.arange(h.numel(), device="cuda").view_as(h) % 1009)).sum()))
+
+# the scan at this size against the CPU oracle (fp64): pooled rows and the carried state
+from oracle import hiertcn_oracle as O   # (a script, not the product: the oracle is the checker here as in tests/)
+p = init_params(args, seed=2)
+pr = O.round_params_bf16(p, E=d)
+stn = st0.cpu().numpy().astype(np.float64)
+worst_pool = 0.0
+for s in range(S):
+    pl = O.session_mean_pool(ids[:, s], pr)
+    worst_pool = max(worst_pool, float(np.abs(pl - pooled[:, s].cpu().numpy()).max()))
+    _, stn = O.multi_rnn_cell(pl, stn, pr, args.hidden_dim, args.num_layer)
+    stn = stn * mask[:, s:s + 1]
+print("vs oracle at B=%d: pooled max abs diff %.3e, final state max abs diff %.3e" % (B, worst_pool, float(np.abs(stn - st_out.cpu().numpy()).max())))
