@@ -22,12 +22,26 @@
 // stages (1024 items) per part, at most 32 parts.  1 = no split (large batches fill the chip with row tiles alone).
 int score_split_parts(int64_t R, int NP) {
   const int64_t tiles = (R + SC_THREADS - 1) / SC_THREADS;
-  if (tiles >= 128) return 1;
-  int64_t parts = (256 + tiles - 1) / tiles;
   const int64_t by_len = (NP / SC_STAGE) / 16;
-  if (parts > by_len) parts = by_len;
-  if (parts > 32) parts = 32;
-  return parts < 1 ? 1 : (int)parts;
+  if (tiles < 128) {
+    int64_t parts = (256 + tiles - 1) / tiles;
+    if (parts > by_len) parts = by_len;
+    if (parts > 32) parts = 32;
+    return parts < 1 ? 1 : (int)parts;
+  }
+  // Mid-size batches: a few rounds of 256 workgroups, the last one partly empty (600 row tiles = 2.34 rounds: the chip idles for
+  // 22 % of the launch).  Splitting the catalogue in p parts makes p x more, p x shorter workgroups: take the smallest p <= 4 whose
+  // last round is at least 93 % full, else the best one.
+  if (tiles >= 2048 || getenv("HIERTCN_NO_MIDSPLIT")) return 1;
+  int best = 1;
+  double best_eff = 0.0;
+  for (int p = 1; p <= 4 && p <= by_len; p++) {
+    const double rounds = (double)(tiles * p) / 256.0;
+    const double eff = rounds / (double)((tiles * p + 255) / 256);
+    if (eff >= 0.93) return p;
+    if (eff > best_eff) { best_eff = eff; best = p; }
+  }
+  return best;
 }
 
 typedef __attribute__((address_space(3))) void lds_void;
