@@ -13,6 +13,8 @@
 //     neighbouring items and every global_store_dword of a half-wave is one full 128-byte line of a G row.
 // The one-hot term touches one element per row: k_dlogits_target rewrites G[r][y_r] (and d bo[y_r]) afterwards from the
 // target logit the forward pass saved -- bitwise the value the row's own MFMA chain would give (score.hip file header).
+#include <stdlib.h>
+
 #include "score_geom.h"
 
 // v2 of the kernel body (v1: two accumulator tiles, XOR-swizzled image, 114 ms per cfg-3 step): the four-tile seamless shape of the
@@ -26,6 +28,19 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __res
                                                            uint16_t* __restrict__ gout, int64_t ldg, float* __restrict__ dbias) {
   using G = ScGeom<C>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];  // 3 stages of 64 rows + 3 x 64 row scalars
+  // gridDim.y > 1 splits the ROW stages of the chunk: the item dimension alone gives N / 512 workgroups (586 at N = 300k: 2.3
+  // rounds of 256 CUs, the last one 29 % full); workgroup (x, p) makes the G rows of stages [p * per, (p + 1) * per) for its items
+  // and adds its column sums to d bo atomically.
+  if (gridDim.y > 1) {
+    const int per = (n_stages + (int)gridDim.y - 1) / (int)gridDim.y;
+    const int s_lo = (int)blockIdx.y * per;
+    const int s_hi = (s_lo + per < n_stages) ? s_lo + per : n_stages;
+    if (s_hi <= s_lo) return;
+    hrows += (int64_t)s_lo * SC_STAGE * C;
+    rowbias += (int64_t)s_lo * SC_STAGE;
+    gout += (int64_t)s_lo * SC_STAGE * ldg;
+    n_stages = s_hi - s_lo;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -201,8 +216,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_dlogits(const uint16_t* __res
   {
     const float t0 = cs0 + __shfl_xor(cs0, 32), t1 = cs1 + __shfl_xor(cs1, 32);
     const int it = item_base + 2 * lr;
-    if (lh == 0 && it < N) dbias[it] += t0;   // one owner per item and launch; launches of a step are stream-ordered
-    if (lh == 0 && it + 1 < N) dbias[it + 1] += t1;
+    if (gridDim.y > 1) {
+      if (lh == 0 && it < N) atomicAdd(dbias + it, t0);
+      if (lh == 0 && it + 1 < N) atomicAdd(dbias + it + 1, t1);
+    } else {
+      if (lh == 0 && it < N) dbias[it] += t0;   // one owner per item and launch; launches of a step are stream-ordered
+      if (lh == 0 && it + 1 < N) dbias[it + 1] += t1;
+    }
   }
 }
 
@@ -236,7 +256,17 @@ static hipError_t launch_dlogits_c(const ModelDev& m, const uint16_t* hrows, con
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_dlogits<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   const unsigned blocks = (unsigned)((m.NP + 511) / 512);
-  hipLaunchKernelGGL(k_dlogits<C>, dim3(blocks), dim3(SC_THREADS), lds, st, hrows, rowbias, n_stages, m.outT, m.out_bias, m.N, m.NP, gout, ldg,
+  // row parts: the smallest p <= 8 (each part at least 32 stages) that fills the last round of 256 workgroups to >= 93 %
+  unsigned parts = 1;
+  if (!getenv("HIERTCN_DLOGITS_NOSPLIT")) {
+    double best = 0.0;
+    for (unsigned p = 1; p <= 8 && (p == 1 || n_stages / (int)p >= 32); p++) {
+      const double eff = ((double)blocks * p / 256.0) / (double)((blocks * p + 255) / 256);
+      if (eff > best + 1e-9) { best = eff; parts = p; }
+      if (eff >= 0.93) break;
+    }
+  }
+  hipLaunchKernelGGL(k_dlogits<C>, dim3(blocks, parts), dim3(SC_THREADS), lds, st, hrows, rowbias, n_stages, m.outT, m.out_bias, m.N, m.NP, gout, ldg,
                      dbias);
   return hipGetLastError();
 }
