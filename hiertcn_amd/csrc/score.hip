@@ -24,7 +24,7 @@ int score_split_parts(int64_t R, int NP) {
   const int64_t tiles = (R + SC_THREADS - 1) / SC_THREADS;
   const int64_t by_len = (NP / SC_STAGE) / 16;
   if (tiles < 128) {
-    int64_t parts = (256 + tiles - 1) / tiles;
+    int64_t parts = 256 / tiles;   // floor: tiles x parts workgroups must fit ONE round of 256 (13 tiles x 20 parts = 260 took two)
     if (parts > by_len) parts = by_len;
     if (parts > 32) parts = 32;
     return parts < 1 ? 1 : (int)parts;
