@@ -39,12 +39,22 @@ def build_all(force: bool = False, verbose: bool = False):
 
 
 def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: bool = False) -> str:
-    OBJ = os.path.join(HERE, "build", "f16") if f16 else os.path.join(HERE, "build")  # noqa: N806
     LIB = LIB_F16 if f16 else globals()["LIB"]  # noqa: N806
     if f16:
         extra_flags = tuple(extra_flags) + ("-DHIERTCN_F16=1",)
-    if os.environ.get("HIERTCN_ABLATION"):   # ablation / timing kernel flavours (scripts/pipe_ablate.sh); never in the shipped build
+    ablation = bool(os.environ.get("HIERTCN_ABLATION"))
+    if ablation:   # ablation / timing kernel flavours (scripts/pipe_ablate.sh); never in the shipped build
         extra_flags = tuple(extra_flags) + ("-DHIERTCN_ABLATION=1",)
+    # objects live in a directory keyed on the flag set, and the library remembers which flag set it was linked from:
+    # an ablation build can never leave objects (or a library) behind that a later plain build would ship as fresh
+    OBJ = os.path.join(HERE, "build", *(["ablation"] if ablation else []), *(["f16"] if f16 else []))  # noqa: N806
+    flagset = " ".join([*FLAGS, *extra_flags])
+    stamp = LIB + ".flags"
+    try:
+        with open(stamp) as f:
+            relink = f.read() != flagset
+    except OSError:
+        relink = True
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
     headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "score_geom.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
@@ -72,12 +82,14 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
         with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
-    if force or jobs or _stale(LIB, objs):
+    if force or jobs or relink or _stale(LIB, objs):
         # rocBLAS: plain GEMMs of the training backward pass only (csrc/train.hip)
         cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (r.stdout, r.stderr))
+        with open(stamp, "w") as f:
+            f.write(flagset)
     return LIB
 
 

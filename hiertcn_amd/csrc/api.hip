@@ -4,6 +4,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -50,6 +51,24 @@ static hipError_t dev_alloc(hiertcn_ctx* c, T** out, size_t count) {
   *out = reinterpret_cast<T*>(p);
   return hipSuccess;
 }
+
+// Every entry point that touches the device runs on the handle's device, whatever the caller's current device is (a second
+// handle on another GPU in the same process must not launch on the first one's device); the caller's device is restored on exit.
+struct DeviceGuard {
+  int prev = -1;
+  bool ok = true;
+  explicit DeviceGuard(int dev) {
+    if (hipGetDevice(&prev) != hipSuccess) { ok = false; return; }
+    if (prev != dev && hipSetDevice(dev) != hipSuccess) ok = false;
+    if (prev == dev) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+};
+#define ON_DEVICE(h)                                                                       \
+  DeviceGuard guard_((h)->device);                                                         \
+  if (!guard_.ok) return fail(HIERTCN_ERR_HIP, "cannot switch to the handle's device %d", (h)->device)
 
 extern "C" {
 
@@ -164,6 +183,13 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
     }
   }
   ALLOC_OR_FAIL(c->metric_scratch, (size_t)8 * HIERTCN_METRIC_BLOCKS_MAX);
+  if (!getenv("HIERTCN_FIXED_WALK")) {   // the scoring kernel's per-XCD item-walk words live with the handle, i.e. on ITS device
+    ALLOC_OR_FAIL(m.walk_pos, (size_t)8 * 32);
+    if (hipMemset(m.walk_pos, 0, 8 * 32 * sizeof(int)) != hipSuccess) {
+      hiertcn_destroy(c);
+      return fail(HIERTCN_ERR_HIP, "hipMemset(walk_pos) failed");
+    }
+  }
 #undef ALLOC_OR_FAIL
   *out = c;
   return HIERTCN_OK;
@@ -171,6 +197,7 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
 
 int hiertcn_destroy(hiertcn_handle_t h) {
   if (!h) return HIERTCN_OK;
+  DeviceGuard guard_(h->device);
   train_destroy(h->train);
   for (void* p : h->allocs) (void)hipFree(p);
   for (hipEvent_t e : h->ev_begin) (void)hipEventDestroy(e);
@@ -187,6 +214,7 @@ int hiertcn_get_config(hiertcn_handle_t h, hiertcn_config_t* out) {
 
 int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* stream) {
   if (!h || !w) return fail(HIERTCN_ERR_INVALID, "null argument");
+  ON_DEVICE(h);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   ModelDev& m = h->m;
   const int E = m.E;
@@ -243,7 +271,8 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
   do {                                                                        \
     if (!(h)) return fail(HIERTCN_ERR_INVALID, "null handle");                \
     if (!(h)->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_set_weights has not been called"); \
-  } while (0)
+  } while (0);                                                                \
+  ON_DEVICE(h)
 
 int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_sessions, int32_t L, float* pooled, void* stream) {
   CHECK_READY(h);
@@ -338,6 +367,7 @@ int hiertcn_metrics(hiertcn_handle_t h, const int32_t* rank, const float* ce, co
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (!rank || !ce || !y_ids || !out8 || B < 1 || T < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  ON_DEVICE(h);
   HIP_TRY(launch_metrics_scratch(h->m, rank, ce, y_ids, B, T, out8, h->metric_scratch, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
@@ -437,6 +467,7 @@ int hiertcn_train_enable(hiertcn_handle_t h) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (h->train.enabled) return HIERTCN_OK;
   if (h->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_train_enable must precede hiertcn_set_weights (the fp32 masters are filled there)");
+  ON_DEVICE(h);
   HIP_TRY(train_enable(h->m, h->train));
   return HIERTCN_OK;
 }
@@ -506,6 +537,7 @@ int hiertcn_timing_enable(hiertcn_handle_t h, int32_t on) {
 
 int hiertcn_timing_read(hiertcn_handle_t h, double* score_ms_avg, int64_t* launches, int32_t reset) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
+  ON_DEVICE(h);
   double total = 0.0;
   for (size_t i = 0; i < h->ev_used; i++) {
     HIP_TRY(hipEventSynchronize(h->ev_end[i]));

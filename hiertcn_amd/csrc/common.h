@@ -80,6 +80,7 @@ struct ModelDev {
   float* lgru_bg[HIERTCN_MAX_LAYERS];
   float* lgru_wc[HIERTCN_MAX_LAYERS];
   float* lgru_bc[HIERTCN_MAX_LAYERS];
+  int* walk_pos;        // [8][32] ints, zeroed: per-XCD position words of the scoring kernel's item walk (null: every workgroup starts at stage 0)
 };
 
 // launchers implemented in the kernel files (all asynchronous on `st`)

@@ -14,7 +14,7 @@
 // covers 8 bf16 channels; E/8 lanes cover a row, 64/(E/8) rows are in flight per instruction.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_session_pool(const uint16_t* __restrict__ emb, const float* __restrict__ emb_bias,
-                                                      const int32_t* __restrict__ y, int64_t n_sessions, int L, int E,
+                                                      const int32_t* __restrict__ y, int64_t n_sessions, int L, int E, int N,
                                                       float* __restrict__ pooled) {
   const int lane = threadIdx.x & 63;
   const int64_t sess = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -31,7 +31,7 @@ __global__ __launch_bounds__(256) void k_session_pool(const uint16_t* __restrict
   for (int t0 = 0; t0 < L; t0 += rows_per_pass) {
     int t = t0 + sub;
     int id = (t < L && sub < rows_per_pass) ? ys[t] : 0;
-    if (id > 0) {
+    if (id > 0 && id < N) {   // an id >= N is a zero one-hot row: no embedding, not counted (model_hier.py:83)
       cnt++;
       uint4 v = *reinterpret_cast<const uint4*>(emb + (int64_t)id * E + ch * 8);
       uint32_t w[4] = {v.x, v.y, v.z, v.w};
@@ -65,7 +65,7 @@ __global__ __launch_bounds__(256) void k_session_pool(const uint16_t* __restrict
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st) {
   if (n_sessions <= 0) return hipSuccess;
   unsigned blocks = (unsigned)((n_sessions + 3) / 4);
-  hipLaunchKernelGGL(k_session_pool, dim3(blocks), dim3(256), 0, st, m.emb, m.emb_bias, y, n_sessions, L, m.E, pooled);
+  hipLaunchKernelGGL(k_session_pool, dim3(blocks), dim3(256), 0, st, m.emb, m.emb_bias, y, n_sessions, L, m.E, m.N, pooled);
   return hipGetLastError();
 }
 

@@ -1059,8 +1059,6 @@ __global__ void k_score_merge(const float* __restrict__ partials, int parts, int
   o_ce[row] = valid ? (M + log2f(S)) * LN2_F - tgt[row] : 0.f;
 }
 
-__device__ int g_walk_pos[8 * 32];
-
 template <int C, int NB, int NSTG, bool PAD>
 static hipError_t launch_score_fixup(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                                      hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev, int* walk) {
@@ -1085,12 +1083,7 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
   const unsigned blocks = (unsigned)((R + 256 * NB - 1) / (256 * NB));
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  static int* walk = nullptr;
-  static bool walk_init = false;
-  if (!walk_init) {
-    walk_init = true;
-    if (!getenv("HIERTCN_FIXED_WALK")) (void)hipGetSymbolAddress(reinterpret_cast<void**>(&walk), HIP_SYMBOL(g_walk_pos));
-  }
+  int* walk = m.walk_pos;   // owned by the handle (per device): hiertcn_create; null with HIERTCN_FIXED_WALK=1
   const int parts = score_split_parts(R, m.NP);
   if ((PMODE == 5 || PMODE >= 7) && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     const int n_all = m.NP / SC_STAGE;

@@ -35,6 +35,7 @@ struct TcnParams {
   const uint16_t* convT[HIERTCN_MAX_BLOCKS];   // [K][C][C]
   const float* conv_bias[HIERTCN_MAX_BLOCKS];  // [C]
   int n_blocks, K, pad;
+  int N;                                       // item_num: ids outside [0, N) embed like the null id
   // training (optional, all [n_sessions * L][C]): what the backward pass needs -- the embedded rows, every layer's output
   // (save_a[0] = projection output or, single level, unused; save_a[k + 1] = output of block k) and relu(conv + b) of every block
   uint16_t* save_emb;
@@ -68,7 +69,8 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
     const int t = r - p.pad;
     const int64_t sess = sess0 + g;
     if (t >= 0 && t < L && sess < n_sessions) {
-      const int id = x[sess * L + t];
+      int id = x[sess * L + t];
+      id = (unsigned)id < (unsigned)p.N ? id : 0;   // out of range = null id: tf.one_hot gives a zero row (model.py:59)
       v = *reinterpret_cast<const uint4*>(p.emb + (int64_t)id * C + ch * 8);  // row 0 is stored as zeros
       if (p.save_emb) *reinterpret_cast<uint4*>(p.save_emb + (sess * L + t) * C + ch * 8) = v;
     }
@@ -230,7 +232,7 @@ hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* 
   p.emb = m.emb;
   p.projT = m.hier ? m.projT : nullptr;
   for (int i = 0; i < HIERTCN_MAX_BLOCKS; i++) { p.convT[i] = m.convT[i]; p.conv_bias[i] = m.conv_bias[i]; }
-  p.n_blocks = m.n_blocks; p.K = m.K;
+  p.n_blocks = m.n_blocks; p.K = m.K; p.N = m.N;
   int halo = (m.K - 1) * (1 << (m.n_blocks - 1));
   p.pad = (halo + 7) & ~7;
   switch (m.E) {

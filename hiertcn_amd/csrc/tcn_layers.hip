@@ -102,20 +102,21 @@ __global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
 
 // ids [R] -> rows [R][E] bf16: the one-hot "lookup" of model.py:56-61 + model_tcn.py:35 / model_hier.py:50
 // (row 0 of the table is stored as zeros).  HBM/L2-bound gather, 16 B per lane.
-__global__ __launch_bounds__(256) void k_embed_rows(const uint16_t* __restrict__ emb, const int32_t* __restrict__ ids, int64_t R, int E,
+__global__ __launch_bounds__(256) void k_embed_rows(const uint16_t* __restrict__ emb, const int32_t* __restrict__ ids, int64_t R, int E, int N,
                                                     uint16_t* __restrict__ out) {
   const int ch = E >> 3;
   const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if (i >= R * ch) return;
   const int64_t r = i / ch;
   const int c = (int)(i - r * ch);
-  const int id = ids[r];
+  int id = ids[r];
+  id = (unsigned)id < (unsigned)N ? id : 0;   // out of range = null id: tf.one_hot gives a zero row (model.py:59)
   *reinterpret_cast<uint4*>(out + r * E + c * 8) = *reinterpret_cast<const uint4*>(emb + (int64_t)id * E + c * 8);
 }
 
 hipError_t launch_embed_rows(const ModelDev& m, const int32_t* ids, int64_t R, uint16_t* out, hipStream_t st) {
   const int64_t n = R * (m.E / 8);
-  hipLaunchKernelGGL(k_embed_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.emb, ids, R, m.E, out);
+  hipLaunchKernelGGL(k_embed_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.emb, ids, R, m.E, m.N, out);
   return hipGetLastError();
 }
 
@@ -145,7 +146,7 @@ hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* s
   int cur = 0;
   {
     const int64_t n = R * (m.E / 8);
-    hipLaunchKernelGGL(k_embed_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.emb, x, R, m.E, buf[cur]);
+    hipLaunchKernelGGL(k_embed_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.emb, x, R, m.E, m.N, buf[cur]);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }

@@ -326,12 +326,12 @@ __global__ void k_shift_rows(const uint16_t* __restrict__ src, uint16_t* __restr
 // takes channels e, e + 64, ...: every atomic instruction of the wave covers 256 contiguous bytes of the destination row
 // (a thread-per-float4 layout issues four strided atomics per lane and takes 4 x as long on the Zipf-distributed ids).
 __global__ __launch_bounds__(256) void k_scatter_add_rows(float* __restrict__ table, const int32_t* __restrict__ ids, const float* __restrict__ rows,
-                                                          int64_t R, int E) {
+                                                          int64_t R, int E, int N) {
   const int lane = threadIdx.x & 63;
   const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (r >= R) return;
   const int id = ids[r];
-  if (id <= 0) return;
+  if (id <= 0 || id >= N) return;   // null / out-of-range ids have no embedding row (the arena's next segment starts right behind the table)
   const float* src = rows + r * E;
   float* d = table + (int64_t)id * E;
   for (int e = lane; e < E; e += 64) atomicAdd(d + e, src[e]);
@@ -355,18 +355,18 @@ __global__ void k_segment_sum(const float* __restrict__ src, int B, int S, int L
 
 // session mean-pool backward (model_hier.py:83-85): table[y[sess][t]] += dpooled[sess] / cnt for valid t
 __global__ __launch_bounds__(256) void k_pool_bwd(float* __restrict__ table, const int32_t* __restrict__ y, const float* __restrict__ dpooled,
-                                                  int64_t n_sessions, int L, int E) {
+                                                  int64_t n_sessions, int L, int E, int N) {
   const int64_t sess = blockIdx.x;
   if (sess >= n_sessions) return;
   int cnt = 0;
-  for (int t = 0; t < L; t++) cnt += y[sess * L + t] > 0 ? 1 : 0;
+  for (int t = 0; t < L; t++) cnt += (y[sess * L + t] > 0 && y[sess * L + t] < N) ? 1 : 0;
   if (cnt == 0) return;
   const float inv = 1.0f / (float)cnt;
   for (int e = threadIdx.x; e < E; e += 256) {
     const float g = dpooled[sess * E + e] * inv;
     for (int t = 0; t < L; t++) {
       const int id = y[sess * L + t];
-      if (id > 0) atomicAdd(table + (int64_t)id * E + e, g);
+      if (id > 0 && id < N) atomicAdd(table + (int64_t)id * E + e, g);
     }
   }
 }
@@ -912,7 +912,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   }
   if (!m.hier) {
     // single-level model_tcn (model.py:56-57,71-73): block 0 reads the embedded ids directly
-    hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, da, R, E);
+    hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, da, R, E, m.N);
     T_HIP(hipGetLastError());
 #undef F32
 #undef BF
@@ -927,7 +927,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   T_BLAS(gemm_bf16_wgrad(bl, E, E, (int)R, a_emb, E, dub, E, G + t.projT.off, F32(w.splitk), st));
   // d e[R][Ein] = du[R][Eout] . projT[Eout][Ein]   == col-major [Ein x R] = projT(col-major [Ein x Eout]) . du^T[Eout x R]
   T_BLAS(gemm_bf16(bl, OPN, OPN, E, (int)R, E, m.projT, E, dub, E, 0.f, dprev, E));
-  hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E);
+  hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E, m.N);
   T_HIP(hipGetLastError());
   // d sproj, laid out [B][S+1][E] like the state history (slot S = 0)
   float* dsp = F32(w.dsp_ext);
@@ -996,7 +996,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   }
   // ================= session mean-pool + 'emb' bias (model_hier.py:83-85) ================================
   T_HIP(colsum_f32(dpooled, n_sess, E, E, G + t.emb_bias.off, st));
-  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)n_sess), dim3(256), 0, st, G + t.emb.off, y, dpooled, n_sess, L, E);
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)n_sess), dim3(256), 0, st, G + t.emb.off, y, dpooled, n_sess, L, E, m.N);
   T_HIP(hipGetLastError());
 #undef F32
 #undef BF

@@ -37,8 +37,28 @@ def _req(t: torch.Tensor, dtype, name: str, shape=None):
     return t
 
 
-def config_from_args(args, hier: bool = True) -> _lib.Config:
+UNSUPPORTED_FLAGS = ("has_gap", "has_impression", "has_batchnorm", "has_weightnorm", "has_layernorm", "l2_normalize")
+
+
+def check_supported(args, train: bool = False):
+    """The ONE place that refuses model-changing flags the hot path does not implement.  Every entry
+    point builds an Engine, and Engine() builds its config here, so neither the model_hier / model_tcn shims nor the run loops
+    nor the CLI can accept such a flag and silently run something else under the requested run name (args.py:232-240)."""
+    for flag in UNSUPPORTED_FLAGS:
+        if getattr(args, flag, False):
+            raise NotImplementedError(f"args.{flag}=True is outside the hot path (reference default is False)")
+    if getattr(args, "data_noise", None) is not None:
+        raise NotImplementedError("args.data_noise is outside the hot path")
+    if getattr(args, "loss", "cross_entropy") != "cross_entropy":
+        raise NotImplementedError(f"args.loss={args.loss!r}: only 'cross_entropy' (loss.py:20-21) is built")
+    if train and float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
+        raise NotImplementedError("args.dropout != 0 while training: tf.layers.Dropout after conv1 (customized_tcn_cell.py:119) "
+                                  "is not built; the reference default is 0.0")
+
+
+def config_from_args(args, hier: bool = True, train: bool = False) -> _lib.Config:
     """args.py attribute names -> hiertcn_config_t."""
+    check_supported(args, train)
     cfg = _lib.Config()
     cfg.item_num = int(args.item_num)
     cfg.emb_dim = int(getattr(args, "emb_dim", 128))
@@ -76,7 +96,7 @@ class Engine:
             raise HierTCNError("no GPU visible: the HierTCN compute path is HIP-only (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         self.hier = hier
-        self.cfg = config_from_args(args, hier)
+        self.cfg = config_from_args(args, hier, train=bool(train))
         self._args_for_shapes = args
         self.N = int(self.cfg.item_num)
         self.E = int(self.cfg.emb_dim)

@@ -23,13 +23,10 @@ from .model import LazyLogits, get_scope, pack_slots
 
 
 def _check_args(args):
+    from .engine import check_supported
     if getattr(args, "model_low_type", "tcn") not in ("tcn", "gru"):
         raise NotImplementedError(f"model_low_type={args.model_low_type!r}: 'tcn' (HierTCN) and 'gru' (HierGRU) are built")
-    for flag in ("has_gap", "has_impression", "has_batchnorm", "has_weightnorm", "has_layernorm", "l2_normalize"):
-        if getattr(args, flag, False):
-            raise NotImplementedError(f"args.{flag}=True is outside the hot path (reference default is False)")
-    if getattr(args, "data_noise", None) is not None:
-        raise NotImplementedError("args.data_noise is outside the hot path")
+    check_supported(args)   # (Engine() runs the same check: the run loops and the CLI reach it too)
 
 
 def model_hier(args, x, y, mask, state, x_gap=None, x_impression=None, name="hier", reuse=True, training=False):

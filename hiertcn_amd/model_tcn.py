@@ -18,9 +18,8 @@ from .model import LazyLogits, _to_ids, get_scope
 
 
 def model_tcn(args, x, x_gap=None, x_impression=None, name="tcn", reuse=True, training=False, mask=None):
-    for flag in ("has_gap", "has_impression", "has_batchnorm", "has_weightnorm", "has_layernorm", "l2_normalize"):
-        if getattr(args, flag, False):
-            raise NotImplementedError(f"args.{flag}=True is outside the hot path (reference default is False)")
+    from .engine import check_supported
+    check_supported(args)
     ids = _to_ids(x)
     if ids.ndim != 2:
         raise NotImplementedError("model_tcn takes ids [B, T] (the one-hot of model.py:56 is undone); "
