@@ -36,8 +36,19 @@ hipError_t train_fill_masters(const ModelDev& m, TrainCtx& t, const hiertcn_weig
 hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t st);
 size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L);
 // forward (training mode: activations kept) + loss + backward of every variable into t.grad(); returns 0 or -1 (train_last_error)
+#define TRAIN_BEGIN 1    // forward + loss + backward of the scoring layer (its gradients are final behind it)
+#define TRAIN_FINISH 2   // the rest of the backward pass
 int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y, const float* mask, const float* state_in, int B,
-                           int S, int L, void* ws, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st);
+                           int S, int L, void* ws, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st,
+                           int phases = TRAIN_BEGIN | TRAIN_FINISH, const float* users_global = nullptr);
+// data-parallel helpers: lanes with a target -> users[0]; the item table's row-sparse gradient exchange
+hipError_t train_count_users(const int32_t* y, int B, int T, float* act_scratch, float* users, hipStream_t st);
+size_t train_rows_workspace_bytes(const ModelDev& m);
+hipError_t train_rows_list(const ModelDev& m, const int32_t* x, const int32_t* y, int64_t n_ids, int32_t* ids_out, int32_t* count_out, void* ws,
+                           hipStream_t st);
+// op: 0 rows_out[i] = grad_emb[ids[i]]; 1 grad_emb[ids[i]] = 0; 2 grad_emb[ids[i]] += rows[i]   (i < count[0], count <= cap)
+hipError_t train_rows_op(const ModelDev& m, const TrainCtx& t, int op, const int32_t* ids, const int32_t* count, int64_t cap, float* rows,
+                         hipStream_t st);
 // TF-1.x AdamOptimizer (model.py:139): lr_t = lr*sqrt(1-b2^t)/(1-b1^t); m,v updates; theta -= lr_t*m/(sqrt(v)+eps)
 hipError_t train_adam(const ModelDev& m, TrainCtx& t, float lr, float beta1, float beta2, float eps, float grad_scale, hipStream_t st);
 // which = 0: masters, 1: gradients -> fp32 tensors in the reference layouts (device destinations)

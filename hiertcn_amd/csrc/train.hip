@@ -669,8 +669,14 @@ static rocblas_status gemm_f32(rocblas_handle h, rocblas_operation ta, rocblas_o
 #define OPN rocblas_operation_none
 #define OPT rocblas_operation_transpose
 
+// phases: TRAIN_BEGIN = forward + loss + backward of the scoring layer (d out_kernel / d out_bias are final behind it: a data-parallel
+// caller starts their collective there), TRAIN_FINISH = the rest of the backward pass; both = the whole step.
+// users_global (device, optional): the user count of the GLOBAL batch (all ranks) that normalises the loss (model.py:113-117);
+// null = this batch's own count.
 int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y, const float* mask, const float* state_in, int B,
-                           int S, int L, void* wsp, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st) {
+                           int S, int L, void* wsp, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st, int phases,
+                           const float* users_global) {
+  const bool do_begin = (phases & TRAIN_BEGIN) != 0, do_finish = (phases & TRAIN_FINISH) != 0;
   if (!t.enabled) return tfail("training is not enabled on this handle (hiertcn_train_enable before hiertcn_set_weights)");
   rocblas_handle bl = reinterpret_cast<rocblas_handle>(t.blas);
   T_BLAS(rocblas_set_stream(bl, st));
@@ -683,7 +689,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   if (R * (int64_t)Cmax >= ((int64_t)1 << 31)) return tfail("train step: B*S*L*C must stay below 2^31 (rocBLAS 32-bit dims); use a smaller batch");
   if (!m.hier && S != 1) return tfail("train step: the single-level model takes one sequence per lane (S = 1)");
   float* G = t.grad();
-  T_HIP(hipMemsetAsync(G, 0, t.total * sizeof(float), st));
+  if (do_begin) T_HIP(hipMemsetAsync(G, 0, t.total * sizeof(float), st));
 #define F32(o) reinterpret_cast<float*>(ws + (o))
 #define BF(o) reinterpret_cast<uint16_t*>(ws + (o))
 
@@ -697,6 +703,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // equal widths and L <= 32: the fused low-level kernel of the evaluation path, writing the kept activations on its way
   // (bitwise the layer-at-a-time kernels' values; HIERTCN_FORCE_LAYERED=1 takes those instead)
   const bool fused_fw = tcn_fused_applies(m, L);
+  if (do_begin) {
   if (!m.low_gru && !fused_fw) T_HIP(launch_embed_rows(m, x, R, a_emb, st));
   if (m.hier) {
     T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
@@ -708,16 +715,17 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       T_HIP(launch_tcn_layer(a, st));
     }
   }
+  }
   LowGruBufs lb;
   memset(&lb, 0, sizeof(lb));
   if (m.low_gru) {   // HierGRU: embedding + projection + the GRU stack over the L steps, every state and gate kept (model_gru.py:46-55)
     lb.a_emb = a_emb; lb.u16 = a0; lb.uf = F32(w.lg_uf); lb.seq_len = reinterpret_cast<int32_t*>(ws + w.lg_len);
     lb.states = F32(w.lg_save); lb.n_states = L + 1;
     lb.rec = lb.states + (size_t)(L + 1) * n_sess * HT; lb.keep_all = 1;
-    T_HIP(launch_low_gru_bufs(m, x, sproj, n_sess, L, BF(w.act[2]), lb, st));
+    if (do_begin) T_HIP(launch_low_gru_bufs(m, x, sproj, n_sess, L, BF(w.act[2]), lb, st));
   }
   auto a_of = [&](int k) -> uint16_t* { return k == 0 ? a0 : BF(w.act[1 + 2 * k]); };   // a^k: output of block k-1
-  if (fused_fw) {
+  if (fused_fw && do_begin) {
     TcnSaves sv;
     memset(&sv, 0, sizeof(sv));
     sv.emb = a_emb;
@@ -728,7 +736,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     }
     T_HIP(launch_tcn_forward(m, x, m.hier ? sproj : nullptr, n_sess, L, a_of(nb), nullptr, st, &sv));
   }
-  for (int i = 0, cin = E; i < nb && !m.low_gru && !fused_fw; cin = m.C[i], i++) {
+  for (int i = 0, cin = E; i < nb && !m.low_gru && !fused_fw && do_begin; cin = m.C[i], i++) {
     LayerArgs a = {};
     a.in = a_of(i);
     a.c_out = BF(w.act[2 + 2 * i]);
@@ -745,6 +753,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // their ascending list; its length comes back to the host once per step because it sizes the rocBLAS calls below.
   int32_t* rmap = reinterpret_cast<int32_t*>(ws + w.map);
   int32_t* nvalid_d = reinterpret_cast<int32_t*>(ws + w.nvalid);
+  float* dH = F32(w.dA);   // [R][C_last] fp32
+  if (do_begin) {
   T_HIP(launch_compact_rows(y, R, rmap, nvalid_d, reinterpret_cast<int32_t*>(ws + w.cscratch), st));
   T_HIP(hipMemsetAsync(so.rank, 0, (size_t)R * 4, st));
   T_HIP(hipMemsetAsync(so.ce, 0, (size_t)R * 4, st));
@@ -760,10 +770,9 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   float* users = F32(w.users);
   T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
   hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
-  hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users, so.ce, so.target, R, S * L,
+  hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce, so.target, R, S * L,
                      F32(w.w), F32(w.lse));
   T_HIP(hipGetLastError());
-  float* dH = F32(w.dA);   // [R][C_last] fp32
   T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
   if (Rv > 0) {
     uint16_t* hc = BF(w.hc);
@@ -808,6 +817,13 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     }
     hipLaunchKernelGGL(k_scatter_rows_f32, dim3((unsigned)((Rv * (CL / 4) + 255) / 256)), dim3(256), 0, st, dHc, rmap, Rv, CL, dH);
     T_HIP(hipGetLastError());
+  }
+
+  }   // do_begin
+  if (!do_finish) {
+#undef F32
+#undef BF
+    return 0;
   }
 
   // ================= TemporalBlocks, last to first =========================================================

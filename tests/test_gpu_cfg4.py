@@ -53,7 +53,8 @@ def test_cfg4_scoring_fp16_d512_one_million_items():
     plain = eng.score_fused(hid, dev(y), want_target=True)       # the production loss + rank flavour at this width (k_score_pipe<512,...>)
     assert np.array_equal(plain["rank"].cpu().numpy(), rank)
     assert np.array_equal(plain["target"].cpu().numpy(), tgt)
-    assert np.abs(plain["ce"].cpu().numpy() - ce).max() < 2e-5
+    # two kernels, two summation orders over 10^6 fp32 terms (log-sum-exp ~ 14): sqrt(n) * eps * lse ~ 1e-4
+    assert np.abs(plain["ce"].cpu().numpy() - ce).max() < 5e-4, np.abs(plain["ce"].cpu().numpy() - ce).max()
 
     rows = np.unique(np.concatenate([np.arange(17), rng.integers(0, R, SAMPLE)]))
     logits = eng.score_logits(hid[torch.as_tensor(rows, device="cuda")].contiguous()).cpu().numpy()    # [rows, N] fp32
@@ -67,7 +68,7 @@ def test_cfg4_scoring_fp16_d512_one_million_items():
     l64 = logits.astype(np.float64)
     mx = l64.max(1, keepdims=True)
     lse = (mx + np.log(np.exp(l64 - mx).sum(1, keepdims=True)))[:, 0]
-    assert np.abs(ce[rows][v] - (lse - t_own)[v]).max() < 1e-4                     # loss.py:21
+    assert np.abs(ce[rows][v] - (lse - t_own)[v]).max() < 5e-4, np.abs(ce[rows][v] - (lse - t_own)[v]).max()   # loss.py:21
     assert not rank[~(y > 0)].any() and not ce[~(y > 0)].any()                     # model.py:105: masked rows
     assert np.array_equal(ti[~(y > 0)], np.broadcast_to(np.arange(K), ti[~(y > 0)].shape))
 

@@ -38,6 +38,16 @@ def test_xing_shape_logits_recall_and_topk_against_oracle():
     hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
     logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
     assert np.abs(logits - pred)[valid].max() < 1e-3
+    # ... and within 1e-3 of the reference arithmetic on the UNROUNDED fp32 weights (what a TF checkpoint holds): nothing rounded,
+    # fp64 accumulate.  This is the north star's "fp32 logits within 1e-3 of the TF reference" as far as it can be stated without
+    # TensorFlow; measured here 7.4e-4 at worst (mean 4.5e-5) at logits of |z| <= 0.34 (glorot init): the bf16 storage costs about
+    # 2e-3 of the logit SCALE, so a trained model with |z| ~ 10 would need the tolerance scaled with it.
+    exact, _ = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64)
+    err_exact = np.abs(logits - exact)[valid]
+    print("device logits vs exact oracle on unrounded weights: max %.3e, q99.9 %.3e, mean %.3e (|z| max %.3f)"
+          % (err_exact.max(), np.quantile(err_exact, 0.999), err_exact.mean(), np.abs(exact[valid]).max()))
+    assert err_exact.max() < 1e-3, err_exact.max()
+    assert err_exact.max() < 4e-3 * np.abs(exact[valid]).max()          # the scale-relative statement
 
     # metrics of the batch: loss within 1e-3; recall / MRR differ only through near-tied ranks
     ref = O.masked_loss_and_metrics(pred, yy, N)
@@ -65,10 +75,53 @@ def test_xing_shape_logits_recall_and_topk_against_oracle():
     clear = (np.diff(-top_vals, axis=-1).min(-1) > 2 * err_row + 1e-7) & valid
     assert clear.sum() > 0.25 * valid.sum(), (clear.sum(), valid.sum())          # the check below is not vacuous
     assert np.array_equal(ti[clear], want[clear][:, :K])
+    # on the OTHER rows (near-ties inside the oracle's own top-11) a swap is legitimate, but only between items the oracle scores
+    # within the tolerance of each other: position by position, the ORACLE's score of the device's p-th item must sit within
+    # 2 x (that row's largest logit difference) of the oracle's own p-th score, and the device's list must be a set of distinct
+    # items scored at least (oracle's K-th score - 2 err) by the oracle
+    dev_vals_in_oracle = np.take_along_axis(pred, ti.astype(np.int64), -1)          # [B, T, K]
+    bracket = 2 * err_row[..., None] + 1e-7
+    assert np.all((np.abs(dev_vals_in_oracle - top_vals[..., :K]) <= bracket)[valid]), \
+        float((np.abs(dev_vals_in_oracle - top_vals[..., :K]) - bracket)[valid].max())
+    srt = np.sort(ti, axis=-1)
+    assert np.all((np.diff(srt, axis=-1) > 0)[valid])                               # K distinct items per row
     # and on ALL scored rows the device's list is the exact top-10 of the device's own logits (bit-exact integer output)
     own = O.top_k_indices(logits.reshape(-1, N), K).reshape(B, S * L, K)
     assert np.array_equal(ti[valid], own[valid])
     # masked rows (never visited by the kernel: the rows are compacted) carry the all-zero row's list 0..K-1 (model.py:105, loss.py:120)
     assert np.array_equal(ti[~valid], np.broadcast_to(np.arange(K), ti[~valid].shape))
     assert not out["topk_val"].cpu().numpy().reshape(B, S * L, K)[~valid].any()
+    eng.close()
+
+
+def test_north_star_width_logits_against_exact_oracle_on_unrounded_weights():
+    """The same statement at the north star's catalogue width (N = 300,000: glorot Wo of +-0.0045) on a few lanes: device fp32
+    logits vs the exact oracle on unrounded fp32 weights < 1e-3 (model_tcn.py:41; measured 2.4e-4 at worst)."""
+    from hiertcn_amd.engine import Engine
+    N, d, B, S, L = 300_000, 256, 4, 5, 30
+    args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
+    p = make_params(args)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    rng = np.random.default_rng(N)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=True, zipf=True)
+    st0 = (0.2 * rng.standard_normal((B, 2 * d))).astype(np.float32)
+    dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")  # noqa: E731
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+    xl, yl, ml = as_lists(x, y, mask)
+    exact, _ = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64)
+    valid = y.reshape(B, S * L) > 0
+    err = np.abs(logits - exact)[valid]
+    assert err.max() < 1e-3, err.max()
+    # ranks against the exact oracle: inside the tolerance bracket of every row (loss.py:179)
+    out = eng.score_fused(hid, dev(y.reshape(-1)))
+    rk = out["rank"].cpu().numpy().reshape(B, S * L)
+    yy = y.reshape(B, S * L).astype(np.int64)
+    tgt = np.take_along_axis(exact, yy[..., None], -1)
+    tol = 2 * err.max()
+    lo, hi = (exact > tgt + tol).sum(-1), (exact > tgt - tol).sum(-1)
+    assert np.all((rk >= lo)[valid]) and np.all((rk <= hi)[valid])
     eng.close()
