@@ -67,6 +67,98 @@ def make_users(draw, first_user: int, n_users: int, ragged: bool):
     return x, y, mask
 
 
+def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks):
+    """-> the `train` object: ms per optimizer step, sessions/s over all ranks, the collectives' cost (exposed = step time minus the
+    same step with the collectives switched off; standalone = the three gradient collectives alone, back to back) and their bus
+    bandwidth against the node's 7 x 153 GB/s of xGMI per GPU."""
+    import copy
+
+    import torch
+
+    from hiertcn_amd.model import HierTCNModel
+
+    targs = copy.copy(args)
+    targs.train = True
+    model = HierTCNModel(targs, params, train=True)
+    eng = model.engine
+    Bt = a.train_users_per_step
+    n_total = a.train_warmup + a.train_steps
+    batches = []
+    for i in range(n_total):
+        first = shard_first + (i * Bt) % max(shard - Bt, 1)
+        x, y, mask = make_users(draw, first, Bt, a.ragged)
+        batches.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda()))
+    state0 = torch.zeros((Bt, eng.HT), dtype=torch.float32, device="cuda")
+    state_out = torch.empty_like(state0)
+    m8 = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(n_total)]
+    lr = 1e-3
+
+    def run(steps_from, steps_to):
+        for i in range(steps_from, steps_to):
+            xb, yb, mb = batches[i]
+            model.train_step_device(xb, yb, mb, state0, lr, state_out=state_out, metrics8=m8[i])
+
+    def timed(steps_from, steps_to):
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(steps_from, steps_to)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+        return max_over_ranks(time.perf_counter() - t0, "cuda")
+
+    run(0, a.train_warmup)
+    dt = timed(a.train_warmup, n_total)
+    losses = [float(v[0] / v[6]) for v in torch.stack(m8[a.train_warmup:]).cpu()]
+    ms_step = dt / max(a.train_steps, 1) * 1e3
+    out = {
+        "what": "one optimizer step at cfg-3 (forward + masked lane-mean CE + backward of every variable + gradient collectives + "
+                "TF-form Adam), users sharded over the ranks, global-batch loss normalisation",
+        "users_per_step_per_gpu": Bt,
+        "sessions_per_step": Bt * S_SESS * world,
+        "steps": a.train_steps, "warmup": a.train_warmup,
+        "ms_per_step": round(ms_step, 3),
+        "sessions_per_s": round(Bt * S_SESS * world * a.train_steps / dt, 1),
+        "loss_first_last": [round(losses[0], 5), round(losses[-1], 5)] if losses else None,
+        "collectives": None,
+    }
+    ex = model._exchange
+    seg = {k: eng.grad_segment(k) for k in (0, 1, 2)}
+    coll = {"backend": "rccl" if world > 1 else None, "algorithm": ex.mode, "item_table_exchange": ex.last.get("item_table", "dense"),
+            "bytes": {"item_table": seg[0][1] * 4, "scoring_layer": seg[1][1] * 4, "rest": seg[2][1] * 4}}
+    if world > 1:
+        # (a) the same steps with the collectives off (replicas drift apart from here on: timing only, the bench ends after it)
+        os.environ["HIERTCN_DP_OFF"] = "1"
+        dt_off = timed(a.train_warmup, n_total)
+        os.environ.pop("HIERTCN_DP_OFF")
+        # (b) the three collectives alone, back to back, on the gradient arena as it stands
+        g = eng.grad_arena()
+        xb, yb, _ = batches[-1]
+        torch.cuda.synchronize()
+        dist.barrier()
+        reps = 3
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ex.after_scoring()
+            ex.after_backward(xb, yb)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t_coll = max_over_ranks((time.perf_counter() - t0) / reps, "cuda")
+        nbytes = (seg[0][1] + seg[1][1] + seg[2][1]) * 4
+        bus = 2.0 * (world - 1) / world * nbytes / t_coll / 1e9
+        coll.update({"standalone_ms": round(t_coll * 1e3, 3), "bus_GBps": round(bus, 1), "bus_peak_GBps": 7 * 153.0,
+                     "bus_frac": round(bus / (7 * 153.0), 4),
+                     "exposed_ms_per_step": round((dt - dt_off) / max(a.train_steps, 1) * 1e3, 3),
+                     "ms_per_step_collectives_off": round(dt_off / max(a.train_steps, 1) * 1e3, 3)})
+        del g
+    out["collectives"] = coll
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -75,7 +167,11 @@ def main():
     ap.add_argument("--users-per-step", type=int, default=4096, help="users per step PER GPU (4096 users = 4800 workgroups = 18.75 rounds of 256 CUs: 1.3 % tail)")
     ap.add_argument("--ragged", action="store_true", help="session lengths ~ U{1..30} instead of full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-budget", type=float, default=12.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-train", action="store_true", help="skip the data-parallel training leg (the `train` object of the JSON line)")
+    ap.add_argument("--train-users-per-step", type=int, default=1024, help="users per training step PER GPU")
+    ap.add_argument("--train-steps", type=int, default=4)
+    ap.add_argument("--train-warmup", type=int, default=2)
+    ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of CPU work for the cpu_baseline leg")
     a = ap.parse_args()
 
     import torch
@@ -190,16 +286,23 @@ def main():
         except Exception as e:  # noqa: BLE001  (a yardstick, never fatal)
             gemm_ref = {"error": str(e)[:200]}
 
+    # ---- training leg (north star: "RCCL all-reduce over xGMI on the shared item-embedding gradients"): the same cfg-3 model,
+    # one optimizer step = forward + loss + backward + gradient collectives + TF-form Adam (model.py:135-141,
+    # run_hier_xing.py:275-301), users sharded over the ranks, timed after the evaluation region under the same launch
+    train = None
+    if not a.no_train:
+        train = train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the checker, timed on this host's cores on a bounded sample of the SAME workload
         from oracle.cpu_baseline import time_cpu_baseline
         xb, yb, mb = batches[a.warmup]
-        n_cpu = min(B, 256)
+        n_cpu = min(B, 128)
         r = time_cpu_baseline(args, params, xb[:n_cpu].cpu().numpy(), yb[:n_cpu].cpu().numpy(), mb[:n_cpu].cpu().numpy(),
-                              lanes=32, budget_s=a.cpu_budget)
+                              budget_s=a.cpu_budget)
         cpu = dict(value=round(r["value"], 3), unit="sessions/s", cores=r["cores"], kind="port", sample=r["sample"],
-                   seconds=round(r["seconds"], 2))
+                   seconds=round(r["seconds"], 2), variants=r["variants"])
 
     if rank == 0:
         out = {
@@ -242,6 +345,7 @@ def main():
                 "scored_rows_per_launch": scored_rows,
             },
             "cpu_baseline": cpu,
+            "train": train,
             "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
             "setup_s": round(t_setup, 1),
         }

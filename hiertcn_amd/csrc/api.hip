@@ -493,6 +493,77 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
   return HIERTCN_OK;
 }
 
+int hiertcn_train_step_begin(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
+                             int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out, double* metrics8,
+                             const float* users_global, void* stream) {
+  CHECK_READY(h);
+  if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
+  if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (h->m.hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
+  if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
+  if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, state_in, B, S, L, workspace, state_out, metrics8, h->metric_scratch,
+                             reinterpret_cast<hipStream_t>(stream), TRAIN_BEGIN, users_global) != 0)
+    return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
+  return HIERTCN_OK;
+}
+
+int hiertcn_train_step_finish(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, int32_t B, int32_t S,
+                              int32_t L, void* workspace, size_t workspace_bytes, void* stream) {
+  CHECK_READY(h);
+  if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
+  if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (h->m.hier && !mask) return fail(HIERTCN_ERR_INVALID, "mask is required for hier models");
+  if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
+  if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, nullptr, B, S, L, workspace, nullptr, nullptr, h->metric_scratch,
+                             reinterpret_cast<hipStream_t>(stream), TRAIN_FINISH, nullptr) != 0)
+    return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
+  return HIERTCN_OK;
+}
+
+int hiertcn_count_users(hiertcn_handle_t h, const int32_t* y_ids, int32_t B, int32_t T, float* users, void* stream) {
+  if (!h || !y_ids || !users || B < 1 || T < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (B > 4 * HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  ON_DEVICE(h);
+  // per-lane counts land in the metric scratch (8 * HIERTCN_METRIC_BLOCKS_MAX doubles >= B floats)
+  HIP_TRY(train_count_users(y_ids, B, T, reinterpret_cast<float*>(h->metric_scratch), users, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+int hiertcn_train_segment(hiertcn_handle_t h, int32_t which, size_t* offset, size_t* count) {
+  if (!h || !h->train.enabled || !offset || !count) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle / bad argument");
+  const TrainCtx& t = h->train;
+  const size_t small0 = t.out_bias.off + ((t.out_bias.n + 63) & ~(size_t)63);
+  switch (which) {
+    case 0: *offset = t.emb.off; *count = t.emb.n; break;                        // item table [N][E]: row-sparse gradient
+    case 1: *offset = t.outT.off; *count = small0 - t.outT.off; break;           // scoring kernel [NP][C] + bias [NP]: dense gradient
+    case 2: *offset = small0; *count = t.total - small0; break;                  // everything else
+    default: return fail(HIERTCN_ERR_INVALID, "segment %d: 0 item table, 1 scoring layer, 2 the rest", which);
+  }
+  return HIERTCN_OK;
+}
+
+size_t hiertcn_grad_rows_workspace_bytes(hiertcn_handle_t h) { return h ? train_rows_workspace_bytes(h->m) : 0; }
+
+int hiertcn_grad_rows_list(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, int64_t n_ids, int32_t* ids_out, int64_t cap,
+                           int32_t* count_out, void* workspace, size_t workspace_bytes, void* stream) {
+  if (!h || !h->train.enabled || !ids_out || !count_out || !workspace || n_ids < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  if (workspace_bytes < train_rows_workspace_bytes(h->m)) return fail(HIERTCN_ERR_WORKSPACE, "rows workspace too small");
+  const int64_t bound = ((x_ids ? n_ids : 0) + (y_ids ? n_ids : 0)) < (int64_t)h->m.N - 1 ? (x_ids ? n_ids : 0) + (y_ids ? n_ids : 0) : (int64_t)h->m.N - 1;
+  if (cap < bound) return fail(HIERTCN_ERR_INVALID, "ids_out holds %lld entries, the batch can touch %lld rows", (long long)cap, (long long)bound);
+  ON_DEVICE(h);
+  HIP_TRY(train_rows_list(h->m, x_ids, y_ids, n_ids, ids_out, count_out, workspace, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+int hiertcn_grad_rows_op(hiertcn_handle_t h, int32_t op, const int32_t* ids, const int32_t* count, int64_t cap, float* rows, void* stream) {
+  if (!h || !h->train.enabled || !ids || !count || cap < 0 || op < 0 || op > 2 || (op != 1 && !rows)) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  ON_DEVICE(h);
+  HIP_TRY(train_rows_op(h->m, h->train, op, ids, count, cap, rows, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
 int hiertcn_grad_arena(hiertcn_handle_t h, float** grad, size_t* count) {
   if (!h || !h->train.enabled || !grad || !count) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
   *grad = h->train.grad();

@@ -526,6 +526,64 @@ hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weig
   return hipSuccess;
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// data-parallel helpers
+// ---------------------------------------------------------------------------------------------------------
+hipError_t train_count_users(const int32_t* y, int B, int T, float* act_scratch, float* users, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(users, 0, sizeof(float), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, T, act_scratch, users);
+  return hipGetLastError();
+}
+
+// Row-sparse exchange of the item table's gradient: only rows whose id occurs in the batch are non-zero (scatter-adds of the
+// input embedding and of the session mean-pool).  flags[id] = 1 for every id seen -> ascending list (the compaction of metrics.hip).
+__global__ void k_flag_ids(const int32_t* __restrict__ ids, int64_t n, int N, int32_t* __restrict__ flags) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int id = ids[i];
+  if (id > 0 && id < N) flags[id] = 1;   // (benign race: every writer stores the same value)
+}
+size_t train_rows_workspace_bytes(const ModelDev& m) {
+  const size_t n = ((size_t)m.N + 255) & ~(size_t)255;
+  return n * 4 /* flags */ + (n / 1024 + 2 + 255) / 256 * 256 * 4 /* block counts */;
+}
+hipError_t train_rows_list(const ModelDev& m, const int32_t* x, const int32_t* y, int64_t n_ids, int32_t* ids_out, int32_t* count_out, void* ws,
+                           hipStream_t st) {
+  const size_t n = ((size_t)m.N + 255) & ~(size_t)255;
+  int32_t* flags = reinterpret_cast<int32_t*>(ws);
+  int32_t* scratch = flags + n;
+  hipError_t e = hipMemsetAsync(flags, 0, n * 4, st);
+  if (e != hipSuccess) return e;
+  const unsigned blocks = (unsigned)((n_ids + 255) / 256);
+  if (x && n_ids > 0) hipLaunchKernelGGL(k_flag_ids, dim3(blocks), dim3(256), 0, st, x, n_ids, m.N, flags);
+  if (y && n_ids > 0) hipLaunchKernelGGL(k_flag_ids, dim3(blocks), dim3(256), 0, st, y, n_ids, m.N, flags);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  return launch_compact_rows(flags, (int64_t)m.N, ids_out, count_out, scratch, st);   // ids_out must hold min(N - 1, 2 n_ids) entries
+}
+// one wave per listed row; lane e takes channels e, e + 64, ...
+__global__ __launch_bounds__(256) void k_rows_op(float* __restrict__ table, int E, int op, const int32_t* __restrict__ ids,
+                                                 const int32_t* __restrict__ count, int64_t cap, float* __restrict__ rows) {
+  const int lane = threadIdx.x & 63;
+  const int64_t i = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n = count[0] < cap ? count[0] : cap;
+  if (i >= n) return;
+  float* d = table + (int64_t)ids[i] * E;
+  float* r = rows ? rows + i * E : nullptr;
+  for (int e = lane; e < E; e += 64) {
+    if (op == 0) r[e] = d[e];
+    else if (op == 1) d[e] = 0.f;
+    else d[e] += r[e];
+  }
+}
+hipError_t train_rows_op(const ModelDev& m, const TrainCtx& t, int op, const int32_t* ids, const int32_t* count, int64_t cap, float* rows,
+                         hipStream_t st) {
+  if (cap <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_rows_op, dim3((unsigned)((cap + 3) / 4)), dim3(256), 0, st, t.grad() + t.emb.off, m.E, op, ids, count, cap, rows);
+  return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // workspace
 // ---------------------------------------------------------------------------------------------------------
@@ -820,11 +878,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   }
 
   }   // do_begin
-  if (!do_finish) {
-#undef F32
-#undef BF
-    return 0;
-  }
+  if (!do_finish) return 0;
 
   // ================= TemporalBlocks, last to first =========================================================
   float* da = dH;              // grad of a^{k+1}, fp32 [R][Cout]

@@ -24,16 +24,31 @@ from .data_prepare import load_xing
 DATA_PATH = "dataset/interactions.csv"  # data_loader.py:54,140 (relative to the working directory)
 
 
-def _split(viewer_table: np.ndarray, split: str) -> np.ndarray:
-    """data_loader.py:55-60,141-146: first 80 % of the users train, next 10 % validate, last 10 % test."""
+def _split(viewer_table: np.ndarray, split: str, rank: int = 0, world: int = 1) -> np.ndarray:
+    """data_loader.py:55-60,141-146: first 80 % of the users train, next 10 % validate, last 10 % test.  Data-parallel runs
+    (world > 1) then take this rank's contiguous share of the split's users (the path shards by user)."""
     n = viewer_table.shape[0]
     if split == "train":
-        return viewer_table[0:int(n * 0.8), :]
-    if split == "validate":
-        return viewer_table[int(n * 0.8):int(n * 0.9), :]
-    if split == "test":
-        return viewer_table[int(n * 0.9):, :]
-    return viewer_table
+        vt = viewer_table[0:int(n * 0.8), :]
+    elif split == "validate":
+        vt = viewer_table[int(n * 0.8):int(n * 0.9), :]
+    elif split == "test":
+        vt = viewer_table[int(n * 0.9):, :]
+    else:
+        vt = viewer_table
+    if world > 1:
+        from .distributed import user_shard
+        first, cnt = user_shard(vt.shape[0], rank, world)
+        vt = vt[first:first + cnt]
+    return vt
+
+
+def _check_item_ids(viewer_data: np.ndarray, args):
+    """load_xing re-indexes the items to 1..n_items, and n_items depends on the filters; args.item_num is a fixed default
+    (args.py:47).  An id >= item_num has no table row: the device treats it as the null id, which is not what was asked for."""
+    if viewer_data.shape[0] and int(viewer_data[:, 1].max()) >= int(args.item_num):
+        raise ValueError("the data holds item id {} but args.item_num is {} (ids must be < item_num; row 0 is the null id): "
+                         "pass --item_num {}".format(int(viewer_data[:, 1].max()), int(args.item_num), int(viewer_data[:, 1].max()) + 1))
 
 
 class _UserWalk:
@@ -53,11 +68,12 @@ class Dataloader_single_level_model_xing:
     """get_batch() -> (x, y, info): x, y float64 [B, T], info [B, T, 5]; T = longest history in the
     batch; rows past the last user of a short final batch stay zero (data_loader.py:78-106)."""
 
-    def __init__(self, args, type: str = "train", data: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+    def __init__(self, args, type: str = "train", data: Optional[Tuple[np.ndarray, np.ndarray]] = None, rank: int = 0, world: int = 1):
         self.args = args
         self.done = False
         vt, self.viewer_data = data if data is not None else load_xing(DATA_PATH, max_activity=int(args.max_seq_len))
-        self.viewer_table = _split(vt, type)
+        _check_item_ids(self.viewer_data, args)
+        self.viewer_table = _split(vt, type, rank, world)
         self._ids = self.viewer_data[:, 1].astype(np.int64)
         self._walk = _UserWalk(self.viewer_table.shape[0], bool(args.shuffle))
 
@@ -109,11 +125,12 @@ class Dataloader_hier_model_xing:
     batch pops one session per lane for each of the S slots (:233-265).  `done` reports that the
     user index wrapped while filling (:214-216, :227), not that the queues drained."""
 
-    def __init__(self, args, type: str = "train", data: Optional[Tuple[np.ndarray, np.ndarray]] = None):
+    def __init__(self, args, type: str = "train", data: Optional[Tuple[np.ndarray, np.ndarray]] = None, rank: int = 0, world: int = 1):
         self.args = args
         self.done = False
         vt, self.viewer_data = data if data is not None else load_xing(DATA_PATH, max_activity=int(args.max_seq_len))
-        self.viewer_table = _split(vt, type)
+        _check_item_ids(self.viewer_data, args)
+        self.viewer_table = _split(vt, type, rank, world)
         self._ids = self.viewer_data[:, 1].astype(np.int64)
         self._cut_sessions()
         self._walk = _UserWalk(self.viewer_table.shape[0], bool(args.shuffle))

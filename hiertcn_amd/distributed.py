@@ -30,6 +30,21 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
     return rank, world, local_rank
 
 
+def rank_world() -> Tuple[int, int]:
+    if dist.is_available() and dist.is_initialized():
+        return dist.get_rank(), dist.get_world_size()
+    return 0, 1
+
+
+def is_main() -> bool:
+    return rank_world()[0] == 0
+
+
+def barrier():
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
 def user_shard(n_users: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous, balanced shard of the user axis: (first_user, n_users_of_rank).  The first
     n_users % world ranks hold one user more."""
@@ -58,6 +73,135 @@ def max_over_ranks(seconds: float, device=None) -> float:
     t = torch.tensor([seconds], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def _is_dist() -> bool:
+    import os
+    if os.environ.get("HIERTCN_DP_OFF"):   # bench.py: time the step without its collectives (replicas drift: timing only)
+        return False
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class _Done:
+    def wait(self):
+        return None
+
+
+def _sum_async(t: torch.Tensor):
+    """Sum `t` over ranks in place; returns a handle with .wait().  RCCL ("nccl"): asynchronous on the backend's own stream (the
+    collective starts when the work queued on the current stream so far is done; wait() makes the current stream wait for it,
+    the host never blocks).  gloo (CPU tests / a smoke run with ranks sharing a GPU): staged through the host, synchronous."""
+    if t.is_cuda and dist.get_backend() == "gloo":
+        host = t.cpu()
+        dist.all_reduce(host, op=dist.ReduceOp.SUM)
+        t.copy_(host)
+        return _Done()
+    return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+
+
+def _gather_cat(t: torch.Tensor) -> torch.Tensor:
+    """[n, ...] per rank -> [world, n, ...] (same shape on every rank)."""
+    world = dist.get_world_size()
+    if t.is_cuda and dist.get_backend() == "gloo":
+        parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
+        dist.all_gather(parts, t.cpu())
+        return torch.stack(parts).to(t.device)
+    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
+    dist.all_gather_into_tensor(out, t)
+    return out
+
+
+class GradientExchange:
+    """The gradient collectives of one data-parallel training step (model.py:135-141 on the global batch), shaped
+    for what the gradient arena holds rather than one post-hoc dense all-reduce:
+
+      1 scoring kernel + bias  [NP, C] + [NP] fp32 (308 MB at cfg-3), DENSE: summed right behind the scoring layer's backward,
+        while the TemporalBlocks / projection / GRU backward still computes (`after_scoring`).  On RCCL as reduce-scatter +
+        all-gather (HIERTCN_DP_COLLECTIVE=allreduce: one all-reduce), which over the fully connected xGMI node moves
+        2 (W-1)/W of the buffer per GPU over all seven links;
+      0 item table [N, E] fp32 (307 MB), ROW-SPARSE: only ids of the batch have a row.  When the batch can touch fewer rows
+        than a dense ring all-reduce would move (host-known bound: 2 ids per step, no read-back), the ranks all-gather
+        (row id, row) pairs and every rank adds them up in rank order (bit-identical replicas); otherwise dense like 1;
+      2 every other variable (a few MB): one all-reduce.
+
+    The loss normaliser is the GLOBAL user count (all-reduced before the step: `global_users`), so the summed gradients need no
+    1/world factor and ragged shards (ranks with different numbers of live lanes) are weighted exactly as model.py:113-117 would
+    weight them in one big batch."""
+
+    def __init__(self, engine, sparse_rows_max_fraction: float = None):
+        import os
+        self.eng = engine
+        self.mode = os.environ.get("HIERTCN_DP_COLLECTIVE", "rs_ag")
+        self.sparse_frac = float(os.environ.get("HIERTCN_DP_SPARSE_FRACTION", "-1")) if sparse_rows_max_fraction is None else sparse_rows_max_fraction
+        self._pending = []
+        self._shard = None
+        self.last = {}
+
+    @property
+    def world(self) -> int:
+        return dist.get_world_size() if _is_dist() else 1
+
+    def global_users(self, y_ids: torch.Tensor):
+        """Device float [1]: lanes with a target over all ranks (None at world 1: the kernel counts its own batch)."""
+        if not _is_dist():
+            return None
+        u = self.eng.count_users(y_ids)
+        _sum_async(u).wait()
+        return u
+
+    def _dense(self, seg: torch.Tensor):
+        world = self.world
+        if (self.mode == "rs_ag" and dist.get_backend() == "nccl" and seg.numel() % world == 0):
+            n = seg.numel() // world
+            if self._shard is None or self._shard.numel() != n:
+                self._shard = torch.empty(n, dtype=seg.dtype, device=seg.device)
+            # both run on the backend's stream, in issue order; neither makes the compute stream wait here
+            w1 = dist.reduce_scatter_tensor(self._shard, seg, op=dist.ReduceOp.SUM, async_op=True)
+            w2 = dist.all_gather_into_tensor(seg, self._shard, async_op=True)
+
+            class _Both:
+                def wait(self_inner):
+                    w1.wait()
+                    w2.wait()
+            return _Both()
+        return _sum_async(seg)
+
+    def after_scoring(self):
+        """Call between train_step_begin and train_step_finish."""
+        self._pending = []
+        if not _is_dist():
+            return
+        off, n = self.eng.grad_segment(1)
+        self._pending.append(self._dense(self.eng.grad_arena()[off:off + n]))
+
+    def after_backward(self, x_ids: torch.Tensor, y_ids):
+        """Call behind train_step_finish; returns when every gradient of the arena is the global sum (stream-ordered)."""
+        if not _is_dist():
+            return
+        eng, world = self.eng, self.world
+        g = eng.grad_arena()
+        off2, n2 = eng.grad_segment(2)
+        self._pending.append(_sum_async(g[off2:off2 + n2]))
+        off0, n0 = eng.grad_segment(0)
+        n_ids = int(x_ids.numel()) * (2 if y_ids is not None else 1)
+        bound = min(eng.N - 1, n_ids)
+        # all-gather of pairs receives (W-1) * bound rows; a ring all-reduce moves 2 (W-1)/W * N rows
+        frac = self.sparse_frac if self.sparse_frac >= 0 else 2.0 / world
+        sparse = bound < frac * eng.N
+        self.last = dict(item_table="row-sparse" if sparse else "dense", rows_bound=bound)
+        if not sparse:
+            self._pending.append(_sum_async(g[off0:off0 + n0]))
+        else:
+            ids, cnt, cap = eng.grad_rows_list(x_ids, y_ids)
+            rows = torch.empty((cap, eng.E), dtype=torch.float32, device=eng.device)
+            eng.grad_rows_op(0, ids, cnt, rows)                 # pack own rows
+            eng.grad_rows_op(1, ids, cnt)                       # and clear them: every rank rebuilds the sum in rank order
+            all_ids, all_cnt, all_rows = _gather_cat(ids), _gather_cat(cnt), _gather_cat(rows)
+            for r in range(world):
+                eng.grad_rows_op(2, all_ids[r], all_cnt[r], all_rows[r])
+        for wk in self._pending:
+            wk.wait()
+        self._pending = []
 
 
 def all_reduce_gradients(flat: torch.Tensor, bucket_bytes: int = 256 << 20) -> int:

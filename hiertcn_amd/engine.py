@@ -353,6 +353,74 @@ class Engine:
                                                       self._stream()))
         return dict(state=state_out, metrics8=metrics8)
 
+    # -- the step in two halves + helpers for data-parallel runs (hiertcn.h "data-parallel training") ---------------------
+    def _train_ws_for(self, B, S, L) -> torch.Tensor:
+        need = int(self.lib.hiertcn_train_workspace_bytes(self._h, B, S, L))
+        if self._train_ws is None or self._train_ws.numel() < need:
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        return self._train_ws
+
+    def train_step_begin(self, x_ids, y_ids, mask=None, state_in=None, state_out=None, metrics8=None, users_global=None):
+        """Forward + loss + backward of the scoring layer; behind it the gradients of out_kernel / out_bias are final.
+        users_global: device float32 [1], the lanes-with-a-target count of the GLOBAL batch (or None: this batch's own)."""
+        B, S, L = x_ids.shape
+        _req(x_ids, torch.int32, "x_ids", (B, S, L))
+        _req(y_ids, torch.int32, "y_ids", (B, S, L))
+        if self.hier:
+            _req(mask, torch.float32, "mask", (B, S))
+            _req(state_in, torch.float32, "state_in", (B, self.HT))
+            if state_out is None:
+                state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
+        else:
+            mask = state_in = state_out = None
+        if users_global is not None:
+            _req(users_global, torch.float32, "users_global", (1,))
+        ws = self._train_ws_for(B, S, L)
+        if metrics8 is None:
+            metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
+        self._ck(self.lib.hiertcn_train_step_begin(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L, _ptr(ws),
+                                                ws.numel(), _ptr(state_out), _ptr(metrics8), _ptr(users_global), self._stream()))
+        return dict(state=state_out, metrics8=metrics8)
+
+    def train_step_finish(self, x_ids, y_ids, mask=None):
+        B, S, L = x_ids.shape
+        ws = self._train_ws_for(B, S, L)
+        self._ck(self.lib.hiertcn_train_step_finish(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask if self.hier else None), B, S, L,
+                                                 _ptr(ws), ws.numel(), self._stream()))
+
+    def count_users(self, y_ids: torch.Tensor) -> torch.Tensor:
+        """-> device float32 [1]: lanes of y [B, ...] with at least one target (model.py:113)."""
+        B = y_ids.shape[0]
+        y = y_ids.reshape(B, -1)
+        _req(y, torch.int32, "y_ids")
+        out = torch.empty(1, dtype=torch.float32, device=self.device)
+        self._ck(self.lib.hiertcn_count_users(self._h, _ptr(y), B, y.shape[1], _ptr(out), self._stream()))
+        return out
+
+    def grad_segment(self, which: int):
+        """(offset, count) in floats of part `which` (0 item table, 1 scoring kernel + bias, 2 the rest) of the flat arenas."""
+        off, n = C.c_size_t(), C.c_size_t()
+        self._ck(self.lib.hiertcn_train_segment(self._h, int(which), C.byref(off), C.byref(n)))
+        return int(off.value), int(n.value)
+
+    def grad_rows_list(self, x_ids, y_ids):
+        """Ascending distinct ids of the batch -> (ids int32 [cap], count int32 [1]) on the device; cap = the most rows the batch
+        can touch (known on the host: no read-back)."""
+        n_ids = int(x_ids.numel())
+        cap = min(self.N - 1, n_ids * (2 if y_ids is not None else 1))
+        ids = torch.zeros(max(cap, self.N), dtype=torch.int32, device=self.device)   # (the compaction writes up to N - 1 entries)
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
+        need = int(self.lib.hiertcn_grad_rows_workspace_bytes(self._h))
+        if getattr(self, "_rows_ws", None) is None or self._rows_ws.numel() < need:
+            self._rows_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self._ck(self.lib.hiertcn_grad_rows_list(self._h, _ptr(x_ids), _ptr(y_ids), n_ids, _ptr(ids), ids.numel(), _ptr(cnt),
+                                              _ptr(self._rows_ws), self._rows_ws.numel(), self._stream()))
+        return ids[:cap], cnt, cap
+
+    def grad_rows_op(self, op: int, ids, count, rows=None):
+        cap = int(ids.numel())
+        self._ck(self.lib.hiertcn_grad_rows_op(self._h, int(op), _ptr(ids), _ptr(count), cap, _ptr(rows), self._stream()))
+
     def grad_arena(self) -> torch.Tensor:
         """The flat fp32 gradient buffer as a torch view (no copy): the all-reduce target of data-parallel training."""
         ptr = C.c_void_p()

@@ -152,16 +152,31 @@ class HierTCNModel:
         return self.train_step_packed(x, y, mask, state_np, lr)
 
     def train_step_packed(self, x, y, mask, state_np, lr):
-        from .distributed import all_reduce_gradients
         eng = self.engine
         dev = eng.device
         xd, yd, md = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, y, mask))
         st = torch.as_tensor(np.asarray(state_np, dtype=np.float32)).to(dev).contiguous()
-        out = eng.train_forward_backward(xd, yd, md, st)
-        world = all_reduce_gradients(eng.grad_arena())
-        eng.adam_step(float(lr), grad_scale=1.0 / world)
+        out = self.train_step_device(xd, yd, md, st, lr)
         m = metrics_dict(out["metrics8"])
         return dict(loss=m["loss"], state=out["state"].cpu().numpy(), user_count=m["user_count"])
+
+    def train_step_device(self, xd, yd, md, st, lr, state_out=None, metrics8=None):
+        """The step on device tensors, nothing read back: [global user count ->] forward + loss + scoring-layer backward ->
+        [collective of the scoring layer's gradient, overlapped with] the rest of the backward -> [the other collectives] ->
+        TF-form Adam.  `metrics8` comes back summed over ranks (its loss is the global batch's, model.py:116-117)."""
+        from .distributed import GradientExchange, all_reduce_metrics
+        eng = self.engine
+        if getattr(self, "_exchange", None) is None:
+            self._exchange = GradientExchange(eng)
+        ex = self._exchange
+        users = ex.global_users(yd)
+        out = eng.train_step_begin(xd, yd, md, st, state_out=state_out, metrics8=metrics8, users_global=users)
+        ex.after_scoring()
+        eng.train_step_finish(xd, yd, md)
+        ex.after_backward(xd, yd if self.hier else None)
+        eng.adam_step(float(lr), grad_scale=1.0)
+        all_reduce_metrics(out["metrics8"])
+        return out
 
 
 class TcnModel:
@@ -218,8 +233,7 @@ class TcnModel:
         return res
 
     def train_step(self, x, y, lr):
-        """One sess.run([train_op, loss]) of run_nn_xing.py: forward, loss, gradients, [all-reduce], TF-form Adam."""
-        from .distributed import all_reduce_gradients
+        """One sess.run([train_op, loss]) of run_nn_xing.py: forward, loss, gradients, [collectives], TF-form Adam."""
         if not self.trainable:
             raise RuntimeError("this model was created without training state (args.train = False)")
         eng = self.engine
@@ -227,9 +241,7 @@ class TcnModel:
         B, T = xi.shape
         xd = torch.from_numpy(np.ascontiguousarray(xi)).to(eng.device).view(B, 1, T)
         yd = torch.from_numpy(np.ascontiguousarray(yi)).to(eng.device).view(B, 1, T)
-        out = eng.train_forward_backward(xd, yd)
-        world = all_reduce_gradients(eng.grad_arena())
-        eng.adam_step(float(lr), grad_scale=1.0 / world)
+        out = HierTCNModel.train_step_device(self, xd, yd, None, None, lr)
         m = metrics_dict(out["metrics8"])
         return dict(loss=m["loss"], user_count=m["user_count"])
 

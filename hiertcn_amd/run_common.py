@@ -42,9 +42,27 @@ class EpochMeter:
         return {tag: self.sums[k] / n for k, tag in SCALARS}
 
     def finish(self) -> Dict[str, float]:
+        self._reduce_over_ranks()
         m = self.means()
         self._write(m, head="final\n" if self.final_header else "")
         return m
+
+    def _reduce_over_ranks(self):
+        """Data-parallel evaluation: every rank walked its own shard of the users; the epoch metric is the mean over ALL batches
+        of all ranks (the reference's mean of per-batch means, run_hier_xing.py:181-188, with the shards' batches pooled)."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return
+        keys = [k for k, _ in SCALARS]
+        t = torch.tensor([self.sums[k] for k in keys] + [float(self.batch_count)], dtype=torch.float64)
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        t = t.cpu()
+        for i, k in enumerate(keys):
+            self.sums[k] = float(t[i])
+        self.batch_count = int(round(float(t[-1])))
 
     def _write(self, m: Dict[str, float], head: str):
         if not self.results_path:

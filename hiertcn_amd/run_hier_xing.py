@@ -39,7 +39,8 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
         raise NotImplementedError("warm-start masks (model.py:102-103) are outside the hot path")
     model = sess
     time_load = time_run = 0.0
-    meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) else None, final_header=True)
+    from .distributed import is_main
+    meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) and is_main() else None, final_header=True)
     ranks_temp = np.zeros(args.max_activity_len + 1)
     ranks_temp_count = np.zeros(args.max_activity_len + 1)
     step = None
@@ -70,6 +71,11 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
     return summary, summary_val, time_load, time_run, state_np
 
 
+def _rank() -> int:
+    from .distributed import rank_world
+    return rank_world()[0]
+
+
 def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, sess=None):
     """run_hier_xing.py:210-350.  `sess` = model handle; when None a HierTCNModel is created for
     `args` (glorot / zeros / gate-bias-1 initialisation, i.e. `sess.run(init)`, :219) and, with
@@ -77,30 +83,32 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
     from . import checkpoint
     from .model import HierTCNModel
 
+    from .distributed import barrier, is_main
     model = sess if sess is not None else HierTCNModel(args)
     epoch = 0
-    state_restored = None
     if args.load:  # :220-229
         fname = args.load_path + str(args.load_epoch) + ".ckpt"
         try:
             params, extra = checkpoint.load(fname, with_extra=True)
-            model.set_parameters(params)
-            if getattr(model, "trainable", False) and "adam_m" in extra:   # optimizer slots, as tf.train.Saver keeps them
-                model.engine.load_optimizer_state(extra)
-            if "state_np" in extra:
-                state_restored = extra["state_np"]
-            print("Model restored: {}".format(fname))
-            epoch = args.load_epoch + 1
-        except Exception:
+        except FileNotFoundError:   # the reference's bare `except` (:227) hides every failure; only a missing file means "from scratch"
             print("No ckpt found: {}, train from scratch".format(fname))
             epoch = 0
-    train_writer = ScalarLog(args.log_path + "train/")
-    validate_writer = ScalarLog(args.log_path + "validate/")
-    test_writer = ScalarLog(args.log_path + "test/")
+        else:
+            model.set_parameters(params)   # a shape / name mismatch propagates: never continue on half-restored weights
+            if getattr(model, "trainable", False) and "adam_m" in extra:   # optimizer slots, as tf.train.Saver keeps them
+                model.engine.load_optimizer_state(extra)
+            print("Model restored: {}".format(fname))
+            epoch = args.load_epoch + 1
+    # data-parallel runs (torch.distributed.run): every rank walks its own shard of the users (the loaders were built with
+    # rank / world, run_xing.py) and steps in lockstep; rank 0 owns the files
+    log = args.log_path if is_main() else args.log_path + "rank{}/".format(_rank())
+    train_writer = ScalarLog(log + "train/")
+    validate_writer = ScalarLog(log + "validate/")
+    test_writer = ScalarLog(log + "test/")
     HT = args.hidden_dim * args.num_layer
-    state_np = np.zeros((args.batch_size, HT))           # :241-243: one carried state per loader
-    if state_restored is not None and state_restored.shape == state_np.shape:
-        state_np = state_restored                        # (the reference re-zeroes it on restart; the checkpoint carries it here)
+    # :241-243: one carried state per loader, zero at every (re)start as in the reference -- the lanes of a freshly built loader
+    # hold other users than the ones a checkpointed state belonged to
+    state_np = np.zeros((args.batch_size, HT))
     state_np_validate = np.zeros((args.batch_size, HT))
     state_np_test = np.zeros((args.batch_size, HT))
     while epoch <= args.epoch_max:  # :261
@@ -116,11 +124,13 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
             train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
             if args.save and epoch % args.save_epoch == 0 and epoch != 0:  # :317-321
                 fname = args.save_path + str(epoch) + ".ckpt"
-                extra = {"state_np": state_np}
-                if getattr(model, "trainable", False):
-                    extra.update(model.engine.optimizer_state())
-                checkpoint.save(fname, model.params, extra=extra)  # .params reads the device masters back
-                print("Model saved in path: %s" % fname)
+                if is_main():   # replicas are bit-identical: one writer (concurrent np.savez into one temp file would corrupt it)
+                    extra = {}
+                    if getattr(model, "trainable", False):
+                        extra.update(model.engine.optimizer_state())
+                    checkpoint.save(fname, model.params, extra=extra)  # .params reads the device masters back
+                    print("Model saved in path: %s" % fname)
+                barrier()
         if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:  # :324
             if args.validate:
                 summary, _, _, _, state_np_validate = evaluate_hier(args, loader_validate, state_np_validate, model, prefix="validate")

@@ -15,7 +15,8 @@ def evaluate_nn(args, loader, sess, prefix="test", warm_start=None):
         raise NotImplementedError("warm-start masks (model.py:102-103) are outside the hot path")
     model = sess
     time_load = time_run = 0.0
-    meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) else None, final_header=False)
+    from .distributed import is_main
+    meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) and is_main() else None, final_header=False)
     step = None
     while True:  # :31
         t1 = time.time()
@@ -42,15 +43,19 @@ def run_nn(args, loader_train, loader_validate, loader_test, warm_start=None, se
     if args.load:
         fname = args.load_path + str(args.load_epoch) + ".ckpt"
         try:
-            model.set_parameters(checkpoint.load(fname))
-            print("Model restored: {}".format(fname))
-            epoch = args.load_epoch + 1
-        except Exception:
+            params = checkpoint.load(fname)
+        except FileNotFoundError:   # only a missing file means "from scratch"; anything else propagates
             print("No ckpt found: {}, train from scratch".format(fname))
             epoch = 0
-    train_writer = ScalarLog(args.log_path + "train/")
-    validate_writer = ScalarLog(args.log_path + "validate/")
-    test_writer = ScalarLog(args.log_path + "test/")
+        else:
+            model.set_parameters(params)
+            print("Model restored: {}".format(fname))
+            epoch = args.load_epoch + 1
+    from .distributed import barrier, is_main, rank_world
+    log = args.log_path if is_main() else args.log_path + "rank{}/".format(rank_world()[0])
+    train_writer = ScalarLog(log + "train/")
+    validate_writer = ScalarLog(log + "validate/")
+    test_writer = ScalarLog(log + "test/")
     while epoch <= args.epoch_max:
         if args.train:
             lr = scheduled_lr(args, epoch)
@@ -62,8 +67,10 @@ def run_nn(args, loader_train, loader_validate, loader_test, warm_start=None, se
             train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
             if args.save and epoch % args.save_epoch == 0 and epoch != 0:
                 fname = args.save_path + str(epoch) + ".ckpt"
-                checkpoint.save(fname, model.params)
-                print("Model saved in path: %s" % fname)
+                if is_main():
+                    checkpoint.save(fname, model.params)
+                    print("Model saved in path: %s" % fname)
+                barrier()
         if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:
             if args.validate:
                 summary, _, _, _ = evaluate_nn(args, loader_validate, model, prefix="validate")

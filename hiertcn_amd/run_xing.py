@@ -17,14 +17,26 @@ from .data_loader import Dataloader_hier_model_xing, Dataloader_single_level_mod
 
 def main(argv=None):
     args = make_args(sys.argv[1:] if argv is None else argv)
-    while os.path.isdir(args.log_path):  # run_xing.py:10-13
-        args.log_path = args.log_path[:-1] + "1/"
-        print("logdir exist, new logdir: ", args.log_path)
-    os.makedirs(args.log_path)
+    # under torch.distributed.run: one process per GPU, users sharded over the ranks; a plain launch is world 1
+    from .distributed import init_from_env
+    import torch
+    if int(os.environ.get("WORLD_SIZE", "1")) > 1 and torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    rank, world, _ = init_from_env()
+    if rank == 0:
+        while os.path.isdir(args.log_path):  # run_xing.py:10-13
+            args.log_path = args.log_path[:-1] + "1/"
+            print("logdir exist, new logdir: ", args.log_path)
+        os.makedirs(args.log_path)
+    if world > 1:   # one log directory for the job: rank 0 picks it
+        import torch.distributed as dist
+        box = [args.log_path]
+        dist.broadcast_object_list(box, src=0)
+        args.log_path = box[0]
     hier = "hier" in args.model_type
     Loader = Dataloader_hier_model_xing if hier else Dataloader_single_level_model_xing
     splits = ("train", "train", "train") if args.warm_start else ("train", "validate", "test")  # :20-35
-    loader_train, loader_validate, loader_test = (Loader(args, s) for s in splits)
+    loader_train, loader_validate, loader_test = (Loader(args, s, rank=rank, world=world) for s in splits)
     if args.model_type == "tcn":
         from .run_nn_xing import run_nn
         return run_nn(args, loader_train, loader_validate, loader_test)

@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 4
+#define HIERTCN_ABI_VERSION 5
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -207,6 +207,37 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
                                    const float* state_in, int32_t B, int32_t S, int32_t L, void* workspace,
                                    size_t workspace_bytes, float* state_out, double* metrics8, void* stream);
 int hiertcn_grad_arena(hiertcn_handle_t h, float** grad, size_t* count);
+
+/* ---- data-parallel training (users sharded over ranks, a full replica per GPU; model.py:135-141 applied to the
+ * GLOBAL batch).  The step in two halves, so that the gradient collective of the scoring layer -- the large dense one -- runs
+ * while the rest of the backward pass computes:
+ *   hiertcn_train_step_begin    forward + loss + backward of the scoring layer (model_tcn.py:41): the gradients of out_kernel /
+ *                               out_bias are FINAL behind it on `stream`.  users_global (device, 1 float, may be NULL): the
+ *                               number of lanes with a target over ALL ranks (hiertcn_count_users, summed by the caller); it
+ *                               replaces this batch's own count in the loss normalisation of model.py:113-117, which makes the
+ *                               plain SUM of the ranks' gradients the gradient of the global batch's loss, ragged shards included.
+ *   hiertcn_train_step_finish   the rest of the backward (blocks, projection, item embedding, GRU, session pool); same arguments.
+ *   hiertcn_train_forward_backward == begin (users_global = NULL) + finish.
+ *   hiertcn_count_users         users[0] = number of lanes of y [B][T] with at least one target (model.py:113).
+ *   hiertcn_train_segment       which = 0 item table, 1 scoring kernel + bias (contiguous), 2 every other variable: offset / count
+ *                               (floats) of that part inside each flat arena (hiertcn_grad_arena, hiertcn_train_arena).
+ * Row-sparse exchange of the item table's gradient (only ids that occur in the batch have a non-zero row):
+ *   hiertcn_grad_rows_list      ascending list of the distinct ids in x_ids / y_ids (either may be NULL; n_ids entries each) into
+ *                               ids_out (capacity cap >= min(N - 1, ids given)), their number into count_out[0]; workspace of
+ *                               hiertcn_grad_rows_workspace_bytes() bytes.
+ *   hiertcn_grad_rows_op        for i < min(count[0], cap): op 0 rows[i][:] = grad_E[ids[i]][:]; 1 grad_E[ids[i]][:] = 0;
+ *                               2 grad_E[ids[i]][:] += rows[i][:]   (rows [cap][E] fp32).                                        */
+int hiertcn_train_step_begin(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
+                             int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out, double* metrics8,
+                             const float* users_global, void* stream);
+int hiertcn_train_step_finish(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, int32_t B, int32_t S,
+                              int32_t L, void* workspace, size_t workspace_bytes, void* stream);
+int hiertcn_count_users(hiertcn_handle_t h, const int32_t* y_ids, int32_t B, int32_t T, float* users, void* stream);
+int hiertcn_train_segment(hiertcn_handle_t h, int32_t which, size_t* offset, size_t* count);
+size_t hiertcn_grad_rows_workspace_bytes(hiertcn_handle_t h);
+int hiertcn_grad_rows_list(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, int64_t n_ids, int32_t* ids_out, int64_t cap,
+                           int32_t* count_out, void* workspace, size_t workspace_bytes, void* stream);
+int hiertcn_grad_rows_op(hiertcn_handle_t h, int32_t op, const int32_t* ids, const int32_t* count, int64_t cap, float* rows, void* stream);
 /* which = 0 masters, 1 gradients, 2 Adam m, 3 Adam v: the flat fp32 arenas (internal layouts; valid for this config
  * only) -- lets a checkpoint carry the optimizer slots as tf.train.Saver does; hiertcn_adam_time reads / sets t. */
 int hiertcn_train_arena(hiertcn_handle_t h, int32_t which, float** ptr, size_t* count);

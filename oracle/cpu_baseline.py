@@ -99,28 +99,40 @@ class CpuHierTCN:
         return out, state
 
 
-def time_cpu_baseline(args, params, x, y, mask, lanes=32, budget_s=15.0, max_batches=8, threads=None):
-    """Time eval_batch on successive `lanes`-user batches of (x, y, mask) until ~budget_s of CPU
-    work has been done (at least one batch).  Returns dict(value sessions/s, sessions, seconds,
-    cores, sample)."""
+def time_cpu_baseline(args, params, x, y, mask, variants=((32, 4), (128, 1)), repeats=3, budget_s=30.0, threads=None):
+    """Times eval_batch on bounded samples of the workload: for every (lanes, slots) variant one untimed warm-up run and up to
+    `repeats` timed runs (median) of the first `lanes` users x `slots` session slots of (x, y, mask) -- (32, 4) is the reference's
+    own batch width (args.py:193), (128, 1) a wide batch (best case for the CPU's GEMMs; at N = 300,000 one slot of 128 lanes is a
+    4.6 GB logits tensor, 1,024 lanes would be 37 GB).  The budget bounds the whole leg.  Returns dict(value = the BEST variant's
+    sessions/s, cores, sample, variants=[...])."""
     model = CpuHierTCN(args, params, threads)
     xt, yt = torch.from_numpy(x.astype(np.int64)), torch.from_numpy(y.astype(np.int64))
     mt = torch.from_numpy(mask.astype(np.float32))
     B, S, L = x.shape
     HT = args.hidden_dim * args.num_layer
-    done_sessions, elapsed, nb = 0, 0.0, 0
-    b0 = 0
-    while b0 + lanes <= B and nb < max_batches:
-        st = torch.zeros(lanes, HT)
-        t0 = time.perf_counter()
-        model.eval_batch(xt[b0:b0 + lanes], yt[b0:b0 + lanes], mt[b0:b0 + lanes], st)
-        dt = time.perf_counter() - t0
-        elapsed += dt
-        done_sessions += lanes * S
-        nb += 1
-        b0 += lanes
-        if elapsed >= budget_s or elapsed + dt > 2.0 * budget_s:
-            break
-    return dict(value=done_sessions / elapsed, sessions=done_sessions, seconds=elapsed, cores=model.threads,
-                sample=f"{nb} batch(es) of {lanes} lanes x {S} sessions x {L} steps, N={args.item_num}, d={getattr(args, 'emb_dim', 128)}, "
-                       f"fp32 torch-CPU {torch.__version__}, full logits per slot")
+    t_leg = time.perf_counter()
+    results = []
+    for lanes, slots in variants:
+        lanes, slots = min(lanes, B), min(slots, S)
+        xs, ys, ms = xt[:lanes, :slots].contiguous(), yt[:lanes, :slots].contiguous(), mt[:lanes, :slots].contiguous()
+        times = []
+        for rep in range(repeats + 1):            # rep 0 = warm-up (page-in, thread pool, allocator)
+            st = torch.zeros(lanes, HT)
+            t0 = time.perf_counter()
+            model.eval_batch(xs, ys, ms, st)
+            dt = time.perf_counter() - t0
+            if rep > 0:
+                times.append(dt)
+            spent = time.perf_counter() - t_leg
+            if rep >= 1 and spent + dt > budget_s * (len(results) + 1) / len(variants):
+                break
+        med = float(np.median(times))
+        results.append(dict(lanes=lanes, slots=slots, sessions=lanes * slots, seconds_median=round(med, 3), timed_runs=len(times),
+                            sessions_per_s=round(lanes * slots / med, 3)))
+    best = max(results, key=lambda r: r["sessions_per_s"])
+    return dict(value=best["sessions_per_s"], sessions=best["sessions"], seconds=time.perf_counter() - t_leg, cores=model.threads,
+                variants=results,
+                sample="best of " + "; ".join(f"{r['lanes']} lanes x {r['slots']} slots ({r['timed_runs']} timed runs after 1 warm-up, "
+                                               f"median {r['seconds_median']} s -> {r['sessions_per_s']} sessions/s)" for r in results)
+                       + f"; {L} steps, N={args.item_num}, d={getattr(args, 'emb_dim', 128)}, fp32 torch-CPU {torch.__version__}, "
+                         "full logits per slot")

@@ -53,5 +53,8 @@ def test_time_cpu_baseline_runs_bounded():
     args = hier_tcn_args(item_num=500, emb_dim=16, hidden_dim=8, tcn_channel=[16, 16])
     p = make_params(args)
     x, y, mask = make_batch(np.random.default_rng(0), 64, 2, 5, 500, ragged=False)
-    r = time_cpu_baseline(args, p, x, y, mask, lanes=32, budget_s=0.01)
-    assert r["sessions"] in (64, 128) and r["value"] > 0 and r["cores"] >= 1
+    r = time_cpu_baseline(args, p, x, y, mask, variants=((32, 2), (64, 1)), repeats=3, budget_s=0.01)
+    assert r["sessions"] == 64 and r["value"] > 0 and r["cores"] >= 1
+    assert len(r["variants"]) == 2 and all(v["timed_runs"] >= 1 for v in r["variants"])   # a warm-up and >= 1 timed run each
+    r = time_cpu_baseline(args, p, x, y, mask, variants=((32, 2),), repeats=3, budget_s=60.0)
+    assert r["variants"][0]["timed_runs"] == 3
