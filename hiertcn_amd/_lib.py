@@ -36,6 +36,17 @@ class Weights(C.Structure):
                 ("low_cand_kernel", C.c_void_p * MAX_LAYERS), ("low_cand_bias", C.c_void_p * MAX_LAYERS)]
 
 
+class GmmConfig(C.Structure):
+    _fields_ = [("item_num", C.c_int32), ("output_dim", C.c_int32), ("num_mixture", C.c_int32), ("kernel_size", C.c_int32),
+                ("n_blocks", C.c_int32), ("channels", C.c_int32 * MAX_BLOCKS), ("sigma", C.c_float)]
+
+
+class GmmWeights(C.Structure):
+    _fields_ = [("conv_kernel", C.c_void_p * MAX_BLOCKS), ("conv_bias", C.c_void_p * MAX_BLOCKS),
+                ("res_kernel", C.c_void_p * MAX_BLOCKS), ("res_bias", C.c_void_p * MAX_BLOCKS),
+                ("head_weights", C.c_void_p), ("head_biases", C.c_void_p)]
+
+
 class ScoreOut(C.Structure):
     _fields_ = [("rank", C.c_void_p), ("ce", C.c_void_p), ("target", C.c_void_p),
                 ("topk_idx", C.c_void_p), ("topk_val", C.c_void_p), ("topk", C.c_int32)]
@@ -82,6 +93,15 @@ SYMBOLS = {
     "hiertcn_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32, C.c_int32]),
     "hiertcn_forward_eval": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                         C.c_int32, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.POINTER(ScoreOut), C.c_void_p]),
+    "hiertcn_gmm_last_error": (C.c_char_p, []),
+    "hiertcn_gmm_create": (C.c_int, [C.POINTER(C.c_void_p), C.POINTER(GmmConfig)]),
+    "hiertcn_gmm_destroy": (C.c_int, [C.c_void_p]),
+    "hiertcn_gmm_set_weights": (C.c_int, [C.c_void_p, C.POINTER(GmmWeights), C.c_void_p]),
+    "hiertcn_gmm_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "hiertcn_gmm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hiertcn_gmm_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hiertcn_gmm_head_means": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hiertcn_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "hiertcn_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
 }

@@ -151,6 +151,7 @@ hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* s
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                         float* logits, hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr,
                         float* split_scratch = nullptr);
+hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, float* o_sq, float* o_tgt, hipStream_t st);
 // small batches: number of catalogue parts the production kernel splits into (1 = none); scratch = parts * 2 * R floats
 int score_split_parts(int64_t R, int NP);
 // ascending list of the rows with y > 0 (device-side, 3 small kernels): map [R], n_valid [1], scratch [(R+1023)/1024 + 1] ints

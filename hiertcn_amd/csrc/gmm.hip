@@ -1,0 +1,353 @@
+// Mixture-output models (BASELINE.json configs[4]): model_tcn_gmm.py:27-44 (trunk + head; model_gru_gmm.py:49-54
+// has the same head) and the two likelihood losses of loss.py:247-257.  C-ABI: hiertcn_gmm_* in include/hiertcn.h.
+//
+//  * trunk on XING ids: the TemporalConvNet runs on one_hot(id) * sign(id) directly (no 'emb' projection, model_tcn_gmm.py:36), so
+//    block 0 has Cin = item_num: a one-hot row times a kernel is a row GATHER -- conv1 = b + sum_j W_j[id[t - (K-1-j)]], Dense residual
+//    = Wr[id[t]] + br (customized_tcn_cell.py:46-49,102-106,120-127) -- one HBM-bound kernel over (K + 1) item-major tables; blocks
+//    1.. are the layer-at-a-time kernels of the main path (tcn_layers.hip);
+//  * head: fully_connected(n_out = M (1 + D)), decoded (the decode is the build's own -- oracle/gmm_oracle.py) as M prior logits +
+//    M mean vectors of D.  Neither the [rows, M D] means nor the one-hot y are ever materialised: for a one-hot target
+//    sum_d (y_d - mu_d)^2 = |mu_m|^2 - 2 mu_m[target] + 1, so each mixture is ONE pass of the scoring kernel's main loop over its
+//    [D, C] table with a sum-of-squares epilogue (score.hip, MODE 3) that also picks the target column by the same MFMA sequence;
+//  * k_gmm_finish turns (|mu_m|^2, mu_m[target], prior logits) into the per-step loss.
+#include <math.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <vector>
+
+#include "common.h"
+
+static thread_local char g_gerr[512] = "";
+extern "C" const char* hiertcn_gmm_last_error(void) { return g_gerr; }
+static int gfail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_gerr, sizeof(g_gerr), fmt, ap);
+  va_end(ap);
+  return code;
+}
+#define G_HIP(expr)                                                                                      \
+  do {                                                                                                   \
+    hipError_t e_ = (expr);                                                                              \
+    if (e_ != hipSuccess) return gfail(HIERTCN_ERR_HIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
+  } while (0)
+
+struct hiertcn_gmm_ctx {
+  hiertcn_gmm_config_t cfg;
+  int device;
+  int N, NP;        // trunk input width (item_num)
+  int D, DP;        // output_dim, padded to 64
+  int M, C0, Clast, K, nb;
+  bool weights_set;
+  std::vector<void*> allocs;
+  uint16_t* gather;                      // [K + 1][N][C0]: taps 0..K-1 of block 0's conv1, then the Dense residual kernel
+  float* b0;                             // [C0] conv1 bias of block 0
+  float* br0;                            // [C0] residual bias of block 0
+  uint16_t* convT[HIERTCN_MAX_BLOCKS];   // blocks 1..: [K][Cout][Cin]
+  float* conv_bias[HIERTCN_MAX_BLOCKS];
+  uint16_t* resT[HIERTCN_MAX_BLOCKS];
+  float* res_bias[HIERTCN_MAX_BLOCKS];
+  uint16_t* muT;                         // [M][DP][Clast]: item-major tables of the M mean blocks of the head, pad rows zero
+  float* mu_bias;                        // [M][DP], pad entries ZERO (a pad output must add 0 to |mu|^2)
+  float* pi_w;                           // [M][Clast] fp32
+  float* pi_b;                           // [M]
+};
+
+template <typename T>
+static hipError_t galloc(hiertcn_gmm_ctx* c, T** out, size_t count) {
+  void* p = nullptr;
+  hipError_t e = hipMalloc(&p, (count ? count : 1) * sizeof(T));
+  if (e != hipSuccess) return e;
+  c->allocs.push_back(p);
+  *out = reinterpret_cast<T*>(p);
+  return hipSuccess;
+}
+
+// ---- block 0 on ids: relu(relu(b + sum_j W_j[id[t-s_j]]) + Wr[id[t]] + br) ------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gmm_block0(const uint16_t* __restrict__ tab, const float* __restrict__ b0, const float* __restrict__ br0,
+                                                    const int32_t* __restrict__ ids, int64_t R, int T, int N, int C0, int K,
+                                                    uint16_t* __restrict__ out) {
+  const int ch = C0 >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch) * 8;
+  const int t = (int)(r % T);
+  float acc[8], res[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) { acc[j] = b0[c + j]; res[j] = br0[c + j]; }
+  for (int j = 0; j <= K; j++) {
+    const int s = (j < K) ? K - 1 - j : 0;   // tap j reads id[t - (K-1-j)] (dilation 1); j == K: the residual reads id[t]
+    if (t - s < 0) continue;                 // causal left padding: zeros (customized_tcn_cell.py:47-48)
+    int id = ids[r - s];
+    if (id <= 0 || id >= N) continue;        // null / out-of-range id: an all-zero one-hot row (model.py:59)
+    const uint4 v = *reinterpret_cast<const uint4*>(tab + ((int64_t)j * N + id) * C0 + c);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    float* dst = (j < K) ? acc : res;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      dst[2 * q] += bf2f((uint16_t)(w[q] & 0xffff));
+      dst[2 * q + 1] += bf2f((uint16_t)(w[q] >> 16));
+    }
+  }
+  uint4 o;
+  uint32_t* ow = reinterpret_cast<uint32_t*>(&o);
+#pragma unroll
+  for (int q = 0; q < 4; q++)
+    ow[q] = pack2bf(fmaxf(fmaxf(acc[2 * q], 0.f) + res[2 * q], 0.f), fmaxf(fmaxf(acc[2 * q + 1], 0.f) + res[2 * q + 1], 0.f));
+  *reinterpret_cast<uint4*>(out + r * C0 + c) = o;
+}
+
+// prior logits: pl[r][m] = hidden[r] . pi_w[m] + pi_b[m]; one wave per row
+__global__ __launch_bounds__(256) void k_gmm_prior(const uint16_t* __restrict__ hidden, const float* __restrict__ pi_w, const float* __restrict__ pi_b,
+                                                   int64_t R, int C, int M, float* __restrict__ pl) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  for (int m = 0; m < M; m++) {
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s = fmaf(bf2f(hidden[r * C + c]), pi_w[m * C + c], s);
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    if (lane == 0) pl[r * M + m] = s + pi_b[m];
+  }
+}
+
+// loss.py:247-257 from (|mu_m|^2, mu_m[target], prior logits); mode 0 gmm_prob, 1 gmm_prob_max; 0 on rows without a target
+// (model.py:111 multiplies the loss by mask_y).  sq / tgt are [M][R].
+__global__ void k_gmm_finish(const float* __restrict__ sq, const float* __restrict__ tgt, const float* __restrict__ pl, const int32_t* __restrict__ y,
+                             int64_t R, int M, int D, float sigma, int mode, float* __restrict__ loss) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  if (y[r] <= 0) { loss[r] = 0.f; return; }
+  float mx = -INFINITY;
+  for (int m = 0; m < M; m++) mx = fmaxf(mx, pl[r * M + m]);
+  float se = 0.f;
+  for (int m = 0; m < M; m++) se += expf(pl[r * M + m] - mx);
+  const float lse_pi = mx + logf(se);
+  const double cst = -(double)D * log((double)sigma) - 0.5 * (double)D * log(2.0 * M_PI);   // -D log sigma - D/2 log 2pi
+  const float inv2s2 = 0.5f / (sigma * sigma);
+  // the constant -D log sigma - D/2 log 2pi (2.9e4 at D = 20,778) is common to every mixture: kept out of the fp32 terms
+  float best = -INFINITY, zmax = -INFINITY;
+  float z[16];
+  for (int m = 0; m < M; m++) {
+    const float d2 = sq[(int64_t)m * R + r] - 2.f * tgt[(int64_t)m * R + r] + 1.f;
+    const float q = -inv2s2 * d2;                                   // mvn_m.log_prob(y) - cst
+    const float lpi = pl[r * M + m] - lse_pi;                       // log pi_m
+    z[m] = lpi + q;
+    zmax = fmaxf(zmax, z[m]);
+    best = fmaxf(best, lpi + q / (float)D);
+  }
+  if (mode == 1) { loss[r] = (float)(-((double)best + cst / (double)D)); return; }   // -log max_m pi_m exp(lp_m / D)
+  float s = 0.f;
+  for (int m = 0; m < M; m++) s += expf(z[m] - zmax);
+  loss[r] = (float)(-((double)(zmax + logf(s)) + cst) / (double)D);                   // -log(exp(log_prob / D))
+}
+
+extern "C" {
+
+int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cfg) {
+  if (!out || !cfg) return gfail(HIERTCN_ERR_INVALID, "null argument");
+  if (cfg->item_num < 2 || cfg->output_dim < 2) return gfail(HIERTCN_ERR_INVALID, "item_num / output_dim must be >= 2");
+  if (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS) return gfail(HIERTCN_ERR_INVALID, "n_blocks out of range");
+  if (cfg->kernel_size < 1 || cfg->kernel_size > 8) return gfail(HIERTCN_ERR_INVALID, "kernel_size out of range");
+  if (cfg->num_mixture < 1 || cfg->num_mixture > 16) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: 1..16", cfg->num_mixture);
+  if (!(cfg->sigma > 0.f)) return gfail(HIERTCN_ERR_INVALID, "sigma must be > 0 (a learned sigma, args.sigma None, is not built)");
+  for (int i = 0; i < cfg->n_blocks; i++)
+    if (cfg->channels[i] < 32 || (cfg->channels[i] & 31) || cfg->channels[i] > 1024)
+      return gfail(HIERTCN_ERR_INVALID, "tcn_channel[%d]=%d: widths are multiples of 32 up to 1024", i, cfg->channels[i]);
+  const int cl = cfg->channels[cfg->n_blocks - 1];
+  if (!(cl == 64 || cl == 128 || cl == 256 || cl == 512)) return gfail(HIERTCN_ERR_INVALID, "last tcn_channel %d: the head kernel is built for 64, 128, 256, 512", cl);
+  hiertcn_gmm_ctx* c = new hiertcn_gmm_ctx();
+  memset(static_cast<void*>(&c->cfg), 0, sizeof(c->cfg));
+  c->cfg = *cfg;
+  c->weights_set = false;
+  if (hipGetDevice(&c->device) != hipSuccess) { delete c; return gfail(HIERTCN_ERR_HIP, "hipGetDevice failed (no GPU?)"); }
+  c->N = cfg->item_num; c->NP = (c->N + 63) & ~63;
+  c->D = cfg->output_dim; c->DP = (c->D + 63) & ~63;
+  c->M = cfg->num_mixture; c->K = cfg->kernel_size; c->nb = cfg->n_blocks;
+  c->C0 = cfg->channels[0]; c->Clast = cl;
+  memset(c->convT, 0, sizeof(c->convT)); memset(c->conv_bias, 0, sizeof(c->conv_bias));
+  memset(c->resT, 0, sizeof(c->resT)); memset(c->res_bias, 0, sizeof(c->res_bias));
+#define GA(ptr, count)                                                                              \
+  do {                                                                                              \
+    hipError_t e_ = galloc(c, &(ptr), (size_t)(count));                                             \
+    if (e_ != hipSuccess) { hiertcn_gmm_destroy(c); return gfail(HIERTCN_ERR_HIP, "hipMalloc(%s) failed: %s", #ptr, hipGetErrorString(e_)); } \
+  } while (0)
+  GA(c->gather, (size_t)(c->K + 1) * c->N * c->C0);
+  GA(c->b0, c->C0);
+  GA(c->br0, c->C0);
+  for (int i = 1, cin = c->C0; i < c->nb; cin = cfg->channels[i], i++) {
+    GA(c->convT[i], (size_t)c->K * cin * cfg->channels[i]);
+    GA(c->conv_bias[i], cfg->channels[i]);
+    if (cin != cfg->channels[i]) { GA(c->resT[i], (size_t)cin * cfg->channels[i]); GA(c->res_bias[i], cfg->channels[i]); }
+  }
+  GA(c->muT, (size_t)c->M * c->DP * cl);
+  GA(c->mu_bias, (size_t)c->M * c->DP);
+  GA(c->pi_w, (size_t)c->M * cl);
+  GA(c->pi_b, c->M);
+#undef GA
+  *out = c;
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_destroy(hiertcn_gmm_handle_t g) {
+  if (!g) return HIERTCN_OK;
+  for (void* p : g->allocs) (void)hipFree(p);
+  delete g;
+  return HIERTCN_OK;
+}
+
+// strided 2-D copies used below: dst[r][c] (ld_dst) = src[r][c0 + c] (ld_src), fp32
+__global__ void k_copy_cols_f32(const float* __restrict__ src, int64_t ld_src, int64_t c0, float* __restrict__ dst, int64_t ld_dst, int64_t rows,
+                                int64_t cols) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const int64_t r = i / cols, c = i - r * cols;
+  dst[r * ld_dst + c] = src[r * ld_src + c0 + c];
+}
+// muT[m][n][c] = bf16(W[c][M + m D + n]) for n < D, 0 for D <= n < DP; one thread per (m, n, c) with c fastest
+__global__ void k_gmm_head_tables(const float* __restrict__ W, int64_t n_out, int C, int M, int D, int DP, uint16_t* __restrict__ muT) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * DP * C) return;
+  const int c = (int)(i % C);
+  const int64_t mn = i / C;
+  const int n = (int)(mn % DP), m = (int)(mn / DP);
+  muT[i] = n < D ? f2bf(W[(int64_t)c * n_out + M + (int64_t)m * D + n]) : (uint16_t)0;
+}
+
+int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream) {
+  if (!g || !w) return gfail(HIERTCN_ERR_INVALID, "null argument");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (!w->conv_kernel[0] || !w->conv_bias[0] || !w->res_kernel[0] || !w->res_bias[0] || !w->head_weights || !w->head_biases)
+    return gfail(HIERTCN_ERR_INVALID, "block 0 (conv1 + Dense residual: Cin = item_num != Cout) and the head are required");
+  const int N = g->N, C0 = g->C0, K = g->K, M = g->M, D = g->D, DP = g->DP, CL = g->Clast;
+  // block 0: the K taps [N][C0] and the residual kernel [N][C0] are already item-major in the reference layout: rows -> bf16
+  for (int j = 0; j < K; j++) G_HIP(launch_rows_to_bf16(w->conv_kernel[0] + (size_t)j * N * C0, g->gather + (size_t)j * N * C0, N, C0, 0, st));
+  G_HIP(launch_rows_to_bf16(w->res_kernel[0], g->gather + (size_t)K * N * C0, N, C0, 0, st));
+  G_HIP(launch_copy_pad_f32(w->conv_bias[0], g->b0, C0, C0, 0.f, st));
+  G_HIP(launch_copy_pad_f32(w->res_bias[0], g->br0, C0, C0, 0.f, st));
+  for (int i = 1, cin = C0; i < g->nb; cin = g->cfg.channels[i], i++) {
+    const int cout = g->cfg.channels[i];
+    if (!w->conv_kernel[i] || !w->conv_bias[i]) return gfail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
+    if ((cin != cout) != (w->res_kernel[i] != nullptr)) return gfail(HIERTCN_ERR_INVALID, "block %d: a Dense residual exists exactly when Cin != Cout", i);
+    for (int j = 0; j < K; j++)
+      G_HIP(launch_transpose_to_bf16(w->conv_kernel[i] + (size_t)j * cin * cout, g->convT[i] + (size_t)j * cin * cout, cin, cout, cout, st));
+    G_HIP(launch_copy_pad_f32(w->conv_bias[i], g->conv_bias[i], cout, cout, 0.f, st));
+    if (w->res_kernel[i]) {
+      G_HIP(launch_transpose_to_bf16(w->res_kernel[i], g->resT[i], cin, cout, cout, st));
+      G_HIP(launch_copy_pad_f32(w->res_bias[i], g->res_bias[i], cout, cout, 0.f, st));
+    }
+  }
+  // head [C][M (1 + D)]: columns [0, M) -> prior kernel [M][C] fp32; columns M + m D + n -> table m, row n (bf16, item-major)
+  const int64_t n_out = (int64_t)M * (1 + D);
+  {
+    // pi_w[m][c] = W[c][m]
+    const int64_t n = (int64_t)M * CL;
+    // transpose through the column copy: tmp[c][m] = W[c][m] (ld n_out) then launch_transpose_f32 [C][M] -> [M][C]
+    float* tmp = nullptr;
+    G_HIP(hipMalloc(reinterpret_cast<void**>(&tmp), (size_t)n * sizeof(float)));
+    hipLaunchKernelGGL(k_copy_cols_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w->head_weights, n_out, (int64_t)0, tmp, (int64_t)M,
+                       (int64_t)CL, (int64_t)M);
+    hipError_t e = launch_transpose_f32(tmp, g->pi_w, CL, M, st);
+    if (e == hipSuccess) e = hipStreamSynchronize(st);
+    (void)hipFree(tmp);
+    G_HIP(e);
+  }
+  G_HIP(hipMemcpyAsync(g->pi_b, w->head_biases, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, st));
+  {
+    const int64_t n = (int64_t)M * DP * CL;
+    hipLaunchKernelGGL(k_gmm_head_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w->head_weights, n_out, CL, M, D, DP, g->muT);
+    G_HIP(hipGetLastError());
+  }
+  G_HIP(hipMemsetAsync(g->mu_bias, 0, (size_t)M * DP * sizeof(float), st));
+  for (int m = 0; m < M; m++)
+    G_HIP(hipMemcpyAsync(g->mu_bias + (size_t)m * DP, w->head_biases + M + (size_t)m * D, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  g->weights_set = true;
+  return HIERTCN_OK;
+}
+
+static int max_w(const hiertcn_gmm_ctx* g) {
+  int w = 0;
+  for (int i = 0; i < g->nb; i++) w = g->cfg.channels[i] > w ? g->cfg.channels[i] : w;
+  return w;
+}
+
+size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R) {
+  if (!g || R < 0) return 0;
+  const size_t act = (((size_t)R * max_w(g) * 2) + 255) & ~(size_t)255;
+  const size_t per = (((size_t)R * sizeof(float)) + 255) & ~(size_t)255;
+  return 2 * act + 2 * g->M * per + ((((size_t)R * g->M * sizeof(float)) + 255) & ~(size_t)255);
+}
+
+#define G_READY(g)                                                                       \
+  if (!(g)) return gfail(HIERTCN_ERR_INVALID, "null handle");                            \
+  if (!(g)->weights_set) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_set_weights has not been called")
+
+int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  G_READY(g);
+  if (!x_ids || !hidden || B < 1 || T < 1 || T > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  const int64_t R = B * T;
+  if (!workspace || workspace_bytes < hiertcn_gmm_workspace_bytes(g, R)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t act = (((size_t)R * max_w(g) * 2) + 255) & ~(size_t)255;
+  uint16_t* buf[2] = {reinterpret_cast<uint16_t*>(workspace), reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(workspace) + act)};
+  uint16_t* out0 = (g->nb == 1) ? hidden : buf[0];
+  const int64_t n0 = R * (g->C0 / 8);
+  hipLaunchKernelGGL(k_gmm_block0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, g->gather, g->b0, g->br0, x_ids, R, T, g->N, g->C0, g->K, out0);
+  G_HIP(hipGetLastError());
+  int cur = 0;
+  for (int i = 1, cin = g->C0; i < g->nb; cin = g->cfg.channels[i], i++) {
+    LayerArgs a = {};
+    a.in = buf[cur];
+    a.out = (i == g->nb - 1) ? hidden : buf[cur ^ 1];
+    a.W = g->convT[i]; a.bias = g->conv_bias[i]; a.Wres = g->resT[i]; a.bres = g->res_bias[i];
+    a.Cin = cin; a.Cout = g->cfg.channels[i]; a.taps = g->K; a.dil = 1 << i; a.L = T; a.n_seq = B; a.linear = 0;
+    G_HIP(launch_tcn_layer(a, st));
+    cur ^= 1;
+  }
+  return HIERTCN_OK;
+}
+
+static void table_model(const hiertcn_gmm_ctx* g, int m, ModelDev* md) {
+  memset(md, 0, sizeof(*md));
+  md->N = g->D; md->NP = g->DP; md->Clast = g->Clast;
+  md->outT = g->muT + (size_t)m * g->DP * g->Clast;
+  md->out_bias = g->mu_bias + (size_t)m * g->DP;
+}
+
+int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32_t* y_ids, int64_t R, int32_t mode, float* loss, float* sq_out,
+                     float* tgt_out, float* prior_out, void* workspace, size_t workspace_bytes, void* stream) {
+  G_READY(g);
+  if (!hidden || !y_ids || !loss || R < 1 || mode < 0 || mode > 1) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  if (!workspace || workspace_bytes < hiertcn_gmm_workspace_bytes(g, R)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  const size_t act = (((size_t)R * max_w(g) * 2) + 255) & ~(size_t)255;
+  const size_t per = (((size_t)R * sizeof(float)) + 255) & ~(size_t)255;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace) + 2 * act;
+  float* sq = sq_out ? sq_out : reinterpret_cast<float*>(ws);                       // [M][R]
+  float* tg = tgt_out ? tgt_out : reinterpret_cast<float*>(ws + g->M * per);        // [M][R]
+  float* pl = prior_out ? prior_out : reinterpret_cast<float*>(ws + 2 * g->M * per);   // [R][M]
+  for (int m = 0; m < g->M; m++) {
+    ModelDev md;
+    table_model(g, m, &md);
+    G_HIP(launch_score_sumsq(md, hidden, y_ids, R, sq + (size_t)m * R, tg + (size_t)m * R, st));
+  }
+  hipLaunchKernelGGL(k_gmm_prior, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, hidden, g->pi_w, g->pi_b, R, g->Clast, g->M, pl);
+  hipLaunchKernelGGL(k_gmm_finish, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, sq, tg, pl, y_ids, R, g->M, g->D, g->cfg.sigma, mode, loss);
+  G_HIP(hipGetLastError());
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64_t R, int32_t m, float* mu_out, void* stream) {
+  G_READY(g);
+  if (!hidden || !mu_out || R < 1 || m < 0 || m >= g->M) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  ModelDev md;
+  table_model(g, m, &md);
+  G_HIP(launch_score(md, hidden, nullptr, R, nullptr, mu_out, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
+}  // extern "C"

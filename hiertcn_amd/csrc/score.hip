@@ -80,6 +80,18 @@ __device__ __forceinline__ void epilogue(const f32x16& v, RowState& st) {
     for (int i = 0; i < 16; i++) st.cnt += (v[i] > st.t) ? 1 : 0;
     return;
   }
+  if (MODE == 3) {   // mixture head (gmm.hip): st.s = sum of squares of the row's outputs (|mu_m|^2 of loss.py:247-257's Gaussians)
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; i += 4) {
+      s0 = fmaf(v[i], v[i], s0);
+      s1 = fmaf(v[i + 1], v[i + 1], s1);
+      s2 = fmaf(v[i + 2], v[i + 2], s2);
+      s3 = fmaf(v[i + 3], v[i + 3], s3);
+    }
+    st.s += (s0 + s1) + (s2 + s3);
+    return;
+  }
   float x[16];
 #pragma unroll
   for (int i = 0; i < 16; i++) x[i] = fmaf(v[i], LOG2E_F, -st.m2);  // fma results are canonical: no v_max canonicalisation below
@@ -406,6 +418,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       const float M2 = fmaxf(st[cbk].m2, m_o);
       const float S = st[cbk].s * __builtin_amdgcn_exp2f(st[cbk].m2 - M2) + s_o * __builtin_amdgcn_exp2f(m_o - M2);
       const int cnt = st[cbk].cnt + c_o;
+      if (MODE == 3) {   // sum of squares over ALL outputs of the row (null-id rows too: their y is the zero vector, not "no row")
+        if (lh == 0 && myrow[cbk] < Rin) {
+          if (o_ce) o_ce[myrow[cbk]] = st[cbk].s + s_o;
+          if (o_tgt) o_tgt[myrow[cbk]] = myy[cbk] > 0 ? st[cbk].t : 0.f;
+        }
+        continue;
+      }
       if (lh == 0 && myrow[cbk] < Rin) {
         const bool valid = myy[cbk] > 0;
         const float lse = (M2 + log2f(S)) * LN2_F;
@@ -1274,6 +1293,21 @@ static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, co
                      out ? out->topk_idx : nullptr, out ? out->topk_val : nullptr, out ? (int)out->topk : 0, lse, w, stg_begin, stg_end,
                      row_map, n_rows_dev);
   return hipGetLastError();
+}
+
+// Mixture head (gmm.hip): for the table (m.outT [NP][C], m.out_bias [NP], pad rows / biases ZERO) -> o_sq[r] = sum_n z[r][n]^2,
+// o_tgt[r] = z[r][y[r]] (0 for the null id); the same streaming kernel with a sum-of-squares epilogue.
+hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, float* o_sq, float* o_tgt, hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  hiertcn_score_out_t out;
+  out.rank = nullptr; out.ce = o_sq; out.target = o_tgt; out.topk_idx = nullptr; out.topk_val = nullptr; out.topk = 0;
+  switch (m.Clast) {
+    case 64: return launch_score_v<64, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
+    case 128: return launch_score_v<128, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
+    case 256: return launch_score_v<256, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
+    case 512: return launch_score_512<false, 3, 0>(m, hidden, y, R, &out, nullptr, nullptr, nullptr, 0, -1, st);
+    default: return hipErrorInvalidValue;
+  }
 }
 
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,

@@ -40,7 +40,7 @@ def _req(t: torch.Tensor, dtype, name: str, shape=None):
 UNSUPPORTED_FLAGS = ("has_gap", "has_impression", "has_batchnorm", "has_weightnorm", "has_layernorm", "l2_normalize")
 
 
-def check_supported(args, train: bool = False):
+def check_supported(args, train: bool = False, loss_ok=("cross_entropy",)):
     """The ONE place that refuses model-changing flags the hot path does not implement.  Every entry
     point builds an Engine, and Engine() builds its config here, so neither the model_hier / model_tcn shims nor the run loops
     nor the CLI can accept such a flag and silently run something else under the requested run name (args.py:232-240)."""
@@ -49,8 +49,8 @@ def check_supported(args, train: bool = False):
             raise NotImplementedError(f"args.{flag}=True is outside the hot path (reference default is False)")
     if getattr(args, "data_noise", None) is not None:
         raise NotImplementedError("args.data_noise is outside the hot path")
-    if getattr(args, "loss", "cross_entropy") != "cross_entropy":
-        raise NotImplementedError(f"args.loss={args.loss!r}: only 'cross_entropy' (loss.py:20-21) is built")
+    if getattr(args, "loss", "cross_entropy") not in loss_ok:
+        raise NotImplementedError(f"args.loss={args.loss!r}: this model is built for {loss_ok} (loss.py:20-21, 247-257)")
     if train and float(getattr(args, "dropout", 0.0) or 0.0) != 0.0:
         raise NotImplementedError("args.dropout != 0 while training: tf.layers.Dropout after conv1 (customized_tcn_cell.py:119) "
                                   "is not built; the reference default is 0.0")

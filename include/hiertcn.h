@@ -245,6 +245,51 @@ int hiertcn_adam_time(hiertcn_handle_t h, int64_t* get, const int64_t* set);
 int hiertcn_adam_step(hiertcn_handle_t h, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
 int hiertcn_export_weights(hiertcn_handle_t h, const hiertcn_weights_t* dst, int32_t which, void* stream);
 
+/* ---- mixture-output models (BASELINE.json configs[4]: model_tcn_gmm.py:12-44; the head of model_gru_gmm.py:49-54; the likelihood
+ * losses of loss.py:247-257).  A handle of its own: the trunk differs from model_tcn's (no 'emb' projection -- on XING the
+ * TemporalConvNet reads one_hot(id)*sign(id) directly, so block 0 has Cin = item_num and a Dense residual) and the head has
+ * n_out = num_mixture * (1 + output_dim) outputs (args.sigma set; a learned sigma is not built).
+ * The DECODE of the head output is not in the reference (calc_loss_gmm has no caller): this library uses pi = softmax of the first
+ * M outputs, mu = the next M*D outputs mixture-major, sigma = args.sigma -- "parity unpinned" for the decode; the head GEMM and the
+ * formulas are checked against oracle/gmm_oracle.py.
+ *   hiertcn_gmm_set_weights  fp32 device tensors in the reference layouts: conv_kernel[i] [K][Cin][Cout] (Cin = item_num for i = 0),
+ *                            conv_bias[i], res_kernel[i] [Cin][Cout] / res_bias[i] where Cin != Cout (always for i = 0),
+ *                            head_weights [C_last][M(1+D)], head_biases [M(1+D)]  (<scope>/fully_connected/{weights,biases}).
+ *   hiertcn_gmm_forward      x_ids [B][T] -> hidden [B*T][C_last] (storage type), model_tcn_gmm.py:27-36.
+ *   hiertcn_gmm_loss         hidden [R][C_last], y_ids [R] -> loss [R] (mode 0: loss.py:248 gmm_prob, 1: loss.py:249-257
+ *                            gmm_prob_max; 0 where y == 0, as model.py:111 masks it).  Neither the [R][M*D] means nor the one-hot
+ *                            targets are materialised: sum_d (y_d - mu_d)^2 = |mu_m|^2 - 2 mu_m[y] + 1.  Optional outputs (NULL =
+ *                            not wanted): sq [M][R] = |mu_m|^2, tgt [M][R] = mu_m[y], prior [R][M] = the prior logits.
+ *   hiertcn_gmm_head_means   parity/debug: materialise mu_m [R][D] fp32 for one mixture m.                                        */
+typedef struct hiertcn_gmm_ctx* hiertcn_gmm_handle_t;
+typedef struct {
+  int32_t item_num;                      /* width of the one-hot input (args.item_num)            */
+  int32_t output_dim;                    /* D, args.output_dim (= item_num on XING)                 */
+  int32_t num_mixture;                   /* M, args.num_mixture                                     */
+  int32_t kernel_size;
+  int32_t n_blocks;
+  int32_t channels[HIERTCN_MAX_BLOCKS];
+  float sigma;                           /* args.sigma (> 0)                                        */
+} hiertcn_gmm_config_t;
+typedef struct {
+  const float* conv_kernel[HIERTCN_MAX_BLOCKS];
+  const float* conv_bias[HIERTCN_MAX_BLOCKS];
+  const float* res_kernel[HIERTCN_MAX_BLOCKS];
+  const float* res_bias[HIERTCN_MAX_BLOCKS];
+  const float* head_weights;
+  const float* head_biases;
+} hiertcn_gmm_weights_t;
+const char* hiertcn_gmm_last_error(void);
+int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cfg);
+int hiertcn_gmm_destroy(hiertcn_gmm_handle_t g);
+int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream);
+size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R);
+int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
+                        size_t workspace_bytes, void* stream);
+int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32_t* y_ids, int64_t R, int32_t mode, float* loss,
+                     float* sq_out, float* tgt_out, float* prior_out, void* workspace, size_t workspace_bytes, void* stream);
+int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64_t R, int32_t m, float* mu_out, void* stream);
+
 /* Measurement hook for bench.py: average duration in milliseconds of the scoring kernel over the
  * launches made since the last reset, measured with HIP events recorded on the launch stream.
  * Disabled (0 cost) unless enabled. */

