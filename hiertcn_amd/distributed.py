@@ -149,6 +149,19 @@ class GradientExchange:
         _sum_async(u).wait()
         return u
 
+    def _max_over_ranks_cached(self, n: int) -> int:
+        """Largest batch (ids per rank) over the ranks: the all-gather of (row id, row) pairs needs one capacity for all.  Asked once
+        per distinct local size (a host-side collective), not per step."""
+        if not hasattr(self, "_nmax"):
+            self._nmax = {}
+        if n not in self._nmax:
+            t = torch.tensor([n], dtype=torch.int64)
+            if dist.get_backend() == "nccl":
+                t = t.to(self.eng.device)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            self._nmax[n] = int(t.item())
+        return self._nmax[n]
+
     def _dense(self, seg: torch.Tensor):
         world = self.world
         if (self.mode == "rs_ag" and dist.get_backend() == "nccl" and seg.numel() % world == 0):
@@ -183,7 +196,7 @@ class GradientExchange:
         off2, n2 = eng.grad_segment(2)
         self._pending.append(_sum_async(g[off2:off2 + n2]))
         off0, n0 = eng.grad_segment(0)
-        n_ids = int(x_ids.numel()) * (2 if y_ids is not None else 1)
+        n_ids = self._max_over_ranks_cached(int(x_ids.numel())) * (2 if y_ids is not None else 1)   # the same on every rank
         bound = min(eng.N - 1, n_ids)
         # all-gather of pairs receives (W-1) * bound rows; a ring all-reduce moves 2 (W-1)/W * N rows
         frac = self.sparse_frac if self.sparse_frac >= 0 else 2.0 / world
@@ -192,7 +205,7 @@ class GradientExchange:
         if not sparse:
             self._pending.append(_sum_async(g[off0:off0 + n0]))
         else:
-            ids, cnt, cap = eng.grad_rows_list(x_ids, y_ids)
+            ids, cnt, cap = eng.grad_rows_list(x_ids, y_ids, cap=bound)
             rows = torch.empty((cap, eng.E), dtype=torch.float32, device=eng.device)
             eng.grad_rows_op(0, ids, cnt, rows)                 # pack own rows
             eng.grad_rows_op(1, ids, cnt)                       # and clear them: every rank rebuilds the sum in rank order

@@ -403,11 +403,11 @@ class Engine:
         self._ck(self.lib.hiertcn_train_segment(self._h, int(which), C.byref(off), C.byref(n)))
         return int(off.value), int(n.value)
 
-    def grad_rows_list(self, x_ids, y_ids):
-        """Ascending distinct ids of the batch -> (ids int32 [cap], count int32 [1]) on the device; cap = the most rows the batch
+    def grad_rows_list(self, x_ids, y_ids, cap=None):
+        """Ascending distinct ids of the batch -> (ids int32 [cap], count int32 [1]) on the device; cap >= the most rows the batch
         can touch (known on the host: no read-back)."""
         n_ids = int(x_ids.numel())
-        cap = min(self.N - 1, n_ids * (2 if y_ids is not None else 1))
+        cap = max(int(cap or 0), min(self.N - 1, n_ids * (2 if y_ids is not None else 1)))
         ids = torch.zeros(max(cap, self.N), dtype=torch.int32, device=self.device)   # (the compaction writes up to N - 1 entries)
         cnt = torch.zeros(1, dtype=torch.int32, device=self.device)
         need = int(self.lib.hiertcn_grad_rows_workspace_bytes(self._h))

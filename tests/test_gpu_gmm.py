@@ -38,6 +38,7 @@ def test_tcn_gmm_forward_head_and_losses_vs_oracle(N, M, channels, K, B, T):
 
     # trunk: bf16-mirror oracle (weights rounded as stored, activations rounded after every block)
     pr = {k: (O.round_bf16(v) if (k.endswith("kernel") or k.endswith("weights")) else v) for k, v in p.items()}
+    pr["tcn_gmm/fully_connected/weights"][:, :M] = p["tcn_gmm/fully_connected/weights"][:, :M]   # the M prior columns stay fp32 on the device
     hid = model.forward(dev(x))
     h_ref = G.tcn_gmm_hidden(a, x, pr, "tcn_gmm", O.MIRROR)
     assert np.abs(hid.float().cpu().numpy().reshape(B, T, -1) - h_ref).max() < 2e-2 * max(1.0, np.abs(h_ref).max())   # one bf16 ulp of the largest activation
@@ -79,6 +80,7 @@ def test_reference_surface_model_tcn_gmm_and_calc_loss_gmm():
     model = MG._SCOPES["tcn_gmm"]
     h = pred.hidden.float().cpu().numpy().astype(np.float64).reshape(3, 12, -1)
     pr = {k: (O.round_bf16(v) if (k.endswith("kernel") or k.endswith("weights")) else v) for k, v in model.params.items()}
+    pr["tcn_gmm/fully_connected/weights"][:, :4] = model.params["tcn_gmm/fully_connected/weights"][:, :4]
     want = G.calc_loss_gmm_ids(G.gmm_head(h, pr, "tcn_gmm"), y, a)
     assert np.abs(loss.cpu().numpy() - want)[y > 0].max() < 1e-4
     with pytest.raises(NotImplementedError):
