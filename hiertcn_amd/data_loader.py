@@ -243,3 +243,49 @@ class Dataloader_hier_model_xing:
         x *= t < slot_len[None, :, None]                           # nothing exists past a slot's own width
         mask = self._s_mask[sess].astype(np.float32)
         return x, y, mask, [int(v) for v in slot_len]
+
+
+class Prefetcher:
+    """Runs a batch source (`loader.get_packed_batch`, `loader.get_batch`) on a background thread, `depth` batches ahead, so that
+    packing batch i+1 overlaps the GPU work on batch i (the packers are NumPy array passes that release the GIL for most of their
+    time).  Order and contents are exactly the source's; `done` travels with each batch when the source has the attribute.
+
+        pre = Prefetcher(loader.get_packed_batch, depth=4, owner=loader)
+        x, y, mask, widths = pre.get();  pre.done  # == loader.done as it was right after that batch
+    """
+
+    def __init__(self, source, depth: int = 2, owner=None):
+        import queue
+        import threading
+        self._q = queue.Queue(maxsize=max(1, int(depth)))
+        self._stop = threading.Event()
+        self._source, self._owner = source, owner
+        self.done = False
+        self._t = threading.Thread(target=self._run, daemon=True)
+        self._t.start()
+
+    def _run(self):
+        while not self._stop.is_set():
+            try:
+                item = (self._source(), bool(getattr(self._owner, "done", False)), None)
+            except Exception as e:  # noqa: BLE001  (re-raised in the consumer)
+                item = (None, False, e)
+            while not self._stop.is_set():
+                try:
+                    self._q.put(item, timeout=0.1)
+                    break
+                except Exception:  # queue.Full
+                    continue
+            if item[2] is not None:
+                return
+
+    def get(self):
+        batch, done, err = self._q.get()
+        if err is not None:
+            raise err
+        self.done = done
+        return batch
+
+    def close(self):
+        self._stop.set()
+        self._t.join(timeout=2.0)

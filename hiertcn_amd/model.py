@@ -191,16 +191,22 @@ class TcnModel:
         self._params = params if params is not None else init_params(args, seed, "tcn")
         renamed = {("tcn" + k[len(name):] if k.startswith(name + "/") else k): v for k, v in self._params.items()}
         self._dev_args, dev_params = pad_widths(args, renamed, "tcn")
-        if self.trainable and (self._dev_args.emb_dim != int(getattr(args, "emb_dim", 128)) or
-                               list(self._dev_args.tcn_channel) != [int(c) for c in args.tcn_channel]):
-            raise NotImplementedError("training a width-padded model is not built: use widths that are multiples of 32")
+        # width-padded models (d = 100 -> 128) train as they are: the padded channels stay exactly zero (params.unpad_widths)
+        self._padded = (self._dev_args.emb_dim != int(getattr(args, "emb_dim", 128)) or
+                        list(self._dev_args.tcn_channel) != [int(c) for c in args.tcn_channel])
         self.engine = Engine(self._dev_args, hier=False, train=self.trainable)
         self.engine.set_weights(dev_params, root="tcn")
 
     @property
     def params(self) -> dict:
         if self.trainable:
-            self._params = self.engine.export("weights", root=self.name)
+            dev = self.engine.export("weights", root=self.name)
+            if self._padded:
+                from .params import unpad_widths
+                tcn_named = {("tcn" + k[len(self.name):] if k.startswith(self.name + "/") else k): v for k, v in dev.items()}
+                cut = unpad_widths(self.args, tcn_named, "tcn")
+                dev = {(self.name + k[3:] if k.startswith("tcn/") else k): v for k, v in cut.items()}
+            self._params = dev
         return self._params
 
     @params.setter

@@ -124,3 +124,20 @@ def pad_widths(args, params: Dict[str, np.ndarray], model: str = "hier", multipl
             dst[tuple(slice(0, n) for n in src.shape)] = src
         out[name] = dst
     return a, out
+
+
+def unpad_widths(args, padded: Dict[str, np.ndarray], model: str = "hier") -> Dict[str, np.ndarray]:
+    """Inverse of pad_widths: cut the tensors of a width-padded model back to the shapes of `args` (what a checkpoint holds).  The cut
+    entries are exactly zero for a model that was created by pad_widths and trained on the device: a zero-padded channel has zero
+    activations, so every gradient into its weights and every gradient flowing back through it is exactly zero, and Adam on a
+    zero gradient with zero moments is a zero update."""
+    E0 = int(getattr(args, "emb_dim", 128))
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in param_shapes(args, model).items():
+        src = np.asarray(padded[name])
+        if name.endswith("tcn/emb/kernel") and model == "hier":
+            E1 = src.shape[1]
+            out[name] = np.concatenate([src[:E0, :E0], src[E1:, :E0]], 0)
+        else:
+            out[name] = src[tuple(slice(0, n) for n in shape)]
+    return out

@@ -45,10 +45,18 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
     ranks_temp_count = np.zeros(args.max_activity_len + 1)
     step = None
     packed = hasattr(loader, "get_packed_batch") and hasattr(model, "eval_step_packed")
+    pre = None
+    if packed and int(getattr(args, "load_worker_num", 0) or 0) > 0:
+        # the packer runs ahead on a background thread (args.load_worker_num > 0, the reference's loader-worker flag, args.py:75):
+        # one Prefetcher per loader for its whole life, so no batch it has already drawn is ever dropped between evaluations
+        from .data_loader import Prefetcher
+        pre = getattr(loader, "_prefetcher", None)
+        if pre is None:
+            pre = loader._prefetcher = Prefetcher(loader.get_packed_batch, depth=2, owner=loader)
     while True:  # :112
         t1 = time.time()
         if packed:   # same batch, already in the C-ABI layout (tests/test_data_loader.py)
-            x, y, mask, widths = loader.get_packed_batch()
+            x, y, mask, widths = pre.get() if pre is not None else loader.get_packed_batch()
             t2 = time.time()
             step = model.eval_step_packed(x, y, mask, widths, state_np)
             slot_shapes = [np.empty((0, w)) for w in widths]
@@ -63,7 +71,7 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
         t3 = time.time()
         time_load += t2 - t1
         time_run += t3 - t2
-        if loader.done:  # :177
+        if (pre.done if pre is not None else loader.done):  # :177
             break
     summary = meter.finish()
     summary_val = {k: v for k, v in step.items() if np.ndim(v) == 0}

@@ -385,3 +385,56 @@ def test_scoring_backward_properties_at_north_star_size():
     dW = g["hier/tcn/dense/kernel"][:, J].astype(np.float64)
     assert np.linalg.norm(dW - dW_ref) <= 5e-3 * np.linalg.norm(dW_ref), np.linalg.norm(dW - dW_ref) / np.linalg.norm(dW_ref)
     eng.close()
+
+
+def test_width_padded_model_trains_d100():
+    """BASELINE.json config 1's width (d = 100, zero-padded to 128 on upload): gradients vs autograd AT d = 100, the padded channels
+    stay exactly zero through Adam steps, the loss falls, and the exported variables have the reference's shapes."""
+    from hiertcn_amd.args import make_args
+    from hiertcn_amd.engine import metrics_dict
+    from hiertcn_amd.model import TcnModel
+    from hiertcn_amd.params import init_params, pad_widths
+    N = 700
+    a = make_args([], model_type="hier", item_num=N, emb_dim=100, tcn_channel=[100, 100], kernel_size=3)
+    a.model_type = "tcn"
+    rng = np.random.default_rng(100)
+    p = init_params(a, 2, "tcn")
+    p = {k: (v + 0.05 * rng.standard_normal(v.shape).astype(np.float32)) if k.endswith("/bias") else v for k, v in p.items()}
+    B, T = 6, 33
+    lens = rng.integers(5, T + 1, B)
+    y = (rng.integers(1, N, (B, T)) * (np.arange(T)[None, :] < lens[:, None])).astype(np.int32)
+    x = np.zeros_like(y)
+    x[:, 1:] = y[:, :-1]
+    model = TcnModel(a, p, train=True)
+    eng = model.engine
+    assert eng.E == 128 and model._padded
+    dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).cuda().contiguous()  # noqa: E731
+    out = eng.train_forward_backward(dev(x).view(B, 1, T), dev(y).view(B, 1, T))
+    g_pad = eng.export("grads")
+    # autograd reference at the true width, on the values the device stores (bf16-rounded tables)
+    pr = O.round_params_bf16(p, E=100)
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in pr.items()}
+    ref_loss = torch_tcn_loss(a, P, x, y)
+    ref_loss.backward()
+    assert abs(metrics_dict(out["metrics8"])["loss"] - float(ref_loss.detach())) < 2e-3
+    for k in sorted(P):
+        r = P[k].grad.numpy()
+        g = g_pad[k].astype(np.float64)
+        cut = g[tuple(slice(0, n) for n in r.shape)]
+        rest = g.copy()
+        rest[tuple(slice(0, n) for n in r.shape)] = 0
+        assert not rest.any(), k                                    # gradients of the padding: exactly zero
+        rel = np.linalg.norm(cut - r) / max(np.linalg.norm(r), 1e-30)
+        assert rel < 3e-2, (k, rel)
+    losses = [model.train_step(x, y, 1e-2)["loss"] for _ in range(4)]
+    assert losses[-1] < losses[0], losses
+    w_pad = eng.export("weights")
+    _, p0_pad = pad_widths(a, p, "tcn")
+    for k, v in w_pad.items():                                       # padding still exactly zero after four Adam steps
+        mask = np.ones(v.shape, bool)
+        mask[tuple(slice(0, n) for n in p[k].shape)] = False
+        assert not v[mask].any(), k
+    got = model.params
+    assert {k: v.shape for k, v in got.items()} == {k: v.shape for k, v in p.items()}
+    assert np.abs(got["tcn/emb/kernel"] - p["tcn/emb/kernel"]).max() > 0          # it did train
+    model.engine.close()
