@@ -100,6 +100,15 @@ int64_t dlogits_ld(const ModelDev& m);
 hipError_t launch_dlogits_rowbias(const float* wc, const float* lc, int64_t Rv, int64_t Rpad, float* rb, hipStream_t st);
 hipError_t launch_dlogits_rows(const ModelDev& m, const uint16_t* hc, const float* rb, const int32_t* yc, const float* wc, const float* lc,
                                const float* tgt, const int32_t* map, int64_t r0, int64_t r1, uint16_t* gout, float* dbias, hipStream_t st);
+// score_bwd.hip: the scoring layer's backward without the d-logits matrix (recompute + second product fused, device-side row count)
+bool sgrad_supported(const ModelDev& m);
+hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* lse, const int32_t* map,
+                                const int32_t* n_dev, int64_t R, uint16_t* hc, int32_t* yc, float* wc, float* rb_nat, float* rb_l2, float* bias_l2,
+                                hipStream_t st);
+hipError_t launch_sgrad(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const float* rb_l2, const int32_t* n_dev, int64_t R,
+                        const float* bias_l2, float* dhc, float* dwo, float* dbias, hipStream_t st);
+hipError_t launch_sgrad_finish(const ModelDev& m, const float* dhc, const uint16_t* hc, const int32_t* map, const int32_t* n_dev, const int32_t* yc,
+                               const float* wc, int64_t R, float* dh, float* dwo, float* dbias, hipStream_t st);
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L);
 // buffers of the HierGRU low level: evaluation keeps two states and one record per layer, training all of them
 struct LowGruBufs {

@@ -593,14 +593,22 @@ struct TrainWs {
   size_t total;
   size_t lg_uf, lg_len, lg_save, lg_dcar[2], lg_dac, lg_dag, lg_dhpart, lg_dcat_c, lg_dcat_g, lg_din_up;   // HierGRU low level
   size_t splitk;  // partial outputs of the split-K weight-gradient GEMMs
-  size_t rb;      // ln w - lse per compact row (+ one padding stage of -inf), k_dlogits
+  size_t rb;      // ln w - lse per compact row (+ one padding stage of -inf), k_dlogits / k_sgrad
+  size_t rb2;     // the same x log2e (k_sgrad, rows stationary)
+  size_t bl2;     // bo x log2e [NP] (k_sgrad, items stationary)
+  int fused;      // 1: the G-free scoring backward (score_bwd.hip); 0: the d-logits chunks + rocBLAS products
   int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
   int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
 };
 
+// The scoring layer's backward: score_bwd.hip (no d-logits matrix, no rocBLAS, no host read-back) where the kernel is built for the
+// width; HIERTCN_TRAIN_LEGACY=1 selects the previous path (G chunks + two rocBLAS products per chunk) for A/B runs.
+static bool fused_scoring_backward(const ModelDev& m) { return sgrad_supported(m) && !getenv("HIERTCN_TRAIN_LEGACY"); }
+
 static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   TrainWs w;
   memset(&w, 0, sizeof(w));
+  w.fused = fused_scoring_backward(m) ? 1 : 0;
   size_t off = 0;
   auto take = [&](size_t bytes) { const size_t o = off; off += (bytes + 255) & ~(size_t)255; return o; };
   const size_t R = (size_t)B * S * L, E = (size_t)m.E, HT = (size_t)m.HT, H = (size_t)m.H;
@@ -615,7 +623,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.rank = take(R * 4); w.ce = take(R * 4); w.tgt = take(R * 4); w.lse = take(R * 4); w.w = take(R * 4);
   w.lane_act = take((size_t)B * 4);
   w.users = take(256);
-  w.dA = take(R * C * 4); w.dB = take(R * C * 4); w.dsf = take(R * C * 4);
+  w.dA = take(R * C * 4); w.dB = take(R * C * 4); w.dsf = take((R + 64) * C * 4);
   w.dcb = take(R * C * 2); w.shb = take(R * C * 2); w.dub = take(R * C * 2);
   // G chunk: at most 16 GiB of bf16 (the two products per chunk run 12 % faster than with 4 GiB chunks: fewer, larger
   // GEMMs -- profiles/r1_train_notes.md), at least one 64-item stage
@@ -650,10 +658,12 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     w.rc_stages = (int)rs;
     gbytes = rs * 64 * ldg * 2;
   }
-  w.gchunk = take(gbytes);
+  w.gchunk = take(w.fused ? 256 : gbytes);
   w.map = take(R * 4); w.nvalid = take(256); w.cscratch = take((R / 1024 + 2) * 4);
   w.hc = take((R + 64) * C * 2); w.yc = take(R * 4); w.wc = take(R * 4); w.lc = take(R * 4);
   w.rb = take((R + 64) * 4);
+  w.rb2 = take((R + 64) * 4);
+  w.bl2 = take((size_t)m.NP * 4);
   w.splitk = take((size_t)32 * C * C * 4);
   w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
   w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
@@ -819,10 +829,13 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   T_HIP(hipMemsetAsync(so.target, 0, (size_t)R * 4, st));
   T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st, rmap, nvalid_d));
   if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
-  int32_t nvalid_h = 0;
-  T_HIP(hipMemcpyAsync(&nvalid_h, nvalid_d, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-  T_HIP(hipStreamSynchronize(st));
-  const int64_t Rv = nvalid_h;
+  int64_t Rv = 0;
+  if (!w.fused) {   // legacy path only: the row count sizes the rocBLAS calls below
+    int32_t nvalid_h = 0;
+    T_HIP(hipMemcpyAsync(&nvalid_h, nvalid_d, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    T_HIP(hipStreamSynchronize(st));
+    Rv = nvalid_h;
+  }
 
   // ================= d loss / d logits, scoring layer =====================================================
   float* users = F32(w.users);
@@ -832,6 +845,15 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
                      F32(w.w), F32(w.lse));
   T_HIP(hipGetLastError());
   T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
+  if (w.fused) {
+    // score_bwd.hip: everything below is sized by R on the host and by the device-side count inside the kernels
+    uint16_t* hc = BF(w.hc);
+    int32_t* yc = reinterpret_cast<int32_t*>(ws + w.yc);
+    float* dHc = F32(w.dsf);   // [R + 64][C_last] fp32 compact (the block loop's scratch, free until then)
+    T_HIP(launch_sgrad_prepare(m, hidden, y, F32(w.w), F32(w.lse), rmap, nvalid_d, R, hc, yc, F32(w.wc), F32(w.rb), F32(w.rb2), F32(w.bl2), st));
+    T_HIP(launch_sgrad(m, hc, F32(w.rb), F32(w.rb2), nvalid_d, R, F32(w.bl2), dHc, G + t.outT.off, G + t.out_bias.off, st));
+    T_HIP(launch_sgrad_finish(m, dHc, hc, rmap, nvalid_d, yc, F32(w.wc), R, dH, G + t.outT.off, G + t.out_bias.off, st));
+  } else
   if (Rv > 0) {
     uint16_t* hc = BF(w.hc);
     int32_t* yc = reinterpret_cast<int32_t*>(ws + w.yc);
