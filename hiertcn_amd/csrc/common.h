@@ -105,10 +105,16 @@ bool sgrad_supported(const ModelDev& m);
 hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* lse, const int32_t* map,
                                 const int32_t* n_dev, int64_t R, uint16_t* hc, int32_t* yc, float* wc, float* rb_nat, float* rb_l2, float* bias_l2,
                                 hipStream_t st);
-hipError_t launch_sgrad(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const float* rb_l2, const int32_t* n_dev, int64_t R,
-                        const float* bias_l2, float* dhc, float* dwo, float* dbias, hipStream_t st);
-hipError_t launch_sgrad_finish(const ModelDev& m, const float* dhc, const uint16_t* hc, const int32_t* map, const int32_t* n_dev, const int32_t* yc,
-                               const float* wc, int64_t R, float* dh, float* dwo, float* dbias, hipStream_t st);
+hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const int32_t* row_map,
+                                const int32_t* n_dev, int64_t R, int32_t* o_rank, float* o_ce, float* o_tgt, float* dh, int32_t* ovf,
+                                hipStream_t st);
+hipError_t launch_sgrad_dh(const ModelDev& m, const uint16_t* hc, const float* rb_l2, const int32_t* yc, const float* wc, const int32_t* row_map,
+                           const int32_t* n_dev, int64_t R, float* dh, int32_t* ovf, int vote, hipStream_t st);
+hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const int32_t* yc, const float* wc, const int32_t* n_dev,
+                            int64_t R, const float* bias_l2, float* dwo, float* dbias, hipStream_t st);
+// score.hip: the fix-up flavour of the production scoring kernel alone (row tiles whose ce is non-finite are redone with the per-tile redo)
+hipError_t launch_score_fixup_only(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                                   hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev);
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L);
 // buffers of the HierGRU low level: evaluation keeps two states and one record per layer, training all of them
 struct LowGruBufs {

@@ -1295,6 +1295,17 @@ static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, co
   return hipGetLastError();
 }
 
+hipError_t launch_score_fixup_only(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                                   hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev) {
+  if (R <= 0) return hipSuccess;
+  switch (m.Clast) {
+    case 64: return launch_score_fixup<64, 2, 3, false>(m, hidden, y, R, out, st, row_map, n_rows_dev, m.walk_pos);
+    case 128: return launch_score_fixup<128, 2, 3, false>(m, hidden, y, R, out, st, row_map, n_rows_dev, m.walk_pos);
+    case 256: return launch_score_fixup<256, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, m.walk_pos);
+    default: return hipErrorInvalidValue;
+  }
+}
+
 // Mixture head (gmm.hip): for the table (m.outT [NP][C], m.out_bias [NP], pad rows / biases ZERO) -> o_sq[r] = sum_n z[r][n]^2,
 // o_tgt[r] = z[r][y[r]] (0 for the null id); the same streaming kernel with a sum-of-squares epilogue.
 hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, float* o_sq, float* o_tgt, hipStream_t st) {

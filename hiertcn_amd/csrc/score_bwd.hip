@@ -17,6 +17,8 @@
 // ((row >> 2) & 3)) (cdna_hip_programming.md T10, image (b)), applied on the SOURCE address of the LDS-DMA.
 // The one-hot term is one element per row: k_dh_finish / k_dwo_onehot subtract it afterwards.
 // Everything is sized by the DEVICE-side count of scored rows (metrics.hip, launch_compact_rows): no host read-back in the step.
+#include <string.h>
+
 #include "score_geom.h"
 
 typedef short s16x4 __attribute__((ext_vector_type(4)));
@@ -26,30 +28,53 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {
   return __builtin_bit_cast(uint2, v);
 }
 
-template <int C, bool ROWSTAT>
-__global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const uint16_t* __restrict__ stat, const float* __restrict__ stat_const,
-                                                         int64_t n_stat_max, const int32_t* __restrict__ n_stat_dev,
-                                                         const uint16_t* __restrict__ stream, const float* __restrict__ stream_bias,
-                                                         int n_stages_max, const int32_t* __restrict__ n_stream_dev,
-                                                         float* __restrict__ out, float* __restrict__ colsum) {
+// MODE 0  ITEMSTAT  (d Wo, d bo)      stat = Wo^T rows, stream = compact scored rows
+// MODE 1  ROWSTAT   (d hidden)        stat = compact scored rows, stream = Wo^T; p normalised by the SAVED log-sum-exp.  With `vote` set it
+//                                     is the FIX-UP of mode 2: a 256-row block runs only if one of its rows is flagged in `ovf`
+// MODE 2  ROWSTAT + forward statistics, "flash" form: the training step's ONE pass over the logits of a row computes rank, log-sum-exp
+//         and target logit (what k_score_pipe computes in evaluation) AND the unnormalised sum_n 2^(z_n log2e - m) Wo[n], which divided
+//         by the final sum is softmax . Wo -- d hidden without a second recompute.  The reference point m is fixed (target logit + 64 in
+//         log2 units, as in score.hip), so nothing is ever rescaled; a row whose sum overflows fp32 (a logit > 133 nats above the target)
+//         is flagged in `ovf` and redone by the fix-up launches (score.hip FIXUP flavour for rank / ce, mode 1 + vote for d hidden).
+struct SgradArgs {
+  const uint16_t* stat; const float* stat_const; int64_t n_stat_max; const int32_t* n_stat_dev;
+  const uint16_t* stream; const float* stream_bias; int n_stages_max; const int32_t* n_stream_dev;
+  float* out;            // mode 0: d Wo [NP][C] (+=); mode 1 / 2: d hidden [R][C], written at row row_map[p]
+  float* colsum;         // mode 0: d bo
+  // modes 1, 2
+  const int32_t* row_map; const int32_t* yc; const float* wc;   // mode 1: compact arrays y, w by p; mode 2: y and w by ORIGINAL row
+  const uint16_t* outT; int N;                                    // the one-hot term  - w Wo[y]
+  int32_t* ovf; int vote;
+  // mode 2
+  const float* out_bias; int32_t* o_rank; float* o_ce; float* o_tgt;
+};
+
+template <int C, int MODE>
+__global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
   using G = ScGeom<C>;
   static_assert(C == 128 || C == 256, "the dual-use LDS image is laid out for 256- and 512-byte rows");
+  constexpr bool ROWSTAT = MODE != 0;
   constexpr int NCB = C / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages of 64 stream vectors + 3 x 64 stream scalars
-  const int64_t n_stat = n_stat_dev ? (int64_t)n_stat_dev[0] : n_stat_max;
+  const int64_t n_stat = a.n_stat_dev ? (int64_t)a.n_stat_dev[0] : a.n_stat_max;
   if ((int64_t)blockIdx.x * 256 >= n_stat) return;
-  int n_stages = n_stream_dev ? (int)(((int64_t)n_stream_dev[0] + SC_STAGE - 1) / SC_STAGE) : n_stages_max;
-  if (n_stages > n_stages_max) n_stages = n_stages_max;
+  if (MODE == 1 && a.vote) {   // fix-up launch: only blocks with a flagged row do anything
+    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int bad = ((int)threadIdx.x < 256 && p < n_stat) ? a.ovf[p] : 0;
+    if (!__syncthreads_or(bad)) return;
+  }
+  int n_stages = a.n_stream_dev ? (int)(((int64_t)a.n_stream_dev[0] + SC_STAGE - 1) / SC_STAGE) : a.n_stages_max;
+  if (n_stages > a.n_stages_max) n_stages = a.n_stages_max;
   int s_lo = 0;
-  if (gridDim.y > 1) {   // the stream split in parts (ITEMSTAT: the item dimension alone gives N / 256 workgroups): partial sums added atomically
+  if (gridDim.y > 1) {   // the stream split in parts (mode 0: the item dimension alone gives N / 256 workgroups): partial sums added atomically
     const int per = (n_stages + (int)gridDim.y - 1) / (int)gridDim.y;
     s_lo = (int)blockIdx.y * per;
     const int s_hi = (s_lo + per < n_stages) ? s_lo + per : n_stages;
     if (s_hi <= s_lo) return;
     n_stages = s_hi - s_lo;
   }
-  stream += (int64_t)s_lo * SC_STAGE * C;
-  stream_bias += (int64_t)s_lo * SC_STAGE;
+  const uint16_t* stream = a.stream + (int64_t)s_lo * SC_STAGE * C;
+  const float* stream_bias = a.stream_bias + (int64_t)s_lo * SC_STAGE;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -57,14 +82,38 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const uint16_t* __restr
   const int lr = lane & 31, lh = lane >> 5;
   const int64_t sv = ((int64_t)blockIdx.x * 8 + wave) * 32 + lr;   // this lane's stationary vector
   const int64_t svc = sv < n_stat ? sv : n_stat - 1;   // (lanes past the end read the last live vector: finite data, their column is never stored)
+  const int64_t srow = (MODE == 2) ? (int64_t)a.row_map[svc] : svc;   // mode 2 reads the hidden rows in place
 
   uint4 hf[G::KS];
   {
-    const uint16_t* sp = stat + svc * C + 8 * lh;
+    const uint16_t* sp = a.stat + srow * C + 8 * lh;
 #pragma unroll
     for (int s = 0; s < G::KS; s++) hf[s] = *reinterpret_cast<const uint4*>(sp + 16 * s);
   }
-  const float cst = (sv < n_stat) ? stat_const[svc] : -INFINITY;   // (ln w - lse) log2e, or bo log2e; -inf: every p of this column is 0
+  float cst;            // the stationary vector's scalar inside the exponent: (ln w - lse) log2e, bo log2e, or -(reference) in mode 2
+  float tlog = 0.f;     // mode 2: the target logit
+  int myy = 0;
+  if (MODE == 2) {
+    // target logit: the same MFMA sequence as the streamed logits on the gathered row Wo^T[y] (diagonal of a 32 x 32 tile), so that
+    // z_n > z_target is exactly false for n == y (score.hip file header)
+    const int yy = (sv < n_stat) ? a.yc[srow] : 0;
+    myy = (yy > 0 && yy < a.N) ? yy : 0;
+    f32x16 acc;
+#pragma unroll
+    for (int reg = 0; reg < 16; reg++) acc[reg] = a.out_bias[__shfl(myy, acc_row(reg, lh))];
+    const uint16_t* ap = a.outT + (int64_t)myy * C + 8 * lh;
+#pragma unroll
+    for (int s = 0; s < G::KS; s++) acc = mfma32(*reinterpret_cast<const uint4*>(ap + 16 * s), hf[s], acc);
+    const int dreg = (lr & 3) + 4 * (lr >> 3);
+    float d = acc[0];
+#pragma unroll
+    for (int reg = 1; reg < 16; reg++) d = (dreg == reg) ? acc[reg] : d;
+    const float other = __shfl_xor(d, 32);
+    tlog = (((lr >> 2) & 1) == lh) ? d : other;
+    cst = -(tlog * LOG2E_F + 64.0f);
+  } else {
+    cst = (sv < n_stat) ? a.stat_const[svc] : -INFINITY;   // -inf: every p of this column is 0
+  }
 
   constexpr int PIECES = G::STAGE_BYTES / 1024;
   constexpr int PPW = PIECES / 8;
@@ -121,7 +170,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const uint16_t* __restr
   for (int cb = 0; cb < NCB; cb++)
 #pragma unroll
     for (int i = 0; i < 16; i++) oacc[cb][i] = 0.f;
-  float cs = 0.f;
+  float cs = 0.f;   // mode 0: column sum (d bo); mode 2: running softmax sum
+  int cnt = 0;      // mode 2: #{z > target}
 
   if (n_stages > 0) stage_issue(0, 0);
   if (n_stages > 1) stage_issue(1, 1);
@@ -146,8 +196,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const uint16_t* __restr
       }
 #pragma unroll
       for (int s = 0; s < G::KS; s++) {
-        const uint4 a = *reinterpret_cast<const uint4*>(tl + (ak ^ (s << 5)));
-        acc = mfma32(a, hf[s], acc);
+        const uint4 af = *reinterpret_cast<const uint4*>(tl + (ak ^ (s << 5)));
+        acc = mfma32(af, hf[s], acc);
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the three parts of a tile apart: overlapping them costs registers this kernel does not have
       uint32_t pk[8];
@@ -155,7 +205,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const uint16_t* __restr
       for (int i = 0; i < 16; i += 2) {
         const float e0 = __builtin_amdgcn_exp2f(fmaf(acc[i], LOG2E_F, cst));
         const float e1 = __builtin_amdgcn_exp2f(fmaf(acc[i + 1], LOG2E_F, cst));
-        if (!ROWSTAT) cs += e0 + e1;
+        if (MODE != 1) cs += e0 + e1;
+        if (MODE == 2) cnt += (acc[i] > tlog ? 1 : 0) + (acc[i + 1] > tlog ? 1 : 0);
         pk[i >> 1] = pack2bf(e0, e1);
       }
       __builtin_amdgcn_sched_barrier(0);
@@ -178,25 +229,72 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const uint16_t* __restr
   }
 
   // out^T[c][stationary]: register i of tile cb is channel 32 cb + (i & 3) + 8 (i >> 2) + 4 lh of this lane's stationary vector
-  if (sv < n_stat_max && (ROWSTAT ? sv < n_stat : true)) {
-    float* op = out + sv * C;
+  if (MODE == 0) {
+    if (sv < a.n_stat_max) {
+      float* op = a.out + sv * C;
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          float* d = op + 32 * cb + 8 * q + 4 * lh;
+          if (gridDim.y > 1) {
+#pragma unroll
+            for (int j = 0; j < 4; j++) atomicAdd(d + j, oacc[cb][4 * q + j]);
+          } else {
+            *reinterpret_cast<float4*>(d) = make_float4(oacc[cb][4 * q], oacc[cb][4 * q + 1], oacc[cb][4 * q + 2], oacc[cb][4 * q + 3]);
+          }
+        }
+      }
+    }
+    if (a.colsum) {
+      const float t = cs + __shfl_xor(cs, 32);
+      if (lh == 0 && sv < n_stat) atomicAdd(a.colsum + sv, t);
+    }
+    return;
+  }
+  // modes 1, 2: d hidden[row][c] = scale * out^T[c][row] - w Wo[y][c]
+  float scale = 1.f, w;
+  int yv;
+  int64_t drow;
+  if (MODE == 2) {
+    const float s_tot = cs + __shfl_xor(cs, 32);   // the two halves saw disjoint items, with the same reference point
+    const int c_tot = cnt + __shfl_xor(cnt, 32);
+    const bool over = (__float_as_uint(s_tot) & 0x7f800000u) == 0x7f800000u;
+    w = (sv < n_stat) ? a.wc[srow] : 0.f;
+    scale = myy > 0 ? w / s_tot : 0.f;
+    yv = myy;
+    drow = srow;
+    if (lh == 0 && sv < n_stat) {
+      const float lse = (log2f(s_tot) - cst) * LN2_F;   // (m + log2 S) ln 2, m = -cst
+      a.o_rank[srow] = myy > 0 ? c_tot : 0;
+      a.o_ce[srow] = myy > 0 ? (over ? INFINITY : lse - tlog) : 0.f;   // non-finite: the score.hip fix-up launch redoes this row's tile
+      a.o_tgt[srow] = myy > 0 ? tlog : 0.f;
+      if (over) a.ovf[sv] = 1;
+    }
+  } else {
+    w = (sv < n_stat) ? a.wc[svc] : 0.f;
+    yv = (sv < n_stat) ? a.yc[svc] : 0;
+    drow = (int64_t)a.row_map[svc];
+  }
+  if (sv < n_stat) {
+    float* op = a.out + drow * C;
+    const bool hot = yv > 0 && yv < a.N;
+    const uint16_t* wr = a.outT + (int64_t)(hot ? yv : 0) * C;
+    const float wh = hot ? w : 0.f;
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        float* d = op + 32 * cb + 8 * q + 4 * lh;
-        if (gridDim.y > 1) {
-#pragma unroll
-          for (int j = 0; j < 4; j++) atomicAdd(d + j, oacc[cb][4 * q + j]);
-        } else {
-          *reinterpret_cast<float4*>(d) = make_float4(oacc[cb][4 * q], oacc[cb][4 * q + 1], oacc[cb][4 * q + 2], oacc[cb][4 * q + 3]);
-        }
+        const int c = 32 * cb + 8 * q + 4 * lh;
+        const uint2 t2 = *reinterpret_cast<const uint2*>(wr + c);
+        float4 v;
+        v.x = oacc[cb][4 * q] * scale - wh * bf2f((uint16_t)(t2.x & 0xffff));
+        v.y = oacc[cb][4 * q + 1] * scale - wh * bf2f((uint16_t)(t2.x >> 16));
+        v.z = oacc[cb][4 * q + 2] * scale - wh * bf2f((uint16_t)(t2.y & 0xffff));
+        v.w = oacc[cb][4 * q + 3] * scale - wh * bf2f((uint16_t)(t2.y >> 16));
+        *reinterpret_cast<float4*>(op + c) = v;
       }
     }
-  }
-  if (!ROWSTAT && colsum) {
-    const float t = cs + __shfl_xor(cs, 32);
-    if (lh == 0 && sv < n_stat) atomicAdd(colsum + sv, t);
   }
 }
 
@@ -232,26 +330,6 @@ __global__ void k_scale_log2e(const float* __restrict__ src, float* __restrict__
   if (i < n && i < n_max) dst[i] = src[i] * LOG2E_F;
 }
 
-// d hidden[map[p]][:] = dHc[p][:] - w_p Wo[y_p][:]   (the one-hot term of g; dH zeroed beforehand: padded steps have no gradient)
-__global__ void k_dh_finish(const float* __restrict__ dhc, const int32_t* __restrict__ map, const int32_t* __restrict__ n_dev,
-                            const int32_t* __restrict__ yc, const float* __restrict__ wc, const uint16_t* __restrict__ outT, int C, int N,
-                            float* __restrict__ dh) {
-  const int ch = C >> 2;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const int64_t p = i / ch;
-  if (p >= (int64_t)n_dev[0]) return;
-  const int c = (int)(i - p * ch) * 4;
-  float4 v = *reinterpret_cast<const float4*>(dhc + p * C + c);
-  const int yv = yc[p];
-  if (yv > 0 && yv < N) {
-    const uint2 wr = *reinterpret_cast<const uint2*>(outT + (int64_t)yv * C + c);
-    const float w = wc[p];
-    v.x -= w * bf2f((uint16_t)(wr.x & 0xffff)); v.y -= w * bf2f((uint16_t)(wr.x >> 16));
-    v.z -= w * bf2f((uint16_t)(wr.y & 0xffff)); v.w -= w * bf2f((uint16_t)(wr.y >> 16));
-  }
-  *reinterpret_cast<float4*>(dh + (int64_t)map[p] * C + c) = v;
-}
-
 // d Wo[y_p][:] -= w_p h_p[:],  d bo[y_p] -= w_p: one wave per scored row, 256 contiguous bytes per atomic instruction
 __global__ __launch_bounds__(256) void k_dwo_onehot(const uint16_t* __restrict__ hc, const int32_t* __restrict__ yc, const float* __restrict__ wc,
                                                     const int32_t* __restrict__ n_dev, int C, int N, float* __restrict__ dwo,
@@ -268,45 +346,75 @@ __global__ __launch_bounds__(256) void k_dwo_onehot(const uint16_t* __restrict__
 
 bool sgrad_supported(const ModelDev& m) { return m.Clast == 128 || m.Clast == 256; }
 
-template <int C>
-static hipError_t launch_sgrad_c(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const float* rb_l2, const int32_t* n_dev, int64_t R,
-                                 const float* bias_l2, float* dhc, float* dwo, float* dbias, hipStream_t st) {
+template <int C, int MODE>
+static hipError_t launch_k_sgrad(const SgradArgs& a, dim3 grid, hipStream_t st) {
   using G = ScGeom<C>;
   const size_t lds = 3 * (size_t)G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgrad<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgrad<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgrad<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess)
-    return e;
-  // d hidden: rows stationary (workgroups past the device-side row count exit at once), the whole item table streamed
-  hipLaunchKernelGGL((k_sgrad<C, true>), dim3((unsigned)((R + 255) / 256)), dim3(SC_THREADS), lds, st, hc, rb_l2, R + 64, n_dev, m.outT, m.out_bias,
-                     m.NP / SC_STAGE, (const int32_t*)nullptr, dhc, (float*)nullptr);
-  // d Wo / d bo: items stationary, the scored rows streamed; row parts so that the grid covers the chip a few times over
-  const unsigned blocks = (unsigned)((m.NP + 255) / 256);
-  unsigned parts = 1;
-  const int st_max = (int)((R + 63) / 64);
-  {
-    double best = 0.0;
-    for (unsigned p = 1; p <= 8 && (p == 1 || st_max / (int)p >= 64); p++) {
-      const double eff = ((double)blocks * p / 256.0) / (double)((blocks * p + 255) / 256);
-      if (eff > best + 1e-9) { best = eff; parts = p; }
-      if (eff >= 0.93) break;
-    }
-  }
-  hipLaunchKernelGGL((k_sgrad<C, false>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, m.outT, bias_l2, (int64_t)m.NP, (const int32_t*)nullptr, hc, rb_nat,
-                     st_max, n_dev, dwo, dbias);
+  hipLaunchKernelGGL((k_sgrad<C, MODE>), grid, dim3(SC_THREADS), lds, st, a);
   return hipGetLastError();
 }
-
-// The scoring layer's backward from the compact scored rows (k_sgrad_gather): dhc [R + 64][C] fp32 (compact), d outT [NP][C] and d bo [NP]
-// ACCUMULATED into (the gradient arena is zeroed at the start of the step).  bias_l2 [NP]: bo log2e (-inf on the padding items).
-hipError_t launch_sgrad(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const float* rb_l2, const int32_t* n_dev, int64_t R,
-                        const float* bias_l2, float* dhc, float* dwo, float* dbias, hipStream_t st) {
-  if (R <= 0) return hipSuccess;
+template <int MODE>
+static hipError_t launch_k_sgrad_c(const ModelDev& m, const SgradArgs& a, dim3 grid, hipStream_t st) {
   switch (m.Clast) {
-    case 128: return launch_sgrad_c<128>(m, hc, rb_nat, rb_l2, n_dev, R, bias_l2, dhc, dwo, dbias, st);
-    case 256: return launch_sgrad_c<256>(m, hc, rb_nat, rb_l2, n_dev, R, bias_l2, dhc, dwo, dbias, st);
+    case 128: return launch_k_sgrad<128, MODE>(a, grid, st);
+    case 256: return launch_k_sgrad<256, MODE>(a, grid, st);
     default: return hipErrorInvalidValue;
   }
+}
+
+// Training forward of the scoring layer + d hidden in one pass (mode 2): rank / ce / target as launch_score would write them for the
+// rows listed in row_map (the caller zero-fills the others), d hidden [R][C] (zero-filled by the caller) at those rows, ovf [R] ints
+// (zero-filled by the caller) flagged where the running sum overflowed.  w [R]: d loss / d ce per row (model.py:111-117).
+hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const int32_t* row_map,
+                                const int32_t* n_dev, int64_t R, int32_t* o_rank, float* o_ce, float* o_tgt, float* dh, int32_t* ovf,
+                                hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  SgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.stat = hidden; a.n_stat_max = R; a.n_stat_dev = n_dev;
+  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / SC_STAGE;
+  a.out = dh; a.row_map = row_map; a.yc = y; a.wc = w; a.outT = m.outT; a.N = m.N; a.ovf = ovf;
+  a.out_bias = m.out_bias; a.o_rank = o_rank; a.o_ce = o_ce; a.o_tgt = o_tgt;
+  return launch_k_sgrad_c<2>(m, a, dim3((unsigned)((R + 255) / 256)), st);
+}
+
+// d hidden from the saved log-sum-exp (mode 1) for the compact scored rows; vote != 0: only the 256-row blocks with a row flagged in ovf
+hipError_t launch_sgrad_dh(const ModelDev& m, const uint16_t* hc, const float* rb_l2, const int32_t* yc, const float* wc, const int32_t* row_map,
+                           const int32_t* n_dev, int64_t R, float* dh, int32_t* ovf, int vote, hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  SgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.stat = hc; a.stat_const = rb_l2; a.n_stat_max = R + 64; a.n_stat_dev = n_dev;
+  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / SC_STAGE;
+  a.out = dh; a.row_map = row_map; a.yc = yc; a.wc = wc; a.outT = m.outT; a.N = m.N; a.ovf = ovf; a.vote = vote;
+  return launch_k_sgrad_c<1>(m, a, dim3((unsigned)((R + 255) / 256)), st);
+}
+
+// d Wo / d bo (mode 0), ACCUMULATED into dwo [NP][C] / dbias [NP] (the gradient arena is zeroed at the start of the step), followed by
+// the one-hot term.  bias_l2 [NP]: bo log2e (-inf on the padding items); rb_nat [R + 64]: ln w - lse per compact row (-inf padding).
+hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const int32_t* yc, const float* wc, const int32_t* n_dev,
+                            int64_t R, const float* bias_l2, float* dwo, float* dbias, hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  SgradArgs a;
+  memset(&a, 0, sizeof(a));
+  a.stat = m.outT; a.stat_const = bias_l2; a.n_stat_max = m.NP;
+  a.stream = hc; a.stream_bias = rb_nat; a.n_stages_max = (int)((R + 63) / 64); a.n_stream_dev = n_dev;
+  a.out = dwo; a.colsum = dbias;
+  // row parts so that the grid covers the chip a few times over (the item dimension alone gives N / 256 workgroups)
+  const unsigned blocks = (unsigned)((m.NP + 255) / 256);
+  unsigned parts = 1;
+  double best = 0.0;
+  for (unsigned p = 1; p <= 8 && (p == 1 || a.n_stages_max / (int)p >= 64); p++) {
+    const double eff = ((double)blocks * p / 256.0) / (double)((blocks * p + 255) / 256);
+    if (eff > best + 1e-9) { best = eff; parts = p; }
+    if (eff >= 0.93) break;
+  }
+  hipError_t e = launch_k_sgrad_c<0>(m, a, dim3(blocks, parts), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_dwo_onehot, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, hc, yc, wc, n_dev, m.Clast, m.N, dwo, dbias);
+  return hipGetLastError();
 }
 
 hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* lse, const int32_t* map,
@@ -317,14 +425,5 @@ hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const
   hipLaunchKernelGGL(k_sgrad_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hidden, y, w, lse, map, n_dev, m.Clast, hc, yc, wc, rb_nat);
   hipLaunchKernelGGL(k_scale_log2e, dim3((unsigned)((R + 64 + 255) / 256)), dim3(256), 0, st, rb_nat, rb_l2, R + 64, n_dev, 1);
   hipLaunchKernelGGL(k_scale_log2e, dim3((unsigned)((m.NP + 255) / 256)), dim3(256), 0, st, m.out_bias, bias_l2, (int64_t)m.NP, (const int32_t*)nullptr, 0);
-  return hipGetLastError();
-}
-
-hipError_t launch_sgrad_finish(const ModelDev& m, const float* dhc, const uint16_t* hc, const int32_t* map, const int32_t* n_dev, const int32_t* yc,
-                               const float* wc, int64_t R, float* dh, float* dwo, float* dbias, hipStream_t st) {
-  if (R <= 0) return hipSuccess;
-  const int64_t n = R * (m.Clast / 4);
-  hipLaunchKernelGGL(k_dh_finish, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dhc, map, n_dev, yc, wc, m.outT, m.Clast, m.N, dh);
-  hipLaunchKernelGGL(k_dwo_onehot, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, hc, yc, wc, n_dev, m.Clast, m.N, dwo, dbias);
   return hipGetLastError();
 }

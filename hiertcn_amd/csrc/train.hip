@@ -596,6 +596,7 @@ struct TrainWs {
   size_t rb;      // ln w - lse per compact row (+ one padding stage of -inf), k_dlogits / k_sgrad
   size_t rb2;     // the same x log2e (k_sgrad, rows stationary)
   size_t bl2;     // bo x log2e [NP] (k_sgrad, items stationary)
+  size_t ovf;     // per compact row: the forward pass's running sum overflowed (k_sgrad mode 2 -> fix-up launches)
   int fused;      // 1: the G-free scoring backward (score_bwd.hip); 0: the d-logits chunks + rocBLAS products
   int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
   int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
@@ -664,6 +665,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.rb = take((R + 64) * 4);
   w.rb2 = take((R + 64) * 4);
   w.bl2 = take((size_t)m.NP * 4);
+  w.ovf = take((R + 64) * 4);
   w.splitk = take((size_t)32 * C * C * 4);
   w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
   w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
@@ -827,6 +829,20 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   T_HIP(hipMemsetAsync(so.rank, 0, (size_t)R * 4, st));
   T_HIP(hipMemsetAsync(so.ce, 0, (size_t)R * 4, st));
   T_HIP(hipMemsetAsync(so.target, 0, (size_t)R * 4, st));
+  float* users = F32(w.users);
+  if (w.fused) {
+    // score_bwd.hip, mode 2: ONE pass over the logits gives rank / ce / target (the evaluation kernel's outputs) and d hidden; the row
+    // weights d loss / d ce depend on the mask only and are needed first
+    T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
+    hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
+    hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce,
+                       so.target, R, S * L, F32(w.w), F32(w.lse));
+    T_HIP(hipGetLastError());
+    T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
+    T_HIP(hipMemsetAsync(ws + w.ovf, 0, (size_t)R * 4, st));
+    T_HIP(launch_sgrad_forward(m, hidden, y, F32(w.w), rmap, nvalid_d, R, so.rank, so.ce, so.target, dH, reinterpret_cast<int32_t*>(ws + w.ovf), st));
+    T_HIP(launch_score_fixup_only(m, hidden, y, R, &so, st, rmap, nvalid_d));   // rank / ce of row tiles whose sum overflowed (pathological inputs)
+  } else
   T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st, rmap, nvalid_d));
   if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
   int64_t Rv = 0;
@@ -838,21 +854,20 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   }
 
   // ================= d loss / d logits, scoring layer =====================================================
-  float* users = F32(w.users);
   T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
   hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
   hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce, so.target, R, S * L,
                      F32(w.w), F32(w.lse));
   T_HIP(hipGetLastError());
-  T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
+  if (!w.fused) T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
   if (w.fused) {
-    // score_bwd.hip: everything below is sized by R on the host and by the device-side count inside the kernels
+    // score_bwd.hip: everything is sized by R on the host and by the device-side row count inside the kernels.  d hidden came out of
+    // the forward pass; what is left is d Wo / d bo from the saved log-sum-exp (and d hidden again for row blocks that overflowed).
     uint16_t* hc = BF(w.hc);
     int32_t* yc = reinterpret_cast<int32_t*>(ws + w.yc);
-    float* dHc = F32(w.dsf);   // [R + 64][C_last] fp32 compact (the block loop's scratch, free until then)
     T_HIP(launch_sgrad_prepare(m, hidden, y, F32(w.w), F32(w.lse), rmap, nvalid_d, R, hc, yc, F32(w.wc), F32(w.rb), F32(w.rb2), F32(w.bl2), st));
-    T_HIP(launch_sgrad(m, hc, F32(w.rb), F32(w.rb2), nvalid_d, R, F32(w.bl2), dHc, G + t.outT.off, G + t.out_bias.off, st));
-    T_HIP(launch_sgrad_finish(m, dHc, hc, rmap, nvalid_d, yc, F32(w.wc), R, dH, G + t.outT.off, G + t.out_bias.off, st));
+    T_HIP(launch_sgrad_dh(m, hc, F32(w.rb2), yc, F32(w.wc), rmap, nvalid_d, R, dH, reinterpret_cast<int32_t*>(ws + w.ovf), 1, st));
+    T_HIP(launch_sgrad_dwo(m, hc, F32(w.rb), yc, F32(w.wc), nvalid_d, R, F32(w.bl2), G + t.outT.off, G + t.out_bias.off, st));
   } else
   if (Rv > 0) {
     uint16_t* hc = BF(w.hc);

@@ -6,6 +6,8 @@ Tolerances: the device multiplies bf16 operands (weights, activations, d-logits)
 and passes gradients straight through the forward roundings, the reference is fp64 on the bf16-rounded
 weights: per-tensor relative L2 error < 3e-2 and cosine > 0.999; Adam arithmetic itself (given the
 device's own gradients) to 1e-6."""
+import os
+
 import numpy as np
 import pytest
 
@@ -438,3 +440,53 @@ def test_width_padded_model_trains_d100():
     assert {k: v.shape for k, v in got.items()} == {k: v.shape for k, v in p.items()}
     assert np.abs(got["tcn/emb/kernel"] - p["tcn/emb/kernel"]).max() > 0          # it did train
     model.engine.close()
+
+
+@pytest.mark.parametrize("d,overflow", [(128, False), (256, False), (256, True), (128, True)])
+def test_fused_scoring_backward_matches_the_chunked_path(d, overflow):
+    """csrc/score_bwd.hip (one pass over the logits for rank / ce / d hidden, a second for d Wo / d bo, nothing materialised, row count on
+    the device) against the previous implementation (bf16 d-logits chunks + rocBLAS products, HIERTCN_TRAIN_LEGACY=1): loss, per-step
+    outputs and every gradient.  overflow: scoring weights that put one item > 133 nats above every target, so the forward pass's
+    running sum leaves fp32 range and both fix-up launches (rank / ce and d hidden) run."""
+    from hiertcn_amd.engine import Engine, metrics_dict
+    N, H, B, S, L = 1500, 32, 7, 3, 13
+    args = small_args(N=N, d=d, H=H, S=S, L=L, B=B)
+    p = make_params(args)
+    rng = np.random.default_rng(d + overflow)
+    if overflow:
+        W = p["hier/tcn/dense/kernel"].copy()
+        W[:, 1:N // 2] -= 6.0              # candidate targets far below zero (hidden rows are relu outputs: their channel sum is > 0)
+        W[:, N - 7] += 6.0                 # one item far above
+        p["hier/tcn/dense/kernel"] = W
+        p["hier/tcn/temporal_conv_net/tblock_1/conv1/bias"] = p["hier/tcn/temporal_conv_net/tblock_1/conv1/bias"] + 0.5
+    x, y, mask = make_batch(rng, B, S, L, N // 2 if overflow else N)
+    st0 = (0.1 * rng.standard_normal((B, 2 * H))).astype(np.float32)
+    dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).cuda().contiguous()  # noqa: E731
+    res = {}
+    for mode in ("fused", "legacy"):
+        if mode == "legacy":
+            os.environ["HIERTCN_TRAIN_LEGACY"] = "1"
+        try:
+            eng = Engine(args, hier=True, train=True)
+            eng.set_weights(p)
+            out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+            torch.cuda.synchronize()
+            res[mode] = (metrics_dict(out["metrics8"]), eng.export("grads"))
+            if mode == "fused" and overflow:   # the input does what it is meant to do: gaps beyond the fixed reference's range
+                pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+                sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+                hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+                z = eng.score_logits(hid).cpu().numpy()
+                yy = y.reshape(-1)
+                gap = (z.max(1) - z[np.arange(len(yy)), yy])[yy > 0]
+                assert (gap * np.log2(np.e) > 200).any(), gap.max()
+            eng.close()
+        finally:
+            os.environ.pop("HIERTCN_TRAIN_LEGACY", None)
+    (mf, gf), (ml, gl) = res["fused"], res["legacy"]
+    for k in ("loss", "recall10", "mrr", "rank_frac"):
+        assert abs(mf[k] - ml[k]) < 1e-4 * max(1.0, abs(ml[k])), (k, mf[k], ml[k])
+    for k in gl:
+        a, b = gf[k].astype(np.float64), gl[k].astype(np.float64)
+        rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
+        assert np.isfinite(a).all() and rel < 2e-2, (k, rel)     # both round p to bf16 at different points: ~1e-2 apart at most
