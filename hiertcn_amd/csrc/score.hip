@@ -499,14 +499,19 @@ struct RowState2 {
 // r mod 16.  C = 512: one row per piece, pitch 1024 + 16.
 // FIXUP: launched behind a DUAL kernel (which has no room for the overflow redo): a row tile is re-done, with the per-tile redo,
 // only if the fast kernel left a non-finite ce in it (running sum past fp32); every other workgroup exits after one vote.
-template <int C, int PMODE = 0, int NB = 2, int NSTG = 3, bool PAD = false, bool FIXUP = false>
+// KT > 0 (NB = 1 shape only): the ranked top-KT list of every row beside rank / ce (loss.py:120) -- per lane a sorted list, each drained
+// tile tested against the list's last entry with one wave-uniform branch behind its epilogue, while the next tile's MFMAs run; the walk
+// must start at item 0 (walk_pos null) so that equal values arrive in index order, which is tf.nn.top_k's order.
+template <int C, int PMODE = 0, int NB = 2, int NSTG = 3, bool PAD = false, bool FIXUP = false, int KT = 0>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y,
                                                               int64_t R, const uint16_t* __restrict__ outT,
                                                               const float* __restrict__ out_bias, int N, int NP,
                                                               int32_t* __restrict__ o_rank, float* __restrict__ o_ce,
                                                               float* __restrict__ o_tgt, const int32_t* __restrict__ row_map,
                                                               const int32_t* __restrict__ n_rows_dev, int part_stages,
-                                                              float* __restrict__ partials, int* __restrict__ walk_pos) {
+                                                              float* __restrict__ partials, int* __restrict__ walk_pos,
+                                                              int32_t* __restrict__ o_topi, float* __restrict__ o_topv, int topk) {
+  static_assert(KT == 0 || NB == 1, "the per-lane lists fit beside ONE resident step block");
   // Small batches: gridDim.y > 1 splits the CATALOGUE -- workgroup (x, p) walks stages [p*part_stages, (p+1)*part_stages)
   // for row tile x and writes (count, log2-sum-exp2) per row into `partials` [gridDim.y][2][R]; k_score_merge adds them
   // up.  A 6,400-row XING batch (32 lanes) otherwise occupies 13 of the 256 CUs for a whole pass over the table.
@@ -899,6 +904,12 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     post5(y1, st[1]);                                                                        \
   } while (0)
 
+  constexpr int KTA = KT > 0 ? KT : 1;
+  TopList<KTA> top;
+  if (KT > 0) {
+#pragma unroll
+    for (int k = 0; k < KTA; k++) { top.v[k] = -INFINITY; top.i[k] = 0x7fffffff; }
+  }
   f32x16 accA, accB;
   if constexpr (NB == 2 && SEAMLESS && C <= 256) {
     f32x16 xa0, xa1, xb0, xb1;
@@ -1010,10 +1021,12 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     for (int stg = 0; stg < n_stages; stg++) {
       const int buf = stg & 1;
       SC_PHASE(accB, 0, accA, 0, buf, 1, true);                        // MFMA (stg, ib1)   || epilogue (stg, ib0)
+      if (KT > 0) top_tile<KTA>(top, accA, (stg_lo + stg) * SC_STAGE + 4 * lh);        // (walk_pos is null: stage stg IS item stage stg)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (stg + 2 < n_stages) stage_issue(stg + 2, buf);
       SC_PHASE(accA, 0, accB, 0, buf ^ 1, 0, stg + 1 < n_stages);      // MFMA (stg+1, ib0) || epilogue (stg, ib1)
+      if (KT > 0) top_tile<KTA>(top, accB, (stg_lo + stg) * SC_STAGE + 32 + 4 * lh);
     }
   }
 #undef SC_PHASE
@@ -1055,6 +1068,33 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       if (o_tgt) o_tgt[dst] = valid ? st[cbk].t : 0.f;
     }
   }
+  if constexpr (KT > 0) {
+    // the two half-waves hold disjoint item subsets of the same step: merge the two sorted lists (value descending, then index
+    // ascending) through LDS, which the item stream no longer needs
+    float* lv = reinterpret_cast<float*>(smem);                       // [512 lanes][KT]
+    int* li = reinterpret_cast<int*>(smem + SC_THREADS * KTA * 4);    // [512 lanes][KT]
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < KTA; k++) { lv[tid * KTA + k] = top.v[k]; li[tid * KTA + k] = top.i[k]; }
+    __syncthreads();
+    if (lh == 0 && row0 + lr < Rv) {
+      const bool valid = myy[0] > 0;
+      const int64_t dst = mysrc[0];
+      const float* av = lv + tid * KTA; const int* ai = li + tid * KTA;
+      const float* bv = lv + (tid + 32) * KTA; const int* bi = li + (tid + 32) * KTA;
+      int pa = 0, pb = 0;
+      for (int k = 0; k < topk; k++) {
+        // masked rows are all-zero logit rows (model.py:105): every value ties at 0 -> indices 0..k-1
+        const float va = pa < KTA ? av[pa] : -INFINITY, vb = pb < KTA ? bv[pb] : -INFINITY;
+        const int ia = pa < KTA ? ai[pa] : 0x7fffffff, ib = pb < KTA ? bi[pb] : 0x7fffffff;
+        const bool ta = (va > vb) || (va == vb && ia < ib);
+        o_topi[dst * topk + k] = valid ? (ta ? ia : ib) : k;
+        o_topv[dst * topk + k] = valid ? (ta ? va : vb) : 0.f;
+        pa += ta ? 1 : 0;
+        pb += ta ? 0 : 1;
+      }
+    }
+  }
 }
 
 // adds up the catalogue parts of k_score_pipe (small-batch split): rank = sum of counts, lse = log-sum-exp over parts
@@ -1088,7 +1128,7 @@ static hipError_t launch_score_fixup(const ModelDev& m, const uint16_t* hidden, 
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL(kern, dim3((unsigned)((R + 256 * NB - 1) / (256 * NB))), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N,
-                     m.NP, out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk);
+                     m.NP, out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk, (int32_t*)nullptr, (float*)nullptr, 0);
   return hipGetLastError();
 }
 
@@ -1108,14 +1148,14 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;
     hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                       out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr);
+                       out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
                        out->target, out->rank, out->ce);
     if (PMODE == 12 || PMODE == 14) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
-                     out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk);
+                     out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk, (int32_t*)nullptr, (float*)nullptr, 0);
   if ((PMODE == 12 || PMODE == 14) && out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
   return hipGetLastError();
 }
@@ -1143,6 +1183,19 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
                                     const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
                                     const int32_t* n_rows_dev = nullptr) {
   using G = ScGeom<C>;
+  if (!getenv("HIERTCN_TOPK_V1")) {   // the pipelined skeleton (epilogue in the MFMA gaps, one step block per wave, two LDS stages); V1: A/B
+    constexpr bool PADI = C >= 256;
+    const size_t pitch = PADI ? 1024 + (C == 256 ? 32 : 16) : 1024;
+    size_t lds = 2 * (G::STAGE_BYTES / 1024) * pitch + 2 * SC_STAGE * sizeof(float);
+    const size_t merge = (size_t)SC_THREADS * KT * 8;
+    if (merge > lds) lds = merge;
+    auto kern = k_score_pipe<C, 5, 1, 2, PADI, false, KT>;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3((unsigned)((R + 255) / 256)), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out->rank,
+                       out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, (int*)nullptr, out->topk_idx, out->topk_val, (int)out->topk);
+    return hipGetLastError();
+  }
   size_t lds = 2 * G::STAGE_BYTES + 2 * SC_STAGE * sizeof(float);
   const size_t merge = (size_t)SC_THREADS * KT * 8;
   if (merge > lds) lds = merge;

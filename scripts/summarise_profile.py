@@ -23,7 +23,7 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     for k, v in agg.items():
-        if "score" in k or "tcn" in k:
+        if "score" in k or "tcn" in k or "sgrad" in k:
             n = max(len(disp[k]), 1)
             res.setdefault("pmc_per_launch", {}).setdefault(k, {}).update({c: val / n for c, val in v.items()})
             res["pmc_per_launch"][k]["launches"] = n
