@@ -106,9 +106,9 @@ def _gather_cat(t: torch.Tensor) -> torch.Tensor:
         parts = [torch.empty_like(t, device="cpu") for _ in range(world)]
         dist.all_gather(parts, t.cpu())
         return torch.stack(parts).to(t.device)
-    out = torch.empty((world,) + tuple(t.shape), dtype=t.dtype, device=t.device)
-    dist.all_gather_into_tensor(out, t)
-    return out
+    out = torch.empty((world * t.shape[0],) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)   # concatenation along dim 0
+    dist.all_gather_into_tensor(out, t.contiguous())
+    return out.view((world,) + tuple(t.shape))
 
 
 class GradientExchange:

@@ -623,5 +623,6 @@ def test_side_stream_calls_match_default_stream(setup):
     assert torch.equal(out["rank"], ref["rank"])
     assert (out["ce"] - ref["ce"]).abs().max().item() < 2e-5
     assert torch.equal(out["state"], ref["state"])
-    assert (out["metrics8"] - ref["metrics8"]).abs().max().item() < 1e-6
+    # (lane-mean SUMS of ce values whose last bits depend on where a workgroup entered the item table: fp32 resolution of the sum)
+    assert (out["metrics8"] - ref["metrics8"]).abs().max().item() < 1e-6 * max(1.0, ref["metrics8"].abs().max().item())
     assert top["topk_idx"].shape[-1] == 5
