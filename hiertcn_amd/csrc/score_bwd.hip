@@ -194,30 +194,51 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
 #pragma unroll
         for (int j = 0; j < 4; j++) acc[4 * q + j] = b4[j];
       }
+      {   // fragment reads two k-steps ahead of their MFMA (the registers of the packed probabilities are free during this part)
+        uint4 ring[3];
+        ring[0] = *reinterpret_cast<const uint4*>(tl + (ak ^ (0 << 5)));
+        ring[1] = *reinterpret_cast<const uint4*>(tl + (ak ^ (1 << 5)));
 #pragma unroll
-      for (int s = 0; s < G::KS; s++) {
-        const uint4 af = *reinterpret_cast<const uint4*>(tl + (ak ^ (s << 5)));
-        acc = mfma32(af, hf[s], acc);
+        for (int s = 0; s < G::KS; s++) {
+          if (s + 2 < G::KS) ring[(s + 2) % 3] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 2) << 5)));
+          acc = mfma32(ring[s % 3], hf[s], acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);   // keep the three parts of a tile apart: overlapping them costs registers this kernel does not have
       uint32_t pk[8];
-#pragma unroll
-      for (int i = 0; i < 16; i += 2) {
+      auto prob_pair = [&](int i) {   // values i, i + 1 of the tile -> one packed bf16 pair
         const float e0 = __builtin_amdgcn_exp2f(fmaf(acc[i], LOG2E_F, cst));
         const float e1 = __builtin_amdgcn_exp2f(fmaf(acc[i + 1], LOG2E_F, cst));
         if (MODE != 1) cs += e0 + e1;
         if (MODE == 2) cnt += (acc[i] > tlog ? 1 : 0) + (acc[i + 1] > tlog ? 1 : 0);
         pk[i >> 1] = pack2bf(e0, e1);
-      }
+      };
+      // The first k-step of GEMM-2 needs the probabilities of values 0..7 only: those now, values 8..15 in the gaps of that k-step's MFMAs.
+      // (The two waves of a SIMD meet at one barrier per stage and run the same part of a tile at the same time, so VALU work that sits
+      // beside a wave's OWN MFMAs is time saved: 333 -> 323 ms per training step.  Running waves 4-7 one part behind waves 0-3 instead
+      // -- a per-tile rotated loop with the two halves' barriers at different points -- was built and measured: 364 ms; the rotated
+      // loop costs more registers than it buys overlap.)
+#pragma unroll
+      for (int i = 0; i < 8; i += 2) prob_pair(i);
       __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; s2++) {
-        const uint4 bfrag = make_uint4(pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]);
-#pragma unroll
-        for (int cb = 0; cb < NCB; cb++) {
+      {   // transposed fragment reads two MFMAs ahead (the GEMM-1 tile's registers are dead once its probabilities are packed)
+        auto tr_frag = [&](int idx) -> uint4 {   // idx = s2 * NCB + cb
+          const int s2 = idx / NCB, cb = idx % NCB;
           const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + s2 * 32 * C));
           const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + s2 * 32 * C));
-          oacc[cb] = mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), bfrag, oacc[cb]);
+          return make_uint4(lo.x, lo.y, hi.x, hi.y);
+        };
+        uint4 ring[3];
+        ring[0] = tr_frag(0);
+        ring[1] = tr_frag(1);
+#pragma unroll
+        for (int idx = 0; idx < 2 * NCB; idx++) {
+          const int s2 = idx / NCB, cb = idx % NCB;
+          if (idx + 2 < 2 * NCB) ring[(idx + 2) % 3] = tr_frag(idx + 2);
+          oacc[cb] = mfma32(ring[idx % 3], make_uint4(pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]), oacc[cb]);
+          if (idx < NCB && (idx * 4) % NCB == 0) prob_pair(8 + 2 * ((idx * 4) / NCB));
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
