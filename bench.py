@@ -291,7 +291,11 @@ def main():
     # run_hier_xing.py:275-301), users sharded over the ranks, timed after the evaluation region under the same launch
     train = None
     if not a.no_train:
-        train = train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)
+        try:
+            train = train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)
+        except Exception as e:  # noqa: BLE001  (the headline line above must survive a failure of the secondary leg; the error is reported)
+            import traceback
+            train = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:

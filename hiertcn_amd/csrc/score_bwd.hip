@@ -53,7 +53,6 @@ template <int C, int MODE>
 __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
   using G = ScGeom<C>;
   static_assert(C == 128 || C == 256, "the dual-use LDS image is laid out for 256- and 512-byte rows");
-  constexpr bool ROWSTAT = MODE != 0;
   constexpr int NCB = C / 32;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages of 64 stream vectors + 3 x 64 stream scalars
   const int64_t n_stat = a.n_stat_dev ? (int64_t)a.n_stat_dev[0] : a.n_stat_max;
