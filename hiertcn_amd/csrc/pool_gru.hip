@@ -108,8 +108,11 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 // SPLITK (small batches: fewer tiles than CUs): the four waves of a workgroup share ONE tile and take every fourth
 // 8-deep k-step each, then add their accumulators through LDS -- a 32-lane XING batch otherwise runs each of its 40
 // dependent GRU GEMMs as a single 256-MFMA chain per wave (20 us per launch, 80 % of the batch's time).
+struct GemmPair { GemmArgs g[2]; };
+
 template <int EPI, bool SPLITK = false>
-__global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
+__global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
+  const GemmArgs& g = gp.g[blockIdx.y];   // up to two independent GEMMs of one shape per launch (the scan's wavefront: launch_gru_scan)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
@@ -220,15 +223,21 @@ __global__ __launch_bounds__(256) void k_gemm_f32(GemmArgs g) {
   }
 }
 
+// n = 1 or 2 GEMMs of the SAME shape (M, N) in one launch
 template <int EPI>
-static hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) {
-  const int tiles = ((g.M + 31) / 32) * (g.N / 32);
-  if (tiles <= 128)
-    hipLaunchKernelGGL((k_gemm_f32<EPI, true>), dim3(tiles), dim3(256), 0, st, g);
+static hipError_t launch_gemm(const GemmArgs* g, int n, hipStream_t st) {
+  GemmPair gp;
+  gp.g[0] = g[0];
+  gp.g[1] = g[n > 1 ? 1 : 0];
+  const int tiles = ((g[0].M + 31) / 32) * (g[0].N / 32);
+  if (tiles * n <= 128)
+    hipLaunchKernelGGL((k_gemm_f32<EPI, true>), dim3(tiles, n), dim3(256), 0, st, gp);
   else
-    hipLaunchKernelGGL((k_gemm_f32<EPI, false>), dim3((tiles + 3) / 4), dim3(256), 0, st, g);
+    hipLaunchKernelGGL((k_gemm_f32<EPI, false>), dim3((tiles + 3) / 4, n), dim3(256), 0, st, gp);
   return hipGetLastError();
 }
+template <int EPI>
+static hipError_t launch_gemm(const GemmArgs& g, hipStream_t st) { return launch_gemm<EPI>(&g, 1, st); }
 
 __global__ void k_state_rows(const float* __restrict__ src, int64_t src_stride, float* __restrict__ dst, int64_t dst_stride,
                              int rows, int cols) {
@@ -245,8 +254,8 @@ static hipError_t copy_rows(const float* src, int64_t ss, float* dst, int64_t ds
 }
 
 size_t gru_workspace_bytes(const ModelDev& m, int B, int S) {
-  // history [B][S+1][HT] + gates [B][2H] + rh [B][H] + per-layer unmasked outputs [nl][B][H]
-  return sizeof(float) * ((size_t)B * (S + 1) * m.HT + (size_t)B * 2 * m.H + (size_t)B * m.H + (size_t)m.nl * B * m.H);
+  // history [B][S+1][HT] + per layer: gates [B][2H] + rh [B][H] + unmasked outputs [2 (slot parity)][B][H]
+  return sizeof(float) * ((size_t)B * (S + 1) * m.HT + (size_t)m.nl * B * 5 * m.H);
 }
 
 size_t gru_save_floats(const ModelDev& m, int B, int S) {
@@ -259,41 +268,67 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
   if (B <= 0) return hipSuccess;
   const int E = m.E, H = m.H, HT = m.HT;
   float* hist = ws;                                  // [B][S+1][HT]
-  float* gates = hist + (size_t)B * (S + 1) * HT;    // [B][2H]
-  float* rh = gates + (size_t)B * 2 * H;             // [B][H]
-  float* hcur = rh + (size_t)B * H;                  // [nl][B][H]
+  float* gates0 = hist + (size_t)B * (S + 1) * HT;   // [nl][B][2H]
+  float* rh0 = gates0 + (size_t)m.nl * B * 2 * H;    // [nl][B][H]
+  float* hcur = rh0 + (size_t)m.nl * B * H;          // [2][nl][B][H]: by slot parity -- cell (s+1, l) writes its output in the same
+                                                     // launch in which cell (s, l+1) still reads the output of (s, l)
   const size_t cell = (size_t)B * 5 * H;             // one (slot, layer) record of `save`
   const int64_t hs = (int64_t)(S + 1) * HT;          // row stride of the history
   hipError_t e = copy_rows(state_in, HT, hist, hs, B, HT, st);
   if (e != hipSuccess) return e;
-  for (int s = 0; s < S; s++) {
+  // Wavefront over (slot, layer): cell (s, l) needs (s, l-1) and (s-1, l) only, so the cells with s + l = tau are independent -- layer 1
+  // of slot s runs beside layer 0 of slot s + 1.  The critical path is S + nl - 1 cells instead of S * nl, and the independent cells of
+  // a step go out as ONE grouped launch per GEMM kind when they have one shape (layers >= 1 all do; layer 0 too when E == H): 2 (S + 1)
+  // dependent launches instead of 4 S for the reference's two layers -- the scan is latency-bound at the reference's batch sizes (§4.5).
+  auto cell_args = [&](int s, int l, GemmArgs& gg, GemmArgs& gc) {
+    memset(&gg, 0, sizeof(gg));
+    const float* in = (l == 0) ? pooled + (size_t)s * E
+                      : (save ? save + ((size_t)s * m.nl + (l - 1)) * cell + (size_t)B * 4 * H : hcur + ((size_t)(s & 1) * m.nl + (l - 1)) * B * H);
+    const int ldin = (l == 0) ? S * E : H;
+    const int in_dim = (l == 0) ? E : H;
+    const float* hold = hist + (size_t)s * HT + (size_t)l * H;
+    float* gates = gates0 + (size_t)l * B * 2 * H;
+    float* rh = rh0 + (size_t)l * B * H;
+    float* hout = hcur + ((size_t)(s & 1) * m.nl + l) * B * H;
+    if (save) {  // training: every (slot, layer) keeps its own gates / r*h / candidate / output (GruSaved in train.hip)
+      float* rec = save + ((size_t)s * m.nl + l) * cell;
+      gates = rec; rh = rec + (size_t)B * 2 * H; gg.cand_out = rec + (size_t)B * 3 * H; gg.ldc = H;
+      hout = rec + (size_t)B * 4 * H;
+    }
+    gg.M = B; gg.H = H;
+    gg.A1 = in; gg.lda1 = ldin; gg.K1 = in_dim;
+    gg.A2 = hold; gg.lda2 = (int)hs; gg.K2 = H;
+    gg.Wt = m.gru_wg[l]; gg.bias = m.gru_bg[l]; gg.N = 2 * H;
+    gg.out = gates; gg.ldo = 2 * H; gg.out2 = rh; gg.ldo2 = H; gg.h = hold; gg.ldh = (int)hs;
+    gc = gg;
+    gc.A2 = rh; gc.lda2 = H;
+    gc.Wt = m.gru_wc[l]; gc.bias = m.gru_bc[l]; gc.N = H;
+    gc.out = hout; gc.ldo = H;
+    gc.out2 = hist + (size_t)(s + 1) * HT + (size_t)l * H; gc.ldo2 = (int)hs;
+    gc.gates = gates; gc.ldg = 2 * H;
+    gc.mask = mask + s; gc.ldm = S;
+  };
+  for (int tau = 0; tau < S + m.nl - 1; tau++) {
+    GemmArgs gg[HIERTCN_MAX_LAYERS], gc[HIERTCN_MAX_LAYERS];
+    int n = 0;
     for (int l = 0; l < m.nl; l++) {
-      GemmArgs g;
-      memset(&g, 0, sizeof(g));
-      const float* in = (l == 0) ? pooled + (size_t)s * E
-                        : (save ? save + ((size_t)s * m.nl + (l - 1)) * cell + (size_t)B * 4 * H : hcur + (size_t)(l - 1) * B * H);
-      const int ldin = (l == 0) ? S * E : H;
-      const int in_dim = (l == 0) ? E : H;
-      const float* hold = hist + (size_t)s * HT + (size_t)l * H;
-      float* hout = hcur + (size_t)l * B * H;
-      if (save) {  // training: every (slot, layer) keeps its own gates / r*h / candidate / output (GruSaved in train.hip)
-        float* rec = save + ((size_t)s * m.nl + l) * cell;
-        gates = rec; rh = rec + (size_t)B * 2 * H; g.cand_out = rec + (size_t)B * 3 * H; g.ldc = H;
-        hout = rec + (size_t)B * 4 * H;
-      }
-      g.M = B; g.H = H;
-      g.A1 = in; g.lda1 = ldin; g.K1 = in_dim;
-      g.A2 = hold; g.lda2 = (int)hs; g.K2 = H;
-      g.Wt = m.gru_wg[l]; g.bias = m.gru_bg[l]; g.N = 2 * H;
-      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = (int)hs;
-      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
-      g.A2 = rh; g.lda2 = H;
-      g.Wt = m.gru_wc[l]; g.bias = m.gru_bc[l]; g.N = H;
-      g.out = hout; g.ldo = H;
-      g.out2 = hist + (size_t)(s + 1) * HT + (size_t)l * H; g.ldo2 = (int)hs;
-      g.gates = gates; g.ldg = 2 * H;
-      g.mask = mask + s; g.ldm = S;
-      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+      const int s = tau - l;
+      if (s < 0 || s >= S) continue;
+      cell_args(s, l, gg[n], gc[n]);
+      n++;
+    }
+    // group cells of one shape (K1 may differ between layer 0 and the others when E != H: then they go out separately)
+    for (int i = 0; i < n;) {
+      int j = i + 1;
+      if (j < n && gg[j].K1 == gg[i].K1) j++;   // at most two per launch
+      if ((e = launch_gemm<EPI_GATES>(gg + i, j - i, st)) != hipSuccess) return e;
+      i = j;
+    }
+    for (int i = 0; i < n;) {
+      int j = i + 1;
+      if (j < n && gc[j].K1 == gc[i].K1) j++;
+      if ((e = launch_gemm<EPI_CAND>(gc + i, j - i, st)) != hipSuccess) return e;
+      i = j;
     }
   }
   {  // state half of the input projection for every slot at once: [B*(S+1), HT] x [HT, E]
