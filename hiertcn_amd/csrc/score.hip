@@ -125,10 +125,18 @@ __device__ __forceinline__ void epilogue(const f32x16& v, RowState& st) {
 
 // Running top-KT list of one lane (one step, half of the items): values descending, equal values in arrival
 // (= index) order, which is the order tf.nn.top_k returns (loss.py:120: ties -> lower index first).
+// A candidate does not go into the sorted list at once: it is parked in a two-entry buffer, and the buffers of all 64 lanes are
+// flushed into their lists (two insertions) only when a lane that already holds two needs a third.  A wave pays for a list insertion
+// whenever ONE of its lanes has a candidate (~6,000 times per pass over 300,000 items), a buffered candidate costs a handful of selects
+// and the flushes are ~40 x rarer; the list's last entry -- the admission threshold -- is merely a little stale in between, which admits
+// a few candidates more and changes nothing in the result (top_insert re-checks; arrival order is kept: buffer order = arrival order).
 template <int KT>
 struct TopList {
   float v[KT];
   int i[KT];
+  float pv0, pv1;   // parked candidates
+  int pi0, pi1;
+  int pc;           // how many are parked (0..2)
 };
 
 // insert (val, idx) below the last entry and bubble it up; strict '>' keeps equal values in arrival order
@@ -147,6 +155,24 @@ __device__ __forceinline__ void top_insert(TopList<KT>& L, float val, int idx) {
   }
 }
 
+template <int KT>
+__device__ __forceinline__ void top_init(TopList<KT>& L) {
+#pragma unroll
+  for (int k = 0; k < KT; k++) { L.v[k] = -INFINITY; L.i[k] = 0x7fffffff; }
+  L.pv0 = L.pv1 = -INFINITY;
+  L.pi0 = L.pi1 = 0x7fffffff;
+  L.pc = 0;
+}
+
+// parked candidates -> the sorted list, in arrival order (an empty slot holds -inf: its insertion is a no-op)
+template <int KT>
+__device__ __forceinline__ void top_flush(TopList<KT>& L) {
+  top_insert<KT>(L, L.pv0, L.pi0);
+  top_insert<KT>(L, L.pv1, L.pi1);
+  L.pv0 = L.pv1 = -INFINITY;
+  L.pc = 0;
+}
+
 // one 32-item x 32-step accumulator tile against the lane's list; item index of register r is item0 + 8*(r>>2) + (r&3)
 template <int KT>
 __device__ __forceinline__ void top_tile(TopList<KT>& L, const f32x16& v, int item0) {
@@ -155,7 +181,18 @@ __device__ __forceinline__ void top_tile(TopList<KT>& L, const f32x16& v, int it
   if (!__any(tm > L.v[KT - 1])) return;  // wave-uniform: no lane of this wave has a candidate in this tile
 #pragma unroll
   for (int r = 0; r < 16; r++) {
-    if (__any(v[r] > L.v[KT - 1])) top_insert<KT>(L, v[r], item0 + 8 * (r >> 2) + (r & 3));
+    bool take = v[r] > L.v[KT - 1];
+    if (__any(take)) {
+      if (__any(take && L.pc == 2)) {   // a lane with a full buffer needs a third slot: everybody flushes (rare)
+        top_flush<KT>(L);
+        take = v[r] > L.v[KT - 1];      // the threshold may have risen
+      }
+      const int idx = item0 + 8 * (r >> 2) + (r & 3);
+      const bool t0 = take && L.pc == 0, t1 = take && L.pc == 1;
+      L.pv0 = t0 ? v[r] : L.pv0; L.pi0 = t0 ? idx : L.pi0;
+      L.pv1 = t1 ? v[r] : L.pv1; L.pi1 = t1 ? idx : L.pi1;
+      L.pc += take ? 1 : 0;
+    }
   }
 }
 
@@ -197,10 +234,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
   TopList<KTA> top[NB];
   if (KT > 0) {
 #pragma unroll
-    for (int cbk = 0; cbk < NB; cbk++) {
-#pragma unroll
-      for (int k = 0; k < KTA; k++) { top[cbk].v[k] = -INFINITY; top[cbk].i[k] = 0x7fffffff; }
-    }
+    for (int cbk = 0; cbk < NB; cbk++) top_init<KTA>(top[cbk]);
   }
 
   // ---- this wave's 64 steps as the B operand, resident for the whole kernel -------------------
@@ -440,6 +474,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score(const uint16_t* __restr
       int* li = reinterpret_cast<int*>(smem + SC_THREADS * KTA * 4);    // [512 lanes][KT]
 #pragma unroll
       for (int cbk = 0; cbk < NB; cbk++) {
+        top_flush<KTA>(top[cbk]);
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < KTA; k++) { lv[tid * KTA + k] = top[cbk].v[k]; li[tid * KTA + k] = top[cbk].i[k]; }
@@ -906,10 +941,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 
   constexpr int KTA = KT > 0 ? KT : 1;
   TopList<KTA> top;
-  if (KT > 0) {
-#pragma unroll
-    for (int k = 0; k < KTA; k++) { top.v[k] = -INFINITY; top.i[k] = 0x7fffffff; }
-  }
+  if (KT > 0) top_init<KTA>(top);
   f32x16 accA, accB;
   if constexpr (NB == 2 && SEAMLESS && C <= 256) {
     f32x16 xa0, xa1, xb0, xb1;
@@ -1073,6 +1105,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     // ascending) through LDS, which the item stream no longer needs
     float* lv = reinterpret_cast<float*>(smem);                       // [512 lanes][KT]
     int* li = reinterpret_cast<int*>(smem + SC_THREADS * KTA * 4);    // [512 lanes][KT]
+    top_flush<KTA>(top);
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < KTA; k++) { lv[tid * KTA + k] = top.v[k]; li[tid * KTA + k] = top.i[k]; }
