@@ -127,7 +127,7 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
     }
     ex = model._exchange
     seg = {k: eng.grad_segment(k) for k in (0, 1, 2)}
-    coll = {"backend": "rccl" if world > 1 else None, "algorithm": ex.mode, "item_table_exchange": ex.last.get("item_table", "dense"),
+    coll = {"backend": (("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else None), "algorithm": ex.mode, "item_table_exchange": ex.last.get("item_table", "dense"),
             "bytes": {"item_table": seg[0][1] * 4, "scoring_layer": seg[1][1] * 4, "rest": seg[2][1] * 4}}
     if world > 1:
         # (a) the same steps with the collectives off (replicas drift apart from here on: timing only, the bench ends after it)

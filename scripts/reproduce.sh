@@ -4,7 +4,8 @@ python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" | tail -1
 echo "== headline (bench.py defaults: 4096 users/step, cfg-3 shape)"; python3 bench.py 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 b = json.loads(sys.stdin.read()); r = b['roofline']
-print(f\"{b['value']:.0f} sessions/s, {b['ms_per_step']:.1f} ms/step; scoring {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of peak, {r['frac_of_library_gemm']:.2f} x library GEMM; cpu {b['cpu_baseline']['value']:.1f} sessions/s on {b['cpu_baseline']['cores']} cores\")"
+t = b.get('train') or {}
+print(f\"{b['value']:.0f} sessions/s, {b['ms_per_step']:.1f} ms/step; scoring {r['achieved']:.0f} TFLOP/s = {r['frac']:.3f} of peak, {r['frac_of_library_gemm']:.2f} x library GEMM; cpu {b['cpu_baseline']['value']:.1f} sessions/s on {b['cpu_baseline']['cores']} cores; train leg {t.get('ms_per_step')} ms/step = {t.get('sessions_per_s')} sessions/s\")"
 echo "== ragged sessions (lengths ~ U{1..30})"; python3 bench.py --ragged --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json; b = json.loads(sys.stdin.read()); print(f\"{b['value']:.0f} sessions/s\")"
 echo "== reference batching (32 lanes x 10 x <=20, XING catalogue)"; python3 scripts/cfg2_bench.py 2>&1 | tail -2
@@ -14,9 +15,14 @@ echo "== d = 512, N = 1,000,000 (bf16, then the IEEE-half build)"
 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
 DTYPE=fp16 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
 echo "== ranked top-k flavour"; python3 scripts/topk_bench.py 2>&1 | tail -3
-echo "== training step (1024 users), dense / ragged / HierGRU"
+echo "== training step (1024 users), dense / ragged / previous scoring backward (G chunks + rocBLAS) / HierGRU"
 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 python3 scripts/train_bench.py 1024 3 ragged 2>&1 | tail -1
+HIERTCN_TRAIN_LEGACY=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
+echo "== data-parallel code path, 2 ranks sharing the GPU over gloo (smoke: RCCL needs one GPU per rank)"
+HIERTCN_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --users-per-step 512 --train-users-per-step 256 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
+import sys, json; b = json.loads(sys.stdin.read()); t = b['train']; print(b['n_gpus'], 'ranks:', round(b['value']), 'sessions/s eval;', 'train', t.get('ms_per_step'), 'ms/step', t.get('collectives'))"
+echo "== parity against the exact oracle on unrounded fp32 weights"; python3 scripts/parity_fp32_probe.py 2>&1 | grep shape | cut -c1-400
 echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3
 echo "== repeated full-size launches agree (ranks, target logits bitwise; ce to 5e-5)"; python3 scripts/soak_score.py 2>&1 | grep mismatching
