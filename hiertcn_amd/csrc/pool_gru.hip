@@ -5,6 +5,7 @@
 //
 // Both kernels are fp32 end to end (the recurrence is the only true sequential dependency of
 // the path and < 0.1 % of its FLOPs; rounding the carried state would compound over sessions).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -110,15 +111,18 @@ typedef float f32x16v __attribute__((ext_vector_type(16)));
 // dependent GRU GEMMs as a single 256-MFMA chain per wave (20 us per launch, 80 % of the batch's time).
 struct GemmPair { GemmArgs g[2]; };
 
-template <int EPI, bool SPLITK = false>
+// SPLITK = 0: four tiles per 256-thread workgroup; 4: ONE tile per workgroup, wave w takes every 4th k-step (small launches).  (A 16-wave /
+// 1024-thread form of the split was measured on the 32-lane XING batch: 0.49 vs 0.41 ms per batch -- the serial sum of fifteen partial
+// tiles and the larger workgroups cost more than the shorter k chains save.)
+template <int EPI, int SPLITK = 0>
 __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
   const GemmArgs& g = gp.g[blockIdx.y];   // up to two independent GEMMs of one shape per launch (the scan's wavefront: launch_gru_scan)
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int tiles_n = g.N >> 5;
-  const int t = SPLITK ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;
-  constexpr int KSTEP = SPLITK ? 4 : 1;
+  const int t = SPLITK ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave;   // (SPLITK: all waves of the workgroup share tile blockIdx.x)
+  constexpr int KSTEP = SPLITK ? SPLITK : 1;
   const int k_first = SPLITK ? wave : 0;
   const int tm = t / tiles_n, tn = t - tm * tiles_n;
   if (tm * 32 >= g.M) return;
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
   const int n1 = g.K1 >> 3;
-#pragma unroll 4
+#pragma unroll 8
   for (int i = k_first; i < n1; i += KSTEP) {
     const float4 a = *reinterpret_cast<const float4*>(wp + 8 * i);
     const float4 b = *reinterpret_cast<const float4*>(x1 + 8 * i);
@@ -147,7 +151,7 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
     const float* x2 = g.A2 + (int64_t)mrow * g.lda2 + 4 * lh;
     const float* wp2 = wp + g.K1;
     const int n2 = g.K2 >> 3;
-#pragma unroll 4
+#pragma unroll 8
     for (int i = k_first; i < n2; i += KSTEP) {
       const float4 a = *reinterpret_cast<const float4*>(wp2 + 8 * i);
       const float4 b = *reinterpret_cast<const float4*>(x2 + 8 * i);
@@ -157,8 +161,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
   }
-  if (SPLITK) {   // fixed-order sum of the four partial tiles (deterministic)
-    __shared__ float part[3][16][64];
+  if (SPLITK) {   // fixed-order sum of the partial tiles (deterministic)
+    constexpr int NP_ = SPLITK ? SPLITK - 1 : 1;
+    __shared__ float part[NP_][16][64];
     if (wave > 0) {
 #pragma unroll
       for (int i = 0; i < 16; i++) part[wave - 1][i][lane] = acc[i];
@@ -166,7 +171,12 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
     __syncthreads();
     if (wave > 0) return;
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = ((acc[i] + part[0][i][lane]) + part[1][i][lane]) + part[2][i][lane];
+    for (int i = 0; i < 16; i++) {
+      float s_ = acc[i];
+#pragma unroll
+      for (int w = 0; w < NP_; w++) s_ += part[w][i][lane];
+      acc[i] = s_;
+    }
   }
   if (!mvalid) return;
   const int m = tm * 32 + lr;
@@ -231,9 +241,9 @@ static hipError_t launch_gemm(const GemmArgs* g, int n, hipStream_t st) {
   gp.g[1] = g[n > 1 ? 1 : 0];
   const int tiles = ((g[0].M + 31) / 32) * (g[0].N / 32);
   if (tiles * n <= 128)
-    hipLaunchKernelGGL((k_gemm_f32<EPI, true>), dim3(tiles, n), dim3(256), 0, st, gp);
+    hipLaunchKernelGGL((k_gemm_f32<EPI, 4>), dim3(tiles, n), dim3(256), 0, st, gp);
   else
-    hipLaunchKernelGGL((k_gemm_f32<EPI, false>), dim3((tiles + 3) / 4, n), dim3(256), 0, st, gp);
+    hipLaunchKernelGGL((k_gemm_f32<EPI, 0>), dim3((tiles + 3) / 4, n), dim3(256), 0, st, gp);
   return hipGetLastError();
 }
 template <int EPI>
