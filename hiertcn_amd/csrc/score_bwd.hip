@@ -172,80 +172,107 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
   float cs = 0.f;   // mode 0: column sum (d bo); mode 2: running softmax sum
   int cnt = 0;      // mode 2: #{z > target}
 
+  // One tile = GEMM-1 (C/16 MFMAs into `acc`) -> 16 probabilities per lane -> GEMM-2 (two k-steps of C/32 MFMAs each, from the packed
+  // probabilities pk[0..3] / pk[4..7]).  The two waves of a SIMD meet at one barrier per stage, so they run the same part of a tile at the
+  // same time; VALU work therefore has to sit beside a wave's OWN MFMAs to be hidden.  Software pipeline, no extra registers:
+  //     G1(t)                                            16 MFMAs (dependent chain)
+  //     probabilities 0..7 of t   ||  GEMM-2 k-step 1 of tile t-1   (pk[4..7] of t-1 were kept across G1(t); its LDS tile is still resident)
+  //     GEMM-2 k-step 0 of t      ||  probabilities 8..15 of t       (-> pk[4..7])
+  // The deferred k-step of a stage's last tile reads that stage's buffer during the NEXT iteration, so the stage barrier (and the refill
+  // of the oldest buffer behind it) sits behind the first of those overlapped parts instead of at the end of the iteration: still one
+  // barrier per stage, still three buffers (s-1 until that barrier, s, s+1; s+2 lands in the buffer of s-1).
+  // (Measured alternatives: fragment reads 1 / 2 ahead: no difference; waves 4-7 one part behind waves 0-3 through a rotated per-tile
+  // loop with the two halves' barriers at different points: 364 vs 323 ms per training step, the rotated loop costs registers.)
+  f32x16 acc;
+  uint32_t pk[8];
+  auto prob_pair = [&](int i) {   // values i, i + 1 of the tile -> one packed bf16 pair
+    const float e0 = __builtin_amdgcn_exp2f(fmaf(acc[i], LOG2E_F, cst));
+    const float e1 = __builtin_amdgcn_exp2f(fmaf(acc[i + 1], LOG2E_F, cst));
+    if (MODE != 1) cs += e0 + e1;
+    if (MODE == 2) cnt += (acc[i] > tlog ? 1 : 0) + (acc[i + 1] > tlog ? 1 : 0);
+    pk[i >> 1] = pack2bf(e0, e1);
+  };
+  auto g1 = [&](const unsigned char* tl, const float* tb) {
+    int ak = a_k0;   // opaque copy: hipcc otherwise hoists the 16 XOR-ed fragment addresses out of the stage loop and spills them
+    asm volatile("" : "+v"(ak));
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(tb + 8 * q + 4 * lh);
+#pragma unroll
+      for (int j = 0; j < 4; j++) acc[4 * q + j] = b4[j];
+    }
+    uint4 ring[2];
+    ring[0] = *reinterpret_cast<const uint4*>(tl + (ak ^ (0 << 5)));
+#pragma unroll
+    for (int s = 0; s < G::KS; s++) {
+      if (s + 1 < G::KS) ring[(s + 1) & 1] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 1) << 5)));
+      acc = mfma32(ring[s & 1], hf[s], acc);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // one k-step (s2) of GEMM-2 on the tile at `tl`, with `first` probabilities pairs of the CURRENT tile computed in its MFMA gaps
+  auto g2 = [&](const unsigned char* tl, int s2, int first, bool run) {
+    int tr0 = tr_a[0], tr1 = tr_a[1];
+    asm volatile("" : "+v"(tr0), "+v"(tr1));
+    auto tr_frag = [&](int cb) -> uint4 {
+      const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + s2 * 32 * C));
+      const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + s2 * 32 * C));
+      return make_uint4(lo.x, lo.y, hi.x, hi.y);
+    };
+    const uint4 bfrag = make_uint4(pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]);
+    uint4 ring[2];
+    if (run) ring[0] = tr_frag(0);
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+      if (run) {
+        if (cb + 1 < NCB) ring[(cb + 1) & 1] = tr_frag(cb + 1);
+        oacc[cb] = mfma32(ring[cb & 1], bfrag, oacc[cb]);
+      }
+      if ((cb * 4) % NCB == 0) prob_pair(first + 2 * ((cb * 4) / NCB));   // 4 pairs spread over the NCB gaps
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   if (n_stages > 0) stage_issue(0, 0);
   if (n_stages > 1) stage_issue(1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  int buf = 0;
+  int buf = 0, pbuf = 0;
   for (int stg = 0; stg < n_stages; stg++) {
-    const int buf2 = (buf >= 1) ? buf - 1 : 2;   // (buf + 2) % 3
-    if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
-#pragma unroll
-    for (int tile = 0; tile < 2; tile++) {
-      const unsigned char* tl = smem + buf * STAGE_LDS + tile * TILE_LDS;
-      // opaque copies: hipcc otherwise hoists the 16 + 16 XOR-ed fragment addresses out of the stage loop and spills them
-      int ak = a_k0, tr0 = tr_a[0], tr1 = tr_a[1];
-      asm volatile("" : "+v"(ak), "+v"(tr0), "+v"(tr1));
-      f32x16 acc;
-#pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const f32x4 b4 = *reinterpret_cast<const f32x4*>(sbias + buf * SC_STAGE + tile * 32 + 8 * q + 4 * lh);
-#pragma unroll
-        for (int j = 0; j < 4; j++) acc[4 * q + j] = b4[j];
-      }
-      {   // fragment reads two k-steps ahead of their MFMA (the registers of the packed probabilities are free during this part)
-        uint4 ring[3];
-        ring[0] = *reinterpret_cast<const uint4*>(tl + (ak ^ (0 << 5)));
-        ring[1] = *reinterpret_cast<const uint4*>(tl + (ak ^ (1 << 5)));
-#pragma unroll
-        for (int s = 0; s < G::KS; s++) {
-          if (s + 2 < G::KS) ring[(s + 2) % 3] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 2) << 5)));
-          acc = mfma32(ring[s % 3], hf[s], acc);
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);   // keep the three parts of a tile apart: overlapping them costs registers this kernel does not have
-      uint32_t pk[8];
-      auto prob_pair = [&](int i) {   // values i, i + 1 of the tile -> one packed bf16 pair
-        const float e0 = __builtin_amdgcn_exp2f(fmaf(acc[i], LOG2E_F, cst));
-        const float e1 = __builtin_amdgcn_exp2f(fmaf(acc[i + 1], LOG2E_F, cst));
-        if (MODE != 1) cs += e0 + e1;
-        if (MODE == 2) cnt += (acc[i] > tlog ? 1 : 0) + (acc[i + 1] > tlog ? 1 : 0);
-        pk[i >> 1] = pack2bf(e0, e1);
-      };
-      // The first k-step of GEMM-2 needs the probabilities of values 0..7 only: those now, values 8..15 in the gaps of that k-step's MFMAs.
-      // (The two waves of a SIMD meet at one barrier per stage and run the same part of a tile at the same time, so VALU work that sits
-      // beside a wave's OWN MFMAs is time saved: 333 -> 323 ms per training step.  Running waves 4-7 one part behind waves 0-3 instead
-      // -- a per-tile rotated loop with the two halves' barriers at different points -- was built and measured: 364 ms; the rotated
-      // loop costs more registers than it buys overlap.)
-#pragma unroll
-      for (int i = 0; i < 8; i += 2) prob_pair(i);
-      __builtin_amdgcn_sched_barrier(0);
-      {   // transposed fragment reads two MFMAs ahead (the GEMM-1 tile's registers are dead once its probabilities are packed)
-        auto tr_frag = [&](int idx) -> uint4 {   // idx = s2 * NCB + cb
-          const int s2 = idx / NCB, cb = idx % NCB;
-          const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + s2 * 32 * C));
-          const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + s2 * 32 * C));
-          return make_uint4(lo.x, lo.y, hi.x, hi.y);
-        };
-        uint4 ring[3];
-        ring[0] = tr_frag(0);
-        ring[1] = tr_frag(1);
-#pragma unroll
-        for (int idx = 0; idx < 2 * NCB; idx++) {
-          const int s2 = idx / NCB, cb = idx % NCB;
-          if (idx + 2 < 2 * NCB) ring[(idx + 2) % 3] = tr_frag(idx + 2);
-          oacc[cb] = mfma32(ring[idx % 3], make_uint4(pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]), oacc[cb]);
-          if (idx < NCB && (idx * 4) % NCB == 0) prob_pair(8 + 2 * ((idx * 4) / NCB));
-          __builtin_amdgcn_sched_barrier(0);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
+    const unsigned char* t0 = smem + buf * STAGE_LDS;
+    const unsigned char* t1 = t0 + TILE_LDS;
+    const float* tb = sbias + buf * SC_STAGE;
+    // ---- tile 0
+    g1(t0, tb);
+    __builtin_amdgcn_sched_barrier(0);
+    g2(smem + pbuf * STAGE_LDS + TILE_LDS, 1, 0, stg > 0);   // probabilities 0..7 || the previous stage's last tile, k-step 1 (pk[4..7] still its own)
+    __builtin_amdgcn_sched_barrier(0);
+    // stage boundary: everyone is done with the buffer of stage stg - 1, and stage stg + 1 (issued one iteration ago) has landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
+    if (stg + 2 < n_stages) stage_issue(stg + 2, (buf >= 1) ? buf - 1 : 2);
+    g2(t0, 0, 8, true);                                         // k-step 0 of tile 0 || probabilities 8..15
+    __builtin_amdgcn_sched_barrier(0);
+    // ---- tile 1
+    g1(t1, tb + 32);
+    __builtin_amdgcn_sched_barrier(0);
+    g2(t0, 1, 0, true);                                         // probabilities 0..7 of tile 1 || k-step 1 of tile 0
+    __builtin_amdgcn_sched_barrier(0);
+    g2(t1, 0, 8, true);                                         // k-step 0 of tile 1 || probabilities 8..15
+    __builtin_amdgcn_sched_barrier(0);
+    pbuf = buf;
     buf = (buf == 2) ? 0 : buf + 1;
+  }
+  if (n_stages > 0) {   // drain: k-step 1 of the very last tile (its probabilities are in pk[4..7]; nothing left to compute beside it)
+    const unsigned char* tl = smem + pbuf * STAGE_LDS + TILE_LDS;
+    int tr0 = tr_a[0], tr1 = tr_a[1];
+#pragma unroll
+    for (int cb = 0; cb < NCB; cb++) {
+      const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + 32 * C));
+      const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + 32 * C));
+      oacc[cb] = mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), make_uint4(pk[4], pk[5], pk[6], pk[7]), oacc[cb]);
+    }
   }
 
   // out^T[c][stationary]: register i of tile cb is channel 32 cb + (i & 3) + 8 (i >> 2) + 4 lh of this lane's stationary vector
