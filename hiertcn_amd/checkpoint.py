@@ -37,6 +37,12 @@ def save(fname: str, params: Dict[str, np.ndarray], extra: Optional[Dict[str, np
 
 
 def load(fname: str, with_extra: bool = False):
+    """`fname` = what was passed to save() -- or the prefix of a checkpoint written by TensorFlow's own tf.train.Saver
+    (`<prefix>.index` + `<prefix>.data-*`: hiertcn_amd.tf_checkpoint reads it without TensorFlow; Adam slots are skipped)."""
+    if not os.path.exists(_path(fname)) and os.path.exists(fname + ".index"):
+        from .tf_checkpoint import read_tf_checkpoint
+        params = {k: v for k, v in read_tf_checkpoint(fname).items() if v.dtype == np.float32 and k != "global_step"}
+        return (params, {}) if with_extra else params
     with np.load(_path(fname)) as z:
         params = {k: z[k] for k in z.files if not k.startswith(EXTRA)}
         extra = {k[len(EXTRA):]: z[k] for k in z.files if k.startswith(EXTRA)}
