@@ -159,6 +159,54 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
     return out
 
 
+def dvfs_probe(eng, rows, n_items, dim, seconds=1.5):
+    """The scoring kernel alone, back to back for `seconds`, on random-normal hidden rows and on all-zero hidden rows (the MFMA B
+    operand: same instruction stream, same LDS / L2 traffic, every product zero), with the shader clock read from rocm-smi (sysfs)
+    meanwhile: how much of the distance to the data-sheet peak is the clock the chip holds under this load, not the kernel."""
+    import re
+    import subprocess
+    import threading
+
+    def sampler(stop, out):
+        while not stop.is_set():
+            try:
+                r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showpower", "--showclocks"], capture_output=True, text=True, timeout=10).stdout
+                ck = re.search(r"sclk clock level:?\s*\d*:?\s*\(?([0-9.]+)\s*Mhz", r, re.I)
+                pw = re.search(r"Power \(W\):\s*([0-9.]+)", r)
+                out.append((float(ck.group(1)) if ck else None, float(pw.group(1)) if pw else None))
+            except Exception:  # noqa: BLE001  (no rocm-smi: the timings below still stand)
+                return
+            time.sleep(0.15)
+
+    y = torch.randint(1, n_items, (rows,), device="cuda", dtype=torch.int32)
+    res = {"what": "scoring kernel alone on random-normal vs all-zero hidden rows (same binary, same instruction stream); sclk / socket "
+                   "power = median of rocm-smi samples during the loop"}
+    for name, scale in (("random", 0.5), ("zero_hidden_rows", 0.0)):
+        hid = (torch.randn(rows, dim, device="cuda") * scale).to(eng.act_dtype)
+        eng.score_fused(hid, y)
+        torch.cuda.synchronize()
+        stop, smp = threading.Event(), []
+        th = threading.Thread(target=sampler, args=(stop, smp))
+        th.start()
+        eng.timing_enable(True)
+        eng.timing_read(reset=True)
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < seconds:
+            eng.score_fused(hid, y)
+            torch.cuda.synchronize()
+        ms, n = eng.timing_read(reset=True)
+        eng.timing_enable(False)
+        stop.set()
+        th.join()
+        ck = sorted(v[0] for v in smp if v[0] is not None)
+        pw = sorted(v[1] for v in smp if v[1] is not None)
+        tf = 2.0 * rows * dim * n_items / (ms * 1e-3) / 1e12
+        res[name] = {"launch_ms": round(ms, 3), "launches": int(n), "tflops": round(tf, 1), "frac_of_peak": round(tf / MFMA_PEAK_TFLOPS, 4),
+                     "sclk_mhz": ck[len(ck) // 2] if ck else None, "power_w": pw[len(pw) // 2] if pw else None}
+        del hid
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -286,6 +334,13 @@ def main():
         except Exception as e:  # noqa: BLE001  (a yardstick, never fatal)
             gemm_ref = {"error": str(e)[:200]}
 
+    dvfs = None
+    if rank == 0 and world == 1 and not a.ragged:
+        try:
+            dvfs = dvfs_probe(eng, rows_per_launch, N_ITEMS, DIM)
+        except Exception as e:  # noqa: BLE001  (a diagnostic, never fatal)
+            dvfs = {"error": repr(e)[:200]}
+
     # ---- training leg (north star: "RCCL all-reduce over xGMI on the shared item-embedding gradients"): the same cfg-3 model,
     # one optimizer step = forward + loss + backward + gradient collectives + TF-form Adam (model.py:135-141,
     # run_hier_xing.py:275-301), users sharded over the ranks, timed after the evaluation region under the same launch
@@ -339,6 +394,7 @@ def main():
                 "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
                 "library_gemm_reference": gemm_ref,
                 "frac_of_library_gemm": (round(achieved / gemm_ref["tflops"], 4) if gemm_ref and gemm_ref.get("tflops") else None),
+                "clock_probe": dvfs,
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch through the L2's memory-side port (Infinity-Cache hits included)",
                 "traffic_source": traffic_src,

@@ -13,9 +13,11 @@ d = int(os.environ.get("D", "256"))
 for N in Ns:
     args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, tcn_channel=[d, d])
     p = init_params(args, 2)
+    if os.environ.get("ZERO_TABLE"):   # data-dependence probe: same instruction stream, no operand toggling
+        p["hier/tcn/dense/kernel"] = np.zeros_like(p["hier/tcn/dense/kernel"])
     eng = Engine(args, dtype=os.environ.get("DTYPE", "bf16"))
     eng.set_weights(p)
-    hid = (torch.randn(rows, d, device="cuda") * 0.5).to(eng.act_dtype)
+    hid = (torch.randn(rows, d, device="cuda") * float(os.environ.get("HID_SCALE", "0.5"))).to(eng.act_dtype)
     y = torch.randint(1, N, (rows,), device="cuda", dtype=torch.int32)
     eng.score_fused(hid, y)
     torch.cuda.synchronize()
