@@ -5,7 +5,7 @@
 // the epilogue of the previous tile's values sits in the MFMA gaps exactly as in k_score_pipe.
 //   SHAPE 0: v_mfma_f32_32x32x16_bf16, two 32-row blocks per wave (production): 16 k-steps, one logit per gap and block
 //   SHAPE 1: v_mfma_f32_16x16x32_bf16, four 16-row blocks per wave: 8 k-steps x 4 MFMAs, one logit per TWO gaps
-//   EPI 0: none; 5: fma, exp, add, cmp, addc (production); 4: fma, exp, add, alignbit (comparison folded into the MFMA)
+//   EPI 0: none; 1: one v_add per logit; 5: fma, exp, add, cmp, addc (production); 4: fma, exp, add, alignbit (comparison folded into the MFMA)
 // Each mode runs back to back for `seconds`; prints ms per launch, TFLOP/s chip-wide, ns per 32,768 flop per SIMD, and the in-kernel
 // clock (s_memtime / s_memrealtime, median over workgroups).  build: hipcc --offload-arch=gfx950 -O3 scripts/shape_bench.hip -o /tmp/shape_bench
 #include <hip/hip_runtime.h>
@@ -41,6 +41,7 @@ struct Row { float s, ep, xp, t, m2; int c; unsigned bits; };
 template <int EPI>
 static __device__ __forceinline__ void val(int i, float v, Row& r) {
   if (EPI == 0) return;
+  if (EPI == 1) { r.s += v; asm volatile("" : "+v"(r.s)); return; }
   r.s += r.ep;
   r.ep = __builtin_amdgcn_exp2f(r.xp);
   if (EPI == 5) {
@@ -74,7 +75,7 @@ static __device__ __forceinline__ void val_half(int i, int half, float v, Row& r
 
 constexpr int LDS_BYTES = 128 * 1024;   // 128 fragments of 1 KB: the A stream of 8 tiles (32x32: 16 per tile; 16x16: 8 per sub-tile)
 
-template <int SHAPE, int EPI>
+template <int SHAPE, int EPI, int NOLDS = 0>
 __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* clk, int tiles, int zero) {
   extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -103,15 +104,15 @@ __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* clk,
       const unsigned char* tile = base + ((TI) & 7) * 16384;                                             \
       const unsigned char* ntile = base + (((TI) + 1) & 7) * 16384;                                      \
       _Pragma("unroll") for (int s = 0; s < 16; s++) {                                                   \
-        ring[(s + 1) & 1] = *reinterpret_cast<const uint4*>(s + 1 < 16 ? tile + 1024 * (s + 1) : ntile); \
-        X0 = mfma32(ring[s & 1], hf[s], X0);                                                             \
+        if (!NOLDS) ring[(s + 1) & 1] = *reinterpret_cast<const uint4*>(s + 1 < 16 ? tile + 1024 * (s + 1) : ntile); \
+        X0 = mfma32(NOLDS ? hf[(s + 5) & 31] : ring[s & 1], hf[s], X0);                                                             \
         val<EPI>(s, Y0[s], st[0]);                                                                       \
         if ((s & 3) == 3) {                                                                              \
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * (s >> 2) + ((TI) & 7) * 256);     \
           _Pragma("unroll") for (int j = 0; j < 4; j++) Y0[(s & ~3) + j] = b4[j];                        \
         }                                                                                                \
         __builtin_amdgcn_sched_barrier(0);                                                               \
-        X1 = mfma32(ring[s & 1], hf[16 + s], X1);                                                        \
+        X1 = mfma32(NOLDS ? hf[(s + 21) & 31] : ring[s & 1], hf[16 + s], X1);                                                        \
         val<EPI>(s, Y1[s], st[1]);                                                                       \
         if ((s & 3) == 3) {                                                                              \
           const f32x4 b4 = *reinterpret_cast<const f32x4*>(bias + 32 * (s >> 2) + ((TI) & 7) * 256);     \
@@ -177,9 +178,9 @@ __global__ __launch_bounds__(512, 2) void k(float* out, unsigned long long* clk,
   }
 }
 
-template <int SHAPE, int EPI>
+template <int SHAPE, int EPI, int NOLDS = 0>
 static void run(float* d, unsigned long long* clk, int tiles, double seconds, int zero) {
-  auto kern = k<SHAPE, EPI>;
+  auto kern = k<SHAPE, EPI, NOLDS>;
   hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
@@ -199,8 +200,8 @@ static void run(float* d, unsigned long long* clk, int tiles, double seconds, in
   std::sort(mhz.begin(), mhz.end());
   const double flop = 256.0 * 8 * tiles * 32.0 * 32768.0;   // per CU: 8 waves x tiles x 32 MFMA-equivalents of 32,768 flop
   const double ns = ms_last * 1e6 / (2.0 * tiles * 32.0);   // two waves per SIMD
-  printf("shape %s epi %d %s: %.2f ms/launch  %.0f TFLOP/s  %.2f ns per 32k flop per SIMD  in-kernel clock %.0f MHz -> %.1f cycles\n",
-         SHAPE ? "16x16x32" : "32x32x16", EPI, zero ? "zeros " : "random", ms_last, flop / (ms_last * 1e-3) / 1e12, ns,
+  printf("shape %s epi %d%s %s: %.2f ms/launch  %.0f TFLOP/s  %.2f ns per 32k flop per SIMD  in-kernel clock %.0f MHz -> %.1f cycles\n",
+         SHAPE ? "16x16x32" : "32x32x16", EPI, NOLDS ? " (A operand from registers, no LDS reads)" : "", zero ? "zeros " : "random", ms_last, flop / (ms_last * 1e-3) / 1e12, ns,
          mhz.empty() ? 0.0 : mhz[mhz.size() / 2], mhz.empty() ? 0.0 : ns * mhz[mhz.size() / 2] * 1e-3);
   fflush(stdout);
 }
@@ -217,6 +218,9 @@ int main(int argc, char** argv) {
     run<0, 4>(d, clk, tiles, seconds, zero);
     run<1, 5>(d, clk, tiles, seconds, zero);
     run<1, 4>(d, clk, tiles, seconds, zero);
+    run<0, 5, 1>(d, clk, tiles, seconds, zero);
+    run<0, 1>(d, clk, tiles, seconds, zero);
+    run<0, 1, 1>(d, clk, tiles, seconds, zero);
   }
   return 0;
 }
