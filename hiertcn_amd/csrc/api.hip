@@ -183,6 +183,17 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
     }
   }
   ALLOC_OR_FAIL(c->metric_scratch, (size_t)8 * HIERTCN_METRIC_BLOCKS_MAX);
+  {  // barrier counters of the persistent GRU scan (gru_persist.hip): 64-bit words on lines of their own, zero once, never reset
+    int ncu = 0, dev = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) m.n_cu = ncu;
+    unsigned long long* bar = nullptr;
+    ALLOC_OR_FAIL(bar, (size_t)256);   // 8 group counters 128 bytes apart + the time-out word
+    if (hipMemset(bar, 0, 256 * sizeof(unsigned long long)) != hipSuccess) {
+      hiertcn_destroy(c);
+      return fail(HIERTCN_ERR_HIP, "hipMemset(gru_bar) failed");
+    }
+    m.gru_bar = bar;
+  }
   if (!getenv("HIERTCN_FIXED_WALK")) {   // the scoring kernel's per-XCD item-walk words live with the handle, i.e. on ITS device
     ALLOC_OR_FAIL(m.walk_pos, (size_t)8 * 32);
     if (hipMemset(m.walk_pos, 0, 8 * 32 * sizeof(int)) != hipSuccess) {

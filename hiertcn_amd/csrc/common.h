@@ -76,6 +76,8 @@ struct ModelDev {
   float* gru_bg[HIERTCN_MAX_LAYERS];
   float* gru_wc[HIERTCN_MAX_LAYERS];  // [H][in+H]
   float* gru_bc[HIERTCN_MAX_LAYERS];
+  unsigned long long* gru_bar;        // group-barrier counters + time-out word of the persistent scan (gru_persist.hip), one set per handle, only ever grow
+  int n_cu;                           // compute units of the handle's device
   float* lgru_wg[HIERTCN_MAX_LAYERS]; // low-level GRU stack of HierGRU (same layouts), low_gru only
   float* lgru_bg[HIERTCN_MAX_LAYERS];
   float* lgru_wc[HIERTCN_MAX_LAYERS];
@@ -90,6 +92,9 @@ hipError_t launch_transpose_f32(const float* src, float* dst, int64_t rows, int6
 hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t npad, float padval, hipStream_t st);
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
 size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
+int gru_persist_groups(const ModelDev& m, int B, int S, bool saving);
+hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
+                                   float* state_out, float* ws, int G, hipStream_t st);
 size_t gru_save_floats(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
                            float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st, float* save = nullptr);

@@ -1,0 +1,309 @@
+// The across-session GRU scan of small batches as ONE persistent launch (model_hier.py:91-93 -> customed_gru_cell.py:323-337).
+//
+// launch_gru_scan (pool_gru.hip) runs the scan as a chain of 2 (S + nl - 1) dependent GEMM launches; at the reference's own batch size
+// (32 lanes) each of them is a ~11 us launch for ~1 us of work and the chain is 60 % of the batch.  Here the whole scan is one kernel:
+//
+//  * lanes do not interact in the scan, so the batch is cut into GP_GROUPS = 8 lane groups and each group is scanned by its own set of
+//    P = H / 8 workgroups (group = blockIdx % 8: the blocks the dispatcher is observed to deal to one XCD -- a speed hint only, nothing
+//    below relies on it).  Workgroup t of a group OWNS hidden units [8 t, 8 t + 8) of every layer: the three weight rows of a unit (reset
+//    gate, update gate, candidate: gru_wg rows j and H + j, gru_wc row j) are read ONCE into LDS and stay there for all S slots, so a cell
+//    costs no weight traffic at all -- only the group's cell inputs ([in | h], 2 KB per lane at H = 256) are exchanged;
+//  * thread (lane b of 4, unit u of 8, k-slice ks of 8): one eighth of the k range of one lane for the three columns of one unit; the
+//    eight partial sums are folded with wavefront shuffles (xor 1, 2, 4), fixed order, fp32 throughout (the carried state is never
+//    rounded); the cell inputs are staged once per workgroup in LDS;
+//  * cells (s, l) with s + l = tau are independent (the same wavefront as launch_gru_scan); a diagonal is two phases: A = gates, r * h,
+//    and the input half of the candidate; B = the (r * h) half, tanh, blend, masked next state;
+//  * the exchange between the workgroups of a group (r * h, a layer's output, the next state: 4 bytes per lane and unit) goes through
+//    global memory as `sc1` stores and `sc1` loads around ONE agent-scope counter per group (MI355X_MICROARCH.md, inter-workgroup
+//    visibility: one lane per workgroup adds after every storing wave's vmcnt(0) and a workgroup barrier; the poll is an sc1 load; the
+//    other waves load behind a workgroup barrier) -- no L2 write-back / invalidate fences, correct wherever the workgroups run.  A
+//    barrier of the group's P workgroups sits behind each phase.  The counters only grow (64 bit): a barrier waits for the next multiple
+//    of P above the value its own add returned, so nothing is ever reset and a hipGraph replay is as good as the first launch.
+//    Every spin is bounded: a barrier that times out sets the handle's error word and the launch finishes with wrong numbers instead of
+//    hanging the device -- all 8 P <= 256 workgroups are resident by construction (one per CU).
+//    (Measured and dropped: 8-byte {value, launch tag} elements polled by the consumers instead of a barrier -- the same fabric round
+//    trips, twice the bytes: 0.319 vs 0.298 ms per 32-lane batch.)
+//
+// Results differ from the GEMM chain in summation order only (both are fp32 dot products): tests/test_gpu_gru_persist.py compares the two
+// directly and soaks the hand-off.
+#include "common.h"
+#include <cstring>
+#include <cstdlib>
+
+namespace {
+
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+constexpr int GP_THREADS = 256;
+constexpr int GP_GROUPS = 8;    // lane groups = independent scans
+constexpr int GP_U = 8;         // hidden units per workgroup
+constexpr int GP_KS = 8;        // k slices per (lane, unit)
+constexpr int GP_LB = GP_THREADS / (GP_U * GP_KS);   // 4 lanes per pass
+constexpr int GP_NLD = 4;       // staging loads in flight per thread and wait
+constexpr unsigned GP_SPIN_MAX = 1u << 21;           // ~ seconds of polling; a healthy hand-off takes microseconds
+
+struct GruPersistArgs {
+  const float* pooled; const float* mask; const float* state_in;
+  float* hist; float* rh; float* hcur; float* state_out;
+  const float* wg[HIERTCN_MAX_LAYERS]; const float* bg[HIERTCN_MAX_LAYERS];
+  const float* wc[HIERTCN_MAX_LAYERS]; const float* bc[HIERTCN_MAX_LAYERS];
+  unsigned long long* bar;   // [GP_GROUPS] counters, 128 bytes apart, then the time-out word
+  int B, S, H, HT, nl, P;
+};
+
+__device__ __forceinline__ f4 ld_sc1(const void* p) {
+  f4 v;
+  asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// every wave's stores are complete (vmcnt(0)) before the workgroup's one add; the poll and everything behind it sit behind workgroup barriers
+__device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned P, unsigned long long* err) {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned long long old = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long target = (old / P + 1ull) * P;
+    unsigned spins = 0;
+    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > GP_SPIN_MAX) {   // never in a healthy run: leave a mark and go on rather than hang the device
+        __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ float dot4(const f4 a, const f4 b, float acc) {
+  acc = fmaf(a.x, b.x, acc);
+  acc = fmaf(a.y, b.y, acc);
+  acc = fmaf(a.z, b.z, acc);
+  return fmaf(a.w, b.w, acc);
+}
+
+// LDS image of a layer's weights: row (kind, u) = 2 Q 8 chunks of 16 bytes in the order [operand half][i][ks], rows 8 chunks further apart
+// than they are long, so that the 16 lanes a ds_read_b128 serves together (u, ks mixed) fall into 16 different bank groups
+template <int Q>
+__device__ __forceinline__ int wchunk(int kind, int u, int part, int i, int ks) {
+  return (kind * GP_U + u) * (2 * Q * GP_KS + 8) + (part * Q + i) * GP_KS + ks;
+}
+
+struct SegDesc { const float* base; unsigned long long lane_floats; int dst; };   // one operand half of one cell: n lanes x H floats
+
+// Stage `n_seg` segments (H floats for each of n_lanes lanes) into LDS, 16 bytes per load, GP_NLD loads in flight per thread and wait.
+// No branch sits between a load and its wait (an index past the end is clamped and its load repeated, only the LDS write is guarded).
+__device__ __forceinline__ void stage_segments(const SegDesc* segs, int n_seg, int n_lanes, int H, int b_lo, int b_hi, float* xs, int lane_floats) {
+  const int per_seg = n_lanes * (H / 4), total = n_seg * per_seg;
+  for (int base = 0; base < total; base += GP_NLD * GP_THREADS) {
+    f4 v[GP_NLD];
+    int dst[GP_NLD];
+#pragma unroll
+    for (int it = 0; it < GP_NLD; it++) {
+      const int w = min(base + it * GP_THREADS + (int)threadIdx.x, total - 1);
+      const int k = w / per_seg, r = w - k * per_seg, pl = r / (H / 4), q = r - pl * (H / 4);
+      const SegDesc sd = segs[k];
+      const int b = min(b_lo + pl, b_hi - 1);
+      v[it] = ld_sc1(sd.base + (size_t)b * sd.lane_floats + 4 * q);
+      dst[it] = sd.dst + pl * lane_floats + 4 * q;
+    }
+    static_assert(GP_NLD == 4, "the wait below names four registers");
+    asm volatile("s_waitcnt vmcnt(0)" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3])::"memory");
+#pragma unroll
+    for (int it = 0; it < GP_NLD; it++)
+      if (base + it * GP_THREADS + (int)threadIdx.x < total) *reinterpret_cast<f4*>(xs + dst[it]) = v[it];
+  }
+}
+
+template <int Q>   // Q = float4 per thread and operand half = H / 32 (the persistent path needs E == H)
+__global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ SegDesc segs[2 * HIERTCN_MAX_LAYERS];
+  const int tid = threadIdx.x;
+  const int ks = tid & (GP_KS - 1), u = (tid >> 3) & (GP_U - 1), bl = tid >> 6;
+  const int H = a.H, HT = a.HT, nl = a.nl, B = a.B, S = a.S, K = 2 * H;
+  const int grp = (int)blockIdx.x % GP_GROUPS, t = (int)blockIdx.x / GP_GROUPS;
+  const int Bc = (B + GP_GROUPS - 1) / GP_GROUPS;
+  const int b_lo = grp * Bc, b_hi = min(B, b_lo + Bc);
+  if (b_lo >= b_hi) return;   // a group without lanes
+  unsigned long long* bar = a.bar + (size_t)grp * 16;
+  unsigned long long* err = a.bar + (size_t)GP_GROUPS * 16;
+  const int n_pass = (b_hi - b_lo + GP_LB - 1) / GP_LB, n_lanes = n_pass * GP_LB;
+  const int j = t * GP_U + u;   // this thread's hidden unit
+  constexpr int WL = 3 * GP_U * (2 * Q * GP_KS + 8);   // 16-byte chunks per layer
+  f4* wl = reinterpret_cast<f4*>(lds);
+  float* xs = reinterpret_cast<float*>(wl + (size_t)nl * WL);     // [cell of the diagonal][lane of the group][in | h][H]: the staged cell inputs
+  const int lane_floats = 2 * H, cell_floats = n_lanes * lane_floats;
+  float* keep = xs + (size_t)nl * cell_floats;                     // [cell][lane][unit] x (z, old h, candidate part): phase A -> phase B
+  for (int l = 0; l < nl; l++) {
+    for (int c = tid; c < 3 * GP_U * 2 * Q * GP_KS; c += GP_THREADS) {
+      const int row = c / (2 * Q * GP_KS), r = c - row * (2 * Q * GP_KS);
+      const int kind = row / GP_U, uu = row - kind * GP_U;
+      const int part = r / (Q * GP_KS), r2 = r - part * (Q * GP_KS), i = r2 / GP_KS, kk = r2 - i * GP_KS;
+      const int jj = t * GP_U + uu;
+      const float* src = (kind == 2) ? a.wc[l] + (size_t)jj * K : a.wg[l] + (size_t)(kind * H + jj) * K;
+      wl[(size_t)l * WL + wchunk<Q>(kind, uu, part, i, kk)] = *reinterpret_cast<const f4*>(src + part * H + kk * (H >> 3) + 4 * i);
+    }
+  }
+  // slot 0 of the history is the incoming state (the state half of the low level's projection reads it: pool_gru.hip)
+  for (int i = tid; i < (b_hi - b_lo) * GP_U * nl; i += GP_THREADS) {
+    const int b = b_lo + i / (GP_U * nl), r = i % (GP_U * nl), l = r / GP_U, uu = r % GP_U;
+    a.hist[(size_t)b * (S + 1) * HT + (size_t)l * H + t * GP_U + uu] = a.state_in[(size_t)b * HT + (size_t)l * H + t * GP_U + uu];
+  }
+  __syncthreads();
+
+  for (int tau = 0; tau < S + nl - 1; tau++) {
+    int l_first = 0, n_cells = 0;                  // the cells of this diagonal: layers l_first .. l_first + n_cells - 1, slot = tau - layer
+    for (int l = nl - 1; l >= 0; l--)
+      if (tau - l >= 0 && tau - l < S) { l_first = l; n_cells++; }
+    // ---------------- phase A: gates, r * h, input half of the candidate
+    __syncthreads();
+    if (tid < 2 * n_cells) {
+      const int ci = tid >> 1, part = tid & 1, l = l_first + ci, s = tau - l;
+      SegDesc sd;
+      if (part == 0) {
+        if (l == 0) { sd.base = a.pooled + (size_t)s * H; sd.lane_floats = (unsigned long long)S * H; }
+        else { sd.base = a.hcur + ((size_t)(s & 1) * nl + (l - 1)) * B * H; sd.lane_floats = (unsigned long long)H; }
+      } else {
+        if (s == 0) { sd.base = a.state_in + (size_t)l * H; sd.lane_floats = (unsigned long long)HT; }
+        else { sd.base = a.hist + (size_t)s * HT + (size_t)l * H; sd.lane_floats = (unsigned long long)(S + 1) * HT; }
+      }
+      sd.dst = ci * cell_floats + part * H;
+      segs[tid] = sd;
+    }
+    __syncthreads();
+    stage_segments(segs, 2 * n_cells, n_lanes, H, b_lo, b_hi, xs, lane_floats);
+    __syncthreads();
+    for (int ci = 0; ci < n_cells; ci++) {
+      const int l = l_first + ci;
+      const f4* w = wl + (size_t)l * WL;
+      for (int ps = 0; ps < n_pass; ps++) {
+        const f4* xp = reinterpret_cast<const f4*>(xs + (size_t)ci * cell_floats + (size_t)(ps * GP_LB + bl) * lane_floats);
+        float ar = 0.f, au = 0.f, ac = 0.f;
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+          const f4 xv = xp[ks * Q + i];
+          ar = dot4(xv, w[wchunk<Q>(0, u, 0, i, ks)], ar);
+          au = dot4(xv, w[wchunk<Q>(1, u, 0, i, ks)], au);
+          ac = dot4(xv, w[wchunk<Q>(2, u, 0, i, ks)], ac);
+        }
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+          const f4 hv = xp[(H / 4) + ks * Q + i];
+          ar = dot4(hv, w[wchunk<Q>(0, u, 1, i, ks)], ar);
+          au = dot4(hv, w[wchunk<Q>(1, u, 1, i, ks)], au);
+        }
+#pragma unroll
+        for (int d = 1; d < GP_KS; d <<= 1) {
+          ar += __shfl_xor(ar, d);
+          au += __shfl_xor(au, d);
+          ac += __shfl_xor(ac, d);
+        }
+        const int b = b_lo + ps * GP_LB + bl;
+        if (ks == 0 && b < b_hi) {
+          const float hj = reinterpret_cast<const float*>(xp)[H + j];
+          const float r = 1.0f / (1.0f + expf(-(ar + a.bg[l][j])));        // customed_gru_cell.py:323-324: r is the first half
+          const float z = 1.0f / (1.0f + expf(-(au + a.bg[l][H + j])));
+          st_sc1(a.rh + ((size_t)l * B + b) * H + j, r * hj);              // :326
+          float* kp = keep + (((size_t)ci * n_lanes + ps * GP_LB + bl) * GP_U + u) * 3;
+          kp[0] = z; kp[1] = hj; kp[2] = ac;
+        }
+      }
+    }
+    group_barrier(bar, (unsigned)a.P, err);   // (its closing workgroup barrier also frees the staging buffer and the descriptors)
+    // ---------------- phase B: (r * h) half of the candidate, tanh, blend, masked next state
+    if (tid < n_cells) {
+      SegDesc sd;
+      sd.base = a.rh + (size_t)(l_first + tid) * B * H; sd.lane_floats = (unsigned long long)H;
+      sd.dst = tid * cell_floats;
+      segs[tid] = sd;
+    }
+    __syncthreads();
+    stage_segments(segs, n_cells, n_lanes, H, b_lo, b_hi, xs, lane_floats);
+    __syncthreads();
+    for (int ci = 0; ci < n_cells; ci++) {
+      const int l = l_first + ci, s = tau - l;
+      const f4* w = wl + (size_t)l * WL;
+      for (int ps = 0; ps < n_pass; ps++) {
+        const f4* xp = reinterpret_cast<const f4*>(xs + (size_t)ci * cell_floats + (size_t)(ps * GP_LB + bl) * lane_floats);
+        float ac = 0.f;
+#pragma unroll
+        for (int i = 0; i < Q; i++) ac = dot4(xp[ks * Q + i], w[wchunk<Q>(2, u, 1, i, ks)], ac);
+#pragma unroll
+        for (int d = 1; d < GP_KS; d <<= 1) ac += __shfl_xor(ac, d);
+        const int b = b_lo + ps * GP_LB + bl;
+        if (ks == 0 && b < b_hi) {
+          const float mk = a.mask[(size_t)b * S + s];
+          const float* kp = keep + (((size_t)ci * n_lanes + ps * GP_LB + bl) * GP_U + u) * 3;
+          const float z = kp[0], hj = kp[1];
+          const float c = tanhf(kp[2] + ac + a.bc[l][j]);                       // :333-335
+          const float hn = z * hj + (1.0f - z) * c;                             // :336
+          if (l + 1 < nl) st_sc1(a.hcur + (((size_t)(s & 1) * nl + l) * B + b) * H + j, hn);   // the next layer's input (not masked)
+          st_sc1(a.hist + ((size_t)b * (S + 1) + s + 1) * HT + (size_t)l * H + j, hn * mk);     // model_hier.py:93
+          if (s == S - 1) a.state_out[(size_t)b * HT + (size_t)l * H + j] = hn * mk;
+        }
+      }
+    }
+    if (tau + 1 < S + nl - 1) group_barrier(bar, (unsigned)a.P, err);
+  }
+}
+
+template <int Q>
+hipError_t launch_q(const GruPersistArgs& a, size_t lds_bytes, hipStream_t st) {
+  auto kern = k_gru_scan_persist<Q>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(GP_GROUPS * a.P)), dim3(GP_THREADS), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+size_t persist_lds_bytes(int H, int nl, int B) {
+  const int Q = H >> 5;
+  const int Bc = (B + GP_GROUPS - 1) / GP_GROUPS, n_pass = (Bc + GP_LB - 1) / GP_LB;
+  // weights + the staged inputs of a whole diagonal (every layer x every lane of the group) + the cross-phase scratch
+  return (size_t)nl * 3 * GP_U * (2 * Q * GP_KS + 8) * 16 + (size_t)nl * n_pass * GP_LB * 2 * H * 4 + (size_t)nl * n_pass * GP_LB * GP_U * 3 * 4;
+}
+
+}  // namespace
+
+// shapes the persistent launch handles (no environment switch looked at: the workspace is sized by this)
+bool gru_persist_shape_ok(const ModelDev& m, int B, int S) {
+  if (!m.gru_bar || m.n_cu <= 0 || B <= 0 || S <= 0 || B > 96) return false;   // measured cross-over with the GEMM chain: ~100 lanes
+  if (m.E != m.H || (m.H != 64 && m.H != 128 && m.H != 256)) return false;      // (E != H, H = 512 or odd widths: the GEMM chain)
+  if (GP_GROUPS * (m.H / GP_U) > m.n_cu) return false;                           // every workgroup resident, one per CU
+  return persist_lds_bytes(m.H, m.nl, B) <= 150 * 1024;
+}
+
+// 0 = not applicable (the caller runs the GEMM chain), else the number of workgroups per lane group
+int gru_persist_groups(const ModelDev& m, int B, int S, bool saving) {
+  const char* off = getenv("HIERTCN_GRU_CHAIN");   // "1": always the GEMM chain (A/B runs, tests; read on every call)
+  if (off && off[0] == '1') return 0;
+  if (saving || !gru_persist_shape_ok(m, B, S)) return 0;
+  const char* ml = getenv("HIERTCN_GRU_PERSIST_MAX_LANES");
+  if (ml && B > atoi(ml)) return 0;
+  return m.H / GP_U;
+}
+
+hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
+                                   float* state_out, float* ws, int P, hipStream_t st) {
+  const int H = m.H, HT = m.HT;
+  GruPersistArgs a;
+  memset(&a, 0, sizeof(a));
+  a.pooled = pooled; a.mask = mask; a.state_in = state_in; a.state_out = state_out;
+  a.hist = ws;                                                   // the workspace layout of launch_gru_scan
+  float* gates0 = a.hist + (size_t)B * (S + 1) * HT;
+  a.rh = gates0 + (size_t)m.nl * B * 2 * H;
+  a.hcur = a.rh + (size_t)m.nl * B * H;
+  for (int l = 0; l < m.nl; l++) { a.wg[l] = m.gru_wg[l]; a.bg[l] = m.gru_bg[l]; a.wc[l] = m.gru_wc[l]; a.bc[l] = m.gru_bc[l]; }
+  a.bar = m.gru_bar;
+  a.B = B; a.S = S; a.H = H; a.HT = HT; a.nl = m.nl; a.P = P;
+  const size_t lds_bytes = persist_lds_bytes(H, m.nl, B);
+  switch (H >> 5) {
+    case 2: return launch_q<2>(a, lds_bytes, st);
+    case 4: return launch_q<4>(a, lds_bytes, st);
+    case 8: return launch_q<8>(a, lds_bytes, st);
+    default: return hipErrorInvalidValue;
+  }
+}

@@ -284,8 +284,12 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
                                                      // launch in which cell (s, l+1) still reads the output of (s, l)
   const size_t cell = (size_t)B * 5 * H;             // one (slot, layer) record of `save`
   const int64_t hs = (int64_t)(S + 1) * HT;          // row stride of the history
-  hipError_t e = copy_rows(state_in, HT, hist, hs, B, HT, st);
-  if (e != hipSuccess) return e;
+  hipError_t e;
+  // small batches: the whole scan as one persistent launch (gru_persist.hip); it also fills slot 0 of the history and state_out
+  const int persist_groups = gru_persist_groups(m, B, S, save != nullptr);
+  if (persist_groups > 0) {
+    if ((e = launch_gru_scan_persist(m, pooled, mask, state_in, B, S, state_out, ws, persist_groups, st)) != hipSuccess) return e;
+  } else if ((e = copy_rows(state_in, HT, hist, hs, B, HT, st)) != hipSuccess) return e;
   // Wavefront over (slot, layer): cell (s, l) needs (s, l-1) and (s-1, l) only, so the cells with s + l = tau are independent -- layer 1
   // of slot s runs beside layer 0 of slot s + 1.  The critical path is S + nl - 1 cells instead of S * nl, and the independent cells of
   // a step go out as ONE grouped launch per GEMM kind when they have one shape (layers >= 1 all do; layer 0 too when E == H): 2 (S + 1)
@@ -318,7 +322,7 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
     gc.gates = gates; gc.ldg = 2 * H;
     gc.mask = mask + s; gc.ldm = S;
   };
-  for (int tau = 0; tau < S + m.nl - 1; tau++) {
+  for (int tau = 0; tau < S + m.nl - 1 && persist_groups == 0; tau++) {
     GemmArgs gg[HIERTCN_MAX_LAYERS], gc[HIERTCN_MAX_LAYERS];
     int n = 0;
     for (int l = 0; l < m.nl; l++) {
@@ -348,7 +352,7 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
     g.Wt = m.projS; g.bias = nullptr; g.out = sproj; g.ldo = E; g.rowmap_S = S;
     if ((e = launch_gemm<EPI_STORE>(g, st)) != hipSuccess) return e;
   }
-  if ((e = copy_rows(hist + (size_t)S * HT, hs, state_out, HT, B, HT, st)) != hipSuccess) return e;
+  if (persist_groups == 0 && (e = copy_rows(hist + (size_t)S * HT, hs, state_out, HT, B, HT, st)) != hipSuccess) return e;
   if (state_before) {
     for (int s = 0; s < S; s++)
       if ((e = copy_rows(hist + (size_t)s * HT, hs, state_before + (size_t)s * HT, (int64_t)S * HT, B, HT, st)) != hipSuccess) return e;
