@@ -167,6 +167,8 @@ def dvfs_probe(eng, rows, n_items, dim, seconds=1.5):
     import subprocess
     import threading
 
+    import torch
+
     def sampler(stop, out):
         while not stop.is_set():
             try:
