@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -38,13 +38,16 @@ class Weights(C.Structure):
 
 class GmmConfig(C.Structure):
     _fields_ = [("item_num", C.c_int32), ("output_dim", C.c_int32), ("num_mixture", C.c_int32), ("kernel_size", C.c_int32),
-                ("n_blocks", C.c_int32), ("channels", C.c_int32 * MAX_BLOCKS), ("sigma", C.c_float)]
+                ("n_blocks", C.c_int32), ("channels", C.c_int32 * MAX_BLOCKS), ("sigma", C.c_float),
+                ("trunk", C.c_int32), ("hidden_dim", C.c_int32), ("num_layer", C.c_int32)]
 
 
 class GmmWeights(C.Structure):
     _fields_ = [("conv_kernel", C.c_void_p * MAX_BLOCKS), ("conv_bias", C.c_void_p * MAX_BLOCKS),
                 ("res_kernel", C.c_void_p * MAX_BLOCKS), ("res_bias", C.c_void_p * MAX_BLOCKS),
-                ("head_weights", C.c_void_p), ("head_biases", C.c_void_p)]
+                ("head_weights", C.c_void_p), ("head_biases", C.c_void_p),
+                ("gru_gate_kernel", C.c_void_p * MAX_LAYERS), ("gru_gate_bias", C.c_void_p * MAX_LAYERS),
+                ("gru_cand_kernel", C.c_void_p * MAX_LAYERS), ("gru_cand_bias", C.c_void_p * MAX_LAYERS)]
 
 
 class ScoreOut(C.Structure):
@@ -98,6 +101,7 @@ SYMBOLS = {
     "hiertcn_gmm_destroy": (C.c_int, [C.c_void_p]),
     "hiertcn_gmm_set_weights": (C.c_int, [C.c_void_p, C.POINTER(GmmWeights), C.c_void_p]),
     "hiertcn_gmm_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
+    "hiertcn_gmm_forward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "hiertcn_gmm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hiertcn_gmm_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),

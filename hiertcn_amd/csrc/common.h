@@ -135,6 +135,16 @@ struct LowGruBufs {
 size_t low_gru_save_floats(const ModelDev& m, int64_t n_sess, int L);
 hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden,
                                const LowGruBufs& b, hipStream_t st);
+// GRU stack on one-hot input (model_gru_gmm's trunk): layer 0's input half as gathered rows of in_g [N][2H] / in_c [N][H]; wg[0] [2H][H] and
+// wc[0] [H][H] hold the state half only (output-major), layers >= 1 the full [2H][2H] / [H][2H]
+struct OneHotGru {
+  int N, H, nl;
+  const float* in_g; const float* in_c;
+  const float* wg[HIERTCN_MAX_LAYERS]; const float* bg[HIERTCN_MAX_LAYERS];
+  const float* wc[HIERTCN_MAX_LAYERS]; const float* bc[HIERTCN_MAX_LAYERS];
+};
+size_t onehot_gru_workspace_bytes(int H, int nl, int64_t n_sess);
+hipError_t launch_onehot_gru(const OneHotGru& w, const int32_t* x, int64_t n_sess, int L, uint16_t* hidden, void* workspace, hipStream_t st);
 hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
                           hipStream_t st);
 size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);

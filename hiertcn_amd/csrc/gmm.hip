@@ -53,6 +53,14 @@ struct hiertcn_gmm_ctx {
   float* mu_bias;                        // [M][DP], pad entries ZERO (a pad output must add 0 to |mu|^2)
   float* pi_w;                           // [M][Clast] fp32
   float* pi_b;                           // [M]
+  // trunk 1 (model_gru_gmm): GRU stack on one-hot rows
+  int trunk, H, nl;
+  float* gin_g;                          // [N][2H]: input half of layer 0's gate kernel (a one-hot row times it = its row)
+  float* gin_c;                          // [N][H]:  input half of layer 0's candidate kernel
+  float* gwg[HIERTCN_MAX_LAYERS];        // output-major: layer 0 [2H][H] (state half), layers >= 1 [2H][2H]
+  float* gbg[HIERTCN_MAX_LAYERS];
+  float* gwc[HIERTCN_MAX_LAYERS];        // layer 0 [H][H], layers >= 1 [H][2H]
+  float* gbc[HIERTCN_MAX_LAYERS];
 };
 
 template <typename T>
@@ -150,14 +158,21 @@ extern "C" {
 int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cfg) {
   if (!out || !cfg) return gfail(HIERTCN_ERR_INVALID, "null argument");
   if (cfg->item_num < 2 || cfg->output_dim < 2) return gfail(HIERTCN_ERR_INVALID, "item_num / output_dim must be >= 2");
-  if (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS) return gfail(HIERTCN_ERR_INVALID, "n_blocks out of range");
-  if (cfg->kernel_size < 1 || cfg->kernel_size > 8) return gfail(HIERTCN_ERR_INVALID, "kernel_size out of range");
+  const bool gru = cfg->trunk == 1;
+  if (cfg->trunk != 0 && cfg->trunk != 1) return gfail(HIERTCN_ERR_INVALID, "trunk %d: 0 (TemporalConvNet) or 1 (GRU stack)", cfg->trunk);
+  if (gru) {
+    const int H = cfg->hidden_dim;
+    if (!(H == 64 || H == 128 || H == 256 || H == 512)) return gfail(HIERTCN_ERR_INVALID, "hidden_dim %d: the head kernel is built for 64, 128, 256, 512", H);
+    if (cfg->num_layer < 1 || cfg->num_layer > HIERTCN_MAX_LAYERS) return gfail(HIERTCN_ERR_INVALID, "num_layer out of range");
+  }
+  if (!gru && (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS)) return gfail(HIERTCN_ERR_INVALID, "n_blocks out of range");
+  if (!gru && (cfg->kernel_size < 1 || cfg->kernel_size > 8)) return gfail(HIERTCN_ERR_INVALID, "kernel_size out of range");
   if (cfg->num_mixture < 1 || cfg->num_mixture > 16) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: 1..16", cfg->num_mixture);
   if (!(cfg->sigma > 0.f)) return gfail(HIERTCN_ERR_INVALID, "sigma must be > 0 (a learned sigma, args.sigma None, is not built)");
-  for (int i = 0; i < cfg->n_blocks; i++)
+  for (int i = 0; i < cfg->n_blocks && !gru; i++)
     if (cfg->channels[i] < 32 || (cfg->channels[i] & 31) || cfg->channels[i] > 1024)
       return gfail(HIERTCN_ERR_INVALID, "tcn_channel[%d]=%d: widths are multiples of 32 up to 1024", i, cfg->channels[i]);
-  const int cl = cfg->channels[cfg->n_blocks - 1];
+  const int cl = gru ? cfg->hidden_dim : cfg->channels[cfg->n_blocks - 1];
   if (!(cl == 64 || cl == 128 || cl == 256 || cl == 512)) return gfail(HIERTCN_ERR_INVALID, "last tcn_channel %d: the head kernel is built for 64, 128, 256, 512", cl);
   hiertcn_gmm_ctx* c = new hiertcn_gmm_ctx();
   memset(static_cast<void*>(&c->cfg), 0, sizeof(c->cfg));
@@ -166,8 +181,11 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
   if (hipGetDevice(&c->device) != hipSuccess) { delete c; return gfail(HIERTCN_ERR_HIP, "hipGetDevice failed (no GPU?)"); }
   c->N = cfg->item_num; c->NP = (c->N + 63) & ~63;
   c->D = cfg->output_dim; c->DP = (c->D + 63) & ~63;
-  c->M = cfg->num_mixture; c->K = cfg->kernel_size; c->nb = cfg->n_blocks;
-  c->C0 = cfg->channels[0]; c->Clast = cl;
+  c->M = cfg->num_mixture; c->K = cfg->kernel_size; c->nb = gru ? 0 : cfg->n_blocks;
+  c->C0 = gru ? 0 : cfg->channels[0]; c->Clast = cl;
+  c->trunk = cfg->trunk; c->H = gru ? cfg->hidden_dim : 0; c->nl = gru ? cfg->num_layer : 0;
+  c->gather = nullptr; c->b0 = c->br0 = nullptr; c->gin_g = c->gin_c = nullptr;
+  memset(c->gwg, 0, sizeof(c->gwg)); memset(c->gbg, 0, sizeof(c->gbg)); memset(c->gwc, 0, sizeof(c->gwc)); memset(c->gbc, 0, sizeof(c->gbc));
   memset(c->convT, 0, sizeof(c->convT)); memset(c->conv_bias, 0, sizeof(c->conv_bias));
   memset(c->resT, 0, sizeof(c->resT)); memset(c->res_bias, 0, sizeof(c->res_bias));
 #define GA(ptr, count)                                                                              \
@@ -175,9 +193,20 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
     hipError_t e_ = galloc(c, &(ptr), (size_t)(count));                                             \
     if (e_ != hipSuccess) { hiertcn_gmm_destroy(c); return gfail(HIERTCN_ERR_HIP, "hipMalloc(%s) failed: %s", #ptr, hipGetErrorString(e_)); } \
   } while (0)
-  GA(c->gather, (size_t)(c->K + 1) * c->N * c->C0);
-  GA(c->b0, c->C0);
-  GA(c->br0, c->C0);
+  if (gru) {
+    const size_t H = (size_t)c->H;
+    GA(c->gin_g, (size_t)c->N * 2 * H);
+    GA(c->gin_c, (size_t)c->N * H);
+    for (int l = 0; l < c->nl; l++) {
+      const size_t kin = (l == 0) ? H : 2 * H;   // layer 0 keeps the state half only
+      GA(c->gwg[l], 2 * H * kin); GA(c->gbg[l], 2 * H);
+      GA(c->gwc[l], H * kin);     GA(c->gbc[l], H);
+    }
+  } else {
+    GA(c->gather, (size_t)(c->K + 1) * c->N * c->C0);
+    GA(c->b0, c->C0);
+    GA(c->br0, c->C0);
+  }
   for (int i = 1, cin = c->C0; i < c->nb; cin = cfg->channels[i], i++) {
     GA(c->convT[i], (size_t)c->K * cin * cfg->channels[i]);
     GA(c->conv_bias[i], cfg->channels[i]);
@@ -220,9 +249,29 @@ __global__ void k_gmm_head_tables(const float* __restrict__ W, int64_t n_out, in
 int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream) {
   if (!g || !w) return gfail(HIERTCN_ERR_INVALID, "null argument");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
-  if (!w->conv_kernel[0] || !w->conv_bias[0] || !w->res_kernel[0] || !w->res_bias[0] || !w->head_weights || !w->head_biases)
-    return gfail(HIERTCN_ERR_INVALID, "block 0 (conv1 + Dense residual: Cin = item_num != Cout) and the head are required");
+  if (!w->head_weights || !w->head_biases) return gfail(HIERTCN_ERR_INVALID, "the head (fully_connected weights / biases) is required");
   const int N = g->N, C0 = g->C0, K = g->K, M = g->M, D = g->D, DP = g->DP, CL = g->Clast;
+  if (g->trunk == 1) {
+    const size_t H = (size_t)g->H;
+    for (int l = 0; l < g->nl; l++) {
+      if (!w->gru_gate_kernel[l] || !w->gru_gate_bias[l] || !w->gru_cand_kernel[l] || !w->gru_cand_bias[l])
+        return gfail(HIERTCN_ERR_INVALID, "GRU layer %d: gate / candidate kernel and bias are required", l);
+      const size_t in = (l == 0) ? (size_t)N : H;
+      if (l == 0) {   // rows [0, N) of [N + H][.]: the input half, already item-major; rows [N, N + H): the state half -> output-major
+        G_HIP(hipMemcpyAsync(g->gin_g, w->gru_gate_kernel[0], (size_t)N * 2 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+        G_HIP(hipMemcpyAsync(g->gin_c, w->gru_cand_kernel[0], (size_t)N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+        G_HIP(launch_transpose_f32(w->gru_gate_kernel[0] + in * 2 * H, g->gwg[0], (int64_t)H, (int64_t)(2 * H), st));
+        G_HIP(launch_transpose_f32(w->gru_cand_kernel[0] + in * H, g->gwc[0], (int64_t)H, (int64_t)H, st));
+      } else {
+        G_HIP(launch_transpose_f32(w->gru_gate_kernel[l], g->gwg[l], (int64_t)(2 * H), (int64_t)(2 * H), st));
+        G_HIP(launch_transpose_f32(w->gru_cand_kernel[l], g->gwc[l], (int64_t)(2 * H), (int64_t)H, st));
+      }
+      G_HIP(hipMemcpyAsync(g->gbg[l], w->gru_gate_bias[l], 2 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
+      G_HIP(hipMemcpyAsync(g->gbc[l], w->gru_cand_bias[l], H * sizeof(float), hipMemcpyDeviceToDevice, st));
+    }
+  } else {
+  if (!w->conv_kernel[0] || !w->conv_bias[0] || !w->res_kernel[0] || !w->res_bias[0])
+    return gfail(HIERTCN_ERR_INVALID, "block 0 (conv1 + Dense residual: Cin = item_num != Cout) is required");
   // block 0: the K taps [N][C0] and the residual kernel [N][C0] are already item-major in the reference layout: rows -> bf16
   for (int j = 0; j < K; j++) G_HIP(launch_rows_to_bf16(w->conv_kernel[0] + (size_t)j * N * C0, g->gather + (size_t)j * N * C0, N, C0, 0, st));
   G_HIP(launch_rows_to_bf16(w->res_kernel[0], g->gather + (size_t)K * N * C0, N, C0, 0, st));
@@ -239,6 +288,7 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
       G_HIP(launch_transpose_to_bf16(w->res_kernel[i], g->resT[i], cin, cout, cout, st));
       G_HIP(launch_copy_pad_f32(w->res_bias[i], g->res_bias[i], cout, cout, 0.f, st));
     }
+  }
   }
   // head [C][M (1 + D)]: columns [0, M) -> prior kernel [M][C] fp32; columns M + m D + n -> table m, row n (bf16, item-major)
   const int64_t n_out = (int64_t)M * (1 + D);
@@ -269,7 +319,7 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
 }
 
 static int max_w(const hiertcn_gmm_ctx* g) {
-  int w = 0;
+  int w = g->trunk == 1 ? g->H : 0;
   for (int i = 0; i < g->nb; i++) w = g->cfg.channels[i] > w ? g->cfg.channels[i] : w;
   return w;
 }
@@ -281,6 +331,13 @@ size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R) {
   return 2 * act + 2 * g->M * per + ((((size_t)R * g->M * sizeof(float)) + 255) & ~(size_t)255);
 }
 
+size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T) {
+  if (!g || B < 0 || T < 0) return 0;
+  const size_t base = hiertcn_gmm_workspace_bytes(g, B * T);
+  const size_t trunk = g->trunk == 1 ? onehot_gru_workspace_bytes(g->H, g->nl, B) : 0;
+  return base > trunk ? base : trunk;
+}
+
 #define G_READY(g)                                                                       \
   if (!(g)) return gfail(HIERTCN_ERR_INVALID, "null handle");                            \
   if (!(g)->weights_set) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_set_weights has not been called")
@@ -290,8 +347,16 @@ int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B,
   G_READY(g);
   if (!x_ids || !hidden || B < 1 || T < 1 || T > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
   const int64_t R = B * T;
-  if (!workspace || workspace_bytes < hiertcn_gmm_workspace_bytes(g, R)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
+  if (!workspace || workspace_bytes < hiertcn_gmm_forward_workspace_bytes(g, B, T)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (g->trunk == 1) {   // model_gru_gmm.py:33-48: MultiRNNCell of GRUCells under dynamic_rnn on the one-hot rows, from a zero state
+    OneHotGru og;
+    memset(&og, 0, sizeof(og));
+    og.N = g->N; og.H = g->H; og.nl = g->nl; og.in_g = g->gin_g; og.in_c = g->gin_c;
+    for (int l = 0; l < g->nl; l++) { og.wg[l] = g->gwg[l]; og.bg[l] = g->gbg[l]; og.wc[l] = g->gwc[l]; og.bc[l] = g->gbc[l]; }
+    G_HIP(launch_onehot_gru(og, x_ids, B, T, hidden, workspace, st));
+    return HIERTCN_OK;
+  }
   const size_t act = (((size_t)R * max_w(g) * 2) + 255) & ~(size_t)255;
   uint16_t* buf[2] = {reinterpret_cast<uint16_t*>(workspace), reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(workspace) + act)};
   uint16_t* out0 = (g->nb == 1) ? hidden : buf[0];

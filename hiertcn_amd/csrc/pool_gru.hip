@@ -102,6 +102,8 @@ struct GemmArgs {
   uint16_t* hid_out; int64_t ldho;     // CAND, optional: the layer's output as a 16-bit row (scoring operand), zero when inactive
   int H;
   int rowmap_S;                        // STORE: >0 -> row m = b*(S+1)+s maps to out row b*S+s, s == S skipped
+  const float* add_tab; int add_ld; int add_n;   // optional: + add_tab[id][n] for id = add_ids[m * add_ids_ld] in (0, add_n) -- the product of a
+  const int32_t* add_ids; int add_ids_ld;        //   one-hot input row with the input half of the kernel is a row gather (model_gru_gmm on XING)
 };
 
 typedef float f32x16v __attribute__((ext_vector_type(16)));
@@ -186,6 +188,13 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
     float v[4];
 #pragma unroll
     for (int j = 0; j < 4; j++) v[j] = acc[4 * q + j] + (g.bias ? g.bias[n0 + j] : 0.f);
+    if (g.add_tab) {
+      const int id = g.add_ids[(int64_t)m * g.add_ids_ld];
+      if (id > 0 && id < g.add_n) {
+        const float4 a4 = *reinterpret_cast<const float4*>(g.add_tab + (int64_t)id * g.add_ld + n0);
+        v[0] += a4.x; v[1] += a4.y; v[2] += a4.z; v[3] += a4.w;
+      }
+    }
     if (EPI == EPI_STORE) {
       int64_t orow = m;
       if (g.rowmap_S > 0) {
@@ -469,4 +478,76 @@ hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* spro
   b.rec = reinterpret_cast<float*>(take((size_t)m.nl * n_sess * 5 * m.H * 4));
   b.keep_all = 0;
   return launch_low_gru_bufs(m, x, sproj, n_sess, L, hidden, b, st);
+}
+
+
+// ---------------------------------------------------------------------------------------------
+// GRU stack on ONE-HOT input rows (model_gru_gmm.py:33-48 on XING, where x = one_hot(id) * sign(id), model.py:56-61; no 'emb' projection
+// in that model): layer 0's input half of [x, h] . W is the row W[id] -- gathered in the GEMM epilogue (GemmArgs::add_tab) -- so the
+// GEMMs of layer 0 run over the state half only; dynamic_rnn's sequence_length (model_gru_gmm.py:57-67: the COUNT of non-zero input rows =
+// of ids > 0, used as a prefix length) as in launch_low_gru_bufs.  hidden: the top layer's outputs [session * L + t][H], storage type.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_count_ids(const int32_t* __restrict__ x, int64_t n_sess, int L, int N, int32_t* __restrict__ seq_len) {
+  const int64_t s = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (s >= n_sess) return;
+  int c = 0;
+  for (int t = 0; t < L; t++) {
+    const int id = x[s * L + t];
+    c += (id > 0 && id < N) ? 1 : 0;
+  }
+  seq_len[s] = c;
+}
+
+size_t onehot_gru_workspace_bytes(int H, int nl, int64_t n_sess) {
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  return al((size_t)n_sess * 4) + al((size_t)2 * n_sess * H * nl * 4) + al((size_t)nl * n_sess * 5 * H * 4);
+}
+
+hipError_t launch_onehot_gru(const OneHotGru& w, const int32_t* x, int64_t n_sess, int L, uint16_t* hidden, void* workspace, hipStream_t st) {
+  if (n_sess <= 0) return hipSuccess;
+  const int H = w.H, HT = w.H * w.nl;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  unsigned char* p = reinterpret_cast<unsigned char*>(workspace);
+  int32_t* seq_len = reinterpret_cast<int32_t*>(p); p += al((size_t)n_sess * 4);
+  float* states = reinterpret_cast<float*>(p);      p += al((size_t)2 * n_sess * HT * 4);
+  float* recs = reinterpret_cast<float*>(p);
+  const size_t cell = (size_t)n_sess * 5 * H;   // gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
+  hipError_t e;
+  hipLaunchKernelGGL(k_count_ids, dim3((unsigned)((n_sess + 255) / 256)), dim3(256), 0, st, x, n_sess, L, w.N, seq_len);
+  if ((e = hipGetLastError()) != hipSuccess) return e;
+  if ((e = hipMemsetAsync(states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state
+  for (int t = 0; t < L; t++) {
+    const float* s_old = states + (size_t)(t & 1) * n_sess * HT;
+    float* s_new = states + (size_t)((t + 1) & 1) * n_sess * HT;
+    for (int l = 0; l < w.nl; l++) {
+      float* rec = recs + (size_t)l * cell;
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      const float* hold = s_old + (size_t)l * H;
+      float* gates = rec;
+      float* rh = rec + (size_t)n_sess * 2 * H;
+      g.M = (int)n_sess; g.H = H;
+      if (l == 0) {
+        g.A1 = nullptr; g.lda1 = 0; g.K1 = 0;
+        g.add_tab = w.in_g; g.add_ld = 2 * H; g.add_n = w.N; g.add_ids = x + t; g.add_ids_ld = L;
+      } else {
+        g.A1 = recs + (size_t)(l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H;
+      }
+      g.A2 = hold; g.lda2 = HT; g.K2 = H;
+      g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
+      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
+      g.A2 = rh; g.lda2 = H;
+      g.Wt = w.wc[l]; g.bias = w.bc[l]; g.N = H;
+      if (l == 0) { g.add_tab = w.in_c; g.add_ld = H; }
+      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
+      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
+      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
+      g.gates = gates; g.ldg = 2 * H;
+      g.seq_len = seq_len; g.tstep = t;
+      if (l == w.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
+      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
 }

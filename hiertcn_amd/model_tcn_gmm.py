@@ -8,7 +8,7 @@ projection in this model -- so block 0 is a row gather).  `pred` stands for the 
 materialising it (5 x the item catalogue per step): GmmHead keeps the last TCN activations and scores them on demand.
 The decode of `pred` into (pi, mu, sigma) is NOT in the reference (calc_loss_gmm has no caller); the one used here is documented
 in oracle/gmm_oracle.py and include/hiertcn.h ("parity unpinned" for the decode).  model_gru_gmm (model_gru_gmm.py:11) shares the
-head; its GRU trunk on one-hot input is not built.
+head: hiertcn_amd/model_gru_gmm.py.
 """
 from __future__ import annotations
 
@@ -113,7 +113,10 @@ class TcnGmmModel:
         """ids int32 [B, T] -> last TCN activations [B*T, C] (storage type)."""
         B, T = ids.shape
         hidden = torch.empty((B * T, self.C), dtype=torch.bfloat16, device=self.device)
-        ws = self._workspace(B * T)
+        need = int(self.lib.hiertcn_gmm_forward_workspace_bytes(self._h, B, T))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws
         _ck(self.lib.hiertcn_gmm_forward(self._h, C.c_void_p(ids.data_ptr()), B, T, C.c_void_p(hidden.data_ptr()), C.c_void_p(ws.data_ptr()),
                                          ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
         return hidden

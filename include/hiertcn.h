@@ -43,7 +43,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 5
+#define HIERTCN_ABI_VERSION 6
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -255,7 +255,9 @@ int hiertcn_export_weights(hiertcn_handle_t h, const hiertcn_weights_t* dst, int
  *   hiertcn_gmm_set_weights  fp32 device tensors in the reference layouts: conv_kernel[i] [K][Cin][Cout] (Cin = item_num for i = 0),
  *                            conv_bias[i], res_kernel[i] [Cin][Cout] / res_bias[i] where Cin != Cout (always for i = 0),
  *                            head_weights [C_last][M(1+D)], head_biases [M(1+D)]  (<scope>/fully_connected/{weights,biases}).
- *   hiertcn_gmm_forward      x_ids [B][T] -> hidden [B*T][C_last] (storage type), model_tcn_gmm.py:27-36.
+ *   hiertcn_gmm_forward      x_ids [B][T] -> hidden [B*T][C_last] (storage type), model_tcn_gmm.py:27-36; trunk 1: the GRU stack of
+ *                            model_gru_gmm.py:33-48 on one-hot rows -- layer 0's input half is a row gather, sequence_length = the count
+ *                            of ids > 0 (model_gru_gmm.py:57-67), C_last = hidden_dim.
  *   hiertcn_gmm_loss         hidden [R][C_last], y_ids [R] -> loss [R] (mode 0: loss.py:248 gmm_prob, 1: loss.py:249-257
  *                            gmm_prob_max; 0 where y == 0, as model.py:111 masks it).  Neither the [R][M*D] means nor the one-hot
  *                            targets are materialised: sum_d (y_d - mu_d)^2 = |mu_m|^2 - 2 mu_m[y] + 1.  Optional outputs (NULL =
@@ -270,6 +272,10 @@ typedef struct {
   int32_t n_blocks;
   int32_t channels[HIERTCN_MAX_BLOCKS];
   float sigma;                           /* args.sigma (> 0)                                        */
+  int32_t trunk;                         /* 0: TemporalConvNet (model_tcn_gmm.py:27-36); 1: GRU stack run by dynamic_rnn on the one-hot
+                                          *    input (model_gru_gmm.py:33-48) -- n_blocks / channels / kernel_size are then ignored      */
+  int32_t hidden_dim;                    /* trunk 1: args.hidden_dim in {64, 128, 256, 512}         */
+  int32_t num_layer;                     /* trunk 1: args.num_layer                                 */
 } hiertcn_gmm_config_t;
 typedef struct {
   const float* conv_kernel[HIERTCN_MAX_BLOCKS];
@@ -278,12 +284,20 @@ typedef struct {
   const float* res_bias[HIERTCN_MAX_BLOCKS];
   const float* head_weights;
   const float* head_biases;
+  /* trunk 1 (rnn.GRUCell layouts, customed_gru_cell.py:309-337): gate kernel [in + H][2H] with in = item_num for layer 0 and H above,
+   * gate bias [2H], candidate kernel [in + H][H], candidate bias [H]  (<scope>/rnn/multi_rnn_cell/cell_l/gru_cell/{gates,candidate}/...) */
+  const float* gru_gate_kernel[HIERTCN_MAX_LAYERS];
+  const float* gru_gate_bias[HIERTCN_MAX_LAYERS];
+  const float* gru_cand_kernel[HIERTCN_MAX_LAYERS];
+  const float* gru_cand_bias[HIERTCN_MAX_LAYERS];
 } hiertcn_gmm_weights_t;
 const char* hiertcn_gmm_last_error(void);
 int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cfg);
 int hiertcn_gmm_destroy(hiertcn_gmm_handle_t g);
 int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream);
 size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R);
+/* workspace of hiertcn_gmm_forward for B sequences of T steps (>= hiertcn_gmm_workspace_bytes(g, B*T): one buffer serves both calls) */
+size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T);
 int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                         size_t workspace_bytes, void* stream);
 int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32_t* y_ids, int64_t R, int32_t mode, float* loss,

@@ -5,7 +5,7 @@ Restates, in NumPy fp64:
     input directly (on XING that input is one_hot(id) * sign(id), model.py:56-61, so block 0 has Cin = item_num and a Dense
     down-sample residual, customized_tcn_cell.py:102-106) -- then tf.contrib.layers.fully_connected(n_out, activation_fn=None)
     with n_out = M * (1 + D), D = args.output_dim, when args.sigma is set (model_tcn_gmm.py:39-44; model_gru_gmm.py:49-54 has
-    the same head on a GRU trunk);
+    the same head on a GRU trunk: gru_gmm_hidden / model_gru_gmm at the end of this file);
   * the two GMM likelihood losses of calc_loss_gmm that need no negative samples (loss.py:247-257):
         gmm_prob      loss = -log(exp(gmm.log_prob(y) / D))
         gmm_prob_max  loss = -log(max_m  pi_m * exp(mvn_m.log_prob(y) / D))
@@ -161,3 +161,51 @@ def masked_mean_loss(loss_bt, y_ids):
     act = mask.sum(1)
     users = np.sign(act).sum()
     return float((((loss_bt * mask).sum(1)) / (act + 1e-6)).sum() / users)
+
+
+# ---- model_gru_gmm (model_gru_gmm.py:11-54): the same head on a GRU trunk that reads the one-hot rows directly (no 'emb' projection) ----
+
+def init_params_gru(args, seed=2, scope="rnn_gmm"):
+    """Variables of model_gru_gmm [TF-sem names]: <scope>/rnn/multi_rnn_cell/cell_l/gru_cell/{gates,candidate}/{kernel,bias} with
+    in_0 = item_num (the one-hot width) and in_l = H above; gate bias init 1.0 (customed_gru_cell.py:314); then the fully_connected head."""
+    rng = np.random.default_rng(seed)
+    N, H = int(args.item_num), int(args.hidden_dim)
+    p = {}
+    for l in range(int(args.num_layer)):
+        pre = f"{scope}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+        inp = N if l == 0 else H
+        p[f"{pre}/gates/kernel"] = O._glorot(rng, (inp + H, 2 * H), inp + H, 2 * H)
+        p[f"{pre}/gates/bias"] = np.ones(2 * H, np.float32)
+        p[f"{pre}/candidate/kernel"] = O._glorot(rng, (inp + H, H), inp + H, H)
+        p[f"{pre}/candidate/bias"] = np.zeros(H, np.float32)
+    no = n_out(args)
+    p[f"{scope}/fully_connected/weights"] = O._glorot(rng, (H, no), H, no)
+    p[f"{scope}/fully_connected/biases"] = np.zeros(no, np.float32)
+    return p
+
+
+def gru_gmm_hidden(args, ids, params, scope="rnn_gmm", num: O.Numerics = O.EXACT64):
+    """model_gru_gmm.py:33-48 on x = one_hot(id) * sign(id) (model.py:56-61), LITERALLY: the one-hot rows are built and multiplied.
+    MultiRNNCell of GRUCells under dynamic_rnn from a zero state with sequence_length = length(x) (:57-67) -- the count of non-zero
+    rows, used as a prefix length; past it the state is carried through and the output is zero [TF-sem].  ids [B, T] -> [B, T, H]."""
+    ids = np.asarray(ids).astype(np.int64)
+    N, H, nl = int(args.item_num), int(args.hidden_dim), int(args.num_layer)
+    B, T = ids.shape
+    x = np.zeros((B, T, N))
+    bb, tt = np.nonzero(ids > 0)
+    x[bb, tt, ids[bb, tt]] = 1.0
+    length = O.seq_length(x)
+    state = np.zeros((B, H * nl))
+    outs = np.zeros((B, T, H))
+    for t in range(T):
+        active = (t < length)[:, None]
+        cur, new_state = O.multi_rnn_cell(x[:, t], state, params, H, nl, scope=f"{scope}/rnn")
+        state = np.where(active, new_state, state)
+        outs[:, t] = np.where(active, cur, 0.0)
+    return num.act(outs)
+
+
+def model_gru_gmm(args, ids, params, scope="rnn_gmm", num: O.Numerics = O.EXACT64, return_hidden=False):
+    h = gru_gmm_hidden(args, ids, params, scope, num)
+    pred = gmm_head(h, params, scope)
+    return (pred, h) if return_hidden else pred

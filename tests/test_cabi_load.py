@@ -34,7 +34,7 @@ def test_header_and_binding_agree(lib):
 
 
 def test_abi_version(lib):
-    assert lib.hiertcn_abi_version() == 5
+    assert lib.hiertcn_abi_version() == 6
 
 
 def test_create_rejects_bad_config_without_touching_the_gpu(lib):

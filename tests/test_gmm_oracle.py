@@ -78,3 +78,26 @@ def test_known_answers():
     assert abs(G.calc_loss_gmm_ids(pred2, ids, a)[0, 0] - want2) < 1e-10
     # masked mean (model.py:111-117)
     assert abs(G.masked_mean_loss(np.array([[2.0, 4.0], [9.0, 9.0]]), np.array([[3, 0], [0, 0]])) - 2.0 / (1 + 1e-6)) < 1e-9
+
+
+def test_gru_gmm_oracle_shapes_and_dynamic_rnn_prefix():
+    """model_gru_gmm.py:33-54 restated: parameter shapes, the count-as-prefix sequence_length, zero rows past it, a known answer with
+    zero kernels (gate bias 1: h' = sigmoid(1) h + (1 - sigmoid(1)) tanh(0) = 0 from a zero state -> all-zero outputs, head = biases)."""
+    a = make_args([], model_type="gru_gmm", item_num=23, output_dim=23, num_mixture=2, sigma=0.1, hidden_dim=8, num_layer=2, adjust=False)
+    p = G.init_params_gru(a, seed=1)
+    assert p["rnn_gmm/rnn/multi_rnn_cell/cell_0/gru_cell/gates/kernel"].shape == (23 + 8, 16)
+    assert p["rnn_gmm/rnn/multi_rnn_cell/cell_1/gru_cell/candidate/kernel"].shape == (16, 8)
+    assert p["rnn_gmm/fully_connected/weights"].shape == (8, 2 * 24) and (p["rnn_gmm/rnn/multi_rnn_cell/cell_0/gru_cell/gates/bias"] == 1).all()
+    ids = np.array([[0, 5, 0, 7, 9, 0], [3, 4, 5, 6, 7, 8]])
+    for k in p:
+        if k.endswith("/kernel"):
+            p[k] = p[k] * 8.0
+    h = G.gru_gmm_hidden(a, ids, p)
+    assert h.shape == (2, 6, 8)
+    assert not h[0, 3:].any() and h[0, 1].any()          # three non-null ids -> steps 0..2 run, step 3 (a real id!) and later are zero
+    assert h[1].any(-1).all()
+    # step 0 of row 0 reads the null id from a zero state: x = 0, h = 0 -> c = tanh(bc) = 0, h' = 0
+    assert not h[0, 0].any()
+    z = {k: (np.zeros_like(v) if k.endswith("/kernel") else v) for k, v in p.items()}
+    pred, hz = G.model_gru_gmm(a, ids, z, return_hidden=True)
+    assert not hz.any() and np.allclose(pred, z["rnn_gmm/fully_connected/biases"])
