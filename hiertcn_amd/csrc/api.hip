@@ -446,24 +446,17 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, hidden, ws + w.tcn, st));
   // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): zero the outputs, list the rows that do
   // carry a target and score only those (a ragged XING batch is mostly padding: slot width = longest session of the slot).
-  int32_t* row_map = nullptr;
-  int32_t* n_valid = nullptr;
-  {
-    row_map = reinterpret_cast<int32_t*>(ws + w.map);
-    n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
-    HIP_TRY(launch_compact_rows(y_ids, R, row_map, n_valid, reinterpret_cast<int32_t*>(ws + w.cscratch), st));
-    HIP_TRY(hipMemsetAsync(so.rank, 0, (size_t)R * sizeof(int32_t), st));
-    HIP_TRY(hipMemsetAsync(so.ce, 0, (size_t)R * sizeof(float), st));
-    if (so.target) HIP_TRY(hipMemsetAsync(so.target, 0, (size_t)R * sizeof(float), st));
-    // a masked row is an all-zero logit row (model.py:105): its ranked list is 0..k-1 with values 0 (loss.py:120 on ties)
-    if (so.topk > 0) HIP_TRY(launch_topk_fill(so.topk_idx, so.topk_val, R, so.topk, st));
-  }
+  int32_t* row_map = reinterpret_cast<int32_t*>(ws + w.map);
+  int32_t* n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
   float* split = nullptr;
   if (so.topk == 0 && score_split_parts(R, h->m.NP) > 1) {
     split = reinterpret_cast<float*>(ws + w.split);
     if (!so.target) so.target = reinterpret_cast<float*>(ws + w.tgt);   // the merge needs the target logit
-    HIP_TRY(hipMemsetAsync(so.target, 0, (size_t)R * sizeof(float), st));
   }
+  // (the same pass zeroes rank / ce / target of every row: one launch instead of the list's three plus three memsets at XING batch sizes)
+  HIP_TRY(launch_compact_rows(y_ids, R, row_map, n_valid, reinterpret_cast<int32_t*>(ws + w.cscratch), st, so.rank, so.ce, so.target));
+  // a masked row is an all-zero logit row (model.py:105): its ranked list is 0..k-1 with values 0 (loss.py:120 on ties)
+  if (so.topk > 0) HIP_TRY(launch_topk_fill(so.topk_idx, so.topk_val, R, so.topk, st));
   int rc = score_timed(h, hidden, y_ids, R, &so, st, row_map, n_valid, split);
   if (rc != HIERTCN_OK) return rc;
   if (metrics8) {
@@ -630,6 +623,18 @@ int hiertcn_timing_read(hiertcn_handle_t h, double* score_ms_avg, int64_t* launc
   if (score_ms_avg) *score_ms_avg = h->ev_used ? total / (double)h->ev_used : 0.0;
   if (launches) *launches = (int64_t)h->ev_used;
   if (reset) h->ev_used = 0;
+  return HIERTCN_OK;
+}
+
+int hiertcn_persistent_health(hiertcn_handle_t h, int32_t* timed_out) {
+  if (!h || !timed_out) return fail(HIERTCN_ERR_INVALID, "null argument");
+  ON_DEVICE(h);
+  *timed_out = 0;
+  if (!h->m.gru_bar) return HIERTCN_OK;
+  unsigned long long w = 0;
+  HIP_TRY(hipDeviceSynchronize());
+  HIP_TRY(hipMemcpy(&w, h->m.gru_bar + 8 * 16, sizeof(w), hipMemcpyDeviceToHost));   // the word behind the 8 group counters (gru_persist.hip)
+  *timed_out = w ? 1 : 0;
   return HIERTCN_OK;
 }
 

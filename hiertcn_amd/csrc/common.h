@@ -185,7 +185,8 @@ hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const i
 // small batches: number of catalogue parts the production kernel splits into (1 = none); scratch = parts * 2 * R floats
 int score_split_parts(int64_t R, int NP);
 // ascending list of the rows with y > 0 (device-side, 3 small kernels): map [R], n_valid [1], scratch [(R+1023)/1024 + 1] ints
-hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_t* n_valid, int32_t* scratch, hipStream_t st);
+hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_t* n_valid, int32_t* scratch, hipStream_t st, int32_t* z0 = nullptr,
+                               float* z1 = nullptr, float* z2 = nullptr);
 hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse, const float* w,
                                    int stg_begin, int stg_end, uint16_t* gout, hipStream_t st);
 hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,

@@ -70,8 +70,59 @@ __global__ __launch_bounds__(256) void k_metrics_final(const double* __restrict_
 
 // `partial` scratch lives behind out8: the caller passes a buffer of 8 * (1 + ceil(B/256)) doubles
 // through the handle's metric scratch (see api.hip).
+// Small batches (the reference's 32 lanes): ONE workgroup of 16 waves does both steps -- wave w takes lanes w, w + 16, ... in order and
+// adds their quotients up in fp64, the sixteen partial rows are combined in a fixed order.  Same arithmetic per lane as k_lane_metrics.
+__global__ __launch_bounds__(1024) void k_metrics_small(const int32_t* __restrict__ rank, const float* __restrict__ ce, const int32_t* __restrict__ y,
+                                                        int B, int T, int N, double* __restrict__ out8) {
+  __shared__ double red[16][8];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  const float invN = 1.0f / (float)N;
+  for (int b = wave; b < B; b += 16) {
+    float loss = 0.f, r1 = 0.f, r5 = 0.f, r10 = 0.f, rr = 0.f, rf = 0.f;
+    int act = 0;
+    const int64_t base = (int64_t)b * T;
+    for (int t = lane; t < T; t += 64) {
+      if (y[base + t] > 0) {
+        const float rk = (float)rank[base + t];
+        act++;
+        loss += ce[base + t];
+        r1 += (rk <= 0.f) ? 1.f : 0.f;
+        r5 += (rk <= 4.f) ? 1.f : 0.f;
+        r10 += (rk <= 9.f) ? 1.f : 0.f;
+        rr += 1.0f / (1.0f + rk);
+        rf += rk * invN;
+      }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+      loss += __shfl_down(loss, off); r1 += __shfl_down(r1, off); r5 += __shfl_down(r5, off); r10 += __shfl_down(r10, off);
+      rr += __shfl_down(rr, off); rf += __shfl_down(rf, off); act += __shfl_down(act, off);
+    }
+    if (lane == 0 && act > 0) {
+      const float den = (float)act + 1e-6f;  // model.py:114 (fp32 in the reference graph)
+      acc[0] += loss / den; acc[1] += r1 / den; acc[2] += r5 / den; acc[3] += r10 / den; acc[4] += rr / den; acc[5] += rf / den;
+      acc[6] += 1.0;
+      acc[7] += (double)act;
+    }
+  }
+  if (lane == 0) {
+#pragma unroll
+    for (int k = 0; k < 8; k++) red[wave][k] = acc[k];
+  }
+  __syncthreads();
+  if (threadIdx.x < 8) {
+    double s_ = 0.0;
+    for (int w = 0; w < 16; w++) s_ += red[w][threadIdx.x];
+    out8[threadIdx.x] = s_;
+  }
+}
+
 hipError_t launch_metrics_scratch(const ModelDev& m, const int32_t* rank, const float* ce, const int32_t* y, int B, int T,
                                   double* out8, double* scratch, hipStream_t st) {
+  if (B <= 32) {   // (measured: at 128 lanes the two-launch form is faster again)
+    hipLaunchKernelGGL(k_metrics_small, dim3(1), dim3(1024), 0, st, rank, ce, y, B, T, m.N, out8);
+    return hipGetLastError();
+  }
   const int nblocks = (B + MT_THREADS / 64 - 1) / (MT_THREADS / 64);   // 4 lanes per workgroup
   hipLaunchKernelGGL(k_lane_metrics, dim3(nblocks), dim3(MT_THREADS), 0, st, rank, ce, y, B, T, m.N, scratch);
   hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(256), 0, st, scratch, nblocks, out8);
@@ -120,12 +171,20 @@ __global__ __launch_bounds__(1024) void k_scan_counts(int32_t* __restrict__ coun
   if (threadIdx.x == 1023) n_valid[0] = part[1023];
 }
 __global__ __launch_bounds__(256) void k_write_map(const int32_t* __restrict__ y, int64_t R, const int32_t* __restrict__ offsets,
-                                                  int32_t* __restrict__ map) {
+                                                  int32_t* __restrict__ map, int32_t* __restrict__ z0, float* __restrict__ z1, float* __restrict__ z2) {
   __shared__ int wsum[4];
   const int64_t r0 = (int64_t)blockIdx.x * CP_ROWS + threadIdx.x * 4;
   int f[4], c = 0;
 #pragma unroll
   for (int j = 0; j < 4; j++) { f[j] = (r0 + j < R && y[r0 + j] > 0) ? 1 : 0; c += f[j]; }
+#pragma unroll
+  for (int j = 0; j < 4; j++) {   // per-row outputs of the scoring launch start from zero: the rows it skips (y == 0) must read 0 (model.py:105)
+    if (r0 + j < R) {
+      if (z0) z0[r0 + j] = 0;
+      if (z1) z1[r0 + j] = 0.f;
+      if (z2) z2[r0 + j] = 0.f;
+    }
+  }
   // exclusive scan of c over the 256 threads: inside each wave by shuffles, then across the 4 waves
   int incl = c;
   const int lane = threadIdx.x & 63;
@@ -143,11 +202,49 @@ __global__ __launch_bounds__(256) void k_write_map(const int32_t* __restrict__ y
     if (f[j]) map[pos++] = (int32_t)(r0 + j);
 }
 
-hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_t* n_valid, int32_t* scratch, hipStream_t st) {
+// up to 8,192 rows (a 32-lane XING batch has 6,400): count, scan and write in ONE workgroup, 1024 rows at a time (thread t takes row
+// chunk * 1024 + t: coalesced; positions from a wave ballot + the sixteen wave totals + the running base)
+__global__ __launch_bounds__(1024) void k_compact_small(const int32_t* __restrict__ y, int R, int32_t* __restrict__ map, int32_t* __restrict__ n_valid,
+                                                        int32_t* __restrict__ z0, float* __restrict__ z1, float* __restrict__ z2) {
+  __shared__ int wtot[16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int base = 0;
+  for (int r0 = 0; r0 < R; r0 += 1024) {
+    const int r = r0 + threadIdx.x;
+    const bool f = r < R && y[r] > 0;
+    if (r < R) {
+      if (z0) z0[r] = 0;
+      if (z1) z1[r] = 0.f;
+      if (z2) z2[r] = 0.f;
+    }
+    const unsigned long long bal = __ballot(f);
+    const int before = __popcll(bal & ((1ull << lane) - 1ull));
+    if (lane == 0) wtot[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base, tot = 0;
+    for (int w = 0; w < 16; w++) {
+      const int c = wtot[w];
+      off += (w < wave) ? c : 0;
+      tot += c;
+    }
+    if (f) map[off + before] = r;
+    base += tot;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) n_valid[0] = base;
+}
+
+// z0 / z1 / z2 (optional): per-row int32 / fp32 / fp32 arrays of R entries that the same pass sets to zero (the scoring outputs)
+hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_t* n_valid, int32_t* scratch, hipStream_t st, int32_t* z0, float* z1,
+                               float* z2) {
+  if (R <= 8192) {
+    hipLaunchKernelGGL(k_compact_small, dim3(1), dim3(1024), 0, st, y, (int)R, map, n_valid, z0, z1, z2);
+    return hipGetLastError();
+  }
   const int nblk = (int)((R + CP_ROWS - 1) / CP_ROWS);
   hipLaunchKernelGGL(k_valid_counts, dim3(nblk), dim3(256), 0, st, y, R, scratch);
   hipLaunchKernelGGL(k_scan_counts, dim3(1), dim3(1024), 0, st, scratch, nblk, n_valid);
-  hipLaunchKernelGGL(k_write_map, dim3(nblk), dim3(256), 0, st, y, R, scratch, map);
+  hipLaunchKernelGGL(k_write_map, dim3(nblk), dim3(256), 0, st, y, R, scratch, map, z0, z1, z2);
   return hipGetLastError();
 }
 

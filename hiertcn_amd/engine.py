@@ -496,6 +496,12 @@ class Engine:
     def timing_enable(self, on: bool = True):
         self._ck(self.lib.hiertcn_timing_enable(self._h, 1 if on else 0))
 
+    def persistent_timed_out(self) -> bool:
+        """True if a bounded wait inside a persistent launch of this handle ever ran out (include/hiertcn.h); synchronises."""
+        f = C.c_int32(0)
+        self._ck(self.lib.hiertcn_persistent_health(self._h, C.byref(f)))
+        return bool(f.value)
+
     def timing_read(self, reset: bool = True):
         ms = C.c_double(0.0)
         n = C.c_int64(0)

@@ -310,6 +310,11 @@ int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64
 int hiertcn_timing_enable(hiertcn_handle_t h, int32_t on);
 int hiertcn_timing_read(hiertcn_handle_t h, double* score_ms_avg, int64_t* launches, int32_t reset);
 
+/* Health word of the handle's persistent launches (the across-session GRU scan of small batches, csrc/gru_persist.hip): every wait of
+ * one workgroup for another is bounded, and a wait that ran out sets this word instead of hanging the device -- the results of that
+ * launch are then wrong.  *timed_out = 1 if that ever happened on this handle (0 in a healthy run).  Synchronises the device. */
+int hiertcn_persistent_health(hiertcn_handle_t h, int32_t* timed_out);
+
 #ifdef __cplusplus
 }
 #endif

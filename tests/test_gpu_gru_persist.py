@@ -91,4 +91,5 @@ def test_persistent_scan_soak_and_graph_replay():
                 assert np.array_equal(g.cpu().numpy(), f), f"launch {it}: result differs from the first launch of its shape"
     finally:
         os.environ.pop("HIERTCN_GRU_CHAIN", None)
+    assert not eng.persistent_timed_out()   # no bounded wait ever ran out
     eng.close()
