@@ -1,4 +1,4 @@
-# Every number quoted in DESIGN.md / README.md, one command each (run on an MI355X box from the repo root; ~6 minutes).
+# Every number quoted in DESIGN.md / README.md, one command each (run on an MI355X box from the repo root; ~8 minutes).
 set -u
 python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" | tail -1
 echo "== headline (bench.py defaults: 4096 users/step, cfg-3 shape)"; python3 bench.py 2>/dev/null | tail -1 | python3 -c "
@@ -9,8 +9,13 @@ print(f\"{b['value']:.0f} sessions/s, {b['ms_per_step']:.1f} ms/step; scoring {r
 echo "== ragged sessions (lengths ~ U{1..30})"; python3 bench.py --ragged --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json; b = json.loads(sys.stdin.read()); print(f\"{b['value']:.0f} sessions/s\")"
 echo "== reference batching (32 lanes x 10 x <=20, XING catalogue)"; python3 scripts/cfg2_bench.py 2>&1 | tail -2
+echo "== across-session GRU scan: chain of GEMM launches vs the persistent launch"; bash scripts/gru_ab.sh 2>&1 | grep -v "^$"
 echo "== scoring kernel alone, d = 256 / 128 / 64 (2,457,600 rows x 300,000 items)"
 for d in 256 128 64; do D=$d python3 scripts/score_diag.py 2457600 300000 2>&1 | tail -1 | sed "s/^/d=$d: /"; done
+echo "== the clock the chip holds: same kernel on random / zero / relu operands (rocm-smi sclk, socket power)"; python3 scripts/power_probe.py 2457600 300000 4 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== the scoring main loop without its staging, both MFMA shapes x both epilogues (scripts/shape_bench.hip)"
+[ -x scripts/build/shape_bench ] || { mkdir -p scripts/build; hipcc --offload-arch=gfx950 -O3 -fno-honor-nans -Wno-unused-result scripts/shape_bench.hip -o scripts/build/shape_bench 2>/dev/null; }
+scripts/build/shape_bench 2.0 2>&1 | grep -v "epi 0 " | grep "random"
 echo "== d = 512, N = 1,000,000 (bf16, then the IEEE-half build)"
 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
 DTYPE=fp16 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
