@@ -218,6 +218,7 @@ def main():
     ap.add_argument("--ragged", action="store_true", help="session lengths ~ U{1..30} instead of full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel training leg (the `train` object of the JSON line)")
+    ap.add_argument("--no-clock-probe", action="store_true", help="skip roofline.clock_probe (extra launches of the scoring kernel on random / zero operands; profiling runs skip it so that the kernel's average duration in the trace is the timed region's)")
     ap.add_argument("--train-users-per-step", type=int, default=1024, help="users per training step PER GPU")
     ap.add_argument("--train-steps", type=int, default=4)
     ap.add_argument("--train-warmup", type=int, default=2)
@@ -337,7 +338,7 @@ def main():
             gemm_ref = {"error": str(e)[:200]}
 
     dvfs = None
-    if rank == 0 and world == 1 and not a.ragged:
+    if rank == 0 and world == 1 and not a.ragged and not a.no_clock_probe:
         try:
             dvfs = dvfs_probe(eng, rows_per_launch, N_ITEMS, DIM)
         except Exception as e:  # noqa: BLE001  (a diagnostic, never fatal)

@@ -5,7 +5,7 @@ TAG=${1:-r1}
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT  # every rocprofv3 call below sits under `timeout`: a failed counter request once hung for the whole gpurun limit
 OUT=gpurun_out/prof_$TAG
 mkdir -p $OUT
-B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-clock-probe"
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $B > $OUT/bench_trace.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_fetch -- $B > $OUT/pmc_fetch.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
