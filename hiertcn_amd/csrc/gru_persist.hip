@@ -40,7 +40,7 @@ constexpr int GP_U = 8;         // hidden units per workgroup
 constexpr int GP_KS = 8;        // k slices per (lane, unit)
 constexpr int GP_LB = GP_THREADS / (GP_U * GP_KS);   // 4 lanes per pass
 constexpr int GP_NLD = 4;       // staging loads in flight per thread and wait
-constexpr unsigned GP_SPIN_MAX = 1u << 21;           // ~ seconds of polling; a healthy hand-off takes microseconds
+constexpr unsigned GP_SPIN_MAX = 1u << 19;           // ~ a second of polling; a healthy hand-off takes microseconds
 
 struct GruPersistArgs {
   const float* pooled; const float* mask; const float* state_in;
@@ -58,19 +58,21 @@ __device__ __forceinline__ f4 ld_sc1(const void* p) {
 }
 __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 
-// every wave's stores are complete (vmcnt(0)) before the workgroup's one add; the poll and everything behind it sit behind workgroup barriers
-__device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned P, unsigned long long* err) {
+// every wave's stores are complete (vmcnt(0)) before the workgroup's one add; the poll and everything behind it sit behind workgroup barriers.
+// `dead` (LDS): once a wait of this workgroup has run out, its later barriers add and go on without waiting -- a launch that cannot
+// complete correctly ends in about a second instead of twenty-two time-outs.
+__device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned P, unsigned long long* err, int* dead) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned long long old = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = (old / P + 1ull) * P;
     unsigned spins = 0;
-    while (__hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    while (!*dead && __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > GP_SPIN_MAX) {   // never in a healthy run: leave a mark and go on rather than hang the device
         __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
+        *dead = 1;
       }
     }
   }
@@ -121,6 +123,7 @@ template <int Q>   // Q = float4 per thread and operand half = H / 32 (the persi
 __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersistArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ SegDesc segs[2 * HIERTCN_MAX_LAYERS];
+  __shared__ int s_dead;
   const int tid = threadIdx.x;
   const int ks = tid & (GP_KS - 1), u = (tid >> 3) & (GP_U - 1), bl = tid >> 6;
   const int H = a.H, HT = a.HT, nl = a.nl, B = a.B, S = a.S, K = 2 * H;
@@ -130,6 +133,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
   if (b_lo >= b_hi) return;   // a group without lanes
   unsigned long long* bar = a.bar + (size_t)grp * 16;
   unsigned long long* err = a.bar + (size_t)GP_GROUPS * 16;
+  if (tid == 0) s_dead = 0;
   const int n_pass = (b_hi - b_lo + GP_LB - 1) / GP_LB, n_lanes = n_pass * GP_LB;
   const int j = t * GP_U + u;   // this thread's hidden unit
   constexpr int WL = 3 * GP_U * (2 * Q * GP_KS + 8);   // 16-byte chunks per layer
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
         }
       }
     }
-    group_barrier(bar, (unsigned)a.P, err);   // (its closing workgroup barrier also frees the staging buffer and the descriptors)
+    group_barrier(bar, (unsigned)a.P, err, &s_dead);   // (its closing workgroup barrier also frees the staging buffer and the descriptors)
     // ---------------- phase B: (r * h) half of the candidate, tanh, blend, masked next state
     if (tid < n_cells) {
       SegDesc sd;
@@ -246,7 +250,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
         }
       }
     }
-    if (tau + 1 < S + nl - 1) group_barrier(bar, (unsigned)a.P, err);
+    if (tau + 1 < S + nl - 1) group_barrier(bar, (unsigned)a.P, err, &s_dead);
   }
 }
 
@@ -255,7 +259,7 @@ hipError_t launch_q(const GruPersistArgs& a, size_t lds_bytes, hipStream_t st) {
   auto kern = k_gru_scan_persist<Q>;
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(kern, dim3((unsigned)(GP_GROUPS * a.P)), dim3(GP_THREADS), lds_bytes, st, a);
+  hipLaunchKernelGGL(kern, dim3((unsigned)(GP_GROUPS * (a.H / GP_U))), dim3(GP_THREADS), lds_bytes, st, a);
   return hipGetLastError();
 }
 
@@ -299,6 +303,7 @@ hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const
   for (int l = 0; l < m.nl; l++) { a.wg[l] = m.gru_wg[l]; a.bg[l] = m.gru_bg[l]; a.wc[l] = m.gru_wc[l]; a.bc[l] = m.gru_bc[l]; }
   a.bar = m.gru_bar;
   a.B = B; a.S = S; a.H = H; a.HT = HT; a.nl = m.nl; a.P = P;
+  if (getenv("HIERTCN_GRU_TEST_MISSING_WG")) a.P = P + 1;   // test hook: every barrier waits for a workgroup that does not exist -> the bounded waits run out
   const size_t lds_bytes = persist_lds_bytes(H, m.nl, B);
   switch (H >> 5) {
     case 2: return launch_q<2>(a, lds_bytes, st);

@@ -93,3 +93,28 @@ def test_persistent_scan_soak_and_graph_replay():
         os.environ.pop("HIERTCN_GRU_CHAIN", None)
     assert not eng.persistent_timed_out()   # no bounded wait ever ran out
     eng.close()
+
+
+def test_a_wait_that_cannot_be_met_times_out_instead_of_hanging():
+    """Every wait inside the persistent launch is bounded: with a workgroup missing (test hook: the barriers expect one more arrival than
+    there are workgroups) the launch ends within seconds, the handle's health word is set, and nothing hangs."""
+    import time
+    d, nl = 128, 1
+    args = hier_tcn_args(item_num=300, emb_dim=d, hidden_dim=d, tcn_channel=[d, d], num_layer=nl)
+    eng = Engine(args)
+    eng.set_weights(init_params(args, 5))
+    data = _inputs(np.random.default_rng(2), 8, 3, d, d * nl)
+    assert not eng.persistent_timed_out()
+    os.environ["HIERTCN_GRU_TEST_MISSING_WG"] = "1"
+    os.environ["HIERTCN_GRU_CHAIN"] = "0"
+    try:
+        t0 = time.time()
+        eng.gru_scan(*data)
+        torch.cuda.synchronize()
+        took = time.time() - t0
+    finally:
+        os.environ.pop("HIERTCN_GRU_TEST_MISSING_WG", None)
+        os.environ.pop("HIERTCN_GRU_CHAIN", None)
+    assert eng.persistent_timed_out()
+    assert took < 30.0, took
+    eng.close()
