@@ -49,7 +49,10 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
   return row * (2 * C) + ((chunk ^ (row & TcnGeom<C>::SWZ)) << 4);
 }
 
-template <int C>
+// DEEP: all of a tap's weight fragments in flight at once (156 VGPRs at C = 256: one workgroup per CU) -- for grids that do not fill the
+// chip anyway (the reference's 32-lane batches: 80 workgroups), where the kernel is bound by the L2 round trips of its weight loads;
+// otherwise four fragments at a time and two workgroups per CU (cfg-3: 3.1 ms per 81,920 sessions against 5.3 ms with DEEP)
+template <int C, bool DEEP = false>
 __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const int32_t* __restrict__ x,
                                                            const float* __restrict__ sproj, int64_t n_sessions, int L,
                                                            uint16_t* __restrict__ hidden) {
@@ -112,14 +115,29 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
     for (int j = 0; j < taps; j++) {
       const int shift = is_proj ? 0 : (p.K - 1 - j) * dil;  // o[t] += x[t - (K-1-j)*dil] . W[j]
       const uint16_t* Wj = W + (int64_t)j * C * C + (int64_t)arow * C + 8 * lh;
-#pragma unroll 4
-      for (int s = 0; s < G::KS; s++) {
-        const uint4 a = *reinterpret_cast<const uint4*>(Wj + 16 * s);
+      if constexpr (DEEP) {
+        uint4 af[G::KS];
 #pragma unroll
-        for (int r = 0; r < G::RPW; r++) {
-          const int row = (g0 + r) * ROWS + p.pad + lr - shift;
-          const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));
-          acc[r] = mfma32(a, b, acc[r]);
+        for (int s = 0; s < G::KS; s++) af[s] = *reinterpret_cast<const uint4*>(Wj + 16 * s);
+#pragma unroll
+        for (int s = 0; s < G::KS; s++) {
+#pragma unroll
+          for (int r = 0; r < G::RPW; r++) {
+            const int row = (g0 + r) * ROWS + p.pad + lr - shift;
+            const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));
+            acc[r] = mfma32(af[s], b, acc[r]);
+          }
+        }
+      } else {
+#pragma unroll 4
+        for (int s = 0; s < G::KS; s++) {
+          const uint4 a = *reinterpret_cast<const uint4*>(Wj + 16 * s);
+#pragma unroll
+          for (int r = 0; r < G::RPW; r++) {
+            const int row = (g0 + r) * ROWS + p.pad + lr - shift;
+            const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));
+            acc[r] = mfma32(a, b, acc[r]);
+          }
         }
       }
     }
@@ -193,10 +211,16 @@ template <int C>
 static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
                                uint16_t* hidden, hipStream_t st) {
   size_t lds = (size_t)TCN_G * (p.pad + 32) * 2 * C;
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-  if (e != hipSuccess) return e;
   unsigned blocks = (unsigned)((n_sessions + TCN_G - 1) / TCN_G);
-  hipLaunchKernelGGL(k_tcn_fused<C>, dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
+  if (blocks <= 384 && !p.save_emb) {   // fewer workgroups than one and a half per CU: latency of the weight loads, not occupancy, is the limit
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL((k_tcn_fused<C, true>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
+    return hipGetLastError();
+  }
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((k_tcn_fused<C, false>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
   return hipGetLastError();
 }
 
