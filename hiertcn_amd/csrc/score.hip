@@ -196,6 +196,26 @@ __device__ __forceinline__ void top_tile(TopList<KT>& L, const f32x16& v, int it
   }
 }
 
+// the slow half of top_tile alone (the caller has already voted that some lane of the wave has a candidate in this tile)
+template <int KT>
+__device__ __forceinline__ void top_tile_slow(TopList<KT>& L, const f32x16& v, int item0) {
+#pragma unroll
+  for (int r = 0; r < 16; r++) {
+    bool take = v[r] > L.v[KT - 1];
+    if (__any(take)) {
+      if (__any(take && L.pc == 2)) {   // a lane with a full buffer needs a third slot: everybody flushes (rare)
+        top_flush<KT>(L);
+        take = v[r] > L.v[KT - 1];      // the threshold may have risen
+      }
+      const int idx = item0 + 8 * (r >> 2) + (r & 3);
+      const bool t0 = take && L.pc == 0, t1 = take && L.pc == 1;
+      L.pv0 = t0 ? v[r] : L.pv0; L.pi0 = t0 ? idx : L.pi0;
+      L.pv1 = t1 ? v[r] : L.pv1; L.pi1 = t1 ? idx : L.pi1;
+      L.pc += take ? 1 : 0;
+    }
+  }
+}
+
 // NB = step blocks of 32 rows per wave: 2 everywhere except the top-k build, whose per-lane lists would not fit
 // the 256-VGPR budget of a 512-thread workgroup beside two resident step blocks.
 template <int C, bool LOGITS, int MODE, bool STAMP = false, int KT = 0, int NB = 2>
@@ -555,10 +575,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // stands for row row_map[p], workgroups past the count exit at once, and padded steps cost no MFMA at all.
   // Every row's arithmetic is independent of its position, so results are bit-identical to the dense launch.
   const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
-  static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2), "two pipeline shapes are written out below");
+  static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2) || (NB == 1 && NSTG == 3 && PMODE == 15), "the pipeline shapes written out below");
   if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
   constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14 || PMODE == 16;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
+  constexpr bool SEAM1 = PMODE == 15;   // ONE step block per wave (room for per-lane top-k lists) with the seamless tile boundary of PMODE 14: see SC_PHASE1
   constexpr bool SEAMLESS = PMODE == 14 || PMODE == 16;   // 16: timing experiment, no stage barrier (racy by design)   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
   if constexpr (FIXUP) {
     const int64_t r = (int64_t)blockIdx.x * (256 * NB) + threadIdx.x;
@@ -807,7 +828,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   auto post5 = [&](const f32x16& v, RowState2& rs) {
     rs.s += rs.ep;
     rs.s += __builtin_amdgcn_exp2f(rs.xp);
-    if (!DUAL && __any(!(rs.s < 1.0e38f))) {
+    if (!DUAL && !SEAM1 && __any(!(rs.s < 1.0e38f))) {
       // redo this tile from the checkpoint with a reference that bounds every term and the carried sum by 1
       float tm = fmaxf(fmaxf(fmaxf(v[0], v[1]), fmaxf(v[2], v[3])), fmaxf(fmaxf(v[4], v[5]), fmaxf(v[6], v[7])));
       tm = fmaxf(tm, fmaxf(fmaxf(fmaxf(v[8], v[9]), fmaxf(v[10], v[11])), fmaxf(fmaxf(v[12], v[13]), fmaxf(v[14], v[15]))));
@@ -942,8 +963,87 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   constexpr int KTA = KT > 0 ? KT : 1;
   TopList<KTA> top;
   if (KT > 0) top_init<KTA>(top);
+  // SEAM1 (PMODE 15, NB = 1, three LDS stages): the ranked top-k flavour on the seamless skeleton.  As SC_PHASE3 with one step block: the
+  // accumulator tile being drained takes the NEXT tile's bias four registers at a time (behind gaps 3, 7, 11, 15) and the A-fragment
+  // ring (four deep here: with one MFMA per fragment a read must be issued three MFMAs ahead to cover the LDS latency) runs on across
+  // the tile boundary, so no wave waits for LDS at a tile start -- the two-stage flavour it replaces loses a third of its MFMA time
+  // there (MFMA pipe busy 43 %).  The tile's maximum is folded over gaps 0..3 (two v_max per gap); in gap 3 -- the last one before the
+  // bias starts to overwrite the drained values -- one wave vote decides whether any lane has a candidate for its list (top_tile's
+  // slow path: per-lane sorted lists in registers, candidates parked two at a time).  The softmax sum has no per-tile redo here: a sum
+  // past fp32 is handed to the fix-up launch, as in PMODE 14.
+  float tk_m = -INFINITY;
+#define SC_GAP1(x, y, s)                                                                     \
+      if (MF_ && (s) < G::KS) {                                                              \
+        ring4_[((s) + 3) & 3] = *reinterpret_cast<const uint4*>(((s) + 3 < G::KS) ? tile_ + SC_FRAG((s) + 3) : ntile_ + SC_FRAG((s) + 3 - G::KS)); \
+        x = mfma32(ring4_[(s) & 3], hf[0][s], x);                                            \
+      }                                                                                      \
+      val5(s, y[s], st[0]);
+#define SC_PHASE1(x, y, buf_, ib_, MF, nbuf_, nib_, dit_)                                      \
+  do {                                                                                       \
+    constexpr bool MF_ = MF;                                                                 \
+    const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;               \
+    const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nib_) * TILE_LDS;            \
+    const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nib_) * 32 + 4 * lh;                 \
+    /* gaps 0..3, the tile's maximum folded in beside them (the slow path is kept OUT of the unrolled loops) */ \
+    SC_GAP1(x, y, 0) if (KT > 0) tk_m = fmaxf(fmaxf(fmaxf(y[0], y[1]), y[2]), fmaxf(y[3], y[4]));      __builtin_amdgcn_sched_barrier(0); \
+    SC_GAP1(x, y, 1) if (KT > 0) tk_m = fmaxf(fmaxf(fmaxf(tk_m, y[5]), y[6]), fmaxf(y[7], y[8]));      __builtin_amdgcn_sched_barrier(0); \
+    SC_GAP1(x, y, 2) if (KT > 0) tk_m = fmaxf(fmaxf(fmaxf(tk_m, y[9]), y[10]), fmaxf(y[11], y[12]));   __builtin_amdgcn_sched_barrier(0); \
+    SC_GAP1(x, y, 3)                                                                         \
+    if (KT > 0) {                                                                            \
+      tk_m = fmaxf(fmaxf(fmaxf(tk_m, y[13]), y[14]), y[15]);                                 \
+      if (__any(tk_m > top.v[KTA - 1])) top_tile_slow<KTA>(top, y, dit_);                    \
+    }                                                                                        \
+    {                                                                                        \
+      const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_);                             \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) y[j] = b4_[j];                           \
+    }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    _Pragma("unroll") for (int s = 4; s < 16; s++) {                                         \
+      SC_GAP1(x, y, s)                                                                       \
+      if ((s & 3) == 3) {                                                                    \
+        const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 2));           \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) y[(s & ~3) + j] = b4_[j];              \
+      }                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+    }                                                                                        \
+    post5(y, st[0]);                                                                         \
+  } while (0)
+
   f32x16 accA, accB;
-  if constexpr (NB == 2 && SEAMLESS && C <= 256) {
+  if constexpr (SEAM1) {
+    static_assert(G::KS >= 4, "the four-deep fragment ring needs at least four k-steps");
+    uint4 ring4_[4];
+    if (n_stages > 0) stage_issue(0, 0);
+    if (n_stages > 1) stage_issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (n_stages > 0) {
+      bias_init(accA, 0, 0);
+      bias_init(accB, 0, 1);
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + SC_FRAG(s));
+        accA = mfma32(a, hf[0][s], accA);
+      }
+#pragma unroll
+      for (int s = 0; s < 3; s++) ring4_[s] = *reinterpret_cast<const uint4*>(smem + TILE_LDS + SC_FRAG(s));   // first fragments of (stage 0, ib1)
+    }
+    int buf = 0;
+    for (int stg = 0; stg + 1 < n_stages; stg++) {   // the last stage is peeled: no run-time "is there a next tile" inside the phases
+      const int buf1 = (buf == 2) ? 0 : buf + 1;
+      const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
+      if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
+      SC_PHASE1(accB, accA, buf, 1, true, buf1, 0, (stg_lo + stg) * SC_STAGE + 4 * lh);        // MFMA (stg, ib1)   || epilogue (stg, ib0); accA <- bias (stg+1, ib0)
+      SC_PHASE1(accA, accB, buf1, 0, true, buf1, 1, (stg_lo + stg) * SC_STAGE + 32 + 4 * lh);  // MFMA (stg+1, ib0) || epilogue (stg, ib1); accB <- bias (stg+1, ib1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      buf = buf1;
+    }
+    if (n_stages > 0) {
+      SC_PHASE1(accB, accA, buf, 1, true, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 4 * lh);         // (the "next tile" reads land in dead registers)
+      SC_PHASE1(accA, accB, buf, 1, false, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 32 + 4 * lh);   // epilogue of the last tile only
+    }
+  } else if constexpr (NB == 2 && SEAMLESS && C <= 256) {
     f32x16 xa0, xa1, xb0, xb1;
     uint4 ring_[2];
     if (n_stages > 0) stage_issue(0, 0);
@@ -1064,6 +1164,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 #undef SC_PHASE
 #undef SC_PHASE2
 #undef SC_PHASE3
+#undef SC_PHASE1
+#undef SC_GAP1
 #undef SC_FRAG
 
 #pragma unroll
@@ -1092,7 +1194,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       const bool valid = myy[cbk] > 0;
       float lse = (M2 + log2f(S)) * LN2_F;
       // DUAL has no overflow redo: a running sum past fp32 is handed to the fix-up launch as an all-ones exponent in ce
-      if (DUAL && ((__float_as_uint(s_own) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(s_other) & 0x7f800000u) == 0x7f800000u))
+      if ((DUAL || SEAM1) && ((__float_as_uint(s_own) & 0x7f800000u) == 0x7f800000u || (__float_as_uint(s_other) & 0x7f800000u) == 0x7f800000u))
         lse = INFINITY;
       const int64_t dst = mysrc[cbk];
       if (o_rank) o_rank[dst] = valid ? cnt : 0;
@@ -1216,6 +1318,24 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
                                     const hiertcn_score_out_t* out, hipStream_t st, const int32_t* row_map = nullptr,
                                     const int32_t* n_rows_dev = nullptr) {
   using G = ScGeom<C>;
+  if constexpr (C >= 64 && C <= 256) {
+    // the seamless one-step-block kernel (three LDS stages, four-deep fragment ring) + the fix-up launch for a softmax sum past fp32;
+    // HIERTCN_TOPK_V2=1: the two-stage flavour it replaces, HIERTCN_TOPK_V1=1: the un-pipelined kernel -- both for A/B runs
+    if (!getenv("HIERTCN_TOPK_V1") && !getenv("HIERTCN_TOPK_V2")) {
+      constexpr bool PADI = C >= 256;
+      const size_t pitch = PADI ? 1024 + (C == 256 ? 32 : 16) : 1024;
+      size_t lds = 3 * (G::STAGE_BYTES / 1024) * pitch + 3 * SC_STAGE * sizeof(float);
+      const size_t merge = (size_t)SC_THREADS * KT * 8;
+      if (merge > lds) lds = merge;
+      auto kern = k_score_pipe<C, 15, 1, 3, PADI, false, KT>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((R + 255) / 256)), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out->rank,
+                         out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, (int*)nullptr, out->topk_idx, out->topk_val, (int)out->topk);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      return out->ce ? launch_score_fixup<C, 2, 3, PADI>(m, hidden, y, R, out, st, row_map, n_rows_dev, (int*)nullptr) : hipSuccess;
+    }
+  }
   if (!getenv("HIERTCN_TOPK_V1")) {   // the pipelined skeleton (epilogue in the MFMA gaps, one step block per wave, two LDS stages); V1: A/B
     constexpr bool PADI = C >= 256;
     const size_t pitch = PADI ? 1024 + (C == 256 ? 32 : 16) : 1024;
