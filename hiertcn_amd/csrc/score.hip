@@ -575,7 +575,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // stands for row row_map[p], workgroups past the count exit at once, and padded steps cost no MFMA at all.
   // Every row's arithmetic is independent of its position, so results are bit-identical to the dense launch.
   const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
-  static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2) || (NB == 1 && NSTG == 3 && PMODE == 15), "the pipeline shapes written out below");
+  static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2) || (NB == 1 && PMODE == 15 && (NSTG == 3 || (NSTG == 2 && C == 512))), "the pipeline shapes written out below");
   if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
   constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14 || PMODE == 16;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
@@ -1009,8 +1009,64 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     post5(y, st[0]);                                                                         \
   } while (0)
 
+  // C = 512 (32 k-steps per tile, a value drained every second gap, no list test): the same seamless phase
+#define SC_PHASE1W(x, y, buf_, ib_, MF, nbuf_, nib_)                                          \
+  do {                                                                                       \
+    const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;               \
+    const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nib_) * TILE_LDS;            \
+    const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nib_) * 32 + 4 * lh;                 \
+    _Pragma("unroll") for (int s = 0; s < 32; s++) {                                         \
+      if (MF) {                                                                              \
+        ring4_[(s + 3) & 3] = *reinterpret_cast<const uint4*>((s + 3 < 32) ? tile_ + SC_FRAG(s + 3) : ntile_ + SC_FRAG(s + 3 - 32)); \
+        x = mfma32(ring4_[s & 3], hf[0][s], x);                                              \
+      }                                                                                      \
+      if ((s & 1) == 0) val5(s >> 1, y[s >> 1], st[0]);                                      \
+      if ((s & 7) == 7) {                                                                    \
+        const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 3));           \
+        _Pragma("unroll") for (int j = 0; j < 4; j++) y[4 * (s >> 3) + j] = b4_[j];          \
+      }                                                                                      \
+      __builtin_amdgcn_sched_barrier(0);                                                     \
+    }                                                                                        \
+    post5(y, st[0]);                                                                         \
+  } while (0)
+
   f32x16 accA, accB;
-  if constexpr (SEAM1) {
+  if constexpr (SEAM1 && NSTG == 2) {
+    // two LDS stages (three 64 KB stages do not fit at C = 512): the freed buffer is refilled between the two phases of an iteration, and
+    // a second wait + barrier behind the second phase makes sure the stage has landed before the next iteration's first phase reads its
+    // first fragments across the tile boundary
+    static_assert(C == 512 && KT == 0, "the two-stage seamless loop is written for C = 512 without lists");
+    uint4 ring4_[4];
+    if (n_stages > 0) stage_issue(0, 0);
+    if (n_stages > 1) stage_issue(1, 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (n_stages > 0) {
+      bias_init(accA, 0, 0);
+      bias_init(accB, 0, 1);
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) {
+        const uint4 a = *reinterpret_cast<const uint4*>(smem + SC_FRAG(s));
+        accA = mfma32(a, hf[0][s], accA);
+      }
+#pragma unroll
+      for (int s = 0; s < 3; s++) ring4_[s] = *reinterpret_cast<const uint4*>(smem + TILE_LDS + SC_FRAG(s));
+    }
+    for (int stg = 0; stg + 1 < n_stages; stg++) {
+      const int buf = stg & 1;
+      SC_PHASE1W(accB, accA, buf, 1, true, buf ^ 1, 0);        // MFMA (stg, ib1)   || epilogue (stg, ib0); accA <- bias (stg+1, ib0)
+      __syncthreads();                                          // every wave is done with stage stg: its buffer takes stage stg + 2
+      if (stg + 2 < n_stages) stage_issue(stg + 2, buf);
+      SC_PHASE1W(accA, accB, buf ^ 1, 0, true, buf ^ 1, 1);    // MFMA (stg+1, ib0) || epilogue (stg, ib1); accB <- bias (stg+1, ib1)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                                          // stage stg + 2 has landed (the next first phase reads it at its tail)
+    }
+    if (n_stages > 0) {
+      const int buf = (n_stages - 1) & 1;
+      SC_PHASE1W(accB, accA, buf, 1, true, buf, 1);            // (the "next tile" reads land in dead registers)
+      SC_PHASE1W(accA, accB, buf, 1, false, buf, 1);           // epilogue of the last tile only
+    }
+  } else if constexpr (SEAM1) {
     static_assert(G::KS >= 4, "the four-deep fragment ring needs at least four k-steps");
     uint4 ring4_[4];
     if (n_stages > 0) stage_issue(0, 0);
@@ -1165,6 +1221,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 #undef SC_PHASE2
 #undef SC_PHASE3
 #undef SC_PHASE1
+#undef SC_PHASE1W
 #undef SC_GAP1
 #undef SC_FRAG
 
@@ -1286,12 +1343,12 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
                        out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
                        out->target, out->rank, out->ce);
-    if (PMODE == 12 || PMODE == 14) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+    if (PMODE == 12 || PMODE == 14 || PMODE == 15) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                      out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk, (int32_t*)nullptr, (float*)nullptr, 0);
-  if ((PMODE == 12 || PMODE == 14) && out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+  if ((PMODE == 12 || PMODE == 14 || PMODE == 15) && out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
   return hipGetLastError();
 }
 
@@ -1541,7 +1598,8 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
       if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st, row_map, n_rows_dev);
       if (getenv("HIERTCN_SCORE512_V1")) return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);   // A/B
       if (getenv("HIERTCN_SCORE512_XOR")) return launch_score_pipe<512, 5, 1, 2>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // A/B
-      return launch_score_pipe<512, 5, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+      if (getenv("HIERTCN_SCORE512_V2")) return launch_score_pipe<512, 5, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // A/B: per-tile redo, bubble at every tile start
+      return launch_score_pipe<512, 15, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     default: return hipErrorInvalidValue;
   }
 }
