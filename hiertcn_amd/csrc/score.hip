@@ -578,9 +578,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2) || (NB == 1 && PMODE == 15 && (NSTG == 3 || (NSTG == 2 && C == 512))), "the pipeline shapes written out below");
   if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
-  constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14 || PMODE == 16;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
+  constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14 || PMODE == 16 || PMODE == 21;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
+  constexpr bool SUMSQ = PMODE == 21;   // mixture head (gmm.hip): the four-tile seamless kernel with a one-fma epilogue -- sum of squares of the row's outputs
   constexpr bool SEAM1 = PMODE == 15;   // ONE step block per wave (room for per-lane top-k lists) with the seamless tile boundary of PMODE 14: see SC_PHASE1
-  constexpr bool SEAMLESS = PMODE == 14 || PMODE == 16;   // 16: timing experiment, no stage barrier (racy by design)   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
+  constexpr bool SEAMLESS = PMODE == 14 || PMODE == 16 || PMODE == 21;   // 16: timing experiment, no stage barrier (racy by design)   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
   if constexpr (FIXUP) {
     const int64_t r = (int64_t)blockIdx.x * (256 * NB) + threadIdx.x;
     int bad = 0;
@@ -754,6 +755,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // the MFMAs, where they are free, into one block of their own, where they are not.
   // PMODE 5: value i of a tile.  s += e(i-2); e(i-1) = 2^x(i-1); x(i) = v*log2(e) - m2; c += v > t.
   auto val5 = [&](int i, float v, RowState2& rs) {
+    if (SUMSQ) { rs.s = fmaf(v, v, rs.s); asm volatile("" : "+v"(rs.s)); return; }
     const bool gt = v > rs.t;
     if (i >= 2) rs.s += rs.ep;
     if (i >= 1) rs.ep = __builtin_amdgcn_exp2f(rs.xp);
@@ -826,6 +828,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   };
   // PMODE 5: end of a tile: drain the two pending values, then the overflow check (wave-uniform branch, rare).
   auto post5 = [&](const f32x16& v, RowState2& rs) {
+    if (SUMSQ) return;
     rs.s += rs.ep;
     rs.s += __builtin_amdgcn_exp2f(rs.xp);
     if (!DUAL && !SEAM1 && __any(!(rs.s < 1.0e38f))) {
@@ -1238,6 +1241,13 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const float M2 = fmaxf(l_own, l_o);
     const float S = __builtin_amdgcn_exp2f(l_own - M2) + __builtin_amdgcn_exp2f(l_o - M2);
     const int cnt = c_own + c_o;
+    if (SUMSQ) {   // sum of squares over ALL outputs of the row (null-id rows too: their y is the zero vector, not "no row")
+      if (lh == 0 && myr < Rv) {
+        if (o_ce) o_ce[mysrc[cbk]] = s_own + s_other;
+        if (o_tgt) o_tgt[mysrc[cbk]] = myy[cbk] > 0 ? st[cbk].t : 0.f;
+      }
+      continue;
+    }
     if (partials) {
       if (lh == 0 && myr < Rv) {
         float* pp = partials + (int64_t)blockIdx.y * 2 * R;
@@ -1576,6 +1586,14 @@ hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const i
   if (R <= 0) return hipSuccess;
   hiertcn_score_out_t out;
   out.rank = nullptr; out.ce = o_sq; out.target = o_tgt; out.topk_idx = nullptr; out.topk_val = nullptr; out.topk = 0;
+  if (!getenv("HIERTCN_SUMSQ_V1")) {   // the four-tile seamless skeleton with the one-fma epilogue (V1: the un-pipelined kernel, A/B)
+    switch (m.Clast) {
+      case 64: return launch_score_pipe<64, 21>(m, hidden, y, R, &out, st);
+      case 128: return launch_score_pipe<128, 21>(m, hidden, y, R, &out, st);
+      case 256: return launch_score_pipe<256, 21, 2, 3, true>(m, hidden, y, R, &out, st);
+      default: break;
+    }
+  }
   switch (m.Clast) {
     case 64: return launch_score_v<64, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
     case 128: return launch_score_v<128, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
