@@ -40,7 +40,9 @@ constexpr int GP_U = 8;         // hidden units per workgroup
 constexpr int GP_KS = 8;        // k slices per (lane, unit)
 constexpr int GP_LB = GP_THREADS / (GP_U * GP_KS);   // 4 lanes per pass
 constexpr int GP_NLD = 4;       // staging loads in flight per thread and wait
-constexpr unsigned GP_SPIN_MAX = 1u << 19;           // ~ a second of polling; a healthy hand-off takes microseconds
+constexpr unsigned GP_SPIN_MAX = 1u << 19;           // ~ 0.2 s of polling; a healthy hand-off takes microseconds
+constexpr unsigned GP_SPIN_FIRST = 1u << 24;         // the launch's FIRST barrier also waits for residency: a long kernel running beside this
+                                                     // one (another stream) can hold CUs for hundreds of milliseconds before the last workgroup starts
 
 struct GruPersistArgs {
   const float* pooled; const float* mask; const float* state_in;
@@ -61,7 +63,7 @@ __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p
 // every wave's stores are complete (vmcnt(0)) before the workgroup's one add; the poll and everything behind it sit behind workgroup barriers.
 // `dead` (LDS): once a wait of this workgroup has run out, its later barriers add and go on without waiting -- a launch that cannot
 // complete correctly ends in about a second instead of twenty-two time-outs.
-__device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned P, unsigned long long* err, int* dead) {
+__device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned P, unsigned long long* err, int* dead, unsigned spin_max) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
@@ -70,7 +72,7 @@ __device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned 
     unsigned spins = 0;
     while (!*dead && __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
-      if (++spins > GP_SPIN_MAX) {   // never in a healthy run: leave a mark and go on rather than hang the device
+      if (++spins > spin_max) {   // never in a healthy run: leave a mark and go on rather than hang the device
         __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         *dead = 1;
       }
@@ -216,7 +218,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
         }
       }
     }
-    group_barrier(bar, (unsigned)a.P, err, &s_dead);   // (its closing workgroup barrier also frees the staging buffer and the descriptors)
+    group_barrier(bar, (unsigned)a.P, err, &s_dead, tau == 0 ? GP_SPIN_FIRST : GP_SPIN_MAX);   // (its closing workgroup barrier also frees the staging buffer and the descriptors)
     // ---------------- phase B: (r * h) half of the candidate, tanh, blend, masked next state
     if (tid < n_cells) {
       SegDesc sd;
@@ -250,7 +252,7 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
         }
       }
     }
-    if (tau + 1 < S + nl - 1) group_barrier(bar, (unsigned)a.P, err, &s_dead);
+    if (tau + 1 < S + nl - 1) group_barrier(bar, (unsigned)a.P, err, &s_dead, GP_SPIN_MAX);
   }
 }
 

@@ -118,3 +118,33 @@ def test_a_wait_that_cannot_be_met_times_out_instead_of_hanging():
     assert eng.persistent_timed_out()
     assert took < 30.0, took
     eng.close()
+
+
+def test_persistent_scan_beside_a_long_kernel_on_another_stream():
+    """The launch's workgroups can only all be resident once a long kernel on another stream has let go of the CUs: the first barrier waits
+    for that (long bound), the result is the same and no wait runs out."""
+    d, nl = 256, 2
+    args = hier_tcn_args(item_num=500, emb_dim=d, hidden_dim=d, tcn_channel=[d, d], num_layer=nl)
+    eng = Engine(args)
+    eng.set_weights(init_params(args, 5))
+    data = _inputs(np.random.default_rng(4), 32, 10, d, d * nl)
+    want = [t.clone() for t in eng.gru_scan(*data, want_state_before=True)]
+    big = hier_tcn_args(item_num=120_000, emb_dim=d, hidden_dim=d, tcn_channel=[d, d], num_layer=nl)
+    eb = Engine(big)
+    eb.set_weights(init_params(big, 6))
+    rows = 600_000
+    hid = (torch.randn(rows, d, device="cuda") * 0.5).to(torch.bfloat16)
+    y = torch.randint(1, 120_000, (rows,), device="cuda", dtype=torch.int32)
+    eb.score_fused(hid, y)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            eb.score_fused(hid, y)               # ~30 ms of every CU
+        got = eng.gru_scan(*data, want_state_before=True)
+        torch.cuda.synchronize()
+        for g, w in zip(got, want):
+            assert torch.equal(g, w)
+    assert not eng.persistent_timed_out()
+    eb.close()
+    eng.close()
