@@ -398,6 +398,10 @@ def main():
                 "library_gemm_reference": gemm_ref,
                 "frac_of_library_gemm": (round(achieved / gemm_ref["tflops"], 4) if gemm_ref and gemm_ref.get("tflops") else None),
                 "clock_probe": dvfs,
+                # informational: the same achieved rate against the peak at the shader clock rocm-smi reported under this very load
+                # (2.5 PFLOP/s assumes 2.4 GHz); `frac` above stays the data-sheet fraction
+                "frac_at_held_clock": (round(achieved / (MFMA_PEAK_TFLOPS * dvfs["random"]["sclk_mhz"] / 2400.0), 4)
+                                       if dvfs and dvfs.get("random") and dvfs["random"].get("sclk_mhz") else None),
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch through the L2's memory-side port (Infinity-Cache hits included)",
                 "traffic_source": traffic_src,
