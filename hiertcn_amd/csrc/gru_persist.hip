@@ -279,7 +279,7 @@ bool gru_persist_shape_ok(const ModelDev& m, int B, int S) {
   if (!m.gru_bar || m.n_cu <= 0 || B <= 0 || S <= 0 || B > 96) return false;   // measured cross-over with the GEMM chain: ~100 lanes
   if (m.E != m.H || (m.H != 64 && m.H != 128 && m.H != 256)) return false;      // (E != H, H = 512 or odd widths: the GEMM chain)
   if (GP_GROUPS * (m.H / GP_U) > m.n_cu) return false;                           // every workgroup resident, one per CU
-  return persist_lds_bytes(m.H, m.nl, B) <= 150 * 1024;
+  return persist_lds_bytes(m.H, m.nl, B) <= 150 * 1024;   // (H = 256, two layers: up to 64 lanes)
 }
 
 // 0 = not applicable (the caller runs the GEMM chain), else the number of workgroups per lane group

@@ -140,28 +140,41 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
 #pragma unroll
   for (int i = 0; i < 16; i++) acc[i] = 0.f;
   const int n1 = g.K1 >> 3;
-#pragma unroll 8
-  for (int i = k_first; i < n1; i += KSTEP) {
-    const float4 a = *reinterpret_cast<const float4*>(wp + 8 * i);
-    const float4 b = *reinterpret_cast<const float4*>(x1 + 8 * i);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
-    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
-  }
-  if (g.K2 > 0) {
-    const float* x2 = g.A2 + (int64_t)mrow * g.lda2 + 4 * lh;
-    const float* wp2 = wp + g.K1;
-    const int n2 = g.K2 >> 3;
-#pragma unroll 8
-    for (int i = k_first; i < n2; i += KSTEP) {
-      const float4 a = *reinterpret_cast<const float4*>(wp2 + 8 * i);
-      const float4 b = *reinterpret_cast<const float4*>(x2 + 8 * i);
+  // four 8-deep k-steps per trip, their eight loads issued before the first MFMA (hipcc does not unroll this loop on request -- the
+  // run-time trip count and stride defeat `#pragma unroll 8` -- and one k-step per trip exposes a full load latency every 4 MFMAs);
+  // the MFMA order, hence every result bit, is unchanged
+  auto k_run = [&](const float* wq, const float* xq, int nk) {
+    int i = k_first;
+    for (; i + 3 * KSTEP < nk; i += 4 * KSTEP) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        a[u] = *reinterpret_cast<const float4*>(wq + 8 * (i + u * KSTEP));
+        b[u] = *reinterpret_cast<const float4*>(xq + 8 * (i + u * KSTEP));
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].x, b[u].x, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].y, b[u].y, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].z, b[u].z, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u].w, b[u].w, acc, 0, 0, 0);
+      }
+    }
+    for (; i < nk; i += KSTEP) {
+      const float4 a = *reinterpret_cast<const float4*>(wq + 8 * i);
+      const float4 b = *reinterpret_cast<const float4*>(xq + 8 * i);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, b.x, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, b.y, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, b.z, acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, b.w, acc, 0, 0, 0);
     }
+  };
+  if (n1 > 0) k_run(wp, x1, n1);
+  if (g.K2 > 0) {
+    const float* x2 = g.A2 + (int64_t)mrow * g.lda2 + 4 * lh;
+    const float* wp2 = wp + g.K1;
+    const int n2 = g.K2 >> 3;
+    k_run(wp2, x2, n2);
   }
   if (SPLITK) {   // fixed-order sum of the partial tiles (deterministic)
     constexpr int NP_ = SPLITK ? SPLITK - 1 : 1;
