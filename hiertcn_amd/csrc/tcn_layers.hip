@@ -44,28 +44,38 @@ __global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
   }
 
   const uint4 zero = make_uint4(0, 0, 0, 0);
+  // four k-steps per trip with their eight loads issued before the first MFMA (hipcc does not unroll the run-time loop on request; one
+  // k-step per trip exposes a load latency per MFMA); the MFMA order, hence every result bit, is unchanged
+  auto k_run = [&](const uint16_t* arow, const uint16_t* brow, bool ok, f32x16& c) {
+    int s = 0;
+    for (; s + 3 < ks; s += 4) {
+      uint4 av[4], bv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        av[u] = *reinterpret_cast<const uint4*>(arow + 16 * (s + u));
+        bv[u] = ok ? *reinterpret_cast<const uint4*>(brow + 16 * (s + u)) : zero;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) c = mfma32(av[u], bv[u], c);
+    }
+    for (; s < ks; s++) {
+      const uint4 av = *reinterpret_cast<const uint4*>(arow + 16 * s);
+      const uint4 bv = ok ? *reinterpret_cast<const uint4*>(brow + 16 * s) : zero;
+      c = mfma32(av, bv, c);
+    }
+  };
   for (int j = 0; j < a.taps; j++) {
     const int tsrc = t - (a.taps - 1 - j) * a.dil;   // o[t] += x[t - (K-1-j)*dil] . W[j]
     const bool ok = tsrc >= 0 && t < a.L;
     const uint16_t* brow = a.in + (row0 + (ok ? tsrc : 0)) * a.Cin + 8 * lh;
     const uint16_t* arow = a.W + ((int64_t)j * a.Cout + cb * 32 + lr) * a.Cin + 8 * lh;
-#pragma unroll 4
-    for (int s = 0; s < ks; s++) {
-      const uint4 av = *reinterpret_cast<const uint4*>(arow + 16 * s);
-      const uint4 bv = ok ? *reinterpret_cast<const uint4*>(brow + 16 * s) : zero;
-      acc = mfma32(av, bv, acc);
-    }
+    k_run(arow, brow, ok, acc);
   }
   if (!a.linear && a.Wres) {   // res(x) = x . Wr + br  (customized_tcn_cell.py:106,124)
     const bool ok = t < a.L;
     const uint16_t* brow = a.in + (row0 + (ok ? t : 0)) * a.Cin + 8 * lh;
     const uint16_t* arow = a.Wres + ((int64_t)cb * 32 + lr) * a.Cin + 8 * lh;
-#pragma unroll 4
-    for (int s = 0; s < ks; s++) {
-      const uint4 av = *reinterpret_cast<const uint4*>(arow + 16 * s);
-      const uint4 bv = ok ? *reinterpret_cast<const uint4*>(brow + 16 * s) : zero;
-      racc = mfma32(av, bv, racc);
-    }
+    k_run(arow, brow, ok, racc);
   }
   if (t >= a.L) return;
 #pragma unroll
