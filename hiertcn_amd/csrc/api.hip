@@ -99,7 +99,7 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
     cfg_local.n_blocks = 1; cfg_local.channels[0] = cfg->hidden_dim; cfg_local.kernel_size = 1;
   }
   if (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS) return fail(HIERTCN_ERR_INVALID, "n_blocks out of range");
-  bool uniform = (E == 64 || E == 128 || E == 256);
+  bool uniform = (E == 64 || E == 128 || E == 256 || E == 512);
   for (int i = 0; i < cfg->n_blocks; i++) {
     const int ci = cfg->channels[i];
     if (ci < 32 || (ci & 31) || ci > 1024) return fail(HIERTCN_ERR_INVALID, "tcn_channel[%d]=%d: widths are multiples of 32 up to 1024", i, ci);

@@ -59,7 +59,7 @@ struct ModelDev {
   int Clast;
   int hier;
   int low_gru;     // 1: HierGRU -- the low level is model_gru.py's GRU stack instead of the TemporalConvNet (hier only)
-  int fused_tcn;   // 1: every width == E in {64,128,256} and no down-sample residual -> tcn.hip's fused kernel applies (L <= 32)
+  int fused_tcn;   // 1: every width == E in {64,128,256,512} and no down-sample residual -> tcn.hip's fused kernel applies (L <= 32)
   // bf16 tensors (uint16 bit patterns)
   uint16_t* emb;        // [N][E], row 0 zeroed
   uint16_t* projT;      // [E(out)][E(in)]   = transpose(Wp[:E])          (hier only)

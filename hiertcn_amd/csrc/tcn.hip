@@ -20,13 +20,15 @@
 
 template <int C>
 struct TcnGeom {
+  static constexpr int GS = (C == 512) ? 2 : TCN_G;   // sessions per workgroup: the LDS slabs of four 512-channel sessions would take all 160 KB
   static constexpr int NCB = C / 32;        // output-channel blocks
-  static constexpr int WPC = 8 / NCB;       // waves sharing one channel block
-  static constexpr int RPW = TCN_G / WPC;   // sessions (row blocks) per wave
+  static constexpr int CBW = NCB > 8 ? NCB / 8 : 1;   // channel blocks per wave (C = 512: two)
+  static constexpr int WPC = NCB >= 8 ? 1 : 8 / NCB;  // waves sharing one channel block
+  static constexpr int RPW = GS / WPC;      // sessions (row blocks) per wave
   static constexpr int KS = C / 16;         // MFMA k-steps
   static constexpr int CH = C / 8;          // 16-byte chunks per row
   static constexpr int SWZ = (CH < 16 ? CH : 16) - 1;
-  static_assert(NCB >= 1 && NCB <= 8 && (8 % NCB) == 0 && (TCN_G % WPC) == 0, "unsupported channel count");
+  static_assert(NCB >= 1 && NCB <= 16 && (NCB <= 8 ? (8 % NCB) == 0 : (NCB % 8) == 0) && (GS % WPC) == 0, "unsupported channel count");
 };
 
 struct TcnParams {
@@ -62,10 +64,10 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t sess0 = (int64_t)blockIdx.x * TCN_G;
+  const int64_t sess0 = (int64_t)blockIdx.x * G::GS;
 
   // ---- phase 0: zero halo rows, gather embedding rows (16 B per lane) -------------------------
-  for (int i = tid; i < TCN_G * ROWS * G::CH; i += TCN_THREADS) {
+  for (int i = tid; i < G::GS * ROWS * G::CH; i += TCN_THREADS) {
     const int row = i / G::CH, ch = i % G::CH;
     const int g = row / ROWS, r = row % ROWS;
     uint4 v = make_uint4(0, 0, 0, 0);
@@ -81,9 +83,8 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
   }
   __syncthreads();
 
-  const int cb = wave / G::WPC;                 // output-channel block of this wave
+  const int cb0 = (wave / G::WPC) * G::CBW;      // first output-channel block of this wave (C = 512: two blocks per wave)
   const int g0 = (wave % G::WPC) * G::RPW;      // first session (row block) of this wave
-  const int arow = cb * 32 + lr;                // weight row (output channel) this lane feeds as A
 
   // One layer = (taps x k-steps) MFMAs per row block; layer < 0 is the input projection.
   const int n_layers = p.n_blocks + (p.projT ? 1 : 0);
@@ -94,13 +95,15 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
     const int taps = is_proj ? 1 : p.K;
     const uint16_t* W = is_proj ? p.projT : p.convT[blk];
 
-    f32x16 acc[G::RPW];
+    f32x16 acc[G::CBW][G::RPW];
+#pragma unroll
+    for (int cbi = 0; cbi < G::CBW; cbi++)
 #pragma unroll
     for (int r = 0; r < G::RPW; r++) {
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         f32x4 init = {0.f, 0.f, 0.f, 0.f};
-        const int c0 = cb * 32 + 8 * q + 4 * lh;  // 4 consecutive output channels of this register quad
+        const int c0 = (cb0 + cbi) * 32 + 8 * q + 4 * lh;  // 4 consecutive output channels of this register quad
         if (is_proj) {
           const int64_t sess = sess0 + g0 + r;
           if (sproj != nullptr && sess < n_sessions) init = *reinterpret_cast<const f32x4*>(sproj + sess * C + c0);
@@ -108,14 +111,15 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
           init = *reinterpret_cast<const f32x4*>(p.conv_bias[blk] + c0);
         }
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[r][4 * q + j] = init[j];
+        for (int j = 0; j < 4; j++) acc[cbi][r][4 * q + j] = init[j];
       }
     }
 
     for (int j = 0; j < taps; j++) {
       const int shift = is_proj ? 0 : (p.K - 1 - j) * dil;  // o[t] += x[t - (K-1-j)*dil] . W[j]
-      const uint16_t* Wj = W + (int64_t)j * C * C + (int64_t)arow * C + 8 * lh;
+      const uint16_t* Wj = W + (int64_t)j * C * C + (int64_t)(cb0 * 32 + lr) * C + 8 * lh;   // (+ 32 C per further channel block of the wave)
       if constexpr (DEEP) {
+        static_assert(G::CBW == 1, "the deep prefetch is written for one channel block per wave");
         uint4 af[G::KS];
 #pragma unroll
         for (int s = 0; s < G::KS; s++) af[s] = *reinterpret_cast<const uint4*>(Wj + 16 * s);
@@ -125,33 +129,39 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
           for (int r = 0; r < G::RPW; r++) {
             const int row = (g0 + r) * ROWS + p.pad + lr - shift;
             const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));
-            acc[r] = mfma32(af[s], b, acc[r]);
+            acc[0][r] = mfma32(af[s], b, acc[0][r]);
           }
         }
       } else {
 #pragma unroll 4
         for (int s = 0; s < G::KS; s++) {
-          const uint4 a = *reinterpret_cast<const uint4*>(Wj + 16 * s);
+          uint4 a[G::CBW];
+#pragma unroll
+          for (int cbi = 0; cbi < G::CBW; cbi++) a[cbi] = *reinterpret_cast<const uint4*>(Wj + (int64_t)cbi * 32 * C + 16 * s);
 #pragma unroll
           for (int r = 0; r < G::RPW; r++) {
             const int row = (g0 + r) * ROWS + p.pad + lr - shift;
-            const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));
-            acc[r] = mfma32(a, b, acc[r]);
+            const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));   // one LDS read feeds every channel block of the wave
+#pragma unroll
+            for (int cbi = 0; cbi < G::CBW; cbi++) acc[cbi][r] = mfma32(a[cbi], b, acc[cbi][r]);
           }
         }
       }
     }
 
     // epilogue in registers: projection -> identity; block -> relu(relu(conv+b) + x)
-    uint2 outv[G::RPW][4];
+    uint2 outv[G::CBW][G::RPW][4];
+#pragma unroll
+    for (int cbi = 0; cbi < G::CBW; cbi++)
 #pragma unroll
     for (int r = 0; r < G::RPW; r++) {
+      const int cb = cb0 + cbi;
       const int row = (g0 + r) * ROWS + p.pad + lr;
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) v[j] = acc[r][4 * q + j];
+        for (int j = 0; j < 4; j++) v[j] = acc[cbi][r][4 * q + j];
         if (!is_proj) {
           if (p.save_c[blk]) {   // training: relu(conv + b) before the residual add (its sign pattern gates the backward pass)
             const int64_t sess = sess0 + g0 + r;
@@ -170,22 +180,24 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
           v[2] = fmaxf(fmaxf(v[2], 0.f) + r2, 0.f);
           v[3] = fmaxf(fmaxf(v[3], 0.f) + r3, 0.f);
         }
-        outv[r][q].x = pack2bf(v[0], v[1]);
-        outv[r][q].y = pack2bf(v[2], v[3]);
+        outv[cbi][r][q].x = pack2bf(v[0], v[1]);
+        outv[cbi][r][q].y = pack2bf(v[2], v[3]);
       }
     }
     __syncthreads();  // every wave has finished reading this layer's input
+#pragma unroll
+    for (int cbi = 0; cbi < G::CBW; cbi++)
 #pragma unroll
     for (int r = 0; r < G::RPW; r++) {
       const int row = (g0 + r) * ROWS + p.pad + lr;
 #pragma unroll
       for (int q = 0; q < 4; q++)
-        *reinterpret_cast<uint2*>(smem + lds_off<C>(row, cb * 4 + q) + 8 * lh) = outv[r][q];
+        *reinterpret_cast<uint2*>(smem + lds_off<C>(row, (cb0 + cbi) * 4 + q) + 8 * lh) = outv[cbi][r][q];
     }
     __syncthreads();
     uint16_t* sv = p.save_a[is_proj ? 0 : blk + 1];
     if (sv) {   // training: this layer's output, 16 B per lane (the next layer's first barrier also covers these reads)
-      for (int i = tid; i < TCN_G * 32 * G::CH; i += TCN_THREADS) {
+      for (int i = tid; i < G::GS * 32 * G::CH; i += TCN_THREADS) {
         const int ch = i % G::CH, rt = i / G::CH;
         const int g = rt >> 5, t = rt & 31;
         const int64_t sess = sess0 + g;
@@ -196,7 +208,7 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
   }
 
   // ---- write the valid rows out, 16 B per lane, rows compacted to [session][t < L] -----------
-  for (int i = tid; i < TCN_G * 32 * G::CH; i += TCN_THREADS) {
+  for (int i = tid; i < G::GS * 32 * G::CH; i += TCN_THREADS) {
     const int ch = i % G::CH, rt = i / G::CH;
     const int g = rt >> 5, t = rt & 31;
     const int64_t sess = sess0 + g;
@@ -210,12 +222,14 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
 template <int C>
 static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
                                uint16_t* hidden, hipStream_t st) {
-  size_t lds = (size_t)TCN_G * (p.pad + 32) * 2 * C;
-  unsigned blocks = (unsigned)((n_sessions + TCN_G - 1) / TCN_G);
-  if (blocks <= 384 && !p.save_emb) {   // fewer workgroups than one and a half per CU: latency of the weight loads, not occupancy, is the limit
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  constexpr int GS = TcnGeom<C>::GS;
+  size_t lds = (size_t)GS * (p.pad + 32) * 2 * C;
+  unsigned blocks = (unsigned)((n_sessions + GS - 1) / GS);
+  if (C <= 256 && blocks <= 384 && !p.save_emb) {   // fewer workgroups than one and a half per CU: latency of the weight loads, not occupancy, is the limit
+    constexpr bool DEEP_OK = C <= 256;
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, DEEP_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((k_tcn_fused<C, true>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
+    hipLaunchKernelGGL((k_tcn_fused<C, DEEP_OK>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
     return hipGetLastError();
   }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -230,7 +244,7 @@ static bool use_fused(const ModelDev& m, int L) {
   static const bool force_layers = getenv("HIERTCN_FORCE_LAYERED") != nullptr;  // tests: both paths must agree bitwise
   if (force_layers) return false;
   const int halo = (m.K - 1) * (1 << (m.n_blocks - 1));
-  const size_t lds = (size_t)TCN_G * (((halo + 7) & ~7) + 32) * 2 * m.E;
+  const size_t lds = (size_t)(m.E == 512 ? 2 : TCN_G) * (((halo + 7) & ~7) + 32) * 2 * m.E;   // TcnGeom<C>::GS sessions per workgroup
   return m.fused_tcn && L <= 32 && lds <= 160 * 1024;
 }
 
@@ -263,6 +277,7 @@ hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* 
     case 64: return launch_tcn_c<64>(p, x, sproj, n_sessions, L, hidden, st);
     case 128: return launch_tcn_c<128>(p, x, sproj, n_sessions, L, hidden, st);
     case 256: return launch_tcn_c<256>(p, x, sproj, n_sessions, L, hidden, st);
+    case 512: return launch_tcn_c<512>(p, x, sproj, n_sessions, L, hidden, st);
     default: return hipErrorInvalidValue;
   }
 }

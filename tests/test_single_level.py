@@ -113,8 +113,10 @@ def test_single_level_hip_vs_oracle(cfg):
 
 
 @pytest.mark.gpu
-def test_layered_and_fused_low_level_agree_bitwise():
-    """Same accumulation order in both device paths -> identical bf16 activations (hier config, L = 13)."""
+@pytest.mark.parametrize("width", [128, 512])
+def test_layered_and_fused_low_level_agree_bitwise(width):
+    """Same accumulation order in both device paths -> identical bf16 activations (hier config, L = 13); width 512 runs the fused kernel with
+    two channel blocks per wave and two sessions per workgroup."""
     import subprocess
     import sys
     code = r'''
@@ -122,13 +124,13 @@ import numpy as np, torch, sys
 sys.path.insert(0, %r)
 from tests.gpu_common import make_batch, make_params, small_args
 from hiertcn_amd.engine import Engine
-args = small_args(N=800, d=128, H=64)
+args = small_args(N=800, d=int(sys.argv[2]), H=64)
 eng = Engine(args, hier=True); eng.set_weights(make_params(args))
 rng = np.random.default_rng(4)
 x, y, mask = make_batch(rng, 6, 3, 13, 800)
 dev = lambda a: torch.as_tensor(a).cuda().contiguous()
 pooled = eng.session_pool(dev(y.reshape(18, 13))).view(6, 3, -1)
-st = dev((0.2 * rng.standard_normal((6, 128))).astype(np.float32))
+st = dev((0.2 * rng.standard_normal((6, 128))).astype(np.float32))   # H * nl = 64 * 2
 sproj, _, _ = eng.gru_scan(pooled, dev(mask), st)
 hid = eng.tcn_forward(dev(x.reshape(18, 13)), sproj.view(18, -1))
 np.save(sys.argv[1], hid.view(torch.int16).cpu().numpy())
@@ -138,7 +140,7 @@ np.save(sys.argv[1], hid.view(torch.int16).cpu().numpy())
         outs = []
         for i, env in enumerate(({}, {"HIERTCN_FORCE_LAYERED": "1"})):
             f = os.path.join(tmp, f"h{i}.npy")
-            subprocess.run([sys.executable, "-c", code, f], check=True, env={**os.environ, **env})
+            subprocess.run([sys.executable, "-c", code, f, str(width)], check=True, env={**os.environ, **env})
             outs.append(np.load(f))
         assert outs[0].shape == outs[1].shape and np.array_equal(outs[0], outs[1])
 
