@@ -11,23 +11,30 @@
 // customized_tcn_cell.py:47-48), D[row = cout][col = t]; taps outermost, k-steps inner -- the SAME
 // accumulation order as the fused kernel, so both produce bitwise identical activations.
 #include "common.h"
+#include <cstdlib>
 
+// RB = time blocks (32 steps each) per wave: the wave's weight fragment of a (tap, k-step) then feeds RB MFMAs instead of one -- at RB = 1
+// every MFMA pulls 2 KB through L2 (a weight fragment and an activation fragment, nothing reused inside a wave), which is what bounds
+// the kernel on long sequences (single-level model_tcn: T <= 500); the activation fragments of a time block are shared by the four waves
+// of a workgroup (consecutive channel blocks) through the CU's L1.  Accumulation order per output is unchanged (bias, then taps, then
+// k-steps), so results are bit-identical for every RB.
+template <int RB>
 __global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int ncb = a.Cout >> 5;
   const int ntt = (a.L + 31) >> 5;
+  const int ntg = (ntt + RB - 1) / RB;                 // groups of RB time blocks
   const int64_t tile = (int64_t)blockIdx.x * 4 + wave;
   const int cb = (int)(tile % ncb);
   const int64_t rest = tile / ncb;
-  const int tt = (int)(rest % ntt);
-  const int64_t seq = rest / ntt;
+  const int tg = (int)(rest % ntg);
+  const int64_t seq = rest / ntg;
   if (seq >= a.n_seq) return;
-  const int t = tt * 32 + lr;
   const int64_t row0 = seq * a.L;
   const int ks = a.Cin >> 4;
 
-  f32x16 acc, racc;
+  f32x16 acc[RB], racc[RB];
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int c0 = cb * 32 + 8 * q + 4 * lh;
@@ -40,73 +47,74 @@ __global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
     }
     if (a.bres) rinit = *reinterpret_cast<const f32x4*>(a.bres + c0);
 #pragma unroll
-    for (int j = 0; j < 4; j++) { acc[4 * q + j] = init[j]; racc[4 * q + j] = rinit[j]; }
+    for (int r = 0; r < RB; r++)
+#pragma unroll
+      for (int j = 0; j < 4; j++) { acc[r][4 * q + j] = init[j]; racc[r][4 * q + j] = rinit[j]; }
   }
 
   const uint4 zero = make_uint4(0, 0, 0, 0);
-  // four k-steps per trip with their eight loads issued before the first MFMA (hipcc does not unroll the run-time loop on request; one
-  // k-step per trip exposes a load latency per MFMA); the MFMA order, hence every result bit, is unchanged
-  auto k_run = [&](const uint16_t* arow, const uint16_t* brow, bool ok, f32x16& c) {
-    int s = 0;
-    for (; s + 3 < ks; s += 4) {
-      uint4 av[4], bv[4];
+  // per trip: one weight fragment and the RB activation fragments it multiplies, loads before MFMAs
+  auto k_run = [&](const uint16_t* arow, int back, f32x16* c) {
+    const uint16_t* brow[RB];
+    bool ok[RB];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
+    for (int r = 0; r < RB; r++) {
+      const int t = (tg * RB + r) * 32 + lr, tsrc = t - back;
+      ok[r] = tsrc >= 0 && t < a.L;
+      brow[r] = a.in + (row0 + (ok[r] ? tsrc : 0)) * a.Cin + 8 * lh;
+    }
+    for (int s = 0; s < ks; s += 2) {   // (Cin is a multiple of 32: ks is even)
+      uint4 av[2], bv[2][RB];
+#pragma unroll
+      for (int u = 0; u < 2; u++) {
         av[u] = *reinterpret_cast<const uint4*>(arow + 16 * (s + u));
-        bv[u] = ok ? *reinterpret_cast<const uint4*>(brow + 16 * (s + u)) : zero;
+#pragma unroll
+        for (int r = 0; r < RB; r++) bv[u][r] = ok[r] ? *reinterpret_cast<const uint4*>(brow[r] + 16 * (s + u)) : zero;
       }
 #pragma unroll
-      for (int u = 0; u < 4; u++) c = mfma32(av[u], bv[u], c);
-    }
-    for (; s < ks; s++) {
-      const uint4 av = *reinterpret_cast<const uint4*>(arow + 16 * s);
-      const uint4 bv = ok ? *reinterpret_cast<const uint4*>(brow + 16 * s) : zero;
-      c = mfma32(av, bv, c);
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int r = 0; r < RB; r++) c[r] = mfma32(av[u], bv[u][r], c[r]);
     }
   };
-  for (int j = 0; j < a.taps; j++) {
-    const int tsrc = t - (a.taps - 1 - j) * a.dil;   // o[t] += x[t - (K-1-j)*dil] . W[j]
-    const bool ok = tsrc >= 0 && t < a.L;
-    const uint16_t* brow = a.in + (row0 + (ok ? tsrc : 0)) * a.Cin + 8 * lh;
-    const uint16_t* arow = a.W + ((int64_t)j * a.Cout + cb * 32 + lr) * a.Cin + 8 * lh;
-    k_run(arow, brow, ok, acc);
-  }
-  if (!a.linear && a.Wres) {   // res(x) = x . Wr + br  (customized_tcn_cell.py:106,124)
-    const bool ok = t < a.L;
-    const uint16_t* brow = a.in + (row0 + (ok ? t : 0)) * a.Cin + 8 * lh;
-    const uint16_t* arow = a.Wres + ((int64_t)cb * 32 + lr) * a.Cin + 8 * lh;
-    k_run(arow, brow, ok, racc);
-  }
-  if (t >= a.L) return;
+  for (int j = 0; j < a.taps; j++)   // o[t] += x[t - (K-1-j)*dil] . W[j]
+    k_run(a.W + ((int64_t)j * a.Cout + cb * 32 + lr) * a.Cin + 8 * lh, (a.taps - 1 - j) * a.dil, acc);
+  if (!a.linear && a.Wres)           // res(x) = x . Wr + br  (customized_tcn_cell.py:106,124)
+    k_run(a.Wres + ((int64_t)cb * 32 + lr) * a.Cin + 8 * lh, 0, racc);
 #pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int c0 = cb * 32 + 8 * q + 4 * lh;
-    float v[4];
+  for (int r = 0; r < RB; r++) {
+    const int t = (tg * RB + r) * 32 + lr;
+    if (t >= a.L) continue;
 #pragma unroll
-    for (int j = 0; j < 4; j++) v[j] = acc[4 * q + j];
-    if (!a.linear) {
-      float r[4];
-      if (a.Wres) {
+    for (int q = 0; q < 4; q++) {
+      const int c0 = cb * 32 + 8 * q + 4 * lh;
+      float v[4];
 #pragma unroll
-        for (int j = 0; j < 4; j++) r[j] = racc[4 * q + j];
-      } else {   // identity residual (Cin == Cout)
-        const uint2 res = *reinterpret_cast<const uint2*>(a.in + (row0 + t) * a.Cin + c0);
-        r[0] = bf2f((uint16_t)(res.x & 0xffff)); r[1] = bf2f((uint16_t)(res.x >> 16));
-        r[2] = bf2f((uint16_t)(res.y & 0xffff)); r[3] = bf2f((uint16_t)(res.y >> 16));
+      for (int j = 0; j < 4; j++) v[j] = acc[r][4 * q + j];
+      if (!a.linear) {
+        float rr[4];
+        if (a.Wres) {
+#pragma unroll
+          for (int j = 0; j < 4; j++) rr[j] = racc[r][4 * q + j];
+        } else {   // identity residual (Cin == Cout)
+          const uint2 res = *reinterpret_cast<const uint2*>(a.in + (row0 + t) * a.Cin + c0);
+          rr[0] = bf2f((uint16_t)(res.x & 0xffff)); rr[1] = bf2f((uint16_t)(res.x >> 16));
+          rr[2] = bf2f((uint16_t)(res.y & 0xffff)); rr[3] = bf2f((uint16_t)(res.y >> 16));
+        }
+        if (a.c_out) {   // training: keep relu(conv + b) -- the backward pass needs its sign pattern
+          uint2 co;
+          co.x = pack2bf(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
+          co.y = pack2bf(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
+          *reinterpret_cast<uint2*>(a.c_out + (row0 + t) * a.Cout + c0) = co;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++) v[j] = fmaxf(fmaxf(v[j], 0.f) + rr[j], 0.f);
       }
-      if (a.c_out) {   // training: keep relu(conv + b) -- the backward pass needs its sign pattern
-        uint2 co;
-        co.x = pack2bf(fmaxf(v[0], 0.f), fmaxf(v[1], 0.f));
-        co.y = pack2bf(fmaxf(v[2], 0.f), fmaxf(v[3], 0.f));
-        *reinterpret_cast<uint2*>(a.c_out + (row0 + t) * a.Cout + c0) = co;
-      }
-#pragma unroll
-      for (int j = 0; j < 4; j++) v[j] = fmaxf(fmaxf(v[j], 0.f) + r[j], 0.f);
+      uint2 o;
+      o.x = pack2bf(v[0], v[1]);
+      o.y = pack2bf(v[2], v[3]);
+      *reinterpret_cast<uint2*>(a.out + (row0 + t) * a.Cout + c0) = o;
     }
-    uint2 o;
-    o.x = pack2bf(v[0], v[1]);
-    o.y = pack2bf(v[2], v[3]);
-    *reinterpret_cast<uint2*>(a.out + (row0 + t) * a.Cout + c0) = o;
   }
 }
 
@@ -143,8 +151,19 @@ size_t tcn_layers_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) 
 }
 
 hipError_t launch_tcn_layer(const LayerArgs& a, hipStream_t st) {
-  const int64_t tiles = a.n_seq * ((a.L + 31) / 32) * (a.Cout / 32);
-  hipLaunchKernelGGL(k_tcn_layer, dim3((unsigned)((tiles + 3) / 4)), dim3(256), 0, st, a);
+  const int ntt = (a.L + 31) / 32;
+  // time blocks per wave: as many as a sequence has, up to four, while the grid still fills the chip a few times over
+  const int64_t tiles1 = a.n_seq * ntt * (a.Cout / 32);
+  int rb = ntt >= 4 ? 4 : (ntt >= 2 ? 2 : 1);
+  while (rb > 1 && tiles1 / rb < 4 * 1024) rb >>= 1;
+  if (getenv("HIERTCN_TCN_LAYER_RB1")) rb = 1;   // A/B
+  const int64_t tiles = a.n_seq * ((ntt + rb - 1) / rb) * (a.Cout / 32);
+  const dim3 grid((unsigned)((tiles + 3) / 4));
+  switch (rb) {
+    case 4: hipLaunchKernelGGL(k_tcn_layer<4>, grid, dim3(256), 0, st, a); break;
+    case 2: hipLaunchKernelGGL(k_tcn_layer<2>, grid, dim3(256), 0, st, a); break;
+    default: hipLaunchKernelGGL(k_tcn_layer<1>, grid, dim3(256), 0, st, a); break;
+  }
   return hipGetLastError();
 }
 
