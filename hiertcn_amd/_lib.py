@@ -11,7 +11,9 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 6
+ABI_VERSION = 7
+N_STRUCTS = 5
+PRECISION_STORAGE16, PRECISION_FP32 = 0, 1
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)
@@ -64,6 +66,9 @@ SYMBOLS = {
     "hiertcn_destroy": (C.c_int, [C.c_void_p]),
     "hiertcn_get_config": (C.c_int, [C.c_void_p, C.POINTER(Config)]),
     "hiertcn_set_weights": (C.c_int, [C.c_void_p, C.POINTER(Weights), C.c_void_p]),
+    "hiertcn_set_precision": (C.c_int, [C.c_void_p, C.c_int32]),
+    "hiertcn_get_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
+    "hiertcn_struct_sizes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "hiertcn_session_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hiertcn_gru_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "hiertcn_gru_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,

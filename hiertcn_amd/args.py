@@ -7,7 +7,9 @@ Mirrors /root/reference/args.py:3-206 (flags and defaults), :208-228 (input path
   * nothing is parsed at import time (the reference does `args = make_args()` at args.py:318);
     call make_args(argv) or use default_args();
   * `--emb_dim` is added: the reference hard-codes 128 for the item-embedding / projection width
-    (model_hier.py:50,85; model_tcn.py:35); BASELINE.json's configs vary it ("d").
+    (model_hier.py:50,85; model_tcn.py:35); BASELINE.json's configs vary it ("d");
+  * `--storage_dtype` is added: bf16 (production), fp16 (BASELINE.json configs[3]) or fp32 -- the exact evaluation mode that
+    computes everything in fp32 like the reference's graph (for parity runs on trained checkpoints).
 """
 from __future__ import annotations
 
@@ -102,6 +104,7 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--data_splits", dest="data_splits", default=100, type=int)
     # build-only addition (see module docstring)
     p.add_argument("--emb_dim", dest="emb_dim", default=128, type=int)
+    p.add_argument("--storage_dtype", dest="storage_dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
     # args.py:193 -- the "eval" default set
     p.set_defaults(save=False, load=False, train=False, validate=False, test=True, html=False,
                    test_random=False, filter_user=False, shuffle=False)

@@ -10,6 +10,7 @@
 #include <vector>
 
 #include "common.h"
+#include "exact.h"
 #include "train.h"
 
 static thread_local char g_err[512] = "";
@@ -36,6 +37,8 @@ struct hiertcn_ctx {
   std::vector<void*> allocs;
   double* metric_scratch;
   TrainCtx train;
+  ExactDev x;        // fp32 copies of the 16-bit tensors (hiertcn_set_precision)
+  int precision;
   // timing hook
   bool timing;
   std::vector<hipEvent_t> ev_begin, ev_end;
@@ -120,6 +123,8 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
   hiertcn_ctx* c = new hiertcn_ctx();
   c->cfg = *cfg;
   c->weights_set = false;
+  memset(&c->x, 0, sizeof(c->x));
+  c->precision = HIERTCN_PRECISION_STORAGE16;
   c->timing = false;
   c->ev_used = 0;
   c->metric_scratch = nullptr;
@@ -274,7 +279,73 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
     }
   }
   if (h->train.enabled) HIP_TRY(train_fill_masters(m, h->train, w, st));
+  if (h->x.enabled) {   // exact numerics mode: fp32 copies in the same internal layouts (reduction index contiguous)
+    ExactDev& x = h->x;
+    HIP_TRY(hipMemcpyAsync(x.emb, w->emb_kernel, (size_t)m.N * E * sizeof(float), hipMemcpyDeviceToDevice, st));
+    HIP_TRY(hipMemsetAsync(x.emb, 0, (size_t)E * sizeof(float), st));   // row 0 = the null id (model.py:59)
+    HIP_TRY(launch_transpose_f32(w->out_kernel, x.outT, m.Clast, m.N, st));   // [C][N] -> [N][C]
+    for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
+      const int cout = m.C[i];
+      for (int j = 0; j < m.K; j++)
+        HIP_TRY(launch_transpose_f32(w->conv_kernel[i] + (size_t)j * cin * cout, x.convT[i] + (size_t)j * cin * cout, cin, cout, st));
+      if (w->res_kernel[i]) HIP_TRY(launch_transpose_f32(w->res_kernel[i], x.resT[i], cin, cout, st));
+    }
+    if (m.hier) HIP_TRY(launch_transpose_f32(w->proj_kernel, x.projT, E, E, st));   // rows [0, E) of Wp: the item half
+    x.filled = 1;
+  }
   h->weights_set = true;
+  return HIERTCN_OK;
+}
+
+int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision) {
+  if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
+  if (precision != HIERTCN_PRECISION_STORAGE16 && precision != HIERTCN_PRECISION_FP32)
+    return fail(HIERTCN_ERR_INVALID, "precision %d: HIERTCN_PRECISION_STORAGE16 (0) or HIERTCN_PRECISION_FP32 (1)", precision);
+  if (precision == HIERTCN_PRECISION_FP32 && !h->x.enabled) {
+    if (h->weights_set)
+      return fail(HIERTCN_ERR_STATE, "the first hiertcn_set_precision(FP32) must precede hiertcn_set_weights (the fp32 copies are filled there)");
+    if (h->train.enabled) return fail(HIERTCN_ERR_STATE, "the fp32 mode is evaluation only: this handle has training enabled");
+    ON_DEVICE(h);
+    hiertcn_ctx* c = h;
+    ModelDev& m = h->m;
+    ExactDev& x = h->x;
+    const int E = m.E;
+#define XALLOC(ptr, count)                                                                                     \
+  do {                                                                                                         \
+    hipError_t e_ = dev_alloc(c, &(ptr), (size_t)(count));                                                     \
+    if (e_ != hipSuccess) return fail(HIERTCN_ERR_HIP, "hipMalloc(%s) failed: %s", #ptr, hipGetErrorString(e_)); \
+  } while (0)
+    XALLOC(x.emb, (size_t)m.N * E);
+    XALLOC(x.outT, (size_t)m.N * m.Clast);
+    for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
+      XALLOC(x.convT[i], (size_t)m.K * cin * m.C[i]);
+      if (cin != m.C[i]) XALLOC(x.resT[i], (size_t)cin * m.C[i]);
+    }
+    if (m.hier) XALLOC(x.projT, (size_t)E * E);
+    x.chunk_rows = exact_chunk_rows(m.N);
+    XALLOC(x.logits, (size_t)x.chunk_rows * m.N);
+#undef XALLOC
+    x.enabled = 1;
+  }
+  if (precision == HIERTCN_PRECISION_FP32 && h->weights_set && !h->x.filled)
+    return fail(HIERTCN_ERR_STATE, "the fp32 copies were allocated after hiertcn_set_weights: set the weights again");
+  h->precision = precision;
+  return HIERTCN_OK;
+}
+
+int hiertcn_get_precision(hiertcn_handle_t h, int32_t* precision) {
+  if (!h || !precision) return fail(HIERTCN_ERR_INVALID, "null argument");
+  *precision = h->precision;
+  return HIERTCN_OK;
+}
+
+int hiertcn_struct_sizes(size_t out[HIERTCN_N_STRUCTS]) {
+  if (!out) return fail(HIERTCN_ERR_INVALID, "null argument");
+  out[0] = sizeof(hiertcn_config_t);
+  out[1] = sizeof(hiertcn_weights_t);
+  out[2] = sizeof(hiertcn_score_out_t);
+  out[3] = sizeof(hiertcn_gmm_config_t);
+  out[4] = sizeof(hiertcn_gmm_weights_t);
   return HIERTCN_OK;
 }
 
@@ -284,12 +355,14 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
     if (!(h)->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_set_weights has not been called"); \
   } while (0);                                                                \
   ON_DEVICE(h)
+#define IS_EXACT(h) ((h)->precision == HIERTCN_PRECISION_FP32)
 
 int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_sessions, int32_t L, float* pooled, void* stream) {
   CHECK_READY(h);
   if (!h->m.hier) return fail(HIERTCN_ERR_STATE, "session_pool is a model_hier operation");
   if (!y_ids || !pooled || n_sessions < 0 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, reinterpret_cast<hipStream_t>(stream)));
+  if (IS_EXACT(h)) HIP_TRY(launch_xsession_pool(h->m, h->x, y_ids, n_sessions, L, pooled, reinterpret_cast<hipStream_t>(stream)));
+  else HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
 
@@ -312,25 +385,31 @@ int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask,
 
 size_t hiertcn_tcn_workspace_bytes(hiertcn_handle_t h, int64_t n_sessions, int32_t L) {
   if (!h || n_sessions < 0 || L < 1) return 0;
+  if (IS_EXACT(h)) return exact_tcn_workspace_bytes(h->m, n_sessions, L);
   return tcn_workspace_bytes(h->m, n_sessions, L);
 }
 
 int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* sproj, int64_t n_sessions, int32_t L,
-                        uint16_t* hidden, void* workspace, size_t workspace_bytes, void* stream) {
+                        void* hidden, void* workspace, size_t workspace_bytes, void* stream) {
   CHECK_READY(h);
   if (!x_ids || !hidden || n_sessions < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (L < 1 || L > 4096) return fail(HIERTCN_ERR_INVALID, "L=%d out of range 1..4096", L);
   if (h->m.hier && !sproj) return fail(HIERTCN_ERR_INVALID, "sproj is required for hier models (run hiertcn_gru_scan first)");
-  const size_t need = tcn_workspace_bytes(h->m, n_sessions, L);
+  const size_t need = IS_EXACT(h) ? exact_tcn_workspace_bytes(h->m, n_sessions, L) : tcn_workspace_bytes(h->m, n_sessions, L);
   if (need > 0) {
     if (!workspace || workspace_bytes < need) return fail(HIERTCN_ERR_WORKSPACE, "tcn workspace %zu < required %zu bytes", workspace_bytes, need);
     if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   }
-  HIP_TRY(launch_tcn_forward(h->m, x_ids, h->m.hier ? sproj : nullptr, n_sessions, L, hidden, workspace, reinterpret_cast<hipStream_t>(stream)));
+  if (IS_EXACT(h))
+    HIP_TRY(launch_exact_tcn(h->m, h->x, x_ids, h->m.hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<float*>(hidden), workspace,
+                             reinterpret_cast<hipStream_t>(stream)));
+  else
+    HIP_TRY(launch_tcn_forward(h->m, x_ids, h->m.hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<uint16_t*>(hidden), workspace,
+                               reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
 
-static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+static int score_timed(hiertcn_handle_t h, const void* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                        hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr, float* split_scratch = nullptr) {
   size_t slot = 0;
   const bool timing = h->timing;
@@ -345,7 +424,8 @@ static int score_timed(hiertcn_handle_t h, const uint16_t* hidden, const int32_t
     slot = h->ev_used++;
     HIP_TRY(hipEventRecord(h->ev_begin[slot], st));
   }
-  HIP_TRY(launch_score(h->m, hidden, y, R, out, nullptr, st, row_map, n_rows_dev, split_scratch));
+  if (IS_EXACT(h)) HIP_TRY(launch_exact_score(h->m, h->x, reinterpret_cast<const float*>(hidden), y, R, out, st));
+  else HIP_TRY(launch_score(h->m, reinterpret_cast<const uint16_t*>(hidden), y, R, out, nullptr, st, row_map, n_rows_dev, split_scratch));
   if (timing) HIP_TRY(hipEventRecord(h->ev_end[slot], st));
   return HIERTCN_OK;
 }
@@ -358,7 +438,7 @@ static int check_topk(const hiertcn_ctx* h, const hiertcn_score_out_t* o) {
   return HIERTCN_OK;
 }
 
-int hiertcn_score_fused(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y_ids, int64_t R, const hiertcn_score_out_t* out,
+int hiertcn_score_fused(hiertcn_handle_t h, const void* hidden, const int32_t* y_ids, int64_t R, const hiertcn_score_out_t* out,
                         void* stream) {
   CHECK_READY(h);
   if (!hidden || !y_ids || !out || R < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
@@ -366,10 +446,11 @@ int hiertcn_score_fused(hiertcn_handle_t h, const uint16_t* hidden, const int32_
   return score_timed(h, hidden, y_ids, R, out, reinterpret_cast<hipStream_t>(stream));
 }
 
-int hiertcn_score_logits(hiertcn_handle_t h, const uint16_t* hidden, int64_t R, float* logits, void* stream) {
+int hiertcn_score_logits(hiertcn_handle_t h, const void* hidden, int64_t R, float* logits, void* stream) {
   CHECK_READY(h);
   if (!hidden || !logits || R < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  HIP_TRY(launch_score(h->m, hidden, nullptr, R, nullptr, logits, reinterpret_cast<hipStream_t>(stream)));
+  if (IS_EXACT(h)) HIP_TRY(launch_exact_logits(h->m, h->x, reinterpret_cast<const float*>(hidden), R, logits, reinterpret_cast<hipStream_t>(stream)));
+  else HIP_TRY(launch_score(h->m, reinterpret_cast<const uint16_t*>(hidden), nullptr, R, nullptr, logits, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
 
@@ -388,16 +469,16 @@ struct EvalWs {
   size_t pooled, sproj, hidden, rank, ce, tgt, gru, tcn, map, nvalid, cscratch, split, total;
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
+static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L, bool exact = false) {
   EvalWs w;
   size_t off = 0;
   w.pooled = off; off += al256((size_t)B * S * m.E * sizeof(float));
   w.sproj = off;  off += al256((size_t)B * S * m.E * sizeof(float));
-  w.hidden = off; off += al256((size_t)B * S * L * m.Clast * sizeof(uint16_t));
+  w.hidden = off; off += al256((size_t)B * S * L * m.Clast * (exact ? sizeof(float) : sizeof(uint16_t)));
   w.rank = off;   off += al256((size_t)B * S * L * sizeof(int32_t));
   w.ce = off;     off += al256((size_t)B * S * L * sizeof(float));
   w.gru = off;    off += al256(m.hier ? gru_workspace_bytes(m, (int)B, (int)S) : 0);
-  w.tcn = off;    off += al256(tcn_workspace_bytes(m, B * S, (int)L));
+  w.tcn = off;    off += al256(exact ? exact_tcn_workspace_bytes(m, B * S, (int)L) : tcn_workspace_bytes(m, B * S, (int)L));
   w.map = off;    off += al256((size_t)B * S * L * sizeof(int32_t));           // ragged batches: rows that carry a target
   w.nvalid = off; off += al256(sizeof(int32_t));
   w.cscratch = off; off += al256(((size_t)B * S * L / 1024 + 2) * sizeof(int32_t));
@@ -409,7 +490,7 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L) {
 
 size_t hiertcn_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t L) {
   if (!h || B < 0 || S < 0 || L < 0) return 0;
-  return eval_ws(h->m, B, S, L).total;
+  return eval_ws(h->m, B, S, L, IS_EXACT(h)).total;
 }
 
 int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
@@ -421,14 +502,15 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   if (hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
   if (!hier && S != 1) return fail(HIERTCN_ERR_INVALID, "single-level model_tcn: one sequence per lane (S must be 1, L = T)");
   if (L < 1 || L > 4096) return fail(HIERTCN_ERR_INVALID, "L=%d out of range 1..4096", L);
-  const EvalWs w = eval_ws(h->m, B, S, L);
+  const bool exact = IS_EXACT(h);
+  const EvalWs w = eval_ws(h->m, B, S, L, exact);
   if (workspace_bytes < w.total) return fail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.total);
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
   float* pooled = reinterpret_cast<float*>(ws + w.pooled);
   float* sproj = reinterpret_cast<float*>(ws + w.sproj);
-  uint16_t* hidden = reinterpret_cast<uint16_t*>(ws + w.hidden);
+  void* hidden = ws + w.hidden;
   hiertcn_score_out_t so;
   memset(&so, 0, sizeof(so));
   if (score_out) so = *score_out;
@@ -440,10 +522,21 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   // scan first (it never reads the low level's output: model_hier.py:83-93), then every
   // (user, session) low-level problem is independent.
   if (hier) {
-    HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
+    if (exact) HIP_TRY(launch_xsession_pool(h->m, h->x, y_ids, n_sessions, L, pooled, st));
+    else HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
     HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
   }
-  HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, hidden, ws + w.tcn, st));
+  if (exact) {   // fp32 end to end: every row is scored on materialised logits; rows without a target come out as 0 / 0 / 0..k-1 there
+    HIP_TRY(launch_exact_tcn(h->m, h->x, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<float*>(hidden), ws + w.tcn, st));
+    int rc = score_timed(h, hidden, y_ids, R, &so, st);
+    if (rc != HIERTCN_OK) return rc;
+    if (metrics8) {
+      if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+      HIP_TRY(launch_metrics_scratch(h->m, so.rank, so.ce, y_ids, B, S * L, metrics8, h->metric_scratch, st));
+    }
+    return HIERTCN_OK;
+  }
+  HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<uint16_t*>(hidden), ws + w.tcn, st));
   // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): zero the outputs, list the rows that do
   // carry a target and score only those (a ragged XING batch is mostly padding: slot width = longest session of the slot).
   int32_t* row_map = reinterpret_cast<int32_t*>(ws + w.map);
@@ -471,6 +564,7 @@ int hiertcn_train_enable(hiertcn_handle_t h) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (h->train.enabled) return HIERTCN_OK;
   if (h->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_train_enable must precede hiertcn_set_weights (the fp32 masters are filled there)");
+  if (h->x.enabled) return fail(HIERTCN_ERR_STATE, "this handle is in the fp32 evaluation mode (hiertcn_set_precision): training runs on 16-bit storage handles");
   ON_DEVICE(h);
   HIP_TRY(train_enable(h->m, h->train));
   return HIERTCN_OK;

@@ -131,6 +131,7 @@ struct LowGruBufs {
   int n_states;       // 2 (ping-pong) or L + 1
   float* rec;         // per layer (keep_all: per step and layer): gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
   int keep_all;
+  float* hidden32;    // exact numerics mode (exact.hip): uf is already filled with the fp32 projection and the outputs go here as fp32 rows
 };
 size_t low_gru_save_floats(const ModelDev& m, int64_t n_sess, int L);
 hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden,

@@ -1,0 +1,41 @@
+// The exact (fp32 end-to-end) numerics mode: fp32 copies of the tensors the production path stores in 16 bits, and its launchers (exact.hip).
+#pragma once
+#include "common.h"
+
+struct ExactDev {
+  int enabled;          // fp32 copies allocated (hiertcn_set_precision before hiertcn_set_weights)
+  int filled;           // ... and filled by hiertcn_set_weights
+  float* emb;           // [N][E], row 0 zeroed
+  float* projT;         // [E out][E in] = transpose(Wp[:E])                  (hier only)
+  float* convT[HIERTCN_MAX_BLOCKS];   // [K][Cout][Cin]
+  float* resT[HIERTCN_MAX_BLOCKS];    // [Cout][Cin] or null
+  float* outT;          // [N][Clast]
+  float* logits;        // [chunk_rows][N] scratch of the scoring layer (owned by the handle: hiertcn_score_fused takes no workspace)
+  int64_t chunk_rows;
+};
+
+enum { XEPI_LINEAR = 0, XEPI_BLOCK = 1 };
+
+struct XGemm {
+  const float* A; int64_t lda;        // activations [M][lda], or (ids != null) an item table gathered by ids[m]
+  const int32_t* ids; int n_tab;      // gather: ids outside (0, n_tab) are zero rows
+  const float* Wt;                    // [taps][N][Cin]  (output-major)
+  int taps, dil, L;                   // causal taps inside sequences of L rows (L == 0: plain rows)
+  int Cin;                            // multiple of 32
+  int64_t M; int N;
+  const float* bias;                  // [N] or null
+  const float* seq_init; int Lseq;    // [M / Lseq][N] or null: added per sequence (the state half of the input projection)
+  const float* res; int64_t ldres;    // XEPI_BLOCK: residual rows
+  float* out; int64_t ldo;
+  int epi;
+};
+
+hipError_t launch_xgemm(const XGemm& g, hipStream_t st);
+hipError_t launch_xsession_pool(const ModelDev& m, const ExactDev& x, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
+size_t exact_tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
+hipError_t launch_exact_tcn(const ModelDev& m, const ExactDev& x, const int32_t* ids, const float* sproj, int64_t n_sessions, int L, float* hidden,
+                            void* workspace, hipStream_t st);
+int64_t exact_chunk_rows(int N);
+hipError_t launch_exact_logits(const ModelDev& m, const ExactDev& x, const float* hidden, int64_t R, float* logits, hipStream_t st);
+hipError_t launch_exact_score(const ModelDev& m, const ExactDev& x, const float* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                              hipStream_t st);

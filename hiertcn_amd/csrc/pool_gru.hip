@@ -100,6 +100,7 @@ struct GemmArgs {
   const int32_t* seq_len; int tstep;   // CAND, optional (low-level GRU under dynamic_rnn): row m is active iff tstep < seq_len[m];
                                        //   inactive rows keep their old state, and their output row is zero
   uint16_t* hid_out; int64_t ldho;     // CAND, optional: the layer's output as a 16-bit row (scoring operand), zero when inactive
+  float* hid_out32;                    // ... or as an fp32 row (the exact numerics mode, exact.hip); same row stride ldho
   int H;
   int rowmap_S;                        // STORE: >0 -> row m = b*(S+1)+s maps to out row b*S+s, s == S skipped
   const float* add_tab; int add_ld; int add_n;   // optional: + add_tab[id][n] for id = add_ids[m * add_ids_ld] in (0, add_n) -- the product of a
@@ -248,6 +249,9 @@ __global__ __launch_bounds__(256) void k_gemm_f32(const GemmPair gp) {
           o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
           *reinterpret_cast<uint2*>(g.hid_out + (int64_t)m * g.ldho + n0) = o;
         }
+        if (g.hid_out32)
+          *reinterpret_cast<float4*>(g.hid_out32 + (int64_t)m * g.ldho + n0) =
+              active ? make_float4(hn[0], hn[1], hn[2], hn[3]) : make_float4(0.f, 0.f, 0.f, 0.f);
         continue;
       }
       *reinterpret_cast<float4*>(g.out2 + (int64_t)m * g.ldo2 + n0) = make_float4(hn[0] * mk, hn[1] * mk, hn[2] * mk, hn[3] * mk);
@@ -411,6 +415,21 @@ __global__ __launch_bounds__(256) void k_rows_f32_and_len(const uint16_t* __rest
   if (lane == 0) seq_len[sess] = cnt;
 }
 
+// exact numerics mode: the projected rows arrive as fp32 (exact.hip); only the lengths are taken here
+__global__ __launch_bounds__(256) void k_len_f32(const float* __restrict__ uf, int64_t n_sess, int L, int E, int32_t* __restrict__ seq_len) {
+  const int lane = threadIdx.x & 63;
+  const int64_t sess = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sess >= n_sess) return;
+  int cnt = 0;
+  for (int t = 0; t < L; t++) {
+    const int64_t r = sess * L + t;
+    int nz = 0;
+    for (int c = lane; c < E; c += 64) nz |= (uf[r * E + c] != 0.f) ? 1 : 0;
+    cnt += __any(nz) ? 1 : 0;
+  }
+  if (lane == 0) seq_len[sess] = cnt;
+}
+
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
   // embedded rows + u (16-bit) + u (fp32) + lengths + two state buffers + one (gates | r*h | cand | out) record per layer
   const size_t R = (size_t)n_sess * L;
@@ -431,15 +450,20 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
   const int64_t R = n_sess * L;
   const size_t cell = (size_t)n_sess * 5 * H;   // gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
   hipError_t e;
-  if ((e = launch_embed_rows(m, x, R, b.a_emb, st)) != hipSuccess) return e;
-  {  // 'emb' projection of [e, state] (model_gru.py:46), rounded to the 16-bit storage type like the TCN's input
-    LayerArgs a = {};
-    a.in = b.a_emb; a.out = b.u16; a.W = m.projT; a.seq_init = sproj;
-    a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
-    if ((e = launch_tcn_layer(a, st)) != hipSuccess) return e;
+  if (b.hidden32) {   // exact numerics mode: b.uf already holds the fp32 projection (exact.hip)
+    hipLaunchKernelGGL(k_len_f32, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.uf, n_sess, L, E, b.seq_len);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+  } else {
+    if ((e = launch_embed_rows(m, x, R, b.a_emb, st)) != hipSuccess) return e;
+    {  // 'emb' projection of [e, state] (model_gru.py:46), rounded to the 16-bit storage type like the TCN's input
+      LayerArgs a = {};
+      a.in = b.a_emb; a.out = b.u16; a.W = m.projT; a.seq_init = sproj;
+      a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
+      if ((e = launch_tcn_layer(a, st)) != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state (model_gru.py:52: initial_state=None)
   for (int t = 0; t < L; t++) {
     const float* s_old = b.states + (size_t)(t % b.n_states) * n_sess * HT;
@@ -468,7 +492,10 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
       g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
       g.gates = gates; g.ldg = 2 * H;
       g.seq_len = b.seq_len; g.tstep = t;
-      if (l == m.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
+      if (l == m.nl - 1) {
+        g.ldho = (int64_t)L * H;
+        if (b.hidden32) g.hid_out32 = b.hidden32 + (size_t)t * H; else g.hid_out = hidden + (size_t)t * H;
+      }
       if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
     }
   }
@@ -490,6 +517,7 @@ hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* spro
   b.n_states = 2;
   b.rec = reinterpret_cast<float*>(take((size_t)m.nl * n_sess * 5 * m.H * 4));
   b.keep_all = 0;
+  b.hidden32 = nullptr;
   return launch_low_gru_bufs(m, x, sproj, n_sess, L, hidden, b, st);
 }
 

@@ -85,12 +85,17 @@ class Engine:
     def __init__(self, args, hier: bool = True, device: Optional[torch.device] = None, train: bool = False,
                  dtype: Optional[str] = None):
         """dtype: storage type of the 16-bit tensors: 'bf16' (default; args.storage_dtype overrides) or 'fp16' (the
-        libhiertcn_gfx950_f16.so build: BASELINE.json configs[3], inference only)."""
+        libhiertcn_gfx950_f16.so build: BASELINE.json configs[3], inference only); 'fp32' = the exact numerics mode
+        (hiertcn_set_precision: everything fp32 as the reference computes it, model_tcn.py:35-41; evaluation only, for
+        parity runs on trained checkpoints -- the mode that meets "fp32 logits within 1e-3" at any logit scale)."""
         dtype = dtype or getattr(args, "storage_dtype", "bf16")
-        if dtype not in ("bf16", "fp16"):
-            raise HierTCNError(f"storage dtype {dtype!r}: 'bf16' or 'fp16'")
+        if dtype not in ("bf16", "fp16", "fp32"):
+            raise HierTCNError(f"storage dtype {dtype!r}: 'bf16', 'fp16' or 'fp32' (exact mode)")
+        if dtype == "fp32" and train:
+            raise HierTCNError("dtype='fp32' is the exact EVALUATION mode; training runs on bf16 storage with fp32 masters")
         self.f16 = dtype == "fp16"
-        self.act_dtype = torch.float16 if self.f16 else torch.bfloat16
+        self.exact = dtype == "fp32"
+        self.act_dtype = torch.float32 if self.exact else (torch.float16 if self.f16 else torch.bfloat16)
         self.lib = _lib.load(f16=self.f16)
         if not torch.cuda.is_available():
             raise HierTCNError("no GPU visible: the HierTCN compute path is HIP-only (no CPU fallback)")
@@ -108,6 +113,8 @@ class Engine:
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             self._ck(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
+            if self.exact:   # allocates the fp32 copies that set_weights fills; must precede set_weights
+                self._ck(self.lib.hiertcn_set_precision(self._h, _lib.PRECISION_FP32))
         self.train = bool(train)
         if self.train:   # fp32 masters / gradients / Adam moments; must precede set_weights
             with torch.cuda.device(self.device):
@@ -136,6 +143,16 @@ class Engine:
     @staticmethod
     def _stream():
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+    def set_precision(self, dtype: str):
+        """Switch an Engine built with dtype='fp32' between the exact mode ('fp32') and the production kernels on 16-bit storage
+        ('bf16' / 'fp16', whichever library the handle was built from) -- both weight sets live on the handle."""
+        want_exact = dtype == "fp32"
+        if not want_exact and dtype != ("fp16" if self.f16 else "bf16"):
+            raise HierTCNError(f"precision {dtype!r}: this handle offers 'fp32' and {'fp16' if self.f16 else 'bf16'!r}")
+        self._ck(self.lib.hiertcn_set_precision(self._h, _lib.PRECISION_FP32 if want_exact else _lib.PRECISION_STORAGE16))
+        self.exact = want_exact
+        self.act_dtype = torch.float32 if want_exact else (torch.float16 if self.f16 else torch.bfloat16)
 
     # ---------------------------------------------------------------------------------------
     def set_weights(self, params: Dict[str, "np.ndarray | torch.Tensor"], root: Optional[str] = None):

@@ -32,6 +32,10 @@
  *     model.py:62: mask_y = sign(y_id)).  Batch layout is user-major:
  *       x_ids, y_ids [B][S][L] ; mask [B][S] ; state [B][H*nl] ; rows r = (b*S+s)*L+t.
  *   - "bf16" buffers are uint16_t holding IEEE bfloat16 bit patterns.
+ *   - numerics: by default the item tables, conv kernels, scoring kernel and the activations between layers are STORED in 16 bits
+ *     (bfloat16; IEEE half in libhiertcn_gfx950_f16.so) and accumulated in fp32.  hiertcn_set_precision(h, HIERTCN_PRECISION_FP32)
+ *     selects the exact mode: everything fp32, as the reference computes it (model_tcn.py:35-41) -- the mode that meets "fp32
+ *     logits within 1e-3" at the logit scale of a trained model.  `hidden` buffers then hold float instead of uint16_t.
  */
 #ifndef HIERTCN_H_
 #define HIERTCN_H_
@@ -43,7 +47,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 6
+#define HIERTCN_ABI_VERSION 7
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -131,6 +135,25 @@ int hiertcn_get_config(hiertcn_handle_t h, hiertcn_config_t* out);
 
 int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* stream);
 
+/* Numerics mode of the evaluation path (session_pool, gru_scan, tcn_forward, score_fused, score_logits, forward_eval).
+ *   HIERTCN_PRECISION_STORAGE16 (default)  16-bit storage / fp32 accumulate: the production kernels.
+ *   HIERTCN_PRECISION_FP32                 fp32 end to end on v_mfma_f32_32x32x2_f32, logits materialised per row chunk; rank / cross
+ *                                          entropy / ranked top-k taken on the materialised fp32 values (loss.py:21,120,179).  Every
+ *                                          `hidden` argument is then float [R][C_last].  Evaluation only: the training entry points
+ *                                          return HIERTCN_ERR_STATE.  For parity runs, not for throughput (~20x slower).
+ * The first switch to FP32 must precede hiertcn_set_weights (it allocates the fp32 copies that set_weights fills, plus a logits scratch
+ * of <= 1 GiB owned by the handle); after that the mode may be switched back and forth between calls. */
+#define HIERTCN_PRECISION_STORAGE16 0
+#define HIERTCN_PRECISION_FP32 1
+int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision);
+int hiertcn_get_precision(hiertcn_handle_t h, int32_t* precision);
+
+/* sizeof() of the five structs of this header as the LIBRARY was compiled, in declaration order: hiertcn_config_t, hiertcn_weights_t,
+ * hiertcn_score_out_t, hiertcn_gmm_config_t, hiertcn_gmm_weights_t -- lets a binding written in another language verify its own
+ * struct definitions at load time (tests/test_cabi_load.py does, for hiertcn_amd/_lib.py and for the stub in INTEGRATION.md). */
+#define HIERTCN_N_STRUCTS 5
+int hiertcn_struct_sizes(size_t out[HIERTCN_N_STRUCTS]);
+
 /* model_hier.py:83-85.  y_ids [n_sessions][L] -> pooled [n_sessions][E] fp32. */
 int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_sessions, int32_t L,
                          float* pooled, void* stream);
@@ -149,7 +172,7 @@ int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask,
 
 /* model.py:59-61 + model_hier.py:50 + model_tcn.py:35-36: ids -> last TCN activations.
  * x_ids [n_sessions][L]; sproj [n_sessions][E] or NULL (single-level) ->
- * hidden [n_sessions*L][C_last] bf16.
+ * hidden [n_sessions*L][C_last]: uint16_t bit patterns of the storage type (float in HIERTCN_PRECISION_FP32).
  * (widths: emb_dim and tcn_channel are multiples of 32; the last channel count, which the scoring kernels are built
  *  for, is one of 64, 128, 256, 512.)
  * Two device paths, same results: the fused kernel (every width == emb_dim in {64,128,256}, L <= 32:
@@ -159,14 +182,14 @@ int hiertcn_gru_scan(hiertcn_handle_t h, const float* pooled, const float* mask,
  * which needs hiertcn_tcn_workspace_bytes() bytes of 256-byte aligned scratch. */
 size_t hiertcn_tcn_workspace_bytes(hiertcn_handle_t h, int64_t n_sessions, int32_t L);
 int hiertcn_tcn_forward(hiertcn_handle_t h, const int32_t* x_ids, const float* sproj, int64_t n_sessions,
-                        int32_t L, uint16_t* hidden, void* workspace, size_t workspace_bytes, void* stream);
+                        int32_t L, void* hidden, void* workspace, size_t workspace_bytes, void* stream);
 
 /* model_tcn.py:41 + model.py:105 + loss.py:21,179(,120) fused: logits are never written. */
-int hiertcn_score_fused(hiertcn_handle_t h, const uint16_t* hidden, const int32_t* y_ids, int64_t R,
+int hiertcn_score_fused(hiertcn_handle_t h, const void* hidden, const int32_t* y_ids, int64_t R,
                         const hiertcn_score_out_t* out, void* stream);
 
 /* parity/debug: materialise logits [R][N] fp32 (pre-mask, i.e. model_tcn.py:41's output). */
-int hiertcn_score_logits(hiertcn_handle_t h, const uint16_t* hidden, int64_t R, float* logits, void* stream);
+int hiertcn_score_logits(hiertcn_handle_t h, const void* hidden, int64_t R, float* logits, void* stream);
 
 /* model.py:111-117 + loss.py:189-219.  rank, ce, y_ids are [B][T] (T = S*L); out8 (device, 8
  * doubles) = SUMS over lanes of the per-lane means, ready for a cross-rank all-reduce:

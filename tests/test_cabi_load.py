@@ -34,7 +34,109 @@ def test_header_and_binding_agree(lib):
 
 
 def test_abi_version(lib):
-    assert lib.hiertcn_abi_version() == 6
+    from hiertcn_amd import _lib
+    src = open(os.path.join(ROOT, "include", "hiertcn.h")).read()
+    header_version = int(re.search(r"#define\s+HIERTCN_ABI_VERSION\s+(\d+)", src).group(1))
+    assert lib.hiertcn_abi_version() == header_version == _lib.ABI_VERSION
+    # the documents that quote the version quote the current one
+    integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert re.findall(r"==\s*(\d+)\s*\(HIERTCN_ABI_VERSION\)", integ) == [str(header_version)]
+    design = open(os.path.join(ROOT, "DESIGN.md")).read()
+    assert set(re.findall(r"C-ABI v(\d+)", design)) == {str(header_version)}
+
+
+# ---- struct layouts: header (compiled as C99 by gcc) == hiertcn_amd/_lib.py == the built library == the stubs in INTEGRATION.md ----------
+C_STRUCTS = ["hiertcn_config_t", "hiertcn_weights_t", "hiertcn_score_out_t", "hiertcn_gmm_config_t", "hiertcn_gmm_weights_t"]
+
+
+def _binding_structs():
+    from hiertcn_amd import _lib
+    return dict(zip(C_STRUCTS, [_lib.Config, _lib.Weights, _lib.ScoreOut, _lib.GmmConfig, _lib.GmmWeights]))
+
+
+def _header_fields():
+    """{struct: [field names in declaration order]} parsed from the header text."""
+    src = open(os.path.join(ROOT, "include", "hiertcn.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    out = {}
+    for body, name in re.findall(r"typedef\s+struct\s*\{(.*?)\}\s*(hiertcn_\w+_t)\s*;", src, flags=re.S):
+        out[name] = [re.match(r".*?(\w+)\s*(\[[^\]]*\])?$", decl.strip(), flags=re.S).group(1)
+                     for decl in body.split(";") if decl.strip()]
+    return out
+
+
+@pytest.fixture(scope="module")
+def c_layouts(tmp_path_factory):
+    """sizeof / offsetof of every field of the header's structs, from a C99 program compiled with gcc."""
+    import shutil
+    import subprocess
+    if not shutil.which("gcc"):
+        pytest.skip("gcc not available")
+    fields = _header_fields()
+    assert sorted(fields) == sorted(C_STRUCTS), fields.keys()
+    d = tmp_path_factory.mktemp("layout")
+    lines = ['#include <stddef.h>', '#include <stdio.h>', '#include "hiertcn.h"', "int main(void) {"]
+    for st in C_STRUCTS:
+        lines.append(f'  printf("{st} %zu\\n", sizeof({st}));')
+        for f in fields[st]:
+            lines.append(f'  printf("{st}.{f} %zu\\n", offsetof({st}, {f}));')
+    lines += ["  return 0;", "}"]
+    (d / "layout.c").write_text("\n".join(lines))
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-pedantic", "-I", os.path.join(ROOT, "include"), str(d / "layout.c"), "-o", str(d / "layout")],
+                   check=True)
+    out = subprocess.run([str(d / "layout")], check=True, capture_output=True, text=True).stdout
+    return {k: int(v) for k, v in (ln.split() for ln in out.splitlines())}, fields
+
+
+def _check_struct(cls, st, layouts, fields):
+    assert [f[0] for f in cls._fields_] == fields[st], (st, [f[0] for f in cls._fields_], fields[st])
+    assert C.sizeof(cls) == layouts[st], (st, C.sizeof(cls), layouts[st])
+    for f in fields[st]:
+        assert getattr(cls, f).offset == layouts[f"{st}.{f}"], (st, f)
+
+
+def test_struct_layouts_header_equals_binding_equals_library(lib, c_layouts):
+    from hiertcn_amd import _lib
+    layouts, fields = c_layouts
+    for st, cls in _binding_structs().items():
+        _check_struct(cls, st, layouts, fields)
+    sz = (C.c_size_t * _lib.N_STRUCTS)()
+    assert lib.hiertcn_struct_sizes(sz) == 0
+    assert list(sz) == [layouts[st] for st in C_STRUCTS]
+    assert _lib.load(f16=True).hiertcn_struct_sizes(sz) == 0 and list(sz) == [layouts[st] for st in C_STRUCTS]
+
+
+def integration_md_stubs(text):
+    """The ctypes.Structure classes of INTEGRATION.md's python blocks, executed: {C struct name (from the trailing comment): class}."""
+    found = {}
+    for block in re.findall(r"```python\n(.*?)```", text, flags=re.S):
+        for m in re.finditer(r"^class\s+(\w+)\(C\.Structure\):\s*#\s*(hiertcn_\w+_t)\n(?:[ \t]+.*\n)+", block, flags=re.M):
+            ns = {"C": C}
+            exec(m.group(0), ns)
+            found[m.group(2)] = ns[m.group(1)]
+    return found
+
+
+def test_integration_md_stubs_match_the_header(c_layouts):
+    layouts, fields = c_layouts
+    stubs = integration_md_stubs(open(os.path.join(ROOT, "INTEGRATION.md")).read())
+    assert {"hiertcn_config_t", "hiertcn_score_out_t", "hiertcn_gmm_config_t"} <= set(stubs), stubs.keys()
+    for st, cls in stubs.items():
+        _check_struct(cls, st, layouts, fields)
+
+
+def test_a_stale_stub_is_caught(c_layouts):
+    """The round-2 stub of hiertcn_gmm_config_t (it stopped at `sigma`: 56 bytes against the header's 68) must fail the check above."""
+    layouts, fields = c_layouts
+    stale = """```python
+class GmmConfig(C.Structure):                  # hiertcn_gmm_config_t
+    _fields_ = [("item_num", C.c_int32), ("output_dim", C.c_int32), ("num_mixture", C.c_int32), ("kernel_size", C.c_int32),
+                ("n_blocks", C.c_int32), ("channels", C.c_int32 * 8), ("sigma", C.c_float)]
+```"""
+    stubs = integration_md_stubs(stale)
+    assert list(stubs) == ["hiertcn_gmm_config_t"] and C.sizeof(stubs["hiertcn_gmm_config_t"]) == 56
+    with pytest.raises(AssertionError):
+        _check_struct(stubs["hiertcn_gmm_config_t"], "hiertcn_gmm_config_t", layouts, fields)
 
 
 def test_create_rejects_bad_config_without_touching_the_gpu(lib):

@@ -1,0 +1,278 @@
+"""-m gpu: the EXACT numerics mode (Engine(dtype='fp32') = hiertcn_set_precision(h, HIERTCN_PRECISION_FP32); csrc/exact.hip) against
+the exact oracle on UNROUNDED fp32 weights, at the logit scale of a TRAINED model.
+
+BASELINE.json's parity statement is "ranked top-K indices bit-exact, fp32 logits within 1e-3" on a TF-trained XING model.  The production
+path stores tables / kernels / activations in 16 bits, which costs ~2e-3 of the logit SCALE: fine at glorot scale (|z| <= 0.34, 7.4e-4
+measured, tests/test_gpu_xing_shape.py) and 20-60x outside the tolerance at |z| ~ 10-30.  The exact mode computes everything in fp32 like
+the reference's graph (model_tcn.py:35-41, loss.py:21,120,179) and is what these tests hold to 1e-3 at |z| = 10 and |z| = 30, together with
+rank and top-10 equality; the same tests RECORD the 16-bit path's error at those scales (gpurun_out/exact_mode_errors.json).
+"""
+import json
+import os
+
+import numpy as np
+import pytest
+
+from oracle import hiertcn_oracle as O
+from tests.gpu_common import as_lists, make_batch, make_params, small_args
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).to("cuda:0")  # noqa: E731
+
+
+def _trained_like(p, args, root, conv_gain=1.6, emb_gain=3.0):
+    """A glorot model pushed towards a trained one's magnitudes: larger item embeddings and conv kernels (activations of order 1 instead
+    of 0.05).  The scoring layer is scaled separately, per target logit scale."""
+    q = {k: np.array(v, np.float32) for k, v in p.items()}
+    for k in q:
+        if k.endswith("/emb/kernel") and q[k].shape[0] == int(args.item_num):
+            q[k] *= emb_gain
+        if "/conv1/kernel" in k:
+            q[k] *= conv_gain
+    return q
+
+
+def _record(name, payload):
+    os.makedirs("gpurun_out", exist_ok=True)
+    path = "gpurun_out/exact_mode_errors.json"
+    try:
+        with open(path) as f:
+            all_ = json.load(f)
+    except (OSError, ValueError):
+        all_ = {}
+    all_[name] = payload
+    with open(path, "w") as f:
+        json.dump(all_, f, indent=1, sort_keys=True)
+
+
+@pytest.mark.parametrize("zscale", [10.0, 30.0])
+def test_exact_mode_at_trained_logit_scale_xing_shape(zscale):
+    """BASELINE.json configs[1]'s shape (XING catalogue 20,778, d = 256, 32 lanes x 10 slots x 20 steps), the scoring layer scaled so that
+    max |z| = zscale: device logits < 1e-3 of the exact oracle (fp64, unrounded weights), ranks equal, top-10 identical on every row whose
+    oracle gaps exceed twice that row's logit error; the 16-bit path's error at the same scale is recorded and must be >= 10x larger."""
+    from hiertcn_amd.engine import Engine, metrics_dict
+    N, d, B, S, L, K = 20_778, 256, 32, 10, 20, 10
+    args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
+    p = _trained_like(make_params(args), args, "hier/tcn")
+    rng = np.random.default_rng(20778)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=True, zipf=True)
+    st0 = (0.2 * rng.standard_normal((B, 2 * d))).astype(np.float32)
+    xl, yl, ml = as_lists(x, y, mask)
+    yy = y.reshape(B, S * L).astype(np.int64)
+    valid = yy > 0
+    # exact oracle: hidden once, then the scoring layer at the requested scale (z is linear in (Wo, bo))
+    hid64, st_ref = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64, return_hidden=True)
+    Wo, bo = p["hier/tcn/dense/kernel"].astype(np.float64), p["hier/tcn/dense/bias"].astype(np.float64)
+    z0 = hid64 @ Wo + bo
+    f = np.float32(zscale / np.abs(z0[valid]).max())
+    p["hier/tcn/dense/kernel"] = (p["hier/tcn/dense/kernel"] * f).astype(np.float32)
+    p["hier/tcn/dense/bias"] = (p["hier/tcn/dense/bias"] * f).astype(np.float32)
+    del z0
+    exact = hid64 @ p["hier/tcn/dense/kernel"].astype(np.float64) + p["hier/tcn/dense/bias"].astype(np.float64)   # [B, S*L, N]
+    zmax = float(np.abs(exact[valid]).max())
+    assert abs(zmax - zscale) < 0.05 * zscale
+
+    eng = Engine(args, hier=True, dtype="fp32")
+    eng.set_weights(p)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True, topk=K)
+    m = metrics_dict(out["metrics8"])
+    assert np.abs(out["state"].cpu().numpy() - st_ref).max() < 1e-5
+
+    def logits_now():
+        pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+        sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+        hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+        assert hid.dtype == eng.act_dtype
+        return eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+
+    logits = logits_now()
+    err = np.abs(logits - exact)
+    err_row = err.max(-1)
+    e_max, e_mean = float(err[valid].max()), float(err[valid].mean())
+    print("fp32 mode, |z| max %.1f: logits vs exact oracle max %.3e mean %.3e" % (zmax, e_max, e_mean))
+    assert e_max < 1e-3, e_max                                   # the north star's tolerance, at a trained model's logit scale
+
+    # ranks (loss.py:179): equal on every row where no item sits within twice the row's logit error of the target (then the strict
+    # comparison cannot have flipped); that must be nearly every row, and the others stay inside the bracket
+    ref = O.masked_loss_and_metrics(exact, yy, N)
+    rk = out["rank"].cpu().numpy().reshape(B, S * L)
+    rk_ref = np.asarray(ref["ranks"]).astype(np.int64)
+    tgt = np.take_along_axis(exact, yy[..., None], -1)
+    gap = np.abs(exact - tgt)
+    np.put_along_axis(gap, yy[..., None], np.inf, -1)
+    clear_rank = (gap.min(-1) > 2 * err_row + 1e-7) & valid
+    assert clear_rank.sum() > 0.97 * valid.sum(), (clear_rank.sum(), valid.sum())
+    assert np.array_equal(rk[clear_rank], rk_ref[clear_rank])
+    tol = 2 * err_row[..., None] + 1e-7
+    lo, hi = (exact > tgt + tol).sum(-1), (exact > tgt - tol).sum(-1)
+    assert np.all((rk >= lo)[valid]) and np.all((rk <= hi)[valid])
+    assert np.all(rk[~valid] == 0)
+    n_rank_equal = int((rk == rk_ref)[valid].sum())
+    # cross entropy and the batch metrics
+    ce = out["ce"].cpu().numpy().reshape(B, S * L)
+    assert np.abs(ce - ref["ce"])[valid].max() < 1e-3
+    assert not ce[~valid].any()
+    assert abs(m["loss"] - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"]))
+    for k in ("recall1", "recall5", "recall10", "mrr"):
+        assert abs(m[k] - ref[k]) < 1e-3, (k, m[k], ref[k])
+
+    # ranked top-10 (loss.py:120): identical to the oracle's on every row whose first 11 oracle scores are separated by more than twice
+    # the row's logit error -- nearly every row at this precision -- and on ALL rows the exact top-10 of the device's own logits
+    ti = out["topk_idx"].cpu().numpy().reshape(B, S * L, K)
+    tv = out["topk_val"].cpu().numpy().reshape(B, S * L, K)
+    want = O.top_k_indices(exact.reshape(-1, N), K + 1).reshape(B, S * L, K + 1)
+    top_vals = np.take_along_axis(exact, want.astype(np.int64), -1)
+    clear_top = (np.diff(-top_vals, axis=-1).min(-1) > 2 * err_row + 1e-7) & valid
+    assert clear_top.sum() > 0.97 * valid.sum(), (clear_top.sum(), valid.sum())
+    assert np.array_equal(ti[clear_top], want[clear_top][:, :K])
+    own = O.top_k_indices(logits.reshape(-1, N), K).reshape(B, S * L, K)
+    assert np.array_equal(ti[valid], own[valid])
+    assert np.array_equal(tv[valid], np.take_along_axis(logits, own.astype(np.int64), -1)[valid])
+    assert np.array_equal(ti[~valid], np.broadcast_to(np.arange(K), ti[~valid].shape)) and not tv[~valid].any()
+
+    # the production path (16-bit storage) on the same handle, same weights, same batch: its error at this logit scale, recorded
+    eng.set_precision("bf16")
+    err16 = np.abs(logits_now() - exact)[valid]
+    out16 = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+    rk16 = out16["rank"].cpu().numpy().reshape(B, S * L)
+    print("bf16 storage, |z| max %.1f: logits vs exact oracle max %.3e mean %.3e" % (zmax, err16.max(), err16.mean()))
+    assert err16.max() > 10 * e_max
+    _record("xing_shape_z%d" % int(zscale), dict(
+        z_max=zmax, fp32_max=e_max, fp32_mean=e_mean, bf16_max=float(err16.max()), bf16_mean=float(err16.mean()),
+        rows=int(valid.sum()), fp32_rank_equal=n_rank_equal, bf16_rank_equal=int((rk16 == rk_ref)[valid].sum()),
+        rows_clear_rank=int(clear_rank.sum()), rows_clear_top10=int(clear_top.sum())))
+    eng.set_precision("fp32")
+    assert np.array_equal(logits_now(), logits)          # switching back reproduces the exact mode bit for bit
+    eng.close()
+
+
+def test_exact_mode_single_level_with_downsample_blocks():
+    """model_tcn (model.py:71-73) with Dense down-sample residuals (customized_tcn_cell.py:102-106), T = 70: fp32 mode vs the exact oracle."""
+    from hiertcn_amd.args import make_args
+    from hiertcn_amd.engine import Engine
+    N, T, B = 3000, 70, 6
+    args = make_args([], model_type="hier", item_num=N, emb_dim=64, tcn_channel=[64, 96, 96, 128], kernel_size=3)  # 'hier': skips args_adjust's override
+    args.model_type = "tcn"
+    p = O.init_params(args, seed=5, model="tcn")
+    rng = np.random.default_rng(5)
+    for k in p:
+        if k.endswith("/bias"):
+            p[k] = (0.1 * rng.standard_normal(p[k].shape)).astype(np.float32)
+        if "/conv1/kernel" in k:
+            p[k] = (p[k] * 2.5).astype(np.float32)
+        if k.endswith("tcn/dense/kernel"):
+            p[k] = (p[k] * 12).astype(np.float32)
+    ids = rng.integers(1, N, (B, T + 1))
+    lens = rng.integers(5, T + 1, B)
+    ids = ids * (np.arange(T + 1)[None] < lens[:, None] + 1)
+    x, y = ids[:, :-1].astype(np.int32), ids[:, 1:].astype(np.int32)
+    eng = Engine(args, hier=False, dtype="fp32")
+    eng.set_weights(p)
+    hid = eng.tcn_forward(dev(x), None)
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, T, N)
+    exact = O.model_tcn(args, x.astype(np.int64), p, "tcn", O.EXACT64)
+    assert np.abs(exact).max() > 5.0
+    err = np.abs(logits - exact).max()
+    assert err < 2e-5 * np.abs(exact).max(), err
+    out = eng.forward_eval(dev(x[:, None]), dev(y[:, None]), None, None, want_rows=True, topk=5)
+    ref = O.masked_loss_and_metrics(exact, y.astype(np.int64), N)
+    valid = y > 0
+    rk = out["rank"].cpu().numpy().reshape(B, T)
+    assert (rk == ref["ranks"])[valid].mean() > 0.99
+    assert np.abs(out["ce"].cpu().numpy().reshape(B, T) - ref["ce"])[valid].max() < 1e-4
+    own = O.top_k_indices(logits.reshape(-1, N), 5).reshape(B, T, 5)
+    assert np.array_equal(out["topk_idx"].cpu().numpy().reshape(B, T, 5)[valid], own[valid])
+    eng.close()
+
+
+def test_exact_mode_hiergru_low_level():
+    """model_low_type='gru' (the reference's default, model_hier.py:67-68 -> model_gru.py:16-63) in the fp32 mode vs the exact oracle,
+    dynamic_rnn's sequence_length quirk included."""
+    from hiertcn_amd.engine import Engine
+    N, d, B, S, L = 1500, 64, 6, 4, 12
+    args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
+    args.model_low_type = "gru"
+    p = O.init_params(args, seed=3)
+    rng = np.random.default_rng(3)
+    for k in p:
+        if k.endswith("dense/kernel"):
+            p[k] = (p[k] * 40).astype(np.float32)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=True)
+    st0 = (0.2 * rng.standard_normal((B, 2 * d))).astype(np.float32)
+    st0[0] = 0          # a zero carried state: the session's leading null-id row projects to zero and is not counted (model_gru.py:109-118)
+    eng = Engine(args, hier=True, dtype="fp32")
+    eng.set_weights(p)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+    xl, yl, ml = as_lists(x, y, mask)
+    exact, st = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64)
+    assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+    assert np.abs(exact).max() > 1.0
+    assert np.abs(logits - exact).max() < 2e-5 * np.abs(exact).max()
+    ref = O.masked_loss_and_metrics(exact, y.reshape(B, S * L).astype(np.int64), N)
+    valid = y.reshape(B, S * L) > 0
+    assert (out["rank"].cpu().numpy().reshape(B, S * L) == ref["ranks"])[valid].mean() > 0.99
+    eng.close()
+
+
+def test_exact_mode_topk_ties_masked_rows_and_chunks():
+    """tf.nn.top_k's order on the materialised rows: equal values in index order (duplicated items give bitwise equal logits), masked rows
+    0..k-1, and a row count that spans several logits chunks with a ragged last one."""
+    from hiertcn_amd.engine import Engine
+    N, d = 700, 64
+    args = small_args(N=N, d=d, H=d, nl=1, blocks=1, K=3, L=8, S=2, B=4)
+    p = make_params(args)
+    Wo, bo = p["hier/tcn/dense/kernel"], p["hier/tcn/dense/bias"]
+    for a, b in ((5, 6), (6, 300), (17, 18)):      # identical columns -> identical logits
+        Wo[:, b] = Wo[:, a]
+        bo[b] = bo[a]
+    Wo[:, [5, 6, 300]] *= 30                       # ... near the top of many rows
+    eng = Engine(args, hier=True, dtype="fp32")
+    eng.set_weights(p)
+    R = 4096 + 4096 + 37
+    rng = np.random.default_rng(0)
+    hid = torch.as_tensor(rng.standard_normal((R, d)).astype(np.float32)).to("cuda:0")
+    y = rng.integers(1, N, R).astype(np.int32)
+    y[::7] = 0
+    y[3] = N + 5                                   # out-of-range id = null (one_hot gives a zero row)
+    out = eng.score_fused(hid, dev(y), want_target=True, topk=16)
+    logits = eng.score_logits(hid).cpu().numpy()
+    valid = (y > 0) & (y < N)
+    own = O.top_k_indices(logits, 16)
+    ti = out["topk_idx"].cpu().numpy()
+    assert np.array_equal(ti[valid], own[valid])
+    assert np.array_equal(ti[~valid], np.broadcast_to(np.arange(16), ti[~valid].shape))
+    tie_rows = (np.abs(np.diff(np.take_along_axis(logits, own.astype(np.int64), -1), axis=-1)) == 0).any(-1) & valid
+    assert tie_rows.sum() > 100                    # the tie order was exercised
+    tgt = logits[np.arange(R), np.where(valid, y, 0)]
+    rk = (logits > tgt[:, None]).sum(-1)
+    assert np.array_equal(out["rank"].cpu().numpy()[valid], rk[valid])
+    assert np.array_equal(out["target"].cpu().numpy()[valid], tgt[valid])       # the target IS the materialised value: z_y > z_y never holds
+    assert not out["rank"].cpu().numpy()[~valid].any() and not out["ce"].cpu().numpy()[~valid].any()
+    lse = O.log_sum_exp(logits.astype(np.float64))
+    assert np.abs(out["ce"].cpu().numpy() - (lse - tgt))[valid].max() < 2e-5
+    eng.close()
+
+
+def test_exact_mode_contract_errors():
+    from hiertcn_amd.engine import Engine
+    from hiertcn_amd._lib import HierTCNError, PRECISION_FP32
+    args = small_args(N=300, d=64, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
+    with pytest.raises(HierTCNError, match="EVALUATION"):
+        Engine(args, hier=True, dtype="fp32", train=True)
+    eng = Engine(args, hier=True)                     # a 16-bit handle whose weights are set cannot be switched: no fp32 copies
+    eng.set_weights(make_params(args))
+    with pytest.raises(HierTCNError, match="precede hiertcn_set_weights"):
+        eng._ck(eng.lib.hiertcn_set_precision(eng._h, PRECISION_FP32))
+    eng.close()
+    ex = Engine(args, hier=True, dtype="fp32")
+    with pytest.raises(HierTCNError, match="fp32 evaluation mode"):
+        ex._ck(ex.lib.hiertcn_train_enable(ex._h))
+    with pytest.raises(HierTCNError):
+        ex.set_precision("fp16")                      # this handle offers fp32 and bf16
+    ex.close()
