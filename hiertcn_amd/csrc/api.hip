@@ -163,15 +163,18 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
   ALLOC_OR_FAIL(m.out_bias, (size_t)m.NP);
   for (int i = 0, cin = E; i < m.n_blocks && !low_gru; cin = m.C[i], i++) {
     ALLOC_OR_FAIL(m.convT[i], (size_t)m.K * cin * m.C[i]);
+    ALLOC_OR_FAIL(m.convF[i], (size_t)m.K * cin * m.C[i]);
     ALLOC_OR_FAIL(m.conv_bias[i], (size_t)m.C[i]);
     if (cin != m.C[i]) {  // customized_tcn_cell.py:102-106: a biased Dense down-sample on the residual path
       ALLOC_OR_FAIL(m.resT[i], (size_t)cin * m.C[i]);
+      ALLOC_OR_FAIL(m.resF[i], (size_t)cin * m.C[i]);
       ALLOC_OR_FAIL(m.res_bias[i], (size_t)m.C[i]);
     }
   }
   if (m.hier) {
     ALLOC_OR_FAIL(m.emb_bias, (size_t)E);
     ALLOC_OR_FAIL(m.projT, (size_t)E * E);
+    ALLOC_OR_FAIL(m.projF, (size_t)E * E);
     ALLOC_OR_FAIL(m.projS, (size_t)m.HT * E);
     for (int l = 0; l < m.nl; l++) {
       const int in = (l == 0) ? E : m.H;
@@ -278,6 +281,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
       }
     }
   }
+  HIP_TRY(refresh_frag_major(m, st));
   if (h->train.enabled) HIP_TRY(train_fill_masters(m, h->train, w, st));
   if (h->x.enabled) {   // exact numerics mode: fp32 copies in the same internal layouts (reduction index contiguous)
     ExactDev& x = h->x;

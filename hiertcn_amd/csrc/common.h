@@ -66,6 +66,10 @@ struct ModelDev {
   uint16_t* convT[HIERTCN_MAX_BLOCKS];  // [K][Cout][Cin]
   uint16_t* resT[HIERTCN_MAX_BLOCKS];   // [Cout][Cin] or null
   uint16_t* outT;       // [NP][Clast], rows >= N zero
+  // fragment-major copies for the LDS-tiled layer kernel (tcn_layers.hip): [Cout/32][taps][Cin/16][64 lanes][8]
+  uint16_t* projF;
+  uint16_t* convF[HIERTCN_MAX_BLOCKS];
+  uint16_t* resF[HIERTCN_MAX_BLOCKS];
   // fp32 tensors
   float* emb_bias;      // [E]
   float* projS;         // [E][HT]  = transpose(Wp[E:]), fp32                  (hier only)
@@ -171,9 +175,13 @@ struct LayerArgs {
   int64_t n_seq;
   uint16_t* c_out;         // optional [n_seq * L][Cout]: relu(conv + b) before the residual add (kept for training)
   int linear;              // 1: out = conv (the 'emb' projection, model_tcn.py:35); 0: relu(relu(conv + b) + res)
+  const uint16_t* Wf;      // optional fragment-major copies of W / Wres (launch_frag_major): with them, long sequences run the LDS-tiled kernel
+  const uint16_t* Wresf;
 };
 
 hipError_t launch_tcn_layer(const LayerArgs& a, hipStream_t st);
+hipError_t launch_frag_major(const uint16_t* W, uint16_t* Wf, int taps, int Cout, int Cin, hipStream_t st);
+hipError_t refresh_frag_major(const ModelDev& m, hipStream_t st);   // all fragment-major copies from projT / convT / resT
 hipError_t launch_embed_rows(const ModelDev& m, const int32_t* ids, int64_t R, uint16_t* out, hipStream_t st);
 size_t tcn_layers_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
 hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sessions, int L, uint16_t* hidden,

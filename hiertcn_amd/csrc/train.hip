@@ -158,7 +158,7 @@ hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t 
     if ((e = cast_bf16(M + t.convT[i].off, m.convT[i], (int64_t)t.convT[i].n, 0, st)) != hipSuccess) return e;
     if (t.resT[i].n && (e = cast_bf16(M + t.resT[i].off, m.resT[i], (int64_t)t.resT[i].n, 0, st)) != hipSuccess) return e;
   }
-  return hipSuccess;
+  return refresh_frag_major(m, st);
 }
 
 hipError_t train_fill_masters(const ModelDev& m, TrainCtx& t, const hiertcn_weights_t* w, hipStream_t st) {
@@ -780,7 +780,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
     if (!m.low_gru && !fused_fw) {
       LayerArgs a = {};
-      a.in = a_emb; a.out = a0; a.W = m.projT; a.seq_init = sproj;
+      a.in = a_emb; a.out = a0; a.W = m.projT; a.Wf = m.projF; a.seq_init = sproj;
       a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
       T_HIP(launch_tcn_layer(a, st));
     }
@@ -811,7 +811,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     a.in = a_of(i);
     a.c_out = BF(w.act[2 + 2 * i]);
     a.out = a_of(i + 1);
-    a.W = m.convT[i]; a.bias = m.conv_bias[i]; a.Wres = m.resT[i]; a.bres = m.res_bias[i];
+    a.W = m.convT[i]; a.bias = m.conv_bias[i]; a.Wres = m.resT[i]; a.bres = m.res_bias[i]; a.Wf = m.convF[i]; a.Wresf = m.resF[i];
     a.Cin = cin; a.Cout = m.C[i]; a.taps = m.K; a.dil = 1 << i; a.L = L; a.n_seq = n_sess; a.linear = 0;
     T_HIP(launch_tcn_layer(a, st));
   }

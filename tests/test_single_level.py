@@ -146,6 +146,46 @@ np.save(sys.argv[1], hid.view(torch.int16).cpu().numpy())
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("cfg", ["reference_6_blocks_T500", "equal_256_T300_K3", "narrow_64_T97_K2", "hier_L100_d128", "mixed_128_256_128_T200"])
+def test_lds_tiled_and_unstaged_layer_kernels_agree_bitwise(cfg):
+    """k_tcn_layer_lds (activation slab in LDS, fragment-major weights through a register ring) keeps the accumulation order of k_tcn_layer
+    (bias, taps outermost, k-steps inner, zero operands outside the sequence): identical 16-bit activations, for long single-level sequences
+    (args.py:310-311's six blocks at T = 500, incl. the Dense down-sample of block 4), tiles that end inside a sequence, dilations whose halo
+    reaches past the sequence start, and the hier projection with its per-session accumulator start.  HIERTCN_TCN_LAYER_V1 is read per launch."""
+    import torch
+    from hiertcn_amd.engine import Engine
+    from tests.gpu_common import make_params, small_args
+    rng = np.random.default_rng(11)
+    dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).cuda()  # noqa: E731
+    if cfg == "hier_L100_d128":
+        args = small_args(N=800, d=128, H=64, nl=1, blocks=3, K=5, L=100, S=2, B=3)
+        eng = Engine(args, hier=True)
+        eng.set_weights(make_params(args))
+        x = rng.integers(0, 800, (6, 100)).astype(np.int32)
+        sproj = dev((0.3 * rng.standard_normal((6, 128))).astype(np.float32))
+    else:
+        N, d, ch, B, T, K = {"reference_6_blocks_T500": (900, 128, [128, 128, 128, 128, 256, 256], 7, 500, 5),
+                             "equal_256_T300_K3": (600, 256, [256, 256, 256], 5, 300, 3),
+                             "narrow_64_T97_K2": (500, 64, [64, 64, 64, 64, 64], 9, 97, 2),
+                             "mixed_128_256_128_T200": (700, 128, [128, 256, 128], 4, 200, 4)}[cfg]
+        a = tcn_args(N, d, ch, K=K)
+        eng = Engine(a, hier=False)
+        eng.set_weights(noisy(init_params(a, 2, "tcn")))
+        x = rng.integers(0, N, (B, T)).astype(np.int32)
+        sproj = None
+    outs = []
+    for v1 in (False, True):
+        if v1:
+            os.environ["HIERTCN_TCN_LAYER_V1"] = "1"
+        try:
+            outs.append(eng.tcn_forward(dev(x), sproj).view(torch.int16).cpu().numpy())
+        finally:
+            os.environ.pop("HIERTCN_TCN_LAYER_V1", None)
+    assert outs[0].any() and np.array_equal(outs[0], outs[1])
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_evaluate_nn_hip_vs_oracle(tmp_path):
     from hiertcn_amd.data_loader import Dataloader_single_level_model_xing
     from hiertcn_amd.data_prepare import load_xing
