@@ -77,21 +77,46 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
 
     from hiertcn_amd.model import HierTCNModel
 
-    targs = copy.copy(args)
-    targs.train = True
-    model = HierTCNModel(targs, params, train=True)
-    eng = model.engine
     Bt = a.train_users_per_step
     n_total = a.train_warmup + a.train_steps
-    batches = []
-    for i in range(n_total):
-        first = shard_first + (i * Bt) % max(shard - Bt, 1)
-        x, y, mask = make_users(draw, first, Bt, a.ragged)
-        batches.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda()))
-    state0 = torch.zeros((Bt, eng.HT), dtype=torch.float32, device="cuda")
-    state_out = torch.empty_like(state0)
-    m8 = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(n_total)]
     lr = 1e-3
+    # Phase 1, rank-local (no collective inside): everything that can fail on ONE rank -- the training handle's arenas, the batches, and one
+    # whole step with the collectives switched off (kernel / workspace errors surface here).  Then the ranks AGREE on success with one
+    # all-reduce that every rank reaches whatever happened before; only then does the collective part start.  (A rank that raised inside
+    # the collective part while the others wait in RCCL would hang the run and the JSON line with it.)
+    model, err = None, None
+    try:
+        targs = copy.copy(args)
+        targs.train = True
+        model = HierTCNModel(targs, params, train=True)
+        eng = model.engine
+        batches = []
+        for i in range(n_total):
+            first = shard_first + (i * Bt) % max(shard - Bt, 1)
+            x, y, mask = make_users(draw, first, Bt, a.ragged)
+            batches.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda()))
+        state0 = torch.zeros((Bt, eng.HT), dtype=torch.float32, device="cuda")
+        state_out = torch.empty_like(state0)
+        m8 = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(n_total)]
+        if world > 1:
+            os.environ["HIERTCN_DP_OFF"] = "1"
+            try:
+                model.train_step_device(batches[0][0], batches[0][1], batches[0][2], state0, 0.0, state_out=state_out, metrics8=m8[0])
+                torch.cuda.synchronize()
+            finally:
+                os.environ.pop("HIERTCN_DP_OFF", None)
+    except Exception as e:  # noqa: BLE001
+        import traceback
+        err = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:], "rank": rank}
+    if world > 1:
+        ok = torch.tensor([0.0 if err else 1.0], device="cuda")
+        dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) == 0.0 and err is None:
+            err = {"error": "the training leg failed on another rank before its first collective", "rank": rank}
+    if err is not None:
+        if model is not None:
+            model.engine.close()
+        return err
 
     def run(steps_from, steps_to):
         for i in range(steps_from, steps_to):
@@ -294,6 +319,24 @@ def main():
     score_ms, launches = eng.timing_read(reset=True)
     eng.timing_enable(False)
 
+    # what the driver needs to confirm an N-GPU run WAS one: the collective backend, how many ranks it joined, and how many DISTINCT
+    # physical devices they ran on (uuid where the runtime reports one, PCI address otherwise), plus every rank's own scoring-launch
+    # average so that a straggling GPU shows
+    prop = torch.cuda.get_device_properties(dev_index)
+    ident = str(getattr(prop, "uuid", "")) or ""
+    pci = "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0), getattr(prop, "pci_device_id", 0))
+    mine = {"rank": rank, "local_rank": local_rank, "device_index": dev_index, "uuid": ident, "pci": pci, "name": prop.name,
+            "score_launch_ms": round(score_ms, 4), "step_ms": round(dt / max(a.steps, 1) * 1e3, 3)}
+    per_rank = [mine]
+    if world > 1:
+        per_rank = [None] * world
+        dist.all_gather_object(per_rank, mine)
+    multi = {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
+             "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else (0 if world > 1 else None)),
+             "ranks": world,
+             "distinct_devices": len({(r["uuid"] or r["pci"]) for r in per_rank}),
+             "per_rank": per_rank}
+
     sessions_per_step = B * S_SESS * world
     value = sessions_per_step * a.steps / dt
     rows_per_launch = B * S_SESS * L_STEPS
@@ -349,11 +392,14 @@ def main():
     # run_hier_xing.py:275-301), users sharded over the ranks, timed after the evaluation region under the same launch
     train = None
     if not a.no_train:
-        try:
-            train = train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)
-        except Exception as e:  # noqa: BLE001  (the headline line above must survive a failure of the secondary leg; the error is reported)
-            import traceback
-            train = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
+        if world > 1:
+            train = train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)   # (agrees on failure across ranks itself)
+        else:
+            try:
+                train = train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)
+            except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of the secondary leg; the error is reported)
+                import traceback
+                train = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
 
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
@@ -407,11 +453,13 @@ def main():
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": rows_per_launch * (2 * DIM + 4 + 8) + 2 * DIM * N_ITEMS + 4 * N_ITEMS,
                 "launch_ms": round(score_ms, 4),
+                "launch_ms_per_rank_min_max": [min(r["score_launch_ms"] for r in per_rank), max(r["score_launch_ms"] for r in per_rank)],
                 "launches_timed": int(launches),
                 "flops_per_launch": flops_per_launch,
                 "scored_rows_per_launch": scored_rows,
             },
             "cpu_baseline": cpu,
+            "multi_gpu": multi,
             "train": train,
             "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
             "setup_s": round(t_setup, 1),

@@ -733,6 +733,12 @@ int hiertcn_persistent_health(hiertcn_handle_t h, int32_t* timed_out) {
   HIP_TRY(hipDeviceSynchronize());
   HIP_TRY(hipMemcpy(&w, h->m.gru_bar + 8 * 16, sizeof(w), hipMemcpyDeviceToHost));   // the word behind the 8 group counters (gru_persist.hip)
   *timed_out = w ? 1 : 0;
+  if (w) {
+    // a timed-out launch leaves the group counters at a value that is no multiple of its workgroup count, and every later barrier target
+    // is derived from them: the handle would mis-synchronise for good.  The device is idle here (synchronised above), so start over --
+    // counters and error word back to zero; the caller has been told that the launches since the last check produced wrong states.
+    HIP_TRY(hipMemset(h->m.gru_bar, 0, 256 * sizeof(unsigned long long)));
+  }
   return HIERTCN_OK;
 }
 

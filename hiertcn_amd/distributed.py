@@ -27,6 +27,10 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    if world > 1 and torch.cuda.is_available() and world > torch.cuda.device_count():
+        # ranks share a GPU (a gloo smoke run): the persistent GRU scan assumes its workgroups are co-resident on a device of their own
+        # (csrc/gru_persist.hip) -- run the scan as the chain of GEMM launches instead
+        os.environ.setdefault("HIERTCN_GRU_CHAIN", "1")
     return rank, world, local_rank
 
 
@@ -128,9 +132,15 @@ class GradientExchange:
     1/world factor and ragged shards (ranks with different numbers of live lanes) are weighted exactly as model.py:113-117 would
     weight them in one big batch."""
 
-    def __init__(self, engine, sparse_rows_max_fraction: float = None):
+    def __init__(self, engine, sparse_rows_max_fraction: float = None, ids_bound: int = None):
+        """ids_bound: a HOST-KNOWN, RANK-INDEPENDENT upper bound on the number of ids one rank feeds per step (x_ids.numel(): e.g.
+        batch_size * max_session_num * max_activity_len from args).  It sizes the one all-gather capacity every rank must agree on and
+        drives the sparse-versus-dense choice.  Ranks pad to their OWN longest session (pack_slots), so a bound taken from the local
+        batch would differ between ranks and steps; without ids_bound the ranks agree on the step's maximum with one small MAX
+        all-reduce EVERY step -- unconditionally: a collective only some ranks enter would pair mismatched collectives or hang."""
         import os
         self.eng = engine
+        self.ids_bound = None if ids_bound is None else int(ids_bound)
         self.mode = os.environ.get("HIERTCN_DP_COLLECTIVE", "rs_ag")
         self.sparse_frac = float(os.environ.get("HIERTCN_DP_SPARSE_FRACTION", "-1")) if sparse_rows_max_fraction is None else sparse_rows_max_fraction
         self._pending = []
@@ -149,18 +159,19 @@ class GradientExchange:
         _sum_async(u).wait()
         return u
 
-    def _max_over_ranks_cached(self, n: int) -> int:
-        """Largest batch (ids per rank) over the ranks: the all-gather of (row id, row) pairs needs one capacity for all.  Asked once
-        per distinct local size (a host-side collective), not per step."""
-        if not hasattr(self, "_nmax"):
-            self._nmax = {}
-        if n not in self._nmax:
-            t = torch.tensor([n], dtype=torch.int64)
-            if dist.get_backend() == "nccl":
-                t = t.to(self.eng.device)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            self._nmax[n] = int(t.item())
-        return self._nmax[n]
+    def _ids_per_rank(self, n_local: int) -> int:
+        """The number every rank uses for the all-gather capacity and the sparse-versus-dense decision of this step: the same on all
+        ranks by construction (the host-known bound), or agreed on by a collective that every rank enters every step."""
+        if self.ids_bound is not None:
+            if n_local > self.ids_bound:
+                raise ValueError(f"this rank feeds {n_local} ids in one step, more than ids_bound = {self.ids_bound}: the bound must hold on every "
+                                 "rank and step (batch_size * max_session_num * max_activity_len)")
+            return self.ids_bound
+        t = torch.tensor([n_local], dtype=torch.int64)
+        if dist.get_backend() == "nccl":
+            t = t.to(self.eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return int(t.item())
 
     def _dense(self, seg: torch.Tensor):
         world = self.world
@@ -177,6 +188,8 @@ class GradientExchange:
                     w1.wait()
                     w2.wait()
             return _Both()
+        if self.mode == "allreduce" and dist.get_backend() == "nccl":
+            return _sum_async_bucketed(seg)
         return _sum_async(seg)
 
     def after_scoring(self):
@@ -196,7 +209,7 @@ class GradientExchange:
         off2, n2 = eng.grad_segment(2)
         self._pending.append(_sum_async(g[off2:off2 + n2]))
         off0, n0 = eng.grad_segment(0)
-        n_ids = self._max_over_ranks_cached(int(x_ids.numel())) * (2 if y_ids is not None else 1)   # the same on every rank
+        n_ids = self._ids_per_rank(int(x_ids.numel())) * (2 if y_ids is not None else 1)   # the same on every rank
         bound = min(eng.N - 1, n_ids)
         # all-gather of pairs receives (W-1) * bound rows; a ring all-reduce moves 2 (W-1)/W * N rows
         frac = self.sparse_frac if self.sparse_frac >= 0 else 2.0 / world
@@ -217,15 +230,14 @@ class GradientExchange:
         self._pending = []
 
 
-def all_reduce_gradients(flat: torch.Tensor, bucket_bytes: int = 256 << 20) -> int:
-    """Sum the flat fp32 gradient arena over ranks, in place, in buckets (so that a bucket's RCCL all-reduce can
-    overlap the next bucket's launch; the arena is dominated by the two [N, d] item tables -- 2 x 307 MB at
-    cfg-3).  Returns the world size: the caller divides by it (equal user counts per rank: weak scaling), which
-    makes the update the gradient of the GLOBAL batch's lane-mean loss (model.py:116-117)."""
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-        return 1
-    n = max(1, bucket_bytes // 4)
+def _sum_async_bucketed(flat: torch.Tensor, bucket_bytes: int = 256 << 20):
+    """HIERTCN_DP_COLLECTIVE=allreduce on RCCL: the dense segment as a few large all-reduces in flight at once (a bucket's ring can start
+    while the next one is queued) instead of reduce-scatter + all-gather.  Returns a handle with .wait()."""
+    n = max(1, bucket_bytes // flat.element_size())
     works = [dist.all_reduce(flat[i:i + n], op=dist.ReduceOp.SUM, async_op=True) for i in range(0, flat.numel(), n)]
-    for wk in works:
-        wk.wait()
-    return dist.get_world_size()
+
+    class _All:
+        def wait(self):
+            for wk in works:
+                wk.wait()
+    return _All()

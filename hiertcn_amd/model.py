@@ -167,7 +167,12 @@ class HierTCNModel:
         from .distributed import GradientExchange, all_reduce_metrics
         eng = self.engine
         if getattr(self, "_exchange", None) is None:
-            self._exchange = GradientExchange(eng)
+            # ids per rank and step, known on the host and the same on every rank (ranks pad to their own longest session, so the local
+            # tensor's size is neither): lanes x slots x longest kept session (hier), lanes x longest kept sequence (single-level)
+            a = self.args
+            bound = (int(a.batch_size) * int(a.max_session_num) * int(a.max_activity_len) if self.hier
+                     else int(a.batch_size) * int(getattr(a, "max_seq_len", 500)))
+            self._exchange = GradientExchange(eng, ids_bound=max(bound, 1))
         ex = self._exchange
         users = ex.global_users(yd)
         out = eng.train_step_begin(xd, yd, md, st, state_out=state_out, metrics8=metrics8, users_global=users)

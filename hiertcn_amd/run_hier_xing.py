@@ -73,10 +73,21 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
         time_run += t3 - t2
         if (pre.done if pre is not None else loader.done):  # :177
             break
+    _check_persistent_health(model, "evaluation epoch '%s'" % prefix)
     summary = meter.finish()
     summary_val = {k: v for k, v in step.items() if np.ndim(v) == 0}
     summary_val["ranks_by_position"] = ranks_temp / (ranks_temp_count + 1e-6)  # :183
     return summary, summary_val, time_load, time_run, state_np
+
+
+def _check_persistent_health(model, what: str):
+    """One read of hiertcn_persistent_health per epoch (it synchronises the device): a bounded wait inside the persistent GRU scan that ran
+    out -- workgroups not co-resident because another process, rank or CU mask holds the CUs -- finishes its launch with WRONG carried
+    states instead of hanging; metrics built on them must not be reported."""
+    eng = getattr(model, "engine", None)
+    if eng is not None and eng.persistent_timed_out():
+        raise RuntimeError(f"{what}: a persistent GRU-scan launch timed out (its workgroups were not co-resident); the states and metrics of "
+                           "this epoch are invalid.  Set HIERTCN_GRU_CHAIN=1 to run the scan as a chain of GEMM launches on a shared GPU.")
 
 
 def _rank() -> int:

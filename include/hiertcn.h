@@ -335,7 +335,9 @@ int hiertcn_timing_read(hiertcn_handle_t h, double* score_ms_avg, int64_t* launc
 
 /* Health word of the handle's persistent launches (the across-session GRU scan of small batches, csrc/gru_persist.hip): every wait of
  * one workgroup for another is bounded, and a wait that ran out sets this word instead of hanging the device -- the results of that
- * launch are then wrong.  *timed_out = 1 if that ever happened on this handle (0 in a healthy run).  Synchronises the device. */
+ * launch are then wrong.  *timed_out = 1 if that happened on this handle since the last call (0 in a healthy run).  Synchronises the
+ * device; a reported time-out also resets the handle's barrier counters, so that later launches synchronise correctly again.  The run
+ * loops read it once per evaluation epoch and raise (hiertcn_amd/run_hier_xing.py). */
 int hiertcn_persistent_health(hiertcn_handle_t h, int32_t* timed_out);
 
 #ifdef __cplusplus

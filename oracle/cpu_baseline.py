@@ -100,32 +100,42 @@ class CpuHierTCN:
 
 
 def time_cpu_baseline(args, params, x, y, mask, variants=((32, 4), (128, 1)), repeats=3, budget_s=30.0, threads=None):
-    """Times eval_batch on bounded samples of the workload: for every (lanes, slots) variant one untimed warm-up run and up to
-    `repeats` timed runs (median) of the first `lanes` users x `slots` session slots of (x, y, mask) -- (32, 4) is the reference's
-    own batch width (args.py:193), (128, 1) a wide batch (best case for the CPU's GEMMs; at N = 300,000 one slot of 128 lanes is a
-    4.6 GB logits tensor, 1,024 lanes would be 37 GB).  The budget bounds the whole leg.  Returns dict(value = the BEST variant's
-    sessions/s, cores, sample, variants=[...])."""
+    """Times eval_batch on bounded samples of the workload: for every (lanes, slots) variant one untimed warm-up run and ALWAYS
+    `repeats` (>= 3) timed runs (median) of the first `lanes` users x `slots` session slots of (x, y, mask) -- (32, 4)
+    is the reference's own batch width (args.py:193), (128, 1) a wide batch (best case for the CPU's GEMMs; at N = 300,000 one slot of
+    128 lanes is a 4.6 GB logits tensor, 1,024 lanes would be 37 GB).  The budget bounds the whole leg by SHRINKING THE SAMPLE, never
+    the repeats: a calibration run (one slot of 32 lanes) gives the cost per session, and a variant whose 1 + repeats runs would not fit
+    its share of the budget gets fewer slots (never fewer than one) or fewer lanes (in steps of 32, never fewer than 32).  Returns
+    dict(value = the BEST variant's sessions/s, cores, sample, variants=[...])."""
+    repeats = max(int(repeats), 3)
     model = CpuHierTCN(args, params, threads)
     xt, yt = torch.from_numpy(x.astype(np.int64)), torch.from_numpy(y.astype(np.int64))
     mt = torch.from_numpy(mask.astype(np.float32))
     B, S, L = x.shape
     HT = args.hidden_dim * args.num_layer
     t_leg = time.perf_counter()
+
+    def run(lanes, slots):
+        xs, ys, ms = xt[:lanes, :slots].contiguous(), yt[:lanes, :slots].contiguous(), mt[:lanes, :slots].contiguous()
+        st = torch.zeros(lanes, HT)
+        t0 = time.perf_counter()
+        model.eval_batch(xs, ys, ms, st)
+        return time.perf_counter() - t0
+
+    cal_lanes = min(32, B)
+    run(cal_lanes, 1)                                   # page-in, thread pool, allocator
+    per_session = run(cal_lanes, 1) / cal_lanes         # calibration: seconds per session at the narrow width
+    share = max(budget_s - (time.perf_counter() - t_leg), 1e-3) / len(variants)
+    fit = max(int(share / ((repeats + 1) * per_session)), 1)      # sessions per run that keep 1 + repeats runs inside the share
     results = []
     for lanes, slots in variants:
         lanes, slots = min(lanes, B), min(slots, S)
-        xs, ys, ms = xt[:lanes, :slots].contiguous(), yt[:lanes, :slots].contiguous(), mt[:lanes, :slots].contiguous()
-        times = []
-        for rep in range(repeats + 1):            # rep 0 = warm-up (page-in, thread pool, allocator)
-            st = torch.zeros(lanes, HT)
-            t0 = time.perf_counter()
-            model.eval_batch(xs, ys, ms, st)
-            dt = time.perf_counter() - t0
-            if rep > 0:
-                times.append(dt)
-            spent = time.perf_counter() - t_leg
-            if rep >= 1 and spent + dt > budget_s * (len(results) + 1) / len(variants):
-                break
+        if lanes * slots > fit:
+            if slots > 1:
+                slots = max(1, min(slots, fit // lanes))
+            if lanes * slots > fit:
+                lanes = max(min(32, lanes), (fit // slots) // 32 * 32)
+        times = [run(lanes, slots) for _ in range(repeats + 1)][1:]            # run 0 = this shape's warm-up
         med = float(np.median(times))
         results.append(dict(lanes=lanes, slots=slots, sessions=lanes * slots, seconds_median=round(med, 3), timed_runs=len(times),
                             sessions_per_s=round(lanes * slots / med, 3)))

@@ -89,21 +89,20 @@ def test_two_rank_metric_all_reduce_equals_single_process(tmp_path):
 
 def _grad_worker(rank, world, port, out_dir):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
-    from hiertcn_amd.distributed import all_reduce_gradients, init_from_env
+    from hiertcn_amd.distributed import _sum_async_bucketed, init_from_env
     import torch.distributed as dist
     init_from_env("gloo")
-    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)      # stands for the flat gradient arena
-    w = all_reduce_gradients(g, bucket_bytes=4 * 96)              # 96-float buckets: 11 async all-reduces, a ragged last one
+    g = torch.arange(1000, dtype=torch.float32) * (rank + 1)      # stands for a dense segment of the gradient arena
+    _sum_async_bucketed(g, bucket_bytes=4 * 96).wait()            # 96-float buckets: 11 async all-reduces in flight, a ragged last one
     if rank == 0:
         np.save(os.path.join(out_dir, "g.npy"), g.numpy())
-        np.save(os.path.join(out_dir, "w.npy"), np.array([w]))
     dist.barrier()
     dist.destroy_process_group()
 
 
 def test_bucketed_gradient_all_reduce(tmp_path):
+    """HIERTCN_DP_COLLECTIVE=allreduce: the dense segment as several all-reduces in flight at once."""
     mp.spawn(_grad_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
-    assert np.load(tmp_path / "w.npy")[0] == 2
     np.testing.assert_array_equal(np.load(tmp_path / "g.npy"), np.arange(1000, dtype=np.float32) * 3)
 
 
@@ -156,12 +155,30 @@ class _HostEngine:
             tab.index_add_(0, idx, rows[:n])
 
 
-def _exchange_worker(rank, world, port, out_dir, sparse_fraction):
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+def _exchange_worker(rank, world, port, out_dir, sparse_fraction, ids_bound=None, as_rccl=False, mode="rs_ag", N=97):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank),
+                      HIERTCN_DP_COLLECTIVE=mode)
+    from hiertcn_amd import distributed as D
     from hiertcn_amd.distributed import GradientExchange, init_from_env
     import torch.distributed as dist
     init_from_env("gloo")
-    N, E = 97, 8
+    calls = []
+    if as_rccl:
+        # RCCL cannot run here; its branches of the exchange (reduce_scatter_tensor + all_gather_into_tensor, the bucketed all-reduce, the
+        # flat all_gather_into_tensor of the row lists, async handles) are backend-agnostic torch.distributed calls that gloo also
+        # implements on host tensors: report "nccl" to the module and record which collectives it then issues
+        D.dist.get_backend = lambda *a, **k: "nccl"
+        for name in ("reduce_scatter_tensor", "all_gather_into_tensor", "all_reduce", "all_gather"):
+            real = getattr(dist, name)
+
+            def spy(*a, _real=real, _name=name, **k):
+                calls.append(_name)
+                h = _real(*a, **k)
+                if h is not None:   # RCCL runs its collectives in issue order on one stream; gloo's async ops are unordered
+                    h.wait()        # worker-thread jobs: complete each before the next is issued to keep that order
+                return h
+            setattr(D.dist, name, spy)
+    E = 8
     eng = _HostEngine(N, E, 33, rank)
     rng = np.random.default_rng(rank)
     B = 3 + rank                                      # uneven shards: different numbers of ids per rank
@@ -169,28 +186,101 @@ def _exchange_worker(rank, world, port, out_dir, sparse_fraction):
     y = torch.from_numpy(rng.integers(0, N, (B, 2, 5)).astype(np.int32))
     eng.touch(x, y, rank)
     np.save(os.path.join(out_dir, f"before{rank}.npy"), eng.arena.numpy().copy())
-    ex = GradientExchange(eng, sparse_rows_max_fraction=sparse_fraction)
+    ex = GradientExchange(eng, sparse_rows_max_fraction=sparse_fraction, ids_bound=ids_bound)
     users = ex.global_users(y)
     ex.after_scoring()
     ex.after_backward(x, y)
     np.save(os.path.join(out_dir, f"after{rank}.npy"), eng.arena.numpy())
     if rank == 0:
         np.save(os.path.join(out_dir, "meta.npy"), np.array([float(users[0]), 1.0 if ex.last["item_table"] == "row-sparse" else 0.0]))
+        with open(os.path.join(out_dir, "calls.txt"), "w") as f:
+            f.write(" ".join(calls))
     dist.barrier()
     dist.destroy_process_group()
 
 
+def _check_exchange(d, want_sparse):
+    b0, b1 = np.load(d / "before0.npy"), np.load(d / "before1.npy")
+    a0, a1 = np.load(d / "after0.npy"), np.load(d / "after1.npy")
+    users, sparse = np.load(d / "meta.npy")
+    assert sparse == want_sparse
+    assert users == 3 + 4                                        # every lane of both shards has a target
+    assert np.array_equal(a0, a1)                                 # replicas stay bit-identical
+    np.testing.assert_allclose(a0, b0 + b1, rtol=1e-6, atol=1e-6)
+
+
 def test_gradient_exchange_dense_and_row_sparse(tmp_path):
     """hiertcn_amd.distributed.GradientExchange on two ranks: every part of the arena ends as the SUM over ranks on BOTH ranks,
-    bit-identical between them, whether the item table goes densely or as (row id, row) pairs; the user count is global."""
-    for frac, want_sparse in ((0.0, 0.0), (2.0, 1.0)):
-        d = tmp_path / str(frac)
+    bit-identical between them, whether the item table goes densely or as (row id, row) pairs; the user count is global.  With a
+    host-known ids_bound (what the models pass) and without (the ranks agree per step)."""
+    for bound in (None, 4 * 2 * 5):
+        for frac, want_sparse in ((0.0, 0.0), (2.0, 1.0)):
+            d = tmp_path / f"{frac}_{bound}"
+            d.mkdir()
+            mp.spawn(_exchange_worker, args=(2, _free_port(), str(d), frac, bound), nprocs=2, join=True)
+            _check_exchange(d, want_sparse)
+
+
+def test_gradient_exchange_rccl_branches_over_host_tensors(tmp_path):
+    """The branches taken when dist.get_backend() == "nccl" (RCCL), run here over gloo on host tensors: reduce_scatter_tensor +
+    all_gather_into_tensor on the scoring segment when its size divides by the world size (N = 96: 2 N E + N = 1632 floats), the plain
+    async all-reduce when it does not (N = 97: 1649), the bucketed all-reduce of HIERTCN_DP_COLLECTIVE=allreduce, and the flat
+    all_gather_into_tensor of the (row id, row) lists."""
+    for tag, mode, frac, N in (("rs_ag", "rs_ag", 2.0, 96), ("rs_ag_odd", "rs_ag", 2.0, 97), ("allreduce", "allreduce", 0.0, 96)):
+        d = tmp_path / tag
         d.mkdir()
-        mp.spawn(_exchange_worker, args=(2, _free_port(), str(d), frac), nprocs=2, join=True)
-        b0, b1 = np.load(d / "before0.npy"), np.load(d / "before1.npy")
-        a0, a1 = np.load(d / "after0.npy"), np.load(d / "after1.npy")
-        users, sparse = np.load(d / "meta.npy")
-        assert sparse == want_sparse
-        assert users == 3 + 4                                        # every lane of both shards has a target
-        assert np.array_equal(a0, a1)                                 # replicas stay bit-identical
-        np.testing.assert_allclose(a0, b0 + b1, rtol=1e-6, atol=1e-6)
+        mp.spawn(_exchange_worker, args=(2, _free_port(), str(d), frac, 4 * 2 * 5, True, mode, N), nprocs=2, join=True)
+        _check_exchange(d, 1.0 if frac > 1 else 0.0)
+        calls = open(d / "calls.txt").read().split()
+        if tag == "rs_ag":
+            assert calls.count("reduce_scatter_tensor") == 1
+            assert calls.count("all_gather_into_tensor") == 1 + 3          # the segment's all-gather + ids, counts, rows of the row-sparse exchange
+        elif tag == "rs_ag_odd":
+            assert "reduce_scatter_tensor" not in calls                     # the numel % world fallback
+            assert calls.count("all_gather_into_tensor") == 3
+        else:
+            assert "reduce_scatter_tensor" not in calls and "all_gather_into_tensor" not in calls
+            assert calls.count("all_reduce") >= 4                           # user count, scoring segment (bucketed), item table, the rest
+        assert "all_gather" not in calls                                    # the gloo-only host staging is not what RCCL runs
+
+
+def _ragged_steps_worker(rank, world, port, out_dir, ids_bound):
+    """Several steps whose id tensors differ in size between the ranks AND from step to step, as run_xing produces them (pack_slots pads
+    to the rank's own longest session).  Round 2 asked the ranks for their maximum only when the LOCAL size was new and cached the
+    answer under it: rank 0 entered that all-reduce in a step where rank 1 hit its cache."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hiertcn_amd.distributed import GradientExchange, init_from_env
+    import torch.distributed as dist
+    import datetime
+    init_from_env("gloo")
+    N, E = 61, 4
+    eng = _HostEngine(N, E, 10, rank)
+    ex = GradientExchange(eng, sparse_rows_max_fraction=2.0, ids_bound=ids_bound)
+    L_by_step = ([3, 5, 3, 7, 5], [5, 5, 4, 3, 7])[rank]     # rank 0 repeats a size where rank 1 sees a new one, and vice versa
+    rng = np.random.default_rng(10 + rank)
+    sums = []
+    for step, L in enumerate(L_by_step):
+        eng.arena.zero_()
+        x = torch.from_numpy(rng.integers(0, N, (2, 2, L)).astype(np.int32))
+        y = torch.from_numpy(rng.integers(0, N, (2, 2, L)).astype(np.int32))
+        eng.touch(x, y, rank * 100 + step)
+        before = eng.arena.clone()
+        ex.global_users(y)
+        ex.after_scoring()
+        ex.after_backward(x, y)
+        both = [torch.zeros_like(before) for _ in range(world)]
+        dist.all_gather(both, before)
+        sums.append(float((eng.arena - (both[0] + both[1])).abs().max()))
+    if rank == 0:
+        np.save(os.path.join(out_dir, "err.npy"), np.array(sums))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_exchange_with_sizes_that_differ_per_rank_and_step(tmp_path):
+    for bound in (2 * 2 * 7, None):
+        d = tmp_path / str(bound)
+        d.mkdir()
+        mp.spawn(_ragged_steps_worker, args=(2, _free_port(), str(d), bound), nprocs=2, join=True)
+        err = np.load(d / "err.npy")
+        assert err.shape == (5,) and err.max() < 1e-5
