@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhiertcn_gfx950.so")
-SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_grad.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "exact.hip"]
+SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_grad.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "exact.hip", "gemm.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed",
          "-fno-gpu-rdc", "-D__HIP_PLATFORM_AMD__"]
 
@@ -57,7 +57,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
         relink = True
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "exact.h"), os.path.join(CSRC, "score_geom.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "exact.h"), os.path.join(CSRC, "gemm.h"), os.path.join(CSRC, "score_geom.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -83,8 +83,8 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
             list(ex.map(cc, jobs))
     objs = [os.path.join(OBJ, s.replace(".hip", ".o")) for s in SOURCES]
     if force or jobs or relink or _stale(LIB, objs):
-        # rocBLAS: plain GEMMs of the training backward pass only (csrc/train.hip)
-        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs, "-L/opt/rocm/lib", "-lrocblas", "-Wl,-rpath,/opt/rocm/lib"]
+        # nothing but the HIP runtime: every kernel of the library, the plain GEMMs of the backward pass included (csrc/gemm.hip), is its own
+        cmd = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB, *objs]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError("link failed: %s\n%s" % (r.stdout, r.stderr))

@@ -1,0 +1,22 @@
+// Plain GEMMs of the training backward pass (gemm.hip): row-major operands, fp32 results, everything asynchronous on `st`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+// fp32, bit-exact multiply-add chains on v_mfma_f32_32x32x2_f32
+//   NN: C[M][N] (ldc) = beta C + A[M][K] (lda) . B[K][N] (ldb)
+hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st);
+//   TN: C[N1][N2] (ldc) = beta C + sum_{m < Mred} A[m][N1] (lda) . B[m][N2] (ldb); scratch (optional): partial tiles of the row slices
+hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int N1, int N2, int Mred, float beta,
+                     float* scratch, size_t scratch_floats, hipStream_t st);
+
+// 16-bit storage operands (the library's storage type), fp32 results; row shifts per tap inside sequences of L rows (L = 0: none)
+//   NT: C[M][N] (ldc) = beta C + sum_taps A[r + shift_tap][K] (lda) . Bt[tap][N][K]^T (ldb)
+hipError_t gemm16_nt(const uint16_t* A, int64_t lda, const uint16_t* Bt, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, int taps,
+                     const int* shift, int L, float beta, hipStream_t st);
+//   TN: C[tap][N1][N2] (tap stride c_tap) = beta C + sum_r A[r][N1]^T . B[r + shift_tap][N2]; scratch holds the row slices' partials
+hipError_t gemm16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t c_tap, int N1, int N2, int64_t R, int taps,
+                     const int* shift, int L, float beta, float* scratch, size_t scratch_floats, hipStream_t st);
+//   NN: C[M][N] (ldc) = beta C + A[M][K] (lda) . B[K][N] (ldb)
+hipError_t gemm16_nn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, float beta,
+                     hipStream_t st);

@@ -1,0 +1,475 @@
+// The plain products of the training backward pass (model.py:139-141 differentiates customized_tcn_cell.py:109-127,
+// customed_gru_cell.py:323-337 and the 'emb' projections): hand-written MFMA GEMMs, so that the library links nothing but the HIP runtime.
+//
+//   fp32 (GRU cells, state half of the projection): v_mfma_f32_32x32x2_f32 -- a bit-exact fp32 multiply-add chain, like the forward
+//        scan's k_gemm_f32 -- in the two forms the backward needs:
+//          NN   C[M][N]  = beta C + A[M][K] . B[K][N]                      (d [in | h] = d a . W)
+//          TN   C[N1][N2] = beta C + sum_m A[m][N1] . B[m][N2]             (d W += d a^T . [in | h]: the reduction runs over the ROWS)
+//   16-bit storage (TemporalBlock taps, Dense residual, 'emb' projection, scoring layer at widths the fused kernels do not take):
+//          NT   C[M][N]  = beta C + A[M][K] . Bt[N][K]^T, fp32 out          (d a_in = d c . W^T with W kept [Cin][Cout])
+//          TN   C[N1][N2] = sum_r A[r][N1] . B[r][N2], fp32 out             (d W = d c^T . a_in over all rows of the batch)
+//
+// One LDS-tiled kernel per element type: a 128 x 128 output tile per workgroup (4 waves x four 32 x 32 accumulators), 32-deep k chunks,
+// the next chunk's global loads in flight during the MFMAs.  An operand is staged in the layout it has in memory -- [mn][k] rows
+// (pitch 36 floats) or [k][mn] rows (pitch 136) -- and the fragment reads follow it (one ds_read_b128, or four ds_read_b32 down the k
+// rows), so no transposed copy of anything is ever made.  The row reduction of the TN forms is cut into `splits` slices over blockIdx.z
+// (a [Cout x Cin] weight gradient is 16 tiles: one slice would leave 240 CUs idle); slices write partial tiles to scratch and a second
+// launch adds them in slice order -- deterministic, no atomics.
+#include "common.h"
+#include "gemm.h"
+
+typedef float f32x16g __attribute__((ext_vector_type(16)));
+
+#define GT 128
+#define GK 32
+#define GP_K 36    // pitch of a [mn][k] tile: the 16 lanes of a ds_read_b128 phase fall into 16 distinct bank groups
+#define GP_M 136   // pitch of a [k][mn] tile: rows 4 apart (the two lane halves of a ds_read_b32) are 32 banks apart
+
+struct G32 {
+  const float* A; int64_t lda; const float* B; int64_t ldb;
+  float* C; int64_t ldc;
+  int M, N, K;          // C is M x N, the reduction has length K
+  int k_per_split;      // multiple of GK
+  float beta;
+  float* parts;         // splits > 1: partial tiles [split][M][N], C untouched
+};
+
+// AK: A element (i, k) at A[k * lda + i] (k-major rows) instead of A[i * lda + k]; BK likewise: B element (k, j) at B[k * ldb + j]
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void k_gemm32(const G32 g) {
+  __shared__ float As[AK ? GK * GP_M : GT * GP_K];
+  __shared__ float Bs[BK ? GK * GP_M : GT * GP_K];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int k_lo = blockIdx.z * g.k_per_split;
+  const int k_hi = min(g.K, k_lo + g.k_per_split);
+  const int n_it = (k_hi - k_lo + GK - 1) / GK;
+
+  float4 ra[4], rb[4];
+  auto fetch_one = [&](const float* P, int64_t ld, int mn0, int MN, bool kmaj, int kc, int p) -> float4 {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (kmaj) {          // tile [32 k][128 mn]: thread -> k = tid / 32 + 8 p, mn = 4 (tid % 32)
+      const int k = kc + (tid >> 5) + 8 * p, mn = mn0 + (tid & 31) * 4;
+      if (k < k_hi && mn < MN) v = *reinterpret_cast<const float4*>(P + (int64_t)k * ld + mn);
+    } else {             // tile [128 mn][32 k]: thread -> mn = tid / 8 + 32 p, k = 4 (tid % 8)
+      const int mn = mn0 + (tid >> 3) + 32 * p, k = kc + (tid & 7) * 4;
+      if (mn < MN && k < k_hi) v = *reinterpret_cast<const float4*>(P + (int64_t)mn * ld + k);
+    }
+    return v;
+  };
+  auto fetch = [&](int it) {
+    const int kc = k_lo + it * GK;
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      ra[p] = fetch_one(g.A, g.lda, m0, g.M, AK, kc, p);
+      rb[p] = fetch_one(g.B, g.ldb, n0, g.N, BK, kc, p);
+    }
+  };
+  auto stash = [&](float* T, const float4* r, bool kmaj) {
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      if (kmaj) *reinterpret_cast<float4*>(&T[((tid >> 5) + 8 * p) * GP_M + (tid & 31) * 4]) = r[p];
+      else *reinterpret_cast<float4*>(&T[((tid >> 3) + 32 * p) * GP_K + (tid & 7) * 4]) = r[p];
+    }
+  };
+  // fragment of tile rows [mn0, mn0 + 32) for the 8-deep step s: four values per lane, k = 8 s + 4 lh + c for MFMA c
+  auto frag = [&](const float* T, bool kmaj, int mn0l, int s) -> float4 {
+    if (kmaj) {
+      const float* q = &T[(8 * s + 4 * lh) * GP_M + mn0l + lr];
+      return make_float4(q[0], q[GP_M], q[2 * GP_M], q[3 * GP_M]);
+    }
+    return *reinterpret_cast<const float4*>(&T[(mn0l + lr) * GP_K + 8 * s + 4 * lh]);
+  };
+
+  f32x16g acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
+
+  if (n_it > 0) fetch(0);
+  for (int it = 0; it < n_it; it++) {
+    __syncthreads();
+    stash(As, ra, AK);
+    stash(Bs, rb, BK);
+    __syncthreads();
+    if (it + 1 < n_it) fetch(it + 1);
+#pragma unroll
+    for (int s = 0; s < GK / 8; s++) {
+      const float4 a0 = frag(As, AK, 64 * wm, s), a1 = frag(As, AK, 64 * wm + 32, s);
+      const float4 b0 = frag(Bs, BK, 64 * wn, s), b1 = frag(Bs, BK, 64 * wn + 32, s);
+#define GSTEP(c)                                                                      \
+  acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b0.c, acc[0][0], 0, 0, 0);   \
+  acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0.c, b1.c, acc[0][1], 0, 0, 0);   \
+  acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b0.c, acc[1][0], 0, 0, 0);   \
+  acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1.c, b1.c, acc[1][1], 0, 0, 0);
+      GSTEP(x) GSTEP(y) GSTEP(z) GSTEP(w)
+#undef GSTEP
+    }
+  }
+  float* out = g.parts ? g.parts + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  const int64_t ldo = g.parts ? g.N : g.ldc;
+  const float beta = g.parts ? 0.f : g.beta;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int n = n0 + 64 * wn + 32 * j + lr;
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = m0 + 64 * wm + 32 * i + acc_row(q, lh);
+        if (m >= g.M) continue;
+        float v = acc[i][j][q];
+        if (beta != 0.f) v += beta * out[(int64_t)m * ldo + n];
+        out[(int64_t)m * ldo + n] = v;
+      }
+  }
+}
+
+__global__ void k_gemm_sum_parts(const float* __restrict__ parts, int P, int M, int N, float* __restrict__ C, int64_t ldc, float beta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * N) return;
+  const int m = (int)(i / N), n = (int)(i - (int64_t)m * N);
+  float s = 0.f;
+  for (int p = 0; p < P; p++) s += parts[(int64_t)p * M * N + i];
+  float* c = C + (int64_t)m * ldc + n;
+  *c = beta != 0.f ? beta * *c + s : s;
+}
+
+// slices of the reduction: enough workgroups for the chip (>= ~1.5 per CU) while a slice keeps >= 256 rows, bounded by the scratch
+static int pick_splits(int tiles, int K, int64_t MN, size_t scratch_floats) {
+  int s = 1;
+  while (tiles * s < 384 && K / (2 * s) >= 256 && (size_t)(2 * s) * MN <= scratch_floats && s < 64) s *= 2;
+  return s;
+}
+
+template <bool AK, bool BK>
+static hipError_t run32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta,
+                        float* scratch, size_t scratch_floats, hipStream_t st) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  const int tm = (M + GT - 1) / GT, tn = (N + GT - 1) / GT;
+  const int splits = scratch ? pick_splits(tm * tn, K, (int64_t)M * N, scratch_floats) : 1;
+  G32 g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.beta = beta;
+  g.k_per_split = (((K + splits - 1) / splits) + GK - 1) / GK * GK;
+  g.parts = splits > 1 ? scratch : nullptr;
+  hipLaunchKernelGGL((k_gemm32<AK, BK>), dim3(tn, tm, splits), dim3(256), 0, st, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || splits == 1) return e;
+  const int64_t mn = (int64_t)M * N;
+  hipLaunchKernelGGL(k_gemm_sum_parts, dim3((unsigned)((mn + 255) / 256)), dim3(256), 0, st, scratch, splits, M, N, C, ldc, beta);
+  return hipGetLastError();
+}
+
+hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st) {
+  if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along k (A) and n (B)
+  return run32<false, true>(A, lda, B, ldb, C, ldc, M, N, K, beta, nullptr, 0, st);
+}
+
+hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int N1, int N2, int Mred, float beta,
+                     float* scratch, size_t scratch_floats, hipStream_t st) {
+  if ((N1 & 3) || (N2 & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along the output dimensions
+  return run32<true, true>(A, lda, B, ldb, C, ldc, N1, N2, Mred, beta, scratch, scratch_floats, st);
+}
+
+// =================================================================================================================================
+// 16-bit storage operands (bf16, or IEEE half in the HIERTCN_F16 build), fp32 results, v_mfma_f32_32x32x16.
+// Both kernels take a ROW SHIFT per tap: inside sequences of L rows, tap j reads row r + shift_j of the shifted operand and a zero row
+// where that leaves the sequence -- the backward forms of the causal conv (customized_tcn_cell.py:46-49: o[t] = sum_j x[t - s_j] . W_j
+// => d x[t] = sum_j d o[t + s_j] . W_j^T and d W_j = sum_t d o[t]^T x[t - s_j]) without materialising shifted copies.
+// =================================================================================================================================
+#define HK 64      // k chunk of the NT kernel (16-bit elements)
+#define HP_K 144   // byte pitch of a [mn][64 k] tile: 36 words, (9 r) mod 16 distinct for the 16 lanes of a ds_read_b128 phase
+#define HR 64      // row chunk of the TN kernel
+#define HP_T 320   // byte pitch of a [row][128 channel] tile: 80 words, the four rows of a transposed-read block 16 banks apart
+
+__device__ __forceinline__ uint2 lds_tr16(const unsigned char* p) {
+  typedef short s16x4g __attribute__((ext_vector_type(4)));
+  const s16x4g v = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4g*)p);
+  return __builtin_bit_cast(uint2, v);
+}
+
+struct G16nt {
+  const uint16_t* A; int64_t lda;        // [M][K] rows, read at row r + shift[tap]
+  const uint16_t* Bt; int64_t ldb;       // [taps][N][K]; BKM (one tap only): B [K][N], the reduction index on the rows
+  float* C; int64_t ldc;
+  int64_t M; int N, K;
+  int taps, L; int shift[8];
+  float beta;
+};
+
+// C[M][N] = beta C + sum_taps A[r + shift_tap][K] . Bt[tap][N][K]^T      (BKM: ... + A[M][K] . B[K][N], B staged as [k][n] rows and read
+// through the hardware transpose read, like both operands of k_gemm16_tn)
+template <bool BKM>
+__global__ __launch_bounds__(256) void k_gemm16_nt(const G16nt g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[GT * HP_K];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[BKM ? HK * HP_T : GT * HP_K];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int64_t m0 = (int64_t)blockIdx.y * GT;
+  const int n0 = blockIdx.x * GT;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int ldrow = tid >> 3, ldc8 = (tid & 7) * 8;      // this thread stages rows ldrow + 32 p, elements [ldc8, ldc8 + 8) of a 64-deep chunk
+  int64_t a_row[4]; int a_t[4];
+#pragma unroll
+  for (int p = 0; p < 4; p++) {
+    const int64_t gm = m0 + ldrow + 32 * p;
+    a_row[p] = gm < g.M ? gm : -1;
+    a_t[p] = (gm < g.M && g.L > 0) ? (int)(gm % g.L) : 0;
+  }
+  const int kchunks = (g.K + HK - 1) / HK;
+  const int n_it = g.taps * kchunks;
+  uint4 ra[4], rb[4];
+  auto fetch = [&](int it) {
+    const int j = it / kchunks, kc = (it - j * kchunks) * HK;
+    const int sh = g.shift[j];
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      ra[p] = zero; rb[p] = zero;
+      const bool inside = g.L > 0 ? (a_t[p] + sh >= 0 && a_t[p] + sh < g.L) : true;
+      if (a_row[p] >= 0 && inside && kc + ldc8 < g.K) ra[p] = *reinterpret_cast<const uint4*>(g.A + (a_row[p] + sh) * g.lda + kc + ldc8);
+      if (BKM) {   // tile [64 k][128 n]: thread -> k rows tid / 16 + 16 p, columns 8 (tid % 16)
+        const int k = kc + (tid >> 4) + 16 * p, gn = n0 + (tid & 15) * 8;
+        if (k < g.K && gn < g.N) rb[p] = *reinterpret_cast<const uint4*>(g.Bt + (int64_t)k * g.ldb + gn);
+      } else {
+        const int gn = n0 + ldrow + 32 * p;
+        if (gn < g.N && kc + ldc8 < g.K) rb[p] = *reinterpret_cast<const uint4*>(g.Bt + ((int64_t)j * g.N + gn) * g.ldb + kc + ldc8);
+      }
+    }
+  };
+  const int gq = lane >> 4, w16 = lane & 15;
+  const int tr_off = (8 * lh + (w16 >> 2)) * HP_T + (16 * (gq & 1) + 4 * (w16 & 3)) * 2;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
+  fetch(0);
+  for (int it = 0; it < n_it; it++) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      *reinterpret_cast<uint4*>(As + (ldrow + 32 * p) * HP_K + ldc8 * 2) = ra[p];
+      if (BKM) *reinterpret_cast<uint4*>(Bs + ((tid >> 4) + 16 * p) * HP_T + (tid & 15) * 16) = rb[p];
+      else *reinterpret_cast<uint4*>(Bs + (ldrow + 32 * p) * HP_K + ldc8 * 2) = rb[p];
+    }
+    __syncthreads();
+    if (it + 1 < n_it) fetch(it + 1);
+#pragma unroll
+    for (int s = 0; s < HK / 16; s++) {
+      const uint4 a0 = *reinterpret_cast<const uint4*>(As + (64 * wm + lr) * HP_K + 32 * s + 16 * lh);
+      const uint4 a1 = *reinterpret_cast<const uint4*>(As + (64 * wm + 32 + lr) * HP_K + 32 * s + 16 * lh);
+      uint4 b0, b1;
+      if (BKM) {
+        const unsigned char* pb = Bs + 16 * s * HP_T + (64 * wn) * 2 + tr_off;
+        const uint2 l0 = lds_tr16(pb), h0 = lds_tr16(pb + 4 * HP_T), l1 = lds_tr16(pb + 64), h1 = lds_tr16(pb + 64 + 4 * HP_T);
+        b0 = make_uint4(l0.x, l0.y, h0.x, h0.y);
+        b1 = make_uint4(l1.x, l1.y, h1.x, h1.y);
+      } else {
+        b0 = *reinterpret_cast<const uint4*>(Bs + (64 * wn + lr) * HP_K + 32 * s + 16 * lh);
+        b1 = *reinterpret_cast<const uint4*>(Bs + (64 * wn + 32 + lr) * HP_K + 32 * s + 16 * lh);
+      }
+      acc[0][0] = mfma32(a0, b0, acc[0][0]);
+      acc[0][1] = mfma32(a0, b1, acc[0][1]);
+      acc[1][0] = mfma32(a1, b0, acc[1][0]);
+      acc[1][1] = mfma32(a1, b1, acc[1][1]);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int n = n0 + 64 * wn + 32 * j + lr;
+    if (n >= g.N) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int64_t m = m0 + 64 * wm + 32 * i + acc_row(q, lh);
+        if (m >= g.M) continue;
+        float v = acc[i][j][q];
+        float* c = g.C + m * g.ldc + n;
+        if (g.beta != 0.f) v += g.beta * *c;
+        *c = v;
+      }
+  }
+}
+
+hipError_t gemm16_nt(const uint16_t* A, int64_t lda, const uint16_t* Bt, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, int taps,
+                     const int* shift, int L, float beta, hipStream_t st) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if ((K & 7) || (lda & 7) || (ldb & 7) || taps < 1 || taps > 8) return hipErrorInvalidValue;
+  const int64_t unit = L > 0 ? L : 1;
+  const int64_t rows_per_launch = ((int64_t)65535 * GT / unit) * unit;   // gridDim.y <= 65535; cut at a sequence boundary
+  for (int64_t r0 = 0; r0 < M; r0 += rows_per_launch) {
+    G16nt g;
+    g.A = A + r0 * lda; g.lda = lda; g.Bt = Bt; g.ldb = ldb; g.C = C + r0 * ldc; g.ldc = ldc;
+    g.M = M - r0 < rows_per_launch ? M - r0 : rows_per_launch; g.N = N; g.K = K; g.taps = taps; g.L = L; g.beta = beta;
+    for (int j = 0; j < 8; j++) g.shift[j] = j < taps && shift ? shift[j] : 0;
+    hipLaunchKernelGGL(k_gemm16_nt<false>, dim3((unsigned)((N + GT - 1) / GT), (unsigned)((g.M + GT - 1) / GT)), dim3(256), 0, st, g);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
+hipError_t gemm16_nn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, float beta,
+                     hipStream_t st) {
+  if (M <= 0 || N <= 0) return hipSuccess;
+  if ((K & 7) || (N & 7) || (lda & 7) || (ldb & 7) || M > (int64_t)65535 * GT) return hipErrorInvalidValue;
+  G16nt g;
+  g.A = A; g.lda = lda; g.Bt = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.taps = 1; g.L = 0; g.beta = beta;
+  for (int j = 0; j < 8; j++) g.shift[j] = 0;
+  hipLaunchKernelGGL(k_gemm16_nt<true>, dim3((unsigned)((N + GT - 1) / GT), (unsigned)((M + GT - 1) / GT)), dim3(256), 0, st, g);
+  return hipGetLastError();
+}
+
+struct G16tn {
+  const uint16_t* A; int64_t lda;        // [R][N1]
+  const uint16_t* B; int64_t ldb;        // [R][N2], read at row r + shift[tap]
+  int64_t R; int N1, N2;
+  int taps, L; int shift[8];
+  int splits; int64_t rows_per_split;    // multiple of HR
+  float* parts;                          // [taps][splits][N1][N2]; null (splits == 1, taps == 1): straight into C with beta
+  float* C; int64_t ldc; float beta;
+};
+
+// parts[tap][split][N1][N2] = sum over the split's rows r of A[r][N1]^T . B[r + shift_tap][N2]: both operands are staged as [row][channel]
+// tiles, exactly as they lie in memory, and the MFMA fragments (8 consecutive ROWS of one channel per lane) come out of LDS through the
+// hardware transpose read ds_read_b64_tr_b16 (two reads of 4 rows each); every lane takes part in every read (EXEC all ones).
+__global__ __launch_bounds__(256) void k_gemm16_tn(const G16tn g) {
+  __shared__ __attribute__((aligned(16))) unsigned char As[HR * HP_T];
+  __shared__ __attribute__((aligned(16))) unsigned char Bs[HR * HP_T];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lh = lane >> 5;
+  const int i0 = blockIdx.y * GT, j0 = blockIdx.x * GT;
+  const int tap = blockIdx.z / g.splits, split = blockIdx.z - tap * g.splits;
+  const int sh = g.shift[tap];
+  const int wm = wave >> 1, wn = wave & 1;
+  const int64_t r_lo = split * g.rows_per_split;
+  const int64_t r_hi = r_lo + g.rows_per_split < g.R ? r_lo + g.rows_per_split : g.R;
+  const int n_it = r_hi > r_lo ? (int)((r_hi - r_lo + HR - 1) / HR) : 0;
+  const int ldrow = tid >> 4, ldc8 = (tid & 15) * 8;     // tile [64 rows][128 channels]: thread -> rows ldrow + 16 p, channels [ldc8, ldc8 + 8)
+  uint4 ra[4], rb[4];
+  auto fetch = [&](int it) {
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int64_t r = r_lo + (int64_t)it * HR + ldrow + 16 * p;
+      ra[p] = zero; rb[p] = zero;
+      if (r < r_hi) {
+        if (i0 + ldc8 < g.N1) ra[p] = *reinterpret_cast<const uint4*>(g.A + r * g.lda + i0 + ldc8);
+        const int t = g.L > 0 ? (int)(r % g.L) : 0;
+        const bool inside = g.L > 0 ? (t + sh >= 0 && t + sh < g.L) : true;
+        if (inside && j0 + ldc8 < g.N2) rb[p] = *reinterpret_cast<const uint4*>(g.B + (r + sh) * g.ldb + j0 + ldc8);
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
+  // transposed-read address of this lane inside a 32-channel x 16-row operand block: 16-lane group gq = lane / 16 covers rows 8 lh + 0..3
+  // (second read: + 4) and channels 16 (gq & 1) + 0..15; lane 4 q + p of the group supplies row q, channels 4 p .. 4 p + 3
+  const int gq = lane >> 4, w16 = lane & 15;
+  const int tr_off = (8 * lh + (w16 >> 2)) * HP_T + (16 * (gq & 1) + 4 * (w16 & 3)) * 2;
+  if (n_it > 0) fetch(0);
+  for (int it = 0; it < n_it; it++) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      *reinterpret_cast<uint4*>(As + (ldrow + 16 * p) * HP_T + ldc8 * 2) = ra[p];
+      *reinterpret_cast<uint4*>(Bs + (ldrow + 16 * p) * HP_T + ldc8 * 2) = rb[p];
+    }
+    __syncthreads();
+    if (it + 1 < n_it) fetch(it + 1);
+#pragma unroll
+    for (int s = 0; s < HR / 16; s++) {
+      uint4 a[2], b[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const unsigned char* pa = As + 16 * s * HP_T + (64 * wm + 32 * i) * 2 + tr_off;
+        const unsigned char* pb = Bs + 16 * s * HP_T + (64 * wn + 32 * i) * 2 + tr_off;
+        const uint2 a_lo = lds_tr16(pa), a_hi = lds_tr16(pa + 4 * HP_T);
+        const uint2 b_lo = lds_tr16(pb), b_hi = lds_tr16(pb + 4 * HP_T);
+        a[i] = make_uint4(a_lo.x, a_lo.y, a_hi.x, a_hi.y);
+        b[i] = make_uint4(b_lo.x, b_lo.y, b_hi.x, b_hi.y);
+      }
+      acc[0][0] = mfma32(a[0], b[0], acc[0][0]);
+      acc[0][1] = mfma32(a[0], b[1], acc[0][1]);
+      acc[1][0] = mfma32(a[1], b[0], acc[1][0]);
+      acc[1][1] = mfma32(a[1], b[1], acc[1][1]);
+    }
+  }
+  float* out = g.parts ? g.parts + ((int64_t)tap * g.splits + split) * g.N1 * g.N2 : g.C;
+  const int64_t ldo = g.parts ? g.N2 : g.ldc;
+  const float beta = g.parts ? 0.f : g.beta;
+  const int lr = lane & 31;
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int n = j0 + 64 * wn + 32 * j + lr;
+    if (n >= g.N2) continue;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = i0 + 64 * wm + 32 * i + acc_row(q, lh);
+        if (m >= g.N1) continue;
+        float v = acc[i][j][q];
+        float* c = out + (int64_t)m * ldo + n;
+        if (beta != 0.f) v += beta * *c;
+        *c = v;
+      }
+  }
+}
+
+// C[tap][N1][N2] (contiguous per tap, tap stride c_tap) = beta C + sum of the split partials, in split order
+__global__ void k_gemm16_tn_sum(const float* __restrict__ parts, int taps, int splits, int64_t n, float* __restrict__ C, int64_t c_tap, float beta) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * taps) return;
+  const int tap = (int)(i / n);
+  const int64_t e = i - (int64_t)tap * n;
+  float s = 0.f;
+  for (int p = 0; p < splits; p++) s += parts[((int64_t)tap * splits + p) * n + e];
+  float* c = C + tap * c_tap + e;
+  *c = beta != 0.f ? beta * *c + s : s;
+}
+
+hipError_t gemm16_tn(const uint16_t* A, int64_t lda, const uint16_t* B, int64_t ldb, float* C, int64_t c_tap, int N1, int N2, int64_t R, int taps,
+                     const int* shift, int L, float beta, float* scratch, size_t scratch_floats, hipStream_t st) {
+  if (N1 <= 0 || N2 <= 0 || taps < 1 || taps > 8) return hipErrorInvalidValue;
+  if ((N1 & 7) || (N2 & 7) || (lda & 7) || (ldb & 7)) return hipErrorInvalidValue;
+  const int64_t tiles = (int64_t)((N1 + GT - 1) / GT) * ((N2 + GT - 1) / GT) * taps;
+  const int64_t n = (int64_t)N1 * N2;
+  int splits = 1;
+  while (scratch && tiles * splits < 512 && R / (2 * splits) >= 4 * HR && (size_t)(2 * splits) * taps * n <= scratch_floats && splits < 256) splits *= 2;
+  G16tn g;
+  g.C = C; g.ldc = N2; g.beta = beta;
+  if (splits == 1 && taps == 1) {   // enough tiles already (a [N x C] table gradient): no partials, one launch
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.R = R; g.N1 = N1; g.N2 = N2; g.taps = 1; g.L = L; g.splits = 1;
+    g.rows_per_split = (R + HR - 1) / HR * HR;
+    g.parts = nullptr;
+    for (int j = 0; j < 8; j++) g.shift[j] = j == 0 && shift ? shift[0] : 0;
+    hipLaunchKernelGGL(k_gemm16_tn, dim3((unsigned)((N2 + GT - 1) / GT), (unsigned)((N1 + GT - 1) / GT), 1u), dim3(256), 0, st, g);
+    return hipGetLastError();
+  }
+  if (!scratch || (size_t)splits * taps * n > scratch_floats) return hipErrorInvalidValue;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.R = R; g.N1 = N1; g.N2 = N2; g.taps = taps; g.L = L; g.splits = splits;
+  g.rows_per_split = ((R + splits - 1) / splits + HR - 1) / HR * HR;
+  g.parts = scratch;
+  for (int j = 0; j < 8; j++) g.shift[j] = j < taps && shift ? shift[j] : 0;
+  hipLaunchKernelGGL(k_gemm16_tn, dim3((unsigned)((N2 + GT - 1) / GT), (unsigned)((N1 + GT - 1) / GT), (unsigned)(taps * splits)), dim3(256), 0, st, g);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_gemm16_tn_sum, dim3((unsigned)((n * taps + 255) / 256)), dim3(256), 0, st, scratch, taps, splits, n, C, c_tap, beta);
+  return hipGetLastError();
+}

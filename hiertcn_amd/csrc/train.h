@@ -16,7 +16,10 @@ struct TrainCtx {
   TrainSeg convT[HIERTCN_MAX_BLOCKS], conv_bias[HIERTCN_MAX_BLOCKS], resT[HIERTCN_MAX_BLOCKS], res_bias[HIERTCN_MAX_BLOCKS];
   TrainSeg wg[HIERTCN_MAX_LAYERS], bg[HIERTCN_MAX_LAYERS], wc[HIERTCN_MAX_LAYERS], bc[HIERTCN_MAX_LAYERS];
   TrainSeg lwg[HIERTCN_MAX_LAYERS], lbg[HIERTCN_MAX_LAYERS], lwc[HIERTCN_MAX_LAYERS], lbc[HIERTCN_MAX_LAYERS];   // HierGRU low level
-  void* blas = nullptr;  // rocblas_handle
+  uint16_t* dlay = nullptr;   // one allocation behind projD / convD / resD: the 16-bit kernels with the OUTPUT channel contiguous
+  uint16_t* projD = nullptr;  // [Ein][Eout]
+  uint16_t* convD[HIERTCN_MAX_BLOCKS] = {};   // [tap][Cin][Cout]
+  uint16_t* resD[HIERTCN_MAX_BLOCKS] = {};    // [Cin][Cout]
   int64_t step = 0;      // Adam time step t
   float* master() const { return arena; }
   float* grad() const { return arena + total; }
@@ -27,7 +30,7 @@ struct TrainCtx {
 const char* train_last_error();
 // lays out the segments (no allocation); returns total floats per arena
 size_t train_layout(const ModelDev& m, TrainCtx& t);
-// allocates the arenas + the rocBLAS handle and points ModelDev's fp32 tensors INTO the master arena
+// allocates the arenas and points ModelDev's fp32 tensors INTO the master arena
 hipError_t train_enable(ModelDev& m, TrainCtx& t);
 void train_destroy(TrainCtx& t);
 // fp32 masters of the bf16-stored tensors, from the reference-layout sources (called by hiertcn_set_weights)

@@ -6,18 +6,18 @@
 //
 // First build, correctness first.  The d-logits matrix [rows, N] is never held whole: the scoring kernel
 // re-computes it 64-item stage by stage and writes bf16 chunks G[rows, NC]; the two products per chunk
-// (d hidden += G . Wo_chunk^T, d Wo_chunk = hidden^T . G) and every other backward matrix product are PLAIN
-// GEMMs and go to rocBLAS (bf16 inputs / fp32 accumulate for the low level, fp32 for the GRU); the pieces
+// (d hidden += G . Wo_chunk^T, d Wo_chunk = hidden^T . G) and every other backward matrix product are plain
+// GEMMs on the library's own MFMA kernels (gemm.hip: 16-bit inputs / fp32 accumulate for the low level, exact fp32 for the GRU); the pieces
 // around them (masks of the relus, causal shifts, scatter-adds into the item table, gate derivatives, Adam)
 // are hand-written, bandwidth-bound kernels.  Gradients pass straight through the bf16 roundings of the
 // forward pass.  Both model_hier and the single-level model_tcn (per-block widths, Dense down-sample residual).
-#include <rocblas/rocblas.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include "train.h"
+#include "gemm.h"
 
 static thread_local char g_terr[512] = "";
 const char* train_last_error() { return g_terr; }
@@ -33,18 +33,6 @@ static int tfail(const char* fmt, ...) {
     hipError_t e_ = (expr);                                                                              \
     if (e_ != hipSuccess) return tfail("%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_), __FILE__, __LINE__); \
   } while (0)
-#define T_BLAS(expr)                                                                          \
-  do {                                                                                        \
-    rocblas_status s_ = (expr);                                                               \
-    if (s_ != rocblas_status_success) return tfail("%s failed: rocblas_status %d (%s:%d)", #expr, (int)s_, __FILE__, __LINE__); \
-  } while (0)
-
-#ifdef HIERTCN_F16
-#define HIERTCN_BLAS_16 rocblas_datatype_f16_r
-#else
-#define HIERTCN_BLAS_16 rocblas_datatype_bf16_r
-#endif
-
 static size_t al64(size_t n) { return (n + 63) & ~(size_t)63; }
 
 size_t train_layout(const ModelDev& m, TrainCtx& t) {
@@ -93,10 +81,17 @@ hipError_t train_enable(ModelDev& m, TrainCtx& t) {
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&t.arena), 4 * t.total * sizeof(float));
   if (e != hipSuccess) return e;
   if ((e = hipMemset(t.arena, 0, 4 * t.total * sizeof(float))) != hipSuccess) return e;
-  rocblas_handle hdl = nullptr;
-  if (rocblas_create_handle(&hdl) != rocblas_status_success) return hipErrorUnknown;
-  rocblas_set_pointer_mode(hdl, rocblas_pointer_mode_host);
-  t.blas = hdl;
+  {  // [tap][Cin][Cout] / [Ein][Eout] copies of the 16-bit kernels: the k-contiguous B operand of d a_in = d c . W^T (gemm16_nt)
+    size_t n = m.hier ? (size_t)m.E * m.E : 0;
+    for (int i = 0, cin = m.E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) n += (size_t)m.K * cin * m.C[i] + (cin != m.C[i] ? (size_t)cin * m.C[i] : 0);
+    if ((e = hipMalloc(reinterpret_cast<void**>(&t.dlay), (n ? n : 8) * sizeof(uint16_t))) != hipSuccess) return e;
+    uint16_t* p = t.dlay;
+    if (m.hier) { t.projD = p; p += (size_t)m.E * m.E; }
+    for (int i = 0, cin = m.E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
+      t.convD[i] = p; p += (size_t)m.K * cin * m.C[i];
+      if (cin != m.C[i]) { t.resD[i] = p; p += (size_t)cin * m.C[i]; }
+    }
+  }
   // the fp32-stored tensors ARE their masters from now on (the conversion kernels of set_weights write into the arena)
   float* M = t.master();
   m.out_bias = M + t.out_bias.off;
@@ -122,9 +117,9 @@ hipError_t train_enable(ModelDev& m, TrainCtx& t) {
 }
 
 void train_destroy(TrainCtx& t) {
-  if (t.blas) rocblas_destroy_handle(reinterpret_cast<rocblas_handle>(t.blas));
   if (t.arena) (void)hipFree(t.arena);
-  t.blas = nullptr; t.arena = nullptr; t.enabled = false;
+  if (t.dlay) (void)hipFree(t.dlay);
+  t.arena = nullptr; t.dlay = nullptr; t.enabled = false;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -158,6 +153,14 @@ hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t 
     if ((e = cast_bf16(M + t.convT[i].off, m.convT[i], (int64_t)t.convT[i].n, 0, st)) != hipSuccess) return e;
     if (t.resT[i].n && (e = cast_bf16(M + t.resT[i].off, m.resT[i], (int64_t)t.resT[i].n, 0, st)) != hipSuccess) return e;
   }
+  // the transposed copies the backward's d a_in products read (masters are [tap][Cout][Cin] / [Eout][Ein])
+  if (m.hier && (e = launch_transpose_to_bf16(M + t.projT.off, t.projD, m.E, m.E, m.E, st)) != hipSuccess) return e;
+  for (int i = 0, cin = m.E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
+    const int cout = m.C[i];
+    for (int j = 0; j < m.K; j++)
+      if ((e = launch_transpose_to_bf16(M + t.convT[i].off + (size_t)j * cin * cout, t.convD[i] + (size_t)j * cin * cout, cout, cin, cin, st)) != hipSuccess) return e;
+    if (t.resT[i].n && (e = launch_transpose_to_bf16(M + t.resT[i].off, t.resD[i], cout, cin, cin, st)) != hipSuccess) return e;
+  }
   return refresh_frag_major(m, st);
 }
 
@@ -179,7 +182,7 @@ hipError_t train_fill_masters(const ModelDev& m, TrainCtx& t, const hiertcn_weig
   }
   t.step = 0;
   if ((e = hipMemsetAsync(t.mom1(), 0, 2 * t.total * sizeof(float), st)) != hipSuccess) return e;  // m and v
-  return hipSuccess;
+  return train_refresh_bf16(m, t, st);   // every 16-bit copy from the masters, incl. the transposed ones only the backward reads
 }
 
 // act[b] = number of valid steps of lane b; users += 1 for every lane with at least one (model.py:112-113)
@@ -306,20 +309,6 @@ __global__ void k_block_bwd(const float* __restrict__ da, const uint16_t* __rest
   o.x = pack2bf(d4[0], d4[1]);
   o.y = pack2bf(d4[2], d4[3]);
   *reinterpret_cast<uint2*>(dc + i) = o;
-}
-
-// dst[seq][t][:] = src[seq][t - shift][:] when 0 <= t - shift < L, else 0  (causal shift forward, anti-causal for shift < 0)
-__global__ void k_shift_rows(const uint16_t* __restrict__ src, uint16_t* __restrict__ dst, int64_t n_rows, int L, int C, int shift) {
-  const int ch = C >> 3;
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_rows * ch) return;
-  const int64_t r = i / ch;
-  const int c = (int)(i - r * ch);
-  const int t = (int)(r % L);
-  const int ts = t - shift;
-  uint4 v = make_uint4(0, 0, 0, 0);
-  if (ts >= 0 && ts < L) v = *reinterpret_cast<const uint4*>(src + (r - shift) * C + c * 8);
-  *reinterpret_cast<uint4*>(dst + r * C + c * 8) = v;
 }
 
 // table[ids[r]][:] += rows[r][:] (fp32 atomics; id 0 = null id has no embedding: model.py:59).  One wave per row, lane e
@@ -589,10 +578,11 @@ hipError_t train_rows_op(const ModelDev& m, const TrainCtx& t, int op, const int
 // ---------------------------------------------------------------------------------------------------------
 struct TrainWs {
   size_t pooled, sproj, gru_ws, gru_save, act[2 * HIERTCN_MAX_BLOCKS + 2], rank, ce, tgt, lse, w, lane_act, users;
-  size_t dA, dB, dsf, dcb, shb, dub, gchunk, map, nvalid, cscratch, hc, yc, wc, lc, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
+  size_t dA, dB, dsf, dcb, dub, gchunk, map, nvalid, cscratch, hc, yc, wc, lc, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
   size_t total;
   size_t lg_uf, lg_len, lg_save, lg_dcar[2], lg_dac, lg_dag, lg_dhpart, lg_dcat_c, lg_dcat_g, lg_din_up;   // HierGRU low level
   size_t splitk;  // partial outputs of the split-K weight-gradient GEMMs
+  size_t splitk_floats;
   size_t rb;      // ln w - lse per compact row (+ one padding stage of -inf), k_dlogits / k_sgrad
   size_t rb2;     // the same x log2e (k_sgrad, rows stationary)
   size_t bl2;     // bo x log2e [NP] (k_sgrad, items stationary)
@@ -625,7 +615,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.lane_act = take((size_t)B * 4);
   w.users = take(256);
   w.dA = take(R * C * 4); w.dB = take(R * C * 4); w.dsf = take((R + 64) * C * 4);
-  w.dcb = take(R * C * 2); w.shb = take(R * C * 2); w.dub = take(R * C * 2);
+  w.dcb = take(R * C * 2); w.dub = take(R * C * 2);
   // G chunk: at most 16 GiB of bf16 (the two products per chunk run 12 % faster than with 4 GiB chunks: fewer, larger
   // GEMMs -- profiles/r1_train_notes.md), at least one 64-item stage
   size_t budget = (size_t)16 << 30;
@@ -666,7 +656,11 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.rb2 = take((R + 64) * 4);
   w.bl2 = take((size_t)m.NP * 4);
   w.ovf = take((R + 64) * 4);
-  w.splitk = take((size_t)32 * C * C * 4);
+  {  // partial tiles of the row-sliced weight-gradient GEMMs (gemm.hip): up to 64 slices of the largest [out x in] gradient
+    const size_t gw = (size_t)2 * H * (size_t)(E > H ? E : H), cw = (size_t)C * C;
+    w.splitk_floats = (size_t)64 * (gw > cw ? gw : cw);
+    w.splitk = take(w.splitk_floats * 4);
+  }
   w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
   w.dsb_ext = take((size_t)B * (S + 1) * HT * 4);
   w.dpooled = take((size_t)B * S * E * 4);
@@ -689,56 +683,6 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
 
 size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L) { return train_ws(m, B, S, L).total; }
 
-// row-major helpers over rocBLAS (column-major):  C[M][N] (ldc) (+)= A[M][K] (lda) . B[K][N] (ldb), any operand optionally transposed
-// expressed directly in the column-major call: see the derivations next to each call site.
-static rocblas_status gemm_bf16(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const void* A, int lda,
-                                const void* B, int ldb, float beta, float* Cc, int ldc) {
-  const float one = 1.f;
-  return rocblas_gemm_ex(h, ta, tb, m, n, k, &one, A, HIERTCN_BLAS_16, lda, B, HIERTCN_BLAS_16, ldb, &beta, Cc,
-                         rocblas_datatype_f32_r, ldc, Cc, rocblas_datatype_f32_r, ldc, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-}
-// Weight gradients of the conv / projection layers: [Cin x Cout] outputs with K = all rows of the batch.  One such GEMM has
-// 16 output tiles and leaves 240 CUs idle (rocBLAS: MT64x64, 988 us at cfg-3), so K is cut into P slices run as one strided
-// batch into P partial outputs, which k_sum_parts adds up (P * 256 KB of scratch).
-__global__ void k_sum_parts(const float* __restrict__ parts, int P, int64_t n, float* __restrict__ out) {
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
-  float s = 0.f;
-  for (int p = 0; p < P; p++) s += parts[(int64_t)p * n + i];
-  out[i] = s;
-}
-static int splitk_parts(int64_t k) {
-  for (int p = 32; p > 1; p >>= 1)
-    if (k % p == 0 && k / p >= 2048) return p;
-  return 1;
-}
-// C[m x n] (ldc == m) = A[m x k] . B[n x k]^T, column-major, both operands K-contiguous by column: the (OPN, OPT) weight-gradient form
-static rocblas_status gemm_bf16_wgrad(rocblas_handle h, int m, int n, int k, const void* A, int lda, const void* B, int ldb, float* Cc,
-                                      float* scratch, hipStream_t st) {
-  const int P = scratch ? splitk_parts(k) : 1;
-  const float one = 1.f, zero = 0.f;
-  if (P == 1)
-    return rocblas_gemm_ex(h, rocblas_operation_none, rocblas_operation_transpose, m, n, k, &one, A, HIERTCN_BLAS_16, lda, B, HIERTCN_BLAS_16, ldb,
-                           &zero, Cc, rocblas_datatype_f32_r, m, Cc, rocblas_datatype_f32_r, m, rocblas_datatype_f32_r,
-                           rocblas_gemm_algo_standard, 0, 0);
-  const int kp = k / P;
-  rocblas_status rs = rocblas_gemm_strided_batched_ex(
-      h, rocblas_operation_none, rocblas_operation_transpose, m, n, kp, &one, A, HIERTCN_BLAS_16, lda, (rocblas_stride)kp * lda, B, HIERTCN_BLAS_16,
-      ldb, (rocblas_stride)kp * ldb, &zero, scratch, rocblas_datatype_f32_r, m, (rocblas_stride)m * n, scratch, rocblas_datatype_f32_r, m,
-      (rocblas_stride)m * n, P, rocblas_datatype_f32_r, rocblas_gemm_algo_standard, 0, 0);
-  if (rs != rocblas_status_success) return rs;
-  const int64_t nn = (int64_t)m * n;
-  hipLaunchKernelGGL(k_sum_parts, dim3((unsigned)((nn + 255) / 256)), dim3(256), 0, st, scratch, P, nn, Cc);
-  return hipGetLastError() == hipSuccess ? rocblas_status_success : rocblas_status_internal_error;
-}
-static rocblas_status gemm_f32(rocblas_handle h, rocblas_operation ta, rocblas_operation tb, int m, int n, int k, const float* A, int lda,
-                               const float* B, int ldb, float beta, float* Cc, int ldc) {
-  const float one = 1.f;
-  return rocblas_sgemm(h, ta, tb, m, n, k, &one, A, lda, B, ldb, &beta, Cc, ldc);
-}
-#define OPN rocblas_operation_none
-#define OPT rocblas_operation_transpose
-
 // phases: TRAIN_BEGIN = forward + loss + backward of the scoring layer (d out_kernel / d out_bias are final behind it: a data-parallel
 // caller starts their collective there), TRAIN_FINISH = the rest of the backward pass; both = the whole step.
 // users_global (device, optional): the user count of the GLOBAL batch (all ranks) that normalises the loss (model.py:113-117);
@@ -748,16 +692,13 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
                            const float* users_global) {
   const bool do_begin = (phases & TRAIN_BEGIN) != 0, do_finish = (phases & TRAIN_FINISH) != 0;
   if (!t.enabled) return tfail("training is not enabled on this handle (hiertcn_train_enable before hiertcn_set_weights)");
-  rocblas_handle bl = reinterpret_cast<rocblas_handle>(t.blas);
-  T_BLAS(rocblas_set_stream(bl, st));
   const TrainWs w = train_ws(m, B, S, L);
   unsigned char* ws = reinterpret_cast<unsigned char*>(wsp);
   const int E = m.E, H = m.H, HT = m.HT, nb = m.n_blocks, CL = m.Clast;
   int Cmax = E;
   for (int i = 0; i < nb; i++) Cmax = m.C[i] > Cmax ? m.C[i] : Cmax;
   const int64_t n_sess = (int64_t)B * S, R = n_sess * L;
-  if (R * (int64_t)Cmax >= ((int64_t)1 << 31)) return tfail("train step: B*S*L*C must stay below 2^31 (rocBLAS 32-bit dims); use a smaller batch");
-  if (!m.hier && S != 1) return tfail("train step: the single-level model takes one sequence per lane (S = 1)");
+    if (!m.hier && S != 1) return tfail("train step: the single-level model takes one sequence per lane (S = 1)");
   float* G = t.grad();
   if (do_begin) T_HIP(hipMemsetAsync(G, 0, t.total * sizeof(float), st));
 #define F32(o) reinterpret_cast<float*>(ws + (o))
@@ -892,9 +833,9 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
         const int rows = (int)(r1 - r0);
         T_HIP(launch_dlogits_rows(m, hc, F32(w.rb), yc, F32(w.wc), F32(w.lc), so.target, rmap, r0, r1, Gc, G + t.out_bias.off, st));
         // dH[rows][C] = G[rows][NP] . outT[NP][C]   == col-major: dH^T[C x rows] = outT^T[C x NP] . G^T[NP x rows] (ld = ldg)
-        T_BLAS(gemm_bf16(bl, OPN, OPN, CL, rows, m.NP, m.outT, CL, Gc, (int)ldg, 0.f, dHc + r0 * CL, CL));
+        T_HIP(gemm16_nn(Gc, ldg, m.outT, CL, dHc + r0 * CL, CL, rows, CL, m.NP, 0.f, st));
         // d outT[NP][C] += G^T[NP x rows] . hidden[rows][C]   == col-major [C x NP] += hidden^T[C x rows] . (G^T[NP x rows])^T
-        T_BLAS(gemm_bf16(bl, OPN, OPT, CL, m.NP, rows, hc + r0 * CL, CL, Gc, (int)ldg, r0 == 0 ? 0.f : 1.f, G + t.outT.off, CL));
+        T_HIP(gemm16_tn(Gc, ldg, hc + r0 * CL, CL, G + t.outT.off, 0, m.NP, CL, rows, 1, nullptr, 0, r0 == 0 ? 0.f : 1.f, nullptr, 0, st));
       }
     } else
     for (int s0 = 0; s0 < n_stages; s0 += w.nc_stages) {
@@ -906,9 +847,9 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
                          G + t.out_bias.off + (size_t)s0 * 64);
       T_HIP(hipGetLastError());
       // dH[Rv][C] += G[Rv][NC] . outT_chunk[NC][C]   == col-major: dH^T[C x Rv] += outT_chunk^T[C x NC] . G^T[NC x Rv]
-      T_BLAS(gemm_bf16(bl, OPN, OPN, CL, (int)Rv, NC, m.outT + (size_t)s0 * 64 * CL, CL, Gc, NC, 1.f, dHc, CL));
+      T_HIP(gemm16_nn(Gc, NC, m.outT + (size_t)s0 * 64 * CL, CL, dHc, CL, Rv, CL, NC, 1.f, st));
       // d outT_chunk[NC][C] = G^T[NC x Rv] . hidden[Rv][C]   == col-major [C x NC] = hidden^T[C x Rv] . (G^T[NC x Rv])^T
-      T_BLAS(gemm_bf16(bl, OPN, OPT, CL, NC, (int)Rv, hc, CL, Gc, NC, 0.f, G + t.outT.off + (size_t)s0 * 64 * CL, CL));
+      T_HIP(gemm16_tn(Gc, NC, hc, CL, G + t.outT.off + (size_t)s0 * 64 * CL, 0, NC, CL, Rv, 1, nullptr, 0, 0.f, nullptr, 0, st));
     }
     hipLaunchKernelGGL(k_scatter_rows_f32, dim3((unsigned)((Rv * (CL / 4) + 255) / 256)), dim3(256), 0, st, dHc, rmap, Rv, CL, dH);
     T_HIP(hipGetLastError());
@@ -922,7 +863,6 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   float* dprev = F32(w.dB);    // grad of a^k
   float* dsf = F32(w.dsf);
   uint16_t* dcb = BF(w.dcb);
-  uint16_t* shb = BF(w.shb);
   uint16_t* dub = BF(w.dub);
   if (m.low_gru) {
     // ============ HierGRU low level: BPTT over the L steps of every session (model_gru.py:47-55), last step first ============
@@ -957,15 +897,15 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
         hipLaunchKernelGGL(k_lgru_bwd_a, dim3(gMH), dim3(256), 0, st, lcar + (size_t)l * H, HT, dout, ld_dout, lb.seq_len, tt, hold, HT, gates, cand,
                            M, H, dac, dag, dhpart);
         T_HIP(hipGetLastError());
-        T_BLAS(gemm_f32(bl, OPN, OPN, K, M, H, m.lgru_wc[l], K, dac, H, 0.f, dcat_c, K));
-        T_BLAS(gemm_f32(bl, OPN, OPT, in, H, M, inp, ldin, dac, H, 1.f, G + t.lwc[l].off, K));
-        T_BLAS(gemm_f32(bl, OPN, OPT, H, H, M, rh, H, dac, H, 1.f, G + t.lwc[l].off + in, K));
+        T_HIP(gemm32_nn(dac, H, m.lgru_wc[l], K, dcat_c, K, M, K, H, 0.f, st));
+        T_HIP(gemm32_tn(dac, H, inp, ldin, G + t.lwc[l].off, K, H, in, M, 1.f, F32(w.splitk), w.splitk_floats, st));
+        T_HIP(gemm32_tn(dac, H, rh, H, G + t.lwc[l].off + in, K, H, H, M, 1.f, F32(w.splitk), w.splitk_floats, st));
         T_HIP(colsum_f32(dac, M, H, H, G + t.lbc[l].off, st));
         hipLaunchKernelGGL(k_gru_bwd_b, dim3(gMH), dim3(256), 0, st, dcat_c, K, in, hold, HT, gates, M, H, dag, dhpart);
         T_HIP(hipGetLastError());
-        T_BLAS(gemm_f32(bl, OPN, OPN, K, M, 2 * H, m.lgru_wg[l], K, dag, 2 * H, 0.f, dcat_g, K));
-        T_BLAS(gemm_f32(bl, OPN, OPT, in, 2 * H, M, inp, ldin, dag, 2 * H, 1.f, G + t.lwg[l].off, K));
-        T_BLAS(gemm_f32(bl, OPN, OPT, H, 2 * H, M, hold, HT, dag, 2 * H, 1.f, G + t.lwg[l].off + in, K));
+        T_HIP(gemm32_nn(dag, 2 * H, m.lgru_wg[l], K, dcat_g, K, M, K, 2 * H, 0.f, st));
+        T_HIP(gemm32_tn(dag, 2 * H, inp, ldin, G + t.lwg[l].off, K, 2 * H, in, M, 1.f, F32(w.splitk), w.splitk_floats, st));
+        T_HIP(gemm32_tn(dag, 2 * H, hold, HT, G + t.lwg[l].off + in, K, 2 * H, H, M, 1.f, F32(w.splitk), w.splitk_floats, st));
         T_HIP(colsum_f32(dag, M, 2 * H, 2 * H, G + t.lbg[l].off, st));
         float* dst_in = (l == 0) ? du + (size_t)tt * E : din_up;
         const int64_t ldi = (l == 0) ? (int64_t)L * E : H;
@@ -996,24 +936,21 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       T_HIP(cast_bf16(dsf, dub, nOut, 0, st));
       T_HIP(colsum_f32(dsf, R, cout, cout, G + t.res_bias[i].off, st));
       // d resT[Cout][Cin] = ds^T[Cout x R] . a_in[R][Cin]   == col-major [Cin x Cout] = a_in^T[Cin x R] . (ds^T)^T
-      T_BLAS(gemm_bf16_wgrad(bl, cin, cout, (int)R, a_in, cin, dub, cout, G + t.resT[i].off, F32(w.splitk), st));
+      T_HIP(gemm16_tn(dub, cout, a_in, cin, G + t.resT[i].off, 0, cout, cin, R, 1, nullptr, 0, 0.f, F32(w.splitk), w.splitk_floats, st));
       // d a_in[R][Cin] = ds[R][Cout] . resT[Cout][Cin]   == col-major [Cin x R] = resT(col-major [Cin x Cout]) . ds^T[Cout x R]
-      T_BLAS(gemm_bf16(bl, OPN, OPN, cin, (int)R, cout, m.resT[i], cin, dub, cout, 0.f, dprev, cin));
+      T_HIP(gemm16_nt(dub, cout, t.resD[i], cout, dprev, cin, R, cin, cout, 1, nullptr, 0, 0.f, st));
     } else {
       // identity residual: d a_in starts as ds
       T_HIP(hipMemcpyAsync(dprev, dsf, (size_t)nOut * 4, hipMemcpyDeviceToDevice, st));
     }
-    for (int j = 0; j < m.K; j++) {
-      const int shift = (m.K - 1 - j) * dil;   // o[t] += a_in[t - shift] . W_j
-      const uint16_t* Wj = m.convT[i] + (size_t)j * cin * cout;   // [Cout][Cin]
-      // d W_j^T [Cout][Cin] = dc^T[Cout x R] . Xs[R][Cin], Xs[t] = a_in[t - shift]   == col-major [Cin x Cout] = Xs^T[Cin x R] . (dc^T[Cout x R])^T
-      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (cin / 8) + 255) / 256)), dim3(256), 0, st, a_in, shb, R, L, cin, shift);
-      T_HIP(hipGetLastError());
-      T_BLAS(gemm_bf16_wgrad(bl, cin, cout, (int)R, shb, cin, dcb, cout, G + t.convT[i].off + (size_t)j * cin * cout, F32(w.splitk), st));
-      // d a_in[tau] += dc[tau + shift] . W_j^T: rows [R][Cout] . [Cout][Cin]   == col-major [Cin x R] += W_j(col-major [Cin x Cout]) . dcs^T[Cout x R]
-      hipLaunchKernelGGL(k_shift_rows, dim3((unsigned)((R * (cout / 8) + 255) / 256)), dim3(256), 0, st, dcb, shb, R, L, cout, -shift);
-      T_HIP(hipGetLastError());
-      T_BLAS(gemm_bf16(bl, OPN, OPN, cin, (int)R, cout, Wj, cin, shb, cout, 1.f, dprev, cin));
+    {
+      // o[t] = sum_j a_in[t - s_j] . W_j with s_j = (K-1-j) dil (customized_tcn_cell.py:46-49), all taps in one launch each:
+      //   d W_j^T[Cout][Cin] = sum_t dc[t]^T . a_in[t - s_j]          (row-sliced, partial tiles summed in slice order)
+      //   d a_in[tau]       += sum_j dc[tau + s_j] . W_j^T            (W kept as [tap][Cin][Cout] for this product: TrainCtx::convD)
+      int back[8], fwd[8];
+      for (int j = 0; j < m.K; j++) { fwd[j] = (m.K - 1 - j) * dil; back[j] = -fwd[j]; }
+      T_HIP(gemm16_tn(dcb, cout, a_in, cin, G + t.convT[i].off, (int64_t)cin * cout, cout, cin, R, m.K, back, L, 0.f, F32(w.splitk), w.splitk_floats, st));
+      T_HIP(gemm16_nt(dcb, cout, t.convD[i], cout, dprev, cin, R, cin, cout, m.K, fwd, L, 1.f, st));
     }
     float* tmp = da; da = dprev; dprev = tmp;
   }
@@ -1031,9 +968,9 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // ================= projection u = e . Wp[:E] + sproj (model_hier.py:54-55 -> model_tcn.py:35) ============
   T_HIP(cast_bf16(da, dub, nRC, 0, st));
   // d projT[Eout][Ein] = du^T[Eout x R] . e[R][Ein]   == col-major [Ein x Eout] = e^T[Ein x R] . (du^T)^T
-  T_BLAS(gemm_bf16_wgrad(bl, E, E, (int)R, a_emb, E, dub, E, G + t.projT.off, F32(w.splitk), st));
+  T_HIP(gemm16_tn(dub, E, a_emb, E, G + t.projT.off, 0, E, E, R, 1, nullptr, 0, 0.f, F32(w.splitk), w.splitk_floats, st));
   // d e[R][Ein] = du[R][Eout] . projT[Eout][Ein]   == col-major [Ein x R] = projT(col-major [Ein x Eout]) . du^T[Eout x R]
-  T_BLAS(gemm_bf16(bl, OPN, OPN, E, (int)R, E, m.projT, E, dub, E, 0.f, dprev, E));
+  T_HIP(gemm16_nt(dub, E, t.projD, E, dprev, E, R, E, E, 1, nullptr, 0, 0.f, st));
   hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E, m.N);
   T_HIP(hipGetLastError());
   // d sproj, laid out [B][S+1][E] like the state history (slot S = 0)
@@ -1042,10 +979,10 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   T_HIP(hipGetLastError());
   const int Mext = B * (S + 1);
   // d projS[E][HT] = dsproj^T[E x M] . state_before[M][HT]   == col-major [HT x E] = hist^T[HT x M] . (dsp^T[E x M])^T
-  T_BLAS(gemm_f32(bl, OPN, OPT, HT, E, Mext, hist, HT, dsp, E, 0.f, G + t.projS.off, HT));
+  T_HIP(gemm32_tn(dsp, E, hist, HT, G + t.projS.off, HT, E, HT, Mext, 0.f, F32(w.splitk), w.splitk_floats, st));
   // d state_before[M][HT] = dsproj[M][E] . projS[E][HT]   == col-major [HT x M] = projS(col-major [HT x E]) . dsp^T[E x M]
   float* dsb = F32(w.dsb_ext);
-  T_BLAS(gemm_f32(bl, OPN, OPN, HT, Mext, E, m.projS, HT, dsp, E, 0.f, dsb, HT));
+  T_HIP(gemm32_nn(dsp, E, m.projS, HT, dsb, HT, Mext, HT, E, 0.f, st));
 
   // ================= GRU through the S slots, last to first (customed_gru_cell.py:323-337, model_hier.py:91-93) =====
   float* dcar = F32(w.dstate[0]);
@@ -1080,17 +1017,17 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
                          gates, cand, B, H, dac, dag, dhpart);
       T_HIP(hipGetLastError());
       // d[in | r*h] [B][K] = dac[B][H] . wc[H][K]   == col-major [K x B] = wc(col-major [K x H]) . dac^T[H x B]
-      T_BLAS(gemm_f32(bl, OPN, OPN, K, B, H, m.gru_wc[l], K, dac, H, 0.f, dcat_c, K));
+      T_HIP(gemm32_nn(dac, H, m.gru_wc[l], K, dcat_c, K, B, K, H, 0.f, st));
       // d wc[H][K] += dac^T[H x B] . [in | r*h][B][K]   == col-major [K x H], rows [0,in) from `in`, rows [in,K) from r*h
-      T_BLAS(gemm_f32(bl, OPN, OPT, in, H, B, inp, ldin, dac, H, 1.f, G + t.wc[l].off, K));
-      T_BLAS(gemm_f32(bl, OPN, OPT, H, H, B, rh, H, dac, H, 1.f, G + t.wc[l].off + in, K));
+      T_HIP(gemm32_tn(dac, H, inp, ldin, G + t.wc[l].off, K, H, in, B, 1.f, F32(w.splitk), w.splitk_floats, st));
+      T_HIP(gemm32_tn(dac, H, rh, H, G + t.wc[l].off + in, K, H, H, B, 1.f, F32(w.splitk), w.splitk_floats, st));
       T_HIP(colsum_f32(dac, B, H, H, G + t.bc[l].off, st));
       hipLaunchKernelGGL(k_gru_bwd_b, dim3(gBH), dim3(256), 0, st, dcat_c, K, in, hold, (int)hs, gates, B, H, dag, dhpart);
       T_HIP(hipGetLastError());
       // d[in | h] [B][K] = dag[B][2H] . wg[2H][K]
-      T_BLAS(gemm_f32(bl, OPN, OPN, K, B, 2 * H, m.gru_wg[l], K, dag, 2 * H, 0.f, dcat_g, K));
-      T_BLAS(gemm_f32(bl, OPN, OPT, in, 2 * H, B, inp, ldin, dag, 2 * H, 1.f, G + t.wg[l].off, K));
-      T_BLAS(gemm_f32(bl, OPN, OPT, H, 2 * H, B, hold, (int)hs, dag, 2 * H, 1.f, G + t.wg[l].off + in, K));
+      T_HIP(gemm32_nn(dag, 2 * H, m.gru_wg[l], K, dcat_g, K, B, K, 2 * H, 0.f, st));
+      T_HIP(gemm32_tn(dag, 2 * H, inp, ldin, G + t.wg[l].off, K, 2 * H, in, B, 1.f, F32(w.splitk), w.splitk_floats, st));
+      T_HIP(gemm32_tn(dag, 2 * H, hold, (int)hs, G + t.wg[l].off + in, K, 2 * H, H, B, 1.f, F32(w.splitk), w.splitk_floats, st));
       T_HIP(colsum_f32(dag, B, 2 * H, 2 * H, G + t.bg[l].off, st));
       float* dst_in = (l == 0) ? dpooled + (size_t)s * E : din_up;
       const int ldi = (l == 0) ? S * E : H;
