@@ -184,6 +184,31 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
     return out
 
 
+def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
+    """-> the `gmm` object: ms per hiertcn_gmm_loss call at BASELINE.json configs[4]'s shape and the MFMA rate of its M mean-table passes."""
+    import torch
+
+    from hiertcn_amd.args import make_args
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel, init_params
+    ga = make_args([], model_type="tcn_gmm", item_num=n_out, output_dim=n_out, num_mixture=n_mix, sigma=0.1, loss="gmm_prob",
+                   tcn_channel=[dim, dim], kernel_size=5, adjust=False)
+    model = TcnGmmModel(ga, init_params(ga, 3))
+    hid = (torch.randn(rows, dim, device="cuda") * 0.5).to(torch.bfloat16)
+    y = torch.randint(1, n_out, (rows,), device="cuda", dtype=torch.int32)
+    model.loss_rows(hid, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model.loss_rows(hid, y)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    model.close()
+    flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
+    return {"what": "hiertcn_gmm_loss (gmm_prob): M passes of k_score_pipe<256,21,...> (sum-of-squares epilogue) over the [D, C] mean tables + prior + "
+                    "finish, random hidden rows", "rows": rows, "output_dim": n_out, "num_mixture": n_mix, "ms": round(dt * 1e3, 3),
+            "tflops": round(flop / dt / 1e12, 1), "frac_of_peak": round(flop / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+
+
 def dvfs_probe(eng, rows, n_items, dim, seconds=1.5):
     """The scoring kernel alone, back to back for `seconds`, on random-normal hidden rows and on all-zero hidden rows (the MFMA B
     operand: same instruction stream, same LDS / L2 traffic, every product zero), with the shader clock read from rocm-smi (sysfs)
@@ -242,6 +267,7 @@ def main():
     ap.add_argument("--users-per-step", type=int, default=4096, help="users per step PER GPU (4096 users = 4800 workgroups = 18.75 rounds of 256 CUs: 1.3 % tail)")
     ap.add_argument("--ragged", action="store_true", help="session lengths ~ U{1..30} instead of full")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-gmm", action="store_true", help="skip the mixture-head figure (the `gmm` object of the JSON line)")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel training leg (the `train` object of the JSON line)")
     ap.add_argument("--no-clock-probe", action="store_true", help="skip roofline.clock_probe (extra launches of the scoring kernel on random / zero operands; profiling runs skip it so that the kernel's average duration in the trace is the timed region's)")
     ap.add_argument("--train-users-per-step", type=int, default=1024, help="users per training step PER GPU")
@@ -387,6 +413,15 @@ def main():
         except Exception as e:  # noqa: BLE001  (a diagnostic, never fatal)
             dvfs = {"error": repr(e)[:200]}
 
+    # ---- mixture-output head (BASELINE.json configs[4]: model_tcn_gmm / model_gru_gmm): hiertcn_gmm_loss = M passes of the scoring kernel's main
+    # loop with the sum-of-squares epilogue over the [D, C] mean tables, at configs[4]'s shape (614,400 rows x 20,778 outputs x 5 mixtures)
+    gmm = None
+    if rank == 0 and not a.no_gmm:
+        try:
+            gmm = gmm_leg()
+        except Exception as e:  # noqa: BLE001  (secondary figure, never fatal)
+            gmm = {"error": repr(e)[:300]}
+
     # ---- training leg (north star: "RCCL all-reduce over xGMI on the shared item-embedding gradients"): the same cfg-3 model,
     # one optimizer step = forward + loss + backward + gradient collectives + TF-form Adam (model.py:135-141,
     # run_hier_xing.py:275-301), users sharded over the ranks, timed after the evaluation region under the same launch
@@ -460,6 +495,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "multi_gpu": multi,
+            "gmm": gmm,
             "train": train,
             "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
             "setup_s": round(t_setup, 1),

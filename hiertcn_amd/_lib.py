@@ -111,6 +111,7 @@ SYMBOLS = {
     "hiertcn_gmm_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hiertcn_gmm_head_means": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_gmm_lane_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
     "hiertcn_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "hiertcn_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
     "hiertcn_persistent_health": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

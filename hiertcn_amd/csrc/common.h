@@ -111,7 +111,7 @@ hipError_t launch_dlogits_rows(const ModelDev& m, const uint16_t* hc, const floa
                                const float* tgt, const int32_t* map, int64_t r0, int64_t r1, uint16_t* gout, float* dbias, hipStream_t st);
 // score_bwd.hip: the scoring layer's backward without the d-logits matrix (recompute + second product fused, device-side row count)
 bool sgrad_supported(const ModelDev& m);
-hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* lse, const int32_t* map,
+hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* ce, const float* tgt, const int32_t* map,
                                 const int32_t* n_dev, int64_t R, uint16_t* hc, int32_t* yc, float* wc, float* rb_nat, float* rb_l2, float* bias_l2,
                                 hipStream_t st);
 hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const int32_t* row_map,

@@ -406,6 +406,41 @@ int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32
   return HIERTCN_OK;
 }
 
+// model.py:111-117 on a per-step loss: mask by sign(y), per-lane mean over the valid steps (+1e-6), summed over the lanes that have one;
+// one workgroup, a lane per thread, fixed-order tree: deterministic.  out2 = [sum of lane means, user count].
+__global__ __launch_bounds__(1024) void k_gmm_lane_loss(const float* __restrict__ loss, const int32_t* __restrict__ y, int B, int T,
+                                                        double* __restrict__ out2) {
+  __shared__ double s_sum[1024];
+  __shared__ double s_usr[1024];
+  double acc = 0.0, usr = 0.0;
+  for (int b = threadIdx.x; b < B; b += 1024) {
+    float ls = 0.f;
+    int cnt = 0;
+    for (int t = 0; t < T; t++) {
+      const bool v = y[(int64_t)b * T + t] > 0;
+      ls += v ? loss[(int64_t)b * T + t] : 0.f;
+      cnt += v ? 1 : 0;
+    }
+    if (cnt > 0) { acc += (double)(ls / ((float)cnt + 1e-6f)); usr += 1.0; }
+  }
+  s_sum[threadIdx.x] = acc;
+  s_usr[threadIdx.x] = usr;
+  __syncthreads();
+  for (int o = 512; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) { s_sum[threadIdx.x] += s_sum[threadIdx.x + o]; s_usr[threadIdx.x] += s_usr[threadIdx.x + o]; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) { out2[0] = s_sum[0]; out2[1] = s_usr[0]; }
+}
+
+int hiertcn_gmm_lane_loss(hiertcn_gmm_handle_t g, const float* loss, const int32_t* y_ids, int32_t B, int32_t T, double* out2, void* stream) {
+  if (!g) return gfail(HIERTCN_ERR_INVALID, "null handle");
+  if (!loss || !y_ids || !out2 || B < 1 || T < 1) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  hipLaunchKernelGGL(k_gmm_lane_loss, dim3(1), dim3(1024), 0, reinterpret_cast<hipStream_t>(stream), loss, y_ids, B, T, out2);
+  G_HIP(hipGetLastError());
+  return HIERTCN_OK;
+}
+
 int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64_t R, int32_t m, float* mu_out, void* stream) {
   G_READY(g);
   if (!hidden || !mu_out || R < 1 || m < 0 || m >= g->M) return gfail(HIERTCN_ERR_INVALID, "bad argument");

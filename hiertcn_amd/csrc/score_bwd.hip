@@ -348,8 +348,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
 // compact scored rows: hc[p] = hidden[map[p]], yc, (ln w - lse) log2e, w for p < Rv; zeros / -inf up to the next multiple of 64 (the
 // padding rows of the last stage are read as operands).  Grid sized by R (host bound); Rv is read on the device.
 __global__ void k_sgrad_gather(const uint16_t* __restrict__ hidden, const int32_t* __restrict__ y, const float* __restrict__ w,
-                               const float* __restrict__ lse, const int32_t* __restrict__ map, const int32_t* __restrict__ n_dev, int C,
-                               uint16_t* __restrict__ hc, int32_t* __restrict__ yc, float* __restrict__ wc, float* __restrict__ rb2) {
+                               const float* __restrict__ ce, const float* __restrict__ tgt, const int32_t* __restrict__ map,
+                               const int32_t* __restrict__ n_dev, int C, uint16_t* __restrict__ hc, int32_t* __restrict__ yc, float* __restrict__ wc,
+                               float* __restrict__ rb2) {
   const int ch = C >> 3;
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t Rv = n_dev[0], Rpad = (Rv + 63) & ~(int64_t)63;
@@ -367,7 +368,7 @@ __global__ void k_sgrad_gather(const uint16_t* __restrict__ hidden, const int32_
     const float wv = w[r];
     yc[p] = y[r];
     wc[p] = wv;
-    rb2[p] = wv > 0.f ? logf(wv) - lse[r] : -INFINITY;   // natural units: the stream scalar of ITEMSTAT; ROWSTAT scales it by log2e on load
+    rb2[p] = wv > 0.f ? logf(wv) - (ce[r] + tgt[r]) : -INFINITY;   // ln w - log-sum-exp (lse = ce + target logit, loss.py:21); natural units: the stream scalar of ITEMSTAT; ROWSTAT scales it by log2e on load
   }
 }
 __global__ void k_scale_log2e(const float* __restrict__ src, float* __restrict__ dst, int64_t n_max, const int32_t* __restrict__ n_dev, int pad64) {
@@ -464,12 +465,12 @@ hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* 
   return hipGetLastError();
 }
 
-hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* lse, const int32_t* map,
+hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* ce, const float* tgt, const int32_t* map,
                                 const int32_t* n_dev, int64_t R, uint16_t* hc, int32_t* yc, float* wc, float* rb_nat, float* rb_l2, float* bias_l2,
                                 hipStream_t st) {
   if (R <= 0) return hipSuccess;
   const int64_t n = (R + 64) * (m.Clast / 8);
-  hipLaunchKernelGGL(k_sgrad_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hidden, y, w, lse, map, n_dev, m.Clast, hc, yc, wc, rb_nat);
+  hipLaunchKernelGGL(k_sgrad_gather, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, hidden, y, w, ce, tgt, map, n_dev, m.Clast, hc, yc, wc, rb_nat);
   hipLaunchKernelGGL(k_scale_log2e, dim3((unsigned)((R + 64 + 255) / 256)), dim3(256), 0, st, rb_nat, rb_l2, R + 64, n_dev, 1);
   hipLaunchKernelGGL(k_scale_log2e, dim3((unsigned)((m.NP + 255) / 256)), dim3(256), 0, st, m.out_bias, bias_l2, (int64_t)m.NP, (const int32_t*)nullptr, 0);
   return hipGetLastError();

@@ -795,18 +795,20 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   }
 
   // ================= d loss / d logits, scoring layer =====================================================
-  T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
-  hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
-  hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce, so.target, R, S * L,
-                     F32(w.w), F32(w.lse));
-  T_HIP(hipGetLastError());
-  if (!w.fused) T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
+  if (!w.fused) {   // (the fused path took the row weights before its forward pass and reads ce + target, the log-sum-exp, where it needs it)
+    T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
+    hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
+    hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce, so.target, R, S * L,
+                       F32(w.w), F32(w.lse));
+    T_HIP(hipGetLastError());
+    T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
+  }
   if (w.fused) {
     // score_bwd.hip: everything is sized by R on the host and by the device-side row count inside the kernels.  d hidden came out of
     // the forward pass; what is left is d Wo / d bo from the saved log-sum-exp (and d hidden again for row blocks that overflowed).
     uint16_t* hc = BF(w.hc);
     int32_t* yc = reinterpret_cast<int32_t*>(ws + w.yc);
-    T_HIP(launch_sgrad_prepare(m, hidden, y, F32(w.w), F32(w.lse), rmap, nvalid_d, R, hc, yc, F32(w.wc), F32(w.rb), F32(w.rb2), F32(w.bl2), st));
+    T_HIP(launch_sgrad_prepare(m, hidden, y, F32(w.w), so.ce, so.target, rmap, nvalid_d, R, hc, yc, F32(w.wc), F32(w.rb), F32(w.rb2), F32(w.bl2), st));
     T_HIP(launch_sgrad_dh(m, hc, F32(w.rb2), yc, F32(w.wc), rmap, nvalid_d, R, dH, reinterpret_cast<int32_t*>(ws + w.ovf), 1, st));
     T_HIP(launch_sgrad_dwo(m, hc, F32(w.rb), yc, F32(w.wc), nvalid_d, R, F32(w.bl2), G + t.outT.off, G + t.out_bias.off, st));
   } else

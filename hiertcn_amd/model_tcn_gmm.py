@@ -135,6 +135,22 @@ class TcnGmmModel:
                                       p(ws), ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
         return (loss, sq, tg, pl) if parts else loss
 
+    def eval_step(self, x, y) -> dict:
+        """One evaluation step of the run loop (run_gmm_xing.evaluate_gmm): ids x, y [B, T] -> the batch's masked lane-mean mixture
+        loss (model.py:111-117 on args.loss) as `loss_sum` / `user_count` (device doubles summed over lanes: ready for a cross-rank sum)."""
+        ids = torch.as_tensor(np.ascontiguousarray(np.asarray(x).astype(np.int32))).to(self.device)
+        yd = torch.as_tensor(np.ascontiguousarray(np.asarray(y).astype(np.int32))).to(self.device)
+        B, T = ids.shape
+        hidden = self.forward(ids)
+        mode = getattr(self.args, "loss", "gmm_prob")
+        if mode not in ("gmm_prob", "gmm_prob_max"):
+            raise NotImplementedError(f"args.loss={mode!r}: the mixture models evaluate 'gmm_prob' or 'gmm_prob_max' (loss.py:247-257)")
+        rows = self.loss_rows(hidden, yd, mode)
+        out2 = torch.empty(2, dtype=torch.float64, device=self.device)
+        _ck(self.lib.hiertcn_gmm_lane_loss(self._h, C.c_void_p(rows.data_ptr()), C.c_void_p(yd.data_ptr()), B, T, C.c_void_p(out2.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        return dict(sums=out2, loss_rows=rows.view(B, T))
+
     def head_means(self, hidden: torch.Tensor, m: int) -> torch.Tensor:
         """parity/debug: mu_m [R, D] fp32 materialised."""
         R = hidden.shape[0]

@@ -3,8 +3,8 @@
     python -m hiertcn_amd.run_xing --model_type hier --model_low_type tcn [flags of args.py]
 
 uniquify the log directory, build the three loaders from dataset/interactions.csv, dispatch on
-model_type.  Only the hot-path models are built: 'hier' (model_low_type 'tcn' = HierTCN, trainable; 'gru' = HierGRU,
-evaluation only) and 'tcn'.
+model_type.  Only the hot-path models are built: 'hier' (model_low_type 'tcn' = HierTCN and 'gru' = HierGRU), 'tcn', and the
+mixture-output models 'tcn_gmm' / 'gru_gmm' (evaluation flow: run_gmm_xing.py).
 """
 from __future__ import annotations
 
@@ -43,7 +43,10 @@ def main(argv=None):
     if args.model_type == "hier":
         from .run_hier_xing import run_hier
         return run_hier(args, loader_train, loader_validate, loader_test)
-    raise NotImplementedError(f"model_type {args.model_type!r}: only 'hier' (HierTCN) and 'tcn' are built (SURVEY.md 8)")
+    if args.model_type in ("tcn_gmm", "gru_gmm"):   # model.py:74-77
+        from .run_gmm_xing import run_gmm
+        return run_gmm(args, loader_train, loader_validate, loader_test)
+    raise NotImplementedError(f"model_type {args.model_type!r}: 'hier', 'tcn', 'tcn_gmm' and 'gru_gmm' are built (SURVEY.md 8)")
 
 
 if __name__ == "__main__":

@@ -326,6 +326,9 @@ int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B,
 int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32_t* y_ids, int64_t R, int32_t mode, float* loss,
                      float* sq_out, float* tgt_out, float* prior_out, void* workspace, size_t workspace_bytes, void* stream);
 int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64_t R, int32_t m, float* mu_out, void* stream);
+/* model.py:111-117 applied to the per-step mixture loss [B][T] (mask = sign(y), per-lane mean over valid steps + 1e-6): out2 (device, 2
+ * doubles) = [sum over lanes of the lane means, number of lanes with a target] -- ready for a cross-rank sum; batch loss = out2[0] / out2[1]. */
+int hiertcn_gmm_lane_loss(hiertcn_gmm_handle_t g, const float* loss, const int32_t* y_ids, int32_t B, int32_t T, double* out2, void* stream);
 
 /* Measurement hook for bench.py: average duration in milliseconds of the scoring kernel over the
  * launches made since the last reset, measured with HIP events recorded on the launch stream.

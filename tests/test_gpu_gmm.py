@@ -154,3 +154,41 @@ def test_reference_surface_model_gru_gmm():
         a.has_gap = True
         MG.model_gru_gmm(a, ids[:, :-1], x_gap=np.zeros((4, 10, 1)))
     MG.reset_scopes()
+
+
+def test_run_gmm_evaluation_loop_on_the_synthetic_xing_file(tmp_path):
+    """run_gmm_xing.evaluate_gmm (the evaluate_nn-shaped loop behind `run_xing --model_type tcn_gmm`): per batch the masked lane mean
+    (model.py:111-117) of the mixture loss through hiertcn_gmm_lane_loss, epoch value = mean over batches; against the oracle on the
+    device's own hidden rows, batch for batch."""
+    import os
+    from hiertcn_amd.data_loader import Dataloader_single_level_model_xing
+    from hiertcn_amd.data_prepare import load_xing
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    from hiertcn_amd.run_gmm_xing import evaluate_gmm
+    data = load_xing(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interactions_synth.csv"))
+    N = int(data[1][:, 1].max()) + 1
+    a = _args(N, 3, (64, 64), 3)
+    a.batch_size = 5
+    a.log_path = str(tmp_path) + "/log/"
+    os.makedirs(a.log_path + "test/")
+    p = G.init_params(a, seed=11)
+    model = TcnGmmModel(a, p)
+    pr = {k: (O.round_bf16(v) if (k.endswith("kernel") or k.endswith("weights")) else v) for k, v in p.items()}
+    pr["tcn_gmm/fully_connected/weights"][:, :3] = p["tcn_gmm/fully_connected/weights"][:, :3]
+    want = []
+    loader = Dataloader_single_level_model_xing(a, "test", data=data)
+    while True:
+        x, y, _ = loader.get_batch()
+        x, y = np.asarray(x).astype(np.int32), np.asarray(y).astype(np.int32)
+        hid = model.forward(torch.as_tensor(np.ascontiguousarray(x)).to("cuda:0"))
+        h_dev = hid.float().cpu().numpy().astype(np.float64).reshape(x.shape[0], x.shape[1], -1)
+        pred = G.gmm_head(h_dev, pr, "tcn_gmm")
+        want.append(G.masked_mean_loss(G.calc_loss_gmm_ids(pred, y, a), y))
+        if loader.done:
+            break
+    got, _, _ = evaluate_gmm(a, Dataloader_single_level_model_xing(a, "test", data=data), model, prefix="test")
+    assert len(want) >= 2
+    assert abs(got["loss_epoch"] - float(np.mean(want))) < 1e-4 * max(1.0, abs(float(np.mean(want))))
+    txt = open(a.log_path + "test/results.txt").read()
+    assert txt.startswith("loss_epoch ") and "nan" in txt          # a density model has no rank metrics: written as nan
+    model.close()

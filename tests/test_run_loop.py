@@ -124,3 +124,46 @@ def test_checkpoint_roundtrip_with_carried_state(tmp_path, data):
     q, extra = checkpoint.load(args.save_path + "20.ckpt", with_extra=True)
     assert set(q) == set(p) and all(np.array_equal(q[k], p[k]) for k in p)
     assert "hier/multi_rnn_cell/cell_1/gru_cell/gates/kernel" in q and extra["state_np"].shape == (4, 16)
+
+
+def test_run_xing_dispatches_the_mixture_models_and_refuses_training(tmp_path):
+    """model.py:74-77: --model_type tcn_gmm / gru_gmm reach run_gmm_xing.run_gmm (evaluation flow over a model handle with eval_step -> 'sums');
+    training of these models is not built and says so."""
+    import numpy as np
+    import pytest
+    import torch
+    from hiertcn_amd.args import make_args
+    from hiertcn_amd.run_gmm_xing import evaluate_gmm, run_gmm
+
+    class FakeGmm:
+        def __init__(self):
+            self.calls = 0
+
+        def eval_step(self, x, y):
+            self.calls += 1
+            mask = (np.asarray(y) > 0)
+            lanes = mask.any(1).sum()
+            return dict(sums=torch.tensor([2.5 * lanes * self.calls, float(lanes)], dtype=torch.float64))
+
+    class Loader:
+        def __init__(self, n):
+            self.n, self.i, self.done = n, 0, False
+
+        def get_batch(self):
+            self.i += 1
+            self.done = self.i >= self.n
+            y = np.ones((4, 6), np.int32)
+            return y, y, None
+
+    a = make_args([], model_type="tcn_gmm", item_num=50, num_mixture=2, sigma=0.1, loss="gmm_prob", adjust=False)
+    a.log_path = str(tmp_path) + "/log/"
+    a.name = "t"
+    fake = FakeGmm()
+    m, _, _ = evaluate_gmm(a, Loader(3), fake, prefix="test")
+    assert fake.calls == 3 and abs(m["loss_epoch"] - 2.5 * (1 + 2 + 3) / 3) < 1e-12      # mean over batches of the per-batch lane means
+    assert np.isnan(m["recall10_epoch_mean"])
+    a.train = True
+    with pytest.raises(NotImplementedError, match="training of the mixture-output models"):
+        run_gmm(a, None, None, None, sess=fake)
+    a.train, a.validate, a.test, a.load = False, False, True, False
+    assert run_gmm(a, None, None, Loader(2), sess=fake) is fake
