@@ -45,6 +45,7 @@ struct SgradArgs {
   const int32_t* row_map; const int32_t* yc; const float* wc;   // mode 1: compact arrays y, w by p; mode 2: y and w by ORIGINAL row
   const uint16_t* outT; int N;                                    // the one-hot term  - w Wo[y]
   int32_t* ovf; int vote;
+  int* walk;             // per-XCD stream-position words ([8][32] ints, the handle's; null: every workgroup starts at stage 0)
   // mode 2
   const float* out_bias; int32_t* o_rank; float* o_ce; float* o_tgt;
 };
@@ -126,7 +127,28 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
     const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
     return (unsigned)(row * (2 * C) + ((slot ^ swz(row)) << 4));
   };
-  auto stage_issue = [&](int stg, int buf) {   // LDS-DMA by hand (score.hip: why asm); SGPR stage base + 32-bit lane offset
+  // XCD-synchronised walk of the stream (score.hip, k_score_pipe: the same reasoning and the same caveats).  Every sum this kernel forms
+  // over the stream -- the softmax denominator and count of mode 2, the d hidden / d Wo accumulators -- is independent of the stream
+  // order beyond fp32 rounding, so a workgroup may enter the stream at any stage and wrap around.  Workgroups dealt to one XCD
+  // (blockIdx.x % 8) start where their running neighbours are, which keeps an XCD's workgroups on the same few MB of the 150 MB item
+  // table (mode 2) or of the scored rows (mode 0) however the dispatcher staggers them: without it the bytes through the L2's
+  // memory-side port depend on the box (35 GB at 91 % hit on one, 98 GB at 76 % on another, profiles/r2_b vs r2_c).
+  // ONE read per workgroup, handed to the waves through LDS (waves reading the moving word themselves could disagree).
+  int s0 = 0;
+  int* walk_word = nullptr;
+  if (a.walk && !(MODE == 1 && a.vote)) {
+    walk_word = a.walk + (blockIdx.x & 7) * 32 + 8 + 4 * MODE + (int)(blockIdx.y & 3);
+    int* s0_sh = reinterpret_cast<int*>(smem);   // (the stage buffers are not in use yet)
+    if (tid == 0) *s0_sh = __hip_atomic_load(walk_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();
+    s0 = __builtin_amdgcn_readfirstlane(*s0_sh);
+    __syncthreads();
+    s0 = (s0 >= 0 && s0 < n_stages) ? s0 : 0;
+  }
+  auto stage_issue = [&](int stg_rel, int buf) {   // LDS-DMA by hand (score.hip: why asm); SGPR stage base + 32-bit lane offset
+    int stg = s0 + stg_rel;
+    stg -= (stg >= n_stages) ? n_stages : 0;
+    if (walk_word && wave == 0 && lane == 0 && (stg_rel & 7) == 0) __hip_atomic_store(walk_word, stg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const uint16_t* sbase = stream + (int64_t)stg * SC_STAGE * C;
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
@@ -425,6 +447,7 @@ hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const
   a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / SC_STAGE;
   a.out = dh; a.row_map = row_map; a.yc = y; a.wc = w; a.outT = m.outT; a.N = m.N; a.ovf = ovf;
   a.out_bias = m.out_bias; a.o_rank = o_rank; a.o_ce = o_ce; a.o_tgt = o_tgt;
+  a.walk = m.walk_pos;
   return launch_k_sgrad_c<2>(m, a, dim3((unsigned)((R + 255) / 256)), st);
 }
 
@@ -437,6 +460,7 @@ hipError_t launch_sgrad_dh(const ModelDev& m, const uint16_t* hc, const float* r
   a.stat = hc; a.stat_const = rb_l2; a.n_stat_max = R + 64; a.n_stat_dev = n_dev;
   a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / SC_STAGE;
   a.out = dh; a.row_map = row_map; a.yc = yc; a.wc = wc; a.outT = m.outT; a.N = m.N; a.ovf = ovf; a.vote = vote;
+  a.walk = m.walk_pos;
   return launch_k_sgrad_c<1>(m, a, dim3((unsigned)((R + 255) / 256)), st);
 }
 
@@ -450,6 +474,7 @@ hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* 
   a.stat = m.outT; a.stat_const = bias_l2; a.n_stat_max = m.NP;
   a.stream = hc; a.stream_bias = rb_nat; a.n_stages_max = (int)((R + 63) / 64); a.n_stream_dev = n_dev;
   a.out = dwo; a.colsum = dbias;
+  a.walk = m.walk_pos;
   // row parts so that the grid covers the chip a few times over (the item dimension alone gives N / 256 workgroups)
   const unsigned blocks = (unsigned)((m.NP + 255) / 256);
   unsigned parts = 1;
