@@ -1,0 +1,44 @@
+"""VERDICT r2 item 9, as a census instead of a kernel variant: how many 32-item x 32-row tiles of the scoring kernel COULD skip their softmax
+VALU ops (v_fma, v_exp, v_add per logit) because every term of the tile underflows -- i.e. every logit of the tile lies more than 43 nats
+(62 in log2 units) below the target logit of its row, the kernel's reference point being target + 64 (csrc/score.hip)?  The fraction is an
+upper bound on what a per-tile wave vote could save.  Models: glorot weights (the bench's) and the same model with the scoring layer scaled
+to max |z| = 10, 30, 60 (a peaked, trained-like model).  usage: python scripts/skip_tile_census.py [N] [lanes]"""
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from hiertcn_amd.args import hier_tcn_args
+from hiertcn_amd.engine import Engine
+from hiertcn_amd.params import init_params
+import bench
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 20778
+B = int(sys.argv[2]) if len(sys.argv) > 2 else 16
+d, S, L = 256, bench.S_SESS, bench.L_STEPS
+args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L, max_session_num=S, batch_size=B)
+p0 = init_params(args, seed=2)
+draw = bench.zipf_sampler(N)
+x, y, mask = bench.make_users(draw, 0, B, False)
+dev = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+st0 = torch.zeros((B, 2 * d), device="cuda")
+for scale in (None, 10.0, 30.0, 60.0):
+    p = {k: np.array(v) for k, v in p0.items()}
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), st0)
+    hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+    z = eng.score_logits(hid)                       # [R, N]
+    if scale is not None:                            # z is linear in (Wo, bo): scale the materialised logits instead of the weights
+        z = z * (scale / float(z.abs().max()))
+    yy = dev(y.reshape(-1)).long()
+    t = z.gather(1, yy[:, None])                     # target logit per row
+    R = z.shape[0]
+    NP = (N + 31) // 32 * 32
+    gap = torch.full((R, NP), -1e30, device="cuda")
+    gap[:, :N] = z - t                               # z_n - z_target
+    tile_max = gap.view(R // 32, 32, NP // 32, 32).amax(dim=(1, 3))     # max over the tile's 32 rows x 32 items
+    skippable = (tile_max < -43.0).float().mean().item()
+    per_row = ((gap[:, :N] < -43.0).float().mean()).item()
+    print(f"max|z| = {float(z.abs().max()):6.2f}: tiles whose every term underflows {100 * skippable:6.3f} %  (single logits more than 43 nats "
+          f"below their row's target: {100 * per_row:6.3f} %)", flush=True)
+    eng.close()
