@@ -32,7 +32,8 @@ for scale in (None, 10.0, 30.0, 60.0):
         z = z * (scale / float(z.abs().max()))
     yy = dev(y.reshape(-1)).long()
     t = z.gather(1, yy[:, None])                     # target logit per row
-    R = z.shape[0]
+    R = z.shape[0] // 32 * 32
+    z, t = z[:R], t[:R]
     NP = (N + 31) // 32 * 32
     gap = torch.full((R, NP), -1e30, device="cuda")
     gap[:, :N] = z - t                               # z_n - z_target
