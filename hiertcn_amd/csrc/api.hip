@@ -187,6 +187,11 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
         ALLOC_OR_FAIL(m.lgru_bg[l], (size_t)2 * m.H);
         ALLOC_OR_FAIL(m.lgru_wc[l], (size_t)(in + m.H) * m.H);
         ALLOC_OR_FAIL(m.lgru_bc[l], (size_t)m.H);
+        ALLOC_OR_FAIL(m.lgru_wg_hi[l], (size_t)(in + m.H) * 2 * m.H);
+        ALLOC_OR_FAIL(m.lgru_wg_lo[l], (size_t)(in + m.H) * 2 * m.H);
+        ALLOC_OR_FAIL(m.lgru_wc_hi[l], (size_t)(in + m.H) * m.H);
+        ALLOC_OR_FAIL(m.lgru_wc_lo[l], (size_t)(in + m.H) * m.H);
+        m.lgru_split = 1;
       }
     }
   }
@@ -282,6 +287,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
     }
   }
   HIP_TRY(refresh_frag_major(m, st));
+  HIP_TRY(refresh_lgru_split(m, st));
   if (h->train.enabled) HIP_TRY(train_fill_masters(m, h->train, w, st));
   if (h->x.enabled) {   // exact numerics mode: fp32 copies in the same internal layouts (reduction index contiguous)
     ExactDev& x = h->x;

@@ -86,6 +86,9 @@ struct ModelDev {
   float* lgru_bg[HIERTCN_MAX_LAYERS];
   float* lgru_wc[HIERTCN_MAX_LAYERS];
   float* lgru_bc[HIERTCN_MAX_LAYERS];
+  int lgru_split;                         // 1: the hi / lo 16-bit splits of the low-level GRU kernels below are allocated (gru_x3.hip)
+  uint16_t* lgru_wg_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wg_lo[HIERTCN_MAX_LAYERS];   // [2H][in+H]
+  uint16_t* lgru_wc_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wc_lo[HIERTCN_MAX_LAYERS];   // [H][in+H]
   int* walk_pos;        // [8][32] ints, zeroed: per-XCD position words of the scoring kernel's item walk (null: every workgroup starts at stage 0)
 };
 
@@ -136,7 +139,30 @@ struct LowGruBufs {
   float* rec;         // per layer (keep_all: per step and layer): gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
   int keep_all;
   float* hidden32;    // exact numerics mode (exact.hip): uf is already filled with the fp32 projection and the outputs go here as fp32 rows
+  uint16_t* x3;       // scratch of the split-operand cells (gru_x3.hip), low_gru_x3_elems() 16-bit elements; null: the fp32 cells run
 };
+size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess);
+// one GRU cell product + epilogue on split 16-bit operands (gru_x3.hip)
+enum { X3_GATES = 0, X3_CAND = 1 };
+struct GruX3Args {
+  const uint16_t* Wh; const uint16_t* Wl; const float* bias;     // [N][K1 + K2] hi / lo, [N]
+  const uint16_t* A1h; const uint16_t* A1l; int64_t lda1; int K1;   // first K1 reduction columns: the cell's input (A1l may be null)
+  const uint16_t* A2h; const uint16_t* A2l; int64_t lda2; int K2;   // next K2: h (gates) or r * h (candidate)
+  int64_t M; int N, H, epi;
+  int save_all;                      // 1 (training forward): r, r*h, the candidate and the output are kept in fp32 for the backward pass
+  float* gates;                      // [M][2H]: written (GATES) / read (CAND: the update gate)
+  const float* h; int64_t ldh;       // the layer's old state slice
+  float* rh; uint16_t* rh_hi; uint16_t* rh_lo;                   // GATES: r * h, fp32 [M][H] + its split
+  float* cand_out;                   // CAND, optional: tanh(.) [M][H] (kept for the backward pass)
+  float* out; uint16_t* out_hi; uint16_t* out_lo;                // CAND: h' [M][H] (+ split for the next layer, optional)
+  float* state_new; uint16_t* state_hi; uint16_t* state_lo; int64_t lds_;   // CAND: the carried state slice (h' while the row is active) + split
+  const int32_t* seq_len; int tstep;
+  uint16_t* hid_out; int64_t ldho;   // CAND, optional: the scoring operand row
+};
+hipError_t launch_gru_x3(const GruX3Args& g, hipStream_t st);
+hipError_t launch_split_f32(const float* v, int64_t n, uint16_t* hi, uint16_t* lo, hipStream_t st);
+bool gru_x3_applies(const ModelDev& m);
+hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st);
 size_t low_gru_save_floats(const ModelDev& m, int64_t n_sess, int L);
 hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden,
                                const LowGruBufs& b, hipStream_t st);

@@ -1,0 +1,221 @@
+// HierGRU low level (model_hier.py:67-68 -> model_gru.py:47-55; cell arithmetic customed_gru_cell.py:309-337) on the 16-bit MFMA with SPLIT
+// operands: every fp32 value v that enters a product is carried as v_hi + v_lo (v_hi = v rounded to the 16-bit storage type, v_lo = the
+// rounded remainder) and a . w is formed as a_hi w_hi + a_lo w_hi + a_hi w_lo in fp32 accumulators -- 16 mantissa bits per factor, relative
+// error ~2^-16 per product, three bf16 MFMAs (2.5 PFLOP/s dense) instead of one fp32 MFMA (157 TFLOP/s).
+//
+// Why here and not in the across-session scan: the low level runs dynamic_rnn from a ZERO state for at most L = 30 steps per session and its
+// outputs are rounded to the storage type for the scoring layer anyway (2^-9 relative), so a 2^-16 perturbation of the recurrence never
+// compounds past that rounding; the scan carries its state across sessions AND batches without bound and stays on exact fp32 chains
+// (pool_gru.hip, gru_persist.hip).  At the bench shape this cell is M = 20,480 sessions x K = 512: the fp32 kernels spent 18.6 of the
+// evaluation step's 91 ms here at 45-56 TFLOP/s.  The exact numerics mode (exact.hip) and HIERTCN_LGRU_FP32=1 keep the fp32 cells.
+//
+// One kernel, two epilogues (the fp32 kernel's, pool_gru.hip): D[row = output unit n][col = session m], so a lane holds four consecutive
+// units of one session and every epilogue access is a 16-byte row access.  Workgroup = 128 units x 128 sessions (4 waves x four 32 x 32
+// accumulators); the reduction runs over [in | h] in 64-deep chunks; W_hi, W_lo, A_hi, A_lo chunks are staged in LDS (pitch 144 B) with the
+// next chunk's loads in flight during the MFMAs.  The layer-0 input (the projected rows, already 16-bit) has no low part: two products.
+#include "common.h"
+
+#define XT 128
+#define XK 64
+#define XP 144   // byte pitch of a [128][64] 16-bit tile: 36 words, (9 r) mod 16 distinct over the 16 lanes of a ds_read_b128 phase
+
+__device__ __forceinline__ void split2(float v, uint16_t& hi, uint16_t& lo) {
+  hi = f2bf(v);
+  lo = f2bf(v - bf2f(hi));
+}
+
+__global__ __launch_bounds__(256) void k_gru_x3(const GruX3Args g) {
+  __shared__ __attribute__((aligned(16))) unsigned char Wh[XT * XP];
+  __shared__ __attribute__((aligned(16))) unsigned char Wl[XT * XP];
+  __shared__ __attribute__((aligned(16))) unsigned char Ah[XT * XP];
+  __shared__ __attribute__((aligned(16))) unsigned char Al[XT * XP];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int n0 = blockIdx.x * XT;
+  const int64_t m0 = (int64_t)blockIdx.y * XT;
+  const int wn = wave >> 1, wm = wave & 1;
+  const int ldrow = tid >> 3, ldc8 = (tid & 7) * 8;
+  const int K = g.K1 + g.K2;
+  const int n_it = K / XK;
+  uint4 rwh[4], rwl[4], rah[4], ral[4];
+  auto fetch = [&](int it) {
+    const int kc = it * XK;
+    const bool seg2 = kc >= g.K1;
+    const uint16_t* ah = seg2 ? g.A2h : g.A1h;
+    const uint16_t* al = seg2 ? g.A2l : g.A1l;
+    const int64_t lda = seg2 ? g.lda2 : g.lda1;
+    const int ka = (seg2 ? kc - g.K1 : kc) + ldc8;
+    const uint4 zero = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int n = n0 + ldrow + 32 * p;
+      rwh[p] = zero; rwl[p] = zero;
+      if (n < g.N) {
+        rwh[p] = *reinterpret_cast<const uint4*>(g.Wh + (int64_t)n * K + kc + ldc8);
+        rwl[p] = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)n * K + kc + ldc8);
+      }
+      const int64_t m = m0 + ldrow + 32 * p;
+      rah[p] = zero; ral[p] = zero;
+      if (m < g.M) {
+        rah[p] = *reinterpret_cast<const uint4*>(ah + m * lda + ka);
+        if (al) ral[p] = *reinterpret_cast<const uint4*>(al + m * lda + ka);
+      }
+    }
+  };
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; i++)
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+#pragma unroll
+      for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
+  fetch(0);
+  for (int it = 0; it < n_it; it++) {
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < 4; p++) {
+      const int o = (ldrow + 32 * p) * XP + ldc8 * 2;
+      *reinterpret_cast<uint4*>(Wh + o) = rwh[p];
+      *reinterpret_cast<uint4*>(Wl + o) = rwl[p];
+      *reinterpret_cast<uint4*>(Ah + o) = rah[p];
+      *reinterpret_cast<uint4*>(Al + o) = ral[p];
+    }
+    __syncthreads();
+    if (it + 1 < n_it) fetch(it + 1);
+#pragma unroll
+    for (int s = 0; s < XK / 16; s++) {
+      const int ko = 32 * s + 16 * lh;
+      uint4 wh[2], wl[2], ah[2], al[2];
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        wh[i] = *reinterpret_cast<const uint4*>(Wh + (64 * wn + 32 * i + lr) * XP + ko);
+        wl[i] = *reinterpret_cast<const uint4*>(Wl + (64 * wn + 32 * i + lr) * XP + ko);
+        ah[i] = *reinterpret_cast<const uint4*>(Ah + (64 * wm + 32 * i + lr) * XP + ko);
+        al[i] = *reinterpret_cast<const uint4*>(Al + (64 * wm + 32 * i + lr) * XP + ko);
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) {
+          // smallest terms first: (a_lo w_hi + a_hi w_lo) + a_hi w_hi inside one fp32 accumulator chain.  (An operand without a low part --
+          // the layer-0 input rows -- has a zero tile in Al: its product is kept rather than branched around, a branch between the prefetch
+          // and the MFMAs makes hipcc wait for vmcnt(0) early.)
+          acc[i][j] = mfma32(wh[i], al[j], acc[i][j]);
+          acc[i][j] = mfma32(wl[i], ah[j], acc[i][j]);
+          acc[i][j] = mfma32(wh[i], ah[j], acc[i][j]);
+        }
+    }
+  }
+  // epilogues: D[row = unit n][col = session m]; registers 4q..4q+3 of a tile are units 8q + 4 lh + 0..3 of session lr: 16-byte accesses, the
+  // two lane halves side by side (32 bytes per row per instruction, a 128-byte line over the four q).  (The transposed orientation -- one unit
+  // of 16 sessions per lane, whole lines per instruction but four times as many instructions -- measured 158 vs 109 us per cell.)
+  // Evaluation (save_all == 0) writes only what the next product reads: u, the split r*h, the split state and output; the training forward
+  // also keeps r, r*h, the candidate and the output in fp32 for the backward pass.
+  const int H = g.H;
+  auto pack4 = [](const uint16_t* v) { return make_uint2(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16)); };
+#pragma unroll
+  for (int j = 0; j < 2; j++) {
+    const int64_t m = m0 + 64 * wm + 32 * j + lr;
+    if (m >= g.M) continue;
+    const bool active = g.seq_len ? g.tstep < g.seq_len[m] : true;
+#pragma unroll
+    for (int i = 0; i < 2; i++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int n = n0 + 64 * wn + 32 * i + 8 * q + 4 * lh;
+        if (n >= g.N) continue;
+        float v[4];
+        const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
+        v[0] = acc[i][j][4 * q] + b4.x; v[1] = acc[i][j][4 * q + 1] + b4.y; v[2] = acc[i][j][4 * q + 2] + b4.z; v[3] = acc[i][j][4 * q + 3] + b4.w;
+        uint16_t hi[4], lo[4];
+        if (g.epi == X3_GATES) {   // customed_gru_cell.py:323-326: value = sigmoid(.), r first, u second; r_state = r * h
+          float s4[4];
+#pragma unroll
+          for (int c = 0; c < 4; c++) s4[c] = 1.0f / (1.0f + expf(-v[c]));
+          if (n >= H || g.save_all) *reinterpret_cast<float4*>(g.gates + m * 2 * H + n) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+          if (n < H) {
+            const float4 hv = *reinterpret_cast<const float4*>(g.h + m * g.ldh + n);
+            const float r4[4] = {s4[0] * hv.x, s4[1] * hv.y, s4[2] * hv.z, s4[3] * hv.w};
+            if (g.save_all) *reinterpret_cast<float4*>(g.rh + m * H + n) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+#pragma unroll
+            for (int c = 0; c < 4; c++) split2(r4[c], hi[c], lo[c]);
+            *reinterpret_cast<uint2*>(g.rh_hi + m * H + n) = pack4(hi);
+            *reinterpret_cast<uint2*>(g.rh_lo + m * H + n) = pack4(lo);
+          }
+        } else {                   // :335-336: c = tanh(.), h' = u h + (1 - u) c; dynamic_rnn past the row's length: state through, output 0
+          const float4 hv = *reinterpret_cast<const float4*>(g.h + m * g.ldh + n);
+          const float4 uv = *reinterpret_cast<const float4*>(g.gates + m * 2 * H + H + n);
+          const float c4[4] = {tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
+          float hn[4];
+          hn[0] = uv.x * hv.x + (1.0f - uv.x) * c4[0];
+          hn[1] = uv.y * hv.y + (1.0f - uv.y) * c4[1];
+          hn[2] = uv.z * hv.z + (1.0f - uv.z) * c4[2];
+          hn[3] = uv.w * hv.w + (1.0f - uv.w) * c4[3];
+          if (g.save_all) {
+            *reinterpret_cast<float4*>(g.cand_out + m * H + n) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+            *reinterpret_cast<float4*>(g.out + m * H + n) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+          }
+          const float st4[4] = {active ? hn[0] : hv.x, active ? hn[1] : hv.y, active ? hn[2] : hv.z, active ? hn[3] : hv.w};
+          *reinterpret_cast<float4*>(g.state_new + m * g.lds_ + n) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+#pragma unroll
+          for (int c = 0; c < 4; c++) split2(st4[c], hi[c], lo[c]);
+          *reinterpret_cast<uint2*>(g.state_hi + m * g.lds_ + n) = pack4(hi);
+          *reinterpret_cast<uint2*>(g.state_lo + m * g.lds_ + n) = pack4(lo);
+          if (g.out_hi) {          // the next layer's input operand
+#pragma unroll
+            for (int c = 0; c < 4; c++) split2(hn[c], hi[c], lo[c]);
+            *reinterpret_cast<uint2*>(g.out_hi + m * H + n) = pack4(hi);
+            *reinterpret_cast<uint2*>(g.out_lo + m * H + n) = pack4(lo);
+          }
+          if (g.hid_out) {         // top layer: the scoring operand row, zero past the length
+            uint2 o;
+            o.x = active ? pack2bf(hn[0], hn[1]) : 0u;
+            o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
+            *reinterpret_cast<uint2*>(g.hid_out + m * g.ldho + n) = o;
+          }
+        }
+      }
+  }
+}
+
+hipError_t launch_gru_x3(const GruX3Args& g, hipStream_t st) {
+  if (g.M <= 0) return hipSuccess;
+  if ((g.K1 % XK) || (g.K2 % XK) || (g.N & 31)) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_gru_x3, dim3((unsigned)((g.N + XT - 1) / XT), (unsigned)((g.M + XT - 1) / XT)), dim3(256), 0, st, g);
+  return hipGetLastError();
+}
+
+// v [rows][cols] fp32 -> hi, lo (16-bit storage type): v ~ hi + lo
+__global__ void k_split_f32(const float* __restrict__ v, int64_t n, uint16_t* __restrict__ hi, uint16_t* __restrict__ lo) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float4 x = *reinterpret_cast<const float4*>(v + i);
+  uint16_t h[4], l[4];
+  split2(x.x, h[0], l[0]); split2(x.y, h[1], l[1]); split2(x.z, h[2], l[2]); split2(x.w, h[3], l[3]);
+  *reinterpret_cast<uint2*>(hi + i) = make_uint2(h[0] | ((uint32_t)h[1] << 16), h[2] | ((uint32_t)h[3] << 16));
+  *reinterpret_cast<uint2*>(lo + i) = make_uint2(l[0] | ((uint32_t)l[1] << 16), l[2] | ((uint32_t)l[3] << 16));
+}
+
+hipError_t launch_split_f32(const float* v, int64_t n, uint16_t* hi, uint16_t* lo, hipStream_t st) {
+  if (n <= 0) return hipSuccess;
+  if (n & 3) return hipErrorInvalidValue;
+  hipLaunchKernelGGL(k_split_f32, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, v, n, hi, lo);
+  return hipGetLastError();
+}
+
+bool gru_x3_applies(const ModelDev& m) {
+  if (!m.low_gru || !m.lgru_split || getenv("HIERTCN_LGRU_FP32")) return false;
+  return (m.E % XK) == 0 && (m.H % XK) == 0;
+}
+
+hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st) {
+  if (!m.low_gru || !m.lgru_split) return hipSuccess;
+  hipError_t e;
+  for (int l = 0; l < m.nl; l++) {
+    const int in = (l == 0) ? m.E : m.H;
+    const int64_t ng = (int64_t)(in + m.H) * 2 * m.H, nc = (int64_t)(in + m.H) * m.H;
+    if ((e = launch_split_f32(m.lgru_wg[l], ng, m.lgru_wg_hi[l], m.lgru_wg_lo[l], st)) != hipSuccess) return e;
+    if ((e = launch_split_f32(m.lgru_wc[l], nc, m.lgru_wc_hi[l], m.lgru_wc_lo[l], st)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}

@@ -430,12 +430,15 @@ __global__ __launch_bounds__(256) void k_len_f32(const float* __restrict__ uf, i
   if (lane == 0) seq_len[sess] = cnt;
 }
 
+// split-operand cells: state hi / lo ping-pong [2][2][M][HT] + per layer r*h hi / lo and output hi / lo [nl][4][M][H]
+size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess) { return (size_t)8 * n_sess * m.HT; }
+
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
-  // embedded rows + u (16-bit) + u (fp32) + lengths + two state buffers + one (gates | r*h | cand | out) record per layer
+  // embedded rows + u (16-bit) + u (fp32) + lengths + two state buffers + one (gates | r*h | cand | out) record per layer + the split scratch
   const size_t R = (size_t)n_sess * L;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   return 2 * al(R * m.E * 2) + al(R * m.E * 4) + al((size_t)n_sess * 4) + 2 * al((size_t)n_sess * m.HT * 4) +
-         al((size_t)m.nl * n_sess * 5 * m.H * 4);
+         al((size_t)m.nl * n_sess * 5 * m.H * 4) + al(low_gru_x3_elems(m, n_sess) * 2);
 }
 
 // training keeps everything the backward pass needs: L+1 states and one record per (step, layer)
@@ -457,7 +460,7 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
     if ((e = launch_embed_rows(m, x, R, b.a_emb, st)) != hipSuccess) return e;
     {  // 'emb' projection of [e, state] (model_gru.py:46), rounded to the 16-bit storage type like the TCN's input
       LayerArgs a = {};
-      a.in = b.a_emb; a.out = b.u16; a.W = m.projT; a.seq_init = sproj;
+      a.in = b.a_emb; a.out = b.u16; a.W = m.projT; a.Wf = m.projF; a.seq_init = sproj;
       a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
       if ((e = launch_tcn_layer(a, st)) != hipSuccess) return e;
     }
@@ -465,6 +468,47 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if ((e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state (model_gru.py:52: initial_state=None)
+  if (b.x3 && !b.hidden32 && gru_x3_applies(m)) {
+    // split-operand cells on the 16-bit MFMA (gru_x3.hip): same records, states and outputs as the fp32 cells below
+    const size_t MS = (size_t)n_sess * HT, MH = (size_t)n_sess * H;
+    uint16_t* st_hi = b.x3;                 // [2][M][HT]
+    uint16_t* st_lo = st_hi + 2 * MS;       // [2][M][HT]
+    uint16_t* rh_hi = st_lo + 2 * MS;       // [nl][M][H]
+    uint16_t* rh_lo = rh_hi + (size_t)m.nl * MH;
+    uint16_t* o_hi = rh_lo + (size_t)m.nl * MH;
+    uint16_t* o_lo = o_hi + (size_t)m.nl * MH;
+    if ((e = hipMemsetAsync(st_hi, 0, MS * 2, st)) != hipSuccess) return e;
+    if ((e = hipMemsetAsync(st_lo, 0, MS * 2, st)) != hipSuccess) return e;
+    for (int t = 0; t < L; t++) {
+      const float* s_old = b.states + (size_t)(t % b.n_states) * n_sess * HT;
+      float* s_new = b.states + (size_t)((t + 1) % b.n_states) * n_sess * HT;
+      const int po = t & 1, pn = (t + 1) & 1;
+      for (int l = 0; l < m.nl; l++) {
+        float* rec = b.rec + (b.keep_all ? ((size_t)t * m.nl + l) : (size_t)l) * cell;
+        GruX3Args g;
+        memset(&g, 0, sizeof(g));
+        g.M = n_sess; g.H = H; g.save_all = b.keep_all;
+        if (l == 0) { g.A1h = b.u16 + (size_t)t * E; g.A1l = nullptr; g.lda1 = (int64_t)L * E; g.K1 = E; }
+        else { g.A1h = o_hi + (size_t)(l - 1) * MH; g.A1l = o_lo + (size_t)(l - 1) * MH; g.lda1 = H; g.K1 = H; }
+        g.A2h = st_hi + (size_t)po * MS + (size_t)l * H; g.A2l = st_lo + (size_t)po * MS + (size_t)l * H; g.lda2 = HT; g.K2 = H;
+        g.Wh = m.lgru_wg_hi[l]; g.Wl = m.lgru_wg_lo[l]; g.bias = m.lgru_bg[l]; g.N = 2 * H; g.epi = X3_GATES;
+        g.gates = rec; g.h = s_old + (size_t)l * H; g.ldh = HT;
+        g.rh = rec + (size_t)n_sess * 2 * H; g.rh_hi = rh_hi + (size_t)l * MH; g.rh_lo = rh_lo + (size_t)l * MH;
+        if ((e = launch_gru_x3(g, st)) != hipSuccess) return e;
+        g.A2h = g.rh_hi; g.A2l = g.rh_lo; g.lda2 = H;
+        g.Wh = m.lgru_wc_hi[l]; g.Wl = m.lgru_wc_lo[l]; g.bias = m.lgru_bc[l]; g.N = H; g.epi = X3_CAND;
+        g.cand_out = rec + (size_t)n_sess * 3 * H;
+        g.out = rec + (size_t)n_sess * 4 * H;
+        if (l + 1 < m.nl) { g.out_hi = o_hi + (size_t)l * MH; g.out_lo = o_lo + (size_t)l * MH; }
+        g.state_new = s_new + (size_t)l * H; g.state_hi = st_hi + (size_t)pn * MS + (size_t)l * H; g.state_lo = st_lo + (size_t)pn * MS + (size_t)l * H;
+        g.lds_ = HT;
+        g.seq_len = b.seq_len; g.tstep = t;
+        if (l == m.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
+        if ((e = launch_gru_x3(g, st)) != hipSuccess) return e;
+      }
+    }
+    return hipSuccess;
+  }
   for (int t = 0; t < L; t++) {
     const float* s_old = b.states + (size_t)(t % b.n_states) * n_sess * HT;
     float* s_new = b.states + (size_t)((t + 1) % b.n_states) * n_sess * HT;
@@ -518,6 +562,7 @@ hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* spro
   b.rec = reinterpret_cast<float*>(take((size_t)m.nl * n_sess * 5 * m.H * 4));
   b.keep_all = 0;
   b.hidden32 = nullptr;
+  b.x3 = reinterpret_cast<uint16_t*>(take(low_gru_x3_elems(m, n_sess) * 2));
   return launch_low_gru_bufs(m, x, sproj, n_sess, L, hidden, b, st);
 }
 

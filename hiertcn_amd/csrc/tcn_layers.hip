@@ -11,6 +11,7 @@
 // customized_tcn_cell.py:47-48), D[row = cout][col = t]; taps outermost, k-steps inner -- the SAME
 // accumulation order as the fused kernel, so both produce bitwise identical activations.
 #include "common.h"
+#include <cstdio>
 #include <cstdlib>
 
 // RB = time blocks (32 steps each) per wave: the wave's weight fragment of a (tap, k-step) then feeds RB MFMAs instead of one -- at RB = 1
@@ -134,7 +135,7 @@ __global__ __launch_bounds__(256) void k_tcn_layer(LayerArgs a) {
 // Accumulation order per output (bias, taps outermost, k-steps inner, zero operands outside the sequence) is the other two kernels', so
 // the three low-level paths stay bitwise identical (tests/test_single_level.py).
 // ---------------------------------------------------------------------------------------------------------------------------------
-struct LdsGeom { int cbw, tgw, halo, pitch, rows; };
+struct LdsGeom { int cbw, tgw, halo, pitch, rows; int seq_L; };   // seq_L > 0: flat rows (one tap: no row depends on another), seq_init by row / seq_L
 
 template <int RB>
 __global__ __launch_bounds__(512) void k_tcn_layer_lds(LayerArgs a, LdsGeom g) {
@@ -178,18 +179,23 @@ __global__ __launch_bounds__(512) void k_tcn_layer_lds(LayerArgs a, LdsGeom g) {
 #pragma unroll
   for (int q = 0; q < 4; q++) {
     const int c0 = cb * 32 + 8 * q + 4 * lh;
-    f32x4 init = {0.f, 0.f, 0.f, 0.f}, rinit = {0.f, 0.f, 0.f, 0.f};
-    if (a.seq_init) init = *reinterpret_cast<const f32x4*>(a.seq_init + seq * a.Cout + c0);
-    if (a.bias) {
-      const f32x4 b4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
-#pragma unroll
-      for (int j = 0; j < 4; j++) init[j] += b4[j];
-    }
+    f32x4 bias4 = {0.f, 0.f, 0.f, 0.f}, rinit = {0.f, 0.f, 0.f, 0.f};
+    if (a.bias) bias4 = *reinterpret_cast<const f32x4*>(a.bias + c0);
     if (a.bres) rinit = *reinterpret_cast<const f32x4*>(a.bres + c0);
 #pragma unroll
-    for (int r = 0; r < RB; r++)
+    for (int r = 0; r < RB; r++) {
+      f32x4 init = {0.f, 0.f, 0.f, 0.f};
+      if (a.seq_init) {
+        int64_t sq = seq;
+        if (g.seq_L > 0) {   // flat rows: this lane's row belongs to sequence row / seq_L
+          const int64_t row = (int64_t)t0 + (tgi * RB + r) * 32 + lr;
+          sq = (row < a.L ? row : (int64_t)a.L - 1) / g.seq_L;
+        }
+        init = *reinterpret_cast<const f32x4*>(a.seq_init + sq * a.Cout + c0);
+      }
 #pragma unroll
-      for (int j = 0; j < 4; j++) { acc[r][4 * q + j] = init[j]; racc[r][4 * q + j] = rinit[j]; }
+      for (int j = 0; j < 4; j++) { acc[r][4 * q + j] = init[j] + bias4[j]; racc[r][4 * q + j] = rinit[j]; }
+    }
   }
   // B-operand base of time block r: slab row (tgi*RB + r)*32 + lr (+ halo - back per tap), byte column 16*lh (+ 32 per k-step)
   const unsigned char* bbase = slab + ((tgi * RB) * 32 + lr) * g.pitch + 16 * lh;
@@ -330,14 +336,19 @@ static LdsGeom lds_geom(const LayerArgs& a) {
   LdsGeom g = {0, 0, 0, 0, 0};
   if (!a.Wf || (a.Wres && !a.Wresf) || getenv("HIERTCN_TCN_LAYER_V1")) return g;
   const int ncb = a.Cout >> 5;
-  if (a.L < 96 || (ncb & (ncb - 1))) return g;   // short sequences: the un-staged kernel (tiles of 128 steps would be mostly padding)
+  if (ncb & (ncb - 1)) return g;
+  if (a.L < 96 && !(a.taps == 1 && a.n_seq * (int64_t)a.L >= 4096 && a.n_seq * (int64_t)a.L < ((int64_t)1 << 31)))
+    return g;   // short sequences: the un-staged kernel (tiles of 128 steps would be mostly padding) -- unless the layer has ONE tap (the 'emb'
+                // projection, a Dense): then no row depends on another and the rows of all sequences tile as one flat run
   const int cbw = ncb < 8 ? ncb : 8;
   const int halo = (a.taps - 1) * a.dil;
   const int pitch = a.Cin * 2 + 16;
   for (int tgw = 8 / cbw; tgw >= 1; tgw >>= 1) {
     const int rows = tgw * 128 + halo;
-    if ((int64_t)rows * pitch <= 160 * 1024 - 512 && (tgw == 1 || (tgw - 1) * 128 < a.L)) {
+    const int64_t Leff = a.L < 96 ? a.n_seq * (int64_t)a.L : a.L;   // (flat rows when the sequences are short: see above)
+    if ((int64_t)rows * pitch <= 160 * 1024 - 512 && (tgw == 1 || (tgw - 1) * 128 < Leff)) {
       g.cbw = cbw; g.tgw = tgw; g.halo = halo; g.pitch = pitch; g.rows = rows;
+      g.seq_L = (a.L < 96) ? a.L : 0;
       return g;
     }
   }
@@ -376,21 +387,32 @@ size_t tcn_layers_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) 
   return 2 * one;
 }
 
+static hipError_t launch_tcn_layer_lds(const LayerArgs& a, const LdsGeom& g, hipStream_t st) {
+  const int TT = g.tgw * 128;
+  const size_t lds = (size_t)g.rows * g.pitch;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_layer_lds<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  const dim3 grid((unsigned)(a.n_seq * ((a.L + TT - 1) / TT)), (unsigned)((a.Cout >> 5) / g.cbw));
+  hipLaunchKernelGGL(k_tcn_layer_lds<4>, grid, dim3(64 * g.cbw * g.tgw), lds, st, a, g);
+  return hipGetLastError();
+}
+
 hipError_t launch_tcn_layer(const LayerArgs& a, hipStream_t st) {
   const LdsGeom g = lds_geom(a);
-  if (g.cbw > 0) {
-    const int TT = g.tgw * 128;
-    const size_t lds = (size_t)g.rows * g.pitch;
-    static bool attr_set = false;
-    if (!attr_set) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_layer_lds<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      attr_set = true;
-    }
-    const dim3 grid((unsigned)(a.n_seq * ((a.L + TT - 1) / TT)), (unsigned)((a.Cout >> 5) / g.cbw));
-    hipLaunchKernelGGL(k_tcn_layer_lds<4>, grid, dim3(64 * g.cbw * g.tgw), lds, st, a, g);
-    return hipGetLastError();
+  if (getenv("HIERTCN_DEBUG_LAYER"))
+    fprintf(stderr, "launch_tcn_layer: L %d n_seq %lld Cin %d Cout %d taps %d Wf %p Wres %p Wresf %p -> cbw %d tgw %d seq_L %d\n", a.L, (long long)a.n_seq, a.Cin,
+            a.Cout, a.taps, (const void*)a.Wf, (const void*)a.Wres, (const void*)a.Wresf, g.cbw, g.tgw, g.seq_L);
+  if (g.cbw > 0 && g.seq_L > 0) {   // flat rows: one "sequence" of n_seq * L rows
+    LayerArgs f = a;
+    f.L = (int)(a.n_seq * (int64_t)a.L);
+    f.n_seq = 1;
+    return launch_tcn_layer_lds(f, g, st);
   }
+  if (g.cbw > 0) return launch_tcn_layer_lds(a, g, st);
   const int ntt = (a.L + 31) / 32;
   // time blocks per wave: as many as a sequence has, up to four, while the grid still fills the chip a few times over
   const int64_t tiles1 = a.n_seq * ntt * (a.Cout / 32);
