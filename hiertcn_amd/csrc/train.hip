@@ -267,22 +267,30 @@ __global__ __launch_bounds__(256) void k_colsum_bf16(const uint16_t* __restrict_
   }
 }
 
-// out[c] += sum over rows of fp32 src[r * ld + c]
+// out[c] += sum over rows of fp32 src[r * ld + c].  256 rows per workgroup: a [20,480 x 256] gate gradient is 320 workgroups (it was 40 at 2048
+// rows each: 86 us per call on a quarter of the chip, 17 ms of the HierGRU training step over its 200 calls), four independent partial sums
+// per thread so that the loads of a thread overlap.
+#define COLSUM_ROWS 256
 __global__ __launch_bounds__(256) void k_colsum_f32(const float* __restrict__ src, int64_t rows, int64_t ld, int cols, float* __restrict__ out) {
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int ry = threadIdx.x >> 6;
   __shared__ float red[4][64];
-  const int64_t r0 = (int64_t)blockIdx.y * 2048;
-  const int64_t r1 = (r0 + 2048 < rows) ? r0 + 2048 : rows;
-  float s = 0.f;
-  if (c < cols)
-    for (int64_t r = r0 + ry; r < r1; r += 4) s += src[r * ld + c];
-  red[ry][threadIdx.x & 63] = s;
+  const int64_t r0 = (int64_t)blockIdx.y * COLSUM_ROWS;
+  const int64_t r1 = (r0 + COLSUM_ROWS < rows) ? r0 + COLSUM_ROWS : rows;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < cols) {
+    int64_t r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      s0 += src[r * ld + c]; s1 += src[(r + 4) * ld + c]; s2 += src[(r + 8) * ld + c]; s3 += src[(r + 12) * ld + c];
+    }
+    for (; r < r1; r += 4) s0 += src[r * ld + c];
+  }
+  red[ry][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (threadIdx.x < 64 && c < cols) atomicAdd(out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
 }
 static hipError_t colsum_f32(const float* src, int64_t rows, int64_t ld, int cols, float* out, hipStream_t st) {
-  hipLaunchKernelGGL(k_colsum_f32, dim3((cols + 63) / 64, (unsigned)((rows + 2047) / 2048)), dim3(256), 0, st, src, rows, ld, cols, out);
+  hipLaunchKernelGGL(k_colsum_f32, dim3((cols + 63) / 64, (unsigned)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS)), dim3(256), 0, st, src, rows, ld, cols, out);
   return hipGetLastError();
 }
 

@@ -1,4 +1,4 @@
-# Every number quoted in DESIGN.md / README.md, one command each (run on an MI355X box from the repo root; ~8 minutes).
+# Every number quoted in DESIGN.md / README.md, one command each (run on an MI355X box from the repo root; ~10 minutes).
 set -u
 python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" | tail -1
 echo "== headline (bench.py defaults: 4096 users/step, cfg-3 shape)"; python3 bench.py 2>/dev/null | tail -1 | python3 -c "
@@ -20,7 +20,7 @@ echo "== d = 512, N = 1,000,000 (bf16, then the IEEE-half build)"
 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
 DTYPE=fp16 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
 echo "== ranked top-k flavour"; python3 scripts/topk_bench.py 2>&1 | tail -3
-echo "== training step (1024 users), dense / ragged / previous scoring backward (G chunks + rocBLAS) / HierGRU"
+echo "== training step (1024 users), dense / ragged / previous scoring backward (G chunks + the plain GEMMs of gemm.hip) / HierGRU"
 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 python3 scripts/train_bench.py 1024 3 ragged 2>&1 | tail -1
 HIERTCN_TRAIN_LEGACY=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
@@ -28,6 +28,17 @@ LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
 echo "== data-parallel code path, 2 ranks sharing the GPU over gloo (smoke: RCCL needs one GPU per rank)"
 HIERTCN_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --users-per-step 512 --train-users-per-step 256 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json; b = json.loads(sys.stdin.read()); t = b['train']; print(b['n_gpus'], 'ranks:', round(b['value']), 'sessions/s eval;', 'train', t.get('ms_per_step'), 'ms/step', t.get('collectives'))"
+echo "== single-level model_tcn: six blocks, T = 500, 256 sequences (LDS-tiled layer kernel, then HIERTCN_TCN_LAYER_V1=1) and the evaluation step"
+python3 scripts/tcn_layer_bench.py single eval 2>&1 | grep -v amdgpu.ids
+HIERTCN_TCN_LAYER_V1=1 python3 scripts/tcn_layer_bench.py single eval 2>&1 | grep -v amdgpu.ids | sed "s/^/V1: /"
+echo "== HierGRU low level: split-operand cells vs the fp32 cells"
+LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
+LOW=gru EVAL=1 HIERTCN_LGRU_FP32=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2 | sed "s/^/fp32 cells: /"
+echo "== mixture head (614,400 rows x 20,778 outputs x 5 mixtures)"; python3 scripts/gmm_bench.py 2>&1 | tail -1
+echo "== exact fp32 evaluation mode: throughput, and errors at a trained model's logit scale (tests/test_gpu_exact_mode.py)"
+python3 scripts/exact_mode_bench.py 256 2>&1 | grep -v amdgpu.ids
+python3 -m pytest tests/test_gpu_exact_mode.py -q -m gpu -s -k xing_shape 2>&1 | grep -E "mode,|storage,|passed|failed"
+echo "== tile-skip census (profiles/r3_score_ablation.md)"; python3 scripts/skip_tile_census.py 20778 16 2>&1 | grep -v amdgpu.ids
 echo "== parity against the exact oracle on unrounded fp32 weights"; python3 scripts/parity_fp32_probe.py 2>&1 | grep shape | cut -c1-400
 echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3
 echo "== repeated full-size launches agree (ranks, target logits bitwise; ce to 5e-5)"; python3 scripts/soak_score.py 2>&1 | grep mismatching

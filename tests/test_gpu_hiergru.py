@@ -206,3 +206,34 @@ def test_hiergru_training_step_matches_autograd(d, H, N, nl):
     assert metrics_dict(out["metrics8"])["loss"] < l0
     assert set(eng.export("weights")) == set(p)
     eng.close()
+
+
+def test_split_operand_cells_agree_with_the_fp32_cells():
+    """csrc/gru_x3.hip (a.w = a_hi w_hi + a_lo w_hi + a_hi w_lo on the 16-bit MFMA, fp32 accumulators) against the exact-fp32 cells
+    (HIERTCN_LGRU_FP32=1, read per call) over 30 steps and two layers: the 16-bit output rows are identical except where a ~2^-16 relative
+    difference of the recurrence straddles a rounding boundary of the storage type -- rare, and never more than one ulp."""
+    import os
+    from hiertcn_amd.engine import Engine
+    N, d, H, B, S, L = 1500, 128, 128, 16, 4, 30
+    args = gru_args(N=N, d=d, H=H, nl=2, L=L, S=S, B=B)
+    eng = Engine(args, hier=True)
+    eng.set_weights(make_params(args))
+    rng = np.random.default_rng(9)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = dev((0.3 * rng.standard_normal((B, 2 * H))).astype(np.float32))
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), st0)
+    outs = []
+    for fp32 in (False, True):
+        if fp32:
+            os.environ["HIERTCN_LGRU_FP32"] = "1"
+        try:
+            outs.append(eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1)).float().cpu().numpy())
+        finally:
+            os.environ.pop("HIERTCN_LGRU_FP32", None)
+    a, b = outs
+    assert np.abs(b).max() > 0.05
+    diff = np.abs(a - b)
+    assert (diff > 0).mean() < 0.01                                     # almost every 16-bit output is bit-identical
+    assert diff.max() <= 2.0 ** -8 * np.abs(b).max() + 1e-12             # ... and no output differs by more than one ulp of the storage type
+    eng.close()
