@@ -13,6 +13,9 @@
 // MFMA orientation: A = weights [cout][cin] (internal layout, transposed at set_weights),
 // B = activations^T, D[row = cout][col = time step].  A lane then owns ONE time step and four
 // runs of 4 consecutive output channels -> 8-byte packed bf16 stores and residual loads.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 
 #define TCN_G 4          // sessions per workgroup
@@ -35,6 +38,8 @@ struct TcnParams {
   const uint16_t* emb;                         // [N][C] bf16, row 0 zero
   const uint16_t* projT;                       // [C][C] bf16 (cout-major) or null (single level: no projection)
   const uint16_t* convT[HIERTCN_MAX_BLOCKS];   // [K][C][C]
+  const uint16_t* projF;                       // fragment-major copies ([channel block][tap][k-step][lane][8], tcn_layers.hip), FRAG kernels
+  const uint16_t* convF[HIERTCN_MAX_BLOCKS];
   const float* conv_bias[HIERTCN_MAX_BLOCKS];  // [C]
   int n_blocks, K, pad;
   int N;                                       // item_num: ids outside [0, N) embed like the null id
@@ -54,7 +59,11 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 // DEEP: all of a tap's weight fragments in flight at once (156 VGPRs at C = 256: one workgroup per CU) -- for grids that do not fill the
 // chip anyway (the reference's 32-lane batches: 80 workgroups), where the kernel is bound by the L2 round trips of its weight loads;
 // otherwise four fragments at a time and two workgroups per CU (cfg-3: 3.1 ms per 81,920 sessions against 5.3 ms with DEEP)
-template <int C, bool DEEP = false>
+// FRAG (round 3; one channel block per wave): the wave's weight stream of a layer -- taps x k-steps fragments -- is read from the
+// fragment-major copy (one contiguous, fully coalesced 1 KB per fragment instead of 32 rows x 32 bytes) in batches of eight through two
+// register sets, the loads of batch g + 1 issued in one run before the MFMAs of batch g (the recipe of k_tcn_layer_lds); the accumulation
+// order per output is unchanged, so the three low-level paths stay bitwise identical.
+template <int C, bool DEEP = false, bool FRAG = false>
 __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const int32_t* __restrict__ x,
                                                            const float* __restrict__ sproj, int64_t n_sessions, int L,
                                                            uint16_t* __restrict__ hidden) {
@@ -115,6 +124,58 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
       }
     }
 
+    if constexpr (FRAG) {
+      static_assert(G::CBW == 1, "the fragment-major stream is written for one channel block per wave");
+      const int n_steps = taps * G::KS, n_full = n_steps & ~7;
+      const uint16_t* wp = (is_proj ? p.projF : p.convF[blk]) + (int64_t)cb0 * n_steps * 512 + lane * 8;
+      int s = 0;
+      int shift = is_proj ? 0 : (p.K - 1) * dil;              // tap 0 reaches furthest back: o[t] += x[t - (K-1-j)*dil] . W[j]
+      auto step = [&](const uint4 av) {
+#pragma unroll
+        for (int r = 0; r < G::RPW; r++) {
+          const int row = (g0 + r) * ROWS + p.pad + lr - shift;
+          const uint4 b = *reinterpret_cast<const uint4*>(smem + lds_off<C>(row, 2 * s + lh));
+          acc[0][r] = mfma32(av, b, acc[0][r]);
+        }
+        s++;
+        const bool wrap = s == G::KS;
+        s = wrap ? 0 : s;
+        shift -= wrap ? dil : 0;
+      };
+      auto load8 = [&](uint4* w, int g0s) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+          const int idx = g0s + u < n_steps ? g0s + u : n_steps - 1;
+          w[u] = *reinterpret_cast<const uint4*>(wp + (int64_t)idx * 512);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto comp8 = [&](const uint4* w) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) step(w[u]);
+      };
+      auto tail = [&](const uint4* w) {
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (n_full + u < n_steps) step(w[u]);
+      };
+      uint4 wa[8], wb[8];
+      load8(wa, 0);
+      int i0 = 0;
+      for (; i0 + 16 <= n_full; i0 += 16) {
+        load8(wb, i0 + 8);
+        comp8(wa);
+        load8(wa, i0 + 16);
+        comp8(wb);
+      }
+      if (i0 < n_full) {
+        load8(wb, i0 + 8);
+        comp8(wa);
+        tail(wb);
+      } else {
+        tail(wa);
+      }
+    } else
     for (int j = 0; j < taps; j++) {
       const int shift = is_proj ? 0 : (p.K - 1 - j) * dil;  // o[t] += x[t - (K-1-j)*dil] . W[j]
       const uint16_t* Wj = W + (int64_t)j * C * C + (int64_t)(cb0 * 32 + lr) * C + 8 * lh;   // (+ 32 C per further channel block of the wave)
@@ -232,6 +293,14 @@ static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float
     hipLaunchKernelGGL((k_tcn_fused<C, DEEP_OK>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
     return hipGetLastError();
   }
+  if constexpr (C <= 256) {
+    if (p.convF[0] && (!p.projT || p.projF) && !getenv("HIERTCN_TCN_FUSED_V1")) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_tcn_fused<C, false, true>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
+      return hipGetLastError();
+    }
+  }
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   hipLaunchKernelGGL((k_tcn_fused<C, false>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
@@ -269,7 +338,8 @@ hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* 
   }
   p.emb = m.emb;
   p.projT = m.hier ? m.projT : nullptr;
-  for (int i = 0; i < HIERTCN_MAX_BLOCKS; i++) { p.convT[i] = m.convT[i]; p.conv_bias[i] = m.conv_bias[i]; }
+  for (int i = 0; i < HIERTCN_MAX_BLOCKS; i++) { p.convT[i] = m.convT[i]; p.conv_bias[i] = m.conv_bias[i]; p.convF[i] = m.convF[i]; }
+  p.projF = m.hier ? m.projF : nullptr;
   p.n_blocks = m.n_blocks; p.K = m.K; p.N = m.N;
   int halo = (m.K - 1) * (1 << (m.n_blocks - 1));
   p.pad = (halo + 7) & ~7;
