@@ -41,7 +41,11 @@ def load(fname: str, with_extra: bool = False):
     (`<prefix>.index` + `<prefix>.data-*`: hiertcn_amd.tf_checkpoint reads it without TensorFlow; Adam slots are skipped)."""
     if not os.path.exists(_path(fname)) and os.path.exists(fname + ".index"):
         from .tf_checkpoint import read_tf_checkpoint
-        params = {k: v for k, v in read_tf_checkpoint(fname).items() if v.dtype == np.float32 and k != "global_step"}
+        allv = read_tf_checkpoint(fname)
+        params = {k: v for k, v in allv.items() if v.dtype == np.float32 and k != "global_step"}
+        skipped = sorted(set(allv) - set(params))
+        if skipped:   # said out loud: a model variable that arrived as a non-float tensor would otherwise vanish silently
+            print("checkpoint %s: %d non-float32 variable(s) not loaded: %s" % (fname, len(skipped), ", ".join(skipped)))
         return (params, {}) if with_extra else params
     with np.load(_path(fname)) as z:
         params = {k: z[k] for k in z.files if not k.startswith(EXTRA)}

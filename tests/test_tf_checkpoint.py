@@ -136,3 +136,29 @@ def test_checkpoint_load_accepts_a_tf_prefix(tmp_path):
     write_bundle(prefix, w)
     params = checkpoint.load(prefix)
     assert np.array_equal(params["hier/emb/bias"], w["hier/emb/bias"])
+
+
+def test_crc32c_fast_equals_the_scalar_crc_and_large_tensors_are_verified(tmp_path):
+    """crc32c_fast (chunk CRCs advanced together + zero-advance combine) is bit-identical to the byte-serial CRC at sizes around its chunking
+    boundaries, and the reader now verifies tensors of every size: a flipped byte inside a multi-megabyte table is caught, and a data shard
+    cut short is refused instead of being read past its end."""
+    from hiertcn_amd import tf_checkpoint as T
+    rng = np.random.default_rng(0)
+    assert T.crc32c(b"123456789") == 0xE3069283                      # the CRC-32C check value
+    for n in (1 << 16, (1 << 16) + 1, 70_001, 1_048_577, 3_000_017):
+        data = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert T.crc32c_fast(data) == T.crc32c(data), n
+    big = rng.standard_normal((700, 600)).astype(np.float32)          # 1.68 MB: above the old 1 MB verification limit
+    prefix = str(tmp_path / "big.ckpt")
+    write_bundle(prefix, {"hier/emb/kernel": big})
+    got = T.read_tf_checkpoint(prefix)
+    assert np.array_equal(got["hier/emb/kernel"], big)
+    shard = prefix + ".data-00000-of-00001"
+    raw = bytearray(open(shard, "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    open(shard, "wb").write(bytes(raw))
+    with pytest.raises(ValueError, match="checksum"):
+        T.read_tf_checkpoint(prefix)
+    open(shard, "wb").write(bytes(raw[: len(raw) // 2]))
+    with pytest.raises(ValueError, match="truncated"):
+        T.read_tf_checkpoint(prefix)
