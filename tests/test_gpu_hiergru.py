@@ -195,7 +195,7 @@ def test_hiergru_training_step_matches_autograd(d, H, N, nl):
         rel = np.linalg.norm(g - r) / max(nr, 1e-30)
         cos = float((g * r).sum() / max(np.linalg.norm(g) * nr, 1e-30))
         report.append(f"{k}: rel {rel:.3e} cos {cos:.5f} |ref| {nr:.3e}")
-        if nr > 1e-9 and (rel > 3e-2 or cos < 0.999):
+        if nr > 1e-9 and (rel > 2e-2 or cos < 0.999):
             bad.append(k)
     assert not bad, "\n".join(report)
     # three Adam steps on the batch lower its loss, and the masters come back under the reference's variable names

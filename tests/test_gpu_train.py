@@ -4,7 +4,7 @@ reference is the checker here, as for the forward pass in tests/test_oracle_vs_t
 
 Tolerances: the device multiplies bf16 operands (weights, activations, d-logits) with fp32 accumulation
 and passes gradients straight through the forward roundings, the reference is fp64 on the bf16-rounded
-weights: per-tensor relative L2 error < 3e-2 and cosine > 0.999; Adam arithmetic itself (given the
+weights: per-tensor relative L2 error < 2e-2 and cosine > 0.999; Adam arithmetic itself (given the
 device's own gradients) to 1e-6."""
 import os
 
@@ -113,7 +113,7 @@ def test_every_gradient_matches_autograd(trained):
         rel = np.linalg.norm(g - r) / max(nr, 1e-30)
         cos = float((g * r).sum() / max(np.linalg.norm(g) * nr, 1e-30))
         report.append((k, rel, cos, nr))
-    bad = [(k, rel, cos) for k, rel, cos, nr in report if nr > 1e-9 and (rel > 3e-2 or cos < 0.999)]
+    bad = [(k, rel, cos) for k, rel, cos, nr in report if nr > 1e-9 and (rel > 2e-2 or cos < 0.999)]
     assert not bad, "\n".join(f"{k}: rel {rel:.3e} cos {cos:.5f}" for k, rel, cos in bad) + "\nall:\n" + "\n".join(
         f"{k}: rel {rel:.3e} cos {cos:.5f} |ref| {nr:.3e}" for k, rel, cos, nr in report)
     # the null id never receives a gradient (model.py:59)
@@ -299,7 +299,7 @@ def test_single_level_training_with_downsample_residual():
         g, r = grads[k].astype(np.float64), P[k].grad.numpy()
         rel = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
         cos = float((g * r).sum() / max(np.linalg.norm(g) * np.linalg.norm(r), 1e-30))
-        assert rel < 3e-2 and cos > 0.999, (k, rel, cos)
+        assert rel < 2e-2 and cos > 0.999, (k, rel, cos)
     eng.close()
     model = TcnModel(a, p, train=True)
     losses = [model.train_step(x, y, 1e-2)["loss"] for _ in range(4)]
@@ -427,7 +427,7 @@ def test_width_padded_model_trains_d100():
         rest[tuple(slice(0, n) for n in r.shape)] = 0
         assert not rest.any(), k                                    # gradients of the padding: exactly zero
         rel = np.linalg.norm(cut - r) / max(np.linalg.norm(r), 1e-30)
-        assert rel < 3e-2, (k, rel)
+        assert rel < 2e-2, (k, rel)
     losses = [model.train_step(x, y, 1e-2)["loss"] for _ in range(4)]
     assert losses[-1] < losses[0], losses
     w_pad = eng.export("weights")
