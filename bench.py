@@ -266,6 +266,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--users-per-step", type=int, default=4096, help="users per step PER GPU (4096 users = 4800 workgroups = 18.75 rounds of 256 CUs: 1.3 % tail)")
     ap.add_argument("--ragged", action="store_true", help="session lengths ~ U{1..30} instead of full")
+    ap.add_argument("--streams", type=int, default=1, help="HIP streams the evaluation steps alternate between (one handle + workspace each).  2: the pool / "
+                    "GRU scan / low-level kernels of step i + 1 fill the tail round of step i's scoring launch, +0.7 %% sessions/s (scripts/two_stream_probe.py) "
+                    "-- but the HIP events around a scoring launch then include its wait for the other stream's launch, so roofline.launch_ms is no longer the "
+                    "kernel's own duration: the default stays 1 so that the roofline figures mean what they say")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-gmm", action="store_true", help="skip the mixture-head figure (the `gmm` object of the JSON line)")
     ap.add_argument("--no-train", action="store_true", help="skip the data-parallel training leg (the `train` object of the JSON line)")
@@ -302,8 +306,12 @@ def main():
                          max_activity_len=L_STEPS, max_session_num=S_SESS, batch_size=a.users_per_step)
     t_setup = time.perf_counter()
     params = init_params(args, seed=2)  # glorot-uniform / GRU gate bias 1.0, default_rng(2)
-    eng = Engine(args, hier=True)
-    eng.set_weights(params)
+    n_streams = max(1, int(a.streams))
+    engs = [Engine(args, hier=True) for _ in range(n_streams)]
+    for e in engs:
+        e.set_weights(params)
+    eng = engs[0]
+    streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
 
     B = a.users_per_step
     n_steps_total = a.warmup + a.steps
@@ -315,24 +323,28 @@ def main():
         x, y, mask = make_users(draw, first, B, a.ragged)
         batches.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda()))
     state0 = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")  # run_hier_xing.py:241
-    state_out = torch.empty_like(state0)
+    state_outs = [torch.empty_like(state0) for _ in range(n_streams)]
     m8 = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(n_steps_total)]
-    eng.workspace(B, S_SESS, L_STEPS)
+    for e in engs:
+        e.workspace(B, S_SESS, L_STEPS)
     torch.cuda.synchronize()
     t_setup = time.perf_counter() - t_setup
 
     def step(i):
         xb, yb, mb = batches[i]
-        eng.forward_eval(xb, yb, mb, state0, state_out=state_out, metrics8=m8[i])
-        all_reduce_metrics(m8[i])  # RCCL: the only collective of the evaluation path (8 doubles); no-op at N=1
+        k = i % n_streams
+        with torch.cuda.stream(streams[k]):
+            engs[k].forward_eval(xb, yb, mb, state0, state_out=state_outs[k], metrics8=m8[i])
+            all_reduce_metrics(m8[i])  # RCCL: the only collective of the evaluation path (8 doubles); no-op at N=1
 
     for i in range(a.warmup):
         step(i)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    eng.timing_enable(True)
-    eng.timing_read(reset=True)
+    for e in engs:
+        e.timing_enable(True)
+        e.timing_read(reset=True)
     t0 = time.perf_counter()
     for i in range(a.warmup, n_steps_total):
         step(i)
@@ -342,8 +354,13 @@ def main():
         torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     dt = max_over_ranks(dt, "cuda")
-    score_ms, launches = eng.timing_read(reset=True)
-    eng.timing_enable(False)
+    tr = [e.timing_read(reset=True) for e in engs]      # (average ms, launches) per handle, HIP events on the handle's own stream
+    launches = sum(n for _, n in tr)
+    score_ms = sum(ms * n for ms, n in tr) / max(launches, 1)
+    for e in engs:
+        e.timing_enable(False)
+    for e in engs[1:]:
+        e.close()
 
     # what the driver needs to confirm an N-GPU run WAS one: the collective backend, how many ranks it joined, and how many DISTINCT
     # physical devices they ran on (uuid where the runtime reports one, PCI address otherwise), plus every rank's own scoring-launch
@@ -465,6 +482,7 @@ def main():
                 "workload": "cfg3-synth: 200k users x 20 sessions x 30 steps, 300k-item catalogue, d=256 (E=C=H), "
                             "2 TCN blocks K=5, 2-layer GRU; eval step = pool+GRU scan+TCN+fused scoring(loss+rank)+lane metrics",
                 "users_per_step_per_gpu": B,
+                "streams": n_streams,
                 "sessions_per_step": sessions_per_step,
                 "ragged": bool(a.ragged),
                 "parallelism": f"user-batch dp{world}",
