@@ -166,15 +166,18 @@ def torch_loss_gru(args, P, x, y, mask, state):
     return ((ce.sum(1) / (act + 1e-6)).sum() / users), st
 
 
-@pytest.mark.parametrize("d,H,N,nl", [(64, 64, 700, 2), (128, 64, 1500, 1)])
-def test_hiergru_training_step_matches_autograd(d, H, N, nl):
+# the last shape has 640 sessions per step: the row-reduced weight-gradient GEMMs of the low-level cells (csrc/gemm.hip, gemm32_tn) then run in two
+# row slices whose partial tiles are summed in slice order
+@pytest.mark.parametrize("d,H,N,nl,shape", [(64, 64, 700, 2, (6, 3, 8)), (128, 64, 1500, 1, (6, 3, 8)), (64, 64, 700, 2, (160, 4, 6))],
+                         ids=["d64_nl2", "d128_nl1", "d64_nl2_640_sessions"])
+def test_hiergru_training_step_matches_autograd(d, H, N, nl, shape):
     from hiertcn_amd.engine import Engine, metrics_dict
     args = gru_args(N=N, d=d, H=H, nl=nl)
     p = make_params(args)
     eng = Engine(args, hier=True, train=True)
     eng.set_weights(p)
     rng = np.random.default_rng(d + 7)
-    B, S, L = 6, 3, 8
+    B, S, L = shape
     x, y, mask = make_batch(rng, B, S, L, N)
     st0 = (0.3 * rng.standard_normal((B, H * nl))).astype(np.float32)
     st0[:2] = 0.0
