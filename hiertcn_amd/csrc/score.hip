@@ -1576,6 +1576,7 @@ hipError_t launch_score_fixup_only(const ModelDev& m, const uint16_t* hidden, co
     case 64: return launch_score_fixup<64, 2, 3, false>(m, hidden, y, R, out, st, row_map, n_rows_dev, m.walk_pos);
     case 128: return launch_score_fixup<128, 2, 3, false>(m, hidden, y, R, out, st, row_map, n_rows_dev, m.walk_pos);
     case 256: return launch_score_fixup<256, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, m.walk_pos);
+    case 512: return launch_score_fixup<512, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, m.walk_pos);
     default: return hipErrorInvalidValue;
   }
 }

@@ -36,6 +36,22 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {
 //         by the final sum is softmax . Wo -- d hidden without a second recompute.  The reference point m is fixed (target logit + 64 in
 //         log2 units, as in score.hip), so nothing is ever rescaled; a row whose sum overflows fp32 (a logit > 133 nats above the target)
 //         is flagged in `ovf` and redone by the fix-up launches (score.hip FIXUP flavour for rank / ce, mode 1 + vote for d hidden).
+// Workgroup shape by width.  C <= 256: 8 waves (two per SIMD), 64 stream vectors per LDS stage (two 32-vector tiles), three stages.
+// C = 512 (round 3): the stationary operand (128 VGPRs) and the running output (256) of a wave no longer fit two waves per SIMD, so a
+// workgroup is 4 waves -- one per SIMD, up to 512 registers each -- of 32 stationary vectors, and a stage is ONE 32-vector tile of 32 KB
+// (three stages = 96 KB).  Everything else (LDS image, fragment addressing, the software pipeline) is the same code.
+template <int C>
+struct SgGeom {
+  static constexpr int W = (C == 512) ? 4 : 8;        // waves per workgroup
+  static constexpr int SI = (C == 512) ? 32 : 64;     // stream vectors per LDS stage
+  static constexpr int TILES = SI / 32;
+  static constexpr int THREADS = 64 * W;
+  static constexpr int STAT = 32 * W;                 // stationary vectors per workgroup
+  static constexpr int STAGE_BYTES = SI * 2 * C;
+};
+static int sg_stat(int C) { return C == 512 ? 128 : 256; }
+static int sg_si(int C) { return C == 512 ? 32 : 64; }
+
 struct SgradArgs {
   const uint16_t* stat; const float* stat_const; int64_t n_stat_max; const int32_t* n_stat_dev;
   const uint16_t* stream; const float* stream_bias; int n_stages_max; const int32_t* n_stream_dev;
@@ -51,19 +67,21 @@ struct SgradArgs {
 };
 
 template <int C, int MODE>
-__global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
+__global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgrad(const SgradArgs a) {
   using G = ScGeom<C>;
-  static_assert(C == 128 || C == 256, "the dual-use LDS image is laid out for 256- and 512-byte rows");
+  using SG = SgGeom<C>;
+  static_assert(C == 128 || C == 256 || C == 512, "the dual-use LDS image is laid out for 256-, 512- and 1024-byte rows");
   constexpr int NCB = C / 32;
+  constexpr int SI = SG::SI;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages of 64 stream vectors + 3 x 64 stream scalars
   const int64_t n_stat = a.n_stat_dev ? (int64_t)a.n_stat_dev[0] : a.n_stat_max;
-  if ((int64_t)blockIdx.x * 256 >= n_stat) return;
+  if ((int64_t)blockIdx.x * SG::STAT >= n_stat) return;
   if (MODE == 1 && a.vote) {   // fix-up launch: only blocks with a flagged row do anything
-    const int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    const int bad = ((int)threadIdx.x < 256 && p < n_stat) ? a.ovf[p] : 0;
+    const int64_t p = (int64_t)blockIdx.x * SG::STAT + threadIdx.x;
+    const int bad = ((int)threadIdx.x < SG::STAT && p < n_stat) ? a.ovf[p] : 0;
     if (!__syncthreads_or(bad)) return;
   }
-  int n_stages = a.n_stream_dev ? (int)(((int64_t)a.n_stream_dev[0] + SC_STAGE - 1) / SC_STAGE) : a.n_stages_max;
+  int n_stages = a.n_stream_dev ? (int)(((int64_t)a.n_stream_dev[0] + SI - 1) / SI) : a.n_stages_max;
   if (n_stages > a.n_stages_max) n_stages = a.n_stages_max;
   int s_lo = 0;
   if (gridDim.y > 1) {   // the stream split in parts (mode 0: the item dimension alone gives N / 256 workgroups): partial sums added atomically
@@ -73,14 +91,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
     if (s_hi <= s_lo) return;
     n_stages = s_hi - s_lo;
   }
-  const uint16_t* stream = a.stream + (int64_t)s_lo * SC_STAGE * C;
-  const float* stream_bias = a.stream_bias + (int64_t)s_lo * SC_STAGE;
+  const uint16_t* stream = a.stream + (int64_t)s_lo * SI * C;
+  const float* stream_bias = a.stream_bias + (int64_t)s_lo * SI;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t sv = ((int64_t)blockIdx.x * 8 + wave) * 32 + lr;   // this lane's stationary vector
+  const int64_t sv = ((int64_t)blockIdx.x * SG::W + wave) * 32 + lr;   // this lane's stationary vector
   const int64_t svc = sv < n_stat ? sv : n_stat - 1;   // (lanes past the end read the last live vector: finite data, their column is never stored)
   const int64_t srow = (MODE == 2) ? (int64_t)a.row_map[svc] : svc;   // mode 2 reads the hidden rows in place
 
@@ -115,10 +133,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
     cst = (sv < n_stat) ? a.stat_const[svc] : -INFINITY;   // -inf: every p of this column is 0
   }
 
-  constexpr int PIECES = G::STAGE_BYTES / 1024;
-  constexpr int PPW = PIECES / 8;
-  constexpr int STAGE_LDS = G::STAGE_BYTES;
-  constexpr int TILE_LDS = STAGE_LDS / 2;
+  constexpr int PIECES = SG::STAGE_BYTES / 1024;
+  constexpr int PPW = PIECES / SG::W;
+  constexpr int STAGE_LDS = SG::STAGE_BYTES;
+  constexpr int TILE_LDS = STAGE_LDS / SG::TILES;
   constexpr int BIAS_OFF = 3 * STAGE_LDS;
   const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
   auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
@@ -149,7 +167,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
     int stg = s0 + stg_rel;
     stg -= (stg >= n_stages) ? n_stages : 0;
     if (walk_word && wave == 0 && lane == 0 && (stg_rel & 7) == 0) __hip_atomic_store(walk_word, stg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const uint16_t* sbase = stream + (int64_t)stg * SC_STAGE * C;
+    const uint16_t* sbase = stream + (int64_t)stg * SI * C;
 #pragma unroll
     for (int i = 0; i < PPW; i++) {
       const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + buf * STAGE_LDS + (wave * PPW + i) * 1024);
@@ -159,9 +177,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
                    : "v"(dma_voff(i)), "s"(sbase), "s"(dst)
                    : "memory");
     }
-    if (wave == 0 && lane < SC_STAGE / 4) {
-      const float* src = stream_bias + (int64_t)stg * SC_STAGE + lane * 4;
-      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + BIAS_OFF + buf * SC_STAGE * 4);
+    if (wave == 0 && lane < SI / 4) {
+      const float* src = stream_bias + (int64_t)stg * SI + lane * 4;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + BIAS_OFF + buf * SI * 4);
       unsigned keep;
       asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                    : "=&s"(keep)
@@ -262,12 +280,11 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
   int buf = 0, pbuf = 0;
   for (int stg = 0; stg < n_stages; stg++) {
     const unsigned char* t0 = smem + buf * STAGE_LDS;
-    const unsigned char* t1 = t0 + TILE_LDS;
-    const float* tb = sbias + buf * SC_STAGE;
+    const float* tb = sbias + buf * SI;
     // ---- tile 0
     g1(t0, tb);
     __builtin_amdgcn_sched_barrier(0);
-    g2(smem + pbuf * STAGE_LDS + TILE_LDS, 1, 0, stg > 0);   // probabilities 0..7 || the previous stage's last tile, k-step 1 (pk[4..7] still its own)
+    g2(smem + pbuf * STAGE_LDS + (SG::TILES - 1) * TILE_LDS, 1, 0, stg > 0);   // probabilities 0..7 || the previous stage's last tile, k-step 1 (pk[4..7] still its own)
     __builtin_amdgcn_sched_barrier(0);
     // stage boundary: everyone is done with the buffer of stage stg - 1, and stage stg + 1 (issued one iteration ago) has landed
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -276,18 +293,21 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_sgrad(const SgradArgs a) {
     if (stg + 2 < n_stages) stage_issue(stg + 2, (buf >= 1) ? buf - 1 : 2);
     g2(t0, 0, 8, true);                                         // k-step 0 of tile 0 || probabilities 8..15
     __builtin_amdgcn_sched_barrier(0);
-    // ---- tile 1
-    g1(t1, tb + 32);
-    __builtin_amdgcn_sched_barrier(0);
-    g2(t0, 1, 0, true);                                         // probabilities 0..7 of tile 1 || k-step 1 of tile 0
-    __builtin_amdgcn_sched_barrier(0);
-    g2(t1, 0, 8, true);                                         // k-step 0 of tile 1 || probabilities 8..15
-    __builtin_amdgcn_sched_barrier(0);
+    if constexpr (SG::TILES == 2) {
+      const unsigned char* t1 = t0 + TILE_LDS;
+      // ---- tile 1
+      g1(t1, tb + 32);
+      __builtin_amdgcn_sched_barrier(0);
+      g2(t0, 1, 0, true);                                         // probabilities 0..7 of tile 1 || k-step 1 of tile 0
+      __builtin_amdgcn_sched_barrier(0);
+      g2(t1, 0, 8, true);                                         // k-step 0 of tile 1 || probabilities 8..15
+      __builtin_amdgcn_sched_barrier(0);
+    }
     pbuf = buf;
     buf = (buf == 2) ? 0 : buf + 1;
   }
   if (n_stages > 0) {   // drain: k-step 1 of the very last tile (its probabilities are in pk[4..7]; nothing left to compute beside it)
-    const unsigned char* tl = smem + pbuf * STAGE_LDS + TILE_LDS;
+    const unsigned char* tl = smem + pbuf * STAGE_LDS + (SG::TILES - 1) * TILE_LDS;
     int tr0 = tr_a[0], tr1 = tr_a[1];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
@@ -414,15 +434,15 @@ __global__ __launch_bounds__(256) void k_dwo_onehot(const uint16_t* __restrict__
   if (lane == 0) atomicAdd(dbias + yv, -w);
 }
 
-bool sgrad_supported(const ModelDev& m) { return m.Clast == 128 || m.Clast == 256; }
+bool sgrad_supported(const ModelDev& m) { return m.Clast == 128 || m.Clast == 256 || (m.Clast == 512 && !getenv("HIERTCN_SGRAD512_OFF")); }
 
 template <int C, int MODE>
 static hipError_t launch_k_sgrad(const SgradArgs& a, dim3 grid, hipStream_t st) {
-  using G = ScGeom<C>;
-  const size_t lds = 3 * (size_t)G::STAGE_BYTES + 3 * SC_STAGE * sizeof(float);
+  using SG = SgGeom<C>;
+  const size_t lds = 3 * (size_t)SG::STAGE_BYTES + 3 * SG::SI * sizeof(float);
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgrad<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sgrad<C, MODE>), grid, dim3(SC_THREADS), lds, st, a);
+  hipLaunchKernelGGL((k_sgrad<C, MODE>), grid, dim3(SG::THREADS), lds, st, a);
   return hipGetLastError();
 }
 template <int MODE>
@@ -430,6 +450,7 @@ static hipError_t launch_k_sgrad_c(const ModelDev& m, const SgradArgs& a, dim3 g
   switch (m.Clast) {
     case 128: return launch_k_sgrad<128, MODE>(a, grid, st);
     case 256: return launch_k_sgrad<256, MODE>(a, grid, st);
+    case 512: return launch_k_sgrad<512, MODE>(a, grid, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -444,11 +465,11 @@ hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const
   SgradArgs a;
   memset(&a, 0, sizeof(a));
   a.stat = hidden; a.n_stat_max = R; a.n_stat_dev = n_dev;
-  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / SC_STAGE;
+  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / sg_si(m.Clast);
   a.out = dh; a.row_map = row_map; a.yc = y; a.wc = w; a.outT = m.outT; a.N = m.N; a.ovf = ovf;
   a.out_bias = m.out_bias; a.o_rank = o_rank; a.o_ce = o_ce; a.o_tgt = o_tgt;
   a.walk = m.walk_pos;
-  return launch_k_sgrad_c<2>(m, a, dim3((unsigned)((R + 255) / 256)), st);
+  return launch_k_sgrad_c<2>(m, a, dim3((unsigned)((R + sg_stat(m.Clast) - 1) / sg_stat(m.Clast))), st);
 }
 
 // d hidden from the saved log-sum-exp (mode 1) for the compact scored rows; vote != 0: only the 256-row blocks with a row flagged in ovf
@@ -458,10 +479,10 @@ hipError_t launch_sgrad_dh(const ModelDev& m, const uint16_t* hc, const float* r
   SgradArgs a;
   memset(&a, 0, sizeof(a));
   a.stat = hc; a.stat_const = rb_l2; a.n_stat_max = R + 64; a.n_stat_dev = n_dev;
-  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / SC_STAGE;
+  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / sg_si(m.Clast);
   a.out = dh; a.row_map = row_map; a.yc = yc; a.wc = wc; a.outT = m.outT; a.N = m.N; a.ovf = ovf; a.vote = vote;
   a.walk = m.walk_pos;
-  return launch_k_sgrad_c<1>(m, a, dim3((unsigned)((R + 255) / 256)), st);
+  return launch_k_sgrad_c<1>(m, a, dim3((unsigned)((R + sg_stat(m.Clast) - 1) / sg_stat(m.Clast))), st);
 }
 
 // d Wo / d bo (mode 0), ACCUMULATED into dwo [NP][C] / dbias [NP] (the gradient arena is zeroed at the start of the step), followed by
@@ -472,11 +493,12 @@ hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* 
   SgradArgs a;
   memset(&a, 0, sizeof(a));
   a.stat = m.outT; a.stat_const = bias_l2; a.n_stat_max = m.NP;
-  a.stream = hc; a.stream_bias = rb_nat; a.n_stages_max = (int)((R + 63) / 64); a.n_stream_dev = n_dev;
+  const int si = sg_si(m.Clast), stat = sg_stat(m.Clast);
+  a.stream = hc; a.stream_bias = rb_nat; a.n_stages_max = (int)((R + 63) / 64 * 64 / si); a.n_stream_dev = n_dev;   // (the compact rows are padded to 64)
   a.out = dwo; a.colsum = dbias;
   a.walk = m.walk_pos;
   // row parts so that the grid covers the chip a few times over (the item dimension alone gives N / 256 workgroups)
-  const unsigned blocks = (unsigned)((m.NP + 255) / 256);
+  const unsigned blocks = (unsigned)((m.NP + stat - 1) / stat);
   unsigned parts = 1;
   double best = 0.0;
   for (unsigned p = 1; p <= 8 && (p == 1 || a.n_stages_max / (int)p >= 64); p++) {
