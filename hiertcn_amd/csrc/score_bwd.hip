@@ -120,8 +120,21 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) acc[reg] = a.out_bias[__shfl(myy, acc_row(reg, lh))];
     const uint16_t* ap = a.outT + (int64_t)myy * C + 8 * lh;
+    if constexpr (C == 512) {   // two accumulator chains, even / odd k-steps, added at the end: exactly what g1 does below (bitwise equal logits)
+      f32x16 acc2;
 #pragma unroll
-    for (int s = 0; s < G::KS; s++) acc = mfma32(*reinterpret_cast<const uint4*>(ap + 16 * s), hf[s], acc);
+      for (int reg = 0; reg < 16; reg++) acc2[reg] = 0.f;
+#pragma unroll
+      for (int s = 0; s < G::KS; s += 2) {
+        acc = mfma32(*reinterpret_cast<const uint4*>(ap + 16 * s), hf[s], acc);
+        acc2 = mfma32(*reinterpret_cast<const uint4*>(ap + 16 * (s + 1)), hf[s + 1], acc2);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) acc[reg] += acc2[reg];
+    } else {
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) acc = mfma32(*reinterpret_cast<const uint4*>(ap + 16 * s), hf[s], acc);
+    }
     const int dreg = (lr & 3) + 4 * (lr >> 3);
     float d = acc[0];
 #pragma unroll
@@ -241,13 +254,34 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[4 * q + j] = b4[j];
     }
-    uint4 ring[2];
-    ring[0] = *reinterpret_cast<const uint4*>(tl + (ak ^ (0 << 5)));
+    if constexpr (C == 512) {
+      // one wave per SIMD: nothing else fills the latency of a dependent MFMA chain, so the 32 k-steps run as TWO independent chains (even / odd
+      // k-steps) that are added at the end; fragment reads three ahead
+      f32x16 acc2;
 #pragma unroll
-    for (int s = 0; s < G::KS; s++) {
-      if (s + 1 < G::KS) ring[(s + 1) & 1] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 1) << 5)));
-      acc = mfma32(ring[s & 1], hf[s], acc);
-      __builtin_amdgcn_sched_barrier(0);
+      for (int reg = 0; reg < 16; reg++) acc2[reg] = 0.f;
+      uint4 ring[4];
+#pragma unroll
+      for (int s = 0; s < 3; s++) ring[s] = *reinterpret_cast<const uint4*>(tl + (ak ^ (s << 5)));
+#pragma unroll
+      for (int s = 0; s < G::KS; s += 2) {
+        if (s + 3 < G::KS) ring[(s + 3) & 3] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 3) << 5)));
+        acc = mfma32(ring[s & 3], hf[s], acc);
+        if (s + 4 < G::KS) ring[(s + 4) & 3] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 4) << 5)));
+        acc2 = mfma32(ring[(s + 1) & 3], hf[s + 1], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) acc[reg] += acc2[reg];
+    } else {
+      uint4 ring[2];
+      ring[0] = *reinterpret_cast<const uint4*>(tl + (ak ^ (0 << 5)));
+#pragma unroll
+      for (int s = 0; s < G::KS; s++) {
+        if (s + 1 < G::KS) ring[(s + 1) & 1] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 1) << 5)));
+        acc = mfma32(ring[s & 1], hf[s], acc);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
   };
   // one k-step (s2) of GEMM-2 on the tile at `tl`, with `first` probabilities pairs of the CURRENT tile computed in its MFMA gaps
