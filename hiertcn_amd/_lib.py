@@ -136,7 +136,7 @@ def load(f16: bool = False):
         return _lib_f16
     if _lib is not None:
         return _lib
-    _lib = _open(LIB_PATH, 0)
+    _lib = _open(os.environ.get("HIERTCN_LIB", LIB_PATH), 0)   # (HIERTCN_LIB: another build of the same ABI, for A/B runs on one box)
     return _lib
 
 

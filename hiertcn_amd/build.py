@@ -47,7 +47,10 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
         extra_flags = tuple(extra_flags) + ("-DHIERTCN_ABLATION=1",)
     # objects live in a directory keyed on the flag set, and the library remembers which flag set it was linked from:
     # an ablation build can never leave objects (or a library) behind that a later plain build would ship as fresh
-    OBJ = os.path.join(HERE, "build", *(["ablation"] if ablation else []), *(["f16"] if f16 else []))  # noqa: N806
+    import hashlib
+    user_flags = [f for f in extra_flags if f not in ("-DHIERTCN_F16=1", "-DHIERTCN_ABLATION=1")]
+    OBJ = os.path.join(HERE, "build", *(["ablation"] if ablation else []), *(["f16"] if f16 else []),  # noqa: N806
+                       *(["x" + hashlib.sha1(" ".join(user_flags).encode()).hexdigest()[:8]] if user_flags else []))
     flagset = " ".join([*FLAGS, *extra_flags])
     stamp = LIB + ".flags"
     try:

@@ -93,17 +93,22 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Args g) {
         ah[i] = *reinterpret_cast<const uint4*>(Ah + (64 * wm + 32 * i + lr) * XP + ko);
         al[i] = *reinterpret_cast<const uint4*>(Al + (64 * wm + 32 * i + lr) * XP + ko);
       }
+      // smallest terms first -- (a_lo w_hi + a_hi w_lo) + a_hi w_hi inside each fp32 accumulator -- and product-major, so that the four tiles'
+      // MFMAs of one product sit between the dependent MFMAs of a tile.  (An operand without a low part -- the layer-0 input rows -- has a zero
+      // tile in Al: its product is kept rather than branched around, a branch between the prefetch and the MFMAs makes hipcc wait for vmcnt(0)
+      // early.)
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) {
-          // smallest terms first: (a_lo w_hi + a_hi w_lo) + a_hi w_hi inside one fp32 accumulator chain.  (An operand without a low part --
-          // the layer-0 input rows -- has a zero tile in Al: its product is kept rather than branched around, a branch between the prefetch
-          // and the MFMAs makes hipcc wait for vmcnt(0) early.)
-          acc[i][j] = mfma32(wh[i], al[j], acc[i][j]);
-          acc[i][j] = mfma32(wl[i], ah[j], acc[i][j]);
-          acc[i][j] = mfma32(wh[i], ah[j], acc[i][j]);
-        }
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma32(wh[i], al[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma32(wl[i], ah[j], acc[i][j]);
+#pragma unroll
+      for (int i = 0; i < 2; i++)
+#pragma unroll
+        for (int j = 0; j < 2; j++) acc[i][j] = mfma32(wh[i], ah[j], acc[i][j]);
     }
   }
   // epilogues: D[row = unit n][col = session m]; registers 4q..4q+3 of a tile are units 8q + 4 lh + 0..3 of session lr: 16-byte accesses, the

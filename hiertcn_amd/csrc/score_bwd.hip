@@ -73,6 +73,11 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
   static_assert(C == 128 || C == 256 || C == 512, "the dual-use LDS image is laid out for 256-, 512- and 1024-byte rows");
   constexpr int NCB = C / 32;
   constexpr int SI = SG::SI;
+#ifdef HIERTCN_SGRAD_TWO_CHAINS_256   // (measured: 396 vs 344 ms per training step -- the second accumulator spills at two waves per SIMD)
+  constexpr bool TWO_CHAINS = C >= 256;
+#else
+  constexpr bool TWO_CHAINS = C == 512;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages of 64 stream vectors + 3 x 64 stream scalars
   const int64_t n_stat = a.n_stat_dev ? (int64_t)a.n_stat_dev[0] : a.n_stat_max;
   if ((int64_t)blockIdx.x * SG::STAT >= n_stat) return;
@@ -120,7 +125,7 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
 #pragma unroll
     for (int reg = 0; reg < 16; reg++) acc[reg] = a.out_bias[__shfl(myy, acc_row(reg, lh))];
     const uint16_t* ap = a.outT + (int64_t)myy * C + 8 * lh;
-    if constexpr (C == 512) {   // two accumulator chains, even / odd k-steps, added at the end: exactly what g1 does below (bitwise equal logits)
+    if constexpr (TWO_CHAINS) {   // two accumulator chains, even / odd k-steps, added at the end: exactly what g1 does below (bitwise equal logits)
       f32x16 acc2;
 #pragma unroll
       for (int reg = 0; reg < 16; reg++) acc2[reg] = 0.f;
@@ -254,7 +259,7 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[4 * q + j] = b4[j];
     }
-    if constexpr (C == 512) {
+    if constexpr (TWO_CHAINS) {
       // one wave per SIMD: nothing else fills the latency of a dependent MFMA chain, so the 32 k-steps run as TWO independent chains (even / odd
       // k-steps) that are added at the end; fragment reads three ahead
       f32x16 acc2;
