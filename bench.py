@@ -264,7 +264,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=6)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--users-per-step", type=int, default=4096, help="users per step PER GPU (4096 users = 4800 workgroups = 18.75 rounds of 256 CUs: 1.3 % tail)")
+    ap.add_argument("--users-per-step", type=int, default=16384, help="users per step PER GPU (16384 users = 19,200 scoring workgroups = exactly 75 rounds of 256 CUs: no "
+                    "partly filled last round; 4096 users = 18.75 rounds measured 2.7 %% fewer sessions/s on the same box)")
     ap.add_argument("--ragged", action="store_true", help="session lengths ~ U{1..30} instead of full")
     ap.add_argument("--streams", type=int, default=1, help="HIP streams the evaluation steps alternate between (one handle + workspace each).  2: the pool / "
                     "GRU scan / low-level kernels of step i + 1 fill the tail round of step i's scoring launch, +0.7 %% sessions/s (scripts/two_stream_probe.py) "
