@@ -276,3 +276,51 @@ def test_exact_mode_contract_errors():
     with pytest.raises(HierTCNError):
         ex.set_precision("fp16")                      # this handle offers fp32 and bf16
     ex.close()
+
+
+@pytest.mark.parametrize("N,d,zscale", [(300_000, 256, 30.0), (100_000, 512, 10.0)], ids=["cfg3_width_z30", "cfg4_width_d512_z10"])
+def test_exact_mode_at_the_north_star_catalogue_widths(N, d, zscale):
+    """BASELINE.json configs[2] / configs[3] widths (300,000 items at d = 256; d = 512) on a few lanes, scoring layer scaled to a trained
+    model's logit range: fp32-mode logits < 1e-3 of the exact oracle on unrounded weights, ranks inside the oracle's near-tie bracket and
+    equal on nearly every row, ranked top-10 equal wherever the oracle's own gaps exceed the row's logit error."""
+    from hiertcn_amd.engine import Engine
+    B, S, L, K = 2, 3, 30, 10
+    args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
+    p = _trained_like(make_params(args), args, "hier/tcn")
+    rng = np.random.default_rng(N + d)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=True, zipf=True)
+    st0 = (0.2 * rng.standard_normal((B, 2 * d))).astype(np.float32)
+    xl, yl, ml = as_lists(x, y, mask)
+    yy = y.reshape(B, S * L).astype(np.int64)
+    valid = yy > 0
+    hid64, _ = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64, return_hidden=True)
+    z0 = hid64 @ p["hier/tcn/dense/kernel"].astype(np.float64) + p["hier/tcn/dense/bias"].astype(np.float64)
+    f = np.float32(zscale / np.abs(z0[valid]).max())
+    del z0
+    p["hier/tcn/dense/kernel"] = (p["hier/tcn/dense/kernel"] * f).astype(np.float32)
+    p["hier/tcn/dense/bias"] = (p["hier/tcn/dense/bias"] * f).astype(np.float32)
+    exact = hid64 @ p["hier/tcn/dense/kernel"].astype(np.float64) + p["hier/tcn/dense/bias"].astype(np.float64)
+    eng = Engine(args, hier=True, dtype="fp32")
+    eng.set_weights(p)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True, topk=K)
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1))
+    logits = eng.score_logits(hid).cpu().numpy().reshape(B, S * L, N)
+    err_row = np.abs(logits - exact).max(-1)
+    assert err_row[valid].max() < 1e-3, err_row[valid].max()
+    tgt = np.take_along_axis(exact, yy[..., None], -1)
+    rk = out["rank"].cpu().numpy().reshape(B, S * L)
+    tol = 2 * err_row[..., None] + 1e-7
+    lo, hi = (exact > tgt + tol).sum(-1), (exact > tgt - tol).sum(-1)
+    assert np.all((rk >= lo)[valid]) and np.all((rk <= hi)[valid])
+    assert (rk == (exact > tgt).sum(-1))[valid].mean() > 0.9
+    ti = out["topk_idx"].cpu().numpy().reshape(B, S * L, K)
+    want = O.top_k_indices(exact.reshape(-1, N), K + 1).reshape(B, S * L, K + 1)
+    top_vals = np.take_along_axis(exact, want.astype(np.int64), -1)
+    clear = (np.diff(-top_vals, axis=-1).min(-1) > 2 * err_row + 1e-7) & valid
+    assert clear.sum() > 0.9 * valid.sum()
+    assert np.array_equal(ti[clear], want[clear][:, :K])
+    _record("width_N%d_d%d_z%d" % (N, d, int(zscale)), dict(z_max=float(np.abs(exact[valid]).max()), fp32_max=float(err_row[valid].max()),
+                                                           rows=int(valid.sum()), rows_clear_top10=int(clear.sum())))
+    eng.close()
