@@ -81,7 +81,7 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
     n_total = a.train_warmup + a.train_steps
     lr = 1e-3
     # Phase 1, rank-local (no collective inside): everything that can fail on ONE rank -- the training handle's arenas, the batches, and one
-    # whole step with the collectives switched off (kernel / workspace errors surface here).  Then the ranks AGREE on success with one
+    # forward + backward pass (kernel / workspace errors surface here).  Then the ranks AGREE on success with one
     # all-reduce that every rank reaches whatever happened before; only then does the collective part start.  (A rank that raised inside
     # the collective part while the others wait in RCCL would hang the run and the JSON line with it.)
     model, err = None, None
@@ -98,13 +98,9 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
         state0 = torch.zeros((Bt, eng.HT), dtype=torch.float32, device="cuda")
         state_out = torch.empty_like(state0)
         m8 = [torch.zeros(8, dtype=torch.float64, device="cuda") for _ in range(n_total)]
-        if world > 1:
-            os.environ["HIERTCN_DP_OFF"] = "1"
-            try:
-                model.train_step_device(batches[0][0], batches[0][1], batches[0][2], state0, 0.0, state_out=state_out, metrics8=m8[0])
-                torch.cuda.synchronize()
-            finally:
-                os.environ.pop("HIERTCN_DP_OFF", None)
+        if world > 1:   # forward + backward only: no collective, no Adam step (the replicas' optimizer state stays identical)
+            eng.train_forward_backward(batches[0][0], batches[0][1], batches[0][2], state0, state_out=state_out, metrics8=m8[0])
+            torch.cuda.synchronize()
     except Exception as e:  # noqa: BLE001
         import traceback
         err = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:], "rank": rank}
