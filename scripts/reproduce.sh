@@ -1,7 +1,7 @@
 # Every number quoted in DESIGN.md / README.md, one command each (run on an MI355X box from the repo root; ~10 minutes).
 set -u
 python3 -c "import __graft_entry__ as g; g.build(); g.smoke()" | tail -1
-echo "== headline (bench.py defaults: 4096 users/step, cfg-3 shape)"; python3 bench.py 2>/dev/null | tail -1 | python3 -c "
+echo "== headline (bench.py defaults: 16,384 users per evaluation step, 4096 per training step, cfg-3 shape)"; python3 bench.py 2>/dev/null | tail -1 | python3 -c "
 import sys, json
 b = json.loads(sys.stdin.read()); r = b['roofline']
 t = b.get('train') or {}
