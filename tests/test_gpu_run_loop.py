@@ -59,3 +59,32 @@ def test_evaluate_hier_hip_vs_oracle(tmp_path, packed):
         assert abs(got[k] - want[k]) < 5e-3, (k, got[k], want[k])
     assert os.path.exists(args.log_path + "test/results.txt")
     model.engine.close()
+
+
+def test_evaluate_hier_in_the_exact_mode_equals_the_exact_oracle(tmp_path):
+    """`--storage_dtype fp32` through the run loop: the epoch metrics of evaluate_hier on the fp32 mode equal those of the exact oracle
+    (fp64, unrounded weights) driven through the same loop -- loss to 1e-5, every rank-derived mean exactly or within one near-tie --
+    with a scoring layer scaled to a trained model's logit range, where the 16-bit path would be visibly off."""
+    from hiertcn_amd.model import HierTCNModel
+
+    data = load_xing(CSV)
+    n_items = int(data[1][:, 1].max()) + 1
+    args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=5,
+                         batch_size=4, max_session_num=3, max_activity_len=6, storage_dtype="fp32")
+    args.log_path = str(tmp_path) + "/log/"
+    os.makedirs(args.log_path + "test/")
+    params = make_params(args)
+    params["hier/tcn/dense/kernel"] = (params["hier/tcn/dense/kernel"] * 60).astype(np.float32)     # logits of order 10
+    model = HierTCNModel(args, params)
+    assert model.engine.exact and model.engine.act_dtype.is_floating_point and model.engine.act_dtype.itemsize == 4
+    oracle = OracleSession(args, params, O.EXACT64)
+    st0 = np.zeros((4, 64))
+    got, _, _, _, st = evaluate_hier(args, Dataloader_hier_model_xing(args, "test", data=data), st0, model, prefix="test")
+    want, _, _, _, st_ref = evaluate_hier(args, _SlotListsOnly(Dataloader_hier_model_xing(args, "test", data=data)), st0, oracle,
+                                          prefix="oracle")
+    assert abs(got["loss_epoch"] - want["loss_epoch"]) < 1e-5 * max(1.0, abs(want["loss_epoch"]))
+    np.testing.assert_allclose(st, st_ref, atol=1e-5, rtol=0)
+    for k in ("recall1_epoch_mean", "recall5_epoch_mean", "recall10_epoch_mean", "reciprocal_ranks_float_epoch_mean",
+              "ranks_float_epoch_mean"):
+        assert abs(got[k] - want[k]) < 1e-4, (k, got[k], want[k])
+    model.engine.close()
