@@ -304,26 +304,34 @@ __global__ __launch_bounds__(256) void k_xrow_stats(const float* __restrict__ lo
   }
   const float* z = logits + r * ld;
   const float tz = z[yi];
+  // ONE pass over the row (it is read from HBM: a chunk of materialised logits does not fit any cache): count, running maximum and the sum
+  // of exponentials relative to the running maximum (rescaled when the maximum moves), per thread; then the threads' (max, sum) pairs are
+  // merged at the row maximum.  The sum is carried in fp64: N fp32 terms would put ~1e-6 of rounding into ce, this keeps it at the logit error.
   float mx = -INFINITY;
+  double s = 0.0;
   int cnt = 0;
   for (int n = threadIdx.x; n < N; n += 256) {
     const float v = z[n];
-    mx = fmaxf(mx, v);
     cnt += v > tz ? 1 : 0;
+    if (v > mx) {
+      s = s * (double)expf(mx - v) + 1.0;   // (mx = -inf at the first element: exp(-inf) = 0)
+      mx = v;
+    } else {
+      s += (double)expf(v - mx);
+    }
   }
-  mx = xblock_max(mx, shf);
-  for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-  if ((threadIdx.x & 63) == 0) shi[threadIdx.x >> 6] = cnt;
-  // the sum of exponentials in fp64: N terms of fp32 would carry ~1e-6 of rounding into ce, this keeps it at the fp32 logit error
-  double s = 0.0;
-  for (int n = threadIdx.x; n < N; n += 256) s += (double)expf(z[n] - mx);
-  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
-  if ((threadIdx.x & 63) == 0) shd[threadIdx.x >> 6] = s;
+  const float row_max = xblock_max(mx, shf);
+  s *= (double)expf(mx - row_max);           // a thread that saw no element has mx = -inf, s = 0: 0 * 0
+  for (int o = 32; o > 0; o >>= 1) {
+    cnt += __shfl_xor(cnt, o);
+    s += __shfl_xor(s, o);
+  }
+  if ((threadIdx.x & 63) == 0) { shi[threadIdx.x >> 6] = cnt; shd[threadIdx.x >> 6] = s; }
   __syncthreads();
   if (threadIdx.x == 0) {
     if (o_rank) o_rank[r] = shi[0] + shi[1] + shi[2] + shi[3];
     const double tot = (shd[0] + shd[1]) + (shd[2] + shd[3]);
-    if (o_ce) o_ce[r] = (float)((double)mx + log(tot) - (double)tz);
+    if (o_ce) o_ce[r] = (float)((double)row_max + log(tot) - (double)tz);
     if (o_tgt) o_tgt[r] = tz;
   }
 }
