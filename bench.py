@@ -181,28 +181,44 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
 
 
 def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
-    """-> the `gmm` object: ms per hiertcn_gmm_loss call at BASELINE.json configs[4]'s shape and the MFMA rate of its M mean-table passes."""
+    """-> the `gmm` object: ms per hiertcn_gmm_loss call at BASELINE.json configs[4]'s shape, through the Gram form (csrc/gmm_gram.hip: |mu_m|^2
+    as a C x C quadratic form of the hidden row, the default) and through the pass over the M [D, C] mean tables it replaces
+    (HIERTCN_GMM_TABLE_PASS=1: the scoring kernel's main loop with a sum-of-squares epilogue), whose MFMA rate is `table_pass_tflops`."""
     import torch
 
     from hiertcn_amd.args import make_args
     from hiertcn_amd.model_tcn_gmm import TcnGmmModel, init_params
     ga = make_args([], model_type="tcn_gmm", item_num=n_out, output_dim=n_out, num_mixture=n_mix, sigma=0.1, loss="gmm_prob",
                    tcn_channel=[dim, dim], kernel_size=5, adjust=False)
-    model = TcnGmmModel(ga, init_params(ga, 3))
     hid = (torch.randn(rows, dim, device="cuda") * 0.5).to(torch.bfloat16)
     y = torch.randint(1, n_out, (rows,), device="cuda", dtype=torch.int32)
-    model.loss_rows(hid, y)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        model.loss_rows(hid, y)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    model.close()
+    ms, losses = {}, {}
+    saved = os.environ.pop("HIERTCN_GMM_TABLE_PASS", None)
+    try:
+        for name in ("gram", "table_pass"):
+            if name == "table_pass":
+                os.environ["HIERTCN_GMM_TABLE_PASS"] = "1"   # read at hiertcn_gmm_create
+            model = TcnGmmModel(ga, init_params(ga, 3))
+            losses[name] = model.loss_rows(hid, y).clone()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(reps):
+                model.loss_rows(hid, y)
+            torch.cuda.synchronize()
+            ms[name] = (time.perf_counter() - t0) / reps * 1e3
+            model.close()
+    finally:
+        os.environ.pop("HIERTCN_GMM_TABLE_PASS", None)
+        if saved is not None:
+            os.environ["HIERTCN_GMM_TABLE_PASS"] = saved
+    diff = float((losses["gram"] - losses["table_pass"]).abs().max())
     flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
-    return {"what": "hiertcn_gmm_loss (gmm_prob): M passes of k_score_pipe<256,21,...> (sum-of-squares epilogue) over the [D, C] mean tables + prior + "
-                    "finish, random hidden rows", "rows": rows, "output_dim": n_out, "num_mixture": n_mix, "ms": round(dt * 1e3, 3),
-            "tflops": round(flop / dt / 1e12, 1), "frac_of_peak": round(flop / dt / 1e12 / MFMA_PEAK_TFLOPS, 4)}
+    return {"what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
+                    "bf16 parts, + one row-wise kernel for prior / linear terms / target mean + finish); ms_table_pass: M passes of "
+                    "k_score_pipe<256,21,...> (sum-of-squares epilogue) over the [D, C] mean tables + prior + finish",
+            "rows": rows, "output_dim": n_out, "num_mixture": n_mix, "ms": round(ms["gram"], 3), "ms_table_pass": round(ms["table_pass"], 3),
+            "rows_per_s": round(rows / ms["gram"] * 1e3), "max_abs_loss_difference": diff,
+            "table_pass_tflops": round(flop / ms["table_pass"] / 1e9, 1), "table_pass_frac_of_peak": round(flop / ms["table_pass"] / 1e9 / MFMA_PEAK_TFLOPS, 4)}
 
 
 def dvfs_probe(eng, rows, n_items, dim, seconds=1.5):

@@ -217,6 +217,16 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
                         float* logits, hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr,
                         float* split_scratch = nullptr);
 hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, float* o_sq, float* o_tgt, hipStream_t st);
+// Gram form of the mixture losses (gmm_gram.hip): |mu_m|^2 as a C x C quadratic form of the hidden row instead of a pass over the [D, C] table
+bool gmm_gram_applies(int C, int D);
+size_t gmm_gram_scratch_doubles(int M, int C);
+size_t gmm_gram_table_bytes(int M, int C);
+hipError_t launch_gmm_gram_build(const uint16_t* muT, const float* mu_bias, int M, int D, int DP, int C, double* gram64, unsigned char* G3, float* gx,
+                                 float* g0, hipStream_t st);
+hipError_t launch_gmm_quad(const uint16_t* hidden, int64_t R, int C, int M, const unsigned char* G3, float* sq, hipStream_t st);
+hipError_t launch_gmm_prior_gram(const uint16_t* hidden, const float* pi_w, const float* pi_b, const float* gx, const float* g0, const uint16_t* muT,
+                                 const float* mu_bias, const int32_t* y, int64_t R, int C, int M, int D, int DP, float* pl, float* sq, float* tg,
+                                 hipStream_t st);
 // small batches: number of catalogue parts the production kernel splits into (1 = none); scratch = parts * 2 * R floats
 int score_split_parts(int64_t R, int NP);
 // ascending list of the rows with y > 0 (device-side, 3 small kernels): map [R], n_valid [1], scratch [(R+1023)/1024 + 1] ints

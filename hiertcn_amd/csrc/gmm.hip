@@ -13,6 +13,7 @@
 #include <math.h>
 #include <stdarg.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -53,6 +54,12 @@ struct hiertcn_gmm_ctx {
   float* mu_bias;                        // [M][DP], pad entries ZERO (a pad output must add 0 to |mu|^2)
   float* pi_w;                           // [M][Clast] fp32
   float* pi_b;                           // [M]
+  // Gram form of |mu_m|^2 (gmm_gram.hip): used by hiertcn_gmm_loss when it applies and HIERTCN_GMM_TABLE_PASS is not set
+  bool gram;
+  double* gram64;                        // [M][C + 1][C + 1] (scratch of set_weights)
+  unsigned char* G3;                     // per (m, 32-row tile): the LDS image of k_gmm_quad (hi | mid | lo parts of G_m[:C][:C])
+  float* gx;                             // [M][C]: 2 G_m[c][C]
+  float* g0;                             // [M]: G_m[C][C]
   // trunk 1 (model_gru_gmm): GRU stack on one-hot rows
   int trunk, H, nl;
   float* gin_g;                          // [N][2H]: input half of layer 0's gate kernel (a one-hot row times it = its row)
@@ -216,6 +223,14 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
   GA(c->mu_bias, (size_t)c->M * c->DP);
   GA(c->pi_w, (size_t)c->M * cl);
   GA(c->pi_b, c->M);
+  c->gram = gmm_gram_applies(cl, c->D) && !getenv("HIERTCN_GMM_TABLE_PASS");
+  c->gram64 = nullptr; c->G3 = nullptr; c->gx = c->g0 = nullptr;
+  if (c->gram) {
+    GA(c->gram64, gmm_gram_scratch_doubles(c->M, cl));
+    GA(c->G3, gmm_gram_table_bytes(c->M, cl));
+    GA(c->gx, (size_t)c->M * cl);
+    GA(c->g0, c->M);
+  }
 #undef GA
   *out = c;
   return HIERTCN_OK;
@@ -314,6 +329,7 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
   G_HIP(hipMemsetAsync(g->mu_bias, 0, (size_t)M * DP * sizeof(float), st));
   for (int m = 0; m < M; m++)
     G_HIP(hipMemcpyAsync(g->mu_bias + (size_t)m * DP, w->head_biases + M + (size_t)m * D, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (g->gram) G_HIP(launch_gmm_gram_build(g->muT, g->mu_bias, M, D, DP, CL, g->gram64, g->G3, g->gx, g->g0, st));
   g->weights_set = true;
   return HIERTCN_OK;
 }
@@ -395,12 +411,19 @@ int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32
   float* sq = sq_out ? sq_out : reinterpret_cast<float*>(ws);                       // [M][R]
   float* tg = tgt_out ? tgt_out : reinterpret_cast<float*>(ws + g->M * per);        // [M][R]
   float* pl = prior_out ? prior_out : reinterpret_cast<float*>(ws + 2 * g->M * per);   // [R][M]
-  for (int m = 0; m < g->M; m++) {
-    ModelDev md;
-    table_model(g, m, &md);
-    G_HIP(launch_score_sumsq(md, hidden, y_ids, R, sq + (size_t)m * R, tg + (size_t)m * R, st));
+  if (g->gram) {
+    // |mu_m|^2 = x^T G_m x, x = [h; 1] (gmm_gram.hip): the C x C part on the MFMA, the linear / constant terms, the prior logits and the target
+    // mean (a gathered dot product) in one row-wise kernel -- no pass over the [D, C] tables
+    G_HIP(launch_gmm_quad(hidden, R, g->Clast, g->M, g->G3, sq, st));
+    G_HIP(launch_gmm_prior_gram(hidden, g->pi_w, g->pi_b, g->gx, g->g0, g->muT, g->mu_bias, y_ids, R, g->Clast, g->M, g->D, g->DP, pl, sq, tg, st));
+  } else {
+    for (int m = 0; m < g->M; m++) {
+      ModelDev md;
+      table_model(g, m, &md);
+      G_HIP(launch_score_sumsq(md, hidden, y_ids, R, sq + (size_t)m * R, tg + (size_t)m * R, st));
+    }
+    hipLaunchKernelGGL(k_gmm_prior, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, hidden, g->pi_w, g->pi_b, R, g->Clast, g->M, pl);
   }
-  hipLaunchKernelGGL(k_gmm_prior, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, hidden, g->pi_w, g->pi_b, R, g->Clast, g->M, pl);
   hipLaunchKernelGGL(k_gmm_finish, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, sq, tg, pl, y_ids, R, g->M, g->D, g->cfg.sigma, mode, loss);
   G_HIP(hipGetLastError());
   return HIERTCN_OK;

@@ -285,6 +285,10 @@ int hiertcn_export_weights(hiertcn_handle_t h, const hiertcn_weights_t* dst, int
  *                            gmm_prob_max; 0 where y == 0, as model.py:111 masks it).  Neither the [R][M*D] means nor the one-hot
  *                            targets are materialised: sum_d (y_d - mu_d)^2 = |mu_m|^2 - 2 mu_m[y] + 1.  Optional outputs (NULL =
  *                            not wanted): sq [M][R] = |mu_m|^2, tgt [M][R] = mu_m[y], prior [R][M] = the prior logits.
+ *                            |mu_m|^2 is linear algebra on the hidden row -- x^T G_m x, x = [h; 1], G_m = [W_m^T | b_m]^T [W_m^T | b_m]
+ *                            formed in fp64 by hiertcn_gmm_set_weights -- so where 3 C_last < D (and C_last <= 256, bf16 library)
+ *                            no pass over the [D][C_last] mean tables is made at all (csrc/gmm_gram.hip); the environment variable
+ *                            HIERTCN_GMM_TABLE_PASS=1, read by hiertcn_gmm_create, keeps the table pass (A/B, checks).
  *   hiertcn_gmm_head_means   parity/debug: materialise mu_m [R][D] fp32 for one mixture m.                                        */
 typedef struct hiertcn_gmm_ctx* hiertcn_gmm_handle_t;
 typedef struct {

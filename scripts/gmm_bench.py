@@ -1,5 +1,6 @@
-"""Mixture head throughput (BASELINE.json configs[4]): hiertcn_gmm_loss = M passes of the scoring kernel with the sum-of-squares epilogue +
-prior + finish, on random hidden rows.  usage: [HIERTCN_SUMSQ_V1=1] python scripts/gmm_bench.py [rows] [N] [M]"""
+"""Mixture head throughput (BASELINE.json configs[4]): hiertcn_gmm_loss on random hidden rows -- the Gram form (csrc/gmm_gram.hip, default) or,
+with HIERTCN_GMM_TABLE_PASS=1, M passes of the scoring kernel with the sum-of-squares epilogue over the [D, C] mean tables; + prior + finish.
+usage: [HIERTCN_GMM_TABLE_PASS=1] python scripts/gmm_bench.py [rows] [N] [M]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -20,5 +21,8 @@ for _ in range(5):
     model.loss_rows(hid, y)
 torch.cuda.synchronize()
 dt = (time.perf_counter() - t0) / 5
-print(f"gmm loss: rows {rows} N {N} M {M}: {dt*1e3:.2f} ms, {2.0*rows*d*((N+63)//64*64)*M/dt/1e12:.0f} TFLOP/s over the M mean tables", flush=True)
+if os.environ.get("HIERTCN_GMM_TABLE_PASS"):
+    print(f"gmm loss (table pass): rows {rows} N {N} M {M}: {dt*1e3:.2f} ms, {2.0*rows*d*((N+63)//64*64)*M/dt/1e12:.0f} TFLOP/s over the M mean tables", flush=True)
+else:
+    print(f"gmm loss (Gram form): rows {rows} N {N} M {M}: {dt*1e3:.2f} ms = {rows/dt/1e6:.0f} M rows/s ({2.0*rows*3*d*d*M/dt/1e12:.0f} TFLOP/s on the three-part quadratic form)", flush=True)
 model.close()

@@ -34,7 +34,7 @@ HIERTCN_TCN_LAYER_V1=1 python3 scripts/tcn_layer_bench.py single eval 2>&1 | gre
 echo "== HierGRU low level: split-operand cells vs the fp32 cells"
 LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
 LOW=gru EVAL=1 HIERTCN_LGRU_FP32=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2 | sed "s/^/fp32 cells: /"
-echo "== mixture head (614,400 rows x 20,778 outputs x 5 mixtures)"; python3 scripts/gmm_bench.py 2>&1 | tail -1
+echo "== mixture head (614,400 rows x 20,778 outputs x 5 mixtures): Gram form, then the pass over the mean tables"; python3 scripts/gmm_bench.py 2>&1 | tail -1; HIERTCN_GMM_TABLE_PASS=1 python3 scripts/gmm_bench.py 2>&1 | tail -1
 echo "== exact fp32 evaluation mode: throughput, and errors at a trained model's logit scale (tests/test_gpu_exact_mode.py)"
 python3 scripts/exact_mode_bench.py 256 2>&1 | grep -v amdgpu.ids
 python3 -m pytest tests/test_gpu_exact_mode.py -q -m gpu -s -k xing_shape 2>&1 | grep -E "mode,|storage,|passed|failed"

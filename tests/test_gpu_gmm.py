@@ -18,10 +18,17 @@ def _args(N, M, channels, K, loss="gmm_prob"):
                      kernel_size=K, adjust=False)
 
 
+@pytest.mark.parametrize("table_pass", [False, True])
 @pytest.mark.parametrize("N,M,channels,K,B,T", [(1500, 5, (64, 64), 5, 6, 23), (20_778, 5, (256, 256), 5, 4, 40), (3001, 3, (128, 256, 256), 3, 5, 17),
-                                                (700, 2, (512,), 2, 3, 9)])
-def test_tcn_gmm_forward_head_and_losses_vs_oracle(N, M, channels, K, B, T):
+                                                (2500, 3, (64, 128), 3, 4, 19), (700, 2, (512,), 2, 3, 9)])
+def test_tcn_gmm_forward_head_and_losses_vs_oracle(N, M, channels, K, B, T, table_pass, monkeypatch):
+    """table_pass False: |mu_m|^2 through the Gram form (csrc/gmm_gram.hip: a C x C quadratic form of the hidden row; the default wherever
+    3 C < D and C <= 256); True: HIERTCN_GMM_TABLE_PASS=1, the pass over the [D, C] mean tables.  Same assertions against the oracle."""
     from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    if table_pass:
+        monkeypatch.setenv("HIERTCN_GMM_TABLE_PASS", "1")   # read at hiertcn_gmm_create
+    else:
+        monkeypatch.delenv("HIERTCN_GMM_TABLE_PASS", raising=False)
     a = _args(N, M, channels, K)
     p = G.init_params(a, seed=7)
     rng = np.random.default_rng(N + M)
@@ -56,7 +63,10 @@ def test_tcn_gmm_forward_head_and_losses_vs_oracle(N, M, channels, K, B, T):
         np.testing.assert_allclose(sq[m], (mu[:, :, m] ** 2).sum(-1), rtol=2e-4)                  # |mu_m|^2
         t_ref = np.take_along_axis(mu[:, :, m], y[..., None].astype(np.int64), -1)[..., 0]
         assert np.abs(tg[m] - t_ref)[live].max() < 1e-4 and not tg[m][~live].any()                # mu_m[target]
-        assert np.array_equal(tg[m][live], mu_dev[live, y[live]])                                 # ... bitwise the streamed value
+        if table_pass or channels[-1] > 256:
+            assert np.array_equal(tg[m][live], mu_dev[live, y[live]])                             # ... bitwise the streamed value
+        else:   # Gram form: a gathered fp32 dot product instead of the MFMA sequence -- summation order only
+            assert np.abs(tg[m][live] - mu_dev[live, y[live]]).max() < 2e-6 * max(1.0, np.abs(mu_dev).max())
     for mode in ("gmm_prob", "gmm_prob_max"):
         a.loss = mode
         got = model.loss_rows(hid, dev(y), mode).cpu().numpy().reshape(B, T)
@@ -192,3 +202,38 @@ def test_run_gmm_evaluation_loop_on_the_synthetic_xing_file(tmp_path):
     txt = open(a.log_path + "test/results.txt").read()
     assert txt.startswith("loss_epoch ") and "nan" in txt          # a density model has no rank metrics: written as nan
     model.close()
+
+
+@pytest.mark.parametrize("C", [64, 128, 256])
+def test_gram_form_equals_the_table_pass(C, monkeypatch):
+    """The two ways to |mu_m|^2 and mu_m[target] on the same handle contents and the same hidden rows, with LARGE biases (the cross term
+    2 h.W b and |b|^2 then dominate): |mu|^2 to 2e-6 relative (fp32 summation order: both are exact products of 16-bit operands), target
+    mean to 2e-6, losses to 1e-5 -- at R = 700 rows (not a multiple of the 256-row workgroup) with null targets."""
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    N, M = 4000, 4
+    a = _args(N, M, (C,), 2)
+    p = G.init_params(a, seed=11)
+    rng = np.random.default_rng(C)
+    p["tcn_gmm/fully_connected/biases"] = (0.3 * rng.standard_normal(p["tcn_gmm/fully_connected/biases"].shape)).astype(np.float32)
+    R = 700
+    hid = (torch.randn(R, C, device="cuda:0") * 0.7).relu().to(torch.bfloat16)
+    y = torch.as_tensor(rng.integers(0, N, R).astype(np.int32)).to("cuda:0")
+    y[::7] = 0
+    out = {}
+    for name, env in (("gram", None), ("table", "1")):
+        if env:
+            monkeypatch.setenv("HIERTCN_GMM_TABLE_PASS", env)
+        else:
+            monkeypatch.delenv("HIERTCN_GMM_TABLE_PASS", raising=False)
+        model = TcnGmmModel(a, p)
+        loss, sq, tg, pl = model.loss_rows(hid, y, "gmm_prob", parts=True)
+        lmax = model.loss_rows(hid, y, "gmm_prob_max")
+        out[name] = [v.cpu().numpy().astype(np.float64) for v in (loss, sq, tg, pl, lmax)]
+        model.close()
+    g, t = out["gram"], out["table"]
+    assert np.abs(g[1] - t[1]).max() < 2e-6 * np.abs(t[1]).max(), np.abs(g[1] - t[1]).max() / np.abs(t[1]).max()
+    assert np.abs(g[2] - t[2]).max() < 2e-6 * max(1.0, np.abs(t[2]).max())
+    assert np.array_equal(g[3], t[3]) or np.abs(g[3] - t[3]).max() < 1e-6
+    for i in (0, 4):
+        assert np.abs(g[i] - t[i]).max() < 1e-5 * max(1.0, np.abs(t[i]).max()), (i, np.abs(g[i] - t[i]).max())
+    assert not g[0][::7].any() and not g[2][:, ::7].any()
