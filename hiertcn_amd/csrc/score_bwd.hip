@@ -78,6 +78,11 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
 #else
   constexpr bool TWO_CHAINS = C == 512;
 #endif
+#ifdef HIERTCN_SGRAD_WHOLE_PAIRS   // A/B: a pair's whole epilogue in one MFMA gap (until round 3)
+  constexpr bool SPLIT_PAIRS = false;
+#else
+  constexpr bool SPLIT_PAIRS = NCB >= 8;
+#endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages of 64 stream vectors + 3 x 64 stream scalars
   const int64_t n_stat = a.n_stat_dev ? (int64_t)a.n_stat_dev[0] : a.n_stat_max;
   if ((int64_t)blockIdx.x * SG::STAT >= n_stat) return;
@@ -250,6 +255,20 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
     if (MODE == 2) cnt += (acc[i] > tlog ? 1 : 0) + (acc[i + 1] > tlog ? 1 : 0);
     pk[i >> 1] = pack2bf(e0, e1);
   };
+  // The same pair in two halves for two consecutive MFMA gaps (same operations in the same order: bit-identical results).  A whole pair is
+  // 2 fma + 2 exp + 2 add + pack (+ 2 cmp + 2 addc in mode 2) = 36 (52) cycles of vector issue beside an MFMA's 8 -- in one 32-cycle gap it
+  // stretches that gap to 44 (60) while the next gap idles at 8; halved, both gaps stay at or near 32 (MI355X_MICROARCH.md, issue costs).
+  float e_half = 0.f;
+  auto prob_half_a = [&](int i) {
+    e_half = __builtin_amdgcn_exp2f(fmaf(acc[i], LOG2E_F, cst));
+    if (MODE == 2) cnt += (acc[i] > tlog ? 1 : 0) + (acc[i + 1] > tlog ? 1 : 0);
+    asm volatile("" : "+v"(e_half), "+v"(cnt));
+  };
+  auto prob_half_b = [&](int i) {
+    const float e1 = __builtin_amdgcn_exp2f(fmaf(acc[i + 1], LOG2E_F, cst));
+    if (MODE != 1) cs += e_half + e1;
+    pk[i >> 1] = pack2bf(e_half, e1);
+  };
   auto g1 = [&](const unsigned char* tl, const float* tb) {
     int ak = a_k0;   // opaque copy: hipcc otherwise hoists the 16 XOR-ed fragment addresses out of the stage loop and spills them
     asm volatile("" : "+v"(ak));
@@ -307,7 +326,13 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
         if (cb + 1 < NCB) ring[(cb + 1) & 1] = tr_frag(cb + 1);
         oacc[cb] = mfma32(ring[cb & 1], bfrag, oacc[cb]);
       }
-      if ((cb * 4) % NCB == 0) prob_pair(first + 2 * ((cb * 4) / NCB));   // 4 pairs spread over the NCB gaps
+      if constexpr (SPLIT_PAIRS) {   // 4 pairs over the NCB gaps, each pair over two of them
+        constexpr int GP = NCB / 4;
+        if (cb % GP == 0) prob_half_a(first + 2 * (cb / GP));
+        if (cb % GP == GP / 2) prob_half_b(first + 2 * (cb / GP));
+      } else {
+        if ((cb * 4) % NCB == 0) prob_pair(first + 2 * ((cb * 4) / NCB));   // 4 pairs spread over the NCB gaps
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
