@@ -1,6 +1,6 @@
 """Run loop of the mixture-output models (model.py:74-77: --model_type tcn_gmm | gru_gmm) in the shape of run_nn / evaluate_nn
 (run_nn_xing.py:10-98,101-192): single-level loader, no carried state, one scalar per batch -- the masked lane-mean (model.py:111-117) of
-the likelihood loss args.loss in {gmm_prob, gmm_prob_max} (loss.py:247-257) -- averaged over the batches of ALL ranks.
+the likelihood loss args.loss in {gmm_prob, gmm_prob_max} (loss.py:247-257) -- averaged over the batches of ALL ranks (pooled once per epoch).
 
 What the reference itself does with these models on XING cannot be run: its graph feeds the [B, T, M (1 + D)] head output to calc_loss /
 calc_metric_fast against the [B, T, item_num] one-hot targets (model.py:105-132), whose last dimensions differ, and calc_loss_gmm has no
@@ -16,8 +16,6 @@ from .run_common import SCALARS, EpochMeter, ScalarLog
 
 def evaluate_gmm(args, loader, sess, prefix="test"):
     """-> (summary, time_load, time_run).  `sess`: a TcnGmmModel / GruGmmModel (anything with eval_step(x, y) -> {'sums': 2 doubles})."""
-    import torch
-    import torch.distributed as dist
     from .distributed import is_main
     model = sess
     time_load = time_run = 0.0
@@ -28,14 +26,6 @@ def evaluate_gmm(args, loader, sess, prefix="test"):
         batch_x, batch_y, _info = loader.get_batch()
         t2 = time.time()
         sums = model.eval_step(batch_x, batch_y)["sums"]
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            # users are sharded over the ranks: the batch metric is the lane mean over the lanes of ALL ranks (as hiertcn_metrics' sums)
-            if sums.is_cuda and dist.get_backend() == "gloo":
-                host = sums.cpu()
-                dist.all_reduce(host)
-                sums = host
-            else:
-                dist.all_reduce(sums)
         s = [float(v) for v in sums.cpu()]
         step = {k: nan for k, _ in SCALARS}
         step["loss"] = s[0] / s[1] if s[1] > 0 else nan
@@ -45,9 +35,10 @@ def evaluate_gmm(args, loader, sess, prefix="test"):
         time_run += t3 - t2
         if loader.done:
             break
-    # every rank already holds the global per-batch values: no second reduction over ranks
-    m = meter.means()
-    meter._write(m, head="")
+    # data-parallel evaluation: every rank walked its own shard of the users -- shards may differ in their number of batches, so there is
+    # no collective inside the loop (a rank that finished early would leave the others waiting in it); the epoch value is the mean over
+    # the batches of all ranks, pooled once here exactly as evaluate_hier / evaluate_nn pool theirs (EpochMeter.finish)
+    m = meter.finish()
     return m, time_load, time_run
 
 

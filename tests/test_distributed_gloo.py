@@ -284,3 +284,49 @@ def test_gradient_exchange_with_sizes_that_differ_per_rank_and_step(tmp_path):
         mp.spawn(_ragged_steps_worker, args=(2, _free_port(), str(d), bound), nprocs=2, join=True)
         err = np.load(d / "err.npy")
         assert err.shape == (5,) and err.max() < 1e-5
+
+
+class _FakeGmm:
+    """eval_step(x, y) -> {'sums': [sum of lane means, users]}: stands for TcnGmmModel in the run loop (no GPU here)."""
+
+    def eval_step(self, x, y):
+        x = np.asarray(x, np.float64)
+        return dict(sums=torch.tensor([float(x.sum()), float(x.shape[0])], dtype=torch.float64))
+
+
+class _ListLoader:
+    def __init__(self, batches):
+        self.batches, self.i, self.done = batches, 0, False
+
+    def get_batch(self):
+        b = self.batches[self.i]
+        self.i += 1
+        self.done = self.i == len(self.batches)
+        return b, b, None
+
+
+def _gmm_eval_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from types import SimpleNamespace
+
+    from hiertcn_amd.distributed import init_from_env
+    from hiertcn_amd.run_gmm_xing import evaluate_gmm
+    init_from_env("gloo")
+    rng = np.random.default_rng(10 + rank)
+    n_batches = 3 if rank == 0 else 5          # shards of different lengths: a collective inside the batch loop would hang here
+    batches = [rng.random((4, 6)) for _ in range(n_batches)]
+    args = SimpleNamespace(log_path=os.path.join(out_dir, "log") + "/")
+    os.makedirs(args.log_path + "test/", exist_ok=True)
+    m, _, _ = evaluate_gmm(args, _ListLoader(batches), _FakeGmm(), prefix="test")
+    np.save(os.path.join(out_dir, f"gmm_{rank}.npy"), np.array([m["loss_epoch"]] + [b.sum() / 4 for b in batches]))
+    torch.distributed.destroy_process_group()
+
+
+def test_evaluate_gmm_with_shards_of_different_lengths(tmp_path):
+    """run_gmm_xing.evaluate_gmm under two ranks whose loaders yield 3 and 5 batches: it returns (no rank waits in a per-batch collective
+    for a rank that is already done) and both ranks report the mean over all 8 batches."""
+    mp.spawn(_gmm_eval_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    a, b = (np.load(tmp_path / f"gmm_{r}.npy") for r in range(2))
+    want = np.concatenate([a[1:], b[1:]]).mean()
+    assert abs(a[0] - want) < 1e-12 and abs(b[0] - want) < 1e-12
+    assert open(tmp_path / "log" / "test" / "results.txt").read().startswith("loss_epoch ")
