@@ -39,6 +39,6 @@ echo "== exact fp32 evaluation mode: throughput, and errors at a trained model's
 python3 scripts/exact_mode_bench.py 256 2>&1 | grep -v amdgpu.ids
 python3 -m pytest tests/test_gpu_exact_mode.py -q -m gpu -s -k xing_shape 2>&1 | grep -E "mode,|storage,|passed|failed"
 echo "== tile-skip census (profiles/r3_score_ablation.md)"; python3 scripts/skip_tile_census.py 20778 16 2>&1 | grep -v amdgpu.ids
-echo "== parity against the exact oracle on unrounded fp32 weights"; python3 scripts/parity_fp32_probe.py 2>&1 | grep shape | cut -c1-400
+echo "== parity against the exact oracle on unrounded fp32 weights"; python3 tests/tools/parity_fp32_probe.py 2>&1 | grep shape | cut -c1-400
 echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3
 echo "== repeated full-size launches agree (ranks, target logits bitwise; ce to 5e-5)"; python3 scripts/soak_score.py 2>&1 | grep mismatching

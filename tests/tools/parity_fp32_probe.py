@@ -2,7 +2,7 @@
 Prints max / quantiles of |device - O.model_hier(..., p_unrounded, EXACT64)| for the shipped bf16 path (and, when present,
 the exact-fp32 parity mode) at BASELINE.json configs[1]'s shape and at the north star's catalogue width.
 
-    python scripts/parity_fp32_probe.py            (on the GPU box)
+    python tests/tools/parity_fp32_probe.py            (on the GPU box)
 """
 import json
 import os
@@ -11,7 +11,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from hiertcn_amd.engine import Engine  # noqa: E402
 from oracle import hiertcn_oracle as O  # noqa: E402

@@ -1,5 +1,7 @@
+"""Full-size check of everything in front of the scoring kernel (gather, scan, low level) against the oracle; lives under tests/ because it
+uses oracle/ (checker code).  usage (GPU box): python tests/tools/soak_frontend.py"""
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 import bench
 from hiertcn_amd.args import hier_tcn_args
