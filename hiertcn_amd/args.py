@@ -46,7 +46,7 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--multi_num", dest="multi_num", default=3, type=int)
     p.add_argument("--dropout", dest="dropout", default=0.0, type=float)
     p.add_argument("--topic_dim", dest="topic_dim", default=50, type=int)
-    p.add_argument("--sigma", dest="sigma", default=0.1, type=float)
+    p.add_argument("--sigma", dest="sigma", default=0.1, type=lambda v: None if str(v).lower() in ("none", "learn", "0", "0.0") else float(v))   # None: a learned scale
     p.add_argument("--num_mixture", dest="num_mixture", default=5, type=int)
     p.add_argument("--pred_mode", dest="pred_mode", default="gmm_score")
     p.add_argument("--mix_weight", dest="mix_weight", default=0.01, type=float)

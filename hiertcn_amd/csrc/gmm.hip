@@ -54,6 +54,13 @@ struct hiertcn_gmm_ctx {
   float* mu_bias;                        // [M][DP], pad entries ZERO (a pad output must add 0 to |mu|^2)
   float* pi_w;                           // [M][Clast] fp32
   float* pi_b;                           // [M]
+  // learned scale (cfg.sigma == 0; model_tcn_gmm.py:39-40: n_out = M (1 + 2 D)): tables M .. 2M-1 of muT / mu_bias hold the log-scale blocks
+  bool learned;
+  int NPs;                               // rows of an interleaved table: 64 per stage of 32 outputs
+  uint16_t* sgT;                         // [M][NPs][Clast]: per stage the 32 mean rows, then the 32 log-scale rows of the same outputs
+  float* sg_bias;                        // [M][NPs]
+  float* svec;                           // [M][Clast]: sum_d of the log-scale table's rows (sum_d s_d is linear in the hidden row)
+  float* s0;                             // [M]: sum_d of the log-scale biases
   // Gram form of |mu_m|^2 (gmm_gram.hip): used by hiertcn_gmm_loss when it applies and HIERTCN_GMM_TABLE_PASS is not set
   bool gram;
   double* gram64;                        // [M][C + 1][C + 1] (scratch of set_weights)
@@ -160,6 +167,109 @@ __global__ void k_gmm_finish(const float* __restrict__ sq, const float* __restri
   loss[r] = (float)(-((double)(zmax + logf(s)) + cst) / (double)D);                   // -log(exp(log_prob / D))
 }
 
+// ---- learned scale: sigma_d = exp(s_d), s = the second block of D outputs per mixture (the decode is the build's own: oracle/gmm_oracle.py)
+// log N_m(y) = -1/2 [ Q_m + (1 - 2 mu_m[y]) exp(-2 s_m[y]) ] - S_m - D/2 log 2 pi   for a one-hot y, with
+// Q_m = sum_d mu_d^2 exp(-2 s_d) (score.hip PMODE 22: one pass over the interleaved table) and S_m = sum_d s_d (linear in the hidden row).
+__global__ void k_gmm_interleave(const uint16_t* __restrict__ muT, const float* __restrict__ mu_bias, int M, int DP, int NPs, int C,
+                                 uint16_t* __restrict__ sgT, float* __restrict__ sg_bias) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c8 = C / 8;
+  if (i >= (int64_t)M * NPs * c8) return;
+  const int c = (int)(i % c8) * 8;
+  const int64_t mr = i / c8;
+  const int row = (int)(mr % NPs), m = (int)(mr / NPs);
+  const int d = (row >> 6) * 32 + (row & 31);            // output of this row
+  const int tab = (row & 32) ? M + m : m;                 // second half of a stage: the log-scale table
+  const bool in = d < DP;
+  const uint4 z = make_uint4(0, 0, 0, 0);
+  *reinterpret_cast<uint4*>(sgT + ((size_t)m * NPs + row) * C + c) = in ? *reinterpret_cast<const uint4*>(muT + ((size_t)tab * DP + d) * C + c) : z;
+  if (c == 0) sg_bias[(size_t)m * NPs + row] = in ? mu_bias[(size_t)tab * DP + d] : 0.f;
+}
+// svec[m][c] = sum_d table_{M+m}[d][c], s0[m] = sum_d bias_{M+m}[d]   (fp64 sums of the stored values)
+__global__ void k_gmm_scale_sums(const uint16_t* __restrict__ muT, const float* __restrict__ mu_bias, int M, int D, int DP, int C,
+                                 float* __restrict__ svec, float* __restrict__ s0) {
+  const int m = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  double acc = 0.0;
+  if (c < C) {
+    const uint16_t* tab = muT + (size_t)(M + m) * DP * C;
+    for (int d = 0; d < D; d++) acc += (double)bf2f(tab[(size_t)d * C + c]);
+    svec[(size_t)m * C + c] = (float)acc;
+  } else {
+    const float* b = mu_bias + (size_t)(M + m) * DP;
+    for (int d = 0; d < D; d++) acc += (double)b[d];
+    s0[m] = (float)acc;
+  }
+}
+// 16 lanes per row: prior logits, S_m = h . svec_m + s0_m, mu_m[y] and s_m[y] from the gathered rows of tables m and M + m
+__global__ __launch_bounds__(256) void k_gmm_prior_sigma(const uint16_t* __restrict__ hidden, const float* __restrict__ pi_w, const float* __restrict__ pi_b,
+                                                          const float* __restrict__ svec, const float* __restrict__ s0, const uint16_t* __restrict__ muT,
+                                                          const float* __restrict__ mu_bias, const int32_t* __restrict__ y, int64_t R, int C, int M, int D,
+                                                          int DP, float* __restrict__ pl, float* __restrict__ tg, float* __restrict__ sy,
+                                                          float* __restrict__ ssum) {
+  const int l16 = threadIdx.x & 15;
+  const int64_t r = (int64_t)blockIdx.x * 16 + (threadIdx.x >> 4);
+  const int64_t rc = r < R ? r : R - 1;
+  const int yy = y[rc];
+  const bool live = yy > 0 && yy < D;
+  for (int m = 0; m < M; m++) {
+    const uint16_t* mrow = muT + ((size_t)m * DP + (live ? yy : 0)) * C;
+    const uint16_t* srow = muT + ((size_t)(M + m) * DP + (live ? yy : 0)) * C;
+    float a[4] = {0.f, 0.f, 0.f, 0.f};   // prior, S, mu[y], s[y]
+    for (int c = 8 * l16; c < C; c += 128) {
+      const uint4 hv = *reinterpret_cast<const uint4*>(hidden + rc * C + c);
+      const uint4 mv = *reinterpret_cast<const uint4*>(mrow + c);
+      const uint4 sv = *reinterpret_cast<const uint4*>(srow + c);
+      const uint32_t hw[4] = {hv.x, hv.y, hv.z, hv.w}, mw[4] = {mv.x, mv.y, mv.z, mv.w}, sw[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const float h0 = bf2f((uint16_t)(hw[q] & 0xffff)), h1 = bf2f((uint16_t)(hw[q] >> 16));
+        a[0] = fmaf(h0, pi_w[(size_t)m * C + c + 2 * q], fmaf(h1, pi_w[(size_t)m * C + c + 2 * q + 1], a[0]));
+        a[1] = fmaf(h0, svec[(size_t)m * C + c + 2 * q], fmaf(h1, svec[(size_t)m * C + c + 2 * q + 1], a[1]));
+        a[2] = fmaf(h0, bf2f((uint16_t)(mw[q] & 0xffff)), fmaf(h1, bf2f((uint16_t)(mw[q] >> 16)), a[2]));
+        a[3] = fmaf(h0, bf2f((uint16_t)(sw[q] & 0xffff)), fmaf(h1, bf2f((uint16_t)(sw[q] >> 16)), a[3]));
+      }
+    }
+#pragma unroll
+    for (int off = 8; off > 0; off >>= 1)
+#pragma unroll
+      for (int k = 0; k < 4; k++) a[k] += __shfl_xor(a[k], off);
+    if (l16 == 0 && r < R) {
+      pl[r * M + m] = a[0] + pi_b[m];
+      ssum[(size_t)m * R + r] = a[1] + s0[m];
+      tg[(size_t)m * R + r] = live ? a[2] + mu_bias[(size_t)m * DP + yy] : 0.f;
+      sy[(size_t)m * R + r] = live ? a[3] + mu_bias[(size_t)(M + m) * DP + yy] : 0.f;
+    }
+  }
+}
+__global__ void k_gmm_finish_sigma(const float* __restrict__ q, const float* __restrict__ tgt, const float* __restrict__ sy, const float* __restrict__ ssum,
+                                   const float* __restrict__ pl, const int32_t* __restrict__ y, int64_t R, int M, int D, int mode, float* __restrict__ loss) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= R) return;
+  if (y[r] <= 0 || y[r] >= D) { loss[r] = 0.f; return; }
+  float mx = -INFINITY;
+  for (int m = 0; m < M; m++) mx = fmaxf(mx, pl[r * M + m]);
+  float se = 0.f;
+  for (int m = 0; m < M; m++) se += expf(pl[r * M + m] - mx);
+  const float lse_pi = mx + logf(se);
+  const double cst = -0.5 * (double)D * log(2.0 * M_PI);
+  float best = -INFINITY, zmax = -INFINITY;
+  float z[16];
+  for (int m = 0; m < M; m++) {
+    const int64_t k = (int64_t)m * R + r;
+    const float lp = -0.5f * (q[k] + (1.f - 2.f * tgt[k]) * expf(-2.f * sy[k])) - ssum[k];   // mvn_m.log_prob(y) - cst
+    const float lpi = pl[r * M + m] - lse_pi;
+    z[m] = lpi + lp;
+    zmax = fmaxf(zmax, z[m]);
+    best = fmaxf(best, lpi + lp / (float)D);
+  }
+  if (mode == 1) { loss[r] = (float)(-((double)best + cst / (double)D)); return; }
+  float s = 0.f;
+  for (int m = 0; m < M; m++) s += expf(z[m] - zmax);
+  loss[r] = (float)(-((double)(zmax + logf(s)) + cst) / (double)D);
+}
+
 extern "C" {
 
 int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cfg) {
@@ -175,12 +285,13 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
   if (!gru && (cfg->n_blocks < 1 || cfg->n_blocks > HIERTCN_MAX_BLOCKS)) return gfail(HIERTCN_ERR_INVALID, "n_blocks out of range");
   if (!gru && (cfg->kernel_size < 1 || cfg->kernel_size > 8)) return gfail(HIERTCN_ERR_INVALID, "kernel_size out of range");
   if (cfg->num_mixture < 1 || cfg->num_mixture > 16) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: 1..16", cfg->num_mixture);
-  if (!(cfg->sigma > 0.f)) return gfail(HIERTCN_ERR_INVALID, "sigma must be > 0 (a learned sigma, args.sigma None, is not built)");
+  if (!(cfg->sigma >= 0.f)) return gfail(HIERTCN_ERR_INVALID, "sigma must be > 0, or 0 for a learned scale (args.sigma None: n_out = M (1 + 2 D))");
   for (int i = 0; i < cfg->n_blocks && !gru; i++)
     if (cfg->channels[i] < 32 || (cfg->channels[i] & 31) || cfg->channels[i] > 1024)
       return gfail(HIERTCN_ERR_INVALID, "tcn_channel[%d]=%d: widths are multiples of 32 up to 1024", i, cfg->channels[i]);
   const int cl = gru ? cfg->hidden_dim : cfg->channels[cfg->n_blocks - 1];
   if (!(cl == 64 || cl == 128 || cl == 256 || cl == 512)) return gfail(HIERTCN_ERR_INVALID, "last tcn_channel %d: the head kernel is built for 64, 128, 256, 512", cl);
+  if (cfg->sigma == 0.f && cl > 256) return gfail(HIERTCN_ERR_INVALID, "a learned scale is built for a last width of 64, 128 or 256 (got %d)", cl);
   hiertcn_gmm_ctx* c = new hiertcn_gmm_ctx();
   memset(static_cast<void*>(&c->cfg), 0, sizeof(c->cfg));
   c->cfg = *cfg;
@@ -219,11 +330,21 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
     GA(c->conv_bias[i], cfg->channels[i]);
     if (cin != cfg->channels[i]) { GA(c->resT[i], (size_t)cin * cfg->channels[i]); GA(c->res_bias[i], cfg->channels[i]); }
   }
-  GA(c->muT, (size_t)c->M * c->DP * cl);
-  GA(c->mu_bias, (size_t)c->M * c->DP);
+  c->learned = cfg->sigma == 0.f;
+  const size_t n_tab = c->learned ? 2 * (size_t)c->M : (size_t)c->M;   // learned scale: tables M .. 2M-1 are the log-scale blocks
+  GA(c->muT, n_tab * c->DP * cl);
+  GA(c->mu_bias, n_tab * c->DP);
+  c->NPs = ((c->D + 31) / 32) * 64;
+  c->sgT = nullptr; c->sg_bias = c->svec = c->s0 = nullptr;
+  if (c->learned) {
+    GA(c->sgT, (size_t)c->M * c->NPs * cl);
+    GA(c->sg_bias, (size_t)c->M * c->NPs);
+    GA(c->svec, (size_t)c->M * cl);
+    GA(c->s0, c->M);
+  }
   GA(c->pi_w, (size_t)c->M * cl);
   GA(c->pi_b, c->M);
-  c->gram = gmm_gram_applies(cl, c->D) && !getenv("HIERTCN_GMM_TABLE_PASS");
+  c->gram = !c->learned && gmm_gram_applies(cl, c->D) && !getenv("HIERTCN_GMM_TABLE_PASS");
   c->gram64 = nullptr; c->G3 = nullptr; c->gx = c->g0 = nullptr;
   if (c->gram) {
     GA(c->gram64, gmm_gram_scratch_doubles(c->M, cl));
@@ -251,10 +372,11 @@ __global__ void k_copy_cols_f32(const float* __restrict__ src, int64_t ld_src, i
   const int64_t r = i / cols, c = i - r * cols;
   dst[r * ld_dst + c] = src[r * ld_src + c0 + c];
 }
-// muT[m][n][c] = bf16(W[c][M + m D + n]) for n < D, 0 for D <= n < DP; one thread per (m, n, c) with c fastest
-__global__ void k_gmm_head_tables(const float* __restrict__ W, int64_t n_out, int C, int M, int D, int DP, uint16_t* __restrict__ muT) {
+// muT[m][n][c] = bf16(W[c][M + m D + n]) for n < D, 0 for D <= n < DP, m < T tables (T = M, or 2 M with a learned scale: the log-scale blocks
+// follow the mean blocks); one thread per (m, n, c) with c fastest
+__global__ void k_gmm_head_tables(const float* __restrict__ W, int64_t n_out, int C, int M, int T, int D, int DP, uint16_t* __restrict__ muT) {
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)M * DP * C) return;
+  if (i >= (int64_t)T * DP * C) return;
   const int c = (int)(i % C);
   const int64_t mn = i / C;
   const int n = (int)(mn % DP), m = (int)(mn / DP);
@@ -306,7 +428,8 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
   }
   }
   // head [C][M (1 + D)]: columns [0, M) -> prior kernel [M][C] fp32; columns M + m D + n -> table m, row n (bf16, item-major)
-  const int64_t n_out = (int64_t)M * (1 + D);
+  const int T = g->learned ? 2 * M : M;   // tables: means, then (learned scale) log-scales
+  const int64_t n_out = (int64_t)M + (int64_t)T * D;
   {
     // pi_w[m][c] = W[c][m]
     const int64_t n = (int64_t)M * CL;
@@ -322,13 +445,19 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
   }
   G_HIP(hipMemcpyAsync(g->pi_b, w->head_biases, (size_t)M * sizeof(float), hipMemcpyDeviceToDevice, st));
   {
-    const int64_t n = (int64_t)M * DP * CL;
-    hipLaunchKernelGGL(k_gmm_head_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w->head_weights, n_out, CL, M, D, DP, g->muT);
+    const int64_t n = (int64_t)T * DP * CL;
+    hipLaunchKernelGGL(k_gmm_head_tables, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w->head_weights, n_out, CL, M, T, D, DP, g->muT);
     G_HIP(hipGetLastError());
   }
-  G_HIP(hipMemsetAsync(g->mu_bias, 0, (size_t)M * DP * sizeof(float), st));
-  for (int m = 0; m < M; m++)
+  G_HIP(hipMemsetAsync(g->mu_bias, 0, (size_t)T * DP * sizeof(float), st));
+  for (int m = 0; m < T; m++)
     G_HIP(hipMemcpyAsync(g->mu_bias + (size_t)m * DP, w->head_biases + M + (size_t)m * D, (size_t)D * sizeof(float), hipMemcpyDeviceToDevice, st));
+  if (g->learned) {
+    const int64_t n = (int64_t)M * g->NPs * (CL / 8);
+    hipLaunchKernelGGL(k_gmm_interleave, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g->muT, g->mu_bias, M, DP, g->NPs, CL, g->sgT, g->sg_bias);
+    hipLaunchKernelGGL(k_gmm_scale_sums, dim3((unsigned)((CL + 1 + 255) / 256), (unsigned)M), dim3(256), 0, st, g->muT, g->mu_bias, M, D, DP, CL, g->svec, g->s0);
+    G_HIP(hipGetLastError());
+  }
   if (g->gram) G_HIP(launch_gmm_gram_build(g->muT, g->mu_bias, M, D, DP, CL, g->gram64, g->G3, g->gx, g->g0, st));
   g->weights_set = true;
   return HIERTCN_OK;
@@ -344,7 +473,7 @@ size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R) {
   if (!g || R < 0) return 0;
   const size_t act = (((size_t)R * max_w(g) * 2) + 255) & ~(size_t)255;
   const size_t per = (((size_t)R * sizeof(float)) + 255) & ~(size_t)255;
-  return 2 * act + 2 * g->M * per + ((((size_t)R * g->M * sizeof(float)) + 255) & ~(size_t)255);
+  return 2 * act + 4 * g->M * per + ((((size_t)R * g->M * sizeof(float)) + 255) & ~(size_t)255);   // |mu|^2, mu[y], (learned scale) s[y], sum s; prior
 }
 
 size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T) {
@@ -410,7 +539,25 @@ int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32
   unsigned char* ws = reinterpret_cast<unsigned char*>(workspace) + 2 * act;
   float* sq = sq_out ? sq_out : reinterpret_cast<float*>(ws);                       // [M][R]
   float* tg = tgt_out ? tgt_out : reinterpret_cast<float*>(ws + g->M * per);        // [M][R]
-  float* pl = prior_out ? prior_out : reinterpret_cast<float*>(ws + 2 * g->M * per);   // [R][M]
+  float* pl = prior_out ? prior_out : reinterpret_cast<float*>(ws + 4 * g->M * per);   // [R][M]
+  if (g->learned) {
+    // sq = Q_m = sum_d mu_d^2 exp(-2 s_d): one pass per mixture over the interleaved (means | log-scales) table; everything else row-wise
+    float* sy = reinterpret_cast<float*>(ws + 2 * g->M * per);                         // [M][R] s_m[y]
+    float* ssum = reinterpret_cast<float*>(ws + 3 * g->M * per);                       // [M][R] sum_d s_d
+    for (int m = 0; m < g->M; m++) {
+      ModelDev md;
+      memset(&md, 0, sizeof(md));
+      md.N = md.NP = g->NPs; md.Clast = g->Clast;
+      md.outT = g->sgT + (size_t)m * g->NPs * g->Clast;
+      md.out_bias = g->sg_bias + (size_t)m * g->NPs;
+      G_HIP(launch_score_sigma(md, hidden, y_ids, R, sq + (size_t)m * R, st));
+    }
+    hipLaunchKernelGGL(k_gmm_prior_sigma, dim3((unsigned)((R + 15) / 16)), dim3(256), 0, st, hidden, g->pi_w, g->pi_b, g->svec, g->s0, g->muT, g->mu_bias,
+                       y_ids, R, g->Clast, g->M, g->D, g->DP, pl, tg, sy, ssum);
+    hipLaunchKernelGGL(k_gmm_finish_sigma, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, sq, tg, sy, ssum, pl, y_ids, R, g->M, g->D, mode, loss);
+    G_HIP(hipGetLastError());
+    return HIERTCN_OK;
+  }
   if (g->gram) {
     // |mu_m|^2 = x^T G_m x, x = [h; 1] (gmm_gram.hip): the C x C part on the MFMA, the linear / constant terms, the prior logits and the target
     // mean (a gathered dot product) in one row-wise kernel -- no pass over the [D, C] tables
@@ -466,7 +613,7 @@ int hiertcn_gmm_lane_loss(hiertcn_gmm_handle_t g, const float* loss, const int32
 
 int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64_t R, int32_t m, float* mu_out, void* stream) {
   G_READY(g);
-  if (!hidden || !mu_out || R < 1 || m < 0 || m >= g->M) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  if (!hidden || !mu_out || R < 1 || m < 0 || m >= (g->learned ? 2 * g->M : g->M)) return gfail(HIERTCN_ERR_INVALID, "bad argument");
   ModelDev md;
   table_model(g, m, &md);
   G_HIP(launch_score(md, hidden, nullptr, R, nullptr, mu_out, reinterpret_cast<hipStream_t>(stream)));

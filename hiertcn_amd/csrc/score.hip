@@ -575,12 +575,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // stands for row row_map[p], workgroups past the count exit at once, and padded steps cost no MFMA at all.
   // Every row's arithmetic is independent of its position, so results are bit-identical to the dense launch.
   const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
-  static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2) || (NB == 1 && PMODE == 15 && (NSTG == 3 || (NSTG == 2 && C == 512))), "the pipeline shapes written out below");
+  static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2) || (NB == 1 && (PMODE == 15 || PMODE == 22) && (NSTG == 3 || (NSTG == 2 && C == 512))), "the pipeline shapes written out below");
   if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
   constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14 || PMODE == 16 || PMODE == 21;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
   constexpr bool SUMSQ = PMODE == 21;   // mixture head (gmm.hip): the four-tile seamless kernel with a one-fma epilogue -- sum of squares of the row's outputs
-  constexpr bool SEAM1 = PMODE == 15;   // ONE step block per wave (room for per-lane top-k lists) with the seamless tile boundary of PMODE 14: see SC_PHASE1
+  constexpr bool SIGMA = PMODE == 22;   // mixture head with a learned scale (gmm.hip): tiles come in PAIRS -- the 32 means of a stage, then the 32 log-scales of the same
+                                        // outputs -- and the row accumulates sum_d mu_d^2 exp(-2 s_d): the seamless one-block skeleton with a two-phase epilogue
+  constexpr bool SEAM1 = PMODE == 15 || PMODE == 22;   // ONE step block per wave (room for per-lane top-k lists) with the seamless tile boundary of PMODE 14: see SC_PHASE1
   constexpr bool SEAMLESS = PMODE == 14 || PMODE == 16 || PMODE == 21;   // 16: timing experiment, no stage barrier (racy by design)   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
   if constexpr (FIXUP) {
     const int64_t r = (int64_t)blockIdx.x * (256 * NB) + threadIdx.x;
@@ -828,7 +830,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   };
   // PMODE 5: end of a tile: drain the two pending values, then the overflow check (wave-uniform branch, rare).
   auto post5 = [&](const f32x16& v, RowState2& rs) {
-    if (SUMSQ) return;
+    if (SUMSQ || SIGMA) return;
     rs.s += rs.ep;
     rs.s += __builtin_amdgcn_exp2f(rs.xp);
     if (!DUAL && !SEAM1 && __any(!(rs.s < 1.0e38f))) {
@@ -975,15 +977,23 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // slow path: per-lane sorted lists in registers, candidates parked two at a time).  The softmax sum has no per-tile redo here: a sum
   // past fp32 is handed to the fix-up launch, as in PMODE 14.
   float tk_m = -INFINITY;
+  float mu2_[16];   // SIGMA: squares of the stage's means, kept from the first tile's drain to the second's
+  // half 0: a tile of means -> their squares; half 1: the log-scales of the same outputs -> sum += mu^2 exp(-2 s), exponent clamped below fp32 overflow
+  auto sig_val = [&](int half, float& m2, float v, RowState2& rs) {
+    if (half == 0) m2 = v * v;
+    else rs.s = fmaf(m2, __builtin_amdgcn_exp2f(fminf(v * (-2.0f * LOG2E_F), 126.0f)), rs.s);
+    asm volatile("" : "+v"(rs.s), "+v"(m2));
+  };
 #define SC_GAP1(x, y, s)                                                                     \
       if (MF_ && (s) < G::KS) {                                                              \
         ring4_[((s) + 3) & 3] = *reinterpret_cast<const uint4*>(((s) + 3 < G::KS) ? tile_ + SC_FRAG((s) + 3) : ntile_ + SC_FRAG((s) + 3 - G::KS)); \
         x = mfma32(ring4_[(s) & 3], hf[0][s], x);                                            \
       }                                                                                      \
-      val5(s, y[s], st[0]);
-#define SC_PHASE1(x, y, buf_, ib_, MF, nbuf_, nib_, dit_)                                      \
+      if (SIGMA) sig_val(HALF_, mu2_[s], y[s], st[0]); else val5(s, y[s], st[0]);
+#define SC_PHASE1(x, y, buf_, ib_, MF, nbuf_, nib_, dit_, half_)                               \
   do {                                                                                       \
     constexpr bool MF_ = MF;                                                                 \
+    constexpr int HALF_ = half_;                                                             \
     const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;               \
     const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nib_) * TILE_LDS;            \
     const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nib_) * 32 + 4 * lh;                 \
@@ -1092,15 +1102,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
       const int buf1 = (buf == 2) ? 0 : buf + 1;
       const int buf2 = (buf1 == 2) ? 0 : buf1 + 1;
       if (stg + 2 < n_stages) stage_issue(stg + 2, buf2);
-      SC_PHASE1(accB, accA, buf, 1, true, buf1, 0, (stg_lo + stg) * SC_STAGE + 4 * lh);        // MFMA (stg, ib1)   || epilogue (stg, ib0); accA <- bias (stg+1, ib0)
-      SC_PHASE1(accA, accB, buf1, 0, true, buf1, 1, (stg_lo + stg) * SC_STAGE + 32 + 4 * lh);  // MFMA (stg+1, ib0) || epilogue (stg, ib1); accB <- bias (stg+1, ib1)
+      SC_PHASE1(accB, accA, buf, 1, true, buf1, 0, (stg_lo + stg) * SC_STAGE + 4 * lh, 0);        // MFMA (stg, ib1)   || epilogue (stg, ib0); accA <- bias (stg+1, ib0)
+      SC_PHASE1(accA, accB, buf1, 0, true, buf1, 1, (stg_lo + stg) * SC_STAGE + 32 + 4 * lh, 1);  // MFMA (stg+1, ib0) || epilogue (stg, ib1); accB <- bias (stg+1, ib1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       buf = buf1;
     }
     if (n_stages > 0) {
-      SC_PHASE1(accB, accA, buf, 1, true, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 4 * lh);         // (the "next tile" reads land in dead registers)
-      SC_PHASE1(accA, accB, buf, 1, false, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 32 + 4 * lh);   // epilogue of the last tile only
+      SC_PHASE1(accB, accA, buf, 1, true, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 4 * lh, 0);         // (the "next tile" reads land in dead registers)
+      SC_PHASE1(accA, accB, buf, 1, false, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 32 + 4 * lh, 1);   // epilogue of the last tile only
     }
   } else if constexpr (NB == 2 && SEAMLESS && C <= 256) {
     f32x16 xa0, xa1, xb0, xb1;
@@ -1241,7 +1251,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     const float M2 = fmaxf(l_own, l_o);
     const float S = __builtin_amdgcn_exp2f(l_own - M2) + __builtin_amdgcn_exp2f(l_o - M2);
     const int cnt = c_own + c_o;
-    if (SUMSQ) {   // sum of squares over ALL outputs of the row (null-id rows too: their y is the zero vector, not "no row")
+    if (SUMSQ || SIGMA) {   // sum of squares (SIGMA: of mu^2 exp(-2 s)) over ALL outputs of the row (null-id rows too: their y is the zero vector, not "no row")
       if (lh == 0 && myr < Rv) {
         if (o_ce) o_ce[mysrc[cbk]] = s_own + s_other;
         if (o_tgt) o_tgt[mysrc[cbk]] = myy[cbk] > 0 ? st[cbk].t : 0.f;
@@ -1353,12 +1363,14 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
                        out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
                        out->target, out->rank, out->ce);
-    if (PMODE == 12 || PMODE == 14 || PMODE == 15) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+    if constexpr (PMODE == 12 || PMODE == 14 || PMODE == 15) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                      out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk, (int32_t*)nullptr, (float*)nullptr, 0);
-  if ((PMODE == 12 || PMODE == 14 || PMODE == 15) && out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+  if constexpr (PMODE == 12 || PMODE == 14 || PMODE == 15) {
+    if (out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+  }
   return hipGetLastError();
 }
 
@@ -1600,6 +1612,21 @@ hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const i
     case 128: return launch_score_v<128, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
     case 256: return launch_score_v<256, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
     case 512: return launch_score_512<false, 3, 0>(m, hidden, y, R, &out, nullptr, nullptr, nullptr, 0, -1, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// Mixture head with a learned scale (gmm.hip): the table interleaves, per 64-row stage, the 32 mean rows and the 32 log-scale rows of the same
+// outputs (pad rows / biases ZERO) -> o_q[r] = sum_d mu[r][d]^2 exp(-2 s[r][d]).  y is read (the kernel's prologue gathers a row) but no target
+// column means anything in this layout: the caller gathers mu[y] and s[y] itself.
+hipError_t launch_score_sigma(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, float* o_q, hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  hiertcn_score_out_t out;
+  out.rank = nullptr; out.ce = o_q; out.target = nullptr; out.topk_idx = nullptr; out.topk_val = nullptr; out.topk = 0;
+  switch (m.Clast) {
+    case 64: return launch_score_pipe<64, 22, 1, 3, false>(m, hidden, y, R, &out, st);
+    case 128: return launch_score_pipe<128, 22, 1, 3, false>(m, hidden, y, R, &out, st);
+    case 256: return launch_score_pipe<256, 22, 1, 3, true>(m, hidden, y, R, &out, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -43,7 +43,7 @@ def init_params(args, seed: int = 2, scope: str = "rnn_gmm") -> Dict[str, np.nda
         p[f"{pre}/gates/bias"] = np.ones(2 * H, np.float32)
         p[f"{pre}/candidate/kernel"] = glorot((inp + H, H), inp + H, H)
         p[f"{pre}/candidate/bias"] = np.zeros(H, np.float32)
-    n_out = int(args.num_mixture) * (1 + int(args.output_dim))
+    n_out = int(args.num_mixture) * (1 + (1 if getattr(args, "sigma", 0.1) else 2) * int(args.output_dim))   # learned scale: M (1 + 2 D)
     p[f"{scope}/fully_connected/weights"] = glorot((H, n_out), H, n_out)
     p[f"{scope}/fully_connected/biases"] = np.zeros(n_out, np.float32)
     return p
@@ -55,8 +55,6 @@ class GruGmmModel(TcnGmmModel):
     def __init__(self, args, params: Optional[dict] = None, name: str = "rnn_gmm", seed: int = 2):
         from .engine import check_supported
         check_supported(args, loss_ok=("gmm_prob", "gmm_prob_max", "cross_entropy"))
-        if not getattr(args, "sigma", 0.1):
-            raise NotImplementedError("a learned sigma (args.sigma None: n_out = M*(1+2D), model_gru_gmm.py:50-51) is not built")
         if not torch.cuda.is_available():
             raise HierTCNError("no GPU visible: the compute path is HIP-only (no CPU fallback)")
         self.args, self.name = args, name
@@ -65,7 +63,8 @@ class GruGmmModel(TcnGmmModel):
         self.M, self.D, self.N = int(args.num_mixture), int(args.output_dim), int(args.item_num)
         self.C = int(args.hidden_dim)
         self.nl = int(args.num_layer)
-        cfg = _lib.GmmConfig(item_num=self.N, output_dim=self.D, num_mixture=self.M, kernel_size=0, n_blocks=0, sigma=float(args.sigma),
+        cfg = _lib.GmmConfig(item_num=self.N, output_dim=self.D, num_mixture=self.M, kernel_size=0, n_blocks=0,
+                             sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0,   # 0: learned scale (args.sigma None)
                              trunk=1, hidden_dim=self.C, num_layer=self.nl)
         self._h = C.c_void_p()
         _ck(self.lib.hiertcn_gmm_create(C.byref(self._h), C.byref(cfg)), self.lib)

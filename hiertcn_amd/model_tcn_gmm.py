@@ -48,7 +48,7 @@ def init_params(args, seed: int = 2, scope: str = "tcn_gmm") -> Dict[str, np.nda
             p[f"{pre}/dense/kernel"] = glorot((cin, cout), cin, cout)
             p[f"{pre}/dense/bias"] = np.zeros(cout, np.float32)
         cin = cout
-    n_out = int(args.num_mixture) * (1 + int(args.output_dim))
+    n_out = int(args.num_mixture) * (1 + (1 if getattr(args, "sigma", 0.1) else 2) * int(args.output_dim))   # learned scale: M (1 + 2 D)
     p[f"{scope}/fully_connected/weights"] = glorot((cin, n_out), cin, n_out)
     p[f"{scope}/fully_connected/biases"] = np.zeros(n_out, np.float32)
     return p
@@ -60,8 +60,6 @@ class TcnGmmModel:
     def __init__(self, args, params: Optional[dict] = None, name: str = "tcn_gmm", seed: int = 2):
         from .engine import check_supported
         check_supported(args, loss_ok=("gmm_prob", "gmm_prob_max", "cross_entropy"))
-        if not getattr(args, "sigma", 0.1):
-            raise NotImplementedError("a learned sigma (args.sigma None: n_out = M*(1+2D), model_tcn_gmm.py:39-40) is not built")
         if not torch.cuda.is_available():
             raise HierTCNError("no GPU visible: the compute path is HIP-only (no CPU fallback)")
         self.args, self.name = args, name
@@ -71,7 +69,7 @@ class TcnGmmModel:
         ch = [int(c) for c in args.tcn_channel]
         self.C = ch[-1]
         cfg = _lib.GmmConfig(item_num=self.N, output_dim=self.D, num_mixture=self.M, kernel_size=int(args.kernel_size), n_blocks=len(ch),
-                             sigma=float(args.sigma))
+                             sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0)   # 0: learned scale (args.sigma None)
         for i, c in enumerate(ch):
             cfg.channels[i] = c
         self._h = C.c_void_p()
@@ -122,7 +120,7 @@ class TcnGmmModel:
         return hidden
 
     def loss_rows(self, hidden: torch.Tensor, y_ids: torch.Tensor, mode: str = "gmm_prob", parts: bool = False):
-        """-> loss [R] (0 where y == 0) [, |mu_m|^2 [M, R], mu_m[y] [M, R], prior logits [R, M]]."""
+        """-> loss [R] (0 where y == 0) [, |mu_m|^2 [M, R] (learned scale: sum_d mu_d^2 exp(-2 s_d)), mu_m[y] [M, R], prior logits [R, M]]."""
         R = hidden.shape[0]
         y = y_ids.reshape(-1).contiguous()
         loss = torch.empty(R, dtype=torch.float32, device=self.device)
@@ -152,7 +150,7 @@ class TcnGmmModel:
         return dict(sums=out2, loss_rows=rows.view(B, T))
 
     def head_means(self, hidden: torch.Tensor, m: int) -> torch.Tensor:
-        """parity/debug: mu_m [R, D] fp32 materialised."""
+        """parity/debug: mu_m [R, D] fp32 materialised (learned scale: m in [M, 2M) materialises the log-scales s_{m-M})."""
         R = hidden.shape[0]
         out = torch.empty((R, self.D), dtype=torch.float32, device=self.device)
         _ck(self.lib.hiertcn_gmm_head_means(self._h, C.c_void_p(hidden.data_ptr()), R, int(m), C.c_void_p(out.data_ptr()),
@@ -168,7 +166,8 @@ class GmmHead:
 
     @property
     def shape(self):
-        return (self.B, self.T, self.model.M * (1 + self.model.D))
+        learned = not getattr(self.model.args, "sigma", 0.1)   # model_tcn_gmm.py:39-42
+        return (self.B, self.T, self.model.M * (1 + (2 if learned else 1) * self.model.D))
 
 
 def model_tcn_gmm(args, x, x_gap=None, x_impression=None, name="tcn_gmm", reuse=True, training=False, mask=None):

@@ -271,7 +271,8 @@ int hiertcn_export_weights(hiertcn_handle_t h, const hiertcn_weights_t* dst, int
 /* ---- mixture-output models (BASELINE.json configs[4]: model_tcn_gmm.py:12-44; the head of model_gru_gmm.py:49-54; the likelihood
  * losses of loss.py:247-257).  A handle of its own: the trunk differs from model_tcn's (no 'emb' projection -- on XING the
  * TemporalConvNet reads one_hot(id)*sign(id) directly, so block 0 has Cin = item_num and a Dense residual) and the head has
- * n_out = num_mixture * (1 + output_dim) outputs (args.sigma set; a learned sigma is not built).
+ * n_out = num_mixture * (1 + output_dim) outputs with args.sigma set, num_mixture * (1 + 2 output_dim) with a learned scale (cfg.sigma = 0:
+ * model_tcn_gmm.py:39-40; head columns: M priors, M*D means mixture-major, M*D LOG-scales mixture-major, sigma = exp(s); last width <= 256).
  * The DECODE of the head output is not in the reference (calc_loss_gmm has no caller): this library uses pi = softmax of the first
  * M outputs, mu = the next M*D outputs mixture-major, sigma = args.sigma -- "parity unpinned" for the decode; the head GEMM and the
  * formulas are checked against oracle/gmm_oracle.py.
@@ -298,7 +299,7 @@ typedef struct {
   int32_t kernel_size;
   int32_t n_blocks;
   int32_t channels[HIERTCN_MAX_BLOCKS];
-  float sigma;                           /* args.sigma (> 0)                                        */
+  float sigma;                           /* args.sigma (> 0); 0 = learned scale (args.sigma None)   */
   int32_t trunk;                         /* 0: TemporalConvNet (model_tcn_gmm.py:27-36); 1: GRU stack run by dynamic_rnn on the one-hot
                                           *    input (model_gru_gmm.py:33-48) -- n_blocks / channels / kernel_size are then ignored      */
   int32_t hidden_dim;                    /* trunk 1: args.hidden_dim in {64, 128, 256, 512}         */

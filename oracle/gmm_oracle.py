@@ -35,10 +35,14 @@ import numpy as np
 from . import hiertcn_oracle as O
 
 
+def learned_sigma(args) -> bool:
+    """model_tcn_gmm.py:39 / model_gru_gmm.py:50 `if not args.sigma`: None (or 0) -> the head also emits a scale per mean."""
+    return not getattr(args, "sigma", 0.1)
+
+
 def n_out(args) -> int:
-    if not getattr(args, "sigma", 0.1):
-        raise NotImplementedError("learned sigma (args.sigma None: n_out = M*(1+2D), model_tcn_gmm.py:39-40) is not built")
-    return int(args.num_mixture) * (1 + int(args.output_dim))
+    """model_tcn_gmm.py:39-42: M (1 + D + D) with a learned scale, M (1 + D) with args.sigma fixed."""
+    return int(args.num_mixture) * (1 + (2 if learned_sigma(args) else 1) * int(args.output_dim))
 
 
 def init_params(args, seed=2, scope="tcn_gmm", input_dim=None):
@@ -111,18 +115,30 @@ def decode(pred, M: int, D: int):
     return log_pi, mu
 
 
-def mvn_diag_log_prob(y, mu, sigma: float):
-    """tf.contrib.distributions.MultivariateNormalDiag(loc=mu, scale_diag=sigma).log_prob(y) [TF-sem]; y [..., D], mu [..., M, D]."""
+def decode_scale(pred, M: int, D: int):
+    """Learned scale (args.sigma None): the THIRD block of the head output (docstring of model_tcn_gmm.py:16-18: prior, mean, variance parts),
+    mixture-major like the means, as a LOG scale: sigma = exp(s) -> s [..., M, D].  The build's own choice like the rest of the decode
+    (the reference never splits the head output): an unconstrained output needs some positive map, exp is the usual one."""
+    return pred[..., M + M * D:M + 2 * M * D].reshape(pred.shape[:-1] + (M, D))
+
+
+def mvn_diag_log_prob(y, mu, sigma):
+    """tf.contrib.distributions.MultivariateNormalDiag(loc=mu, scale_diag=sigma).log_prob(y) [TF-sem]; y [..., D], mu [..., M, D];
+    sigma: a float (args.sigma) or an array [..., M, D] (loss.py:250-251: scale_diag=sigma[:, :, i, :])."""
     D = y.shape[-1]
-    d2 = ((y[..., None, :] - mu) ** 2).sum(-1)
-    return -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+    if np.ndim(sigma) == 0:
+        d2 = ((y[..., None, :] - mu) ** 2).sum(-1)
+        return -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+    return -0.5 * (((y[..., None, :] - mu) / sigma) ** 2).sum(-1) - np.log(sigma).sum(-1) - 0.5 * D * np.log(2 * np.pi)
 
 
 def calc_loss_gmm(pred, y, args):
     """loss.py:247-257 for args.loss in {'gmm_prob', 'gmm_prob_max'}.  pred [B, T, n_out] (raw head output), y [B, T, D]
     (one_hot(y_id) * sign(y_id) on XING) -> loss [B, T] (NOT yet masked: model.py:111 multiplies by mask_y afterwards)."""
-    M, D, sigma = int(args.num_mixture), int(args.output_dim), float(args.sigma)
-    log_pi, mu = decode(np.asarray(pred, np.float64), M, D)
+    M, D = int(args.num_mixture), int(args.output_dim)
+    pred = np.asarray(pred, np.float64)
+    log_pi, mu = decode(pred, M, D)
+    sigma = np.exp(decode_scale(pred, M, D)) if learned_sigma(args) else float(args.sigma)
     lp_m = mvn_diag_log_prob(np.asarray(y, np.float64), mu, sigma)            # [B, T, M]
     if args.loss == "gmm_prob":
         z = log_pi + lp_m
@@ -137,15 +153,23 @@ def calc_loss_gmm(pred, y, args):
 def calc_loss_gmm_ids(pred, y_ids, args):
     """The same through the one-hot shortcut: sum_d (y_d - mu_d)^2 = |mu|^2 - 2 mu[target] + 1 for a target id > 0 and |mu|^2 for the
     null id (an all-zero y row).  This is the form the HIP epilogue computes; tests assert it equals calc_loss_gmm on real one-hots."""
-    M, D, sigma = int(args.num_mixture), int(args.output_dim), float(args.sigma)
+    M, D = int(args.num_mixture), int(args.output_dim)
     pred = np.asarray(pred, np.float64)
     y_ids = np.asarray(y_ids).astype(np.int64)
     log_pi, mu = decode(pred, M, D)
-    s2 = (mu ** 2).sum(-1)                                                               # [B, T, M]
     t = np.take_along_axis(mu, y_ids[..., None, None], -1)[..., 0]                        # mu_m[target]
     live = (y_ids > 0)[..., None]
-    d2 = s2 + np.where(live, 1.0 - 2.0 * t, 0.0)
-    lp_m = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+    if learned_sigma(args):
+        # sum_d ((y_d - mu_d) / sigma_d)^2 = sum_d mu_d^2 e^{-2 s_d} + (1 - 2 mu[target]) e^{-2 s[target]};  sum_d log sigma_d = sum_d s_d
+        sc = decode_scale(pred, M, D)
+        q = (mu ** 2 * np.exp(-2.0 * sc)).sum(-1)
+        s_t = np.take_along_axis(sc, y_ids[..., None, None], -1)[..., 0]
+        lp_m = -0.5 * (q + np.where(live, (1.0 - 2.0 * t) * np.exp(-2.0 * s_t), 0.0)) - sc.sum(-1) - 0.5 * D * np.log(2 * np.pi)
+    else:
+        sigma = float(args.sigma)
+        s2 = (mu ** 2).sum(-1)                                                           # [B, T, M]
+        d2 = s2 + np.where(live, 1.0 - 2.0 * t, 0.0)
+        lp_m = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
     if args.loss == "gmm_prob":
         z = log_pi + lp_m
         mx = z.max(-1, keepdims=True)

@@ -101,3 +101,27 @@ def test_gru_gmm_oracle_shapes_and_dynamic_rnn_prefix():
     z = {k: (np.zeros_like(v) if k.endswith("/kernel") else v) for k, v in p.items()}
     pred, hz = G.model_gru_gmm(a, ids, z, return_hidden=True)
     assert not hz.any() and np.allclose(pred, z["rnn_gmm/fully_connected/biases"])
+
+
+def test_learned_scale_head_width_density_and_id_form():
+    """args.sigma None (model_tcn_gmm.py:39-40): n_out = M (1 + 2 D); the per-dimension density against scipy; the id form the HIP
+    epilogue computes (sum_d mu_d^2 e^{-2 s_d} + (1 - 2 mu[y]) e^{-2 s[y]}, sum_d s_d) against the one-hot form; a hand-derived value."""
+    a = _args()
+    a.sigma = None
+    assert G.learned_sigma(a) and G.n_out(a) == 3 * (1 + 2 * 37)
+    assert G.init_params(a, seed=1)["tcn_gmm/fully_connected/weights"].shape == (16, 3 * 75)
+    rng = np.random.default_rng(0)
+    y, mu, sc = rng.standard_normal(6), rng.standard_normal((2, 6)), 0.4 * rng.standard_normal((2, 6))
+    got = G.mvn_diag_log_prob(y, mu, np.exp(sc))
+    want = [multivariate_normal(mean=m, cov=np.diag(np.exp(2 * s))).logpdf(y) for m, s in zip(mu, sc)]
+    np.testing.assert_allclose(got, want, rtol=1e-12)
+    for loss in ("gmm_prob", "gmm_prob_max"):
+        a.loss = loss
+        pred = 0.3 * rng.standard_normal((4, 7, G.n_out(a)))
+        ids = rng.integers(0, 37, (4, 7))
+        onehot = np.eye(37)[ids] * (ids > 0)[..., None]
+        np.testing.assert_allclose(G.calc_loss_gmm_ids(pred, ids, a), G.calc_loss_gmm(pred, onehot, a), rtol=1e-10, atol=1e-12)
+    # every output zero: pi uniform, mu = 0, sigma = e^0 = 1 -> log_prob = -1/2 - D/2 log 2 pi
+    b = _args(N=10, M=2)
+    b.sigma = None
+    assert abs(G.calc_loss_gmm_ids(np.zeros((1, 1, G.n_out(b))), np.array([[4]]), b)[0, 0] - (0.5 + 5 * np.log(2 * np.pi)) / 10) < 1e-12

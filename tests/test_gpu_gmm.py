@@ -237,3 +237,63 @@ def test_gram_form_equals_the_table_pass(C, monkeypatch):
     for i in (0, 4):
         assert np.abs(g[i] - t[i]).max() < 1e-5 * max(1.0, np.abs(t[i]).max()), (i, np.abs(g[i] - t[i]).max())
     assert not g[0][::7].any() and not g[2][:, ::7].any()
+
+
+@pytest.mark.parametrize("N,M,channels,K,B,T", [(1500, 4, (64, 64), 3, 5, 21), (20_778, 5, (256, 256), 5, 3, 30), (3001, 3, (64, 128), 3, 4, 18)])
+def test_learned_scale_head_vs_oracle(N, M, channels, K, B, T):
+    """args.sigma None (model_tcn_gmm.py:39-40: n_out = M (1 + 2 D), sigma = exp of the third block -- the build's decode): the paired pass over
+    the interleaved (means | log-scales) table (score.hip PMODE 22: Q_m = sum_d mu_d^2 e^{-2 s_d}), the linear sum_d s_d, the gathered mu[y] /
+    s[y] and both losses against oracle/gmm_oracle.py on the device's hidden rows; every mean and every log-scale through head_means."""
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    a = _args(N, M, channels, K)
+    a.sigma = None
+    p = G.init_params(a, seed=5)
+    rng = np.random.default_rng(N)
+    hw = p["tcn_gmm/fully_connected/weights"]
+    hw[:, M + M * N:] *= 6.0                                          # log-scales of order 1: sigma between ~0.3 and ~3
+    p["tcn_gmm/fully_connected/biases"] = (0.05 * rng.standard_normal(p["tcn_gmm/fully_connected/biases"].shape)).astype(np.float32)
+    model = TcnGmmModel(a, p)
+    ids = rng.integers(1, N, (B, T + 1))
+    lens = rng.integers(2, T + 1, B)
+    ids = ids * (np.arange(T + 1)[None, :] <= lens[:, None])
+    x, y = ids[:, :-1].astype(np.int32), ids[:, 1:].astype(np.int32)
+    x[:, 0] = 0
+    dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).to("cuda:0")  # noqa: E731
+    pr = {k: (O.round_bf16(v) if (k.endswith("kernel") or k.endswith("weights")) else v) for k, v in p.items()}
+    pr["tcn_gmm/fully_connected/weights"][:, :M] = p["tcn_gmm/fully_connected/weights"][:, :M]
+    hid = model.forward(dev(x))
+    h_dev = hid.float().cpu().numpy().astype(np.float64).reshape(B, T, -1)
+    pred = G.gmm_head(h_dev, pr, "tcn_gmm")                           # [B, T, M (1 + 2 D)]
+    assert pred.shape[-1] == M * (1 + 2 * N) and model_shape(model, B, T) == pred.shape
+    _, mu = G.decode(pred, M, N)
+    sc = G.decode_scale(pred, M, N)
+    loss, q, tg, pl = model.loss_rows(hid, dev(y), "gmm_prob", parts=True)
+    q, tg = q.cpu().numpy().reshape(M, B, T), tg.cpu().numpy().reshape(M, B, T)
+    live = y > 0
+    for m in range(M):
+        assert np.abs(model.head_means(hid, m).cpu().numpy().reshape(B, T, N) - mu[:, :, m]).max() < 1e-4
+        assert np.abs(model.head_means(hid, M + m).cpu().numpy().reshape(B, T, N) - sc[:, :, m]).max() < 1e-4
+        np.testing.assert_allclose(q[m], (mu[:, :, m] ** 2 * np.exp(-2 * sc[:, :, m])).sum(-1), rtol=3e-4)      # Q_m (v_exp_f32 per output)
+        t_ref = np.take_along_axis(mu[:, :, m], y[..., None].astype(np.int64), -1)[..., 0]
+        assert np.abs(tg[m] - t_ref)[live].max() < 1e-4 and not tg[m][~live].any()
+    for mode in ("gmm_prob", "gmm_prob_max"):
+        a.loss = mode
+        got = model.loss_rows(hid, dev(y), mode).cpu().numpy().reshape(B, T)
+        want = G.calc_loss_gmm_ids(pred, y, a)
+        assert np.abs(got - want)[live].max() < 2e-4 * max(1.0, np.abs(want[live]).max()), (mode, np.abs(got - want)[live].max())
+        assert not got[~live].any()
+    model.close()
+
+
+def model_shape(model, B, T):
+    from hiertcn_amd.model_tcn_gmm import GmmHead
+    return GmmHead(model, None, B, T).shape
+
+
+def test_learned_scale_is_refused_at_width_512():
+    from hiertcn_amd._lib import HierTCNError
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    a = _args(700, 2, (512,), 2)
+    a.sigma = None
+    with pytest.raises(HierTCNError, match="learned scale"):
+        TcnGmmModel(a, None)
