@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 7
+ABI_VERSION = 8
 N_STRUCTS = 5
 PRECISION_STORAGE16, PRECISION_FP32 = 0, 1
 
@@ -41,7 +41,7 @@ class Weights(C.Structure):
 class GmmConfig(C.Structure):
     _fields_ = [("item_num", C.c_int32), ("output_dim", C.c_int32), ("num_mixture", C.c_int32), ("kernel_size", C.c_int32),
                 ("n_blocks", C.c_int32), ("channels", C.c_int32 * MAX_BLOCKS), ("sigma", C.c_float),
-                ("trunk", C.c_int32), ("hidden_dim", C.c_int32), ("num_layer", C.c_int32)]
+                ("trunk", C.c_int32), ("hidden_dim", C.c_int32), ("num_layer", C.c_int32), ("input_dim", C.c_int32)]
 
 
 class GmmWeights(C.Structure):
@@ -70,6 +70,7 @@ SYMBOLS = {
     "hiertcn_get_precision": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),
     "hiertcn_struct_sizes": (C.c_int, [C.POINTER(C.c_size_t)]),
     "hiertcn_session_pool": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_embed_concat": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hiertcn_gru_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int32, C.c_int32]),
     "hiertcn_gru_scan": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32,
                                     C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
@@ -108,6 +109,7 @@ SYMBOLS = {
     "hiertcn_gmm_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64]),
     "hiertcn_gmm_forward_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "hiertcn_gmm_forward": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "hiertcn_gmm_forward_rows": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hiertcn_gmm_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hiertcn_gmm_head_means": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),

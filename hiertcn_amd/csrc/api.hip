@@ -376,6 +376,16 @@ int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_ses
   return HIERTCN_OK;
 }
 
+int hiertcn_embed_concat(hiertcn_handle_t h, const int32_t* x_ids, const float* state, int64_t n_sessions, int32_t L, uint16_t* rows,
+                         void* stream) {
+  CHECK_READY(h);
+  if (!h->m.hier) return fail(HIERTCN_ERR_STATE, "embed_concat is a model_hier operation");
+  if (IS_EXACT(h)) return fail(HIERTCN_ERR_STATE, "embed_concat writes storage-type rows: not available in the exact fp32 mode");
+  if (!x_ids || !state || !rows || n_sessions < 0 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
+  HIP_TRY(launch_embed_concat(h->m, x_ids, state, n_sessions, L, rows, reinterpret_cast<hipStream_t>(stream)));
+  return HIERTCN_OK;
+}
+
 size_t hiertcn_gru_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S) {
   if (!h || !h->m.hier || B < 0 || S < 0) return 0;
   return gru_workspace_bytes(h->m, B, S);

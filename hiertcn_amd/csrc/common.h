@@ -216,6 +216,7 @@ hipError_t launch_tcn_layers(const ModelDev& m, const int32_t* x, const float* s
 hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                         float* logits, hipStream_t st, const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr,
                         float* split_scratch = nullptr);
+hipError_t launch_embed_concat(const ModelDev& m, const int32_t* ids, const float* state, int64_t n_sess, int L, uint16_t* out, hipStream_t st);
 hipError_t launch_score_sigma(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, float* o_q, hipStream_t st);
 hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, float* o_sq, float* o_tgt, hipStream_t st);
 // Gram form of the mixture losses (gmm_gram.hip): |mu_m|^2 as a C x C quadratic form of the hidden row instead of a pass over the [D, C] table

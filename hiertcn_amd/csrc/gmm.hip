@@ -274,9 +274,12 @@ extern "C" {
 
 int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cfg) {
   if (!out || !cfg) return gfail(HIERTCN_ERR_INVALID, "null argument");
-  if (cfg->item_num < 2 || cfg->output_dim < 2) return gfail(HIERTCN_ERR_INVALID, "item_num / output_dim must be >= 2");
+  if ((cfg->trunk != 2 && cfg->item_num < 2) || cfg->output_dim < 2) return gfail(HIERTCN_ERR_INVALID, "item_num / output_dim must be >= 2");
   const bool gru = cfg->trunk == 1;
-  if (cfg->trunk != 0 && cfg->trunk != 1) return gfail(HIERTCN_ERR_INVALID, "trunk %d: 0 (TemporalConvNet) or 1 (GRU stack)", cfg->trunk);
+  const bool rows = cfg->trunk == 2;   // TemporalConvNet on dense rows (the low level of model_hier): block 0 is an ordinary block
+  if (cfg->trunk < 0 || cfg->trunk > 2) return gfail(HIERTCN_ERR_INVALID, "trunk %d: 0 (TemporalConvNet on ids), 1 (GRU stack), 2 (TemporalConvNet on rows)", cfg->trunk);
+  if (rows && (cfg->input_dim < 32 || (cfg->input_dim & 31) || cfg->input_dim > 4096))
+    return gfail(HIERTCN_ERR_INVALID, "input_dim %d: the width of the input rows is a multiple of 32 up to 4096", cfg->input_dim);
   if (gru) {
     const int H = cfg->hidden_dim;
     if (!(H == 64 || H == 128 || H == 256 || H == 512)) return gfail(HIERTCN_ERR_INVALID, "hidden_dim %d: the head kernel is built for 64, 128, 256, 512", H);
@@ -297,7 +300,7 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
   c->cfg = *cfg;
   c->weights_set = false;
   if (hipGetDevice(&c->device) != hipSuccess) { delete c; return gfail(HIERTCN_ERR_HIP, "hipGetDevice failed (no GPU?)"); }
-  c->N = cfg->item_num; c->NP = (c->N + 63) & ~63;
+  c->N = rows ? 0 : cfg->item_num; c->NP = (c->N + 63) & ~63;
   c->D = cfg->output_dim; c->DP = (c->D + 63) & ~63;
   c->M = cfg->num_mixture; c->K = cfg->kernel_size; c->nb = gru ? 0 : cfg->n_blocks;
   c->C0 = gru ? 0 : cfg->channels[0]; c->Clast = cl;
@@ -320,12 +323,12 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
       GA(c->gwg[l], 2 * H * kin); GA(c->gbg[l], 2 * H);
       GA(c->gwc[l], H * kin);     GA(c->gbc[l], H);
     }
-  } else {
+  } else if (!rows) {
     GA(c->gather, (size_t)(c->K + 1) * c->N * c->C0);
     GA(c->b0, c->C0);
     GA(c->br0, c->C0);
   }
-  for (int i = 1, cin = c->C0; i < c->nb; cin = cfg->channels[i], i++) {
+  for (int i = rows ? 0 : 1, cin = rows ? cfg->input_dim : c->C0; i < c->nb; cin = cfg->channels[i], i++) {
     GA(c->convT[i], (size_t)c->K * cin * cfg->channels[i]);
     GA(c->conv_bias[i], cfg->channels[i]);
     if (cin != cfg->channels[i]) { GA(c->resT[i], (size_t)cin * cfg->channels[i]); GA(c->res_bias[i], cfg->channels[i]); }
@@ -407,6 +410,8 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
       G_HIP(hipMemcpyAsync(g->gbc[l], w->gru_cand_bias[l], H * sizeof(float), hipMemcpyDeviceToDevice, st));
     }
   } else {
+  const bool rows = g->trunk == 2;
+  if (!rows) {
   if (!w->conv_kernel[0] || !w->conv_bias[0] || !w->res_kernel[0] || !w->res_bias[0])
     return gfail(HIERTCN_ERR_INVALID, "block 0 (conv1 + Dense residual: Cin = item_num != Cout) is required");
   // block 0: the K taps [N][C0] and the residual kernel [N][C0] are already item-major in the reference layout: rows -> bf16
@@ -414,7 +419,8 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
   G_HIP(launch_rows_to_bf16(w->res_kernel[0], g->gather + (size_t)K * N * C0, N, C0, 0, st));
   G_HIP(launch_copy_pad_f32(w->conv_bias[0], g->b0, C0, C0, 0.f, st));
   G_HIP(launch_copy_pad_f32(w->res_bias[0], g->br0, C0, C0, 0.f, st));
-  for (int i = 1, cin = C0; i < g->nb; cin = g->cfg.channels[i], i++) {
+  }
+  for (int i = rows ? 0 : 1, cin = rows ? g->cfg.input_dim : C0; i < g->nb; cin = g->cfg.channels[i], i++) {
     const int cout = g->cfg.channels[i];
     if (!w->conv_kernel[i] || !w->conv_bias[i]) return gfail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
     if ((cin != cout) != (w->res_kernel[i] != nullptr)) return gfail(HIERTCN_ERR_INVALID, "block %d: a Dense residual exists exactly when Cin != Cout", i);
@@ -463,6 +469,9 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
   return HIERTCN_OK;
 }
 
+static int hiertcn_gmm_run_blocks(hiertcn_gmm_ctx* g, const uint16_t* in0, int first, int cin0, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
+                                  hipStream_t st);
+
 static int max_w(const hiertcn_gmm_ctx* g) {
   int w = g->trunk == 1 ? g->H : 0;
   for (int i = 0; i < g->nb; i++) w = g->cfg.channels[i] > w ? g->cfg.channels[i] : w;
@@ -490,6 +499,7 @@ size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, in
 int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                         size_t workspace_bytes, void* stream) {
   G_READY(g);
+  if (g->trunk == 2) return gfail(HIERTCN_ERR_STATE, "this handle reads dense rows (trunk 2): hiertcn_gmm_forward_rows");
   if (!x_ids || !hidden || B < 1 || T < 1 || T > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
   const int64_t R = B * T;
   if (!workspace || workspace_bytes < hiertcn_gmm_forward_workspace_bytes(g, B, T)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
@@ -508,17 +518,37 @@ int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B,
   const int64_t n0 = R * (g->C0 / 8);
   hipLaunchKernelGGL(k_gmm_block0, dim3((unsigned)((n0 + 255) / 256)), dim3(256), 0, st, g->gather, g->b0, g->br0, x_ids, R, T, g->N, g->C0, g->K, out0);
   G_HIP(hipGetLastError());
-  int cur = 0;
-  for (int i = 1, cin = g->C0; i < g->nb; cin = g->cfg.channels[i], i++) {
+  return hiertcn_gmm_run_blocks(g, buf[0], 1, g->C0, B, T, hidden, workspace, st);
+}
+
+// blocks first .. nb-1 (dilation 2^i) from `in0` (which may be workspace buffer 0) to `hidden`, ping-ponging through the two workspace buffers
+static int hiertcn_gmm_run_blocks(hiertcn_gmm_ctx* g, const uint16_t* in0, int first, int cin0, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
+                                  hipStream_t st) {
+  const int64_t R = B * T;
+  const size_t act = (((size_t)R * max_w(g) * 2) + 255) & ~(size_t)255;
+  uint16_t* buf[2] = {reinterpret_cast<uint16_t*>(workspace), reinterpret_cast<uint16_t*>(reinterpret_cast<unsigned char*>(workspace) + act)};
+  const uint16_t* cur_in = in0;
+  int nxt = (in0 == buf[0]) ? 1 : 0;
+  for (int i = first, cin = cin0; i < g->nb; cin = g->cfg.channels[i], i++) {
     LayerArgs a = {};
-    a.in = buf[cur];
-    a.out = (i == g->nb - 1) ? hidden : buf[cur ^ 1];
+    a.in = cur_in;
+    a.out = (i == g->nb - 1) ? hidden : buf[nxt];
     a.W = g->convT[i]; a.bias = g->conv_bias[i]; a.Wres = g->resT[i]; a.bres = g->res_bias[i];
     a.Cin = cin; a.Cout = g->cfg.channels[i]; a.taps = g->K; a.dil = 1 << i; a.L = T; a.n_seq = B; a.linear = 0;
     G_HIP(launch_tcn_layer(a, st));
-    cur ^= 1;
+    cur_in = a.out;
+    nxt ^= 1;
   }
   return HIERTCN_OK;
+}
+
+int hiertcn_gmm_forward_rows(hiertcn_gmm_handle_t g, const uint16_t* x_rows, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  G_READY(g);
+  if (g->trunk != 2) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_forward_rows is for trunk 2 (dense input rows); this handle's trunk is %d", g->trunk);
+  if (!x_rows || !hidden || B < 1 || T < 1 || T > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  if (!workspace || workspace_bytes < hiertcn_gmm_forward_workspace_bytes(g, B, T)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
+  return hiertcn_gmm_run_blocks(g, x_rows, 0, g->cfg.input_dim, B, T, hidden, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 
 static void table_model(const hiertcn_gmm_ctx* g, int m, ModelDev* md) {

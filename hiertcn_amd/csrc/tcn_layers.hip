@@ -375,6 +375,36 @@ hipError_t launch_embed_rows(const ModelDev& m, const int32_t* ids, int64_t R, u
   return hipGetLastError();
 }
 
+// rows [n_sess * L][E + HT] = E[x_t] (zero row for a null / out-of-range id) | state of the session, rounded to the storage type
+// (model_hier.py:50,54-55: dense 'emb' of the one-hot row, the carried state tiled over the steps, concatenated)
+__global__ __launch_bounds__(256) void k_embed_concat(const uint16_t* __restrict__ emb, const int32_t* __restrict__ ids, const float* __restrict__ state,
+                                                      int64_t R, int L, int E, int HT, int N, uint16_t* __restrict__ out) {
+  const int W = E + HT, ch = W >> 3;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch) * 8;
+  uint4 v;
+  if (c < E) {
+    int id = ids[r];
+    id = (unsigned)id < (unsigned)N ? id : 0;
+    v = *reinterpret_cast<const uint4*>(emb + (int64_t)id * E + c);
+  } else {
+    const float* sp = state + (r / L) * HT + (c - E);
+    v = make_uint4(pack2bf(sp[0], sp[1]), pack2bf(sp[2], sp[3]), pack2bf(sp[4], sp[5]), pack2bf(sp[6], sp[7]));
+  }
+  *reinterpret_cast<uint4*>(out + r * W + c) = v;
+}
+
+hipError_t launch_embed_concat(const ModelDev& m, const int32_t* ids, const float* state, int64_t n_sess, int L, uint16_t* out, hipStream_t st) {
+  if ((m.E & 7) || (m.HT & 7)) return hipErrorInvalidValue;
+  const int64_t R = n_sess * L;
+  const int64_t n = R * ((m.E + m.HT) / 8);
+  if (n == 0) return hipSuccess;
+  hipLaunchKernelGGL(k_embed_concat, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.emb, ids, state, R, L, m.E, m.HT, m.N, out);
+  return hipGetLastError();
+}
+
 static int max_width(const ModelDev& m) {
   int w = m.E;
   for (int i = 0; i < m.n_blocks; i++) w = m.C[i] > w ? m.C[i] : w;

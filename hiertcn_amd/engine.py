@@ -223,6 +223,16 @@ class Engine:
         self._ck(self.lib.hiertcn_session_pool(self._h, _ptr(y_ids), n, L, _ptr(out), self._stream()))
         return out
 
+    def embed_concat(self, x_ids: torch.Tensor, state: torch.Tensor) -> torch.Tensor:
+        """x_ids [n_sessions, L] int32, state [n_sessions, H*nl] fp32 -> rows [n_sessions*L, E + H*nl] (storage type): E[x_t] | state
+        (model_hier.py:50,54-55 as rows: the input of a low level without an 'emb' projection of its own)."""
+        _req(x_ids, torch.int32, "x_ids")
+        n, L = x_ids.shape
+        _req(state, torch.float32, "state", (n, self.HT))
+        rows = torch.empty((n * L, self.E + self.HT), dtype=self.act_dtype, device=self.device)
+        self._ck(self.lib.hiertcn_embed_concat(self._h, _ptr(x_ids), _ptr(state), n, L, _ptr(rows), self._stream()))
+        return rows
+
     def gru_scan(self, pooled: torch.Tensor, mask: torch.Tensor, state_in: torch.Tensor, want_state_before=False):
         """pooled [B,S,E], mask [B,S], state_in [B,H*nl] -> (sproj [B,S,E], state_out, state_before|None)."""
         B, S, _ = pooled.shape

@@ -1,0 +1,175 @@
+"""model_hier with the mixture model as its LOW level (model_hier.py:64-65: model_low_type 'tcn_gmm'), backed by the HIP kernels.
+
+The reference's slot loop (model_hier.py:39-93) with pred = model_tcn_gmm(args, x_slice, ...): x_slice = [dense 'emb' of the one-hot step,
+the carried state tiled over the steps] (model_hier.py:50,54-55) goes STRAIGHT into the TemporalConvNet -- model_tcn_gmm has no 'emb'
+projection of its own (model_tcn_gmm.py:27-36) -- so block 0 is an ordinary TemporalBlock with Cin = emb + hidden_dim * num_layer and a Dense
+residual, followed by the mixture head (model_tcn_gmm.py:39-44).  The high level (session mean-pool + 'emb' bias, MultiRNNCell, user-boundary
+mask: model_hier.py:83-93) is model_hier's own.
+
+Two native handles: the main one (hiertcn_session_pool, hiertcn_gru_scan with state_before, hiertcn_embed_concat) for the item table and the
+across-session GRU -- created with a minimal low level of its own that is never run -- and a hiertcn_gmm handle with trunk 2 (dense input rows)
+for the TemporalConvNet and the head.  Variables (TF names under scope 'hier'): hier/emb/{kernel,bias}, hier/multi_rnn_cell/cell_l/gru_cell/...,
+hier/tcn_gmm/temporal_conv_net/tblock_i/{conv1,dense}/{kernel,bias}, hier/tcn_gmm/fully_connected/{weights,biases}.
+What the reference does with `pred` afterwards cannot be run (it feeds the [B, T, M (1 + D)] head output to the cross-entropy against
+[B, T, item_num] targets, model.py:105-132): `pred` is a GmmHead, scored by calc_loss_gmm like model_tcn_gmm's.  model_low_type 'gru_gmm'
+(a GRU stack on the x_slice rows) is not built.
+"""
+from __future__ import annotations
+
+import copy
+import ctypes as C
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import HierTCNError
+from .model_tcn_gmm import GmmHead, TcnGmmModel, _ck
+
+_SCOPES: Dict[str, "HierGmmModel"] = {}
+
+
+def init_params(args, seed: int = 2, scope: str = "hier") -> Dict[str, np.ndarray]:
+    """glorot-uniform kernels, zero biases, GRU gate bias 1 [TF-sem] in the shapes model_hier + model_tcn_gmm create."""
+    from .params import init_params as hier_init
+    rng = np.random.default_rng(seed)
+
+    def glorot(shape, fi, fo):
+        lim = np.sqrt(6.0 / (fi + fo))
+        return rng.uniform(-lim, lim, size=shape).astype(np.float32)
+
+    base = hier_init(_scan_args(args), seed=seed)
+    p = {k: v for k, v in base.items() if k.startswith(f"{scope}/emb/") or k.startswith(f"{scope}/multi_rnn_cell/")}
+    E, HT, K = int(args.emb_dim), int(args.hidden_dim) * int(args.num_layer), int(args.kernel_size)
+    cin = E + HT
+    for i, cout in enumerate(int(c) for c in args.tcn_channel):
+        pre = f"{scope}/tcn_gmm/temporal_conv_net/tblock_{i}"
+        p[f"{pre}/conv1/kernel"] = glorot((K, cin, cout), K * cin, K * cout)
+        p[f"{pre}/conv1/bias"] = np.zeros(cout, np.float32)
+        if cin != cout:
+            p[f"{pre}/dense/kernel"] = glorot((cin, cout), cin, cout)
+            p[f"{pre}/dense/bias"] = np.zeros(cout, np.float32)
+        cin = cout
+    n_out = int(args.num_mixture) * (1 + (1 if getattr(args, "sigma", 0.1) else 2) * int(args.output_dim))
+    p[f"{scope}/tcn_gmm/fully_connected/weights"] = glorot((cin, n_out), cin, n_out)
+    p[f"{scope}/tcn_gmm/fully_connected/biases"] = np.zeros(n_out, np.float32)
+    return p
+
+
+def _scan_args(args):
+    """args of the main handle: the same item table / GRU, with the smallest low level the library accepts (it is never run here)."""
+    a = copy.copy(args)
+    a.model_low_type, a.tcn_channel, a.kernel_size, a.loss = "tcn", [64], 1, "cross_entropy"   # (64: the narrowest last width the library builds)
+    return a
+
+
+class HierGmmModel(TcnGmmModel):
+    """Main handle (table, session pool, across-session GRU) + gmm handle with trunk 2 (TemporalConvNet on [e, state] rows + mixture head)."""
+
+    def __init__(self, args, params: Optional[dict] = None, name: str = "hier", seed: int = 2):
+        from .engine import Engine, check_supported
+        from .params import init_params as hier_init
+        check_supported(_scan_args(args))
+        if getattr(args, "loss", "gmm_prob") not in ("gmm_prob", "gmm_prob_max", "cross_entropy"):
+            raise NotImplementedError(f"args.loss={args.loss!r}: the mixture low level evaluates 'gmm_prob' or 'gmm_prob_max' (loss.py:247-257)")
+        if not torch.cuda.is_available():
+            raise HierTCNError("no GPU visible: the compute path is HIP-only (no CPU fallback)")
+        self.args, self.name = args, name
+        self.lib = _lib.load()
+        self.device = torch.device("cuda", torch.cuda.current_device())
+        self.M, self.D, self.N = int(args.num_mixture), int(args.output_dim), int(args.item_num)
+        ch = [int(c) for c in args.tcn_channel]
+        self.C = ch[-1]
+        self.E, self.HT = int(args.emb_dim), int(args.hidden_dim) * int(args.num_layer)
+        self.params = params if params is not None else init_params(args, seed, name)
+        # main handle: our table / emb bias / GRU cells; its own (unused) low level and scoring layer keep their initial values
+        sa = _scan_args(args)
+        ep = hier_init(sa, seed=seed)
+        for k, v in self.params.items():
+            if k.startswith(f"{name}/emb/") or k.startswith(f"{name}/multi_rnn_cell/"):
+                ep[k] = v
+        self.engine = Engine(sa, hier=True)
+        self.engine.set_weights(ep)
+        cfg = _lib.GmmConfig(item_num=0, output_dim=self.D, num_mixture=self.M, kernel_size=int(args.kernel_size), n_blocks=len(ch),
+                             sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=2, input_dim=self.E + self.HT)
+        for i, c in enumerate(ch):
+            cfg.channels[i] = c
+        self._h = C.c_void_p()
+        _ck(self.lib.hiertcn_gmm_create(C.byref(self._h), C.byref(cfg)), self.lib)
+        self._upload(self.params)
+        self._ws = None
+
+    def close(self):
+        super().close()
+        if getattr(self, "engine", None) is not None:
+            self.engine.close()
+            self.engine = None
+
+    def _upload(self, params):
+        keep = []
+
+        def dev(k):
+            t = torch.as_tensor(np.asarray(params[k], dtype=np.float32)).to(self.device).contiguous()
+            keep.append(t)
+            return t.data_ptr()
+
+        root = f"{self.name}/tcn_gmm"
+        w = _lib.GmmWeights()
+        for i in range(len(self.args.tcn_channel)):
+            pre = f"{root}/temporal_conv_net/tblock_{i}"
+            w.conv_kernel[i], w.conv_bias[i] = dev(f"{pre}/conv1/kernel"), dev(f"{pre}/conv1/bias")
+            if f"{pre}/dense/kernel" in params:
+                w.res_kernel[i], w.res_bias[i] = dev(f"{pre}/dense/kernel"), dev(f"{pre}/dense/bias")
+        w.head_weights, w.head_biases = dev(f"{root}/fully_connected/weights"), dev(f"{root}/fully_connected/biases")
+        _ck(self.lib.hiertcn_gmm_set_weights(self._h, C.byref(w), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        torch.cuda.current_stream().synchronize()
+
+    def forward_rows(self, rows: torch.Tensor, n_seq: int, L: int) -> torch.Tensor:
+        """rows [n_seq*L, E + HT] (storage type) -> last TCN activations [n_seq*L, C]."""
+        hidden = torch.empty((n_seq * L, self.C), dtype=torch.bfloat16, device=self.device)
+        need = int(self.lib.hiertcn_gmm_forward_workspace_bytes(self._h, n_seq, L))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        ws = self._ws
+        _ck(self.lib.hiertcn_gmm_forward_rows(self._h, C.c_void_p(rows.data_ptr()), n_seq, L, C.c_void_p(hidden.data_ptr()), C.c_void_p(ws.data_ptr()),
+                                              ws.numel(), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        return hidden
+
+    def forward(self, ids):   # (TcnGmmModel's id-input forward does not apply to this trunk)
+        raise HierTCNError("HierGmmModel reads [e, state] rows: use model_hier(args, x, y, mask, state) or forward_rows")
+
+    def forward_hier(self, xd: torch.Tensor, yd: torch.Tensor, md: torch.Tensor, st: torch.Tensor):
+        """packed ids xd, yd [B, S, L] int32, mask md [B, S] fp32, state st [B, HT] fp32 -> (hidden [B*S*L, C], state_out [B, HT])."""
+        eng = self.engine
+        B, S, L = xd.shape
+        pooled = eng.session_pool(yd.view(B * S, L)).view(B, S, -1)
+        _, state_out, before = eng.gru_scan(pooled, md, st, want_state_before=True)
+        rows = eng.embed_concat(xd.view(B * S, L), before.view(B * S, -1))
+        return self.forward_rows(rows, B * S, L), state_out
+
+
+def model_hier_tcn_gmm(args, x, y, mask, state, name="hier"):
+    """-> (pred: GmmHead over the [B, S * Lmax] packed steps, state [B, HT] on the GPU); called by model_hier for model_low_type 'tcn_gmm'."""
+    from .model import pack_slots
+    if name not in _SCOPES:
+        _SCOPES[name] = HierGmmModel(args, None, name)
+    model = _SCOPES[name]
+    xs, ys, ms, lens = pack_slots(x, y, mask)
+    B, S, Lmax = xs.shape
+    dev = model.device
+    xd, yd, md = (torch.from_numpy(v).to(dev) for v in (xs, ys, ms))
+    if isinstance(state, torch.Tensor):
+        st = state.to(device=dev, dtype=torch.float32).contiguous()
+    else:
+        st = torch.as_tensor(np.asarray(state, dtype=np.float32)).to(dev).contiguous()
+    hidden, state_out = model.forward_hier(xd, yd, md, st)
+    head = GmmHead(model, hidden, B, S * Lmax)
+    head.lens = lens
+    return head, state_out
+
+
+def reset_scopes():
+    for m in _SCOPES.values():
+        m.close()
+    _SCOPES.clear()

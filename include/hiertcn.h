@@ -47,7 +47,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 7
+#define HIERTCN_ABI_VERSION 8
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -157,6 +157,12 @@ int hiertcn_struct_sizes(size_t out[HIERTCN_N_STRUCTS]);
 /* model_hier.py:83-85.  y_ids [n_sessions][L] -> pooled [n_sessions][E] fp32. */
 int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_sessions, int32_t L,
                          float* pooled, void* stream);
+
+/* model_hier.py:50,54-55 as rows: x_ids [n_sessions][L], state [n_sessions][H*nl] fp32 (the state each slot's low level sees:
+ * hiertcn_gru_scan's state_before) -> rows [n_sessions*L][E + H*nl] in the storage type: E[x_t] (zeros for the null id) | state.
+ * The input of a low level that has no 'emb' projection of its own (model_low_type tcn_gmm: hiertcn_gmm_forward_rows). */
+int hiertcn_embed_concat(hiertcn_handle_t h, const int32_t* x_ids, const float* state, int64_t n_sessions, int32_t L, uint16_t* rows,
+                         void* stream);
 
 /* model_hier.py:91-93 scanned over the S slots for every lane, plus the state half of the low
  * level's input projection (model_hier.py:54-55 -> model_tcn.py:35: [e, state].Wp = e.Wp[:E] +
@@ -304,6 +310,11 @@ typedef struct {
                                           *    input (model_gru_gmm.py:33-48) -- n_blocks / channels / kernel_size are then ignored      */
   int32_t hidden_dim;                    /* trunk 1: args.hidden_dim in {64, 128, 256, 512}         */
   int32_t num_layer;                     /* trunk 1: args.num_layer                                 */
+  int32_t input_dim;                     /* trunk 2 (ABI 8): the TemporalConvNet on DENSE rows the caller provides -- model_hier.py:64-65, the
+                                          *    mixture model as the LOW level of model_hier: rows [e_t, state] of width emb + hidden_dim*num_layer
+                                          *    (hiertcn_embed_concat) -- width of those rows, a multiple of 32; block 0 is then an ordinary
+                                          *    TemporalBlock with Cin = input_dim (conv_kernel[0] [K][input_dim][C0], Dense residual where they
+                                          *    differ); item_num is ignored; hiertcn_gmm_forward_rows instead of hiertcn_gmm_forward          */
 } hiertcn_gmm_config_t;
 typedef struct {
   const float* conv_kernel[HIERTCN_MAX_BLOCKS];
@@ -328,6 +339,9 @@ size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R);
 size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T);
 int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                         size_t workspace_bytes, void* stream);
+/* trunk 2: x_rows [B*T][input_dim] (storage type) -> hidden [B*T][C_last]; same workspace as hiertcn_gmm_forward */
+int hiertcn_gmm_forward_rows(hiertcn_gmm_handle_t g, const uint16_t* x_rows, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
+                             size_t workspace_bytes, void* stream);
 int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32_t* y_ids, int64_t R, int32_t mode, float* loss,
                      float* sq_out, float* tgt_out, float* prior_out, void* workspace, size_t workspace_bytes, void* stream);
 int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64_t R, int32_t m, float* mu_out, void* stream);

@@ -179,6 +179,39 @@ def calc_loss_gmm_ids(pred, y_ids, args):
     raise NotImplementedError(args.loss)
 
 
+def init_params_hier(args, seed=2, scope="hier"):
+    """Variables of model_hier with model_low_type 'tcn_gmm' (model_hier.py:28-93 + model_tcn_gmm.py:27-44 under scope 'hier')."""
+    base = O.init_params(args, seed=seed, model="hier", emb_dim=int(getattr(args, "emb_dim", 128)))
+    p = {k: v for k, v in base.items() if k.startswith(f"{scope}/emb/") or k.startswith(f"{scope}/multi_rnn_cell/")}
+    cin = int(getattr(args, "emb_dim", 128)) + int(args.hidden_dim) * int(args.num_layer)
+    p.update(init_params(args, seed=seed + 1, scope=f"{scope}/tcn_gmm", input_dim=cin))
+    return p
+
+
+def model_hier_tcn_gmm(args, x, y, mask, state, params, num: O.Numerics = O.EXACT64, return_hidden=False, round_input=None):
+    """model_hier.py:21-94 with model_low_type 'tcn_gmm' (:64-65): per slot x_slice = [emb(x), state tiled] (:50,54-55) straight into
+    model_tcn_gmm's TemporalConvNet (no 'emb' of its own) and its head; high level as in O.model_hier (:83-93).
+    round_input: optional rounding of the x_slice rows (the device stores them in 16 bits).  -> (pred_all [B, sum L_i, n_out] or hidden, state)"""
+    dt = num.dtype
+    H, nl = int(args.hidden_dim), int(args.num_layer)
+    state = np.asarray(state, dt)
+    outs = []
+    nb = len(args.tcn_channel)
+    for i in range(len(x)):
+        xi = np.asarray(x[i]).astype(np.int64)
+        e = O.embed_ids(xi, params["hier/emb/kernel"], dt)
+        feat = np.repeat(state[:, None, :], xi.shape[1], axis=1)
+        xs = np.concatenate([e, feat], axis=-1)
+        if round_input is not None:
+            xs = round_input(xs)
+        h = O.temporal_conv_net(xs, params, "hier/tcn_gmm", nb, num)
+        outs.append(h if return_hidden else gmm_head(h, params, "hier/tcn_gmm"))
+        y_slice = O.session_mean_pool(y[i], params, dt)
+        _, state = O.multi_rnn_cell(y_slice, state, params, H, nl)
+        state = state * np.asarray(mask[i], dt)
+    return np.concatenate(outs, axis=1), state
+
+
 def masked_mean_loss(loss_bt, y_ids):
     """model.py:111-117 applied to a [B, T] loss."""
     mask = (np.asarray(y_ids) > 0).astype(np.float64)

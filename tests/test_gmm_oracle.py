@@ -125,3 +125,29 @@ def test_learned_scale_head_width_density_and_id_form():
     b = _args(N=10, M=2)
     b.sigma = None
     assert abs(G.calc_loss_gmm_ids(np.zeros((1, 1, G.n_out(b))), np.array([[4]]), b)[0, 0] - (0.5 + 5 * np.log(2 * np.pi)) / 10) < 1e-12
+
+
+def test_hier_with_mixture_low_level_shares_the_high_level_with_model_hier():
+    """G.model_hier_tcn_gmm (model_hier.py:64-65): block 0 reads [emb, state] rows of width emb + H * nl with a Dense residual, the head has
+    M (1 + D) outputs per step, and the carried state is exactly O.model_hier's on the same table / GRU variables (the high level never sees
+    the low level's output, model_hier.py:83-93)."""
+    from hiertcn_amd.args import hier_tcn_args
+    a = hier_tcn_args(item_num=50, output_dim=50, emb_dim=16, hidden_dim=8, num_layer=2, tcn_channel=[16, 16], kernel_size=3, num_mixture=2,
+                      model_low_type="tcn_gmm", loss="gmm_prob", sigma=0.1)
+    p = G.init_params_hier(a, seed=3)
+    assert p["hier/tcn_gmm/temporal_conv_net/tblock_0/conv1/kernel"].shape == (3, 16 + 16, 16)
+    assert p["hier/tcn_gmm/temporal_conv_net/tblock_0/dense/kernel"].shape == (32, 16)
+    rng = np.random.default_rng(0)
+    x = [rng.integers(0, 50, (3, 5)) for _ in range(4)]
+    y = [rng.integers(0, 50, (3, 5)) for _ in range(4)]
+    for v in y:
+        v[:, 0] = np.maximum(v[:, 0], 1)          # a session is never empty (data_loader.py:184-200)
+    mask = [np.array([[1.0], [0.0], [1.0]]) for _ in range(4)]
+    st0 = rng.standard_normal((3, 16))
+    pred, st = G.model_hier_tcn_gmm(a, x, y, mask, st0, p)
+    assert pred.shape == (3, 20, 2 * 51)
+    b = hier_tcn_args(item_num=50, emb_dim=16, hidden_dim=8, num_layer=2, tcn_channel=[16, 16], kernel_size=3)
+    q = O.init_params(b, seed=9, emb_dim=16)
+    q.update({k: v for k, v in p.items() if k.startswith("hier/emb/") or k.startswith("hier/multi_rnn_cell/")})
+    _, st_h = O.model_hier(b, x, y, mask, st0, q)
+    np.testing.assert_allclose(st, st_h, atol=1e-12)

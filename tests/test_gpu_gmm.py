@@ -297,3 +297,49 @@ def test_learned_scale_is_refused_at_width_512():
     a.sigma = None
     with pytest.raises(HierTCNError, match="learned scale"):
         TcnGmmModel(a, None)
+
+
+@pytest.mark.parametrize("sigma", [0.1, None])
+def test_model_hier_with_the_mixture_model_as_its_low_level(sigma):
+    """model_hier(args with model_low_type='tcn_gmm') (model_hier.py:64-65): [emb(x), carried state] rows straight into model_tcn_gmm's
+    TemporalConvNet (block 0: Cin = emb + hidden_dim * num_layer, Dense residual) + the mixture head, the across-session GRU as in HierTCN.
+    Hidden rows, carried state and the likelihood loss against oracle/gmm_oracle.model_hier_tcn_gmm (weights and input rows rounded as
+    stored), over ragged sessions with user boundaries, fixed and learned scale."""
+    from hiertcn_amd import model_hier_gmm as HG
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.model_hier import model_hier
+    from hiertcn_amd.model_tcn_gmm import calc_loss_gmm
+    from tests.gpu_common import as_lists, make_batch
+    N, E, H, nl, M = 900, 64, 32, 2, 3
+    a = hier_tcn_args(item_num=N, output_dim=N, emb_dim=E, hidden_dim=H, num_layer=nl, tcn_channel=[64, 128], kernel_size=3, num_mixture=M,
+                      model_low_type="tcn_gmm", loss="gmm_prob", sigma=0.1)
+    a.sigma = sigma
+    p = G.init_params_hier(a, seed=4)
+    rng = np.random.default_rng(8)
+    for k in p:
+        if (k.endswith("/bias") and "gates" not in k) or k.endswith("biases"):
+            p[k] = (p[k] + 0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    HG.reset_scopes()
+    HG._SCOPES["hier"] = HG.HierGmmModel(a, p, "hier")
+    B, S, L = 5, 4, 7
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, H * nl))).astype(np.float32)
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, st = model_hier(a, xl, yl, ml, st0)
+    assert pred.shape == (B, S * L, M * (1 + (1 if sigma else 2) * N))
+    # oracle on the numbers the device holds: table / conv / head kernels rounded to bf16 (the M prior columns stay fp32), x_slice rows rounded
+    pr = {k: (O.round_bf16(v) if (k.endswith("kernel") and "multi_rnn_cell" not in k) or k.endswith("weights") else v) for k, v in p.items()}
+    pr["hier/tcn_gmm/fully_connected/weights"][:, :M] = p["hier/tcn_gmm/fully_connected/weights"][:, :M]
+    h_ref, st_ref = G.model_hier_tcn_gmm(a, xl, yl, ml, st0, pr, O.MIRROR, return_hidden=True, round_input=O.round_bf16)
+    h_dev = pred.hidden.float().cpu().numpy().reshape(B, S * L, -1)
+    assert np.abs(h_dev - h_ref).max() < 2e-2 * max(1.0, np.abs(h_ref).max())          # one bf16 ulp of the largest activation
+    np.testing.assert_allclose(st.cpu().numpy(), st_ref, atol=2e-5, rtol=0)              # the across-session scan is fp32
+    yy = y.reshape(B, S * L)
+    for mode in ("gmm_prob", "gmm_prob_max"):
+        a.loss = mode
+        got = calc_loss_gmm(pred, yy, loss=mode).cpu().numpy()
+        want = G.calc_loss_gmm_ids(G.gmm_head(h_dev.astype(np.float64), pr, "hier/tcn_gmm"), yy, a)
+        live = yy > 0
+        assert np.abs(got - want)[live].max() < 2e-4 * max(1.0, np.abs(want[live]).max()), (mode, np.abs(got - want)[live].max())
+        assert not got[~live].any()
+    HG.reset_scopes()
