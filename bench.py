@@ -211,13 +211,29 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
         os.environ.pop("HIERTCN_GMM_TABLE_PASS", None)
         if saved is not None:
             os.environ["HIERTCN_GMM_TABLE_PASS"] = saved
+    # a learned scale (args.sigma None: M (1 + 2 D) outputs): one paired pass per mixture over the interleaved means / log-scales table
+    gl = make_args([], model_type="tcn_gmm", item_num=n_out, output_dim=n_out, num_mixture=n_mix, sigma=0.1, loss="gmm_prob",
+                   tcn_channel=[dim, dim], kernel_size=5, adjust=False)
+    gl.sigma = None
+    model = TcnGmmModel(gl, init_params(gl, 3))
+    model.loss_rows(hid, y)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        model.loss_rows(hid, y)
+    torch.cuda.synchronize()
+    ms["learned_scale"] = (time.perf_counter() - t0) / reps * 1e3
+    model.close()
     diff = float((losses["gram"] - losses["table_pass"]).abs().max())
     flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
     return {"what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
                     "bf16 parts, + one row-wise kernel for prior / linear terms / target mean + finish); ms_table_pass: M passes of "
-                    "k_score_pipe<256,21,...> (sum-of-squares epilogue) over the [D, C] mean tables + prior + finish",
+                    "k_score_pipe<256,21,...> (sum-of-squares epilogue) over the [D, C] mean tables + prior + finish; ms_learned_scale: args.sigma None, M passes of "
+                    "k_score_pipe<256,22,...> over the interleaved means / log-scales tables (twice the rows)",
             "rows": rows, "output_dim": n_out, "num_mixture": n_mix, "ms": round(ms["gram"], 3), "ms_table_pass": round(ms["table_pass"], 3),
             "rows_per_s": round(rows / ms["gram"] * 1e3), "max_abs_loss_difference": diff,
+            "ms_learned_scale": round(ms["learned_scale"], 3),
+            "learned_scale_tflops": round(2.0 * rows * dim * ((n_out + 31) // 32 * 64) * n_mix / ms["learned_scale"] / 1e9, 1),
             "table_pass_tflops": round(flop / ms["table_pass"] / 1e9, 1), "table_pass_frac_of_peak": round(flop / ms["table_pass"] / 1e9 / MFMA_PEAK_TFLOPS, 4)}
 
 
