@@ -73,10 +73,15 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
   static_assert(C == 128 || C == 256 || C == 512, "the dual-use LDS image is laid out for 256-, 512- and 1024-byte rows");
   constexpr int NCB = C / 32;
   constexpr int SI = SG::SI;
-#ifdef HIERTCN_SGRAD_TWO_CHAINS_256   // (measured: 396 vs 344 ms per training step -- the second accumulator spills at two waves per SIMD)
-  constexpr bool TWO_CHAINS = C >= 256;
-#else
+  // GEMM-1 as two accumulator chains (even / odd k-steps, added at the end).  C = 512 (one wave per SIMD): nothing else fills the latency of a
+  // dependent MFMA chain, fragment reads three ahead (1061 -> 899 ms per step).  C = 256 (two waves per SIMD, 254 of 256 registers in use): the
+  // second wave hides most of it already, and round 3's first attempt (four-deep fragment ring) spilled -- 396 vs 344 ms; with the reads one ahead,
+  // as the single chain has them, modes 0 / 1 fit and mode 2 spills 9 registers outside the MFMA phases: 337.6 -> 331.1 ms per 1024-user step.
+  // -DHIERTCN_SGRAD_ONE_CHAIN_256: the single chain, for A/B.
+#ifdef HIERTCN_SGRAD_ONE_CHAIN_256
   constexpr bool TWO_CHAINS = C == 512;
+#else
+  constexpr bool TWO_CHAINS = C >= 256;
 #endif
 #ifdef HIERTCN_SGRAD_WHOLE_PAIRS   // A/B: a pair's whole epilogue in one MFMA gap (until round 3)
   constexpr bool SPLIT_PAIRS = false;
@@ -278,7 +283,24 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[4 * q + j] = b4[j];
     }
-    if constexpr (TWO_CHAINS) {
+    if constexpr (TWO_CHAINS && C < 512) {
+      // two waves per SIMD: fragment reads one ahead, as the single chain has them (a deeper ring spills)
+      f32x16 acc2;
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) acc2[reg] = 0.f;
+      uint4 ring[2];
+      ring[0] = *reinterpret_cast<const uint4*>(tl + (ak ^ (0 << 5)));
+#pragma unroll
+      for (int s = 0; s < G::KS; s += 2) {
+        ring[1] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 1) << 5)));
+        acc = mfma32(ring[0], hf[s], acc);
+        if (s + 2 < G::KS) ring[0] = *reinterpret_cast<const uint4*>(tl + (ak ^ ((s + 2) << 5)));
+        acc2 = mfma32(ring[1], hf[s + 1], acc2);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int reg = 0; reg < 16; reg++) acc[reg] += acc2[reg];
+    } else if constexpr (TWO_CHAINS) {
       // one wave per SIMD: nothing else fills the latency of a dependent MFMA chain, so the 32 k-steps run as TWO independent chains (even / odd
       // k-steps) that are added at the end; fragment reads three ahead
       f32x16 acc2;
