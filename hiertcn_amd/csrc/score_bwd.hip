@@ -249,7 +249,8 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
   // The deferred k-step of a stage's last tile reads that stage's buffer during the NEXT iteration, so the stage barrier (and the refill
   // of the oldest buffer behind it) sits behind the first of those overlapped parts instead of at the end of the iteration: still one
   // barrier per stage, still three buffers (s-1 until that barrier, s, s+1; s+2 lands in the buffer of s-1).
-  // (Measured alternatives: fragment reads 1 / 2 ahead: no difference; waves 4-7 one part behind waves 0-3 through a rotated per-tile
+  // (Measured alternatives: GEMM-1 of tile t + 1 issued one MFMA at a time between the MFMAs of GEMM-2 of tile t (two tiles in flight, no
+  // MFMA-only phase at all): 17 spill accesses per stage at C = 256 and three LDS reads per gap -- 423 vs 337 ms per training step; fragment reads 1 / 2 ahead: no difference; waves 4-7 one part behind waves 0-3 through a rotated per-tile
   // loop with the two halves' barriers at different points: 364 vs 323 ms per training step, the rotated loop costs registers.)
   f32x16 acc;
   uint32_t pk[8];
