@@ -159,7 +159,8 @@ struct GruX3Args {
   const int32_t* seq_len; int tstep;
   uint16_t* hid_out; int64_t ldho;   // CAND, optional: the scoring operand row
 };
-hipError_t launch_gru_x3(const GruX3Args& g, hipStream_t st);
+struct GruX3Batch { GruX3Args g[HIERTCN_MAX_LAYERS]; int n; };   // the cells (layer l, step tau - l) of one wavefront diagonal
+hipError_t launch_gru_x3(const GruX3Batch& bt, hipStream_t st);
 hipError_t launch_split_f32(const float* v, int64_t n, uint16_t* hi, uint16_t* lo, hipStream_t st);
 bool gru_x3_applies(const ModelDev& m);
 hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st);

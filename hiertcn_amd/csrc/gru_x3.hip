@@ -24,7 +24,8 @@ __device__ __forceinline__ void split2(float v, uint16_t& hi, uint16_t& lo) {
   lo = f2bf(v - bf2f(hi));
 }
 
-__global__ __launch_bounds__(256) void k_gru_x3(const GruX3Args g) {
+__global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
+  const GruX3Args& g = bt.g[blockIdx.z];   // the cells of one wavefront diagonal are independent products: one launch
   __shared__ __attribute__((aligned(16))) unsigned char Wh[XT * XP];
   __shared__ __attribute__((aligned(16))) unsigned char Wl[XT * XP];
   __shared__ __attribute__((aligned(16))) unsigned char Ah[XT * XP];
@@ -183,10 +184,14 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Args g) {
   }
 }
 
-hipError_t launch_gru_x3(const GruX3Args& g, hipStream_t st) {
-  if (g.M <= 0) return hipSuccess;
-  if ((g.K1 % XK) || (g.K2 % XK) || (g.N & 31)) return hipErrorInvalidValue;
-  hipLaunchKernelGGL(k_gru_x3, dim3((unsigned)((g.N + XT - 1) / XT), (unsigned)((g.M + XT - 1) / XT)), dim3(256), 0, st, g);
+hipError_t launch_gru_x3(const GruX3Batch& bt, hipStream_t st) {
+  if (bt.n <= 0 || bt.g[0].M <= 0) return hipSuccess;
+  const GruX3Args& g = bt.g[0];
+  for (int i = 0; i < bt.n; i++) {   // one grid for the batch: same shape, same epilogue kind
+    const GruX3Args& q = bt.g[i];
+    if ((q.K1 % XK) || (q.K2 % XK) || (q.N & 31) || q.N != g.N || q.M != g.M || q.epi != g.epi) return hipErrorInvalidValue;
+  }
+  hipLaunchKernelGGL(k_gru_x3, dim3((unsigned)((g.N + XT - 1) / XT), (unsigned)((g.M + XT - 1) / XT), (unsigned)bt.n), dim3(256), 0, st, bt);
   return hipGetLastError();
 }
 

@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void k_len_f32(const float* __restrict__ uf, i
 }
 
 // split-operand cells: state hi / lo ping-pong [2][2][M][HT] + per layer r*h hi / lo and output hi / lo [nl][4][M][H]
-size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess) { return (size_t)8 * n_sess * m.HT; }
+size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess) { return (size_t)10 * n_sess * m.HT; }   // states 2 x 2, r*h 2, outputs 2 x 2 (hi, lo each)
 
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
   // embedded rows + u (16-bit) + u (fp32) + lengths + two state buffers + one (gates | r*h | cand | out) record per layer + the split scratch
@@ -475,37 +475,51 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
     uint16_t* st_lo = st_hi + 2 * MS;       // [2][M][HT]
     uint16_t* rh_hi = st_lo + 2 * MS;       // [nl][M][H]
     uint16_t* rh_lo = rh_hi + (size_t)m.nl * MH;
-    uint16_t* o_hi = rh_lo + (size_t)m.nl * MH;
-    uint16_t* o_lo = o_hi + (size_t)m.nl * MH;
+    uint16_t* o_hi = rh_lo + (size_t)m.nl * MH;        // [nl][2 step parities][M][H]
+    uint16_t* o_lo = o_hi + 2 * (size_t)m.nl * MH;
     if ((e = hipMemsetAsync(st_hi, 0, MS * 2, st)) != hipSuccess) return e;
     if ((e = hipMemsetAsync(st_lo, 0, MS * 2, st)) != hipSuccess) return e;
-    for (int t = 0; t < L; t++) {
-      const float* s_old = b.states + (size_t)(t % b.n_states) * n_sess * HT;
-      float* s_new = b.states + (size_t)((t + 1) % b.n_states) * n_sess * HT;
-      const int po = t & 1, pn = (t + 1) & 1;
+    // Wavefront over (step, layer): the cells (l, t = tau - l) of a diagonal are independent -- layer l at step t needs layer l - 1 at step t
+    // (previous diagonal) and its own state from step t - 1 (previous diagonal) -- so a diagonal is TWO launches (gates, candidates) whatever
+    // the number of layers: 2 (L + nl - 1) launches instead of 2 L nl, each with nl x the tiles (at 20,480 sessions and two layers 1280 tiles =
+    // exactly five rounds of 256 CUs instead of 2.5).  The layers' output operands are double-buffered by step parity (layer l + 1 reads step
+    // t's while layer l writes step t + 1's); states and records are per layer slices already.
+    for (int tau = 0; tau < L + m.nl - 1; tau++) {
+      GruX3Batch gb, cb;
+      memset(&gb, 0, sizeof(gb));
+      memset(&cb, 0, sizeof(cb));
+      int n = 0;
       for (int l = 0; l < m.nl; l++) {
+        const int t = tau - l;
+        if (t < 0 || t >= L) continue;
+        const float* s_old = b.states + (size_t)(t % b.n_states) * n_sess * HT;
+        float* s_new = b.states + (size_t)((t + 1) % b.n_states) * n_sess * HT;
+        const int po = t & 1, pn = (t + 1) & 1;
         float* rec = b.rec + (b.keep_all ? ((size_t)t * m.nl + l) : (size_t)l) * cell;
-        GruX3Args g;
-        memset(&g, 0, sizeof(g));
+        GruX3Args& g = gb.g[n];
         g.M = n_sess; g.H = H; g.save_all = b.keep_all;
         if (l == 0) { g.A1h = b.u16 + (size_t)t * E; g.A1l = nullptr; g.lda1 = (int64_t)L * E; g.K1 = E; }
-        else { g.A1h = o_hi + (size_t)(l - 1) * MH; g.A1l = o_lo + (size_t)(l - 1) * MH; g.lda1 = H; g.K1 = H; }
+        else { g.A1h = o_hi + ((size_t)(l - 1) * 2 + po) * MH; g.A1l = o_lo + ((size_t)(l - 1) * 2 + po) * MH; g.lda1 = H; g.K1 = H; }
         g.A2h = st_hi + (size_t)po * MS + (size_t)l * H; g.A2l = st_lo + (size_t)po * MS + (size_t)l * H; g.lda2 = HT; g.K2 = H;
         g.Wh = m.lgru_wg_hi[l]; g.Wl = m.lgru_wg_lo[l]; g.bias = m.lgru_bg[l]; g.N = 2 * H; g.epi = X3_GATES;
         g.gates = rec; g.h = s_old + (size_t)l * H; g.ldh = HT;
         g.rh = rec + (size_t)n_sess * 2 * H; g.rh_hi = rh_hi + (size_t)l * MH; g.rh_lo = rh_lo + (size_t)l * MH;
-        if ((e = launch_gru_x3(g, st)) != hipSuccess) return e;
-        g.A2h = g.rh_hi; g.A2l = g.rh_lo; g.lda2 = H;
-        g.Wh = m.lgru_wc_hi[l]; g.Wl = m.lgru_wc_lo[l]; g.bias = m.lgru_bc[l]; g.N = H; g.epi = X3_CAND;
-        g.cand_out = rec + (size_t)n_sess * 3 * H;
-        g.out = rec + (size_t)n_sess * 4 * H;
-        if (l + 1 < m.nl) { g.out_hi = o_hi + (size_t)l * MH; g.out_lo = o_lo + (size_t)l * MH; }
-        g.state_new = s_new + (size_t)l * H; g.state_hi = st_hi + (size_t)pn * MS + (size_t)l * H; g.state_lo = st_lo + (size_t)pn * MS + (size_t)l * H;
-        g.lds_ = HT;
         g.seq_len = b.seq_len; g.tstep = t;
-        if (l == m.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
-        if ((e = launch_gru_x3(g, st)) != hipSuccess) return e;
+        GruX3Args& c = cb.g[n];
+        c = g;
+        c.A2h = g.rh_hi; c.A2l = g.rh_lo; c.lda2 = H;
+        c.Wh = m.lgru_wc_hi[l]; c.Wl = m.lgru_wc_lo[l]; c.bias = m.lgru_bc[l]; c.N = H; c.epi = X3_CAND;
+        c.cand_out = rec + (size_t)n_sess * 3 * H;
+        c.out = rec + (size_t)n_sess * 4 * H;
+        if (l + 1 < m.nl) { c.out_hi = o_hi + ((size_t)l * 2 + po) * MH; c.out_lo = o_lo + ((size_t)l * 2 + po) * MH; }
+        c.state_new = s_new + (size_t)l * H; c.state_hi = st_hi + (size_t)pn * MS + (size_t)l * H; c.state_lo = st_lo + (size_t)pn * MS + (size_t)l * H;
+        c.lds_ = HT;
+        if (l == m.nl - 1) { c.hid_out = hidden + (size_t)t * H; c.ldho = (int64_t)L * H; }
+        n++;
       }
+      gb.n = cb.n = n;
+      if ((e = launch_gru_x3(gb, st)) != hipSuccess) return e;
+      if ((e = launch_gru_x3(cb, st)) != hipSuccess) return e;
     }
     return hipSuccess;
   }

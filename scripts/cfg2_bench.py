@@ -1,6 +1,6 @@
 """Evaluation at the reference's own batching (BASELINE.json configs[1]: model_hier d=256, XING catalogue N=20,778,
 B=32 lanes x S=10 slots x L<=20 steps per batch): batches/s and sessions/s, ids resident on the device.
-usage: python scripts/cfg2_bench.py [lanes] [batches]"""
+usage: [LOW=gru] python scripts/cfg2_bench.py [lanes] [batches]     (LOW=gru: HierGRU, the reference's default low level)"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -21,7 +21,8 @@ def make_batch(rng, B, S, L, N):
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 N, d, S, L = 20778, 256, 10, 20
-args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B)
+args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B,
+                     model_low_type=os.environ.get("LOW", "tcn"))
 eng = Engine(args, hier=True)
 eng.set_weights(init_params(args, seed=2))
 rng = np.random.default_rng(0)

@@ -9,6 +9,7 @@ print(f\"{b['value']:.0f} sessions/s, {b['ms_per_step']:.1f} ms/step; scoring {r
 echo "== ragged sessions (lengths ~ U{1..30})"; python3 bench.py --ragged --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json; b = json.loads(sys.stdin.read()); print(f\"{b['value']:.0f} sessions/s\")"
 echo "== reference batching (32 lanes x 10 x <=20, XING catalogue)"; python3 scripts/cfg2_bench.py 2>&1 | tail -2
+echo "== reference batching, HierGRU (the reference's default low level)"; LOW=gru python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1
 echo "== across-session GRU scan: chain of GEMM launches vs the persistent launch"; bash scripts/gru_ab.sh 2>&1 | grep -v "^$"
 echo "== scoring kernel alone, d = 256 / 128 / 64 (2,457,600 rows x 300,000 items)"
 for d in 256 128 64; do D=$d python3 scripts/score_diag.py 2457600 300000 2>&1 | tail -1 | sed "s/^/d=$d: /"; done
