@@ -13,11 +13,18 @@
 // units of one session and every epilogue access is a 16-byte row access.  Workgroup = 128 units x 128 sessions (4 waves x four 32 x 32
 // accumulators); the reduction runs over [in | h] in 64-deep chunks; W_hi, W_lo, A_hi, A_lo chunks are staged in LDS (pitch 144 B) with the
 // next chunk's loads in flight during the MFMAs.  The layer-0 input (the projected rows, already 16-bit) has no low part: two products.
+#include <type_traits>
+
 #include "common.h"
 
 #define XT 128
 #define XK 64
 #define XP 144   // byte pitch of a [128][64] 16-bit tile: 36 words, (9 r) mod 16 distinct over the 16 lanes of a ds_read_b128 phase
+
+// sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of libm's expf / tanhf + a division: at 64
+// activations per thread the libm forms were as long as the cell's whole MFMA loop.  Both saturate correctly (exp2 -> 0 or inf, rcp(inf) = 0).
+__device__ __forceinline__ float fast_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float fast_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
 
 __device__ __forceinline__ void split2(float v, uint16_t& hi, uint16_t& lo) {
   hi = f2bf(v);
@@ -26,10 +33,11 @@ __device__ __forceinline__ void split2(float v, uint16_t& hi, uint16_t& lo) {
 
 __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
   const GruX3Args& g = bt.g[blockIdx.z];   // the cells of one wavefront diagonal are independent products: one launch
-  __shared__ __attribute__((aligned(16))) unsigned char Wh[XT * XP];
-  __shared__ __attribute__((aligned(16))) unsigned char Wl[XT * XP];
-  __shared__ __attribute__((aligned(16))) unsigned char Ah[XT * XP];
-  __shared__ __attribute__((aligned(16))) unsigned char Al[XT * XP];
+  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XT * XP];   // four operand tiles; behind the main loop: the fp32 result tile
+  unsigned char* const Wh = smem;
+  unsigned char* const Wl = smem + XT * XP;
+  unsigned char* const Ah = smem + 2 * XT * XP;
+  unsigned char* const Al = smem + 3 * XT * XP;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * XT;
@@ -38,8 +46,11 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
   const int ldrow = tid >> 3, ldc8 = (tid & 7) * 8;
   const int K = g.K1 + g.K2;
   const int n_it = K / XK;
-  uint4 rwh[4], rwl[4], rah[4], ral[4];
-  auto fetch = [&](int it) {
+  // two chunks of loads in flight (register sets 0 / 1): with one, a chunk's 48 MFMAs per wave (~0.7 us) did not cover a load's round trip and
+  // the kernel moved 3.4 TB/s through L2 at the bench shape
+  uint4 rwh[2][4], rwl[2][4], rah[2][4], ral[2][4];
+  auto fetch = [&](int it, auto setc) {
+    constexpr int S = decltype(setc)::value;
     const int kc = it * XK;
     const bool seg2 = kc >= g.K1;
     const uint16_t* ah = seg2 ? g.A2h : g.A1h;
@@ -50,16 +61,16 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int n = n0 + ldrow + 32 * p;
-      rwh[p] = zero; rwl[p] = zero;
+      rwh[S][p] = zero; rwl[S][p] = zero;
       if (n < g.N) {
-        rwh[p] = *reinterpret_cast<const uint4*>(g.Wh + (int64_t)n * K + kc + ldc8);
-        rwl[p] = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)n * K + kc + ldc8);
+        rwh[S][p] = *reinterpret_cast<const uint4*>(g.Wh + (int64_t)n * K + kc + ldc8);
+        rwl[S][p] = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)n * K + kc + ldc8);
       }
       const int64_t m = m0 + ldrow + 32 * p;
-      rah[p] = zero; ral[p] = zero;
+      rah[S][p] = zero; ral[S][p] = zero;
       if (m < g.M) {
-        rah[p] = *reinterpret_cast<const uint4*>(ah + m * lda + ka);
-        if (al) ral[p] = *reinterpret_cast<const uint4*>(al + m * lda + ka);
+        rah[S][p] = *reinterpret_cast<const uint4*>(ah + m * lda + ka);
+        if (al) ral[S][p] = *reinterpret_cast<const uint4*>(al + m * lda + ka);
       }
     }
   };
@@ -70,19 +81,19 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
-  fetch(0);
-  for (int it = 0; it < n_it; it++) {
+  auto step = [&](int it, auto setc) {
+    constexpr int S = decltype(setc)::value;
     __syncthreads();
 #pragma unroll
     for (int p = 0; p < 4; p++) {
       const int o = (ldrow + 32 * p) * XP + ldc8 * 2;
-      *reinterpret_cast<uint4*>(Wh + o) = rwh[p];
-      *reinterpret_cast<uint4*>(Wl + o) = rwl[p];
-      *reinterpret_cast<uint4*>(Ah + o) = rah[p];
-      *reinterpret_cast<uint4*>(Al + o) = ral[p];
+      *reinterpret_cast<uint4*>(Wh + o) = rwh[S][p];
+      *reinterpret_cast<uint4*>(Wl + o) = rwl[S][p];
+      *reinterpret_cast<uint4*>(Ah + o) = rah[S][p];
+      *reinterpret_cast<uint4*>(Al + o) = ral[S][p];
     }
     __syncthreads();
-    if (it + 1 < n_it) fetch(it + 1);
+    if (it + 2 < n_it) fetch(it + 2, setc);   // this register set is free again: chunk it + 2 goes into it
 #pragma unroll
     for (int s = 0; s < XK / 16; s++) {
       const int ko = 32 * s + 16 * lh;
@@ -111,76 +122,93 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = mfma32(wh[i], ah[j], acc[i][j]);
     }
+  };
+  constexpr std::integral_constant<int, 0> set0{};
+  constexpr std::integral_constant<int, 1> set1{};
+  fetch(0, set0);
+  if (n_it > 1) fetch(1, set1);
+  for (int it = 0; it < n_it; it += 2) {
+    step(it, set0);
+    if (it + 1 < n_it) step(it + 1, set1);
   }
-  // epilogues: D[row = unit n][col = session m]; registers 4q..4q+3 of a tile are units 8q + 4 lh + 0..3 of session lr: 16-byte accesses, the
-  // two lane halves side by side (32 bytes per row per instruction, a 128-byte line over the four q).  (The transposed orientation -- one unit
-  // of 16 sessions per lane, whole lines per instruction but four times as many instructions -- measured 158 vs 109 us per cell.)
+  // Epilogues.  D[row = output unit n][col = session m]: a lane holds four consecutive units of one session, and 32 lanes hold 32 different
+  // sessions -- written from the registers, every instruction touches 32 rows of the global arrays with 32 bytes each (a quarter of every
+  // 128-byte line it opens; the four q of a tile come in four separate instructions), and the cell was bound by that: ~190 MB of useful
+  // epilogue traffic per gates + candidate pair moved at ~1 TB/s.  So the result tile goes through LDS (the operand tiles are dead): written as
+  // it lies in the accumulators, read back ROW-major -- a wave covers two sessions x 128 units, 512 contiguous bytes per row and array.
   // Evaluation (save_all == 0) writes only what the next product reads: u, the split r*h, the split state and output; the training forward
   // also keeps r, r*h, the candidate and the output in fp32 for the backward pass.
-  const int H = g.H;
-  auto pack4 = [](const uint16_t* v) { return make_uint2(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16)); };
+  constexpr int TP = XT + 4;   // floats per row of the result tile: rows 4 banks apart for the 16-byte writes of 16 lanes
+  static_assert(XT * TP * 4 <= 4 * XT * XP, "the result tile fits the operand buffers");
+  float* T = reinterpret_cast<float*>(smem);
+  __syncthreads();   // every wave is done reading the last operand chunk
 #pragma unroll
-  for (int j = 0; j < 2; j++) {
-    const int64_t m = m0 + 64 * wm + 32 * j + lr;
-    if (m >= g.M) continue;
-    const bool active = g.seq_len ? g.tstep < g.seq_len[m] : true;
+  for (int j = 0; j < 2; j++)
 #pragma unroll
     for (int i = 0; i < 2; i++)
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        const int n = n0 + 64 * wn + 32 * i + 8 * q + 4 * lh;
-        if (n >= g.N) continue;
-        float v[4];
-        const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
-        v[0] = acc[i][j][4 * q] + b4.x; v[1] = acc[i][j][4 * q + 1] + b4.y; v[2] = acc[i][j][4 * q + 2] + b4.z; v[3] = acc[i][j][4 * q + 3] + b4.w;
-        uint16_t hi[4], lo[4];
-        if (g.epi == X3_GATES) {   // customed_gru_cell.py:323-326: value = sigmoid(.), r first, u second; r_state = r * h
-          float s4[4];
+      for (int q = 0; q < 4; q++)
+        *reinterpret_cast<float4*>(T + (64 * wm + 32 * j + lr) * TP + 64 * wn + 32 * i + 8 * q + 4 * lh) =
+            make_float4(acc[i][j][4 * q], acc[i][j][4 * q + 1], acc[i][j][4 * q + 2], acc[i][j][4 * q + 3]);
+  __syncthreads();
+  const int H = g.H;
+  auto pack4 = [](const uint16_t* v) { return make_uint2(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16)); };
+  for (int pass = 0; pass < XT * XT / 4 / 256; pass++) {
+    const int idx = pass * 256 + tid;
+    const int ml = idx >> 5, n = n0 + 4 * (idx & 31);
+    const int64_t m = m0 + ml;
+    if (m >= g.M || n >= g.N) continue;
+    const bool active = g.seq_len ? g.tstep < g.seq_len[m] : true;
+    const float4 t4 = *reinterpret_cast<const float4*>(T + ml * TP + 4 * (idx & 31));
+    const float4 b4 = *reinterpret_cast<const float4*>(g.bias + n);
+    const float v[4] = {t4.x + b4.x, t4.y + b4.y, t4.z + b4.z, t4.w + b4.w};
+    uint16_t hi[4], lo[4];
+    if (g.epi == X3_GATES) {   // customed_gru_cell.py:323-326: value = sigmoid(.), r first, u second; r_state = r * h
+      float s4[4];
 #pragma unroll
-          for (int c = 0; c < 4; c++) s4[c] = 1.0f / (1.0f + expf(-v[c]));
-          if (n >= H || g.save_all) *reinterpret_cast<float4*>(g.gates + m * 2 * H + n) = make_float4(s4[0], s4[1], s4[2], s4[3]);
-          if (n < H) {
-            const float4 hv = *reinterpret_cast<const float4*>(g.h + m * g.ldh + n);
-            const float r4[4] = {s4[0] * hv.x, s4[1] * hv.y, s4[2] * hv.z, s4[3] * hv.w};
-            if (g.save_all) *reinterpret_cast<float4*>(g.rh + m * H + n) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+      for (int c = 0; c < 4; c++) s4[c] = fast_sigmoid(v[c]);
+      if (n >= H || g.save_all) *reinterpret_cast<float4*>(g.gates + m * 2 * H + n) = make_float4(s4[0], s4[1], s4[2], s4[3]);
+      if (n < H) {
+        const float4 hv = *reinterpret_cast<const float4*>(g.h + m * g.ldh + n);
+        const float r4[4] = {s4[0] * hv.x, s4[1] * hv.y, s4[2] * hv.z, s4[3] * hv.w};
+        if (g.save_all) *reinterpret_cast<float4*>(g.rh + m * H + n) = make_float4(r4[0], r4[1], r4[2], r4[3]);
 #pragma unroll
-            for (int c = 0; c < 4; c++) split2(r4[c], hi[c], lo[c]);
-            *reinterpret_cast<uint2*>(g.rh_hi + m * H + n) = pack4(hi);
-            *reinterpret_cast<uint2*>(g.rh_lo + m * H + n) = pack4(lo);
-          }
-        } else {                   // :335-336: c = tanh(.), h' = u h + (1 - u) c; dynamic_rnn past the row's length: state through, output 0
-          const float4 hv = *reinterpret_cast<const float4*>(g.h + m * g.ldh + n);
-          const float4 uv = *reinterpret_cast<const float4*>(g.gates + m * 2 * H + H + n);
-          const float c4[4] = {tanhf(v[0]), tanhf(v[1]), tanhf(v[2]), tanhf(v[3])};
-          float hn[4];
-          hn[0] = uv.x * hv.x + (1.0f - uv.x) * c4[0];
-          hn[1] = uv.y * hv.y + (1.0f - uv.y) * c4[1];
-          hn[2] = uv.z * hv.z + (1.0f - uv.z) * c4[2];
-          hn[3] = uv.w * hv.w + (1.0f - uv.w) * c4[3];
-          if (g.save_all) {
-            *reinterpret_cast<float4*>(g.cand_out + m * H + n) = make_float4(c4[0], c4[1], c4[2], c4[3]);
-            *reinterpret_cast<float4*>(g.out + m * H + n) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-          }
-          const float st4[4] = {active ? hn[0] : hv.x, active ? hn[1] : hv.y, active ? hn[2] : hv.z, active ? hn[3] : hv.w};
-          *reinterpret_cast<float4*>(g.state_new + m * g.lds_ + n) = make_float4(st4[0], st4[1], st4[2], st4[3]);
-#pragma unroll
-          for (int c = 0; c < 4; c++) split2(st4[c], hi[c], lo[c]);
-          *reinterpret_cast<uint2*>(g.state_hi + m * g.lds_ + n) = pack4(hi);
-          *reinterpret_cast<uint2*>(g.state_lo + m * g.lds_ + n) = pack4(lo);
-          if (g.out_hi) {          // the next layer's input operand
-#pragma unroll
-            for (int c = 0; c < 4; c++) split2(hn[c], hi[c], lo[c]);
-            *reinterpret_cast<uint2*>(g.out_hi + m * H + n) = pack4(hi);
-            *reinterpret_cast<uint2*>(g.out_lo + m * H + n) = pack4(lo);
-          }
-          if (g.hid_out) {         // top layer: the scoring operand row, zero past the length
-            uint2 o;
-            o.x = active ? pack2bf(hn[0], hn[1]) : 0u;
-            o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
-            *reinterpret_cast<uint2*>(g.hid_out + m * g.ldho + n) = o;
-          }
-        }
+        for (int c = 0; c < 4; c++) split2(r4[c], hi[c], lo[c]);
+        *reinterpret_cast<uint2*>(g.rh_hi + m * H + n) = pack4(hi);
+        *reinterpret_cast<uint2*>(g.rh_lo + m * H + n) = pack4(lo);
       }
+    } else {                   // :335-336: c = tanh(.), h' = u h + (1 - u) c; dynamic_rnn past the row's length: state through, output 0
+      const float4 hv = *reinterpret_cast<const float4*>(g.h + m * g.ldh + n);
+      const float4 uv = *reinterpret_cast<const float4*>(g.gates + m * 2 * H + H + n);
+      const float c4[4] = {fast_tanh(v[0]), fast_tanh(v[1]), fast_tanh(v[2]), fast_tanh(v[3])};
+      float hn[4];
+      hn[0] = uv.x * hv.x + (1.0f - uv.x) * c4[0];
+      hn[1] = uv.y * hv.y + (1.0f - uv.y) * c4[1];
+      hn[2] = uv.z * hv.z + (1.0f - uv.z) * c4[2];
+      hn[3] = uv.w * hv.w + (1.0f - uv.w) * c4[3];
+      if (g.save_all) {
+        *reinterpret_cast<float4*>(g.cand_out + m * H + n) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+        *reinterpret_cast<float4*>(g.out + m * H + n) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+      }
+      const float st4[4] = {active ? hn[0] : hv.x, active ? hn[1] : hv.y, active ? hn[2] : hv.z, active ? hn[3] : hv.w};
+      *reinterpret_cast<float4*>(g.state_new + m * g.lds_ + n) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+#pragma unroll
+      for (int c = 0; c < 4; c++) split2(st4[c], hi[c], lo[c]);
+      *reinterpret_cast<uint2*>(g.state_hi + m * g.lds_ + n) = pack4(hi);
+      *reinterpret_cast<uint2*>(g.state_lo + m * g.lds_ + n) = pack4(lo);
+      if (g.out_hi) {          // the next layer's input operand
+#pragma unroll
+        for (int c = 0; c < 4; c++) split2(hn[c], hi[c], lo[c]);
+        *reinterpret_cast<uint2*>(g.out_hi + m * H + n) = pack4(hi);
+        *reinterpret_cast<uint2*>(g.out_lo + m * H + n) = pack4(lo);
+      }
+      if (g.hid_out) {         // top layer: the scoring operand row, zero past the length
+        uint2 o;
+        o.x = active ? pack2bf(hn[0], hn[1]) : 0u;
+        o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
+        *reinterpret_cast<uint2*>(g.hid_out + m * g.ldho + n) = o;
+      }
+    }
   }
 }
 
