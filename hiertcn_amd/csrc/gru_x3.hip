@@ -11,15 +11,14 @@
 //
 // One kernel, two epilogues (the fp32 kernel's, pool_gru.hip): D[row = output unit n][col = session m], so a lane holds four consecutive
 // units of one session and every epilogue access is a 16-byte row access.  Workgroup = 128 units x 128 sessions (4 waves x four 32 x 32
-// accumulators); the reduction runs over [in | h] in 64-deep chunks; W_hi, W_lo, A_hi, A_lo chunks are staged in LDS (pitch 144 B) with the
-// next chunk's loads in flight during the MFMAs.  The layer-0 input (the projected rows, already 16-bit) has no low part: two products.
+// accumulators); the reduction runs over [in | h] in 64- or 32-deep chunks; W_hi, W_lo, A_hi, A_lo chunks arrive in LDS by LDS-DMA (two buffers,
+// source-side swizzle) with the next chunk in flight during the MFMAs.  The layer-0 input (the projected rows, already 16-bit) has no low part: two products.
 #include <type_traits>
 
 #include "common.h"
 
 #define XT 128
-#define XK 64
-#define XP 144   // byte pitch of a [128][64] 16-bit tile: 36 words, (9 r) mod 16 distinct over the 16 lanes of a ds_read_b128 phase
+#define XK_MIN 32   // reduction widths are multiples of this (the kernel's chunk depth is 64 or 32: k_gru_x3<XK>)
 
 // sigmoid / tanh on the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each) instead of libm's expf / tanhf + a division: at 64
 // activations per thread the libm forms were as long as the cell's whole MFMA loop.  Both saturate correctly (exp2 -> 0 or inf, rcp(inf) = 0).
@@ -31,47 +30,57 @@ __device__ __forceinline__ void split2(float v, uint16_t& hi, uint16_t& lo) {
   lo = f2bf(v - bf2f(hi));
 }
 
+// XK = reduction columns per chunk: 64 (128-byte tile rows, 128 KB of LDS: one workgroup per CU, half as many barriers -- launches too small to fill
+// the chip) or 32 (64-byte rows, 66 KB: two workgroups per CU, whose prologues and epilogues overlap each other's products)
+template <int XK>
 __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
   const GruX3Args& g = bt.g[blockIdx.z];   // the cells of one wavefront diagonal are independent products: one launch
-  __shared__ __attribute__((aligned(16))) unsigned char smem[4 * XT * XP];   // four operand tiles; behind the main loop: the fp32 result tile
-  unsigned char* const Wh = smem;
-  unsigned char* const Wl = smem + XT * XP;
-  unsigned char* const Ah = smem + 2 * XT * XP;
-  unsigned char* const Al = smem + 3 * XT * XP;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // Operand path: LDS-DMA (global_load_lds_dwordx4, 1 KB = 8 rows x 128 B per wave instruction) into two 64 KB chunk buffers -- the register-
+  // staged path it replaces (global -> VGPR -> ds_write_b128, two register sets) left the waves waiting half of their cycles at 11 % MFMA busy
+  // (scripts/profile_gru_x3.sh).  A tile row is 128 bytes = eight 16-byte chunks; DMA writes rows back to back (no padding possible), so the
+  // chunk order is swizzled on the SOURCE side: LDS position (row r, chunk c) holds the row's chunk c ^ ((r >> 1) & 7), which puts the 16 rows
+  // of a ds_read_b128 phase (same logical chunk) on 16 different 16-byte bank groups.
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 2 x [Wh | Wl | Ah | Al] x 16 KB; behind the main loop: the fp32 result tile
+  constexpr int ROWB = XK * 2, CPR = ROWB / 16, RPP = 1024 / ROWB, RW = 256 / ROWB, PPW = XT / RPP / 4;   // row bytes, chunks per row, rows per piece, rows per bank sweep, pieces per wave
+  constexpr int RWS = RW == 2 ? 1 : 2;   // log2(RW)
+  constexpr int TILE_B = XT * ROWB, CHUNK_B = 4 * TILE_B;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int n0 = blockIdx.x * XT;
   const int64_t m0 = (int64_t)blockIdx.y * XT;
   const int wn = wave >> 1, wm = wave & 1;
-  const int ldrow = tid >> 3, ldc8 = (tid & 7) * 8;
   const int K = g.K1 + g.K2;
   const int n_it = K / XK;
-  // two chunks of loads in flight (register sets 0 / 1): with one, a chunk's 48 MFMAs per wave (~0.7 us) did not cover a load's round trip and
-  // the kernel moved 3.4 TB/s through L2 at the bench shape
-  uint4 rwh[2][4], rwl[2][4], rah[2][4], ral[2][4];
-  auto fetch = [&](int it, auto setc) {
-    constexpr int S = decltype(setc)::value;
+  const unsigned lds_base = (unsigned)(size_t)((__attribute__((address_space(3))) unsigned char*)smem);
+  auto dma = [&](const void* gsrc, unsigned lds_dst) {   // (score.hip: why inline asm, and why the waits are placed by hand)
+    unsigned keep;
+    const unsigned dst = __builtin_amdgcn_readfirstlane(lds_dst);
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(dst)
+                 : "memory");
+  };
+  // wave w moves pieces 4 w .. 4 w + 3 (rows 32 w .. 32 w + 31) of each of the four tiles; a lane's row inside a piece and its source chunk
+  const int prow = lane / CPR;
+  auto issue = [&](int it, int buf) {
     const int kc = it * XK;
     const bool seg2 = kc >= g.K1;
     const uint16_t* ah = seg2 ? g.A2h : g.A1h;
     const uint16_t* al = seg2 ? g.A2l : g.A1l;
     const int64_t lda = seg2 ? g.lda2 : g.lda1;
-    const int ka = (seg2 ? kc - g.K1 : kc) + ldc8;
-    const uint4 zero = make_uint4(0, 0, 0, 0);
+    const int ka = seg2 ? kc - g.K1 : kc;
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int n = n0 + ldrow + 32 * p;
-      rwh[S][p] = zero; rwl[S][p] = zero;
-      if (n < g.N) {
-        rwh[S][p] = *reinterpret_cast<const uint4*>(g.Wh + (int64_t)n * K + kc + ldc8);
-        rwl[S][p] = *reinterpret_cast<const uint4*>(g.Wl + (int64_t)n * K + kc + ldc8);
-      }
-      const int64_t m = m0 + ldrow + 32 * p;
-      rah[S][p] = zero; ral[S][p] = zero;
-      if (m < g.M) {
-        rah[S][p] = *reinterpret_cast<const uint4*>(ah + m * lda + ka);
-        if (al) ral[S][p] = *reinterpret_cast<const uint4*>(al + m * lda + ka);
-      }
+    for (int pp = 0; pp < PPW; pp++) {
+      const int row = 32 * wave + RPP * pp + prow;
+      const int cs = ((lane & (CPR - 1)) ^ ((row >> RWS) & (CPR - 1))) * 8;  // source chunk (elements) for this LDS position
+      const int64_t n = (n0 + row < g.N) ? n0 + row : g.N - 1;               // (rows past the end re-read the last one: never stored)
+      const int64_t m = (m0 + row < g.M) ? m0 + row : g.M - 1;
+      const unsigned dst = lds_base + buf * CHUNK_B + (PPW * wave + pp) * 1024;
+      dma(g.Wh + n * K + kc + cs, dst);
+      dma(g.Wl + n * K + kc + cs, dst + TILE_B);
+      dma(ah + m * lda + ka + cs, dst + 2 * TILE_B);
+      if (al) dma(al + m * lda + ka + cs, dst + 3 * TILE_B);                 // (wave-uniform)
     }
   };
   f32x16 acc[2][2];
@@ -81,38 +90,44 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
     for (int j = 0; j < 2; j++)
 #pragma unroll
       for (int q = 0; q < 16; q++) acc[i][j][q] = 0.f;
-  auto step = [&](int it, auto setc) {
-    constexpr int S = decltype(setc)::value;
-    __syncthreads();
+  // fragment addresses inside a tile: row * ROWB + ((2 s + lh) ^ swizzle(row)) * 16
+  int wrow[2], arow[2], wsw[2], asw[2];
 #pragma unroll
-    for (int p = 0; p < 4; p++) {
-      const int o = (ldrow + 32 * p) * XP + ldc8 * 2;
-      *reinterpret_cast<uint4*>(Wh + o) = rwh[S][p];
-      *reinterpret_cast<uint4*>(Wl + o) = rwl[S][p];
-      *reinterpret_cast<uint4*>(Ah + o) = rah[S][p];
-      *reinterpret_cast<uint4*>(Al + o) = ral[S][p];
-    }
-    __syncthreads();
-    if (it + 2 < n_it) fetch(it + 2, setc);   // this register set is free again: chunk it + 2 goes into it
+  for (int i = 0; i < 2; i++) {
+    const int rw = 64 * wn + 32 * i + lr, ra = 64 * wm + 32 * i + lr;
+    wrow[i] = rw * ROWB; wsw[i] = (rw >> RWS) & (CPR - 1);
+    arow[i] = ra * ROWB; asw[i] = (ra >> RWS) & (CPR - 1);
+  }
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int it = 0; it < n_it; it++) {
+    const int buf = it & 1;
+    if (it + 1 < n_it) issue(it + 1, buf ^ 1);   // its readers passed the barrier that ended the previous chunk
+    const unsigned char* Wh = smem + buf * CHUNK_B;
+    const unsigned char* Wl = Wh + TILE_B;
+    const unsigned char* Ah = Wh + 2 * TILE_B;
+    const unsigned char* Al = Wh + 3 * TILE_B;
+    const bool has_lo = (it * XK >= g.K1 ? g.A2l : g.A1l) != nullptr;   // the layer-0 input rows are 16-bit already: two products
 #pragma unroll
     for (int s = 0; s < XK / 16; s++) {
-      const int ko = 32 * s + 16 * lh;
       uint4 wh[2], wl[2], ah[2], al[2];
 #pragma unroll
       for (int i = 0; i < 2; i++) {
-        wh[i] = *reinterpret_cast<const uint4*>(Wh + (64 * wn + 32 * i + lr) * XP + ko);
-        wl[i] = *reinterpret_cast<const uint4*>(Wl + (64 * wn + 32 * i + lr) * XP + ko);
-        ah[i] = *reinterpret_cast<const uint4*>(Ah + (64 * wm + 32 * i + lr) * XP + ko);
-        al[i] = *reinterpret_cast<const uint4*>(Al + (64 * wm + 32 * i + lr) * XP + ko);
+        const int wo = wrow[i] + (((2 * s + lh) ^ wsw[i]) << 4), ao = arow[i] + (((2 * s + lh) ^ asw[i]) << 4);
+        wh[i] = *reinterpret_cast<const uint4*>(Wh + wo);
+        wl[i] = *reinterpret_cast<const uint4*>(Wl + wo);
+        ah[i] = *reinterpret_cast<const uint4*>(Ah + ao);
+        if (has_lo) al[i] = *reinterpret_cast<const uint4*>(Al + ao);
       }
       // smallest terms first -- (a_lo w_hi + a_hi w_lo) + a_hi w_hi inside each fp32 accumulator -- and product-major, so that the four tiles'
-      // MFMAs of one product sit between the dependent MFMAs of a tile.  (An operand without a low part -- the layer-0 input rows -- has a zero
-      // tile in Al: its product is kept rather than branched around, a branch between the prefetch and the MFMAs makes hipcc wait for vmcnt(0)
-      // early.)
+      // MFMAs of one product sit between the dependent MFMAs of a tile
+      if (has_lo) {
 #pragma unroll
-      for (int i = 0; i < 2; i++)
+        for (int i = 0; i < 2; i++)
 #pragma unroll
-        for (int j = 0; j < 2; j++) acc[i][j] = mfma32(wh[i], al[j], acc[i][j]);
+          for (int j = 0; j < 2; j++) acc[i][j] = mfma32(wh[i], al[j], acc[i][j]);
+      }
 #pragma unroll
       for (int i = 0; i < 2; i++)
 #pragma unroll
@@ -122,14 +137,8 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
 #pragma unroll
         for (int j = 0; j < 2; j++) acc[i][j] = mfma32(wh[i], ah[j], acc[i][j]);
     }
-  };
-  constexpr std::integral_constant<int, 0> set0{};
-  constexpr std::integral_constant<int, 1> set1{};
-  fetch(0, set0);
-  if (n_it > 1) fetch(1, set1);
-  for (int it = 0; it < n_it; it += 2) {
-    step(it, set0);
-    if (it + 1 < n_it) step(it + 1, set1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of the next chunk have landed ...
+    __syncthreads();                                    // ... and everyone's; every wave is done reading this one
   }
   // Epilogues.  D[row = output unit n][col = session m]: a lane holds four consecutive units of one session, and 32 lanes hold 32 different
   // sessions -- written from the registers, every instruction touches 32 rows of the global arrays with 32 bytes each (a quarter of every
@@ -139,9 +148,8 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
   // Evaluation (save_all == 0) writes only what the next product reads: u, the split r*h, the split state and output; the training forward
   // also keeps r, r*h, the candidate and the output in fp32 for the backward pass.
   constexpr int TP = XT + 4;   // floats per row of the result tile: rows 4 banks apart for the 16-byte writes of 16 lanes
-  static_assert(XT * TP * 4 <= 4 * XT * XP, "the result tile fits the operand buffers");
+  // (the launch sizes the dynamic LDS as max(two chunk buffers, this tile))
   float* T = reinterpret_cast<float*>(smem);
-  __syncthreads();   // every wave is done reading the last operand chunk
 #pragma unroll
   for (int j = 0; j < 2; j++)
 #pragma unroll
@@ -212,15 +220,29 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
   }
 }
 
+template <int XK>
+static hipError_t launch_gru_x3_k(const GruX3Batch& bt, hipStream_t st) {
+  const GruX3Args& g = bt.g[0];
+  size_t lds = 2 * 4 * XT * XK * 2;   // two chunk buffers of four tiles ...
+  if (lds < (size_t)XT * (XT + 4) * 4) lds = (size_t)XT * (XT + 4) * 4;   // ... or the fp32 result tile of the epilogue
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_x3<XK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_gru_x3<XK>, dim3((unsigned)((g.N + XT - 1) / XT), (unsigned)((g.M + XT - 1) / XT), (unsigned)bt.n), dim3(256), lds, st, bt);
+  return hipGetLastError();
+}
+
 hipError_t launch_gru_x3(const GruX3Batch& bt, hipStream_t st) {
   if (bt.n <= 0 || bt.g[0].M <= 0) return hipSuccess;
   const GruX3Args& g = bt.g[0];
+  bool k64 = true;
   for (int i = 0; i < bt.n; i++) {   // one grid for the batch: same shape, same epilogue kind
     const GruX3Args& q = bt.g[i];
-    if ((q.K1 % XK) || (q.K2 % XK) || (q.N & 31) || q.N != g.N || q.M != g.M || q.epi != g.epi) return hipErrorInvalidValue;
+    if ((q.K1 % XK_MIN) || (q.K2 % XK_MIN) || (q.N & 31) || q.N != g.N || q.M != g.M || q.epi != g.epi) return hipErrorInvalidValue;
+    k64 = k64 && (q.K1 % 64) == 0 && (q.K2 % 64) == 0;
   }
-  hipLaunchKernelGGL(k_gru_x3, dim3((unsigned)((g.N + XT - 1) / XT), (unsigned)((g.M + XT - 1) / XT), (unsigned)bt.n), dim3(256), 0, st, bt);
-  return hipGetLastError();
+  const int64_t tiles = (int64_t)((g.N + XT - 1) / XT) * ((g.M + XT - 1) / XT) * bt.n;
+  if (k64 && tiles <= 256) return launch_gru_x3_k<64>(bt, st);   // fewer workgroups than CUs: nothing to overlap with, half the barriers
+  return launch_gru_x3_k<32>(bt, st);
 }
 
 // v [rows][cols] fp32 -> hi, lo (16-bit storage type): v ~ hi + lo
@@ -243,7 +265,7 @@ hipError_t launch_split_f32(const float* v, int64_t n, uint16_t* hi, uint16_t* l
 
 bool gru_x3_applies(const ModelDev& m) {
   if (!m.low_gru || !m.lgru_split || getenv("HIERTCN_LGRU_FP32")) return false;
-  return (m.E % XK) == 0 && (m.H % XK) == 0;
+  return (m.E % XK_MIN) == 0 && (m.H % XK_MIN) == 0;
 }
 
 hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st) {
