@@ -1043,6 +1043,9 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     post5(y, st[0]);                                                                         \
   } while (0)
 
+#ifdef HIERTCN_SCORE_SETPRIO   // experiment (MI355X_MICROARCH.md, two waves per SIMD, item 4): static priority for the second-dispatched half
+  if (wave >= 4) __builtin_amdgcn_s_setprio(1);
+#endif
   f32x16 accA, accB;
   if constexpr (SEAM1 && NSTG == 2) {
     // two LDS stages (three 64 KB stages do not fit at C = 512): the freed buffer is refilled between the two phases of an iteration, and
