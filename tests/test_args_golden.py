@@ -43,3 +43,10 @@ def test_the_fixture_covers_the_adjust_rules_and_the_name():
     assert FIX["single_gru"]["namespace"]["hidden_dim"] == 200                                  # args.py:306-307
     assert FIX["overrides"]["namespace"]["name"].endswith("warm")                               # args.py:282-283
     assert len(FIX["defaults"]["namespace"]) >= 70
+
+
+def test_sigma_none_selects_the_learned_scale():
+    """`if not args.sigma` (model_tcn_gmm.py:39, model_gru_gmm.py:50) is the reference's switch for a learned scale; the reference's untyped
+    flag can only express it by editing the default -- here `--sigma none` (or 0) parses to None, any number to a float."""
+    assert make_args(["--sigma", "none"]).sigma is None and make_args(["--sigma", "0"]).sigma is None
+    assert make_args(["--sigma", "0.25"]).sigma == 0.25 and make_args([]).sigma == 0.1
