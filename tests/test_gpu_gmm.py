@@ -166,7 +166,8 @@ def test_reference_surface_model_gru_gmm():
     MG.reset_scopes()
 
 
-def test_run_gmm_evaluation_loop_on_the_synthetic_xing_file(tmp_path):
+@pytest.mark.parametrize("sigma", [0.1, None], ids=["fixed_sigma", "learned_scale"])
+def test_run_gmm_evaluation_loop_on_the_synthetic_xing_file(tmp_path, sigma):
     """run_gmm_xing.evaluate_gmm (the evaluate_nn-shaped loop behind `run_xing --model_type tcn_gmm`): per batch the masked lane mean
     (model.py:111-117) of the mixture loss through hiertcn_gmm_lane_loss, epoch value = mean over batches; against the oracle on the
     device's own hidden rows, batch for batch."""
@@ -178,6 +179,7 @@ def test_run_gmm_evaluation_loop_on_the_synthetic_xing_file(tmp_path):
     data = load_xing(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interactions_synth.csv"))
     N = int(data[1][:, 1].max()) + 1
     a = _args(N, 3, (64, 64), 3)
+    a.sigma = sigma                       # None: `--sigma none`, M (1 + 2 D) head outputs
     a.batch_size = 5
     a.log_path = str(tmp_path) + "/log/"
     os.makedirs(a.log_path + "test/")
