@@ -345,3 +345,55 @@ def test_model_hier_with_the_mixture_model_as_its_low_level(sigma):
         assert np.abs(got - want)[live].max() < 2e-4 * max(1.0, np.abs(want[live]).max()), (mode, np.abs(got - want)[live].max())
         assert not got[~live].any()
     HG.reset_scopes()
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_mixture_loss_fuzz_shapes(seed, monkeypatch):
+    """Random head shapes (last width 64 / 128 / 256, D from just above 3 C to a few thousand and not a multiple of 32, 1..16 mixtures, row counts
+    from 1 to ~900 that are no multiple of anything): the Gram form against the table pass on the same rows (fixed sigma), and the learned-scale
+    pass against the density rebuilt on the host from the materialised means / log-scales (hiertcn_gmm_head_means) -- both losses, null targets."""
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    rng = np.random.default_rng(1000 + seed)
+    C = int(rng.choice([64, 128, 256]))
+    D = int(rng.integers(3 * C + 1, 3 * C + 2500))
+    M = int(rng.integers(1, 17))
+    R = int(rng.integers(1, 900))
+    a = _args(D, M, (C,), 2)
+    p = G.init_params(a, seed=seed)
+    p["tcn_gmm/fully_connected/biases"] = (0.2 * rng.standard_normal(p["tcn_gmm/fully_connected/biases"].shape)).astype(np.float32)
+    hid = (torch.as_tensor(rng.standard_normal((R, C)).astype(np.float32)).to("cuda:0") * 0.8).relu().to(torch.bfloat16)
+    yn = rng.integers(0, D, R).astype(np.int32)
+    yn[rng.random(R) < 0.2] = 0
+    y = torch.as_tensor(yn).to("cuda:0")
+    out = {}
+    for name, env in (("gram", None), ("table", "1")):
+        if env:
+            monkeypatch.setenv("HIERTCN_GMM_TABLE_PASS", env)
+        else:
+            monkeypatch.delenv("HIERTCN_GMM_TABLE_PASS", raising=False)
+        model = TcnGmmModel(a, p)
+        out[name] = [model.loss_rows(hid, y, mode).cpu().numpy().astype(np.float64) for mode in ("gmm_prob", "gmm_prob_max")]
+        model.close()
+    monkeypatch.delenv("HIERTCN_GMM_TABLE_PASS", raising=False)
+    for g_, t_ in zip(out["gram"], out["table"]):
+        assert np.abs(g_ - t_).max() < 2e-5 * max(1.0, np.abs(t_).max()), (C, D, M, R, np.abs(g_ - t_).max())
+        assert not g_[yn == 0].any()
+    # learned scale on the same rows
+    a.sigma = None
+    p2 = G.init_params(a, seed=seed + 50)
+    p2["tcn_gmm/fully_connected/weights"][:, M + M * D:] *= 5.0
+    p2["tcn_gmm/fully_connected/biases"] = (0.1 * rng.standard_normal(p2["tcn_gmm/fully_connected/biases"].shape)).astype(np.float32)
+    model = TcnGmmModel(a, p2)
+    mu = np.stack([model.head_means(hid, m).cpu().numpy().astype(np.float64) for m in range(M)], 1)            # [R, M, D]
+    sc = np.stack([model.head_means(hid, M + m).cpu().numpy().astype(np.float64) for m in range(M)], 1)
+    _, _, _, pl = model.loss_rows(hid, y, "gmm_prob", parts=True)
+    pred = np.concatenate([pl.cpu().numpy().astype(np.float64), mu.reshape(R, -1), sc.reshape(R, -1)], -1)[None]   # [1, R, M (1 + 2 D)]
+    live = yn > 0
+    for mode in ("gmm_prob", "gmm_prob_max"):
+        a.loss = mode
+        got = model.loss_rows(hid, y, mode).cpu().numpy()
+        want = G.calc_loss_gmm_ids(pred, yn[None], a)[0]
+        if live.any():
+            assert np.abs(got - want)[live].max() < 3e-4 * max(1.0, np.abs(want[live]).max()), (C, D, M, R, mode)
+        assert not got[~live].any()
+    model.close()
