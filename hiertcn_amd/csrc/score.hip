@@ -1022,18 +1022,41 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     post5(y, st[0]);                                                                         \
   } while (0)
 
-  // C = 512 (32 k-steps per tile, a value drained every second gap, no list test): the same seamless phase
-#define SC_PHASE1W(x, y, buf_, ib_, MF, nbuf_, nib_)                                          \
+  // C = 512 (32 k-steps per tile, a value drained every second gap): the same seamless phase.  With lists (KT > 0) the tile's maximum is folded in
+  // the odd gaps 1, 3, 5 and the wave votes in gap 7 -- the last one before the next tile's bias starts to overwrite the drained values.
+#define SC_GAPW(x, y, s)                                                                     \
+      if (MF_) {                                                                             \
+        ring4_[((s) + 3) & 3] = *reinterpret_cast<const uint4*>(((s) + 3 < 32) ? tile_ + SC_FRAG((s) + 3) : ntile_ + SC_FRAG((s) + 3 - 32)); \
+        x = mfma32(ring4_[(s) & 3], hf[0][s], x);                                            \
+      }                                                                                      \
+      if (((s) & 1) == 0) val5((s) >> 1, y[(s) >> 1], st[0]);
+#define SC_PHASE1W(x, y, buf_, ib_, MF, nbuf_, nib_, dit_)                                    \
   do {                                                                                       \
+    constexpr bool MF_ = MF;                                                                 \
     const unsigned char* tile_ = smem + (buf_) * STAGE_LDS + (ib_) * TILE_LDS;               \
     const unsigned char* ntile_ = smem + (nbuf_) * STAGE_LDS + (nib_) * TILE_LDS;            \
     const float* nbias_ = sbias + (nbuf_) * SC_STAGE + (nib_) * 32 + 4 * lh;                 \
-    _Pragma("unroll") for (int s = 0; s < 32; s++) {                                         \
-      if (MF) {                                                                              \
-        ring4_[(s + 3) & 3] = *reinterpret_cast<const uint4*>((s + 3 < 32) ? tile_ + SC_FRAG(s + 3) : ntile_ + SC_FRAG(s + 3 - 32)); \
-        x = mfma32(ring4_[s & 3], hf[0][s], x);                                              \
-      }                                                                                      \
-      if ((s & 1) == 0) val5(s >> 1, y[s >> 1], st[0]);                                      \
+    /* gaps 0..7 written out: the list test (its slow path is a call-sized body) must not sit inside an unrolled loop, or hipcc gives up the unroll \
+       and indexes the 128 registers of the B operand dynamically -- through scratch */      \
+    SC_GAPW(x, y, 0) __builtin_amdgcn_sched_barrier(0);                                      \
+    SC_GAPW(x, y, 1) if (KT > 0) tk_m = fmaxf(fmaxf(fmaxf(y[0], y[1]), y[2]), fmaxf(y[3], y[4]));      __builtin_amdgcn_sched_barrier(0); \
+    SC_GAPW(x, y, 2) __builtin_amdgcn_sched_barrier(0);                                      \
+    SC_GAPW(x, y, 3) if (KT > 0) tk_m = fmaxf(fmaxf(fmaxf(tk_m, y[5]), y[6]), fmaxf(y[7], y[8]));      __builtin_amdgcn_sched_barrier(0); \
+    SC_GAPW(x, y, 4) __builtin_amdgcn_sched_barrier(0);                                      \
+    SC_GAPW(x, y, 5) if (KT > 0) tk_m = fmaxf(fmaxf(fmaxf(tk_m, y[9]), y[10]), fmaxf(y[11], y[12]));   __builtin_amdgcn_sched_barrier(0); \
+    SC_GAPW(x, y, 6) __builtin_amdgcn_sched_barrier(0);                                      \
+    SC_GAPW(x, y, 7)                                                                         \
+    if (KT > 0) {                                                                            \
+      tk_m = fmaxf(fmaxf(fmaxf(tk_m, y[13]), y[14]), y[15]);                                 \
+      if (__any(tk_m > top.v[KTA - 1])) top_tile_slow<KTA>(top, y, dit_);                    \
+    }                                                                                        \
+    {                                                                                        \
+      const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_);                             \
+      _Pragma("unroll") for (int j = 0; j < 4; j++) y[j] = b4_[j];                           \
+    }                                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                       \
+    _Pragma("unroll") for (int s = 8; s < 32; s++) {                                         \
+      SC_GAPW(x, y, s)                                                                       \
       if ((s & 7) == 7) {                                                                    \
         const f32x4 b4_ = *reinterpret_cast<const f32x4*>(nbias_ + 8 * (s >> 3));           \
         _Pragma("unroll") for (int j = 0; j < 4; j++) y[4 * (s >> 3) + j] = b4_[j];          \
@@ -1051,7 +1074,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     // two LDS stages (three 64 KB stages do not fit at C = 512): the freed buffer is refilled between the two phases of an iteration, and
     // a second wait + barrier behind the second phase makes sure the stage has landed before the next iteration's first phase reads its
     // first fragments across the tile boundary
-    static_assert(C == 512 && KT == 0, "the two-stage seamless loop is written for C = 512 without lists");
+    static_assert(C == 512, "the two-stage seamless loop is written for C = 512");
     uint4 ring4_[4];
     if (n_stages > 0) stage_issue(0, 0);
     if (n_stages > 1) stage_issue(1, 1);
@@ -1070,17 +1093,17 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     }
     for (int stg = 0; stg + 1 < n_stages; stg++) {
       const int buf = stg & 1;
-      SC_PHASE1W(accB, accA, buf, 1, true, buf ^ 1, 0);        // MFMA (stg, ib1)   || epilogue (stg, ib0); accA <- bias (stg+1, ib0)
+      SC_PHASE1W(accB, accA, buf, 1, true, buf ^ 1, 0, (stg_lo + stg) * SC_STAGE + 4 * lh);        // MFMA (stg, ib1)   || epilogue (stg, ib0); accA <- bias (stg+1, ib0)
       __syncthreads();                                          // every wave is done with stage stg: its buffer takes stage stg + 2
       if (stg + 2 < n_stages) stage_issue(stg + 2, buf);
-      SC_PHASE1W(accA, accB, buf ^ 1, 0, true, buf ^ 1, 1);    // MFMA (stg+1, ib0) || epilogue (stg, ib1); accB <- bias (stg+1, ib1)
+      SC_PHASE1W(accA, accB, buf ^ 1, 0, true, buf ^ 1, 1, (stg_lo + stg) * SC_STAGE + 32 + 4 * lh);    // MFMA (stg+1, ib0) || epilogue (stg, ib1); accB <- bias (stg+1, ib1)
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();                                          // stage stg + 2 has landed (the next first phase reads it at its tail)
     }
     if (n_stages > 0) {
       const int buf = (n_stages - 1) & 1;
-      SC_PHASE1W(accB, accA, buf, 1, true, buf, 1);            // (the "next tile" reads land in dead registers)
-      SC_PHASE1W(accA, accB, buf, 1, false, buf, 1);           // epilogue of the last tile only
+      SC_PHASE1W(accB, accA, buf, 1, true, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 4 * lh);            // (the "next tile" reads land in dead registers)
+      SC_PHASE1W(accA, accB, buf, 1, false, buf, 1, (stg_lo + n_stages - 1) * SC_STAGE + 32 + 4 * lh);           // epilogue of the last tile only
     }
   } else if constexpr (SEAM1) {
     static_assert(G::KS >= 4, "the four-deep fragment ring needs at least four k-steps");
@@ -1238,6 +1261,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 #undef SC_PHASE3
 #undef SC_PHASE1
 #undef SC_PHASE1W
+#undef SC_GAPW
 #undef SC_GAP1
 #undef SC_FRAG
 
@@ -1418,6 +1442,24 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
       return out->ce ? launch_score_fixup<C, 2, 3, PADI>(m, hidden, y, R, out, st, row_map, n_rows_dev, (int*)nullptr) : hipSuccess;
     }
   }
+  if constexpr (C == 512) {
+    // the two-stage seamless kernel of the loss + rank flavour (k_score_pipe<512, 15, 1, 2, pad>) with the list test in its gaps + the fix-up launch;
+    // HIERTCN_TOPK512_V1=1: the un-pipelined kernel it replaces (launch_score_512: 175 ms per 307,200 x 300,000 launch against 72 for loss + rank)
+    if (!getenv("HIERTCN_TOPK512_V1")) {
+      const size_t pitch = 1024 + 16;
+      size_t lds = 2 * (G::STAGE_BYTES / 1024) * pitch + 2 * SC_STAGE * sizeof(float);
+      const size_t merge = (size_t)SC_THREADS * KT * 8;
+      if (merge > lds) lds = merge;
+      auto kern = k_score_pipe<512, 15, 1, 2, true, false, KT>;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL(kern, dim3((unsigned)((R + 255) / 256)), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP, out->rank,
+                         out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, (int*)nullptr, out->topk_idx, out->topk_val, (int)out->topk);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+      return out->ce ? launch_score_fixup<512, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, (int*)nullptr) : hipSuccess;
+    }
+    return hipErrorNotSupported;   // (the caller falls back to launch_score_512)
+  } else {
   if (!getenv("HIERTCN_TOPK_V1")) {   // the pipelined skeleton (epilogue in the MFMA gaps, one step block per wave, two LDS stages); V1: A/B
     constexpr bool PADI = C >= 256;
     const size_t pitch = PADI ? 1024 + (C == 256 ? 32 : 16) : 1024;
@@ -1442,6 +1484,7 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
                      out->target, (float*)nullptr, 0, (unsigned long long*)nullptr, out->topk_idx, out->topk_val, (int)out->topk,
                      (const float*)nullptr, (const float*)nullptr, 0, -1, row_map, n_rows_dev);
   return hipGetLastError();
+  }
 }
 
 template <int C>
@@ -1643,6 +1686,10 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
     case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
     case 512:   // (dense rows: callers zero-fill nothing here, the kernel writes rank 0 / ce 0 on masked rows itself)
       if (logits) return launch_score_512<true, 0, 0>(m, hidden, y, R, nullptr, logits, nullptr, nullptr, 0, -1, st);
+      if (out && out->topk > 0 && !getenv("HIERTCN_TOPK512_V1"))   // lists in the gaps of the seamless two-stage kernel (round 3)
+        return out->topk <= 8    ? launch_score_topk<512, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev)
+               : out->topk <= 10 ? launch_score_topk<512, 10>(m, hidden, y, R, out, st, row_map, n_rows_dev)
+                                 : launch_score_topk<512, 16>(m, hidden, y, R, out, st, row_map, n_rows_dev);
       if (out && out->topk > 8) return launch_score_512<false, 0, 16>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st, row_map, n_rows_dev);
       if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st, row_map, n_rows_dev);
       if (getenv("HIERTCN_SCORE512_V1")) return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);   // A/B

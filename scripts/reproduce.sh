@@ -21,6 +21,7 @@ echo "== d = 512, N = 1,000,000 (bf16, then the IEEE-half build)"
 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
 DTYPE=fp16 D=512 python3 scripts/score_diag.py 614400 1000000 2>&1 | tail -1
 echo "== ranked top-k flavour"; python3 scripts/topk_bench.py 2>&1 | tail -3
+echo "== ranked top-k flavour at d = 512 (307,200 rows x 300,000 items)"; D=512 python3 scripts/topk_bench.py 2>&1 | tail -3
 echo "== training step (1024 users), dense / ragged / previous scoring backward (G chunks + the plain GEMMs of gemm.hip) / HierGRU"
 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 python3 scripts/train_bench.py 1024 3 ragged 2>&1 | tail -1
