@@ -181,8 +181,9 @@ __global__ void k_gmm_interleave(const uint16_t* __restrict__ muT, const float* 
   const int d = (row >> 6) * 32 + (row & 31);            // output of this row
   const int tab = (row & 32) ? M + m : m;                 // second half of a stage: the log-scale table
   const bool in = d < DP;
-  const uint4 z = make_uint4(0, 0, 0, 0);
-  *reinterpret_cast<uint4*>(sgT + ((size_t)m * NPs + row) * C + c) = in ? *reinterpret_cast<const uint4*>(muT + ((size_t)tab * DP + d) * C + c) : z;
+  uint4 v = make_uint4(0, 0, 0, 0);
+  if (in) v = *reinterpret_cast<const uint4*>(muT + ((size_t)tab * DP + d) * C + c);   // (cond ? *ptr : zero would go through scratch)
+  *reinterpret_cast<uint4*>(sgT + ((size_t)m * NPs + row) * C + c) = v;
   if (c == 0) sg_bias[(size_t)m * NPs + row] = in ? mu_bias[(size_t)tab * DP + d] : 0.f;
 }
 // svec[m][c] = sum_d table_{M+m}[d][c], s0[m] = sum_d bias_{M+m}[d]   (fp64 sums of the stored values)
