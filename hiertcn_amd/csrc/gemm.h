@@ -10,6 +10,11 @@ hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, f
 hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int N1, int N2, int Mred, float beta,
                      float* scratch, size_t scratch_floats, hipStream_t st);
 
+//   TN over slabs: reduction row m of A (B) lies at (m / a_div) * a_ss + (m % a_div) * lda when a_div > 0 (else m * lda): ONE product over the rows of
+//   many records that are a fixed distance apart -- the deferred weight gradients of a scan (train.hip)
+hipError_t gemm32_tn_slabs(const float* A, int64_t lda, int a_div, int64_t a_ss, const float* B, int64_t ldb, int b_div, int64_t b_ss, float* C,
+                           int64_t ldc, int N1, int N2, int Mred, float beta, float* scratch, size_t scratch_floats, hipStream_t st);
+
 // 16-bit storage operands (the library's storage type), fp32 results; row shifts per tap inside sequences of L rows (L = 0: none)
 //   NT: C[M][N] (ldc) = beta C + sum_taps A[r + shift_tap][K] (lda) . Bt[tap][N][K]^T (ldb)
 hipError_t gemm16_nt(const uint16_t* A, int64_t lda, const uint16_t* Bt, int64_t ldb, float* C, int64_t ldc, int64_t M, int N, int K, int taps,

@@ -32,6 +32,9 @@ struct G32 {
   int k_per_split;      // multiple of GK
   float beta;
   float* parts;         // splits > 1: partial tiles [split][M][N], C untouched
+  // k-major operands only (the TN form): reduction row k of A / B lies at (k / div) * ss + (k % div) * ld instead of k * ld when div > 0 -- the
+  // rows of one GEMM gathered from `K / div` slabs that are `ss` apart (the per-slot records of a scan: train.hip)
+  int a_div, b_div; int64_t a_ss, b_ss;
 };
 
 // AK: A element (i, k) at A[k * lda + i] (k-major rows) instead of A[i * lda + k]; BK likewise: B element (k, j) at B[k * ldb + j]
@@ -48,11 +51,12 @@ __global__ __launch_bounds__(256) void k_gemm32(const G32 g) {
   const int n_it = (k_hi - k_lo + GK - 1) / GK;
 
   float4 ra[4], rb[4];
-  auto fetch_one = [&](const float* P, int64_t ld, int mn0, int MN, bool kmaj, int kc, int p) -> float4 {
+  auto fetch_one = [&](const float* P, int64_t ld, int mn0, int MN, bool kmaj, int kc, int p, int div, int64_t ss) -> float4 {
     float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
     if (kmaj) {          // tile [32 k][128 mn]: thread -> k = tid / 32 + 8 p, mn = 4 (tid % 32)
       const int k = kc + (tid >> 5) + 8 * p, mn = mn0 + (tid & 31) * 4;
-      if (k < k_hi && mn < MN) v = *reinterpret_cast<const float4*>(P + (int64_t)k * ld + mn);
+      const int64_t ro = div > 0 ? (int64_t)(k / div) * ss + (int64_t)(k % div) * ld : (int64_t)k * ld;
+      if (k < k_hi && mn < MN) v = *reinterpret_cast<const float4*>(P + ro + mn);
     } else {             // tile [128 mn][32 k]: thread -> mn = tid / 8 + 32 p, k = 4 (tid % 8)
       const int mn = mn0 + (tid >> 3) + 32 * p, k = kc + (tid & 7) * 4;
       if (mn < MN && k < k_hi) v = *reinterpret_cast<const float4*>(P + (int64_t)mn * ld + k);
@@ -63,8 +67,8 @@ __global__ __launch_bounds__(256) void k_gemm32(const G32 g) {
     const int kc = k_lo + it * GK;
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      ra[p] = fetch_one(g.A, g.lda, m0, g.M, AK, kc, p);
-      rb[p] = fetch_one(g.B, g.ldb, n0, g.N, BK, kc, p);
+      ra[p] = fetch_one(g.A, g.lda, m0, g.M, AK, kc, p, g.a_div, g.a_ss);
+      rb[p] = fetch_one(g.B, g.ldb, n0, g.N, BK, kc, p, g.b_div, g.b_ss);
     }
   };
   auto stash = [&](float* T, const float4* r, bool kmaj) {
@@ -150,7 +154,7 @@ static int pick_splits(int tiles, int K, int64_t MN, size_t scratch_floats) {
 
 template <bool AK, bool BK>
 static hipError_t run32(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta,
-                        float* scratch, size_t scratch_floats, hipStream_t st) {
+                        float* scratch, size_t scratch_floats, hipStream_t st, int a_div = 0, int64_t a_ss = 0, int b_div = 0, int64_t b_ss = 0) {
   if (M <= 0 || N <= 0) return hipSuccess;
   const int tm = (M + GT - 1) / GT, tn = (N + GT - 1) / GT;
   const int splits = scratch ? pick_splits(tm * tn, K, (int64_t)M * N, scratch_floats) : 1;
@@ -158,6 +162,7 @@ static hipError_t run32(const float* A, int64_t lda, const float* B, int64_t ldb
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.beta = beta;
   g.k_per_split = (((K + splits - 1) / splits) + GK - 1) / GK * GK;
   g.parts = splits > 1 ? scratch : nullptr;
+  g.a_div = a_div; g.a_ss = a_ss; g.b_div = b_div; g.b_ss = b_ss;
   hipLaunchKernelGGL((k_gemm32<AK, BK>), dim3(tn, tm, splits), dim3(256), 0, st, g);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess || splits == 1) return e;
@@ -175,6 +180,12 @@ hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, f
                      float* scratch, size_t scratch_floats, hipStream_t st) {
   if ((N1 & 3) || (N2 & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along the output dimensions
   return run32<true, true>(A, lda, B, ldb, C, ldc, N1, N2, Mred, beta, scratch, scratch_floats, st);
+}
+
+hipError_t gemm32_tn_slabs(const float* A, int64_t lda, int a_div, int64_t a_ss, const float* B, int64_t ldb, int b_div, int64_t b_ss, float* C,
+                           int64_t ldc, int N1, int N2, int Mred, float beta, float* scratch, size_t scratch_floats, hipStream_t st) {
+  if ((N1 & 3) || (N2 & 3) || (lda & 3) || (ldb & 3) || (a_ss & 3) || (b_ss & 3) || a_div < 0 || b_div < 0) return hipErrorInvalidValue;
+  return run32<true, true>(A, lda, B, ldb, C, ldc, N1, N2, Mred, beta, scratch, scratch_floats, st, a_div, a_ss, b_div, b_ss);
 }
 
 // =================================================================================================================================

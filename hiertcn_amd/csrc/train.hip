@@ -676,7 +676,9 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.dpooled = take((size_t)B * S * E * 4);
   w.dstate[0] = take((size_t)B * HT * 4); w.dstate[1] = take((size_t)B * HT * 4);
   w.dhp = take((size_t)B * HT * 4);
-  w.dac = take((size_t)B * H * 4); w.dag = take((size_t)B * 2 * H * 4); w.dhpart = take((size_t)B * H * 4);
+  // the gate / candidate pre-activation gradients of EVERY (slot, layer) cell of the across-session scan: [nl][S][B][H] and [nl][S][B][2H] -- the
+  // weight gradients are formed behind the scan in one product per layer and operand instead of two per cell
+  w.dac = take((size_t)m.nl * S * B * H * 4); w.dag = take((size_t)m.nl * S * B * 2 * H * 4); w.dhpart = take((size_t)B * H * 4);
   const size_t Kmax = (E > H ? E : H) + H;
   w.dcat_c = take((size_t)B * Kmax * 4); w.dcat_g = take((size_t)B * Kmax * 4); w.din_up = take((size_t)B * H * 4);
   if (m.low_gru) {
@@ -1003,8 +1005,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   float* dnext = F32(w.dstate[1]);
   T_HIP(hipMemsetAsync(dcar, 0, (size_t)B * HT * 4, st));
   float* dhp = F32(w.dhp);
-  float* dac = F32(w.dac);
-  float* dag = F32(w.dag);
+  float* dac_all = F32(w.dac);
+  float* dag_all = F32(w.dag);
   float* dhpart = F32(w.dhpart);
   float* dcat_c = F32(w.dcat_c);
   float* dcat_g = F32(w.dcat_g);
@@ -1026,23 +1028,18 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       const float* cand = rec + (size_t)B * 3 * H;
       const float* hold = hist + (size_t)s * HT + (size_t)l * H;   // row stride hs
       const float* inp = (l == 0) ? pooled + (size_t)s * E : gsave + ((size_t)s * m.nl + (l - 1)) * cell + (size_t)B * 4 * H;
-      const int ldin = (l == 0) ? S * E : H;
+      (void)rh; (void)inp;
+      float* dac = dac_all + ((size_t)l * S + s) * B * H;        // this cell's slots: kept for the weight gradients behind the scan
+      float* dag = dag_all + ((size_t)l * S + s) * B * 2 * H;
       hipLaunchKernelGGL(k_gru_bwd_a, dim3(gBH), dim3(256), 0, st, dhp + (size_t)l * H, HT, (l < m.nl - 1) ? din_up : nullptr, hold, (int)hs,
                          gates, cand, B, H, dac, dag, dhpart);
       T_HIP(hipGetLastError());
       // d[in | r*h] [B][K] = dac[B][H] . wc[H][K]   == col-major [K x B] = wc(col-major [K x H]) . dac^T[H x B]
       T_HIP(gemm32_nn(dac, H, m.gru_wc[l], K, dcat_c, K, B, K, H, 0.f, st));
-      // d wc[H][K] += dac^T[H x B] . [in | r*h][B][K]   == col-major [K x H], rows [0,in) from `in`, rows [in,K) from r*h
-      T_HIP(gemm32_tn(dac, H, inp, ldin, G + t.wc[l].off, K, H, in, B, 1.f, F32(w.splitk), w.splitk_floats, st));
-      T_HIP(gemm32_tn(dac, H, rh, H, G + t.wc[l].off + in, K, H, H, B, 1.f, F32(w.splitk), w.splitk_floats, st));
-      T_HIP(colsum_f32(dac, B, H, H, G + t.bc[l].off, st));
       hipLaunchKernelGGL(k_gru_bwd_b, dim3(gBH), dim3(256), 0, st, dcat_c, K, in, hold, (int)hs, gates, B, H, dag, dhpart);
       T_HIP(hipGetLastError());
       // d[in | h] [B][K] = dag[B][2H] . wg[2H][K]
       T_HIP(gemm32_nn(dag, 2 * H, m.gru_wg[l], K, dcat_g, K, B, K, 2 * H, 0.f, st));
-      T_HIP(gemm32_tn(dag, 2 * H, inp, ldin, G + t.wg[l].off, K, 2 * H, in, B, 1.f, F32(w.splitk), w.splitk_floats, st));
-      T_HIP(gemm32_tn(dag, 2 * H, hold, (int)hs, G + t.wg[l].off + in, K, 2 * H, H, B, 1.f, F32(w.splitk), w.splitk_floats, st));
-      T_HIP(colsum_f32(dag, B, 2 * H, 2 * H, G + t.bg[l].off, st));
       float* dst_in = (l == 0) ? dpooled + (size_t)s * E : din_up;
       const int ldi = (l == 0) ? S * E : H;
       const int Wd = in > H ? in : H;
@@ -1051,6 +1048,27 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       T_HIP(hipGetLastError());
     }
     float* tmp = dcar; dcar = dnext; dnext = tmp;
+  }
+  // Weight gradients of the scan, behind it: d wc[H][K] = sum over ALL (slot, lane) rows of dac^T . [in | r*h], d wg likewise with [in | h] -- one
+  // product per layer and operand over S * B rows instead of one per cell over B (at the reference's 32 lanes a cell's product is 8 workgroups of 20
+  // chunks: 161 launches of 14 us were a third of the training step).  The operands stay where the forward left them: row (s, b) of `in` / r*h / h is
+  // addressed as slab s (the slot's record, the slot's column of `pooled` / `hist`) + lane b (gemm32_tn_slabs).
+  for (int l = 0; l < m.nl; l++) {
+    const int in = (l == 0) ? E : H;
+    const int K = in + H;
+    const float* dac = dac_all + (size_t)l * S * B * H;
+    const float* dag = dag_all + (size_t)l * S * B * 2 * H;
+    const float* inp = (l == 0) ? pooled : gsave + (size_t)(l - 1) * cell + (size_t)B * 4 * H;
+    const int64_t in_ld = (l == 0) ? (int64_t)S * E : H, in_ss = (l == 0) ? (int64_t)E : (int64_t)m.nl * cell;
+    const float* rh = gsave + (size_t)l * cell + (size_t)B * 2 * H;
+    const float* hold = hist + (size_t)l * H;
+    const int SB = S * B;
+    T_HIP(gemm32_tn_slabs(dac, H, 0, 0, inp, in_ld, B, in_ss, G + t.wc[l].off, K, H, in, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
+    T_HIP(gemm32_tn_slabs(dac, H, 0, 0, rh, H, B, (int64_t)m.nl * cell, G + t.wc[l].off + in, K, H, H, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
+    T_HIP(colsum_f32(dac, SB, H, H, G + t.bc[l].off, st));
+    T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, inp, in_ld, B, in_ss, G + t.wg[l].off, K, 2 * H, in, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
+    T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, hold, hs, B, (int64_t)HT, G + t.wg[l].off + in, K, 2 * H, H, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
+    T_HIP(colsum_f32(dag, SB, 2 * H, 2 * H, G + t.bg[l].off, st));
   }
   // ================= session mean-pool + 'emb' bias (model_hier.py:83-85) ================================
   T_HIP(colsum_f32(dpooled, n_sess, E, E, G + t.emb_bias.off, st));
