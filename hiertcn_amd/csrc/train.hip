@@ -604,6 +604,13 @@ struct TrainWs {
 
 // The scoring layer's backward: score_bwd.hip (no d-logits matrix, no rocBLAS, no host read-back) where the kernel is built for the
 // width; HIERTCN_TRAIN_LEGACY=1 selects the previous path (G chunks + two rocBLAS products per chunk) for A/B runs.
+// HierGRU low level: keep the pre-activation gradients of every (step, layer) cell and form the weight gradients behind the BPTT loop (as the
+// across-session scan always does) while that costs at most 1 GiB: the launch-bound regime (the reference's 32 lanes = 640 sessions: 118 MB).  Past
+// it a cell's products fill the chip by themselves and the 15 GB this would take at the bench shape buy nothing.
+static bool lgru_deferred_wgrad(const ModelDev& m, size_t M, int L) {
+  return (size_t)m.nl * L * M * 3 * m.H * 4 <= ((size_t)1 << 30) && !getenv("HIERTCN_LGRU_WGRAD_PER_CELL");
+}
+
 static bool fused_scoring_backward(const ModelDev& m) { return sgrad_supported(m) && !getenv("HIERTCN_TRAIN_LEGACY"); }
 
 static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
@@ -687,7 +694,8 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     w.lg_x3 = take(low_gru_x3_elems(m, (int64_t)M) * 2);
     w.lg_save = take(low_gru_save_floats(m, (int64_t)M, L) * 4);
     w.lg_dcar[0] = take(M * HT * 4); w.lg_dcar[1] = take(M * HT * 4);
-    w.lg_dac = take(M * H * 4); w.lg_dag = take(M * 2 * H * 4); w.lg_dhpart = take(M * H * 4);
+    const size_t cells = lgru_deferred_wgrad(m, M, L) ? (size_t)m.nl * L : 1;
+    w.lg_dac = take(cells * M * H * 4); w.lg_dag = take(cells * M * 2 * H * 4); w.lg_dhpart = take(M * H * 4);
     w.lg_dcat_c = take(M * Kmax * 4); w.lg_dcat_g = take(M * Kmax * 4); w.lg_din_up = take(M * H * 4);
   }
   w.total = off;
@@ -890,8 +898,9 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     float* lcar = F32(w.lg_dcar[0]);
     float* lnext = F32(w.lg_dcar[1]);
     T_HIP(hipMemsetAsync(lcar, 0, (size_t)M * HT * 4, st));   // the low level's final state is dropped (model_gru.py:47)
-    float* dac = F32(w.lg_dac);
-    float* dag = F32(w.lg_dag);
+    float* dac_all = F32(w.lg_dac);
+    float* dag_all = F32(w.lg_dag);
+    const bool deferred = lgru_deferred_wgrad(m, (size_t)M, L);
     float* dhpart = F32(w.lg_dhpart);
     float* dcat_c = F32(w.lg_dcat_c);
     float* dcat_g = F32(w.lg_dcat_g);
@@ -910,19 +919,25 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
         const int ldin = (l == 0) ? L * E : H;
         const float* dout = (l == m.nl - 1) ? dH + (size_t)tt * H : din_up;
         const int64_t ld_dout = (l == m.nl - 1) ? (int64_t)L * H : H;
+        float* dac = deferred ? dac_all + ((size_t)l * L + tt) * M * H : dac_all;
+        float* dag = deferred ? dag_all + ((size_t)l * L + tt) * M * 2 * H : dag_all;
         hipLaunchKernelGGL(k_lgru_bwd_a, dim3(gMH), dim3(256), 0, st, lcar + (size_t)l * H, HT, dout, ld_dout, lb.seq_len, tt, hold, HT, gates, cand,
                            M, H, dac, dag, dhpart);
         T_HIP(hipGetLastError());
         T_HIP(gemm32_nn(dac, H, m.lgru_wc[l], K, dcat_c, K, M, K, H, 0.f, st));
-        T_HIP(gemm32_tn(dac, H, inp, ldin, G + t.lwc[l].off, K, H, in, M, 1.f, F32(w.splitk), w.splitk_floats, st));
-        T_HIP(gemm32_tn(dac, H, rh, H, G + t.lwc[l].off + in, K, H, H, M, 1.f, F32(w.splitk), w.splitk_floats, st));
-        T_HIP(colsum_f32(dac, M, H, H, G + t.lbc[l].off, st));
+        if (!deferred) {
+          T_HIP(gemm32_tn(dac, H, inp, ldin, G + t.lwc[l].off, K, H, in, M, 1.f, F32(w.splitk), w.splitk_floats, st));
+          T_HIP(gemm32_tn(dac, H, rh, H, G + t.lwc[l].off + in, K, H, H, M, 1.f, F32(w.splitk), w.splitk_floats, st));
+          T_HIP(colsum_f32(dac, M, H, H, G + t.lbc[l].off, st));
+        }
         hipLaunchKernelGGL(k_gru_bwd_b, dim3(gMH), dim3(256), 0, st, dcat_c, K, in, hold, HT, gates, M, H, dag, dhpart);
         T_HIP(hipGetLastError());
         T_HIP(gemm32_nn(dag, 2 * H, m.lgru_wg[l], K, dcat_g, K, M, K, 2 * H, 0.f, st));
-        T_HIP(gemm32_tn(dag, 2 * H, inp, ldin, G + t.lwg[l].off, K, 2 * H, in, M, 1.f, F32(w.splitk), w.splitk_floats, st));
-        T_HIP(gemm32_tn(dag, 2 * H, hold, HT, G + t.lwg[l].off + in, K, 2 * H, H, M, 1.f, F32(w.splitk), w.splitk_floats, st));
-        T_HIP(colsum_f32(dag, M, 2 * H, 2 * H, G + t.lbg[l].off, st));
+        if (!deferred) {
+          T_HIP(gemm32_tn(dag, 2 * H, inp, ldin, G + t.lwg[l].off, K, 2 * H, in, M, 1.f, F32(w.splitk), w.splitk_floats, st));
+          T_HIP(gemm32_tn(dag, 2 * H, hold, HT, G + t.lwg[l].off + in, K, 2 * H, H, M, 1.f, F32(w.splitk), w.splitk_floats, st));
+          T_HIP(colsum_f32(dag, M, 2 * H, 2 * H, G + t.lbg[l].off, st));
+        }
         float* dst_in = (l == 0) ? du + (size_t)tt * E : din_up;
         const int64_t ldi = (l == 0) ? (int64_t)L * E : H;
         const int Wd = in > H ? in : H;
@@ -931,6 +946,25 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
         T_HIP(hipGetLastError());
       }
       float* tmp = lcar; lcar = lnext; lnext = tmp;
+    }
+    if (deferred) {   // the weight gradients of all L * nl cells: one product per layer and operand over the L * M rows (rows (t, m): slab t, session m)
+      for (int l = 0; l < m.nl; l++) {
+        const int in = (l == 0) ? E : H;
+        const int K = in + H;
+        const float* dac = dac_all + (size_t)l * L * M * H;
+        const float* dag = dag_all + (size_t)l * L * M * 2 * H;
+        const float* inp = (l == 0) ? lb.uf : lrec + (size_t)(l - 1) * lcell + (size_t)M * 4 * H;
+        const int64_t in_ld = (l == 0) ? (int64_t)L * E : H, in_ss = (l == 0) ? (int64_t)E : (int64_t)m.nl * lcell;
+        const float* rh = lrec + (size_t)l * lcell + (size_t)M * 2 * H;
+        const float* hold = lst + (size_t)l * H;   // states 0 .. L-1 are contiguous rows (t, m) of HT floats
+        const int LM = L * M;
+        T_HIP(gemm32_tn_slabs(dac, H, 0, 0, inp, in_ld, M, in_ss, G + t.lwc[l].off, K, H, in, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
+        T_HIP(gemm32_tn_slabs(dac, H, 0, 0, rh, H, M, (int64_t)m.nl * lcell, G + t.lwc[l].off + in, K, H, H, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
+        T_HIP(colsum_f32(dac, LM, H, H, G + t.lbc[l].off, st));
+        T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, inp, in_ld, M, in_ss, G + t.lwg[l].off, K, 2 * H, in, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
+        T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, hold, HT, 0, 0, G + t.lwg[l].off + in, K, 2 * H, H, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
+        T_HIP(colsum_f32(dag, LM, 2 * H, 2 * H, G + t.lbg[l].off, st));
+      }
     }
     da = du;
   }
