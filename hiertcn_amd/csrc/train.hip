@@ -239,24 +239,37 @@ __global__ void k_scatter_rows_f32(const float* __restrict__ src, const int32_t*
   *reinterpret_cast<float4*>(dst + (int64_t)map[p] * C + c) = *reinterpret_cast<const float4*>(src + p * C + c);
 }
 
-// out[c] += sum over rows of bf16 src[r][c]  (d bias of the scoring layer from a G chunk)
+// out[c] += sum over rows of bf16 src[r][c]  (d bias of a TemporalBlock / of the scoring layer from a G chunk).  512 rows per workgroup, four
+// independent partial sums per thread: at 4096 rows and one dependent chain of 512 loads per thread a [19,200 x 128] call (the reference's 32
+// lanes) ran 134 us on 20 workgroups.
+#define COLSUM16_ROWS 512
 __global__ __launch_bounds__(256) void k_colsum_bf16(const uint16_t* __restrict__ src, int64_t rows, int64_t ld, int cols,
                                                      float* __restrict__ out) {
   __shared__ float red[8][64];
   const int cx = threadIdx.x & 31, ry = threadIdx.x >> 5;  // 32 column pairs x 8 row lanes
   const int c0 = blockIdx.x * 64 + cx * 2;
-  const int64_t r0 = (int64_t)blockIdx.y * 4096;
-  const int64_t r1 = (r0 + 4096 < rows) ? r0 + 4096 : rows;
-  float s0 = 0.f, s1 = 0.f;
+  const int64_t r0 = (int64_t)blockIdx.y * COLSUM16_ROWS;
+  const int64_t r1 = (r0 + COLSUM16_ROWS < rows) ? r0 + COLSUM16_ROWS : rows;
+  float s0 = 0.f, s1 = 0.f, t0 = 0.f, t1 = 0.f, u0 = 0.f, u1 = 0.f, v0 = 0.f, v1 = 0.f;
   if (c0 < cols) {
-    for (int64_t r = r0 + ry; r < r1; r += 8) {
-      const uint32_t v = *reinterpret_cast<const uint32_t*>(src + r * ld + c0);
-      s0 += bf2f((uint16_t)(v & 0xffff));
-      s1 += bf2f((uint16_t)(v >> 16));
+    int64_t r = r0 + ry;
+    for (; r + 24 < r1; r += 32) {
+      const uint32_t a = *reinterpret_cast<const uint32_t*>(src + r * ld + c0);
+      const uint32_t b = *reinterpret_cast<const uint32_t*>(src + (r + 8) * ld + c0);
+      const uint32_t c = *reinterpret_cast<const uint32_t*>(src + (r + 16) * ld + c0);
+      const uint32_t d = *reinterpret_cast<const uint32_t*>(src + (r + 24) * ld + c0);
+      s0 += bf2f((uint16_t)(a & 0xffff)); s1 += bf2f((uint16_t)(a >> 16));
+      t0 += bf2f((uint16_t)(b & 0xffff)); t1 += bf2f((uint16_t)(b >> 16));
+      u0 += bf2f((uint16_t)(c & 0xffff)); u1 += bf2f((uint16_t)(c >> 16));
+      v0 += bf2f((uint16_t)(d & 0xffff)); v1 += bf2f((uint16_t)(d >> 16));
+    }
+    for (; r < r1; r += 8) {
+      const uint32_t a = *reinterpret_cast<const uint32_t*>(src + r * ld + c0);
+      s0 += bf2f((uint16_t)(a & 0xffff)); s1 += bf2f((uint16_t)(a >> 16));
     }
   }
-  red[ry][cx * 2] = s0;
-  red[ry][cx * 2 + 1] = s1;
+  red[ry][cx * 2] = (s0 + t0) + (u0 + v0);
+  red[ry][cx * 2 + 1] = (s1 + t1) + (u1 + v1);
   __syncthreads();
   if (threadIdx.x < 64) {
     float s = 0.f;
@@ -867,7 +880,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       const int NC = (s1 - s0) * 64;
       T_HIP(launch_score_grad_chunk(m, hc, yc, Rv, F32(w.lc), F32(w.wc), s0, s1, Gc, st));
       // d bo[n] = sum_r G[r][n]
-      hipLaunchKernelGGL(k_colsum_bf16, dim3(NC / 64, (unsigned)((Rv + 4095) / 4096)), dim3(256), 0, st, Gc, Rv, (int64_t)NC, NC,
+      hipLaunchKernelGGL(k_colsum_bf16, dim3(NC / 64, (unsigned)((Rv + COLSUM16_ROWS - 1) / COLSUM16_ROWS)), dim3(256), 0, st, Gc, Rv, (int64_t)NC, NC,
                          G + t.out_bias.off + (size_t)s0 * 64);
       T_HIP(hipGetLastError());
       // dH[Rv][C] += G[Rv][NC] . outT_chunk[NC][C]   == col-major: dH^T[C x Rv] += outT_chunk^T[C x NC] . G^T[NC x Rv]
@@ -978,7 +991,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     hipLaunchKernelGGL(k_block_bwd, dim3((unsigned)((nOut / 4 + 255) / 256)), dim3(256), 0, st, da, a_out, c_act, nOut, dsf, dcb);
     T_HIP(hipGetLastError());
     // conv bias: sum over rows of dc
-    hipLaunchKernelGGL(k_colsum_bf16, dim3((cout + 63) / 64, (unsigned)((R + 4095) / 4096)), dim3(256), 0, st, dcb, R, (int64_t)cout, cout,
+    hipLaunchKernelGGL(k_colsum_bf16, dim3((cout + 63) / 64, (unsigned)((R + COLSUM16_ROWS - 1) / COLSUM16_ROWS)), dim3(256), 0, st, dcb, R, (int64_t)cout, cout,
                        G + t.conv_bias[i].off);
     T_HIP(hipGetLastError());
     if (m.resT[i]) {
