@@ -47,8 +47,16 @@ __global__ __launch_bounds__(256) void k_gru_x3(const GruX3Batch bt) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int n0 = blockIdx.x * XT;
-  const int64_t m0 = (int64_t)blockIdx.y * XT;
+  // Tile order: the N / 128 unit tiles of one 128-session tile read the SAME activation rows, and a workgroup's XCD is its linear id mod 8 (observed
+  // round-robin placement: a speed hint, never correctness) -- so consecutive slots of one XCD take the unit tiles of one session tile, and its rows
+  // come from HBM into that XCD's L2 once instead of once per unit tile (the grid's y extent is padded to a multiple of 8 session tiles).
+  const int NT = gridDim.x, MT = (int)((g.M + XT - 1) / XT);
+  const int lin = blockIdx.x + NT * blockIdx.y;
+  const int xcd = lin & 7, slot = lin >> 3;
+  const int m_tile = (slot / NT) * 8 + xcd, n_tile = slot % NT;
+  if (m_tile >= MT) return;
+  const int n0 = n_tile * XT;
+  const int64_t m0 = (int64_t)m_tile * XT;
   const int wn = wave >> 1, wm = wave & 1;
   const int K = g.K1 + g.K2;
   const int n_it = K / XK;
@@ -227,7 +235,8 @@ static hipError_t launch_gru_x3_k(const GruX3Batch& bt, hipStream_t st) {
   if (lds < (size_t)XT * (XT + 4) * 4) lds = (size_t)XT * (XT + 4) * 4;   // ... or the fp32 result tile of the epilogue
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_gru_x3<XK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(k_gru_x3<XK>, dim3((unsigned)((g.N + XT - 1) / XT), (unsigned)((g.M + XT - 1) / XT), (unsigned)bt.n), dim3(256), lds, st, bt);
+  const unsigned mt = (unsigned)((g.M + XT - 1) / XT);
+  hipLaunchKernelGGL(k_gru_x3<XK>, dim3((unsigned)((g.N + XT - 1) / XT), (mt + 7) / 8 * 8, (unsigned)bt.n), dim3(256), lds, st, bt);
   return hipGetLastError();
 }
 
