@@ -171,8 +171,72 @@ static hipError_t run32(const float* A, int64_t lda, const float* B, int64_t ldb
   return hipGetLastError();
 }
 
+// NN for a handful of rows (M <= 64: the d [in | h] = d a . W products of a recurrent cell at the reference's 32 lanes).  The tiled kernel spends such a
+// product on fixed costs -- a 128 x 128 tile for 32 rows, two barriers per 32-deep chunk, 3 workgroups -- 18 us per launch, 81 of them per training step.
+// Here a workgroup (2 waves) owns 32 rows x 64 columns, takes the reduction in 128-deep chunks with every load of a chunk in flight at once, and
+// runs the same fp32 MFMA chain (same k order: bit-identical results).
+#define SK_K 128
+#define SK_PA (SK_K + 4)   // pitch of the [32 m][128 k] tile
+#define SK_PB 68           // pitch of the [128 k][64 n] tile: rows 4 apart are 16 banks apart
+__global__ __launch_bounds__(128) void k_gemm32_nn_skinny(const G32 g) {
+  __shared__ float As[32 * SK_PA];
+  __shared__ float Bs[SK_K * SK_PB];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64;
+  f32x16g acc;
+#pragma unroll
+  for (int q = 0; q < 16; q++) acc[q] = 0.f;
+  for (int kc = 0; kc < g.K; kc += SK_K) {
+    float4 ra[8], rb[16];
+#pragma unroll
+    for (int p = 0; p < 8; p++) {    // A tile: 32 rows x 32 float4 = 1024 float4 / 128 threads
+      const int idx = p * 128 + tid, m = m0 + (idx >> 5), k = kc + (idx & 31) * 4;
+      ra[p] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (int64_t)m * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int p = 0; p < 16; p++) {   // B tile: 128 k rows x 16 float4
+      const int idx = p * 128 + tid, k = kc + (idx >> 4), n = n0 + (idx & 15) * 4;
+      rb[p] = (k < g.K && n < g.N) ? *reinterpret_cast<const float4*>(g.B + (int64_t)k * g.ldb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    __syncthreads();   // the previous chunk has been consumed
+#pragma unroll
+    for (int p = 0; p < 8; p++) { const int idx = p * 128 + tid; *reinterpret_cast<float4*>(&As[(idx >> 5) * SK_PA + (idx & 31) * 4]) = ra[p]; }
+#pragma unroll
+    for (int p = 0; p < 16; p++) { const int idx = p * 128 + tid; *reinterpret_cast<float4*>(&Bs[(idx >> 4) * SK_PB + (idx & 15) * 4]) = rb[p]; }
+    __syncthreads();
+#pragma unroll 4
+    for (int s = 0; s < SK_K / 8; s++) {   // the tiled kernel's step: k = 8 s + 4 lh + c for MFMA c
+      const float4 a = *reinterpret_cast<const float4*>(&As[lr * SK_PA + 8 * s + 4 * lh]);
+      const float* q = &Bs[(8 * s + 4 * lh) * SK_PB + 32 * wave + lr];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[0], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.y, q[SK_PB], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[2 * SK_PB], acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[3 * SK_PB], acc, 0, 0, 0);
+    }
+  }
+  const int n = n0 + 32 * wave + lr;
+  if (n >= g.N) return;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    const int m = m0 + acc_row(q, lh);
+    if (m >= g.M) continue;
+    float v = acc[q];
+    float* c = g.C + (int64_t)m * g.ldc + n;
+    if (g.beta != 0.f) v += g.beta * *c;
+    *c = v;
+  }
+}
+
 hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st) {
   if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along k (A) and n (B)
+  if (M > 0 && M <= 64 && N > 0) {
+    G32 g;
+    g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.beta = beta;
+    g.k_per_split = K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;
+    hipLaunchKernelGGL(k_gemm32_nn_skinny, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32)), dim3(128), 0, st, g);
+    return hipGetLastError();
+  }
   return run32<false, true>(A, lda, B, ldb, C, ldc, M, N, K, beta, nullptr, 0, st);
 }
 
