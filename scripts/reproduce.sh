@@ -27,6 +27,8 @@ python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 python3 scripts/train_bench.py 1024 3 ragged 2>&1 | tail -1
 HIERTCN_TRAIN_LEGACY=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
+echo "== training step at the reference batch (32 lanes x 20 x 30, XING catalogue): HierTCN d = 128 / 256, HierGRU d = 128 / 256"
+for cfg in "D=128" "D=256" "D=128 LOW=gru" "D=256 LOW=gru"; do env N=20778 $cfg python3 scripts/train_bench.py 32 30 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done
 echo "== data-parallel code path, 2 ranks sharing the GPU over gloo (smoke: RCCL needs one GPU per rank)"
 HIERTCN_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --users-per-step 512 --train-users-per-step 256 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json; b = json.loads(sys.stdin.read()); t = b['train']; print(b['n_gpus'], 'ranks:', round(b['value']), 'sessions/s eval;', 'train', t.get('ms_per_step'), 'ms/step', t.get('collectives'))"
