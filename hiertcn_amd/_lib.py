@@ -11,9 +11,9 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 8
+ABI_VERSION = 9
 N_STRUCTS = 5
-PRECISION_STORAGE16, PRECISION_FP32 = 0, 1
+PRECISION_STORAGE16, PRECISION_FP32, PRECISION_SPLIT16 = 0, 1, 2
 
 c_f32p = C.POINTER(C.c_float)
 c_i32p = C.POINTER(C.c_int32)

@@ -104,7 +104,7 @@ def build_parser() -> ArgumentParser:
     p.add_argument("--data_splits", dest="data_splits", default=100, type=int)
     # build-only addition (see module docstring)
     p.add_argument("--emb_dim", dest="emb_dim", default=128, type=int)
-    p.add_argument("--storage_dtype", dest="storage_dtype", default="bf16", choices=["bf16", "fp16", "fp32"])
+    p.add_argument("--storage_dtype", dest="storage_dtype", default="bf16", choices=["bf16", "fp16", "fp32", "split16"])
     # args.py:193 -- the "eval" default set
     p.set_defaults(save=False, load=False, train=False, validate=False, test=True, html=False,
                    test_random=False, filter_user=False, shuffle=False)

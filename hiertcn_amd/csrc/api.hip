@@ -289,11 +289,12 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
   HIP_TRY(refresh_frag_major(m, st));
   HIP_TRY(refresh_lgru_split(m, st));
   if (h->train.enabled) HIP_TRY(train_fill_masters(m, h->train, w, st));
-  if (h->x.enabled) {   // exact numerics mode: fp32 copies in the same internal layouts (reduction index contiguous)
+  if (h->x.enabled) {   // exact / split numerics modes: fp32 copies in the same internal layouts (reduction index contiguous)
     ExactDev& x = h->x;
     HIP_TRY(hipMemcpyAsync(x.emb, w->emb_kernel, (size_t)m.N * E * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(x.emb, 0, (size_t)E * sizeof(float), st));   // row 0 = the null id (model.py:59)
-    HIP_TRY(launch_transpose_f32(w->out_kernel, x.outT, m.Clast, m.N, st));   // [C][N] -> [N][C]
+    if (x.enabled & X_FP32) HIP_TRY(launch_transpose_f32(w->out_kernel, x.outT, m.Clast, m.N, st));   // [C][N] -> [N][C]
+    if (x.enabled & X_SPLIT) HIP_TRY(launch_transpose_split(w->out_kernel, x.outS, m.Clast, m.N, m.NP, x.outS_scale, st));   // [C][N] -> [NP][hi C | lo C]
     for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
       const int cout = m.C[i];
       for (int j = 0; j < m.K; j++)
@@ -301,7 +302,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
       if (w->res_kernel[i]) HIP_TRY(launch_transpose_f32(w->res_kernel[i], x.resT[i], cin, cout, st));
     }
     if (m.hier) HIP_TRY(launch_transpose_f32(w->proj_kernel, x.projT, E, E, st));   // rows [0, E) of Wp: the item half
-    x.filled = 1;
+    x.filled = x.enabled;
   }
   h->weights_set = true;
   return HIERTCN_OK;
@@ -309,12 +310,16 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
 
 int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
-  if (precision != HIERTCN_PRECISION_STORAGE16 && precision != HIERTCN_PRECISION_FP32)
-    return fail(HIERTCN_ERR_INVALID, "precision %d: HIERTCN_PRECISION_STORAGE16 (0) or HIERTCN_PRECISION_FP32 (1)", precision);
-  if (precision == HIERTCN_PRECISION_FP32 && !h->x.enabled) {
+  if (precision != HIERTCN_PRECISION_STORAGE16 && precision != HIERTCN_PRECISION_FP32 && precision != HIERTCN_PRECISION_SPLIT16)
+    return fail(HIERTCN_ERR_INVALID, "precision %d: HIERTCN_PRECISION_STORAGE16 (0), HIERTCN_PRECISION_FP32 (1) or HIERTCN_PRECISION_SPLIT16 (2)", precision);
+  const int need = precision == HIERTCN_PRECISION_FP32 ? (X_LOW | X_FP32) : precision == HIERTCN_PRECISION_SPLIT16 ? (X_LOW | X_SPLIT) : 0;
+  if (precision == HIERTCN_PRECISION_SPLIT16 && !score_x3_supported(h->m))
+    return fail(HIERTCN_ERR_INVALID, "HIERTCN_PRECISION_SPLIT16: the split-operand scoring kernel is built for a last width of 64, 128 or 256 (this model: %d); "
+                "use HIERTCN_PRECISION_FP32", h->m.Clast);
+  if (need & ~h->x.enabled) {
     if (h->weights_set)
-      return fail(HIERTCN_ERR_STATE, "the first hiertcn_set_precision(FP32) must precede hiertcn_set_weights (the fp32 copies are filled there)");
-    if (h->train.enabled) return fail(HIERTCN_ERR_STATE, "the fp32 mode is evaluation only: this handle has training enabled");
+      return fail(HIERTCN_ERR_STATE, "the first hiertcn_set_precision to a mode must precede hiertcn_set_weights (its weight copies are filled there)");
+    if (h->train.enabled) return fail(HIERTCN_ERR_STATE, "the fp32 / split modes are evaluation only: this handle has training enabled");
     ON_DEVICE(h);
     hiertcn_ctx* c = h;
     ModelDev& m = h->m;
@@ -325,20 +330,28 @@ int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision) {
     hipError_t e_ = dev_alloc(c, &(ptr), (size_t)(count));                                                     \
     if (e_ != hipSuccess) return fail(HIERTCN_ERR_HIP, "hipMalloc(%s) failed: %s", #ptr, hipGetErrorString(e_)); \
   } while (0)
-    XALLOC(x.emb, (size_t)m.N * E);
-    XALLOC(x.outT, (size_t)m.N * m.Clast);
-    for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
-      XALLOC(x.convT[i], (size_t)m.K * cin * m.C[i]);
-      if (cin != m.C[i]) XALLOC(x.resT[i], (size_t)cin * m.C[i]);
+    if (!(x.enabled & X_LOW)) {
+      XALLOC(x.emb, (size_t)m.N * E);
+      for (int i = 0, cin = E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
+        XALLOC(x.convT[i], (size_t)m.K * cin * m.C[i]);
+        if (cin != m.C[i]) XALLOC(x.resT[i], (size_t)cin * m.C[i]);
+      }
+      if (m.hier) XALLOC(x.projT, (size_t)E * E);
     }
-    if (m.hier) XALLOC(x.projT, (size_t)E * E);
-    x.chunk_rows = exact_chunk_rows(m.N);
-    XALLOC(x.logits, (size_t)x.chunk_rows * m.N);
+    if ((need & X_FP32) && !(x.enabled & X_FP32)) {
+      XALLOC(x.outT, (size_t)m.N * m.Clast);
+      x.chunk_rows = exact_chunk_rows(m.N);
+      XALLOC(x.logits, (size_t)x.chunk_rows * m.N);
+    }
+    if ((need & X_SPLIT) && !(x.enabled & X_SPLIT)) {
+      XALLOC(x.outS, (size_t)m.NP * 2 * m.Clast);
+      XALLOC(x.outS_scale, 4);
+    }
 #undef XALLOC
-    x.enabled = 1;
+    x.enabled |= need;
   }
-  if (precision == HIERTCN_PRECISION_FP32 && h->weights_set && !h->x.filled)
-    return fail(HIERTCN_ERR_STATE, "the fp32 copies were allocated after hiertcn_set_weights: set the weights again");
+  if (h->weights_set && (need & ~h->x.filled))
+    return fail(HIERTCN_ERR_STATE, "the weight copies of this mode were allocated after hiertcn_set_weights: set the weights again");
   h->precision = precision;
   return HIERTCN_OK;
 }
@@ -365,7 +378,8 @@ int hiertcn_struct_sizes(size_t out[HIERTCN_N_STRUCTS]) {
     if (!(h)->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_set_weights has not been called"); \
   } while (0);                                                                \
   ON_DEVICE(h)
-#define IS_EXACT(h) ((h)->precision == HIERTCN_PRECISION_FP32)
+#define IS_EXACT(h) ((h)->precision != HIERTCN_PRECISION_STORAGE16)   /* fp32 hidden rows, fp32 low level: the FP32 and the SPLIT16 mode */
+#define IS_SPLIT(h) ((h)->precision == HIERTCN_PRECISION_SPLIT16)
 
 int hiertcn_session_pool(hiertcn_handle_t h, const int32_t* y_ids, int64_t n_sessions, int32_t L, float* pooled, void* stream) {
   CHECK_READY(h);
@@ -444,7 +458,8 @@ static int score_timed(hiertcn_handle_t h, const void* hidden, const int32_t* y,
     slot = h->ev_used++;
     HIP_TRY(hipEventRecord(h->ev_begin[slot], st));
   }
-  if (IS_EXACT(h)) HIP_TRY(launch_exact_score(h->m, h->x, reinterpret_cast<const float*>(hidden), y, R, out, st));
+  if (IS_SPLIT(h)) HIP_TRY(launch_score_x3(h->m, h->x, reinterpret_cast<const float*>(hidden), y, R, out, nullptr, st, row_map, n_rows_dev, split_scratch));
+  else if (IS_EXACT(h)) HIP_TRY(launch_exact_score(h->m, h->x, reinterpret_cast<const float*>(hidden), y, R, out, st));
   else HIP_TRY(launch_score(h->m, reinterpret_cast<const uint16_t*>(hidden), y, R, out, nullptr, st, row_map, n_rows_dev, split_scratch));
   if (timing) HIP_TRY(hipEventRecord(h->ev_end[slot], st));
   return HIERTCN_OK;
@@ -469,7 +484,8 @@ int hiertcn_score_fused(hiertcn_handle_t h, const void* hidden, const int32_t* y
 int hiertcn_score_logits(hiertcn_handle_t h, const void* hidden, int64_t R, float* logits, void* stream) {
   CHECK_READY(h);
   if (!hidden || !logits || R < 0) return fail(HIERTCN_ERR_INVALID, "bad argument");
-  if (IS_EXACT(h)) HIP_TRY(launch_exact_logits(h->m, h->x, reinterpret_cast<const float*>(hidden), R, logits, reinterpret_cast<hipStream_t>(stream)));
+  if (IS_SPLIT(h)) HIP_TRY(launch_score_x3(h->m, h->x, reinterpret_cast<const float*>(hidden), nullptr, R, nullptr, logits, reinterpret_cast<hipStream_t>(stream), nullptr, nullptr, nullptr));
+  else if (IS_EXACT(h)) HIP_TRY(launch_exact_logits(h->m, h->x, reinterpret_cast<const float*>(hidden), R, logits, reinterpret_cast<hipStream_t>(stream)));
   else HIP_TRY(launch_score(h->m, reinterpret_cast<const uint16_t*>(hidden), nullptr, R, nullptr, logits, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
@@ -489,7 +505,7 @@ struct EvalWs {
   size_t pooled, sproj, hidden, rank, ce, tgt, gru, tcn, map, nvalid, cscratch, split, total;
 };
 static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
-static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L, bool exact = false) {
+static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L, bool exact = false, bool split = false) {
   EvalWs w;
   size_t off = 0;
   w.pooled = off; off += al256((size_t)B * S * m.E * sizeof(float));
@@ -503,14 +519,14 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L, bool e
   w.nvalid = off; off += al256(sizeof(int32_t));
   w.cscratch = off; off += al256(((size_t)B * S * L / 1024 + 2) * sizeof(int32_t));
   w.tgt = off;    off += al256((size_t)B * S * L * sizeof(float));
-  w.split = off;  off += al256((size_t)score_split_parts(B * S * L, m.NP) * 2 * B * S * L * sizeof(float));   // small batches only (parts > 1)
+  w.split = off;  off += al256((size_t)score_split_parts(B * S * L, m.NP, split ? 256 : 512) * 2 * B * S * L * sizeof(float));   // small batches only (parts > 1)
   w.total = off;
   return w;
 }
 
 size_t hiertcn_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t L) {
   if (!h || B < 0 || S < 0 || L < 0) return 0;
-  return eval_ws(h->m, B, S, L, IS_EXACT(h)).total;
+  return eval_ws(h->m, B, S, L, IS_EXACT(h), IS_SPLIT(h)).total;
 }
 
 int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
@@ -522,8 +538,8 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   if (hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
   if (!hier && S != 1) return fail(HIERTCN_ERR_INVALID, "single-level model_tcn: one sequence per lane (S must be 1, L = T)");
   if (L < 1 || L > 4096) return fail(HIERTCN_ERR_INVALID, "L=%d out of range 1..4096", L);
-  const bool exact = IS_EXACT(h);
-  const EvalWs w = eval_ws(h->m, B, S, L, exact);
+  const bool exact = IS_EXACT(h), split16 = IS_SPLIT(h);
+  const EvalWs w = eval_ws(h->m, B, S, L, exact, split16);
   if (workspace_bytes < w.total) return fail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.total);
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -546,7 +562,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
     else HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
     HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
   }
-  if (exact) {   // fp32 end to end: every row is scored on materialised logits; rows without a target come out as 0 / 0 / 0..k-1 there
+  if (exact && !split16) {   // fp32 end to end: every row is scored on materialised logits; rows without a target come out as 0 / 0 / 0..k-1 there
     HIP_TRY(launch_exact_tcn(h->m, h->x, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<float*>(hidden), ws + w.tcn, st));
     int rc = score_timed(h, hidden, y_ids, R, &so, st);
     if (rc != HIERTCN_OK) return rc;
@@ -556,13 +572,16 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
     }
     return HIERTCN_OK;
   }
-  HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<uint16_t*>(hidden), ws + w.tcn, st));
+  if (split16)   // the fp32 low level (exact.hip), then the fused scoring kernel on split operands (score_x3.hip) exactly as the 16-bit path below
+    HIP_TRY(launch_exact_tcn(h->m, h->x, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<float*>(hidden), ws + w.tcn, st));
+  else
+    HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<uint16_t*>(hidden), ws + w.tcn, st));
   // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): zero the outputs, list the rows that do
   // carry a target and score only those (a ragged XING batch is mostly padding: slot width = longest session of the slot).
   int32_t* row_map = reinterpret_cast<int32_t*>(ws + w.map);
   int32_t* n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
   float* split = nullptr;
-  if (so.topk == 0 && score_split_parts(R, h->m.NP) > 1) {
+  if (so.topk == 0 && score_split_parts(R, h->m.NP, split16 ? 256 : 512) > 1) {
     split = reinterpret_cast<float*>(ws + w.split);
     if (!so.target) so.target = reinterpret_cast<float*>(ws + w.tgt);   // the merge needs the target logit
   }

@@ -2,14 +2,18 @@
 #pragma once
 #include "common.h"
 
+enum { X_LOW = 1, X_FP32 = 2, X_SPLIT = 4 };   // fp32 copies of the low level | fp32 scoring table + logits scratch | split 16-bit scoring table
+
 struct ExactDev {
-  int enabled;          // fp32 copies allocated (hiertcn_set_precision before hiertcn_set_weights)
+  int enabled;          // X_* bits: what is allocated (hiertcn_set_precision before hiertcn_set_weights)
   int filled;           // ... and filled by hiertcn_set_weights
   float* emb;           // [N][E], row 0 zeroed
   float* projT;         // [E out][E in] = transpose(Wp[:E])                  (hier only)
   float* convT[HIERTCN_MAX_BLOCKS];   // [K][Cout][Cin]
   float* resT[HIERTCN_MAX_BLOCKS];    // [Cout][Cin] or null
-  float* outT;          // [N][Clast]
+  float* outT;          // [N][Clast]                                                                                   (X_FP32)
+  uint16_t* outS;       // [NP][2 Clast] IEEE half: row n = [hi(Wo[:, n]) | lo(Wo[:, n])], rows >= N zero (score_x3.hip)          (X_SPLIT)
+  float* outS_scale;    // 4 words: [0] 2^kw, the power of two outS was scaled by; [1] 2^-kw; [2] max |Wo| (bits)                     (X_SPLIT)
   float* logits;        // [chunk_rows][N] scratch of the scoring layer (owned by the handle: hiertcn_score_fused takes no workspace)
   int64_t chunk_rows;
 };
@@ -37,5 +41,10 @@ hipError_t launch_exact_tcn(const ModelDev& m, const ExactDev& x, const int32_t*
                             void* workspace, hipStream_t st);
 int64_t exact_chunk_rows(int N);
 hipError_t launch_exact_logits(const ModelDev& m, const ExactDev& x, const float* hidden, int64_t R, float* logits, hipStream_t st);
+// score_x3.hip: the fused scoring kernel on split 16-bit operands (HIERTCN_PRECISION_SPLIT16); hidden fp32 [R][Clast]
+bool score_x3_supported(const ModelDev& m);
+hipError_t launch_transpose_split(const float* src, uint16_t* dst, int C, int64_t N, int64_t NP, float* scale, hipStream_t st);
+hipError_t launch_score_x3(const ModelDev& m, const ExactDev& x, const float* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                           float* logits, hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev, float* split_scratch);
 hipError_t launch_exact_score(const ModelDev& m, const ExactDev& x, const float* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                               hipStream_t st);

@@ -610,13 +610,13 @@ struct TrainWs {
   size_t rb2;     // the same x log2e (k_sgrad, rows stationary)
   size_t bl2;     // bo x log2e [NP] (k_sgrad, items stationary)
   size_t ovf;     // per compact row: the forward pass's running sum overflowed (k_sgrad mode 2 -> fix-up launches)
-  int fused;      // 1: the G-free scoring backward (score_bwd.hip); 0: the d-logits chunks + rocBLAS products
+  int fused;      // 1: the G-free scoring backward (score_bwd.hip); 0: the d-logits chunks + two products per chunk (gemm.hip)
   int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
   int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
 };
 
-// The scoring layer's backward: score_bwd.hip (no d-logits matrix, no rocBLAS, no host read-back) where the kernel is built for the
-// width; HIERTCN_TRAIN_LEGACY=1 selects the previous path (G chunks + two rocBLAS products per chunk) for A/B runs.
+// The scoring layer's backward: score_bwd.hip (no d-logits matrix, no host read-back) where the kernel is built for the
+// width; HIERTCN_TRAIN_LEGACY=1 selects the previous path (G chunks + two products per chunk on gemm.hip's kernels) for A/B runs.
 // HierGRU low level: keep the pre-activation gradients of every (step, layer) cell and form the weight gradients behind the BPTT loop (as the
 // across-session scan always does) while that costs at most 1 GiB: the launch-bound regime (the reference's 32 lanes = 640 sessions: 118 MB).  Past
 // it a cell's products fill the chip by themselves and the 15 GB this would take at the bench shape buy nothing.
@@ -796,7 +796,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   memset(&so, 0, sizeof(so));
   so.rank = reinterpret_cast<int32_t*>(ws + w.rank); so.ce = F32(w.ce); so.target = F32(w.tgt);
   // Only the rows that carry a target are scored and differentiated (a ragged batch is mostly padding): the device builds
-  // their ascending list; its length comes back to the host once per step because it sizes the rocBLAS calls below.
+  // their ascending list; its length comes back to the host once per step because it sizes the chunk products below.
   int32_t* rmap = reinterpret_cast<int32_t*>(ws + w.map);
   int32_t* nvalid_d = reinterpret_cast<int32_t*>(ws + w.nvalid);
   float* dH = F32(w.dA);   // [R][C_last] fp32
@@ -822,7 +822,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st, rmap, nvalid_d));
   if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
   int64_t Rv = 0;
-  if (!w.fused) {   // legacy path only: the row count sizes the rocBLAS calls below
+  if (!w.fused) {   // legacy path only: the row count sizes the chunk products below
     int32_t nvalid_h = 0;
     T_HIP(hipMemcpyAsync(&nvalid_h, nvalid_d, sizeof(int32_t), hipMemcpyDeviceToHost, st));
     T_HIP(hipStreamSynchronize(st));

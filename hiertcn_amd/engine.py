@@ -87,14 +87,17 @@ class Engine:
         """dtype: storage type of the 16-bit tensors: 'bf16' (default; args.storage_dtype overrides) or 'fp16' (the
         libhiertcn_gfx950_f16.so build: BASELINE.json configs[3], inference only); 'fp32' = the exact numerics mode
         (hiertcn_set_precision: everything fp32 as the reference computes it, model_tcn.py:35-41; evaluation only, for
-        parity runs on trained checkpoints -- the mode that meets "fp32 logits within 1e-3" at any logit scale)."""
+        parity runs on trained checkpoints -- the mode that meets "fp32 logits within 1e-3" at any logit scale);
+        'split16' = the FAST parity-grade mode (HIERTCN_PRECISION_SPLIT16: fp32 low level, fused scoring on hi + lo IEEE-half
+        operands, three MFMAs per product, csrc/score_x3.hip): the same tolerance at a third of the bf16 rate; evaluation only."""
         dtype = dtype or getattr(args, "storage_dtype", "bf16")
-        if dtype not in ("bf16", "fp16", "fp32"):
-            raise HierTCNError(f"storage dtype {dtype!r}: 'bf16', 'fp16' or 'fp32' (exact mode)")
-        if dtype == "fp32" and train:
-            raise HierTCNError("dtype='fp32' is the exact EVALUATION mode; training runs on bf16 storage with fp32 masters")
+        if dtype not in ("bf16", "fp16", "fp32", "split16"):
+            raise HierTCNError(f"storage dtype {dtype!r}: 'bf16', 'fp16', 'fp32' (exact mode) or 'split16' (fast parity-grade mode)")
+        if dtype in ("fp32", "split16") and train:
+            raise HierTCNError(f"dtype={dtype!r} is an EVALUATION mode; training runs on bf16 storage with fp32 masters")
         self.f16 = dtype == "fp16"
-        self.exact = dtype == "fp32"
+        self.mode = dtype if dtype in ("fp32", "split16") else "storage16"
+        self.exact = self.mode != "storage16"       # fp32 hidden rows / fp32 low level (the FP32 and the SPLIT16 mode)
         self.act_dtype = torch.float32 if self.exact else (torch.float16 if self.f16 else torch.bfloat16)
         self.lib = _lib.load(f16=self.f16)
         if not torch.cuda.is_available():
@@ -113,8 +116,8 @@ class Engine:
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
             self._ck(self.lib.hiertcn_create(C.byref(self._h), C.byref(self.cfg)))
-            if self.exact:   # allocates the fp32 copies that set_weights fills; must precede set_weights
-                self._ck(self.lib.hiertcn_set_precision(self._h, _lib.PRECISION_FP32))
+            if self.exact:   # allocates the weight copies of the mode, which set_weights fills; must precede set_weights
+                self._ck(self.lib.hiertcn_set_precision(self._h, _lib.PRECISION_SPLIT16 if self.mode == "split16" else _lib.PRECISION_FP32))
         self.train = bool(train)
         if self.train:   # fp32 masters / gradients / Adam moments; must precede set_weights
             with torch.cuda.device(self.device):
@@ -145,14 +148,18 @@ class Engine:
         return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
     def set_precision(self, dtype: str):
-        """Switch an Engine built with dtype='fp32' between the exact mode ('fp32') and the production kernels on 16-bit storage
-        ('bf16' / 'fp16', whichever library the handle was built from) -- both weight sets live on the handle."""
-        want_exact = dtype == "fp32"
-        if not want_exact and dtype != ("fp16" if self.f16 else "bf16"):
-            raise HierTCNError(f"precision {dtype!r}: this handle offers 'fp32' and {'fp16' if self.f16 else 'bf16'!r}")
-        self._ck(self.lib.hiertcn_set_precision(self._h, _lib.PRECISION_FP32 if want_exact else _lib.PRECISION_STORAGE16))
-        self.exact = want_exact
-        self.act_dtype = torch.float32 if want_exact else (torch.float16 if self.f16 else torch.bfloat16)
+        """Switch between the numerics modes of the handle: 'fp32' (exact), 'split16' (fast parity-grade) and the 16-bit storage kernels
+        ('bf16' / 'fp16', whichever library the handle was built from).  The FIRST switch to 'fp32' / 'split16' allocates that mode's
+        weight copies and must precede set_weights; afterwards the modes can be switched between calls."""
+        store = "fp16" if self.f16 else "bf16"
+        if dtype not in ("fp32", "split16", store):
+            raise HierTCNError(f"precision {dtype!r}: this handle offers 'fp32', 'split16' and {store!r}")
+        code = {"fp32": _lib.PRECISION_FP32, "split16": _lib.PRECISION_SPLIT16}.get(dtype, _lib.PRECISION_STORAGE16)
+        with torch.cuda.device(self.device):
+            self._ck(self.lib.hiertcn_set_precision(self._h, code))
+        self.mode = dtype if dtype in ("fp32", "split16") else "storage16"
+        self.exact = self.mode != "storage16"
+        self.act_dtype = torch.float32 if self.exact else (torch.float16 if self.f16 else torch.bfloat16)
 
     # ---------------------------------------------------------------------------------------
     def set_weights(self, params: Dict[str, "np.ndarray | torch.Tensor"], root: Optional[str] = None):

@@ -34,8 +34,9 @@
  *   - "bf16" buffers are uint16_t holding IEEE bfloat16 bit patterns.
  *   - numerics: by default the item tables, conv kernels, scoring kernel and the activations between layers are STORED in 16 bits
  *     (bfloat16; IEEE half in libhiertcn_gfx950_f16.so) and accumulated in fp32.  hiertcn_set_precision(h, HIERTCN_PRECISION_FP32)
- *     selects the exact mode: everything fp32, as the reference computes it (model_tcn.py:35-41) -- the mode that meets "fp32
- *     logits within 1e-3" at the logit scale of a trained model.  `hidden` buffers then hold float instead of uint16_t.
+ *     selects the exact mode: everything fp32, as the reference computes it (model_tcn.py:35-41); HIERTCN_PRECISION_SPLIT16 the fast
+ *     parity-grade mode (split 16-bit operands, three MFMAs per product).  Both meet "fp32 logits within 1e-3" at the logit scale of a
+ *     trained model; `hidden` buffers then hold float instead of uint16_t.
  */
 #ifndef HIERTCN_H_
 #define HIERTCN_H_
@@ -47,7 +48,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 8
+#define HIERTCN_ABI_VERSION 9
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -136,15 +137,25 @@ int hiertcn_get_config(hiertcn_handle_t h, hiertcn_config_t* out);
 int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* stream);
 
 /* Numerics mode of the evaluation path (session_pool, gru_scan, tcn_forward, score_fused, score_logits, forward_eval).
- *   HIERTCN_PRECISION_STORAGE16 (default)  16-bit storage / fp32 accumulate: the production kernels.
+ *   HIERTCN_PRECISION_STORAGE16 (default)  16-bit storage / fp32 accumulate: the throughput kernels (8 mantissa bits per factor of a product).
  *   HIERTCN_PRECISION_FP32                 fp32 end to end on v_mfma_f32_32x32x2_f32, logits materialised per row chunk; rank / cross
- *                                          entropy / ranked top-k taken on the materialised fp32 values (loss.py:21,120,179).  Every
- *                                          `hidden` argument is then float [R][C_last].  Evaluation only: the training entry points
- *                                          return HIERTCN_ERR_STATE.  For parity runs, not for throughput (~20x slower).
- * The first switch to FP32 must precede hiertcn_set_weights (it allocates the fp32 copies that set_weights fills, plus a logits scratch
- * of <= 1 GiB owned by the handle); after that the mode may be switched back and forth between calls. */
+ *                                          entropy / ranked top-k taken on the materialised fp32 values (loss.py:21,120,179).  For parity
+ *                                          runs, not for throughput (~20x slower than STORAGE16).
+ *   HIERTCN_PRECISION_SPLIT16 (ABI 9)      the parity-grade FAST mode: the low level in fp32 (as FP32), the scoring layer -- 99 % of the work --
+ *                                          FUSED as in STORAGE16 (no logits written; rank / cross entropy / ranked top-k in registers) on the
+ *                                          16-bit MFMA with every factor carried as hi + lo IEEE-half parts (22 mantissa bits, in either library
+ *                                          build): h.w ~= h_hi w_hi + h_lo w_hi + h_hi w_lo in one fp32 accumulator (csrc/score_x3.hip).  Logit
+ *                                          error of fp32 order (~1e-6 of the logit scale): inside the north star's "fp32 logits within 1e-3" at
+ *                                          the scale of a trained model (|z| ~ 10-30), ranks and ranked top-k equal to the fp32 reference's
+ *                                          wherever its own gaps exceed that error.  A third of STORAGE16's rate.  Last width 64, 128 or 256.
+ *                                          (The table and every hidden row are scaled by powers of two before the split: no range limit
+ *                                          short of fp32's own.)
+ * In FP32 and SPLIT16 every `hidden` argument is float [R][C_last].  Evaluation only: the training entry points return HIERTCN_ERR_STATE.
+ * The first switch to a mode must precede hiertcn_set_weights (it allocates the weight copies that set_weights fills -- for FP32 also a logits
+ * scratch of <= 1 GiB owned by the handle); after that the modes may be switched back and forth between calls. */
 #define HIERTCN_PRECISION_STORAGE16 0
 #define HIERTCN_PRECISION_FP32 1
+#define HIERTCN_PRECISION_SPLIT16 2
 int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision);
 int hiertcn_get_precision(hiertcn_handle_t h, int32_t* precision);
 
@@ -220,7 +231,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
 
 /* ---- training step (model.py:135-141: Adam on the masked lane-mean cross entropy of model.py:102-117) ----------
  * hiertcn_train_enable   before hiertcn_set_weights: allocates fp32 masters / gradients / Adam moments for every
- *                        variable (4 x parameter count floats) and a rocBLAS handle.
+ *                        variable (4 x parameter count floats).
  * hiertcn_train_forward_backward   one `sess.run([train_op minus the apply, loss, state])` of run_hier_xing.py:301:
  *                        forward with activations kept in `workspace`, loss into metrics8 (as hiertcn_metrics), gradients
  *                        of every variable into the gradient arena.  No gradient crosses the batch boundary (state_in is data).

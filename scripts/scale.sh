@@ -1,5 +1,5 @@
 # The four runs of the scaling curve (BASELINE.json: sessions/sec at 1, 2, 4 and 8 MI355X of ONE node), exactly as the driver
-# launches them: one rank per GPU over RCCL (backend "nccl"), weak scaling (4096 users per step per GPU).  Each prints ONE JSON line whose
+# launches them: one rank per GPU over RCCL (backend "nccl"), weak scaling (bench.py's default users per step per GPU: 16,384).  Each prints ONE JSON line whose
 # `multi_gpu` object carries backend / rccl_ranks / distinct_devices / per-rank launch times.
 # usage (on a node with >= 8 GPUs): bash scripts/scale.sh [steps] [warmup] > scale.jsonl
 STEPS=${1:-6}; WARMUP=${2:-2}; PORT=${PORT:-29611}

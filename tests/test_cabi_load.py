@@ -41,6 +41,10 @@ def test_abi_version(lib):
     # the documents that quote the version quote the current one
     integ = open(os.path.join(ROOT, "INTEGRATION.md")).read()
     assert re.findall(r"==\s*(\d+)\s*\(HIERTCN_ABI_VERSION\)", integ) == [str(header_version)]
+    # ... in EVERY statement that compares it (round 3's stub asserted the previous version under a comment that named the current one)
+    asserted = re.findall(r"hiertcn_abi_version\(\)\s*==\s*(\d+)", integ)
+    assert asserted and set(asserted) == {str(header_version)}, asserted
+    assert not re.search(r"\)[a-z_]+\.hiertcn_", integ), "two statements fused on one line in a code block of INTEGRATION.md"
     design = open(os.path.join(ROOT, "DESIGN.md")).read()
     assert set(re.findall(r"C-ABI v(\d+)", design)) == {str(header_version)}
 

@@ -47,9 +47,12 @@ def _record(name, payload):
         json.dump(all_, f, indent=1, sort_keys=True)
 
 
+@pytest.mark.parametrize("mode", ["fp32", "split16"])
 @pytest.mark.parametrize("zscale", [10.0, 30.0])
-def test_exact_mode_at_trained_logit_scale_xing_shape(zscale):
-    """BASELINE.json configs[1]'s shape (XING catalogue 20,778, d = 256, 32 lanes x 10 slots x 20 steps), the scoring layer scaled so that
+def test_exact_mode_at_trained_logit_scale_xing_shape(zscale, mode):
+    """Both parity-grade modes -- 'fp32' (exact.hip: fp32 MFMA, materialised logits) and 'split16' (score_x3.hip: the FUSED kernel on
+    hi + lo 16-bit operands, three MFMAs per product; the fast one) -- at
+    BASELINE.json configs[1]'s shape (XING catalogue 20,778, d = 256, 32 lanes x 10 slots x 20 steps), the scoring layer scaled so that
     max |z| = zscale: device logits < 1e-3 of the exact oracle (fp64, unrounded weights), ranks equal, top-10 identical on every row whose
     oracle gaps exceed twice that row's logit error; the 16-bit path's error at the same scale is recorded and must be >= 10x larger."""
     from hiertcn_amd.engine import Engine, metrics_dict
@@ -74,7 +77,7 @@ def test_exact_mode_at_trained_logit_scale_xing_shape(zscale):
     zmax = float(np.abs(exact[valid]).max())
     assert abs(zmax - zscale) < 0.05 * zscale
 
-    eng = Engine(args, hier=True, dtype="fp32")
+    eng = Engine(args, hier=True, dtype=mode)
     eng.set_weights(p)
     out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True, topk=K)
     m = metrics_dict(out["metrics8"])
@@ -91,7 +94,7 @@ def test_exact_mode_at_trained_logit_scale_xing_shape(zscale):
     err = np.abs(logits - exact)
     err_row = err.max(-1)
     e_max, e_mean = float(err[valid].max()), float(err[valid].mean())
-    print("fp32 mode, |z| max %.1f: logits vs exact oracle max %.3e mean %.3e" % (zmax, e_max, e_mean))
+    print("%s mode, |z| max %.1f: logits vs exact oracle max %.3e mean %.3e" % (mode, zmax, e_max, e_mean))
     assert e_max < 1e-3, e_max                                   # the north star's tolerance, at a trained model's logit scale
 
     # ranks (loss.py:179): equal on every row where no item sits within twice the row's logit error of the target (then the strict
@@ -103,13 +106,14 @@ def test_exact_mode_at_trained_logit_scale_xing_shape(zscale):
     gap = np.abs(exact - tgt)
     np.put_along_axis(gap, yy[..., None], np.inf, -1)
     clear_rank = (gap.min(-1) > 2 * err_row + 1e-7) & valid
-    assert clear_rank.sum() > 0.97 * valid.sum(), (clear_rank.sum(), valid.sum())
+    assert clear_rank.sum() > 0.93 * valid.sum(), (clear_rank.sum(), valid.sum())   # (how many rows the next line is conclusive on)
     assert np.array_equal(rk[clear_rank], rk_ref[clear_rank])
     tol = 2 * err_row[..., None] + 1e-7
     lo, hi = (exact > tgt + tol).sum(-1), (exact > tgt - tol).sum(-1)
     assert np.all((rk >= lo)[valid]) and np.all((rk <= hi)[valid])
     assert np.all(rk[~valid] == 0)
     n_rank_equal = int((rk == rk_ref)[valid].sum())
+    assert n_rank_equal >= 0.99 * valid.sum(), (n_rank_equal, valid.sum())
     # cross entropy and the batch metrics
     ce = out["ce"].cpu().numpy().reshape(B, S * L)
     assert np.abs(ce - ref["ce"])[valid].max() < 1e-3
@@ -139,12 +143,12 @@ def test_exact_mode_at_trained_logit_scale_xing_shape(zscale):
     rk16 = out16["rank"].cpu().numpy().reshape(B, S * L)
     print("bf16 storage, |z| max %.1f: logits vs exact oracle max %.3e mean %.3e" % (zmax, err16.max(), err16.mean()))
     assert err16.max() > 10 * e_max
-    _record("xing_shape_z%d" % int(zscale), dict(
-        z_max=zmax, fp32_max=e_max, fp32_mean=e_mean, bf16_max=float(err16.max()), bf16_mean=float(err16.mean()),
+    _record("xing_shape_z%d%s" % (int(zscale), "" if mode == "fp32" else "_" + mode), dict(
+        z_max=zmax, mode=mode, fp32_max=e_max, fp32_mean=e_mean, bf16_max=float(err16.max()), bf16_mean=float(err16.mean()),
         rows=int(valid.sum()), fp32_rank_equal=n_rank_equal, bf16_rank_equal=int((rk16 == rk_ref)[valid].sum()),
         rows_clear_rank=int(clear_rank.sum()), rows_clear_top10=int(clear_top.sum())))
-    eng.set_precision("fp32")
-    assert np.array_equal(logits_now(), logits)          # switching back reproduces the exact mode bit for bit
+    eng.set_precision(mode)
+    assert np.array_equal(logits_now(), logits)          # switching back reproduces the mode bit for bit
     eng.close()
 
 
@@ -278,8 +282,9 @@ def test_exact_mode_contract_errors():
     ex.close()
 
 
-@pytest.mark.parametrize("N,d,zscale", [(300_000, 256, 30.0), (100_000, 512, 10.0)], ids=["cfg3_width_z30", "cfg4_width_d512_z10"])
-def test_exact_mode_at_the_north_star_catalogue_widths(N, d, zscale):
+@pytest.mark.parametrize("N,d,zscale,mode", [(300_000, 256, 30.0, "fp32"), (300_000, 256, 30.0, "split16"), (100_000, 512, 10.0, "fp32")],
+                         ids=["cfg3_width_z30", "cfg3_width_z30_split16", "cfg4_width_d512_z10"])
+def test_exact_mode_at_the_north_star_catalogue_widths(N, d, zscale, mode):
     """BASELINE.json configs[2] / configs[3] widths (300,000 items at d = 256; d = 512) on a few lanes, scoring layer scaled to a trained
     model's logit range: fp32-mode logits < 1e-3 of the exact oracle on unrounded weights, ranks inside the oracle's near-tie bracket and
     equal on nearly every row, ranked top-10 equal wherever the oracle's own gaps exceed the row's logit error."""
@@ -300,7 +305,7 @@ def test_exact_mode_at_the_north_star_catalogue_widths(N, d, zscale):
     p["hier/tcn/dense/kernel"] = (p["hier/tcn/dense/kernel"] * f).astype(np.float32)
     p["hier/tcn/dense/bias"] = (p["hier/tcn/dense/bias"] * f).astype(np.float32)
     exact = hid64 @ p["hier/tcn/dense/kernel"].astype(np.float64) + p["hier/tcn/dense/bias"].astype(np.float64)
-    eng = Engine(args, hier=True, dtype="fp32")
+    eng = Engine(args, hier=True, dtype=mode)
     eng.set_weights(p)
     out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True, topk=K)
     pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
@@ -321,6 +326,6 @@ def test_exact_mode_at_the_north_star_catalogue_widths(N, d, zscale):
     clear = (np.diff(-top_vals, axis=-1).min(-1) > 2 * err_row + 1e-7) & valid
     assert clear.sum() > 0.9 * valid.sum()
     assert np.array_equal(ti[clear], want[clear][:, :K])
-    _record("width_N%d_d%d_z%d" % (N, d, int(zscale)), dict(z_max=float(np.abs(exact[valid]).max()), fp32_max=float(err_row[valid].max()),
+    _record("width_N%d_d%d_z%d%s" % (N, d, int(zscale), "" if mode == "fp32" else "_" + mode), dict(mode=mode, z_max=float(np.abs(exact[valid]).max()), fp32_max=float(err_row[valid].max()),
                                                            rows=int(valid.sum()), rows_clear_top10=int(clear.sum())))
     eng.close()
