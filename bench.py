@@ -88,6 +88,7 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
     try:
         targs = copy.copy(args)
         targs.train = True
+        targs.batch_size = Bt           # the gradient exchange sizes its row-sparse all-gather from args.batch_size: the batch actually fed
         model = HierTCNModel(targs, params, train=True)
         eng = model.engine
         batches = []
@@ -148,7 +149,7 @@ def train_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
     }
     ex = model._exchange
     seg = {k: eng.grad_segment(k) for k in (0, 1, 2)}
-    coll = {"backend": (("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else None), "algorithm": ex.mode, "item_table_exchange": ex.last.get("item_table", "dense"),
+    coll = {"backend": (("rccl" if dist.get_backend() == "nccl" else dist.get_backend()) if world > 1 else None), "algorithm": ex.mode, "algorithm_taken": ex.dense_taken, "item_table_exchange": ex.last.get("item_table", "dense"),
             "bytes": {"item_table": seg[0][1] * 4, "scoring_layer": seg[1][1] * 4, "rest": seg[2][1] * 4}}
     if world > 1:
         # (a) the same steps with the collectives off (replicas drift apart from here on: timing only, the bench ends after it)
@@ -287,6 +288,79 @@ def dvfs_probe(eng, rows, n_items, dim, seconds=1.5):
     return res
 
 
+def exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks):
+    """-> the `exact` object: the SAME evaluation step in the parity-grade modes (tests/test_gpu_exact_mode.py: logits < 1e-3 of the exact
+    oracle at |z| = 10 and 30, ranks equal on > 99 % of rows, top-10 equal on every clear row) -- 'split16' (HIERTCN_PRECISION_SPLIT16: fp32
+    low level, fused scoring on hi + lo half operands, three MFMAs per product) timed like the headline (barrier, max over ranks, HIP events
+    around the scoring launches), and the 'fp32' mode (fp32 MFMA, materialised logits) beside it on a smaller batch."""
+    import torch
+
+    from hiertcn_amd.engine import Engine
+
+    Bx = a.exact_users_per_step
+    eng = Engine(args, hier=True, dtype="split16")
+    eng.set_precision("fp32")          # both parity modes on one handle: their weight copies are allocated before the weights are set
+    eng.set_precision("split16")
+    eng.set_weights(params)
+    n_total = a.exact_warmup + a.exact_steps
+    batches = []
+    for i in range(n_total):
+        first = shard_first + (i * Bx) % max(shard - Bx, 1)
+        x, y, mask = make_users(draw, first, Bx, a.ragged)
+        batches.append((torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda(), torch.from_numpy(mask).cuda()))
+    state0 = torch.zeros((Bx, eng.HT), dtype=torch.float32, device="cuda")
+    m8 = torch.zeros(8, dtype=torch.float64, device="cuda")
+    for i in range(a.exact_warmup):
+        eng.forward_eval(*batches[i], state0, metrics8=m8)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    eng.timing_enable(True)
+    eng.timing_read(reset=True)
+    t0 = time.perf_counter()
+    for i in range(a.exact_warmup, n_total):
+        eng.forward_eval(*batches[i], state0, metrics8=m8)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    dt = max_over_ranks(time.perf_counter() - t0, "cuda")
+    score_ms, launches = eng.timing_read(reset=True)
+    eng.timing_enable(False)
+    rows = Bx * S_SESS * L_STEPS
+    scored = float(m8.cpu()[7])
+    flop = 2.0 * scored * DIM * N_ITEMS                      # algorithmic (SURVEY.md 8(d)); the kernel executes three MFMAs per product
+    alg = flop / (score_ms * 1e-3) / 1e12 if score_ms > 0 else 0.0
+    out = {"mode": "split16",
+           "what": "the evaluation step of the headline in HIERTCN_PRECISION_SPLIT16 (csrc/score_x3.hip): fp32 low level + the fused scoring kernel on hi + lo "
+                   "IEEE-half operands, h.w = h_hi w_hi + h_lo w_hi + h_hi w_lo in one fp32 accumulator; the mode tests/test_gpu_exact_mode.py holds to "
+                   "logits < 1e-3 / ranks / top-10 of the exact oracle at |z| = 10 and 30",
+           "value": round(Bx * S_SESS * world * a.exact_steps / dt, 2), "unit": "sessions/s", "n_gpus": world,
+           "users_per_step_per_gpu": Bx, "steps": a.exact_steps, "warmup": a.exact_warmup, "ms_per_step": round(dt / a.exact_steps * 1e3, 3),
+           "kernel": "k_score_x3<256,0,0> (+ its fix-up launch)", "launch_ms": round(score_ms, 4), "launches_timed": int(launches),
+           "scored_rows_per_launch": scored, "rows_per_launch": rows,
+           "achieved_algorithmic_tflops": round(alg, 2), "achieved_executed_tflops": round(3 * alg, 2),
+           "frac_of_peak_over_3": round(alg / (MFMA_PEAK_TFLOPS / 3), 4),
+           "peak_over_3": round(MFMA_PEAK_TFLOPS / 3, 1)}
+    # the fp32 mode (exact.hip) on the same handle, a smaller batch: ~20x slower, bounded by the 157 TFLOP/s fp32 MFMA
+    if rank == 0:
+        Bf = min(a.exact_fp32_users, Bx)
+        eng.set_precision("fp32")
+        xb, yb, mb = (t[:Bf].contiguous() for t in batches[0])
+        st = state0[:Bf].contiguous()
+        eng.forward_eval(xb, yb, mb, st, metrics8=m8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(2):
+            eng.forward_eval(xb, yb, mb, st, metrics8=m8)
+        torch.cuda.synchronize()
+        tf = (time.perf_counter() - t0) / 2
+        out["fp32_mode"] = {"value": round(Bf * S_SESS / tf, 2), "unit": "sessions/s", "n_gpus": 1, "users_per_step": Bf, "ms_per_step": round(tf * 1e3, 3),
+                            "what": "HIERTCN_PRECISION_FP32 (csrc/exact.hip): fp32 MFMA, logits materialised per row chunk"}
+    eng.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -308,6 +382,11 @@ def main():
     ap.add_argument("--train-steps", type=int, default=4)
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of CPU work for the cpu_baseline leg")
+    ap.add_argument("--no-exact", action="store_true", help="skip the parity-grade modes (the `exact` object of the JSON line)")
+    ap.add_argument("--exact-users-per-step", type=int, default=4096, help="users per step PER GPU of the split16 leg (4096 users = 9,600 workgroups of 256 rows = 37.5 rounds)")
+    ap.add_argument("--exact-steps", type=int, default=3)
+    ap.add_argument("--exact-warmup", type=int, default=1)
+    ap.add_argument("--exact-fp32-users", type=int, default=256)
     a = ap.parse_args()
 
     import torch
@@ -389,6 +468,9 @@ def main():
     score_ms = sum(ms * n for ms, n in tr) / max(launches, 1)
     for e in engs:
         e.timing_enable(False)
+    # health word of the persistent launches (the across-session scan of small batches; include/hiertcn.h): a bounded wait that ran out would
+    # have produced wrong states in the timed region -- read once, behind it
+    persistent_timed_out = any(e.persistent_timed_out() for e in engs)
     for e in engs[1:]:
         e.close()
 
@@ -483,6 +565,17 @@ def main():
                 import traceback
                 train = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
 
+    exact = None
+    if not a.no_exact:
+        if world > 1:
+            exact = exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)
+        else:
+            try:
+                exact = exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks)
+            except Exception as e:  # noqa: BLE001  (the headline line must survive a failure of a secondary leg; the error is reported)
+                import traceback
+                exact = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the checker, timed on this host's cores on a bounded sample of the SAME workload
@@ -491,7 +584,10 @@ def main():
         n_cpu = min(B, 128)
         r = time_cpu_baseline(args, params, xb[:n_cpu].cpu().numpy(), yb[:n_cpu].cpu().numpy(), mb[:n_cpu].cpu().numpy(),
                               budget_s=a.cpu_budget)
-        cpu = dict(value=round(r["value"], 3), unit="sessions/s", cores=r["cores"], kind="port", sample=r["sample"],
+        plan = 1024 * S_SESS          # BASELINE.md 3 planned 1,024 users x 20 sessions; the default budget times a fraction of that
+        cpu = dict(value=round(r["value"], 3), unit="sessions/s", cores=r["cores"], kind="port",
+                   sample=f"{r['sessions']} of the planned {plan:,} sessions (BASELINE.md 3) in the best variant: " + r["sample"],
+                   sample_sessions=int(r["sessions"]), planned_sessions=plan,
                    seconds=round(r["seconds"], 2), variants=r["variants"])
 
     if rank == 0:
@@ -542,9 +638,11 @@ def main():
                 "scored_rows_per_launch": scored_rows,
             },
             "cpu_baseline": cpu,
+            "exact": exact,
             "multi_gpu": multi,
             "gmm": gmm,
             "train": train,
+            "persistent_timed_out": bool(persistent_timed_out),
             "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
             "setup_s": round(t_setup, 1),
         }

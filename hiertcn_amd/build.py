@@ -33,9 +33,44 @@ def _stale(target, deps):
 LIB_F16 = os.path.join(HERE, "libhiertcn_gfx950_f16.so")
 
 
+LIB_TESTHOOKS = os.path.join(HERE, "libhiertcn_gfx950_testhooks.so")
+TESTHOOK_SOURCES = ["gru_persist.hip"]   # the sources that hold an `#ifdef HIERTCN_TEST_HOOKS` switch
+
+
 def build_all(force: bool = False, verbose: bool = False):
     """Both storage variants: bfloat16 (default, training + inference) and IEEE half (-DHIERTCN_F16, inference)."""
-    return build_lib(force, verbose), build_lib(force, verbose, f16=True)
+    libs = build_lib(force, verbose), build_lib(force, verbose, f16=True)
+    build_testhooks(force)
+    return libs
+
+
+def build_testhooks(force: bool = False) -> str:
+    """libhiertcn_gfx950_testhooks.so: the bfloat16 library with the fault-injection switches of the tests compiled IN (-DHIERTCN_TEST_HOOKS; the
+    shipped libraries have none).  Same objects as the shipped library except the few sources that hold a switch.  Loaded only by
+    tests/tools/persist_timeout_probe.py through HIERTCN_LIB."""
+    build_lib(False)
+    hipcc = _hipcc()
+    obj_dir = os.path.join(HERE, "build", "testhooks")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
+    objs = []
+    rebuilt = False
+    for src in SOURCES:
+        if src in TESTHOOK_SOURCES:
+            s, o = os.path.join(CSRC, src), os.path.join(obj_dir, src.replace(".hip", ".o"))
+            if force or _stale(o, [s] + headers):
+                r = subprocess.run([hipcc, *FLAGS, "-DHIERTCN_TEST_HOOKS=1", "-c", s, "-o", o], capture_output=True, text=True)
+                if r.returncode != 0:
+                    raise RuntimeError("hipcc failed: %s\n%s" % (s, r.stderr))
+                rebuilt = True
+            objs.append(o)
+        else:
+            objs.append(os.path.join(HERE, "build", src.replace(".hip", ".o")))
+    if force or rebuilt or _stale(LIB_TESTHOOKS, objs):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_TESTHOOKS, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s" % (r.stdout, r.stderr))
+    return LIB_TESTHOOKS
 
 
 def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: bool = False) -> str:

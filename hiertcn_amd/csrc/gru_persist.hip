@@ -305,7 +305,9 @@ hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const
   for (int l = 0; l < m.nl; l++) { a.wg[l] = m.gru_wg[l]; a.bg[l] = m.gru_bg[l]; a.wc[l] = m.gru_wc[l]; a.bc[l] = m.gru_bc[l]; }
   a.bar = m.gru_bar;
   a.B = B; a.S = S; a.H = H; a.HT = HT; a.nl = m.nl; a.P = P;
-  if (getenv("HIERTCN_GRU_TEST_MISSING_WG")) a.P = P + 1;   // test hook: every barrier waits for a workgroup that does not exist -> the bounded waits run out
+#ifdef HIERTCN_TEST_HOOKS   // libhiertcn_gfx950_testhooks.so only (hiertcn_amd/build.py): the shipped libraries read no test switch on this path
+  if (getenv("HIERTCN_GRU_TEST_MISSING_WG")) a.P = P + 1;   // every barrier waits for a workgroup that does not exist -> the bounded waits run out
+#endif
   const size_t lds_bytes = persist_lds_bytes(H, m.nl, B);
   switch (H >> 5) {
     case 2: return launch_q<2>(a, lds_bytes, st);

@@ -146,24 +146,49 @@ class GradientExchange:
         self._pending = []
         self._shard = None
         self.last = {}
+        self.dense_taken = None      # what _dense actually ran last: 'rs_ag', 'allreduce_bucketed' or 'allreduce' (rs_ag needs numel % world == 0)
+        self._over_host = None       # pinned host copy of the step's summed "some rank exceeds ids_bound" flag + the event behind its copy
+        self._over_event = None
 
     @property
     def world(self) -> int:
         return dist.get_world_size() if _is_dist() else 1
 
     def global_users(self, y_ids: torch.Tensor):
-        """Device float [1]: lanes with a target over all ranks (None at world 1: the kernel counts its own batch)."""
+        """Device float [1]: lanes with a target over all ranks (None at world 1: the kernel counts its own batch).  The same all-reduce
+        carries one more float: 1 from every rank that feeds more ids this step than `ids_bound` allows.  Its sum reaches the host through
+        a pinned buffer (no stream synchronisation) and is read in `_ids_per_rank`, where ALL ranks then raise together -- a rank that
+        raised alone would leave the others waiting in the next collective."""
         if not _is_dist():
             return None
         u = self.eng.count_users(y_ids)
-        _sum_async(u).wait()
-        return u
+        over = 1.0 if (self.ids_bound is not None and int(y_ids.numel()) > self.ids_bound) else 0.0
+        t = torch.cat([u, torch.full((1,), over, dtype=torch.float32, device=u.device)])
+        _sum_async(t).wait()
+        if self.ids_bound is not None:
+            if t.is_cuda:
+                if self._over_host is None:
+                    self._over_host = torch.zeros(1, dtype=torch.float32).pin_memory()
+                    self._over_event = torch.cuda.Event()
+                self._over_host.copy_(t[1:2], non_blocking=True)
+                self._over_event.record()
+            else:
+                self._over_host = t[1:2].clone()
+        return t[0:1]
 
     def _ids_per_rank(self, n_local: int) -> int:
         """The number every rank uses for the all-gather capacity and the sparse-versus-dense decision of this step: the same on all
         ranks by construction (the host-known bound), or agreed on by a collective that every rank enters every step."""
         if self.ids_bound is not None:
-            if n_local > self.ids_bound:
+            if self._over_host is not None:          # the flag summed over ranks by this step's global_users: the same value everywhere
+                if self._over_event is not None:
+                    self._over_event.synchronize()
+                n_over = float(self._over_host[0])
+                self._over_host[0] = 0.0
+                if n_over > 0:
+                    raise ValueError(f"{int(n_over)} rank(s) feed more ids in one step than ids_bound = {self.ids_bound} (this rank: {n_local}): the bound "
+                                     "must hold on every rank and step (batch_size * max_session_num * max_activity_len); raised on every rank")
+            elif n_local > self.ids_bound:           # (after_backward called without global_users: nothing was agreed on)
                 raise ValueError(f"this rank feeds {n_local} ids in one step, more than ids_bound = {self.ids_bound}: the bound must hold on every "
                                  "rank and step (batch_size * max_session_num * max_activity_len)")
             return self.ids_bound
@@ -182,6 +207,7 @@ class GradientExchange:
             # both run on the backend's stream, in issue order; neither makes the compute stream wait here
             w1 = dist.reduce_scatter_tensor(self._shard, seg, op=dist.ReduceOp.SUM, async_op=True)
             w2 = dist.all_gather_into_tensor(seg, self._shard, async_op=True)
+            self.dense_taken = "rs_ag"
 
             class _Both:
                 def wait(self_inner):
@@ -189,7 +215,9 @@ class GradientExchange:
                     w2.wait()
             return _Both()
         if self.mode == "allreduce" and dist.get_backend() == "nccl":
+            self.dense_taken = "allreduce_bucketed"
             return _sum_async_bucketed(seg)
+        self.dense_taken = "allreduce"   # (gloo, or rs_ag asked for a segment that does not divide by the world size)
         return _sum_async(seg)
 
     def after_scoring(self):

@@ -286,6 +286,40 @@ def test_gradient_exchange_with_sizes_that_differ_per_rank_and_step(tmp_path):
         assert err.shape == (5,) and err.max() < 1e-5
 
 
+def _bound_violation_worker(rank, world, port, out_dir):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from hiertcn_amd.distributed import GradientExchange, init_from_env
+    import torch.distributed as dist
+    init_from_env("gloo")
+    N, E = 61, 4
+    eng = _HostEngine(N, E, 10, rank)
+    ex = GradientExchange(eng, sparse_rows_max_fraction=2.0, ids_bound=3 * 2 * 5)      # holds on rank 0 (3 lanes), not on rank 1 (4 lanes)
+    rng = np.random.default_rng(rank)
+    B = 3 + rank
+    x = torch.from_numpy(rng.integers(0, N, (B, 2, 5)).astype(np.int32))
+    y = torch.from_numpy(rng.integers(0, N, (B, 2, 5)).astype(np.int32))
+    ex.global_users(y)
+    ex.after_scoring()
+    try:
+        ex.after_backward(x, y)
+        msg = "no error"
+    except ValueError as e:
+        msg = str(e)
+    with open(os.path.join(out_dir, f"msg{rank}.txt"), "w") as f:
+        f.write(msg)
+    dist.barrier()          # both ranks get here: neither is left waiting inside a collective the other never entered
+    dist.destroy_process_group()
+
+
+def test_ids_bound_violated_on_one_rank_raises_on_every_rank(tmp_path):
+    """Round 3 raised only on the rank whose batch exceeded ids_bound, with the other rank already inside the next collective (a hang).  The
+    overflow flag now rides on the user-count all-reduce of the same step and every rank raises."""
+    mp.spawn(_bound_violation_worker, args=(2, _free_port(), str(tmp_path)), nprocs=2, join=True)
+    for r in (0, 1):
+        msg = open(tmp_path / f"msg{r}.txt").read()
+        assert "1 rank(s) feed more ids" in msg and "raised on every rank" in msg, msg
+
+
 class _FakeGmm:
     """eval_step(x, y) -> {'sums': [sum of lane means, users]}: stands for TcnGmmModel in the run loop (no GPU here)."""
 

@@ -96,31 +96,31 @@ def test_persistent_scan_soak_and_graph_replay():
 
 
 def test_a_wait_that_cannot_be_met_times_out_instead_of_hanging():
-    """Every wait inside the persistent launch is bounded: with a workgroup missing (test hook: the barriers expect one more arrival than
-    there are workgroups) the launch ends within seconds, the handle's health word is set, and nothing hangs."""
-    import time
+    """Every wait inside the persistent launch is bounded: with a workgroup missing the launch ends within seconds, the handle's health word
+    is set, nothing hangs and the handle recovers.  The missing workgroup is a fault-injection switch that only the test-hooks build of the
+    library contains (the shipped libraries read no environment variable on this path): tests/tools/persist_timeout_probe.py runs against it
+    in a process of its own.  The shipped library ignores the switch (second half)."""
+    import subprocess
+    import sys
+    from hiertcn_amd.build import LIB_TESTHOOKS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(LIB_TESTHOOKS), "python -m hiertcn_amd.build (or __graft_entry__.build()) builds the test-hooks library"
+    env = dict(os.environ, HIERTCN_LIB=LIB_TESTHOOKS)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "persist_timeout_probe.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "persist_timeout_probe ok" in r.stdout
+    # the shipped library: the same switch changes nothing
     d, nl = 128, 1
     args = hier_tcn_args(item_num=300, emb_dim=d, hidden_dim=d, tcn_channel=[d, d], num_layer=nl)
     eng = Engine(args)
     eng.set_weights(init_params(args, 5))
     data = _inputs(np.random.default_rng(2), 8, 3, d, d * nl)
-    assert not eng.persistent_timed_out()
+    want = _scan(eng, *data, chain=True)
     os.environ["HIERTCN_GRU_TEST_MISSING_WG"] = "1"
-    os.environ["HIERTCN_GRU_CHAIN"] = "0"
     try:
-        t0 = time.time()
-        eng.gru_scan(*data)
-        torch.cuda.synchronize()
-        took = time.time() - t0
+        got = _scan(eng, *data, chain=False)
     finally:
         os.environ.pop("HIERTCN_GRU_TEST_MISSING_WG", None)
-        os.environ.pop("HIERTCN_GRU_CHAIN", None)
-    assert eng.persistent_timed_out()
-    assert took < 30.0, took
-    # the health read that reported the time-out also reset the handle's barrier counters (they were left at a value that is no multiple
-    # of the workgroup count, and every later barrier target derives from them): the handle works again, and reports healthy
-    want = _scan(eng, *data, chain=True)
-    got = _scan(eng, *data, chain=False)
     for g, w in zip(got, want):
         np.testing.assert_allclose(g, w, rtol=2e-5, atol=2e-5)
     assert not eng.persistent_timed_out()
