@@ -6,7 +6,7 @@ src = os.path.join(ROOT, "hiertcn_amd", "csrc", sys.argv[1])
 flt = sys.argv[2] if len(sys.argv) > 2 else ""
 cmd = ["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-fno-gpu-rdc", "-D__HIP_PLATFORM_AMD__", "-Wno-shift-negative-value",
        "-Rpass-analysis=kernel-resource-usage", "-c", src, "-o", "/tmp/_kr.o"]
-if sys.argv[1] in ("score.hip", "score_x3.hip"):
+if sys.argv[1].startswith("score"):
     cmd.insert(1, "-fno-honor-nans")
 err = subprocess.run(cmd, capture_output=True, text=True).stderr
 cur, d = None, {}
