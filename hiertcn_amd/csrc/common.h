@@ -127,9 +127,6 @@ hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* 
 // score.hip: the fix-up flavour of the production scoring kernel alone (row tiles whose ce is non-finite are redone with the per-tile redo)
 hipError_t launch_score_fixup_only(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                                    hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev);
-// score_topk2.hip: ranked lists beside rank / ce at C_last = 256 on the four-tile shape, one wave per SIMD
-hipError_t launch_score_topk2(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out, hipStream_t st,
-                              const int32_t* row_map, const int32_t* n_rows_dev);
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L);
 // buffers of the HierGRU low level: evaluation keeps two states and one record per layer, training all of them
 struct LowGruBufs {

@@ -1406,10 +1406,6 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
                                  const hiertcn_score_out_t* out, float* logits, hipStream_t st, const int32_t* row_map,
                                  const int32_t* n_rows_dev, float* split_scratch) {
   if (logits) return launch_score_v<C, true, 0>(m, hidden, y, R, nullptr, logits, 0, st);
-  if constexpr (C == 256) {   // round 4: the lists beside the FOUR-TILE shape, one wave per SIMD (score_topk2.hip); HIERTCN_TOPK_V3=1: the one-step-block kernel it replaces (A/B)
-    if (out && out->topk > 0 && !getenv("HIERTCN_TOPK_V3") && !getenv("HIERTCN_TOPK_V2") && !getenv("HIERTCN_TOPK_V1"))
-      return launch_score_topk2(m, hidden, y, R, out, st, row_map, n_rows_dev);
-  }
   if (out && out->topk > 0)  // loss.py:120 ranked indices beside rank / ce: the list kernel (slower epilogue)
     return out->topk <= 8    ? launch_score_topk<C, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev)
            : out->topk <= 10 ? launch_score_topk<C, 10>(m, hidden, y, R, out, st, row_map, n_rows_dev)   // the reference's recall@10 lists

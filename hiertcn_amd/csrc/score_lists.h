@@ -79,6 +79,10 @@ __device__ __forceinline__ void top_tile(TopList<KT>& L, const f32x16& v, int it
 // the slow half of top_tile alone (the caller has already voted that some lane of the wave has a candidate in this tile)
 template <int KT>
 __device__ __forceinline__ void top_tile_slow(TopList<KT>& L, const f32x16& v, int item0) {
+#ifdef HIERTCN_TOPK_NOSLOW   // timing experiment (wrong lists): what the list maintenance itself costs
+  L.v[KT - 1] = fmaxf(L.v[KT - 1], v[0]);
+  return;
+#endif
 #pragma unroll
   for (int r = 0; r < 16; r++) {
     bool take = v[r] > L.v[KT - 1];
