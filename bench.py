@@ -227,7 +227,9 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     model.close()
     diff = float((losses["gram"] - losses["table_pass"]).abs().max())
     flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
-    return {"what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
+    return {"training": "not built: the mixture models evaluate (forward, gmm_prob / gmm_prob_max, lane loss, run loop); no backward of hiertcn_gmm_loss / the head / "
+                        "the one-hot trunk exists, `run_xing --model_type tcn_gmm --train` refuses (the reference's calc_loss_gmm, loss.py:225-292, has no caller either)",
+            "what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
                     "bf16 parts, + one row-wise kernel for prior / linear terms / target mean + finish); ms_table_pass: M passes of "
                     "k_score_pipe<256,21,...> (sum-of-squares epilogue) over the [D, C] mean tables + prior + finish; ms_learned_scale: args.sigma None, M passes of "
                     "k_score_pipe<256,22,...> over the interleaved means / log-scales tables (twice the rows)",
