@@ -200,8 +200,8 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
     int ncu = 0, dev = 0;
     if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) m.n_cu = ncu;
     unsigned long long* bar = nullptr;
-    ALLOC_OR_FAIL(bar, (size_t)256);   // 8 group counters 128 bytes apart + the time-out word
-    if (hipMemset(bar, 0, 256 * sizeof(unsigned long long)) != hipSuccess) {
+    ALLOC_OR_FAIL(bar, (size_t)512);   // 8 group counters 128 bytes apart + the time-out word; the low-level GRU's 8 counters behind them
+    if (hipMemset(bar, 0, 512 * sizeof(unsigned long long)) != hipSuccess) {
       hiertcn_destroy(c);
       return fail(HIERTCN_ERR_HIP, "hipMemset(gru_bar) failed");
     }
@@ -772,7 +772,7 @@ int hiertcn_persistent_health(hiertcn_handle_t h, int32_t* timed_out) {
     // a timed-out launch leaves the group counters at a value that is no multiple of its workgroup count, and every later barrier target
     // is derived from them: the handle would mis-synchronise for good.  The device is idle here (synchronised above), so start over --
     // counters and error word back to zero; the caller has been told that the launches since the last check produced wrong states.
-    HIP_TRY(hipMemset(h->m.gru_bar, 0, 256 * sizeof(unsigned long long)));
+    HIP_TRY(hipMemset(h->m.gru_bar, 0, 512 * sizeof(unsigned long long)));
   }
   return HIERTCN_OK;
 }

@@ -140,8 +140,14 @@ struct LowGruBufs {
   int keep_all;
   float* hidden32;    // exact numerics mode (exact.hip): uf is already filled with the fp32 projection and the outputs go here as fp32 rows
   uint16_t* x3;       // scratch of the split-operand cells (gru_x3.hip), low_gru_x3_elems() 16-bit elements; null: the fp32 cells run
+  float* persist;     // scratch of the persistent launch (gru_persist.hip), low_gru_persist_floats() floats; null: the launch chain runs
 };
 size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess);
+// gru_persist.hip: the HierGRU low level of small evaluation batches as one persistent launch
+bool low_gru_persist_applies(const ModelDev& m, int64_t n_sess);
+size_t low_gru_persist_floats(const ModelDev& m, int64_t n_sess, int L);
+hipError_t launch_low_gru_persist(const ModelDev& m, const float* u, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* hidden32,
+                                  float* ws, hipStream_t st);
 // one GRU cell product + epilogue on split 16-bit operands (gru_x3.hip)
 enum { X3_GATES = 0, X3_CAND = 1 };
 struct GruX3Args {

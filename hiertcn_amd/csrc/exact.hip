@@ -202,7 +202,7 @@ static size_t xal(size_t b) { return (b + 255) & ~(size_t)255; }
 size_t exact_tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L) {
   if (m.low_gru)   // projected rows (fp32) + lengths + two state buffers + one (gates | r*h | cand | out) record per layer
     return xal((size_t)n_sessions * L * m.E * 4) + xal((size_t)n_sessions * 4) + 2 * xal((size_t)n_sessions * m.HT * 4) +
-           xal((size_t)m.nl * n_sessions * 5 * m.H * 4);
+           xal((size_t)m.nl * n_sessions * 5 * m.H * 4) + (n_sessions <= 1024 ? xal(low_gru_persist_floats(m, n_sessions, L) * 4) : 0);
   return 3 * xal((size_t)n_sessions * L * xmaxc(m) * sizeof(float));
 }
 
@@ -221,6 +221,7 @@ static hipError_t launch_exact_low_gru(const ModelDev& m, const ExactDev& x, con
   b.rec = reinterpret_cast<float*>(take((size_t)m.nl * n_sess * 5 * m.H * 4));
   b.keep_all = 0;
   b.hidden32 = hidden;
+  b.persist = n_sess <= 1024 ? reinterpret_cast<float*>(take(low_gru_persist_floats(m, n_sess, L) * 4)) : nullptr;
   XGemm g = {};
   g.A = x.emb; g.lda = m.E; g.ids = ids; g.n_tab = m.N;
   g.Wt = x.projT; g.taps = 1; g.Cin = m.E; g.M = R; g.N = m.E;

@@ -256,6 +256,249 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The HierGRU LOW level (model_hier.py:67-68 -> model_gru.py:47-55: dynamic_rnn of a MultiRNNCell of GRUCells from a zero state, with
+// sequence_length) of small batches as ONE persistent launch -- the same machinery as the scan above: sessions do not interact, so they
+// are cut into 8 groups, each scanned by H / 8 workgroups that keep their units' weight rows in LDS for all L steps; cells (t, l) with
+// t + l = tau form a diagonal of two phases with one group barrier behind each.  At the reference's batch (32 lanes x 10 slots = 320
+// sessions, L = 20, two layers) the launch chain it replaces is 2 (L + nl - 1) = 42 dependent launches of the split-operand cell kernel
+// (gru_x3.hip), ~25 us each for ~2 us of work.  Differences from the scan: the cell input of layer 0 is the projected row u[session][t]
+// (fp32, launch_low_gru_bufs); a step t >= sequence_length[session] leaves every layer's state as it was and emits a zero output
+// (dynamic_rnn: state copied through, output zeroed); the top layer's outputs are the scoring operand rows [session * L + t][H], in the
+// storage type or (exact / split16 modes) fp32; a group's sessions are staged in CHUNKS of lanes, so any number of sessions fits the LDS.
+// Exact fp32 dot products (the launch chain's split-operand cells carry 2^-16 per product): tests/test_gpu_hiergru.py compares both with
+// the oracle and with each other.
+// stage_segments for the low-level kernel: the width is a template constant (index arithmetic in shifts), up to 8 loads in flight per thread
+// and wait -- a group of 40 sessions stages 80 KB per phase, and every wait is a round trip to the L2 (sc1)
+template <int Q>
+__device__ __forceinline__ void stage_segments_wide(const SegDesc* segs, int n_seg, int n_lanes, int b_lo, int b_hi, float* xs, int lane_floats) {
+  constexpr int NLD = 8, HQ = 8 * Q;   // float4 per lane and segment (H / 4)
+  const int per_seg = n_lanes * HQ, total = n_seg * per_seg;
+  for (int base = 0; base < total; base += NLD * GP_THREADS) {
+    f4 v[NLD];
+    int dst[NLD];
+#pragma unroll
+    for (int it = 0; it < NLD; it++) {
+      const int w = min(base + it * GP_THREADS + (int)threadIdx.x, total - 1);
+      const int k = (w >= per_seg ? 1 : 0) + (w >= 2 * per_seg ? 1 : 0) + (w >= 3 * per_seg ? 1 : 0) + (w >= 4 * per_seg ? 1 : 0) +
+                    (w >= 5 * per_seg ? 1 : 0) + (w >= 6 * per_seg ? 1 : 0) + (w >= 7 * per_seg ? 1 : 0);
+      const int r = w - k * per_seg, pl = r / HQ, q = r % HQ;
+      const SegDesc sd = segs[k];
+      const int b = min(b_lo + pl, b_hi - 1);
+      v[it] = ld_sc1(sd.base + (size_t)b * sd.lane_floats + 4 * q);
+      dst[it] = sd.dst + pl * lane_floats + 4 * q;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+    for (int it = 0; it < NLD; it++) {
+      asm volatile("" : "+v"(v[it]));   // (not before the wait above)
+      if (base + it * GP_THREADS + (int)threadIdx.x < total) *reinterpret_cast<f4*>(xs + dst[it]) = v[it];
+    }
+  }
+}
+
+struct LowPersistArgs {
+  const float* u; const int32_t* seq_len;
+  float* hist;       // [M][L + 1][HT]: every layer's state before step t (slot 0 = the zero state, written here)
+  float* rh;         // [nl][M][H]
+  float* hcur;       // [2 step parities][nl][M][H]: a layer's output, the next layer's input
+  uint16_t* hidden; float* hidden32;
+  const float* wg[HIERTCN_MAX_LAYERS]; const float* bg[HIERTCN_MAX_LAYERS];
+  const float* wc[HIERTCN_MAX_LAYERS]; const float* bc[HIERTCN_MAX_LAYERS];
+  unsigned long long* bar;   // this kernel's own 8 group counters (behind the scan's) + the shared time-out word
+  unsigned long long* err;
+  int M, L, H, HT, nl, P, CH;   // CH: lanes staged at a time (a multiple of GP_LB)
+};
+
+template <int Q>
+__global__ __launch_bounds__(GP_THREADS) void k_low_gru_persist(const LowPersistArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ SegDesc segs[2 * HIERTCN_MAX_LAYERS];
+  __shared__ int s_dead;
+  const int tid = threadIdx.x;
+  const int ks = tid & (GP_KS - 1), u = (tid >> 3) & (GP_U - 1), bl = tid >> 6;
+  const int H = a.H, HT = a.HT, nl = a.nl, M = a.M, L = a.L, K = 2 * H, CH = a.CH;
+  const int grp = (int)blockIdx.x % GP_GROUPS, t = (int)blockIdx.x / GP_GROUPS;
+  const int Bc = (M + GP_GROUPS - 1) / GP_GROUPS;
+  const int b_lo = grp * Bc, b_hi = min(M, b_lo + Bc);
+  if (b_lo >= b_hi) return;   // a group without sessions
+  unsigned long long* bar = a.bar + (size_t)grp * 16;
+  if (tid == 0) s_dead = 0;
+  const int n_grp = b_hi - b_lo;                       // sessions of this group
+  const int n_grp_pad = (n_grp + GP_LB - 1) / GP_LB * GP_LB;
+  const int j = t * GP_U + u;   // this thread's hidden unit
+  constexpr int WL = 3 * GP_U * (2 * Q * GP_KS + 8);   // 16-byte chunks per layer
+  f4* wl = reinterpret_cast<f4*>(lds);
+  float* xs = reinterpret_cast<float*>(wl + (size_t)nl * WL);     // [cell of the diagonal][lane of the chunk][in | h][H]
+  const int lane_floats = 2 * H, cell_floats = CH * lane_floats;
+  float* keep = xs + (size_t)nl * cell_floats;                     // [cell][session of the group][unit] x (z, old h, candidate part): phase A -> phase B
+  for (int l = 0; l < nl; l++) {
+    for (int c = tid; c < 3 * GP_U * 2 * Q * GP_KS; c += GP_THREADS) {
+      const int row = c / (2 * Q * GP_KS), r = c - row * (2 * Q * GP_KS);
+      const int kind = row / GP_U, uu = row - kind * GP_U;
+      const int part = r / (Q * GP_KS), r2 = r - part * (Q * GP_KS), i = r2 / GP_KS, kk = r2 - i * GP_KS;
+      const int jj = t * GP_U + uu;
+      const float* src = (kind == 2) ? a.wc[l] + (size_t)jj * K : a.wg[l] + (size_t)(kind * H + jj) * K;
+      wl[(size_t)l * WL + wchunk<Q>(kind, uu, part, i, kk)] = *reinterpret_cast<const f4*>(src + part * H + kk * (H >> 3) + 4 * i);
+    }
+  }
+  // zero_state (model_gru.py:52, initial_state=None): slot 0 of the history, this workgroup's units
+  for (int i = tid; i < n_grp * GP_U * nl; i += GP_THREADS) {
+    const int b = b_lo + i / (GP_U * nl), r = i % (GP_U * nl), l = r / GP_U, uu = r % GP_U;
+    st_sc1(a.hist + (size_t)b * (L + 1) * HT + (size_t)l * H + t * GP_U + uu, 0.f);
+  }
+  // the first phase reads slot 0 of EVERY unit: the group's workgroups meet once before it (also the residency wait of the launch)
+  group_barrier(bar, (unsigned)a.P, a.err, &s_dead, GP_SPIN_FIRST);
+
+  for (int tau = 0; tau < L + nl - 1; tau++) {
+    int l_first = 0, n_cells = 0;                  // the cells of this diagonal: layers l_first .. l_first + n_cells - 1, step = tau - layer
+    for (int l = nl - 1; l >= 0; l--)
+      if (tau - l >= 0 && tau - l < L) { l_first = l; n_cells++; }
+    // ---------------- phase A: gates, r * h, input half of the candidate
+    for (int c_lo = 0; c_lo < n_grp; c_lo += CH) {
+      const int c_n = min(CH, n_grp - c_lo), c_pad = (c_n + GP_LB - 1) / GP_LB * GP_LB;
+      __syncthreads();
+      if (tid < 2 * n_cells) {
+        const int ci = tid >> 1, part = tid & 1, l = l_first + ci, s = tau - l;
+        SegDesc sd;
+        if (part == 0) {
+          if (l == 0) { sd.base = a.u + (size_t)s * H; sd.lane_floats = (unsigned long long)L * H; }
+          else { sd.base = a.hcur + ((size_t)(s & 1) * nl + (l - 1)) * M * H; sd.lane_floats = (unsigned long long)H; }
+        } else {
+          sd.base = a.hist + (size_t)s * HT + (size_t)l * H; sd.lane_floats = (unsigned long long)(L + 1) * HT;
+        }
+        sd.dst = ci * cell_floats + part * H;
+        segs[tid] = sd;
+      }
+      __syncthreads();
+      stage_segments_wide<Q>(segs, 2 * n_cells, c_pad, b_lo + c_lo, b_lo + c_lo + c_n, xs, lane_floats);
+      __syncthreads();
+      // Passes (4 lanes each) in blocks of eight: the dot products of a pass leave their three sums on all eight k-slice lanes of a (lane, unit)
+      // after the shuffle fold, and k-slice lane p keeps those of the block's p-th pass -- so the epilogue (two sigmoids, three stores) runs
+      // ONCE per block with every lane busy, instead of once per pass on one lane in eight.
+      for (int ci = 0; ci < n_cells; ci++) {
+        const int l = l_first + ci;
+        const f4* w = wl + (size_t)l * WL;
+        for (int pb = 0; pb < c_pad / GP_LB; pb += GP_KS) {
+          float my_r = 0.f, my_u = 0.f, my_c = 0.f;
+#pragma unroll
+          for (int p8 = 0; p8 < GP_KS; p8++) {
+            const int ps = pb + p8;
+            if (ps >= c_pad / GP_LB) break;   // (uniform)
+            const f4* xp = reinterpret_cast<const f4*>(xs + (size_t)ci * cell_floats + (size_t)(ps * GP_LB + bl) * lane_floats);
+            float ar = 0.f, au = 0.f, ac = 0.f;
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+              const f4 xv = xp[ks * Q + i];
+              ar = dot4(xv, w[wchunk<Q>(0, u, 0, i, ks)], ar);
+              au = dot4(xv, w[wchunk<Q>(1, u, 0, i, ks)], au);
+              ac = dot4(xv, w[wchunk<Q>(2, u, 0, i, ks)], ac);
+            }
+#pragma unroll
+            for (int i = 0; i < Q; i++) {
+              const f4 hv = xp[(H / 4) + ks * Q + i];
+              ar = dot4(hv, w[wchunk<Q>(0, u, 1, i, ks)], ar);
+              au = dot4(hv, w[wchunk<Q>(1, u, 1, i, ks)], au);
+            }
+#pragma unroll
+            for (int d = 1; d < GP_KS; d <<= 1) {
+              ar += __shfl_xor(ar, d);
+              au += __shfl_xor(au, d);
+              ac += __shfl_xor(ac, d);
+            }
+            my_r = (ks == p8) ? ar : my_r;
+            my_u = (ks == p8) ? au : my_u;
+            my_c = (ks == p8) ? ac : my_c;
+          }
+          const int ps = pb + ks;
+          const int gl = c_lo + ps * GP_LB + bl;   // session inside the group
+          if (ps < c_pad / GP_LB && gl < n_grp) {
+            const int b = b_lo + gl;
+            const float hj = xs[(size_t)ci * cell_floats + (size_t)(ps * GP_LB + bl) * lane_floats + H + j];
+            const float r = 1.0f / (1.0f + expf(-(my_r + a.bg[l][j])));        // customed_gru_cell.py:323-324: r is the first half
+            const float z = 1.0f / (1.0f + expf(-(my_u + a.bg[l][H + j])));
+            st_sc1(a.rh + ((size_t)l * M + b) * H + j, r * hj);                // :326
+            float* kp = keep + (((size_t)ci * n_grp_pad + gl) * GP_U + u) * 3;
+            kp[0] = z; kp[1] = hj; kp[2] = my_c;
+          }
+        }
+      }
+    }
+    group_barrier(bar, (unsigned)a.P, a.err, &s_dead, GP_SPIN_MAX);
+    // ---------------- phase B: (r * h) half of the candidate, tanh, blend; sequence_length: a finished session keeps its state, emits zeros
+    for (int c_lo = 0; c_lo < n_grp; c_lo += CH) {
+      const int c_n = min(CH, n_grp - c_lo), c_pad = (c_n + GP_LB - 1) / GP_LB * GP_LB;
+      __syncthreads();
+      if (tid < n_cells) {
+        SegDesc sd;
+        sd.base = a.rh + (size_t)(l_first + tid) * M * H; sd.lane_floats = (unsigned long long)H;
+        sd.dst = tid * cell_floats;
+        segs[tid] = sd;
+      }
+      __syncthreads();
+      stage_segments_wide<Q>(segs, n_cells, c_pad, b_lo + c_lo, b_lo + c_lo + c_n, xs, lane_floats);
+      __syncthreads();
+      for (int ci = 0; ci < n_cells; ci++) {
+        const int l = l_first + ci, s = tau - l;
+        const f4* w = wl + (size_t)l * WL;
+        for (int pb = 0; pb < c_pad / GP_LB; pb += GP_KS) {
+          float my_c = 0.f;
+#pragma unroll
+          for (int p8 = 0; p8 < GP_KS; p8++) {
+            const int ps = pb + p8;
+            if (ps >= c_pad / GP_LB) break;   // (uniform)
+            const f4* xp = reinterpret_cast<const f4*>(xs + (size_t)ci * cell_floats + (size_t)(ps * GP_LB + bl) * lane_floats);
+            float ac = 0.f;
+#pragma unroll
+            for (int i = 0; i < Q; i++) ac = dot4(xp[ks * Q + i], w[wchunk<Q>(2, u, 1, i, ks)], ac);
+#pragma unroll
+            for (int d = 1; d < GP_KS; d <<= 1) ac += __shfl_xor(ac, d);
+            my_c = (ks == p8) ? ac : my_c;
+          }
+          const int ps = pb + ks;
+          const int gl = c_lo + ps * GP_LB + bl;
+          if (ps < c_pad / GP_LB && gl < n_grp) {
+            const int b = b_lo + gl;
+            const bool active = s < a.seq_len[b];
+            const float* kp = keep + (((size_t)ci * n_grp_pad + gl) * GP_U + u) * 3;
+            const float z = kp[0], hj = kp[1];
+            const float c = tanhf(kp[2] + my_c + a.bc[l][j]);                     // :333-335
+            const float hn = z * hj + (1.0f - z) * c;                             // :336
+            const float out = active ? hn : 0.f;
+            if (l + 1 < nl) st_sc1(a.hcur + (((size_t)(s & 1) * nl + l) * M + b) * H + j, out);   // the next layer's input
+            st_sc1(a.hist + ((size_t)b * (L + 1) + s + 1) * HT + (size_t)l * H + j, active ? hn : hj);
+            if (l == nl - 1) {
+              if (a.hidden32) a.hidden32[((size_t)b * L + s) * H + j] = out;
+              else a.hidden[((size_t)b * L + s) * H + j] = f2bf(out);
+            }
+          }
+        }
+      }
+    }
+    if (tau + 1 < L + nl - 1) group_barrier(bar, (unsigned)a.P, a.err, &s_dead, GP_SPIN_MAX);
+  }
+}
+
+template <int Q>
+hipError_t launch_low_q(const LowPersistArgs& a, size_t lds_bytes, hipStream_t st) {
+  auto kern = k_low_gru_persist<Q>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(GP_GROUPS * (a.H / GP_U))), dim3(GP_THREADS), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
+// lanes staged at a time for M sessions (0: the weights alone do not leave room for one pass of 4 lanes)
+int low_persist_chunk(int H, int nl, int64_t M) {
+  const int Q = H >> 5;
+  const int Bc = (int)((M + GP_GROUPS - 1) / GP_GROUPS), pad = (Bc + GP_LB - 1) / GP_LB * GP_LB;
+  const size_t fixed = (size_t)nl * 3 * GP_U * (2 * Q * GP_KS + 8) * 16 + (size_t)nl * pad * GP_U * 3 * 4;
+  const size_t budget = 150 * 1024;
+  if (fixed >= budget) return 0;
+  int ch = (int)((budget - fixed) / ((size_t)nl * 2 * H * 4)) / GP_LB * GP_LB;
+  return ch > pad ? pad : ch;
+}
+
 template <int Q>
 hipError_t launch_q(const GruPersistArgs& a, size_t lds_bytes, hipStream_t st) {
   auto kern = k_gru_scan_persist<Q>;
@@ -313,6 +556,49 @@ hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const
     case 2: return launch_q<2>(a, lds_bytes, st);
     case 4: return launch_q<4>(a, lds_bytes, st);
     case 8: return launch_q<8>(a, lds_bytes, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// ---- HierGRU low level as one persistent launch (k_low_gru_persist) ------------------------------------------------------------------
+// applies to evaluation batches of up to 1024 sessions (beyond that the split-operand MFMA cells of gru_x3.hip win), E == H in {64, 128}; at
+// H = 256 two layers of weight rows leave LDS room for 8 staged sessions at a time and the launch is no faster than the chain it replaces
+// (1.53 vs 1.41 ms per 32-lane batch; H = 128: 0.81 vs 1.04, H = 64: 0.63 vs 0.91) -- HIERTCN_LGRU_CHAIN=0 forces it there too (A/B, tests)
+bool low_gru_persist_applies(const ModelDev& m, int64_t n_sess) {
+  const char* off = getenv("HIERTCN_LGRU_CHAIN");   // "1": always the launch chain; "0": the persistent launch wherever it fits (read on every call)
+  if (off && off[0] == '1') return false;
+  if (!m.low_gru || !m.gru_bar || m.n_cu <= 0 || n_sess <= 0 || n_sess > 1024) return false;
+  if (m.E != m.H || (m.H != 64 && m.H != 128 && m.H != 256)) return false;
+  if (m.H == 256 && !(off && off[0] == '0')) return false;
+  if (GP_GROUPS * (m.H / GP_U) > m.n_cu) return false;
+  return low_persist_chunk(m.H, m.nl, n_sess) >= GP_LB;
+}
+
+size_t low_gru_persist_floats(const ModelDev& m, int64_t n_sess, int L) {
+  return (size_t)n_sess * (L + 1) * m.HT + (size_t)m.nl * n_sess * m.H + 2 * (size_t)m.nl * n_sess * m.H;   // hist | rh | hcur
+}
+
+hipError_t launch_low_gru_persist(const ModelDev& m, const float* u, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* hidden32,
+                                  float* ws, hipStream_t st) {
+  const int H = m.H;
+  LowPersistArgs a;
+  memset(&a, 0, sizeof(a));
+  a.u = u; a.seq_len = seq_len; a.hidden = hidden; a.hidden32 = hidden32;
+  a.hist = ws;
+  a.rh = a.hist + (size_t)n_sess * (L + 1) * m.HT;
+  a.hcur = a.rh + (size_t)m.nl * n_sess * H;
+  for (int l = 0; l < m.nl; l++) { a.wg[l] = m.lgru_wg[l]; a.bg[l] = m.lgru_bg[l]; a.wc[l] = m.lgru_wc[l]; a.bc[l] = m.lgru_bc[l]; }
+  a.bar = m.gru_bar + 9 * 16;                 // the scan's eight counters and the time-out word come first
+  a.err = m.gru_bar + (size_t)GP_GROUPS * 16;
+  a.M = (int)n_sess; a.L = L; a.H = H; a.HT = m.HT; a.nl = m.nl; a.P = H / GP_U;
+  a.CH = low_persist_chunk(H, m.nl, n_sess);
+  const int Q = H >> 5;
+  const int Bc = (int)((n_sess + GP_GROUPS - 1) / GP_GROUPS), pad = (Bc + GP_LB - 1) / GP_LB * GP_LB;
+  const size_t lds_bytes = (size_t)m.nl * 3 * GP_U * (2 * Q * GP_KS + 8) * 16 + (size_t)m.nl * a.CH * 2 * H * 4 + (size_t)m.nl * pad * GP_U * 3 * 4;
+  switch (Q) {
+    case 2: return launch_low_q<2>(a, lds_bytes, st);
+    case 4: return launch_low_q<4>(a, lds_bytes, st);
+    case 8: return launch_low_q<8>(a, lds_bytes, st);
     default: return hipErrorInvalidValue;
   }
 }

@@ -438,7 +438,8 @@ size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
   const size_t R = (size_t)n_sess * L;
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   return 2 * al(R * m.E * 2) + al(R * m.E * 4) + al((size_t)n_sess * 4) + 2 * al((size_t)n_sess * m.HT * 4) +
-         al((size_t)m.nl * n_sess * 5 * m.H * 4) + al(low_gru_x3_elems(m, n_sess) * 2);
+         al((size_t)m.nl * n_sess * 5 * m.H * 4) + al(low_gru_x3_elems(m, n_sess) * 2) +
+         (n_sess <= 1024 ? al(low_gru_persist_floats(m, n_sess, L) * 4) : 0);   // small batches: the persistent launch's history / exchange buffers
 }
 
 // training keeps everything the backward pass needs: L+1 states and one record per (step, layer)
@@ -467,6 +468,8 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
     hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
+  if (b.persist && !b.keep_all && low_gru_persist_applies(m, n_sess))   // small evaluation batches: the whole recurrence as ONE launch (gru_persist.hip)
+    return launch_low_gru_persist(m, b.uf, b.seq_len, n_sess, L, hidden, b.hidden32, b.persist, st);
   if ((e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state (model_gru.py:52: initial_state=None)
   if (b.x3 && !b.hidden32 && gru_x3_applies(m)) {
     // split-operand cells on the 16-bit MFMA (gru_x3.hip): same records, states and outputs as the fp32 cells below
@@ -577,6 +580,7 @@ hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* spro
   b.keep_all = 0;
   b.hidden32 = nullptr;
   b.x3 = reinterpret_cast<uint16_t*>(take(low_gru_x3_elems(m, n_sess) * 2));
+  b.persist = n_sess <= 1024 ? reinterpret_cast<float*>(take(low_gru_persist_floats(m, n_sess, L) * 4)) : nullptr;
   return launch_low_gru_bufs(m, x, sproj, n_sess, L, hidden, b, st);
 }
 

@@ -20,7 +20,7 @@ def make_batch(rng, B, S, L, N):
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 32
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-N, d, S, L = 20778, 256, 10, 20
+N, d, S, L = 20778, int(os.environ.get("D", "256")), 10, 20
 args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B,
                      model_low_type=os.environ.get("LOW", "tcn"))
 eng = Engine(args, hier=True)

@@ -240,3 +240,55 @@ def test_split_operand_cells_agree_with_the_fp32_cells():
     assert (diff > 0).mean() < 0.01                                     # almost every 16-bit output is bit-identical
     assert diff.max() <= 2.0 ** -8 * np.abs(b).max() + 1e-12             # ... and no output differs by more than one ulp of the storage type
     eng.close()
+
+
+@pytest.mark.parametrize("d,nl,B,S,L", [(64, 2, 32, 10, 20), (128, 2, 32, 10, 20), (256, 2, 32, 10, 20), (128, 1, 5, 3, 7), (128, 3, 60, 10, 12)])
+def test_persistent_low_level_matches_the_launch_chain_and_the_oracle(d, nl, B, S, L):
+    """Small evaluation batches run the HierGRU low level as ONE persistent launch (csrc/gru_persist.hip, k_low_gru_persist: E == H, <= 1024
+    sessions); HIERTCN_LGRU_CHAIN=1 keeps the chain of split-operand cell launches.  Same rows from both (a storage-type ulp where the cells'
+    2^-16 products differ from the exact fp32 ones), the mirror oracle's zeros past sequence_length, and the fp32 mode's rows to 1e-5."""
+    import os
+    from hiertcn_amd.engine import Engine
+    N = 900
+    args = gru_args(N=N, d=d, H=d, nl=nl, L=L, S=S, B=B)
+    p = make_params(args)
+    rng = np.random.default_rng(d + nl)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, d * nl))).astype(np.float32)
+    st0[:3] = 0.0
+    xl, yl, ml = as_lists(x, y, mask)
+    ref, _ = O.model_hier(args, xl, yl, ml, st0, O.round_params_bf16(p, E=d), O.MIRROR, return_hidden=True)
+    ref = ref.reshape(B * S * L, d)
+    ref64, _ = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64, return_hidden=True)
+    ref64 = ref64.reshape(B * S * L, d)
+
+    def rows(dtype):
+        eng = Engine(args, hier=True, dtype=dtype)
+        eng.set_weights(p)
+        pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+        sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+        hid = eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1)).float().cpu().numpy()
+        out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True)
+        rk = out["rank"].cpu().numpy()
+        assert not eng.persistent_timed_out()
+        eng.close()
+        return hid, rk
+
+    assert os.environ.get("HIERTCN_LGRU_CHAIN") is None
+    os.environ["HIERTCN_LGRU_CHAIN"] = "0"       # the persistent launch wherever it fits (by default not at H = 256, where it is no faster)
+    try:
+        one, rk_one = rows("bf16")
+        one32, _ = rows("fp32")
+        os.environ["HIERTCN_LGRU_CHAIN"] = "1"
+        chain, rk_chain = rows("bf16")
+        chain32, _ = rows("fp32")
+    finally:
+        os.environ.pop("HIERTCN_LGRU_CHAIN")
+    assert np.array_equal(one == 0, ref == 0)                      # [TF-sem] exact zeros past the counted length, from the one launch too
+    for got in (one, chain):
+        diff = np.abs(got - ref)
+        assert diff.max() <= 2.0 ** -7 and diff.mean() <= 1e-4, (diff.max(), diff.mean())
+    assert np.abs(one - chain).max() <= 2.0 ** -7
+    assert (rk_one == rk_chain).mean() > 0.97                      # ranks move only where a storage-type ulp moved a near-tie
+    assert np.abs(one32 - ref64).max() < 1e-5 and np.abs(chain32 - ref64).max() < 1e-5
+    assert np.abs(one32 - chain32).max() < 1e-5
