@@ -292,3 +292,4 @@ def test_persistent_low_level_matches_the_launch_chain_and_the_oracle(d, nl, B, 
     assert (rk_one == rk_chain).mean() > 0.97                      # ranks move only where a storage-type ulp moved a near-tie
     assert np.abs(one32 - ref64).max() < 1e-5 and np.abs(chain32 - ref64).max() < 1e-5
     assert np.abs(one32 - chain32).max() < 1e-5
+    assert not np.array_equal(one32, chain32)                      # two different kernels did run (fp32 dot products in another summation order)
