@@ -282,18 +282,19 @@ def test_exact_mode_contract_errors():
     ex.close()
 
 
-@pytest.mark.parametrize("N,d,zscale,mode", [(300_000, 256, 30.0, "fp32"), (300_000, 256, 30.0, "split16"), (100_000, 512, 10.0, "fp32")],
-                         ids=["cfg3_width_z30", "cfg3_width_z30_split16", "cfg4_width_d512_z10"])
+@pytest.mark.parametrize("N,d,zscale,mode", [(300_000, 256, 30.0, "fp32"), (300_000, 256, 30.0, "split16"), (100_000, 512, 10.0, "fp32"),
+                                             (1_000_000, 512, 10.0, "fp32")],
+                         ids=["cfg3_width_z30", "cfg3_width_z30_split16", "cfg4_width_d512_z10", "cfg4_full_catalogue_d512_z10"])
 def test_exact_mode_at_the_north_star_catalogue_widths(N, d, zscale, mode):
     """BASELINE.json configs[2] / configs[3] widths (300,000 items at d = 256; d = 512) on a few lanes, scoring layer scaled to a trained
     model's logit range: fp32-mode logits < 1e-3 of the exact oracle on unrounded weights, ranks inside the oracle's near-tie bracket and
     equal on nearly every row, ranked top-10 equal wherever the oracle's own gaps exceed the row's logit error."""
     from hiertcn_amd.engine import Engine
-    B, S, L, K = 2, 3, 30, 10
+    B, S, L, K = (1, 1, 30, 10) if N >= 1_000_000 else (2, 3, 30, 10)   # BASELINE.json configs[3]'s full 1 M-item catalogue: one lane x one slot (240 MB of fp64 logits)
     args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
     p = _trained_like(make_params(args), args, "hier/tcn")
     rng = np.random.default_rng(N + d)
-    x, y, mask = make_batch(rng, B, S, L, N, ragged=True, zipf=True)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=N < 1_000_000, zipf=True)
     st0 = (0.2 * rng.standard_normal((B, 2 * d))).astype(np.float32)
     xl, yl, ml = as_lists(x, y, mask)
     yy = y.reshape(B, S * L).astype(np.int64)
@@ -319,7 +320,8 @@ def test_exact_mode_at_the_north_star_catalogue_widths(N, d, zscale, mode):
     tol = 2 * err_row[..., None] + 1e-7
     lo, hi = (exact > tgt + tol).sum(-1), (exact > tgt - tol).sum(-1)
     assert np.all((rk >= lo)[valid]) and np.all((rk <= hi)[valid])
-    assert (rk == (exact > tgt).sum(-1))[valid].mean() > 0.9
+    # (a mid-ranked target among 10^6 items has neighbours within the fp32 error itself: there only the bracket above is asserted)
+    assert (rk == (exact > tgt).sum(-1))[valid].mean() > (0.9 if N < 1_000_000 else 0.3)
     ti = out["topk_idx"].cpu().numpy().reshape(B, S * L, K)
     want = O.top_k_indices(exact.reshape(-1, N), K + 1).reshape(B, S * L, K + 1)
     top_vals = np.take_along_axis(exact, want.astype(np.int64), -1)
