@@ -40,17 +40,27 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {
 // C = 512 (round 3): the stationary operand (128 VGPRs) and the running output (256) of a wave no longer fit two waves per SIMD, so a
 // workgroup is 4 waves -- one per SIMD, up to 512 registers each -- of 32 stationary vectors, and a stage is ONE 32-vector tile of 32 KB
 // (three stages = 96 KB).  Everything else (LDS image, fragment addressing, the software pipeline) is the same code.
-template <int C>
+// ONE = one wave per SIMD: forced at C = 512; at C = 256 an experiment (HIERTCN_SGRAD_ONEWAVE, profiles/r4_train_notes.md)
+template <int C, bool ONE = (C == 512)>
 struct SgGeom {
-  static constexpr int W = (C == 512) ? 4 : 8;        // waves per workgroup
-  static constexpr int SI = (C == 512) ? 32 : 64;     // stream vectors per LDS stage
+  static constexpr int W = ONE ? 4 : 8;        // waves per workgroup
+  static constexpr int SI = ONE ? 32 : 64;     // stream vectors per LDS stage
   static constexpr int TILES = SI / 32;
   static constexpr int THREADS = 64 * W;
   static constexpr int STAT = 32 * W;                 // stationary vectors per workgroup
   static constexpr int STAGE_BYTES = SI * 2 * C;
 };
-static int sg_stat(int C) { return C == 512 ? 128 : 256; }
-static int sg_si(int C) { return C == 512 ? 32 : 64; }
+// HIERTCN_SGRAD_ONEWAVE: a string of mode digits ("0", "2", "02", ...) whose C = 256 kernels run in the one-wave-per-SIMD shape (A/B runs)
+static bool sg_one(int C, int mode) {
+  if (C == 512) return true;
+  const char* e = getenv("HIERTCN_SGRAD_ONEWAVE");
+  if (C != 256 || !e) return false;
+  for (; *e; e++)
+    if (*e - '0' == mode || (mode == 1 && *e == '2')) return true;   // (the fix-up, mode 1, follows mode 2's shape)
+  return false;
+}
+static int sg_stat(int C, bool one) { return one ? 128 : 256; }
+static int sg_si(int C, bool one) { return one ? 32 : 64; }
 
 struct SgradArgs {
   const uint16_t* stat; const float* stat_const; int64_t n_stat_max; const int32_t* n_stat_dev;
@@ -66,10 +76,10 @@ struct SgradArgs {
   const float* out_bias; int32_t* o_rank; float* o_ce; float* o_tgt;
 };
 
-template <int C, int MODE>
-__global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgrad(const SgradArgs a) {
+template <int C, int MODE, bool ONE = (C == 512)>
+__global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sgrad(const SgradArgs a) {
   using G = ScGeom<C>;
-  using SG = SgGeom<C>;
+  using SG = SgGeom<C, ONE>;
   static_assert(C == 128 || C == 256 || C == 512, "the dual-use LDS image is laid out for 256-, 512- and 1024-byte rows");
   constexpr int NCB = C / 32;
   constexpr int SI = SG::SI;
@@ -79,7 +89,7 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
   // as the single chain has them, modes 0 / 1 fit and mode 2 spills 9 registers outside the MFMA phases: 337.6 -> 331.1 ms per 1024-user step.
   // -DHIERTCN_SGRAD_ONE_CHAIN_256: the single chain, for A/B.
 #ifdef HIERTCN_SGRAD_ONE_CHAIN_256
-  constexpr bool TWO_CHAINS = C == 512;
+  constexpr bool TWO_CHAINS = ONE;
 #else
   constexpr bool TWO_CHAINS = C >= 256;
 #endif
@@ -284,7 +294,7 @@ __global__ __launch_bounds__(SgGeom<C>::THREADS, (C == 512 ? 1 : 2)) void k_sgra
 #pragma unroll
       for (int j = 0; j < 4; j++) acc[4 * q + j] = b4[j];
     }
-    if constexpr (TWO_CHAINS && C < 512) {
+    if constexpr (TWO_CHAINS && !ONE) {
       // two waves per SIMD: fragment reads one ahead, as the single chain has them (a deeper ring spills)
       f32x16 acc2;
 #pragma unroll
@@ -523,21 +533,21 @@ __global__ __launch_bounds__(256) void k_dwo_onehot(const uint16_t* __restrict__
 
 bool sgrad_supported(const ModelDev& m) { return m.Clast == 128 || m.Clast == 256 || (m.Clast == 512 && !getenv("HIERTCN_SGRAD512_OFF")); }
 
-template <int C, int MODE>
+template <int C, int MODE, bool ONE>
 static hipError_t launch_k_sgrad(const SgradArgs& a, dim3 grid, hipStream_t st) {
-  using SG = SgGeom<C>;
+  using SG = SgGeom<C, ONE>;
   const size_t lds = 3 * (size_t)SG::STAGE_BYTES + 3 * SG::SI * sizeof(float);
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgrad<C, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_sgrad<C, MODE, ONE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((k_sgrad<C, MODE>), grid, dim3(SG::THREADS), lds, st, a);
+  hipLaunchKernelGGL((k_sgrad<C, MODE, ONE>), grid, dim3(SG::THREADS), lds, st, a);
   return hipGetLastError();
 }
 template <int MODE>
 static hipError_t launch_k_sgrad_c(const ModelDev& m, const SgradArgs& a, dim3 grid, hipStream_t st) {
   switch (m.Clast) {
-    case 128: return launch_k_sgrad<128, MODE>(a, grid, st);
-    case 256: return launch_k_sgrad<256, MODE>(a, grid, st);
-    case 512: return launch_k_sgrad<512, MODE>(a, grid, st);
+    case 128: return launch_k_sgrad<128, MODE, false>(a, grid, st);
+    case 256: return sg_one(256, MODE) ? launch_k_sgrad<256, MODE, true>(a, grid, st) : launch_k_sgrad<256, MODE, false>(a, grid, st);
+    case 512: return launch_k_sgrad<512, MODE, true>(a, grid, st);
     default: return hipErrorInvalidValue;
   }
 }
@@ -552,11 +562,12 @@ hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const
   SgradArgs a;
   memset(&a, 0, sizeof(a));
   a.stat = hidden; a.n_stat_max = R; a.n_stat_dev = n_dev;
-  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / sg_si(m.Clast);
+  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / sg_si(m.Clast, sg_one(m.Clast, 2));
   a.out = dh; a.row_map = row_map; a.yc = y; a.wc = w; a.outT = m.outT; a.N = m.N; a.ovf = ovf;
   a.out_bias = m.out_bias; a.o_rank = o_rank; a.o_ce = o_ce; a.o_tgt = o_tgt;
   a.walk = m.walk_pos;
-  return launch_k_sgrad_c<2>(m, a, dim3((unsigned)((R + sg_stat(m.Clast) - 1) / sg_stat(m.Clast))), st);
+  const int stat2 = sg_stat(m.Clast, sg_one(m.Clast, 2));
+  return launch_k_sgrad_c<2>(m, a, dim3((unsigned)((R + stat2 - 1) / stat2)), st);
 }
 
 // d hidden from the saved log-sum-exp (mode 1) for the compact scored rows; vote != 0: only the 256-row blocks with a row flagged in ovf
@@ -566,10 +577,11 @@ hipError_t launch_sgrad_dh(const ModelDev& m, const uint16_t* hc, const float* r
   SgradArgs a;
   memset(&a, 0, sizeof(a));
   a.stat = hc; a.stat_const = rb_l2; a.n_stat_max = R + 64; a.n_stat_dev = n_dev;
-  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / sg_si(m.Clast);
+  a.stream = m.outT; a.stream_bias = m.out_bias; a.n_stages_max = m.NP / sg_si(m.Clast, sg_one(m.Clast, 1));
   a.out = dh; a.row_map = row_map; a.yc = yc; a.wc = wc; a.outT = m.outT; a.N = m.N; a.ovf = ovf; a.vote = vote;
   a.walk = m.walk_pos;
-  return launch_k_sgrad_c<1>(m, a, dim3((unsigned)((R + sg_stat(m.Clast) - 1) / sg_stat(m.Clast))), st);
+  const int stat1 = sg_stat(m.Clast, sg_one(m.Clast, 1));
+  return launch_k_sgrad_c<1>(m, a, dim3((unsigned)((R + stat1 - 1) / stat1)), st);
 }
 
 // d Wo / d bo (mode 0), ACCUMULATED into dwo [NP][C] / dbias [NP] (the gradient arena is zeroed at the start of the step), followed by
@@ -580,7 +592,7 @@ hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* 
   SgradArgs a;
   memset(&a, 0, sizeof(a));
   a.stat = m.outT; a.stat_const = bias_l2; a.n_stat_max = m.NP;
-  const int si = sg_si(m.Clast), stat = sg_stat(m.Clast);
+  const int si = sg_si(m.Clast, sg_one(m.Clast, 0)), stat = sg_stat(m.Clast, sg_one(m.Clast, 0));
   a.stream = hc; a.stream_bias = rb_nat; a.n_stages_max = (int)((R + 63) / 64 * 64 / si); a.n_stream_dev = n_dev;   // (the compact rows are padded to 64)
   a.out = dwo; a.colsum = dbias;
   a.walk = m.walk_pos;

@@ -27,10 +27,24 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
-    if world > 1 and torch.cuda.is_available() and world > torch.cuda.device_count():
-        # ranks share a GPU (a gloo smoke run): the persistent GRU scan assumes its workgroups are co-resident on a device of their own
-        # (csrc/gru_persist.hip) -- run the scan as the chain of GEMM launches instead
-        os.environ.setdefault("HIERTCN_GRU_CHAIN", "1")
+    if world > 1 and torch.cuda.is_available():
+        # Do ranks share a GPU (a gloo smoke run, HIP_VISIBLE_DEVICES mapping several ranks to one device, ...)?  The persistent launches (the
+        # across-session scan and the HierGRU low level of small batches, csrc/gru_persist.hip) assume their workgroups are co-resident on a
+        # device of their own: decided from the devices actually in use -- every rank's (uuid | pci address) of its current device -- not
+        # from the rank count, and the launch chains run instead where a device is shared.
+        shared = world > torch.cuda.device_count()
+        try:
+            prop = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device())
+            ident = str(getattr(prop, "uuid", "")) or "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
+                                                                          getattr(prop, "pci_device_id", 0))
+            idents = [None] * world
+            dist.all_gather_object(idents, ident)
+            shared = shared or len(set(idents)) < world
+        except Exception:  # noqa: BLE001  (an identity the runtime does not report: keep the count-based answer)
+            pass
+        if shared:
+            os.environ.setdefault("HIERTCN_GRU_CHAIN", "1")
+            os.environ.setdefault("HIERTCN_LGRU_CHAIN", "1")
     return rank, world, local_rank
 
 

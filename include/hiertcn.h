@@ -151,6 +151,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
  *                                          (The table and every hidden row are scaled by powers of two before the split: no range limit
  *                                          short of fp32's own.)
  * In FP32 and SPLIT16 every `hidden` argument is float [R][C_last].  Evaluation only: the training entry points return HIERTCN_ERR_STATE.
+ * FP32 keeps ONE logits scratch per handle: calls of a handle in that mode must not overlap on different streams (SPLIT16 and STORAGE16 have no such state).
  * The first switch to a mode must precede hiertcn_set_weights (it allocates the weight copies that set_weights fills -- for FP32 also a logits
  * scratch of <= 1 GiB owned by the handle); after that the modes may be switched back and forth between calls. */
 #define HIERTCN_PRECISION_STORAGE16 0
