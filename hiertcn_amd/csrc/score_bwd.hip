@@ -40,7 +40,8 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {
 // C = 512 (round 3): the stationary operand (128 VGPRs) and the running output (256) of a wave no longer fit two waves per SIMD, so a
 // workgroup is 4 waves -- one per SIMD, up to 512 registers each -- of 32 stationary vectors, and a stage is ONE 32-vector tile of 32 KB
 // (three stages = 96 KB).  Everything else (LDS image, fragment addressing, the software pipeline) is the same code.
-// ONE = one wave per SIMD: forced at C = 512; at C = 256 an experiment (HIERTCN_SGRAD_ONEWAVE, profiles/r4_train_notes.md)
+// ONE = one wave per SIMD: what C = 512 needs.  At C = 256 it was measured in round 4 and is slower (mode 0: 150 -> 230 ms, mode 2: 167 -> 232 ms per
+// 1024-user step, bit-identical results: profiles/r4_train_notes.md), so only <512, *, true> and <128 / 256, *, false> are instantiated.
 template <int C, bool ONE = (C == 512)>
 struct SgGeom {
   static constexpr int W = ONE ? 4 : 8;        // waves per workgroup
@@ -50,15 +51,7 @@ struct SgGeom {
   static constexpr int STAT = 32 * W;                 // stationary vectors per workgroup
   static constexpr int STAGE_BYTES = SI * 2 * C;
 };
-// HIERTCN_SGRAD_ONEWAVE: a string of mode digits ("0", "2", "02", ...) whose C = 256 kernels run in the one-wave-per-SIMD shape (A/B runs)
-static bool sg_one(int C, int mode) {
-  if (C == 512) return true;
-  const char* e = getenv("HIERTCN_SGRAD_ONEWAVE");
-  if (C != 256 || !e) return false;
-  for (; *e; e++)
-    if (*e - '0' == mode || (mode == 1 && *e == '2')) return true;   // (the fix-up, mode 1, follows mode 2's shape)
-  return false;
-}
+static bool sg_one(int C, int mode) { (void)mode; return C == 512; }
 static int sg_stat(int C, bool one) { return one ? 128 : 256; }
 static int sg_si(int C, bool one) { return one ? 32 : 64; }
 
@@ -546,7 +539,7 @@ template <int MODE>
 static hipError_t launch_k_sgrad_c(const ModelDev& m, const SgradArgs& a, dim3 grid, hipStream_t st) {
   switch (m.Clast) {
     case 128: return launch_k_sgrad<128, MODE, false>(a, grid, st);
-    case 256: return sg_one(256, MODE) ? launch_k_sgrad<256, MODE, true>(a, grid, st) : launch_k_sgrad<256, MODE, false>(a, grid, st);
+    case 256: return launch_k_sgrad<256, MODE, false>(a, grid, st);
     case 512: return launch_k_sgrad<512, MODE, true>(a, grid, st);
     default: return hipErrorInvalidValue;
   }
