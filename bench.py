@@ -344,8 +344,9 @@ def exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
            "achieved_algorithmic_tflops": round(alg, 2), "achieved_executed_tflops": round(3 * alg, 2),
            "frac_of_peak_over_3": round(alg / (MFMA_PEAK_TFLOPS / 3), 4),
            "peak_over_3": round(MFMA_PEAK_TFLOPS / 3, 1)}
-    # the fp32 mode (exact.hip) on the same handle, a smaller batch: ~20x slower, bounded by the 157 TFLOP/s fp32 MFMA
-    if rank == 0:
+    # the fp32 mode (exact.hip) on the same handle, a smaller batch: ~20x slower, bounded by the 157 TFLOP/s fp32 MFMA (single-GPU runs only:
+    # every rank of an N-GPU run does the same work in the same order)
+    if rank == 0 and world == 1:
         Bf = min(a.exact_fp32_users, Bx)
         eng.set_precision("fp32")
         xb, yb, mb = (t[:Bf].contiguous() for t in batches[0])
