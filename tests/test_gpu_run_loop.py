@@ -61,8 +61,9 @@ def test_evaluate_hier_hip_vs_oracle(tmp_path, packed):
     model.engine.close()
 
 
-def test_evaluate_hier_in_the_exact_mode_equals_the_exact_oracle(tmp_path):
-    """`--storage_dtype fp32` through the run loop: the epoch metrics of evaluate_hier on the fp32 mode equal those of the exact oracle
+@pytest.mark.parametrize("dtype", ["fp32", "split16"])
+def test_evaluate_hier_in_the_exact_mode_equals_the_exact_oracle(tmp_path, dtype):
+    """`--storage_dtype fp32` (exact.hip) and `--storage_dtype split16` (the fast parity-grade mode, score_x3.hip) through the run loop: the epoch metrics of evaluate_hier on the fp32 mode equal those of the exact oracle
     (fp64, unrounded weights) driven through the same loop -- loss to 1e-5, every rank-derived mean exactly or within one near-tie --
     with a scoring layer scaled to a trained model's logit range, where the 16-bit path would be visibly off."""
     from hiertcn_amd.model import HierTCNModel
@@ -70,7 +71,7 @@ def test_evaluate_hier_in_the_exact_mode_equals_the_exact_oracle(tmp_path):
     data = load_xing(CSV)
     n_items = int(data[1][:, 1].max()) + 1
     args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=5,
-                         batch_size=4, max_session_num=3, max_activity_len=6, storage_dtype="fp32")
+                         batch_size=4, max_session_num=3, max_activity_len=6, storage_dtype=dtype)
     args.log_path = str(tmp_path) + "/log/"
     os.makedirs(args.log_path + "test/")
     params = make_params(args)

@@ -227,6 +227,27 @@ def test_ranks_do_not_depend_on_the_item_walk_or_the_launch():
     eng.close()
 
 
+def test_eval_graph_replay_in_this_mode_matches_the_direct_call():
+    """hiertcn_forward_eval in the split16 mode captured into a hipGraph (Engine.capture_eval_graph): nothing in it synchronises or allocates,
+    and a replay gives the direct call's state and metrics bit for bit."""
+    from hiertcn_amd.engine import Engine
+    N, d, B, S, L = 3000, 128, 8, 4, 12
+    args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
+    eng = Engine(args, hier=True, dtype="split16")
+    eng.set_weights(make_params(args))
+    rng = np.random.default_rng(1)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=True)
+    st0 = (0.2 * rng.standard_normal((B, 2 * d))).astype(np.float32)
+    want = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0))
+    g = eng.capture_eval_graph(B, S, L)
+    g.x.copy_(dev(x)); g.y.copy_(dev(y)); g.mask.copy_(dev(mask)); g.state_in.copy_(dev(st0))
+    g.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(g.state_out, want["state"])
+    assert torch.equal(g.metrics8[:6], want["metrics8"][:6]) or (g.metrics8 - want["metrics8"]).abs().max().item() < 1e-6   # (ce: the item walk's entry point)
+    eng.close()
+
+
 def test_split16_contract_errors():
     from hiertcn_amd.engine import Engine
     from hiertcn_amd._lib import HierTCNError
