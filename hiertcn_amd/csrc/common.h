@@ -89,6 +89,9 @@ struct ModelDev {
   int lgru_split;                         // 1: the hi / lo 16-bit splits of the low-level GRU kernels below are allocated (gru_x3.hip)
   uint16_t* lgru_wg_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wg_lo[HIERTCN_MAX_LAYERS];   // [2H][in+H]
   uint16_t* lgru_wc_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wc_lo[HIERTCN_MAX_LAYERS];   // [H][in+H]
+  // fragment-major copies of the four (lgru_tile.hip): [N/32][(in+H)/16][64 lanes][8]
+  uint16_t* lgru_wgF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wgF_lo[HIERTCN_MAX_LAYERS];
+  uint16_t* lgru_wcF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wcF_lo[HIERTCN_MAX_LAYERS];
   int* walk_pos;        // [8][32] ints, zeroed: per-XCD position words of the scoring kernel's item walk (null: every workgroup starts at stage 0)
 };
 
@@ -143,6 +146,10 @@ struct LowGruBufs {
   float* persist;     // scratch of the persistent launch (gru_persist.hip), low_gru_persist_floats() floats; null: the launch chain runs
 };
 size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess);
+// lgru_tile.hip: the HierGRU low level of small batches, one workgroup per 32 sessions through all steps and layers (no launch chain, no exchange)
+bool lgru_tile_applies(const ModelDev& m, int64_t n_sess);
+hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
+                            hipStream_t st);
 // gru_persist.hip: the HierGRU low level of small evaluation batches as one persistent launch
 bool low_gru_persist_applies(const ModelDev& m, int64_t n_sess);
 size_t low_gru_persist_floats(const ModelDev& m, int64_t n_sess, int L);

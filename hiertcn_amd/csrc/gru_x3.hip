@@ -285,6 +285,12 @@ hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st) {
     const int64_t ng = (int64_t)(in + m.H) * 2 * m.H, nc = (int64_t)(in + m.H) * m.H;
     if ((e = launch_split_f32(m.lgru_wg[l], ng, m.lgru_wg_hi[l], m.lgru_wg_lo[l], st)) != hipSuccess) return e;
     if ((e = launch_split_f32(m.lgru_wc[l], nc, m.lgru_wc_hi[l], m.lgru_wc_lo[l], st)) != hipSuccess) return e;
+    if (m.lgru_wgF_hi[l] && ((in + m.H) % 16) == 0 && (m.H % 32) == 0) {   // fragment-major copies for the session-tile kernel (lgru_tile.hip)
+      if ((e = launch_frag_major(m.lgru_wg_hi[l], m.lgru_wgF_hi[l], 1, 2 * m.H, in + m.H, st)) != hipSuccess) return e;
+      if ((e = launch_frag_major(m.lgru_wg_lo[l], m.lgru_wgF_lo[l], 1, 2 * m.H, in + m.H, st)) != hipSuccess) return e;
+      if ((e = launch_frag_major(m.lgru_wc_hi[l], m.lgru_wcF_hi[l], 1, m.H, in + m.H, st)) != hipSuccess) return e;
+      if ((e = launch_frag_major(m.lgru_wc_lo[l], m.lgru_wcF_lo[l], 1, m.H, in + m.H, st)) != hipSuccess) return e;
+    }
   }
   return hipSuccess;
 }

@@ -274,7 +274,9 @@ def test_persistent_low_level_matches_the_launch_chain_and_the_oracle(d, nl, B, 
         eng.close()
         return hid, rk
 
-    assert os.environ.get("HIERTCN_LGRU_CHAIN") is None
+    assert os.environ.get("HIERTCN_LGRU_CHAIN") is None and os.environ.get("HIERTCN_LGRU_TILE") is None
+    tile, rk_tile = rows("bf16")                 # default: the session-tile kernel (csrc/lgru_tile.hip) where it applies (E == H <= 128), else as below
+    os.environ["HIERTCN_LGRU_TILE"] = "0"
     os.environ["HIERTCN_LGRU_CHAIN"] = "0"       # the persistent launch wherever it fits (by default not at H = 256, where it is no faster)
     try:
         one, rk_one = rows("bf16")
@@ -284,8 +286,11 @@ def test_persistent_low_level_matches_the_launch_chain_and_the_oracle(d, nl, B, 
         chain32, _ = rows("fp32")
     finally:
         os.environ.pop("HIERTCN_LGRU_CHAIN")
+        os.environ.pop("HIERTCN_LGRU_TILE")
     assert np.array_equal(one == 0, ref == 0)                      # [TF-sem] exact zeros past the counted length, from the one launch too
-    for got in (one, chain):
+    assert np.array_equal(tile == 0, ref == 0)
+    assert (rk_tile == rk_chain).mean() > 0.97
+    for got in (one, chain, tile):
         diff = np.abs(got - ref)
         assert diff.max() <= 2.0 ** -7 and diff.mean() <= 1e-4, (diff.max(), diff.mean())
     assert np.abs(one - chain).max() <= 2.0 ** -7
