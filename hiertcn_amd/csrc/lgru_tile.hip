@@ -9,14 +9,13 @@
 // activations [x | h] of the 32 sessions live in LDS as split 16-bit rows (the MFMA B operand), the fp32 states in registers.
 //   D[row = unit][col = session] (swapped orientation, as gru_x3.hip): a lane holds 16 units of one session per tile.
 //   wave w owns unit blocks w, w + 4, ...: the r, z and candidate tiles of the same units, so only r * h crosses waves (through LDS).
-// Two workgroup barriers per cell.  Applies to E == H in {64, 128} and up to 2048 sessions, 16-bit storage mode, evaluation and the training
+// Two workgroup barriers per cell.  Applies to E == H in {64, 128, 256}, one or two layers and up to 2048 sessions, 16-bit storage mode, evaluation and the training
 // forward (which also keeps r, z, r * h, the candidate, the output and every state for the backward pass).
 #include <string.h>
 
 #include "common.h"
 
 #define LT_THREADS 256
-#define LT_R 8           // register ring: fragments of LT_R - 1 k-steps in flight
 
 struct LgruTileArgs {
   const uint16_t* u16;                       // [M][L][E] projected [e, state] rows, storage type
@@ -37,14 +36,17 @@ __device__ __forceinline__ void lt_split(float v, uint16_t& hi, uint16_t& lo) {
   lo = f2bf(v - bf2f(hi));
 }
 
-template <int HB>   // H / 32: 2 or 4 (E == H)
+template <int HB, int NLM>   // H / 32 in {2, 4, 8} (E == H); NLM: compile-time bound on the layers (the states are register arrays)
 __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile(const LgruTileArgs a) {
   constexpr int H = 32 * HB, KS = 4 * HB;          // k-steps of a product: (E + H) / 16 with E == H
   constexpr int KSI = KS / 2;                      // ... of which the input half
   constexpr int PITCH = 2 * H + 16;                // bytes per session row of a split activation buffer (rows 4 banks apart)
-  constexpr int NBW = (HB + 3) / 4;                // unit blocks per wave (1 here)
-  constexpr int IC = NBW * 3 * KS;                 // ring items (k-steps of weight fragments) a wave consumes per cell
-  static_assert(HB == 2 || HB == 4, "E == H in {64, 128}");
+  constexpr int NBW = (HB + 3) / 4;                // unit blocks per wave: block b = wave + 4 bi
+  constexpr int IC = NBW * 3 * KS;                 // k-steps of weight fragments a wave consumes per cell
+  constexpr int LT_R = (HB == 2) ? 8 : 16;         // register ring: the fragments of LT_R - 1 k-steps in flight (an L2 round trip under this load is ~1 us:
+                                                   // with 7 in flight a k-step took ~280 cycles against the 96 of its three MFMAs)
+  static_assert(HB == 2 || HB == 4 || HB == 8, "E == H in {64, 128, 256}");
+  static_assert(IC % LT_R == 0, "ring slots must repeat from cell to cell");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -56,7 +58,6 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile(const LgruTileArgs 
   const int64_t sc = live ? sess : (int64_t)M - 1;
   const int len = a.seq_len[sc];
   const bool has_blocks = wave < HB;               // (H = 64: two of the four waves have no unit block; they help with the row loads only)
-  const int blk = wave;                            // this wave's unit block (NBW == 1)
 
   // ---- LDS carve-up
   unsigned char* UB = smem;                                        // [2][32][PITCH]: the projected rows of step t (storage type, no lo part)
@@ -66,24 +67,26 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile(const LgruTileArgs 
   unsigned char* RHl = RHh + 32 * PITCH;
   for (int i = tid; i < 2 * nl * 32 * PITCH / 16; i += LT_THREADS) reinterpret_cast<uint4*>(HSh)[i] = make_uint4(0, 0, 0, 0);   // zero_state
 
-  // ---- weight stream.  Item i of a cell (i < 3 KS): gates r tile (k-steps 0 .. KS-1), gates z tile, candidate tile; its fragments:
-  const uint16_t* wg_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wg_lo[HIERTCN_MAX_LAYERS];
-  const uint16_t* wc_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wc_lo[HIERTCN_MAX_LAYERS];
+  // ---- weight stream.  Item i of a cell (i < IC): for every block of the wave its r tile (k-steps 0 .. KS-1) and its z tile, then -- behind the
+  // barrier -- every block's candidate tile.  Fragment-major tables: tile row T, k-step s at ((T KS + s) 64 + lane) 8.
+  const uint16_t* wg_hi[NLM]; const uint16_t* wg_lo[NLM];
+  const uint16_t* wc_hi[NLM]; const uint16_t* wc_lo[NLM];
 #pragma unroll
-  for (int l = 0; l < HIERTCN_MAX_LAYERS; l++) {   // this wave's rows of every table, this lane's 16 bytes of a fragment
-    wg_hi[l] = a.wgF_hi[l] + (size_t)blk * KS * 512 + lane * 8; wg_lo[l] = a.wgF_lo[l] + (size_t)blk * KS * 512 + lane * 8;
-    wc_hi[l] = a.wcF_hi[l] + (size_t)blk * KS * 512 + lane * 8; wc_lo[l] = a.wcF_lo[l] + (size_t)blk * KS * 512 + lane * 8;
+  for (int l = 0; l < NLM; l++) {   // this wave's first block of every table, this lane's 16 bytes of a fragment
+    wg_hi[l] = a.wgF_hi[l] + (size_t)wave * KS * 512 + lane * 8; wg_lo[l] = a.wgF_lo[l] + (size_t)wave * KS * 512 + lane * 8;
+    wc_hi[l] = a.wcF_hi[l] + (size_t)wave * KS * 512 + lane * 8; wc_lo[l] = a.wcF_lo[l] + (size_t)wave * KS * 512 + lane * 8;
   }
-  uint4 rgh[LT_R], rgl[LT_R];   // the ring: item n of the running sequence in slot n % LT_R (IC is a multiple of LT_R: slots are the same in every cell)
-  static_assert(IC % LT_R == 0, "ring slots must repeat from cell to cell");
+  uint4 rgh[LT_R], rgl[LT_R];   // the ring: item n of the running sequence in slot n % LT_R
   auto frag_load = [&](const uint16_t* ghi, const uint16_t* glo, const uint16_t* chi, const uint16_t* clo, int i, uint4& fh, uint4& fl) {
-    // (i is a compile-time constant at every call site)
-    if (i < 2 * KS) {
-      const size_t off = ((size_t)(i / KS) * HB * KS + (i % KS)) * 512;   // z rows start HB tiles behind the r rows
+    // (i is a compile-time constant at every call site once the loops are unrolled)
+    if (i < 2 * NBW * KS) {
+      const int bi = i / (2 * KS), sel = (i / KS) & 1, ks = i % KS;
+      const size_t off = ((size_t)(sel * HB + 4 * bi) * KS + ks) * 512;   // z rows start HB tiles behind the r rows
       fh = *reinterpret_cast<const uint4*>(ghi + off);
       fl = *reinterpret_cast<const uint4*>(glo + off);
     } else {
-      const size_t off = (size_t)(i - 2 * KS) * 512;
+      const int c = i - 2 * NBW * KS, bi = c / KS, ks = c % KS;
+      const size_t off = ((size_t)(4 * bi) * KS + ks) * 512;
       fh = *reinterpret_cast<const uint4*>(chi + off);
       fl = *reinterpret_cast<const uint4*>(clo + off);
     }
@@ -93,19 +96,20 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile(const LgruTileArgs 
     for (int i = 0; i < LT_R - 1; i++) frag_load(wg_hi[0], wg_lo[0], wc_hi[0], wc_lo[0], i, rgh[i], rgl[i]);
   }
 
-  float hreg[HIERTCN_MAX_LAYERS][16];   // this lane's 16 units of its session, every layer (fp32 state)
+  float hreg[NLM][NBW][16];   // this lane's units of its session, every layer (fp32 state)
 #pragma unroll
-  for (int l = 0; l < HIERTCN_MAX_LAYERS; l++)
+  for (int l = 0; l < NLM; l++)
 #pragma unroll
-    for (int i = 0; i < 16; i++) hreg[l][i] = 0.f;
+    for (int b = 0; b < NBW; b++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) hreg[l][b][i] = 0.f;
 
   // the projected rows of a step: 32 sessions x H 16-bit values = 32 x (H / 8) chunks of 16 bytes
-  constexpr int UCH = 32 * (H / 8);
-  static_assert(UCH <= 2 * LT_THREADS, "two chunks per thread at most");
-  uint4 ureg[2];
+  constexpr int UCH = 32 * (H / 8), UPT = (UCH + LT_THREADS - 1) / LT_THREADS;
+  uint4 ureg[UPT];
   auto u_fetch = [&](int t) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < UPT; k++) {
       const int c = tid + k * LT_THREADS;
       if (c < UCH) {
         const int row = c / (H / 8), ch = c % (H / 8);
@@ -116,7 +120,7 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile(const LgruTileArgs 
   };
   auto u_store = [&](int buf) {
 #pragma unroll
-    for (int k = 0; k < 2; k++) {
+    for (int k = 0; k < UPT; k++) {
       const int c = tid + k * LT_THREADS;
       if (c < UCH) {
         const int row = c / (H / 8), ch = c % (H / 8);
@@ -133,112 +137,126 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile(const LgruTileArgs 
     if (t + 1 < L) u_fetch(t + 1);          // in flight during the step's cells
     const bool active = t < len;
 #pragma unroll
-    for (int l = 0; l < HIERTCN_MAX_LAYERS; l++) {   // (compile-time l: the states are register arrays)
+    for (int l = 0; l < NLM; l++) {   // (compile-time l: the states are register arrays)
       if (l >= nl) break;
       const unsigned char* Xh = (l == 0) ? UB + (t & 1) * 32 * PITCH : HSh + (l - 1) * 32 * PITCH;
       const unsigned char* Xl = (l == 0) ? nullptr : HSl + (l - 1) * 32 * PITCH;
       const unsigned char* Sh = HSh + l * 32 * PITCH;
       const unsigned char* Sl = HSl + l * 32 * PITCH;
       float* rec = a.rec ? a.rec + ((size_t)t * nl + l) * cellf : nullptr;
-      float zreg[16];
+      float zreg[NBW][16];
       // the tables of this cell and of the next one (the ring prefetches across the cell boundary)
       const uint16_t* ghi = wg_hi[l]; const uint16_t* glo = wg_lo[l]; const uint16_t* chi = wc_hi[l]; const uint16_t* clo = wc_lo[l];
       const bool wrap = l + 1 >= nl;
-      const uint16_t* nghi = wrap ? wg_hi[0] : wg_hi[(l + 1) % HIERTCN_MAX_LAYERS]; const uint16_t* nglo = wrap ? wg_lo[0] : wg_lo[(l + 1) % HIERTCN_MAX_LAYERS];
-      const uint16_t* nchi = wrap ? wc_hi[0] : wc_hi[(l + 1) % HIERTCN_MAX_LAYERS]; const uint16_t* nclo = wrap ? wc_lo[0] : wc_lo[(l + 1) % HIERTCN_MAX_LAYERS];
+      const uint16_t* nghi = wrap ? wg_hi[0] : wg_hi[(l + 1) % NLM]; const uint16_t* nglo = wrap ? wg_lo[0] : wg_lo[(l + 1) % NLM];
+      const uint16_t* nchi = wrap ? wc_hi[0] : wc_hi[(l + 1) % NLM]; const uint16_t* nclo = wrap ? wc_lo[0] : wc_lo[(l + 1) % NLM];
       // (opaque copies: the fragment loads do not depend on t, and hipcc would otherwise hoist every one of them out of the step loop -- 512 registers
       // and 1.8 KB of scratch per lane)
       asm volatile("" : "+v"(ghi), "+v"(glo), "+v"(chi), "+v"(clo), "+v"(nghi), "+v"(nglo), "+v"(nchi), "+v"(nclo));
-      // one k-step: item i of the cell into `acc`; B operand fragment ks of (bh_p | bl_p); the ring slot freed by item i - 1 takes item i + LT_R - 1
-#define LT_KSTEP(acc_, i_, bh_p_, bl_p_, kl_)                                                                        \
+      // one k-step: item i of the cell into `acc`.  The B operand fragment of k-step ks (hi, lo) was read one k-step earlier (a single wave per
+      // SIMD has nobody to cover an LDS round trip); this step reads the next one's -- k-step ks + 1 of the same tile, or k-step 0 of the tile's
+      // successor in the same phase -- and the ring slot freed by item i - 1 takes item i + LT_R - 1.
+      uint4 bqh[2], bql[2];
+      auto b_read = [&](const unsigned char* hp, const unsigned char* lp, int ks, uint4& oh, uint4& ol) {   // ks compile-time; second half from (hp2, lp2)
+        const int ko = ks * 32 + lh * 16;
+        oh = *reinterpret_cast<const uint4*>(hp + lr * PITCH + ko);
+        ol = lp ? *reinterpret_cast<const uint4*>(lp + lr * PITCH + ko) : make_uint4(0, 0, 0, 0);
+      };
+#define LT_BPTR_H(ks_, h2_) ((ks_) < KSI ? Xh : (h2_))
+#define LT_BPTR_L(ks_, l2_) ((ks_) < KSI ? Xl : (l2_))
+#define LT_KSTEP(acc_, i_, ks_, h2_, l2_, more_)                                                                      \
       {                                                                                                               \
-        const int ii_ = (i_);                                                                                        \
+        const int ii_ = (i_), kk_ = (ks_);                                                                           \
         if (ii_ + LT_R - 1 < IC) frag_load(ghi, glo, chi, clo, ii_ + LT_R - 1, rgh[(ii_ + LT_R - 1) % LT_R], rgl[(ii_ + LT_R - 1) % LT_R]);          \
         else frag_load(nghi, nglo, nchi, nclo, ii_ + LT_R - 1 - IC, rgh[(ii_ + LT_R - 1) % LT_R], rgl[(ii_ + LT_R - 1) % LT_R]);                     \
-        const int ko_ = (kl_) * 32 + lh * 16;                                                                        \
-        const uint4 bh_ = *reinterpret_cast<const uint4*>((bh_p_) + lr * PITCH + ko_);                               \
-        acc_ = mfma32(rgh[ii_ % LT_R], bh_, acc_);                                                                   \
-        acc_ = mfma32(rgl[ii_ % LT_R], bh_, acc_);                                                                   \
-        if (bl_p_) {                                                                                                 \
-          const uint4 bl_ = *reinterpret_cast<const uint4*>((bl_p_) + lr * PITCH + ko_);                             \
-          acc_ = mfma32(rgh[ii_ % LT_R], bl_, acc_);                                                                 \
-        }                                                                                                            \
+        if (kk_ + 1 < KS) b_read(LT_BPTR_H(kk_ + 1, h2_), LT_BPTR_L(kk_ + 1, l2_), (kk_ + 1) % KSI, bqh[(kk_ + 1) & 1], bql[(kk_ + 1) & 1]);         \
+        else if (more_) b_read(Xh, Xl, 0, bqh[0], bql[0]);   /* KS is even: the next tile's k-step 0 lands in slot 0 */                              \
+        acc_ = mfma32(rgh[ii_ % LT_R], bqh[kk_ & 1], acc_);                                                          \
+        acc_ = mfma32(rgl[ii_ % LT_R], bqh[kk_ & 1], acc_);                                                          \
+        if (LT_BPTR_L(kk_, l2_)) acc_ = mfma32(rgh[ii_ % LT_R], bql[kk_ & 1], acc_);                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                           \
       }
       if (has_blocks) {
-        // ---------------- gates: r and z tiles of this wave's units
-        f32x16 acc[2];
+        // ---------------- gates: the r and z tiles of this wave's units
 #pragma unroll
-        for (int sel = 0; sel < 2; sel++) {
+        for (int bi = 0; bi < NBW; bi++) {
+          const int blk = wave + 4 * bi;
+          f32x16 acc[2];
 #pragma unroll
-          for (int reg = 0; reg < 16; reg++) acc[sel][reg] = a.bg[l][sel * H + 32 * blk + acc_row(reg, lh)];
+          for (int sel = 0; sel < 2; sel++) {
 #pragma unroll
-          for (int ks = 0; ks < KSI; ks++) LT_KSTEP(acc[sel], sel * KS + ks, Xh, Xl, ks)
+            for (int reg = 0; reg < 16; reg++) acc[sel][reg] = a.bg[l][sel * H + 32 * blk + acc_row(reg, lh)];
+            if (bi == 0 && sel == 0) b_read(Xh, Xl, 0, bqh[0], bql[0]);   // (every later tile's first fragment is read by its predecessor's last k-step)
 #pragma unroll
-          for (int ks = KSI; ks < KS; ks++) LT_KSTEP(acc[sel], sel * KS + ks, Sh, Sl, ks - KSI)
-        }
-        // epilogue (customed_gru_cell.py:323-326): r, z = sigmoid; r * h -> LDS (split) for the candidate's recurrent half
-#pragma unroll
-        for (int q = 0; q < 4; q++) {
-          float r4[4], rh4[4];
-          uint16_t hi[4], lo[4];
-#pragma unroll
-          for (int j = 0; j < 4; j++) {
-            r4[j] = lt_sigmoid(acc[0][4 * q + j]);
-            zreg[4 * q + j] = lt_sigmoid(acc[1][4 * q + j]);
-            rh4[j] = r4[j] * hreg[l][4 * q + j];
-            lt_split(rh4[j], hi[j], lo[j]);
+            for (int ks = 0; ks < KS; ks++) LT_KSTEP(acc[sel], (bi * 2 + sel) * KS + ks, ks, Sh, Sl, !(bi == NBW - 1 && sel == 1))
           }
-          const int unit = 32 * blk + 8 * q + 4 * lh;
-          *reinterpret_cast<uint2*>(RHh + lr * PITCH + unit * 2) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
-          *reinterpret_cast<uint2*>(RHl + lr * PITCH + unit * 2) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
-          if (rec && live) {
-            *reinterpret_cast<float4*>(rec + sess * 2 * H + unit) = make_float4(r4[0], r4[1], r4[2], r4[3]);
-            *reinterpret_cast<float4*>(rec + sess * 2 * H + H + unit) = make_float4(zreg[4 * q], zreg[4 * q + 1], zreg[4 * q + 2], zreg[4 * q + 3]);
-            *reinterpret_cast<float4*>(rec + (size_t)M * 2 * H + sess * H + unit) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
+          // epilogue (customed_gru_cell.py:323-326): r, z = sigmoid; r * h -> LDS (split) for the candidate's recurrent half
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            float r4[4], rh4[4];
+            uint16_t hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              r4[j] = lt_sigmoid(acc[0][4 * q + j]);
+              zreg[bi][4 * q + j] = lt_sigmoid(acc[1][4 * q + j]);
+              rh4[j] = r4[j] * hreg[l][bi][4 * q + j];
+              lt_split(rh4[j], hi[j], lo[j]);
+            }
+            const int unit = 32 * blk + 8 * q + 4 * lh;
+            *reinterpret_cast<uint2*>(RHh + lr * PITCH + unit * 2) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+            *reinterpret_cast<uint2*>(RHl + lr * PITCH + unit * 2) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+            if (rec && live) {
+              *reinterpret_cast<float4*>(rec + sess * 2 * H + unit) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+              *reinterpret_cast<float4*>(rec + sess * 2 * H + H + unit) = make_float4(zreg[bi][4 * q], zreg[bi][4 * q + 1], zreg[bi][4 * q + 2], zreg[bi][4 * q + 3]);
+              *reinterpret_cast<float4*>(rec + (size_t)M * 2 * H + sess * H + unit) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
+            }
           }
         }
       }
       __syncthreads();   // r * h of every unit is in LDS
       if (has_blocks) {
         // ---------------- candidate (customed_gru_cell.py:333-336): c = tanh([x, r*h] Wc + b); h' = z h + (1 - z) c
-        f32x16 acc;
 #pragma unroll
-        for (int reg = 0; reg < 16; reg++) acc[reg] = a.bc[l][32 * blk + acc_row(reg, lh)];
+        for (int bi = 0; bi < NBW; bi++) {
+          const int blk = wave + 4 * bi;
+          f32x16 acc;
 #pragma unroll
-        for (int ks = 0; ks < KSI; ks++) LT_KSTEP(acc, 2 * KS + ks, Xh, Xl, ks)
+          for (int reg = 0; reg < 16; reg++) acc[reg] = a.bc[l][32 * blk + acc_row(reg, lh)];
+          if (bi == 0) b_read(Xh, Xl, 0, bqh[0], bql[0]);
 #pragma unroll
-        for (int ks = KSI; ks < KS; ks++) LT_KSTEP(acc, 2 * KS + ks, RHh, RHl, ks - KSI)
-        // dynamic_rnn past the session's length: state through, output zero (model_gru.py:47-53)
+          for (int ks = 0; ks < KS; ks++) LT_KSTEP(acc, (2 * NBW + bi) * KS + ks, ks, RHh, RHl, bi + 1 < NBW)
+          // dynamic_rnn past the session's length: state through, output zero (model_gru.py:47-53)
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          float c4[4], hn[4], st4[4];
-          uint16_t hi[4], lo[4];
+          for (int q = 0; q < 4; q++) {
+            float c4[4], hn[4], st4[4];
+            uint16_t hi[4], lo[4];
 #pragma unroll
-          for (int j = 0; j < 4; j++) {
-            const float h = hreg[l][4 * q + j], z = zreg[4 * q + j];
-            c4[j] = lt_tanh(acc[4 * q + j]);
-            hn[j] = z * h + (1.0f - z) * c4[j];
-            st4[j] = active ? hn[j] : h;
-            hreg[l][4 * q + j] = st4[j];
-            lt_split(st4[j], hi[j], lo[j]);
-          }
-          const int unit = 32 * blk + 8 * q + 4 * lh;
-          // the state's split is the h operand of step t + 1 and the next layer's input at this step (for a finished session the next layer's
-          // result is discarded, so the carried state standing in for the cell output there changes nothing)
-          *reinterpret_cast<uint2*>(HSh + (l * 32 + lr) * PITCH + unit * 2) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
-          *reinterpret_cast<uint2*>(HSl + (l * 32 + lr) * PITCH + unit * 2) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
-          if (live) {
-            if (rec) {
-              *reinterpret_cast<float4*>(rec + (size_t)M * 3 * H + sess * H + unit) = make_float4(c4[0], c4[1], c4[2], c4[3]);
-              *reinterpret_cast<float4*>(rec + (size_t)M * 4 * H + sess * H + unit) = make_float4(hn[0], hn[1], hn[2], hn[3]);
-              *reinterpret_cast<float4*>(a.states + ((size_t)(t + 1) * M + sess) * HT + (size_t)l * H + unit) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+            for (int j = 0; j < 4; j++) {
+              const float h = hreg[l][bi][4 * q + j], z = zreg[bi][4 * q + j];
+              c4[j] = lt_tanh(acc[4 * q + j]);
+              hn[j] = z * h + (1.0f - z) * c4[j];
+              st4[j] = active ? hn[j] : h;
+              hreg[l][bi][4 * q + j] = st4[j];
+              lt_split(st4[j], hi[j], lo[j]);
             }
-            if (l == nl - 1) {
-              uint2 o;
-              o.x = active ? pack2bf(hn[0], hn[1]) : 0u;
-              o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
-              *reinterpret_cast<uint2*>(a.hidden + (sess * L + t) * H + unit) = o;
+            const int unit = 32 * blk + 8 * q + 4 * lh;
+            // the state's split is the h operand of step t + 1 and the next layer's input at this step (for a finished session the next layer's
+            // result is discarded, so the carried state standing in for the cell output there changes nothing).  Nobody reads HS[l] in this
+            // phase (its readers are the gates phases of this layer and the cells of layer l + 1, all behind a barrier from here).
+            *reinterpret_cast<uint2*>(HSh + (l * 32 + lr) * PITCH + unit * 2) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+            *reinterpret_cast<uint2*>(HSl + (l * 32 + lr) * PITCH + unit * 2) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+            if (live) {
+              if (rec) {
+                *reinterpret_cast<float4*>(rec + (size_t)M * 3 * H + sess * H + unit) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+                *reinterpret_cast<float4*>(rec + (size_t)M * 4 * H + sess * H + unit) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+                *reinterpret_cast<float4*>(a.states + ((size_t)(t + 1) * M + sess) * HT + (size_t)l * H + unit) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+              }
+              if (l == nl - 1) {
+                uint2 o;
+                o.x = active ? pack2bf(hn[0], hn[1]) : 0u;
+                o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
+                *reinterpret_cast<uint2*>(a.hidden + (sess * L + t) * H + unit) = o;
+              }
             }
           }
         }
@@ -248,6 +266,8 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile(const LgruTileArgs 
     }
   }
 #undef LT_KSTEP
+#undef LT_BPTR_H
+#undef LT_BPTR_L
 }
 
 static size_t lt_lds_bytes(const ModelDev& m) {
@@ -260,7 +280,7 @@ bool lgru_tile_applies(const ModelDev& m, int64_t n_sess) {
   if (sw && sw[0] == '0') return false;
   if (!m.low_gru || !m.lgru_split || !m.lgru_wgF_hi[0] || n_sess <= 0 || n_sess > 2048) return false;
   if (getenv("HIERTCN_LGRU_FP32")) return false;   // (the fp32 cells were asked for)
-  return m.E == m.H && (m.H == 64 || m.H == 128) && lt_lds_bytes(m) <= 160 * 1024;
+  return m.E == m.H && (m.H == 64 || m.H == 128 || m.H == 256) && m.nl <= 2 && lt_lds_bytes(m) <= 160 * 1024;
 }
 
 hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
@@ -275,13 +295,16 @@ hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_
   a.M = (int)n_sess; a.L = L; a.H = m.H; a.HT = m.HT; a.nl = m.nl;
   const size_t lds = lt_lds_bytes(m);
   const unsigned blocks = (unsigned)((n_sess + 31) / 32);
-  hipError_t e;
-  if (m.H == 64) {
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_tile<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lgru_tile<2>, dim3(blocks), dim3(LT_THREADS), lds, st, a);
-  } else {
-    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_tile<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lgru_tile<4>, dim3(blocks), dim3(LT_THREADS), lds, st, a);
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(LT_THREADS), lds, st, a);
+    return hipGetLastError();
+  };
+  switch (m.H) {
+    case 64: return go(k_lgru_tile<2, 2>);
+    case 128: return go(k_lgru_tile<4, 2>);
+    case 256: return go(k_lgru_tile<8, 2>);
+    default: return hipErrorInvalidValue;
   }
-  return hipGetLastError();
 }
