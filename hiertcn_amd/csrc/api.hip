@@ -195,6 +195,10 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
         ALLOC_OR_FAIL(m.lgru_wgF_lo[l], (size_t)(in + m.H) * 2 * m.H);
         ALLOC_OR_FAIL(m.lgru_wcF_hi[l], (size_t)(in + m.H) * m.H);
         ALLOC_OR_FAIL(m.lgru_wcF_lo[l], (size_t)(in + m.H) * m.H);
+        ALLOC_OR_FAIL(m.lgru_wgTF_hi[l], (size_t)(in + m.H) * 2 * m.H);
+        ALLOC_OR_FAIL(m.lgru_wgTF_lo[l], (size_t)(in + m.H) * 2 * m.H);
+        ALLOC_OR_FAIL(m.lgru_wcTF_hi[l], (size_t)(in + m.H) * m.H);
+        ALLOC_OR_FAIL(m.lgru_wcTF_lo[l], (size_t)(in + m.H) * m.H);
         m.lgru_split = 1;
       }
     }

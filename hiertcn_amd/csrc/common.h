@@ -92,6 +92,9 @@ struct ModelDev {
   // fragment-major copies of the four (lgru_tile.hip): [N/32][(in+H)/16][64 lanes][8]
   uint16_t* lgru_wgF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wgF_lo[HIERTCN_MAX_LAYERS];
   uint16_t* lgru_wcF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wcF_lo[HIERTCN_MAX_LAYERS];
+  // ... and of their transposes (the backward pass of lgru_tile.hip): [(in+H)/32][N/16][64 lanes][8]
+  uint16_t* lgru_wgTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wgTF_lo[HIERTCN_MAX_LAYERS];
+  uint16_t* lgru_wcTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wcTF_lo[HIERTCN_MAX_LAYERS];
   int* walk_pos;        // [8][32] ints, zeroed: per-XCD position words of the scoring kernel's item walk (null: every workgroup starts at stage 0)
 };
 
@@ -148,6 +151,9 @@ struct LowGruBufs {
 size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess);
 // lgru_tile.hip: the HierGRU low level of small batches, one workgroup per 32 sessions through all steps and layers (no launch chain, no exchange)
 bool lgru_tile_applies(const ModelDev& m, int64_t n_sess);
+hipError_t launch_lgru_tile_bwd(const ModelDev& m, const float* dH, const int32_t* seq_len, const float* states, const float* rec, int64_t n_sess, int L, float* du,
+                                float* dac_all, float* dag_all, hipStream_t st);
+hipError_t launch_frag_major_T(const uint16_t* W, uint16_t* WfT, int N, int K, hipStream_t st);
 hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
                             hipStream_t st);
 // gru_persist.hip: the HierGRU low level of small evaluation batches as one persistent launch

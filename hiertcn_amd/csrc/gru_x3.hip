@@ -290,6 +290,12 @@ hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st) {
       if ((e = launch_frag_major(m.lgru_wg_lo[l], m.lgru_wgF_lo[l], 1, 2 * m.H, in + m.H, st)) != hipSuccess) return e;
       if ((e = launch_frag_major(m.lgru_wc_hi[l], m.lgru_wcF_hi[l], 1, m.H, in + m.H, st)) != hipSuccess) return e;
       if ((e = launch_frag_major(m.lgru_wc_lo[l], m.lgru_wcF_lo[l], 1, m.H, in + m.H, st)) != hipSuccess) return e;
+      if (m.lgru_wgTF_hi[l] && ((in + m.H) % 32) == 0) {   // ... and of the transposes (its backward pass)
+        if ((e = launch_frag_major_T(m.lgru_wg_hi[l], m.lgru_wgTF_hi[l], 2 * m.H, in + m.H, st)) != hipSuccess) return e;
+        if ((e = launch_frag_major_T(m.lgru_wg_lo[l], m.lgru_wgTF_lo[l], 2 * m.H, in + m.H, st)) != hipSuccess) return e;
+        if ((e = launch_frag_major_T(m.lgru_wc_hi[l], m.lgru_wcTF_hi[l], m.H, in + m.H, st)) != hipSuccess) return e;
+        if ((e = launch_frag_major_T(m.lgru_wc_lo[l], m.lgru_wcTF_lo[l], m.H, in + m.H, st)) != hipSuccess) return e;
+      }
     }
   }
   return hipSuccess;

@@ -308,3 +308,290 @@ hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_
     default: return hipErrorInvalidValue;
   }
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward through time of the same cells (model_gru.py:47-55 differentiated by model.py:139-141), same decomposition: a workgroup takes its 32
+// sessions from the last step to the first through every layer, the carried state gradients and the gradient handed down to the layer below stay
+// in registers (with E == H the input-half tile of a unit block belongs to the wave that owns that block one layer down), the TRANSPOSED weight
+// rows stream through the register ring.  Per cell (customed_gru_cell.py:323-336 backwards):
+//   d = active ? (carried + d out) : 0;  da_c = d (1-z)(1-c^2);  dh' = d z;  da_z = d (h - c) z (1-z)
+//   [d x_c | d(r h)] = da_c . Wc;   da_r = d(r h) h r (1-r);   dh' += d(r h) r
+//   [d x_g | d h_g]  = [da_r | da_z] . Wg;   d x = d x_c + d x_g  (-> the layer below, or d u);   carried = active ? dh' + d h_g : carried
+// The pre-activation gradients da_c, [da_r | da_z] of every cell are kept: the weight gradients are formed behind the loop, one product per layer
+// and operand over all L x M rows (train.hip, lgru_deferred_wgrad).  Two workgroup barriers per cell.
+struct LgruTileBwdArgs {
+  const float* dH;                           // [M * L][H]: d loss / d (top layer output)
+  const int32_t* seq_len;
+  const float* states;                       // [(L + 1)][M][HT]
+  const float* rec;                          // per (t, l): gates [M][2H] | r*h | cand | out
+  const uint16_t* wcT_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wcT_lo[HIERTCN_MAX_LAYERS];   // (Wc)^T fragment-major: [K/32][H/16][64][8]
+  const uint16_t* wgT_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wgT_lo[HIERTCN_MAX_LAYERS];   // (Wg)^T: [K/32][2H/16][64][8]
+  float* du;                                 // [M * L][E]: gradient of the projected rows
+  float* dac_all;                            // [(l L + t)][M][H]
+  float* dag_all;                            // [(l L + t)][M][2H]
+  int M, L, H, HT, nl;
+};
+
+template <int HB, int NLM>
+__global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile_bwd(const LgruTileBwdArgs a) {
+  constexpr int H = 32 * HB;
+  constexpr int KSC = 2 * HB, KSG = 4 * HB;        // k-steps (reduction over H resp. 2H) of the two products
+  constexpr int PC = 2 * H + 16, PG = 4 * H + 16;  // LDS pitches of the split da_c resp. [da_r | da_z] rows
+  constexpr int NBW = (HB + 3) / 4;
+  constexpr int IC = NBW * 2 * (KSC + KSG);
+  constexpr int LT_R = (HB == 2) ? 8 : 16;
+  static_assert(IC % LT_R == 0, "ring slots must repeat from cell to cell");
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nl = a.nl, L = a.L, M = a.M, HT = a.HT;
+  const int64_t sess = (int64_t)blockIdx.x * 32 + lr;
+  const bool live = sess < M;
+  const int64_t sc = live ? sess : (int64_t)M - 1;
+  const int len = a.seq_len[sc];
+  const bool has_blocks = wave < HB;
+  unsigned char* DCh = smem;                 // [32][PC] da_c, hi
+  unsigned char* DCl = DCh + 32 * PC;
+  unsigned char* DGh = DCl + 32 * PC;        // [32][PG] [da_r | da_z], hi
+  unsigned char* DGl = DGh + 32 * PG;
+
+  const uint16_t* tc_hi[NLM]; const uint16_t* tc_lo[NLM];
+  const uint16_t* tg_hi[NLM]; const uint16_t* tg_lo[NLM];
+#pragma unroll
+  for (int l = 0; l < NLM; l++) {
+    tc_hi[l] = a.wcT_hi[l] + (size_t)wave * KSC * 512 + lane * 8; tc_lo[l] = a.wcT_lo[l] + (size_t)wave * KSC * 512 + lane * 8;
+    tg_hi[l] = a.wgT_hi[l] + (size_t)wave * KSG * 512 + lane * 8; tg_lo[l] = a.wgT_lo[l] + (size_t)wave * KSG * 512 + lane * 8;
+  }
+  uint4 rgh[LT_R], rgl[LT_R];
+  // item i of a cell: for every block (candidate product) its input-half tile then its state-half tile; then the same for the gates product
+  auto frag_load = [&](const uint16_t* chi, const uint16_t* clo, const uint16_t* ghi, const uint16_t* glo, int i, uint4& fh, uint4& fl) {
+    if (i < 2 * NBW * KSC) {
+      const int bi = i / (2 * KSC), part = (i / KSC) & 1, ks = i % KSC;
+      const size_t off = ((size_t)(part * HB + 4 * bi) * KSC + ks) * 512;
+      fh = *reinterpret_cast<const uint4*>(chi + off);
+      fl = *reinterpret_cast<const uint4*>(clo + off);
+    } else {
+      const int c = i - 2 * NBW * KSC, bi = c / (2 * KSG), part = (c / KSG) & 1, ks = c % KSG;
+      const size_t off = ((size_t)(part * HB + 4 * bi) * KSG + ks) * 512;
+      fh = *reinterpret_cast<const uint4*>(ghi + off);
+      fl = *reinterpret_cast<const uint4*>(glo + off);
+    }
+  };
+  const int ltop = nl - 1;
+  if (has_blocks) {
+    const uint16_t* c0 = ltop == 0 ? tc_hi[0] : (ltop == 1 ? tc_hi[1 % NLM] : tc_hi[0]);   // (NLM <= 2)
+    const uint16_t* c1 = ltop == 0 ? tc_lo[0] : tc_lo[1 % NLM];
+    const uint16_t* g0 = ltop == 0 ? tg_hi[0] : tg_hi[1 % NLM];
+    const uint16_t* g1 = ltop == 0 ? tg_lo[0] : tg_lo[1 % NLM];
+#pragma unroll
+    for (int i = 0; i < LT_R - 1; i++) frag_load(c0, c1, g0, g1, i, rgh[i], rgl[i]);
+  }
+
+  float dcar[NLM][NBW][16];   // carried state gradients
+  float dinu[NBW][16];        // gradient handed down by the layer above at this step
+#pragma unroll
+  for (int l = 0; l < NLM; l++)
+#pragma unroll
+    for (int b = 0; b < NBW; b++)
+#pragma unroll
+      for (int i = 0; i < 16; i++) dcar[l][b][i] = 0.f;   // the low level's final state is dropped (model_gru.py:47)
+#pragma unroll
+  for (int b = 0; b < NBW; b++)
+#pragma unroll
+    for (int i = 0; i < 16; i++) dinu[b][i] = 0.f;
+
+  const size_t cellf = (size_t)M * 5 * H;
+  for (int t = L - 1; t >= 0; t--) {
+    const bool active = t < len;
+#pragma unroll
+    for (int lq = 0; lq < NLM; lq++) {      // layers top down: l = nl - 1 - lq (compile-time lq, l = a select below)
+      if (lq >= nl) break;
+      // (the register arrays are indexed by the compile-time POSITION from the top: position lq holds layer nl - 1 - lq)
+      const int l = nl - 1 - lq;
+      const float* rec = a.rec + ((size_t)t * nl + l) * cellf;
+      const float* hp = a.states + ((size_t)t * M + sc) * HT + (size_t)l * H;
+      const uint16_t* chi = l == 0 ? tc_hi[0] : tc_hi[1 % NLM]; const uint16_t* clo = l == 0 ? tc_lo[0] : tc_lo[1 % NLM];
+      const uint16_t* ghi = l == 0 ? tg_hi[0] : tg_hi[1 % NLM]; const uint16_t* glo = l == 0 ? tg_lo[0] : tg_lo[1 % NLM];
+      const int ln = l == 0 ? nl - 1 : l - 1;   // the next cell's layer
+      const uint16_t* nchi = ln == 0 ? tc_hi[0] : tc_hi[1 % NLM]; const uint16_t* nclo = ln == 0 ? tc_lo[0] : tc_lo[1 % NLM];
+      const uint16_t* nghi = ln == 0 ? tg_hi[0] : tg_hi[1 % NLM]; const uint16_t* nglo = ln == 0 ? tg_lo[0] : tg_lo[1 % NLM];
+      asm volatile("" : "+v"(chi), "+v"(clo), "+v"(ghi), "+v"(glo), "+v"(nchi), "+v"(nclo), "+v"(nghi), "+v"(nglo));
+      float rr[NBW][16], zz[NBW][16], hh[NBW][16], dhp[NBW][16], dagz[NBW][16], dxc[NBW][16];
+      // ---------------- P1: through the blend and the tanh
+      if (has_blocks) {
+#pragma unroll
+        for (int bi = 0; bi < NBW; bi++) {
+          const int blk = wave + 4 * bi;
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int unit = 32 * blk + 8 * q + 4 * lh;
+            const float4 r4 = *reinterpret_cast<const float4*>(rec + sc * 2 * H + unit);
+            const float4 z4 = *reinterpret_cast<const float4*>(rec + sc * 2 * H + H + unit);
+            const float4 c4 = *reinterpret_cast<const float4*>(rec + (size_t)M * 3 * H + sc * H + unit);
+            const float4 h4 = *reinterpret_cast<const float4*>(hp + unit);
+            float4 o4 = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (lq == 0) o4 = *reinterpret_cast<const float4*>(a.dH + (sc * L + t) * H + unit);
+            const float rv[4] = {r4.x, r4.y, r4.z, r4.w}, zv[4] = {z4.x, z4.y, z4.z, z4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
+            const float ov[4] = {o4.x, o4.y, o4.z, o4.w};
+            float dac[4];
+            uint16_t hi[4], lo[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int e = 4 * q + j;
+              const float dout = (lq == 0) ? ov[j] : dinu[bi][e];
+              const float d = active ? dcar[lq][bi][e] + dout : 0.f;
+              rr[bi][e] = rv[j]; zz[bi][e] = zv[j]; hh[bi][e] = hv[j];
+              dac[j] = d * (1.f - zv[j]) * (1.f - cv[j] * cv[j]);
+              dhp[bi][e] = d * zv[j];
+              dagz[bi][e] = d * (hv[j] - cv[j]) * zv[j] * (1.f - zv[j]);
+              lt_split(dac[j], hi[j], lo[j]);
+            }
+            *reinterpret_cast<uint2*>(DCh + lr * PC + unit * 2) = make_uint2(hi[0] | ((uint32_t)hi[1] << 16), hi[2] | ((uint32_t)hi[3] << 16));
+            *reinterpret_cast<uint2*>(DCl + lr * PC + unit * 2) = make_uint2(lo[0] | ((uint32_t)lo[1] << 16), lo[2] | ((uint32_t)lo[3] << 16));
+            if (live) *reinterpret_cast<float4*>(a.dac_all + (((size_t)l * L + t) * M + sess) * H + unit) = make_float4(dac[0], dac[1], dac[2], dac[3]);
+          }
+        }
+      }
+      __syncthreads();   // da_c of every unit is in LDS
+      uint4 bqh[2], bql[2];
+      auto b_read = [&](const unsigned char* hp_, const unsigned char* lp_, int pitch, int ks, uint4& oh, uint4& ol) {
+        const int ko = ks * 32 + lh * 16;
+        oh = *reinterpret_cast<const uint4*>(hp_ + lr * pitch + ko);
+        ol = *reinterpret_cast<const uint4*>(lp_ + lr * pitch + ko);
+      };
+#define LB_KSTEP(acc_, i_, ks_, nks_, bh_, bl_, pitch_, more_)                                                        \
+      {                                                                                                               \
+        const int ii_ = (i_), kk_ = (ks_);                                                                           \
+        if (ii_ + LT_R - 1 < IC) frag_load(chi, clo, ghi, glo, ii_ + LT_R - 1, rgh[(ii_ + LT_R - 1) % LT_R], rgl[(ii_ + LT_R - 1) % LT_R]);          \
+        else frag_load(nchi, nclo, nghi, nglo, ii_ + LT_R - 1 - IC, rgh[(ii_ + LT_R - 1) % LT_R], rgl[(ii_ + LT_R - 1) % LT_R]);                     \
+        if (kk_ + 1 < (nks_)) b_read(bh_, bl_, pitch_, kk_ + 1, bqh[(kk_ + 1) & 1], bql[(kk_ + 1) & 1]);              \
+        else if (more_) b_read(bh_, bl_, pitch_, 0, bqh[0], bql[0]);                                                 \
+        acc_ = mfma32(rgh[ii_ % LT_R], bqh[kk_ & 1], acc_);                                                          \
+        acc_ = mfma32(rgl[ii_ % LT_R], bqh[kk_ & 1], acc_);                                                          \
+        acc_ = mfma32(rgh[ii_ % LT_R], bql[kk_ & 1], acc_);                                                          \
+        __builtin_amdgcn_sched_barrier(0);                                                                           \
+      }
+      if (has_blocks) {
+        // ---------------- P2: [d x_c | d(r h)] = da_c . Wc; through the reset gate
+#pragma unroll
+        for (int bi = 0; bi < NBW; bi++) {
+          const int blk = wave + 4 * bi;
+          f32x16 acc[2];
+#pragma unroll
+          for (int part = 0; part < 2; part++) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) acc[part][reg] = 0.f;
+            if (bi == 0 && part == 0) b_read(DCh, DCl, PC, 0, bqh[0], bql[0]);
+#pragma unroll
+            for (int ks = 0; ks < KSC; ks++) LB_KSTEP(acc[part], (bi * 2 + part) * KSC + ks, ks, KSC, DCh, DCl, PC, !(bi == NBW - 1 && part == 1))
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int unit = 32 * blk + 8 * q + 4 * lh;
+            float dagr[4];
+            uint16_t rhi[4], rlo[4], zhi[4], zlo[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int e = 4 * q + j;
+              dxc[bi][e] = acc[0][e];
+              const float drh = acc[1][e];
+              dagr[j] = drh * hh[bi][e] * rr[bi][e] * (1.f - rr[bi][e]);
+              dhp[bi][e] += drh * rr[bi][e];
+              lt_split(dagr[j], rhi[j], rlo[j]);
+              lt_split(dagz[bi][e], zhi[j], zlo[j]);
+            }
+            *reinterpret_cast<uint2*>(DGh + lr * PG + unit * 2) = make_uint2(rhi[0] | ((uint32_t)rhi[1] << 16), rhi[2] | ((uint32_t)rhi[3] << 16));
+            *reinterpret_cast<uint2*>(DGl + lr * PG + unit * 2) = make_uint2(rlo[0] | ((uint32_t)rlo[1] << 16), rlo[2] | ((uint32_t)rlo[3] << 16));
+            *reinterpret_cast<uint2*>(DGh + lr * PG + (H + unit) * 2) = make_uint2(zhi[0] | ((uint32_t)zhi[1] << 16), zhi[2] | ((uint32_t)zhi[3] << 16));
+            *reinterpret_cast<uint2*>(DGl + lr * PG + (H + unit) * 2) = make_uint2(zlo[0] | ((uint32_t)zlo[1] << 16), zlo[2] | ((uint32_t)zlo[3] << 16));
+            if (live) {
+              float* dg = a.dag_all + (((size_t)l * L + t) * M + sess) * 2 * H;
+              *reinterpret_cast<float4*>(dg + unit) = make_float4(dagr[0], dagr[1], dagr[2], dagr[3]);
+              *reinterpret_cast<float4*>(dg + H + unit) = make_float4(dagz[bi][4 * q], dagz[bi][4 * q + 1], dagz[bi][4 * q + 2], dagz[bi][4 * q + 3]);
+            }
+          }
+        }
+      }
+      __syncthreads();   // [da_r | da_z] of every unit is in LDS
+      if (has_blocks) {
+        // ---------------- P3: [d x_g | d h_g] = [da_r | da_z] . Wg
+#pragma unroll
+        for (int bi = 0; bi < NBW; bi++) {
+          const int blk = wave + 4 * bi;
+          f32x16 acc[2];
+#pragma unroll
+          for (int part = 0; part < 2; part++) {
+#pragma unroll
+            for (int reg = 0; reg < 16; reg++) acc[part][reg] = 0.f;
+            if (bi == 0 && part == 0) b_read(DGh, DGl, PG, 0, bqh[0], bql[0]);
+#pragma unroll
+            for (int ks = 0; ks < KSG; ks++) LB_KSTEP(acc[part], 2 * NBW * KSC + (bi * 2 + part) * KSG + ks, ks, KSG, DGh, DGl, PG, !(bi == NBW - 1 && part == 1))
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int unit = 32 * blk + 8 * q + 4 * lh;
+            float dx[4];
+#pragma unroll
+            for (int j = 0; j < 4; j++) {
+              const int e = 4 * q + j;
+              dx[j] = dxc[bi][e] + acc[0][e];                                   // zero for a finished session (its da rows are zero)
+              dinu[bi][e] = dx[j];
+              dcar[lq][bi][e] = active ? dhp[bi][e] + acc[1][e] : dcar[lq][bi][e];
+            }
+            if (l == 0 && live) *reinterpret_cast<float4*>(a.du + (sess * L + t) * H + unit) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+          }
+        }
+      }
+    }
+  }
+#undef LB_KSTEP
+}
+
+static size_t lt_bwd_lds_bytes(const ModelDev& m) { return 2 * 32 * (2 * (size_t)m.H + 16) + 2 * 32 * (4 * (size_t)m.H + 16); }
+
+hipError_t launch_lgru_tile_bwd(const ModelDev& m, const float* dH, const int32_t* seq_len, const float* states, const float* rec, int64_t n_sess, int L, float* du,
+                                float* dac_all, float* dag_all, hipStream_t st) {
+  LgruTileBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dH = dH; a.seq_len = seq_len; a.states = states; a.rec = rec; a.du = du; a.dac_all = dac_all; a.dag_all = dag_all;
+  for (int l = 0; l < m.nl; l++) {
+    a.wcT_hi[l] = m.lgru_wcTF_hi[l]; a.wcT_lo[l] = m.lgru_wcTF_lo[l]; a.wgT_hi[l] = m.lgru_wgTF_hi[l]; a.wgT_lo[l] = m.lgru_wgTF_lo[l];
+  }
+  a.M = (int)n_sess; a.L = L; a.H = m.H; a.HT = m.HT; a.nl = m.nl;
+  const size_t lds = lt_bwd_lds_bytes(m);
+  const unsigned blocks = (unsigned)((n_sess + 31) / 32);
+  auto go = [&](auto kern) -> hipError_t {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(kern, dim3(blocks), dim3(LT_THREADS), lds, st, a);
+    return hipGetLastError();
+  };
+  switch (m.H) {
+    case 64: return go(k_lgru_tile_bwd<2, 2>);
+    case 128: return go(k_lgru_tile_bwd<4, 2>);
+    case 256: return go(k_lgru_tile_bwd<8, 2>);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+// W [N][K] (16-bit, row-major) -> fragment-major copy of its TRANSPOSE [K][N]: WfT[((kb (N / 16) + s) 64 + lane) 8 + j] = W[16 s + 8 (lane >> 5) + j][32 kb + (lane & 31)]
+__global__ void k_frag_major_T(const uint16_t* __restrict__ W, uint16_t* __restrict__ WfT, int N, int K) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int64_t total = (int64_t)(K >> 5) * (N >> 4) * 64;
+  if (i >= total) return;
+  const int lane = (int)(i & 63);
+  const int64_t f = i >> 6;
+  const int s = (int)(f % (N >> 4)), kb = (int)(f / (N >> 4));
+  uint16_t v[8];
+#pragma unroll
+  for (int j = 0; j < 8; j++) v[j] = W[(int64_t)(16 * s + 8 * (lane >> 5) + j) * K + 32 * kb + (lane & 31)];
+  *reinterpret_cast<uint4*>(WfT + i * 8) = make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16));
+}
+
+hipError_t launch_frag_major_T(const uint16_t* W, uint16_t* WfT, int N, int K, hipStream_t st) {
+  const int64_t total = (int64_t)(K >> 5) * (N >> 4) * 64;
+  if (total <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_frag_major_T, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, W, WfT, N, K);
+  return hipGetLastError();
+}

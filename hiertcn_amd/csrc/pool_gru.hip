@@ -468,8 +468,10 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
     hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
-  if (!b.hidden32 && lgru_tile_applies(m, n_sess))   // small batches: one workgroup per 32 sessions through every step and layer (lgru_tile.hip); training keeps the records
+  if (!b.hidden32 && lgru_tile_applies(m, n_sess)) {   // small batches: one workgroup per 32 sessions through every step and layer (lgru_tile.hip); training keeps the records
+    if (b.keep_all && (e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // slot 0 of the kept states: the zero state the backward pass reads at t = 0
     return launch_lgru_tile(m, b.u16, b.seq_len, n_sess, L, hidden, b.keep_all ? b.states : nullptr, b.keep_all ? b.rec : nullptr, st);
+  }
   if (b.persist && !b.keep_all && low_gru_persist_applies(m, n_sess))   // small evaluation batches (fp32 modes): the whole recurrence as ONE launch (gru_persist.hip)
     return launch_low_gru_persist(m, b.uf, b.seq_len, n_sess, L, hidden, b.hidden32, b.persist, st);
   if ((e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state (model_gru.py:52: initial_state=None)

@@ -919,7 +919,11 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     float* dcat_g = F32(w.lg_dcat_g);
     float* din_up = F32(w.lg_din_up);
     const unsigned gMH = (unsigned)(((int64_t)M * H + 255) / 256);
-    for (int tt = L - 1; tt >= 0; tt--) {
+    // small batches: the whole BPTT as one launch, a workgroup per 32 sessions (lgru_tile.hip); it keeps the cells' pre-activation gradients, the
+    // weight gradients follow below as always in this regime
+    const bool tile_bwd = deferred && m.H <= 128 && lgru_tile_applies(m, (int64_t)M) && !getenv("HIERTCN_LGRU_TILE_BWD_OFF");   // (H = 256: the kernel spills; the launch chain stays)
+    if (tile_bwd) T_HIP(launch_lgru_tile_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, st));
+    for (int tt = L - 1; tt >= 0 && !tile_bwd; tt--) {
       for (int l = m.nl - 1; l >= 0; l--) {
         const int in = (l == 0) ? E : H;
         const int K = in + H;
