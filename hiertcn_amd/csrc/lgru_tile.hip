@@ -339,7 +339,7 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile_bwd(const LgruTileB
   constexpr int PC = 2 * H + 16, PG = 4 * H + 16;  // LDS pitches of the split da_c resp. [da_r | da_z] rows
   constexpr int NBW = (HB + 3) / 4;
   constexpr int IC = NBW * 2 * (KSC + KSG);
-  constexpr int LT_R = (HB == 2) ? 8 : 16;
+  constexpr int LT_R = (HB == 4) ? 16 : 8;         // (H = 256: two blocks per wave leave no room for sixteen)
   static_assert(IC % LT_R == 0, "ring slots must repeat from cell to cell");
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -417,7 +417,7 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile_bwd(const LgruTileB
       const uint16_t* nchi = ln == 0 ? tc_hi[0] : tc_hi[1 % NLM]; const uint16_t* nclo = ln == 0 ? tc_lo[0] : tc_lo[1 % NLM];
       const uint16_t* nghi = ln == 0 ? tg_hi[0] : tg_hi[1 % NLM]; const uint16_t* nglo = ln == 0 ? tg_lo[0] : tg_lo[1 % NLM];
       asm volatile("" : "+v"(chi), "+v"(clo), "+v"(ghi), "+v"(glo), "+v"(nchi), "+v"(nclo), "+v"(nghi), "+v"(nglo));
-      float rr[NBW][16], zz[NBW][16], hh[NBW][16], dhp[NBW][16], dagz[NBW][16], dxc[NBW][16];
+      float dhp[NBW][16], dagz[NBW][16], dxc[NBW][16];   // (r and the old state are read again in P2: cheaper than 32 registers per block across a barrier)
       // ---------------- P1: through the blend and the tanh
       if (has_blocks) {
 #pragma unroll
@@ -441,7 +441,6 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile_bwd(const LgruTileB
               const int e = 4 * q + j;
               const float dout = (lq == 0) ? ov[j] : dinu[bi][e];
               const float d = active ? dcar[lq][bi][e] + dout : 0.f;
-              rr[bi][e] = rv[j]; zz[bi][e] = zv[j]; hh[bi][e] = hv[j];
               dac[j] = d * (1.f - zv[j]) * (1.f - cv[j] * cv[j]);
               dhp[bi][e] = d * zv[j];
               dagz[bi][e] = d * (hv[j] - cv[j]) * zv[j] * (1.f - zv[j]);
@@ -491,13 +490,16 @@ __global__ __launch_bounds__(LT_THREADS, 1) void k_lgru_tile_bwd(const LgruTileB
             const int unit = 32 * blk + 8 * q + 4 * lh;
             float dagr[4];
             uint16_t rhi[4], rlo[4], zhi[4], zlo[4];
+            const float4 r4 = *reinterpret_cast<const float4*>(rec + sc * 2 * H + unit);
+            const float4 h4 = *reinterpret_cast<const float4*>(hp + unit);
+            const float rv[4] = {r4.x, r4.y, r4.z, r4.w}, hv[4] = {h4.x, h4.y, h4.z, h4.w};
 #pragma unroll
             for (int j = 0; j < 4; j++) {
               const int e = 4 * q + j;
               dxc[bi][e] = acc[0][e];
               const float drh = acc[1][e];
-              dagr[j] = drh * hh[bi][e] * rr[bi][e] * (1.f - rr[bi][e]);
-              dhp[bi][e] += drh * rr[bi][e];
+              dagr[j] = drh * hv[j] * rv[j] * (1.f - rv[j]);
+              dhp[bi][e] += drh * rv[j];
               lt_split(dagr[j], rhi[j], rlo[j]);
               lt_split(dagz[bi][e], zhi[j], zlo[j]);
             }

@@ -921,7 +921,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     const unsigned gMH = (unsigned)(((int64_t)M * H + 255) / 256);
     // small batches: the whole BPTT as one launch, a workgroup per 32 sessions (lgru_tile.hip); it keeps the cells' pre-activation gradients, the
     // weight gradients follow below as always in this regime
-    const bool tile_bwd = deferred && m.H <= 128 && lgru_tile_applies(m, (int64_t)M) && !getenv("HIERTCN_LGRU_TILE_BWD_OFF");   // (H = 256: the kernel spills; the launch chain stays)
+    const bool tile_bwd = deferred && lgru_tile_applies(m, (int64_t)M) && !getenv("HIERTCN_LGRU_TILE_BWD_OFF");
     if (tile_bwd) T_HIP(launch_lgru_tile_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, st));
     for (int tt = L - 1; tt >= 0 && !tile_bwd; tt--) {
       for (int l = m.nl - 1; l >= 0; l--) {

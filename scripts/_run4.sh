@@ -1,3 +1,2 @@
-python -m pytest tests/test_gpu_hiergru.py tests/test_gpu_train.py tests/test_gpu_run_loop.py tests/test_gpu_dp_train.py -x -q 2>&1 | tail -5
 python -m pytest tests/test_gpu_hiergru.py -x -q 2>&1 | tail -3
-for cfg in "D=128 LOW=gru" "D=64 LOW=gru" "D=256 LOW=gru" "D=128"; do env N=20778 $cfg python3 scripts/train_bench.py 32 30 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done
+for cfg in "D=128 LOW=gru" "D=256 LOW=gru"; do env N=20778 $cfg python3 scripts/train_bench.py 32 30 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done

@@ -169,8 +169,8 @@ def torch_loss_gru(args, P, x, y, mask, state):
 # the last shape has 640 sessions per step: the row-reduced weight-gradient GEMMs of the low-level cells (csrc/gemm.hip, gemm32_tn) then run in two
 # row slices whose partial tiles are summed in slice order
 @pytest.mark.parametrize("d,H,N,nl,shape", [(64, 64, 700, 2, (6, 3, 8)), (128, 64, 1500, 1, (6, 3, 8)), (64, 64, 700, 2, (160, 4, 6)),
-                                            (128, 128, 900, 2, (9, 4, 7)), (128, 128, 900, 1, (40, 2, 5))],
-                         ids=["d64_nl2", "d128_nl1", "d64_nl2_640_sessions", "d128_h128_nl2", "d128_h128_nl1"])
+                                            (128, 128, 900, 2, (9, 4, 7)), (128, 128, 900, 1, (40, 2, 5)), (256, 256, 600, 2, (5, 3, 6))],
+                         ids=["d64_nl2", "d128_nl1", "d64_nl2_640_sessions", "d128_h128_nl2", "d128_h128_nl1", "d256_h256_nl2"])
 def test_hiergru_training_step_matches_autograd(d, H, N, nl, shape):
     from hiertcn_amd.engine import Engine, metrics_dict
     args = gru_args(N=N, d=d, H=H, nl=nl)
