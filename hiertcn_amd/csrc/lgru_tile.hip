@@ -9,8 +9,9 @@
 // activations [x | h] of the 32 sessions live in LDS as split 16-bit rows (the MFMA B operand), the fp32 states in registers.
 //   D[row = unit][col = session] (swapped orientation, as gru_x3.hip): a lane holds 16 units of one session per tile.
 //   wave w owns unit blocks w, w + 4, ...: the r, z and candidate tiles of the same units, so only r * h crosses waves (through LDS).
-// Two workgroup barriers per cell.  Applies to E == H in {64, 128, 256}, one or two layers and up to 2048 sessions, 16-bit storage mode, evaluation and the training
+// Two workgroup barriers per cell.  Applies to E == H in {64, 128, 256}, one or two layers and up to 32,768 sessions, 16-bit storage mode, evaluation and the training
 // forward (which also keeps r, z, r * h, the candidate, the output and every state for the backward pass).
+#include <stdlib.h>
 #include <string.h>
 
 #include "common.h"
@@ -275,10 +276,15 @@ static size_t lt_lds_bytes(const ModelDev& m) {
   return 2 * 32 * pitch + 2 * (size_t)m.nl * 32 * pitch + 2 * 32 * pitch;   // rows of step t (x 2) | states hi, lo | r*h hi, lo
 }
 
+static int64_t lt_max_sessions() {
+  const char* e = getenv("HIERTCN_LGRU_TILE_MAX");   // sessions up to which the session-tile kernels run (A/B runs)
+  return e ? atoll(e) : 32768;   // (measured up to 20,480 sessions: 77.6 vs 80.0 ms per 1024-user evaluation step at d = 256 against the launch chain, 51.9 vs 53.7 at d = 128)
+}
+
 bool lgru_tile_applies(const ModelDev& m, int64_t n_sess) {
   const char* sw = getenv("HIERTCN_LGRU_TILE");   // "0": never (A/B runs, tests; read on every call)
   if (sw && sw[0] == '0') return false;
-  if (!m.low_gru || !m.lgru_split || !m.lgru_wgF_hi[0] || n_sess <= 0 || n_sess > 2048) return false;
+  if (!m.low_gru || !m.lgru_split || !m.lgru_wgF_hi[0] || n_sess <= 0 || n_sess > lt_max_sessions()) return false;
   if (getenv("HIERTCN_LGRU_FP32")) return false;   // (the fp32 cells were asked for)
   return m.E == m.H && (m.H == 64 || m.H == 128 || m.H == 256) && m.nl <= 2 && lt_lds_bytes(m) <= 160 * 1024;
 }

@@ -1,2 +1,4 @@
-python -m pytest tests/test_gpu_hiergru.py -x -q 2>&1 | tail -3
-for cfg in "D=128 LOW=gru" "D=256 LOW=gru"; do env N=20778 $cfg python3 scripts/train_bench.py 32 30 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done
+for mx in 2048 100000; do
+for D in 128 256; do
+echo "== max $mx d=$D"; HIERTCN_LGRU_TILE_MAX=$mx D=$D LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | grep -v amdgpu | tail -2 | cut -c1-90
+done; done
