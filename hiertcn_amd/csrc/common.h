@@ -195,6 +195,9 @@ struct OneHotGru {
   const float* wc[HIERTCN_MAX_LAYERS]; const float* bc[HIERTCN_MAX_LAYERS];
 };
 size_t onehot_gru_workspace_bytes(int H, int nl, int64_t n_sess);
+size_t rows_gru_workspace_bytes(int H, int nl, int in_dim, int64_t n_sess, int L);
+// the same stack on dense 16-bit rows of width in_dim (wg[0] [2H][in_dim + H], wc[0] [H][in_dim + H]: full kernels, output-major; in_g / in_c unused)
+hipError_t launch_rows_gru(const OneHotGru& w, const uint16_t* rows16, int in_dim, int64_t n_sess, int L, uint16_t* hidden, void* workspace, hipStream_t st);
 hipError_t launch_onehot_gru(const OneHotGru& w, const int32_t* x, int64_t n_sess, int L, uint16_t* hidden, void* workspace, hipStream_t st);
 hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
                           hipStream_t st);

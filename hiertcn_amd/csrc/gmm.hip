@@ -275,10 +275,11 @@ extern "C" {
 
 int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cfg) {
   if (!out || !cfg) return gfail(HIERTCN_ERR_INVALID, "null argument");
-  if ((cfg->trunk != 2 && cfg->item_num < 2) || cfg->output_dim < 2) return gfail(HIERTCN_ERR_INVALID, "item_num / output_dim must be >= 2");
-  const bool gru = cfg->trunk == 1;
-  const bool rows = cfg->trunk == 2;   // TemporalConvNet on dense rows (the low level of model_hier): block 0 is an ordinary block
-  if (cfg->trunk < 0 || cfg->trunk > 2) return gfail(HIERTCN_ERR_INVALID, "trunk %d: 0 (TemporalConvNet on ids), 1 (GRU stack), 2 (TemporalConvNet on rows)", cfg->trunk);
+  if ((cfg->trunk != 2 && cfg->trunk != 3 && cfg->item_num < 2) || cfg->output_dim < 2) return gfail(HIERTCN_ERR_INVALID, "item_num / output_dim must be >= 2");
+  const bool gru = cfg->trunk == 1 || cfg->trunk == 3;
+  const bool rows = cfg->trunk == 2 || cfg->trunk == 3;   // dense input rows (the low level of model_hier): trunk 2 TemporalConvNet (block 0 an ordinary block), 3 GRU stack
+  if (cfg->trunk < 0 || cfg->trunk > 3)
+    return gfail(HIERTCN_ERR_INVALID, "trunk %d: 0 (TemporalConvNet on ids), 1 (GRU stack on ids), 2 (TemporalConvNet on rows), 3 (GRU stack on rows)", cfg->trunk);
   if (rows && (cfg->input_dim < 32 || (cfg->input_dim & 31) || cfg->input_dim > 4096))
     return gfail(HIERTCN_ERR_INVALID, "input_dim %d: the width of the input rows is a multiple of 32 up to 4096", cfg->input_dim);
   if (gru) {
@@ -317,10 +318,12 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
   } while (0)
   if (gru) {
     const size_t H = (size_t)c->H;
-    GA(c->gin_g, (size_t)c->N * 2 * H);
-    GA(c->gin_c, (size_t)c->N * H);
+    if (!rows) {
+      GA(c->gin_g, (size_t)c->N * 2 * H);
+      GA(c->gin_c, (size_t)c->N * H);
+    }
     for (int l = 0; l < c->nl; l++) {
-      const size_t kin = (l == 0) ? H : 2 * H;   // layer 0 keeps the state half only
+      const size_t kin = (l == 0) ? (rows ? (size_t)cfg->input_dim + H : H) : 2 * H;   // one-hot input: layer 0 keeps the state half only
       GA(c->gwg[l], 2 * H * kin); GA(c->gbg[l], 2 * H);
       GA(c->gwc[l], H * kin);     GA(c->gbc[l], H);
     }
@@ -329,7 +332,7 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
     GA(c->b0, c->C0);
     GA(c->br0, c->C0);
   }
-  for (int i = rows ? 0 : 1, cin = rows ? cfg->input_dim : c->C0; i < c->nb; cin = cfg->channels[i], i++) {
+  for (int i = rows ? 0 : 1, cin = rows ? cfg->input_dim : c->C0; i < c->nb; cin = cfg->channels[i], i++) {   // (nb == 0 for the GRU trunks)
     GA(c->convT[i], (size_t)c->K * cin * cfg->channels[i]);
     GA(c->conv_bias[i], cfg->channels[i]);
     if (cin != cfg->channels[i]) { GA(c->resT[i], (size_t)cin * cfg->channels[i]); GA(c->res_bias[i], cfg->channels[i]); }
@@ -392,13 +395,16 @@ int hiertcn_gmm_set_weights(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t*
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   if (!w->head_weights || !w->head_biases) return gfail(HIERTCN_ERR_INVALID, "the head (fully_connected weights / biases) is required");
   const int N = g->N, C0 = g->C0, K = g->K, M = g->M, D = g->D, DP = g->DP, CL = g->Clast;
-  if (g->trunk == 1) {
+  if (g->trunk == 1 || g->trunk == 3) {
     const size_t H = (size_t)g->H;
     for (int l = 0; l < g->nl; l++) {
       if (!w->gru_gate_kernel[l] || !w->gru_gate_bias[l] || !w->gru_cand_kernel[l] || !w->gru_cand_bias[l])
         return gfail(HIERTCN_ERR_INVALID, "GRU layer %d: gate / candidate kernel and bias are required", l);
-      const size_t in = (l == 0) ? (size_t)N : H;
-      if (l == 0) {   // rows [0, N) of [N + H][.]: the input half, already item-major; rows [N, N + H): the state half -> output-major
+      const size_t in = (l == 0) ? (g->trunk == 3 ? (size_t)g->cfg.input_dim : (size_t)N) : H;
+      if (l == 0 && g->trunk == 3) {   // dense input rows: the whole [in + H][.] kernels, output-major
+        G_HIP(launch_transpose_f32(w->gru_gate_kernel[0], g->gwg[0], (int64_t)(in + H), (int64_t)(2 * H), st));
+        G_HIP(launch_transpose_f32(w->gru_cand_kernel[0], g->gwc[0], (int64_t)(in + H), (int64_t)H, st));
+      } else if (l == 0) {   // rows [0, N) of [N + H][.]: the input half, already item-major; rows [N, N + H): the state half -> output-major
         G_HIP(hipMemcpyAsync(g->gin_g, w->gru_gate_kernel[0], (size_t)N * 2 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
         G_HIP(hipMemcpyAsync(g->gin_c, w->gru_cand_kernel[0], (size_t)N * H * sizeof(float), hipMemcpyDeviceToDevice, st));
         G_HIP(launch_transpose_f32(w->gru_gate_kernel[0] + in * 2 * H, g->gwg[0], (int64_t)H, (int64_t)(2 * H), st));
@@ -474,7 +480,7 @@ static int hiertcn_gmm_run_blocks(hiertcn_gmm_ctx* g, const uint16_t* in0, int f
                                   hipStream_t st);
 
 static int max_w(const hiertcn_gmm_ctx* g) {
-  int w = g->trunk == 1 ? g->H : 0;
+  int w = (g->trunk == 1 || g->trunk == 3) ? g->H : 0;
   for (int i = 0; i < g->nb; i++) w = g->cfg.channels[i] > w ? g->cfg.channels[i] : w;
   return w;
 }
@@ -489,7 +495,8 @@ size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R) {
 size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T) {
   if (!g || B < 0 || T < 0) return 0;
   const size_t base = hiertcn_gmm_workspace_bytes(g, B * T);
-  const size_t trunk = g->trunk == 1 ? onehot_gru_workspace_bytes(g->H, g->nl, B) : 0;
+  const size_t trunk = g->trunk == 1 ? onehot_gru_workspace_bytes(g->H, g->nl, B)
+                       : g->trunk == 3 ? rows_gru_workspace_bytes(g->H, g->nl, g->cfg.input_dim, B, T) : 0;
   return base > trunk ? base : trunk;
 }
 
@@ -500,7 +507,7 @@ size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, in
 int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                         size_t workspace_bytes, void* stream) {
   G_READY(g);
-  if (g->trunk == 2) return gfail(HIERTCN_ERR_STATE, "this handle reads dense rows (trunk 2): hiertcn_gmm_forward_rows");
+  if (g->trunk >= 2) return gfail(HIERTCN_ERR_STATE, "this handle reads dense rows (trunk %d): hiertcn_gmm_forward_rows", g->trunk);
   if (!x_ids || !hidden || B < 1 || T < 1 || T > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
   const int64_t R = B * T;
   if (!workspace || workspace_bytes < hiertcn_gmm_forward_workspace_bytes(g, B, T)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
@@ -546,9 +553,17 @@ static int hiertcn_gmm_run_blocks(hiertcn_gmm_ctx* g, const uint16_t* in0, int f
 int hiertcn_gmm_forward_rows(hiertcn_gmm_handle_t g, const uint16_t* x_rows, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                              size_t workspace_bytes, void* stream) {
   G_READY(g);
-  if (g->trunk != 2) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_forward_rows is for trunk 2 (dense input rows); this handle's trunk is %d", g->trunk);
+  if (g->trunk < 2) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_forward_rows is for trunks 2 / 3 (dense input rows); this handle's trunk is %d", g->trunk);
   if (!x_rows || !hidden || B < 1 || T < 1 || T > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
   if (!workspace || workspace_bytes < hiertcn_gmm_forward_workspace_bytes(g, B, T)) return gfail(HIERTCN_ERR_WORKSPACE, "gmm workspace too small");
+  if (g->trunk == 3) {   // model_hier.py:68-69 -> model_gru_gmm.py:33-48: the GRU stack under dynamic_rnn on the [e_t, state] rows, from a zero state
+    OneHotGru og;
+    memset(&og, 0, sizeof(og));
+    og.N = 0; og.H = g->H; og.nl = g->nl;
+    for (int l = 0; l < g->nl; l++) { og.wg[l] = g->gwg[l]; og.bg[l] = g->gbg[l]; og.wc[l] = g->gwc[l]; og.bc[l] = g->gbc[l]; }
+    G_HIP(launch_rows_gru(og, x_rows, g->cfg.input_dim, B, T, hidden, workspace, reinterpret_cast<hipStream_t>(stream)));
+    return HIERTCN_OK;
+  }
   return hiertcn_gmm_run_blocks(g, x_rows, 0, g->cfg.input_dim, B, T, hidden, workspace, reinterpret_cast<hipStream_t>(stream));
 }
 

@@ -610,19 +610,49 @@ size_t onehot_gru_workspace_bytes(int H, int nl, int64_t n_sess) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   return al((size_t)n_sess * 4) + al((size_t)2 * n_sess * H * nl * 4) + al((size_t)nl * n_sess * 5 * H * 4);
 }
+// ... on DENSE rows of width in_dim (model_hier.py:68-69: model_gru_gmm as the low level reads the [e_t, state] rows): + the rows as fp32
+size_t rows_gru_workspace_bytes(int H, int nl, int in_dim, int64_t n_sess, int L) {
+  return onehot_gru_workspace_bytes(H, nl, n_sess) + (((size_t)n_sess * L * in_dim * 4 + 255) & ~(size_t)255);
+}
+
+static hipError_t gru_rows_cells(const OneHotGru& w, const int32_t* x, const float* rows, int in_dim, int64_t n_sess, int L, uint16_t* hidden,
+                                 int32_t* seq_len, float* states, float* recs, hipStream_t st);
+
+hipError_t launch_rows_gru(const OneHotGru& w, const uint16_t* rows16, int in_dim, int64_t n_sess, int L, uint16_t* hidden, void* workspace, hipStream_t st) {
+  if (n_sess <= 0) return hipSuccess;
+  auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+  unsigned char* p = reinterpret_cast<unsigned char*>(workspace);
+  int32_t* seq_len = reinterpret_cast<int32_t*>(p); p += al((size_t)n_sess * 4);
+  float* states = reinterpret_cast<float*>(p);      p += al((size_t)2 * n_sess * w.H * w.nl * 4);
+  float* recs = reinterpret_cast<float*>(p);        p += al((size_t)w.nl * n_sess * 5 * w.H * 4);
+  float* rows = reinterpret_cast<float*>(p);
+  // the rows as fp32 (the GEMM operand) and dynamic_rnn's sequence_length = the count of rows that are not all-zero (model_gru_gmm.py:57-67)
+  hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, rows16, n_sess, L, in_dim, rows, seq_len);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return gru_rows_cells(w, nullptr, rows, in_dim, n_sess, L, hidden, seq_len, states, recs, st);
+}
 
 hipError_t launch_onehot_gru(const OneHotGru& w, const int32_t* x, int64_t n_sess, int L, uint16_t* hidden, void* workspace, hipStream_t st) {
   if (n_sess <= 0) return hipSuccess;
-  const int H = w.H, HT = w.H * w.nl;
+  const int HT = w.H * w.nl;
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
   unsigned char* p = reinterpret_cast<unsigned char*>(workspace);
   int32_t* seq_len = reinterpret_cast<int32_t*>(p); p += al((size_t)n_sess * 4);
   float* states = reinterpret_cast<float*>(p);      p += al((size_t)2 * n_sess * HT * 4);
   float* recs = reinterpret_cast<float*>(p);
+  hipLaunchKernelGGL(k_count_ids, dim3((unsigned)((n_sess + 255) / 256)), dim3(256), 0, st, x, n_sess, L, w.N, seq_len);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  return gru_rows_cells(w, x, nullptr, 0, n_sess, L, hidden, seq_len, states, recs, st);
+}
+
+// the cells: layer 0's input half is a gathered table row (x: ids, one-hot input) or a dense fp32 row (rows, width in_dim)
+static hipError_t gru_rows_cells(const OneHotGru& w, const int32_t* x, const float* rows, int in_dim, int64_t n_sess, int L, uint16_t* hidden,
+                                 int32_t* seq_len, float* states, float* recs, hipStream_t st) {
+  const int H = w.H, HT = w.H * w.nl;
   const size_t cell = (size_t)n_sess * 5 * H;   // gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
   hipError_t e;
-  hipLaunchKernelGGL(k_count_ids, dim3((unsigned)((n_sess + 255) / 256)), dim3(256), 0, st, x, n_sess, L, w.N, seq_len);
-  if ((e = hipGetLastError()) != hipSuccess) return e;
   if ((e = hipMemsetAsync(states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state
   for (int t = 0; t < L; t++) {
     const float* s_old = states + (size_t)(t & 1) * n_sess * HT;
@@ -635,7 +665,9 @@ hipError_t launch_onehot_gru(const OneHotGru& w, const int32_t* x, int64_t n_ses
       float* gates = rec;
       float* rh = rec + (size_t)n_sess * 2 * H;
       g.M = (int)n_sess; g.H = H;
-      if (l == 0) {
+      if (l == 0 && rows) {
+        g.A1 = rows + (size_t)t * in_dim; g.lda1 = L * in_dim; g.K1 = in_dim;
+      } else if (l == 0) {
         g.A1 = nullptr; g.lda1 = 0; g.K1 = 0;
         g.add_tab = w.in_g; g.add_ld = 2 * H; g.add_n = w.N; g.add_ids = x + t; g.add_ids_ld = L;
       } else {
@@ -647,7 +679,7 @@ hipError_t launch_onehot_gru(const OneHotGru& w, const int32_t* x, int64_t n_ses
       if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
       g.A2 = rh; g.lda2 = H;
       g.Wt = w.wc[l]; g.bias = w.bc[l]; g.N = H;
-      if (l == 0) { g.add_tab = w.in_c; g.add_ld = H; }
+      if (l == 0 && !rows) { g.add_tab = w.in_c; g.add_ld = H; }
       g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
       g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
       g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;

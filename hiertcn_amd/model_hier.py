@@ -11,7 +11,7 @@ state  : [B, hidden_dim*num_layer]
 returns: pred_all  a LazyLogits standing for the [B, sum L_i, N] logits of model_hier.py:79
          state     torch.float32 [B, hidden_dim*num_layer] on the GPU (model_hier.py:93-94)
 
-Only the default-graph branches are implemented: model_low_type 'tcn', 'gru' or 'tcn_gmm' (model_hier.py:62-68), no gap decay, no
+Only the default-graph branches are implemented: model_low_type 'tcn', 'gru', 'tcn_gmm' or 'gru_gmm' (model_hier.py:62-69), no gap decay, no
 impressions, no noise, no batch/weight/layer norm; anything else raises.
 """
 from __future__ import annotations
@@ -25,12 +25,12 @@ from .model import LazyLogits, get_scope, pack_slots
 def _check_args(args):
     from .engine import check_supported
     if getattr(args, "model_low_type", "tcn") not in ("tcn", "gru"):
-        raise NotImplementedError(f"model_low_type={args.model_low_type!r}: 'tcn' (HierTCN), 'gru' (HierGRU) and 'tcn_gmm' are built")
+        raise NotImplementedError(f"model_low_type={args.model_low_type!r}: 'tcn' (HierTCN), 'gru' (HierGRU), 'tcn_gmm' and 'gru_gmm' are built")
     check_supported(args)   # (Engine() runs the same check: the run loops and the CLI reach it too)
 
 
 def model_hier(args, x, y, mask, state, x_gap=None, x_impression=None, name="hier", reuse=True, training=False):
-    if getattr(args, "model_low_type", "tcn") == "tcn_gmm":   # model_hier.py:64-65: pred is a mixture head (model_hier_gmm.py)
+    if getattr(args, "model_low_type", "tcn") in ("tcn_gmm", "gru_gmm"):   # model_hier.py:64-65,68-69: pred is a mixture head (model_hier_gmm.py)
         from .model_hier_gmm import model_hier_tcn_gmm
         return model_hier_tcn_gmm(args, x, y, mask, state, name)
     _check_args(args)

@@ -11,8 +11,10 @@ across-session GRU -- created with a minimal low level of its own that is never 
 for the TemporalConvNet and the head.  Variables (TF names under scope 'hier'): hier/emb/{kernel,bias}, hier/multi_rnn_cell/cell_l/gru_cell/...,
 hier/tcn_gmm/temporal_conv_net/tblock_i/{conv1,dense}/{kernel,bias}, hier/tcn_gmm/fully_connected/{weights,biases}.
 What the reference does with `pred` afterwards cannot be run (it feeds the [B, T, M (1 + D)] head output to the cross-entropy against
-[B, T, item_num] targets, model.py:105-132): `pred` is a GmmHead, scored by calc_loss_gmm like model_tcn_gmm's.  model_low_type 'gru_gmm'
-(a GRU stack on the x_slice rows) is not built.
+[B, T, item_num] targets, model.py:105-132): `pred` is a GmmHead, scored by calc_loss_gmm like model_tcn_gmm's.
+model_low_type 'gru_gmm' (model_hier.py:68-69 -> model_gru_gmm.py:33-54) is the same with trunk 3: the MultiRNNCell of GRUCells under dynamic_rnn on
+the x_slice rows (sequence_length = the count of rows that are not all-zero), variables hier/rnn_gmm/rnn/multi_rnn_cell/cell_l/gru_cell/... and
+hier/rnn_gmm/fully_connected/{weights,biases} (model_gru_gmm's default scope name 'rnn_gmm' under 'hier').
 """
 from __future__ import annotations
 
@@ -43,6 +45,19 @@ def init_params(args, seed: int = 2, scope: str = "hier") -> Dict[str, np.ndarra
     p = {k: v for k, v in base.items() if k.startswith(f"{scope}/emb/") or k.startswith(f"{scope}/multi_rnn_cell/")}
     E, HT, K = int(args.emb_dim), int(args.hidden_dim) * int(args.num_layer), int(args.kernel_size)
     cin = E + HT
+    n_out = int(args.num_mixture) * (1 + (1 if getattr(args, "sigma", 0.1) else 2) * int(args.output_dim))
+    if getattr(args, "model_low_type", "tcn_gmm") == "gru_gmm":   # the GRU stack on the [e, state] rows (gate bias 1 [TF-sem]) + the head
+        H = int(args.hidden_dim)
+        for l in range(int(args.num_layer)):
+            pre = f"{scope}/rnn_gmm/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+            inp = cin if l == 0 else H
+            p[f"{pre}/gates/kernel"] = glorot((inp + H, 2 * H), inp + H, 2 * H)
+            p[f"{pre}/gates/bias"] = np.ones(2 * H, np.float32)
+            p[f"{pre}/candidate/kernel"] = glorot((inp + H, H), inp + H, H)
+            p[f"{pre}/candidate/bias"] = np.zeros(H, np.float32)
+        p[f"{scope}/rnn_gmm/fully_connected/weights"] = glorot((H, n_out), H, n_out)
+        p[f"{scope}/rnn_gmm/fully_connected/biases"] = np.zeros(n_out, np.float32)
+        return p
     for i, cout in enumerate(int(c) for c in args.tcn_channel):
         pre = f"{scope}/tcn_gmm/temporal_conv_net/tblock_{i}"
         p[f"{pre}/conv1/kernel"] = glorot((K, cin, cout), K * cin, K * cout)
@@ -51,7 +66,6 @@ def init_params(args, seed: int = 2, scope: str = "hier") -> Dict[str, np.ndarra
             p[f"{pre}/dense/kernel"] = glorot((cin, cout), cin, cout)
             p[f"{pre}/dense/bias"] = np.zeros(cout, np.float32)
         cin = cout
-    n_out = int(args.num_mixture) * (1 + (1 if getattr(args, "sigma", 0.1) else 2) * int(args.output_dim))
     p[f"{scope}/tcn_gmm/fully_connected/weights"] = glorot((cin, n_out), cin, n_out)
     p[f"{scope}/tcn_gmm/fully_connected/biases"] = np.zeros(n_out, np.float32)
     return p
@@ -79,8 +93,11 @@ class HierGmmModel(TcnGmmModel):
         self.lib = _lib.load()
         self.device = torch.device("cuda", torch.cuda.current_device())
         self.M, self.D, self.N = int(args.num_mixture), int(args.output_dim), int(args.item_num)
+        self.low = getattr(args, "model_low_type", "tcn_gmm")
+        if self.low not in ("tcn_gmm", "gru_gmm"):
+            raise NotImplementedError(f"model_low_type={self.low!r}: the mixture low levels are 'tcn_gmm' and 'gru_gmm'")
         ch = [int(c) for c in args.tcn_channel]
-        self.C = ch[-1]
+        self.C = int(args.hidden_dim) if self.low == "gru_gmm" else ch[-1]
         self.E, self.HT = int(args.emb_dim), int(args.hidden_dim) * int(args.num_layer)
         self.params = params if params is not None else init_params(args, seed, name)
         # main handle: our table / emb bias / GRU cells; its own (unused) low level and scoring layer keep their initial values
@@ -91,10 +108,15 @@ class HierGmmModel(TcnGmmModel):
                 ep[k] = v
         self.engine = Engine(sa, hier=True)
         self.engine.set_weights(ep)
-        cfg = _lib.GmmConfig(item_num=0, output_dim=self.D, num_mixture=self.M, kernel_size=int(args.kernel_size), n_blocks=len(ch),
-                             sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=2, input_dim=self.E + self.HT)
-        for i, c in enumerate(ch):
-            cfg.channels[i] = c
+        if self.low == "gru_gmm":
+            cfg = _lib.GmmConfig(item_num=0, output_dim=self.D, num_mixture=self.M, kernel_size=1, n_blocks=0,
+                                 sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=3, hidden_dim=int(args.hidden_dim),
+                                 num_layer=int(args.num_layer), input_dim=self.E + self.HT)
+        else:
+            cfg = _lib.GmmConfig(item_num=0, output_dim=self.D, num_mixture=self.M, kernel_size=int(args.kernel_size), n_blocks=len(ch),
+                                 sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=2, input_dim=self.E + self.HT)
+            for i, c in enumerate(ch):
+                cfg.channels[i] = c
         self._h = C.c_void_p()
         _ck(self.lib.hiertcn_gmm_create(C.byref(self._h), C.byref(cfg)), self.lib)
         self._upload(self.params)
@@ -114,9 +136,13 @@ class HierGmmModel(TcnGmmModel):
             keep.append(t)
             return t.data_ptr()
 
-        root = f"{self.name}/tcn_gmm"
+        root = f"{self.name}/rnn_gmm" if self.low == "gru_gmm" else f"{self.name}/tcn_gmm"
         w = _lib.GmmWeights()
-        for i in range(len(self.args.tcn_channel)):
+        for l in range(int(self.args.num_layer) if self.low == "gru_gmm" else 0):
+            pre = f"{root}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+            w.gru_gate_kernel[l], w.gru_gate_bias[l] = dev(f"{pre}/gates/kernel"), dev(f"{pre}/gates/bias")
+            w.gru_cand_kernel[l], w.gru_cand_bias[l] = dev(f"{pre}/candidate/kernel"), dev(f"{pre}/candidate/bias")
+        for i in range(0 if self.low == "gru_gmm" else len(self.args.tcn_channel)):
             pre = f"{root}/temporal_conv_net/tblock_{i}"
             w.conv_kernel[i], w.conv_bias[i] = dev(f"{pre}/conv1/kernel"), dev(f"{pre}/conv1/bias")
             if f"{pre}/dense/kernel" in params:
@@ -150,7 +176,7 @@ class HierGmmModel(TcnGmmModel):
 
 
 def model_hier_tcn_gmm(args, x, y, mask, state, name="hier"):
-    """-> (pred: GmmHead over the [B, S * Lmax] packed steps, state [B, HT] on the GPU); called by model_hier for model_low_type 'tcn_gmm'."""
+    """-> (pred: GmmHead over the [B, S * Lmax] packed steps, state [B, HT] on the GPU); called by model_hier for model_low_type 'tcn_gmm' / 'gru_gmm'."""
     from .model import pack_slots
     if name not in _SCOPES:
         _SCOPES[name] = HierGmmModel(args, None, name)

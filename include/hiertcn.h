@@ -319,14 +319,18 @@ typedef struct {
   int32_t channels[HIERTCN_MAX_BLOCKS];
   float sigma;                           /* args.sigma (> 0); 0 = learned scale (args.sigma None)   */
   int32_t trunk;                         /* 0: TemporalConvNet (model_tcn_gmm.py:27-36); 1: GRU stack run by dynamic_rnn on the one-hot
-                                          *    input (model_gru_gmm.py:33-48) -- n_blocks / channels / kernel_size are then ignored      */
+                                          *    input (model_gru_gmm.py:33-48) -- n_blocks / channels / kernel_size are then ignored;
+                                          *    2 / 3 (input_dim below): the same two trunks on DENSE rows -- the low levels of model_hier    */
   int32_t hidden_dim;                    /* trunk 1: args.hidden_dim in {64, 128, 256, 512}         */
   int32_t num_layer;                     /* trunk 1: args.num_layer                                 */
   int32_t input_dim;                     /* trunk 2 (ABI 8): the TemporalConvNet on DENSE rows the caller provides -- model_hier.py:64-65, the
                                           *    mixture model as the LOW level of model_hier: rows [e_t, state] of width emb + hidden_dim*num_layer
                                           *    (hiertcn_embed_concat) -- width of those rows, a multiple of 32; block 0 is then an ordinary
                                           *    TemporalBlock with Cin = input_dim (conv_kernel[0] [K][input_dim][C0], Dense residual where they
-                                          *    differ); item_num is ignored; hiertcn_gmm_forward_rows instead of hiertcn_gmm_forward          */
+                                          *    differ); item_num is ignored; hiertcn_gmm_forward_rows instead of hiertcn_gmm_forward.
+                                          *    trunk 3 (ABI 9): the GRU stack on the same rows -- model_hier.py:68-69, model_low_type 'gru_gmm':
+                                          *    gru_gate_kernel[0] [input_dim + H][2H], gru_cand_kernel[0] [input_dim + H][H], sequence_length =
+                                          *    the count of rows that are not all-zero (model_gru_gmm.py:57-67); hidden_dim / num_layer as trunk 1 */
 } hiertcn_gmm_config_t;
 typedef struct {
   const float* conv_kernel[HIERTCN_MAX_BLOCKS];
@@ -351,7 +355,7 @@ size_t hiertcn_gmm_workspace_bytes(hiertcn_gmm_handle_t g, int64_t R);
 size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T);
 int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                         size_t workspace_bytes, void* stream);
-/* trunk 2: x_rows [B*T][input_dim] (storage type) -> hidden [B*T][C_last]; same workspace as hiertcn_gmm_forward */
+/* trunks 2, 3: x_rows [B*T][input_dim] (storage type) -> hidden [B*T][C_last]; workspace: hiertcn_gmm_forward_workspace_bytes */
 int hiertcn_gmm_forward_rows(hiertcn_gmm_handle_t g, const uint16_t* x_rows, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                              size_t workspace_bytes, void* stream);
 int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32_t* y_ids, int64_t R, int32_t mode, float* loss,

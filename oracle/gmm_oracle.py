@@ -212,6 +212,59 @@ def model_hier_tcn_gmm(args, x, y, mask, state, params, num: O.Numerics = O.EXAC
     return np.concatenate(outs, axis=1), state
 
 
+def init_params_hier_gru(args, seed=2, scope="hier"):
+    """Variables of model_hier with model_low_type 'gru_gmm' (model_hier.py:28-93 + model_gru_gmm.py:33-54 under scope 'hier/rnn_gmm')."""
+    base = O.init_params(args, seed=seed, model="hier", emb_dim=int(getattr(args, "emb_dim", 128)))
+    p = {k: v for k, v in base.items() if k.startswith(f"{scope}/emb/") or k.startswith(f"{scope}/multi_rnn_cell/")}
+    cin = int(getattr(args, "emb_dim", 128)) + int(args.hidden_dim) * int(args.num_layer)
+    rng = np.random.default_rng(seed + 1)
+    H = int(args.hidden_dim)
+    for l in range(int(args.num_layer)):
+        pre = f"{scope}/rnn_gmm/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+        inp = cin if l == 0 else H
+        p[f"{pre}/gates/kernel"] = O._glorot(rng, (inp + H, 2 * H), inp + H, 2 * H)
+        p[f"{pre}/gates/bias"] = np.ones(2 * H, np.float32)
+        p[f"{pre}/candidate/kernel"] = O._glorot(rng, (inp + H, H), inp + H, H)
+        p[f"{pre}/candidate/bias"] = np.zeros(H, np.float32)
+    no = n_out(args)
+    p[f"{scope}/rnn_gmm/fully_connected/weights"] = O._glorot(rng, (H, no), H, no)
+    p[f"{scope}/rnn_gmm/fully_connected/biases"] = np.zeros(no, np.float32)
+    return p
+
+
+def model_hier_gru_gmm(args, x, y, mask, state, params, num: O.Numerics = O.EXACT64, return_hidden=False, round_input=None):
+    """model_hier.py:21-94 with model_low_type 'gru_gmm' (:68-69): per slot x_slice = [emb(x), state tiled] (:50,54-55) into model_gru_gmm's
+    MultiRNNCell of GRUCells under dynamic_rnn from a zero state, sequence_length = the count of non-zero rows of x_slice used as a prefix length
+    (model_gru_gmm.py:33-48,57-67; past it the state is carried and the output is zero [TF-sem]), then its head; high level as in O.model_hier.
+    -> (pred_all [B, sum L_i, n_out] or hidden, state)"""
+    dt = num.dtype
+    H, nl = int(args.hidden_dim), int(args.num_layer)
+    state = np.asarray(state, dt)
+    outs = []
+    for i in range(len(x)):
+        xi = np.asarray(x[i]).astype(np.int64)
+        e = O.embed_ids(xi, params["hier/emb/kernel"], dt)
+        feat = np.repeat(state[:, None, :], xi.shape[1], axis=1)
+        xs = np.concatenate([e, feat], axis=-1)
+        if round_input is not None:
+            xs = round_input(xs)
+        B, T = xi.shape
+        length = O.seq_length(xs)
+        ls = np.zeros((B, H * nl), dt)
+        h = np.zeros((B, T, H), dt)
+        for t in range(T):
+            active = (t < length)[:, None]
+            cur, new_state = O.multi_rnn_cell(xs[:, t], ls, params, H, nl, scope="hier/rnn_gmm/rnn")
+            ls = np.where(active, new_state, ls)
+            h[:, t] = np.where(active, cur, 0.0)
+        h = num.act(h)
+        outs.append(h if return_hidden else gmm_head(h, params, "hier/rnn_gmm"))
+        y_slice = O.session_mean_pool(y[i], params, dt)
+        _, state = O.multi_rnn_cell(y_slice, state, params, H, nl)
+        state = state * np.asarray(mask[i], dt)
+    return np.concatenate(outs, axis=1), state
+
+
 def masked_mean_loss(loss_bt, y_ids):
     """model.py:111-117 applied to a [B, T] loss."""
     mask = (np.asarray(y_ids) > 0).astype(np.float64)

@@ -9,7 +9,10 @@ print(f\"{b['value']:.0f} sessions/s, {b['ms_per_step']:.1f} ms/step; scoring {r
 echo "== ragged sessions (lengths ~ U{1..30})"; python3 bench.py --ragged --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json; b = json.loads(sys.stdin.read()); print(f\"{b['value']:.0f} sessions/s\")"
 echo "== reference batching (32 lanes x 10 x <=20, XING catalogue)"; python3 scripts/cfg2_bench.py 2>&1 | tail -2
-echo "== reference batching, HierGRU (the reference's default low level)"; LOW=gru python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1
+echo "== reference batching, HierGRU (the reference's default low level): d = 256, 128 (the reference's default width), 64; then the launch chain it replaces"
+for d in 256 128 64; do D=$d LOW=gru python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1 | sed "s/^/d=$d session tiles: /"; done
+for d in 256 128 64; do D=$d LOW=gru HIERTCN_LGRU_TILE=0 HIERTCN_LGRU_CHAIN=1 python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1 | sed "s/^/d=$d launch chain: /"; done
+echo "== split16 (the fast parity-grade mode): scoring kernel alone (614,400 x 300,000; loss + rank, top-10), then the evaluation step"; python3 scripts/split16_bench.py 4096 2>&1 | grep -v amdgpu.ids | tail -3
 echo "== across-session GRU scan: chain of GEMM launches vs the persistent launch"; bash scripts/gru_ab.sh 2>&1 | grep -v "^$"
 echo "== scoring kernel alone, d = 256 / 128 / 64 (2,457,600 rows x 300,000 items)"
 for d in 256 128 64; do D=$d python3 scripts/score_diag.py 2457600 300000 2>&1 | tail -1 | sed "s/^/d=$d: /"; done
@@ -29,6 +32,7 @@ HIERTCN_TRAIN_LEGACY=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
 echo "== training step at the reference batch (32 lanes x 20 x 30, XING catalogue): HierTCN d = 128 / 256, HierGRU d = 128 / 256"
 for cfg in "D=128" "D=256" "D=128 LOW=gru" "D=256 LOW=gru"; do env N=20778 $cfg python3 scripts/train_bench.py 32 30 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done
+for cfg in "D=128 LOW=gru" "D=256 LOW=gru"; do env N=20778 HIERTCN_LGRU_TILE=0 $cfg python3 scripts/train_bench.py 32 30 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg, launch chains: /"; done
 echo "== data-parallel code path, 2 ranks sharing the GPU over gloo (smoke: RCCL needs one GPU per rank)"
 HIERTCN_BENCH_BACKEND=gloo python3 -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29533 bench.py --gpus 2 --steps 2 --warmup 1 --users-per-step 512 --train-users-per-step 256 --no-cpu-baseline 2>/dev/null | tail -1 | python3 -c "
 import sys, json; b = json.loads(sys.stdin.read()); t = b['train']; print(b['n_gpus'], 'ranks:', round(b['value']), 'sessions/s eval;', 'train', t.get('ms_per_step'), 'ms/step', t.get('collectives'))"
@@ -41,7 +45,7 @@ LOW=gru EVAL=1 HIERTCN_LGRU_FP32=1 python3 scripts/train_bench.py 1024 3 2>&1 | 
 echo "== mixture head (614,400 rows x 20,778 outputs x 5 mixtures): Gram form, then the pass over the mean tables"; python3 scripts/gmm_bench.py 2>&1 | tail -1; HIERTCN_GMM_TABLE_PASS=1 python3 scripts/gmm_bench.py 2>&1 | tail -1
 echo "== exact fp32 evaluation mode: throughput, and errors at a trained model's logit scale (tests/test_gpu_exact_mode.py)"
 python3 scripts/exact_mode_bench.py 256 2>&1 | grep -v amdgpu.ids
-python3 -m pytest tests/test_gpu_exact_mode.py -q -m gpu -s -k xing_shape 2>&1 | grep -E "mode,|storage,|passed|failed"
+python3 -m pytest tests/test_gpu_exact_mode.py -q -m gpu -s -k xing_shape 2>&1 | grep -E "mode,|storage,|passed|failed"   # (fp32 and split16 modes)
 echo "== tile-skip census (profiles/r3_score_ablation.md)"; python3 scripts/skip_tile_census.py 20778 16 2>&1 | grep -v amdgpu.ids
 echo "== parity against the exact oracle on unrounded fp32 weights"; python3 tests/tools/parity_fp32_probe.py 2>&1 | grep shape | cut -c1-400
 echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3

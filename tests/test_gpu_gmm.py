@@ -347,6 +347,55 @@ def test_model_hier_with_the_mixture_model_as_its_low_level(sigma):
     HG.reset_scopes()
 
 
+@pytest.mark.parametrize("sigma,nl", [(0.1, 2), (None, 1)])
+def test_model_hier_with_the_gru_mixture_model_as_its_low_level(sigma, nl):
+    """model_hier(args with model_low_type='gru_gmm') (model_hier.py:68-69 -> model_gru_gmm.py:33-54): the [emb(x), carried state] rows into a
+    MultiRNNCell of GRUCells under dynamic_rnn (zero state, sequence_length = the count of rows that are not all-zero, used as a prefix length)
+    + the mixture head (hiertcn_gmm trunk 3).  Hidden rows -- exact zeros past the counted length included --, carried state and the likelihood
+    losses against oracle/gmm_oracle.model_hier_gru_gmm on the numbers the device holds."""
+    from hiertcn_amd import model_hier_gmm as HG
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.model_hier import model_hier
+    from hiertcn_amd.model_tcn_gmm import calc_loss_gmm
+    from tests.gpu_common import as_lists, make_batch
+    N, E, H, M = 900, 64, 64, 3
+    a = hier_tcn_args(item_num=N, output_dim=N, emb_dim=E, hidden_dim=H, num_layer=nl, tcn_channel=[64], kernel_size=3, num_mixture=M,
+                      model_low_type="gru_gmm", loss="gmm_prob", sigma=0.1)
+    a.sigma = sigma
+    p = G.init_params_hier_gru(a, seed=4)
+    rng = np.random.default_rng(8)
+    for k in p:
+        if (k.endswith("/bias") and "gates" not in k) or k.endswith("biases"):
+            p[k] = (p[k] + 0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    HG.reset_scopes()
+    HG._SCOPES["hier"] = HG.HierGmmModel(a, p, "hier")
+    B, S, L = 5, 4, 7
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, H * nl))).astype(np.float32)
+    st0[:2] = 0.0        # a user's first session: zero state, so the leading null-id row of x_slice is all-zero and is not counted
+    xl, yl, ml = as_lists(x, y, mask)
+    pred, st = model_hier(a, xl, yl, ml, st0)
+    assert pred.shape == (B, S * L, M * (1 + (1 if sigma else 2) * N))
+    # oracle on the numbers the device holds: the item table and the head kernel rounded to bf16 (the M prior columns and every GRU tensor stay
+    # fp32: the cells run on exact-fp32 products), x_slice rows rounded to the storage type
+    pr = {k: (O.round_bf16(v) if (k == "hier/emb/kernel" or k.endswith("weights")) else v) for k, v in p.items()}
+    pr["hier/rnn_gmm/fully_connected/weights"][:, :M] = p["hier/rnn_gmm/fully_connected/weights"][:, :M]
+    h_ref, st_ref = G.model_hier_gru_gmm(a, xl, yl, ml, st0, pr, O.MIRROR, return_hidden=True, round_input=O.round_bf16)
+    h_dev = pred.hidden.float().cpu().numpy().reshape(B, S * L, -1)
+    assert np.array_equal(h_dev == 0, h_ref == 0)                                        # [TF-sem] zeros past the counted length
+    assert np.abs(h_dev - h_ref).max() <= 2.0 ** -7                                      # |h| <= 1: a storage-type ulp
+    np.testing.assert_allclose(st.cpu().numpy(), st_ref, atol=2e-5, rtol=0)
+    yy = y.reshape(B, S * L)
+    for mode in ("gmm_prob", "gmm_prob_max"):
+        a.loss = mode
+        got = calc_loss_gmm(pred, yy, loss=mode).cpu().numpy()
+        want = G.calc_loss_gmm_ids(G.gmm_head(h_dev.astype(np.float64), pr, "hier/rnn_gmm"), yy, a)
+        live = yy > 0
+        assert np.abs(got - want)[live].max() < 2e-4 * max(1.0, np.abs(want[live]).max()), (mode, np.abs(got - want)[live].max())
+        assert not got[~live].any()
+    HG.reset_scopes()
+
+
 @pytest.mark.parametrize("seed", range(6))
 def test_mixture_loss_fuzz_shapes(seed, monkeypatch):
     """Random head shapes (last width 64 / 128 / 256, D from just above 3 C to a few thousand and not a multiple of 32, 1..16 mixtures, row counts
