@@ -290,6 +290,58 @@ def dvfs_probe(eng, rows, n_items, dim, seconds=1.5):
     return res
 
 
+def reference_batch_leg(n_batches=100):
+    """-> the `reference_batch` object: the reference's OWN operating point (args.py:19,40,51-53,126-129: 32 lanes x 10 slots x <= 20 steps per batch, two
+    layers; BASELINE.json configs[1]'s XING catalogue of 20,778 items): ms per evaluation batch for HierTCN at d = 256 (configs[1]) and for HierGRU -- the
+    reference's default low level -- at d = 128 (its default width) and 256, and ms per training step of the default HierGRU.  Ragged batches, ids resident."""
+    import torch
+
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine
+    from hiertcn_amd.params import init_params
+
+    N, B, S, L = 20_778, 32, 10, 20
+    rng = np.random.default_rng(0)
+    ids = rng.integers(1, N, (8, B, S, L)) * (np.arange(L)[None, None, None, :] < rng.integers(1, L + 1, (8, B, S))[..., None])
+    x = np.zeros_like(ids)
+    x[..., 1:] = ids[..., :-1]
+    mask = (rng.random((8, B, S)) > 0.15).astype(np.float32)
+    xs, ys, ms = (torch.as_tensor(v).cuda().contiguous() for v in (x.astype(np.int32), ids.astype(np.int32), mask))
+    out = {"what": "32 lanes x 10 slots x <= 20 steps per batch (the reference's batch_size / max_session_num / max_activity_len defaults), XING catalogue N = 20,778, "
+                   "two layers, ragged sessions, ids resident; ms per batch = mean over %d back-to-back batches" % n_batches}
+    for name, low, d, train in (("hiertcn_d256", "tcn", 256, False), ("hiergru_d128", "gru", 128, True), ("hiergru_d256", "gru", 256, False)):
+        args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B, model_low_type=low)
+        eng = Engine(args, hier=True, train=train)
+        eng.set_weights(init_params(args, seed=2))
+        st = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")
+        st2 = torch.empty_like(st)
+        m8 = torch.zeros(8, dtype=torch.float64, device="cuda")
+        for i in range(10):
+            eng.forward_eval(xs[i % 8], ys[i % 8], ms[i % 8], st, state_out=st2, metrics8=m8)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_batches):
+            eng.forward_eval(xs[i % 8], ys[i % 8], ms[i % 8], st, state_out=st2, metrics8=m8)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n_batches
+        rec = {"eval_ms_per_batch": round(dt * 1e3, 4), "eval_sessions_per_s": round(B * S / dt)}
+        if train:
+            for i in range(5):
+                eng.train_forward_backward(xs[i % 8], ys[i % 8], ms[i % 8], st)
+                eng.adam_step(1e-3)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for i in range(30):
+                eng.train_forward_backward(xs[i % 8], ys[i % 8], ms[i % 8], st)
+                eng.adam_step(1e-3)
+            torch.cuda.synchronize()
+            rec["train_ms_per_step"] = round((time.perf_counter() - t0) / 30 * 1e3, 4)
+        rec["persistent_timed_out"] = bool(eng.persistent_timed_out())
+        out[name] = rec
+        eng.close()
+    return out
+
+
 def exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks):
     """-> the `exact` object: the SAME evaluation step in the parity-grade modes (tests/test_gpu_exact_mode.py: logits < 1e-3 of the exact
     oracle at |z| = 10 and 30, ranks equal on > 99 % of rows, top-10 equal on every clear row) -- 'split16' (HIERTCN_PRECISION_SPLIT16: fp32
@@ -386,6 +438,7 @@ def main():
     ap.add_argument("--train-warmup", type=int, default=2)
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-exact", action="store_true", help="skip the parity-grade modes (the `exact` object of the JSON line)")
+    ap.add_argument("--no-reference-batch", action="store_true", help="skip the reference's own batch shape (the `reference_batch` object of the JSON line)")
     ap.add_argument("--exact-users-per-step", type=int, default=4096, help="users per step PER GPU of the split16 leg (4096 users = 9,600 workgroups of 256 rows = 37.5 rounds)")
     ap.add_argument("--exact-steps", type=int, default=3)
     ap.add_argument("--exact-warmup", type=int, default=1)
@@ -579,6 +632,13 @@ def main():
                 import traceback
                 exact = {"error": repr(e)[:300], "where": traceback.format_exc()[-600:]}
 
+    refb = None
+    if rank == 0 and world == 1 and not a.no_reference_batch:
+        try:
+            refb = reference_batch_leg()
+        except Exception as e:  # noqa: BLE001  (secondary figure, never fatal)
+            refb = {"error": repr(e)[:300]}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the checker, timed on this host's cores on a bounded sample of the SAME workload
@@ -642,6 +702,7 @@ def main():
             },
             "cpu_baseline": cpu,
             "exact": exact,
+            "reference_batch": refb,
             "multi_gpu": multi,
             "gmm": gmm,
             "train": train,
