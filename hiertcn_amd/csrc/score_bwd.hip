@@ -42,6 +42,9 @@ __device__ __forceinline__ uint2 lds_read_tr16(const unsigned char* p) {
 // (three stages = 96 KB).  Everything else (LDS image, fragment addressing, the software pipeline) is the same code.
 // ONE = one wave per SIMD: what C = 512 needs.  At C = 256 it was measured in round 4 and is slower (mode 0: 150 -> 230 ms, mode 2: 167 -> 232 ms per
 // 1024-user step, bit-identical results: profiles/r4_train_notes.md), so only <512, *, true> and <128 / 256, *, false> are instantiated.
+// C = 64 (round 4, a narrow `args.tcn_channel`): the dual-use LDS image needs rows of at least 256 bytes (the 4-bit chunk swizzle), so a 128-byte
+// vector sits in a 256-byte LDS row (LP = 128 channels of pitch; logical chunks 0..7 spread over the 16 physical ones by the same XOR, the other
+// eight positions are filled with a second copy by the DMA and never read): same addressing, half the k-steps and half the output tiles.
 template <int C, bool ONE = (C == 512)>
 struct SgGeom {
   static constexpr int W = ONE ? 4 : 8;        // waves per workgroup
@@ -49,7 +52,8 @@ struct SgGeom {
   static constexpr int TILES = SI / 32;
   static constexpr int THREADS = 64 * W;
   static constexpr int STAT = 32 * W;                 // stationary vectors per workgroup
-  static constexpr int STAGE_BYTES = SI * 2 * C;
+  static constexpr int LP = C < 128 ? 128 : C;        // channels of LDS row pitch
+  static constexpr int STAGE_BYTES = SI * 2 * LP;
 };
 static bool sg_one(int C, int mode) { (void)mode; return C == 512; }
 static int sg_stat(int C, bool one) { return one ? 128 : 256; }
@@ -73,8 +77,9 @@ template <int C, int MODE, bool ONE = (C == 512)>
 __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sgrad(const SgradArgs a) {
   using G = ScGeom<C>;
   using SG = SgGeom<C, ONE>;
-  static_assert(C == 128 || C == 256 || C == 512, "the dual-use LDS image is laid out for 256-, 512- and 1024-byte rows");
+  static_assert(C == 64 || C == 128 || C == 256 || C == 512, "the dual-use LDS image is laid out for 256-, 512- and 1024-byte rows");
   constexpr int NCB = C / 32;
+  constexpr int LP = SG::LP;
   constexpr int SI = SG::SI;
   // GEMM-1 as two accumulator chains (even / odd k-steps, added at the end).  C = 512 (one wave per SIMD): nothing else fills the latency of a
   // dependent MFMA chain, fragment reads three ahead (1061 -> 899 ms per step).  C = 256 (two waves per SIMD, 254 of 256 registers in use): the
@@ -173,8 +178,8 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
   auto dma_voff = [&](int i) -> unsigned {   // recomputed at every issue: registers are the scarce resource here, not VALU slots
     const int off = (wave * PPW + i) * 1024 + lane * 16;
-    const int row = off / (2 * C), slot = (off % (2 * C)) >> 4;
-    return (unsigned)(row * (2 * C) + ((slot ^ swz(row)) << 4));
+    const int row = off / (2 * LP), slot = (off % (2 * LP)) >> 4;   // LDS row and physical chunk this lane's 16 bytes land in
+    return (unsigned)(row * (2 * C) + (((slot ^ swz(row)) & (C / 8 - 1)) << 4));   // source: the logical chunk (C = 64: two copies of each)
   };
   // XCD-synchronised walk of the stream (score.hip, k_score_pipe: the same reasoning and the same caveats).  Every sum this kernel forms
   // over the stream -- the softmax denominator and count of mode 2, the d hidden / d Wo accumulators -- is independent of the stream
@@ -221,7 +226,7 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   const float* sbias = reinterpret_cast<const float*>(smem + BIAS_OFF);
 
   // GEMM-1 A fragment (row read): stream row lr of the tile, 16-byte chunk 2s + lh
-  const int a_k0 = lr * (2 * C) + ((lh ^ swz(lr)) << 4);
+  const int a_k0 = lr * (2 * LP) + ((lh ^ swz(lr)) << 4);
   // GEMM-2 A fragment (transposed read): lane 4q+p of 16-lane group g (h = g >> 1 picks the k half, e = g & 1 the column half of the
   // 32-channel block) supplies the address of stream row 16 s2 + 8 u + 4 h + q, channels 32 cb + 16 e + 4 p .. + 3; u = 0 / 1 are the
   // two halves of the 8-element fragment.  Element j of lane half h then belongs to stream row 16 s2 + 8 (j >> 2) + 4 h + (j & 3):
@@ -232,7 +237,7 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   for (int u = 0; u < 2; u++) {
     const int row = 8 * u + 4 * th + tq;
     const int low = (2 * te + (tp >> 1)) ^ ((2 * u + th) & 3);
-    tr_a[u] = row * (2 * C) + (tq << 6) + (low << 4) + 8 * (tp & 1);   // chunk' = 4 (cb ^ q) + low: the cb part is an XOR with cb << 6
+    tr_a[u] = row * (2 * LP) + (tq << 6) + (low << 4) + 8 * (tp & 1);   // chunk' = 4 (cb ^ q) + low: the cb part is an XOR with cb << 6
   }
 
   f32x16 oacc[NCB];
@@ -339,8 +344,8 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
     int tr0 = tr_a[0], tr1 = tr_a[1];
     asm volatile("" : "+v"(tr0), "+v"(tr1));
     auto tr_frag = [&](int cb) -> uint4 {
-      const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + s2 * 32 * C));
-      const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + s2 * 32 * C));
+      const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + s2 * 32 * LP));
+      const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + s2 * 32 * LP));
       return make_uint4(lo.x, lo.y, hi.x, hi.y);
     };
     const uint4 bfrag = make_uint4(pk[4 * s2], pk[4 * s2 + 1], pk[4 * s2 + 2], pk[4 * s2 + 3]);
@@ -357,7 +362,12 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
         if (cb % GP == 0) prob_half_a(first + 2 * (cb / GP));
         if (cb % GP == GP / 2) prob_half_b(first + 2 * (cb / GP));
       } else {
-        if ((cb * 4) % NCB == 0) prob_pair(first + 2 * ((cb * 4) / NCB));   // 4 pairs spread over the NCB gaps
+        if constexpr (NCB < 4) {   // C = 64: two pairs beside each of the two MFMAs
+#pragma unroll
+          for (int k = 0; k < 4 / NCB; k++) prob_pair(first + 2 * (cb * (4 / NCB) + k));
+        } else if ((cb * 4) % NCB == 0) {
+          prob_pair(first + 2 * ((cb * 4) / NCB));   // 4 pairs spread over the NCB gaps
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
@@ -401,8 +411,8 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
     int tr0 = tr_a[0], tr1 = tr_a[1];
 #pragma unroll
     for (int cb = 0; cb < NCB; cb++) {
-      const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + 32 * C));
-      const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + 32 * C));
+      const uint2 lo = lds_read_tr16(tl + ((tr0 ^ (cb << 6)) + 32 * LP));
+      const uint2 hi = lds_read_tr16(tl + ((tr1 ^ (cb << 6)) + 32 * LP));
       oacc[cb] = mfma32(make_uint4(lo.x, lo.y, hi.x, hi.y), make_uint4(pk[4], pk[5], pk[6], pk[7]), oacc[cb]);
     }
   }
@@ -524,7 +534,9 @@ __global__ __launch_bounds__(256) void k_dwo_onehot(const uint16_t* __restrict__
   if (lane == 0) atomicAdd(dbias + yv, -w);
 }
 
-bool sgrad_supported(const ModelDev& m) { return m.Clast == 128 || m.Clast == 256 || (m.Clast == 512 && !getenv("HIERTCN_SGRAD512_OFF")); }
+bool sgrad_supported(const ModelDev& m) {
+  return (m.Clast == 64 && !getenv("HIERTCN_SGRAD64_OFF")) || m.Clast == 128 || m.Clast == 256 || (m.Clast == 512 && !getenv("HIERTCN_SGRAD512_OFF"));
+}
 
 template <int C, int MODE, bool ONE>
 static hipError_t launch_k_sgrad(const SgradArgs& a, dim3 grid, hipStream_t st) {
@@ -538,6 +550,7 @@ static hipError_t launch_k_sgrad(const SgradArgs& a, dim3 grid, hipStream_t st) 
 template <int MODE>
 static hipError_t launch_k_sgrad_c(const ModelDev& m, const SgradArgs& a, dim3 grid, hipStream_t st) {
   switch (m.Clast) {
+    case 64: return launch_k_sgrad<64, MODE, false>(a, grid, st);
     case 128: return launch_k_sgrad<128, MODE, false>(a, grid, st);
     case 256: return launch_k_sgrad<256, MODE, false>(a, grid, st);
     case 512: return launch_k_sgrad<512, MODE, true>(a, grid, st);
