@@ -21,9 +21,9 @@
 #define TCN_G 4          // sessions per workgroup
 #define TCN_THREADS 512  // 8 waves
 
-template <int C>
+template <int C, int GSO = 0>   // GSO: sessions per workgroup of the small-grid instances (0: the default below)
 struct TcnGeom {
-  static constexpr int GS = (C == 512) ? 2 : TCN_G;   // sessions per workgroup: the LDS slabs of four 512-channel sessions would take all 160 KB
+  static constexpr int GS = GSO ? GSO : (C == 512) ? 2 : TCN_G;   // sessions per workgroup: the LDS slabs of four 512-channel sessions would take all 160 KB
   static constexpr int NCB = C / 32;        // output-channel blocks
   static constexpr int CBW = NCB > 8 ? NCB / 8 : 1;   // channel blocks per wave (C = 512: two)
   static constexpr int WPC = NCB >= 8 ? 1 : 8 / NCB;  // waves sharing one channel block
@@ -63,11 +63,11 @@ __device__ __forceinline__ int lds_off(int row, int chunk) {
 // fragment-major copy (one contiguous, fully coalesced 1 KB per fragment instead of 32 rows x 32 bytes) in batches of eight through two
 // register sets, the loads of batch g + 1 issued in one run before the MFMAs of batch g (the recipe of k_tcn_layer_lds); the accumulation
 // order per output is unchanged, so the three low-level paths stay bitwise identical.
-template <int C, bool DEEP = false, bool FRAG = false>
+template <int C, bool DEEP = false, bool FRAG = false, int GSO = 0>
 __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const int32_t* __restrict__ x,
                                                            const float* __restrict__ sproj, int64_t n_sessions, int L,
                                                            uint16_t* __restrict__ hidden) {
-  using G = TcnGeom<C>;
+  using G = TcnGeom<C, GSO>;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int ROWS = p.pad + 32;
   const int tid = threadIdx.x;
@@ -286,7 +286,22 @@ static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float
   constexpr int GS = TcnGeom<C>::GS;
   size_t lds = (size_t)GS * (p.pad + 32) * 2 * C;
   unsigned blocks = (unsigned)((n_sessions + GS - 1) / GS);
-  if (C <= 256 && blocks <= 384 && !p.save_emb) {   // fewer workgroups than one and a half per CU: latency of the weight loads, not occupancy, is the limit
+  const bool frag_ok = C <= 256 && p.convF[0] && (!p.projT || p.projF) && !getenv("HIERTCN_TCN_FUSED_V1");
+  if constexpr (C == 128 || C == 256) {
+    // Small grids (round 4; the reference's 32-lane batch = 320 sessions = 80 workgroups of four): every workgroup streams ALL the weights
+    // (1.4 MB at C = 256) through its CU whatever it computes, so two sessions per workgroup put twice the CUs on the same stream:
+    // 56 -> 44 us with the fragment-major stream instead of DEEP's row reads, -> 27 us with two sessions per workgroup (one: 37 us, 320
+    // workgroups are a round and a quarter).  Same accumulation order per output: bitwise identical to the other instances.
+    static const int64_t gs2_max = getenv("HIERTCN_TCN_GS2_MAX") ? atoll(getenv("HIERTCN_TCN_GS2_MAX")) : 512;
+    if (frag_ok && n_sessions <= gs2_max) {
+      const size_t l2 = (size_t)2 * (p.pad + 32) * 2 * C;
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
+      if (e != hipSuccess) return e;
+      hipLaunchKernelGGL((k_tcn_fused<C, false, true, 2>), dim3((unsigned)((n_sessions + 1) / 2)), dim3(TCN_THREADS), l2, st, p, x, sproj, n_sessions, L, hidden);
+      return hipGetLastError();
+    }
+  }
+  if (C <= 256 && blocks <= 384 && !p.save_emb && !frag_ok) {   // no fragment-major tables: all of a tap's row reads in flight (DEEP)
     constexpr bool DEEP_OK = C <= 256;
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, DEEP_OK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
@@ -294,7 +309,7 @@ static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float
     return hipGetLastError();
   }
   if constexpr (C <= 256) {
-    if (p.convF[0] && (!p.projT || p.projF) && !getenv("HIERTCN_TCN_FUSED_V1")) {
+    if (frag_ok) {
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
       if (e != hipSuccess) return e;
       hipLaunchKernelGGL((k_tcn_fused<C, false, true>), dim3(blocks), dim3(TCN_THREADS), lds, st, p, x, sproj, n_sessions, L, hidden);
