@@ -527,7 +527,7 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L, bool e
   w.nvalid = off; off += al256(sizeof(int32_t));
   w.cscratch = off; off += al256(((size_t)B * S * L / 1024 + 2) * sizeof(int32_t));
   w.tgt = off;    off += al256((size_t)B * S * L * sizeof(float));
-  w.split = off;  off += al256((size_t)score_split_parts(B * S * L, m.NP, split ? 256 : 512) * 2 * B * S * L * sizeof(float));   // small batches only (parts > 1)
+  w.split = off;  off += al256((size_t)score_split_scratch_parts(B * S * L, m.NP, split ? 256 : 512) * 2 * B * S * L * sizeof(float));   // small batches only (parts > 1)
   w.total = off;
   return w;
 }

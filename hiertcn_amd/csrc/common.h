@@ -255,7 +255,9 @@ hipError_t launch_gmm_prior_gram(const uint16_t* hidden, const float* pi_w, cons
 // small batches: number of catalogue parts the production kernel splits into (1 = none); scratch = parts * 2 * R floats
 int score_split_parts(int64_t R, int NP, int rows_per_wg = 512);   // 512: the 16-bit kernels' row tile (SC_THREADS); 256: score_x3.hip's
 hipError_t launch_score_merge(const float* partials, int parts, int64_t R, const int32_t* row_map, const int32_t* n_rows_dev, const int32_t* y,
-                               const float* tgt, int32_t* o_rank, float* o_ce, hipStream_t st);
+                               const float* tgt, int32_t* o_rank, float* o_ce, hipStream_t st, int dyn_grid = 0, int rows_per_wg = 0, int n_all = 0);
+// parts the split scratch of a small batch has to hold (the device-side split may take more parts than score_split_parts: score_geom.h)
+int score_split_scratch_parts(int64_t R, int NP, int rows_per_wg = 512);
 // ascending list of the rows with y > 0 (device-side, 3 small kernels): map [R], n_valid [1], scratch [(R+1023)/1024 + 1] ints
 hipError_t launch_compact_rows(const int32_t* y, int64_t R, int32_t* map, int32_t* n_valid, int32_t* scratch, hipStream_t st, int32_t* z0 = nullptr,
                                float* z1 = nullptr, float* z2 = nullptr);

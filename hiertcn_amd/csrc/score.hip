@@ -45,6 +45,16 @@ int score_split_parts(int64_t R, int NP, int rows_per_wg) {
   return best;
 }
 
+int score_split_scratch_parts(int64_t R, int NP, int rows_per_wg) {
+  const int parts = score_split_parts(R, NP, rows_per_wg);
+  return parts > 1 ? (parts > SC_DYN_MAX_PARTS ? parts : SC_DYN_MAX_PARTS) : 1;
+}
+// small batch = the device-side split applies: fewer than 128 row tiles at the host's bound (score_split_parts' first branch) and a split at all
+static bool score_dyn_applies(int64_t R, int NP, int rows_per_wg) {
+  static const bool off = getenv("HIERTCN_SCORE_DYN_OFF") != nullptr;
+  return !off && (R + rows_per_wg - 1) / rows_per_wg < 128 && score_split_parts(R, NP, rows_per_wg) > 1;
+}
+
 typedef __attribute__((address_space(3))) void lds_void;
 typedef const __attribute__((address_space(1))) void gbl_void;
 
@@ -484,7 +494,15 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   // Every row's arithmetic is independent of its position, so results are bit-identical to the dense launch.
   const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
   static_assert((NB == 2 && NSTG == 3) || (NB == 1 && NSTG == 2) || (NB == 1 && (PMODE == 15 || PMODE == 22) && (NSTG == 3 || (NSTG == 2 && C == 512))), "the pipeline shapes written out below");
-  if ((int64_t)blockIdx.x * (256 * NB) >= Rv) return;
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, part_st = part_stages;
+  if (part_stages < 0) {   // the split decided here, from the live row count (score_geom.h): -part_stages = the parts the scratch holds
+    const ScDynSplit d = score_dyn_split(Rv, 256 * NB, NP / SC_STAGE, (int)gridDim.x, -part_stages);
+    by = bx / d.tiles;
+    bx -= by * d.tiles;
+    if (by >= d.parts) return;
+    part_st = d.part_stages;
+  }
+  if ((int64_t)bx * (256 * NB) >= Rv) return;
   using G = ScGeom<C>;
   constexpr bool DUAL = PMODE == 12 || PMODE == 13 || PMODE == 14 || PMODE == 16 || PMODE == 21;   // one A fragment feeds both step blocks (four accumulator tiles in flight); 13: ring of 3
   constexpr bool SUMSQ = PMODE == 21;   // mixture head (gmm.hip): the four-tile seamless kernel with a one-fma epilogue -- sum of squares of the row's outputs
@@ -493,7 +511,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   constexpr bool SEAM1 = PMODE == 15 || PMODE == 22;   // ONE step block per wave (room for per-lane top-k lists) with the seamless tile boundary of PMODE 14: see SC_PHASE1
   constexpr bool SEAMLESS = PMODE == 14 || PMODE == 16 || PMODE == 21;   // 16: timing experiment, no stage barrier (racy by design)   // DUAL + no tile-boundary bubble: the next tile's bias and first fragment are fetched during this one
   if constexpr (FIXUP) {
-    const int64_t r = (int64_t)blockIdx.x * (256 * NB) + threadIdx.x;
+    const int64_t r = (int64_t)bx * (256 * NB) + threadIdx.x;
     int bad = 0;
     if ((int)threadIdx.x < 256 * NB && r < Rv) {
       const int64_t src = row_map ? (int64_t)row_map[r] : r;
@@ -506,7 +524,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * (32 * NB);
+  const int64_t row0 = ((int64_t)bx * 8 + wave) * (32 * NB);
 
   uint4 hf[NB][G::KS];
   int myy[NB];
@@ -560,8 +578,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
   }
 
   const int n_all = NP / SC_STAGE;
-  const int stg_lo = partials ? (int)blockIdx.y * part_stages : 0;
-  const int stg_hi0 = partials ? stg_lo + part_stages : n_all;
+  const int stg_lo = partials ? by * part_st : 0;
+  const int stg_hi0 = partials ? stg_lo + part_st : n_all;
   const int n_stages = ((stg_hi0 < n_all) ? stg_hi0 : n_all) - stg_lo;   // stages of THIS workgroup (may be <= 0 for a tail part)
   constexpr int PIECES = G::STAGE_BYTES / 1024;
   constexpr int PPW = PIECES / 8;
@@ -1195,10 +1213,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
     }
     if (partials) {
       if (lh == 0 && myr < Rv) {
-        float* pp = partials + (int64_t)blockIdx.y * 2 * R;
+        float* pp = partials + (int64_t)by * 2 * R;
         pp[myr] = __int_as_float(cnt);
         pp[R + myr] = (n_stages > 0) ? M2 + log2f(S) : -INFINITY;   // log2 of this part's sum of 2^(z log2 e)
-        if (blockIdx.y == 0 && o_tgt) o_tgt[mysrc[cbk]] = (myy[cbk] > 0) ? st[cbk].t : 0.f;
+        if (by == 0 && o_tgt) o_tgt[mysrc[cbk]] = (myy[cbk] > 0) ? st[cbk].t : 0.f;
       }
       continue;
     }
@@ -1245,12 +1263,14 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_pipe(const uint16_t* __
 }
 
 // adds up the catalogue parts of k_score_pipe (small-batch split): rank = sum of counts, lse = log-sum-exp over parts
+// parts < 0: the device-side split (score_geom.h) of a launch of `dyn_grid` workgroups of `rows_per_wg` rows over n_all stages, -parts = its cap
 __global__ void k_score_merge(const float* __restrict__ partials, int parts, int64_t R, const int32_t* __restrict__ row_map,
                               const int32_t* __restrict__ n_rows_dev, const int32_t* __restrict__ y, const float* __restrict__ tgt,
-                              int32_t* __restrict__ o_rank, float* __restrict__ o_ce) {
+                              int32_t* __restrict__ o_rank, float* __restrict__ o_ce, int dyn_grid, int rows_per_wg, int n_all) {
   const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
   if (p >= Rv) return;
+  if (parts < 0) parts = score_dyn_split(Rv, rows_per_wg, n_all, dyn_grid, -parts).parts;
   const int64_t row = row_map ? (int64_t)row_map[p] : p;
   int cnt = 0;
   float M = -INFINITY;
@@ -1266,8 +1286,9 @@ __global__ void k_score_merge(const float* __restrict__ partials, int parts, int
 }
 
 hipError_t launch_score_merge(const float* partials, int parts, int64_t R, const int32_t* row_map, const int32_t* n_rows_dev, const int32_t* y,
-                               const float* tgt, int32_t* o_rank, float* o_ce, hipStream_t st) {
-  hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, partials, parts, R, row_map, n_rows_dev, y, tgt, o_rank, o_ce);
+                               const float* tgt, int32_t* o_rank, float* o_ce, hipStream_t st, int dyn_grid, int rows_per_wg, int n_all) {
+  hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, partials, parts, R, row_map, n_rows_dev, y, tgt, o_rank, o_ce, dyn_grid,
+                     rows_per_wg, n_all);
   return hipGetLastError();
 }
 
@@ -1296,21 +1317,32 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
   hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess) return e;
   int* walk = m.walk_pos;   // owned by the handle (per device): hiertcn_create; null with HIERTCN_FIXED_WALK=1
+  constexpr int FNB = (NB == 1 && NSTG == 3) ? 2 : NB;   // the fix-up flavour exists in the two-block shape at three stages (as launch_score_topk uses it)
   const int parts = score_split_parts(R, m.NP);
+  if ((PMODE == 5 || PMODE >= 7) && split_scratch && out->rank && out->ce && out->target && score_dyn_applies(R, m.NP, 512)) {
+    // small batch: SC_DYN_GRID workgroups, (row tile, catalogue part) decided on the device from the live row count (score_geom.h)
+    const int n_all = m.NP / SC_STAGE;
+    hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(SC_DYN_GRID), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
+                       out->rank, out->ce, out->target, row_map, n_rows_dev, -SC_DYN_MAX_PARTS, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0);
+    hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, -SC_DYN_MAX_PARTS, R, row_map, n_rows_dev, y,
+                       out->target, out->rank, out->ce, SC_DYN_GRID, 256 * NB, n_all);
+    if constexpr (PMODE == 12 || PMODE == 14 || PMODE == 15) return launch_score_fixup<C, FNB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+    return hipGetLastError();
+  }
   if ((PMODE == 5 || PMODE >= 7) && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;
     hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                        out->rank, out->ce, out->target, row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0);
     hipLaunchKernelGGL(k_score_merge, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, split_scratch, parts, R, row_map, n_rows_dev, y,
-                       out->target, out->rank, out->ce);
-    if constexpr (PMODE == 12 || PMODE == 14 || PMODE == 15) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+                       out->target, out->rank, out->ce, 0, 0, 0);
+    if constexpr (PMODE == 12 || PMODE == 14 || PMODE == 15) return launch_score_fixup<C, FNB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
     return hipGetLastError();
   }
   hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,
                      out->rank, out->ce, out->target, row_map, n_rows_dev, 0, (float*)nullptr, walk, (int32_t*)nullptr, (float*)nullptr, 0);
   if constexpr (PMODE == 12 || PMODE == 14 || PMODE == 15) {
-    if (out->ce) return launch_score_fixup<C, NB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
+    if (out->ce) return launch_score_fixup<C, FNB, NSTG, PAD>(m, hidden, y, R, out, st, row_map, n_rows_dev, walk);
   }
   return hipGetLastError();
 }
@@ -1481,10 +1513,20 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   // production
   if (getenv("HIERTCN_PIPE_VARIANT") && getenv("HIERTCN_PIPE_VARIANT")[0] == '5')   // the two-tile kernel (also the FIXUP flavour), kept for A/B runs
     return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
-  if constexpr (C == 256)   // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
+  if constexpr (C == 256) {  // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
+    // small batches: ONE step block per wave (256-row tiles, the list flavour's skeleton without lists): twice the row tiles for the device-side
+    // split to deal out, half the MFMA chain per stage (a 32-lane XING batch: ~14 live tiles x 18 parts on 252 CUs instead of ~7 x 19 on 133)
+    static const bool nb1 = getenv("HIERTCN_SCORE_SMALL_NB2") == nullptr;
+    if (nb1 && split_scratch && out->rank && out->ce && out->target && score_dyn_applies(R, m.NP, 512))
+      return launch_score_pipe<256, 15, 1, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
-  else   // C = 64 / 128: the same four-tile seamless shape on the XOR-swizzled image (registers are not the problem here)
+  }
+  else {  // C = 64 / 128: the same four-tile seamless shape on the XOR-swizzled image (registers are not the problem here)
+    static const bool nb1 = getenv("HIERTCN_SCORE_SMALL_NB2") == nullptr;
+    if (nb1 && split_scratch && out->rank && out->ce && out->target && score_dyn_applies(R, m.NP, 512))
+      return launch_score_pipe<C, 15, 1, 3>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     return launch_score_pipe<C, 14>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+  }
 }
 
 template <bool LOGITS, int MODE, int KT>

@@ -15,3 +15,23 @@ struct ScGeom {
   static_assert((SC_STAGE * CH) % SC_THREADS == 0, "stage must split evenly");
 };
 
+
+// Small batches (score.hip, k_score_pipe with part_stages < 0): the split of the catalogue is decided ON THE DEVICE from the count of rows that carry
+// a target -- a ragged XING batch has about half the rows of its host-side bound, and a split sized for the bound leaves half the workgroups without
+// work.  `grid` workgroups are dealt as (row tile, catalogue part) = (id % tiles, id / tiles); the merge kernel derives the same numbers.
+struct ScDynSplit { int tiles, parts, part_stages; };
+__host__ __device__ inline ScDynSplit score_dyn_split(int64_t rows, int rows_per_wg, int n_all, int grid, int max_parts) {
+  ScDynSplit d;
+  d.tiles = (int)((rows + rows_per_wg - 1) / rows_per_wg);
+  if (d.tiles < 1) d.tiles = 1;
+  int parts = grid / d.tiles;
+  const int by_len = n_all / 16;   // a part is at least 16 stages: below that the prologue (hidden rows, target logits) outweighs the stages
+  if (parts > by_len) parts = by_len;
+  if (parts > max_parts) parts = max_parts;
+  if (parts < 1) parts = 1;
+  d.parts = parts;
+  d.part_stages = (n_all + parts - 1) / parts;
+  return d;
+}
+#define SC_DYN_MAX_PARTS 32
+#define SC_DYN_GRID 256
