@@ -120,16 +120,18 @@ hipError_t launch_dlogits_rows(const ModelDev& m, const uint16_t* hc, const floa
                                const float* tgt, const int32_t* map, int64_t r0, int64_t r1, uint16_t* gout, float* dbias, hipStream_t st);
 // score_bwd.hip: the scoring layer's backward without the d-logits matrix (recompute + second product fused, device-side row count)
 bool sgrad_supported(const ModelDev& m);
+size_t sgrad_forward_part_floats(const ModelDev& m, int64_t R);
+size_t sgrad_dwo_slab_floats(const ModelDev& m, int64_t R);      // scratch of launch_sgrad_dwo's row parts at small catalogues (0: none)   // scratch of launch_sgrad_forward's small-batch split (0: none)
 hipError_t launch_sgrad_prepare(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const float* ce, const float* tgt, const int32_t* map,
                                 const int32_t* n_dev, int64_t R, uint16_t* hc, int32_t* yc, float* wc, float* rb_nat, float* rb_l2, float* bias_l2,
                                 hipStream_t st);
 hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const int32_t* row_map,
                                 const int32_t* n_dev, int64_t R, int32_t* o_rank, float* o_ce, float* o_tgt, float* dh, int32_t* ovf,
-                                hipStream_t st);
+                                hipStream_t st, float* part = nullptr);
 hipError_t launch_sgrad_dh(const ModelDev& m, const uint16_t* hc, const float* rb_l2, const int32_t* yc, const float* wc, const int32_t* row_map,
                            const int32_t* n_dev, int64_t R, float* dh, int32_t* ovf, int vote, hipStream_t st);
 hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const int32_t* yc, const float* wc, const int32_t* n_dev,
-                            int64_t R, const float* bias_l2, float* dwo, float* dbias, hipStream_t st);
+                            int64_t R, const float* bias_l2, float* dwo, float* dbias, hipStream_t st, float* slabs = nullptr);
 // score.hip: the fix-up flavour of the production scoring kernel alone (row tiles whose ce is non-finite are redone with the per-tile redo)
 hipError_t launch_score_fixup_only(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                                    hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev);

@@ -71,6 +71,14 @@ struct SgradArgs {
   int* walk;             // per-XCD stream-position words ([8][32] ints, the handle's; null: every workgroup starts at stage 0)
   // mode 2
   const float* out_bias; int32_t* o_rank; float* o_ce; float* o_tgt;
+  // mode 2, small batches: the table split in parts decided on the device (score_geom.h, score_dyn_split).  part [2 parts + 1][part_ld]: per part the
+  // row's sum and count, then the target logit; behind them dyn_max_parts slabs [part_ld][C] of the parts' unscaled d hidden by COMPACT row (plain
+  // stores: 16.7 M scattered fp32 atomics per launch made this split only 1.7 x faster than no split); k_sgrad_finish adds the parts up, normalises,
+  // and writes rank / ce / target / d hidden
+  float* part; int64_t part_ld; int dyn_max_parts;
+  // mode 0, small catalogues: part y > 0 of the scored rows STORES its d Wo into slab y - 1 of `slabs` ([NP][C] each) instead of adding atomically
+  // (k_add_slabs folds them into `out` afterwards)
+  float* slabs;
 };
 
 template <int C, int MODE, bool ONE = (C == 512)>
@@ -98,7 +106,15 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
 #endif
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];   // 3 stages of 64 stream vectors + 3 x 64 stream scalars
   const int64_t n_stat = a.n_stat_dev ? (int64_t)a.n_stat_dev[0] : a.n_stat_max;
-  if ((int64_t)blockIdx.x * SG::STAT >= n_stat) return;
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, ny = (int)gridDim.y;
+  if (MODE == 2 && a.dyn_max_parts > 0) {
+    const ScDynSplit d = score_dyn_split(n_stat, SG::STAT, a.n_stages_max, (int)gridDim.x, a.dyn_max_parts);
+    by = bx / d.tiles;
+    bx -= by * d.tiles;
+    ny = d.parts;
+    if (by >= ny) return;
+  }
+  if ((int64_t)bx * SG::STAT >= n_stat) return;
   if (MODE == 1 && a.vote) {   // fix-up launch: only blocks with a flagged row do anything
     const int64_t p = (int64_t)blockIdx.x * SG::STAT + threadIdx.x;
     const int bad = ((int)threadIdx.x < SG::STAT && p < n_stat) ? a.ovf[p] : 0;
@@ -107,12 +123,17 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   int n_stages = a.n_stream_dev ? (int)(((int64_t)a.n_stream_dev[0] + SI - 1) / SI) : a.n_stages_max;
   if (n_stages > a.n_stages_max) n_stages = a.n_stages_max;
   int s_lo = 0;
-  if (gridDim.y > 1) {   // the stream split in parts (mode 0: the item dimension alone gives N / 256 workgroups): partial sums added atomically
-    const int per = (n_stages + (int)gridDim.y - 1) / (int)gridDim.y;
-    s_lo = (int)blockIdx.y * per;
+  if (ny > 1) {   // the stream split in parts (mode 0: the item dimension alone gives N / 256 workgroups): partial sums added atomically
+    const int per = (n_stages + ny - 1) / ny;
+    s_lo = by * per;
     const int s_hi = (s_lo + per < n_stages) ? s_lo + per : n_stages;
-    if (s_hi <= s_lo) return;
-    n_stages = s_hi - s_lo;
+    if (s_hi <= s_lo) {
+      if (!(MODE == 0 && a.slabs)) return;
+      s_lo = 0;   // a slab part without rows still stores its (zero) tile: k_add_slabs reads every slab
+      n_stages = 0;
+    } else {
+      n_stages = s_hi - s_lo;
+    }
   }
   const uint16_t* stream = a.stream + (int64_t)s_lo * SI * C;
   const float* stream_bias = a.stream_bias + (int64_t)s_lo * SI;
@@ -121,7 +142,7 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t sv = ((int64_t)blockIdx.x * SG::W + wave) * 32 + lr;   // this lane's stationary vector
+  const int64_t sv = ((int64_t)bx * SG::W + wave) * 32 + lr;   // this lane's stationary vector
   const int64_t svc = sv < n_stat ? sv : n_stat - 1;   // (lanes past the end read the last live vector: finite data, their column is never stored)
   const int64_t srow = (MODE == 2) ? (int64_t)a.row_map[svc] : svc;   // mode 2 reads the hidden rows in place
 
@@ -191,7 +212,7 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   int s0 = 0;
   int* walk_word = nullptr;
   if (a.walk && !(MODE == 1 && a.vote)) {
-    walk_word = a.walk + (blockIdx.x & 7) * 32 + 8 + 4 * MODE + (int)(blockIdx.y & 3);
+    walk_word = a.walk + (blockIdx.x & 7) * 32 + 8 + 4 * MODE + (by & 3);
     int* s0_sh = reinterpret_cast<int*>(smem);   // (the stage buffers are not in use yet)
     if (tid == 0) *s0_sh = __hip_atomic_load(walk_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __syncthreads();
@@ -420,13 +441,14 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   // out^T[c][stationary]: register i of tile cb is channel 32 cb + (i & 3) + 8 (i >> 2) + 4 lh of this lane's stationary vector
   if (MODE == 0) {
     if (sv < a.n_stat_max) {
-      float* op = a.out + sv * C;
+      const bool slab = a.slabs != nullptr;
+      float* op = (slab && by > 0 ? a.slabs + (int64_t)(by - 1) * a.n_stat_max * C : a.out) + sv * C;
 #pragma unroll
       for (int cb = 0; cb < NCB; cb++) {
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           float* d = op + 32 * cb + 8 * q + 4 * lh;
-          if (gridDim.y > 1) {
+          if (ny > 1 && !slab) {
 #pragma unroll
             for (int j = 0; j < 4; j++) atomicAdd(d + j, oacc[cb][4 * q + j]);
           } else {
@@ -445,6 +467,25 @@ __global__ __launch_bounds__((SgGeom<C, ONE>::THREADS), (ONE ? 1 : 2)) void k_sg
   float scale = 1.f, w;
   int yv;
   int64_t drow;
+  if (MODE == 2 && a.dyn_max_parts > 0) {
+    // one part of the table: the reference point is fixed, so the parts' sums, counts and unscaled d hidden simply add up (k_sgrad_finish)
+    const float s_tot = cs + __shfl_xor(cs, 32);
+    const int c_tot = cnt + __shfl_xor(cnt, 32);
+    if (sv < n_stat) {
+      if (lh == 0) {
+        a.part[(int64_t)(2 * by) * a.part_ld + sv] = s_tot;
+        a.part[(int64_t)(2 * by + 1) * a.part_ld + sv] = __int_as_float(c_tot);
+        if (by == 0) a.part[(int64_t)(2 * a.dyn_max_parts) * a.part_ld + sv] = tlog;
+      }
+      float* op = a.part + (int64_t)(2 * a.dyn_max_parts + 1) * a.part_ld + ((int64_t)by * a.part_ld + sv) * C;
+#pragma unroll
+      for (int cb = 0; cb < NCB; cb++)
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+          *reinterpret_cast<float4*>(op + 32 * cb + 8 * q + 4 * lh) = make_float4(oacc[cb][4 * q], oacc[cb][4 * q + 1], oacc[cb][4 * q + 2], oacc[cb][4 * q + 3]);
+    }
+    return;
+  }
   if (MODE == 2) {
     const float s_tot = cs + __shfl_xor(cs, 32);   // the two halves saw disjoint items, with the same reference point
     const int c_tot = cnt + __shfl_xor(cnt, 32);
@@ -534,6 +575,98 @@ __global__ __launch_bounds__(256) void k_dwo_onehot(const uint16_t* __restrict__
   if (lane == 0) atomicAdd(dbias + yv, -w);
 }
 
+// Small batches, mode 2 split in parts: one wave per compact row adds the parts up, writes rank / ce / target as the unsplit kernel does and turns the
+// accumulated sum_n 2^(z_n log2e - m) Wo[n] into d hidden = w softmax . Wo - w Wo[y].
+__global__ __launch_bounds__(256) void k_sgrad_finish(const float* __restrict__ part, int64_t part_ld, int max_parts, int grid, int stat, int n_all,
+                                                       const int32_t* __restrict__ n_dev, const int32_t* __restrict__ row_map, const int32_t* __restrict__ y,
+                                                       const float* __restrict__ w, const uint16_t* __restrict__ outT, int N, int C, float* __restrict__ dh,
+                                                       int32_t* __restrict__ o_rank, float* __restrict__ o_ce, float* __restrict__ o_tgt, int32_t* __restrict__ ovf) {
+  const int lane = threadIdx.x & 63;
+  const int64_t n = n_dev[0];
+  const int64_t p = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (p >= n) return;
+  int parts = score_dyn_split(n, stat, n_all, grid, max_parts).parts;
+  {  // the kernel cuts the stream in ceil(n_all / parts) stages per part: trailing parts without a stage write nothing
+    const int per = (n_all + parts - 1) / parts;
+    parts = (n_all + per - 1) / per;
+  }
+  const int64_t srow = row_map[p];
+  const int yy = y[srow];
+  const int myy = (yy > 0 && yy < N) ? yy : 0;
+  float s_tot = 0.f;
+  int c_tot = 0;
+  for (int k = 0; k < parts; k++) {
+    s_tot += part[(int64_t)(2 * k) * part_ld + p];
+    c_tot += __float_as_int(part[(int64_t)(2 * k + 1) * part_ld + p]);
+  }
+  const float tlog = part[(int64_t)(2 * max_parts) * part_ld + p];
+  const bool over = (__float_as_uint(s_tot) & 0x7f800000u) == 0x7f800000u;
+  const float wv = w[srow];
+  const float scale = myy > 0 ? wv / s_tot : 0.f;
+  if (lane == 0) {
+    const float cst = -(tlog * LOG2E_F + 64.0f);
+    const float lse = (log2f(s_tot) - cst) * LN2_F;
+    o_rank[srow] = myy > 0 ? c_tot : 0;
+    o_ce[srow] = myy > 0 ? (over ? INFINITY : lse - tlog) : 0.f;
+    o_tgt[srow] = myy > 0 ? tlog : 0.f;
+    if (over) ovf[p] = 1;
+  }
+  const float wh = myy > 0 ? wv : 0.f;
+  const uint16_t* wr = outT + (int64_t)myy * C;
+  float* op = dh + srow * C;
+  const float* slab = part + (int64_t)(2 * max_parts + 1) * part_ld + p * C;
+  for (int c = 4 * lane; c < C; c += 256) {
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int k = 0; k < parts; k++) {
+      const float4 t = *reinterpret_cast<const float4*>(slab + (int64_t)k * part_ld * C + c);
+      v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+    }
+    const uint2 t2 = *reinterpret_cast<const uint2*>(wr + c);
+    v.x = v.x * scale - wh * bf2f((uint16_t)(t2.x & 0xffff));
+    v.y = v.y * scale - wh * bf2f((uint16_t)(t2.x >> 16));
+    v.z = v.z * scale - wh * bf2f((uint16_t)(t2.y & 0xffff));
+    v.w = v.w * scale - wh * bf2f((uint16_t)(t2.y >> 16));
+    *reinterpret_cast<float4*>(op + c) = v;
+  }
+}
+
+// out[i] += sum of n_slabs slabs (float4 per thread)
+__global__ void k_add_slabs(float* __restrict__ out, const float* __restrict__ slabs, int64_t n4, int n_slabs) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  float4 v = reinterpret_cast<float4*>(out)[i];
+  for (int k = 0; k < n_slabs; k++) {
+    const float4 t = reinterpret_cast<const float4*>(slabs)[(int64_t)k * n4 + i];
+    v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+  }
+  reinterpret_cast<float4*>(out)[i] = v;
+}
+// small catalogues (fewer than 128 item blocks: the chip is not filled by the item dimension): row parts of mode 0 through slabs
+static int sgrad_dwo_slab_parts(const ModelDev& m, int64_t R) {
+  static const bool off = getenv("HIERTCN_SGRAD0_SLABS_OFF") != nullptr;
+  const int stat = sg_stat(m.Clast, sg_one(m.Clast, 0));
+  const int blocks = (m.NP + stat - 1) / stat;
+  if (off || blocks >= 128) return 1;
+  const int stages = (int)((R + 63) / 64);
+  int p = 256 / blocks;
+  if (p > 4) p = 4;
+  while (p > 1 && stages / p < 16) p--;
+  return p;
+}
+size_t sgrad_dwo_slab_floats(const ModelDev& m, int64_t R) {
+  const int p = sgrad_dwo_slab_parts(m, R);
+  return p > 1 ? (size_t)(p - 1) * (size_t)m.NP * (size_t)m.Clast : 0;
+}
+
+#define SG_DYN_MAX_PARTS 16   // (a slab of d hidden per part: 16 x 6,464 rows x 1 KB = 106 MB at the reference's batch and d = 256)
+// floats of the `part` scratch of launch_sgrad_forward (0: the batch is not small, no split)
+size_t sgrad_forward_part_floats(const ModelDev& m, int64_t R) {
+  static const bool off = getenv("HIERTCN_SGRAD_DYN_OFF") != nullptr;
+  const int stat2 = sg_stat(m.Clast, sg_one(m.Clast, 2));
+  if (off || (R + stat2 - 1) / stat2 >= 128 || m.NP / sg_si(m.Clast, sg_one(m.Clast, 2)) < 32) return 0;
+  return (size_t)(2 * SG_DYN_MAX_PARTS + 1) * (size_t)(R + 64) + (size_t)SG_DYN_MAX_PARTS * (size_t)(R + 64) * (size_t)m.Clast;
+}
+
 bool sgrad_supported(const ModelDev& m) {
   return (m.Clast == 64 && !getenv("HIERTCN_SGRAD64_OFF")) || m.Clast == 128 || m.Clast == 256 || (m.Clast == 512 && !getenv("HIERTCN_SGRAD512_OFF"));
 }
@@ -563,7 +696,7 @@ static hipError_t launch_k_sgrad_c(const ModelDev& m, const SgradArgs& a, dim3 g
 // (zero-filled by the caller) flagged where the running sum overflowed.  w [R]: d loss / d ce per row (model.py:111-117).
 hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const int32_t* y, const float* w, const int32_t* row_map,
                                 const int32_t* n_dev, int64_t R, int32_t* o_rank, float* o_ce, float* o_tgt, float* dh, int32_t* ovf,
-                                hipStream_t st) {
+                                hipStream_t st, float* part) {
   if (R <= 0) return hipSuccess;
   SgradArgs a;
   memset(&a, 0, sizeof(a));
@@ -573,6 +706,17 @@ hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const
   a.out_bias = m.out_bias; a.o_rank = o_rank; a.o_ce = o_ce; a.o_tgt = o_tgt;
   a.walk = m.walk_pos;
   const int stat2 = sg_stat(m.Clast, sg_one(m.Clast, 2));
+  if (part && n_dev && row_map && sgrad_forward_part_floats(m, R) > 0) {
+    // small batch (the reference's 32 lanes: 25 row blocks, half of them empty when ragged, each walking the whole table): SC_DYN_GRID workgroups dealt
+    // as (row block, table part) on the device from the live row count
+    a.part = part; a.part_ld = R + 64; a.dyn_max_parts = SG_DYN_MAX_PARTS;
+    a.walk = nullptr;
+    hipError_t e = launch_k_sgrad_c<2>(m, a, dim3(SC_DYN_GRID), st);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(k_sgrad_finish, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, part, a.part_ld, SG_DYN_MAX_PARTS, SC_DYN_GRID, stat2, a.n_stages_max, n_dev,
+                       row_map, y, w, m.outT, m.N, m.Clast, dh, o_rank, o_ce, o_tgt, ovf);
+    return hipGetLastError();
+  }
   return launch_k_sgrad_c<2>(m, a, dim3((unsigned)((R + stat2 - 1) / stat2)), st);
 }
 
@@ -593,7 +737,7 @@ hipError_t launch_sgrad_dh(const ModelDev& m, const uint16_t* hc, const float* r
 // d Wo / d bo (mode 0), ACCUMULATED into dwo [NP][C] / dbias [NP] (the gradient arena is zeroed at the start of the step), followed by
 // the one-hot term.  bias_l2 [NP]: bo log2e (-inf on the padding items); rb_nat [R + 64]: ln w - lse per compact row (-inf padding).
 hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* rb_nat, const int32_t* yc, const float* wc, const int32_t* n_dev,
-                            int64_t R, const float* bias_l2, float* dwo, float* dbias, hipStream_t st) {
+                            int64_t R, const float* bias_l2, float* dwo, float* dbias, hipStream_t st, float* slabs) {
   if (R <= 0) return hipSuccess;
   SgradArgs a;
   memset(&a, 0, sizeof(a));
@@ -606,13 +750,23 @@ hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* 
   const unsigned blocks = (unsigned)((m.NP + stat - 1) / stat);
   unsigned parts = 1;
   double best = 0.0;
-  for (unsigned p = 1; p <= 8 && (p == 1 || a.n_stages_max / (int)p >= 64); p++) {
+  static const int min_st = getenv("HIERTCN_SGRAD0_MIN_STAGES") ? atoi(getenv("HIERTCN_SGRAD0_MIN_STAGES")) : 64;
+  for (unsigned p = 1; p <= 8 && (p == 1 || a.n_stages_max / (int)p >= min_st); p++) {
     const double eff = ((double)blocks * p / 256.0) / (double)((blocks * p + 255) / 256);
     if (eff > best + 1e-9) { best = eff; parts = p; }
     if (eff >= 0.93) break;
   }
+  const int sp = slabs ? sgrad_dwo_slab_parts(m, R) : 1;
+  if (sp > 1) {   // (every part stores its whole tile, also a part that finds no live rows behind the device-side count: its accumulators are zero)
+    a.slabs = slabs;
+    parts = (unsigned)sp;
+  }
   hipError_t e = launch_k_sgrad_c<0>(m, a, dim3(blocks, parts), st);
   if (e != hipSuccess) return e;
+  if (sp > 1) {
+    const int64_t n4 = (int64_t)m.NP * m.Clast / 4;
+    hipLaunchKernelGGL(k_add_slabs, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, dwo, slabs, n4, sp - 1);
+  }
   hipLaunchKernelGGL(k_dwo_onehot, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, hc, yc, wc, n_dev, m.Clast, m.N, dwo, dbias);
   return hipGetLastError();
 }

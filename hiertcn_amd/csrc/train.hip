@@ -610,6 +610,10 @@ struct TrainWs {
   size_t rb2;     // the same x log2e (k_sgrad, rows stationary)
   size_t bl2;     // bo x log2e [NP] (k_sgrad, items stationary)
   size_t ovf;     // per compact row: the forward pass's running sum overflowed (k_sgrad mode 2 -> fix-up launches)
+  size_t sgpart;  // small batches: per-part sums / counts of k_sgrad mode 2 (score_bwd.hip, sgrad_forward_part_floats)
+  int sgpart_on;
+  size_t sgslab;  // small catalogues: d Wo slabs of the row parts of k_sgrad mode 0 (sgrad_dwo_slab_floats)
+  int sgslab_on;
   int fused;      // 1: the G-free scoring backward (score_bwd.hip); 0: the d-logits chunks + two products per chunk (gemm.hip)
   int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
   int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
@@ -686,6 +690,10 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.rb2 = take((R + 64) * 4);
   w.bl2 = take((size_t)m.NP * 4);
   w.ovf = take((R + 64) * 4);
+  w.sgpart_on = (w.fused && sgrad_forward_part_floats(m, (int64_t)R) > 0) ? 1 : 0;
+  w.sgpart = take(w.sgpart_on ? sgrad_forward_part_floats(m, (int64_t)R) * 4 : 0);
+  w.sgslab_on = (w.fused && sgrad_dwo_slab_floats(m, (int64_t)R) > 0) ? 1 : 0;
+  w.sgslab = take(w.sgslab_on ? sgrad_dwo_slab_floats(m, (int64_t)R) * 4 : 0);
   {  // partial tiles of the row-sliced weight-gradient GEMMs (gemm.hip): up to 64 slices of the largest [out x in] gradient
     const size_t gw = (size_t)2 * H * (size_t)(E > H ? E : H), cw = (size_t)C * C;
     w.splitk_floats = (size_t)64 * (gw > cw ? gw : cw);
@@ -816,7 +824,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(hipGetLastError());
     T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
     T_HIP(hipMemsetAsync(ws + w.ovf, 0, (size_t)R * 4, st));
-    T_HIP(launch_sgrad_forward(m, hidden, y, F32(w.w), rmap, nvalid_d, R, so.rank, so.ce, so.target, dH, reinterpret_cast<int32_t*>(ws + w.ovf), st));
+    T_HIP(launch_sgrad_forward(m, hidden, y, F32(w.w), rmap, nvalid_d, R, so.rank, so.ce, so.target, dH, reinterpret_cast<int32_t*>(ws + w.ovf), st,
+                                w.sgpart_on ? F32(w.sgpart) : nullptr));
     T_HIP(launch_score_fixup_only(m, hidden, y, R, &so, st, rmap, nvalid_d));   // rank / ce of row tiles whose sum overflowed (pathological inputs)
   } else
   T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st, rmap, nvalid_d));
@@ -845,7 +854,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     int32_t* yc = reinterpret_cast<int32_t*>(ws + w.yc);
     T_HIP(launch_sgrad_prepare(m, hidden, y, F32(w.w), so.ce, so.target, rmap, nvalid_d, R, hc, yc, F32(w.wc), F32(w.rb), F32(w.rb2), F32(w.bl2), st));
     T_HIP(launch_sgrad_dh(m, hc, F32(w.rb2), yc, F32(w.wc), rmap, nvalid_d, R, dH, reinterpret_cast<int32_t*>(ws + w.ovf), 1, st));
-    T_HIP(launch_sgrad_dwo(m, hc, F32(w.rb), yc, F32(w.wc), nvalid_d, R, F32(w.bl2), G + t.outT.off, G + t.out_bias.off, st));
+    T_HIP(launch_sgrad_dwo(m, hc, F32(w.rb), yc, F32(w.wc), nvalid_d, R, F32(w.bl2), G + t.outT.off, G + t.out_bias.off, st,
+                            w.sgslab_on ? F32(w.sgslab) : nullptr));
   } else
   if (Rv > 0) {
     uint16_t* hc = BF(w.hc);
