@@ -107,7 +107,7 @@ hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_se
 size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 int gru_persist_groups(const ModelDev& m, int B, int S, bool saving);
 hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
-                                   float* state_out, float* ws, int G, hipStream_t st);
+                                   float* state_out, float* ws, int G, hipStream_t st, float* save = nullptr);
 size_t gru_save_floats(const ModelDev& m, int B, int S);
 hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
                            float* sproj, float* state_out, float* state_before, float* ws, hipStream_t st, float* save = nullptr);

@@ -5,6 +5,15 @@
 
 // fp32, bit-exact multiply-add chains on v_mfma_f32_32x32x2_f32
 //   NN: C[M][N] (ldc) = beta C + A[M][K] (lda) . B[K][N] (ldb)
+// epilogue operands of gemm32_nn_gru_bwd: the elementwise pieces of a GRU cell's backward (train.hip, k_gru_bwd_b / k_gru_bwd_c) folded into its two products
+struct GruBwdEpi {
+  int in, H, K;                                  // K = in + H
+  const float* gates; const float* h; int ldh;   // mode 1: (r, u) [M][2H], the old state slice (row stride ldh)
+  float* dag; float* dhpart;                     // mode 1: d gates[:, :H] written, d h (partial) updated; mode 2: dhpart read
+  const float* dcat_c;                           // [M][K]: mode 1 writes its input half, mode 2 reads it
+  float* dst_in; int ldi; float* dst_h; int ldo; // mode 2: d input, d old state
+};
+hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, const GruBwdEpi& ep, hipStream_t st);
 hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st);
 //   TN: C[N1][N2] (ldc) = beta C + sum_{m < Mred} A[m][N1] (lda) . B[m][N2] (ldb); scratch (optional): partial tiles of the row slices
 hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int N1, int N2, int Mred, float beta,

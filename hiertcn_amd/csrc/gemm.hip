@@ -178,7 +178,10 @@ static hipError_t run32(const float* A, int64_t lda, const float* B, int64_t ldb
 #define SK_K 128
 #define SK_PA (SK_K + 4)   // pitch of the [32 m][128 k] tile
 #define SK_PB 68           // pitch of the [128 k][64 n] tile: rows 4 apart are 16 banks apart
-__global__ __launch_bounds__(128) void k_gemm32_nn_skinny(const G32 g) {
+// EPI 1 / 2 (round 4): the two products of a GRU cell's backward with the elementwise kernel that followed each folded into the epilogue (GruBwdEpi,
+// gemm.h; train.hip: five launches per cell -> three) -- same accumulation, same formulas, one pass less over [B][K].
+template <int EPI>
+__global__ __launch_bounds__(128) void k_gemm32_nn_skinny(const G32 g, const GruBwdEpi ep) {
   __shared__ float As[32 * SK_PA];
   __shared__ float Bs[SK_K * SK_PB];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -217,14 +220,56 @@ __global__ __launch_bounds__(128) void k_gemm32_nn_skinny(const G32 g) {
   }
   const int n = n0 + 32 * wave + lr;
   if (n >= g.N) return;
+  if constexpr (EPI == 1) {   // acc = d[in | r*h][m][n] (k_gru_bwd_b): the input half is kept for EPI 2, the r*h half goes into d gates (r) and d h
+    if (n < ep.in) {
 #pragma unroll
-  for (int q = 0; q < 16; q++) {
-    const int m = m0 + acc_row(q, lh);
-    if (m >= g.M) continue;
-    float v = acc[q];
-    float* c = g.C + (int64_t)m * g.ldc + n;
-    if (g.beta != 0.f) v += g.beta * *c;
-    *c = v;
+      for (int q = 0; q < 16; q++) {
+        const int m = m0 + acc_row(q, lh);
+        if (m < g.M) g.C[(int64_t)m * g.ldc + n] = acc[q];
+      }
+    } else {
+      const int k = n - ep.in;
+      float r[16], hv[16], dh[16];   // every load before the first store: the pointers may alias as far as the compiler knows, and 16 dependent round trips cost more than the kernel saved
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = min(m0 + acc_row(q, lh), g.M - 1);
+        r[q] = ep.gates[(int64_t)m * 2 * ep.H + k];
+        hv[q] = ep.h[(int64_t)m * ep.ldh + k];
+        dh[q] = ep.dhpart[(int64_t)m * ep.H + k];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = m0 + acc_row(q, lh);
+        if (m >= g.M) continue;
+        ep.dag[(int64_t)m * 2 * ep.H + k] = acc[q] * hv[q] * r[q] * (1.f - r[q]);
+        ep.dhpart[(int64_t)m * ep.H + k] = dh[q] + acc[q] * r[q];
+      }
+    }
+  } else if constexpr (EPI == 2) {   // acc = d[in | h][m][n] from the gates (k_gru_bwd_c): + the candidate's input half / + d h so far
+    const bool inp = n < ep.in;
+    float o[16];
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int m = min(m0 + acc_row(q, lh), g.M - 1);
+      o[q] = inp ? ep.dcat_c[(int64_t)m * ep.K + n] : ep.dhpart[(int64_t)m * ep.H + (n - ep.in)];
+    }
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int m = m0 + acc_row(q, lh);
+      if (m >= g.M) continue;
+      if (inp) ep.dst_in[(int64_t)m * ep.ldi + n] = o[q] + acc[q];
+      else ep.dst_h[(int64_t)m * ep.ldo + (n - ep.in)] = o[q] + acc[q];
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+      const int m = m0 + acc_row(q, lh);
+      if (m >= g.M) continue;
+      float v = acc[q];
+      float* c = g.C + (int64_t)m * g.ldc + n;
+      if (g.beta != 0.f) v += g.beta * *c;
+      *c = v;
+    }
   }
 }
 
@@ -234,10 +279,24 @@ hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, f
     G32 g;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.beta = beta;
     g.k_per_split = K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;
-    hipLaunchKernelGGL(k_gemm32_nn_skinny, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32)), dim3(128), 0, st, g);
+    const GruBwdEpi ep = {};
+    hipLaunchKernelGGL(k_gemm32_nn_skinny<0>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32)), dim3(128), 0, st, g, ep);
     return hipGetLastError();
   }
   return run32<false, true>(A, lda, B, ldb, C, ldc, M, N, K, beta, nullptr, 0, st);
+}
+
+// C-less products of a GRU cell's backward (M <= 64 rows): mode 1: [M][K] = dac[M][H] . wc[H][K] with k_gru_bwd_b's arithmetic as the epilogue (ep.dcat_c
+// receives the input half); mode 2: [M][K] = dag[M][2H] . wg[2H][K] with k_gru_bwd_c's.
+hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, const GruBwdEpi& ep, hipStream_t st) {
+  if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || M <= 0 || M > 64 || N != ep.in + ep.H) return hipErrorInvalidValue;
+  G32 g;
+  g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = const_cast<float*>(ep.dcat_c); g.ldc = ep.K; g.M = M; g.N = N; g.K = K; g.beta = 0.f;
+  g.k_per_split = K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;
+  const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32));
+  if (mode == 1) hipLaunchKernelGGL(k_gemm32_nn_skinny<1>, grid, dim3(128), 0, st, g, ep);
+  else hipLaunchKernelGGL(k_gemm32_nn_skinny<2>, grid, dim3(128), 0, st, g, ep);
+  return hipGetLastError();
 }
 
 hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int N1, int N2, int Mred, float beta,

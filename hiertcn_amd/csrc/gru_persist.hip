@@ -51,6 +51,7 @@ struct GruPersistArgs {
   const float* wc[HIERTCN_MAX_LAYERS]; const float* bc[HIERTCN_MAX_LAYERS];
   unsigned long long* bar;   // [GP_GROUPS] counters, 128 bytes apart, then the time-out word
   int B, S, H, HT, nl, P;
+  float* save;               // training (optional): per (slot, layer) the record [gates B x 2H | r*h B x H | candidate B x H | output B x H] the BPTT reads
 };
 
 __device__ __forceinline__ f4 ld_sc1(const void* p) {
@@ -213,6 +214,12 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
           const float r = 1.0f / (1.0f + expf(-(ar + a.bg[l][j])));        // customed_gru_cell.py:323-324: r is the first half
           const float z = 1.0f / (1.0f + expf(-(au + a.bg[l][H + j])));
           st_sc1(a.rh + ((size_t)l * B + b) * H + j, r * hj);              // :326
+          if (a.save) {
+            float* rec = a.save + ((size_t)(tau - l) * nl + l) * (size_t)B * 5 * H;
+            rec[(size_t)b * 2 * H + j] = r;
+            rec[(size_t)b * 2 * H + H + j] = z;
+            rec[(size_t)B * 2 * H + (size_t)b * H + j] = r * hj;
+          }
           float* kp = keep + (((size_t)ci * n_lanes + ps * GP_LB + bl) * GP_U + u) * 3;
           kp[0] = z; kp[1] = hj; kp[2] = ac;
         }
@@ -246,6 +253,11 @@ __global__ __launch_bounds__(GP_THREADS) void k_gru_scan_persist(const GruPersis
           const float z = kp[0], hj = kp[1];
           const float c = tanhf(kp[2] + ac + a.bc[l][j]);                       // :333-335
           const float hn = z * hj + (1.0f - z) * c;                             // :336
+          if (a.save) {
+            float* rec = a.save + ((size_t)s * nl + l) * (size_t)B * 5 * H;
+            rec[(size_t)B * 3 * H + (size_t)b * H + j] = c;
+            rec[(size_t)B * 4 * H + (size_t)b * H + j] = hn;
+          }
           if (l + 1 < nl) st_sc1(a.hcur + (((size_t)(s & 1) * nl + l) * B + b) * H + j, hn);   // the next layer's input (not masked)
           st_sc1(a.hist + ((size_t)b * (S + 1) + s + 1) * HT + (size_t)l * H + j, hn * mk);     // model_hier.py:93
           if (s == S - 1) a.state_out[(size_t)b * HT + (size_t)l * H + j] = hn * mk;
@@ -529,18 +541,18 @@ bool gru_persist_shape_ok(const ModelDev& m, int B, int S) {
 int gru_persist_groups(const ModelDev& m, int B, int S, bool saving) {
   const char* off = getenv("HIERTCN_GRU_CHAIN");   // "1": always the GEMM chain (A/B runs, tests; read on every call)
   if (off && off[0] == '1') return 0;
-  if (saving || !gru_persist_shape_ok(m, B, S)) return 0;
+  if ((saving && getenv("HIERTCN_GRU_TRAIN_CHAIN")) || !gru_persist_shape_ok(m, B, S)) return 0;   // (training: the launch also writes the BPTT's records)
   const char* ml = getenv("HIERTCN_GRU_PERSIST_MAX_LANES");
   if (ml && B > atoi(ml)) return 0;
   return m.H / GP_U;
 }
 
 hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
-                                   float* state_out, float* ws, int P, hipStream_t st) {
+                                   float* state_out, float* ws, int P, hipStream_t st, float* save) {
   const int H = m.H, HT = m.HT;
   GruPersistArgs a;
   memset(&a, 0, sizeof(a));
-  a.pooled = pooled; a.mask = mask; a.state_in = state_in; a.state_out = state_out;
+  a.pooled = pooled; a.mask = mask; a.state_in = state_in; a.state_out = state_out; a.save = save;
   a.hist = ws;                                                   // the workspace layout of launch_gru_scan
   float* gates0 = a.hist + (size_t)B * (S + 1) * HT;
   a.rh = gates0 + (size_t)m.nl * B * 2 * H;

@@ -314,7 +314,7 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
   // small batches: the whole scan as one persistent launch (gru_persist.hip); it also fills slot 0 of the history and state_out
   const int persist_groups = gru_persist_groups(m, B, S, save != nullptr);
   if (persist_groups > 0) {
-    if ((e = launch_gru_scan_persist(m, pooled, mask, state_in, B, S, state_out, ws, persist_groups, st)) != hipSuccess) return e;
+    if ((e = launch_gru_scan_persist(m, pooled, mask, state_in, B, S, state_out, ws, persist_groups, st, save)) != hipSuccess) return e;
   } else if ((e = copy_rows(state_in, HT, hist, hs, B, HT, st)) != hipSuccess) return e;
   // Wavefront over (slot, layer): cell (s, l) needs (s, l-1) and (s-1, l) only, so the cells with s + l = tau are independent -- layer 1
   // of slot s runs beside layer 0 of slot s + 1.  The critical path is S + nl - 1 cells instead of S * nl, and the independent cells of

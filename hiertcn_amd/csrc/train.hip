@@ -1076,6 +1076,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   const int64_t hs = (int64_t)(S + 1) * HT;
   const size_t cell = (size_t)B * 5 * H;
   const unsigned gBH = (unsigned)(((int64_t)B * H + 255) / 256);
+  static const bool bptt_unfused = getenv("HIERTCN_GRU_BPTT_UNFUSED") != nullptr;
   for (int s = S - 1; s >= 0; s--) {
     hipLaunchKernelGGL(k_gru_out_grad, dim3((unsigned)(((int64_t)B * HT + 255) / 256)), dim3(256), 0, st, dcar, dsb + (size_t)(s + 1) * HT, hs,
                        mask + s, S, B, HT, dhp);
@@ -1095,14 +1096,25 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       hipLaunchKernelGGL(k_gru_bwd_a, dim3(gBH), dim3(256), 0, st, dhp + (size_t)l * H, HT, (l < m.nl - 1) ? din_up : nullptr, hold, (int)hs,
                          gates, cand, B, H, dac, dag, dhpart);
       T_HIP(hipGetLastError());
+      float* dst_in = (l == 0) ? dpooled + (size_t)s * E : din_up;
+      const int ldi = (l == 0) ? S * E : H;
+      if (B <= 64 && !bptt_unfused) {
+        // a handful of lanes: the elementwise kernel behind each product is its epilogue (gemm.hip, gemm32_nn_gru_bwd): three launches per cell, not five
+        GruBwdEpi ep;
+        memset(&ep, 0, sizeof(ep));
+        ep.in = in; ep.H = H; ep.K = K;
+        ep.gates = gates; ep.h = hold; ep.ldh = (int)hs; ep.dag = dag; ep.dhpart = dhpart; ep.dcat_c = dcat_c;
+        ep.dst_in = dst_in; ep.ldi = ldi; ep.dst_h = dnext + (size_t)l * H; ep.ldo = HT;
+        T_HIP(gemm32_nn_gru_bwd(1, dac, H, m.gru_wc[l], K, B, K, H, ep, st));        // d[in | r*h] = dac . wc, then k_gru_bwd_b's arithmetic
+        T_HIP(gemm32_nn_gru_bwd(2, dag, 2 * H, m.gru_wg[l], K, B, K, 2 * H, ep, st));  // d[in | h] = dag . wg, then k_gru_bwd_c's
+        continue;
+      }
       // d[in | r*h] [B][K] = dac[B][H] . wc[H][K]   == col-major [K x B] = wc(col-major [K x H]) . dac^T[H x B]
       T_HIP(gemm32_nn(dac, H, m.gru_wc[l], K, dcat_c, K, B, K, H, 0.f, st));
       hipLaunchKernelGGL(k_gru_bwd_b, dim3(gBH), dim3(256), 0, st, dcat_c, K, in, hold, (int)hs, gates, B, H, dag, dhpart);
       T_HIP(hipGetLastError());
       // d[in | h] [B][K] = dag[B][2H] . wg[2H][K]
       T_HIP(gemm32_nn(dag, 2 * H, m.gru_wg[l], K, dcat_g, K, B, K, 2 * H, 0.f, st));
-      float* dst_in = (l == 0) ? dpooled + (size_t)s * E : din_up;
-      const int ldi = (l == 0) ? S * E : H;
       const int Wd = in > H ? in : H;
       hipLaunchKernelGGL(k_gru_bwd_c, dim3((unsigned)(((int64_t)B * Wd + 255) / 256)), dim3(256), 0, st, dcat_c, dcat_g, K, in, dhpart, B, H, dst_in,
                          ldi, dnext + (size_t)l * H, HT);
