@@ -173,43 +173,48 @@ static hipError_t run32(const float* A, int64_t lda, const float* B, int64_t ldb
 
 // NN for a handful of rows (M <= 64: the d [in | h] = d a . W products of a recurrent cell at the reference's 32 lanes).  The tiled kernel spends such a
 // product on fixed costs -- a 128 x 128 tile for 32 rows, two barriers per 32-deep chunk, 3 workgroups -- 18 us per launch, 81 of them per training step.
-// Here a workgroup (2 waves) owns 32 rows x 64 columns, takes the reduction in 128-deep chunks with every load of a chunk in flight at once, and
-// runs the same fp32 MFMA chain (same k order: bit-identical results).
+// Here a workgroup owns 32 rows x 64 columns and takes the reduction in 128-deep chunks with every load of a chunk in flight at once.
 #define SK_K 128
 #define SK_PA (SK_K + 4)   // pitch of the [32 m][128 k] tile
 #define SK_PB 68           // pitch of the [128 k][64 n] tile: rows 4 apart are 16 banks apart
 // EPI 1 / 2 (round 4): the two products of a GRU cell's backward with the elementwise kernel that followed each folded into the epilogue (GruBwdEpi,
 // gemm.h; train.hip: five launches per cell -> three) -- same accumulation, same formulas, one pass less over [B][K].
+// Round 4: EIGHT waves per workgroup -- wave (k quarter wk, column half wn) runs a quarter of each chunk's MFMA chain (a wave's chain was K / 2 dependent
+// 64-cycle fp32 MFMAs: 8 us at K = 512, on 8 CUs) and the four partial tiles are added in a fixed order through LDS; 512 threads also fetch a chunk in
+// half the round trips.  (The sum over k is split in four: results differ from the tiled kernel's in the last bit.)
+#define SK_THREADS 512
 template <int EPI>
-__global__ __launch_bounds__(128) void k_gemm32_nn_skinny(const G32 g, const GruBwdEpi ep) {
+__global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, const GruBwdEpi ep) {
   __shared__ float As[32 * SK_PA];
-  __shared__ float Bs[SK_K * SK_PB];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float Bs[SK_K * SK_PB];   // (>= 4 x 32 x 64 floats: the partial tiles of the final reduction)
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int wave = wv & 1, wk = wv >> 1;
   const int lr = lane & 31, lh = lane >> 5;
   const int m0 = blockIdx.y * 32, n0 = blockIdx.x * 64;
   f32x16g acc;
 #pragma unroll
   for (int q = 0; q < 16; q++) acc[q] = 0.f;
   for (int kc = 0; kc < g.K; kc += SK_K) {
-    float4 ra[8], rb[16];
+    float4 ra[2], rb[4];
 #pragma unroll
-    for (int p = 0; p < 8; p++) {    // A tile: 32 rows x 32 float4 = 1024 float4 / 128 threads
-      const int idx = p * 128 + tid, m = m0 + (idx >> 5), k = kc + (idx & 31) * 4;
+    for (int p = 0; p < 2; p++) {    // A tile: 32 rows x 32 float4 = 1024 float4 / 512 threads
+      const int idx = p * SK_THREADS + tid, m = m0 + (idx >> 5), k = kc + (idx & 31) * 4;
       ra[p] = (m < g.M && k < g.K) ? *reinterpret_cast<const float4*>(g.A + (int64_t)m * g.lda + k) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 #pragma unroll
-    for (int p = 0; p < 16; p++) {   // B tile: 128 k rows x 16 float4
-      const int idx = p * 128 + tid, k = kc + (idx >> 4), n = n0 + (idx & 15) * 4;
+    for (int p = 0; p < 4; p++) {    // B tile: 128 k rows x 16 float4
+      const int idx = p * SK_THREADS + tid, k = kc + (idx >> 4), n = n0 + (idx & 15) * 4;
       rb[p] = (k < g.K && n < g.N) ? *reinterpret_cast<const float4*>(g.B + (int64_t)k * g.ldb + n) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
     __syncthreads();   // the previous chunk has been consumed
 #pragma unroll
-    for (int p = 0; p < 8; p++) { const int idx = p * 128 + tid; *reinterpret_cast<float4*>(&As[(idx >> 5) * SK_PA + (idx & 31) * 4]) = ra[p]; }
+    for (int p = 0; p < 2; p++) { const int idx = p * SK_THREADS + tid; *reinterpret_cast<float4*>(&As[(idx >> 5) * SK_PA + (idx & 31) * 4]) = ra[p]; }
 #pragma unroll
-    for (int p = 0; p < 16; p++) { const int idx = p * 128 + tid; *reinterpret_cast<float4*>(&Bs[(idx >> 4) * SK_PB + (idx & 15) * 4]) = rb[p]; }
+    for (int p = 0; p < 4; p++) { const int idx = p * SK_THREADS + tid; *reinterpret_cast<float4*>(&Bs[(idx >> 4) * SK_PB + (idx & 15) * 4]) = rb[p]; }
     __syncthreads();
-#pragma unroll 4
-    for (int s = 0; s < SK_K / 8; s++) {   // the tiled kernel's step: k = 8 s + 4 lh + c for MFMA c
+#pragma unroll
+    for (int s4 = 0; s4 < SK_K / 32; s4++) {   // this wave's quarter of the chunk: k = 32 wk + 8 s4 + 4 lh + c for MFMA c
+      const int s = wk * (SK_K / 32) + s4;
       const float4 a = *reinterpret_cast<const float4*>(&As[lr * SK_PA + 8 * s + 4 * lh]);
       const float* q = &Bs[(8 * s + 4 * lh) * SK_PB + 32 * wave + lr];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.x, q[0], acc, 0, 0, 0);
@@ -217,6 +222,22 @@ __global__ __launch_bounds__(128) void k_gemm32_nn_skinny(const G32 g, const Gru
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.z, q[2 * SK_PB], acc, 0, 0, 0);
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a.w, q[3 * SK_PB], acc, 0, 0, 0);
     }
+  }
+  // the four k quarters of a column half: partial tiles through LDS, added as ((0 + 1) + 2) + 3 by the wk = 0 waves
+  __syncthreads();
+  float* red = Bs;
+  if (wk > 0) {
+#pragma unroll
+    for (int q = 0; q < 16; q++) red[((wk - 1) * 16 + q) * 128 + wave * 64 + lane] = acc[q];
+  }
+  __syncthreads();
+  if (wk > 0) return;
+#pragma unroll
+  for (int q = 0; q < 16; q++) {
+    float v = acc[q];
+#pragma unroll
+    for (int k = 0; k < 3; k++) v += red[(k * 16 + q) * 128 + wave * 64 + lane];
+    acc[q] = v;
   }
   const int n = n0 + 32 * wave + lr;
   if (n >= g.N) return;
@@ -280,7 +301,7 @@ hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, f
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.beta = beta;
     g.k_per_split = K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;
     const GruBwdEpi ep = {};
-    hipLaunchKernelGGL(k_gemm32_nn_skinny<0>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32)), dim3(128), 0, st, g, ep);
+    hipLaunchKernelGGL(k_gemm32_nn_skinny<0>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32)), dim3(SK_THREADS), 0, st, g, ep);
     return hipGetLastError();
   }
   return run32<false, true>(A, lda, B, ldb, C, ldc, M, N, K, beta, nullptr, 0, st);
@@ -294,8 +315,8 @@ hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float*
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = const_cast<float*>(ep.dcat_c); g.ldc = ep.K; g.M = M; g.N = N; g.K = K; g.beta = 0.f;
   g.k_per_split = K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;
   const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32));
-  if (mode == 1) hipLaunchKernelGGL(k_gemm32_nn_skinny<1>, grid, dim3(128), 0, st, g, ep);
-  else hipLaunchKernelGGL(k_gemm32_nn_skinny<2>, grid, dim3(128), 0, st, g, ep);
+  if (mode == 1) hipLaunchKernelGGL(k_gemm32_nn_skinny<1>, grid, dim3(SK_THREADS), 0, st, g, ep);
+  else hipLaunchKernelGGL(k_gemm32_nn_skinny<2>, grid, dim3(SK_THREADS), 0, st, g, ep);
   return hipGetLastError();
 }
 
