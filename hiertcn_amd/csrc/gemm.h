@@ -12,6 +12,11 @@ struct GruBwdEpi {
   float* dag; float* dhpart;                     // mode 1: d gates[:, :H] written, d h (partial) updated; mode 2: dhpart read
   const float* dcat_c;                           // [M][K]: mode 1 writes its input half, mode 2 reads it
   float* dst_in; int ldi; float* dst_h; int ldo; // mode 2: d input, d old state
+  // mode 2, optional (na_dac != null; in == H): the cell BELOW is next in the BPTT and its first elementwise step (k_gru_bwd_a) rides on this epilogue --
+  // its output gradient is (carried + state-projection path) * mask (k_gru_out_grad) + the d input just formed, which is then not stored
+  const float* na_dcar; const float* na_dsb; int64_t na_ld_dsb; const float* na_mask; int na_ldm; int na_ldc;
+  const float* na_gates; const float* na_cand; const float* na_h; int na_ldh;
+  float* na_dac; float* na_dag; float* na_dhpart;
 };
 hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, const GruBwdEpi& ep, hipStream_t st);
 hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st);

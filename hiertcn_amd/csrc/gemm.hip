@@ -274,6 +274,29 @@ __global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, co
       const int m = min(m0 + acc_row(q, lh), g.M - 1);
       o[q] = inp ? ep.dcat_c[(int64_t)m * ep.K + n] : ep.dhpart[(int64_t)m * ep.H + (n - ep.in)];
     }
+    if (inp && ep.na_dac) {   // k_gru_out_grad + k_gru_bwd_a of the cell below (same slot), on the d input this lane holds
+      float dc[16], ds[16], mk[16], u[16], c[16], hv[16];
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = min(m0 + acc_row(q, lh), g.M - 1);
+        dc[q] = ep.na_dcar[(int64_t)m * ep.na_ldc + n];
+        ds[q] = ep.na_dsb[(int64_t)m * ep.na_ld_dsb + n];
+        mk[q] = ep.na_mask[(int64_t)m * ep.na_ldm];
+        u[q] = ep.na_gates[(int64_t)m * 2 * ep.H + ep.H + n];
+        c[q] = ep.na_cand[(int64_t)m * ep.H + n];
+        hv[q] = ep.na_h[(int64_t)m * ep.na_ldh + n];
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        const int m = m0 + acc_row(q, lh);
+        if (m >= g.M) continue;
+        const float d = (dc[q] + ds[q]) * mk[q] + (o[q] + acc[q]);
+        ep.na_dac[(int64_t)m * ep.H + n] = d * (1.f - u[q]) * (1.f - c[q] * c[q]);
+        ep.na_dag[(int64_t)m * 2 * ep.H + ep.H + n] = d * (hv[q] - c[q]) * u[q] * (1.f - u[q]);
+        ep.na_dhpart[(int64_t)m * ep.H + n] = d * u[q];
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < 16; q++) {
       const int m = m0 + acc_row(q, lh);

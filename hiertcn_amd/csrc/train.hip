@@ -399,6 +399,20 @@ __global__ void k_gru_bwd_a(const float* __restrict__ dhp, int ldd, const float*
   dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
   dhpart[i] = d * u;
 }
+// the same with k_gru_out_grad folded in (no layer above: the top layer of a slot): dh' = (carried + state-projection path) * mask
+__global__ void k_gru_bwd_a_top(const float* __restrict__ dcar, int ldc, const float* __restrict__ dsb, int64_t ld_dsb, const float* __restrict__ mask, int ldm,
+                                const float* __restrict__ h, int ldh, const float* __restrict__ gates, const float* __restrict__ cand, int B, int H,
+                                float* __restrict__ dac, float* __restrict__ dag, float* __restrict__ dhpart) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * H) return;
+  const int64_t b = i / H;
+  const int k = (int)(i - b * H);
+  const float d = (dcar[b * ldc + k] + dsb[b * ld_dsb + k]) * mask[b * ldm];
+  const float u = gates[b * 2 * H + H + k], c = cand[i], hv = h[b * ldh + k];
+  dac[i] = d * (1.f - u) * (1.f - c * c);
+  dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  dhpart[i] = d * u;
+}
 // drh = dcat_c[:, in:] (grad of r*h);  dag[:, :H] = drh h r (1-r);  dhpart += drh r
 __global__ void k_gru_bwd_b(const float* __restrict__ dcat_c, int K, int in, const float* __restrict__ h, int ldh,
                             const float* __restrict__ gates, int B, int H, float* __restrict__ dag, float* __restrict__ dhpart) {
@@ -706,7 +720,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.dhp = take((size_t)B * HT * 4);
   // the gate / candidate pre-activation gradients of EVERY (slot, layer) cell of the across-session scan: [nl][S][B][H] and [nl][S][B][2H] -- the
   // weight gradients are formed behind the scan in one product per layer and operand instead of two per cell
-  w.dac = take((size_t)m.nl * S * B * H * 4); w.dag = take((size_t)m.nl * S * B * 2 * H * 4); w.dhpart = take((size_t)B * H * 4);
+  w.dac = take((size_t)m.nl * S * B * H * 4); w.dag = take((size_t)m.nl * S * B * 2 * H * 4); w.dhpart = take((size_t)2 * B * H * 4);   // (two: the fused epilogue of a cell's last product writes the next cell's while this cell's is read)
   const size_t Kmax = (E > H ? E : H) + H;
   w.dcat_c = take((size_t)B * Kmax * 4); w.dcat_g = take((size_t)B * Kmax * 4); w.din_up = take((size_t)B * H * 4);
   if (m.low_gru) {
@@ -1077,10 +1091,13 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   const size_t cell = (size_t)B * 5 * H;
   const unsigned gBH = (unsigned)(((int64_t)B * H + 255) / 256);
   static const bool bptt_unfused = getenv("HIERTCN_GRU_BPTT_UNFUSED") != nullptr;
+  const bool bptt_fused = B <= 64 && !bptt_unfused;
   for (int s = S - 1; s >= 0; s--) {
-    hipLaunchKernelGGL(k_gru_out_grad, dim3((unsigned)(((int64_t)B * HT + 255) / 256)), dim3(256), 0, st, dcar, dsb + (size_t)(s + 1) * HT, hs,
-                       mask + s, S, B, HT, dhp);
-    T_HIP(hipGetLastError());
+    if (!bptt_fused) {
+      hipLaunchKernelGGL(k_gru_out_grad, dim3((unsigned)(((int64_t)B * HT + 255) / 256)), dim3(256), 0, st, dcar, dsb + (size_t)(s + 1) * HT, hs,
+                         mask + s, S, B, HT, dhp);
+      T_HIP(hipGetLastError());
+    }
     for (int l = m.nl - 1; l >= 0; l--) {
       const int in = (l == 0) ? E : H;
       const int K = in + H;
@@ -1093,22 +1110,39 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       (void)rh; (void)inp;
       float* dac = dac_all + ((size_t)l * S + s) * B * H;        // this cell's slots: kept for the weight gradients behind the scan
       float* dag = dag_all + ((size_t)l * S + s) * B * 2 * H;
-      hipLaunchKernelGGL(k_gru_bwd_a, dim3(gBH), dim3(256), 0, st, dhp + (size_t)l * H, HT, (l < m.nl - 1) ? din_up : nullptr, hold, (int)hs,
-                         gates, cand, B, H, dac, dag, dhpart);
-      T_HIP(hipGetLastError());
       float* dst_in = (l == 0) ? dpooled + (size_t)s * E : din_up;
       const int ldi = (l == 0) ? S * E : H;
-      if (B <= 64 && !bptt_unfused) {
-        // a handful of lanes: the elementwise kernel behind each product is its epilogue (gemm.hip, gemm32_nn_gru_bwd): three launches per cell, not five
+      if (bptt_fused) {
+        // a handful of lanes: the elementwise kernel behind each product is its epilogue (gemm.hip, gemm32_nn_gru_bwd), the top layer's first step takes
+        // k_gru_out_grad in, and a lower layer's first step rides on the epilogue of the layer above: 2 nl + 1 launches per slot, not 5 nl + 1
+        float* dhp_cell = dhpart + (size_t)((m.nl - 1 - l) & 1) * B * H;
+        if (l == m.nl - 1) {
+          hipLaunchKernelGGL(k_gru_bwd_a_top, dim3(gBH), dim3(256), 0, st, dcar + (size_t)l * H, HT, dsb + (size_t)(s + 1) * HT + (size_t)l * H, hs, mask + s, S,
+                             hold, (int)hs, gates, cand, B, H, dac, dag, dhp_cell);
+          T_HIP(hipGetLastError());
+        }
         GruBwdEpi ep;
         memset(&ep, 0, sizeof(ep));
         ep.in = in; ep.H = H; ep.K = K;
-        ep.gates = gates; ep.h = hold; ep.ldh = (int)hs; ep.dag = dag; ep.dhpart = dhpart; ep.dcat_c = dcat_c;
+        ep.gates = gates; ep.h = hold; ep.ldh = (int)hs; ep.dag = dag; ep.dhpart = dhp_cell; ep.dcat_c = dcat_c;
         ep.dst_in = dst_in; ep.ldi = ldi; ep.dst_h = dnext + (size_t)l * H; ep.ldo = HT;
         T_HIP(gemm32_nn_gru_bwd(1, dac, H, m.gru_wc[l], K, B, K, H, ep, st));        // d[in | r*h] = dac . wc, then k_gru_bwd_b's arithmetic
+        if (l > 0) {   // the cell below: its k_gru_out_grad + k_gru_bwd_a in this product's epilogue
+          const float* rec2 = gsave + ((size_t)s * m.nl + (l - 1)) * cell;
+          ep.na_dcar = dcar + (size_t)(l - 1) * H; ep.na_ldc = HT;
+          ep.na_dsb = dsb + (size_t)(s + 1) * HT + (size_t)(l - 1) * H; ep.na_ld_dsb = hs;
+          ep.na_mask = mask + s; ep.na_ldm = S;
+          ep.na_gates = rec2; ep.na_cand = rec2 + (size_t)B * 3 * H; ep.na_h = hist + (size_t)s * HT + (size_t)(l - 1) * H; ep.na_ldh = (int)hs;
+          ep.na_dac = dac_all + ((size_t)(l - 1) * S + s) * B * H;
+          ep.na_dag = dag_all + ((size_t)(l - 1) * S + s) * B * 2 * H;
+          ep.na_dhpart = dhpart + (size_t)((m.nl - l) & 1) * B * H;
+        }
         T_HIP(gemm32_nn_gru_bwd(2, dag, 2 * H, m.gru_wg[l], K, B, K, 2 * H, ep, st));  // d[in | h] = dag . wg, then k_gru_bwd_c's
         continue;
       }
+      hipLaunchKernelGGL(k_gru_bwd_a, dim3(gBH), dim3(256), 0, st, dhp + (size_t)l * H, HT, (l < m.nl - 1) ? din_up : nullptr, hold, (int)hs,
+                         gates, cand, B, H, dac, dag, dhpart);
+      T_HIP(hipGetLastError());
       // d[in | r*h] [B][K] = dac[B][H] . wc[H][K]   == col-major [K x B] = wc(col-major [K x H]) . dac^T[H x B]
       T_HIP(gemm32_nn(dac, H, m.gru_wc[l], K, dcat_c, K, B, K, H, 0.f, st));
       hipLaunchKernelGGL(k_gru_bwd_b, dim3(gBH), dim3(256), 0, st, dcat_c, K, in, hold, (int)hs, gates, B, H, dag, dhpart);
