@@ -149,6 +149,7 @@ struct LowGruBufs {
   float* hidden32;    // exact numerics mode (exact.hip): uf is already filled with the fp32 projection and the outputs go here as fp32 rows
   uint16_t* x3;       // scratch of the split-operand cells (gru_x3.hip), low_gru_x3_elems() 16-bit elements; null: the fp32 cells run
   float* persist;     // scratch of the persistent launch (gru_persist.hip), low_gru_persist_floats() floats; null: the launch chain runs
+  void* pipe;         // exchange slots + flags of the layer-pipelined launch (lgru_pipe.hip), lgru_pipe_bytes() bytes; null: lgru_tile.hip runs
 };
 size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess);
 // lgru_tile.hip: the HierGRU low level of small batches, one workgroup per 32 sessions through all steps and layers (no launch chain, no exchange)
@@ -156,6 +157,11 @@ bool lgru_tile_applies(const ModelDev& m, int64_t n_sess);
 hipError_t launch_lgru_tile_bwd(const ModelDev& m, const float* dH, const int32_t* seq_len, const float* states, const float* rec, int64_t n_sess, int L, float* du,
                                 float* dac_all, float* dag_all, hipStream_t st);
 hipError_t launch_frag_major_T(const uint16_t* W, uint16_t* WfT, int N, int K, hipStream_t st);
+// lgru_pipe.hip: the same cells at H <= 128 with one workgroup per (32-session tile, layer), the layer's weights resident in registers
+bool lgru_pipe_applies(const ModelDev& m, int64_t n_sess);
+size_t lgru_pipe_bytes(const ModelDev& m, int64_t n_sess, int L);
+hipError_t launch_lgru_pipe(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
+                            void* scratch, hipStream_t st);
 hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
                             hipStream_t st);
 // gru_persist.hip: the HierGRU low level of small evaluation batches as one persistent launch

@@ -439,7 +439,8 @@ size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
   auto al = [](size_t x) { return (x + 255) & ~(size_t)255; };
   return 2 * al(R * m.E * 2) + al(R * m.E * 4) + al((size_t)n_sess * 4) + 2 * al((size_t)n_sess * m.HT * 4) +
          al((size_t)m.nl * n_sess * 5 * m.H * 4) + al(low_gru_x3_elems(m, n_sess) * 2) +
-         (n_sess <= 1024 ? al(low_gru_persist_floats(m, n_sess, L) * 4) : 0);   // small batches: the persistent launch's history / exchange buffers
+         (n_sess <= 1024 ? al(low_gru_persist_floats(m, n_sess, L) * 4) : 0) +   // small batches: the persistent launch's history / exchange buffers
+         al(lgru_pipe_bytes(m, n_sess, L));                                        // ... and the layer-pipelined launch's exchange slots
 }
 
 // training keeps everything the backward pass needs: L+1 states and one record per (step, layer)
@@ -470,6 +471,8 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
   }
   if (!b.hidden32 && lgru_tile_applies(m, n_sess)) {   // small batches: one workgroup per 32 sessions through every step and layer (lgru_tile.hip); training keeps the records
     if (b.keep_all && (e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // slot 0 of the kept states: the zero state the backward pass reads at t = 0
+    if (b.pipe && lgru_pipe_applies(m, n_sess))   // H <= 128: one workgroup per (tile, layer), weights resident in registers (lgru_pipe.hip)
+      return launch_lgru_pipe(m, b.u16, b.seq_len, n_sess, L, hidden, b.keep_all ? b.states : nullptr, b.keep_all ? b.rec : nullptr, b.pipe, st);
     return launch_lgru_tile(m, b.u16, b.seq_len, n_sess, L, hidden, b.keep_all ? b.states : nullptr, b.keep_all ? b.rec : nullptr, st);
   }
   if (b.persist && !b.keep_all && low_gru_persist_applies(m, n_sess))   // small evaluation batches (fp32 modes): the whole recurrence as ONE launch (gru_persist.hip)
@@ -585,6 +588,7 @@ hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* spro
   b.hidden32 = nullptr;
   b.x3 = reinterpret_cast<uint16_t*>(take(low_gru_x3_elems(m, n_sess) * 2));
   b.persist = n_sess <= 1024 ? reinterpret_cast<float*>(take(low_gru_persist_floats(m, n_sess, L) * 4)) : nullptr;
+  b.pipe = lgru_pipe_bytes(m, n_sess, L) ? take(lgru_pipe_bytes(m, n_sess, L)) : nullptr;
   return launch_low_gru_bufs(m, x, sproj, n_sess, L, hidden, b, st);
 }
 

@@ -617,6 +617,7 @@ struct TrainWs {
   size_t dA, dB, dsf, dcb, dub, gchunk, map, nvalid, cscratch, hc, yc, wc, lc, dsp_ext, dsb_ext, dpooled, dstate[2], dhp, dac, dag, dhpart, dcat_c, dcat_g, din_up;
   size_t total;
   size_t lg_x3;   // split-operand scratch of the HierGRU cells (gru_x3.hip)
+  size_t lg_pipe;   // exchange slots + flags of the layer-pipelined HierGRU forward (lgru_pipe.hip)
   size_t lg_uf, lg_len, lg_save, lg_dcar[2], lg_dac, lg_dag, lg_dhpart, lg_dcat_c, lg_dcat_g, lg_din_up;   // HierGRU low level
   size_t splitk;  // partial outputs of the split-K weight-gradient GEMMs
   size_t splitk_floats;
@@ -728,6 +729,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     w.lg_uf = take(R * E * 4); w.lg_len = take(M * 4);
     w.lg_x3 = take(low_gru_x3_elems(m, (int64_t)M) * 2);
     w.lg_save = take(low_gru_save_floats(m, (int64_t)M, L) * 4);
+    w.lg_pipe = take(lgru_pipe_bytes(m, (int64_t)M, L));
     w.lg_dcar[0] = take(M * HT * 4); w.lg_dcar[1] = take(M * HT * 4);
     const size_t cells = lgru_deferred_wgrad(m, M, L) ? (size_t)m.nl * L : 1;
     w.lg_dac = take(cells * M * H * 4); w.lg_dag = take(cells * M * 2 * H * 4); w.lg_dhpart = take(M * H * 4);
@@ -789,6 +791,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     lb.a_emb = a_emb; lb.u16 = a0; lb.uf = F32(w.lg_uf); lb.seq_len = reinterpret_cast<int32_t*>(ws + w.lg_len);
     lb.states = F32(w.lg_save); lb.n_states = L + 1;
     lb.x3 = BF(w.lg_x3);
+    lb.pipe = lgru_pipe_bytes(m, n_sess, L) ? ws + w.lg_pipe : nullptr;
     lb.rec = lb.states + (size_t)(L + 1) * n_sess * HT; lb.keep_all = 1;
     if (do_begin) T_HIP(launch_low_gru_bufs(m, x, sproj, n_sess, L, BF(w.act[2]), lb, st));
   }
