@@ -20,6 +20,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <type_traits>
+
 #include "common.h"
 
 #define LP_THREADS 256
@@ -205,9 +207,39 @@ __global__ __launch_bounds__(LP_THREADS, 1) void k_lgru_pipe(const LgruPipeArgs 
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) __hip_atomic_store(fout + t, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    // (no wait here: the step's flag is set behind the NEXT cell's mid-cell barrier, in front of which every wave waits for its stores -- by then
+    // they have long completed; waiting here cost the producer ~2 us per cell)
+  };
+  // prefetch of the next step's slot by a consumer (flag already seen): compiler-visible agent-scope loads (8 bytes each: `global_load_dwordx2 sc1`),
+  // in flight during the candidate phase
+  unsigned long long xr[4 * UPT];
+  auto x_prefetch = [&](int t) {
+    const uint16_t* slot = xin + (size_t)t * xslot;
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+      const int c = min(tid + k * LP_THREADS, UCH - 1);
+      const int row = c / (H / 8), ch = c % (H / 8);
+      const int64_t s = (sess0 + row < M) ? sess0 + row : (int64_t)M - 1;
+      const unsigned long long* ph = reinterpret_cast<const unsigned long long*>(slot + (size_t)s * H + ch * 8);
+      const unsigned long long* pl = reinterpret_cast<const unsigned long long*>(slot + (size_t)M * H + (size_t)s * H + ch * 8);
+      xr[4 * k + 0] = __hip_atomic_load(ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xr[4 * k + 1] = __hip_atomic_load(ph + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xr[4 * k + 2] = __hip_atomic_load(pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      xr[4 * k + 3] = __hip_atomic_load(pl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto x_prefetch_store = [&](int buf) {
+#pragma unroll
+    for (int k = 0; k < UPT; k++) {
+      const int c = tid + k * LP_THREADS;
+      if (c < UCH) {
+        const int row = c / (H / 8), ch = c % (H / 8);
+        *reinterpret_cast<unsigned long long*>(XH + (buf * 32 + row) * PITCH + ch * 16) = xr[4 * k + 0];
+        *reinterpret_cast<unsigned long long*>(XH + (buf * 32 + row) * PITCH + ch * 16 + 8) = xr[4 * k + 1];
+        *reinterpret_cast<unsigned long long*>(XL + (buf * 32 + row) * PITCH + ch * 16) = xr[4 * k + 2];
+        *reinterpret_cast<unsigned long long*>(XL + (buf * 32 + row) * PITCH + ch * 16 + 8) = xr[4 * k + 3];
+      }
+    }
   };
 
   __syncthreads();
@@ -220,11 +252,15 @@ __global__ __launch_bounds__(LP_THREADS, 1) void k_lgru_pipe(const LgruPipeArgs 
   }
 
   const size_t cellf = (size_t)M * 5 * H;   // floats per (t, l) record
+  __shared__ int s_next;                    // consumer: the next step's flag as seen at the start of this cell
+  auto run = [&](auto first_c) {            // (the layer's position at compile time: no branches in the unrolled k-loops)
+  constexpr bool FIRST = decltype(first_c)::value;
   for (int t = 0; t < L; t++) {
-    if (first && t + 1 < L) u_fetch(t + 1);          // in flight during the cell
+    if (FIRST && t + 1 < L) u_fetch(t + 1);          // in flight during the cell
+    if (!FIRST && tid == 0) s_next = (t + 1 < L) ? __hip_atomic_load(fin + t + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0;
     const bool active = t < len;
     const unsigned char* Xh = XH + (t & 1) * 32 * PITCH;
-    const unsigned char* Xl = first ? nullptr : XL + (t & 1) * 32 * PITCH;
+    const unsigned char* Xl = FIRST ? nullptr : XL + (t & 1) * 32 * PITCH;
     float* rec = a.rec ? a.rec + ((size_t)t * nl + l) * cellf : nullptr;
     float zreg[16];
     uint4 bqh[2], bql[2];
@@ -241,7 +277,7 @@ __global__ __launch_bounds__(LP_THREADS, 1) void k_lgru_pipe(const LgruPipeArgs 
         if (ks + 1 < KS) b_read((ks + 1) < KSI ? Xh : (h2_), (ks + 1) < KSI ? Xl : (l2_), (ks + 1) % KSI, bqh[(ks + 1) & 1], bql[(ks + 1) & 1]); \
         acc_ = mfma32(Wh[sel_][ks], bqh[ks & 1], acc_);                                                                 \
         acc_ = mfma32(Wl[sel_][ks], bqh[ks & 1], acc_);                                                                 \
-        if (ks >= KSI || !first) acc_ = mfma32(Wh[sel_][ks], bql[ks & 1], acc_);                                        \
+        if (ks >= KSI || !FIRST) acc_ = mfma32(Wh[sel_][ks], bql[ks & 1], acc_);                                        \
         __builtin_amdgcn_sched_barrier(0);                                                                              \
       }                                                                                                                 \
     }
@@ -281,7 +317,14 @@ __global__ __launch_bounds__(LP_THREADS, 1) void k_lgru_pipe(const LgruPipeArgs 
           *reinterpret_cast<float4*>(rec + sess * 2 * H + H + 32 * blk + 8 * q + 4 * lh) = make_float4(zreg[4 * q], zreg[4 * q + 1], zreg[4 * q + 2], zreg[4 * q + 3]);
       }
     }
+    if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of the previous step's slot (issued a gates phase ago) have completed
     __syncthreads();   // r * h of every unit is in LDS
+    if (!last && tid == 0 && t > 0) __hip_atomic_store(fout + t - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bool prefetched = false;
+    if (!FIRST) {
+      prefetched = s_next != 0;   // (uniform: one LDS word, written before the barrier)
+      if (prefetched) x_prefetch(t + 1);
+    }
     if (has_block) {
       // ---------------- candidate (customed_gru_cell.py:333-336): c = tanh([x, r*h] Wc + b); h' = z h + (1 - z) c
       f32x16 acc;
@@ -323,10 +366,18 @@ __global__ __launch_bounds__(LP_THREADS, 1) void k_lgru_pipe(const LgruPipeArgs 
       }
     }
 #undef LP_TILE
-    if (first && t + 1 < L) u_store((t + 1) & 1);   // (the other buffer: nobody reads it during step t)
-    __syncthreads();   // the new state (and, for layer 0, the next step's rows) are in LDS
-    if (!last) x_give(t);                            // -> the layer above (reads S: its next writer is this layer's cell t + 1, behind x_give's barrier and the mid-cell one)
-    if (!first && t + 1 < L) x_take(t + 1, (t + 1) & 1);
+    if (FIRST && t + 1 < L) u_store((t + 1) & 1);   // (the other buffer: nobody reads it during step t)
+    if (!FIRST && prefetched) x_prefetch_store((t + 1) & 1);
+    __syncthreads();   // the new state (and the next step's rows, where they were fetched beside the cell) are in LDS
+    if (!last) x_give(t);                            // -> the layer above: stores only (reads S: its next writer is this layer's cell t + 1, behind the mid-cell barrier)
+    if (!FIRST && !prefetched && t + 1 < L) x_take(t + 1, (t + 1) & 1);   // the producer was not ahead at the start of the cell: wait for it now
+  }
+  };
+  if (first) run(std::true_type{}); else run(std::false_type{});
+  if (!last) {   // the last step's slot
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(fout + L - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
 
