@@ -299,3 +299,47 @@ def test_persistent_low_level_matches_the_launch_chain_and_the_oracle(d, nl, B, 
     assert np.abs(one32 - ref64).max() < 1e-5 and np.abs(chain32 - ref64).max() < 1e-5
     assert np.abs(one32 - chain32).max() < 1e-5
     assert not np.array_equal(one32, chain32)                      # two different kernels did run (fp32 dot products in another summation order)
+
+
+@pytest.mark.parametrize("d,nl,B,S,L", [(64, 2, 13, 3, 9), (128, 1, 7, 3, 20), (128, 2, 32, 10, 20), (128, 2, 41, 5, 11)])
+def test_layer_pipelined_low_level_matches_the_session_tile_kernel(d, nl, B, S, L):
+    """H <= 128: one workgroup per (32-session tile, LAYER) with the layer's weights resident in registers and the layers handing their state
+    rows over through global slots + flags inside ONE launch (csrc/lgru_pipe.hip); HIERTCN_LGRU_PIPE=0 keeps the session-tile kernel (all layers in
+    one workgroup, no hand-off).  Same arithmetic: the rows may differ by a storage-type ulp where the compiler contracted the blend differently
+    (a handful per launch); zeros past sequence_length identical; 30 repeated launches of the pipelined kernel are bitwise identical to the first
+    (a hand-off read too early or torn would show as a difference); the time-out word stays clear."""
+    import os
+    from hiertcn_amd.engine import Engine
+    N = 900
+    args = gru_args(N=N, d=d, H=d, nl=nl, L=L, S=S, B=B)
+    p = make_params(args)
+    rng = np.random.default_rng(7 * d + nl + B)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, d * nl))).astype(np.float32)
+    eng = Engine(args, hier=True)
+    eng.set_weights(p)
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    xs, sp = dev(x.reshape(B * S, L)), sproj.view(B * S, -1)
+
+    def rows():
+        h = eng.tcn_forward(xs, sp)
+        torch.cuda.synchronize()
+        return h.view(torch.int16).cpu().numpy().copy()
+
+    assert os.environ.get("HIERTCN_LGRU_PIPE") is None
+    pipe = rows()
+    for _ in range(30):
+        assert np.array_equal(rows(), pipe)
+    os.environ["HIERTCN_LGRU_PIPE"] = "0"
+    try:
+        tile = rows()
+    finally:
+        os.environ.pop("HIERTCN_LGRU_PIPE")
+    assert not eng.persistent_timed_out()
+    eng.close()
+    assert np.array_equal(pipe == 0, tile == 0)
+    a = torch.from_numpy(pipe).view(torch.bfloat16).float().numpy()
+    b = torch.from_numpy(tile).view(torch.bfloat16).float().numpy()
+    diff = np.abs(a - b)
+    assert (diff > 0).mean() < 2e-3 and diff.max() <= 2.0 ** -8   # |h| < 1: one storage-type ulp at most
