@@ -109,9 +109,17 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_x3(const float* __restr
   static_assert(KT == 0 || MAIN, "lists are built by the production flavour");
   // ragged batches / catalogue parts: as k_score_pipe (score.hip)
   const int64_t Rv = n_rows_dev ? (int64_t)n_rows_dev[0] : R;
-  if ((int64_t)blockIdx.x * 256 >= Rv) return;
+  int bx = (int)blockIdx.x, by = (int)blockIdx.y, part_st = part_stages;
+  if (part_stages < 0) {   // the catalogue split decided here, from the live row count (score_geom.h, as in k_score_pipe)
+    const ScDynSplit d = score_dyn_split(Rv, 256, NP / SC_STAGE, (int)gridDim.x, -part_stages);
+    by = bx / d.tiles;
+    bx -= by * d.tiles;
+    if (by >= d.parts) return;
+    part_st = d.part_stages;
+  }
+  if ((int64_t)bx * 256 >= Rv) return;
   if constexpr (FIXUP) {
-    const int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    const int64_t r = (int64_t)bx * 256 + threadIdx.x;
     int bad = 0;
     if ((int)threadIdx.x < 256 && r < Rv) {
       const int64_t src = row_map ? (int64_t)row_map[r] : r;
@@ -124,7 +132,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_x3(const float* __restr
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
-  const int64_t row0 = ((int64_t)blockIdx.x * 8 + wave) * 32;
+  const int64_t row0 = ((int64_t)bx * 8 + wave) * 32;
 
   // ---- this wave's 32 steps, split, as the two B operands, resident for the whole kernel ------------------------------------------------
   uint4 hhi[KSL], hlo[KSL];
@@ -192,8 +200,8 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_x3(const float* __restr
   }
 
   const int n_all = NP / SC_STAGE;
-  const int stg_lo = partials ? (int)blockIdx.y * part_stages : 0;
-  const int stg_hi0 = partials ? stg_lo + part_stages : n_all;
+  const int stg_lo = partials ? by * part_st : 0;
+  const int stg_hi0 = partials ? stg_lo + part_st : n_all;
   const int n_stages = ((stg_hi0 < n_all) ? stg_hi0 : n_all) - stg_lo;   // stages of THIS workgroup (<= 0 for a tail part)
 
   // ---- item stream: LDS-DMA through inline asm, waits placed by hand (score.hip, cdna_hip_programming.md 5.7) ----------------------------
@@ -451,10 +459,10 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_x3(const float* __restr
   const int cnt = st.c + c_o;
   if (partials) {
     if (lh == 0 && myr < Rv) {
-      float* pp = partials + (int64_t)blockIdx.y * 2 * R;
+      float* pp = partials + (int64_t)by * 2 * R;
       pp[myr] = __int_as_float(cnt);
       pp[R + myr] = (n_stages > 0) ? M2 + log2f(S) : -INFINITY;
-      if (blockIdx.y == 0 && o_tgt) o_tgt[mysrc] = (myy > 0) ? st.t * irs : 0.f;
+      if (by == 0 && o_tgt) o_tgt[mysrc] = (myy > 0) ? st.t * irs : 0.f;
     }
   } else if (lh == 0 && myr < Rv) {
     const bool valid = myy > 0;
@@ -563,7 +571,15 @@ static hipError_t launch_x3_c(const ModelDev& m, const ExactDev& x, const float*
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(fix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X::LDS_BYTES)) != hipSuccess) return e;
   int* walk = KT > 0 ? nullptr : m.walk_pos;   // lists: equal values must arrive in index order (tf.nn.top_k), so the walk starts at item 0
   const int parts = score_split_parts(R, m.NP, 256);
-  if (KT == 0 && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
+  static const bool dyn_off = getenv("HIERTCN_SCORE_DYN_OFF") != nullptr;
+  if (KT == 0 && split_scratch && parts > 1 && (R + 255) / 256 < 128 && !dyn_off && out->rank && out->ce && out->target) {
+    // small batches: SC_DYN_GRID workgroups dealt as (row tile, catalogue part) on the device from the live row count (score_geom.h)
+    const int n_all = m.NP / SC_STAGE;
+    hipLaunchKernelGGL(kern, dim3(SC_DYN_GRID), dim3(SC_THREADS), lds, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target,
+                       row_map, n_rows_dev, -SC_DYN_MAX_PARTS, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
+    if ((e = launch_score_merge(split_scratch, -SC_DYN_MAX_PARTS, R, row_map, n_rows_dev, y, out->target, out->rank, out->ce, st, SC_DYN_GRID, 256, n_all)) != hipSuccess) return e;
+  } else if (KT == 0 && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     // small batches: (row tile, catalogue part) workgroups, partial (count, log2-sum) per part added up by score.hip's merge kernel
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;

@@ -23,7 +23,7 @@ n = int(sys.argv[2]) if len(sys.argv) > 2 else 200
 N, d, S, L = 20778, int(os.environ.get("D", "256")), 10, 20
 args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B,
                      model_low_type=os.environ.get("LOW", "tcn"))
-eng = Engine(args, hier=True)
+eng = Engine(args, hier=True, **({"dtype": os.environ["DTYPE"]} if os.environ.get("DTYPE") else {}))   # DTYPE=split16|fp32: the parity-grade modes
 eng.set_weights(init_params(args, seed=2))
 rng = np.random.default_rng(0)
 batches = []
