@@ -26,6 +26,12 @@ hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, f
 
 //   TN over slabs: reduction row m of A (B) lies at (m / a_div) * a_ss + (m % a_div) * lda when a_div > 0 (else m * lda): ONE product over the rows of
 //   many records that are a fixed distance apart -- the deferred weight gradients of a scan (train.hip)
+// one product of gemm32_tn_slabs_batch: the arguments of gemm32_tn_slabs
+struct Gemm32TnDesc {
+  const float* A; int64_t lda; int a_div; int64_t a_ss; const float* B; int64_t ldb; int b_div; int64_t b_ss; float* C; int64_t ldc; int N1, N2, Mred; float beta;
+};
+bool gemm32_tn_slabs_batch_applies(const Gemm32TnDesc* d, int n);
+hipError_t gemm32_tn_slabs_batch(const Gemm32TnDesc* d, int n, hipStream_t st);
 hipError_t gemm32_tn_slabs(const float* A, int64_t lda, int a_div, int64_t a_ss, const float* B, int64_t ldb, int b_div, int64_t b_ss, float* C,
                            int64_t ldc, int N1, int N2, int Mred, float beta, float* scratch, size_t scratch_floats, hipStream_t st);
 

@@ -15,6 +15,9 @@
 // rows), so no transposed copy of anything is ever made.  The row reduction of the TN forms is cut into `splits` slices over blockIdx.z
 // (a [Cout x Cin] weight gradient is 16 tiles: one slice would leave 240 CUs idle); slices write partial tiles to scratch and a second
 // launch adds them in slice order -- deterministic, no atomics.
+#include <stdlib.h>
+#include <string.h>
+
 #include "common.h"
 #include "gemm.h"
 
@@ -39,14 +42,12 @@ struct G32 {
 
 // AK: A element (i, k) at A[k * lda + i] (k-major rows) instead of A[i * lda + k]; BK likewise: B element (k, j) at B[k * ldb + j]
 template <bool AK, bool BK>
-__global__ __launch_bounds__(256) void k_gemm32(const G32 g) {
-  __shared__ float As[AK ? GK * GP_M : GT * GP_K];
-  __shared__ float Bs[BK ? GK * GP_M : GT * GP_K];
+__device__ __forceinline__ void gemm32_tile(const G32& g, int bx, int by, int bz, float* As, float* Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int m0 = blockIdx.y * GT, n0 = blockIdx.x * GT;
+  const int m0 = by * GT, n0 = bx * GT;
   const int wm = wave >> 1, wn = wave & 1;
-  const int k_lo = blockIdx.z * g.k_per_split;
+  const int k_lo = bz * g.k_per_split;
   const int k_hi = min(g.K, k_lo + g.k_per_split);
   const int n_it = (k_hi - k_lo + GK - 1) / GK;
 
@@ -115,7 +116,7 @@ __global__ __launch_bounds__(256) void k_gemm32(const G32 g) {
 #undef GSTEP
     }
   }
-  float* out = g.parts ? g.parts + (int64_t)blockIdx.z * g.M * g.N : g.C;
+  float* out = g.parts ? g.parts + (int64_t)bz * g.M * g.N : g.C;
   const int64_t ldo = g.parts ? g.N : g.ldc;
   const float beta = g.parts ? 0.f : g.beta;
 #pragma unroll
@@ -133,6 +134,32 @@ __global__ __launch_bounds__(256) void k_gemm32(const G32 g) {
         out[(int64_t)m * ldo + n] = v;
       }
   }
+}
+
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void k_gemm32(const G32 g) {
+  __shared__ float As[AK ? GK * GP_M : GT * GP_K];
+  __shared__ float Bs[BK ? GK * GP_M : GT * GP_K];
+  gemm32_tile<AK, BK>(g, (int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z, As, Bs);
+}
+// several independent products of one form in ONE launch (round 4: the eight weight-gradient products behind a scan at the reference's batch are 4-16
+// tiles each with a reduction of ten dependent chunks -- 33 us apiece as launches of their own, about as long all together)
+#define G32_GROUP_MAX 8
+struct G32Group { G32 g[G32_GROUP_MAX]; int tile_off[G32_GROUP_MAX + 1]; int n; };
+template <bool AK, bool BK>
+__global__ __launch_bounds__(256) void k_gemm32_group(const G32Group grp) {
+  __shared__ float As[AK ? GK * GP_M : GT * GP_K];
+  __shared__ float Bs[BK ? GK * GP_M : GT * GP_K];
+  int gi = 0;
+#pragma unroll
+  for (int i = 1; i < G32_GROUP_MAX; i++) gi += (i < grp.n && (int)blockIdx.x >= grp.tile_off[i]) ? 1 : 0;
+  // (copy out of the kernel argument with a uniform index: one product's descriptor)
+  G32 g = grp.g[0];
+#pragma unroll
+  for (int i = 1; i < G32_GROUP_MAX; i++) if (gi == i) g = grp.g[i];
+  const int local = (int)blockIdx.x - grp.tile_off[gi];
+  const int tn = (g.N + GT - 1) / GT;
+  gemm32_tile<AK, BK>(g, local % tn, local / tn, 0, As, Bs);
 }
 
 __global__ void k_gemm_sum_parts(const float* __restrict__ parts, int P, int M, int N, float* __restrict__ C, int64_t ldc, float beta) {
@@ -347,6 +374,35 @@ hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, f
                      float* scratch, size_t scratch_floats, hipStream_t st) {
   if ((N1 & 3) || (N2 & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along the output dimensions
   return run32<true, true>(A, lda, B, ldb, C, ldc, N1, N2, Mred, beta, scratch, scratch_floats, st);
+}
+
+// n <= 8 products C_i[N1_i][N2_i] (+)= A_i^T . B_i of the TN-with-slabs form in one launch; false where the batch form does not apply (a product that
+// would be split over its reduction: the caller then issues them one by one)
+bool gemm32_tn_slabs_batch_applies(const Gemm32TnDesc* d, int n) {
+  if (n < 2 || n > G32_GROUP_MAX || getenv("HIERTCN_GEMM_NO_BATCH")) return false;
+  for (int i = 0; i < n; i++) {
+    if ((d[i].N1 & 3) || (d[i].N2 & 3) || (d[i].lda & 3) || (d[i].ldb & 3) || (d[i].a_ss & 3) || (d[i].b_ss & 3) || d[i].a_div < 0 || d[i].b_div < 0) return false;
+    if (d[i].Mred >= 512 || d[i].N1 <= 0 || d[i].N2 <= 0) return false;   // (pick_splits: a slice keeps >= 256 rows, so below 512 nothing is split)
+  }
+  return true;
+}
+hipError_t gemm32_tn_slabs_batch(const Gemm32TnDesc* d, int n, hipStream_t st) {
+  G32Group grp;
+  memset(&grp, 0, sizeof(grp));
+  grp.n = n;
+  int tiles = 0;
+  for (int i = 0; i < n; i++) {
+    G32& g = grp.g[i];
+    g.A = d[i].A; g.lda = d[i].lda; g.B = d[i].B; g.ldb = d[i].ldb; g.C = d[i].C; g.ldc = d[i].ldc; g.M = d[i].N1; g.N = d[i].N2; g.K = d[i].Mred; g.beta = d[i].beta;
+    g.k_per_split = ((d[i].Mred + GK - 1) / GK) * GK;
+    g.parts = nullptr;
+    g.a_div = d[i].a_div; g.a_ss = d[i].a_ss; g.b_div = d[i].b_div; g.b_ss = d[i].b_ss;
+    grp.tile_off[i] = tiles;
+    tiles += ((d[i].N1 + GT - 1) / GT) * ((d[i].N2 + GT - 1) / GT);
+  }
+  for (int i = n; i <= G32_GROUP_MAX; i++) grp.tile_off[i] = tiles;
+  hipLaunchKernelGGL((k_gemm32_group<true, true>), dim3((unsigned)tiles), dim3(256), 0, st, grp);
+  return hipGetLastError();
 }
 
 hipError_t gemm32_tn_slabs(const float* A, int64_t lda, int a_div, int64_t a_ss, const float* B, int64_t ldb, int b_div, int64_t b_ss, float* C,

@@ -1163,22 +1163,37 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // product per layer and operand over S * B rows instead of one per cell over B (at the reference's 32 lanes a cell's product is 8 workgroups of 20
   // chunks: 161 launches of 14 us were a third of the training step).  The operands stay where the forward left them: row (s, b) of `in` / r*h / h is
   // addressed as slab s (the slot's record, the slot's column of `pooled` / `hist`) + lane b (gemm32_tn_slabs).
-  for (int l = 0; l < m.nl; l++) {
-    const int in = (l == 0) ? E : H;
-    const int K = in + H;
-    const float* dac = dac_all + (size_t)l * S * B * H;
-    const float* dag = dag_all + (size_t)l * S * B * 2 * H;
-    const float* inp = (l == 0) ? pooled : gsave + (size_t)(l - 1) * cell + (size_t)B * 4 * H;
-    const int64_t in_ld = (l == 0) ? (int64_t)S * E : H, in_ss = (l == 0) ? (int64_t)E : (int64_t)m.nl * cell;
-    const float* rh = gsave + (size_t)l * cell + (size_t)B * 2 * H;
-    const float* hold = hist + (size_t)l * H;
-    const int SB = S * B;
-    T_HIP(gemm32_tn_slabs(dac, H, 0, 0, inp, in_ld, B, in_ss, G + t.wc[l].off, K, H, in, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
-    T_HIP(gemm32_tn_slabs(dac, H, 0, 0, rh, H, B, (int64_t)m.nl * cell, G + t.wc[l].off + in, K, H, H, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
-    T_HIP(colsum_f32(dac, SB, H, H, G + t.bc[l].off, st));
-    T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, inp, in_ld, B, in_ss, G + t.wg[l].off, K, 2 * H, in, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
-    T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, hold, hs, B, (int64_t)HT, G + t.wg[l].off + in, K, 2 * H, H, SB, 1.f, F32(w.splitk), w.splitk_floats, st));
-    T_HIP(colsum_f32(dag, SB, 2 * H, 2 * H, G + t.bg[l].off, st));
+  {
+    // (small batches: the 4 nl products are 4-16 output tiles each behind a reduction of S B = 320 rows -- one grouped launch instead of 4 nl)
+    Gemm32TnDesc wd[4 * HIERTCN_MAX_LAYERS];
+    int nw = 0;
+    for (int l = 0; l < m.nl; l++) {
+      const int in = (l == 0) ? E : H;
+      const int K = in + H;
+      const float* dac = dac_all + (size_t)l * S * B * H;
+      const float* dag = dag_all + (size_t)l * S * B * 2 * H;
+      const float* inp = (l == 0) ? pooled : gsave + (size_t)(l - 1) * cell + (size_t)B * 4 * H;
+      const int64_t in_ld = (l == 0) ? (int64_t)S * E : H, in_ss = (l == 0) ? (int64_t)E : (int64_t)m.nl * cell;
+      const float* rh = gsave + (size_t)l * cell + (size_t)B * 2 * H;
+      const float* hold = hist + (size_t)l * H;
+      const int SB = S * B;
+      wd[nw++] = Gemm32TnDesc{dac, H, 0, 0, inp, in_ld, B, in_ss, G + t.wc[l].off, K, H, in, SB, 1.f};
+      wd[nw++] = Gemm32TnDesc{dac, H, 0, 0, rh, H, B, (int64_t)((size_t)m.nl * cell), G + t.wc[l].off + in, K, H, H, SB, 1.f};
+      wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, inp, in_ld, B, in_ss, G + t.wg[l].off, K, 2 * H, in, SB, 1.f};
+      wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, hold, hs, B, (int64_t)HT, G + t.wg[l].off + in, K, 2 * H, H, SB, 1.f};
+      T_HIP(colsum_f32(dac, SB, H, H, G + t.bc[l].off, st));
+      T_HIP(colsum_f32(dag, SB, 2 * H, 2 * H, G + t.bg[l].off, st));
+    }
+    for (int i0 = 0; i0 < nw; i0 += 8) {
+      const int n = nw - i0 < 8 ? nw - i0 : 8;
+      if (gemm32_tn_slabs_batch_applies(wd + i0, n)) {
+        T_HIP(gemm32_tn_slabs_batch(wd + i0, n, st));
+      } else {
+        for (int i = i0; i < i0 + n; i++)
+          T_HIP(gemm32_tn_slabs(wd[i].A, wd[i].lda, wd[i].a_div, wd[i].a_ss, wd[i].B, wd[i].ldb, wd[i].b_div, wd[i].b_ss, wd[i].C, wd[i].ldc, wd[i].N1, wd[i].N2,
+                                wd[i].Mred, wd[i].beta, F32(w.splitk), w.splitk_floats, st));
+      }
+    }
   }
   // ================= session mean-pool + 'emb' bias (model_hier.py:83-85) ================================
   T_HIP(colsum_f32(dpooled, n_sess, E, E, G + t.emb_bias.off, st));
