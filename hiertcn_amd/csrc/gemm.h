@@ -31,7 +31,7 @@ struct Gemm32TnDesc {
   const float* A; int64_t lda; int a_div; int64_t a_ss; const float* B; int64_t ldb; int b_div; int64_t b_ss; float* C; int64_t ldc; int N1, N2, Mred; float beta;
 };
 bool gemm32_tn_slabs_batch_applies(const Gemm32TnDesc* d, int n);
-hipError_t gemm32_tn_slabs_batch(const Gemm32TnDesc* d, int n, hipStream_t st);
+hipError_t gemm32_tn_slabs_batch(const Gemm32TnDesc* d, int n, float* scratch, size_t scratch_floats, hipStream_t st);
 hipError_t gemm32_tn_slabs(const float* A, int64_t lda, int a_div, int64_t a_ss, const float* B, int64_t ldb, int b_div, int64_t b_ss, float* C,
                            int64_t ldc, int N1, int N2, int Mred, float beta, float* scratch, size_t scratch_floats, hipStream_t st);
 

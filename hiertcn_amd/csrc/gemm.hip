@@ -159,7 +159,27 @@ __global__ __launch_bounds__(256) void k_gemm32_group(const G32Group grp) {
   for (int i = 1; i < G32_GROUP_MAX; i++) if (gi == i) g = grp.g[i];
   const int local = (int)blockIdx.x - grp.tile_off[gi];
   const int tn = (g.N + GT - 1) / GT;
-  gemm32_tile<AK, BK>(g, local % tn, local / tn, 0, As, Bs);
+  gemm32_tile<AK, BK>(g, local % tn, local / tn, (int)blockIdx.y, As, Bs);   // blockIdx.y: the slice of the reduction (g.parts set: partial tiles)
+}
+// C_i = beta_i C_i + sum of the P partial tiles of every product of a group (elements of all products in one index space)
+__global__ void k_gemm_sum_parts_group(const G32Group grp, int P) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int64_t base = 0;
+#pragma unroll
+  for (int k = 0; k < G32_GROUP_MAX; k++) {
+    if (k >= grp.n) break;
+    const G32& g = grp.g[k];
+    const int64_t mn = (int64_t)g.M * g.N;
+    if (i >= base && i < base + mn) {
+      const int64_t e = i - base;
+      const int m = (int)(e / g.N), n = (int)(e - (int64_t)m * g.N);
+      float sum = 0.f;
+      for (int p = 0; p < P; p++) sum += g.parts[(int64_t)p * mn + e];
+      float* c = g.C + (int64_t)m * g.ldc + n;
+      *c = g.beta != 0.f ? g.beta * *c + sum : sum;
+    }
+    base += mn;
+  }
 }
 
 __global__ void k_gemm_sum_parts(const float* __restrict__ parts, int P, int M, int N, float* __restrict__ C, int64_t ldc, float beta) {
@@ -376,32 +396,46 @@ hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, f
   return run32<true, true>(A, lda, B, ldb, C, ldc, N1, N2, Mred, beta, scratch, scratch_floats, st);
 }
 
-// n <= 8 products C_i[N1_i][N2_i] (+)= A_i^T . B_i of the TN-with-slabs form in one launch; false where the batch form does not apply (a product that
-// would be split over its reduction: the caller then issues them one by one)
+// n <= 8 products C_i[N1_i][N2_i] (+)= A_i^T . B_i of the TN-with-slabs form in one launch (reductions of >= 512 rows: sliced over blockIdx.y like a single
+// product's, partial tiles in `scratch`, one grouped sum behind them); false where the batch form does not apply: the caller then issues them one by one
 bool gemm32_tn_slabs_batch_applies(const Gemm32TnDesc* d, int n) {
   if (n < 2 || n > G32_GROUP_MAX || getenv("HIERTCN_GEMM_NO_BATCH")) return false;
   for (int i = 0; i < n; i++) {
     if ((d[i].N1 & 3) || (d[i].N2 & 3) || (d[i].lda & 3) || (d[i].ldb & 3) || (d[i].a_ss & 3) || (d[i].b_ss & 3) || d[i].a_div < 0 || d[i].b_div < 0) return false;
-    if (d[i].Mred >= 512 || d[i].N1 <= 0 || d[i].N2 <= 0) return false;   // (pick_splits: a slice keeps >= 256 rows, so below 512 nothing is split)
+    if (d[i].N1 <= 0 || d[i].N2 <= 0 || d[i].Mred != d[0].Mred) return false;   // (one slicing for the whole group)
   }
   return true;
 }
-hipError_t gemm32_tn_slabs_batch(const Gemm32TnDesc* d, int n, hipStream_t st) {
+hipError_t gemm32_tn_slabs_batch(const Gemm32TnDesc* d, int n, float* scratch, size_t scratch_floats, hipStream_t st) {
   G32Group grp;
   memset(&grp, 0, sizeof(grp));
   grp.n = n;
   int tiles = 0;
+  int64_t mn_all = 0;
+  for (int i = 0; i < n; i++) {
+    tiles += ((d[i].N1 + GT - 1) / GT) * ((d[i].N2 + GT - 1) / GT);
+    mn_all += (int64_t)d[i].N1 * d[i].N2;
+  }
+  const int K = d[0].Mred;
+  int splits = 1;   // pick_splits' rule over the group's tiles
+  while (scratch && tiles * splits < 384 && K / (2 * splits) >= 256 && (size_t)(2 * splits) * (size_t)mn_all <= scratch_floats && splits < 64) splits *= 2;
+  tiles = 0;
+  int64_t off = 0;
   for (int i = 0; i < n; i++) {
     G32& g = grp.g[i];
     g.A = d[i].A; g.lda = d[i].lda; g.B = d[i].B; g.ldb = d[i].ldb; g.C = d[i].C; g.ldc = d[i].ldc; g.M = d[i].N1; g.N = d[i].N2; g.K = d[i].Mred; g.beta = d[i].beta;
-    g.k_per_split = ((d[i].Mred + GK - 1) / GK) * GK;
-    g.parts = nullptr;
+    g.k_per_split = (((K + splits - 1) / splits) + GK - 1) / GK * GK;
+    g.parts = splits > 1 ? scratch + off : nullptr;
+    off += (int64_t)splits * d[i].N1 * d[i].N2;
     g.a_div = d[i].a_div; g.a_ss = d[i].a_ss; g.b_div = d[i].b_div; g.b_ss = d[i].b_ss;
     grp.tile_off[i] = tiles;
     tiles += ((d[i].N1 + GT - 1) / GT) * ((d[i].N2 + GT - 1) / GT);
   }
   for (int i = n; i <= G32_GROUP_MAX; i++) grp.tile_off[i] = tiles;
-  hipLaunchKernelGGL((k_gemm32_group<true, true>), dim3((unsigned)tiles), dim3(256), 0, st, grp);
+  hipLaunchKernelGGL((k_gemm32_group<true, true>), dim3((unsigned)tiles, (unsigned)splits), dim3(256), 0, st, grp);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess || splits == 1) return e;
+  hipLaunchKernelGGL(k_gemm_sum_parts_group, dim3((unsigned)((mn_all + 255) / 256)), dim3(256), 0, st, grp, splits);
   return hipGetLastError();
 }
 

@@ -712,6 +712,8 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   {  // partial tiles of the row-sliced weight-gradient GEMMs (gemm.hip): up to 64 slices of the largest [out x in] gradient
     const size_t gw = (size_t)2 * H * (size_t)(E > H ? E : H), cw = (size_t)C * C;
     w.splitk_floats = (size_t)64 * (gw > cw ? gw : cw);
+    // (the grouped launch of a level's 4 nl weight-gradient products slices all of them at once: four times the room where that stays under 256 MB)
+    if (w.splitk_floats * 4 <= ((size_t)64 << 20)) w.splitk_floats *= 4;
     w.splitk = take(w.splitk_floats * 4);
   }
   w.dsp_ext = take((size_t)B * (S + 1) * E * 4);
@@ -992,22 +994,34 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       float* tmp = lcar; lcar = lnext; lnext = tmp;
     }
     if (deferred) {   // the weight gradients of all L * nl cells: one product per layer and operand over the L * M rows (rows (t, m): slab t, session m)
+      Gemm32TnDesc wd[4 * HIERTCN_MAX_LAYERS];
+      int nw = 0;
       for (int l = 0; l < m.nl; l++) {
         const int in = (l == 0) ? E : H;
         const int K = in + H;
         const float* dac = dac_all + (size_t)l * L * M * H;
         const float* dag = dag_all + (size_t)l * L * M * 2 * H;
         const float* inp = (l == 0) ? lb.uf : lrec + (size_t)(l - 1) * lcell + (size_t)M * 4 * H;
-        const int64_t in_ld = (l == 0) ? (int64_t)L * E : H, in_ss = (l == 0) ? (int64_t)E : (int64_t)m.nl * lcell;
+        const int64_t in_ld = (l == 0) ? (int64_t)L * E : H, in_ss = (l == 0) ? (int64_t)E : (int64_t)((size_t)m.nl * lcell);
         const float* rh = lrec + (size_t)l * lcell + (size_t)M * 2 * H;
         const float* hold = lst + (size_t)l * H;   // states 0 .. L-1 are contiguous rows (t, m) of HT floats
         const int LM = L * M;
-        T_HIP(gemm32_tn_slabs(dac, H, 0, 0, inp, in_ld, M, in_ss, G + t.lwc[l].off, K, H, in, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
-        T_HIP(gemm32_tn_slabs(dac, H, 0, 0, rh, H, M, (int64_t)m.nl * lcell, G + t.lwc[l].off + in, K, H, H, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
+        wd[nw++] = Gemm32TnDesc{dac, H, 0, 0, inp, in_ld, M, in_ss, G + t.lwc[l].off, K, H, in, LM, 1.f};
+        wd[nw++] = Gemm32TnDesc{dac, H, 0, 0, rh, H, M, (int64_t)((size_t)m.nl * lcell), G + t.lwc[l].off + in, K, H, H, LM, 1.f};
+        wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, inp, in_ld, M, in_ss, G + t.lwg[l].off, K, 2 * H, in, LM, 1.f};
+        wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, hold, HT, 0, 0, G + t.lwg[l].off + in, K, 2 * H, H, LM, 1.f};
         T_HIP(colsum_f32(dac, LM, H, H, G + t.lbc[l].off, st));
-        T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, inp, in_ld, M, in_ss, G + t.lwg[l].off, K, 2 * H, in, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
-        T_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, hold, HT, 0, 0, G + t.lwg[l].off + in, K, 2 * H, H, LM, 1.f, F32(w.splitk), w.splitk_floats, st));
         T_HIP(colsum_f32(dag, LM, 2 * H, 2 * H, G + t.lbg[l].off, st));
+      }
+      for (int i0 = 0; i0 < nw; i0 += 8) {   // (one grouped launch + one grouped sum for the 4 nl products instead of 4 nl of each)
+        const int n = nw - i0 < 8 ? nw - i0 : 8;
+        if (gemm32_tn_slabs_batch_applies(wd + i0, n)) {
+          T_HIP(gemm32_tn_slabs_batch(wd + i0, n, F32(w.splitk), w.splitk_floats, st));
+        } else {
+          for (int i = i0; i < i0 + n; i++)
+            T_HIP(gemm32_tn_slabs(wd[i].A, wd[i].lda, wd[i].a_div, wd[i].a_ss, wd[i].B, wd[i].ldb, wd[i].b_div, wd[i].b_ss, wd[i].C, wd[i].ldc, wd[i].N1, wd[i].N2,
+                                  wd[i].Mred, wd[i].beta, F32(w.splitk), w.splitk_floats, st));
+        }
       }
     }
     da = du;
@@ -1187,7 +1201,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     for (int i0 = 0; i0 < nw; i0 += 8) {
       const int n = nw - i0 < 8 ? nw - i0 : 8;
       if (gemm32_tn_slabs_batch_applies(wd + i0, n)) {
-        T_HIP(gemm32_tn_slabs_batch(wd + i0, n, st));
+        T_HIP(gemm32_tn_slabs_batch(wd + i0, n, F32(w.splitk), w.splitk_floats, st));
       } else {
         for (int i = i0; i < i0 + n; i++)
           T_HIP(gemm32_tn_slabs(wd[i].A, wd[i].lda, wd[i].a_div, wd[i].a_ss, wd[i].B, wd[i].ldb, wd[i].b_div, wd[i].b_ss, wd[i].C, wd[i].ldc, wd[i].N1, wd[i].N2,

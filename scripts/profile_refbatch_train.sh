@@ -1,9 +1,9 @@
-# Kernel trace of training + evaluation at the reference's batch (32 x 10 x 20, N = 20,778): 31 training steps + 30 evaluation batches.
+# Kernel trace of training + evaluation at the reference's batch (32 lanes x 10 slots x 20 steps, N = 20,778): 31 training steps + 30 evaluation batches.
 # usage (on the GPU box): LOW=tcn|gru D=256 bash scripts/profile_refbatch_train.sh   -> gpurun_out/prof_refbatch/${LOW}_d${D}_kernel_stats.csv + _summary.txt
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
 OUT=gpurun_out/prof_refbatch
 mkdir -p $OUT
-export LOW=${LOW:-tcn} D=${D:-256} N=20778 EVAL=1
+export LOW=${LOW:-tcn} D=${D:-256} N=20778 EVAL=1 S=10 L=20
 T=${LOW}_d${D}
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace_$T -- python3 scripts/train_bench.py 32 30 ragged > $OUT/$T.log 2>&1
 grep "step" $OUT/$T.log | cut -c1-120

@@ -11,7 +11,8 @@ from hiertcn_amd.params import init_params
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 ragged = len(sys.argv) > 3 and sys.argv[3] == "ragged"
-N, d, S, L = int(os.environ.get("N", bench.N_ITEMS)), int(os.environ.get("D", bench.DIM)), bench.S_SESS, bench.L_STEPS   # (D=512 N=1000000: cfg-4's width)
+N, d = int(os.environ.get("N", bench.N_ITEMS)), int(os.environ.get("D", bench.DIM))   # (D=512 N=1000000: cfg-4's width)
+S, L = int(os.environ.get("S", bench.S_SESS)), int(os.environ.get("L", bench.L_STEPS))   # (S=10 L=20: the reference's own max_session_num / max_activity_len)
 args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L,
                      max_session_num=S, batch_size=B)
 args.model_low_type = os.environ.get("LOW", "tcn")
@@ -19,6 +20,7 @@ eng = Engine(args, hier=True, train=True)
 eng.set_weights(init_params(args, seed=2))
 draw = bench.zipf_sampler(N)
 x, y, mask = bench.make_users(draw, 0, B, ragged)
+x, y, mask = np.ascontiguousarray(x[:, :S, :L]), np.ascontiguousarray(y[:, :S, :L]), np.ascontiguousarray(mask[:, :S])
 x, y = np.minimum(x, N - 1), np.minimum(y, N - 1)
 xd, yd, md = (torch.from_numpy(v).cuda() for v in (x, y, mask))
 st0 = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")
