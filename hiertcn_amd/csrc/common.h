@@ -106,6 +106,10 @@ hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t 
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
 size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 int gru_persist_groups(const ModelDev& m, int B, int S, bool saving);
+// the scan's backward (train.hip) as one persistent launch: da_c / [da_r | da_z] of every (slot, layer) into dac_all / dag_all, d pooled
+bool gru_bptt_persist_applies(const ModelDev& m, int B, int S);
+hipError_t launch_gru_bptt_persist(const ModelDev& m, const float* save, const float* hist, const float* mask, const float* dsb, int B, int S, float* dac_all,
+                                   float* dag_all, float* dpooled, hipStream_t st);
 hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const float* mask, const float* state_in, int B, int S,
                                    float* state_out, float* ws, int G, hipStream_t st, float* save = nullptr);
 size_t gru_save_floats(const ModelDev& m, int B, int S);

@@ -527,7 +527,239 @@ size_t persist_lds_bytes(int H, int nl, int B) {
   return (size_t)nl * 3 * GP_U * (2 * Q * GP_KS + 8) * 16 + (size_t)nl * n_pass * GP_LB * 2 * H * 4 + (size_t)nl * n_pass * GP_LB * GP_U * 3 * 4;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward through the across-session scan (customed_gru_cell.py:323-337 / model_hier.py:91-93 differentiated by model.py:139-141) of small
+// batches as ONE persistent launch (round 4) -- the mirror image of k_gru_scan_persist.  train.hip's chain is 2 nl + 1 dependent launches per
+// slot (a first elementwise step and two skinny products with fused epilogues per cell): ~50 launches of 5-8 us for ~1 us of work each.
+// Here the same 8 lane groups x P = H / 8 workgroups; workgroup t OWNS, of every layer, units [8 t, 8 t + 8) -- as elements of the cell's
+// output, and as COLUMNS 8 t + u and in + 8 t + u of the two products' outputs
+//     d[in | r*h] = da_c . Wc        (da_c [lanes][H],  Wc [H][K],  K = in + H, in = E = H)
+//     d[in | h]   = [da_r | da_z] . Wg      ([lanes][2H], Wg [2H][K])
+// whose weight columns (Wc[:, col], Wg[:, col]: 48 H floats per layer) it keeps in LDS for all slots.  With that ownership everything
+// elementwise is local -- the gradient of a cell's output (carried + state-projection path, masked, + the layer above's d input), da_c,
+// da_z, the partial d h, d(r*h) -> da_r, d input, the new carried gradient -- and exactly TWO vectors per cell cross workgroups: da_c (all
+// units, before the first product) and [da_r | da_z] (before the second); they go through their slots of dac_all / dag_all, which the
+// weight-gradient products behind the scan read anyway (sc1 stores, one group barrier, sc1 loads: gru_persist's forward protocol).
+// Cells (s, l) with (S - 1 - s) + (nl - 1 - l) = tau are independent: S + nl - 1 diagonals of two phases.
+// fp32 dot products in a fixed order (k slices folded by shuffles): equal to the chain up to summation order.
+struct GruBpttArgs {
+  const float* save;     // forward records, per (s, l): gates [B][2H] | r*h [B][H] | candidate [B][H] | output [B][H]
+  const float* hist;     // [B][S + 1][HT]: the state before slot s (the cell's old state)
+  const float* mask;     // [B][S]
+  const float* dsb;      // [B][S + 1][HT]: d state_before from the state projection; cell s takes slot s + 1
+  const float* wc[HIERTCN_MAX_LAYERS]; const float* wg[HIERTCN_MAX_LAYERS];
+  float* dac_all;        // [nl][S][B][H]
+  float* dag_all;        // [nl][S][B][2H]
+  float* dpooled;        // [B][S][E]: d input of layer 0
+  unsigned long long* bar;
+  int B, S, H, HT, nl, P;
+};
+
+// LDS image of a layer's weight COLUMNS: row (kind, u) with kind 0 / 1 = Wc[:, 8t+u] / Wc[:, in+8t+u] (H floats), 2 / 3 = Wg[:, 8t+u] / Wg[:, in+8t+u]
+// (2H floats); inside a row the 16-byte chunks in the order [i][ks] (thread ks takes reduction indices ks * len/8 + 4 i ..), rows 8 chunks apart
+template <int Q>
+__device__ __forceinline__ int bchunk(int kind, int u, int i, int ks) {
+  // chunks per row: kind < 2: Q * 8, else 2 Q * 8 (+ 8 of padding each)
+  const int base = kind < 2 ? (kind * GP_U + u) * (Q * GP_KS + 8) : 2 * GP_U * (Q * GP_KS + 8) + ((kind - 2) * GP_U + u) * (2 * Q * GP_KS + 8);
+  return base + i * GP_KS + ks;
+}
+
+template <int Q>
+__global__ __launch_bounds__(GP_THREADS) void k_gru_bptt_persist(const GruBpttArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  __shared__ SegDesc segs[HIERTCN_MAX_LAYERS];
+  __shared__ int s_dead;
+  const int tid = threadIdx.x;
+  const int ks = tid & (GP_KS - 1), u = (tid >> 3) & (GP_U - 1), bl = tid >> 6;
+  const int H = a.H, HT = a.HT, nl = a.nl, B = a.B, S = a.S, K = 2 * H;
+  const int grp = (int)blockIdx.x % GP_GROUPS, t = (int)blockIdx.x / GP_GROUPS;
+  const int Bc = (B + GP_GROUPS - 1) / GP_GROUPS;
+  const int b_lo = grp * Bc, b_hi = min(B, b_lo + Bc);
+  if (b_lo >= b_hi) return;   // a group without lanes
+  unsigned long long* bar = a.bar + (size_t)grp * 16;
+  unsigned long long* err = a.bar + (size_t)GP_GROUPS * 16;
+  if (tid == 0) s_dead = 0;
+  const int n_pass = (b_hi - b_lo + GP_LB - 1) / GP_LB, n_lanes = n_pass * GP_LB;
+  const int j = t * GP_U + u;   // this thread's unit
+  constexpr int WL = 2 * GP_U * (Q * GP_KS + 8) + 2 * GP_U * (2 * Q * GP_KS + 8);   // 16-byte chunks per layer
+  f4* wl = reinterpret_cast<f4*>(lds);
+  float* xs = reinterpret_cast<float*>(wl + (size_t)nl * WL);          // [cell][lane][2H]: the staged da_c (H) or [da_r | da_z] (2H) of the diagonal's cells
+  const int lane_floats = 2 * H, cell_floats = n_lanes * lane_floats;
+  float* keep = xs + (size_t)nl * cell_floats;                          // per (cell, lane, unit): d h partial, d input part of the first product
+  float* dcar = keep + (size_t)nl * n_lanes * GP_U * 2;                 // [layer][lane][unit]: carried state gradient (own units)
+  float* dabove = dcar + (size_t)nl * n_lanes * GP_U;                   // [layer][lane][unit]: d input handed down by the layer above (own units)
+  // ---- the weight columns, once: for every reduction row the 8 + 8 floats at columns 8 t .. and in + 8 t .. (32-byte pieces of the rows)
+  for (int l = 0; l < nl; l++) {
+    float* wf = reinterpret_cast<float*>(wl + (size_t)l * WL);
+    for (int c = tid; c < 3 * H * 2; c += GP_THREADS) {   // (row of Wc: H, of Wg: 2H) x (input part, state part)
+      const int row = c >> 1, part = c & 1;
+      const bool isg = row >= H;
+      const int jj = isg ? row - H : row;
+      const float* src = (isg ? a.wg[l] : a.wc[l]) + (size_t)jj * K + part * H + t * GP_U;
+      const f4 v0 = *reinterpret_cast<const f4*>(src), v1 = *reinterpret_cast<const f4*>(src + 4);
+      const int kind = (isg ? 2 : 0) + part, len = isg ? 2 * H : H;
+      const int kk = jj / (len >> 3), r = jj - kk * (len >> 3), i = r >> 2, e = r & 3;   // reduction index jj -> (k slice, chunk, element)
+      const float vv[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+#pragma unroll
+      for (int uu = 0; uu < GP_U; uu++) wf[(size_t)bchunk<Q>(kind, uu, i, kk) * 4 + e] = vv[uu];
+    }
+  }
+  for (int i = tid; i < 2 * nl * n_lanes * GP_U; i += GP_THREADS) dcar[i] = 0.f;   // dcar and dabove (contiguous): no gradient enters behind the last slot / above the top layer
+  __syncthreads();
+
+  const size_t cellf = (size_t)B * 5 * H;
+  const int64_t hs = (int64_t)(S + 1) * HT;
+  for (int tau = 0; tau < S + nl - 1; tau++) {
+    // the cells of this diagonal: layers l_first .. (descending slot): cell ci has layer l = l_first + ci, slot s = S - 1 - (tau - (nl - 1 - l))
+    int l_first = 0, n_cells = 0;
+    for (int l = nl - 1; l >= 0; l--) {
+      const int s = S - 1 - (tau - (nl - 1 - l));
+      if (s >= 0 && s < S) { l_first = l; n_cells++; }
+    }
+    // ---------------- phase A (local): d = (carried + state-projection path) * mask + d input from above;  da_c, da_z, partial d h
+    if (ks == 0) {
+      for (int ci = 0; ci < n_cells; ci++) {
+        const int l = l_first + ci, s = S - 1 - (tau - (nl - 1 - l));
+        const float* rec = a.save + ((size_t)s * nl + l) * cellf;
+        for (int ps = 0; ps < n_pass; ps++) {
+          const int pl = ps * GP_LB + bl, b = b_lo + pl;
+          if (b >= b_hi) continue;
+          const int li = (l * n_lanes + pl) * GP_U + u;
+          const float d = (dcar[li] + a.dsb[(size_t)b * hs + (size_t)(s + 1) * HT + (size_t)l * H + j]) * a.mask[(size_t)b * S + s] + dabove[li];
+          const float uz = rec[(size_t)b * 2 * H + H + j], c = rec[(size_t)B * 3 * H + (size_t)b * H + j];
+          const float hv = a.hist[(size_t)b * hs + (size_t)s * HT + (size_t)l * H + j];
+          const float dac = d * (1.f - uz) * (1.f - c * c);
+          st_sc1(a.dac_all + (((size_t)l * S + s) * B + b) * H + j, dac);
+          st_sc1(a.dag_all + (((size_t)l * S + s) * B + b) * 2 * H + H + j, d * (hv - c) * uz * (1.f - uz));
+          keep[((ci * n_lanes + pl) * GP_U + u) * 2] = d * uz;
+        }
+      }
+    }
+    group_barrier(bar, (unsigned)a.P, err, &s_dead, tau == 0 ? GP_SPIN_FIRST : GP_SPIN_MAX);
+    // ---------------- phase B: stage da_c of every unit, first product (own columns), d(r*h) -> da_r, partial d h; publish da_r
+    if (tid < n_cells) {
+      const int l = l_first + tid, s = S - 1 - (tau - (nl - 1 - l));
+      SegDesc sd;
+      sd.base = a.dac_all + ((size_t)l * S + s) * B * H; sd.lane_floats = (unsigned long long)H; sd.dst = tid * cell_floats;
+      segs[tid] = sd;
+    }
+    __syncthreads();
+    stage_segments(segs, n_cells, n_lanes, H, b_lo, b_hi, xs, lane_floats);
+    __syncthreads();
+    for (int ci = 0; ci < n_cells; ci++) {
+      const int l = l_first + ci, s = S - 1 - (tau - (nl - 1 - l));
+      const f4* w = wl + (size_t)l * WL;
+      const float* rec = a.save + ((size_t)s * nl + l) * cellf;
+      for (int ps = 0; ps < n_pass; ps++) {
+        const int pl = ps * GP_LB + bl, b = b_lo + pl;
+        const f4* xp = reinterpret_cast<const f4*>(xs + (size_t)ci * cell_floats + (size_t)pl * lane_floats);
+        float ai = 0.f, ar = 0.f;
+#pragma unroll
+        for (int i = 0; i < Q; i++) {
+          const f4 xv = xp[ks * Q + i];
+          ai = dot4(xv, w[bchunk<Q>(0, u, i, ks)], ai);
+          ar = dot4(xv, w[bchunk<Q>(1, u, i, ks)], ar);
+        }
+#pragma unroll
+        for (int d = 1; d < GP_KS; d <<= 1) {
+          ai += __shfl_xor(ai, d);
+          ar += __shfl_xor(ar, d);
+        }
+        if (ks == 0 && b < b_hi) {
+          const float r = rec[(size_t)b * 2 * H + j];
+          const float hv = a.hist[(size_t)b * hs + (size_t)s * HT + (size_t)l * H + j];
+          st_sc1(a.dag_all + (((size_t)l * S + s) * B + b) * 2 * H + j, ar * hv * r * (1.f - r));   // da_r = d(r*h) h r (1 - r)
+          float* kp = keep + ((ci * n_lanes + pl) * GP_U + u) * 2;
+          kp[0] += ar * r;     // d h += d(r*h) r
+          kp[1] = ai;          // the candidate's share of d input
+        }
+      }
+    }
+    group_barrier(bar, (unsigned)a.P, err, &s_dead, GP_SPIN_MAX);
+    // ---------------- phase C: stage [da_r | da_z] of every unit, second product (own columns); d input -> the layer below / d pooled; carried gradient
+    if (tid < n_cells) {
+      const int l = l_first + tid, s = S - 1 - (tau - (nl - 1 - l));
+      SegDesc sd;
+      sd.base = a.dag_all + ((size_t)l * S + s) * B * 2 * H; sd.lane_floats = (unsigned long long)2 * H; sd.dst = tid * cell_floats;
+      segs[tid] = sd;
+    }
+    __syncthreads();
+    stage_segments(segs, n_cells, n_lanes, 2 * H, b_lo, b_hi, xs, lane_floats);
+    __syncthreads();
+    for (int ci = 0; ci < n_cells; ci++) {
+      const int l = l_first + ci, s = S - 1 - (tau - (nl - 1 - l));
+      const f4* w = wl + (size_t)l * WL;
+      for (int ps = 0; ps < n_pass; ps++) {
+        const int pl = ps * GP_LB + bl, b = b_lo + pl;
+        const f4* xp = reinterpret_cast<const f4*>(xs + (size_t)ci * cell_floats + (size_t)pl * lane_floats);
+        float gi = 0.f, gh = 0.f;
+#pragma unroll
+        for (int i = 0; i < 2 * Q; i++) {
+          const f4 xv = xp[ks * 2 * Q + i];
+          gi = dot4(xv, w[bchunk<Q>(2, u, i, ks)], gi);
+          gh = dot4(xv, w[bchunk<Q>(3, u, i, ks)], gh);
+        }
+#pragma unroll
+        for (int d = 1; d < GP_KS; d <<= 1) {
+          gi += __shfl_xor(gi, d);
+          gh += __shfl_xor(gh, d);
+        }
+        if (ks == 0 && b < b_hi) {
+          const float* kp = keep + ((ci * n_lanes + pl) * GP_U + u) * 2;
+          const float din = kp[1] + gi;
+          if (l > 0) dabove[((l - 1) * n_lanes + pl) * GP_U + u] = din;   // the cell below at this slot is on the next diagonal
+          else a.dpooled[((size_t)b * S + s) * H + j] = din;
+          dcar[(l * n_lanes + pl) * GP_U + u] = kp[0] + gh;               // cell (s - 1, l): next diagonal
+        }
+      }
+    }
+    __syncthreads();   // (keep / dcar / dabove of this diagonal are complete before the next phase A reads them)
+  }
+}
+
+size_t bptt_lds_bytes(int H, int nl, int B) {
+  const int Q = H >> 5;
+  const int Bc = (B + GP_GROUPS - 1) / GP_GROUPS, n_pass = (Bc + GP_LB - 1) / GP_LB, n_lanes = n_pass * GP_LB;
+  const size_t WL = 2 * GP_U * (Q * GP_KS + 8) + 2 * GP_U * (2 * Q * GP_KS + 8);
+  return (size_t)nl * WL * 16 + (size_t)nl * n_lanes * 2 * H * 4 + (size_t)nl * n_lanes * GP_U * 4 * 4;   // weights | staging | keep (2) + dcar + dabove
+}
+
+template <int Q>
+hipError_t launch_bptt_q(const GruBpttArgs& a, size_t lds_bytes, hipStream_t st) {
+  auto kern = k_gru_bptt_persist<Q>;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(GP_GROUPS * (a.H / GP_U))), dim3(GP_THREADS), lds_bytes, st, a);
+  return hipGetLastError();
+}
+
 }  // namespace
+
+bool gru_persist_shape_ok(const ModelDev& m, int B, int S);
+// the scan's backward as one persistent launch: the forward's shapes (gru_persist_shape_ok) where its own LDS image fits
+bool gru_bptt_persist_applies(const ModelDev& m, int B, int S) {
+  if (getenv("HIERTCN_GRU_BPTT_CHAIN")) return false;   // A/B runs, tests: train.hip's launch chain
+  const char* off = getenv("HIERTCN_GRU_CHAIN");
+  if (off && off[0] == '1') return false;
+  return gru_persist_shape_ok(m, B, S) && bptt_lds_bytes(m.H, m.nl, B) <= 150 * 1024;
+}
+
+hipError_t launch_gru_bptt_persist(const ModelDev& m, const float* save, const float* hist, const float* mask, const float* dsb, int B, int S, float* dac_all,
+                                   float* dag_all, float* dpooled, hipStream_t st) {
+  GruBpttArgs a;
+  memset(&a, 0, sizeof(a));
+  a.save = save; a.hist = hist; a.mask = mask; a.dsb = dsb; a.dac_all = dac_all; a.dag_all = dag_all; a.dpooled = dpooled;
+  for (int l = 0; l < m.nl; l++) { a.wc[l] = m.gru_wc[l]; a.wg[l] = m.gru_wg[l]; }
+  a.bar = m.gru_bar;
+  a.B = B; a.S = S; a.H = m.H; a.HT = m.HT; a.nl = m.nl; a.P = m.H / GP_U;
+  const size_t lds_bytes = bptt_lds_bytes(m.H, m.nl, B);
+  switch (m.H >> 5) {
+    case 2: return launch_bptt_q<2>(a, lds_bytes, st);
+    case 4: return launch_bptt_q<4>(a, lds_bytes, st);
+    case 8: return launch_bptt_q<8>(a, lds_bytes, st);
+    default: return hipErrorInvalidValue;
+  }
+}
 
 // shapes the persistent launch handles (no environment switch looked at: the workspace is sized by this)
 bool gru_persist_shape_ok(const ModelDev& m, int B, int S) {

@@ -1109,7 +1109,10 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   const unsigned gBH = (unsigned)(((int64_t)B * H + 255) / 256);
   static const bool bptt_unfused = getenv("HIERTCN_GRU_BPTT_UNFUSED") != nullptr;
   const bool bptt_fused = B <= 64 && !bptt_unfused;
-  for (int s = S - 1; s >= 0; s--) {
+  const bool bptt_persist = gru_bptt_persist_applies(m, B, S);
+  if (bptt_persist)   // small batches: the whole backward scan as ONE persistent launch (gru_persist.hip, k_gru_bptt_persist)
+    T_HIP(launch_gru_bptt_persist(m, gsave, hist, mask, dsb, B, S, dac_all, dag_all, dpooled, st));
+  for (int s = S - 1; s >= 0 && !bptt_persist; s--) {
     if (!bptt_fused) {
       hipLaunchKernelGGL(k_gru_out_grad, dim3((unsigned)(((int64_t)B * HT + 255) / 256)), dim3(256), 0, st, dcar, dsb + (size_t)(s + 1) * HT, hs,
                          mask + s, S, B, HT, dhp);

@@ -71,8 +71,11 @@ def torch_loss(args, P, x, y, mask, state):
 
 # the last shape has 11,520 rows: the weight-gradient GEMMs of csrc/gemm.hip then cut their row reduction into slices (partial tiles summed in
 # slice order), which the 252-row shapes never do
-@pytest.fixture(scope="module", params=[(64, 700, 32, (7, 4, 9)), (128, 1500, 64, (7, 4, 9)), (512, 900, 64, (7, 4, 9)), (128, 1500, 64, (96, 4, 30))],
-                ids=["d64", "d128", "d512", "d128_rows11520"])
+# d128_h128: E == H -- the shape whose across-session scan AND its backward run as persistent launches (csrc/gru_persist.hip, k_gru_scan_persist with the
+# training records, k_gru_bptt_persist); 33 lanes: two passes of lanes per group
+@pytest.fixture(scope="module", params=[(64, 700, 32, (7, 4, 9)), (128, 1500, 64, (7, 4, 9)), (512, 900, 64, (7, 4, 9)), (128, 1500, 64, (96, 4, 30)),
+                                        (128, 900, 128, (33, 5, 9))],
+                ids=["d64", "d128", "d512", "d128_rows11520", "d128_h128"])
 def trained(request):
     from hiertcn_amd.engine import Engine, metrics_dict
     d, N, H, (B, S, L) = request.param
