@@ -100,7 +100,7 @@ struct ModelDev {
 
 // launchers implemented in the kernel files (all asynchronous on `st`)
 hipError_t launch_rows_to_bf16(const float* src, uint16_t* dst, int64_t rows, int cols, int zero_row0, hipStream_t st);
-hipError_t launch_transpose_to_bf16(const float* src, uint16_t* dst, int64_t rows, int64_t cols, int64_t dst_rows_padded, hipStream_t st);
+hipError_t launch_transpose_to_bf16(const float* src, uint16_t* dst, int64_t rows, int64_t cols, int64_t dst_rows_padded, hipStream_t st, int batch = 1);
 hipError_t launch_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, hipStream_t st);
 hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t npad, float padval, hipStream_t st);
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);

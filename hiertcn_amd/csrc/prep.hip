@@ -42,6 +42,8 @@ hipError_t launch_rows_to_bf16(const float* src, uint16_t* dst, int64_t rows, in
 __global__ void k_transpose_to_bf16(const float* __restrict__ src, uint16_t* __restrict__ dst, int64_t rows, int64_t cols,
                                     int64_t dst_rows) {
   __shared__ float tile[32][33];
+  src += (int64_t)blockIdx.z * rows * cols;     // blockIdx.z: one of several equally shaped, contiguous matrices (the taps of a conv kernel)
+  dst += (int64_t)blockIdx.z * rows * cols;     // (batched launches have dst_rows == cols: no padding between the outputs)
   const int64_t c0 = (int64_t)blockIdx.x * 32;  // along src cols / dst rows
   const int64_t r0 = (int64_t)blockIdx.y * 32;  // along src rows / dst cols
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 256 threads: 8 rows per pass
@@ -57,8 +59,9 @@ __global__ void k_transpose_to_bf16(const float* __restrict__ src, uint16_t* __r
 }
 
 hipError_t launch_transpose_to_bf16(const float* src, uint16_t* dst, int64_t rows, int64_t cols, int64_t dst_rows_padded,
-                                    hipStream_t st) {
-  dim3 grid((unsigned)((dst_rows_padded + 31) / 32), (unsigned)((rows + 31) / 32));
+                                    hipStream_t st, int batch) {
+  if (batch > 1 && dst_rows_padded != cols) return hipErrorInvalidValue;
+  dim3 grid((unsigned)((dst_rows_padded + 31) / 32), (unsigned)((rows + 31) / 32), (unsigned)(batch > 1 ? batch : 1));
   hipLaunchKernelGGL(k_transpose_to_bf16, grid, dim3(256), 0, st, src, dst, rows, cols, dst_rows_padded);
   return hipGetLastError();
 }

@@ -157,8 +157,7 @@ hipError_t train_refresh_bf16(const ModelDev& m, const TrainCtx& t, hipStream_t 
   if (m.hier && (e = launch_transpose_to_bf16(M + t.projT.off, t.projD, m.E, m.E, m.E, st)) != hipSuccess) return e;
   for (int i = 0, cin = m.E; i < m.n_blocks && !m.low_gru; cin = m.C[i], i++) {
     const int cout = m.C[i];
-    for (int j = 0; j < m.K; j++)
-      if ((e = launch_transpose_to_bf16(M + t.convT[i].off + (size_t)j * cin * cout, t.convD[i] + (size_t)j * cin * cout, cout, cin, cin, st)) != hipSuccess) return e;
+    if ((e = launch_transpose_to_bf16(M + t.convT[i].off, t.convD[i], cout, cin, cin, st, m.K)) != hipSuccess) return e;   // the K taps in one launch
     if (t.resT[i].n && (e = launch_transpose_to_bf16(M + t.resT[i].off, t.resD[i], cout, cin, cin, st)) != hipSuccess) return e;
   }
   if ((e = refresh_lgru_split(m, st)) != hipSuccess) return e;
