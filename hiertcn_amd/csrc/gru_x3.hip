@@ -13,6 +13,9 @@
 // units of one session and every epilogue access is a 16-byte row access.  Workgroup = 128 units x 128 sessions (4 waves x four 32 x 32
 // accumulators); the reduction runs over [in | h] in 64- or 32-deep chunks; W_hi, W_lo, A_hi, A_lo chunks arrive in LDS by LDS-DMA (two buffers,
 // source-side swizzle) with the next chunk in flight during the MFMAs.  The layer-0 input (the projected rows, already 16-bit) has no low part: two products.
+#include <stdlib.h>
+#include <string.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -277,9 +280,66 @@ bool gru_x3_applies(const ModelDev& m) {
   return (m.E % XK_MIN) == 0 && (m.H % XK_MIN) == 0;
 }
 
+// Every derived copy of the low level's weights in ONE launch (round 4: after an optimizer step the split, its fragment-major copies and the
+// fragment-major copies of the transposes were 10 launches per layer -- a fifth of a 32-lane training step's launches): blockIdx.y picks the
+// matrix; thread i takes the i-th 8-element fragment chunk of the fragment-major order (every element exactly once: it also writes the
+// row-major split there) and, where asked, the i-th chunk of the transpose's fragment-major order (8 strided reads).
+struct LgruRefreshDesc { const float* W; int N, K; uint16_t *hi, *lo, *Fhi, *Flo, *TFhi, *TFlo; };
+struct LgruRefreshGroup { LgruRefreshDesc d[2 * HIERTCN_MAX_LAYERS]; };
+__global__ void k_lgru_refresh(const LgruRefreshGroup grp) {
+  const LgruRefreshDesc& d = grp.d[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int N = d.N, K = d.K;
+  if (i >= (int64_t)N * K / 8) return;
+  const int lane = (int)(i & 63);
+  const int64_t f = i >> 6;
+  auto pack8 = [](const uint16_t* v) { return make_uint4(v[0] | ((uint32_t)v[1] << 16), v[2] | ((uint32_t)v[3] << 16), v[4] | ((uint32_t)v[5] << 16), v[6] | ((uint32_t)v[7] << 16)); };
+  {
+    const int ks = K >> 4;
+    const int s = (int)(f % ks), cb = (int)(f / ks);
+    const int64_t off = (int64_t)(cb * 32 + (lane & 31)) * K + 16 * s + 8 * (lane >> 5);
+    const float4 x0 = *reinterpret_cast<const float4*>(d.W + off), x1 = *reinterpret_cast<const float4*>(d.W + off + 4);
+    const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+    uint16_t h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) split2(x[j], h[j], l[j]);
+    const uint4 ph = pack8(h), pl = pack8(l);
+    *reinterpret_cast<uint4*>(d.hi + off) = ph;
+    *reinterpret_cast<uint4*>(d.lo + off) = pl;
+    *reinterpret_cast<uint4*>(d.Fhi + i * 8) = ph;
+    *reinterpret_cast<uint4*>(d.Flo + i * 8) = pl;
+  }
+  if (d.TFhi) {
+    const int ns = N >> 4;
+    const int s = (int)(f % ns), kb = (int)(f / ns);
+    uint16_t h[8], l[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) split2(d.W[(int64_t)(16 * s + 8 * (lane >> 5) + j) * K + 32 * kb + (lane & 31)], h[j], l[j]);
+    *reinterpret_cast<uint4*>(d.TFhi + i * 8) = pack8(h);
+    *reinterpret_cast<uint4*>(d.TFlo + i * 8) = pack8(l);
+  }
+}
+
 hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st) {
   if (!m.low_gru || !m.lgru_split) return hipSuccess;
   hipError_t e;
+  {
+    bool all = !getenv("HIERTCN_LGRU_REFRESH_UNFUSED");
+    LgruRefreshGroup grp;
+    memset(&grp, 0, sizeof(grp));
+    int64_t most = 0;
+    for (int l = 0; l < m.nl && all; l++) {
+      const int K = ((l == 0) ? m.E : m.H) + m.H;
+      all = m.lgru_wgF_hi[l] && m.lgru_wcF_hi[l] && (K % 32) == 0 && (m.H % 32) == 0 && (!m.lgru_wgTF_hi[l] == !m.lgru_wcTF_hi[l]);
+      grp.d[2 * l] = LgruRefreshDesc{m.lgru_wg[l], 2 * m.H, K, m.lgru_wg_hi[l], m.lgru_wg_lo[l], m.lgru_wgF_hi[l], m.lgru_wgF_lo[l], m.lgru_wgTF_hi[l], m.lgru_wgTF_lo[l]};
+      grp.d[2 * l + 1] = LgruRefreshDesc{m.lgru_wc[l], m.H, K, m.lgru_wc_hi[l], m.lgru_wc_lo[l], m.lgru_wcF_hi[l], m.lgru_wcF_lo[l], m.lgru_wcTF_hi[l], m.lgru_wcTF_lo[l]};
+      most = most > (int64_t)2 * m.H * K / 8 ? most : (int64_t)2 * m.H * K / 8;
+    }
+    if (all && m.nl > 0) {
+      hipLaunchKernelGGL(k_lgru_refresh, dim3((unsigned)((most + 255) / 256), (unsigned)(2 * m.nl)), dim3(256), 0, st, grp);
+      return hipGetLastError();
+    }
+  }
   for (int l = 0; l < m.nl; l++) {
     const int in = (l == 0) ? m.E : m.H;
     const int64_t ng = (int64_t)(in + m.H) * 2 * m.H, nc = (int64_t)(in + m.H) * m.H;
