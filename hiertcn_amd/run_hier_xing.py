@@ -10,6 +10,7 @@ evaluations and epochs (:241-243,332,343).
 """
 from __future__ import annotations
 
+import os
 import time
 from typing import Sequence
 
@@ -53,7 +54,37 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
         pre = getattr(loader, "_prefetcher", None)
         if pre is None:
             pre = loader._prefetcher = Prefetcher(loader.get_packed_batch, depth=2, owner=loader)
-    while True:  # :112
+    # the device is left running (model.py, PendingEval): batch i is enqueued -- carried state device to device -- before the host turns to
+    # batch i - 1's ranks and metrics.  HIERTCN_EVAL_SERIAL=1: one blocking sess.run-shaped call per batch, as before round 4.
+    pipelined = packed and hasattr(model, "eval_step_packed_async") and not os.environ.get("HIERTCN_EVAL_SERIAL")
+    if pipelined:
+        model.eval_begin(state_np)
+        pending = None
+
+        def take(p):
+            st = p[0].result()
+            meter.add(st)
+            return st, ranks_analysis(st["ranks_float"], [np.empty((0, w)) for w in p[1]], st["mask_y"], ranks_temp, ranks_temp_count)
+
+        while True:
+            t1 = time.time()
+            x, y, mask, widths = pre.get() if pre is not None else loader.get_packed_batch()
+            done = pre.done if pre is not None else loader.done
+            t2 = time.time()
+            nxt = (model.eval_step_packed_async(x, y, mask, widths), widths)
+            if pending is not None:
+                step, (ranks_temp, ranks_temp_count) = take(pending)
+            pending = nxt
+            t3 = time.time()
+            time_load += t2 - t1
+            time_run += t3 - t2
+            if done:
+                break
+        t2 = time.time()
+        step, (ranks_temp, ranks_temp_count) = take(pending)
+        state_np = model.eval_end()
+        time_run += time.time() - t2
+    while not pipelined:  # :112
         t1 = time.time()
         if packed:   # same batch, already in the C-ABI layout (tests/test_data_loader.py)
             x, y, mask, widths = pre.get() if pre is not None else loader.get_packed_batch()
@@ -134,7 +165,21 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
         if args.train:
             lr = scheduled_lr(args, epoch)
             training_loss_epoch = 0.0
-            for _ in range(args.epoch_batches_train):  # :275
+            if (hasattr(loader_train, "get_packed_batch") and hasattr(model, "train_step_packed_async") and not os.environ.get("HIERTCN_TRAIN_SERIAL")
+                    and args.epoch_batches_train > 0):
+                # the device is left running (model.py, PendingTrain): the carried state goes device to device, a step's loss is read one step later
+                model.train_begin(state_np)
+                pending = None
+                for _ in range(args.epoch_batches_train):  # :275
+                    x, y, mask, _widths = loader_train.get_packed_batch()
+                    nxt = model.train_step_packed_async(x, y, mask, lr)
+                    if pending is not None:
+                        training_loss_epoch += float(pending.result()["loss"])
+                    pending = nxt
+                training_loss_epoch += float(pending.result()["loss"])
+                state_np = model.train_end()
+            else:
+              for _ in range(args.epoch_batches_train):  # :275
                 batch_x_list, batch_y_list, batch_mask_list, _info = loader_train.get_batch()
                 out = model.train_step(batch_x_list, batch_y_list, batch_mask_list, state_np, lr)
                 state_np = out["state"]

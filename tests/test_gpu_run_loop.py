@@ -89,3 +89,62 @@ def test_evaluate_hier_in_the_exact_mode_equals_the_exact_oracle(tmp_path, dtype
               "ranks_float_epoch_mean"):
         assert abs(got[k] - want[k]) < 1e-4, (k, got[k], want[k])
     model.engine.close()
+
+
+def test_pipelined_loops_equal_the_blocking_ones(tmp_path):
+    """Round 4: evaluate_hier / run_hier leave the device running -- carried state device to device, a batch's ranks and metrics read one batch
+    later through pinned buffers (model.py: PendingEval / PendingTrain).  HIERTCN_EVAL_SERIAL=1 / the *_packed calls are the blocking
+    sess.run-shaped form: same epoch summary, same per-position rank table, same carried state (evaluation: bitwise); training: the same
+    losses and carried state to 1e-5 (atomics reorder the gradient sums)."""
+    from hiertcn_amd.model import HierTCNModel
+
+    data = load_xing(CSV)
+    n_items = int(data[1][:, 1].max()) + 1
+    args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=64, num_layer=2, tcn_channel=[64, 64], kernel_size=5,
+                         batch_size=4, max_session_num=3, max_activity_len=6)
+    args.log_path = None
+    params = make_params(args)
+    model = HierTCNModel(args, params)
+    st0 = (0.1 * np.random.default_rng(0).standard_normal((4, 128))).astype(np.float32)
+    outs = []
+    for serial in (False, True):
+        if serial:
+            os.environ["HIERTCN_EVAL_SERIAL"] = "1"
+        try:
+            outs.append(evaluate_hier(args, Dataloader_hier_model_xing(args, "test", data=data), st0, model, prefix="test"))
+        finally:
+            os.environ.pop("HIERTCN_EVAL_SERIAL", None)
+    (s_a, v_a, _, _, st_a), (s_b, v_b, _, _, st_b) = outs
+    assert s_a == s_b
+    assert np.array_equal(v_a["ranks_by_position"], v_b["ranks_by_position"])
+    assert {k: v for k, v in v_a.items() if k != "ranks_by_position"} == {k: v for k, v in v_b.items() if k not in ("ranks_by_position", "state")}
+    assert np.array_equal(np.asarray(st_a, np.float32), np.asarray(st_b, np.float32))
+    # training: n steps blocking vs pipelined on two models with the same weights
+    losses, states = [], []
+    for pipelined in (False, True):
+        m = HierTCNModel(args, params, train=True)
+        ld = Dataloader_hier_model_xing(args, "train", data=data)
+        st, ls = st0.copy(), []
+        if pipelined:
+            m.train_begin(st)
+            pend = None
+            for _ in range(6):
+                x, y, mask, _w = ld.get_packed_batch()
+                nxt = m.train_step_packed_async(x, y, mask, 1e-3)
+                if pend is not None:
+                    ls.append(pend.result()["loss"])
+                pend = nxt
+            ls.append(pend.result()["loss"])
+            st = m.train_end()
+        else:
+            for _ in range(6):
+                x, y, mask, _w = ld.get_packed_batch()
+                out = m.train_step_packed(x, y, mask, st, 1e-3)
+                st = out["state"]
+                ls.append(out["loss"])
+        losses.append(ls)
+        states.append(np.asarray(st, np.float32))
+        m.engine.close()
+    np.testing.assert_allclose(losses[0], losses[1], rtol=1e-5)
+    np.testing.assert_allclose(states[0], states[1], atol=1e-5)
+    assert losses[0][-1] < losses[0][0]
