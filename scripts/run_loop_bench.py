@@ -49,3 +49,29 @@ for rep in range(2):   # (the second pass is the measured one: first-call costs 
 print("evaluate_hier: %d users, lanes %d, workers %d: %d batches, %d sessions in %.3f s (loader %.3f s, steps %.3f s) = %.3f ms per batch, %.0f sessions/s" % (
     users, lanes, workers, count["batches"], count["sessions"], dt, t_load, t_run, dt / max(count["batches"], 1) * 1e3, count["sessions"] / dt), flush=True)
 print({k: round(float(v), 5) for k, v in summary.items()})
+
+if os.environ.get("TRAIN"):   # the training loop of run_hier (run_hier_xing.py:275-301), blocking calls vs the pipelined form
+    tm = HierTCNModel(args, train=True)
+    for form in ("blocking", "pipelined"):
+        ld = Dataloader_hier_model_xing(args, "all", data=data)
+        st = np.zeros((lanes, args.hidden_dim * args.num_layer), np.float32)
+        n = int(os.environ["TRAIN"])
+        t0 = time.perf_counter()
+        if form == "blocking":
+            for _ in range(n):
+                x, y, mask, _w = ld.get_packed_batch()
+                out = tm.train_step_packed(x, y, mask, st, 1e-3)
+                st = out["state"]
+        else:
+            tm.train_begin(st)
+            pend = None
+            for _ in range(n):
+                x, y, mask, _w = ld.get_packed_batch()
+                nxt = tm.train_step_packed_async(x, y, mask, 1e-3)
+                if pend is not None:
+                    pend.result()
+                pend = nxt
+            pend.result()
+            st = tm.train_end()
+        dt = time.perf_counter() - t0
+        print("training loop, %s: %d steps of %d lanes: %.3f ms per step end to end" % (form, n, lanes, dt / n * 1e3), flush=True)
