@@ -184,6 +184,7 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
                 out = model.train_step(batch_x_list, batch_y_list, batch_mask_list, state_np, lr)
                 state_np = out["state"]
                 training_loss_epoch += float(out["loss"])
+            _check_persistent_health(model, "training epoch %d" % epoch)   # (the training step runs persistent launches too: scan, its backward, lgru_pipe)
             training_loss_epoch /= args.epoch_batches_train
             train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
             if args.save and epoch % args.save_epoch == 0 and epoch != 0:  # :317-321
