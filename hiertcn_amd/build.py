@@ -34,7 +34,7 @@ LIB_F16 = os.path.join(HERE, "libhiertcn_gfx950_f16.so")
 
 
 LIB_TESTHOOKS = os.path.join(HERE, "libhiertcn_gfx950_testhooks.so")
-TESTHOOK_SOURCES = ["gru_persist.hip"]   # the sources that hold an `#ifdef HIERTCN_TEST_HOOKS` switch
+TESTHOOK_SOURCES = ("gru_persist.hip", "lgru_pipe.hip")   # the sources that hold a fault-injection switch
 
 
 def build_all(force: bool = False, verbose: bool = False):

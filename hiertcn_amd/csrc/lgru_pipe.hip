@@ -40,6 +40,7 @@ struct LgruPipeArgs {
   int* flags;                                // [nl - 1][tiles][L]
   unsigned long long* err;                   // the handle's persistent-launch error word
   int M, L, H, HT, nl;
+  int test_no_flags;                         // test-hooks build only (fault injection: the producers never signal)
 };
 
 __device__ __forceinline__ float lp_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -319,6 +320,9 @@ __global__ __launch_bounds__(LP_THREADS, 1) void k_lgru_pipe(const LgruPipeArgs 
     }
     if (!last) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's stores of the previous step's slot (issued a gates phase ago) have completed
     __syncthreads();   // r * h of every unit is in LDS
+#ifdef HIERTCN_TEST_HOOKS
+    if (!a.test_no_flags)
+#endif
     if (!last && tid == 0 && t > 0) __hip_atomic_store(fout + t - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     bool prefetched = false;
     if (!FIRST) {
@@ -377,6 +381,9 @@ __global__ __launch_bounds__(LP_THREADS, 1) void k_lgru_pipe(const LgruPipeArgs 
   if (!last) {   // the last step's slot
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+#ifdef HIERTCN_TEST_HOOKS
+    if (!a.test_no_flags)
+#endif
     if (tid == 0) __hip_atomic_store(fout + L - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
 }
@@ -415,6 +422,9 @@ hipError_t launch_lgru_pipe(const ModelDev& m, const uint16_t* u16, const int32_
     a.bg[l] = m.lgru_bg[l]; a.bc[l] = m.lgru_bc[l];
   }
   a.M = (int)n_sess; a.L = L; a.H = m.H; a.HT = m.HT; a.nl = m.nl;
+#ifdef HIERTCN_TEST_HOOKS   // libhiertcn_gfx950_testhooks.so only: the shipped libraries read no test switch on this path
+  if (getenv("HIERTCN_LGRU_PIPE_TEST_NO_FLAGS")) a.test_no_flags = 1;   // every consumer's bounded wait runs out
+#endif
   const unsigned tiles = (unsigned)((n_sess + 31) / 32);
   const size_t xbytes = (((size_t)(m.nl - 1) * L * 2 * (size_t)n_sess * m.H * 2) + 255) & ~(size_t)255;
   a.xch = reinterpret_cast<uint16_t*>(scratch);

@@ -42,4 +42,32 @@ for g, w in zip(got, want):
     np.testing.assert_allclose(g, w, rtol=2e-5, atol=2e-5)
 assert not eng.persistent_timed_out()
 eng.close()
-print("persist_timeout_probe ok: timed out in %.1f s, recovered" % took)
+
+# ---- the layer-pipelined HierGRU low level (csrc/lgru_pipe.hip): consumers wait for their producers' flags inside the launch, bounded the same way.
+# HIERTCN_LGRU_PIPE_TEST_NO_FLAGS (test-hooks build only): the producers never signal.
+from tests.gpu_common import make_batch
+d, nl, B, S, L = 64, 2, 5, 3, 7
+args = hier_tcn_args(item_num=300, emb_dim=d, hidden_dim=d, tcn_channel=[d, d], num_layer=nl, model_low_type="gru")
+eng = Engine(args)
+eng.set_weights(init_params(args, 5))
+rng = np.random.default_rng(4)
+x, y, mask = make_batch(rng, B, S, L, 300)
+dv = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda()
+sproj = (0.1 * torch.randn((B * S, d), device="cuda")).float()
+xs = dv(x.reshape(B * S, L).astype(np.int32))
+good = eng.tcn_forward(xs, sproj).float().cpu().numpy()
+assert not eng.persistent_timed_out()
+os.environ["HIERTCN_LGRU_PIPE_TEST_NO_FLAGS"] = "1"
+try:
+    t0 = time.time()
+    eng.tcn_forward(xs, sproj)
+    torch.cuda.synchronize()
+    took2 = time.time() - t0
+finally:
+    os.environ.pop("HIERTCN_LGRU_PIPE_TEST_NO_FLAGS", None)
+assert eng.persistent_timed_out()       # (the read also clears the word)
+assert took2 < 60.0, took2
+again = eng.tcn_forward(xs, sproj).float().cpu().numpy()
+assert np.array_equal(again, good) and not eng.persistent_timed_out()
+eng.close()
+print("persist_timeout_probe ok: timed out in %.1f s, recovered; lgru_pipe: timed out in %.1f s, recovered" % (took, took2))
