@@ -170,3 +170,15 @@ def test_both_storage_variants_load_and_report_their_dtype():
     a, b = _lib.load(), _lib.load(f16=True)
     assert a.hiertcn_storage_dtype() == 0 and b.hiertcn_storage_dtype() == 1
     assert a.hiertcn_abi_version() == b.hiertcn_abi_version()
+
+
+def test_the_shipped_libraries_hold_no_fault_injection_switch():
+    """The switches the time-out tests use (a missing workgroup in the persistent scan, producers that never signal in the layer-pipelined
+    HierGRU launch) exist only in libhiertcn_gfx950_testhooks.so: the shipped libraries do not even contain their names."""
+    from hiertcn_amd.build import LIB, LIB_F16, LIB_TESTHOOKS
+    names = [b"HIERTCN_GRU_TEST_MISSING_WG", b"HIERTCN_LGRU_PIPE_TEST_NO_FLAGS"]
+    for path in (LIB, LIB_F16):
+        blob = open(path, "rb").read()
+        assert not any(n in blob for n in names), path
+    hooks = open(LIB_TESTHOOKS, "rb").read()
+    assert all(n in hooks for n in names)
