@@ -343,6 +343,48 @@ def reference_batch_leg(n_batches=100):
     return out
 
 
+def run_loop_leg(users=20000, lanes=32):
+    """-> the `run_loop` object: the reference's evaluation LOOP end to end (run_hier_xing.py:112-207 -- loader, one step per batch, meters) over a
+    synthetic XING-format file at the reference's batch, HierTCN d = 256: sessions/s of the whole loop, pipelined (the default: the device is left
+    running) and blocking (one sess.run-shaped call per batch)."""
+    import subprocess
+    import tempfile
+
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.data_loader import Dataloader_hier_model_xing
+    from hiertcn_amd.data_prepare import load_xing
+    from hiertcn_amd.model import HierTCNModel
+    from hiertcn_amd.run_hier_xing import evaluate_hier
+
+    root = os.path.dirname(os.path.abspath(__file__))
+    tmp = tempfile.mkdtemp()
+    subprocess.check_call([sys.executable, os.path.join(root, "scripts", "make_synth_xing.py"), str(users), tmp], stdout=subprocess.DEVNULL)
+    data = load_xing(os.path.join(tmp, "dataset", "interactions.csv"), max_activity=500)
+    n_items = int(data[1][:, 1].max()) + 1
+    d = 256
+    args = hier_tcn_args(item_num=n_items, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=lanes, max_session_num=10,
+                         max_activity_len=20)
+    args.log_path = None
+    model = HierTCNModel(args)
+    n_sessions = int((np.diff(np.flatnonzero(np.r_[True, (data[1][1:, 4] != data[1][:-1, 4]) | (data[1][1:, 0] != data[1][:-1, 0]), True]))).shape[0])
+    out = {"what": "evaluate_hier over a synthetic XING-format file (%d users, %d sessions, %d items), %d lanes x 10 slots x <= 20 steps per batch, HierTCN d = 256, "
+                   "packer on the loop's thread; sessions/s of the whole loop" % (users, n_sessions, n_items, lanes)}
+    for form in ("pipelined", "pipelined", "blocking"):   # (first pass: warm-up)
+        if form == "blocking":
+            os.environ["HIERTCN_EVAL_SERIAL"] = "1"
+        try:
+            loader = Dataloader_hier_model_xing(args, "all", data=data)
+            state = np.zeros((lanes, 2 * d), np.float32)
+            t0 = time.perf_counter()
+            _s, _v, t_load, t_run, _st = evaluate_hier(args, loader, state, model, prefix="test")
+            dt = time.perf_counter() - t0
+        finally:
+            os.environ.pop("HIERTCN_EVAL_SERIAL", None)
+        out[form] = {"seconds": round(dt, 4), "loader_seconds": round(t_load, 4), "sessions_per_s": round(n_sessions / dt)}
+    model.engine.close()
+    return out
+
+
 def exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks):
     """-> the `exact` object: the SAME evaluation step in the parity-grade modes (tests/test_gpu_exact_mode.py: logits < 1e-3 of the exact
     oracle at |z| = 10 and 30, ranks equal on > 99 % of rows, top-10 equal on every clear row) -- 'split16' (HIERTCN_PRECISION_SPLIT16: fp32
@@ -640,6 +682,13 @@ def main():
         except Exception as e:  # noqa: BLE001  (secondary figure, never fatal)
             refb = {"error": repr(e)[:300]}
 
+    rloop = None
+    if rank == 0 and world == 1 and not a.no_reference_batch:
+        try:
+            rloop = run_loop_leg()
+        except Exception as e:  # noqa: BLE001  (secondary figure, never fatal)
+            rloop = {"error": repr(e)[:300]}
+
     cpu = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline:
         # the checker, timed on this host's cores on a bounded sample of the SAME workload
@@ -704,6 +753,7 @@ def main():
             "cpu_baseline": cpu,
             "exact": exact,
             "reference_batch": refb,
+            "run_loop": rloop,
             "multi_gpu": multi,
             "gmm": gmm,
             "train": train,
