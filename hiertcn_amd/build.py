@@ -37,10 +37,23 @@ LIB_TESTHOOKS = os.path.join(HERE, "libhiertcn_gfx950_testhooks.so")
 TESTHOOK_SOURCES = ("gru_persist.hip", "lgru_pipe.hip")   # the sources that hold a fault-injection switch
 
 
+LIB_PACKER = os.path.join(HERE, "libhiertcn_packer.so")   # host-side batch packer (csrc/packer.c: plain C, gcc)
+
+
+def build_packer(force: bool = False) -> str:
+    src = os.path.join(CSRC, "packer.c")
+    if force or _stale(LIB_PACKER, [src]):
+        r = subprocess.run(["gcc", "-O2", "-fPIC", "-shared", "-std=c99", "-Wall", "-o", LIB_PACKER, src], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("gcc failed: %s\n%s" % (src, r.stderr))
+    return LIB_PACKER
+
+
 def build_all(force: bool = False, verbose: bool = False):
     """Both storage variants: bfloat16 (default, training + inference) and IEEE half (-DHIERTCN_F16, inference)."""
     libs = build_lib(force, verbose), build_lib(force, verbose, f16=True)
     build_testhooks(force)
+    build_packer(force)
     return libs
 
 

@@ -14,7 +14,9 @@ assembled by fancy indexing.  `get_packed_batch()` emits ids [B][S][Lmax] int32 
 """
 from __future__ import annotations
 
+import ctypes as C
 import heapq
+import os
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -22,6 +24,38 @@ import numpy as np
 from .data_prepare import load_xing
 
 DATA_PATH = "dataset/interactions.csv"  # data_loader.py:54,140 (relative to the working directory)
+
+_PACKER = None
+
+
+def _packer_lib():
+    """libhiertcn_packer.so (csrc/packer.c, built by hiertcn_amd.build): the lane queues and the batch gather in C.  None when the library
+    has not been built or HIERTCN_PY_PACKER is set: the NumPy / heapq form below does the same, ~10 x slower at 32 lanes."""
+    global _PACKER
+    if os.environ.get("HIERTCN_PY_PACKER"):
+        return None
+    if _PACKER is None:
+        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhiertcn_packer.so")
+        if not os.path.exists(path):
+            _PACKER = False
+        else:
+            lib = C.CDLL(path)
+            p64, pd, pi32, pf = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float)
+            lib.pk_create.restype = C.c_void_p
+            lib.pk_create.argtypes = [C.c_int, C.c_int, p64, p64, pd, p64, p64, p64]
+            lib.pk_destroy.argtypes = [C.c_void_p]
+            lib.pk_fill.argtypes = [C.c_void_p, p64, C.c_int64, p64, C.c_int]
+            lib.pk_peek_lmax.restype = C.c_int64
+            lib.pk_peek_lmax.argtypes = [C.c_void_p]
+            lib.pk_pop.argtypes = [C.c_void_p, p64, pi32, pi32, pf, pi32, C.c_int64]
+            lib.pk_queue_len.restype = C.c_int64
+            lib.pk_queue_len.argtypes = [C.c_void_p, C.c_int]
+            _PACKER = lib
+    return _PACKER or None
+
+
+def _p(a, ct):
+    return a.ctypes.data_as(C.POINTER(ct))
 
 
 def _split(viewer_table: np.ndarray, split: str, rank: int = 0, world: int = 1) -> np.ndarray:
@@ -137,11 +171,56 @@ class Dataloader_hier_model_xing:
         B = int(args.batch_size)
         self._lanes: List[list] = [[] for _ in range(B)]   # session numbers queued per lane; _heads = first unread entry
         self._heads = [0] * B
-        self.queue_len = np.zeros(B)
+        self._queue_len = np.zeros(B)
         # (sessions queued, lane) ordered like np.argmin(queue_len) picks: shortest lane, lowest index on ties.  Lengths in
         # the heap are relative to _popped (every batch takes S from every lane, which keeps the order).
         self._heap = [(0, b) for b in range(B)]
         self._popped = 0
+        # the same queues in C where the packer library is built (csrc/packer.c); the arrays it reads stay referenced here
+        self._pk, self._pk_lib = None, _packer_lib()
+        if self._pk_lib is not None:
+            self._pk_arrays = [np.ascontiguousarray(a, dtype=t) for a, t in (
+                (self._s_begin, np.int64), (self._s_len, np.int64), (self._s_mask, np.float64), (self._ids, np.int64), (self._u_first, np.int64),
+                (self._u_nsess, np.int64))]
+            a = self._pk_arrays
+            self._pk = C.c_void_p(self._pk_lib.pk_create(B, int(args.max_session_num), _p(a[0], C.c_int64), _p(a[1], C.c_int64), _p(a[2], C.c_double),
+                                                         _p(a[3], C.c_int64), _p(a[4], C.c_int64), _p(a[5], C.c_int64)))
+            if not self._pk.value:
+                raise MemoryError("pk_create")
+            self._walk_c = None
+
+    def __del__(self):  # pragma: no cover
+        if getattr(self, "_pk", None) is not None and self._pk.value:
+            self._pk_lib.pk_destroy(self._pk)
+            self._pk = None
+
+    @property
+    def queue_len(self) -> np.ndarray:
+        """Sessions queued per lane (data_loader.py:150,203)."""
+        if self._pk is not None:
+            return np.array([self._pk_lib.pk_queue_len(self._pk, b) for b in range(len(self._lanes))], dtype=np.float64)
+        return self._queue_len
+
+    def _fill_native(self) -> bool:
+        """enqueue_loop in C: at least one user, then until every lane holds more than S sessions; the walk (and its refresh at the end of a
+        pass, which is what `done` reports) stays here."""
+        w = self._walk
+        stop, force = False, 1
+        while True:
+            if self._walk_c is None or self._walk_c[0] is not w.index:
+                self._walk_c = (w.index, np.ascontiguousarray(w.index, dtype=np.int64))
+            ptr = C.c_int64(int(w.index_pointer))
+            rc = self._pk_lib.pk_fill(self._pk, _p(self._walk_c[1], C.c_int64), int(self._walk_c[1].shape[0]), C.byref(ptr), force)
+            w.index_pointer = int(ptr.value)
+            if rc < 0:
+                raise MemoryError("pk_fill")
+            if rc == 0:
+                return stop
+            w.refresh()
+            stop = True
+            if rc == 2:
+                return stop
+            force = 0
 
     # -- one array pass over the event table ------------------------------------------------------
     def _cut_sessions(self):
@@ -175,7 +254,7 @@ class Dataloader_hier_model_xing:
         qlen, lane = heapq.heappop(self._heap)      # == np.argmin(self.queue_len), data_loader.py:203
         self._lanes[lane].extend(range(first, first + n))
         heapq.heappush(self._heap, (qlen + n, lane))
-        self.queue_len[lane] += n
+        self._queue_len[lane] += n
         w.index_pointer += 1
         if w.index_pointer >= w.index.shape[0]:
             w.refresh()
@@ -183,6 +262,8 @@ class Dataloader_hier_model_xing:
         return False
 
     def enqueue_loop(self) -> bool:
+        if self._pk is not None:
+            return self._fill_native()
         stop = False
         while True:
             stop = self.enqueue() or stop
@@ -192,6 +273,10 @@ class Dataloader_hier_model_xing:
     def _pop_slots(self) -> np.ndarray:
         """-> session numbers [B, S] of the next batch."""
         S = int(self.args.max_session_num)
+        if self._pk is not None:
+            out = np.empty((len(self._lanes), S), np.int64)
+            self._pk_lib.pk_pop(self._pk, _p(out, C.c_int64), None, None, None, None, 0)
+            return out
         out = np.array([lane[h:h + S] for lane, h in zip(self._lanes, self._heads)], dtype=np.int64)
         for b, lane in enumerate(self._lanes):
             h = self._heads[b] + S
@@ -199,7 +284,7 @@ class Dataloader_hier_model_xing:
                 del lane[:h]
                 h = 0
             self._heads[b] = h
-        self.queue_len -= S
+        self._queue_len -= S
         self._popped += S
         return out
 
@@ -230,6 +315,13 @@ class Dataloader_hier_model_xing:
         """-> x, y int32 [B, S, Lmax], mask float32 [B, S], lens (per-slot max length, i.e. the L_i
         of the reference's ragged slot arrays; needed only to un-pad `pred`-shaped outputs)."""
         self.done = self.enqueue_loop()
+        if self._pk is not None:
+            B, S = len(self._lanes), int(self.args.max_session_num)
+            Lmax = int(self._pk_lib.pk_peek_lmax(self._pk))
+            x, y = np.empty((B, S, Lmax), np.int32), np.empty((B, S, Lmax), np.int32)
+            mask, widths, sess = np.empty((B, S), np.float32), np.empty(S, np.int32), np.empty((B, S), np.int64)
+            self._pk_lib.pk_pop(self._pk, _p(sess, C.c_int64), _p(x, C.c_int32), _p(y, C.c_int32), _p(mask, C.c_float), _p(widths, C.c_int32), Lmax)
+            return x, y, mask, [int(v) for v in widths]
         sess = self._pop_slots()
         slen = self._s_len[sess]                                   # [B, S]
         Lmax = int(slen.max())

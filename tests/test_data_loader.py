@@ -89,3 +89,52 @@ def test_single_level_loader_matches_reference(fx, data):
         np.testing.assert_array_equal(xp, x.astype(np.int32))
         np.testing.assert_array_equal(yp, y.astype(np.int32))
     np.testing.assert_array_equal(np.array(dones), fx["single_done"])
+
+
+@pytest.mark.parametrize("B,S,L,shuffle", [(4, 3, 6, False), (32, 10, 20, False), (7, 2, 5, True), (64, 4, 9, True)])
+def test_native_packer_equals_the_numpy_packer(B, S, L, shuffle):
+    """csrc/packer.c (lane queues + batch gather in C, libhiertcn_packer.so) against the NumPy / heapq form of the same loader: identical
+    packed batches, slot-list batches, `done` flags and queue lengths over several passes of the split (the walk wraps -- with a fresh
+    permutation when shuffling -- inside a fill; both loaders draw the permutations from the same seeded global RNG state)."""
+    import os
+    from hiertcn_amd import data_loader as DL
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.data_prepare import load_xing
+    if DL._packer_lib() is None:
+        pytest.skip("libhiertcn_packer.so not built (python -m hiertcn_amd.build)")
+    here = os.path.dirname(os.path.abspath(__file__))
+    data = load_xing(os.path.join(here, "golden", "interactions_synth.csv"))
+    n_items = int(data[1][:, 1].max()) + 1
+    args = hier_tcn_args(item_num=n_items, batch_size=B, max_session_num=S, max_activity_len=L, shuffle=shuffle)
+    runs = []
+    for native in (True, False):
+        if not native:
+            os.environ["HIERTCN_PY_PACKER"] = "1"
+        try:
+            np.random.seed(11)
+            ld = DL.Dataloader_hier_model_xing(args, "all", data=data)
+            assert (ld._pk is not None) == native
+            out, dones = [], 0
+            for i in range(60):
+                if i % 3 == 2:
+                    xs, ys, ms, _info = ld.get_batch()
+                    out.append(("slots", [np.asarray(v) for v in xs], [np.asarray(v) for v in ys], [np.asarray(v) for v in ms]))
+                else:
+                    x, y, m, w = ld.get_packed_batch()
+                    out.append(("packed", x, y, m, w))
+                out.append(("state", bool(ld.done), np.asarray(ld.queue_len, np.float64).copy()))
+                dones += int(ld.done)
+            runs.append((out, dones))
+        finally:
+            os.environ.pop("HIERTCN_PY_PACKER", None)
+    (a, da), (b, db) = runs
+    assert da == db and da >= 1          # the split was walked more than once
+    for ea, eb in zip(a, b):
+        assert ea[0] == eb[0]
+        for va, vb in zip(ea[1:], eb[1:]):
+            if isinstance(va, list) and va and isinstance(va[0], np.ndarray):
+                assert len(va) == len(vb) and all(np.array_equal(p, q) and p.dtype == q.dtype for p, q in zip(va, vb))
+            elif isinstance(va, np.ndarray):
+                assert np.array_equal(va, vb) and va.dtype == vb.dtype
+            else:
+                assert va == vb
