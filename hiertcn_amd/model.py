@@ -193,6 +193,7 @@ class HierTCNModel:
         return st
 
     def _pipe_buffers(self, B, W):
+        """Pinned read-back buffers (ranks [B, W], 8 metric sums) + an event, one of three rotating sets per shape."""
         key = (B, W)
         pool = self._pipe_pool.setdefault(key, dict(i=0, bufs=[]))
         if len(pool["bufs"]) < 3:   # (at most two batches are in flight: three sets so that one is always free)
@@ -201,12 +202,35 @@ class HierTCNModel:
         pool["i"] = (pool["i"] + 1) % 3
         return pool["bufs"][pool["i"]]
 
+    def _pipe_upload(self, x, y, mask):
+        """ids and mask to the device through PINNED staging and asynchronous copies.  A pageable `.to(device)` is a blocking copy queued
+        behind everything the stream already holds -- three of them per batch made the host wait for the previous batch's kernels
+        (42 us each, the largest host cost of the loop).  Three rotating sets: a set is reused three batches later, after the result() of
+        the batch that used it has waited for an event recorded behind its copies."""
+        dev = self.engine.device
+        n, nm = x.size, mask.size
+        key = ("up", n, nm)
+        pool = self._pipe_pool.setdefault(key, dict(i=0, bufs=[]))
+        if len(pool["bufs"]) < 3:
+            pool["bufs"].append((torch.empty(2 * n, dtype=torch.int32).pin_memory(), torch.empty(nm, dtype=torch.float32).pin_memory(),
+                                 torch.empty(2 * n, dtype=torch.int32, device=dev), torch.empty(nm, dtype=torch.float32, device=dev)))
+            ih, mh, idv, mdv = pool["bufs"][-1]
+        else:
+            pool["i"] = (pool["i"] + 1) % 3
+            ih, mh, idv, mdv = pool["bufs"][pool["i"]]
+        ihn = ih.numpy()
+        ihn[:n] = x.reshape(-1)
+        ihn[n:] = y.reshape(-1)
+        mh.numpy()[:] = mask.reshape(-1)
+        idv.copy_(ih, non_blocking=True)
+        mdv.copy_(mh, non_blocking=True)
+        return idv[:n].view(x.shape), idv[n:].view(y.shape), mdv.view(mask.shape)
+
     def eval_step_packed_async(self, x, y, mask, lens):
         """Enqueues one evaluation batch (state from / to the device buffers of eval_begin) and returns a PendingEval."""
         eng = self.engine
         B, S, Lmax = x.shape
-        dev = eng.device
-        xd, yd, md = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, y, mask))
+        xd, yd, md = self._pipe_upload(x, y, mask)
         st_in, st_out = self._pipe_state[self._pipe_cur], self._pipe_state[1 - self._pipe_cur]
         out = eng.forward_eval(xd, yd, md, st_in, want_rows=True, state_out=st_out)
         self._pipe_cur ^= 1
@@ -224,9 +248,7 @@ class HierTCNModel:
 
     def train_step_packed_async(self, x, y, mask, lr):
         """One optimizer step with the carried state kept on the device; -> PendingTrain (result(): dict(loss, user_count))."""
-        eng = self.engine
-        dev = eng.device
-        xd, yd, md = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, y, mask))
+        xd, yd, md = self._pipe_upload(x, y, mask)
         st_in, st_out = self._pipe_state[self._pipe_cur], self._pipe_state[1 - self._pipe_cur]
         out = self.train_step_device(xd, yd, md, st_in, lr, state_out=st_out)
         self._pipe_cur ^= 1
