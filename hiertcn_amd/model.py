@@ -67,6 +67,21 @@ class PendingEval:
                     recall10_mean_user=m["recall10"], ranks=rank, user_count=m["user_count"])
 
 
+class PendingEvalNN:
+    """The single-level model's evaluation batch in flight (TcnModel.eval_step_async)."""
+
+    def __init__(self, rank_h, m8_h, event, yi, n_items):
+        self.rank_h, self.m8_h, self.event, self.yi, self.N = rank_h, m8_h, event, yi, n_items
+
+    def result(self):
+        self.event.synchronize()
+        m = metrics_dict(self.m8_h)
+        rank = self.rank_h.numpy().astype(np.float32)
+        return dict(loss=m["loss"], ranks_float_mean_user=m["rank_frac"], ranks_float=rank / float(self.N), mask_y=(self.yi > 0).astype(np.float32),
+                    reciprocal_ranks_float_mean_user=m["mrr"], recall1_mean_user=m["recall1"], recall5_mean_user=m["recall5"],
+                    recall10_mean_user=m["recall10"], ranks=rank, user_count=m["user_count"])
+
+
 class PendingTrain:
     def __init__(self, m8_h, event):
         self.m8_h, self.event = m8_h, event
@@ -357,6 +372,23 @@ class TcnModel:
             hid = eng.tcn_forward(xd.view(B, T), None)
             res["pred"] = eng.score_logits(hid).view(B, T, -1).cpu().numpy()
         return res
+
+    def eval_step_async(self, x, y):
+        """evaluate_nn's fetches with the device left running (as HierTCNModel.eval_step_packed_async: pinned staging, asynchronous copies,
+        read-backs behind an event); -> a pending object whose result() is eval_step's dict."""
+        eng = self.engine
+        xi, yi = _to_ids(x), _to_ids(y)
+        B, T = xi.shape
+        if getattr(self, "_pipe_pool", None) is None:
+            self._pipe_pool = {}
+        dummy = np.zeros(1, np.float32)
+        xd, yd, _md = HierTCNModel._pipe_upload(self, np.ascontiguousarray(xi, np.int32), np.ascontiguousarray(yi, np.int32), dummy)
+        out = eng.forward_eval(xd.view(B, 1, T), yd.view(B, 1, T), None, None, want_rows=True)
+        rank_h, m8_h, ev = HierTCNModel._pipe_buffers(self, B, T)
+        rank_h.copy_(out["rank"].view(B, T), non_blocking=True)
+        m8_h.copy_(out["metrics8"], non_blocking=True)
+        ev.record()
+        return PendingEvalNN(rank_h, m8_h, ev, yi, eng.N)
 
     def train_step(self, x, y, lr):
         """One sess.run([train_op, loss]) of run_nn_xing.py: forward, loss, gradients, [collectives], TF-form Adam."""

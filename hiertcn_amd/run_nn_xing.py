@@ -4,6 +4,7 @@ anything with `eval_step(x, y)` / `train_step(x, y, lr)`).  No state is carried 
 """
 from __future__ import annotations
 
+import os
 import time
 
 from .run_common import EpochMeter, ScalarLog, scheduled_lr
@@ -18,7 +19,29 @@ def evaluate_nn(args, loader, sess, prefix="test", warm_start=None):
     from .distributed import is_main
     meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) and is_main() else None, final_header=False)
     step = None
-    while True:  # :31
+    pipelined = hasattr(model, "eval_step_async") and not os.environ.get("HIERTCN_EVAL_SERIAL")
+    if pipelined:   # the device is left running: batch i is enqueued before the host turns to batch i - 1's ranks and metrics (run_hier_xing.py)
+        pending = None
+        while True:
+            t1 = time.time()
+            batch_x, batch_y, _info = loader.get_batch()
+            done = loader.done
+            t2 = time.time()
+            nxt = model.eval_step_async(batch_x, batch_y)
+            if pending is not None:
+                step = pending.result()
+                meter.add(step)
+            pending = nxt
+            t3 = time.time()
+            time_load += t2 - t1
+            time_run += t3 - t2
+            if done:
+                break
+        t2 = time.time()
+        step = pending.result()
+        meter.add(step)
+        time_run += time.time() - t2
+    while not pipelined:  # :31
         t1 = time.time()
         batch_x, batch_y, _info = loader.get_batch()
         t2 = time.time()

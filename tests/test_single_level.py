@@ -215,4 +215,13 @@ def test_evaluate_nn_hip_vs_oracle(tmp_path):
         assert abs(got[k] - want[k]) < 5e-3, (k, got[k], want[k])
     txt = open(a.log_path + "test/results.txt").read().splitlines()
     assert txt[0].startswith("loss_epoch ") and len(txt) == 3   # evaluate_nn writes no 'final' line (run_nn_xing.py:91-95)
+    # the loop above left the device running (TcnModel.eval_step_async); one blocking call per batch gives the same summary
+    os.environ["HIERTCN_EVAL_SERIAL"] = "1"
+    try:
+        a.log_path = None
+        serial, _, _, _ = evaluate_nn(a, Dataloader_single_level_model_xing(a, "test", data=data), model, prefix="test")
+    finally:
+        os.environ.pop("HIERTCN_EVAL_SERIAL")
+    assert {k: v for k, v in serial.items() if k != "loss_epoch"} == {k: v for k, v in got.items() if k != "loss_epoch"}
+    assert abs(serial["loss_epoch"] - got["loss_epoch"]) <= 1e-6 * abs(got["loss_epoch"])   # (the walk over the table: DESIGN 4.1)
     model.engine.close()
