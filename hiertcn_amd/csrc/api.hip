@@ -565,9 +565,22 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   const int64_t R = n_sessions * L;
   // scan first (it never reads the low level's output: model_hier.py:83-93), then every
   // (user, session) low-level problem is independent.
+  // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): the outputs are zeroed, the rows that do carry a target listed, and
+  // only those scored (a ragged XING batch is mostly padding: slot width = longest session of the slot).
+  int32_t* row_map = reinterpret_cast<int32_t*>(ws + w.map);
+  int32_t* n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
+  float* split = nullptr;
+  if (!(exact && !split16) && so.topk == 0 && score_split_parts(R, h->m.NP, split16 ? 256 : 512) > 1) {
+    split = reinterpret_cast<float*>(ws + w.split);
+    if (!so.target) so.target = reinterpret_cast<float*>(ws + w.tgt);   // the merge needs the target logit
+  }
+  bool compacted = false;
   if (hier) {
     if (exact) HIP_TRY(launch_xsession_pool(h->m, h->x, y_ids, n_sessions, L, pooled, st));
-    else HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
+    else if (session_pool_compact_applies(R)) {   // small batches: the row list rides on the pooling launch (it depends on the ids alone)
+      HIP_TRY(launch_session_pool_compact(h->m, y_ids, n_sessions, L, pooled, row_map, n_valid, so.rank, so.ce, so.target, st));
+      compacted = true;
+    } else HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
     HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
   }
   if (exact && !split16) {   // fp32 end to end: every row is scored on materialised logits; rows without a target come out as 0 / 0 / 0..k-1 there
@@ -584,17 +597,8 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
     HIP_TRY(launch_exact_tcn(h->m, h->x, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<float*>(hidden), ws + w.tcn, st));
   else
     HIP_TRY(launch_tcn_forward(h->m, x_ids, hier ? sproj : nullptr, n_sessions, L, reinterpret_cast<uint16_t*>(hidden), ws + w.tcn, st));
-  // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): zero the outputs, list the rows that do
-  // carry a target and score only those (a ragged XING batch is mostly padding: slot width = longest session of the slot).
-  int32_t* row_map = reinterpret_cast<int32_t*>(ws + w.map);
-  int32_t* n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
-  float* split = nullptr;
-  if (so.topk == 0 && score_split_parts(R, h->m.NP, split16 ? 256 : 512) > 1) {
-    split = reinterpret_cast<float*>(ws + w.split);
-    if (!so.target) so.target = reinterpret_cast<float*>(ws + w.tgt);   // the merge needs the target logit
-  }
   // (the same pass zeroes rank / ce / target of every row: one launch instead of the list's three plus three memsets at XING batch sizes)
-  HIP_TRY(launch_compact_rows(y_ids, R, row_map, n_valid, reinterpret_cast<int32_t*>(ws + w.cscratch), st, so.rank, so.ce, so.target));
+  if (!compacted) HIP_TRY(launch_compact_rows(y_ids, R, row_map, n_valid, reinterpret_cast<int32_t*>(ws + w.cscratch), st, so.rank, so.ce, so.target));
   // a masked row is an all-zero logit row (model.py:105): its ranked list is 0..k-1 with values 0 (loss.py:120 on ties)
   if (so.topk > 0) HIP_TRY(launch_topk_fill(so.topk_idx, so.topk_val, R, so.topk, st));
   int rc = score_timed(h, hidden, y_ids, R, &so, st, row_map, n_valid, split);

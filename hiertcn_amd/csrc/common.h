@@ -104,6 +104,9 @@ hipError_t launch_transpose_to_bf16(const float* src, uint16_t* dst, int64_t row
 hipError_t launch_transpose_f32(const float* src, float* dst, int64_t rows, int64_t cols, hipStream_t st);
 hipError_t launch_copy_pad_f32(const float* src, float* dst, int64_t n, int64_t npad, float padval, hipStream_t st);
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st);
+bool session_pool_compact_applies(int64_t R);
+hipError_t launch_session_pool_compact(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, int32_t* map, int32_t* n_valid,
+                                       int32_t* z0, float* z1, float* z2, hipStream_t st);
 size_t gru_workspace_bytes(const ModelDev& m, int B, int S);
 int gru_persist_groups(const ModelDev& m, int B, int S, bool saving);
 // the scan's backward (train.hip) as one persistent launch: da_c / [da_r | da_z] of every (slot, layer) into dac_all / dag_all, d pooled

@@ -14,9 +14,58 @@
 // session mean-pool: one wave per session.  HBM/L2-bound row gather: each 16-byte lane load
 // covers 8 bf16 channels; E/8 lanes cover a row, 64/(E/8) rows are in flight per instruction.
 // ---------------------------------------------------------------------------------------------
+// Small batches (round 4): the list of rows that carry a target (metrics.hip, k_compact_small: ascending row numbers with y > 0, their count, and the
+// zero fill of the scoring outputs) depends on the ids alone, so it rides on this launch as ONE EXTRA WORKGROUP instead of being a launch of its own
+// in front of the scoring kernel (7 us + a boundary of a 0.23 ms batch).  256 threads, four rows each per pass.
+struct PoolCompact { const int32_t* y; int R; int32_t* map; int32_t* n_valid; int32_t* z0; float* z1; float* z2; };
+__device__ void compact_block(const PoolCompact pc) {
+  __shared__ int wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int base = 0;
+  for (int r0 = 0; r0 < pc.R; r0 += 1024) {
+    const int r = r0 + 4 * tid;
+    int f[4], c = 0;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      f[j] = (r + j < pc.R) ? (pc.y[r + j] > 0 ? 1 : 0) : 0;
+      c += f[j];
+      if (r + j < pc.R) {
+        if (pc.z0) pc.z0[r + j] = 0;
+        if (pc.z1) pc.z1[r + j] = 0.f;
+        if (pc.z2) pc.z2[r + j] = 0.f;
+      }
+    }
+    int incl = c;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+      const int v = __shfl_up(incl, d);
+      incl += (lane >= d) ? v : 0;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int off = base, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; w++) {
+      off += (w < wave) ? wsum[w] : 0;
+      tot += wsum[w];
+    }
+    int pos = off + incl - c;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+      if (f[j]) pc.map[pos++] = r + j;
+    base += tot;
+    __syncthreads();
+  }
+  if (tid == 0) pc.n_valid[0] = base;
+}
+
 __global__ __launch_bounds__(256) void k_session_pool(const uint16_t* __restrict__ emb, const float* __restrict__ emb_bias,
                                                       const int32_t* __restrict__ y, int64_t n_sessions, int L, int E, int N,
-                                                      float* __restrict__ pooled) {
+                                                      float* __restrict__ pooled, const PoolCompact pc) {
+  if (pc.map && blockIdx.x == gridDim.x - 1) {   // (uniform per workgroup)
+    compact_block(pc);
+    return;
+  }
   const int lane = threadIdx.x & 63;
   const int64_t sess = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (sess >= n_sessions) return;
@@ -66,7 +115,21 @@ __global__ __launch_bounds__(256) void k_session_pool(const uint16_t* __restrict
 hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st) {
   if (n_sessions <= 0) return hipSuccess;
   unsigned blocks = (unsigned)((n_sessions + 3) / 4);
-  hipLaunchKernelGGL(k_session_pool, dim3(blocks), dim3(256), 0, st, m.emb, m.emb_bias, y, n_sessions, L, m.E, m.N, pooled);
+  PoolCompact pc;
+  memset(&pc, 0, sizeof(pc));
+  hipLaunchKernelGGL(k_session_pool, dim3(blocks), dim3(256), 0, st, m.emb, m.emb_bias, y, n_sessions, L, m.E, m.N, pooled, pc);
+  return hipGetLastError();
+}
+
+// the same launch + the row compaction of launch_compact_rows (map, n_valid, zero-filled z0 / z1 / z2) as one extra workgroup; R <= 8192 rows
+bool session_pool_compact_applies(int64_t R) { return R > 0 && R <= 8192 && !getenv("HIERTCN_POOL_COMPACT_OFF"); }
+hipError_t launch_session_pool_compact(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, int32_t* map, int32_t* n_valid,
+                                       int32_t* z0, float* z1, float* z2, hipStream_t st) {
+  if (n_sessions <= 0) return hipSuccess;
+  unsigned blocks = (unsigned)((n_sessions + 3) / 4);
+  PoolCompact pc;
+  pc.y = y; pc.R = (int)(n_sessions * L); pc.map = map; pc.n_valid = n_valid; pc.z0 = z0; pc.z1 = z1; pc.z2 = z2;
+  hipLaunchKernelGGL(k_session_pool, dim3(blocks + 1), dim3(256), 0, st, m.emb, m.emb_bias, y, n_sessions, L, m.E, m.N, pooled, pc);
   return hipGetLastError();
 }
 
