@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhiertcn_gfx950.so")
-SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_grad.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "lgru_tile.hip", "lgru_pipe.hip"]
+SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_grad.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "lgru_tile.hip", "lgru_pipe.hip", "lgru_wide.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Wno-shift-negative-value",
          "-fno-gpu-rdc", "-D__HIP_PLATFORM_AMD__"]
 

@@ -169,6 +169,11 @@ bool lgru_pipe_applies(const ModelDev& m, int64_t n_sess);
 size_t lgru_pipe_bytes(const ModelDev& m, int64_t n_sess, int L);
 hipError_t launch_lgru_pipe(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
                             void* scratch, hipStream_t st);
+// lgru_wide.hip: H = 256: eight workgroups per (tile, layer), units and reduction split so that the weights stay in registers
+bool lgru_wide_applies(const ModelDev& m, int64_t n_sess);
+size_t lgru_wide_bytes(const ModelDev& m, int64_t n_sess, int L);
+hipError_t launch_lgru_wide(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
+                            void* scratch, hipStream_t st);
 hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
                             hipStream_t st);
 // gru_persist.hip: the HierGRU low level of small evaluation batches as one persistent launch

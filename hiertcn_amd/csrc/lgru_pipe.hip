@@ -406,6 +406,7 @@ bool lgru_pipe_applies(const ModelDev& m, int64_t n_sess) {
 
 // bytes of the exchange slots + flags (0: the pipelined launch does not apply)
 size_t lgru_pipe_bytes(const ModelDev& m, int64_t n_sess, int L) {
+  if (m.H == 256) return lgru_wide_bytes(m, n_sess, L);   // (lgru_wide.hip takes that width: the same scratch pointer carries its slots)
   if (n_sess <= 0 || (n_sess + 31) / 32 * m.nl > 256 || !(m.H == 64 || m.H == 128) || m.E != m.H || m.nl > 2) return 0;
   const size_t tiles = (size_t)(n_sess + 31) / 32;
   const size_t x = (size_t)(m.nl - 1) * L * 2 * (size_t)n_sess * m.H * 2;

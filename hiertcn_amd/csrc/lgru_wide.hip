@@ -1,0 +1,320 @@
+// HierGRU low level of small batches at H = 256 (round 4; model_gru.py:47-55, customed_gru_cell.py:309-337): register-resident weights as in
+// lgru_pipe.hip, with a layer's units AND its reduction split so that they fit.
+//
+// At H = 256 a layer's weights are 6 H^2 x 4 bytes (hi + lo) = 1.5 MB: lgru_tile.hip streams them from the L2 for every cell (34 us per cell,
+// 10 workgroups of 40 sequential cells per 320-session batch = 0.85 ms), and one CU's register file holds a quarter of a megabyte.  Here a
+// (32-session tile, layer) is EIGHT workgroups: workgroup p owns unit block p (32 units: its r, z and candidate tiles, 196 KB of fragments), and its
+// four waves split the REDUCTION -- wave w keeps k-steps [8 w, 8 w + 8) of the three tiles, 192 registers, loaded once -- so a cell is 72
+// MFMAs per wave, a reduction of the four partial tiles through LDS, and an epilogue on four units per lane.  What crosses workgroups per cell
+// (inside the launch, drained-`sc1` hand-offs as in lgru_pipe.hip, one arrival counter per (layer, tile, step, phase)):
+//   phase 1: r * h of the own 32 units (split 16-bit rows) -> the layer's 8 workgroups (the candidate's recurrent half needs all 256);
+//   phase 2: the new state of the own 32 units -> the layer's 8 workgroups (the next step's recurrent half) and the 8 of the layer above (its input).
+// Layers run pipelined (layer l + 1 of step t beside layer l of step t + 1).  At most 256 workgroups, all resident (tiles x layers x 8 <= CUs);
+// every wait is bounded and a time-out sets the handle's persistent-launch word.  Same split-operand arithmetic as the other HierGRU kernels
+// (a.w = a_hi w_hi + a_lo w_hi + a_hi w_lo, fp32 accumulation); the sum over k is formed as four partial sums, so results equal lgru_tile.hip's up
+// to fp32 summation order (a storage-type ulp in a handful of outputs).
+#include <stdlib.h>
+#include <string.h>
+
+#include "common.h"
+
+#define LW_THREADS 256
+#define LW_PARTS 8
+#define LW_SPIN_MAX (1u << 22)
+
+struct LgruWideArgs {
+  const uint16_t* u16;                       // [M][L][E] projected [e, state] rows, storage type
+  const int32_t* seq_len;                    // [M]
+  const uint16_t* wgF_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wgF_lo[HIERTCN_MAX_LAYERS];   // [2H/32][K/16][64][8]
+  const uint16_t* wcF_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wcF_lo[HIERTCN_MAX_LAYERS];   // [H/32][K/16][64][8]
+  const float* bg[HIERTCN_MAX_LAYERS]; const float* bc[HIERTCN_MAX_LAYERS];
+  uint16_t* hidden;                          // [M * L][H]: the top layer's outputs, zero past the length
+  float* states;                             // training: [(L + 1)][M][HT]; null in evaluation
+  float* rec;                                // training: per (t, l): gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
+  uint16_t* hx;                              // [nl][L][2 (hi, lo)][M][H]: the state rows of (layer, step)
+  uint16_t* rx;                              // [nl][L][2][M][H]: r * h rows
+  int* cnt;                                  // [nl][tiles][L][2]: workgroups that have published phase 1 / phase 2 of (layer, tile, step)
+  unsigned long long* err;
+  int M, L, HT, nl;
+};
+
+__device__ __forceinline__ float lw_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
+__device__ __forceinline__ float lw_tanh(float x) { return 1.0f - 2.0f * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(2.8853900817779268f * x)); }
+__device__ __forceinline__ void lw_split(float v, uint16_t& hi, uint16_t& lo) {
+  hi = f2bf(v);
+  lo = f2bf(v - bf2f(hi));
+}
+
+__global__ __launch_bounds__(LW_THREADS, 1) void k_lgru_wide(const LgruWideArgs a) {
+  constexpr int H = 256, HB = 8, KS = 32, KSI = 16, KW = KS / 4;   // k-steps per wave and tile
+  constexpr int PITCH = 2 * H + 16;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_dead;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nl = a.nl, L = a.L, M = a.M, HT = a.HT;
+  const int tile = (int)blockIdx.x, p = (int)blockIdx.y, l = (int)blockIdx.z, tiles = (int)gridDim.x;
+  const int64_t sess0 = (int64_t)tile * 32;
+  const int64_t sess = sess0 + lr;
+  const bool live = sess < M;
+  const int64_t sc = live ? sess : (int64_t)M - 1;
+  const int len = a.seq_len[sc];
+  const bool first = l == 0, last = l == nl - 1;
+
+  unsigned char* XH = smem;                        // [32][PITCH] the layer's input rows of step t, hi parts (layer 0: the projected rows, no lo part)
+  unsigned char* XL = XH + 32 * PITCH;
+  unsigned char* SH = XL + 32 * PITCH;             // the layer's state before step t
+  unsigned char* SL = SH + 32 * PITCH;
+  unsigned char* RHh = SL + 32 * PITCH;            // r * h of step t
+  unsigned char* RHl = RHh + 32 * PITCH;
+  float* RED = reinterpret_cast<float*>(RHl + 32 * PITCH);   // [2 tiles][4 waves][16][64] partial accumulators
+  for (int i = tid; i < 2 * 32 * PITCH / 16; i += LW_THREADS) reinterpret_cast<uint4*>(SH)[i] = make_uint4(0, 0, 0, 0);   // zero_state
+  if (tid == 0) s_dead = 0;
+
+  // ---- this wave's share of the layer's weights, once: tiles r, z, candidate of unit block p, k-steps [KW wave, KW wave + KW)
+  uint4 Wh[3][KW], Wl[3][KW];
+#pragma unroll
+  for (int sel = 0; sel < 3; sel++) {
+    const size_t T = (size_t)((sel == 1 ? HB : 0) + p);
+    const uint16_t* th = (sel < 2 ? a.wgF_hi[l] : a.wcF_hi[l]) + ((T * KS + (size_t)KW * wave) * 64 + lane) * 8;
+    const uint16_t* tl = (sel < 2 ? a.wgF_lo[l] : a.wcF_lo[l]) + ((T * KS + (size_t)KW * wave) * 64 + lane) * 8;
+#pragma unroll
+    for (int i = 0; i < KW; i++) {
+      Wh[sel][i] = *reinterpret_cast<const uint4*>(th + (size_t)i * 512);
+      Wl[sel][i] = *reinterpret_cast<const uint4*>(tl + (size_t)i * 512);
+    }
+  }
+#pragma unroll
+  for (int sel = 0; sel < 3; sel++)
+#pragma unroll
+    for (int i = 0; i < KW; i++) {   // opaque: keep them in registers (lgru_pipe.hip: hipcc would re-load read-only fragments at every use)
+      asm volatile("" : "+v"(Wh[sel][i].x), "+v"(Wh[sel][i].y), "+v"(Wh[sel][i].z), "+v"(Wh[sel][i].w));
+      asm volatile("" : "+v"(Wl[sel][i].x), "+v"(Wl[sel][i].y), "+v"(Wl[sel][i].z), "+v"(Wl[sel][i].w));
+    }
+  const int unit0 = 32 * p + 8 * wave + 4 * lh;    // this lane's four units (of its session) behind the reduction: accumulator registers 4 wave .. 4 wave + 3
+  float bias_r[4], bias_z[4], bias_c[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) { bias_r[j] = a.bg[l][unit0 + j]; bias_z[j] = a.bg[l][H + unit0 + j]; bias_c[j] = a.bc[l][unit0 + j]; }
+  float hreg[4] = {0.f, 0.f, 0.f, 0.f};
+
+  const size_t slot = (size_t)2 * M * H;           // 16-bit elements of one (layer, step) slot: hi rows, then lo rows
+  auto cnt_of = [&](int ll, int t, int ph) { return a.cnt + (((size_t)ll * tiles + tile) * L + t) * 2 + ph; };
+  auto wait_for = [&](int* c) {   // one lane, bounded; the caller's barrier follows
+    unsigned spins = 0;
+    while (!s_dead && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < LW_PARTS) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > LW_SPIN_MAX) {
+        __hip_atomic_store(a.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_dead = 1;
+      }
+    }
+  };
+  // 32 rows x 256 units of a slot (hi and lo parts) -> two LDS buffers; agent-scope 8-byte loads the compiler can see
+  auto gather = [&](const uint16_t* src, unsigned char* dh, unsigned char* dl) {
+    unsigned long long vh[8], vl[8];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = tid + k * LW_THREADS;          // chunk of 16 bytes: row = c / 32, chunk = c % 32
+      const int row = c >> 5, ch = c & 31;
+      const int64_t s = (sess0 + row < M) ? sess0 + row : (int64_t)M - 1;
+      const unsigned long long* ph = reinterpret_cast<const unsigned long long*>(src + (size_t)s * H + ch * 8);
+      const unsigned long long* pl = reinterpret_cast<const unsigned long long*>(src + (size_t)M * H + (size_t)s * H + ch * 8);
+      vh[2 * k] = __hip_atomic_load(ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vh[2 * k + 1] = __hip_atomic_load(ph + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vl[2 * k] = __hip_atomic_load(pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      vl[2 * k + 1] = __hip_atomic_load(pl + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int c = tid + k * LW_THREADS;
+      const int row = c >> 5, ch = c & 31;
+      *reinterpret_cast<unsigned long long*>(dh + row * PITCH + ch * 16) = vh[2 * k];
+      *reinterpret_cast<unsigned long long*>(dh + row * PITCH + ch * 16 + 8) = vh[2 * k + 1];
+      *reinterpret_cast<unsigned long long*>(dl + row * PITCH + ch * 16) = vl[2 * k];
+      *reinterpret_cast<unsigned long long*>(dl + row * PITCH + ch * 16 + 8) = vl[2 * k + 1];
+    }
+  };
+  // this lane's four values (units unit0 .. + 3 of its session), split, to a slot: 8 bytes hi + 8 bytes lo, write-through
+  auto publish = [&](uint16_t* dst, const float* v4) {
+    uint16_t hi[4], lo[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) lw_split(v4[j], hi[j], lo[j]);
+    if (live) {
+      const unsigned long long ph = (unsigned long long)hi[0] | ((unsigned long long)hi[1] << 16) | ((unsigned long long)hi[2] << 32) | ((unsigned long long)hi[3] << 48);
+      const unsigned long long pl = (unsigned long long)lo[0] | ((unsigned long long)lo[1] << 16) | ((unsigned long long)lo[2] << 32) | ((unsigned long long)lo[3] << 48);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + (size_t)sess * H + unit0), ph, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(reinterpret_cast<unsigned long long*>(dst + (size_t)M * H + (size_t)sess * H + unit0), pl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  };
+  auto arrive = [&](int* c) {   // every wave's stores have completed, then ONE add for the workgroup
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) __hip_atomic_fetch_add(c, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  // this wave's KW k-steps of one tile: k-steps [KW wave, ..) lie in the input half for waves 0, 1 and in the second half (state / r * h) for waves 2, 3
+  const bool in_half = wave < 2;
+  const int ks0 = (KW * wave) % KSI;
+  auto partial = [&](int sel, const unsigned char* h2, const unsigned char* l2) -> f32x16 {
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.f;
+    const unsigned char* bh = in_half ? XH : h2;
+    const unsigned char* bl = in_half ? XL : l2;
+    const bool has_lo = !(in_half && first);
+#pragma unroll
+    for (int i = 0; i < KW; i++) {
+      const int ko = (ks0 + i) * 32 + lh * 16;
+      const uint4 qh = *reinterpret_cast<const uint4*>(bh + lr * PITCH + ko);
+      acc = mfma32(Wh[sel][i], qh, acc);
+      acc = mfma32(Wl[sel][i], qh, acc);
+      if (has_lo) {
+        const uint4 ql = *reinterpret_cast<const uint4*>(bl + lr * PITCH + ko);
+        acc = mfma32(Wh[sel][i], ql, acc);
+      }
+    }
+    return acc;
+  };
+  auto red_put = [&](int slot_i, const f32x16& acc) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) RED[((slot_i * 4 + wave) * 16 + i) * 64 + lane] = acc[i];
+  };
+  auto red_get = [&](int slot_i, const float* bias, float* out4) {   // registers 4 wave .. 4 wave + 3, the four partial tiles in wave order
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float v = bias[j];
+#pragma unroll
+      for (int w = 0; w < 4; w++) v += RED[((slot_i * 4 + w) * 16 + 4 * wave + j) * 64 + lane];
+      out4[j] = v;
+    }
+  };
+  __syncthreads();
+
+  const size_t cellf = (size_t)M * 5 * H;
+  for (int t = 0; t < L; t++) {
+    const bool active = t < len;
+    float* rec = a.rec ? a.rec + ((size_t)t * nl + l) * cellf : nullptr;
+    // ---------------- inputs of the cell: the layer's input rows of step t, the layer's state after step t - 1
+    if (tid == 0) {
+      if (!first) wait_for(cnt_of(l - 1, t, 1));
+      if (t > 0) wait_for(cnt_of(l, t - 1, 1));
+    }
+    __syncthreads();
+    if (first) {
+#pragma unroll
+      for (int k = 0; k < 4; k++) {   // projected rows: 32 x 32 chunks of 16 bytes, plain loads
+        const int c = tid + k * LW_THREADS;
+        const int row = c >> 5, ch = c & 31;
+        const int64_t s = (sess0 + row < M) ? sess0 + row : (int64_t)M - 1;
+        *reinterpret_cast<uint4*>(XH + row * PITCH + ch * 16) = *reinterpret_cast<const uint4*>(a.u16 + ((size_t)s * L + t) * H + ch * 8);
+      }
+    } else {
+      gather(a.hx + ((size_t)(l - 1) * L + t) * slot, XH, XL);
+    }
+    if (t > 0) gather(a.hx + ((size_t)l * L + (t - 1)) * slot, SH, SL);
+    __syncthreads();
+    // ---------------- gates: partial r and z tiles, reduction, epilogue on this lane's four units
+    {
+      const f32x16 pr = partial(0, SH, SL);
+      red_put(0, pr);
+      const f32x16 pz = partial(1, SH, SL);
+      red_put(1, pz);
+    }
+    __syncthreads();
+    float r4[4], z4[4], rh4[4];
+    red_get(0, bias_r, r4);
+    red_get(1, bias_z, z4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      r4[j] = lw_sigmoid(r4[j]);
+      z4[j] = lw_sigmoid(z4[j]);
+      rh4[j] = r4[j] * hreg[j];
+    }
+    publish(a.rx + ((size_t)l * L + t) * slot, rh4);
+    if (rec && live) {
+      *reinterpret_cast<float4*>(rec + sess * 2 * H + unit0) = make_float4(r4[0], r4[1], r4[2], r4[3]);
+      *reinterpret_cast<float4*>(rec + sess * 2 * H + H + unit0) = make_float4(z4[0], z4[1], z4[2], z4[3]);
+      *reinterpret_cast<float4*>(rec + (size_t)M * 2 * H + sess * H + unit0) = make_float4(rh4[0], rh4[1], rh4[2], rh4[3]);
+    }
+    arrive(cnt_of(l, t, 0));
+    // ---------------- candidate: r * h of all 256 units, partial tile, reduction, blend
+    if (tid == 0) wait_for(cnt_of(l, t, 0));
+    __syncthreads();
+    gather(a.rx + ((size_t)l * L + t) * slot, RHh, RHl);
+    __syncthreads();
+    {
+      const f32x16 pc = partial(2, RHh, RHl);
+      red_put(0, pc);
+    }
+    __syncthreads();
+    float c4[4], hn[4], st4[4];
+    red_get(0, bias_c, c4);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      c4[j] = lw_tanh(c4[j]);
+      hn[j] = z4[j] * hreg[j] + (1.0f - z4[j]) * c4[j];
+      st4[j] = active ? hn[j] : hreg[j];   // dynamic_rnn past the session's length: state through, output zero (model_gru.py:47-53)
+      hreg[j] = st4[j];
+    }
+    publish(a.hx + ((size_t)l * L + t) * slot, st4);
+    if (live) {
+      if (rec) {
+        *reinterpret_cast<float4*>(rec + (size_t)M * 3 * H + sess * H + unit0) = make_float4(c4[0], c4[1], c4[2], c4[3]);
+        *reinterpret_cast<float4*>(rec + (size_t)M * 4 * H + sess * H + unit0) = make_float4(hn[0], hn[1], hn[2], hn[3]);
+        *reinterpret_cast<float4*>(a.states + ((size_t)(t + 1) * M + sess) * HT + (size_t)l * H + unit0) = make_float4(st4[0], st4[1], st4[2], st4[3]);
+      }
+      if (last) {
+        uint2 o;
+        o.x = active ? pack2bf(hn[0], hn[1]) : 0u;
+        o.y = active ? pack2bf(hn[2], hn[3]) : 0u;
+        *reinterpret_cast<uint2*>(a.hidden + (sess * L + t) * H + unit0) = o;
+      }
+    }
+    arrive(cnt_of(l, t, 1));   // (its barrier also closes the cell: RED, X, S, RH are free for the next one)
+  }
+}
+
+static size_t lw_lds_bytes() { return 6 * 32 * (2 * 256 + 16) + 2 * 4 * 16 * 64 * sizeof(float); }
+
+bool lgru_wide_applies(const ModelDev& m, int64_t n_sess) {
+  const char* sw = getenv("HIERTCN_LGRU_WIDE");   // "0": never (A/B runs, tests; read on every call)
+  if (sw && sw[0] == '0') return false;
+  const char* chain = getenv("HIERTCN_LGRU_CHAIN");   // "1": set by the shared-GPU guard (distributed.py): no launch that waits on other workgroups
+  if (chain && chain[0] == '1') return false;
+  if (!lgru_tile_applies(m, n_sess) || m.H != 256 || m.gru_bar == nullptr) return false;
+  const int64_t tiles = (n_sess + 31) / 32;
+  return tiles * m.nl * LW_PARTS <= (m.n_cu > 0 ? m.n_cu : 256);   // every workgroup resident at once
+}
+
+// bytes of the exchange slots + counters (0: the launch does not apply at this size)
+size_t lgru_wide_bytes(const ModelDev& m, int64_t n_sess, int L) {
+  if (n_sess <= 0 || m.H != 256 || m.E != m.H || m.nl > 2 || (n_sess + 31) / 32 * m.nl * LW_PARTS > 256) return 0;
+  const size_t tiles = (size_t)(n_sess + 31) / 32;
+  const size_t x = (size_t)m.nl * L * 2 * (size_t)n_sess * m.H * 2;
+  return 2 * ((x + 255) & ~(size_t)255) + ((tiles * m.nl * L * 2 * 4 + 255) & ~(size_t)255);
+}
+
+hipError_t launch_lgru_wide(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
+                            void* scratch, hipStream_t st) {
+  LgruWideArgs a;
+  memset(&a, 0, sizeof(a));
+  a.u16 = u16; a.seq_len = seq_len; a.hidden = hidden; a.states = states; a.rec = rec;
+  for (int l = 0; l < m.nl; l++) {
+    a.wgF_hi[l] = m.lgru_wgF_hi[l]; a.wgF_lo[l] = m.lgru_wgF_lo[l]; a.wcF_hi[l] = m.lgru_wcF_hi[l]; a.wcF_lo[l] = m.lgru_wcF_lo[l];
+    a.bg[l] = m.lgru_bg[l]; a.bc[l] = m.lgru_bc[l];
+  }
+  a.M = (int)n_sess; a.L = L; a.HT = m.HT; a.nl = m.nl;
+  const unsigned tiles = (unsigned)((n_sess + 31) / 32);
+  const size_t xbytes = (((size_t)m.nl * L * 2 * (size_t)n_sess * m.H * 2) + 255) & ~(size_t)255;
+  unsigned char* s = reinterpret_cast<unsigned char*>(scratch);
+  a.hx = reinterpret_cast<uint16_t*>(s);
+  a.rx = reinterpret_cast<uint16_t*>(s + xbytes);
+  a.cnt = reinterpret_cast<int*>(s + 2 * xbytes);
+  a.err = reinterpret_cast<unsigned long long*>(m.gru_bar) + 8 * 16;   // (gru_persist.hip: the word behind the 8 group counters)
+  hipError_t e;
+  if ((e = hipMemsetAsync(a.cnt, 0, (size_t)tiles * m.nl * L * 2 * 4, st)) != hipSuccess) return e;
+  const size_t lds = lw_lds_bytes();
+  if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+  hipLaunchKernelGGL(k_lgru_wide, dim3(tiles, LW_PARTS, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+  return hipGetLastError();
+}

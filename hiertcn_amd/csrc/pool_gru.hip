@@ -534,6 +534,8 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
   }
   if (!b.hidden32 && lgru_tile_applies(m, n_sess)) {   // small batches: one workgroup per 32 sessions through every step and layer (lgru_tile.hip); training keeps the records
     if (b.keep_all && (e = hipMemsetAsync(b.states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // slot 0 of the kept states: the zero state the backward pass reads at t = 0
+    if (b.pipe && lgru_wide_applies(m, n_sess))   // H = 256: eight workgroups per (tile, layer), weights resident in registers (lgru_wide.hip)
+      return launch_lgru_wide(m, b.u16, b.seq_len, n_sess, L, hidden, b.keep_all ? b.states : nullptr, b.keep_all ? b.rec : nullptr, b.pipe, st);
     if (b.pipe && lgru_pipe_applies(m, n_sess))   // H <= 128: one workgroup per (tile, layer), weights resident in registers (lgru_pipe.hip)
       return launch_lgru_pipe(m, b.u16, b.seq_len, n_sess, L, hidden, b.keep_all ? b.states : nullptr, b.keep_all ? b.rec : nullptr, b.pipe, st);
     return launch_lgru_tile(m, b.u16, b.seq_len, n_sess, L, hidden, b.keep_all ? b.states : nullptr, b.keep_all ? b.rec : nullptr, st);

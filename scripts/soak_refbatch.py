@@ -19,7 +19,7 @@ x = np.zeros_like(ids); x[..., 1:] = ids[..., :-1]
 mask = (rng.random((B, S)) > 0.15).astype(np.float32)
 xs, ys, ms = (torch.as_tensor(v).cuda().contiguous() for v in (x.astype(np.int32), ids.astype(np.int32), mask))
 bad = 0
-for low, d, dtype in (("tcn", 256, None), ("gru", 128, None), ("gru", 64, None), ("tcn", 256, "split16")):
+for low, d, dtype in (("tcn", 256, None), ("gru", 128, None), ("gru", 64, None), ("gru", 256, None), ("tcn", 256, "split16")):
     args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B, model_low_type=low)
     eng = Engine(args, hier=True, train=dtype is None, **({"dtype": dtype} if dtype else {}))
     eng.set_weights(init_params(args, seed=2))

@@ -301,13 +301,16 @@ def test_persistent_low_level_matches_the_launch_chain_and_the_oracle(d, nl, B, 
     assert not np.array_equal(one32, chain32)                      # two different kernels did run (fp32 dot products in another summation order)
 
 
-@pytest.mark.parametrize("d,nl,B,S,L", [(64, 2, 13, 3, 9), (128, 1, 7, 3, 20), (128, 2, 32, 10, 20), (128, 2, 41, 5, 11)])
+@pytest.mark.parametrize("d,nl,B,S,L", [(64, 2, 13, 3, 9), (128, 1, 7, 3, 20), (128, 2, 32, 10, 20), (128, 2, 41, 5, 11),
+                                        (256, 2, 32, 10, 20), (256, 1, 9, 3, 7), (256, 2, 11, 5, 9)])
 def test_layer_pipelined_low_level_matches_the_session_tile_kernel(d, nl, B, S, L):
     """H <= 128: one workgroup per (32-session tile, LAYER) with the layer's weights resident in registers and the layers handing their state
     rows over through global slots + flags inside ONE launch (csrc/lgru_pipe.hip); HIERTCN_LGRU_PIPE=0 keeps the session-tile kernel (all layers in
     one workgroup, no hand-off).  Same arithmetic: the rows may differ by a storage-type ulp where the compiler contracted the blend differently
     (a handful per launch); zeros past sequence_length identical; 30 repeated launches of the pipelined kernel are bitwise identical to the first
-    (a hand-off read too early or torn would show as a difference); the time-out word stays clear."""
+    (a hand-off read too early or torn would show as a difference); the time-out word stays clear.  d = 256: csrc/lgru_wide.hip -- eight
+    workgroups per (tile, layer), each keeping one unit block's weights with the reduction split over its four waves, two all-to-all hand-offs per
+    cell (HIERTCN_LGRU_WIDE=0: the tile kernel); its sums over k are four partial sums, so a few more one-ulp differences are allowed."""
     import os
     from hiertcn_amd.engine import Engine
     N = 900
@@ -327,19 +330,21 @@ def test_layer_pipelined_low_level_matches_the_session_tile_kernel(d, nl, B, S, 
         torch.cuda.synchronize()
         return h.view(torch.int16).cpu().numpy().copy()
 
-    assert os.environ.get("HIERTCN_LGRU_PIPE") is None
+    assert os.environ.get("HIERTCN_LGRU_PIPE") is None and os.environ.get("HIERTCN_LGRU_WIDE") is None
     pipe = rows()
     for _ in range(30):
         assert np.array_equal(rows(), pipe)
     os.environ["HIERTCN_LGRU_PIPE"] = "0"
+    os.environ["HIERTCN_LGRU_WIDE"] = "0"
     try:
         tile = rows()
     finally:
         os.environ.pop("HIERTCN_LGRU_PIPE")
+        os.environ.pop("HIERTCN_LGRU_WIDE")
     assert not eng.persistent_timed_out()
     eng.close()
     assert np.array_equal(pipe == 0, tile == 0)
     a = torch.from_numpy(pipe).view(torch.bfloat16).float().numpy()
     b = torch.from_numpy(tile).view(torch.bfloat16).float().numpy()
     diff = np.abs(a - b)
-    assert (diff > 0).mean() < 2e-3 and diff.max() <= 2.0 ** -8   # |h| < 1: one storage-type ulp at most
+    assert (diff > 0).mean() < (2e-2 if d == 256 else 2e-3) and diff.max() <= 2.0 ** -8   # |h| < 1: one storage-type ulp at most
