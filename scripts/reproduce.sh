@@ -10,8 +10,8 @@ echo "== ragged sessions (lengths ~ U{1..30})"; python3 bench.py --ragged --no-c
 import sys, json; b = json.loads(sys.stdin.read()); print(f\"{b['value']:.0f} sessions/s\")"
 echo "== reference batching (32 lanes x 10 x <=20, XING catalogue)"; python3 scripts/cfg2_bench.py 2>&1 | tail -2
 echo "== reference batching, HierGRU (the reference's default low level): d = 256, 128 (the reference's default width), 64; then the launch chain it replaces"
-for d in 256 128 64; do D=$d LOW=gru python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1 | sed "s/^/d=$d (128, 64: layer-pipelined launch; 256: session tiles): /"; done
-for d in 128 64; do D=$d LOW=gru HIERTCN_LGRU_PIPE=0 python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1 | sed "s/^/d=$d session tiles: /"; done
+for d in 256 128 64; do D=$d LOW=gru python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1 | sed "s/^/d=$d (128, 64: lgru_pipe; 256: lgru_wide): /"; done
+for d in 256 128 64; do D=$d LOW=gru HIERTCN_LGRU_PIPE=0 HIERTCN_LGRU_WIDE=0 python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1 | sed "s/^/d=$d session tiles: /"; done
 echo "== reference batching before this round's small-batch forms (k_tcn_fused four sessions per workgroup, host-sized catalogue split, two-block scoring shape)"
 HIERTCN_TCN_GS2_MAX=0 HIERTCN_SCORE_DYN_OFF=1 python3 scripts/cfg2_bench.py 2>&1 | tail -2 | head -1
 echo "== reference batching in the parity-grade modes (split16, fp32)"; for t in split16 fp32; do DTYPE=$t python3 scripts/cfg2_bench.py 32 100 2>&1 | tail -2 | head -1 | sed "s/^/$t: /"; done
@@ -36,7 +36,7 @@ HIERTCN_TRAIN_LEGACY=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
 echo "== training step at the reference's OWN batch (32 lanes x 10 slots x 20 steps, XING catalogue): HierTCN d = 256, HierGRU d = 128; then with the launch chains / unsplit small-batch kernels of round 3"
 for cfg in "D=256" "D=128 LOW=gru"; do env N=20778 S=10 L=20 $cfg python3 scripts/train_bench.py 32 30 ragged 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done
-for cfg in "D=256" "D=128 LOW=gru"; do env N=20778 S=10 L=20 HIERTCN_SGRAD_DYN_OFF=1 HIERTCN_SGRAD0_SLABS_OFF=1 HIERTCN_GRU_TRAIN_CHAIN=1 HIERTCN_GRU_BPTT_CHAIN=1 HIERTCN_GRU_BPTT_UNFUSED=1 HIERTCN_GEMM_NO_BATCH=1 HIERTCN_LGRU_PIPE=0 HIERTCN_LGRU_REFRESH_UNFUSED=1 $cfg python3 scripts/train_bench.py 32 30 ragged 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg, previous forms: /"; done
+for cfg in "D=256" "D=128 LOW=gru"; do env N=20778 S=10 L=20 HIERTCN_SGRAD_DYN_OFF=1 HIERTCN_SGRAD0_SLABS_OFF=1 HIERTCN_GRU_TRAIN_CHAIN=1 HIERTCN_GRU_BPTT_CHAIN=1 HIERTCN_GRU_BPTT_UNFUSED=1 HIERTCN_GEMM_NO_BATCH=1 HIERTCN_LGRU_PIPE=0 HIERTCN_LGRU_WIDE=0 HIERTCN_LGRU_REFRESH_UNFUSED=1 $cfg python3 scripts/train_bench.py 32 30 ragged 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg, previous forms: /"; done
 echo "== the run loops end to end (evaluate_hier over a 60,000-user synthetic XING file, then 600 training steps), pipelined then blocking"; TRAIN=600 python3 scripts/run_loop_bench.py 60000 32 0 2>&1 | grep "evaluate_hier\|training loop"; HIERTCN_EVAL_SERIAL=1 python3 scripts/run_loop_bench.py 60000 32 0 2>&1 | grep "evaluate_hier"
 echo "== soak of the reference-batch paths (in-launch hand-offs, device-sized grids)"; python3 scripts/soak_refbatch.py 500 50 2>&1 | grep -v amdgpu.ids | tail -5
 echo "== training step at 32 lanes x 20 x 30 (cfg-3's slots and steps), XING catalogue: HierTCN d = 128 / 256, HierGRU d = 128 / 256"
