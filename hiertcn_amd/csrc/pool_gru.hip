@@ -478,6 +478,32 @@ __global__ __launch_bounds__(256) void k_rows_f32_and_len(const uint16_t* __rest
   if (lane == 0) seq_len[sess] = cnt;
 }
 
+// evaluation through the session-tile / pipelined kernels (lgru_tile.hip, lgru_pipe.hip, lgru_wide.hip read the 16-bit rows themselves): only the
+// lengths -- one wave per session, 16 bytes per lane and load; the fp32 copy k_rows_f32_and_len also writes is the fp32 cells' and the weight gradients' operand
+__global__ __launch_bounds__(256) void k_len_u16(const uint16_t* __restrict__ u, int64_t n_sess, int L, int E, int32_t* __restrict__ seq_len) {
+  const int lane = threadIdx.x & 63;
+  const int64_t sess = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sess >= n_sess) return;
+  const int cpr = E >> 3;                       // 16-byte chunks per row
+  int cnt = 0;
+  for (int t0 = 0; t0 < L; t0 += 4) {           // four rows in flight per lane
+    int nz[4] = {0, 0, 0, 0};
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const int t = t0 + j;
+      if (t < L)
+        for (int c = lane; c < cpr; c += 64) {
+          const uint4 v = *reinterpret_cast<const uint4*>(u + ((sess * L + t) * (int64_t)E) + c * 8);
+          // a 16-bit float is non-zero unless all bits but the sign are clear (-0 == 0: the fp32 test `v != 0.f` of k_rows_f32_and_len)
+          nz[j] |= ((v.x | v.y | v.z | v.w) & 0x7fff7fffu) ? 1 : 0;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; j++) cnt += (t0 + j < L && __any(nz[j])) ? 1 : 0;
+  }
+  if (lane == 0) seq_len[sess] = cnt;
+}
+
 // exact numerics mode: the projected rows arrive as fp32 (exact.hip); only the lengths are taken here
 __global__ __launch_bounds__(256) void k_len_f32(const float* __restrict__ uf, int64_t n_sess, int L, int E, int32_t* __restrict__ seq_len) {
   const int lane = threadIdx.x & 63;
@@ -529,7 +555,10 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
       a.Cin = E; a.Cout = E; a.taps = 1; a.dil = 0; a.L = L; a.n_seq = n_sess; a.linear = 1;
       if ((e = launch_tcn_layer(a, st)) != hipSuccess) return e;
     }
-    hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
+    if (!b.keep_all && lgru_tile_applies(m, n_sess) && (E % 8) == 0)   // (evaluation on the 16-bit rows: nobody reads the fp32 copy)
+      hipLaunchKernelGGL(k_len_u16, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.seq_len);
+    else
+      hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if (!b.hidden32 && lgru_tile_applies(m, n_sess)) {   // small batches: one workgroup per 32 sessions through every step and layer (lgru_tile.hip); training keeps the records
