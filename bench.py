@@ -294,7 +294,7 @@ def reference_batch_leg(n_batches=100):
     """-> the `reference_batch` object: the reference's OWN operating point (args.py:19,40,51-53,126-129: 32 lanes x 10 slots x <= 20 steps per batch, two
     layers; BASELINE.json configs[1]'s XING catalogue of 20,778 items): ms per evaluation batch for HierTCN at d = 256 (configs[1]) and for HierGRU -- the
     reference's default low level -- at d = 128 (its default width) and 256, and ms per training step (forward + backward of every variable + Adam) of
-    HierTCN d = 256 and of the default HierGRU.  Ragged batches, ids resident."""
+    each.  Ragged batches, ids resident."""
     import torch
 
     from hiertcn_amd.args import hier_tcn_args
@@ -310,7 +310,7 @@ def reference_batch_leg(n_batches=100):
     xs, ys, ms = (torch.as_tensor(v).cuda().contiguous() for v in (x.astype(np.int32), ids.astype(np.int32), mask))
     out = {"what": "32 lanes x 10 slots x <= 20 steps per batch (the reference's batch_size / max_session_num / max_activity_len defaults), XING catalogue N = 20,778, "
                    "two layers, ragged sessions, ids resident; ms per batch = mean over %d back-to-back batches" % n_batches}
-    for name, low, d, train in (("hiertcn_d256", "tcn", 256, True), ("hiergru_d128", "gru", 128, True), ("hiergru_d256", "gru", 256, False)):
+    for name, low, d, train in (("hiertcn_d256", "tcn", 256, True), ("hiergru_d128", "gru", 128, True), ("hiergru_d256", "gru", 256, True)):
         args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B, model_low_type=low)
         eng = Engine(args, hier=True, train=train)
         eng.set_weights(init_params(args, seed=2))
