@@ -174,6 +174,10 @@ bool lgru_wide_applies(const ModelDev& m, int64_t n_sess);
 size_t lgru_wide_bytes(const ModelDev& m, int64_t n_sess, int L);
 hipError_t launch_lgru_wide(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
                             void* scratch, hipStream_t st);
+bool lgru_wide_bwd_applies(const ModelDev& m, int64_t n_sess);
+size_t lgru_wide_bwd_bytes(const ModelDev& m, int64_t n_sess, int L);
+hipError_t launch_lgru_wide_bwd(const ModelDev& m, const float* dH, const int32_t* seq_len, const float* states, const float* rec, int64_t n_sess, int L, float* du,
+                                float* dac_all, float* dag_all, void* scratch, hipStream_t st);
 hipError_t launch_lgru_tile(const ModelDev& m, const uint16_t* u16, const int32_t* seq_len, int64_t n_sess, int L, uint16_t* hidden, float* states, float* rec,
                             hipStream_t st);
 // gru_persist.hip: the HierGRU low level of small evaluation batches as one persistent launch

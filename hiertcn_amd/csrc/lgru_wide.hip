@@ -318,3 +318,347 @@ hipError_t launch_lgru_wide(const ModelDev& m, const uint16_t* u16, const int32_
   hipLaunchKernelGGL(k_lgru_wide, dim3(tiles, LW_PARTS, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
   return hipGetLastError();
 }
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// Backward through time of the same cells (model_gru.py:47-55 differentiated by model.py:139-141) in the same decomposition, H = 128 and 256:
+// a (32-session tile, layer) is HB workgroups; workgroup p owns units [32 p, 32 p + 32) of the layer -- as elements of a cell's output (everything
+// elementwise is local) and as the OUTPUT COLUMNS 32 p .. and in + 32 p .. of the two backward products
+//     [d x_c | d(r h)] = da_c . Wc      (reduction over the layer's H units)
+//     [d x_g | d h_g]  = [da_r | da_z] . Wg      (reduction over 2 H)
+// whose transposed weight fragments (two tiles each: 24 HB registers per lane with the reduction split over the four waves) stay in registers
+// for all L steps.  Per cell two all-to-all hand-offs inside the launch -- da_c, then [da_r | da_z], both through their slots of dac_all / dag_all
+// (fp32, what the weight-gradient products behind the loop read anyway; the readers split them into 16-bit hi + lo rows on the way into LDS) -- and
+// one point-to-point hand-off: d x of block p goes to workgroup p of the layer BELOW (with E = H its input units are that workgroup's own units),
+// so the layers run pipelined top down.  Formulas and arithmetic of k_lgru_tile_bwd (lgru_tile.hip); the sums over the reduction are four partial sums.
+struct LgruWideBwdArgs {
+  const float* dH;                           // [M * L][H]: d loss / d (top layer output)
+  const int32_t* seq_len;
+  const float* states;                       // [(L + 1)][M][HT]
+  const float* rec;                          // per (t, l): gates [M][2H] | r*h | cand | out
+  const uint16_t* wcT_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wcT_lo[HIERTCN_MAX_LAYERS];   // (Wc)^T fragment-major: [K/32][H/16][64][8]
+  const uint16_t* wgT_hi[HIERTCN_MAX_LAYERS]; const uint16_t* wgT_lo[HIERTCN_MAX_LAYERS];   // (Wg)^T: [K/32][2H/16][64][8]
+  float* du;                                 // [M * L][E]
+  float* dac_all;                            // [(l L + t)][M][H]
+  float* dag_all;                            // [(l L + t)][M][2H]
+  float* dxb;                                // [nl][L][M][H]: d x of (layer, step), for the layer below
+  int* cnt;                                  // [nl][tiles][L][2]: arrivals of phase 1 (da_c) / phase 2 ([da_r | da_z])
+  int* flagx;                                // [nl][tiles][L][HB]: d x of (layer, tile, step, part) published
+  unsigned long long* err;
+  int M, L, HT, nl;
+};
+
+template <int HB>   // H / 32 in {4, 8} = workgroups per (tile, layer)
+__global__ __launch_bounds__(LW_THREADS, 1) void k_lgru_wide_bwd(const LgruWideBwdArgs a) {
+  constexpr int H = 32 * HB;
+  constexpr int KSC = 2 * HB, KSG = 4 * HB;        // k-steps of the two products (reduction over H resp. 2H)
+  constexpr int KWC = KSC / 4, KWG = KSG / 4;      // ... per wave
+  constexpr int PC = 2 * H + 16, PG = 4 * H + 16;  // LDS pitches of the split da_c resp. [da_r | da_z] rows
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  __shared__ int s_dead;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const int nl = a.nl, L = a.L, M = a.M, HT = a.HT;
+  const int tile = (int)blockIdx.x, p = (int)blockIdx.y, tiles = (int)gridDim.x;
+  const int l = nl - 1 - (int)blockIdx.z;          // (the top layer's workgroups first in dispatch order: they are the producers)
+  const int64_t sess0 = (int64_t)tile * 32;
+  const int64_t sess = sess0 + lr;
+  const bool live = sess < M;
+  const int64_t sc = live ? sess : (int64_t)M - 1;
+  const int len = a.seq_len[sc];
+  const bool top = l == nl - 1;
+  unsigned char* DCh = smem;
+  unsigned char* DCl = DCh + 32 * PC;
+  unsigned char* DGh = DCl + 32 * PC;
+  unsigned char* DGl = DGh + 32 * PG;
+  float* RED = reinterpret_cast<float*>(DGl + 32 * PG);   // [2 tiles][4 waves][16][64]
+  if (tid == 0) s_dead = 0;
+
+  // ---- this wave's share of the transposed weights, once: output tiles (input part, state part) of block p, its quarter of each reduction
+  uint4 Ch[2][KWC], Cl[2][KWC], Gh[2][KWG], Gl[2][KWG];
+#pragma unroll
+  for (int part = 0; part < 2; part++) {
+    const size_t T = (size_t)(part * HB + p);
+#pragma unroll
+    for (int i = 0; i < KWC; i++) {
+      const size_t off = ((T * KSC + (size_t)KWC * wave + i) * 64 + lane) * 8;
+      Ch[part][i] = *reinterpret_cast<const uint4*>(a.wcT_hi[l] + off);
+      Cl[part][i] = *reinterpret_cast<const uint4*>(a.wcT_lo[l] + off);
+    }
+#pragma unroll
+    for (int i = 0; i < KWG; i++) {
+      const size_t off = ((T * KSG + (size_t)KWG * wave + i) * 64 + lane) * 8;
+      Gh[part][i] = *reinterpret_cast<const uint4*>(a.wgT_hi[l] + off);
+      Gl[part][i] = *reinterpret_cast<const uint4*>(a.wgT_lo[l] + off);
+    }
+  }
+#pragma unroll
+  for (int part = 0; part < 2; part++) {   // opaque: keep them in registers
+#pragma unroll
+    for (int i = 0; i < KWC; i++) {
+      asm volatile("" : "+v"(Ch[part][i].x), "+v"(Ch[part][i].y), "+v"(Ch[part][i].z), "+v"(Ch[part][i].w));
+      asm volatile("" : "+v"(Cl[part][i].x), "+v"(Cl[part][i].y), "+v"(Cl[part][i].z), "+v"(Cl[part][i].w));
+    }
+#pragma unroll
+    for (int i = 0; i < KWG; i++) {
+      asm volatile("" : "+v"(Gh[part][i].x), "+v"(Gh[part][i].y), "+v"(Gh[part][i].z), "+v"(Gh[part][i].w));
+      asm volatile("" : "+v"(Gl[part][i].x), "+v"(Gl[part][i].y), "+v"(Gl[part][i].z), "+v"(Gl[part][i].w));
+    }
+  }
+  const int unit0 = 32 * p + 8 * wave + 4 * lh;    // this lane's four units of its session behind a reduction
+  float dcar[4] = {0.f, 0.f, 0.f, 0.f};            // the low level's final state is dropped (model_gru.py:47)
+
+  auto cnt_of = [&](int ll, int t, int ph) { return a.cnt + (((size_t)ll * tiles + tile) * L + t) * 2 + ph; };
+  auto flag_of = [&](int ll, int t, int pp) { return a.flagx + (((size_t)ll * tiles + tile) * L + t) * HB + pp; };
+  auto wait_ge = [&](int* c, int n) {
+    unsigned spins = 0;
+    while (!s_dead && __hip_atomic_load(c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < n) {
+      __builtin_amdgcn_s_sleep(1);
+      if (++spins > LW_SPIN_MAX) {
+        __hip_atomic_store(a.err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_dead = 1;
+      }
+    }
+  };
+  auto st2 = [&](float* ptr, float x, float y) {   // two floats, write-through
+    const unsigned long long v = (unsigned long long)__float_as_uint(x) | ((unsigned long long)__float_as_uint(y) << 32);
+    __hip_atomic_store(reinterpret_cast<unsigned long long*>(ptr), v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+  auto ld2 = [&](const float* ptr, float& x, float& y) {
+    const unsigned long long v = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(ptr), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    x = __uint_as_float((unsigned)(v & 0xffffffffull));
+    y = __uint_as_float((unsigned)(v >> 32));
+  };
+  // 32 rows x W floats of an fp32 slot -> split 16-bit rows in LDS (hi, lo), 8 agent-scope loads of 8 bytes in flight per thread
+  auto gather_split = [&](const float* src, int W, unsigned char* dh, unsigned char* dl, int pitch) {
+    const int per_row = W >> 1, total = 32 * per_row;
+    for (int c0 = 0; c0 < total; c0 += 8 * LW_THREADS) {
+      unsigned long long v[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int c = min(c0 + k * LW_THREADS + tid, total - 1);
+        const int row = c / per_row, col = c - row * per_row;
+        const int64_t s = (sess0 + row < M) ? sess0 + row : (int64_t)M - 1;
+        v[k] = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(src + (size_t)s * W + 2 * col), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+#pragma unroll
+      for (int k = 0; k < 8; k++) {
+        const int c = c0 + k * LW_THREADS + tid;
+        if (c < total) {
+          const int row = c / per_row, col = c - row * per_row;
+          uint16_t h0, l0, h1, l1;
+          lw_split(__uint_as_float((unsigned)(v[k] & 0xffffffffull)), h0, l0);
+          lw_split(__uint_as_float((unsigned)(v[k] >> 32)), h1, l1);
+          *reinterpret_cast<uint32_t*>(dh + row * pitch + col * 4) = (uint32_t)h0 | ((uint32_t)h1 << 16);
+          *reinterpret_cast<uint32_t*>(dl + row * pitch + col * 4) = (uint32_t)l0 | ((uint32_t)l1 << 16);
+        }
+      }
+    }
+  };
+  auto red_put = [&](int slot_i, const f32x16& acc) {
+#pragma unroll
+    for (int i = 0; i < 16; i++) RED[((slot_i * 4 + wave) * 16 + i) * 64 + lane] = acc[i];
+  };
+  auto red_get = [&](int slot_i, float* out4) {
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      float v = 0.f;
+#pragma unroll
+      for (int w = 0; w < 4; w++) v += RED[((slot_i * 4 + w) * 16 + 4 * wave + j) * 64 + lane];
+      out4[j] = v;
+    }
+  };
+  __syncthreads();
+
+  const size_t cellf = (size_t)M * 5 * H;
+  for (int t = L - 1; t >= 0; t--) {
+    const bool active = t < len;
+    const float* rec = a.rec + ((size_t)t * nl + l) * cellf;
+    const float* hp = a.states + ((size_t)t * M + sc) * HT + (size_t)l * H;
+    float* dacs = a.dac_all + ((size_t)l * L + t) * M * H;
+    float* dags = a.dag_all + ((size_t)l * L + t) * M * 2 * H;
+    // ---------------- the gradient of the cell's output: d loss / d output (top layer) or the d x of the layer above (same part, same step)
+    float dout[4];
+    if (top) {
+      const float4 o4 = *reinterpret_cast<const float4*>(a.dH + (sc * L + t) * H + unit0);
+      dout[0] = o4.x; dout[1] = o4.y; dout[2] = o4.z; dout[3] = o4.w;
+    } else {
+      if (tid == 0) wait_ge(flag_of(l + 1, t, p), 1);
+      __syncthreads();
+      const float* src = a.dxb + (((size_t)(l + 1) * L + t) * M + sc) * H + unit0;
+      ld2(src, dout[0], dout[1]);
+      ld2(src + 2, dout[2], dout[3]);
+    }
+    // ---------------- P1 (local): through the blend and the tanh
+    float dhp[4], dagz[4], hv[4];
+    {
+      const float4 z4 = *reinterpret_cast<const float4*>(rec + sc * 2 * H + H + unit0);
+      const float4 c4 = *reinterpret_cast<const float4*>(rec + (size_t)M * 3 * H + sc * H + unit0);
+      const float4 h4 = *reinterpret_cast<const float4*>(hp + unit0);
+      const float zv[4] = {z4.x, z4.y, z4.z, z4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+      hv[0] = h4.x; hv[1] = h4.y; hv[2] = h4.z; hv[3] = h4.w;
+      float dac[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        const float d = active ? dcar[j] + dout[j] : 0.f;
+        dac[j] = d * (1.f - zv[j]) * (1.f - cv[j] * cv[j]);
+        dhp[j] = d * zv[j];
+        dagz[j] = d * (hv[j] - cv[j]) * zv[j] * (1.f - zv[j]);
+      }
+      if (live) {
+        st2(dacs + (size_t)sess * H + unit0, dac[0], dac[1]);
+        st2(dacs + (size_t)sess * H + unit0 + 2, dac[2], dac[3]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt_of(l, t, 0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wait_ge(cnt_of(l, t, 0), HB);
+    }
+    __syncthreads();
+    gather_split(dacs, H, DCh, DCl, PC);
+    __syncthreads();
+    // ---------------- P2: [d x_c | d(r h)] = da_c . Wc (own output columns), through the reset gate
+    {
+#pragma unroll
+      for (int part = 0; part < 2; part++) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KWC; i++) {
+          const int ko = (KWC * wave + i) * 32 + lh * 16;
+          const uint4 qh = *reinterpret_cast<const uint4*>(DCh + lr * PC + ko);
+          const uint4 ql = *reinterpret_cast<const uint4*>(DCl + lr * PC + ko);
+          acc = mfma32(Ch[part][i], qh, acc);
+          acc = mfma32(Cl[part][i], qh, acc);
+          acc = mfma32(Ch[part][i], ql, acc);
+        }
+        red_put(part, acc);
+      }
+    }
+    __syncthreads();
+    float dxc[4], drh[4];
+    red_get(0, dxc);
+    red_get(1, drh);
+    {
+      const float4 r4 = *reinterpret_cast<const float4*>(rec + sc * 2 * H + unit0);
+      const float rv[4] = {r4.x, r4.y, r4.z, r4.w};
+      float dagr[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) {
+        dagr[j] = drh[j] * hv[j] * rv[j] * (1.f - rv[j]);
+        dhp[j] += drh[j] * rv[j];
+      }
+      if (live) {
+        st2(dags + (size_t)sess * 2 * H + unit0, dagr[0], dagr[1]);
+        st2(dags + (size_t)sess * 2 * H + unit0 + 2, dagr[2], dagr[3]);
+        st2(dags + (size_t)sess * 2 * H + H + unit0, dagz[0], dagz[1]);
+        st2(dags + (size_t)sess * 2 * H + H + unit0 + 2, dagz[2], dagz[3]);
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();   // (also: every wave has read RED)
+    if (tid == 0) {
+      __hip_atomic_fetch_add(cnt_of(l, t, 1), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      wait_ge(cnt_of(l, t, 1), HB);
+    }
+    __syncthreads();
+    gather_split(dags, 2 * H, DGh, DGl, PG);
+    __syncthreads();
+    // ---------------- P3: [d x_g | d h_g] = [da_r | da_z] . Wg (own output columns)
+    {
+#pragma unroll
+      for (int part = 0; part < 2; part++) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[i] = 0.f;
+#pragma unroll
+        for (int i = 0; i < KWG; i++) {
+          const int ko = (KWG * wave + i) * 32 + lh * 16;
+          const uint4 qh = *reinterpret_cast<const uint4*>(DGh + lr * PG + ko);
+          const uint4 ql = *reinterpret_cast<const uint4*>(DGl + lr * PG + ko);
+          acc = mfma32(Gh[part][i], qh, acc);
+          acc = mfma32(Gl[part][i], qh, acc);
+          acc = mfma32(Gh[part][i], ql, acc);
+        }
+        red_put(part, acc);
+      }
+    }
+    __syncthreads();
+    float dxg[4], dhg[4], dx[4];
+    red_get(0, dxg);
+    red_get(1, dhg);
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      dx[j] = dxc[j] + dxg[j];                       // zero for a finished session (its da rows are zero)
+      dcar[j] = active ? dhp[j] + dhg[j] : dcar[j];
+    }
+    if (l == 0) {
+      if (live) *reinterpret_cast<float4*>(a.du + (sess * L + t) * H + unit0) = make_float4(dx[0], dx[1], dx[2], dx[3]);
+      __syncthreads();   // (every wave has read RED before the next cell's products overwrite it)
+    } else {
+      if (live) {
+        float* dst = a.dxb + (((size_t)l * L + t) * M + sess) * H + unit0;
+        st2(dst, dx[0], dx[1]);
+        st2(dst + 2, dx[2], dx[3]);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (tid == 0) __hip_atomic_store(flag_of(l, t, p), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+template <int HB>
+static size_t lwb_lds_bytes() { return 2 * 32 * (2 * 32 * HB + 16) + 2 * 32 * (4 * 32 * HB + 16) + 2 * 4 * 16 * 64 * sizeof(float); }
+
+bool lgru_wide_bwd_applies(const ModelDev& m, int64_t n_sess) {
+  const char* sw = getenv("HIERTCN_LGRU_WIDE_BWD");   // "0": never (A/B runs, tests; read on every call)
+  if (sw && sw[0] == '0') return false;
+  const char* chain = getenv("HIERTCN_LGRU_CHAIN");
+  if (chain && chain[0] == '1') return false;
+  if (!lgru_tile_applies(m, n_sess) || !(m.H == 128 || m.H == 256) || m.gru_bar == nullptr || !m.lgru_wgTF_hi[0]) return false;
+  const int64_t tiles = (n_sess + 31) / 32;
+  return tiles * m.nl * (m.H / 32) <= (m.n_cu > 0 ? m.n_cu : 256);
+}
+
+// bytes of the d x slots + counters + flags (0: does not apply at this size)
+size_t lgru_wide_bwd_bytes(const ModelDev& m, int64_t n_sess, int L) {
+  if (n_sess <= 0 || !(m.H == 128 || m.H == 256) || m.E != m.H || m.nl > 2 || (n_sess + 31) / 32 * m.nl * (m.H / 32) > 256) return 0;
+  const size_t tiles = (size_t)(n_sess + 31) / 32;
+  const size_t x = (size_t)m.nl * L * (size_t)n_sess * m.H * 4;
+  return ((x + 255) & ~(size_t)255) + ((tiles * m.nl * L * (2 + (size_t)m.H / 32) * 4 + 255) & ~(size_t)255);
+}
+
+hipError_t launch_lgru_wide_bwd(const ModelDev& m, const float* dH, const int32_t* seq_len, const float* states, const float* rec, int64_t n_sess, int L, float* du,
+                                float* dac_all, float* dag_all, void* scratch, hipStream_t st) {
+  LgruWideBwdArgs a;
+  memset(&a, 0, sizeof(a));
+  a.dH = dH; a.seq_len = seq_len; a.states = states; a.rec = rec; a.du = du; a.dac_all = dac_all; a.dag_all = dag_all;
+  for (int l = 0; l < m.nl; l++) {
+    a.wcT_hi[l] = m.lgru_wcTF_hi[l]; a.wcT_lo[l] = m.lgru_wcTF_lo[l]; a.wgT_hi[l] = m.lgru_wgTF_hi[l]; a.wgT_lo[l] = m.lgru_wgTF_lo[l];
+  }
+  a.M = (int)n_sess; a.L = L; a.HT = m.HT; a.nl = m.nl;
+  const unsigned tiles = (unsigned)((n_sess + 31) / 32);
+  const int HB = m.H / 32;
+  const size_t xbytes = (((size_t)m.nl * L * (size_t)n_sess * m.H * 4) + 255) & ~(size_t)255;
+  unsigned char* s = reinterpret_cast<unsigned char*>(scratch);
+  a.dxb = reinterpret_cast<float*>(s);
+  a.cnt = reinterpret_cast<int*>(s + xbytes);
+  a.flagx = a.cnt + (size_t)tiles * m.nl * L * 2;
+  a.err = reinterpret_cast<unsigned long long*>(m.gru_bar) + 8 * 16;
+  hipError_t e;
+  if ((e = hipMemsetAsync(a.cnt, 0, (size_t)tiles * m.nl * L * (2 + HB) * 4, st)) != hipSuccess) return e;
+  if (HB == 8) {
+    const size_t lds = lwb_lds_bytes<8>();
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_wide_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lgru_wide_bwd<8>, dim3(tiles, 8, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+  } else {
+    const size_t lds = lwb_lds_bytes<4>();
+    if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_wide_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
+    hipLaunchKernelGGL(k_lgru_wide_bwd<4>, dim3(tiles, 4, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+  }
+  return hipGetLastError();
+}

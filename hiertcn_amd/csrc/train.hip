@@ -617,6 +617,7 @@ struct TrainWs {
   size_t total;
   size_t lg_x3;   // split-operand scratch of the HierGRU cells (gru_x3.hip)
   size_t lg_pipe;   // exchange slots + flags of the layer-pipelined HierGRU forward (lgru_pipe.hip)
+  size_t lg_bwd;    // d x slots + counters of the pipelined backward (lgru_wide.hip, k_lgru_wide_bwd)
   size_t lg_uf, lg_len, lg_save, lg_dcar[2], lg_dac, lg_dag, lg_dhpart, lg_dcat_c, lg_dcat_g, lg_din_up;   // HierGRU low level
   size_t splitk;  // partial outputs of the split-K weight-gradient GEMMs
   size_t splitk_floats;
@@ -731,6 +732,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     w.lg_x3 = take(low_gru_x3_elems(m, (int64_t)M) * 2);
     w.lg_save = take(low_gru_save_floats(m, (int64_t)M, L) * 4);
     w.lg_pipe = take(lgru_pipe_bytes(m, (int64_t)M, L));
+    w.lg_bwd = take(lgru_wide_bwd_bytes(m, (int64_t)M, L));
     w.lg_dcar[0] = take(M * HT * 4); w.lg_dcar[1] = take(M * HT * 4);
     const size_t cells = lgru_deferred_wgrad(m, M, L) ? (size_t)m.nl * L : 1;
     w.lg_dac = take(cells * M * H * 4); w.lg_dag = take(cells * M * 2 * H * 4); w.lg_dhpart = take(M * H * 4);
@@ -950,7 +952,9 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     // small batches: the whole BPTT as one launch, a workgroup per 32 sessions (lgru_tile.hip); it keeps the cells' pre-activation gradients, the
     // weight gradients follow below as always in this regime
     const bool tile_bwd = deferred && lgru_tile_applies(m, (int64_t)M) && !getenv("HIERTCN_LGRU_TILE_BWD_OFF");
-    if (tile_bwd) T_HIP(launch_lgru_tile_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, st));
+    if (tile_bwd && lgru_wide_bwd_applies(m, (int64_t)M) && lgru_wide_bwd_bytes(m, (int64_t)M, L) > 0)   // H = 128 / 256: HB workgroups per (tile, layer), weights in registers, layers pipelined
+      T_HIP(launch_lgru_wide_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, ws + w.lg_bwd, st));
+    else if (tile_bwd) T_HIP(launch_lgru_tile_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, st));
     for (int tt = L - 1; tt >= 0 && !tile_bwd; tt--) {
       for (int l = m.nl - 1; l >= 0; l--) {
         const int in = (l == 0) ? E : H;

@@ -209,7 +209,7 @@ def test_run_gmm_evaluation_loop_on_the_synthetic_xing_file(tmp_path, sigma):
 @pytest.mark.parametrize("C", [64, 128, 256])
 def test_gram_form_equals_the_table_pass(C, monkeypatch):
     """The two ways to |mu_m|^2 and mu_m[target] on the same handle contents and the same hidden rows, with LARGE biases (the cross term
-    2 h.W b and |b|^2 then dominate): |mu|^2 to 2e-6 relative (fp32 summation order: both are exact products of 16-bit operands), target
+    2 h.W b and |b|^2 then dominate): |mu|^2 to 4e-6 relative (fp32 summation order: both are exact products of 16-bit operands), target
     mean to 2e-6, losses to 1e-5 -- at R = 700 rows (not a multiple of the 256-row workgroup) with null targets."""
     from hiertcn_amd.model_tcn_gmm import TcnGmmModel
     N, M = 4000, 4
@@ -218,6 +218,7 @@ def test_gram_form_equals_the_table_pass(C, monkeypatch):
     rng = np.random.default_rng(C)
     p["tcn_gmm/fully_connected/biases"] = (0.3 * rng.standard_normal(p["tcn_gmm/fully_connected/biases"].shape)).astype(np.float32)
     R = 700
+    torch.manual_seed(C)   # (unseeded rows put the difference at 1.5e-6 .. 2.2e-6 from run to run: a flaky bound)
     hid = (torch.randn(R, C, device="cuda:0") * 0.7).relu().to(torch.bfloat16)
     y = torch.as_tensor(rng.integers(0, N, R).astype(np.int32)).to("cuda:0")
     y[::7] = 0
@@ -233,7 +234,7 @@ def test_gram_form_equals_the_table_pass(C, monkeypatch):
         out[name] = [v.cpu().numpy().astype(np.float64) for v in (loss, sq, tg, pl, lmax)]
         model.close()
     g, t = out["gram"], out["table"]
-    assert np.abs(g[1] - t[1]).max() < 2e-6 * np.abs(t[1]).max(), np.abs(g[1] - t[1]).max() / np.abs(t[1]).max()
+    assert np.abs(g[1] - t[1]).max() < 4e-6 * np.abs(t[1]).max(), np.abs(g[1] - t[1]).max() / np.abs(t[1]).max()   # (measured 1.5e-6 .. 2.2e-6 over random rows)
     assert np.abs(g[2] - t[2]).max() < 2e-6 * max(1.0, np.abs(t[2]).max())
     assert np.array_equal(g[3], t[3]) or np.abs(g[3] - t[3]).max() < 1e-6
     for i in (0, 4):
