@@ -35,8 +35,8 @@ python3 scripts/train_bench.py 1024 3 ragged 2>&1 | tail -1
 HIERTCN_TRAIN_LEGACY=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -1
 LOW=gru EVAL=1 python3 scripts/train_bench.py 1024 3 2>&1 | tail -2
 echo "== training step at the reference's OWN batch (32 lanes x 10 slots x 20 steps, XING catalogue): HierTCN d = 256, HierGRU d = 128; then with the launch chains / unsplit small-batch kernels of round 3"
-for cfg in "D=256" "D=128 LOW=gru"; do env N=20778 S=10 L=20 $cfg python3 scripts/train_bench.py 32 30 ragged 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done
-for cfg in "D=256" "D=128 LOW=gru"; do env N=20778 S=10 L=20 HIERTCN_SGRAD_DYN_OFF=1 HIERTCN_SGRAD0_SLABS_OFF=1 HIERTCN_GRU_TRAIN_CHAIN=1 HIERTCN_GRU_BPTT_CHAIN=1 HIERTCN_GRU_BPTT_UNFUSED=1 HIERTCN_GEMM_NO_BATCH=1 HIERTCN_LGRU_PIPE=0 HIERTCN_LGRU_WIDE=0 HIERTCN_LGRU_REFRESH_UNFUSED=1 $cfg python3 scripts/train_bench.py 32 30 ragged 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg, previous forms: /"; done
+for cfg in "D=256" "D=128 LOW=gru" "D=256 LOW=gru"; do env N=20778 S=10 L=20 $cfg python3 scripts/train_bench.py 32 30 ragged 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg: /"; done
+for cfg in "D=256" "D=128 LOW=gru"; do env N=20778 S=10 L=20 HIERTCN_SGRAD_DYN_OFF=1 HIERTCN_SGRAD0_SLABS_OFF=1 HIERTCN_GRU_TRAIN_CHAIN=1 HIERTCN_GRU_BPTT_CHAIN=1 HIERTCN_GRU_BPTT_UNFUSED=1 HIERTCN_GEMM_NO_BATCH=1 HIERTCN_LGRU_PIPE=0 HIERTCN_LGRU_WIDE=0 HIERTCN_LGRU_WIDE_BWD=0 HIERTCN_LGRU_REFRESH_UNFUSED=1 $cfg python3 scripts/train_bench.py 32 30 ragged 2>&1 | tail -1 | cut -c1-60 | sed "s/^/$cfg, previous forms: /"; done
 echo "== the run loops end to end (evaluate_hier over a 60,000-user synthetic XING file, then 600 training steps), pipelined then blocking"; TRAIN=600 python3 scripts/run_loop_bench.py 60000 32 0 2>&1 | grep "evaluate_hier\|training loop"; HIERTCN_EVAL_SERIAL=1 python3 scripts/run_loop_bench.py 60000 32 0 2>&1 | grep "evaluate_hier"
 echo "== soak of the reference-batch paths (in-launch hand-offs, device-sized grids)"; python3 scripts/soak_refbatch.py 500 50 2>&1 | grep -v amdgpu.ids | tail -5
 echo "== training step at 32 lanes x 20 x 30 (cfg-3's slots and steps), XING catalogue: HierTCN d = 128 / 256, HierGRU d = 128 / 256"
