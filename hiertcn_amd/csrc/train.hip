@@ -305,6 +305,35 @@ static hipError_t colsum_f32(const float* src, int64_t rows, int64_t ld, int col
   hipLaunchKernelGGL(k_colsum_f32, dim3((cols + 63) / 64, (unsigned)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS)), dim3(256), 0, st, src, rows, ld, cols, out);
   return hipGetLastError();
 }
+// several column sums over the SAME number of rows in one launch (the bias gradients of a level's cells: 2 nl of them, each a launch of its own before)
+struct ColsumDesc { const float* src; int64_t ld; int cols; float* out; };
+struct ColsumGroup { ColsumDesc d[2 * HIERTCN_MAX_LAYERS]; int n; };
+__global__ __launch_bounds__(256) void k_colsum_f32_group(const ColsumGroup g, int64_t rows) {
+  const ColsumDesc& d = g.d[blockIdx.z];
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int ry = threadIdx.x >> 6;
+  __shared__ float red[4][64];
+  const int64_t r0 = (int64_t)blockIdx.y * COLSUM_ROWS;
+  const int64_t r1 = (r0 + COLSUM_ROWS < rows) ? r0 + COLSUM_ROWS : rows;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+  if (c < d.cols) {
+    int64_t r = r0 + ry;
+    for (; r + 12 < r1; r += 16) {
+      s0 += d.src[r * d.ld + c]; s1 += d.src[(r + 4) * d.ld + c]; s2 += d.src[(r + 8) * d.ld + c]; s3 += d.src[(r + 12) * d.ld + c];
+    }
+    for (; r < r1; r += 4) s0 += d.src[r * d.ld + c];
+  }
+  red[ry][threadIdx.x & 63] = (s0 + s1) + (s2 + s3);
+  __syncthreads();
+  if (threadIdx.x < 64 && c < d.cols) atomicAdd(d.out + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+}
+static hipError_t colsum_f32_group(const ColsumGroup& g, int64_t rows, hipStream_t st) {
+  if (g.n <= 0) return hipSuccess;
+  int most = 0;
+  for (int i = 0; i < g.n; i++) most = g.d[i].cols > most ? g.d[i].cols : most;
+  hipLaunchKernelGGL(k_colsum_f32_group, dim3((most + 63) / 64, (unsigned)((rows + COLSUM_ROWS - 1) / COLSUM_ROWS), (unsigned)g.n), dim3(256), 0, st, g, rows);
+  return hipGetLastError();
+}
 
 // TemporalBlock backward, pointwise part (customized_tcn_cell.py:120-127): out = relu(c + res), c = relu(conv + b)
 //   ds = da * [out > 0]   (grad of the pre-activation sum; also the grad of the identity residual)
@@ -999,6 +1028,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     if (deferred) {   // the weight gradients of all L * nl cells: one product per layer and operand over the L * M rows (rows (t, m): slab t, session m)
       Gemm32TnDesc wd[4 * HIERTCN_MAX_LAYERS];
       int nw = 0;
+      ColsumGroup cg;
+      memset(&cg, 0, sizeof(cg));
       for (int l = 0; l < m.nl; l++) {
         const int in = (l == 0) ? E : H;
         const int K = in + H;
@@ -1013,9 +1044,10 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
         wd[nw++] = Gemm32TnDesc{dac, H, 0, 0, rh, H, M, (int64_t)((size_t)m.nl * lcell), G + t.lwc[l].off + in, K, H, H, LM, 1.f};
         wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, inp, in_ld, M, in_ss, G + t.lwg[l].off, K, 2 * H, in, LM, 1.f};
         wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, hold, HT, 0, 0, G + t.lwg[l].off + in, K, 2 * H, H, LM, 1.f};
-        T_HIP(colsum_f32(dac, LM, H, H, G + t.lbc[l].off, st));
-        T_HIP(colsum_f32(dag, LM, 2 * H, 2 * H, G + t.lbg[l].off, st));
+        cg.d[cg.n++] = ColsumDesc{dac, H, H, G + t.lbc[l].off};
+        cg.d[cg.n++] = ColsumDesc{dag, 2 * H, 2 * H, G + t.lbg[l].off};
       }
+      T_HIP(colsum_f32_group(cg, (int64_t)L * M, st));
       for (int i0 = 0; i0 < nw; i0 += 8) {   // (one grouped launch + one grouped sum for the 4 nl products instead of 4 nl of each)
         const int n = nw - i0 < 8 ? nw - i0 : 8;
         if (gemm32_tn_slabs_batch_applies(wd + i0, n)) {
@@ -1187,6 +1219,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     // (small batches: the 4 nl products are 4-16 output tiles each behind a reduction of S B = 320 rows -- one grouped launch instead of 4 nl)
     Gemm32TnDesc wd[4 * HIERTCN_MAX_LAYERS];
     int nw = 0;
+    ColsumGroup cg;
+    memset(&cg, 0, sizeof(cg));
     for (int l = 0; l < m.nl; l++) {
       const int in = (l == 0) ? E : H;
       const int K = in + H;
@@ -1201,9 +1235,10 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       wd[nw++] = Gemm32TnDesc{dac, H, 0, 0, rh, H, B, (int64_t)((size_t)m.nl * cell), G + t.wc[l].off + in, K, H, H, SB, 1.f};
       wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, inp, in_ld, B, in_ss, G + t.wg[l].off, K, 2 * H, in, SB, 1.f};
       wd[nw++] = Gemm32TnDesc{dag, 2 * H, 0, 0, hold, hs, B, (int64_t)HT, G + t.wg[l].off + in, K, 2 * H, H, SB, 1.f};
-      T_HIP(colsum_f32(dac, SB, H, H, G + t.bc[l].off, st));
-      T_HIP(colsum_f32(dag, SB, 2 * H, 2 * H, G + t.bg[l].off, st));
+      cg.d[cg.n++] = ColsumDesc{dac, H, H, G + t.bc[l].off};
+      cg.d[cg.n++] = ColsumDesc{dag, 2 * H, 2 * H, G + t.bg[l].off};
     }
+    T_HIP(colsum_f32_group(cg, (int64_t)S * B, st));
     for (int i0 = 0; i0 < nw; i0 += 8) {
       const int n = nw - i0 < 8 ? nw - i0 : 8;
       if (gemm32_tn_slabs_batch_applies(wd + i0, n)) {
