@@ -859,9 +859,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   float* dH = F32(w.dA);   // [R][C_last] fp32
   if (do_begin) {
   T_HIP(launch_compact_rows(y, R, rmap, nvalid_d, reinterpret_cast<int32_t*>(ws + w.cscratch), st));
-  T_HIP(hipMemsetAsync(so.rank, 0, (size_t)R * 4, st));
-  T_HIP(hipMemsetAsync(so.ce, 0, (size_t)R * 4, st));
-  T_HIP(hipMemsetAsync(so.target, 0, (size_t)R * 4, st));
+  T_HIP(hipMemsetAsync(ws + w.rank, 0, w.lse - w.rank, st));   // rank, ce, target: three consecutive slices of the workspace (train_ws), one fill
   float* users = F32(w.users);
   if (w.fused) {
     // score_bwd.hip, mode 2: ONE pass over the logits gives rank / ce / target (the evaluation kernel's outputs) and d hidden; the row
@@ -969,7 +967,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     float* du = dsf;                       // d u [R][E]: grad of the projected [e, state] rows
     float* lcar = F32(w.lg_dcar[0]);
     float* lnext = F32(w.lg_dcar[1]);
-    T_HIP(hipMemsetAsync(lcar, 0, (size_t)M * HT * 4, st));   // the low level's final state is dropped (model_gru.py:47)
+    // (lcar: the launch chain's carried gradient; the one-launch forms keep theirs in registers -- zeroed below only where the chain runs)
     float* dac_all = F32(w.lg_dac);
     float* dag_all = F32(w.lg_dag);
     const bool deferred = lgru_deferred_wgrad(m, (size_t)M, L);
@@ -981,6 +979,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     // small batches: the whole BPTT as one launch, a workgroup per 32 sessions (lgru_tile.hip); it keeps the cells' pre-activation gradients, the
     // weight gradients follow below as always in this regime
     const bool tile_bwd = deferred && lgru_tile_applies(m, (int64_t)M) && !getenv("HIERTCN_LGRU_TILE_BWD_OFF");
+    if (!tile_bwd) T_HIP(hipMemsetAsync(lcar, 0, (size_t)M * HT * 4, st));   // the low level's final state is dropped (model_gru.py:47)
     if (tile_bwd && lgru_wide_bwd_applies(m, (int64_t)M) && lgru_wide_bwd_bytes(m, (int64_t)M, L) > 0)   // H = 128 / 256: HB workgroups per (tile, layer), weights in registers, layers pipelined
       T_HIP(launch_lgru_wide_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, ws + w.lg_bwd, st));
     else if (tile_bwd) T_HIP(launch_lgru_tile_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, st));
@@ -1130,7 +1129,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // ================= GRU through the S slots, last to first (customed_gru_cell.py:323-337, model_hier.py:91-93) =====
   float* dcar = F32(w.dstate[0]);
   float* dnext = F32(w.dstate[1]);
-  T_HIP(hipMemsetAsync(dcar, 0, (size_t)B * HT * 4, st));
+  if (!gru_bptt_persist_applies(m, B, S)) T_HIP(hipMemsetAsync(dcar, 0, (size_t)B * HT * 4, st));   // (the persistent launch keeps the carried gradient in LDS)
   float* dhp = F32(w.dhp);
   float* dac_all = F32(w.dac);
   float* dag_all = F32(w.dag);
