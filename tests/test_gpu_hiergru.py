@@ -348,3 +348,63 @@ def test_layer_pipelined_low_level_matches_the_session_tile_kernel(d, nl, B, S, 
     b = torch.from_numpy(tile).view(torch.bfloat16).float().numpy()
     diff = np.abs(a - b)
     assert (diff > 0).mean() < (2e-2 if d == 256 else 2e-3) and diff.max() <= 2.0 ** -8   # |h| < 1: one storage-type ulp at most
+
+
+@pytest.mark.parametrize("d", [128, 256])
+def test_in_launch_hand_offs_beside_a_long_kernel_on_another_stream(d):
+    """csrc/lgru_pipe.hip (d = 128) and csrc/lgru_wide.hip (d = 256) hand rows between workgroups of ONE launch, so a consumer can be resident
+    while a producer still waits for a CU that a long kernel on another stream holds.  Producers carry the lower block ids of their tile (they
+    are dispatched first) and every wait is bounded: the rows are bitwise those of the undisturbed launch and the time-out word stays clear."""
+    from hiertcn_amd.engine import Engine
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.params import init_params
+    N, nl, B, S, L = 900, 2, 32, 10, 20
+    args = gru_args(N=N, d=d, H=d, nl=nl, L=L, S=S, B=B)
+    rng = np.random.default_rng(100 + d)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, d * nl))).astype(np.float32)
+    eng = Engine(args, hier=True)
+    eng.set_weights(make_params(args))
+    pooled = eng.session_pool(dev(y.reshape(B * S, L))).view(B, S, -1)
+    sproj, _, _ = eng.gru_scan(pooled, dev(mask), dev(st0))
+    xs, sp = dev(x.reshape(B * S, L)), sproj.view(B * S, -1)
+    want = eng.tcn_forward(xs, sp).clone()
+    big = hier_tcn_args(item_num=120_000, emb_dim=256, hidden_dim=256, tcn_channel=[256, 256], num_layer=2)
+    eb = Engine(big)
+    eb.set_weights(init_params(big, 6))
+    rows = 600_000
+    hid = (torch.randn(rows, 256, device="cuda") * 0.5).to(torch.bfloat16)
+    yy = torch.randint(1, 120_000, (rows,), device="cuda", dtype=torch.int32)
+    eb.score_fused(hid, yy)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()
+    for _ in range(3):
+        with torch.cuda.stream(side):
+            eb.score_fused(hid, yy)               # ~30 ms of every CU
+        got = eng.tcn_forward(xs, sp)
+        torch.cuda.synchronize()
+        assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    assert not eng.persistent_timed_out()
+    eng.close()
+    # the training step of the same batch: forward scan with records, wide backward cells (csrc/lgru_wide.hip), persistent BPTT
+    from hiertcn_amd.engine import metrics_dict
+    tr = Engine(args, hier=True, train=True)
+    tr.set_weights(make_params(args))
+    dx, dy, dm, ds = dev(x), dev(y), dev(mask), dev(st0)
+    out = tr.train_forward_backward(dx, dy, dm, ds)
+    want_loss, want_state = metrics_dict(out["metrics8"])["loss"], out["state"].clone()
+    want_g = tr.export("grads")
+    for _ in range(2):
+        with torch.cuda.stream(side):
+            eb.score_fused(hid, yy)
+        out = tr.train_forward_backward(dx, dy, dm, ds)
+        torch.cuda.synchronize()
+        assert abs(metrics_dict(out["metrics8"])["loss"] - want_loss) < 1e-5
+        assert torch.allclose(out["state"], want_state, atol=1e-6)
+        got_g = tr.export("grads")
+        for k in want_g:
+            den = max(float(np.linalg.norm(want_g[k])), 1e-12)
+            assert float(np.linalg.norm(got_g[k] - want_g[k])) / den < 1e-4, k    # fp32 atomics in a few reductions: order only
+    assert not tr.persistent_timed_out()
+    tr.close()
+    eb.close()
