@@ -404,10 +404,11 @@ bool lgru_pipe_applies(const ModelDev& m, int64_t n_sess) {
   return tiles * m.nl <= 256;   // every workgroup resident at once: a consumer waits for its producer inside the launch
 }
 
-// bytes of the exchange slots + flags (0: the pipelined launch does not apply)
+// bytes of the exchange slots + flags (0: no pipelined launch for this model; sizes past its range count as the largest one in it)
 size_t lgru_pipe_bytes(const ModelDev& m, int64_t n_sess, int L) {
   if (m.H == 256) return lgru_wide_bytes(m, n_sess, L);   // (lgru_wide.hip takes that width: the same scratch pointer carries its slots)
-  if (n_sess <= 0 || (n_sess + 31) / 32 * m.nl > 256 || !(m.H == 64 || m.H == 128) || m.E != m.H || m.nl > 2) return 0;
+  if (n_sess <= 0 || !(m.H == 64 || m.H == 128) || m.E != m.H || m.nl > 2) return 0;
+  if (n_sess > 32 * (256 / m.nl)) n_sess = 32 * (256 / m.nl);   // a workspace sized for a larger batch still serves the smaller ones the launch takes
   const size_t tiles = (size_t)(n_sess + 31) / 32;
   const size_t x = (size_t)(m.nl - 1) * L * 2 * (size_t)n_sess * m.H * 2;
   return ((x + 255) & ~(size_t)255) + ((tiles * m.nl * L * 4 + 255) & ~(size_t)255);

@@ -21,6 +21,15 @@
 #define LW_THREADS 256
 #define LW_PARTS 8
 #define LW_SPIN_MAX (1u << 22)
+// Batches of more tiles than one launch can keep resident run as several launches over consecutive tile ranges (stream order: each has the chip
+// to itself) -- at H = 256 up to three (measured, training step of 32 x 20 x 30 / 64 / 128 / 200 lanes x 10 x 20: 4.0 / 2.6 / 5.4 / 7.5 ms against
+// 5.7 / 3.8 / 6.1 / 7.5 ms with the session-tile kernels of lgru_tile.hip, which keep every CU busy with a tile of its own); at H = 128 one (two
+// launches of the backward cells at 1,280 sessions: 3.0 against 2.9 ms).
+static int lw_max_launches(int parts) { return parts == 8 ? 3 : 1; }
+static int64_t lw_tiles_per_launch(const ModelDev& m, int parts) {
+  const int64_t cus = m.n_cu > 0 ? m.n_cu : 256;
+  return cus / ((int64_t)m.nl * parts);
+}
 
 struct LgruWideArgs {
   const uint16_t* u16;                       // [M][L][E] projected [e, state] rows, storage type
@@ -36,6 +45,7 @@ struct LgruWideArgs {
   int* cnt;                                  // [nl][tiles][L][2]: workgroups that have published phase 1 / phase 2 of (layer, tile, step)
   unsigned long long* err;
   int M, L, HT, nl;
+  int tile0, tiles;                          // this launch's first tile; tiles of the whole batch (the counters' stride)
 };
 
 __device__ __forceinline__ float lw_sigmoid(float x) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x)); }
@@ -54,7 +64,7 @@ __global__ __launch_bounds__(LW_THREADS, 1) void k_lgru_wide(const LgruWideArgs 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int nl = a.nl, L = a.L, M = a.M, HT = a.HT;
-  const int tile = (int)blockIdx.x, p = (int)blockIdx.y, l = (int)blockIdx.z, tiles = (int)gridDim.x;
+  const int tile = a.tile0 + (int)blockIdx.x, p = (int)blockIdx.y, l = (int)blockIdx.z, tiles = a.tiles;   // (a launch covers tiles [tile0, tile0 + gridDim.x))
   const int64_t sess0 = (int64_t)tile * 32;
   const int64_t sess = sess0 + lr;
   const bool live = sess < M;
@@ -282,13 +292,15 @@ bool lgru_wide_applies(const ModelDev& m, int64_t n_sess) {
   const char* chain = getenv("HIERTCN_LGRU_CHAIN");   // "1": set by the shared-GPU guard (distributed.py): no launch that waits on other workgroups
   if (chain && chain[0] == '1') return false;
   if (!lgru_tile_applies(m, n_sess) || m.H != 256 || m.gru_bar == nullptr) return false;
-  const int64_t tiles = (n_sess + 31) / 32;
-  return tiles * m.nl * LW_PARTS <= (m.n_cu > 0 ? m.n_cu : 256);   // every workgroup resident at once
+  const int64_t tiles = (n_sess + 31) / 32, per = lw_tiles_per_launch(m, LW_PARTS);   // every workgroup of a launch resident at once
+  return per >= 1 && tiles <= lw_max_launches(LW_PARTS) * per;
 }
 
-// bytes of the exchange slots + counters (0: the launch does not apply at this size)
+// bytes of the exchange slots + counters (0: no such launch for this model; sizes past the launch's range count as the largest one in it)
 size_t lgru_wide_bytes(const ModelDev& m, int64_t n_sess, int L) {
-  if (n_sess <= 0 || m.H != 256 || m.E != m.H || m.nl > 2 || (n_sess + 31) / 32 * m.nl * LW_PARTS > 256) return 0;
+  if (n_sess <= 0 || m.H != 256 || m.E != m.H || m.nl > 2) return 0;
+  const int64_t cap = 32 * lw_max_launches(LW_PARTS) * lw_tiles_per_launch(m, LW_PARTS);   // a workspace sized for a larger batch still serves the smaller ones
+  if (n_sess > cap) n_sess = cap;
   const size_t tiles = (size_t)(n_sess + 31) / 32;
   const size_t x = (size_t)m.nl * L * 2 * (size_t)n_sess * m.H * 2;
   return 2 * ((x + 255) & ~(size_t)255) + ((tiles * m.nl * L * 2 * 4 + 255) & ~(size_t)255);
@@ -315,7 +327,12 @@ hipError_t launch_lgru_wide(const ModelDev& m, const uint16_t* u16, const int32_
   if ((e = hipMemsetAsync(a.cnt, 0, (size_t)tiles * m.nl * L * 2 * 4, st)) != hipSuccess) return e;
   const size_t lds = lw_lds_bytes();
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_wide), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-  hipLaunchKernelGGL(k_lgru_wide, dim3(tiles, LW_PARTS, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+  const unsigned per = (unsigned)lw_tiles_per_launch(m, LW_PARTS);
+  a.tiles = (int)tiles;
+  for (unsigned t0 = 0; t0 < tiles; t0 += per) {
+    a.tile0 = (int)t0;
+    hipLaunchKernelGGL(k_lgru_wide, dim3(tiles - t0 < per ? tiles - t0 : per, LW_PARTS, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+  }
   return hipGetLastError();
 }
 
@@ -345,6 +362,7 @@ struct LgruWideBwdArgs {
   int* flagx;                                // [nl][tiles][L][HB]: d x of (layer, tile, step, part) published
   unsigned long long* err;
   int M, L, HT, nl;
+  int tile0, tiles;                          // this launch's first tile; tiles of the whole batch (the counters' stride)
 };
 
 template <int HB>   // H / 32 in {4, 8} = workgroups per (tile, layer)
@@ -359,7 +377,7 @@ __global__ __launch_bounds__(LW_THREADS, 1) void k_lgru_wide_bwd(const LgruWideB
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int lr = lane & 31, lh = lane >> 5;
   const int nl = a.nl, L = a.L, M = a.M, HT = a.HT;
-  const int tile = (int)blockIdx.x, p = (int)blockIdx.y, tiles = (int)gridDim.x;
+  const int tile = a.tile0 + (int)blockIdx.x, p = (int)blockIdx.y, tiles = a.tiles;
   const int l = nl - 1 - (int)blockIdx.z;          // (the top layer's workgroups first in dispatch order: they are the producers)
   const int64_t sess0 = (int64_t)tile * 32;
   const int64_t sess = sess0 + lr;
@@ -620,13 +638,15 @@ bool lgru_wide_bwd_applies(const ModelDev& m, int64_t n_sess) {
   const char* chain = getenv("HIERTCN_LGRU_CHAIN");
   if (chain && chain[0] == '1') return false;
   if (!lgru_tile_applies(m, n_sess) || !(m.H == 128 || m.H == 256) || m.gru_bar == nullptr || !m.lgru_wgTF_hi[0]) return false;
-  const int64_t tiles = (n_sess + 31) / 32;
-  return tiles * m.nl * (m.H / 32) <= (m.n_cu > 0 ? m.n_cu : 256);
+  const int64_t tiles = (n_sess + 31) / 32, per = lw_tiles_per_launch(m, m.H / 32);
+  return per >= 1 && tiles <= lw_max_launches(m.H / 32) * per;
 }
 
-// bytes of the d x slots + counters + flags (0: does not apply at this size)
+// bytes of the d x slots + counters + flags (0: no such launch for this model; sizes past its range count as the largest one in it)
 size_t lgru_wide_bwd_bytes(const ModelDev& m, int64_t n_sess, int L) {
-  if (n_sess <= 0 || !(m.H == 128 || m.H == 256) || m.E != m.H || m.nl > 2 || (n_sess + 31) / 32 * m.nl * (m.H / 32) > 256) return 0;
+  if (n_sess <= 0 || !(m.H == 128 || m.H == 256) || m.E != m.H || m.nl > 2) return 0;
+  const int64_t cap = 32 * lw_max_launches(m.H / 32) * lw_tiles_per_launch(m, m.H / 32);
+  if (n_sess > cap) n_sess = cap;
   const size_t tiles = (size_t)(n_sess + 31) / 32;
   const size_t x = (size_t)m.nl * L * (size_t)n_sess * m.H * 4;
   return ((x + 255) & ~(size_t)255) + ((tiles * m.nl * L * (2 + (size_t)m.H / 32) * 4 + 255) & ~(size_t)255);
@@ -651,14 +671,22 @@ hipError_t launch_lgru_wide_bwd(const ModelDev& m, const float* dH, const int32_
   a.err = reinterpret_cast<unsigned long long*>(m.gru_bar) + 8 * 16;
   hipError_t e;
   if ((e = hipMemsetAsync(a.cnt, 0, (size_t)tiles * m.nl * L * (2 + HB) * 4, st)) != hipSuccess) return e;
+  const unsigned per = (unsigned)lw_tiles_per_launch(m, HB);
+  a.tiles = (int)tiles;
   if (HB == 8) {
     const size_t lds = lwb_lds_bytes<8>();
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_wide_bwd<8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lgru_wide_bwd<8>, dim3(tiles, 8, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+    for (unsigned t0 = 0; t0 < tiles; t0 += per) {
+      a.tile0 = (int)t0;
+      hipLaunchKernelGGL(k_lgru_wide_bwd<8>, dim3(tiles - t0 < per ? tiles - t0 : per, 8, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+    }
   } else {
     const size_t lds = lwb_lds_bytes<4>();
     if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_lgru_wide_bwd<4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)) != hipSuccess) return e;
-    hipLaunchKernelGGL(k_lgru_wide_bwd<4>, dim3(tiles, 4, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+    for (unsigned t0 = 0; t0 < tiles; t0 += per) {
+      a.tile0 = (int)t0;
+      hipLaunchKernelGGL(k_lgru_wide_bwd<4>, dim3(tiles - t0 < per ? tiles - t0 : per, 4, (unsigned)m.nl), dim3(LW_THREADS), lds, st, a);
+    }
   }
   return hipGetLastError();
 }

@@ -169,8 +169,10 @@ def torch_loss_gru(args, P, x, y, mask, state):
 # the last shape has 640 sessions per step: the row-reduced weight-gradient GEMMs of the low-level cells (csrc/gemm.hip, gemm32_tn) then run in two
 # row slices whose partial tiles are summed in slice order
 @pytest.mark.parametrize("d,H,N,nl,shape", [(64, 64, 700, 2, (6, 3, 8)), (128, 64, 1500, 1, (6, 3, 8)), (64, 64, 700, 2, (160, 4, 6)),
-                                            (128, 128, 900, 2, (9, 4, 7)), (128, 128, 900, 1, (40, 2, 5)), (256, 256, 600, 2, (5, 3, 6))],
-                         ids=["d64_nl2", "d128_nl1", "d64_nl2_640_sessions", "d128_h128_nl2", "d128_h128_nl1", "d256_h256_nl2"])
+                                            (128, 128, 900, 2, (9, 4, 7)), (128, 128, 900, 1, (40, 2, 5)), (256, 256, 600, 2, (5, 3, 6)),
+                                            (256, 256, 600, 2, (80, 8, 5)), (128, 128, 600, 2, (150, 8, 4))],
+                         ids=["d64_nl2", "d128_nl1", "d64_nl2_640_sessions", "d128_h128_nl2", "d128_h128_nl1", "d256_h256_nl2",
+                              "d256_640_sessions_two_launches", "d128_1200_sessions"])
 def test_hiergru_training_step_matches_autograd(d, H, N, nl, shape):
     from hiertcn_amd.engine import Engine, metrics_dict
     args = gru_args(N=N, d=d, H=H, nl=nl)
@@ -302,7 +304,7 @@ def test_persistent_low_level_matches_the_launch_chain_and_the_oracle(d, nl, B, 
 
 
 @pytest.mark.parametrize("d,nl,B,S,L", [(64, 2, 13, 3, 9), (128, 1, 7, 3, 20), (128, 2, 32, 10, 20), (128, 2, 41, 5, 11),
-                                        (256, 2, 32, 10, 20), (256, 1, 9, 3, 7), (256, 2, 11, 5, 9)])
+                                        (256, 2, 32, 10, 20), (256, 1, 9, 3, 7), (256, 2, 11, 5, 9), (256, 2, 64, 10, 12), (256, 2, 140, 10, 6)])
 def test_layer_pipelined_low_level_matches_the_session_tile_kernel(d, nl, B, S, L):
     """H <= 128: one workgroup per (32-session tile, LAYER) with the layer's weights resident in registers and the layers handing their state
     rows over through global slots + flags inside ONE launch (csrc/lgru_pipe.hip); HIERTCN_LGRU_PIPE=0 keeps the session-tile kernel (all layers in
@@ -310,7 +312,8 @@ def test_layer_pipelined_low_level_matches_the_session_tile_kernel(d, nl, B, S, 
     (a handful per launch); zeros past sequence_length identical; 30 repeated launches of the pipelined kernel are bitwise identical to the first
     (a hand-off read too early or torn would show as a difference); the time-out word stays clear.  d = 256: csrc/lgru_wide.hip -- eight
     workgroups per (tile, layer), each keeping one unit block's weights with the reduction split over its four waves, two all-to-all hand-offs per
-    cell (HIERTCN_LGRU_WIDE=0: the tile kernel); its sums over k are four partial sums, so a few more one-ulp differences are allowed."""
+    cell (HIERTCN_LGRU_WIDE=0: the tile kernel); its sums over k are four partial sums, so a few more one-ulp differences are allowed.  640 and 1400
+    sessions at d = 256 are more tiles than one launch keeps resident: two resp. three launches over consecutive tile ranges."""
     import os
     from hiertcn_amd.engine import Engine
     N = 900
