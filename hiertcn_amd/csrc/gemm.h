@@ -19,6 +19,7 @@ struct GruBwdEpi {
   float* na_dac; float* na_dag; float* na_dhpart;
 };
 hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, const GruBwdEpi& ep, hipStream_t st);
+int gemm32_skinny_max_rows();
 hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st);
 //   TN: C[N1][N2] (ldc) = beta C + sum_{m < Mred} A[m][N1] (lda) . B[m][N2] (ldb); scratch (optional): partial tiles of the row slices
 hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int N1, int N2, int Mred, float beta,

@@ -364,9 +364,18 @@ __global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, co
   }
 }
 
+// rows up to which the skinny kernel (32-row tiles, the reduction split over a workgroup's waves) takes an nn product instead of the tiled one, and the
+// scan's backward its fused three-launch cells (train.hip).  Round 4: 64 -> 4096 -- the tiled kernel's 33 us per [128 x 512] . [512 x 256] product was
+// 1.4 ms of a 3.6 ms training step at 128 lanes (2.5 ms now; 256 / 512 / 1024 / 2048 lanes: 5.3 -> 4.0, 8.5 -> 7.2, 13.6 -> 12.2, 23.8 -> 22.9 ms;
+// even at 4096, the tiled form ahead from 8192).  HIERTCN_SKINNY_MAX_ROWS overrides.
+int gemm32_skinny_max_rows() {
+  static const int v = [] { const char* e = getenv("HIERTCN_SKINNY_MAX_ROWS"); return e ? atoi(e) : 4096; }();
+  return v;
+}
+
 hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st) {
   if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along k (A) and n (B)
-  if (M > 0 && M <= 64 && N > 0) {
+  if (M > 0 && M <= gemm32_skinny_max_rows() && N > 0) {
     G32 g;
     g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = K; g.beta = beta;
     g.k_per_split = K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;
@@ -380,7 +389,7 @@ hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, f
 // C-less products of a GRU cell's backward (M <= 64 rows): mode 1: [M][K] = dac[M][H] . wc[H][K] with k_gru_bwd_b's arithmetic as the epilogue (ep.dcat_c
 // receives the input half); mode 2: [M][K] = dag[M][2H] . wg[2H][K] with k_gru_bwd_c's.
 hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, const GruBwdEpi& ep, hipStream_t st) {
-  if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || M <= 0 || M > 64 || N != ep.in + ep.H) return hipErrorInvalidValue;
+  if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3) || M <= 0 || M > gemm32_skinny_max_rows() || N != ep.in + ep.H) return hipErrorInvalidValue;
   G32 g;
   g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = const_cast<float*>(ep.dcat_c); g.ldc = ep.K; g.M = M; g.N = N; g.K = K; g.beta = 0.f;
   g.k_per_split = K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;

@@ -1142,7 +1142,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   const size_t cell = (size_t)B * 5 * H;
   const unsigned gBH = (unsigned)(((int64_t)B * H + 255) / 256);
   static const bool bptt_unfused = getenv("HIERTCN_GRU_BPTT_UNFUSED") != nullptr;
-  const bool bptt_fused = B <= 64 && !bptt_unfused;
+  const bool bptt_fused = B <= gemm32_skinny_max_rows() && !bptt_unfused;
   const bool bptt_persist = gru_bptt_persist_applies(m, B, S);
   if (bptt_persist)   // small batches: the whole backward scan as ONE persistent launch (gru_persist.hip, k_gru_bptt_persist)
     T_HIP(launch_gru_bptt_persist(m, gsave, hist, mask, dsb, B, S, dac_all, dag_all, dpooled, st));
