@@ -570,7 +570,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   int32_t* row_map = reinterpret_cast<int32_t*>(ws + w.map);
   int32_t* n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
   float* split = nullptr;
-  if (!(exact && !split16) && so.topk == 0 && score_split_parts(R, h->m.NP, split16 ? 256 : 512) > 1) {
+  if (!(exact && !split16) && so.topk == 0 && score_split_scratch_parts(R, h->m.NP, split16 ? 256 : 512) > 1) {
     split = reinterpret_cast<float*>(ws + w.split);
     if (!so.target) so.target = reinterpret_cast<float*>(ws + w.tgt);   // the merge needs the target logit
   }

@@ -329,7 +329,8 @@ static hipError_t launch_gemm(const GemmArgs* g, int n, hipStream_t st) {
   gp.g[0] = g[0];
   gp.g[1] = g[n > 1 ? 1 : 0];
   const int tiles = ((g[0].M + 31) / 32) * (g[0].N / 32);
-  if (tiles * n <= 128)
+  static const int split_max = [] { const char* e = getenv("HIERTCN_GEMM_SPLIT_MAX_TILES"); return e ? atoi(e) : 1024; }();
+  if (tiles * n <= split_max)
     hipLaunchKernelGGL((k_gemm_f32<EPI, 4>), dim3(tiles, n), dim3(256), 0, st, gp);
   else
     hipLaunchKernelGGL((k_gemm_f32<EPI, 0>), dim3((tiles + 3) / 4, n), dim3(256), 0, st, gp);

@@ -45,11 +45,17 @@ int score_split_parts(int64_t R, int NP, int rows_per_wg) {
   return best;
 }
 
+static bool score_dyn_applies(int64_t R, int NP, int rows_per_wg);
 int score_split_scratch_parts(int64_t R, int NP, int rows_per_wg) {
   const int parts = score_split_parts(R, NP, rows_per_wg);
+  if (rows_per_wg == 512 && score_dyn_applies(R, NP, 1024)) return parts > SC_DYN_MAX_PARTS ? parts : SC_DYN_MAX_PARTS;   // (the two-block kernel's device-side split)
   return parts > 1 ? (parts > SC_DYN_MAX_PARTS ? parts : SC_DYN_MAX_PARTS) : 1;
 }
-// small batch = the device-side split applies: fewer than 128 row tiles at the host's bound (score_split_parts' first branch) and a split at all
+// small batch = the device-side split applies: fewer than 128 row tiles at the host's bound (score_split_parts' first branch) and a split at all.
+// The kernels pass TWICE their rows per workgroup: the 256-workgroup grid deals one (row tile, part) to each workgroup, so up to 256 live tiles fit --
+// one-block workgroups (256 rows) up to 65,024 rows, two-block ones (512 rows) up to 130,048.  The bound is the host's PADDED row count; the live
+// count (ragged sessions: about half of it) is only known on the device, which is why a static split there misjudges the grid (512 lanes x 10 x 20:
+// 200 padded tiles, 105 live ones, one part = 105 workgroups of the whole catalogue on 256 CUs: 0.73 ms of a 1.46 ms batch).
 static bool score_dyn_applies(int64_t R, int NP, int rows_per_wg) {
   static const bool off = getenv("HIERTCN_SCORE_DYN_OFF") != nullptr;
   return !off && (R + rows_per_wg - 1) / rows_per_wg < 128 && score_split_parts(R, NP, rows_per_wg) > 1;
@@ -1319,7 +1325,7 @@ static hipError_t launch_score_pipe(const ModelDev& m, const uint16_t* hidden, c
   int* walk = m.walk_pos;   // owned by the handle (per device): hiertcn_create; null with HIERTCN_FIXED_WALK=1
   constexpr int FNB = (NB == 1 && NSTG == 3) ? 2 : NB;   // the fix-up flavour exists in the two-block shape at three stages (as launch_score_topk uses it)
   const int parts = score_split_parts(R, m.NP);
-  if ((PMODE == 5 || PMODE >= 7) && split_scratch && out->rank && out->ce && out->target && score_dyn_applies(R, m.NP, 512)) {
+  if ((PMODE == 5 || PMODE >= 7) && split_scratch && out->rank && out->ce && out->target && score_dyn_applies(R, m.NP, 512 * NB)) {
     // small batch: SC_DYN_GRID workgroups, (row tile, catalogue part) decided on the device from the live row count (score_geom.h)
     const int n_all = m.NP / SC_STAGE;
     hipLaunchKernelGGL((k_score_pipe<C, PMODE, NB, NSTG, PAD, false>), dim3(SC_DYN_GRID), dim3(SC_THREADS), lds, st, hidden, y, R, m.outT, m.out_bias, m.N, m.NP,

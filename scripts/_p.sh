@@ -1,9 +1,5 @@
-export N=20778 S=10 L=20 D=256
-for B in 4096 8192; do
-  for mx in 64 1000000; do
-    HIERTCN_SKINNY_MAX_ROWS=$mx timeout 120 python3 scripts/train_bench.py $B 10 ragged 2>&1 | tail -1 | cut -c1-75 | sed "s/^/max $mx: /"
-  done
-done
-for mx in 64 1000000; do
-HIERTCN_SKINNY_MAX_ROWS=$mx LOW=gru D=128 timeout 120 python3 scripts/train_bench.py 256 20 ragged 2>&1 | tail -1 | cut -c1-75 | sed "s/^/gru d128 256 lanes max $mx: /"
+python -m pytest tests/test_gpu_parity.py tests/test_gpu_xing_shape.py tests/test_gpu_fuzz.py tests/test_gpu_run_loop.py tests/test_gpu_gru_persist.py -x -q -m gpu 2>&1 | tail -4
+for B in 128 256 512 600 1024 2048; do
+    timeout 120 python3 scripts/cfg2_bench.py $B 100 2>&1 | grep "ms per batch" | head -1
+    HIERTCN_SCORE_DYN_OFF=1 timeout 120 python3 scripts/cfg2_bench.py $B 100 2>&1 | grep "ms per batch" | head -1 | sed "s/^/dyn off: /"
 done
