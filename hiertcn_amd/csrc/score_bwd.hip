@@ -659,12 +659,23 @@ size_t sgrad_dwo_slab_floats(const ModelDev& m, int64_t R) {
 }
 
 #define SG_DYN_MAX_PARTS 16   // (a slab of d hidden per part: 16 x 6,464 rows x 1 KB = 106 MB at the reference's batch and d = 256)
+// ... and fewer for larger batches, so that the slabs stay near those 106 MB: the device deals at most grid / (live row blocks) parts anyway (ragged
+// batches: about half of the padded blocks are live), at least two
+static int sg_dyn_max_parts(const ModelDev& m, int64_t R) {
+  const int64_t p = (int64_t)SG_DYN_MAX_PARTS * 6464 * 256 / ((R + 64) * (int64_t)m.Clast);
+  return p > SG_DYN_MAX_PARTS ? SG_DYN_MAX_PARTS : p < 2 ? 2 : (int)p;
+}
 // floats of the `part` scratch of launch_sgrad_forward (0: the batch is not small, no split)
 size_t sgrad_forward_part_floats(const ModelDev& m, int64_t R) {
   static const bool off = getenv("HIERTCN_SGRAD_DYN_OFF") != nullptr;
+  // fewer than 128 PADDED row blocks.  (Measured and left: up to the grid's 256 -- 256 lanes x 10 x 20 are 200 padded blocks, ~105 live ones, so the device
+  // deals 105 x 2 parts instead of 105 workgroups of the whole table -- took 1.13 ms against 1.10: a stage costs 3.4 us with 105 CUs busy and 5.3 - 6.9 us
+  // with 210, the launch is no shorter.  HIERTCN_SGRAD_DYN_MAX_BLOCKS=256 repeats it.)
+  static const int max_blocks = getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS") ? atoi(getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS")) : 127;
   const int stat2 = sg_stat(m.Clast, sg_one(m.Clast, 2));
-  if (off || (R + stat2 - 1) / stat2 >= 128 || m.NP / sg_si(m.Clast, sg_one(m.Clast, 2)) < 32) return 0;
-  return (size_t)(2 * SG_DYN_MAX_PARTS + 1) * (size_t)(R + 64) + (size_t)SG_DYN_MAX_PARTS * (size_t)(R + 64) * (size_t)m.Clast;
+  if (off || (R + stat2 - 1) / stat2 > max_blocks || m.NP / sg_si(m.Clast, sg_one(m.Clast, 2)) < 32) return 0;
+  const size_t mp = (size_t)sg_dyn_max_parts(m, R);
+  return (2 * mp + 1) * (size_t)(R + 64) + mp * (size_t)(R + 64) * (size_t)m.Clast;
 }
 
 bool sgrad_supported(const ModelDev& m) {
@@ -709,11 +720,11 @@ hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const
   if (part && n_dev && row_map && sgrad_forward_part_floats(m, R) > 0) {
     // small batch (the reference's 32 lanes: 25 row blocks, half of them empty when ragged, each walking the whole table): SC_DYN_GRID workgroups dealt
     // as (row block, table part) on the device from the live row count
-    a.part = part; a.part_ld = R + 64; a.dyn_max_parts = SG_DYN_MAX_PARTS;
+    a.part = part; a.part_ld = R + 64; a.dyn_max_parts = sg_dyn_max_parts(m, R);
     a.walk = nullptr;
     hipError_t e = launch_k_sgrad_c<2>(m, a, dim3(SC_DYN_GRID), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sgrad_finish, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, part, a.part_ld, SG_DYN_MAX_PARTS, SC_DYN_GRID, stat2, a.n_stages_max, n_dev,
+    hipLaunchKernelGGL(k_sgrad_finish, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, part, a.part_ld, a.dyn_max_parts, SC_DYN_GRID, stat2, a.n_stages_max, n_dev,
                        row_map, y, w, m.outT, m.N, m.Clast, dh, o_rank, o_ce, o_tgt, ovf);
     return hipGetLastError();
   }
