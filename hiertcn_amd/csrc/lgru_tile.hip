@@ -278,7 +278,9 @@ static size_t lt_lds_bytes(const ModelDev& m) {
 
 static int64_t lt_max_sessions() {
   const char* e = getenv("HIERTCN_LGRU_TILE_MAX");   // sessions up to which the session-tile kernels run (A/B runs)
-  return e ? atoll(e) : 32768;   // (measured up to 20,480 sessions: 77.6 vs 80.0 ms per 1024-user evaluation step at d = 256 against the launch chain, 51.9 vs 53.7 at d = 128)
+  // (measured up to 20,480 sessions of 30 steps: 77.6 vs 80.0 ms per 1024-user evaluation step at d = 256 against the launch chain, 51.9 vs 53.7 at d = 128;
+  //  round 4, 40,960 sessions of <= 20 steps, N = 20,778: evaluation 10.3 vs 14.4 ms at d = 256, 4.6 vs 7.2 at d = 128; training step 68 vs 82 and 33 vs 39 ms)
+  return e ? atoll(e) : 131072;
 }
 
 bool lgru_tile_applies(const ModelDev& m, int64_t n_sess) {

@@ -666,10 +666,13 @@ struct TrainWs {
 // The scoring layer's backward: score_bwd.hip (no d-logits matrix, no host read-back) where the kernel is built for the
 // width; HIERTCN_TRAIN_LEGACY=1 selects the previous path (G chunks + two products per chunk on gemm.hip's kernels) for A/B runs.
 // HierGRU low level: keep the pre-activation gradients of every (step, layer) cell and form the weight gradients behind the BPTT loop (as the
-// across-session scan always does) while that costs at most 1 GiB: the launch-bound regime (the reference's 32 lanes = 640 sessions: 118 MB).  Past
-// it a cell's products fill the chip by themselves and the 15 GB this would take at the bench shape buy nothing.
+// across-session scan always does) while that costs at most 8 GiB (the reference's 32 lanes = 640 sessions: 118 MB).  That is also what lets the
+// session-tile backward run (lgru_tile.hip / lgru_wide.hip keep every cell's pre-activation gradients).  Round 4: 1 -> 8 GiB -- at 1 GiB batches past
+// ~870 lanes x 10 slots x 20 steps (d = 256) fell back to the per-cell launch chain: 27.1 ms per training step at 1024 lanes against 20.0 (2048: 44.2 -> 36.3;
+// d = 128, 2048: 26.9 -> 17.0).  HIERTCN_LGRU_DEFER_MAX_GIB overrides.
 static bool lgru_deferred_wgrad(const ModelDev& m, size_t M, int L) {
-  return (size_t)m.nl * L * M * 3 * m.H * 4 <= ((size_t)1 << 30) && !getenv("HIERTCN_LGRU_WGRAD_PER_CELL");
+  static const size_t gib = getenv("HIERTCN_LGRU_DEFER_MAX_GIB") ? (size_t)atoi(getenv("HIERTCN_LGRU_DEFER_MAX_GIB")) : 8;
+  return (size_t)m.nl * L * M * 3 * m.H * 4 <= (gib << 30) && !getenv("HIERTCN_LGRU_WGRAD_PER_CELL");
 }
 
 static bool fused_scoring_backward(const ModelDev& m) { return sgrad_supported(m) && !getenv("HIERTCN_TRAIN_LEGACY"); }
