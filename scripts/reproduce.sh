@@ -59,3 +59,4 @@ echo "== tile-skip census (profiles/r3_score_ablation.md)"; python3 scripts/skip
 echo "== parity against the exact oracle on unrounded fp32 weights"; python3 tests/tools/parity_fp32_probe.py 2>&1 | grep shape | cut -c1-400
 echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3
 echo "== repeated full-size launches agree (ranks, target logits bitwise; ce to 5e-5)"; python3 scripts/soak_score.py 2>&1 | grep mismatching
+echo "== evaluation batch and training step against the number of lanes (DESIGN 4.9, profiles/r4_lane_sweep.txt)"; bash scripts/lane_sweep.sh 2>&1 | grep -v amdgpu.ids
