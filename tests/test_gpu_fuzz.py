@@ -24,6 +24,9 @@ def _cases(n=24, seed=20261002):
         out.append(dict(d=d, H=H, low=low, N=int(rng.integers(2, 3000)), B=int(rng.integers(1, 41)), S=int(rng.integers(1, 5)),
                         L=int(rng.integers(1, 34)), K=int(rng.integers(1, 7)), blocks=int(rng.integers(1, 4)), nl=int(rng.integers(1, 3)),
                         seed=int(rng.integers(1 << 30))))
+    # 66,560 padded rows, ~half of them live: past the one-block scoring kernel's device-side catalogue split (65,024 rows), inside the two-block
+    # kernel's (130,048); 2,100 items = 33 stages = two parts
+    out.append(dict(d=64, H=32, low="tcn", N=2100, B=260, S=8, L=32, K=3, blocks=1, nl=1, seed=77))
     return out
 
 
