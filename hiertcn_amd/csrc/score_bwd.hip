@@ -659,21 +659,27 @@ size_t sgrad_dwo_slab_floats(const ModelDev& m, int64_t R) {
 }
 
 #define SG_DYN_MAX_PARTS 16   // (a slab of d hidden per part: 16 x 6,464 rows x 1 KB = 106 MB at the reference's batch and d = 256)
-// ... and fewer for larger batches, so that the slabs stay near those 106 MB: the device deals at most grid / (live row blocks) parts anyway (ragged
-// batches: about half of the padded blocks are live), at least two
+// ... and fewer for larger batches, so that the slabs stay under 1 GiB (the device deals at most by_len = stages / 16 parts, and past 256 live row blocks at most
+// grid / blocks)
 static int sg_dyn_max_parts(const ModelDev& m, int64_t R) {
-  const int64_t p = (int64_t)SG_DYN_MAX_PARTS * 6464 * 256 / ((R + 64) * (int64_t)m.Clast);
+  const int64_t p = ((int64_t)1 << 28) / ((R + 64) * (int64_t)m.Clast);
   return p > SG_DYN_MAX_PARTS ? SG_DYN_MAX_PARTS : p < 2 ? 2 : (int)p;
 }
-// floats of the `part` scratch of launch_sgrad_forward (0: the batch is not small, no split)
+// Workgroups of the device-split launch: one round of the chip for fewer than 128 PADDED row blocks (the live ones are fewer still: every (block, part) gets a CU
+// of its own); past that -- up to 1024 padded blocks -- eight rounds' worth, of which the device uses rounds x 256 >= blocks x parts (score_dyn_split) and the
+// rest exit at once.  Without the split a batch of 138 live blocks is 138 workgroups walking the whole table on 256 CUs, and one of 273 two rounds of which
+// the second holds 17 workgroups.
+static int sg_dyn_grid(const ModelDev& m, int64_t R) {
+  static const int max_blocks = getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS") ? atoi(getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS")) : 1024;
+  const int stat2 = sg_stat(m.Clast, sg_one(m.Clast, 2));
+  const int64_t blocks = (R + stat2 - 1) / stat2;
+  if (blocks < 128) return SC_DYN_GRID;
+  return blocks <= max_blocks ? 8 * SC_DYN_GRID : 0;
+}
+// floats of the `part` scratch of launch_sgrad_forward (0: no device-side split at this size)
 size_t sgrad_forward_part_floats(const ModelDev& m, int64_t R) {
   static const bool off = getenv("HIERTCN_SGRAD_DYN_OFF") != nullptr;
-  // fewer than 128 PADDED row blocks.  (Measured and left: up to the grid's 256 -- 256 lanes x 10 x 20 are 200 padded blocks, ~105 live ones, so the device
-  // deals 105 x 2 parts instead of 105 workgroups of the whole table -- took 1.13 ms against 1.10: a stage costs 3.4 us with 105 CUs busy and 5.3 - 6.9 us
-  // with 210, the launch is no shorter.  HIERTCN_SGRAD_DYN_MAX_BLOCKS=256 repeats it.)
-  static const int max_blocks = getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS") ? atoi(getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS")) : 127;
-  const int stat2 = sg_stat(m.Clast, sg_one(m.Clast, 2));
-  if (off || (R + stat2 - 1) / stat2 > max_blocks || m.NP / sg_si(m.Clast, sg_one(m.Clast, 2)) < 32) return 0;
+  if (off || sg_dyn_grid(m, R) == 0 || m.NP / sg_si(m.Clast, sg_one(m.Clast, 2)) < 32) return 0;
   const size_t mp = (size_t)sg_dyn_max_parts(m, R);
   return (2 * mp + 1) * (size_t)(R + 64) + mp * (size_t)(R + 64) * (size_t)m.Clast;
 }
@@ -722,9 +728,10 @@ hipError_t launch_sgrad_forward(const ModelDev& m, const uint16_t* hidden, const
     // as (row block, table part) on the device from the live row count
     a.part = part; a.part_ld = R + 64; a.dyn_max_parts = sg_dyn_max_parts(m, R);
     a.walk = nullptr;
-    hipError_t e = launch_k_sgrad_c<2>(m, a, dim3(SC_DYN_GRID), st);
+    const int grid = sg_dyn_grid(m, R);
+    hipError_t e = launch_k_sgrad_c<2>(m, a, dim3((unsigned)grid), st);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL(k_sgrad_finish, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, part, a.part_ld, a.dyn_max_parts, SC_DYN_GRID, stat2, a.n_stages_max, n_dev,
+    hipLaunchKernelGGL(k_sgrad_finish, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, part, a.part_ld, a.dyn_max_parts, grid, stat2, a.n_stages_max, n_dev,
                        row_map, y, w, m.outT, m.N, m.Clast, dh, o_rank, o_ce, o_tgt, ovf);
     return hipGetLastError();
   }

@@ -29,6 +29,16 @@ __host__ __device__ inline ScDynSplit score_dyn_split(int64_t rows, int rows_per
   if (parts > by_len) parts = by_len;
   if (parts > max_parts) parts = max_parts;
   if (parts < 1) parts = 1;
+  if (grid > 256 && d.tiles * parts > 256) {
+    // a grid of several rounds of the 256 CUs (k_sgrad mode 2 past 128 row blocks): the part count that makes rounds x (stages per part + a workgroup's fixed
+    // cost, ~16 stages: hidden rows, target logits, the slab it stores) smallest -- 138 live blocks: 5 parts = 3 rounds x 81 against 1 round x 341
+    int best = 1, best_cost = 0x7fffffff;
+    for (int p = 1; p <= parts; p++) {
+      const int cost = ((d.tiles * p + 255) / 256) * ((n_all + p - 1) / p + 16);
+      if (cost < best_cost) { best_cost = cost; best = p; }
+    }
+    parts = best;
+  }
   d.parts = parts;
   d.part_stages = (n_all + parts - 1) / parts;
   return d;

@@ -73,9 +73,11 @@ def torch_loss(args, P, x, y, mask, state):
 # slice order), which the 252-row shapes never do
 # d128_h128: E == H -- the shape whose across-session scan AND its backward run as persistent launches (csrc/gru_persist.hip, k_gru_scan_persist with the
 # training records, k_gru_bptt_persist); 33 lanes: two passes of lanes per group
+# d64_rows33280: 130 padded row blocks -- the training forward's device-side table split on a grid of several rounds (score_bwd.hip, sg_dyn_grid), the scan's
+# backward through the fused skinny products at 130 lanes
 @pytest.fixture(scope="module", params=[(64, 700, 32, (7, 4, 9)), (128, 1500, 64, (7, 4, 9)), (512, 900, 64, (7, 4, 9)), (128, 1500, 64, (96, 4, 30)),
-                                        (128, 900, 128, (33, 5, 9))],
-                ids=["d64", "d128", "d512", "d128_rows11520", "d128_h128"])
+                                        (128, 900, 128, (33, 5, 9)), (64, 2100, 32, (130, 8, 32))],
+                ids=["d64", "d128", "d512", "d128_rows11520", "d128_h128", "d64_rows33280"])
 def trained(request):
     from hiertcn_amd.engine import Engine, metrics_dict
     d, N, H, (B, S, L) = request.param
@@ -495,3 +497,34 @@ def test_fused_scoring_backward_matches_the_chunked_path(d, overflow):
         a, b = gf[k].astype(np.float64), gl[k].astype(np.float64)
         rel = np.linalg.norm(a - b) / max(np.linalg.norm(b), 1e-30)
         assert np.isfinite(a).all() and rel < 2e-2, (k, rel)     # both round p to bf16 at different points: ~1e-2 apart at most
+
+
+def test_scoring_backward_split_over_several_rounds_equals_the_unsplit_walk():
+    """Past 128 padded row blocks the training forward of the scoring layer deals (row block, table part) over a grid of several rounds of the chip
+    (score_bwd.hip: sg_dyn_grid, score_dyn_split's cost rule); HIERTCN_SGRAD_DYN_MAX_BLOCKS=127 keeps one workgroup per row block walking the whole
+    table.  Same sums in another order: loss, carried state and every gradient of a 260-lane XING-sized step agree to 1e-5 (tests/tools/sgrad_split_probe.py,
+    one process per setting -- the library reads the variable once)."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = []
+    for blocks in (None, "127"):
+        env = dict(os.environ)
+        env.pop("HIERTCN_SGRAD_DYN_MAX_BLOCKS", None)
+        if blocks:
+            env["HIERTCN_SGRAD_DYN_MAX_BLOCKS"] = blocks
+        r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "sgrad_split_probe.py")], env=env, capture_output=True, text=True, timeout=600)
+        line = [ln for ln in r.stdout.splitlines() if ln.startswith("SGRAD_SPLIT_PROBE ")]
+        assert r.returncode == 0 and line, r.stderr[-2000:]
+        res.append(json.loads(line[0][len("SGRAD_SPLIT_PROBE "):]))
+    a, b = res
+    assert a["live_rows"] == b["live_rows"] and a["live_rows"] > 129 * 256          # more live row blocks than half the chip
+    assert abs(a["loss"] - b["loss"]) < 1e-5 * abs(b["loss"])
+    assert abs(a["state"] - b["state"]) <= 1e-6 * b["state"]
+    for k in b["grads"]:
+        ga, gb = np.asarray(a["grads"][k]), np.asarray(b["grads"][k])
+        assert abs(ga[0] - gb[0]) <= 1e-4 * gb[0] + 1e-30, k                           # sum of squares
+        scale = np.sqrt(gb[0] / max(1, len(gb) - 1)) if gb[0] > 0 else 1.0
+        assert np.abs(ga[1:] - gb[1:]).max() <= 1e-4 * max(np.abs(gb[1:]).max(), scale) + 1e-12, k
