@@ -25,7 +25,10 @@
 // to itself) -- at H = 256 up to three (measured, training step of 32 x 20 x 30 / 64 / 128 / 200 lanes x 10 x 20: 4.0 / 2.6 / 5.4 / 7.5 ms against
 // 5.7 / 3.8 / 6.1 / 7.5 ms with the session-tile kernels of lgru_tile.hip, which keep every CU busy with a tile of its own); at H = 128 one (two
 // launches of the backward cells at 1,280 sessions: 3.0 against 2.9 ms).
-static int lw_max_launches(int parts) { return parts == 8 ? 3 : 1; }
+static int lw_max_launches(int parts) {
+  static const int v = getenv("HIERTCN_LGRU_WIDE_MAX_LAUNCHES") ? atoi(getenv("HIERTCN_LGRU_WIDE_MAX_LAUNCHES")) : 3;
+  return parts == 8 ? v : 1;
+}
 static int64_t lw_tiles_per_launch(const ModelDev& m, int parts) {
   const int64_t cus = m.n_cu > 0 ? m.n_cu : 256;
   return cus / ((int64_t)m.nl * parts);
