@@ -2,7 +2,10 @@
 layer-pipelined HierGRU low level (lgru_pipe.hip), the device-side catalogue split of the scoring kernels, the persistent scans.  Repeats the
 evaluation of one ragged 32-lane batch and asserts that ranks / cross entropies / carried state are BITWISE those of the first run, then repeats a
 training forward + backward and asserts the loss is bitwise and every gradient within 1e-5 relative of the first run's (atomics reorder sums).
-usage: python scripts/soak_refbatch.py [n_eval] [n_train]"""
+usage: [LANES=260] python scripts/soak_refbatch.py [n_eval] [n_train]
+LANES > 64 (the mid-size forms of DESIGN 4.9: split-K scan chain, the two-block kernel's device-side split, the training forward's split over several rounds, the
+wide HierGRU kernels as several launches): ranks and carried state bitwise, cross entropies within 5e-5 and the loss within 1e-6 relative -- where the host-sized
+split takes over, the scoring workgroups start their item walk wherever their XCD's walk stands (HIERTCN_FIXED_WALK), so sums are formed in another order run to run."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -12,7 +15,8 @@ from hiertcn_amd.params import init_params
 
 n_eval = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
 n_train = int(sys.argv[2]) if len(sys.argv) > 2 else 200
-N, B, S, L = 20778, 32, 10, 20
+N, B, S, L = 20778, int(os.environ.get("LANES", "32")), 10, 20
+loose = B > 64
 rng = np.random.default_rng(0)
 ids = rng.integers(1, N, (B, S, L)) * (np.arange(L)[None, None, :] < rng.integers(1, L + 1, (B, S))[..., None])
 x = np.zeros_like(ids); x[..., 1:] = ids[..., :-1]
@@ -30,11 +34,13 @@ for low, d, dtype in (("tcn", 256, None), ("gru", 128, None), ("gru", 64, None),
         cur = (out["rank"].clone(), out["ce"].clone(), out["state"].clone())
         if first is None:
             first = cur
+        elif loose and torch.equal(first[0], cur[0]) and torch.equal(first[2], cur[2]) and float((first[1] - cur[1]).abs().max()) <= 5e-5:
+            pass
         elif not all(torch.equal(a, b) for a, b in zip(first, cur)):
             bad += 1
             print("MISMATCH eval", low, d, dtype, "iteration", i, flush=True)
     torch.cuda.synchronize()
-    msg = "%s d=%d %s: %d evaluation launches bitwise identical" % (low, d, dtype or "16-bit", n_eval)
+    msg = "%s d=%d %s, %d lanes: %d evaluation launches %s" % (low, d, dtype or "16-bit", B, n_eval, "agree (ranks, state bitwise; ce 5e-5)" if loose else "bitwise identical")
     if dtype is None:
         g0, l0 = None, None
         for i in range(n_train):
@@ -44,13 +50,15 @@ for low, d, dtype in (("tcn", 256, None), ("gru", 128, None), ("gru", 64, None),
             if g0 is None:
                 g0, l0 = g, loss
             else:
-                if not torch.equal(l0, loss):
+                if loose and float((l0 - loss).abs().max()) <= 1e-6 * float(l0.abs().max()):
+                    pass
+                elif not torch.equal(l0, loss):
                     bad += 1; print("MISMATCH train loss", low, d, i, flush=True)
                 for k in g0:
                     den = np.abs(g0[k]).max() + 1e-30
                     if np.abs(g[k] - g0[k]).max() / den > 1e-5:
                         bad += 1; print("MISMATCH grad", low, d, k, i, np.abs(g[k] - g0[k]).max() / den, flush=True)
-        msg += "; %d training passes: loss bitwise, gradients within 1e-5" % n_train
+        msg += "; %d training passes: loss %s, gradients within 1e-5" % (n_train, "within 1e-6" if loose else "bitwise")
     print(msg + "; timed_out %s" % eng.persistent_timed_out(), flush=True)
     bad += int(eng.persistent_timed_out())
     eng.close()
