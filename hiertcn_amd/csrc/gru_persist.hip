@@ -64,6 +64,9 @@ __device__ __forceinline__ void st_sc1(float* p, float v) { __hip_atomic_store(p
 // every wave's stores are complete (vmcnt(0)) before the workgroup's one add; the poll and everything behind it sit behind workgroup barriers.
 // `dead` (LDS): once a wait of this workgroup has run out, its later barriers add and go on without waiting -- a launch that cannot
 // complete correctly ends in about a second instead of twenty-two time-outs.
+// (Measured and dropped, round 4: later barriers of a launch know their target -- the first one's + k P -- so their add need not return before the polling
+// starts; with a non-returning add and polls from the moment of arrival the 32-lane batch took 0.226 ms against 0.2225: P workgroups polling a line that
+// the same P workgroups are still adding to costs more than the return trip saves.)
 __device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned P, unsigned long long* err, int* dead, unsigned spin_max) {
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -71,7 +74,8 @@ __device__ __forceinline__ void group_barrier(unsigned long long* bar, unsigned 
     const unsigned long long old = __hip_atomic_fetch_add(bar, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const unsigned long long target = (old / P + 1ull) * P;
     unsigned spins = 0;
-    while (!*dead && __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+    // (the workgroup whose add completes the epoch -- old + 1 == target -- has seen every arrival in the add's own return value: no poll; 0.2265 -> 0.2225 ms)
+    while (old + 1ull < target && !*dead && __hip_atomic_load(bar, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
       __builtin_amdgcn_s_sleep(1);
       if (++spins > spin_max) {   // never in a healthy run: leave a mark and go on rather than hang the device
         __hip_atomic_store(err, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
