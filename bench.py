@@ -385,6 +385,41 @@ def run_loop_leg(users=20000, lanes=32):
     return out
 
 
+def _sha16(*names):
+    import hashlib
+    h = hashlib.sha256()
+    for n in names:
+        with open(os.path.join(ROOT, "hiertcn_amd", "csrc", n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def traffic_from_profile(section, rows_per_launch, sources, ragged):
+    """-> (bytes per launch | None, traffic_code, source).  profiles/score_traffic.json is written by scripts/profile_round.sh (rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE passes of this same command; bench.py cannot read PMC counters itself) and names the code it was measured on: the
+    sha-256 of the kernel's source files and the git head.  The figure is used only when the hash of today's sources equals the recorded one
+    and the launch had the same rows; otherwise `traffic` is null and `traffic_code` says why."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "score_traffic.json")) as f:
+            tj = json.load(f)
+        sec = tj[section]
+    except (OSError, KeyError, ValueError):
+        return None, "no profile of this kernel in profiles/score_traffic.json", None
+    try:
+        now = _sha16(*sources)
+    except OSError:
+        now = None
+    rec = sec.get("source_sha16")
+    code = {"profiled_git_head": tj.get("git_head"), "profiled_sources_sha16": rec, "current_sources_sha16": now, "sources": list(sources)}
+    if rec is None or rec != now:
+        code["stale"] = "the kernel's sources changed since the counters were read: traffic withheld"
+        return None, code, sec.get("source")
+    if int(sec["rows_per_launch"]) != int(rows_per_launch) or ragged:
+        code["stale"] = "the profiled launch had %d rows, this one %d%s" % (int(sec["rows_per_launch"]), int(rows_per_launch), " (ragged)" if ragged else "")
+        return None, code, sec.get("source")
+    return sec["fetch_bytes_per_launch"] + sec["write_bytes_per_launch"], code, sec.get("source")
+
+
 def exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_over_ranks):
     """-> the `exact` object: the SAME evaluation step in the parity-grade modes (tests/test_gpu_exact_mode.py: logits < 1e-3 of the exact
     oracle at |z| = 10 and 30, ranks equal on > 99 % of rows, top-10 equal on every clear row) -- 'split16' (HIERTCN_PRECISION_SPLIT16: fp32
@@ -439,6 +474,13 @@ def exact_leg(a, args, params, rank, world, draw, shard_first, shard, dist, max_
            "achieved_algorithmic_tflops": round(alg, 2), "achieved_executed_tflops": round(3 * alg, 2),
            "frac_of_peak_over_3": round(alg / (MFMA_PEAK_TFLOPS / 3), 4),
            "peak_over_3": round(MFMA_PEAK_TFLOPS / 3, 1)}
+    tr_bytes, tr_code, tr_src = traffic_from_profile("exact", rows, ("score_x3.hip", "score_x3.h"), a.ragged)
+    out["roofline"] = {"bound": "mfma", "kernel": out["kernel"], "launch_ms": round(score_ms, 4), "launches_timed": int(launches),
+                       "flops_per_launch_algorithmic": flop, "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "achieved_algorithmic": round(alg, 2), "frac_algorithmic": round(alg / MFMA_PEAK_TFLOPS, 4),
+                       "achieved_executed": round(3 * alg, 2), "frac_executed": round(3 * alg / MFMA_PEAK_TFLOPS, 4),
+                       "traffic": tr_bytes, "traffic_code": tr_code, "traffic_source": tr_src,
+                       "algorithmic_bytes_per_launch": rows * (4 * DIM + 4 + 8) + 4 * DIM * N_ITEMS + 4 * N_ITEMS}
     # the fp32 mode (exact.hip) on the same handle, a smaller batch: ~20x slower, bounded by the 157 TFLOP/s fp32 MFMA (single-GPU runs only:
     # every rank of an N-GPU run does the same work in the same order)
     if rank == 0 and world == 1:
@@ -482,9 +524,12 @@ def main():
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of CPU work for the cpu_baseline leg")
     ap.add_argument("--no-exact", action="store_true", help="skip the parity-grade modes (the `exact` object of the JSON line)")
     ap.add_argument("--no-reference-batch", action="store_true", help="skip the reference's own batch shape (the `reference_batch` object of the JSON line)")
-    ap.add_argument("--exact-users-per-step", type=int, default=4096, help="users per step PER GPU of the split16 leg (4096 users = 9,600 workgroups of 256 rows = 37.5 rounds)")
-    ap.add_argument("--exact-steps", type=int, default=3)
-    ap.add_argument("--exact-warmup", type=int, default=1)
+    ap.add_argument("--exact-users-per-step", type=int, default=16384, help="users per step PER GPU of the split16 leg, measured like the headline: 16384 users = 38,400 "
+                    "workgroups of 256 rows = exactly 150 rounds of 256 CUs")
+    ap.add_argument("--exact-steps", type=int, default=10)
+    ap.add_argument("--exact-warmup", type=int, default=2)
+    ap.add_argument("--rccl-one-rank", action="store_true", help="N = 1 only: create a one-rank RCCL process group and run every collective of the step through it "
+                    "(multi_gpu.rccl_ranks: 1): librccl loaded, device tensors accepted, stream ordering exercised -- everything short of a second GPU")
     ap.add_argument("--exact-fp32-users", type=int, default=256)
     a = ap.parse_args()
 
@@ -504,7 +549,7 @@ def main():
     backend = os.environ.get("HIERTCN_BENCH_BACKEND", "nccl")
     dev_index = local_rank % max(torch.cuda.device_count(), 1) if backend != "nccl" else local_rank
     torch.cuda.set_device(dev_index)
-    rank, world, local_rank = init_from_env(backend, torch.device("cuda", dev_index))  # "nccl" = RCCL on ROCm
+    rank, world, local_rank = init_from_env(backend, torch.device("cuda", dev_index), force_group=bool(a.rccl_one_rank and world == 1))  # "nccl" = RCCL on ROCm
 
     from hiertcn_amd.args import hier_tcn_args
     from hiertcn_amd.engine import Engine, metrics_dict
@@ -586,7 +631,7 @@ def main():
         per_rank = [None] * world
         dist.all_gather_object(per_rank, mine)
     multi = {"backend": ("rccl" if backend == "nccl" else backend) if world > 1 else None,
-             "rccl_ranks": (dist.get_world_size() if world > 1 and backend == "nccl" else (0 if world > 1 else None)),
+             "rccl_ranks": (dist.get_world_size() if dist.is_initialized() and dist.get_backend() == "nccl" else (0 if world > 1 else None)),
              "ranks": world,
              "distinct_devices": len({(r["uuid"] or r["pci"]) for r in per_rank}),
              "per_rank": per_rank}
@@ -602,15 +647,7 @@ def main():
 
     # HBM/fabric bytes per scoring launch come from a separate rocprofv3 --pmc run of this same command
     # (bench.py cannot read PMC counters itself); used only when that run had the same rows per launch.
-    traffic, traffic_src = None, None
-    try:
-        with open(os.path.join(ROOT, "profiles", "score_traffic.json")) as f:
-            tj = json.load(f)
-        if int(tj["rows_per_launch"]) == rows_per_launch and not a.ragged:
-            traffic = tj["fetch_bytes_per_launch"] + tj["write_bytes_per_launch"]
-            traffic_src = tj["source"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_code, traffic_src = traffic_from_profile("headline", rows_per_launch, ("score.hip", "score_geom.h", "score_lists.h"), a.ragged)
 
     # a plain library GEMM on the same box, same data kind (random bf16), as a second yardstick beside the datasheet peak
     # ("the ratio against a measured hipBLASLt GEMM peak on the same box"); measurement only, not product path
@@ -742,6 +779,7 @@ def main():
                                        if dvfs and dvfs.get("random") and dvfs["random"].get("sclk_mhz") else None),
                 "traffic": traffic,
                 "traffic_unit": "bytes per launch through the L2's memory-side port (Infinity-Cache hits included)",
+                "traffic_code": traffic_code,
                 "traffic_source": traffic_src,
                 "algorithmic_bytes_per_launch": rows_per_launch * (2 * DIM + 4 + 8) + 2 * DIM * N_ITEMS + 4 * N_ITEMS,
                 "launch_ms": round(score_ms, 4),
@@ -762,7 +800,7 @@ def main():
             "setup_s": round(t_setup, 1),
         }
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhiertcn_gfx950.so")
-SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_grad.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "lgru_tile.hip", "lgru_pipe.hip", "lgru_wide.hip"]
+SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_grad.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "score_x3w.hip", "lgru_tile.hip", "lgru_pipe.hip", "lgru_wide.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Wno-shift-negative-value",
          "-fno-gpu-rdc", "-D__HIP_PLATFORM_AMD__"]
 
@@ -108,7 +108,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
         relink = True
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "exact.h"), os.path.join(CSRC, "gemm.h"), os.path.join(CSRC, "score_geom.h"), os.path.join(CSRC, "score_lists.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
+    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "exact.h"), os.path.join(CSRC, "gemm.h"), os.path.join(CSRC, "score_geom.h"), os.path.join(CSRC, "score_lists.h"), os.path.join(CSRC, "score_x3.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -120,7 +120,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
         s, o = job
         # score.hip: logits are finite or -inf by construction; without NaN-honouring fmaxf needs no
         # canonicalising v_max on MFMA results (cdna_hip_programming.md, attention 'Pitfalls')
-        per_file = ["-fno-honor-nans"] if s.endswith(("score.hip", "score_x3.hip")) else []
+        per_file = ["-fno-honor-nans"] if s.endswith(("score.hip", "score_x3.hip", "score_x3w.hip")) else []
         cmd = [hipcc, *FLAGS, *per_file, *extra_flags, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

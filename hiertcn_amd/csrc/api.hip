@@ -322,7 +322,7 @@ int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision) {
     return fail(HIERTCN_ERR_INVALID, "precision %d: HIERTCN_PRECISION_STORAGE16 (0), HIERTCN_PRECISION_FP32 (1) or HIERTCN_PRECISION_SPLIT16 (2)", precision);
   const int need = precision == HIERTCN_PRECISION_FP32 ? (X_LOW | X_FP32) : precision == HIERTCN_PRECISION_SPLIT16 ? (X_LOW | X_SPLIT) : 0;
   if (precision == HIERTCN_PRECISION_SPLIT16 && !score_x3_supported(h->m))
-    return fail(HIERTCN_ERR_INVALID, "HIERTCN_PRECISION_SPLIT16: the split-operand scoring kernel is built for a last width of 64, 128 or 256 (this model: %d); "
+    return fail(HIERTCN_ERR_INVALID, "HIERTCN_PRECISION_SPLIT16: the split-operand scoring kernels are built for a last width of 64, 128, 256 or 512 (this model: %d); "
                 "use HIERTCN_PRECISION_FP32", h->m.Clast);
   if (need & ~h->x.enabled) {
     if (h->weights_set)
@@ -527,7 +527,7 @@ static EvalWs eval_ws(const ModelDev& m, int64_t B, int64_t S, int64_t L, bool e
   w.nvalid = off; off += al256(sizeof(int32_t));
   w.cscratch = off; off += al256(((size_t)B * S * L / 1024 + 2) * sizeof(int32_t));
   w.tgt = off;    off += al256((size_t)B * S * L * sizeof(float));
-  w.split = off;  off += al256((size_t)score_split_scratch_parts(B * S * L, m.NP, split ? 256 : 512) * 2 * B * S * L * sizeof(float));   // small batches only (parts > 1)
+  w.split = off;  off += al256((size_t)score_split_scratch_parts(B * S * L, m.NP, split ? score_x3_rows_per_wg(m) : 512) * 2 * B * S * L * sizeof(float));   // small batches only (parts > 1)
   w.total = off;
   return w;
 }
@@ -570,7 +570,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   int32_t* row_map = reinterpret_cast<int32_t*>(ws + w.map);
   int32_t* n_valid = reinterpret_cast<int32_t*>(ws + w.nvalid);
   float* split = nullptr;
-  if (!(exact && !split16) && so.topk == 0 && score_split_scratch_parts(R, h->m.NP, split16 ? 256 : 512) > 1) {
+  if (!(exact && !split16) && so.topk == 0 && score_split_scratch_parts(R, h->m.NP, split16 ? score_x3_rows_per_wg(h->m) : 512) > 1) {
     split = reinterpret_cast<float*>(ws + w.split);
     if (!so.target) so.target = reinterpret_cast<float*>(ws + w.tgt);   // the merge needs the target logit
   }

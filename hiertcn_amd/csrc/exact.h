@@ -43,6 +43,9 @@ int64_t exact_chunk_rows(int N);
 hipError_t launch_exact_logits(const ModelDev& m, const ExactDev& x, const float* hidden, int64_t R, float* logits, hipStream_t st);
 // score_x3.hip: the fused scoring kernel on split 16-bit operands (HIERTCN_PRECISION_SPLIT16); hidden fp32 [R][Clast]
 bool score_x3_supported(const ModelDev& m);
+int score_x3_rows_per_wg(const ModelDev& m);
+hipError_t launch_score_x3w(const ModelDev& m, const ExactDev& x, const float* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
+                            float* logits, hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev, float* split_scratch);   // score_x3w.hip: last width 512
 hipError_t launch_transpose_split(const float* src, uint16_t* dst, int C, int64_t N, int64_t NP, float* scale, hipStream_t st);
 hipError_t launch_score_x3(const ModelDev& m, const ExactDev& x, const float* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                            float* logits, hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev, float* split_scratch);

@@ -13,13 +13,39 @@ import torch
 import torch.distributed as dist
 
 
-def init_from_env(backend: str | None = None, device: torch.device | None = None) -> Tuple[int, int, int]:
+_FORCE = False   # init_from_env(force_group=True): run every collective even at world size 1 (a one-rank RCCL communicator)
+
+
+def _active() -> bool:
+    """A process group whose collectives this module should enter: more than one rank, or a group forced at world size 1."""
+    return dist.is_available() and dist.is_initialized() and (dist.get_world_size() > 1 or _FORCE)
+
+
+def device_ident(device=None) -> str:
+    """hostname | (uuid or pci address) of a rank's GPU: equal on two ranks exactly when they share a device.  Never raises: a runtime that
+    reports neither gives a sentinel that is unique per process (the count-based answer then decides)."""
+    import socket
+    try:
+        prop = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device())
+        dev = str(getattr(prop, "uuid", "")) or "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
+                                                                    getattr(prop, "pci_device_id", 0))
+    except Exception:  # noqa: BLE001
+        dev = "unknown-%d" % os.getpid()
+    return socket.gethostname() + "|" + dev
+
+
+def init_from_env(backend: str | None = None, device: torch.device | None = None, force_group: bool = False) -> Tuple[int, int, int]:
     """Reads RANK / WORLD_SIZE / LOCAL_RANK (torch.distributed.run) -> (rank, world, local_rank).
-    world == 1 needs no process group."""
+    world == 1 needs no process group; force_group=True creates one all the same (backend "nccl": a one-rank RCCL communicator) and makes
+    every collective of this module run through it -- the whole multi-GPU path short of a second GPU (tests/test_gpu_rccl_one_rank.py,
+    `bench.py --rccl-one-rank`)."""
+    global _FORCE
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if device is not None and torch.cuda.is_available() and torch.device(device).type == "cuda":
+        torch.cuda.set_device(device)   # object collectives of the nccl backend stage through the CURRENT device
+    if (world > 1 or force_group) and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
@@ -27,21 +53,18 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
         if backend == "nccl" and device is not None:
             kw["device_id"] = device
         dist.init_process_group(backend, rank=rank, world_size=world, **kw)
+    if force_group:
+        _FORCE = True
     if world > 1 and torch.cuda.is_available():
         # Do ranks share a GPU (a gloo smoke run, HIP_VISIBLE_DEVICES mapping several ranks to one device, ...)?  The persistent launches (the
         # across-session scan and the HierGRU low level of small batches, csrc/gru_persist.hip) assume their workgroups are co-resident on a
-        # device of their own: decided from the devices actually in use -- every rank's (uuid | pci address) of its current device -- not
-        # from the rank count, and the launch chains run instead where a device is shared.
-        shared = world > torch.cuda.device_count()
-        try:
-            prop = torch.cuda.get_device_properties(device if device is not None else torch.cuda.current_device())
-            ident = str(getattr(prop, "uuid", "")) or "%04x:%02x:%02x" % (getattr(prop, "pci_domain_id", 0), getattr(prop, "pci_bus_id", 0),
-                                                                          getattr(prop, "pci_device_id", 0))
-            idents = [None] * world
-            dist.all_gather_object(idents, ident)
-            shared = shared or len(set(idents)) < world
-        except Exception:  # noqa: BLE001  (an identity the runtime does not report: keep the count-based answer)
-            pass
+        # device of their own: decided from the devices actually in use -- every rank's hostname | (uuid or pci address) -- not from the rank
+        # count, and the launch chains run instead where a device is shared.  The identity cannot fail (device_ident); the collective is
+        # entered by EVERY rank, outside any try: a rank that skipped it would leave the others waiting, and the answer -- hence the kernel
+        # choice -- is the same on all ranks.
+        idents = [None] * world
+        dist.all_gather_object(idents, device_ident(device))
+        shared = world > torch.cuda.device_count() * max(1, len({i.split("|")[0] for i in idents})) or len(set(idents)) < world
         if shared:
             os.environ.setdefault("HIERTCN_GRU_CHAIN", "1")
             os.environ.setdefault("HIERTCN_LGRU_CHAIN", "1")
@@ -59,7 +82,7 @@ def is_main() -> bool:
 
 
 def barrier():
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         dist.barrier()
 
 
@@ -75,7 +98,7 @@ def user_shard(n_users: int, rank: int, world: int) -> Tuple[int, int]:
 def all_reduce_metrics(m8: torch.Tensor) -> torch.Tensor:
     """In-place sum over ranks of the 8 accumulators; afterwards out[k] / out[6] is the metric
     over the GLOBAL batch (a mean over all lanes of all ranks, model.py:116-117 / loss.py:215-219)."""
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if _active():
         if m8.is_cuda and dist.get_backend() == "gloo":   # (tests / smoke runs: gloo reduces host tensors)
             host = m8.cpu()
             dist.all_reduce(host, op=dist.ReduceOp.SUM)
@@ -86,7 +109,7 @@ def all_reduce_metrics(m8: torch.Tensor) -> torch.Tensor:
 
 
 def max_over_ranks(seconds: float, device=None) -> float:
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+    if not _active():
         return seconds
     t = torch.tensor([seconds], dtype=torch.float64, device=device or ("cuda" if dist.get_backend() == "nccl" else "cpu"))
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -97,7 +120,7 @@ def _is_dist() -> bool:
     import os
     if os.environ.get("HIERTCN_DP_OFF"):   # bench.py: time the step without its collectives (replicas drift: timing only)
         return False
-    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+    return _active()
 
 
 class _Done:
@@ -163,6 +186,7 @@ class GradientExchange:
         self.dense_taken = None      # what _dense actually ran last: 'rs_ag', 'allreduce_bucketed' or 'allreduce' (rs_ag needs numel % world == 0)
         self._over_host = None       # pinned host copy of the step's summed "some rank exceeds ids_bound" flag + the event behind its copy
         self._over_event = None
+        self._over_fresh = False     # set by global_users, cleared by _ids_per_rank: a step that skipped global_users checks its own count
 
     @property
     def world(self) -> int:
@@ -188,13 +212,15 @@ class GradientExchange:
                 self._over_event.record()
             else:
                 self._over_host = t[1:2].clone()
+            self._over_fresh = True
         return t[0:1]
 
     def _ids_per_rank(self, n_local: int) -> int:
         """The number every rank uses for the all-gather capacity and the sparse-versus-dense decision of this step: the same on all
         ranks by construction (the host-known bound), or agreed on by a collective that every rank enters every step."""
         if self.ids_bound is not None:
-            if self._over_host is not None:          # the flag summed over ranks by this step's global_users: the same value everywhere
+            if self._over_fresh:                     # the flag summed over ranks by THIS step's global_users: the same value everywhere
+                self._over_fresh = False
                 if self._over_event is not None:
                     self._over_event.synchronize()
                 n_over = float(self._over_host[0])

@@ -1,4 +1,5 @@
-"""-m gpu: the split-operand scoring kernel (HIERTCN_PRECISION_SPLIT16, Engine(dtype='split16'); csrc/score_x3.hip) -- the fused
+"""-m gpu: the split-operand scoring kernels (HIERTCN_PRECISION_SPLIT16, Engine(dtype='split16'); csrc/score_x3.hip at a last width of 64 / 128 /
+256, csrc/score_x3w.hip at 512 = BASELINE.json configs[3]) -- the fused
 model_tcn.py:41 + model.py:105 + loss.py:21,120,179 on hi + lo IEEE-half parts, three MFMAs per product.
 
 What is held here: (1) the fused outputs are EXACTLY the rank / ranked top-k of the kernel's own materialised logits (same MFMA sequence),
@@ -28,12 +29,12 @@ def _engine(N, d, Wo, bo, seed=2):
     return eng
 
 
-@pytest.mark.parametrize("d,N,R", [(64, 1000, 700), (128, 2053, 1300), (256, 777, 515), (256, 5000, 2049)])
+@pytest.mark.parametrize("d,N,R", [(64, 1000, 700), (128, 2053, 1300), (256, 777, 515), (256, 5000, 2049), (512, 1500, 515), (512, 5000, 1300)])
 @pytest.mark.parametrize("k", [0, 5, 10, 16])
 def test_fused_outputs_are_exactly_those_of_the_kernels_own_logits(d, N, R, k):
     """rank = #{z_n > z_y} (loss.py:179), target = z_y, ranked top-k (loss.py:120: ties -> lower index) of the fused launch against NumPy on the
     logits flavour of the same kernel; ce against an fp64 log-sum-exp of those logits; rows without a target (0, out of range) -> 0 / 0 / 0..k-1.
-    Exact ties are forced by duplicated item columns, R is no multiple of the 256-row tile."""
+    Exact ties are forced by duplicated item columns, R is no multiple of the 256-row tile (128 rows at d = 512)."""
     rng = np.random.default_rng(d + N + k)
     Wo = (rng.standard_normal((d, N)) * (4.0 / np.sqrt(d))).astype(np.float32)
     bo = (0.3 * rng.standard_normal(N)).astype(np.float32)
@@ -74,7 +75,7 @@ def test_fused_outputs_are_exactly_those_of_the_kernels_own_logits(d, N, R, k):
     eng.close()
 
 
-@pytest.mark.parametrize("d", [64, 128, 256])
+@pytest.mark.parametrize("d", [64, 128, 256, 512])
 @pytest.mark.parametrize("wmag,hmag", [(1.0, 1.0), (1e-6, 1e-5), (3e5, 1e6)], ids=["unit", "tiny", "huge"])
 def test_split_logits_are_fp32_grade(d, wmag, hmag):
     """The three-product logits against the fp64 product of the SAME fp32 inputs: error of fp32 order relative to sum |h||w|, whatever the
@@ -123,7 +124,7 @@ def test_factors_far_below_the_tensor_maximum_sit_on_kept_subnormals():
     eng.close()
 
 
-@pytest.mark.parametrize("d", [64, 256])
+@pytest.mark.parametrize("d", [64, 256, 512])
 @pytest.mark.parametrize("case", ["single_term", "sum_of_terms", "late_spike"])
 def test_softmax_sum_past_fp32_is_redone_by_the_fixup_launch(case, d):
     """The production flavour keeps the target logit + 64 as its softmax reference and leaves ce = +inf where the running sum leaves fp32
@@ -162,12 +163,13 @@ def test_softmax_sum_past_fp32_is_redone_by_the_fixup_launch(case, d):
     eng.close()
 
 
-def test_forward_eval_compaction_and_catalogue_split_change_no_rank():
+@pytest.mark.parametrize("d", [256, 512])
+def test_forward_eval_compaction_and_catalogue_split_change_no_rank(d):
     """hiertcn_forward_eval in this mode: the fp32 low level, the device-side list of rows that carry a target, and -- at this batch size --
     (row tile x catalogue part) workgroups merged by k_score_merge, against the step-by-step calls on dense rows (one workgroup per row tile):
     identical ranks, ce to rounding, identical metrics; padded steps 0."""
     from hiertcn_amd.engine import Engine, metrics_dict
-    N, d, B, S, L = 20_778, 256, 32, 10, 20
+    N, B, S, L = 20_778, 32, 10, 20
     args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
     p = make_params(args)
     p["hier/tcn/dense/kernel"] = (p["hier/tcn/dense/kernel"] * 40).astype(np.float32)
@@ -202,10 +204,11 @@ def test_forward_eval_compaction_and_catalogue_split_change_no_rank():
     eng.close()
 
 
-def test_ranks_do_not_depend_on_the_item_walk_or_the_launch():
+@pytest.mark.parametrize("d,R", [(256, 300_000), (512, 100_000)])
+def test_ranks_do_not_depend_on_the_item_walk_or_the_launch(d, R):
     """Large launch (several rounds of workgroups: later ones start their item walk where their XCD's neighbours are): ranks and targets
     identical across repeated launches and equal to the fixed-walk list flavour's; ce equal to rounding."""
-    N, d, R = 60_000, 256, 300_000
+    N = 60_000
     rng = np.random.default_rng(3)
     Wo = (rng.standard_normal((d, N)) * (3.0 / np.sqrt(d))).astype(np.float32)
     bo = (0.2 * rng.standard_normal(N)).astype(np.float32)
@@ -254,9 +257,8 @@ def test_split16_contract_errors():
     args = small_args(N=300, d=64, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
     with pytest.raises(HierTCNError, match="EVALUATION"):
         Engine(args, hier=True, dtype="split16", train=True)
-    wide = small_args(N=300, d=512, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
-    with pytest.raises(HierTCNError, match="64, 128 or 256"):
-        Engine(wide, hier=True, dtype="split16")
+    wide = small_args(N=300, d=512, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)   # every last width hiertcn_create takes has a split kernel (512: score_x3w.hip)
+    Engine(wide, hier=True, dtype="split16").close()
     eng = Engine(args, hier=True)                      # a 16-bit handle whose weights are set has no split table
     eng.set_weights(make_params(args))
     with pytest.raises(HierTCNError, match="precede hiertcn_set_weights"):
