@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhiertcn_gfx950.so")
-SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_grad.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "score_x3w.hip", "lgru_tile.hip", "lgru_pipe.hip", "lgru_wide.hip"]
+SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "score_x3w.hip", "lgru_tile.hip", "lgru_pipe.hip", "lgru_wide.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Wno-shift-negative-value",
          "-fno-gpu-rdc", "-D__HIP_PLATFORM_AMD__"]
 
@@ -37,6 +37,60 @@ LIB_TESTHOOKS = os.path.join(HERE, "libhiertcn_gfx950_testhooks.so")
 TESTHOOK_SOURCES = ("gru_persist.hip", "lgru_pipe.hip")   # the sources that hold a fault-injection switch
 
 
+# libhiertcn_gfx950_ablation.so: the bfloat16 library PLUS every superseded kernel and A/B switch (-DHIERTCN_ABLATION=1): the previous forms of the
+# scoring / top-k / TCN-layer kernels, the legacy scoring backward (score_grad.hip), the timing flavours.  Only there are the old HIERTCN_* environment
+# switches of those alternatives looked up.  Loaded through HIERTCN_LIB / Engine(lib_variant="ablation") by the A/B tests and scripts/reproduce.sh;
+# the shipped libraries hold one kernel per job.
+LIB_ABLATION = os.path.join(HERE, "libhiertcn_gfx950_ablation.so")
+ABLATION_EXTRA_SOURCES = ["score_grad.hip"]
+
+
+def _mentions_ablation(src: str) -> bool:
+    with open(os.path.join(CSRC, src)) as f:
+        t = f.read()
+    return "HIERTCN_ABLATION" in t or "ABL_ENV" in t
+
+
+def build_ablation(force: bool = False) -> str:
+    build_lib(False)
+    hipcc = _hipcc()
+    obj_dir = os.path.join(HERE, "build", "ablation")
+    os.makedirs(obj_dir, exist_ok=True)
+    headers = _headers()
+    jobs, objs = [], []
+    for src in SOURCES + ABLATION_EXTRA_SOURCES:
+        if src in ABLATION_EXTRA_SOURCES or _mentions_ablation(src):
+            s, o = os.path.join(CSRC, src), os.path.join(obj_dir, src.replace(".hip", ".o"))
+            if force or _stale(o, [s] + headers):
+                jobs.append((s, o))
+            objs.append(o)
+        else:   # no ablation content: the shipped library's object
+            objs.append(os.path.join(HERE, "build", src.replace(".hip", ".o")))
+
+    def cc(job):
+        s, o = job
+        per_file = ["-fno-honor-nans"] if s.endswith(NO_NAN_SOURCES) else []
+        r = subprocess.run([hipcc, *FLAGS, *per_file, "-DHIERTCN_ABLATION=1", "-c", s, "-o", o], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed: %s\n%s" % (s, r.stderr))
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(6, len(jobs))) as ex:
+            list(ex.map(cc, jobs))
+    if force or jobs or _stale(LIB_ABLATION, objs):
+        r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_ABLATION, *objs], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("link failed: %s\n%s" % (r.stdout, r.stderr))
+    return LIB_ABLATION
+
+
+NO_NAN_SOURCES = ("score.hip", "score_x3.hip", "score_x3w.hip")
+
+
+def _headers():
+    return [os.path.join(CSRC, h) for h in ("common.h", "train.h", "exact.h", "gemm.h", "score_geom.h", "score_lists.h", "score_x3.h")] + [
+        os.path.join(HERE, "..", "include", "hiertcn.h")]
+
+
 LIB_PACKER = os.path.join(HERE, "libhiertcn_packer.so")   # host-side batch packer (csrc/packer.c: plain C, gcc)
 
 
@@ -53,6 +107,7 @@ def build_all(force: bool = False, verbose: bool = False):
     """Both storage variants: bfloat16 (default, training + inference) and IEEE half (-DHIERTCN_F16, inference)."""
     libs = build_lib(force, verbose), build_lib(force, verbose, f16=True)
     build_testhooks(force)
+    build_ablation(force)
     build_packer(force)
     return libs
 
@@ -65,7 +120,7 @@ def build_testhooks(force: bool = False) -> str:
     hipcc = _hipcc()
     obj_dir = os.path.join(HERE, "build", "testhooks")
     os.makedirs(obj_dir, exist_ok=True)
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
+    headers = _headers()
     objs = []
     rebuilt = False
     for src in SOURCES:
@@ -90,9 +145,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
     LIB = LIB_F16 if f16 else globals()["LIB"]  # noqa: N806
     if f16:
         extra_flags = tuple(extra_flags) + ("-DHIERTCN_F16=1",)
-    ablation = bool(os.environ.get("HIERTCN_ABLATION"))
-    if ablation:   # ablation / timing kernel flavours (scripts/pipe_ablate.sh); never in the shipped build
-        extra_flags = tuple(extra_flags) + ("-DHIERTCN_ABLATION=1",)
+    ablation = False   # (the ablation library is a target of its own: build_ablation)
     # objects live in a directory keyed on the flag set, and the library remembers which flag set it was linked from:
     # an ablation build can never leave objects (or a library) behind that a later plain build would ship as fresh
     import hashlib
@@ -108,7 +161,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
         relink = True
     os.makedirs(OBJ, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, "common.h"), os.path.join(CSRC, "train.h"), os.path.join(CSRC, "exact.h"), os.path.join(CSRC, "gemm.h"), os.path.join(CSRC, "score_geom.h"), os.path.join(CSRC, "score_lists.h"), os.path.join(CSRC, "score_x3.h"), os.path.join(HERE, "..", "include", "hiertcn.h")]
+    headers = _headers()
     jobs = []
     for src in SOURCES:
         s = os.path.join(CSRC, src)
@@ -120,7 +173,7 @@ def build_lib(force: bool = False, verbose: bool = False, extra_flags=(), f16: b
         s, o = job
         # score.hip: logits are finite or -inf by construction; without NaN-honouring fmaxf needs no
         # canonicalising v_max on MFMA results (cdna_hip_programming.md, attention 'Pitfalls')
-        per_file = ["-fno-honor-nans"] if s.endswith(("score.hip", "score_x3.hip", "score_x3w.hip")) else []
+        per_file = ["-fno-honor-nans"] if s.endswith(NO_NAN_SOURCES) else []
         cmd = [hipcc, *FLAGS, *per_file, *extra_flags, "-c", s, "-o", o]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:

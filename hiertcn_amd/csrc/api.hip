@@ -15,6 +15,30 @@
 
 static thread_local char g_err[512] = "";
 
+// ---- launch selection + thresholds (include/hiertcn.h: hiertcn_tuning_t).  The library reads no environment variable. -----------------------
+void tuning_defaults(hiertcn_tuning_t* t) {
+  memset(t, 0, sizeof(*t));
+  t->gru_scan_persistent = t->gru_scan_persistent_train = t->gru_bptt_persistent = t->gru_bptt_fused = -1;
+  t->lgru_persistent = t->lgru_pipe = t->lgru_tile = t->lgru_tile_bwd = t->lgru_wide = t->lgru_wide_bwd = -1;
+  t->lgru_fp32_cells = -1;
+  t->tcn_layered = 0;
+  t->gru_persist_max_lanes = 96;
+  t->gemm_split_max_tiles = 1024;
+  t->skinny_max_rows = 4096;
+  t->lgru_tile_max_sessions = 131072;
+  t->lgru_wide_max_launches = 3;
+  t->sgrad_dyn_max_blocks = 1024;
+  t->sgrad0_min_stages = 64;
+  t->tcn_gs2_max_sessions = 512;
+  t->lgru_defer_max_gib = 8;
+}
+static const hiertcn_tuning_t* default_tuning() {
+  static const hiertcn_tuning_t d = [] { hiertcn_tuning_t t; tuning_defaults(&t); return t; }();
+  return &d;
+}
+static thread_local const hiertcn_tuning_t* g_tune = nullptr;   // the handle whose API call this thread is in (ON_DEVICE)
+const hiertcn_tuning_t& tune_now() { return g_tune ? *g_tune : *default_tuning(); }
+
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
   va_start(ap, fmt);
@@ -71,6 +95,7 @@ struct DeviceGuard {
 };
 #define ON_DEVICE(h)                                                                       \
   DeviceGuard guard_((h)->device);                                                         \
+  g_tune = &(h)->m.tune;                                                                   \
   if (!guard_.ok) return fail(HIERTCN_ERR_HIP, "cannot switch to the handle's device %d", (h)->device)
 
 extern "C" {
@@ -134,6 +159,7 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
   }
   ModelDev& m = c->m;
   memset(&m, 0, sizeof(m));
+  tuning_defaults(&m.tune);
   m.N = cfg->item_num;
   m.NP = (cfg->item_num + 63) & ~63;
   m.E = E;
@@ -215,7 +241,7 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
     }
     m.gru_bar = bar;
   }
-  if (!getenv("HIERTCN_FIXED_WALK")) {   // the scoring kernel's per-XCD item-walk words live with the handle, i.e. on ITS device
+  if (!ABL_ENV("HIERTCN_FIXED_WALK")) {   // the scoring kernel's per-XCD item-walk words live with the handle, i.e. on ITS device
     ALLOC_OR_FAIL(m.walk_pos, (size_t)8 * 32);
     if (hipMemset(m.walk_pos, 0, 8 * 32 * sizeof(int)) != hipSuccess) {
       hiertcn_destroy(c);
@@ -364,6 +390,43 @@ int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision) {
   return HIERTCN_OK;
 }
 
+int hiertcn_get_tuning(hiertcn_handle_t h, hiertcn_tuning_t* out) {
+  if (!h || !out) return fail(HIERTCN_ERR_INVALID, "null argument");
+  *out = h->m.tune;
+  return HIERTCN_OK;
+}
+
+int hiertcn_set_tuning(hiertcn_handle_t h, const hiertcn_tuning_t* in) {
+  if (!h || !in) return fail(HIERTCN_ERR_INVALID, "null argument");
+  hiertcn_tuning_t t = *in, d;
+  tuning_defaults(&d);
+  int32_t* sel[] = {&t.gru_scan_persistent, &t.gru_scan_persistent_train, &t.gru_bptt_persistent, &t.gru_bptt_fused, &t.lgru_persistent, &t.lgru_pipe,
+                    &t.lgru_tile, &t.lgru_tile_bwd, &t.lgru_wide, &t.lgru_wide_bwd, &t.lgru_fp32_cells};
+  for (int32_t* s : sel)
+    if (*s < -1 || *s > 1) return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: a selection field is -1 (automatic), 0 (never) or 1 (wherever the shape allows), not %d", *s);
+  if (t.tcn_layered < 0 || t.tcn_layered > 1) return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: tcn_layered is 0 or 1");
+#define THRESH(f, lo, hi)                                                                                                  \
+  do {                                                                                                                     \
+    if (t.f == 0) t.f = d.f;                                                                                               \
+    if (t.f < (lo) || t.f > (hi)) return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: " #f " = %d outside [%d, %d]", t.f, (int)(lo), (int)(hi)); \
+  } while (0)
+  THRESH(gru_persist_max_lanes, 1, 96);            // (96: what the persistent launch's LDS image and its residency check are built for)
+  THRESH(gemm_split_max_tiles, 1, 1 << 24);
+  THRESH(skinny_max_rows, 1, 1 << 24);
+  THRESH(lgru_tile_max_sessions, 1, 1 << 30);
+  THRESH(lgru_wide_max_launches, 1, 64);
+  THRESH(sgrad_dyn_max_blocks, 1, 1 << 20);
+  THRESH(sgrad0_min_stages, 1, 1 << 20);
+  THRESH(lgru_defer_max_gib, 1, 256);
+#undef THRESH
+  if (t.tcn_gs2_max_sessions == 0) t.tcn_gs2_max_sessions = d.tcn_gs2_max_sessions;
+  if (t.tcn_gs2_max_sessions < -1) return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: tcn_gs2_max_sessions = %d: -1 (never), 0 (the default) or a session count", t.tcn_gs2_max_sessions);
+  for (int32_t r : t.reserved)
+    if (r != 0) return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: reserved fields must be zero");
+  h->m.tune = t;
+  return HIERTCN_OK;
+}
+
 int hiertcn_get_precision(hiertcn_handle_t h, int32_t* precision) {
   if (!h || !precision) return fail(HIERTCN_ERR_INVALID, "null argument");
   *precision = h->precision;
@@ -377,6 +440,7 @@ int hiertcn_struct_sizes(size_t out[HIERTCN_N_STRUCTS]) {
   out[2] = sizeof(hiertcn_score_out_t);
   out[3] = sizeof(hiertcn_gmm_config_t);
   out[4] = sizeof(hiertcn_gmm_weights_t);
+  out[5] = sizeof(hiertcn_tuning_t);
   return HIERTCN_OK;
 }
 
@@ -786,6 +850,14 @@ int hiertcn_persistent_health(hiertcn_handle_t h, int32_t* timed_out) {
     // counters and error word back to zero; the caller has been told that the launches since the last check produced wrong states.
     HIP_TRY(hipMemset(h->m.gru_bar, 0, 512 * sizeof(unsigned long long)));
   }
+  return HIERTCN_OK;
+}
+
+int hiertcn_persistent_health_async(hiertcn_handle_t h, uint64_t* host_word, void* stream) {
+  if (!h || !host_word) return fail(HIERTCN_ERR_INVALID, "null argument");
+  if (!h->m.gru_bar) return HIERTCN_OK;   // (no persistent launches on this handle: the word stays as the caller left it)
+  ON_DEVICE(h);
+  HIP_TRY(hipMemcpyAsync(host_word, h->m.gru_bar + 8 * 16, sizeof(uint64_t), hipMemcpyDeviceToHost, reinterpret_cast<hipStream_t>(stream)));
   return HIERTCN_OK;
 }
 

@@ -96,7 +96,18 @@ struct ModelDev {
   uint16_t* lgru_wgTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wgTF_lo[HIERTCN_MAX_LAYERS];
   uint16_t* lgru_wcTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wcTF_lo[HIERTCN_MAX_LAYERS];
   int* walk_pos;        // [8][32] ints, zeroed: per-XCD position words of the scoring kernel's item walk (null: every workgroup starts at stage 0)
+  hiertcn_tuning_t tune;   // launch selection + thresholds (include/hiertcn.h: hiertcn_set_tuning); the library reads no environment variable
 };
+// the tuning of the handle whose API call this thread is in (api.hip sets it on entry): for the few launch helpers that take no ModelDev
+const hiertcn_tuning_t& tune_now();
+void tuning_defaults(hiertcn_tuning_t* t);
+// A/B alternatives of superseded kernels exist in the ablation build only (hiertcn_amd/build.py, HIERTCN_ABLATION=1): there, and only there, the
+// old environment switches are looked up
+#if HIERTCN_ABLATION
+#define ABL_ENV(name) (getenv(name) != nullptr)
+#else
+#define ABL_ENV(name) false
+#endif
 
 // launchers implemented in the kernel files (all asynchronous on `st`)
 hipError_t launch_rows_to_bf16(const float* src, uint16_t* dst, int64_t rows, int cols, int zero_row0, hipStream_t st);

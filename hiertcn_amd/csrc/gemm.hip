@@ -367,11 +367,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, co
 // rows up to which the skinny kernel (32-row tiles, the reduction split over a workgroup's waves) takes an nn product instead of the tiled one, and the
 // scan's backward its fused three-launch cells (train.hip).  Round 4: 64 -> 4096 -- the tiled kernel's 33 us per [128 x 512] . [512 x 256] product was
 // 1.4 ms of a 3.6 ms training step at 128 lanes (2.5 ms now; 256 / 512 / 1024 / 2048 lanes: 5.3 -> 4.0, 8.5 -> 7.2, 13.6 -> 12.2, 23.8 -> 22.9 ms;
-// even at 4096, the tiled form ahead from 8192).  HIERTCN_SKINNY_MAX_ROWS overrides.
-int gemm32_skinny_max_rows() {
-  static const int v = [] { const char* e = getenv("HIERTCN_SKINNY_MAX_ROWS"); return e ? atoi(e) : 4096; }();
-  return v;
-}
+// even at 4096, the tiled form ahead from 8192).  tune.skinny_max_rows (hiertcn_set_tuning) overrides.
+int gemm32_skinny_max_rows() { return tune_now().skinny_max_rows; }
 
 hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st) {
   if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along k (A) and n (B)
@@ -408,7 +405,7 @@ hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, f
 // n <= 8 products C_i[N1_i][N2_i] (+)= A_i^T . B_i of the TN-with-slabs form in one launch (reductions of >= 512 rows: sliced over blockIdx.y like a single
 // product's, partial tiles in `scratch`, one grouped sum behind them); false where the batch form does not apply: the caller then issues them one by one
 bool gemm32_tn_slabs_batch_applies(const Gemm32TnDesc* d, int n) {
-  if (n < 2 || n > G32_GROUP_MAX || getenv("HIERTCN_GEMM_NO_BATCH")) return false;
+  if (n < 2 || n > G32_GROUP_MAX || ABL_ENV("HIERTCN_GEMM_NO_BATCH")) return false;
   for (int i = 0; i < n; i++) {
     if ((d[i].N1 & 3) || (d[i].N2 & 3) || (d[i].lda & 3) || (d[i].ldb & 3) || (d[i].a_ss & 3) || (d[i].b_ss & 3) || d[i].a_div < 0 || d[i].b_div < 0) return false;
     if (d[i].N1 <= 0 || d[i].N2 <= 0 || d[i].Mred != d[0].Mred) return false;   // (one slicing for the whole group)

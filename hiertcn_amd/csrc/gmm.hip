@@ -351,7 +351,7 @@ int hiertcn_gmm_create(hiertcn_gmm_handle_t* out, const hiertcn_gmm_config_t* cf
   }
   GA(c->pi_w, (size_t)c->M * cl);
   GA(c->pi_b, c->M);
-  c->gram = !c->learned && gmm_gram_applies(cl, c->D) && !getenv("HIERTCN_GMM_TABLE_PASS");
+  c->gram = !c->learned && gmm_gram_applies(cl, c->D) && !cfg->table_pass;
   c->gram64 = nullptr; c->G3 = nullptr; c->gx = c->g0 = nullptr;
   if (c->gram) {
     GA(c->gram64, gmm_gram_scratch_doubles(c->M, cl));
@@ -569,6 +569,7 @@ int hiertcn_gmm_forward_rows(hiertcn_gmm_handle_t g, const uint16_t* x_rows, int
 
 static void table_model(const hiertcn_gmm_ctx* g, int m, ModelDev* md) {
   memset(md, 0, sizeof(*md));
+  tuning_defaults(&md->tune);
   md->N = g->D; md->NP = g->DP; md->Clast = g->Clast;
   md->outT = g->muT + (size_t)m * g->DP * g->Clast;
   md->out_bias = g->mu_bias + (size_t)m * g->DP;
@@ -593,6 +594,7 @@ int hiertcn_gmm_loss(hiertcn_gmm_handle_t g, const uint16_t* hidden, const int32
     for (int m = 0; m < g->M; m++) {
       ModelDev md;
       memset(&md, 0, sizeof(md));
+      tuning_defaults(&md.tune);
       md.N = md.NP = g->NPs; md.Clast = g->Clast;
       md.outT = g->sgT + (size_t)m * g->NPs * g->Clast;
       md.out_bias = g->sg_bias + (size_t)m * g->NPs;

@@ -742,9 +742,7 @@ hipError_t launch_bptt_q(const GruBpttArgs& a, size_t lds_bytes, hipStream_t st)
 bool gru_persist_shape_ok(const ModelDev& m, int B, int S);
 // the scan's backward as one persistent launch: the forward's shapes (gru_persist_shape_ok) where its own LDS image fits
 bool gru_bptt_persist_applies(const ModelDev& m, int B, int S) {
-  if (getenv("HIERTCN_GRU_BPTT_CHAIN")) return false;   // A/B runs, tests: train.hip's launch chain
-  const char* off = getenv("HIERTCN_GRU_CHAIN");
-  if (off && off[0] == '1') return false;
+  if (m.tune.gru_bptt_persistent == 0 || m.tune.gru_scan_persistent == 0) return false;   // (hiertcn_set_tuning: train.hip's launch chain)
   return gru_persist_shape_ok(m, B, S) && bptt_lds_bytes(m.H, m.nl, B) <= 150 * 1024;
 }
 
@@ -775,11 +773,9 @@ bool gru_persist_shape_ok(const ModelDev& m, int B, int S) {
 
 // 0 = not applicable (the caller runs the GEMM chain), else the number of workgroups per lane group
 int gru_persist_groups(const ModelDev& m, int B, int S, bool saving) {
-  const char* off = getenv("HIERTCN_GRU_CHAIN");   // "1": always the GEMM chain (A/B runs, tests; read on every call)
-  if (off && off[0] == '1') return 0;
-  if ((saving && getenv("HIERTCN_GRU_TRAIN_CHAIN")) || !gru_persist_shape_ok(m, B, S)) return 0;   // (training: the launch also writes the BPTT's records)
-  const char* ml = getenv("HIERTCN_GRU_PERSIST_MAX_LANES");
-  if (ml && B > atoi(ml)) return 0;
+  if (m.tune.gru_scan_persistent == 0) return 0;   // always the GEMM chain (a shared GPU, A/B runs, tests)
+  if ((saving && m.tune.gru_scan_persistent_train == 0) || !gru_persist_shape_ok(m, B, S)) return 0;   // (training: the launch also writes the BPTT's records)
+  if (B > m.tune.gru_persist_max_lanes) return 0;
   return m.H / GP_U;
 }
 
@@ -811,13 +807,12 @@ hipError_t launch_gru_scan_persist(const ModelDev& m, const float* pooled, const
 // ---- HierGRU low level as one persistent launch (k_low_gru_persist) ------------------------------------------------------------------
 // applies to evaluation batches of up to 1024 sessions (beyond that the split-operand MFMA cells of gru_x3.hip win), E == H in {64, 128}; at
 // H = 256 two layers of weight rows leave LDS room for 8 staged sessions at a time and the launch is no faster than the chain it replaces
-// (1.53 vs 1.41 ms per 32-lane batch; H = 128: 0.81 vs 1.04, H = 64: 0.63 vs 0.91) -- HIERTCN_LGRU_CHAIN=0 forces it there too (A/B, tests)
+// (1.53 vs 1.41 ms per 32-lane batch; H = 128: 0.81 vs 1.04, H = 64: 0.63 vs 0.91) -- tune.lgru_persistent = 1 forces it there too (A/B, tests)
 bool low_gru_persist_applies(const ModelDev& m, int64_t n_sess) {
-  const char* off = getenv("HIERTCN_LGRU_CHAIN");   // "1": always the launch chain; "0": the persistent launch wherever it fits (read on every call)
-  if (off && off[0] == '1') return false;
+  if (m.tune.lgru_persistent == 0) return false;   // always the launch chain; 1: the persistent launch wherever it fits
   if (!m.low_gru || !m.gru_bar || m.n_cu <= 0 || n_sess <= 0 || n_sess > 1024) return false;
   if (m.E != m.H || (m.H != 64 && m.H != 128 && m.H != 256)) return false;
-  if (m.H == 256 && !(off && off[0] == '0')) return false;
+  if (m.H == 256 && m.tune.lgru_persistent != 1) return false;
   if (GP_GROUPS * (m.H / GP_U) > m.n_cu) return false;
   return low_persist_chunk(m.H, m.nl, n_sess) >= GP_LB;
 }

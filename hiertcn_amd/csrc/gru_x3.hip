@@ -276,7 +276,7 @@ hipError_t launch_split_f32(const float* v, int64_t n, uint16_t* hi, uint16_t* l
 }
 
 bool gru_x3_applies(const ModelDev& m) {
-  if (!m.low_gru || !m.lgru_split || getenv("HIERTCN_LGRU_FP32")) return false;
+  if (!m.low_gru || !m.lgru_split || m.tune.lgru_fp32_cells == 1) return false;
   return (m.E % XK_MIN) == 0 && (m.H % XK_MIN) == 0;
 }
 
@@ -324,7 +324,7 @@ hipError_t refresh_lgru_split(const ModelDev& m, hipStream_t st) {
   if (!m.low_gru || !m.lgru_split) return hipSuccess;
   hipError_t e;
   {
-    bool all = !getenv("HIERTCN_LGRU_REFRESH_UNFUSED");
+    bool all = !ABL_ENV("HIERTCN_LGRU_REFRESH_UNFUSED");
     LgruRefreshGroup grp;
     memset(&grp, 0, sizeof(grp));
     int64_t most = 0;

@@ -394,14 +394,12 @@ static size_t lp_lds_bytes(const ModelDev& m) {
 }
 
 bool lgru_pipe_applies(const ModelDev& m, int64_t n_sess) {
-  const char* sw = getenv("HIERTCN_LGRU_PIPE");   // "0": never (A/B runs, tests; read on every call)
-  if (sw && sw[0] == '0') return false;
-  const char* chain = getenv("HIERTCN_LGRU_CHAIN");   // "1": set by the shared-GPU guard (distributed.py): no launch that waits on other workgroups
-  if (chain && chain[0] == '1') return false;
+  if (m.tune.lgru_pipe == 0) return false;         // never (A/B runs, tests)
+  if (m.tune.lgru_persistent == 0) return false;   // set by the shared-GPU guard (distributed.py): no launch that waits on other workgroups
   if (!lgru_tile_applies(m, n_sess)) return false;
   if (!(m.H == 64 || m.H == 128) || m.gru_bar == nullptr) return false;
   const int64_t tiles = (n_sess + 31) / 32;
-  return tiles * m.nl <= 256;   // every workgroup resident at once: a consumer waits for its producer inside the launch
+  return tiles * m.nl <= (m.n_cu > 0 ? m.n_cu : 256);   // every workgroup resident at once (one per CU): a consumer waits for its producer inside the launch
 }
 
 // bytes of the exchange slots + flags (0: no pipelined launch for this model; sizes past its range count as the largest one in it)

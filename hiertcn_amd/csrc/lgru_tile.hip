@@ -276,18 +276,16 @@ static size_t lt_lds_bytes(const ModelDev& m) {
   return 2 * 32 * pitch + 2 * (size_t)m.nl * 32 * pitch + 2 * 32 * pitch;   // rows of step t (x 2) | states hi, lo | r*h hi, lo
 }
 
-static int64_t lt_max_sessions() {
-  const char* e = getenv("HIERTCN_LGRU_TILE_MAX");   // sessions up to which the session-tile kernels run (A/B runs)
+static int64_t lt_max_sessions(const ModelDev& m) {   // sessions up to which the session-tile kernels run (tune.lgru_tile_max_sessions; default 131072)
   // (measured up to 20,480 sessions of 30 steps: 77.6 vs 80.0 ms per 1024-user evaluation step at d = 256 against the launch chain, 51.9 vs 53.7 at d = 128;
   //  round 4, 40,960 sessions of <= 20 steps, N = 20,778: evaluation 10.3 vs 14.4 ms at d = 256, 4.6 vs 7.2 at d = 128; training step 68 vs 82 and 33 vs 39 ms)
-  return e ? atoll(e) : 131072;
+  return m.tune.lgru_tile_max_sessions;
 }
 
 bool lgru_tile_applies(const ModelDev& m, int64_t n_sess) {
-  const char* sw = getenv("HIERTCN_LGRU_TILE");   // "0": never (A/B runs, tests; read on every call)
-  if (sw && sw[0] == '0') return false;
-  if (!m.low_gru || !m.lgru_split || !m.lgru_wgF_hi[0] || n_sess <= 0 || n_sess > lt_max_sessions()) return false;
-  if (getenv("HIERTCN_LGRU_FP32")) return false;   // (the fp32 cells were asked for)
+  if (m.tune.lgru_tile == 0) return false;   // never (A/B runs, tests)
+  if (!m.low_gru || !m.lgru_split || !m.lgru_wgF_hi[0] || n_sess <= 0 || n_sess > lt_max_sessions(m)) return false;
+  if (m.tune.lgru_fp32_cells == 1) return false;   // (the fp32 cells were asked for)
   return m.E == m.H && (m.H == 64 || m.H == 128 || m.H == 256) && m.nl <= 2 && lt_lds_bytes(m) <= 160 * 1024;
 }
 

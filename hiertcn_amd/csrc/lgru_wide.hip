@@ -25,10 +25,7 @@
 // to itself) -- at H = 256 up to three (measured, training step of 32 x 20 x 30 / 64 / 128 / 200 lanes x 10 x 20: 4.0 / 2.6 / 5.4 / 7.5 ms against
 // 5.7 / 3.8 / 6.1 / 7.5 ms with the session-tile kernels of lgru_tile.hip, which keep every CU busy with a tile of its own); at H = 128 one (two
 // launches of the backward cells at 1,280 sessions: 3.0 against 2.9 ms).
-static int lw_max_launches(int parts) {
-  static const int v = getenv("HIERTCN_LGRU_WIDE_MAX_LAUNCHES") ? atoi(getenv("HIERTCN_LGRU_WIDE_MAX_LAUNCHES")) : 3;
-  return parts == 8 ? v : 1;
-}
+static int lw_max_launches(const ModelDev& m, int parts) { return parts == 8 ? m.tune.lgru_wide_max_launches : 1; }
 static int64_t lw_tiles_per_launch(const ModelDev& m, int parts) {
   const int64_t cus = m.n_cu > 0 ? m.n_cu : 256;
   return cus / ((int64_t)m.nl * parts);
@@ -290,19 +287,17 @@ __global__ __launch_bounds__(LW_THREADS, 1) void k_lgru_wide(const LgruWideArgs 
 static size_t lw_lds_bytes() { return 6 * 32 * (2 * 256 + 16) + 2 * 4 * 16 * 64 * sizeof(float); }
 
 bool lgru_wide_applies(const ModelDev& m, int64_t n_sess) {
-  const char* sw = getenv("HIERTCN_LGRU_WIDE");   // "0": never (A/B runs, tests; read on every call)
-  if (sw && sw[0] == '0') return false;
-  const char* chain = getenv("HIERTCN_LGRU_CHAIN");   // "1": set by the shared-GPU guard (distributed.py): no launch that waits on other workgroups
-  if (chain && chain[0] == '1') return false;
+  if (m.tune.lgru_wide == 0) return false;         // never (A/B runs, tests)
+  if (m.tune.lgru_persistent == 0) return false;   // set by the shared-GPU guard (distributed.py): no launch that waits on other workgroups
   if (!lgru_tile_applies(m, n_sess) || m.H != 256 || m.gru_bar == nullptr) return false;
   const int64_t tiles = (n_sess + 31) / 32, per = lw_tiles_per_launch(m, LW_PARTS);   // every workgroup of a launch resident at once
-  return per >= 1 && tiles <= lw_max_launches(LW_PARTS) * per;
+  return per >= 1 && tiles <= lw_max_launches(m, LW_PARTS) * per;
 }
 
 // bytes of the exchange slots + counters (0: no such launch for this model; sizes past the launch's range count as the largest one in it)
 size_t lgru_wide_bytes(const ModelDev& m, int64_t n_sess, int L) {
   if (n_sess <= 0 || m.H != 256 || m.E != m.H || m.nl > 2) return 0;
-  const int64_t cap = 32 * lw_max_launches(LW_PARTS) * lw_tiles_per_launch(m, LW_PARTS);   // a workspace sized for a larger batch still serves the smaller ones
+  const int64_t cap = 32 * lw_max_launches(m, LW_PARTS) * lw_tiles_per_launch(m, LW_PARTS);   // a workspace sized for a larger batch still serves the smaller ones
   if (n_sess > cap) n_sess = cap;
   const size_t tiles = (size_t)(n_sess + 31) / 32;
   const size_t x = (size_t)m.nl * L * 2 * (size_t)n_sess * m.H * 2;
@@ -636,19 +631,16 @@ template <int HB>
 static size_t lwb_lds_bytes() { return 2 * 32 * (2 * 32 * HB + 16) + 2 * 32 * (4 * 32 * HB + 16) + 2 * 4 * 16 * 64 * sizeof(float); }
 
 bool lgru_wide_bwd_applies(const ModelDev& m, int64_t n_sess) {
-  const char* sw = getenv("HIERTCN_LGRU_WIDE_BWD");   // "0": never (A/B runs, tests; read on every call)
-  if (sw && sw[0] == '0') return false;
-  const char* chain = getenv("HIERTCN_LGRU_CHAIN");
-  if (chain && chain[0] == '1') return false;
+  if (m.tune.lgru_wide_bwd == 0 || m.tune.lgru_persistent == 0) return false;
   if (!lgru_tile_applies(m, n_sess) || !(m.H == 128 || m.H == 256) || m.gru_bar == nullptr || !m.lgru_wgTF_hi[0]) return false;
   const int64_t tiles = (n_sess + 31) / 32, per = lw_tiles_per_launch(m, m.H / 32);
-  return per >= 1 && tiles <= lw_max_launches(m.H / 32) * per;
+  return per >= 1 && tiles <= lw_max_launches(m, m.H / 32) * per;
 }
 
 // bytes of the d x slots + counters + flags (0: no such launch for this model; sizes past its range count as the largest one in it)
 size_t lgru_wide_bwd_bytes(const ModelDev& m, int64_t n_sess, int L) {
   if (n_sess <= 0 || !(m.H == 128 || m.H == 256) || m.E != m.H || m.nl > 2) return 0;
-  const int64_t cap = 32 * lw_max_launches(m.H / 32) * lw_tiles_per_launch(m, m.H / 32);
+  const int64_t cap = 32 * lw_max_launches(m, m.H / 32) * lw_tiles_per_launch(m, m.H / 32);
   if (n_sess > cap) n_sess = cap;
   const size_t tiles = (size_t)(n_sess + 31) / 32;
   const size_t x = (size_t)m.nl * L * (size_t)n_sess * m.H * 4;

@@ -59,6 +59,10 @@ static void heap_down(packer_t* p, int i) {
   }
 }
 
+/* version of this file's interface: hiertcn_amd/data_loader.py refuses a library that reports another one (a stale build after a change here) */
+#define PK_ABI_VERSION 2
+int pk_abi_version(void) { return PK_ABI_VERSION; }
+
 void* pk_create(int B, int S, const int64_t* s_begin, const int64_t* s_len, const double* s_mask, const int64_t* ids, const int64_t* u_first,
                 const int64_t* u_nsess) {
   packer_t* p = (packer_t*)calloc(1, sizeof(packer_t));
@@ -69,7 +73,11 @@ void* pk_create(int B, int S, const int64_t* s_begin, const int64_t* s_len, cons
   p->heap_lane = (int32_t*)calloc((size_t)B, sizeof(int32_t));
   p->heap_pos = (int32_t*)calloc((size_t)B, sizeof(int32_t));
   p->qlen = (int64_t*)calloc((size_t)B, sizeof(int64_t));
-  if (!p->lanes || !p->heap_len || !p->heap_lane || !p->heap_pos || !p->qlen) return NULL;
+  if (!p->lanes || !p->heap_len || !p->heap_lane || !p->heap_pos || !p->qlen) {   /* (free(NULL) is a no-op) */
+    free(p->lanes); free(p->heap_len); free(p->heap_lane); free(p->heap_pos); free(p->qlen);
+    free(p);
+    return NULL;
+  }
   for (int b = 0; b < B; b++) { p->heap_lane[b] = b; p->heap_pos[b] = b; }   /* all lengths 0: lane order = heap order */
   p->s_begin = s_begin; p->s_len = s_len; p->s_mask = s_mask; p->ids = ids; p->u_first = u_first; p->u_nsess = u_nsess;
   return p;

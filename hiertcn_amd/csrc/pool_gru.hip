@@ -122,7 +122,7 @@ hipError_t launch_session_pool(const ModelDev& m, const int32_t* y, int64_t n_se
 }
 
 // the same launch + the row compaction of launch_compact_rows (map, n_valid, zero-filled z0 / z1 / z2) as one extra workgroup; R <= 8192 rows
-bool session_pool_compact_applies(int64_t R) { return R > 0 && R <= 8192 && !getenv("HIERTCN_POOL_COMPACT_OFF"); }
+bool session_pool_compact_applies(int64_t R) { return R > 0 && R <= 8192 && !ABL_ENV("HIERTCN_POOL_COMPACT_OFF"); }
 hipError_t launch_session_pool_compact(const ModelDev& m, const int32_t* y, int64_t n_sessions, int L, float* pooled, int32_t* map, int32_t* n_valid,
                                        int32_t* z0, float* z1, float* z2, hipStream_t st) {
   if (n_sessions <= 0) return hipSuccess;
@@ -329,8 +329,7 @@ static hipError_t launch_gemm(const GemmArgs* g, int n, hipStream_t st) {
   gp.g[0] = g[0];
   gp.g[1] = g[n > 1 ? 1 : 0];
   const int tiles = ((g[0].M + 31) / 32) * (g[0].N / 32);
-  static const int split_max = [] { const char* e = getenv("HIERTCN_GEMM_SPLIT_MAX_TILES"); return e ? atoi(e) : 1024; }();
-  if (tiles * n <= split_max)
+  if (tiles * n <= tune_now().gemm_split_max_tiles)
     hipLaunchKernelGGL((k_gemm_f32<EPI, 4>), dim3(tiles, n), dim3(256), 0, st, gp);
   else
     hipLaunchKernelGGL((k_gemm_f32<EPI, 0>), dim3((tiles + 3) / 4, n), dim3(256), 0, st, gp);

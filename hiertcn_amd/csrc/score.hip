@@ -33,7 +33,7 @@ int score_split_parts(int64_t R, int NP, int rows_per_wg) {
   // Mid-size batches: a few rounds of 256 workgroups, the last one partly empty (600 row tiles = 2.34 rounds: the chip idles for
   // 22 % of the launch).  Splitting the catalogue in p parts makes p x more, p x shorter workgroups: take the smallest p <= 4 whose
   // last round is at least 93 % full, else the best one.
-  if (tiles >= 2048 || getenv("HIERTCN_NO_MIDSPLIT")) return 1;
+  if (tiles >= 2048 || ABL_ENV("HIERTCN_NO_MIDSPLIT")) return 1;
   int best = 1;
   double best_eff = 0.0;
   for (int p = 1; p <= 4 && p <= by_len; p++) {
@@ -57,7 +57,7 @@ int score_split_scratch_parts(int64_t R, int NP, int rows_per_wg) {
 // count (ragged sessions: about half of it) is only known on the device, which is why a static split there misjudges the grid (512 lanes x 10 x 20:
 // 200 padded tiles, 105 live ones, one part = 105 workgroups of the whole catalogue on 256 CUs: 0.73 ms of a 1.46 ms batch).
 static bool score_dyn_applies(int64_t R, int NP, int rows_per_wg) {
-  static const bool off = getenv("HIERTCN_SCORE_DYN_OFF") != nullptr;
+  static const bool off = ABL_ENV("HIERTCN_SCORE_DYN_OFF");
   return !off && (R + rows_per_wg - 1) / rows_per_wg < 128 && score_split_parts(R, NP, rows_per_wg) > 1;
 }
 
@@ -1378,8 +1378,11 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
   using G = ScGeom<C>;
   if constexpr (C >= 64 && C <= 256) {
     // the seamless one-step-block kernel (three LDS stages, four-deep fragment ring) + the fix-up launch for a softmax sum past fp32;
-    // HIERTCN_TOPK_V2=1: the two-stage flavour it replaces, HIERTCN_TOPK_V1=1: the un-pipelined kernel -- both for A/B runs
-    if (!getenv("HIERTCN_TOPK_V1") && !getenv("HIERTCN_TOPK_V2")) {
+    // (ablation build only -- HIERTCN_TOPK_V2=1: the two-stage flavour it replaces, HIERTCN_TOPK_V1=1: the un-pipelined kernel)
+#if HIERTCN_ABLATION
+    if (!getenv("HIERTCN_TOPK_V1") && !getenv("HIERTCN_TOPK_V2"))
+#endif
+    {
       constexpr bool PADI = C >= 256;
       const size_t pitch = PADI ? 1024 + (C == 256 ? 32 : 16) : 1024;
       size_t lds = 3 * (G::STAGE_BYTES / 1024) * pitch + 3 * SC_STAGE * sizeof(float);
@@ -1396,8 +1399,11 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
   }
   if constexpr (C == 512) {
     // the two-stage seamless kernel of the loss + rank flavour (k_score_pipe<512, 15, 1, 2, pad>) with the list test in its gaps + the fix-up launch;
-    // HIERTCN_TOPK512_V1=1: the un-pipelined kernel it replaces (launch_score_512: 175 ms per 307,200 x 300,000 launch against 72 for loss + rank)
-    if (!getenv("HIERTCN_TOPK512_V1")) {
+    // (ablation build only -- HIERTCN_TOPK512_V1=1: the un-pipelined kernel it replaces, launch_score_512: 175 ms per 307,200 x 300,000 launch against 72)
+#if HIERTCN_ABLATION
+    if (!getenv("HIERTCN_TOPK512_V1"))
+#endif
+    {
       const size_t pitch = 1024 + 16;
       size_t lds = 2 * (G::STAGE_BYTES / 1024) * pitch + 2 * SC_STAGE * sizeof(float);
       const size_t merge = (size_t)SC_THREADS * KT * 8;
@@ -1410,8 +1416,13 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
       if ((e = hipGetLastError()) != hipSuccess) return e;
       return out->ce ? launch_score_fixup<512, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, (int*)nullptr) : hipSuccess;
     }
+#if HIERTCN_ABLATION
     return hipErrorNotSupported;   // (the caller falls back to launch_score_512)
+#endif
   } else {
+#if !HIERTCN_ABLATION
+  return hipErrorInvalidValue;   // (not reached: every width returned above)
+#else
   if (!getenv("HIERTCN_TOPK_V1")) {   // the pipelined skeleton (epilogue in the MFMA gaps, one step block per wave, two LDS stages); V1: A/B
     constexpr bool PADI = C >= 256;
     const size_t pitch = PADI ? 1024 + (C == 256 ? 32 : 16) : 1024;
@@ -1436,6 +1447,7 @@ static hipError_t launch_score_topk(const ModelDev& m, const uint16_t* hidden, c
                      out->target, (float*)nullptr, 0, (unsigned long long*)nullptr, out->topk_idx, out->topk_val, (int)out->topk,
                      (const float*)nullptr, (const float*)nullptr, 0, -1, row_map, n_rows_dev);
   return hipGetLastError();
+#endif
   }
 }
 
@@ -1517,18 +1529,16 @@ static hipError_t launch_score_c(const ModelDev& m, const uint16_t* hidden, cons
   }
 #endif
   // production
-  if (getenv("HIERTCN_PIPE_VARIANT") && getenv("HIERTCN_PIPE_VARIANT")[0] == '5')   // the two-tile kernel (also the FIXUP flavour), kept for A/B runs
-    return launch_score_pipe<C, 5>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   if constexpr (C == 256) {  // four accumulator tiles, padded LDS image, overflow handled by the fix-up launch
     // small batches: ONE step block per wave (256-row tiles, the list flavour's skeleton without lists): twice the row tiles for the device-side
     // split to deal out, half the MFMA chain per stage (a 32-lane XING batch: ~14 live tiles x 18 parts on 252 CUs instead of ~7 x 19 on 133)
-    static const bool nb1 = getenv("HIERTCN_SCORE_SMALL_NB2") == nullptr;
+    static const bool nb1 = !ABL_ENV("HIERTCN_SCORE_SMALL_NB2");
     if (nb1 && split_scratch && out->rank && out->ce && out->target && score_dyn_applies(R, m.NP, 512))
       return launch_score_pipe<256, 15, 1, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     return launch_score_pipe<256, 14, 2, 3, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
   }
   else {  // C = 64 / 128: the same four-tile seamless shape on the XOR-swizzled image (registers are not the problem here)
-    static const bool nb1 = getenv("HIERTCN_SCORE_SMALL_NB2") == nullptr;
+    static const bool nb1 = !ABL_ENV("HIERTCN_SCORE_SMALL_NB2");
     if (nb1 && split_scratch && out->rank && out->ce && out->target && score_dyn_applies(R, m.NP, 512))
       return launch_score_pipe<C, 15, 1, 3>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     return launch_score_pipe<C, 14>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
@@ -1540,6 +1550,7 @@ static hipError_t launch_score_512(const ModelDev& m, const uint16_t* hidden, co
                                    float* logits, const float* lse, const float* w, int stg_begin, int stg_end, hipStream_t st,
                                    const int32_t* row_map = nullptr, const int32_t* n_rows_dev = nullptr);
 
+#if HIERTCN_ABLATION   // the legacy training backward's d-logits chunks (train.hip, HIERTCN_TRAIN_LEGACY=1)
 template <int C>
 static hipError_t launch_score_grad_c(const ModelDev& m, const uint16_t* hidden, const int32_t* y, int64_t R, const float* lse,
                                       const float* w, int stg_begin, int stg_end, uint16_t* gout, hipStream_t st) {
@@ -1568,6 +1579,8 @@ hipError_t launch_score_grad_chunk(const ModelDev& m, const uint16_t* hidden, co
     default: return hipErrorInvalidValue;
   }
 }
+
+#endif
 
 // d = 512 (BASELINE.json configs[3]: the scoring-GEMM stress shape): 64 rows x 512 channels of resident B operand
 // would take 256 VGPRs, so every flavour (fused, top-k, logits, gradient chunk) runs the two-stage kernel with ONE
@@ -1607,7 +1620,7 @@ hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const i
   if (R <= 0) return hipSuccess;
   hiertcn_score_out_t out;
   out.rank = nullptr; out.ce = o_sq; out.target = o_tgt; out.topk_idx = nullptr; out.topk_val = nullptr; out.topk = 0;
-  if (!getenv("HIERTCN_SUMSQ_V1")) {   // the four-tile seamless skeleton with the one-fma epilogue (V1: the un-pipelined kernel, A/B)
+  if (!ABL_ENV("HIERTCN_SUMSQ_V1")) {   // the four-tile seamless skeleton with the one-fma epilogue (ablation build, HIERTCN_SUMSQ_V1: the un-pipelined kernel)
     switch (m.Clast) {
       case 64: return launch_score_pipe<64, 21>(m, hidden, y, R, &out, st);
       case 128: return launch_score_pipe<128, 21>(m, hidden, y, R, &out, st);
@@ -1616,9 +1629,11 @@ hipError_t launch_score_sumsq(const ModelDev& m, const uint16_t* hidden, const i
     }
   }
   switch (m.Clast) {
+#if HIERTCN_ABLATION
     case 64: return launch_score_v<64, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
     case 128: return launch_score_v<128, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
     case 256: return launch_score_v<256, false, 3>(m, hidden, y, R, &out, nullptr, 0, st);
+#endif
     case 512: return launch_score_512<false, 3, 0>(m, hidden, y, R, &out, nullptr, nullptr, nullptr, 0, -1, st);
     default: return hipErrorInvalidValue;
   }
@@ -1648,15 +1663,17 @@ hipError_t launch_score(const ModelDev& m, const uint16_t* hidden, const int32_t
     case 256: return launch_score_c<256>(m, hidden, y, R, out, logits, st, row_map, n_rows_dev, split_scratch);
     case 512:   // (dense rows: callers zero-fill nothing here, the kernel writes rank 0 / ce 0 on masked rows itself)
       if (logits) return launch_score_512<true, 0, 0>(m, hidden, y, R, nullptr, logits, nullptr, nullptr, 0, -1, st);
-      if (out && out->topk > 0 && !getenv("HIERTCN_TOPK512_V1"))   // lists in the gaps of the seamless two-stage kernel (round 3)
+      if (out && out->topk > 0 && !ABL_ENV("HIERTCN_TOPK512_V1"))   // lists in the gaps of the seamless two-stage kernel (round 3)
         return out->topk <= 8    ? launch_score_topk<512, 8>(m, hidden, y, R, out, st, row_map, n_rows_dev)
                : out->topk <= 10 ? launch_score_topk<512, 10>(m, hidden, y, R, out, st, row_map, n_rows_dev)
                                  : launch_score_topk<512, 16>(m, hidden, y, R, out, st, row_map, n_rows_dev);
+#if HIERTCN_ABLATION   // the kernels the production forms replaced, for A/B runs on one box
       if (out && out->topk > 8) return launch_score_512<false, 0, 16>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st, row_map, n_rows_dev);
       if (out && out->topk > 0) return launch_score_512<false, 0, 8>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st, row_map, n_rows_dev);
-      if (getenv("HIERTCN_SCORE512_V1")) return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);   // A/B
-      if (getenv("HIERTCN_SCORE512_XOR")) return launch_score_pipe<512, 5, 1, 2>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // A/B
-      if (getenv("HIERTCN_SCORE512_V2")) return launch_score_pipe<512, 5, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // A/B: per-tile redo, bubble at every tile start
+      if (getenv("HIERTCN_SCORE512_V1")) return launch_score_512<false, 0, 0>(m, hidden, y, R, out, nullptr, nullptr, nullptr, 0, -1, st);
+      if (getenv("HIERTCN_SCORE512_XOR")) return launch_score_pipe<512, 5, 1, 2>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
+      if (getenv("HIERTCN_SCORE512_V2")) return launch_score_pipe<512, 5, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);   // per-tile redo, bubble at every tile start
+#endif
       return launch_score_pipe<512, 15, 1, 2, true>(m, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
     default: return hipErrorInvalidValue;
   }

@@ -643,7 +643,7 @@ __global__ void k_add_slabs(float* __restrict__ out, const float* __restrict__ s
 }
 // small catalogues (fewer than 128 item blocks: the chip is not filled by the item dimension): row parts of mode 0 through slabs
 static int sgrad_dwo_slab_parts(const ModelDev& m, int64_t R) {
-  static const bool off = getenv("HIERTCN_SGRAD0_SLABS_OFF") != nullptr;
+  static const bool off = ABL_ENV("HIERTCN_SGRAD0_SLABS_OFF");
   const int stat = sg_stat(m.Clast, sg_one(m.Clast, 0));
   const int blocks = (m.NP + stat - 1) / stat;
   if (off || blocks >= 128) return 1;
@@ -670,7 +670,7 @@ static int sg_dyn_max_parts(const ModelDev& m, int64_t R) {
 // rest exit at once.  Without the split a batch of 138 live blocks is 138 workgroups walking the whole table on 256 CUs, and one of 273 two rounds of which
 // the second holds 17 workgroups.
 static int sg_dyn_grid(const ModelDev& m, int64_t R) {
-  static const int max_blocks = getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS") ? atoi(getenv("HIERTCN_SGRAD_DYN_MAX_BLOCKS")) : 1024;
+  const int max_blocks = m.tune.sgrad_dyn_max_blocks;   // (default 1024)
   const int stat2 = sg_stat(m.Clast, sg_one(m.Clast, 2));
   const int64_t blocks = (R + stat2 - 1) / stat2;
   if (blocks < 128) return SC_DYN_GRID;
@@ -678,14 +678,14 @@ static int sg_dyn_grid(const ModelDev& m, int64_t R) {
 }
 // floats of the `part` scratch of launch_sgrad_forward (0: no device-side split at this size)
 size_t sgrad_forward_part_floats(const ModelDev& m, int64_t R) {
-  static const bool off = getenv("HIERTCN_SGRAD_DYN_OFF") != nullptr;
+  static const bool off = ABL_ENV("HIERTCN_SGRAD_DYN_OFF");
   if (off || sg_dyn_grid(m, R) == 0 || m.NP / sg_si(m.Clast, sg_one(m.Clast, 2)) < 32) return 0;
   const size_t mp = (size_t)sg_dyn_max_parts(m, R);
   return (2 * mp + 1) * (size_t)(R + 64) + mp * (size_t)(R + 64) * (size_t)m.Clast;
 }
 
 bool sgrad_supported(const ModelDev& m) {
-  return (m.Clast == 64 && !getenv("HIERTCN_SGRAD64_OFF")) || m.Clast == 128 || m.Clast == 256 || (m.Clast == 512 && !getenv("HIERTCN_SGRAD512_OFF"));
+  return (m.Clast == 64 && !ABL_ENV("HIERTCN_SGRAD64_OFF")) || m.Clast == 128 || m.Clast == 256 || (m.Clast == 512 && !ABL_ENV("HIERTCN_SGRAD512_OFF"));
 }
 
 template <int C, int MODE, bool ONE>
@@ -768,7 +768,7 @@ hipError_t launch_sgrad_dwo(const ModelDev& m, const uint16_t* hc, const float* 
   const unsigned blocks = (unsigned)((m.NP + stat - 1) / stat);
   unsigned parts = 1;
   double best = 0.0;
-  static const int min_st = getenv("HIERTCN_SGRAD0_MIN_STAGES") ? atoi(getenv("HIERTCN_SGRAD0_MIN_STAGES")) : 64;
+  const int min_st = m.tune.sgrad0_min_stages;   // (default 64)
   for (unsigned p = 1; p <= 8 && (p == 1 || a.n_stages_max / (int)p >= min_st); p++) {
     const double eff = ((double)blocks * p / 256.0) / (double)((blocks * p + 255) / 256);
     if (eff > best + 1e-9) { best = eff; parts = p; }

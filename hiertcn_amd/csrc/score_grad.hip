@@ -258,7 +258,7 @@ static hipError_t launch_dlogits_c(const ModelDev& m, const uint16_t* hrows, con
   const unsigned blocks = (unsigned)((m.NP + 511) / 512);
   // row parts: the smallest p <= 8 (each part at least 32 stages) that fills the last round of 256 workgroups to >= 93 %
   unsigned parts = 1;
-  if (!getenv("HIERTCN_DLOGITS_NOSPLIT")) {
+  if (!ABL_ENV("HIERTCN_DLOGITS_NOSPLIT")) {
     double best = 0.0;
     for (unsigned p = 1; p <= 8 && (p == 1 || n_stages / (int)p >= 32); p++) {
       const double eff = ((double)blocks * p / 256.0) / (double)((blocks * p + 255) / 256);

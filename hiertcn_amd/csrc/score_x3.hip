@@ -536,7 +536,7 @@ static hipError_t launch_x3_c(const ModelDev& m, const ExactDev& x, const float*
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(fix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X::LDS_BYTES)) != hipSuccess) return e;
   int* walk = KT > 0 ? nullptr : m.walk_pos;   // lists: equal values must arrive in index order (tf.nn.top_k), so the walk starts at item 0
   const int parts = score_split_parts(R, m.NP, 256);
-  static const bool dyn_off = getenv("HIERTCN_SCORE_DYN_OFF") != nullptr;
+  static const bool dyn_off = ABL_ENV("HIERTCN_SCORE_DYN_OFF");
   if (KT == 0 && split_scratch && parts > 1 && (R + 255) / 256 < 128 && !dyn_off && out->rank && out->ce && out->target) {
     // small batches: SC_DYN_GRID workgroups dealt as (row tile, catalogue part) on the device from the live row count (score_geom.h)
     const int n_all = m.NP / SC_STAGE;

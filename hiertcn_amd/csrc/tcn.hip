@@ -282,17 +282,17 @@ __global__ __launch_bounds__(TCN_THREADS) void k_tcn_fused(TcnParams p, const in
 
 template <int C>
 static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float* sproj, int64_t n_sessions, int L,
-                               uint16_t* hidden, hipStream_t st) {
+                               uint16_t* hidden, hipStream_t st, int64_t gs2_max) {
   constexpr int GS = TcnGeom<C>::GS;
   size_t lds = (size_t)GS * (p.pad + 32) * 2 * C;
   unsigned blocks = (unsigned)((n_sessions + GS - 1) / GS);
-  const bool frag_ok = C <= 256 && p.convF[0] && (!p.projT || p.projF) && !getenv("HIERTCN_TCN_FUSED_V1");
+  const bool frag_ok = C <= 256 && p.convF[0] && (!p.projT || p.projF) && !ABL_ENV("HIERTCN_TCN_FUSED_V1");
   if constexpr (C == 128 || C == 256) {
     // Small grids (round 4; the reference's 32-lane batch = 320 sessions = 80 workgroups of four): every workgroup streams ALL the weights
     // (1.4 MB at C = 256) through its CU whatever it computes, so two sessions per workgroup put twice the CUs on the same stream:
     // 56 -> 44 us with the fragment-major stream instead of DEEP's row reads, -> 27 us with two sessions per workgroup (one: 37 us, 320
     // workgroups are a round and a quarter).  Same accumulation order per output: bitwise identical to the other instances.
-    static const int64_t gs2_max = getenv("HIERTCN_TCN_GS2_MAX") ? atoll(getenv("HIERTCN_TCN_GS2_MAX")) : 512;
+    // (gs2_max: tune.tcn_gs2_max_sessions, default 512)
     if (frag_ok && n_sessions <= gs2_max) {
       const size_t l2 = (size_t)2 * (p.pad + 32) * 2 * C;
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(k_tcn_fused<C, false, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)l2);
@@ -325,8 +325,7 @@ static hipError_t launch_tcn_c(const TcnParams& p, const int32_t* x, const float
 #include <stdlib.h>
 #include <string.h>
 static bool use_fused(const ModelDev& m, int L) {
-  static const bool force_layers = getenv("HIERTCN_FORCE_LAYERED") != nullptr;  // tests: both paths must agree bitwise
-  if (force_layers) return false;
+  if (m.tune.tcn_layered == 1) return false;   // (tests: both paths must agree bitwise)
   const int halo = (m.K - 1) * (1 << (m.n_blocks - 1));
   const size_t lds = (size_t)(m.E == 512 ? 2 : TCN_G) * (((halo + 7) & ~7) + 32) * 2 * m.E;   // TcnGeom<C>::GS sessions per workgroup
   return m.fused_tcn && L <= 32 && lds <= 160 * 1024;
@@ -359,10 +358,10 @@ hipError_t launch_tcn_forward(const ModelDev& m, const int32_t* x, const float* 
   int halo = (m.K - 1) * (1 << (m.n_blocks - 1));
   p.pad = (halo + 7) & ~7;
   switch (m.E) {
-    case 64: return launch_tcn_c<64>(p, x, sproj, n_sessions, L, hidden, st);
-    case 128: return launch_tcn_c<128>(p, x, sproj, n_sessions, L, hidden, st);
-    case 256: return launch_tcn_c<256>(p, x, sproj, n_sessions, L, hidden, st);
-    case 512: return launch_tcn_c<512>(p, x, sproj, n_sessions, L, hidden, st);
+    case 64: return launch_tcn_c<64>(p, x, sproj, n_sessions, L, hidden, st, m.tune.tcn_gs2_max_sessions);
+    case 128: return launch_tcn_c<128>(p, x, sproj, n_sessions, L, hidden, st, m.tune.tcn_gs2_max_sessions);
+    case 256: return launch_tcn_c<256>(p, x, sproj, n_sessions, L, hidden, st, m.tune.tcn_gs2_max_sessions);
+    case 512: return launch_tcn_c<512>(p, x, sproj, n_sessions, L, hidden, st, m.tune.tcn_gs2_max_sessions);
     default: return hipErrorInvalidValue;
   }
 }

@@ -334,7 +334,7 @@ hipError_t refresh_frag_major(const ModelDev& m, hipStream_t st) {
 // geometry of the LDS-tiled kernel for this layer, or cbw = 0 when it does not apply (then the un-staged kernel runs)
 static LdsGeom lds_geom(const LayerArgs& a) {
   LdsGeom g = {0, 0, 0, 0, 0};
-  if (!a.Wf || (a.Wres && !a.Wresf) || getenv("HIERTCN_TCN_LAYER_V1")) return g;
+  if (!a.Wf || (a.Wres && !a.Wresf) || ABL_ENV("HIERTCN_TCN_LAYER_V1")) return g;   // (ablation build: the un-staged kernel everywhere)
   const int ncb = a.Cout >> 5;
   if (ncb & (ncb - 1)) return g;
   if (a.L < 96 && !(a.taps == 1 && a.n_seq * (int64_t)a.L >= 4096 && a.n_seq * (int64_t)a.L < ((int64_t)1 << 31)))
@@ -433,7 +433,7 @@ static hipError_t launch_tcn_layer_lds(const LayerArgs& a, const LdsGeom& g, hip
 
 hipError_t launch_tcn_layer(const LayerArgs& a, hipStream_t st) {
   const LdsGeom g = lds_geom(a);
-  if (getenv("HIERTCN_DEBUG_LAYER"))
+  if (ABL_ENV("HIERTCN_DEBUG_LAYER"))
     fprintf(stderr, "launch_tcn_layer: L %d n_seq %lld Cin %d Cout %d taps %d Wf %p Wres %p Wresf %p -> cbw %d tgw %d seq_L %d\n", a.L, (long long)a.n_seq, a.Cin,
             a.Cout, a.taps, (const void*)a.Wf, (const void*)a.Wres, (const void*)a.Wresf, g.cbw, g.tgw, g.seq_L);
   if (g.cbw > 0 && g.seq_L > 0) {   // flat rows: one "sequence" of n_seq * L rows
@@ -448,7 +448,7 @@ hipError_t launch_tcn_layer(const LayerArgs& a, hipStream_t st) {
   const int64_t tiles1 = a.n_seq * ntt * (a.Cout / 32);
   int rb = ntt >= 4 ? 4 : (ntt >= 2 ? 2 : 1);
   while (rb > 1 && tiles1 / rb < 4 * 1024) rb >>= 1;
-  if (getenv("HIERTCN_TCN_LAYER_RB1")) rb = 1;   // A/B
+  if (ABL_ENV("HIERTCN_TCN_LAYER_RB1")) rb = 1;   // A/B (ablation build)
   const int64_t tiles = a.n_seq * ((ntt + rb - 1) / rb) * (a.Cout / 32);
   const dim3 grid((unsigned)((tiles + 3) / 4));
   switch (rb) {

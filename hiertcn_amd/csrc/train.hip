@@ -669,13 +669,15 @@ struct TrainWs {
 // across-session scan always does) while that costs at most 8 GiB (the reference's 32 lanes = 640 sessions: 118 MB).  That is also what lets the
 // session-tile backward run (lgru_tile.hip / lgru_wide.hip keep every cell's pre-activation gradients).  Round 4: 1 -> 8 GiB -- at 1 GiB batches past
 // ~870 lanes x 10 slots x 20 steps (d = 256) fell back to the per-cell launch chain: 27.1 ms per training step at 1024 lanes against 20.0 (2048: 44.2 -> 36.3;
-// d = 128, 2048: 26.9 -> 17.0).  HIERTCN_LGRU_DEFER_MAX_GIB overrides.
+// d = 128, 2048: 26.9 -> 17.0).  tune.lgru_defer_max_gib overrides.
 static bool lgru_deferred_wgrad(const ModelDev& m, size_t M, int L) {
-  static const size_t gib = getenv("HIERTCN_LGRU_DEFER_MAX_GIB") ? (size_t)atoi(getenv("HIERTCN_LGRU_DEFER_MAX_GIB")) : 8;
-  return (size_t)m.nl * L * M * 3 * m.H * 4 <= (gib << 30) && !getenv("HIERTCN_LGRU_WGRAD_PER_CELL");
+  const size_t gib = (size_t)m.tune.lgru_defer_max_gib;
+  return (size_t)m.nl * L * M * 3 * m.H * 4 <= (gib << 30) && !ABL_ENV("HIERTCN_LGRU_WGRAD_PER_CELL");
 }
 
-static bool fused_scoring_backward(const ModelDev& m) { return sgrad_supported(m) && !getenv("HIERTCN_TRAIN_LEGACY"); }
+// score_bwd.hip's fused scoring backward covers every last width hiertcn_create takes.  The implementation it replaced (bf16 d-logits chunks from
+// score_grad.hip / k_score + two 16-bit GEMMs per chunk) exists in the ablation build only, behind HIERTCN_TRAIN_LEGACY=1, for A/B runs.
+static bool fused_scoring_backward(const ModelDev& m) { return sgrad_supported(m) && !ABL_ENV("HIERTCN_TRAIN_LEGACY"); }
 
 static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   TrainWs w;
@@ -697,6 +699,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   w.users = take(256);
   w.dA = take(R * C * 4); w.dB = take(R * C * 4); w.dsf = take((R + 64) * C * 4);
   w.dcb = take(R * C * 2); w.dub = take(R * C * 2);
+#if HIERTCN_ABLATION   // the legacy scoring backward's d-logits chunk (HIERTCN_TRAIN_LEGACY=1)
   // G chunk: at most 16 GiB of bf16 (the two products per chunk run 12 % faster than with 4 GiB chunks: fewer, larger
   // GEMMs -- profiles/r1_train_notes.md), at least one 64-item stage
   size_t budget = (size_t)16 << 30;
@@ -731,6 +734,9 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     gbytes = rs * 64 * ldg * 2;
   }
   w.gchunk = take(w.fused ? 256 : gbytes);
+#else
+  w.gchunk = take(256);
+#endif
   w.map = take(R * 4); w.nvalid = take(256); w.cscratch = take((R / 1024 + 2) * 4);
   w.hc = take((R + 64) * C * 2); w.yc = take(R * 4); w.wc = take(R * 4); w.lc = take(R * 4);
   w.rb = take((R + 64) * 4);
@@ -878,8 +884,13 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
                                 w.sgpart_on ? F32(w.sgpart) : nullptr));
     T_HIP(launch_score_fixup_only(m, hidden, y, R, &so, st, rmap, nvalid_d));   // rank / ce of row tiles whose sum overflowed (pathological inputs)
   } else
+#if HIERTCN_ABLATION
   T_HIP(launch_score(m, hidden, y, R, &so, nullptr, st, rmap, nvalid_d));
+#else
+  return tfail("train step: no scoring backward for a last width of %d", CL);   // (not reached: hiertcn_create takes the widths score_bwd.hip covers)
+#endif
   if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
+#if HIERTCN_ABLATION
   int64_t Rv = 0;
   if (!w.fused) {   // legacy path only: the row count sizes the chunk products below
     int32_t nvalid_h = 0;
@@ -887,8 +898,10 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(hipStreamSynchronize(st));
     Rv = nvalid_h;
   }
+#endif
 
   // ================= d loss / d logits, scoring layer =====================================================
+#if HIERTCN_ABLATION
   if (!w.fused) {   // (the fused path took the row weights before its forward pass and reads ce + target, the log-sum-exp, where it needs it)
     T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
     hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
@@ -897,6 +910,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(hipGetLastError());
     T_HIP(hipMemsetAsync(dH, 0, (size_t)R * CL * 4, st));
   }
+#endif
   if (w.fused) {
     // score_bwd.hip: everything is sized by R on the host and by the device-side row count inside the kernels.  d hidden came out of
     // the forward pass; what is left is d Wo / d bo from the saved log-sum-exp (and d hidden again for row blocks that overflowed).
@@ -906,8 +920,9 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(launch_sgrad_dh(m, hc, F32(w.rb2), yc, F32(w.wc), rmap, nvalid_d, R, dH, reinterpret_cast<int32_t*>(ws + w.ovf), 1, st));
     T_HIP(launch_sgrad_dwo(m, hc, F32(w.rb), yc, F32(w.wc), nvalid_d, R, F32(w.bl2), G + t.outT.off, G + t.out_bias.off, st,
                             w.sgslab_on ? F32(w.sgslab) : nullptr));
-  } else
-  if (Rv > 0) {
+  }
+#if HIERTCN_ABLATION
+  else if (Rv > 0) {
     uint16_t* hc = BF(w.hc);
     int32_t* yc = reinterpret_cast<int32_t*>(ws + w.yc);
     float* dHc = F32(w.dsf);   // [Rv][C_last] fp32 (the block loop's scratch, free until then)
@@ -951,6 +966,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     hipLaunchKernelGGL(k_scatter_rows_f32, dim3((unsigned)((Rv * (CL / 4) + 255) / 256)), dim3(256), 0, st, dHc, rmap, Rv, CL, dH);
     T_HIP(hipGetLastError());
   }
+#endif
 
   }   // do_begin
   if (!do_finish) return 0;
@@ -981,7 +997,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     const unsigned gMH = (unsigned)(((int64_t)M * H + 255) / 256);
     // small batches: the whole BPTT as one launch, a workgroup per 32 sessions (lgru_tile.hip); it keeps the cells' pre-activation gradients, the
     // weight gradients follow below as always in this regime
-    const bool tile_bwd = deferred && lgru_tile_applies(m, (int64_t)M) && !getenv("HIERTCN_LGRU_TILE_BWD_OFF");
+    const bool tile_bwd = deferred && lgru_tile_applies(m, (int64_t)M) && m.tune.lgru_tile_bwd != 0;
     if (!tile_bwd) T_HIP(hipMemsetAsync(lcar, 0, (size_t)M * HT * 4, st));   // the low level's final state is dropped (model_gru.py:47)
     if (tile_bwd && lgru_wide_bwd_applies(m, (int64_t)M) && lgru_wide_bwd_bytes(m, (int64_t)M, L) > 0)   // H = 128 / 256: HB workgroups per (tile, layer), weights in registers, layers pipelined
       T_HIP(launch_lgru_wide_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, ws + w.lg_bwd, st));
@@ -1144,8 +1160,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   const int64_t hs = (int64_t)(S + 1) * HT;
   const size_t cell = (size_t)B * 5 * H;
   const unsigned gBH = (unsigned)(((int64_t)B * H + 255) / 256);
-  static const bool bptt_unfused = getenv("HIERTCN_GRU_BPTT_UNFUSED") != nullptr;
-  const bool bptt_fused = B <= gemm32_skinny_max_rows() && !bptt_unfused;
+  const bool bptt_fused = B <= m.tune.skinny_max_rows && m.tune.gru_bptt_fused != 0;
   const bool bptt_persist = gru_bptt_persist_applies(m, B, S);
   if (bptt_persist)   // small batches: the whole backward scan as ONE persistent launch (gru_persist.hip, k_gru_bptt_persist)
     T_HIP(launch_gru_bptt_persist(m, gsave, hist, mask, dsb, B, S, dac_all, dag_all, dpooled, st));

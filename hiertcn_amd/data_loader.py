@@ -26,6 +26,12 @@ from .data_prepare import load_xing
 DATA_PATH = "dataset/interactions.csv"  # data_loader.py:54,140 (relative to the working directory)
 
 _PACKER = None
+PK_ABI_VERSION = 2      # csrc/packer.c's PK_ABI_VERSION
+
+
+def active_packer() -> str:
+    """'c' or 'python': which batch packer get_packed_batch runs on (reported by bench.py's run_loop leg: the C one is ~10 x faster at 32 lanes)."""
+    return "c" if _packer_lib() is not None else "python"
 
 
 def _packer_lib():
@@ -35,11 +41,25 @@ def _packer_lib():
     if os.environ.get("HIERTCN_PY_PACKER"):
         return None
     if _PACKER is None:
-        path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "libhiertcn_packer.so")
+        here = os.path.dirname(os.path.abspath(__file__))
+        path, src = os.path.join(here, "libhiertcn_packer.so"), os.path.join(here, "csrc", "packer.c")
+        if os.path.exists(src) and (not os.path.exists(path) or os.path.getmtime(src) > os.path.getmtime(path)):
+            try:   # absent, or older than its source: (re)build it (one gcc call); a box without gcc keeps the NumPy packer
+                from .build import build_packer
+                build_packer()
+            except Exception:  # noqa: BLE001
+                pass
         if not os.path.exists(path):
             _PACKER = False
         else:
             lib = C.CDLL(path)
+            try:
+                lib.pk_abi_version.restype = C.c_int
+                ver = lib.pk_abi_version()
+            except AttributeError:
+                ver = 1
+            if ver != PK_ABI_VERSION:
+                raise RuntimeError(f"{path}: packer interface {ver}, this binding expects {PK_ABI_VERSION}: rebuild it (python -m hiertcn_amd.build)")
             p64, pd, pi32, pf = C.POINTER(C.c_int64), C.POINTER(C.c_double), C.POINTER(C.c_int32), C.POINTER(C.c_float)
             lib.pk_create.restype = C.c_void_p
             lib.pk_create.argtypes = [C.c_int, C.c_int, p64, p64, pd, p64, p64, p64]
@@ -190,6 +210,8 @@ class Dataloader_hier_model_xing:
             self._walk_c = None
 
     def __del__(self):  # pragma: no cover
+        for pre in getattr(self, "_prefetchers", []):   # no background thread inside pk_pop when the queues are freed
+            pre.close()
         if getattr(self, "_pk", None) is not None and self._pk.value:
             self._pk_lib.pk_destroy(self._pk)
             self._pk = None
@@ -354,6 +376,15 @@ class Prefetcher:
         self._source, self._owner = source, owner
         self.done = False
         self._t = threading.Thread(target=self._run, daemon=True)
+        # the thread calls into the owner's C packer: it is stopped and joined before that packer is destroyed (owner.__del__) and before the
+        # interpreter tears down (a daemon thread inside pk_pop while pk_destroy frees the queues would read freed memory)
+        if owner is not None:
+            try:
+                owner.__dict__.setdefault("_prefetchers", []).append(self)
+            except AttributeError:
+                pass
+        import atexit
+        atexit.register(self.close)
         self._t.start()
 
     def _run(self):
@@ -380,4 +411,5 @@ class Prefetcher:
 
     def close(self):
         self._stop.set()
-        self._t.join(timeout=2.0)
+        if self._t.is_alive():
+            self._t.join(timeout=5.0)

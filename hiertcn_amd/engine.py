@@ -83,13 +83,16 @@ class Engine:
     """One handle on the current CUDA(HIP) device."""
 
     def __init__(self, args, hier: bool = True, device: Optional[torch.device] = None, train: bool = False,
-                 dtype: Optional[str] = None):
+                 dtype: Optional[str] = None, tuning: Optional[dict] = None, lib_variant: Optional[str] = None):
         """dtype: storage type of the 16-bit tensors: 'bf16' (default; args.storage_dtype overrides) or 'fp16' (the
         libhiertcn_gfx950_f16.so build: BASELINE.json configs[3], inference only); 'fp32' = the exact numerics mode
         (hiertcn_set_precision: everything fp32 as the reference computes it, model_tcn.py:35-41; evaluation only, for
         parity runs on trained checkpoints -- the mode that meets "fp32 logits within 1e-3" at any logit scale);
         'split16' = the FAST parity-grade mode (HIERTCN_PRECISION_SPLIT16: fp32 low level, fused scoring on hi + lo IEEE-half
-        operands, three MFMAs per product, csrc/score_x3.hip): the same tolerance at a third of the bf16 rate; evaluation only."""
+        operands, three MFMAs per product, csrc/score_x3.hip): the same tolerance at a third of the bf16 rate; evaluation only.
+        tuning: hiertcn_tuning_t fields (include/hiertcn.h) to set on the handle, on top of what the environment asks for -- the library itself
+        reads no environment variable: _lib.tuning_from_env() maps the HIERTCN_* switches of earlier rounds onto the fields ONCE, here.
+        lib_variant: 'ablation' / 'testhooks' = another build of the bfloat16 library (_lib.LIB_VARIANTS; A/B runs and tests)."""
         dtype = dtype or getattr(args, "storage_dtype", "bf16")
         if dtype not in ("bf16", "fp16", "fp32", "split16"):
             raise HierTCNError(f"storage dtype {dtype!r}: 'bf16', 'fp16', 'fp32' (exact mode) or 'split16' (fast parity-grade mode)")
@@ -99,7 +102,7 @@ class Engine:
         self.mode = dtype if dtype in ("fp32", "split16") else "storage16"
         self.exact = self.mode != "storage16"       # fp32 hidden rows / fp32 low level (the FP32 and the SPLIT16 mode)
         self.act_dtype = torch.float32 if self.exact else (torch.float16 if self.f16 else torch.bfloat16)
-        self.lib = _lib.load(f16=self.f16)
+        self.lib = _lib.load(f16=self.f16, variant=lib_variant)
         if not torch.cuda.is_available():
             raise HierTCNError("no GPU visible: the HierTCN compute path is HIP-only (no CPU fallback)")
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
@@ -127,6 +130,29 @@ class Engine:
         self._gru_ws: Optional[torch.Tensor] = None
         self._tcn_ws: Optional[torch.Tensor] = None
         self._weights_set = False
+        t = _lib.tuning_from_env()
+        t.update(tuning or {})
+        if t:
+            self.set_tuning(**t)
+
+    # ---------------------------------------------------------------------------------------
+    def get_tuning(self) -> dict:
+        """The handle's hiertcn_tuning_t as {field: value} (thresholds: the values in force)."""
+        t = _lib.Tuning()
+        self._ck(self.lib.hiertcn_get_tuning(self._h, C.byref(t)))
+        return {f: int(getattr(t, f)) for f in _lib.TUNING_FIELDS}
+
+    def set_tuning(self, **fields):
+        """Change fields of the handle's hiertcn_tuning_t (launch selection: -1 automatic, 0 never, 1 wherever the shape allows; thresholds:
+        0 = the default).  Cached workspaces are dropped: their sizes are functions of the tuning."""
+        t = _lib.Tuning()
+        self._ck(self.lib.hiertcn_get_tuning(self._h, C.byref(t)))
+        for k, v in fields.items():
+            if k not in _lib.TUNING_FIELDS:
+                raise HierTCNError(f"hiertcn_tuning_t has no field {k!r}: {', '.join(_lib.TUNING_FIELDS)}")
+            setattr(t, k, int(v))
+        self._ck(self.lib.hiertcn_set_tuning(self._h, C.byref(t)))
+        self._train_ws = self._ws = self._gru_ws = self._tcn_ws = None
 
     def _ck(self, rc: int):
         check(rc, self.lib)
@@ -530,6 +556,13 @@ class Engine:
     def timing_enable(self, on: bool = True):
         self._ck(self.lib.hiertcn_timing_enable(self._h, 1 if on else 0))
 
+    def health_probe(self):
+        """Asynchronous read of the persistent launches' health word (hiertcn_persistent_health_async): enqueues an 8-byte device-to-host copy
+        into pinned memory on the current stream and returns a probe; probe.done() says whether it has landed (no wait), probe.timed_out()
+        waits for it and says whether a bounded wait ran out in a launch enqueued before the probe.  The run loops take one where the
+        reference writes results.txt, every 20 batches (run_hier_xing.py)."""
+        return HealthProbe(self)
+
     def persistent_timed_out(self) -> bool:
         """True if a bounded wait inside a persistent launch of this handle ever ran out (include/hiertcn.h); synchronises."""
         f = C.c_int32(0)
@@ -541,6 +574,22 @@ class Engine:
         n = C.c_int64(0)
         self._ck(self.lib.hiertcn_timing_read(self._h, C.byref(ms), C.byref(n), 1 if reset else 0))
         return ms.value, n.value
+
+
+class HealthProbe:
+    def __init__(self, eng: "Engine"):
+        self.word = torch.zeros(1, dtype=torch.int64).pin_memory()
+        self.event = torch.cuda.Event()
+        with torch.cuda.device(eng.device):
+            eng._ck(eng.lib.hiertcn_persistent_health_async(eng._h, self.word.data_ptr(), eng._stream()))
+            self.event.record()
+
+    def done(self) -> bool:
+        return self.event.query()
+
+    def timed_out(self) -> bool:
+        self.event.synchronize()
+        return bool(int(self.word[0]) != 0)
 
 
 class EvalGraph:

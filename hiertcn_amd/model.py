@@ -213,6 +213,7 @@ class HierTCNModel:
         pool = self._pipe_pool.setdefault(key, dict(i=0, bufs=[]))
         if len(pool["bufs"]) < 3:   # (at most two batches are in flight: three sets so that one is always free)
             pool["bufs"].append((torch.empty((B, W), dtype=torch.int32).pin_memory(), torch.empty(8, dtype=torch.float64).pin_memory(), torch.cuda.Event()))
+            pool["i"] = len(pool["bufs"]) - 1   # (so that the rotation continues behind the set just handed out: 0, 1, 2, 0, 1, 2, ...)
             return pool["bufs"][-1]
         pool["i"] = (pool["i"] + 1) % 3
         return pool["bufs"][pool["i"]]
@@ -229,6 +230,7 @@ class HierTCNModel:
         if len(pool["bufs"]) < 3:
             pool["bufs"].append((torch.empty(2 * n, dtype=torch.int32).pin_memory(), torch.empty(nm, dtype=torch.float32).pin_memory(),
                                  torch.empty(2 * n, dtype=torch.int32, device=dev), torch.empty(nm, dtype=torch.float32, device=dev)))
+            pool["i"] = len(pool["bufs"]) - 1
             ih, mh, idv, mdv = pool["bufs"][-1]
         else:
             pool["i"] = (pool["i"] + 1) % 3

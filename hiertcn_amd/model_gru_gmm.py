@@ -14,6 +14,7 @@ inputs are refused (off by default and never fed on XING).  Decode of the head: 
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -66,6 +67,7 @@ class GruGmmModel(TcnGmmModel):
         cfg = _lib.GmmConfig(item_num=self.N, output_dim=self.D, num_mixture=self.M, kernel_size=0, n_blocks=0,
                              sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0,   # 0: learned scale (args.sigma None)
                              trunk=1, hidden_dim=self.C, num_layer=self.nl)
+        cfg.table_pass = 1 if os.environ.get("HIERTCN_GMM_TABLE_PASS") else 0   # A/B runs, tests: never the Gram form (read here, once; the library reads no environment)
         self._h = C.c_void_p()
         _ck(self.lib.hiertcn_gmm_create(C.byref(self._h), C.byref(cfg)), self.lib)
         self.params = params if params is not None else init_params(args, seed, name)

@@ -20,6 +20,7 @@ from __future__ import annotations
 
 import copy
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -117,6 +118,7 @@ class HierGmmModel(TcnGmmModel):
                                  sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=2, input_dim=self.E + self.HT)
             for i, c in enumerate(ch):
                 cfg.channels[i] = c
+        cfg.table_pass = 1 if os.environ.get("HIERTCN_GMM_TABLE_PASS") else 0   # A/B runs, tests: never the Gram form (read here, once; the library reads no environment)
         self._h = C.c_void_p()
         _ck(self.lib.hiertcn_gmm_create(C.byref(self._h), C.byref(cfg)), self.lib)
         self._upload(self.params)

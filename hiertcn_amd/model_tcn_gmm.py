@@ -13,6 +13,7 @@ head: hiertcn_amd/model_gru_gmm.py.
 from __future__ import annotations
 
 import ctypes as C
+import os
 from typing import Dict, Optional
 
 import numpy as np
@@ -72,6 +73,7 @@ class TcnGmmModel:
                              sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0)   # 0: learned scale (args.sigma None)
         for i, c in enumerate(ch):
             cfg.channels[i] = c
+        cfg.table_pass = 1 if os.environ.get("HIERTCN_GMM_TABLE_PASS") else 0   # A/B runs, tests: never the Gram form (read here, once; the library reads no environment)
         self._h = C.c_void_p()
         _ck(self.lib.hiertcn_gmm_create(C.byref(self._h), C.byref(cfg)), self.lib)
         self.params = params if params is not None else init_params(args, seed, name)

@@ -57,6 +57,7 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
     # the device is left running (model.py, PendingEval): batch i is enqueued -- carried state device to device -- before the host turns to
     # batch i - 1's ranks and metrics.  HIERTCN_EVAL_SERIAL=1: one blocking sess.run-shaped call per batch, as before round 4.
     pipelined = packed and hasattr(model, "eval_step_packed_async") and not os.environ.get("HIERTCN_EVAL_SERIAL")
+    health = _HealthWatch(model, "evaluation epoch '%s'" % prefix)
     if pipelined:
         model.eval_begin(state_np)
         pending = None
@@ -72,6 +73,7 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
             done = pre.done if pre is not None else loader.done
             t2 = time.time()
             nxt = (model.eval_step_packed_async(x, y, mask, widths), widths)
+            health.after_batch()
             if pending is not None:
                 step, (ranks_temp, ranks_temp_count) = take(pending)
             pending = nxt
@@ -97,6 +99,7 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
             step = model.eval_step(batch_x_list, batch_y_list, batch_mask_list, state_np)
             slot_shapes = batch_x_list
         state_np = step["state"]  # :147 -- carried into the next batch
+        health.after_batch()
         meter.add(step)
         ranks_temp, ranks_temp_count = ranks_analysis(step["ranks_float"], slot_shapes, step["mask_y"], ranks_temp, ranks_temp_count)
         t3 = time.time()
@@ -111,6 +114,36 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
     return summary, summary_val, time_load, time_run, state_np
 
 
+class _HealthWatch:
+    """The persistent launches' health word, read where the reference writes results.txt (run_hier_xing.py:170-176: every 20 batches) WITHOUT
+    stalling the pipelined loop: every 20th batch an 8-byte copy of the word into pinned memory is enqueued behind the batch's launches
+    (Engine.health_probe -> hiertcn_persistent_health_async); every later batch asks, without waiting, whether it has landed, and a non-zero
+    word raises there -- a time-out (another process on the GPU, a CU mask) costs at most ~20 batches of metrics instead of the epoch."""
+    EVERY = 20
+
+    def __init__(self, model, what: str):
+        self.eng = getattr(model, "engine", None)
+        self.what, self.n, self.probe = what, 0, None
+
+    def after_batch(self):
+        if self.eng is None or not hasattr(self.eng, "health_probe"):
+            return
+        self.n += 1
+        if self.probe is not None and self.probe.done():
+            bad, self.probe = self.probe.timed_out(), None
+            if bad:
+                _check_persistent_health_raise(self.eng, "%s, by batch %d" % (self.what, self.n))
+        if self.n % self.EVERY == 0 and self.probe is None:
+            self.probe = self.eng.health_probe()
+
+
+def _check_persistent_health_raise(eng, what: str):
+    eng.persistent_timed_out()     # (synchronises; resets the handle's barrier counters so that it is usable again)
+    raise RuntimeError(f"{what}: a persistent GRU-scan launch timed out (its workgroups were not co-resident); the states and metrics since the "
+                       "last check are invalid.  On a GPU shared with another process run the scan as a chain of GEMM launches: "
+                       "HIERTCN_GRU_CHAIN=1 (before the model is created) or Engine.set_tuning(gru_scan_persistent=0, lgru_persistent=0).")
+
+
 def _check_persistent_health(model, what: str):
     """One read of hiertcn_persistent_health per epoch (it synchronises the device): a bounded wait inside the persistent GRU scan that ran
     out -- workgroups not co-resident because another process, rank or CU mask holds the CUs -- finishes its launch with WRONG carried
@@ -118,7 +151,8 @@ def _check_persistent_health(model, what: str):
     eng = getattr(model, "engine", None)
     if eng is not None and eng.persistent_timed_out():
         raise RuntimeError(f"{what}: a persistent GRU-scan launch timed out (its workgroups were not co-resident); the states and metrics of "
-                           "this epoch are invalid.  Set HIERTCN_GRU_CHAIN=1 to run the scan as a chain of GEMM launches on a shared GPU.")
+                           "this epoch are invalid.  On a shared GPU: HIERTCN_GRU_CHAIN=1 before the model is created, or "
+                           "Engine.set_tuning(gru_scan_persistent=0, lgru_persistent=0).")
 
 
 def _rank() -> int:

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 9
+#define HIERTCN_ABI_VERSION 10
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -147,7 +147,8 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
  *                                          build): h.w ~= h_hi w_hi + h_lo w_hi + h_hi w_lo in one fp32 accumulator (csrc/score_x3.hip).  Logit
  *                                          error of fp32 order (~1e-6 of the logit scale): inside the north star's "fp32 logits within 1e-3" at
  *                                          the scale of a trained model (|z| ~ 10-30), ranks and ranked top-k equal to the fp32 reference's
- *                                          wherever its own gaps exceed that error.  A third of STORAGE16's rate.  Last width 64, 128 or 256.
+ *                                          wherever its own gaps exceed that error.  A third of STORAGE16's rate.  Every last width (64, 128, 256;
+ *                                          512 since ABI 10: csrc/score_x3w.hip).
  *                                          (The table and every hidden row are scaled by powers of two before the split: no range limit
  *                                          short of fp32's own.)
  * In FP32 and SPLIT16 every `hidden` argument is float [R][C_last].  Evaluation only: the training entry points return HIERTCN_ERR_STATE.
@@ -160,10 +161,48 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
 int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision);
 int hiertcn_get_precision(hiertcn_handle_t h, int32_t* precision);
 
-/* sizeof() of the five structs of this header as the LIBRARY was compiled, in declaration order: hiertcn_config_t, hiertcn_weights_t,
- * hiertcn_score_out_t, hiertcn_gmm_config_t, hiertcn_gmm_weights_t -- lets a binding written in another language verify its own
- * struct definitions at load time (tests/test_cabi_load.py does, for hiertcn_amd/_lib.py and for the stub in INTEGRATION.md). */
-#define HIERTCN_N_STRUCTS 5
+/* Launch selection and thresholds of a handle (ABI 10).  The library reads NO environment variable: what used to be ambient process state
+ * (HIERTCN_GRU_CHAIN, HIERTCN_LGRU_PIPE, ..., looked up inside the launch path) is a field of this struct, defaulted by hiertcn_create, read
+ * from the handle by every launch, changed only through hiertcn_set_tuning.  hiertcn_amd/_lib.py maps the old variable names onto the fields
+ * ONCE, when an Engine is created (tuning_from_env), so scripts that export them keep working.  The A/B alternatives of superseded kernels
+ * are not here: they exist only in the ablation build (hiertcn_amd/build.py, HIERTCN_ABLATION=1).
+ * Selection fields: -1 automatic (the library decides from the shape: the default), 0 never, 1 wherever the shape allows.
+ * Thresholds: hiertcn_get_tuning reports the value in force; 0 in hiertcn_set_tuning = "the default".
+ * Changing a field changes which kernels run and the scratch some of them need: set the tuning BEFORE sizing workspaces
+ * (hiertcn_workspace_bytes / hiertcn_train_workspace_bytes are functions of it). */
+typedef struct {
+  int32_t gru_scan_persistent;        /* the across-session GRU scan as ONE persistent launch (csrc/gru_persist.hip) instead of 2 (S + 1) GEMM
+                                       * launches; 0 on a GPU shared with another process / rank (its workgroups must be co-resident)      */
+  int32_t gru_scan_persistent_train;  /* ... in the training forward, which also writes the backward's records                              */
+  int32_t gru_bptt_persistent;        /* the scan's backward through time as one persistent launch                                          */
+  int32_t gru_bptt_fused;             /* fused epilogues of the chained BPTT GEMMs (0: separate element-wise launches)                      */
+  int32_t lgru_persistent;            /* HierGRU low level: the launches that wait on other workgroups (persistent / layer-pipelined / wide);
+                                       * 0 on a shared GPU; 1 also takes the persistent launch at H = 256, where the chain is as fast       */
+  int32_t lgru_pipe;                  /* csrc/lgru_pipe.hip (H <= 128: one workgroup per (32-session tile, layer))                          */
+  int32_t lgru_tile;                  /* csrc/lgru_tile.hip (one workgroup per 32 sessions through all steps and layers)                    */
+  int32_t lgru_tile_bwd;              /* ... its backward                                                                                   */
+  int32_t lgru_wide;                  /* csrc/lgru_wide.hip (H = 256: eight workgroups per (tile, layer))                                   */
+  int32_t lgru_wide_bwd;              /* ... its backward                                                                                   */
+  int32_t lgru_fp32_cells;            /* 1: the fp32 GRU cells instead of the split-operand ones (default -1 = 0)                           */
+  int32_t tcn_layered;                /* 1: the layer-at-a-time TemporalConvNet kernels even where the fused kernel applies (default 0)     */
+  int32_t gru_persist_max_lanes;      /* lanes up to which the persistent scan runs (default 96: the measured cross-over with the chain)    */
+  int32_t gemm_split_max_tiles;       /* output tiles up to which the fp32 GEMMs of the scan split their reduction (default 1024)           */
+  int32_t skinny_max_rows;            /* rows up to which the backward's fp32 GEMMs take the skinny kernel (default 4096)                   */
+  int32_t lgru_tile_max_sessions;     /* sessions up to which the session-tile kernels run (default 131072)                                 */
+  int32_t lgru_wide_max_launches;     /* launches a batch may be cut into for lgru_wide at H = 256 (default 3)                              */
+  int32_t sgrad_dyn_max_blocks;       /* row blocks up to which the scoring backward deals its grid on the device (default 1024)            */
+  int32_t sgrad0_min_stages;          /* catalogue stages per part of the scoring backward's forward split (default 64)                     */
+  int32_t tcn_gs2_max_sessions;       /* sessions up to which the fused TCN kernel runs two sessions per workgroup (default 512; -1 never)  */
+  int32_t lgru_defer_max_gib;         /* GiB of records up to which HierGRU's weight gradients are deferred to one GEMM (default 8)         */
+  int32_t reserved[11];               /* zero                                                                                               */
+} hiertcn_tuning_t;
+int hiertcn_get_tuning(hiertcn_handle_t h, hiertcn_tuning_t* out);
+int hiertcn_set_tuning(hiertcn_handle_t h, const hiertcn_tuning_t* in);
+
+/* sizeof() of the six structs of this header as the LIBRARY was compiled, in this order: hiertcn_config_t, hiertcn_weights_t,
+ * hiertcn_score_out_t, hiertcn_gmm_config_t, hiertcn_gmm_weights_t, hiertcn_tuning_t -- lets a binding written in another language verify its
+ * own struct definitions at load time (tests/test_cabi_load.py does, for hiertcn_amd/_lib.py and for the stub in INTEGRATION.md). */
+#define HIERTCN_N_STRUCTS 6
 int hiertcn_struct_sizes(size_t out[HIERTCN_N_STRUCTS]);
 
 /* model_hier.py:83-85.  y_ids [n_sessions][L] -> pooled [n_sessions][E] fp32. */
@@ -331,6 +370,8 @@ typedef struct {
                                           *    trunk 3 (ABI 9): the GRU stack on the same rows -- model_hier.py:68-69, model_low_type 'gru_gmm':
                                           *    gru_gate_kernel[0] [input_dim + H][2H], gru_cand_kernel[0] [input_dim + H][H], sequence_length =
                                           *    the count of rows that are not all-zero (model_gru_gmm.py:57-67); hidden_dim / num_layer as trunk 1 */
+  int32_t table_pass;                    /* (ABI 10) 1: hiertcn_gmm_loss always as M passes of the scoring kernel over the [D, C] mean tables, also where
+                                          *    the Gram form (3 C < D, C <= 256: csrc/gmm_gram.hip) applies -- A/B runs and tests; 0: the library decides */
 } hiertcn_gmm_config_t;
 typedef struct {
   const float* conv_kernel[HIERTCN_MAX_BLOCKS];
@@ -377,6 +418,12 @@ int hiertcn_timing_read(hiertcn_handle_t h, double* score_ms_avg, int64_t* launc
  * device; a reported time-out also resets the handle's barrier counters, so that later launches synchronise correctly again.  The run
  * loops read it once per evaluation epoch and raise (hiertcn_amd/run_hier_xing.py). */
 int hiertcn_persistent_health(hiertcn_handle_t h, int32_t* timed_out);
+/* The same word without a synchronisation (ABI 10): enqueues, on `stream`, a copy of the 8-byte health word into *host_word -- pinned host
+ * memory owned by the caller -- and returns.  Once work recorded behind the call on that stream has completed (an event), *host_word != 0
+ * says that a bounded wait ran out in a launch enqueued before the call.  Nothing is reset: a run loop that sees a non-zero word stops and
+ * calls hiertcn_persistent_health.  (hiertcn_amd/run_hier_xing.py polls it where the reference writes results.txt, every 20 batches.)
+ * *host_word is left untouched on a handle without persistent launches (single-level models). */
+int hiertcn_persistent_health_async(hiertcn_handle_t h, uint64_t* host_word, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,18 +1,25 @@
-# The split-operand scoring kernel (csrc/score_x3.hip) under rocprofv3: kernel trace + stats of scripts/split16_bench.py, then two PMC passes
-# (MFMA-pipe busy / stalls / LDS; instruction mix), then two more for the HBM-side traffic.  Summaries -> gpurun_out/r4_split16_*.
+# The split-operand scoring kernels (csrc/score_x3.hip, csrc/score_x3w.hip) under rocprofv3: kernel trace + stats, then two PMC passes
+# (MFMA-pipe busy / stalls / LDS; instruction mix), then one more for the HBM-side traffic.  Summaries -> gpurun_out/<tag>_*.
+# usage: bash scripts/profile_split16.sh [tag] [program ...]
+#   default           r4_split16       python3 scripts/split16_bench.py 1024                           (d = 256, 614,400 x 300,000)
+#   d = 512 (round 5) r5_split16_d512  python3 scripts/split16_kernel_bench.py 512 1000000 153600 0 3
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-B="python3 scripts/split16_bench.py 1024"
+TAG=${1:-r4_split16}
+export TAG
+[ $# -gt 0 ] && shift
+B="${*:-python3 scripts/split16_bench.py 1024}"
 timeout 600 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/sp16_trace -- $B > gpurun_out/sp16_trace.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_VALU_MFMA_BUSY_CYCLES SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE --output-format csv -d gpurun_out/sp16_pmc1 -- $B > gpurun_out/sp16_pmc1.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_INSTS_SALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_WAIT_ANY --output-format csv -d gpurun_out/sp16_pmc2 -- $B > gpurun_out/sp16_pmc2.log 2>&1
 timeout 600 rocprofv3 --kernel-trace --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_HIT_sum TCC_MISS_sum --output-format csv -d gpurun_out/sp16_pmc3 -- $B > gpurun_out/sp16_pmc3.log 2>&1
 python3 - <<'PY'
-import csv, glob, collections, json
+import csv, glob, collections, json, os
+TAG = os.environ["TAG"]
 res = {}
 for f in glob.glob("gpurun_out/sp16_trace/**/*kernel_stats.csv", recursive=True):
     rows = list(csv.DictReader(open(f)))
     res["kernel_stats"] = [{"name": r["Name"][:100], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "pct": float(r["Percentage"])} for r in rows[:14]]
-    open("gpurun_out/r4_split16_kernel_stats.csv", "w").write(open(f).read())
+    open("gpurun_out/%s_kernel_stats.csv" % TAG, "w").write(open(f).read())
 for d in ("sp16_pmc1", "sp16_pmc2", "sp16_pmc3"):
     agg = collections.defaultdict(lambda: collections.defaultdict(float)); disp = collections.defaultdict(set)
     for f in glob.glob(f"gpurun_out/{d}/**/*counter_collection.csv", recursive=True):
@@ -34,7 +41,7 @@ for k, v in res.get("pmc_per_launch", {}).items():
     if "TCC_HIT_sum" in v:
         v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
         v["fetch_bytes"] = (v["TCC_EA0_RDREQ_sum"] - v["TCC_EA0_RDREQ_32B_sum"]) * 64 + v["TCC_EA0_RDREQ_32B_sum"] * 32
-json.dump(res, open("gpurun_out/r4_split16_summary.json", "w"), indent=1)
+json.dump(res, open("gpurun_out/%s_summary.json" % TAG, "w"), indent=1)
 print(json.dumps(res, indent=1)[:6000])
 PY
 tail -5 gpurun_out/sp16_trace.log

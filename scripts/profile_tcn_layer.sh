@@ -10,6 +10,6 @@ timeout 300 rocprofv3 --kernel-trace --pmc FETCH_SIZE GRBM_GUI_ACTIVE --output-f
 timeout 300 rocprofv3 --kernel-trace --pmc WRITE_SIZE TCC_HIT_sum TCC_MISS_sum --output-format csv -d $OUT/pmc_write -- $B > $OUT/pmc_write.log 2>&1
 timeout 300 rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_WAIT_INST_ANY --output-format csv -d $OUT/pmc_sq -- $B > $OUT/pmc_sq.log 2>&1
 python3 scripts/tcn_layer_bench.py single eval > $OUT/bench.txt 2>&1
-HIERTCN_TCN_LAYER_V1=1 python3 scripts/tcn_layer_bench.py single eval > $OUT/bench_v1.txt 2>&1
+HIERTCN_LIB=$PWD/hiertcn_amd/libhiertcn_gfx950_ablation.so HIERTCN_TCN_LAYER_V1=1 python3 scripts/tcn_layer_bench.py single eval > $OUT/bench_v1.txt 2>&1
 python3 scripts/summarise_profile.py $OUT > $OUT/summary.txt 2>&1
 cat $OUT/bench.txt $OUT/bench_v1.txt $OUT/summary.txt

@@ -50,12 +50,12 @@ def test_abi_version(lib):
 
 
 # ---- struct layouts: header (compiled as C99 by gcc) == hiertcn_amd/_lib.py == the built library == the stubs in INTEGRATION.md ----------
-C_STRUCTS = ["hiertcn_config_t", "hiertcn_weights_t", "hiertcn_score_out_t", "hiertcn_gmm_config_t", "hiertcn_gmm_weights_t"]
+C_STRUCTS = ["hiertcn_config_t", "hiertcn_weights_t", "hiertcn_score_out_t", "hiertcn_gmm_config_t", "hiertcn_gmm_weights_t", "hiertcn_tuning_t"]
 
 
 def _binding_structs():
     from hiertcn_amd import _lib
-    return dict(zip(C_STRUCTS, [_lib.Config, _lib.Weights, _lib.ScoreOut, _lib.GmmConfig, _lib.GmmWeights]))
+    return dict(zip(C_STRUCTS, [_lib.Config, _lib.Weights, _lib.ScoreOut, _lib.GmmConfig, _lib.GmmWeights, _lib.Tuning]))
 
 
 def _header_fields():
@@ -182,3 +182,34 @@ def test_the_shipped_libraries_hold_no_fault_injection_switch():
         assert not any(n in blob for n in names), path
     hooks = open(LIB_TESTHOOKS, "rb").read()
     assert all(n in hooks for n in names)
+
+
+def test_the_shipped_libraries_read_no_environment_variable():
+    """hiertcn_tuning_t (ABI 10) replaced the HIERTCN_* switches the launch path used to look up: the shipped libraries import no getenv and hold at
+    most a handful of HIERTCN_ strings (the precision names of two error messages); the A/B switches of superseded kernels live in the ablation
+    build alone, which does hold them."""
+    import subprocess
+    from hiertcn_amd.build import LIB, LIB_ABLATION, LIB_F16
+    for path in (LIB, LIB_F16):
+        blob = open(path, "rb").read()
+        names = set(re.findall(rb"HIERTCN_[A-Z0-9_]+", blob))
+        assert len(names) <= 5, (path, sorted(names))
+        assert not any(n.startswith((b"HIERTCN_GRU_", b"HIERTCN_LGRU_", b"HIERTCN_SCORE", b"HIERTCN_TOPK", b"HIERTCN_TCN_", b"HIERTCN_TRAIN_", b"HIERTCN_SGRAD")) for n in names), sorted(names)
+        nm = subprocess.run(["nm", "-D", "--undefined-only", path], capture_output=True, text=True)
+        if nm.returncode == 0:
+            assert "getenv" not in nm.stdout.split(), path
+    abl = open(LIB_ABLATION, "rb").read()
+    assert b"HIERTCN_TRAIN_LEGACY" in abl and b"HIERTCN_TCN_LAYER_V1" in abl and b"HIERTCN_TOPK_V1" in abl
+
+
+def test_tuning_defaults_round_trip_and_env_mapping(lib):
+    """hiertcn_get_tuning / hiertcn_set_tuning need no GPU... but a handle does (hiertcn_create touches the device), so what is checked here is the
+    host side: the binding's field list equals the header's, and the mapping of the old environment names covers exactly fields that exist."""
+    from hiertcn_amd import _lib
+    for name, (field, conv) in _lib.ENV_TUNING.items():
+        assert field in _lib.TUNING_FIELDS, (name, field)
+    env = {"HIERTCN_GRU_CHAIN": "1", "HIERTCN_LGRU_CHAIN": "0", "HIERTCN_LGRU_PIPE": "0", "HIERTCN_SGRAD_DYN_MAX_BLOCKS": "127", "HIERTCN_TCN_GS2_MAX": "0",
+           "HIERTCN_GRU_CHAIN_UNRELATED": "1"}
+    assert _lib.tuning_from_env(env) == {"gru_scan_persistent": 0, "lgru_persistent": 1, "lgru_pipe": 0, "sgrad_dyn_max_blocks": 127, "tcn_gs2_max_sessions": -1}
+    assert _lib.tuning_from_env({"HIERTCN_GRU_CHAIN": "0"}) == {}       # "0" = the library's own choice
+    assert lib.hiertcn_get_tuning(None, None) == -1 and lib.hiertcn_set_tuning(None, None) == -1

@@ -19,17 +19,14 @@ pytestmark = pytest.mark.gpu
 
 
 def _scan(eng, pooled, mask, st0, chain):
-    old = {k: os.environ.get(k) for k in ("HIERTCN_GRU_CHAIN",)}
-    os.environ["HIERTCN_GRU_CHAIN"] = "1" if chain else "0"
+    """chain: the scan as 2 (S + 1) GEMM launches (hiertcn_tuning_t.gru_scan_persistent = 0); else the library's choice (the persistent launch
+    at these shapes)."""
+    eng.set_tuning(gru_scan_persistent=0 if chain else -1)
     try:
         out = eng.gru_scan(pooled, mask, st0, want_state_before=True)
         torch.cuda.synchronize()
     finally:
-        for k, v in old.items():
-            if v is None:
-                os.environ.pop(k, None)
-            else:
-                os.environ[k] = v
+        eng.set_tuning(gru_scan_persistent=-1)
     return [t.cpu().numpy() for t in out]
 
 
@@ -79,7 +76,7 @@ def test_persistent_scan_soak_and_graph_replay():
     ref = [_scan(eng, *dat, chain=True) for dat in data]
     for f, r in zip(first, ref):
         np.testing.assert_allclose(f[1], r[1], rtol=2e-5, atol=2e-5)
-    os.environ["HIERTCN_GRU_CHAIN"] = "0"
+    assert eng.get_tuning()["gru_scan_persistent"] == -1
     try:
         for it in range(200):
             i = it % len(shapes)
@@ -90,7 +87,7 @@ def test_persistent_scan_soak_and_graph_replay():
             for g, f in zip(got, first[i]):
                 assert np.array_equal(g.cpu().numpy(), f), f"launch {it}: result differs from the first launch of its shape"
     finally:
-        os.environ.pop("HIERTCN_GRU_CHAIN", None)
+        pass
     assert not eng.persistent_timed_out()   # no bounded wait ever ran out
     eng.close()
 

@@ -216,7 +216,7 @@ def test_hiergru_training_step_matches_autograd(d, H, N, nl, shape):
 
 def test_split_operand_cells_agree_with_the_fp32_cells():
     """csrc/gru_x3.hip (a.w = a_hi w_hi + a_lo w_hi + a_hi w_lo on the 16-bit MFMA, fp32 accumulators) against the exact-fp32 cells
-    (HIERTCN_LGRU_FP32=1, read per call) over 30 steps and two layers: the 16-bit output rows are identical except where a ~2^-16 relative
+    (hiertcn_tuning_t.lgru_fp32_cells = 1) over 30 steps and two layers: the 16-bit output rows are identical except where a ~2^-16 relative
     difference of the recurrence straddles a rounding boundary of the storage type -- rare, and never more than one ulp."""
     import os
     from hiertcn_amd.engine import Engine
@@ -231,12 +231,11 @@ def test_split_operand_cells_agree_with_the_fp32_cells():
     sproj, _, _ = eng.gru_scan(pooled, dev(mask), st0)
     outs = []
     for fp32 in (False, True):
-        if fp32:
-            os.environ["HIERTCN_LGRU_FP32"] = "1"
+        eng.set_tuning(lgru_fp32_cells=1 if fp32 else -1)
         try:
             outs.append(eng.tcn_forward(dev(x.reshape(B * S, L)), sproj.view(B * S, -1)).float().cpu().numpy())
         finally:
-            os.environ.pop("HIERTCN_LGRU_FP32", None)
+            eng.set_tuning(lgru_fp32_cells=-1)
     a, b = outs
     assert np.abs(b).max() > 0.05
     diff = np.abs(a - b)
@@ -337,13 +336,8 @@ def test_layer_pipelined_low_level_matches_the_session_tile_kernel(d, nl, B, S, 
     pipe = rows()
     for _ in range(30):
         assert np.array_equal(rows(), pipe)
-    os.environ["HIERTCN_LGRU_PIPE"] = "0"
-    os.environ["HIERTCN_LGRU_WIDE"] = "0"
-    try:
-        tile = rows()
-    finally:
-        os.environ.pop("HIERTCN_LGRU_PIPE")
-        os.environ.pop("HIERTCN_LGRU_WIDE")
+    eng.set_tuning(lgru_pipe=0, lgru_wide=0)     # hiertcn_tuning_t: the session-tile kernel instead
+    tile = rows()
     assert not eng.persistent_timed_out()
     eng.close()
     assert np.array_equal(pipe == 0, tile == 0)

@@ -191,7 +191,7 @@ np.savez(sys.argv[1], **{k.replace("/", "."): v for k, v in g.items()})
     with tempfile.TemporaryDirectory() as tmp:
         outs = []
         # (third run: the layer-at-a-time low level instead of the fused kernel that writes the kept activations on its way)
-        for i, env in enumerate(({}, {"HIERTCN_TRAIN_CHUNK_STAGES": "1"}, {"HIERTCN_FORCE_LAYERED": "1"})):
+        for i, env in enumerate(({}, {"HIERTCN_SGRAD0_MIN_STAGES": "1"}, {"HIERTCN_FORCE_LAYERED": "1"})):   # (mapped onto hiertcn_tuning_t when the Engine is created)
             f = os.path.join(tmp, f"g{i}.npz")
             subprocess.run([sys.executable, "-c", code, f], check=True, env={**os.environ, **env})
             outs.append(dict(np.load(f)))
@@ -452,7 +452,7 @@ def test_width_padded_model_trains_d100():
 @pytest.mark.parametrize("d,overflow", [(128, False), (256, False), (256, True), (128, True)])
 def test_fused_scoring_backward_matches_the_chunked_path(d, overflow):
     """csrc/score_bwd.hip (one pass over the logits for rank / ce / d hidden, a second for d Wo / d bo, nothing materialised, row count on
-    the device) against the previous implementation (bf16 d-logits chunks + rocBLAS products, HIERTCN_TRAIN_LEGACY=1): loss, per-step
+    the device) against the previous implementation (bf16 d-logits chunks + two 16-bit GEMMs per chunk: the ablation build's HIERTCN_TRAIN_LEGACY=1): loss, per-step
     outputs and every gradient.  overflow: scoring weights that put one item > 133 nats above every target, so the forward pass's
     running sum leaves fp32 range and both fix-up launches (rank / ce and d hidden) run."""
     from hiertcn_amd.engine import Engine, metrics_dict
@@ -474,7 +474,7 @@ def test_fused_scoring_backward_matches_the_chunked_path(d, overflow):
         if mode == "legacy":
             os.environ["HIERTCN_TRAIN_LEGACY"] = "1"
         try:
-            eng = Engine(args, hier=True, train=True)
+            eng = Engine(args, hier=True, train=True, lib_variant="ablation" if mode == "legacy" else None)
             eng.set_weights(p)
             out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
             torch.cuda.synchronize()
@@ -503,7 +503,7 @@ def test_scoring_backward_split_over_several_rounds_equals_the_unsplit_walk():
     """Past 128 padded row blocks the training forward of the scoring layer deals (row block, table part) over a grid of several rounds of the chip
     (score_bwd.hip: sg_dyn_grid, score_dyn_split's cost rule); HIERTCN_SGRAD_DYN_MAX_BLOCKS=127 keeps one workgroup per row block walking the whole
     table.  Same sums in another order: loss, carried state and every gradient of a 260-lane XING-sized step agree to 1e-5 (tests/tools/sgrad_split_probe.py,
-    one process per setting -- the library reads the variable once)."""
+    one process per setting: the variable is mapped onto hiertcn_tuning_t.sgrad_dyn_max_blocks when the Engine is created)."""
     import json
     import os
     import subprocess

@@ -151,7 +151,8 @@ def test_lds_tiled_and_unstaged_layer_kernels_agree_bitwise(cfg):
     """k_tcn_layer_lds (activation slab in LDS, fragment-major weights through a register ring) keeps the accumulation order of k_tcn_layer
     (bias, taps outermost, k-steps inner, zero operands outside the sequence): identical 16-bit activations, for long single-level sequences
     (args.py:310-311's six blocks at T = 500, incl. the Dense down-sample of block 4), tiles that end inside a sequence, dilations whose halo
-    reaches past the sequence start, and the hier projection with its per-session accumulator start.  HIERTCN_TCN_LAYER_V1 is read per launch."""
+    reaches past the sequence start, and the hier projection with its per-session accumulator start.  The un-staged kernel is no longer chosen by the
+    shipped library where the LDS-tiled one applies: it runs from the ablation build (Engine(lib_variant="ablation") + HIERTCN_TCN_LAYER_V1=1)."""
     import torch
     from hiertcn_amd.engine import Engine
     from tests.gpu_common import make_params, small_args
@@ -159,8 +160,9 @@ def test_lds_tiled_and_unstaged_layer_kernels_agree_bitwise(cfg):
     dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).cuda()  # noqa: E731
     if cfg == "hier_L100_d128":
         args = small_args(N=800, d=128, H=64, nl=1, blocks=3, K=5, L=100, S=2, B=3)
-        eng = Engine(args, hier=True)
-        eng.set_weights(make_params(args))
+        eng, eng_v1 = Engine(args, hier=True), Engine(args, hier=True, lib_variant="ablation")
+        for e in (eng, eng_v1):
+            e.set_weights(make_params(args))
         x = rng.integers(0, 800, (6, 100)).astype(np.int32)
         sproj = dev((0.3 * rng.standard_normal((6, 128))).astype(np.float32))
     else:
@@ -169,20 +171,22 @@ def test_lds_tiled_and_unstaged_layer_kernels_agree_bitwise(cfg):
                              "narrow_64_T97_K2": (500, 64, [64, 64, 64, 64, 64], 9, 97, 2),
                              "mixed_128_256_128_T200": (700, 128, [128, 256, 128], 4, 200, 4)}[cfg]
         a = tcn_args(N, d, ch, K=K)
-        eng = Engine(a, hier=False)
-        eng.set_weights(noisy(init_params(a, 2, "tcn")))
+        eng, eng_v1 = Engine(a, hier=False), Engine(a, hier=False, lib_variant="ablation")
+        for e in (eng, eng_v1):
+            e.set_weights(noisy(init_params(a, 2, "tcn")))
         x = rng.integers(0, N, (B, T)).astype(np.int32)
         sproj = None
     outs = []
     for v1 in (False, True):
         if v1:
-            os.environ["HIERTCN_TCN_LAYER_V1"] = "1"
+            os.environ["HIERTCN_TCN_LAYER_V1"] = "1"     # (looked up by the ablation build only)
         try:
-            outs.append(eng.tcn_forward(dev(x), sproj).view(torch.int16).cpu().numpy())
+            outs.append((eng_v1 if v1 else eng).tcn_forward(dev(x), sproj).view(torch.int16).cpu().numpy())
         finally:
             os.environ.pop("HIERTCN_TCN_LAYER_V1", None)
     assert outs[0].any() and np.array_equal(outs[0], outs[1])
     eng.close()
+    eng_v1.close()
 
 
 @pytest.mark.gpu
