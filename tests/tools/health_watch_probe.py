@@ -28,10 +28,10 @@ os.makedirs(args.log_path + "test/", exist_ok=True)
 
 
 class Sixty:
-    """60 packed batches: the synthetic loader, started over whenever it runs out; the fault switch is up for batch `bad` alone."""
+    """60 packed batches: the synthetic loader, started over whenever it runs out (no prefetch thread: the batch count is the loop's)."""
 
-    def __init__(self, n=60, bad=3):
-        self.n, self.bad, self.i = n, bad, 0
+    def __init__(self, n=60):
+        self.n, self.i = n, 0
         self.inner = Dataloader_hier_model_xing(args, "test", data=data)
         self.viewer_table = self.inner.viewer_table
 
@@ -39,10 +39,6 @@ class Sixty:
         if self.inner.done:
             self.inner = Dataloader_hier_model_xing(args, "test", data=data)
         self.i += 1
-        if self.i == self.bad:
-            os.environ["HIERTCN_GRU_TEST_MISSING_WG"] = "1"
-        else:
-            os.environ.pop("HIERTCN_GRU_TEST_MISSING_WG", None)
         return self.inner.get_packed_batch()
 
     @property
@@ -52,6 +48,22 @@ class Sixty:
 
 model = HierTCNModel(args, make_params(args))
 assert model.engine.get_tuning()["gru_scan_persistent"] == -1
+# the fault switch of the test-hooks build is looked up when the scan is LAUNCHED: up for the launch of batch 3 alone
+launches = {"n": 0, "bad": 3}
+enqueue = model.eval_step_packed_async
+
+
+def faulty(*a, **k):
+    launches["n"] += 1
+    if launches["n"] == launches["bad"]:
+        os.environ["HIERTCN_GRU_TEST_MISSING_WG"] = "1"
+    try:
+        return enqueue(*a, **k)
+    finally:
+        os.environ.pop("HIERTCN_GRU_TEST_MISSING_WG", None)
+
+
+model.eval_step_packed_async = faulty
 ld = Sixty()
 try:
     evaluate_hier(args, ld, np.zeros((4, 128)), model, prefix="test")
@@ -61,7 +73,8 @@ except RuntimeError as e:
     print("HEALTH_WATCH_PROBE", int(m.group(1)), ld.i)
     # the handle was reset by the synchronising read behind the exception: a clean epoch now runs through
     os.environ.pop("HIERTCN_GRU_TEST_MISSING_WG", None)
-    ld2 = Sixty(n=25, bad=-1)
+    launches["bad"] = -1
+    ld2 = Sixty(n=25)
     evaluate_hier(args, ld2, np.zeros((4, 128)), model, prefix="test")
     print("HEALTH_WATCH_PROBE recovered")
     sys.exit(0)
