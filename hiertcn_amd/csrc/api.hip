@@ -247,6 +247,11 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
       hiertcn_destroy(c);
       return fail(HIERTCN_ERR_HIP, "hipMemset(walk_pos) failed");
     }
+    ALLOC_OR_FAIL(m.walk_pace, (size_t)8 * XW_PACE_INTS);   // slots -1 (= empty), tickets -1 (any start value does)
+    if (hipMemset(m.walk_pace, 0xff, 8 * XW_PACE_INTS * sizeof(int)) != hipSuccess) {
+      hiertcn_destroy(c);
+      return fail(HIERTCN_ERR_HIP, "hipMemset(walk_pace) failed");
+    }
   }
 #undef ALLOC_OR_FAIL
   *out = c;

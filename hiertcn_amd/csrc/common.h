@@ -96,8 +96,11 @@ struct ModelDev {
   uint16_t* lgru_wgTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wgTF_lo[HIERTCN_MAX_LAYERS];
   uint16_t* lgru_wcTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wcTF_lo[HIERTCN_MAX_LAYERS];
   int* walk_pos;        // [8][32] ints, zeroed: per-XCD position words of the scoring kernel's item walk (null: every workgroup starts at stage 0)
+  int* walk_pace;       // [8][XW_PACE_INTS] ints: per-XCD ticket + position slots of the workgroups that pace their item walk on each other (score_x3w.hip); null: no pacing
   hiertcn_tuning_t tune;   // launch selection + thresholds (include/hiertcn.h: hiertcn_set_tuning); the library reads no environment variable
 };
+#define XW_PACE_SLOTS 64                    // position slots per XCD class (32 workgroups are resident per XCD at one per CU)
+#define XW_PACE_INTS (XW_PACE_SLOTS + 32)   // + a line of its own for the ticket counter
 // the tuning of the handle whose API call this thread is in (api.hip sets it on entry): for the few launch helpers that take no ModelDev
 const hiertcn_tuning_t& tune_now();
 void tuning_defaults(hiertcn_tuning_t* t);

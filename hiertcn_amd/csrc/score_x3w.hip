@@ -17,6 +17,13 @@
 //  * ONE workgroup barrier per tile, before k-step 30: behind it tile T + 1 (issued at k-steps 0..15, every wave having waited for its own
 //    pieces) is visible to all waves -- the ring's reads of k-steps 30 and 31 are the first fragments of that tile -- and every wave has read its
 //    last fragment of tile T, whose buffer the next phase refills.
+//  * PACED WALK.  A workgroup streams the whole 2 GB table (N = 10^6) and hides the stream's latency a full tile ahead, so nothing couples the
+//    32 workgroups of an XCD: left alone they drift apart until no two of them read the same 4 MB of the table at the same time (measured: L2 hit
+//    rate 11 %, 1.09 TB per launch through the fabric, 20 % of the wave time in waits).  So the workgroups of an XCD class (blockIdx % 8) publish
+//    their walk position in a slot of `pace` every 4 tiles and, every 8 tiles, the one that is more than XW_WINDOW tiles ahead of a NEIGHBOUR (a
+//    workgroup within XW_FAR tiles: the same cohort) sleeps until the neighbour has caught up -- bounded: a stale slot costs microseconds, never
+//    a hang; placement is assumed for speed only (MI355X_MICROARCH.md, Workgroup dispatch).  The leaders wait for the slowest, the window stays
+//    inside the XCD's L2, and one workgroup's miss is 31 workgroups' hit.
 // Flavours, outputs, catalogue parts for small batches, ragged row lists: as k_score_x3 (one launcher decides between them: score_x3.hip).
 #include "common.h"
 #include "exact.h"
@@ -26,6 +33,9 @@
 
 #define XW_THREADS 256
 #define XW_ROWS 128   // rows per workgroup
+#define XW_WINDOW 16  // tiles (1 MB of table) a workgroup may lead a neighbour of its XCD by
+#define XW_FAR 1024   // tiles beyond which another workgroup's position is not a neighbour's (a later round of the grid at another place of the table)
+#define XW_PACE_TRIES 24   // bounded wait: sleeps of ~2 us
 
 struct XwGeom {
   static constexpr int CL = 512, KSL = 32, CP = 1024;   // CP: halves per table row [hi | lo]
@@ -48,7 +58,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
                                                              const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_rows_dev,
                                                              int part_stages, float* __restrict__ partials, int* __restrict__ walk_pos,
                                                              int32_t* __restrict__ o_topi, float* __restrict__ o_topv, int topk,
-                                                             float* __restrict__ logits, const float* __restrict__ tab_scale) {
+                                                             float* __restrict__ logits, const float* __restrict__ tab_scale, int* __restrict__ pace) {
   using X = XwGeom;
   constexpr int KSL = X::KSL, CP = X::CP, CL = X::CL;
   constexpr bool MAIN = FLAVOUR == 0, FIXUP = FLAVOUR == 1, LOGITS = FLAVOUR == 2;
@@ -166,6 +176,31 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
     stg -= (stg >= n_stages) ? n_stages : 0;
     return (stg_lo + stg) * SC_STAGE + (T & 1) * 32;
   };
+  // ---- paced walk (file header): this workgroup's slot, and the test "am I too far ahead of a neighbour?" on one wave-wide read of the slots
+  int* pace_slot = nullptr;
+  const int* pace_row = nullptr;
+  if (MAIN && pace && !partials && n_tiles > 4 * XW_WINDOW) {
+    int* row = pace + (blockIdx.x & 7) * XW_PACE_INTS;
+    int* t_sh = reinterpret_cast<int*>(smem);
+    if (tid == 0) *t_sh = atomicAdd(row + XW_PACE_SLOTS, 1);
+    __syncthreads();
+    const int ticket = __builtin_amdgcn_readfirstlane(*t_sh);
+    __syncthreads();
+    pace_slot = row + (ticket & (XW_PACE_SLOTS - 1));
+    pace_row = row;
+  }
+  auto tile_abs = [&](int T) {   // position in the table, in tiles
+    int stg = s0 + (T >> 1);
+    stg -= (stg >= n_stages) ? n_stages : 0;
+    return 2 * stg + (T & 1);
+  };
+  // lanes 0..63 of wave 0 look at one slot each: true if some neighbour is more than XW_WINDOW tiles behind `mine`
+  auto pace_ahead = [&](int mine, int other) {
+    int lead = mine - other;                    // cyclic, signed
+    lead += (lead < -(n_tiles >> 1)) ? n_tiles : 0;
+    lead -= (lead > (n_tiles >> 1)) ? n_tiles : 0;
+    return other >= 0 && lead > XW_WINDOW && lead <= XW_FAR;
+  };
   // ---- item stream: LDS-DMA through inline asm (score.hip, cdna_hip_programming.md 5.7).  Piece i of a wave = table row wave * 8 + i / 2, half i % 2
   const unsigned dma_voff = (unsigned)lane * 16u;
   auto dma_piece = [&](int i, const unsigned char* tile_g, int buf) {
@@ -223,12 +258,26 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
     };
     uint4 rH[4], rL[4];
     float tk_m = -INFINITY;
+    int pace_seen_ = -1;
     // Phase T: MF_: the 96 MFMAs of tile T into x (from zero), fragments two k-steps ahead, tile T + 1's DMA one piece per k-step over
     // k-steps 0..15, the tile barrier before k-step 30.  DR_: tile T - 1's values in y: bias read at k-step 0, bias fma over k-steps 1..4 (and the
     // tile maximum for the lists), the list vote behind k-step 4, one value per k-step over 5..20.
 #define XW_STEP(XA, YA, s)                                                                                    \
     {                                                                                                        \
       if (MF_) {                                                                                             \
+        if (s == 0 && pace_slot && wave == 0) {   /* paced walk: publish every 4 tiles; every 8 read the neighbours' slots (used at k-step 29) */ \
+          if ((T_ & 3) == 0 && lane == 0) __hip_atomic_store(pace_slot, tile_abs(T_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+          if ((T_ & 7) == 4) pace_seen_ = __hip_atomic_load(pace_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
+        }                                                                                                    \
+        if (s == KSL - 3 && pace_slot && wave == 0 && (T_ & 7) == 4) {                                       \
+          const int mine_ = tile_abs(T_);                                                                    \
+          int tries_ = 0;                                                                                    \
+          while (__any(pace_ahead(mine_, pace_seen_)) && tries_ < XW_PACE_TRIES) {   /* wave-uniform */        \
+            __builtin_amdgcn_s_sleep(64);                                                                    \
+            pace_seen_ = __hip_atomic_load(pace_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     \
+            tries_++;                                                                                        \
+          }                                                                                                  \
+        }                                                                                                    \
         if (s == KSL - 2) {                                                                                  \
           asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
           __syncthreads();                                                                                   \
@@ -310,6 +359,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
       }
       XW_PHASE(accB, accA, T, true, true);      // the last tile (n_tiles is even)
       XW_PHASE(accA, accB, n_tiles, false, true);   // ... and its drain
+      if (pace_slot && tid == 0) __hip_atomic_store(pace_slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no longer a neighbour
     }
 #undef XW_PHASE
 #undef XW_STEP
@@ -446,32 +496,37 @@ static hipError_t launch_x3w_c(const ModelDev& m, const ExactDev& x, const float
   if (e != hipSuccess) return e;
   if ((e = hipFuncSetAttribute(reinterpret_cast<const void*>(fix), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X::LDS_BYTES)) != hipSuccess) return e;
   int* walk = KT > 0 ? nullptr : m.walk_pos;   // lists: equal values must arrive in index order (tf.nn.top_k), so the walk starts at item 0
+#define PACE_ARG m.walk_pace
   const int parts = score_split_parts(R, m.NP, XW_ROWS);
   const int n_all = m.NP / SC_STAGE;
   if (KT == 0 && split_scratch && parts > 1 && (R + XW_ROWS - 1) / XW_ROWS < 128 && out->rank && out->ce && out->target) {
     // small batches: SC_DYN_GRID workgroups dealt as (row tile, catalogue part) on the device from the live row count (score_geom.h)
     hipLaunchKernelGGL(kern, dim3(SC_DYN_GRID), dim3(XW_THREADS), lds, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target,
-                       row_map, n_rows_dev, -SC_DYN_MAX_PARTS, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale);
+                       row_map, n_rows_dev, -SC_DYN_MAX_PARTS, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale, PACE_ARG);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_score_merge(split_scratch, -SC_DYN_MAX_PARTS, R, row_map, n_rows_dev, y, out->target, out->rank, out->ce, st, SC_DYN_GRID, XW_ROWS, n_all)) != hipSuccess) return e;
   } else if (KT == 0 && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
     // mid-size batches: (row tile, catalogue part) workgroups, partial (count, log2-sum) per part added up by score.hip's merge kernel
     const int part_stages = (n_all + parts - 1) / parts;
     hipLaunchKernelGGL(kern, dim3(blocks, parts), dim3(XW_THREADS), lds, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target,
-                       row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale);
+                       row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale, PACE_ARG);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_score_merge(split_scratch, parts, R, row_map, n_rows_dev, y, out->target, out->rank, out->ce, st, 0, XW_ROWS, n_all)) != hipSuccess) return e;
   } else {
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(XW_THREADS), lds, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target, row_map,
-                       n_rows_dev, 0, (float*)nullptr, walk, out->topk_idx, out->topk_val, (int)out->topk, (float*)nullptr, (const float*)x.outS_scale);
+                       n_rows_dev, 0, (float*)nullptr, walk, out->topk_idx, out->topk_val, (int)out->topk, (float*)nullptr, (const float*)x.outS_scale, PACE_ARG);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
+#undef PACE_ARG
+#define PACE_ARG (int*)nullptr
   if (!out->ce) return hipSuccess;
   hipLaunchKernelGGL(fix, dim3(blocks), dim3(XW_THREADS), X::LDS_BYTES, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target,
-                     row_map, n_rows_dev, 0, (float*)nullptr, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale);
+                     row_map, n_rows_dev, 0, (float*)nullptr, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale, PACE_ARG);
   return hipGetLastError();
+#undef PACE_ARG
 }
 
+#define PACE_ARG (int*)nullptr
 // hidden fp32 [R][512]; out (fused) or logits (materialised, parity / debug) -- exactly one of them (score_x3.hip's launch_score_x3 dispatches here)
 hipError_t launch_score_x3w(const ModelDev& m, const ExactDev& x, const float* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,
                             float* logits, hipStream_t st, const int32_t* row_map, const int32_t* n_rows_dev, float* split_scratch) {
@@ -482,7 +537,7 @@ hipError_t launch_score_x3w(const ModelDev& m, const ExactDev& x, const float* h
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)((R + XW_ROWS - 1) / XW_ROWS)), dim3(XW_THREADS), X::LDS_BYTES, st, hidden, (const int32_t*)nullptr, R, x.outS,
                        m.out_bias, m.N, m.NP, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, 0,
-                       (float*)nullptr, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, logits, (const float*)x.outS_scale);
+                       (float*)nullptr, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, logits, (const float*)x.outS_scale, PACE_ARG);
     return hipGetLastError();
   }
   if (out->topk <= 0) return launch_x3w_c<0>(m, x, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);
