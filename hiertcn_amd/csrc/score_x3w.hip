@@ -14,9 +14,9 @@
 //    epilogue of tile T - 1's 16 values in their gaps.  The accumulator starts at zero and the bias is added (one fma per value: b 2^(kw+kh) + acc)
 //    when the tile is drained, so no phase depends on the NEXT tile's bias; the target logit is formed by the same sequence (MFMAs from zero, then
 //    the same fma) and `z_n > z_target` stays exactly false for n == y (loss.py:179);
-//  * ONE workgroup barrier per tile, before k-step 30: behind it tile T + 1 (issued at k-steps 0..15, every wave having waited for its own
-//    pieces) is visible to all waves -- the ring's reads of k-steps 30 and 31 are the first fragments of that tile -- and every wave has read its
-//    last fragment of tile T, whose buffer the next phase refills.
+//  * ONE workgroup barrier per tile, behind the MFMAs of k-step 28: behind it tile T + 1 (issued at k-steps 0..15, every wave having waited for
+//    its own pieces) is visible to all waves -- the ring reads three k-steps ahead, so the reads of k-steps 29..31 are the first fragments of that
+//    tile -- and every wave has read its last fragment of tile T, whose buffer the next phase refills.
 //  * PACED WALK.  A workgroup streams the whole 2 GB table (N = 10^6) and hides the stream's latency a full tile ahead, so nothing couples the
 //    32 workgroups of an XCD: left alone they drift apart until no two of them read the same 4 MB of the table at the same time (measured: L2 hit
 //    rate 11 %, 1.09 TB per launch through the fabric, 20 % of the wave time in waits).  So the workgroups of an XCD class (blockIdx % 8) publish
@@ -36,6 +36,23 @@
 #define XW_WINDOW 16  // tiles (1 MB of table) a workgroup may lead a neighbour of its XCD by
 #define XW_FAR 1024   // tiles beyond which another workgroup's position is not a neighbour's (a later round of the grid at another place of the table)
 #define XW_PACE_TRIES 24   // bounded wait: sleeps of ~2 us
+#ifndef XW_DR0
+#define XW_DR0 16     // first k-step of the drain (16 values, one per k-step): the half of the phase that issues no LDS-DMA piece
+#endif                // (6 .. 16; -DXW_DR0=6 is the first form of the kernel: drain and DMA in the same k-steps)
+// timing experiments (wrong results by design; scripts/build_alt.py builds them into a library of their own, profiles/r5_split16_d512_ablation.txt):
+// the kernel without its tile barrier / without its LDS-DMA stream / without its epilogue
+#ifndef XW_ABLATE_BARRIER
+#define XW_ABLATE_BARRIER 0
+#endif
+#ifndef XW_ABLATE_DMA
+#define XW_ABLATE_DMA 0
+#endif
+#ifndef XW_ABLATE_EPI
+#define XW_ABLATE_EPI 0
+#endif
+#ifndef XW_DMA_LAG
+#define XW_DMA_LAG 0    // k-steps by which waves 2, 3 issue their LDS-DMA pieces behind waves 0, 1 (8 measured 2.4 % SLOWER on one box: 397.7 vs 388.4 ms)
+#endif
 
 struct XwGeom {
   static constexpr int CL = 512, KSL = 32, CP = 1024;   // CP: halves per table row [hi | lo]
@@ -260,10 +277,13 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
     float tk_m = -INFINITY;
     int pace_seen_ = -1;
     // Phase T: MF_: the 96 MFMAs of tile T into x (from zero), fragments two k-steps ahead, tile T + 1's DMA one piece per k-step over
-    // k-steps 0..15, the tile barrier before k-step 30.  DR_: tile T - 1's values in y: bias read at k-step 0, bias fma over k-steps 1..4 (and the
-    // tile maximum for the lists), the list vote behind k-step 4, one value per k-step over 5..20.
+    // k-steps 0..15, the tile barrier behind k-step 28.  DR_: tile T - 1's values in y, in the k-steps without a DMA piece: bias read at k-step 10,
+    // bias fma over k-steps 11..14 (and the tile maximum for the lists), the list vote behind k-step 14, one value per k-step over 16..31.
 #define XW_STEP(XA, YA, s)                                                                                    \
     {                                                                                                        \
+      /* Issue budget of a wave alone on its SIMD: an MFMA holds the issue port for 8 of its 32 cycles, so each of the three gaps of a k-step */ \
+      /* hides ~24 cycles of other instructions.  The step's other work is dealt over the three gaps: behind MFMA 1 the                        */ \
+      /* compiler's AGPR -> VGPR copies of MFMA 2's operand, behind MFMA 2 the LDS-DMA piece (k-steps 0..15) or the epilogue share (16..31), behind MFMA 3 the fragment reads. */ \
       if (MF_) {                                                                                             \
         if (s == 0 && pace_slot && wave == 0) {   /* paced walk: publish every 4 tiles; every 8 read the neighbours' slots (used at k-step 29) */ \
           if ((T_ & 3) == 0 && lane == 0) __hip_atomic_store(pace_slot, tile_abs(T_), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); \
@@ -278,15 +298,35 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
             tries_++;                                                                                        \
           }                                                                                                  \
         }                                                                                                    \
-        if (s == KSL - 2) {                                                                                  \
-          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
-          __syncthreads();                                                                                   \
+        if (s == 0) {                                                                                        \
+          _Pragma("unroll") for (int j = 0; j < 16; j++) XA[j] = 0.f;                                        \
         }                                                                                                    \
-        const unsigned char* src_ = (s + 2 < KSL) ? tile_ : ntile_;                                          \
-        rH[(s + 2) & 3] = XW_LDS(src_ + XW_FH((s + 2) % KSL));                                               \
-        rL[(s + 2) & 3] = XW_LDS(src_ + XW_FL((s + 2) % KSL));                                               \
-        if (s < X::PPW && more_) {                                                                           \
-          dma_piece(s, gnext_, (T_ + 1) & 1);                                                                \
+        XA = x3_mfma(rH[s & 3], hhi[s], XA);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+      }                                                                                                      \
+      if (MF_) {                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        XA = x3_mfma(rH[s & 3], hlo[s], XA);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+      }                                                                                                      \
+      if (DR_ && !XW_ABLATE_EPI) {   /* the drained tile, in the k-steps that issue no LDS-DMA piece (the second half of the phase) */ \
+        if (s == XW_DR0 - 6) {   /* its 16 bias values: read here, used from the next k-step on (no wait on the LDS in front of an fma) */ \
+          _Pragma("unroll") for (int q = 0; q < 4; q++) bq_[q] = *reinterpret_cast<const f32x4*>(ybias_ + 8 * q); \
+        }                                                                                                    \
+        if (s >= XW_DR0 - 5 && s < XW_DR0 - 1) {                                                             \
+          const int q_ = (s - (XW_DR0 - 5)) & 3;                                                             \
+          _Pragma("unroll") for (int j = 0; j < 4; j++) YA[4 * q_ + j] = fmaf(bq_[q_][j], rs, YA[4 * q_ + j]); \
+          if (KT > 0) tk_m = fmaxf(fmaxf(q_ == 0 ? YA[0] : tk_m, YA[4 * q_ + (q_ == 0 ? 1 : 0)]), fmaxf(fmaxf(YA[4 * q_ + 1], YA[4 * q_ + 2]), YA[4 * q_ + 3])); \
+        }                                                                                                    \
+        if (s >= XW_DR0 && s < XW_DR0 + 16) val(s - XW_DR0, YA[s - XW_DR0]);                                 \
+        if (s == KSL - 1) post();                                                                            \
+      }                                                                                                      \
+      if (MF_) {                                                                                             \
+        /* (XW_DMA_LAG > 0: waves 2, 3 issue their pieces that many k-steps behind waves 0, 1 -- an experiment against four simultaneous LDS-DMA  */ \
+        /* instructions on the CU's one address path; slower, see the define) */                             \
+        if (s < X::PPW + XW_DMA_LAG && more_ && !XW_ABLATE_DMA) {                                                              \
+          const int pi_ = s - ((wave & 2) ? XW_DMA_LAG : 0);                                                 \
+          if (pi_ >= 0 && pi_ < X::PPW) dma_piece(pi_, gnext_, (T_ + 1) & 1);                                \
           if (s == 0) {                                                                                      \
             dma_bias(nitem0_, (T_ + 1) & 3);                                                                 \
             if (walk_pos && !partials && wave == 0 && lane == 0 && ((T_ + 1) & 15) == 0) {                   \
@@ -296,28 +336,17 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
             }                                                                                                \
           }                                                                                                  \
         }                                                                                                    \
-        if (s == 0) {                                                                                        \
-          _Pragma("unroll") for (int j = 0; j < 16; j++) XA[j] = 0.f;                                        \
-        }                                                                                                    \
-        XA = x3_mfma(rH[s & 3], hhi[s], XA);                                                                 \
-      }                                                                                                      \
-      if (DR_) {                                                                                             \
-        if (s == 0) {   /* the drained tile's 16 bias values: read here, used one k-step later (no wait on the LDS in front of an fma) */ \
-          _Pragma("unroll") for (int q = 0; q < 4; q++) bq_[q] = *reinterpret_cast<const f32x4*>(ybias_ + 8 * q); \
-        }                                                                                                    \
-        if (s >= 1 && s < 5) {                                                                               \
-          const int q_ = (s - 1) & 3;                                                                        \
-          _Pragma("unroll") for (int j = 0; j < 4; j++) YA[4 * q_ + j] = fmaf(bq_[q_][j], rs, YA[4 * q_ + j]); \
-          if (KT > 0) tk_m = fmaxf(fmaxf(q_ == 0 ? YA[0] : tk_m, YA[4 * q_ + (q_ == 0 ? 1 : 0)]), fmaxf(fmaxf(YA[4 * q_ + 1], YA[4 * q_ + 2]), YA[4 * q_ + 3])); \
-        }                                                                                                    \
-        if (s >= 5 && s < 21) val(s - 5, YA[s - 5]);                                                         \
-        if (s == 21) post();                                                                                 \
-      }                                                                                                      \
-      if (MF_) {                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                   \
-        XA = x3_mfma(rH[s & 3], hlo[s], XA);                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                                                   \
         XA = x3_mfma(rL[s & 3], hhi[s], XA);                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                   \
+        /* behind MFMA 3: the fragments of k-step s + 3 (a four-deep ring); the first read of the NEXT tile (s = KSL - 3) sits behind the tile barrier */ \
+        if (s == KSL - 3 && !XW_ABLATE_BARRIER) {                                                            \
+          asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");                                        \
+          __syncthreads();                                                                                   \
+        }                                                                                                    \
+        const unsigned char* src_ = (s + 3 < KSL) ? tile_ : ntile_;                                          \
+        rH[(s + 3) & 3] = XW_LDS(src_ + XW_FH((s + 3) % KSL));                                               \
+        rL[(s + 3) & 3] = XW_LDS(src_ + XW_FL((s + 3) % KSL));                                               \
       }                                                                                                      \
       __builtin_amdgcn_sched_barrier(0);                                                                     \
     }
@@ -334,11 +363,11 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
     const int dit_ = DR_ ? tile_item0(T_ - 1) + 4 * lh : 0;                                                  \
     f32x4 bq_[4];                                                                                            \
     (void)tile_; (void)ntile_; (void)gnext_; (void)ybias_; (void)dit_; (void)bq_;                            \
-    _Pragma("unroll") for (int s = 0; s < 5; s++) XW_STEP(XA, YA, s)                                         \
+    _Pragma("unroll") for (int s = 0; s < XW_DR0 - 1; s++) XW_STEP(XA, YA, s)                                         \
     if (DR_ && KT > 0) {   /* the list vote: every value of the drained tile carries its bias by now */      \
       if (__any(tk_m > top.v[KTA - 1])) top_tile_slow<KTA>(top, YA, dit_);                                   \
     }                                                                                                        \
-    _Pragma("unroll") for (int s = 5; s < KSL; s++) XW_STEP(XA, YA, s)                                       \
+    _Pragma("unroll") for (int s = XW_DR0 - 1; s < KSL; s++) XW_STEP(XA, YA, s)                                       \
   } while (0)
 
     if (n_tiles > 0) {
@@ -347,7 +376,7 @@ __global__ __launch_bounds__(XW_THREADS, 1) void k_score_x3w(const float* __rest
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
 #pragma unroll
-      for (int s = 0; s < 2; s++) {   // first fragments of tile 0
+      for (int s = 0; s < 3; s++) {   // first fragments of tile 0
         rH[s] = XW_LDS(smem + XW_FH(s));
         rL[s] = XW_LDS(smem + XW_FL(s));
       }

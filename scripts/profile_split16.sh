@@ -32,13 +32,13 @@ for d in ("sp16_pmc1", "sp16_pmc2", "sp16_pmc3"):
         e = res.setdefault("pmc_per_launch", {}).setdefault(k, {"launches": n})
         e.update({c: x / n for c, x in v.items()})
 for k, v in res.get("pmc_per_launch", {}).items():
-    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and "SQ_BUSY_CYCLES" in v:
+    if "SQ_VALU_MFMA_BUSY_CYCLES" in v and v.get("GRBM_GUI_ACTIVE", 0) > 0:
         # MFMA-pipe busy: SQ_VALU_MFMA_BUSY_CYCLES counts cycles summed over the 1024 SIMDs; GRBM_GUI_ACTIVE is summed over the 8 XCDs (MI355X_MICROARCH.md)
         v["mfma_pipe_busy"] = v["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024 / (v["GRBM_GUI_ACTIVE"] / 8)
-    if "SQ_INSTS_MFMA" in v:
+    if v.get("SQ_INSTS_MFMA", 0) > 0:
         v["valu_per_mfma"] = (v["SQ_INSTS_VALU"] - v["SQ_INSTS_MFMA"]) / v["SQ_INSTS_MFMA"]
         v["lds_per_mfma"] = v["SQ_INSTS_LDS"] / v["SQ_INSTS_MFMA"]
-    if "TCC_HIT_sum" in v:
+    if v.get("TCC_HIT_sum", 0) + v.get("TCC_MISS_sum", 0) > 0:
         v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
         v["fetch_bytes"] = (v["TCC_EA0_RDREQ_sum"] - v["TCC_EA0_RDREQ_32B_sum"]) * 64 + v["TCC_EA0_RDREQ_32B_sum"] * 32
 json.dump(res, open("gpurun_out/%s_summary.json" % TAG, "w"), indent=1)
