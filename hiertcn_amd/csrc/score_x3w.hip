@@ -39,6 +39,10 @@
 #ifndef XW_DR0
 #define XW_DR0 16     // first k-step of the drain (16 values, one per k-step): the half of the phase that issues no LDS-DMA piece
 #endif                // (6 .. 16; -DXW_DR0=6 is the first form of the kernel: drain and DMA in the same k-steps)
+// Tried and dropped (same box, 153,600 rows x 1,000,000 items, scripts/build_alt.py): the tile through registers instead of LDS-DMA (16-byte global
+// loads, ds_write_b128 eight k-steps later, eight pieces in flight per wave): 696 ms against 361; waves 2, 3 issuing their DMA pieces eight k-steps
+// behind waves 0, 1 (XW_DMA_LAG): 398 against 388.  Kept: the drain in the DMA-free k-steps (386 -> 373), the ring three k-steps ahead behind MFMA 3
+// (369 -> 360), the paced walk (411 -> 386).
 // timing experiments (wrong results by design; scripts/build_alt.py builds them into a library of their own, profiles/r5_split16_d512_ablation.txt):
 // the kernel without its tile barrier / without its LDS-DMA stream / without its epilogue
 #ifndef XW_ABLATE_BARRIER
