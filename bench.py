@@ -382,6 +382,8 @@ def run_loop_leg(users=20000, lanes=32):
             os.environ.pop("HIERTCN_EVAL_SERIAL", None)
         out[form] = {"seconds": round(dt, 4), "loader_seconds": round(t_load, 4), "sessions_per_s": round(n_sessions / dt)}
     model.engine.close()
+    from hiertcn_amd.data_loader import active_packer
+    out["packer"] = active_packer()   # 'c' (csrc/packer.c) or 'python' (the NumPy form, ~10 x slower at 32 lanes): the figure depends on it
     return out
 
 

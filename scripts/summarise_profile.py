@@ -39,5 +39,36 @@ try:
 except Exception as e:  # noqa: BLE001
     res["bench_error"] = str(e)
 json.dump(res, open(os.path.join(out, "summary.json"), "w"), indent=1)
+
+# profiles/score_traffic.json (read by bench.py: roofline.traffic of the headline kernel and of the split16 kernel), stamped with the code it was
+# measured on: the sha-256 of the kernels' source files and the git head (passed in by the caller: the GPU box has no .git)
+import hashlib
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def sha16(*names):
+    h = hashlib.sha256()
+    for n in names:
+        h.update(open(os.path.join(ROOT, "hiertcn_amd", "csrc", n), "rb").read())
+    return h.hexdigest()[:16]
+
+
+tag = sys.argv[2] if len(sys.argv) > 2 else "r?"
+head = sys.argv[3] if len(sys.argv) > 3 else None
+bench = res.get("bench") or {}
+sections = {"headline": ("k_score_pipe<256, 14, 2, 3, true", ("score.hip", "score_geom.h", "score_lists.h"), (bench.get("roofline") or {}).get("scored_rows_per_launch")),
+            "exact": ("k_score_x3<256, 0, 0>", ("score_x3.hip", "score_x3.h"), ((bench.get("exact") or {}).get("rows_per_launch")))}
+traffic = {"git_head": head, "tag": tag}
+for sec, (needle, sources, rows) in sections.items():
+    hit = [(k, v) for k, v in res.get("pmc_per_launch", {}).items() if needle in k and "fetch_bytes_corrected" in v and "write_bytes" in v]
+    if not hit or not rows:
+        continue
+    k, v = max(hit, key=lambda kv: kv[1]["fetch_bytes_corrected"])
+    traffic[sec] = {"kernel": k, "rows_per_launch": int(rows), "fetch_bytes_per_launch": v["fetch_bytes_corrected"], "write_bytes_per_launch": v["write_bytes"],
+                    "l2_hit_rate": v.get("l2_hit_rate"), "source_sha16": sha16(*sources), "sources": list(sources),
+                    "source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, scripts/profile_round.sh %s) on `python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline "
+                              "--no-clock-probe` at git %s; FETCH_SIZE (KB) x 1024 x 2 (gfx950 correction, MI355X_MICROARCH.md HBM)" % (tag, head)}
+json.dump(traffic, open(os.path.join(out, "score_traffic.json"), "w"), indent=1)
+print(json.dumps(traffic, indent=1)[:1500])
 print(json.dumps(res.get("pmc_per_launch", {}), indent=1)[:3000])
 print(json.dumps(res.get("kernel_stats", []), indent=0)[:2500])
