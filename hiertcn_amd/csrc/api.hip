@@ -328,7 +328,9 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
   HIP_TRY(refresh_frag_major(m, st));
   HIP_TRY(refresh_lgru_split(m, st));
   if (h->train.enabled) HIP_TRY(train_fill_masters(m, h->train, w, st));
-  if (h->x.enabled) {   // exact / split numerics modes: fp32 copies in the same internal layouts (reduction index contiguous)
+  if (h->x.enabled && h->m.train_fp32) {
+    h->x.filled = h->x.enabled;   // fp32 training mode: the mode's tensors are the masters train_fill_masters has just written
+  } else if (h->x.enabled) {   // exact / split numerics modes: fp32 copies in the same internal layouts (reduction index contiguous)
     ExactDev& x = h->x;
     HIP_TRY(hipMemcpyAsync(x.emb, w->emb_kernel, (size_t)m.N * E * sizeof(float), hipMemcpyDeviceToDevice, st));
     HIP_TRY(hipMemsetAsync(x.emb, 0, (size_t)E * sizeof(float), st));   // row 0 = the null id (model.py:59)
@@ -358,7 +360,7 @@ int hiertcn_set_precision(hiertcn_handle_t h, int32_t precision) {
   if (need & ~h->x.enabled) {
     if (h->weights_set)
       return fail(HIERTCN_ERR_STATE, "the first hiertcn_set_precision to a mode must precede hiertcn_set_weights (its weight copies are filled there)");
-    if (h->train.enabled) return fail(HIERTCN_ERR_STATE, "the fp32 / split modes are evaluation only: this handle has training enabled");
+    if (h->train.enabled) return fail(HIERTCN_ERR_STATE, "a numerics mode must be chosen BEFORE hiertcn_train_enable (fp32: the fp32 training mode; split16: evaluation only)");
     ON_DEVICE(h);
     hiertcn_ctx* c = h;
     ModelDev& m = h->m;
@@ -684,9 +686,29 @@ int hiertcn_train_enable(hiertcn_handle_t h) {
   if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
   if (h->train.enabled) return HIERTCN_OK;
   if (h->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_train_enable must precede hiertcn_set_weights (the fp32 masters are filled there)");
-  if (h->x.enabled) return fail(HIERTCN_ERR_STATE, "this handle is in the fp32 evaluation mode (hiertcn_set_precision): training runs on 16-bit storage handles");
+  // fp32 TRAINING mode (ABI 10): hiertcn_set_precision(h, HIERTCN_PRECISION_FP32) before this call -- forward on the fp32 masters, materialised
+  // logits, every product of the backward an exact-fp32 GEMM (train.hip); model_hier with the TemporalConvNet low level, the reference's own
+  // batch sizes.  The split16 mode stays evaluation only.
+  const bool fp32 = h->precision == HIERTCN_PRECISION_FP32 && (h->x.enabled & X_FP32);
+  if (h->x.enabled && !fp32)
+    return fail(HIERTCN_ERR_STATE, "this handle is in the split16 evaluation mode (hiertcn_set_precision): training runs on 16-bit storage handles, or in the fp32 mode");
+  if (fp32 && (!h->m.hier || h->m.low_gru))
+    return fail(HIERTCN_ERR_STATE, "fp32 training mode: model_hier with the TemporalConvNet low level only (this handle: %s)", h->m.hier ? "HierGRU" : "single-level model_tcn");
   ON_DEVICE(h);
   HIP_TRY(train_enable(h->m, h->train));
+  if (fp32) {
+    // the fp32 masters have exact.hip's layouts: the mode's weight copies ARE the masters from now on (evaluation between steps reads what Adam wrote)
+    h->m.train_fp32 = 1;
+    ExactDev& x = h->x;
+    float* M = h->train.master();
+    x.emb = M + h->train.emb.off;
+    x.projT = M + h->train.projT.off;
+    for (int i = 0; i < h->m.n_blocks; i++) {
+      x.convT[i] = M + h->train.convT[i].off;
+      x.resT[i] = h->train.resT[i].n ? M + h->train.resT[i].off : nullptr;
+    }
+    x.outT = M + h->train.outT.off;
+  }
   return HIERTCN_OK;
 }
 

@@ -96,6 +96,7 @@ struct ModelDev {
   uint16_t* lgru_wgTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wgTF_lo[HIERTCN_MAX_LAYERS];
   uint16_t* lgru_wcTF_hi[HIERTCN_MAX_LAYERS]; uint16_t* lgru_wcTF_lo[HIERTCN_MAX_LAYERS];
   int* walk_pos;        // [8][32] ints, zeroed: per-XCD position words of the scoring kernel's item walk (null: every workgroup starts at stage 0)
+  int train_fp32;       // 1: the handle trains in the fp32 mode (hiertcn_set_precision(FP32) + hiertcn_train_enable): fp32 forward on the masters, materialised logits
   int* walk_pace;       // [8][XW_PACE_INTS] ints: per-XCD ticket + position slots of the workgroups that pace their item walk on each other (score_x3w.hip); null: no pacing
   hiertcn_tuning_t tune;   // launch selection + thresholds (include/hiertcn.h: hiertcn_set_tuning); the library reads no environment variable
 };

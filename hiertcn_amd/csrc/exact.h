@@ -32,6 +32,7 @@ struct XGemm {
   const float* res; int64_t ldres;    // XEPI_BLOCK: residual rows
   float* out; int64_t ldo;
   int epi;
+  float* out2;                        // XEPI_BLOCK, optional: relu(conv + bias) before the residual is added (ldo): the fp32 training step keeps it
 };
 
 hipError_t launch_xgemm(const XGemm& g, hipStream_t st);
@@ -40,6 +41,9 @@ size_t exact_tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);
 hipError_t launch_exact_tcn(const ModelDev& m, const ExactDev& x, const int32_t* ids, const float* sproj, int64_t n_sessions, int L, float* hidden,
                             void* workspace, hipStream_t st);
 int64_t exact_chunk_rows(int N);
+// pieces of the fp32 path the fp32 TRAINING step composes itself (train.hip): embedded rows; rank / ce / target of materialised logits (row stride ld)
+hipError_t launch_xembed_rows(const float* emb, const int32_t* ids, int64_t R, int E, int N, float* out, hipStream_t st);
+hipError_t launch_xrow_stats(const float* logits, int64_t ld, const int32_t* y, int64_t R, int N, int32_t* o_rank, float* o_ce, float* o_tgt, hipStream_t st);
 hipError_t launch_exact_logits(const ModelDev& m, const ExactDev& x, const float* hidden, int64_t R, float* logits, hipStream_t st);
 // score_x3.hip: the fused scoring kernel on split 16-bit operands (HIERTCN_PRECISION_SPLIT16); hidden fp32 [R][Clast]
 bool score_x3_supported(const ModelDev& m);

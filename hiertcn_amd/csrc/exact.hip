@@ -117,6 +117,7 @@ __global__ __launch_bounds__(256) void k_xgemm(const XGemm g) {
         v += bn;
         if (g.epi == XEPI_BLOCK) {   // customized_tcn_cell.py:117-126: relu(relu(conv1(x)) + res(x)), dropout rate 0
           v = fmaxf(v, 0.f);
+          if (g.out2) g.out2[m * g.ldo + n] = v;
           v = fmaxf(v + g.res[m * g.ldres + n], 0.f);
         }
         g.out[m * g.ldo + n] = v;
@@ -137,6 +138,7 @@ hipError_t launch_xgemm(const XGemm& g, hipStream_t st) {
     if (r0 > 0) {
       if (g.ids) p.ids = g.ids + r0; else p.A = g.A + r0 * g.lda;
       p.out = g.out + r0 * g.ldo;
+      if (g.out2) p.out2 = g.out2 + r0 * g.ldo;
       if (g.res) p.res = g.res + r0 * g.ldres;
       if (g.seq_init) p.seq_init = g.seq_init + (r0 / g.Lseq) * (int64_t)g.N;
     }
@@ -180,6 +182,13 @@ __global__ void k_xembed_rows(const float* __restrict__ emb, const int32_t* __re
   float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
   if (id > 0 && id < N) v = *reinterpret_cast<const float4*>(emb + (int64_t)id * E + c);
   *reinterpret_cast<float4*>(out + r * E + c) = v;
+}
+
+hipError_t launch_xembed_rows(const float* emb, const int32_t* ids, int64_t R, int E, int N, float* out, hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  const int64_t n4 = R * (E >> 2);
+  hipLaunchKernelGGL(k_xembed_rows, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, emb, ids, R, E, N, out);
+  return hipGetLastError();
 }
 
 hipError_t launch_xsession_pool(const ModelDev& m, const ExactDev& x, const int32_t* y, int64_t n_sessions, int L, float* pooled, hipStream_t st) {
@@ -391,6 +400,12 @@ hipError_t launch_exact_logits(const ModelDev& m, const ExactDev& x, const float
   g.A = hidden; g.lda = m.Clast; g.Wt = x.outT; g.taps = 1; g.Cin = m.Clast; g.M = R; g.N = m.N; g.bias = m.out_bias;
   g.out = logits; g.ldo = m.N; g.epi = XEPI_LINEAR;
   return launch_xgemm(g, st);
+}
+
+hipError_t launch_xrow_stats(const float* logits, int64_t ld, const int32_t* y, int64_t R, int N, int32_t* o_rank, float* o_ce, float* o_tgt, hipStream_t st) {
+  if (R <= 0) return hipSuccess;
+  hipLaunchKernelGGL(k_xrow_stats, dim3((unsigned)R), dim3(256), 0, st, logits, ld, y, N, o_rank, o_ce, o_tgt);
+  return hipGetLastError();
 }
 
 hipError_t launch_exact_score(const ModelDev& m, const ExactDev& x, const float* hidden, const int32_t* y, int64_t R, const hiertcn_score_out_t* out,

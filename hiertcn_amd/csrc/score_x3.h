@@ -40,3 +40,16 @@ __device__ __forceinline__ void x3_split8(const float* __restrict__ p, float sc,
   hi = make_uint4(h[0], h[1], h[2], h[3]);
   lo = make_uint4(l[0], l[1], l[2], l[3]);
 }
+
+// Paced item walk of the split-operand kernels (score_x3w.hip's file header has the why): the workgroups of an XCD class (blockIdx % 8) publish their
+// position in the table (in units of 64 KB of table rows) in a slot of ModelDev::walk_pace and the one that leads a NEIGHBOUR by more than
+// X3_PACE_WINDOW units sleeps, bounded.  Speed only: no result depends on it.
+#define X3_PACE_WINDOW 16   // units (1 MB of table) a workgroup may lead a neighbour of its XCD by
+#define X3_PACE_FAR 1024    // units beyond which another workgroup's position is not a neighbour's (another round of the grid elsewhere in the table)
+#define X3_PACE_TRIES 24    // bounded wait: sleeps of ~2 us
+__device__ __forceinline__ bool x3_pace_ahead(int mine, int other, int n_units) {
+  int lead = mine - other;   // cyclic, signed
+  lead += (lead < -(n_units >> 1)) ? n_units : 0;
+  lead -= (lead > (n_units >> 1)) ? n_units : 0;
+  return other >= 0 && lead > X3_PACE_WINDOW && lead <= X3_PACE_FAR;
+}

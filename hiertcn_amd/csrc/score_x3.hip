@@ -64,7 +64,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_x3(const float* __restr
                                                             const int32_t* __restrict__ row_map, const int32_t* __restrict__ n_rows_dev,
                                                             int part_stages, float* __restrict__ partials, int* __restrict__ walk_pos,
                                                             int32_t* __restrict__ o_topi, float* __restrict__ o_topv, int topk,
-                                                            float* __restrict__ logits, const float* __restrict__ tab_scale) {
+                                                            float* __restrict__ logits, const float* __restrict__ tab_scale, int* __restrict__ pace) {
   using X = X3Geom<CL>;
   using G = typename X::G;
   constexpr int KSL = X::KSL, CP = X::CP;
@@ -330,10 +330,42 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_x3(const float* __restr
     // Two LDS stages: the buffer of stage stg is refilled with stage stg + 2 between the two phases of an iteration (every wave has read its
     // last fragment of stage stg by then), and a wait + barrier behind the second phase makes sure that stage has landed before the next
     // iteration's first phase reads its first fragments across the tile boundary.
+    // Paced walk (score_x3.h): at the bench batch (38,400 workgroups, 150 rounds of the chip) the workgroups of an XCD drift apart over the launch --
+    // L2 hit rate 73.5 %, 3.19 TB per launch through the fabric (profiles/r5_c_summary.json); paced, one workgroup's miss is its neighbours' hit.
+    int* pace_slot = nullptr;
+    const int* pace_row = nullptr;
+    int pace_seen = -1;
+    if (KT == 0 && pace && !partials && n_stages > 4 * X3_PACE_WINDOW) {   // (not the list flavours: no register to spare at C = 256)
+      int* row = pace + (blockIdx.x & 7) * XW_PACE_INTS;
+      __shared__ int t_sh;
+      if (tid == 0) t_sh = atomicAdd(row + XW_PACE_SLOTS, 1);
+      __syncthreads();
+      const int ticket = __builtin_amdgcn_readfirstlane(t_sh);
+      pace_slot = row + (ticket & (XW_PACE_SLOTS - 1));
+      pace_row = row;
+    }
+    auto stage_abs = [&](int stg_rel) {
+      int stg = s0 + stg_rel;
+      stg -= (stg >= n_stages) ? n_stages : 0;
+      return stg;
+    };
     for (int stg = 0; stg + 1 < n_stages; stg++) {   // the last stage is peeled: no run-time "is there a next tile" inside the phases
       const int buf = stg & 1;
+      if (pace_slot && wave == 0) {   // publish every 4 stages; every 8 read the neighbours' slots (looked at behind the phase: the load's latency is covered)
+        if ((stg & 3) == 0 && lane == 0) __hip_atomic_store(pace_slot, stage_abs(stg), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((stg & 7) == 4) pace_seen = __hip_atomic_load(pace_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
       X3_PHASE(accB, accA, tile_ptr(buf, 1), tile_ptr(buf ^ 1, 0), sbias + (buf ^ 1) * SC_STAGE, true,
                (stg_lo + stg) * SC_STAGE + 4 * lh);         // MFMA (stg, ib1)   || drain (stg, ib0); accA <- bias (stg+1, ib0)
+      if (pace_slot && wave == 0 && (stg & 7) == 4) {
+        const int mine = stage_abs(stg);
+        int tries = 0;
+        while (__any(x3_pace_ahead(mine, pace_seen, n_stages)) && tries < X3_PACE_TRIES) {   // wave-uniform; the other waves wait at the barrier below
+          __builtin_amdgcn_s_sleep(64);
+          pace_seen = __hip_atomic_load(pace_row + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          tries++;
+        }
+      }
       __syncthreads();
       if (stg + 2 < n_stages) stage_issue(stg + 2, buf);
       X3_PHASE(accA, accB, tile_ptr(buf ^ 1, 0), tile_ptr(buf ^ 1, 1), sbias + (buf ^ 1) * SC_STAGE + 32, true,
@@ -348,6 +380,7 @@ __global__ __launch_bounds__(SC_THREADS, 2) void k_score_x3(const float* __restr
       X3_PHASE(accA, accB, tile_ptr(buf, 1), tile_ptr(buf, 1), sbias + buf * SC_STAGE + 32, false,
                (stg_lo + n_stages - 1) * SC_STAGE + 32 + 4 * lh);   // drain of the last tile only
     }
+    if (pace_slot && tid == 0) __hip_atomic_store(pace_slot, -1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // no longer a neighbour
 #undef X3_PHASE
 #undef X3_STEP
 #undef X3_STEP_END
@@ -541,7 +574,7 @@ static hipError_t launch_x3_c(const ModelDev& m, const ExactDev& x, const float*
     // small batches: SC_DYN_GRID workgroups dealt as (row tile, catalogue part) on the device from the live row count (score_geom.h)
     const int n_all = m.NP / SC_STAGE;
     hipLaunchKernelGGL(kern, dim3(SC_DYN_GRID), dim3(SC_THREADS), lds, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target,
-                       row_map, n_rows_dev, -SC_DYN_MAX_PARTS, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale);
+                       row_map, n_rows_dev, -SC_DYN_MAX_PARTS, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale, (int*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_score_merge(split_scratch, -SC_DYN_MAX_PARTS, R, row_map, n_rows_dev, y, out->target, out->rank, out->ce, st, SC_DYN_GRID, 256, n_all)) != hipSuccess) return e;
   } else if (KT == 0 && split_scratch && parts > 1 && out->rank && out->ce && out->target) {
@@ -549,17 +582,17 @@ static hipError_t launch_x3_c(const ModelDev& m, const ExactDev& x, const float*
     const int n_all = m.NP / SC_STAGE;
     const int part_stages = (n_all + parts - 1) / parts;
     hipLaunchKernelGGL(kern, dim3(blocks, parts), dim3(SC_THREADS), lds, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target,
-                       row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale);
+                       row_map, n_rows_dev, part_stages, split_scratch, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale, (int*)nullptr);
     if ((e = hipGetLastError()) != hipSuccess) return e;
     if ((e = launch_score_merge(split_scratch, parts, R, row_map, n_rows_dev, y, out->target, out->rank, out->ce, st)) != hipSuccess) return e;
   } else {
     hipLaunchKernelGGL(kern, dim3(blocks), dim3(SC_THREADS), lds, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target, row_map,
-                       n_rows_dev, 0, (float*)nullptr, walk, out->topk_idx, out->topk_val, (int)out->topk, (float*)nullptr, (const float*)x.outS_scale);
+                       n_rows_dev, 0, (float*)nullptr, walk, out->topk_idx, out->topk_val, (int)out->topk, (float*)nullptr, (const float*)x.outS_scale, m.walk_pace);
     if ((e = hipGetLastError()) != hipSuccess) return e;
   }
   if (!out->ce) return hipSuccess;
   hipLaunchKernelGGL(fix, dim3(blocks), dim3(SC_THREADS), X::LDS_BYTES, st, hidden, y, R, x.outS, m.out_bias, m.N, m.NP, out->rank, out->ce, out->target,
-                     row_map, n_rows_dev, 0, (float*)nullptr, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale);
+                     row_map, n_rows_dev, 0, (float*)nullptr, (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, (float*)nullptr, (const float*)x.outS_scale, (int*)nullptr);
   return hipGetLastError();
 }
 
@@ -573,7 +606,7 @@ static hipError_t launch_x3_k(const ModelDev& m, const ExactDev& x, const float*
     if (e != hipSuccess) return e;
     hipLaunchKernelGGL(kern, dim3((unsigned)((R + 255) / 256)), dim3(SC_THREADS), X::LDS_BYTES, st, hidden, (const int32_t*)nullptr, R, x.outS, m.out_bias,
                        m.N, m.NP, (int32_t*)nullptr, (float*)nullptr, (float*)nullptr, (const int32_t*)nullptr, (const int32_t*)nullptr, 0, (float*)nullptr,
-                       (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, logits, (const float*)x.outS_scale);
+                       (int*)nullptr, (int32_t*)nullptr, (float*)nullptr, 0, logits, (const float*)x.outS_scale, (int*)nullptr);
     return hipGetLastError();
   }
   if (out->topk <= 0) return launch_x3_c<CL, 0>(m, x, hidden, y, R, out, st, row_map, n_rows_dev, split_scratch);

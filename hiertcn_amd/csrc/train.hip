@@ -17,6 +17,7 @@
 #include <string.h>
 
 #include "train.h"
+#include "exact.h"
 #include "gemm.h"
 
 static thread_local char g_terr[512] = "";
@@ -661,6 +662,8 @@ struct TrainWs {
   int fused;      // 1: the G-free scoring backward (score_bwd.hip); 0: the d-logits chunks + two products per chunk (gemm.hip)
   int nc_stages;  // stages (of 64 items) per G chunk (item-chunked path: C_last = 512)
   int rc_stages;  // stages (of 64 rows) per G chunk (row-chunked path, score_grad.hip)
+  // fp32 training mode (m.train_fp32): fp32 activations a^0..a^nb, c^0..c^(nb-1), embedded inputs, materialised logits [R][NP], two shift scratches
+  size_t f_act[HIERTCN_MAX_BLOCKS + 1], f_c[HIERTCN_MAX_BLOCKS], f_emb, f_logits, f_sh[2];
 };
 
 // The scoring layer's backward: score_bwd.hip (no d-logits matrix, no host read-back) where the kernel is built for the
@@ -776,8 +779,79 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     w.lg_dac = take(cells * M * H * 4); w.lg_dag = take(cells * M * 2 * H * 4); w.lg_dhpart = take(M * H * 4);
     w.lg_dcat_c = take(M * Kmax * 4); w.lg_dcat_g = take(M * Kmax * 4); w.lg_din_up = take(M * H * 4);
   }
+  if (m.train_fp32) {
+    for (int i = 0; i <= m.n_blocks; i++) w.f_act[i] = take(R * C * 4);
+    for (int i = 0; i < m.n_blocks; i++) w.f_c[i] = take(R * C * 4);
+    w.f_emb = take(R * E * 4);
+    w.f_logits = take(R * (size_t)m.NP * 4);
+    w.f_sh[0] = take(R * C * 4); w.f_sh[1] = take(R * C * 4);
+  }
   w.total = off;
   return w;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// fp32 training mode (hiertcn_set_precision(FP32) before hiertcn_train_enable; model_hier with the TemporalConvNet low level): the step the
+// reference takes (model.py:135-141 on fp32 tensors, loss.py:20-21 on materialised logits) -- fp32 forward on the MASTERS (exact.hip's GEMM
+// kernel, activations kept in fp32), logits [R][NP] materialised once, d logits formed in place, every product of the backward an exact-fp32
+// MFMA GEMM (gemm.hip).  Sized for the reference's own batch (32 lanes x 10 x 20 x 20,778 items: 532 MB of logits -- what TensorFlow holds
+// too); the throughput path stays the 16-bit one.  Gradients agree with fp64 autograd on the UNROUNDED weights to ~1e-5 (tests/test_gpu_train_fp32.py).
+// ---------------------------------------------------------------------------------------------------------
+// g[r][n] = w_r (exp(z[r][n] - lse_r) - [n == y_r]) in place over [R][ld]; rows without a target have w = 0
+__global__ void k_xdlogits(float* __restrict__ z, int64_t ld, int64_t R, const int32_t* __restrict__ y, const float* __restrict__ w,
+                           const float* __restrict__ lse) {
+  const int64_t r = blockIdx.y;
+  const float wr = w[r], l = lse[r];
+  const int yr = y[r];
+  float* zr = z + r * ld;
+  for (int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; n < ld; n += (int64_t)gridDim.x * blockDim.x * 4) {
+    float4 v = *reinterpret_cast<float4*>(zr + n);
+    float o[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int j = 0; j < 4; j++) o[j] = wr == 0.f ? 0.f : wr * (expf(o[j] - l) - ((int)(n + j) == yr ? 1.f : 0.f));
+    *reinterpret_cast<float4*>(zr + n) = make_float4(o[0], o[1], o[2], o[3]);
+  }
+}
+// TemporalBlock backward, pointwise part, on fp32 activations: ds = da [out > 0], dc = ds [c > 0]
+__global__ void k_block_bwd_f32(const float* __restrict__ da, const float* __restrict__ aout, const float* __restrict__ cact, int64_t n,
+                                float* __restrict__ ds, float* __restrict__ dc) {
+  const int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (i >= n) return;
+  const float4 g = *reinterpret_cast<const float4*>(da + i), a = *reinterpret_cast<const float4*>(aout + i), c = *reinterpret_cast<const float4*>(cact + i);
+  const float4 s4 = make_float4(a.x > 0.f ? g.x : 0.f, a.y > 0.f ? g.y : 0.f, a.z > 0.f ? g.z : 0.f, a.w > 0.f ? g.w : 0.f);
+  *reinterpret_cast<float4*>(ds + i) = s4;
+  *reinterpret_cast<float4*>(dc + i) = make_float4(c.x > 0.f ? s4.x : 0.f, c.y > 0.f ? s4.y : 0.f, c.z > 0.f ? s4.z : 0.f, c.w > 0.f ? s4.w : 0.f);
+}
+// dst[r] = src[r - shift] inside sequences of L rows (zero where r - shift leaves the sequence); shift > 0: the conv tap's delayed input
+// (customized_tcn_cell.py:46-49), shift < 0: the gradient that flows back to an earlier step
+__global__ void k_shift_rows_f32(const float* __restrict__ src, int64_t R, int C, int L, int shift, float* __restrict__ dst) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c4 = C >> 2;
+  if (i >= R * c4) return;
+  const int64_t r = i / c4;
+  const int c = (int)(i - r * c4) * 4;
+  const int t = (int)(r % L) - shift;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (t >= 0 && t < L) v = *reinterpret_cast<const float4*>(src + (r - shift) * C + c);
+  *reinterpret_cast<float4*>(dst + r * C + c) = v;
+}
+static hipError_t shift_rows_f32(const float* src, int64_t R, int C, int L, int shift, float* dst, hipStream_t st) {
+  hipLaunchKernelGGL(k_shift_rows_f32, dim3((unsigned)((R * (C >> 2) + 255) / 256)), dim3(256), 0, st, src, R, C, L, shift, dst);
+  return hipGetLastError();
+}
+// the masters in exact.hip's terms: same layouts ([N][E], [Eout][Ein], [tap][Cout][Cin], [Cout][Cin], [NP][C]), so the fp32 kernels read them as they are
+static ExactDev fp32_master_view(const ModelDev& m, const TrainCtx& t) {
+  ExactDev x;
+  memset(&x, 0, sizeof(x));
+  float* M = t.master();
+  x.emb = M + t.emb.off;
+  x.projT = m.hier ? M + t.projT.off : nullptr;
+  for (int i = 0; i < m.n_blocks; i++) {
+    x.convT[i] = M + t.convT[i].off;
+    x.resT[i] = t.resT[i].n ? M + t.resT[i].off : nullptr;
+  }
+  x.outT = M + t.outT.off;
+  return x;
 }
 
 size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L) { return train_ws(m, B, S, L).total; }
@@ -812,8 +886,42 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   uint16_t* a0 = m.hier ? BF(w.act[1]) : a_emb;   // input of block 0: the projection's output, or the embedded ids themselves
   // equal widths and L <= 32: the fused low-level kernel of the evaluation path, writing the kept activations on its way
   // (bitwise the layer-at-a-time kernels' values; HIERTCN_FORCE_LAYERED=1 takes those instead)
-  const bool fused_fw = tcn_fused_applies(m, L);
-  if (do_begin) {
+  const bool F = m.train_fp32 != 0;   // the fp32 training mode (see fp32_master_view above)
+  if (F && (!m.hier || m.low_gru)) return tfail("fp32 training mode: model_hier with the TemporalConvNet low level only");
+  if (F && (size_t)R * (size_t)m.NP * 4 > ((size_t)8 << 30))
+    return tfail("fp32 training mode: %lld rows x %d items of materialised fp32 logits exceed 8 GiB -- it is built for the reference's own batch; "
+                 "train larger batches on the 16-bit storage path", (long long)R, m.NP);
+  const bool fused_fw = !F && tcn_fused_applies(m, L);
+  if (do_begin && F) {
+    // ---- forward on the masters, everything kept in fp32 (model_hier.py:39-93 as exact.hip computes it) ----
+    const ExactDev xv = fp32_master_view(m, t);
+    T_HIP(launch_xsession_pool(m, xv, y, n_sess, L, pooled, st));
+    T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
+    T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, F32(w.f_emb), st));
+    {
+      XGemm g = {};
+      g.A = F32(w.f_emb); g.lda = E; g.Wt = xv.projT; g.taps = 1; g.Cin = E; g.M = R; g.N = E;
+      g.seq_init = sproj; g.Lseq = L; g.out = F32(w.f_act[0]); g.ldo = E; g.epi = XEPI_LINEAR;
+      T_HIP(launch_xgemm(g, st));
+    }
+    for (int i = 0, cin = E; i < nb; cin = m.C[i], i++) {
+      const int cout = m.C[i];
+      const float* res = F32(w.f_act[i]);
+      int64_t ldres = cin;
+      if (cin != cout) {   // customized_tcn_cell.py:102-106: a biased Dense on the residual path
+        XGemm r = {};
+        r.A = F32(w.f_act[i]); r.lda = cin; r.Wt = xv.resT[i]; r.taps = 1; r.Cin = cin; r.M = R; r.N = cout; r.bias = m.res_bias[i];
+        r.out = F32(w.f_sh[0]); r.ldo = cout; r.epi = XEPI_LINEAR;
+        T_HIP(launch_xgemm(r, st));
+        res = F32(w.f_sh[0]); ldres = cout;
+      }
+      XGemm g = {};
+      g.A = F32(w.f_act[i]); g.lda = cin; g.Wt = xv.convT[i]; g.taps = m.K; g.dil = 1 << i; g.L = L; g.Cin = cin; g.M = R; g.N = cout;
+      g.bias = m.conv_bias[i]; g.res = res; g.ldres = ldres; g.out = F32(w.f_act[i + 1]); g.out2 = F32(w.f_c[i]); g.ldo = cout; g.epi = XEPI_BLOCK;
+      T_HIP(launch_xgemm(g, st));
+    }
+  }
+  if (do_begin && !F) {
   if (!m.low_gru && !fused_fw) T_HIP(launch_embed_rows(m, x, R, a_emb, st));
   if (m.hier) {
     T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
@@ -848,7 +956,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     }
     T_HIP(launch_tcn_forward(m, x, m.hier ? sproj : nullptr, n_sess, L, a_of(nb), nullptr, st, &sv));
   }
-  for (int i = 0, cin = E; i < nb && !m.low_gru && !fused_fw && do_begin; cin = m.C[i], i++) {
+  for (int i = 0, cin = E; i < nb && !m.low_gru && !fused_fw && do_begin && !F; cin = m.C[i], i++) {
     LayerArgs a = {};
     a.in = a_of(i);
     a.c_out = BF(w.act[2 + 2 * i]);
@@ -866,7 +974,33 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   int32_t* rmap = reinterpret_cast<int32_t*>(ws + w.map);
   int32_t* nvalid_d = reinterpret_cast<int32_t*>(ws + w.nvalid);
   float* dH = F32(w.dA);   // [R][C_last] fp32
-  if (do_begin) {
+  if (do_begin && F) {
+    // ---- scoring layer on MATERIALISED fp32 logits (model_tcn.py:41, model.py:105, loss.py:20-21,179), pad columns carry bias -inf ----
+    const ExactDev xv = fp32_master_view(m, t);
+    const float* hid32 = F32(w.f_act[nb]);
+    float* Z = F32(w.f_logits);
+    const int64_t ldz = m.NP;
+    {
+      XGemm g = {};
+      g.A = hid32; g.lda = CL; g.Wt = xv.outT; g.taps = 1; g.Cin = CL; g.M = R; g.N = m.NP; g.bias = m.out_bias; g.out = Z; g.ldo = ldz; g.epi = XEPI_LINEAR;
+      T_HIP(launch_xgemm(g, st));
+    }
+    T_HIP(launch_xrow_stats(Z, ldz, y, R, m.N, so.rank, so.ce, so.target, st));
+    if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
+    float* users = F32(w.users);
+    T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
+    hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
+    hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce,
+                       so.target, R, S * L, F32(w.w), F32(w.lse));
+    T_HIP(hipGetLastError());
+    // d loss / d logits in place; then the three products: d Wo^T [NP][C] = g^T . h, d bo = column sums, d h = g . Wo^T
+    hipLaunchKernelGGL(k_xdlogits, dim3(8, (unsigned)R), dim3(256), 0, st, Z, ldz, R, y, F32(w.w), F32(w.lse));
+    T_HIP(hipGetLastError());
+    T_HIP(gemm32_tn(Z, ldz, hid32, CL, G + t.outT.off, CL, m.NP, CL, (int)R, 0.f, F32(w.splitk), w.splitk_floats, st));
+    T_HIP(colsum_f32(Z, R, ldz, m.NP, G + t.out_bias.off, st));
+    T_HIP(gemm32_nn(Z, ldz, xv.outT, CL, dH, CL, (int)R, CL, m.NP, 0.f, st));
+  }
+  if (do_begin && !F) {
   T_HIP(launch_compact_rows(y, R, rmap, nvalid_d, reinterpret_cast<int32_t*>(ws + w.cscratch), st));
   T_HIP(hipMemsetAsync(ws + w.rank, 0, w.lse - w.rank, st));   // rank, ce, target: three consecutive slices of the workspace (train_ws), one fill
   float* users = F32(w.users);
@@ -1079,7 +1213,45 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     }
     da = du;
   }
-  for (int i = nb - 1; i >= 0 && !m.low_gru; i--) {
+  for (int i = nb - 1; i >= 0 && F; i--) {   // fp32 mode: the same block backward on fp32 activations, every product an exact-fp32 GEMM
+    const ExactDev xv = fp32_master_view(m, t);
+    const int cin = (i == 0) ? E : m.C[i - 1], cout = m.C[i];
+    const float* a_in = F32(w.f_act[i]);
+    const int dil = 1 << i;
+    const int64_t nOut = R * cout;
+    float* dc = F32(w.f_sh[0]);
+    float* sh = F32(w.f_sh[1]);
+    hipLaunchKernelGGL(k_block_bwd_f32, dim3((unsigned)((nOut / 4 + 255) / 256)), dim3(256), 0, st, da, F32(w.f_act[i + 1]), F32(w.f_c[i]), nOut, dsf, dc);
+    T_HIP(hipGetLastError());
+    T_HIP(colsum_f32(dc, R, cout, cout, G + t.conv_bias[i].off, st));
+    if (t.resT[i].n) {
+      T_HIP(colsum_f32(dsf, R, cout, cout, G + t.res_bias[i].off, st));
+      T_HIP(gemm32_tn(dsf, cout, a_in, cin, G + t.resT[i].off, cin, cout, cin, (int)R, 0.f, F32(w.splitk), w.splitk_floats, st));   // d resT[Cout][Cin] = ds^T . a_in
+      T_HIP(gemm32_nn(dsf, cout, xv.resT[i], cin, dprev, cin, (int)R, cin, cout, 0.f, st));                                       // d a_in = ds . resT
+    } else {
+      T_HIP(hipMemcpyAsync(dprev, dsf, (size_t)nOut * 4, hipMemcpyDeviceToDevice, st));   // identity residual
+    }
+    for (int j = 0; j < m.K; j++) {   // tap j reads a_in[t - s_j], s_j = (K-1-j) dil (customized_tcn_cell.py:46-49)
+      const int sj = (m.K - 1 - j) * dil;
+      if (sj >= L) continue;   // the tap only ever saw the zero padding
+      const float* a_sh = a_in;
+      const float* dc_sh = dc;
+      if (sj > 0) {
+        T_HIP(shift_rows_f32(a_in, R, cin, L, sj, sh, st));
+        a_sh = sh;
+      }
+      // d W_j[Cout][Cin] = sum_t dc[t]^T . a_in[t - s_j]
+      T_HIP(gemm32_tn(dc, cout, a_sh, cin, G + t.convT[i].off + (size_t)j * cout * cin, cin, cout, cin, (int)R, 0.f, F32(w.splitk), w.splitk_floats, st));
+      if (sj > 0) {
+        T_HIP(shift_rows_f32(dc, R, cout, L, -sj, sh, st));
+        dc_sh = sh;
+      }
+      // d a_in[tau] += dc[tau + s_j] . W_j      (W_j = master [Cout][Cin]: the k-major operand as it is)
+      T_HIP(gemm32_nn(dc_sh, cout, xv.convT[i] + (size_t)j * cout * cin, cin, dprev, cin, (int)R, cin, cout, 1.f, st));
+    }
+    float* tmp = da; da = dprev; dprev = tmp;
+  }
+  for (int i = nb - 1; i >= 0 && !m.low_gru && !F; i--) {
     const int cin = (i == 0) ? E : m.C[i - 1], cout = m.C[i];
     const uint16_t* a_in = a_of(i);
     const uint16_t* c_act = BF(w.act[2 + 2 * i]);
@@ -1127,11 +1299,17 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
 #define F32(o) reinterpret_cast<float*>(ws + (o))
 #define BF(o) reinterpret_cast<uint16_t*>(ws + (o))
   // ================= projection u = e . Wp[:E] + sproj (model_hier.py:54-55 -> model_tcn.py:35) ============
+  if (F) {
+    const ExactDev xv = fp32_master_view(m, t);
+    T_HIP(gemm32_tn(da, E, F32(w.f_emb), E, G + t.projT.off, E, E, E, (int)R, 0.f, F32(w.splitk), w.splitk_floats, st));   // d projT[Eout][Ein] = du^T . e
+    T_HIP(gemm32_nn(da, E, xv.projT, E, dprev, E, (int)R, E, E, 0.f, st));                                                  // d e = du . projT
+  } else {
   T_HIP(cast_bf16(da, dub, nRC, 0, st));
   // d projT[Eout][Ein] = du^T[Eout x R] . e[R][Ein]   == col-major [Ein x Eout] = e^T[Ein x R] . (du^T)^T
   T_HIP(gemm16_tn(dub, E, a_emb, E, G + t.projT.off, 0, E, E, R, 1, nullptr, 0, 0.f, F32(w.splitk), w.splitk_floats, st));
   // d e[R][Ein] = du[R][Eout] . projT[Eout][Ein]   == col-major [Ein x R] = projT(col-major [Ein x Eout]) . du^T[Eout x R]
   T_HIP(gemm16_nt(dub, E, t.projD, E, dprev, E, R, E, E, 1, nullptr, 0, 0.f, st));
+  }
   hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, dprev, R, E, m.N);
   T_HIP(hipGetLastError());
   // d sproj, laid out [B][S+1][E] like the state history (slot S = 0)

@@ -268,15 +268,21 @@ def test_exact_mode_contract_errors():
     from hiertcn_amd._lib import HierTCNError, PRECISION_FP32
     args = small_args(N=300, d=64, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
     with pytest.raises(HierTCNError, match="EVALUATION"):
-        Engine(args, hier=True, dtype="fp32", train=True)
+        Engine(args, hier=True, dtype="split16", train=True)
+    gru = small_args(N=300, d=64, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
+    gru.model_low_type = "gru"
+    with pytest.raises(HierTCNError, match="fp32 training mode"):    # (fp32 TRAINS since ABI 10 -- model_hier with the TemporalConvNet low level: tests/test_gpu_train_fp32.py)
+        Engine(gru, hier=True, dtype="fp32", train=True)
     eng = Engine(args, hier=True)                     # a 16-bit handle whose weights are set cannot be switched: no fp32 copies
     eng.set_weights(make_params(args))
     with pytest.raises(HierTCNError, match="precede hiertcn_set_weights"):
         eng._ck(eng.lib.hiertcn_set_precision(eng._h, PRECISION_FP32))
     eng.close()
+    sp = Engine(args, hier=True, dtype="split16")
+    with pytest.raises(HierTCNError, match="split16 evaluation mode"):
+        sp._ck(sp.lib.hiertcn_train_enable(sp._h))
+    sp.close()
     ex = Engine(args, hier=True, dtype="fp32")
-    with pytest.raises(HierTCNError, match="fp32 evaluation mode"):
-        ex._ck(ex.lib.hiertcn_train_enable(ex._h))
     with pytest.raises(HierTCNError):
         ex.set_precision("fp16")                      # this handle offers fp32 and bf16
     ex.close()

@@ -1,0 +1,191 @@
+"""-m gpu: the fp32 TRAINING mode (Engine(dtype="fp32", train=True) = hiertcn_set_precision(FP32) + hiertcn_train_enable; csrc/train.hip): the step the
+reference takes (model.py:135-141 on fp32 tensors, loss.py:20-21 on materialised logits) -- fp32 forward on the masters, logits materialised once,
+every product of the backward an exact-fp32 GEMM.  Held here: loss, carried state and EVERY gradient against fp64 autograd on the UNROUNDED weights
+(the 16-bit training path is checked against autograd on the bf16-rounded weights at 2e-2: tests/test_gpu_train.py); TF-form Adam on those
+gradients; a short training run whose loss trajectory follows an fp64 torch run of the same steps; the mode's contract (batch bound, model kinds)."""
+import numpy as np
+import pytest
+
+from tests.gpu_common import make_batch, make_params, small_args
+
+torch = pytest.importorskip("torch")
+F = torch.nn.functional
+pytestmark = pytest.mark.gpu
+
+dev = lambda a: torch.as_tensor(np.ascontiguousarray(a)).cuda().contiguous()  # noqa: E731
+
+
+def torch_loss64(args, P, x, y, mask, state):
+    """model_hier.py:39-93 + model.py:102-117 in fp64, nothing rounded (tests/test_gpu_train.py's torch_loss without its bf16 roundings)."""
+    B, S, L = x.shape
+    H, nl, N = args.hidden_dim, args.num_layer, args.item_num
+    st = torch.as_tensor(state, dtype=torch.float64)
+    E = P["hier/emb/kernel"]
+    xt, yt = torch.as_tensor(x, dtype=torch.int64), torch.as_tensor(y, dtype=torch.int64)
+    mk = torch.as_tensor(mask, dtype=torch.float64)
+    logits = []
+    for s in range(S):
+        e = F.embedding(xt[:, s], E) * (xt[:, s] > 0)[..., None]
+        a = (torch.cat([e, st[:, None, :].expand(-1, L, -1)], -1) @ P["hier/tcn/emb/kernel"]).transpose(1, 2)
+        for i in range(len(args.tcn_channel)):
+            pre = f"hier/tcn/temporal_conv_net/tblock_{i}"
+            W = P[f"{pre}/conv1/kernel"].permute(2, 1, 0)
+            d, K = 2 ** i, W.shape[-1]
+            c = torch.relu(F.conv1d(F.pad(a, ((K - 1) * d, 0)), W, P[f"{pre}/conv1/bias"], dilation=d))
+            res = a
+            if f"{pre}/dense/kernel" in P:
+                res = (a.transpose(1, 2) @ P[f"{pre}/dense/kernel"] + P[f"{pre}/dense/bias"]).transpose(1, 2)
+            a = torch.relu(c + res)
+        logits.append(a.transpose(1, 2) @ P["hier/tcn/dense/kernel"] + P["hier/tcn/dense/bias"])
+        ey = F.embedding(yt[:, s], E) * (yt[:, s] > 0)[..., None]
+        cur = ey.sum(1) / (yt[:, s] > 0).sum(1, keepdim=True) + P["hier/emb/bias"]
+        new = []
+        for l in range(nl):
+            pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
+            h = st[:, l * H:(l + 1) * H]
+            g = torch.sigmoid(torch.cat([cur, h], 1) @ P[f"{pre}/gates/kernel"] + P[f"{pre}/gates/bias"])
+            r, uu = g.chunk(2, 1)
+            c = torch.tanh(torch.cat([cur, r * h], 1) @ P[f"{pre}/candidate/kernel"] + P[f"{pre}/candidate/bias"])
+            cur = uu * h + (1 - uu) * c
+            new.append(cur)
+        st = torch.cat(new, 1) * mk[:, s:s + 1]
+    z = torch.cat(logits, 1)
+    yy = yt.reshape(B, S * L)
+    m = (yy > 0).double()
+    z = z * m[..., None]
+    ce = F.cross_entropy(z.reshape(-1, N), yy.reshape(-1), reduction="none").reshape(B, -1) * m
+    act = m.sum(1)
+    users = (act > 0).double().sum()
+    return ((ce.sum(1) / (act + 1e-6)).sum() / users), st
+
+
+def _trained_scale(p, args):
+    """activations and logits of order 1-10 instead of glorot's 0.05: the regime in which 16-bit storage is visibly off"""
+    q = {k: np.array(v, np.float32) for k, v in p.items()}
+    for k in q:
+        if k.endswith("/emb/kernel") and q[k].shape[0] == int(args.item_num):
+            q[k] *= 3.0
+        if "/conv1/kernel" in k:
+            q[k] *= 1.6
+        if k.endswith("tcn/dense/kernel"):
+            q[k] *= 20.0
+    return q
+
+
+# (d, N, H, channels, K, (B, S, L)); the last: the reference's own batch shape (32 lanes x 10 slots x 20 steps) on a 3,000-item catalogue
+SHAPES = [(64, 700, 32, [64, 64], 5, (7, 4, 9)), (128, 1500, 128, [128, 128], 5, (9, 3, 12)), (64, 900, 32, [64, 128, 128], 3, (6, 3, 20)),
+          (256, 3000, 256, [256, 256], 5, (32, 10, 20))]
+
+
+@pytest.fixture(scope="module", params=SHAPES, ids=["d64", "d128_h128", "d64_downsample_3blocks", "reference_batch_d256"])
+def stepped(request):
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine, metrics_dict
+    d, N, H, ch, K, (B, S, L) = request.param
+    args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=H, num_layer=2, tcn_channel=ch, kernel_size=K, max_activity_len=L, max_session_num=S, batch_size=B)
+    p = _trained_scale(make_params(args), args)
+    eng = Engine(args, hier=True, train=True, dtype="fp32")
+    eng.set_weights(p)
+    rng = np.random.default_rng(d + N)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, H * 2))).astype(np.float32)
+    out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    torch.cuda.synchronize()
+    grads = eng.export("grads")
+    loss = metrics_dict(out["metrics8"])["loss"]
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in p.items()}
+    ref_loss, ref_state = torch_loss64(args, P, x, y, mask, st0)
+    ref_loss.backward()
+    ref = {k: v.grad.numpy() for k, v in P.items()}
+    yield dict(args=args, p=p, eng=eng, grads=grads, ref=ref, loss=loss, ref_loss=float(ref_loss.detach()), state=out["state"].cpu().numpy(),
+               ref_state=ref_state.detach().numpy(), batch=(x, y, mask, st0))
+    eng.close()
+
+
+def test_loss_and_state_are_fp32_grade(stepped):
+    t = stepped
+    assert abs(t["loss"] - t["ref_loss"]) < 2e-5 * max(1.0, abs(t["ref_loss"])), (t["loss"], t["ref_loss"])
+    assert np.abs(t["state"] - t["ref_state"]).max() < 1e-5
+
+
+def test_every_gradient_matches_fp64_autograd_on_the_unrounded_weights(stepped):
+    t = stepped
+    assert set(t["grads"]) == set(t["ref"])
+    report = []
+    for k in sorted(t["ref"]):
+        g, r = t["grads"][k].astype(np.float64), t["ref"][k]
+        assert g.shape == r.shape, k
+        nr = np.linalg.norm(r)
+        report.append((k, np.linalg.norm(g - r) / max(nr, 1e-30), nr))
+    bad = [(k, rel) for k, rel, nr in report if nr > 1e-12 and rel > 1e-4]
+    assert not bad, "\n".join(f"{k}: rel {rel:.3e}" for k, rel in bad) + "\nall:\n" + "\n".join(f"{k}: rel {rel:.3e} |ref| {nr:.3e}" for k, rel, nr in report)
+    print("max relative gradient error %.2e (%s)" % max((rel, k) for k, rel, nr in report if nr > 1e-12))
+    assert not t["grads"]["hier/emb/kernel"][0].any()      # the null id never receives a gradient (model.py:59)
+
+
+def test_a_training_run_follows_the_fp64_trajectory():
+    """Eight Adam steps (TF form, lr 1e-3) on one batch stream: the device's loss after every step against an fp64 torch run of the same steps that starts
+    from the same fp32 weights -- the trajectory a TF run of the reference graph would take, to fp32 grade.  The 16-bit training path on the same stream
+    is recorded beside it (it follows to ~1e-3)."""
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine, metrics_dict
+    d, N, H, B, S, L = 64, 900, 32, 8, 3, 12
+    args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=H, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L, max_session_num=S, batch_size=B)
+    p = _trained_scale(make_params(args), args)
+    rng = np.random.default_rng(5)
+    batches = [make_batch(rng, B, S, L, N) for _ in range(8)]
+    st0 = np.zeros((B, 2 * H), np.float32)
+    lr, b1, b2, eps = 1e-3, 0.9, 0.999, 1e-8
+    # fp64 reference: TF-form Adam (model.py:139: lr_t = lr sqrt(1 - b2^t) / (1 - b1^t); theta -= lr_t m / (sqrt(v) + eps))
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in p.items()}
+    m1 = {k: torch.zeros_like(v) for k, v in P.items()}
+    m2 = {k: torch.zeros_like(v) for k, v in P.items()}
+    ref_losses, state = [], st0.astype(np.float64)
+    for step, (x, y, mask) in enumerate(batches, 1):
+        for v in P.values():
+            v.grad = None
+        loss, st = torch_loss64(args, P, x, y, mask, state)
+        loss.backward()
+        ref_losses.append(float(loss.detach()))
+        state = st.detach().numpy()
+        lr_t = lr * np.sqrt(1 - b2 ** step) / (1 - b1 ** step)
+        with torch.no_grad():
+            for k, v in P.items():
+                g = v.grad if v.grad is not None else torch.zeros_like(v)
+                m1[k] = b1 * m1[k] + (1 - b1) * g
+                m2[k] = b2 * m2[k] + (1 - b2) * g * g
+                v -= lr_t * m1[k] / (m2[k].sqrt() + eps)
+    got = {}
+    for mode in ("fp32", "bf16"):
+        eng = Engine(args, hier=True, train=True, dtype=mode)
+        eng.set_weights(p)
+        st = dev(st0)
+        losses = []
+        for x, y, mask in batches:
+            out = eng.train_forward_backward(dev(x), dev(y), dev(mask), st)
+            eng.adam_step(lr)
+            st = out["state"]
+            losses.append(metrics_dict(out["metrics8"])["loss"])
+        got[mode] = np.array(losses)
+        eng.close()
+    ref = np.array(ref_losses)
+    err32, err16 = np.abs(got["fp32"] - ref).max(), np.abs(got["bf16"] - ref).max()
+    print("loss trajectory (8 steps): fp64 reference %s; fp32 mode max |diff| %.2e; 16-bit path max |diff| %.2e" % (np.round(ref, 5), err32, err16))
+    assert ref[-1] < ref[0]                     # it trains
+    assert err32 < 5e-5 * max(1.0, ref.max()), (got["fp32"], ref)
+    assert err32 < err16                          # ... and closer than the 16-bit path
+
+
+def test_fp32_training_mode_contract():
+    from hiertcn_amd._lib import HierTCNError
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine
+    big = hier_tcn_args(item_num=300_000, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=3, max_activity_len=30, max_session_num=20,
+                        batch_size=16)
+    eng = Engine(big, hier=True, train=True, dtype="fp32")
+    eng.set_weights(make_params(big))
+    rng = np.random.default_rng(0)
+    x, y, mask = make_batch(rng, 16, 20, 30, 300_000)           # 9,600 rows x 300,032 items x 4 B = 11.5 GB of logits: past the mode's bound
+    with pytest.raises(HierTCNError, match="exceed 8 GiB"):
+        eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(np.zeros((16, 64), np.float32)))
+    eng.close()
