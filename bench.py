@@ -310,9 +310,12 @@ def reference_batch_leg(n_batches=100):
     xs, ys, ms = (torch.as_tensor(v).cuda().contiguous() for v in (x.astype(np.int32), ids.astype(np.int32), mask))
     out = {"what": "32 lanes x 10 slots x <= 20 steps per batch (the reference's batch_size / max_session_num / max_activity_len defaults), XING catalogue N = 20,778, "
                    "two layers, ragged sessions, ids resident; ms per batch = mean over %d back-to-back batches" % n_batches}
-    for name, low, d, train in (("hiertcn_d256", "tcn", 256, True), ("hiergru_d128", "gru", 128, True), ("hiergru_d256", "gru", 256, True)):
+    # (hiertcn_d256_fp32: the same model in the fp32 TRAINING mode -- fp32 forward on the masters, 532 MB of materialised logits per step, every product of
+    #  the backward an exact-fp32 GEMM: the configuration in which a TF training trajectory can be followed to fp32 grade; evaluation = the fp32 mode)
+    for name, low, d, train, dtype in (("hiertcn_d256", "tcn", 256, True, None), ("hiergru_d128", "gru", 128, True, None), ("hiergru_d256", "gru", 256, True, None),
+                                       ("hiertcn_d256_fp32", "tcn", 256, True, "fp32")):
         args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B, model_low_type=low)
-        eng = Engine(args, hier=True, train=train)
+        eng = Engine(args, hier=True, train=train, dtype=dtype)
         eng.set_weights(init_params(args, seed=2))
         st = torch.zeros((B, eng.HT), dtype=torch.float32, device="cuda")
         st2 = torch.empty_like(st)

@@ -189,3 +189,43 @@ def test_fp32_training_mode_contract():
     with pytest.raises(HierTCNError, match="exceed 8 GiB"):
         eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(np.zeros((16, 64), np.float32)))
     eng.close()
+
+
+def test_run_hier_trains_in_the_fp32_mode(tmp_path):
+    """`run_xing --train --storage_dtype fp32` end to end on the synthetic XING CSV: three epochs of six batches through run_hier (pipelined train loop,
+    TF-form Adam, checkpoint, evaluation between the epochs in the fp32 mode ON THE MASTERS the optimiser has just written): the loss falls, the
+    checkpoint restores into a fresh fp32 evaluation model that evaluates identically."""
+    import os
+    from hiertcn_amd import checkpoint
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.data_loader import Dataloader_hier_model_xing
+    from hiertcn_amd.data_prepare import load_xing
+    from hiertcn_amd.model import HierTCNModel
+    from hiertcn_amd.run_hier_xing import evaluate_hier, run_hier
+    data = load_xing(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interactions_synth.csv"))
+    n_items = int(data[1][:, 1].max()) + 1
+    args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=5, batch_size=4, max_session_num=3,
+                         max_activity_len=6, storage_dtype="fp32")
+    args.log_path, args.save_path = str(tmp_path) + "/log/", str(tmp_path) + "/model/"
+    args.train, args.validate, args.test, args.save = True, False, True, True
+    args.epoch_max, args.epoch_batches_train, args.save_epoch, args.test_epoch, args.learning_rate = 2, 6, 2, 2, 1e-2
+    mk = lambda split: Dataloader_hier_model_xing(args, split, data=data)  # noqa: E731
+    model = HierTCNModel(args)
+    assert model.engine.exact and model.engine.train and model.engine.mode == "fp32"
+    st0 = np.zeros((4, 64))
+    os.makedirs(args.log_path + "before/")
+    before, *_ = evaluate_hier(args, mk("test"), st0, model, prefix="before")
+    run_hier(args, mk("train"), mk("validate"), mk("test"), sess=model)
+    txt = open(args.log_path + "test/results.txt").read()
+    after_loss = float(txt.split("final\n")[1].split()[1].rstrip(","))
+    assert after_loss < before["loss_epoch"] - 0.05, (before["loss_epoch"], after_loss)
+    params = checkpoint.load(args.save_path + "2.ckpt")
+    fresh = HierTCNModel(args, params, train=False)
+    os.makedirs(args.log_path + "a/")
+    os.makedirs(args.log_path + "b/")
+    ra, *_ = evaluate_hier(args, mk("test"), st0, model, prefix="a")
+    rb, *_ = evaluate_hier(args, mk("test"), st0, fresh, prefix="b")
+    for k in ra:
+        assert abs(ra[k] - rb[k]) < 1e-6 * max(1.0, abs(rb[k])), (k, ra[k], rb[k])
+    model.engine.close()
+    fresh.engine.close()
