@@ -804,6 +804,11 @@ def main():
             "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
             "setup_s": round(t_setup, 1),
         }
+        try:   # RCCL prints its version banner through C stdio, which flushes at exit: flush it NOW so that the JSON line is the last line of stdout
+            import ctypes
+            ctypes.CDLL(None).fflush(None)
+        except Exception:  # noqa: BLE001
+            pass
         print(json.dumps(out), flush=True)
     if dist.is_initialized():
         dist.destroy_process_group()

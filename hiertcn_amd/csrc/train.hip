@@ -887,7 +887,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // equal widths and L <= 32: the fused low-level kernel of the evaluation path, writing the kept activations on its way
   // (bitwise the layer-at-a-time kernels' values; HIERTCN_FORCE_LAYERED=1 takes those instead)
   const bool F = m.train_fp32 != 0;   // the fp32 training mode (see fp32_master_view above)
-  if (F && (!m.hier || m.low_gru)) return tfail("fp32 training mode: model_hier with the TemporalConvNet low level only");
+  if (F && m.low_gru) return tfail("fp32 training mode: the TemporalConvNet models only (model_hier with model_low_type 'tcn', single-level model_tcn)");
   if (F && (size_t)R * (size_t)m.NP * 4 > ((size_t)8 << 30))
     return tfail("fp32 training mode: %lld rows x %d items of materialised fp32 logits exceed 8 GiB -- it is built for the reference's own batch; "
                  "train larger batches on the 16-bit storage path", (long long)R, m.NP);
@@ -895,10 +895,14 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   if (do_begin && F) {
     // ---- forward on the masters, everything kept in fp32 (model_hier.py:39-93 as exact.hip computes it) ----
     const ExactDev xv = fp32_master_view(m, t);
+    if (!m.hier) {   // single-level model_tcn (model.py:71-73): block 0 reads the embedded ids
+      T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, F32(w.f_act[0]), st));
+    } else {
     T_HIP(launch_xsession_pool(m, xv, y, n_sess, L, pooled, st));
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
     T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, F32(w.f_emb), st));
-    {
+    }
+    if (m.hier) {
       XGemm g = {};
       g.A = F32(w.f_emb); g.lda = E; g.Wt = xv.projT; g.taps = 1; g.Cin = E; g.M = R; g.N = E;
       g.seq_init = sproj; g.Lseq = L; g.out = F32(w.f_act[0]); g.ldo = E; g.epi = XEPI_LINEAR;

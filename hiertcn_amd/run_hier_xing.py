@@ -204,9 +204,11 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
                 # the device is left running (model.py, PendingTrain): the carried state goes device to device, a step's loss is read one step later
                 model.train_begin(state_np)
                 pending = None
+                health = _HealthWatch(model, "training epoch %d" % epoch)   # (the training step runs persistent launches too: scan, its backward, lgru_pipe)
                 for _ in range(args.epoch_batches_train):  # :275
                     x, y, mask, _widths = loader_train.get_packed_batch()
                     nxt = model.train_step_packed_async(x, y, mask, lr)
+                    health.after_batch()
                     if pending is not None:
                         training_loss_epoch += float(pending.result()["loss"])
                     pending = nxt

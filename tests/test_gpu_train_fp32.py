@@ -229,3 +229,56 @@ def test_run_hier_trains_in_the_fp32_mode(tmp_path):
         assert abs(ra[k] - rb[k]) < 1e-6 * max(1.0, abs(rb[k])), (k, ra[k], rb[k])
     model.engine.close()
     fresh.engine.close()
+
+
+def test_single_level_model_trains_in_the_fp32_mode():
+    """model_tcn (model.py:71-73) with unequal widths ([64, 64, 128, 128]: a Dense residual on block 2) and T = 70 -- BASELINE.json configs[0]'s model
+    family -- in the fp32 training mode: loss and every gradient against fp64 autograd on the unrounded weights, then TcnModel.train_step lowers the loss."""
+    from hiertcn_amd.args import make_args
+    from hiertcn_amd.engine import Engine, metrics_dict
+    from hiertcn_amd.model import TcnModel
+    from hiertcn_amd.params import init_params
+    N = 600
+    a = make_args([], model_type="hier", item_num=N, emb_dim=64, tcn_channel=[64, 64, 128, 128], kernel_size=3, storage_dtype="fp32")
+    a.model_type = "tcn"
+    rng = np.random.default_rng(5)
+    p = init_params(a, 2, "tcn")
+    p = {k: ((v + 0.05 * rng.standard_normal(v.shape).astype(np.float32)) if k.endswith("/bias") else (v * (8.0 if k.endswith("tcn/dense/kernel") else 1.5)).astype(np.float32))
+         for k, v in p.items()}
+    B, T = 5, 70
+    lens = rng.integers(5, T + 1, B)
+    y = (rng.integers(1, N, (B, T)) * (np.arange(T)[None, :] < lens[:, None])).astype(np.int32)
+    x = np.zeros_like(y)
+    x[:, 1:] = y[:, :-1]
+    eng = Engine(a, hier=False, train=True, dtype="fp32")
+    eng.set_weights(p)
+    out = eng.train_forward_backward(dev(x).view(B, 1, T), dev(y).view(B, 1, T))
+    grads = eng.export("grads")
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in p.items()}
+    xt, yt = torch.as_tensor(x, dtype=torch.int64), torch.as_tensor(y, dtype=torch.int64)
+    h = (F.embedding(xt, P["tcn/emb/kernel"]) * (xt > 0)[..., None]).transpose(1, 2)
+    for i in range(len(a.tcn_channel)):
+        pre = f"tcn/temporal_conv_net/tblock_{i}"
+        W = P[f"{pre}/conv1/kernel"].permute(2, 1, 0)
+        dd, K = 2 ** i, W.shape[-1]
+        c = torch.relu(F.conv1d(F.pad(h, ((K - 1) * dd, 0)), W, P[f"{pre}/conv1/bias"], dilation=dd))
+        r = (h.transpose(1, 2) @ P[f"{pre}/dense/kernel"] + P[f"{pre}/dense/bias"]).transpose(1, 2) if f"{pre}/dense/kernel" in P else h
+        h = torch.relu(c + r)
+    z = h.transpose(1, 2) @ P["tcn/dense/kernel"] + P["tcn/dense/bias"]
+    m = (yt > 0).double()
+    ce = F.cross_entropy((z * m[..., None]).reshape(-1, N), yt.reshape(-1), reduction="none").reshape(B, -1) * m
+    act = m.sum(1)
+    ref_loss = (ce.sum(1) / (act + 1e-6)).sum() / (act > 0).double().sum()
+    ref_loss.backward()
+    assert abs(metrics_dict(out["metrics8"])["loss"] - float(ref_loss.detach())) < 2e-5 * max(1.0, float(ref_loss.detach()))
+    assert set(grads) == set(P) and "tcn/temporal_conv_net/tblock_2/dense/kernel" in grads
+    for k in sorted(P):
+        g, r = grads[k].astype(np.float64), P[k].grad.numpy()
+        rel = np.linalg.norm(g - r) / max(np.linalg.norm(r), 1e-30)
+        assert rel < 1e-4, (k, rel)
+    eng.close()
+    model = TcnModel(a, p, train=True)
+    assert model.engine.mode == "fp32" and model.engine.train
+    losses = [model.train_step(x, y, 1e-2)["loss"] for _ in range(4)]
+    assert losses[-1] < losses[0], losses
+    model.engine.close()
