@@ -683,6 +683,86 @@ def main():
         except Exception as e:  # noqa: BLE001  (a diagnostic, never fatal)
             dvfs = {"error": repr(e)[:200]}
 
+    gmm = train = exact = refb = rloop = cpu = None   # secondary legs fill these in; make_out() reads whatever is there
+
+    def make_out():
+        out = {
+            "metric": "sessions/sec (XING-shape synth) at 1/2/4/8 MI355X; recall@10 parity",
+            "value": round(value, 2),
+            "unit": "sessions/s",
+            "n_gpus": world,
+            "steps": a.steps,
+            "warmup": a.warmup,
+            "ms_per_step": round(dt / a.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "bf16",
+            "data": "synthetic",
+            "config": {
+                "workload": "cfg3-synth: 200k users x 20 sessions x 30 steps, 300k-item catalogue, d=256 (E=C=H), "
+                            "2 TCN blocks K=5, 2-layer GRU; eval step = pool+GRU scan+TCN+fused scoring(loss+rank)+lane metrics",
+                "users_per_step_per_gpu": B,
+                "streams": n_streams,
+                "sessions_per_step": sessions_per_step,
+                "ragged": bool(a.ragged),
+                "parallelism": f"user-batch dp{world}",
+            },
+            "roofline": {
+                "bound": "mfma",
+                "kernel": "k_score_pipe<256,14,2,3,pad> (fused scoring GEMM + loss/rank epilogue; + its fix-up launch)",
+                "achieved": round(achieved, 2),
+                "peak": MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s",
+                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
+                "library_gemm_reference": gemm_ref,
+                "frac_of_library_gemm": (round(achieved / gemm_ref["tflops"], 4) if gemm_ref and gemm_ref.get("tflops") else None),
+                "clock_probe": dvfs,
+                # informational: the same achieved rate against the peak at the shader clock rocm-smi reported under this very load
+                # (2.5 PFLOP/s assumes 2.4 GHz); `frac` above stays the data-sheet fraction
+                "frac_at_held_clock": (round(achieved / (MFMA_PEAK_TFLOPS * dvfs["random"]["sclk_mhz"] / 2400.0), 4)
+                                       if dvfs and dvfs.get("random") and dvfs["random"].get("sclk_mhz") else None),
+                "traffic": traffic,
+                "traffic_unit": "bytes per launch through the L2's memory-side port (Infinity-Cache hits included)",
+                "traffic_code": traffic_code,
+                "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": rows_per_launch * (2 * DIM + 4 + 8) + 2 * DIM * N_ITEMS + 4 * N_ITEMS,
+                "launch_ms": round(score_ms, 4),
+                "launch_ms_per_rank_min_max": [min(r["score_launch_ms"] for r in per_rank), max(r["score_launch_ms"] for r in per_rank)],
+                "launches_timed": int(launches),
+                "flops_per_launch": flops_per_launch,
+                "scored_rows_per_launch": scored_rows,
+            },
+            "cpu_baseline": cpu,
+            "exact": exact,
+            "reference_batch": refb,
+            "run_loop": rloop,
+            "multi_gpu": multi,
+            "gmm": gmm,
+            "train": train,
+            "persistent_timed_out": bool(persistent_timed_out),
+            "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
+            "setup_s": round(t_setup, 1),
+        }
+        return out
+
+    # N > 1: the secondary legs below run collectives that no hardware run has exercised at more than one rank.  A rank stuck in one would take the
+    # headline line with it, so a watchdog on EVERY rank prints the line as it stands (rank 0) and ends the process if they have not finished in time.
+    watchdog = None
+    if world > 1:
+        import threading
+        limit = float(os.environ.get("HIERTCN_BENCH_LEG_LIMIT_S", "420"))
+
+        def _expired():
+            if rank == 0:
+                o = make_out()
+                o["secondary_legs"] = {"error": f"not finished after {limit:.0f} s: line printed by the watchdog, process ended"}
+                print(json.dumps(o), flush=True)
+            os._exit(0)
+        watchdog = threading.Timer(limit, _expired)
+        watchdog.daemon = True
+        watchdog.start()
+
     # ---- mixture-output head (BASELINE.json configs[4]: model_tcn_gmm / model_gru_gmm): hiertcn_gmm_loss = M passes of the scoring kernel's main
     # loop with the sum-of-squares epilogue over the [D, C] mean tables, at configs[4]'s shape (614,400 rows x 20,778 outputs x 5 mixtures)
     gmm = None
@@ -745,65 +825,10 @@ def main():
                    sample_sessions=int(r["sessions"]), planned_sessions=plan,
                    seconds=round(r["seconds"], 2), variants=r["variants"])
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        out = {
-            "metric": "sessions/sec (XING-shape synth) at 1/2/4/8 MI355X; recall@10 parity",
-            "value": round(value, 2),
-            "unit": "sessions/s",
-            "n_gpus": world,
-            "steps": a.steps,
-            "warmup": a.warmup,
-            "ms_per_step": round(dt / a.steps * 1e3, 3),
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "bf16",
-            "data": "synthetic",
-            "config": {
-                "workload": "cfg3-synth: 200k users x 20 sessions x 30 steps, 300k-item catalogue, d=256 (E=C=H), "
-                            "2 TCN blocks K=5, 2-layer GRU; eval step = pool+GRU scan+TCN+fused scoring(loss+rank)+lane metrics",
-                "users_per_step_per_gpu": B,
-                "streams": n_streams,
-                "sessions_per_step": sessions_per_step,
-                "ragged": bool(a.ragged),
-                "parallelism": f"user-batch dp{world}",
-            },
-            "roofline": {
-                "bound": "mfma",
-                "kernel": "k_score_pipe<256,14,2,3,pad> (fused scoring GEMM + loss/rank epilogue; + its fix-up launch)",
-                "achieved": round(achieved, 2),
-                "peak": MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s",
-                "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-                "library_gemm_reference": gemm_ref,
-                "frac_of_library_gemm": (round(achieved / gemm_ref["tflops"], 4) if gemm_ref and gemm_ref.get("tflops") else None),
-                "clock_probe": dvfs,
-                # informational: the same achieved rate against the peak at the shader clock rocm-smi reported under this very load
-                # (2.5 PFLOP/s assumes 2.4 GHz); `frac` above stays the data-sheet fraction
-                "frac_at_held_clock": (round(achieved / (MFMA_PEAK_TFLOPS * dvfs["random"]["sclk_mhz"] / 2400.0), 4)
-                                       if dvfs and dvfs.get("random") and dvfs["random"].get("sclk_mhz") else None),
-                "traffic": traffic,
-                "traffic_unit": "bytes per launch through the L2's memory-side port (Infinity-Cache hits included)",
-                "traffic_code": traffic_code,
-                "traffic_source": traffic_src,
-                "algorithmic_bytes_per_launch": rows_per_launch * (2 * DIM + 4 + 8) + 2 * DIM * N_ITEMS + 4 * N_ITEMS,
-                "launch_ms": round(score_ms, 4),
-                "launch_ms_per_rank_min_max": [min(r["score_launch_ms"] for r in per_rank), max(r["score_launch_ms"] for r in per_rank)],
-                "launches_timed": int(launches),
-                "flops_per_launch": flops_per_launch,
-                "scored_rows_per_launch": scored_rows,
-            },
-            "cpu_baseline": cpu,
-            "exact": exact,
-            "reference_batch": refb,
-            "run_loop": rloop,
-            "multi_gpu": multi,
-            "gmm": gmm,
-            "train": train,
-            "persistent_timed_out": bool(persistent_timed_out),
-            "batch_metrics_last_step": {k: round(v, 6) for k, v in last.items()},
-            "setup_s": round(t_setup, 1),
-        }
+        out = make_out()
         try:   # RCCL prints its version banner through C stdio, which flushes at exit: flush it NOW so that the JSON line is the last line of stdout
             import ctypes
             ctypes.CDLL(None).fflush(None)
