@@ -692,8 +692,6 @@ int hiertcn_train_enable(hiertcn_handle_t h) {
   const bool fp32 = h->precision == HIERTCN_PRECISION_FP32 && (h->x.enabled & X_FP32);
   if (h->x.enabled && !fp32)
     return fail(HIERTCN_ERR_STATE, "this handle is in the split16 evaluation mode (hiertcn_set_precision): training runs on 16-bit storage handles, or in the fp32 mode");
-  if (fp32 && h->m.low_gru)
-    return fail(HIERTCN_ERR_STATE, "fp32 training mode: the TemporalConvNet models (model_hier with low_type 0, single-level model_tcn); this handle is HierGRU");
   ON_DEVICE(h);
   HIP_TRY(train_enable(h->m, h->train));
   if (fp32) {
@@ -703,7 +701,7 @@ int hiertcn_train_enable(hiertcn_handle_t h) {
     float* M = h->train.master();
     x.emb = M + h->train.emb.off;
     x.projT = h->m.hier ? M + h->train.projT.off : nullptr;
-    for (int i = 0; i < h->m.n_blocks; i++) {
+    for (int i = 0; i < h->m.n_blocks && !h->m.low_gru; i++) {
       x.convT[i] = M + h->train.convT[i].off;
       x.resT[i] = h->train.resT[i].n ? M + h->train.resT[i].off : nullptr;
     }

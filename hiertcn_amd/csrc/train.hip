@@ -791,7 +791,8 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// fp32 training mode (hiertcn_set_precision(FP32) before hiertcn_train_enable; model_hier with the TemporalConvNet low level): the step the
+// fp32 training mode (hiertcn_set_precision(FP32) before hiertcn_train_enable; model_hier with either low level -- TemporalConvNet or the GRU stack
+// of model_gru.py:46-55, the reference's default (args.py:40) -- and the single-level model_tcn): the step the
 // reference takes (model.py:135-141 on fp32 tensors, loss.py:20-21 on materialised logits) -- fp32 forward on the MASTERS (exact.hip's GEMM
 // kernel, activations kept in fp32), logits [R][NP] materialised once, d logits formed in place, every product of the backward an exact-fp32
 // MFMA GEMM (gemm.hip).  Sized for the reference's own batch (32 lanes x 10 x 20 x 20,778 items: 532 MB of logits -- what TensorFlow holds
@@ -887,7 +888,6 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // equal widths and L <= 32: the fused low-level kernel of the evaluation path, writing the kept activations on its way
   // (bitwise the layer-at-a-time kernels' values; HIERTCN_FORCE_LAYERED=1 takes those instead)
   const bool F = m.train_fp32 != 0;   // the fp32 training mode (see fp32_master_view above)
-  if (F && m.low_gru) return tfail("fp32 training mode: the TemporalConvNet models only (model_hier with model_low_type 'tcn', single-level model_tcn)");
   if (F && (size_t)R * (size_t)m.NP * 4 > ((size_t)8 << 30))
     return tfail("fp32 training mode: %lld rows x %d items of materialised fp32 logits exceed 8 GiB -- it is built for the reference's own batch; "
                  "train larger batches on the 16-bit storage path", (long long)R, m.NP);
@@ -902,13 +902,13 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
     T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, F32(w.f_emb), st));
     }
-    if (m.hier) {
+    if (m.hier) {   // the 'emb' projection of [e, state] (model_tcn.py:35 / model_gru.py:46): block 0's input, or the low-level GRU's (HierGRU: kept as lb.uf)
       XGemm g = {};
       g.A = F32(w.f_emb); g.lda = E; g.Wt = xv.projT; g.taps = 1; g.Cin = E; g.M = R; g.N = E;
-      g.seq_init = sproj; g.Lseq = L; g.out = F32(w.f_act[0]); g.ldo = E; g.epi = XEPI_LINEAR;
+      g.seq_init = sproj; g.Lseq = L; g.out = m.low_gru ? F32(w.lg_uf) : F32(w.f_act[0]); g.ldo = E; g.epi = XEPI_LINEAR;
       T_HIP(launch_xgemm(g, st));
     }
-    for (int i = 0, cin = E; i < nb; cin = m.C[i], i++) {
+    for (int i = 0, cin = E; i < nb && !m.low_gru; cin = m.C[i], i++) {
       const int cout = m.C[i];
       const float* res = F32(w.f_act[i]);
       int64_t ldres = cin;
@@ -946,7 +946,10 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     lb.x3 = BF(w.lg_x3);
     lb.pipe = lgru_pipe_bytes(m, n_sess, L) ? ws + w.lg_pipe : nullptr;
     lb.rec = lb.states + (size_t)(L + 1) * n_sess * HT; lb.keep_all = 1;
-    if (do_begin) T_HIP(launch_low_gru_bufs(m, x, sproj, n_sess, L, BF(w.act[2]), lb, st));
+    if (F) {   // fp32 mode: lb.uf holds the fp32 projection already; the exact-fp32 cell chain (pool_gru.hip) on the masters, records kept, fp32 output rows
+      lb.hidden32 = F32(w.f_act[nb]); lb.x3 = nullptr; lb.pipe = nullptr; lb.u16 = nullptr; lb.a_emb = nullptr;
+    }
+    if (do_begin) T_HIP(launch_low_gru_bufs(m, x, sproj, n_sess, L, F ? nullptr : BF(w.act[2]), lb, st));
   }
   auto a_of = [&](int k) -> uint16_t* { return k == 0 ? a0 : BF(w.act[1 + 2 * k]); };   // a^k: output of block k-1
   if (fused_fw && do_begin) {
@@ -1135,7 +1138,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     const unsigned gMH = (unsigned)(((int64_t)M * H + 255) / 256);
     // small batches: the whole BPTT as one launch, a workgroup per 32 sessions (lgru_tile.hip); it keeps the cells' pre-activation gradients, the
     // weight gradients follow below as always in this regime
-    const bool tile_bwd = deferred && lgru_tile_applies(m, (int64_t)M) && m.tune.lgru_tile_bwd != 0;
+    const bool tile_bwd = !F && deferred && lgru_tile_applies(m, (int64_t)M) && m.tune.lgru_tile_bwd != 0;   // (fp32 mode: the exact-fp32 launch chain below)
     if (!tile_bwd) T_HIP(hipMemsetAsync(lcar, 0, (size_t)M * HT * 4, st));   // the low level's final state is dropped (model_gru.py:47)
     if (tile_bwd && lgru_wide_bwd_applies(m, (int64_t)M) && lgru_wide_bwd_bytes(m, (int64_t)M, L) > 0)   // H = 128 / 256: HB workgroups per (tile, layer), weights in registers, layers pipelined
       T_HIP(launch_lgru_wide_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, ws + w.lg_bwd, st));
@@ -1217,7 +1220,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     }
     da = du;
   }
-  for (int i = nb - 1; i >= 0 && F; i--) {   // fp32 mode: the same block backward on fp32 activations, every product an exact-fp32 GEMM
+  for (int i = nb - 1; i >= 0 && F && !m.low_gru; i--) {   // fp32 mode: the same block backward on fp32 activations, every product an exact-fp32 GEMM
     const ExactDev xv = fp32_master_view(m, t);
     const int cin = (i == 0) ? E : m.C[i - 1], cout = m.C[i];
     const float* a_in = F32(w.f_act[i]);

@@ -98,9 +98,9 @@ class Engine:
             raise HierTCNError(f"storage dtype {dtype!r}: 'bf16', 'fp16', 'fp32' (exact mode) or 'split16' (fast parity-grade mode)")
         if dtype == "split16" and train:
             raise HierTCNError("dtype='split16' is an EVALUATION mode; training runs on bf16 storage with fp32 masters, or in the fp32 mode (dtype='fp32')")
-        if dtype == "fp32" and train and hier and getattr(args, "model_low_type", "tcn") != "tcn":
+        if dtype == "fp32" and train and hier and getattr(args, "model_low_type", "tcn") not in ("tcn", "gru"):
             raise HierTCNError("dtype='fp32' with train=True (the fp32 training mode: fp32 forward on the masters, materialised logits) is built for "
-                               "the TemporalConvNet models (model_hier with model_low_type 'tcn', single-level model_tcn) at the reference's batch sizes")
+                               "model_hier with model_low_type 'tcn' or 'gru' and the single-level model_tcn, at the reference's batch sizes")
         self.f16 = dtype == "fp16"
         self.mode = dtype if dtype in ("fp32", "split16") else "storage16"
         self.exact = self.mode != "storage16"       # fp32 hidden rows / fp32 low level (the FP32 and the SPLIT16 mode)

@@ -269,10 +269,10 @@ def test_exact_mode_contract_errors():
     args = small_args(N=300, d=64, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
     with pytest.raises(HierTCNError, match="EVALUATION"):
         Engine(args, hier=True, dtype="split16", train=True)
-    gru = small_args(N=300, d=64, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
-    gru.model_low_type = "gru"
-    with pytest.raises(HierTCNError, match="fp32 training mode"):    # (fp32 TRAINS since ABI 10 -- model_hier with the TemporalConvNet low level: tests/test_gpu_train_fp32.py)
-        Engine(gru, hier=True, dtype="fp32", train=True)
+    gmm = small_args(N=300, d=64, H=64, nl=1, blocks=1, K=3, L=8, S=2, B=4)
+    gmm.model_low_type = "tcn_gmm"
+    with pytest.raises(HierTCNError, match="fp32 training mode"):    # (fp32 TRAINS since ABI 10 -- model_hier with the 'tcn' or 'gru' low level, model_tcn: tests/test_gpu_train_fp32.py)
+        Engine(gmm, hier=True, dtype="fp32", train=True)
     eng = Engine(args, hier=True)                     # a 16-bit handle whose weights are set cannot be switched: no fp32 copies
     eng.set_weights(make_params(args))
     with pytest.raises(HierTCNError, match="precede hiertcn_set_weights"):

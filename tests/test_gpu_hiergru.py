@@ -113,11 +113,13 @@ def test_hiergru_model_hier_surface(setup):
 # ---------------------------------------------------------------------------------------------------------------------
 # training step of HierGRU against autograd (same contract as tests/test_gpu_train.py)
 # ---------------------------------------------------------------------------------------------------------------------
-def torch_loss_gru(args, P, x, y, mask, state):
+def torch_loss_gru(args, P, x, y, mask, state, ste_bf16=None):
     """model_hier.py:39-93 with the model_gru.py:16-63 low level + model.py:102-117, on torch fp64 tensors; activations are
-    rounded (straight-through) where the device rounds them: the projected rows and the GRU outputs fed to scoring."""
+    rounded (straight-through) where the device rounds them: the projected rows and the GRU outputs fed to scoring
+    (ste_bf16: that rounding; the fp32 training mode's test passes the identity -- nothing is rounded there)."""
     import torch.nn.functional as F
-    from tests.test_gpu_train import ste_bf16
+    if ste_bf16 is None:
+        from tests.test_gpu_train import ste_bf16
     B, S, L = x.shape
     H, nl, N = args.hidden_dim, args.num_layer, args.item_num
     st = torch.as_tensor(state, dtype=torch.float64)

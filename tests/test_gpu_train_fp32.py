@@ -191,8 +191,9 @@ def test_fp32_training_mode_contract():
     eng.close()
 
 
-def test_run_hier_trains_in_the_fp32_mode(tmp_path):
-    """`run_xing --train --storage_dtype fp32` end to end on the synthetic XING CSV: three epochs of six batches through run_hier (pipelined train loop,
+@pytest.mark.parametrize("low", ["tcn", "gru"])
+def test_run_hier_trains_in_the_fp32_mode(tmp_path, low):
+    """`run_xing --train --storage_dtype fp32 [--model_low_type gru]` end to end on the synthetic XING CSV: three epochs of six batches through run_hier (pipelined train loop,
     TF-form Adam, checkpoint, evaluation between the epochs in the fp32 mode ON THE MASTERS the optimiser has just written): the loss falls, the
     checkpoint restores into a fresh fp32 evaluation model that evaluates identically."""
     import os
@@ -206,12 +207,13 @@ def test_run_hier_trains_in_the_fp32_mode(tmp_path):
     n_items = int(data[1][:, 1].max()) + 1
     args = hier_tcn_args(item_num=n_items, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=5, batch_size=4, max_session_num=3,
                          max_activity_len=6, storage_dtype="fp32")
+    args.model_low_type = low
     args.log_path, args.save_path = str(tmp_path) + "/log/", str(tmp_path) + "/model/"
     args.train, args.validate, args.test, args.save = True, False, True, True
     args.epoch_max, args.epoch_batches_train, args.save_epoch, args.test_epoch, args.learning_rate = 2, 6, 2, 2, 1e-2
     mk = lambda split: Dataloader_hier_model_xing(args, split, data=data)  # noqa: E731
     model = HierTCNModel(args)
-    assert model.engine.exact and model.engine.train and model.engine.mode == "fp32"
+    assert model.engine.exact and model.engine.train and model.engine.mode == "fp32" and model.engine.low_gru == (low == "gru")
     st0 = np.zeros((4, 64))
     os.makedirs(args.log_path + "before/")
     before, *_ = evaluate_hier(args, mk("test"), st0, model, prefix="before")
@@ -282,3 +284,57 @@ def test_single_level_model_trains_in_the_fp32_mode():
     losses = [model.train_step(x, y, 1e-2)["loss"] for _ in range(4)]
     assert losses[-1] < losses[0], losses
     model.engine.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# HierGRU (model_low_type 'gru': the reference's DEFAULT low level, args.py:40 -> model_hier.py:67-68 -> model_gru.py:46-55) in the fp32 training mode
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("d,H,N,nl,shape", [(64, 64, 700, 2, (6, 3, 8)), (128, 64, 1500, 1, (6, 3, 8)), (128, 128, 900, 2, (9, 4, 7)),
+                                            (256, 256, 600, 2, (5, 3, 6)), (128, 128, 3000, 2, (32, 10, 20))],
+                         ids=["d64_nl2", "d128_h64_nl1", "d128_h128_nl2", "d256_h256_nl2", "reference_batch_d128"])
+def test_hiergru_trains_in_the_fp32_mode(d, H, N, nl, shape):
+    """The forward on the masters (fp32 'emb' projection, the exact-fp32 GRU cell chain with every record kept, materialised logits) and the
+    backward (BPTT over the L steps as exact-fp32 GEMMs) against fp64 autograd on the UNROUNDED weights: loss, carried state, every gradient;
+    then Adam steps lower the loss and the masters come back under the reference's variable names."""
+    import copy
+    from hiertcn_amd.engine import Engine, metrics_dict
+    from tests.test_gpu_hiergru import torch_loss_gru
+    args = copy.copy(small_args(N=N, d=d, H=H, nl=nl))
+    args.model_low_type = "gru"
+    p = {k: np.array(v, np.float32) for k, v in make_params(args).items()}
+    p["hier/emb/kernel"] *= 3.0
+    p["hier/gru/dense/kernel"] *= 12.0          # logits of a trained model's scale: the regime in which 16-bit storage is visibly off
+    eng = Engine(args, hier=True, train=True, dtype="fp32")
+    eng.set_weights(p)
+    rng = np.random.default_rng(d + 11)
+    B, S, L = shape
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, H * nl))).astype(np.float32)
+    st0[:2] = 0.0
+    out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    torch.cuda.synchronize()
+    grads = eng.export("grads")
+    loss = metrics_dict(out["metrics8"])["loss"]
+    P = {k: torch.tensor(np.asarray(v, dtype=np.float64), requires_grad=True) for k, v in p.items()}
+    ref_loss, ref_state = torch_loss_gru(args, P, x, y, mask, st0, ste_bf16=lambda t: t)
+    ref_loss.backward()
+    assert abs(loss - float(ref_loss.detach())) < 2e-5 * max(1.0, abs(float(ref_loss.detach()))), (loss, float(ref_loss.detach()))
+    assert np.abs(out["state"].cpu().numpy() - ref_state.detach().numpy()).max() < 1e-5
+    assert set(grads) == set(P)
+    report = []
+    for k in sorted(P):
+        g, r = grads[k].astype(np.float64), P[k].grad.numpy()
+        nr = np.linalg.norm(r)
+        report.append((k, np.linalg.norm(g - r) / max(nr, 1e-30), nr))
+    bad = [(k, rel) for k, rel, nr in report if nr > 1e-12 and rel > 1e-4]
+    assert not bad, "\n".join(f"{k}: rel {rel:.3e}" for k, rel in bad) + "\nall:\n" + "\n".join(f"{k}: rel {rel:.3e} |ref| {nr:.3e}" for k, rel, nr in report)
+    print("HierGRU fp32 mode: max relative gradient error %.2e (%s)" % max((rel, k) for k, rel, nr in report if nr > 1e-12))
+    assert not grads["hier/emb/kernel"][0].any()
+    l0 = loss
+    for _ in range(3):
+        eng.adam_step(1e-2)
+        out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+    assert metrics_dict(out["metrics8"])["loss"] < l0
+    assert set(eng.export("weights")) == set(p)
+    eng.close()
+
