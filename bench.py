@@ -313,7 +313,7 @@ def reference_batch_leg(n_batches=100):
     # (hiertcn_d256_fp32: the same model in the fp32 TRAINING mode -- fp32 forward on the masters, 532 MB of materialised logits per step, every product of
     #  the backward an exact-fp32 GEMM: the configuration in which a TF training trajectory can be followed to fp32 grade; evaluation = the fp32 mode)
     for name, low, d, train, dtype in (("hiertcn_d256", "tcn", 256, True, None), ("hiergru_d128", "gru", 128, True, None), ("hiergru_d256", "gru", 256, True, None),
-                                       ("hiertcn_d256_fp32", "tcn", 256, True, "fp32")):
+                                       ("hiertcn_d256_fp32", "tcn", 256, True, "fp32"), ("hiergru_d128_fp32", "gru", 128, True, "fp32")):
         args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=d, num_layer=2, tcn_channel=[d, d], kernel_size=5, batch_size=B, model_low_type=low)
         eng = Engine(args, hier=True, train=train, dtype=dtype)
         eng.set_weights(init_params(args, seed=2))
