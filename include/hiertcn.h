@@ -154,7 +154,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
  * In FP32 and SPLIT16 every `hidden` argument is float [R][C_last].  SPLIT16 is evaluation only.  FP32 also TRAINS (ABI 10): hiertcn_set_precision(h,
  * HIERTCN_PRECISION_FP32) followed by hiertcn_train_enable puts the handle into the fp32 training mode -- the step of model.py:135-141 as the reference takes
  * it: fp32 forward on the masters, logits [R][NP] materialised once (so: the reference's own batch sizes; the call fails past 8 GiB of logits), every
- * product of the backward an exact-fp32 GEMM; gradients agree with fp64 autograd on the unrounded weights to ~1e-6.  model_hier with low_type 0 and single-level model_tcn.
+ * product of the backward an exact-fp32 GEMM; gradients agree with fp64 autograd on the unrounded weights to ~1e-6.  model_hier with low_type 0 (TemporalConvNet) or 1 (the GRU stack) and single-level model_tcn.
  * FP32 keeps ONE logits scratch per handle: calls of a handle in that mode must not overlap on different streams (SPLIT16 and STORAGE16 have no such state).
  * The first switch to a mode must precede hiertcn_set_weights (it allocates the weight copies that set_weights fills -- for FP32 also a logits
  * scratch of <= 1 GiB owned by the handle); after that the modes may be switched back and forth between calls. */

@@ -23,10 +23,17 @@ for d in ("pmc_fetch", "pmc_write", "pmc_sq"):
             agg[k][r["Counter_Name"]] += float(r["Counter_Value"])
             disp[k].add(r["Dispatch_Id"])
     for k, v in agg.items():
-        if "score" in k or "tcn" in k or "sgrad" in k:
+        if any(w in k for w in ("score", "tcn", "sgrad", "pool", "metrics", "gru_scan", "embed")):   # + the HBM-bound sub-kernels (reported as GB/s)
             n = max(len(disp[k]), 1)
             res.setdefault("pmc_per_launch", {}).setdefault(k, {}).update({c: val / n for c, val in v.items()})
             res["pmc_per_launch"][k]["launches"] = n
+# durations of the SAME launches the counters were read on: the FETCH_SIZE pass's own kernel trace (the counter passes skip the training / mixture /
+# reference-batch legs, so a name's average over the full trace run would mix in launches of other sizes)
+dur = collections.defaultdict(list)
+for f in glob.glob(os.path.join(out, "pmc_fetch", "**", "*kernel_trace.csv"), recursive=True):
+    for r in csv.DictReader(open(f)):
+        dur[r["Kernel_Name"].split("(")[0][-60:]].append(float(r["End_Timestamp"]) - float(r["Start_Timestamp"]))
+avg_ns_of = {k: sum(v) / len(v) for k, v in dur.items() if v}
 for k, v in res.get("pmc_per_launch", {}).items():
     if "FETCH_SIZE" in v:   # KB; gfx950: x2 for wide coalesced streaming reads (MI355X_MICROARCH.md, HBM)
         v["fetch_bytes_corrected"] = v["FETCH_SIZE"] * 1024 * 2
@@ -34,6 +41,11 @@ for k, v in res.get("pmc_per_launch", {}).items():
         v["write_bytes"] = v["WRITE_SIZE"] * 1024
     if "TCC_HIT_sum" in v:
         v["l2_hit_rate"] = v["TCC_HIT_sum"] / (v["TCC_HIT_sum"] + v["TCC_MISS_sum"])
+    if "fetch_bytes_corrected" in v and "write_bytes" in v and k in avg_ns_of:
+        # memory-side GB/s of the kernel: counter bytes per launch / the same launches' average duration (FETCH_SIZE pass), against ~8 TB/s
+        v["avg_ns_counter_run"] = avg_ns_of[k]
+        v["memory_side_GBps"] = (v["fetch_bytes_corrected"] + v["write_bytes"]) / avg_ns_of[k]
+        v["memory_side_frac_of_8TBps"] = v["memory_side_GBps"] / 8000.0
 try:
     res["bench"] = json.loads(open(os.path.join(out, "bench.json")).read().strip().splitlines()[-1])
 except Exception as e:  # noqa: BLE001
