@@ -55,12 +55,12 @@ class GmmWeights(C.Structure):
 TUNING_FIELDS = ("gru_scan_persistent", "gru_scan_persistent_train", "gru_bptt_persistent", "gru_bptt_fused", "lgru_persistent", "lgru_pipe", "lgru_tile",
                  "lgru_tile_bwd", "lgru_wide", "lgru_wide_bwd", "lgru_fp32_cells", "tcn_layered", "gru_persist_max_lanes", "gemm_split_max_tiles",
                  "skinny_max_rows", "lgru_tile_max_sessions", "lgru_wide_max_launches", "sgrad_dyn_max_blocks", "sgrad0_min_stages", "tcn_gs2_max_sessions",
-                 "lgru_defer_max_gib")
+                 "lgru_defer_max_gib", "train_fp32_chunk_mib")
 
 
 class Tuning(C.Structure):
     """hiertcn_tuning_t (include/hiertcn.h, ABI 10): launch selection (-1 automatic, 0 never, 1 wherever the shape allows) and thresholds of a handle."""
-    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 11)]
+    _fields_ = [(f, C.c_int32) for f in TUNING_FIELDS] + [("reserved", C.c_int32 * 10)]
 
 
 # The environment variables the LIBRARY used to read on its launch path (rounds 1-4), mapped onto hiertcn_tuning_t fields.  Parsed HERE, once per
@@ -87,6 +87,7 @@ ENV_TUNING = {
     "HIERTCN_SGRAD0_MIN_STAGES": ("sgrad0_min_stages", int),
     "HIERTCN_TCN_GS2_MAX": ("tcn_gs2_max_sessions", lambda v: -1 if int(v) <= 0 else int(v)),
     "HIERTCN_LGRU_DEFER_MAX_GIB": ("lgru_defer_max_gib", int),
+    "HIERTCN_TRAIN_FP32_CHUNK_MIB": ("train_fp32_chunk_mib", int),
 }
 
 

@@ -31,6 +31,7 @@ void tuning_defaults(hiertcn_tuning_t* t) {
   t->sgrad0_min_stages = 64;
   t->tcn_gs2_max_sessions = 512;
   t->lgru_defer_max_gib = 8;
+  t->train_fp32_chunk_mib = 8192;
 }
 static const hiertcn_tuning_t* default_tuning() {
   static const hiertcn_tuning_t d = [] { hiertcn_tuning_t t; tuning_defaults(&t); return t; }();
@@ -425,6 +426,7 @@ int hiertcn_set_tuning(hiertcn_handle_t h, const hiertcn_tuning_t* in) {
   THRESH(sgrad_dyn_max_blocks, 1, 1 << 20);
   THRESH(sgrad0_min_stages, 1, 1 << 20);
   THRESH(lgru_defer_max_gib, 1, 256);
+  THRESH(train_fp32_chunk_mib, 1, 1 << 20);
 #undef THRESH
   if (t.tcn_gs2_max_sessions == 0) t.tcn_gs2_max_sessions = d.tcn_gs2_max_sessions;
   if (t.tcn_gs2_max_sessions < -1) return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: tcn_gs2_max_sessions = %d: -1 (never), 0 (the default) or a session count", t.tcn_gs2_max_sessions);

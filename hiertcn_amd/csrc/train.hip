@@ -207,8 +207,8 @@ __global__ __launch_bounds__(256) void k_lane_act(const int32_t* __restrict__ y,
 // w[r] = d loss / d ce[r] = mask / ((act_b + 1e-6) * users) (model.py:111-117);  lse[r] = ce[r] + target[r]
 __global__ void k_row_weights(const int32_t* __restrict__ y, const float* __restrict__ act, const float* __restrict__ users,
                               const float* __restrict__ ce, const float* __restrict__ tgt, int64_t R, int T, float* __restrict__ w,
-                              float* __restrict__ lse) {
-  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+                              float* __restrict__ lse, int64_t r0 = 0) {   // rows [r0, R): the fp32 training mode's row chunks
+  const int64_t r = r0 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (r >= R) return;
   const bool valid = y[r] > 0;
   const float u = users[0];
@@ -682,6 +682,14 @@ static bool lgru_deferred_wgrad(const ModelDev& m, size_t M, int L) {
 // score_grad.hip / k_score + two 16-bit GEMMs per chunk) exists in the ablation build only, behind HIERTCN_TRAIN_LEGACY=1, for A/B runs.
 static bool fused_scoring_backward(const ModelDev& m) { return sgrad_supported(m) && !ABL_ENV("HIERTCN_TRAIN_LEGACY"); }
 
+// fp32 training mode: rows of materialised logits per chunk of the scoring layer (tune.train_fp32_chunk_mib MiB of [rows][NP] floats, at least 64 rows)
+static int64_t fp32_chunk_rows(const ModelDev& m, int64_t R) {
+  const int64_t mib = m.tune.train_fp32_chunk_mib > 0 ? m.tune.train_fp32_chunk_mib : 8192;
+  int64_t rows = (mib << 20) / ((int64_t)m.NP * 4);
+  if (rows < 64) rows = 64;
+  return rows < R ? rows : R;
+}
+
 static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
   TrainWs w;
   memset(&w, 0, sizeof(w));
@@ -783,7 +791,7 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     for (int i = 0; i <= m.n_blocks; i++) w.f_act[i] = take(R * C * 4);
     for (int i = 0; i < m.n_blocks; i++) w.f_c[i] = take(R * C * 4);
     w.f_emb = take(R * E * 4);
-    w.f_logits = take(R * (size_t)m.NP * 4);
+    w.f_logits = take((size_t)fp32_chunk_rows(m, (int64_t)R) * (size_t)m.NP * 4);   // one row chunk of logits (the reference's own batch: all of it, 532 MB)
     w.f_sh[0] = take(R * C * 4); w.f_sh[1] = take(R * C * 4);
   }
   w.total = off;
@@ -801,11 +809,11 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
 // g[r][n] = w_r (exp(z[r][n] - lse_r) - [n == y_r]) in place over [R][ld]; rows without a target have w = 0
 __global__ void k_xdlogits(float* __restrict__ z, int64_t ld, int64_t R, const int32_t* __restrict__ y, const float* __restrict__ w,
                            const float* __restrict__ lse) {
-  const int64_t r = blockIdx.y;
+  const int64_t r = blockIdx.x;   // (rows on x: a chunk of a small catalogue can hold more than 65,535 of them)
   const float wr = w[r], l = lse[r];
   const int yr = y[r];
   float* zr = z + r * ld;
-  for (int64_t n = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) * 4; n < ld; n += (int64_t)gridDim.x * blockDim.x * 4) {
+  for (int64_t n = ((int64_t)blockIdx.y * blockDim.x + threadIdx.x) * 4; n < ld; n += (int64_t)gridDim.y * blockDim.x * 4) {
     float4 v = *reinterpret_cast<float4*>(zr + n);
     float o[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -888,9 +896,6 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   // equal widths and L <= 32: the fused low-level kernel of the evaluation path, writing the kept activations on its way
   // (bitwise the layer-at-a-time kernels' values; HIERTCN_FORCE_LAYERED=1 takes those instead)
   const bool F = m.train_fp32 != 0;   // the fp32 training mode (see fp32_master_view above)
-  if (F && (size_t)R * (size_t)m.NP * 4 > ((size_t)8 << 30))
-    return tfail("fp32 training mode: %lld rows x %d items of materialised fp32 logits exceed 8 GiB -- it is built for the reference's own batch; "
-                 "train larger batches on the 16-bit storage path", (long long)R, m.NP);
   const bool fused_fw = !F && tcn_fused_applies(m, L);
   if (do_begin && F) {
     // ---- forward on the masters, everything kept in fp32 (model_hier.py:39-93 as exact.hip computes it) ----
@@ -987,25 +992,33 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     const float* hid32 = F32(w.f_act[nb]);
     float* Z = F32(w.f_logits);
     const int64_t ldz = m.NP;
-    {
-      XGemm g = {};
-      g.A = hid32; g.lda = CL; g.Wt = xv.outT; g.taps = 1; g.Cin = CL; g.M = R; g.N = m.NP; g.bias = m.out_bias; g.out = Z; g.ldo = ldz; g.epi = XEPI_LINEAR;
-      T_HIP(launch_xgemm(g, st));
-    }
-    T_HIP(launch_xrow_stats(Z, ldz, y, R, m.N, so.rank, so.ce, so.target, st));
-    if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
+    // the row weights d loss / d ce depend on the mask only (model.py:111-117): lane activity and the user count first, then the layer in ROW CHUNKS of
+    // at most tune.train_fp32_chunk_mib MiB of logits (the reference's own batch is one chunk; larger batches take several -- d Wo^T and d bo accumulate)
     float* users = F32(w.users);
     T_HIP(hipMemsetAsync(users, 0, sizeof(float), st));
     hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, S * L, F32(w.lane_act), users);
-    hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce,
-                       so.target, R, S * L, F32(w.w), F32(w.lse));
     T_HIP(hipGetLastError());
-    // d loss / d logits in place; then the three products: d Wo^T [NP][C] = g^T . h, d bo = column sums, d h = g . Wo^T
-    hipLaunchKernelGGL(k_xdlogits, dim3(8, (unsigned)R), dim3(256), 0, st, Z, ldz, R, y, F32(w.w), F32(w.lse));
-    T_HIP(hipGetLastError());
-    T_HIP(gemm32_tn(Z, ldz, hid32, CL, G + t.outT.off, CL, m.NP, CL, (int)R, 0.f, F32(w.splitk), w.splitk_floats, st));
-    T_HIP(colsum_f32(Z, R, ldz, m.NP, G + t.out_bias.off, st));
-    T_HIP(gemm32_nn(Z, ldz, xv.outT, CL, dH, CL, (int)R, CL, m.NP, 0.f, st));
+    const int64_t RC = fp32_chunk_rows(m, R);
+    for (int64_t r0 = 0; r0 < R; r0 += RC) {
+      const int64_t rc = R - r0 < RC ? R - r0 : RC;
+      const float* hc32 = hid32 + r0 * CL;
+      {
+        XGemm g = {};
+        g.A = hc32; g.lda = CL; g.Wt = xv.outT; g.taps = 1; g.Cin = CL; g.M = rc; g.N = m.NP; g.bias = m.out_bias; g.out = Z; g.ldo = ldz; g.epi = XEPI_LINEAR;
+        T_HIP(launch_xgemm(g, st));
+      }
+      T_HIP(launch_xrow_stats(Z, ldz, y + r0, rc, m.N, so.rank + r0, so.ce + r0, so.target + r0, st));
+      hipLaunchKernelGGL(k_row_weights, dim3((unsigned)((rc + 255) / 256)), dim3(256), 0, st, y, F32(w.lane_act), users_global ? users_global : users, so.ce,
+                         so.target, r0 + rc, S * L, F32(w.w), F32(w.lse), r0);
+      T_HIP(hipGetLastError());
+      // d loss / d logits in place; then the three products: d Wo^T [NP][C] += g^T . h, d bo += column sums, d h = g . Wo^T
+      hipLaunchKernelGGL(k_xdlogits, dim3((unsigned)rc, 8), dim3(256), 0, st, Z, ldz, rc, y + r0, F32(w.w) + r0, F32(w.lse) + r0);
+      T_HIP(hipGetLastError());
+      T_HIP(gemm32_tn(Z, ldz, hc32, CL, G + t.outT.off, CL, m.NP, CL, (int)rc, r0 == 0 ? 0.f : 1.f, F32(w.splitk), w.splitk_floats, st));
+      T_HIP(colsum_f32(Z, rc, ldz, m.NP, G + t.out_bias.off, st));
+      T_HIP(gemm32_nn(Z, ldz, xv.outT, CL, dH + r0 * CL, CL, (int)rc, CL, m.NP, 0.f, st));
+    }
+    if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
   }
   if (do_begin && !F) {
   T_HIP(launch_compact_rows(y, R, rmap, nvalid_d, reinterpret_cast<int32_t*>(ws + w.cscratch), st));

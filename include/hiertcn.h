@@ -153,7 +153,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
  *                                          short of fp32's own.)
  * In FP32 and SPLIT16 every `hidden` argument is float [R][C_last].  SPLIT16 is evaluation only.  FP32 also TRAINS (ABI 10): hiertcn_set_precision(h,
  * HIERTCN_PRECISION_FP32) followed by hiertcn_train_enable puts the handle into the fp32 training mode -- the step of model.py:135-141 as the reference takes
- * it: fp32 forward on the masters, logits [R][NP] materialised once (so: the reference's own batch sizes; the call fails past 8 GiB of logits), every
+ * it: fp32 forward on the masters, logits [R][NP] materialised in row chunks of at most tuning.train_fp32_chunk_mib MiB (the reference's own batch: one chunk; sized for such batches), every
  * product of the backward an exact-fp32 GEMM; gradients agree with fp64 autograd on the unrounded weights to ~1e-6.  model_hier with low_type 0 (TemporalConvNet) or 1 (the GRU stack) and single-level model_tcn.
  * FP32 keeps ONE logits scratch per handle: calls of a handle in that mode must not overlap on different streams (SPLIT16 and STORAGE16 have no such state).
  * The first switch to a mode must precede hiertcn_set_weights (it allocates the weight copies that set_weights fills -- for FP32 also a logits
@@ -197,7 +197,8 @@ typedef struct {
   int32_t sgrad0_min_stages;          /* catalogue stages per part of the scoring backward's forward split (default 64)                     */
   int32_t tcn_gs2_max_sessions;       /* sessions up to which the fused TCN kernel runs two sessions per workgroup (default 512; -1 never)  */
   int32_t lgru_defer_max_gib;         /* GiB of records up to which HierGRU's weight gradients are deferred to one GEMM (default 8)         */
-  int32_t reserved[11];               /* zero                                                                                               */
+  int32_t train_fp32_chunk_mib;       /* fp32 training mode: MiB of materialised fp32 logits per row chunk of the scoring layer (default 8192)   */
+  int32_t reserved[10];               /* zero                                                                                               */
 } hiertcn_tuning_t;
 int hiertcn_get_tuning(hiertcn_handle_t h, hiertcn_tuning_t* out);
 int hiertcn_set_tuning(hiertcn_handle_t h, const hiertcn_tuning_t* in);

@@ -2,7 +2,7 @@
 reference takes (model.py:135-141 on fp32 tensors, loss.py:20-21 on materialised logits) -- fp32 forward on the masters, logits materialised once,
 every product of the backward an exact-fp32 GEMM.  Held here: loss, carried state and EVERY gradient against fp64 autograd on the UNROUNDED weights
 (the 16-bit training path is checked against autograd on the bf16-rounded weights at 2e-2: tests/test_gpu_train.py); TF-form Adam on those
-gradients; a short training run whose loss trajectory follows an fp64 torch run of the same steps; the mode's contract (batch bound, model kinds)."""
+gradients; a short training run whose loss trajectory follows an fp64 torch run of the same steps; the scoring layer's row chunks; both low levels."""
 import numpy as np
 import pytest
 
@@ -176,19 +176,60 @@ def test_a_training_run_follows_the_fp64_trajectory():
     assert err32 < err16                          # ... and closer than the 16-bit path
 
 
-def test_fp32_training_mode_contract():
-    from hiertcn_amd._lib import HierTCNError
+def test_scoring_layer_in_row_chunks_equals_one_chunk():
+    """The mode materialises the logits in ROW CHUNKS of at most hiertcn_tuning_t.train_fp32_chunk_mib MiB (default 8 GiB: the reference's own batch is one
+    chunk); d Wo and d bo accumulate over the chunks.  A 324-row batch in 1 MiB chunks (273 rows + 51) against the same batch in one chunk: loss,
+    state and every gradient agree to fp32 summation order."""
     from hiertcn_amd.args import hier_tcn_args
-    from hiertcn_amd.engine import Engine
+    from hiertcn_amd.engine import Engine, metrics_dict
+    d, N, H, B, S, L = 64, 900, 32, 9, 3, 12
+    args = hier_tcn_args(item_num=N, emb_dim=d, hidden_dim=H, num_layer=2, tcn_channel=[d, d], kernel_size=5, max_activity_len=L, max_session_num=S, batch_size=B)
+    p = _trained_scale(make_params(args), args)
+    rng = np.random.default_rng(9)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    st0 = (0.3 * rng.standard_normal((B, 2 * H))).astype(np.float32)
+    got = {}
+    for name, tuning in (("one", None), ("chunks", {"train_fp32_chunk_mib": 1})):
+        eng = Engine(args, hier=True, train=True, dtype="fp32", tuning=tuning)
+        if tuning:
+            assert eng.get_tuning()["train_fp32_chunk_mib"] == 1
+        eng.set_weights(p)
+        out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(st0))
+        torch.cuda.synchronize()
+        got[name] = (metrics_dict(out["metrics8"]), out["state"].cpu().numpy(), eng.export("grads"), out["rank"].cpu().numpy() if "rank" in out else None)
+        eng.close()
+    (m1, s1, g1, r1), (m2, s2, g2, r2) = got["one"], got["chunks"]
+    for k in m1:
+        assert abs(m1[k] - m2[k]) < 1e-6 * max(1.0, abs(m1[k])), (k, m1[k], m2[k])
+    assert np.array_equal(s1, s2)
+    if r1 is not None:
+        assert np.array_equal(r1, r2)
+    for k in g1:
+        n = np.linalg.norm(g1[k])
+        assert np.linalg.norm(g1[k] - g2[k]) <= 2e-6 * max(n, 1e-30), (k, np.linalg.norm(g1[k] - g2[k]) / max(n, 1e-30))
+
+
+def test_fp32_training_mode_past_one_chunk_of_logits():
+    """9,600 rows x 300,032 items x 4 B = 11.5 GB of logits = two 8 GiB row chunks (rounds 1-5a refused this batch): the step runs, and its loss and its
+    scoring-layer bias gradient sit where the 16-bit training path puts them (that path is held to autograd in tests/test_gpu_train.py)."""
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.engine import Engine, metrics_dict
     big = hier_tcn_args(item_num=300_000, emb_dim=64, hidden_dim=32, num_layer=2, tcn_channel=[64, 64], kernel_size=3, max_activity_len=30, max_session_num=20,
                         batch_size=16)
-    eng = Engine(big, hier=True, train=True, dtype="fp32")
-    eng.set_weights(make_params(big))
+    p = make_params(big)
     rng = np.random.default_rng(0)
-    x, y, mask = make_batch(rng, 16, 20, 30, 300_000)           # 9,600 rows x 300,032 items x 4 B = 11.5 GB of logits: past the mode's bound
-    with pytest.raises(HierTCNError, match="exceed 8 GiB"):
-        eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(np.zeros((16, 64), np.float32)))
-    eng.close()
+    x, y, mask = make_batch(rng, 16, 20, 30, 300_000)
+    res = {}
+    for mode in ("fp32", "bf16"):
+        eng = Engine(big, hier=True, train=True, dtype=mode)
+        eng.set_weights(p)
+        out = eng.train_forward_backward(dev(x), dev(y), dev(mask), dev(np.zeros((16, 64), np.float32)))
+        torch.cuda.synchronize()
+        res[mode] = (metrics_dict(out["metrics8"])["loss"], eng.export("grads")["hier/tcn/dense/bias"])
+        eng.close()
+    (l32, g32), (l16, g16) = res["fp32"], res["bf16"]
+    assert np.isfinite(l32) and abs(l32 - l16) < 2e-2 * max(1.0, abs(l16)), (l32, l16)
+    assert np.linalg.norm(g32 - g16) < 3e-2 * np.linalg.norm(g32), np.linalg.norm(g32 - g16) / np.linalg.norm(g32)
 
 
 @pytest.mark.parametrize("low", ["tcn", "gru"])
