@@ -224,6 +224,39 @@ def test_exact_mode_hiergru_low_level():
     eng.close()
 
 
+@pytest.mark.parametrize("d,N", [(64, 1500), (256, 2100)])
+def test_split16_mode_hiergru_low_level(d, N):
+    """The reference's DEFAULT model (model_low_type 'gru') in the FAST parity-grade mode: fp32 low level (the exact-fp32 cell chain) + the fused scoring
+    kernel on hi + lo half operands -- state, loss, ranks and top-5 lists against the exact oracle at a trained model's logit scale."""
+    from hiertcn_amd.engine import Engine, metrics_dict
+    B, S, L = 6, 4, 12
+    args = small_args(N=N, d=d, H=d, nl=2, blocks=2, K=5, L=L, S=S, B=B)
+    args.model_low_type = "gru"
+    p = O.init_params(args, seed=3)
+    rng = np.random.default_rng(3 + d)
+    for k in p:
+        if k.endswith("dense/kernel"):
+            p[k] = (p[k] * 40).astype(np.float32)
+    x, y, mask = make_batch(rng, B, S, L, N, ragged=True)
+    st0 = (0.2 * rng.standard_normal((B, 2 * d))).astype(np.float32)
+    st0[0] = 0
+    eng = Engine(args, hier=True, dtype="split16")
+    eng.set_weights(p)
+    out = eng.forward_eval(dev(x), dev(y), dev(mask), dev(st0), want_rows=True, topk=5)
+    xl, yl, ml = as_lists(x, y, mask)
+    exact, st = O.model_hier(args, xl, yl, ml, st0, p, O.EXACT64)
+    assert np.abs(exact).max() > 1.0
+    assert np.abs(out["state"].cpu().numpy() - st).max() < 1e-5
+    ref = O.masked_loss_and_metrics(exact, y.reshape(B, S * L).astype(np.int64), N)
+    valid = y.reshape(B, S * L) > 0
+    m = metrics_dict(out["metrics8"])
+    assert abs(m["loss"] - ref["loss"]) < 1e-4 * max(1.0, abs(ref["loss"])), (m["loss"], ref["loss"])
+    assert (out["rank"].cpu().numpy().reshape(B, S * L) == ref["ranks"])[valid].mean() > 0.99
+    top_ref = O.top_k_indices(exact.reshape(-1, N), 5).reshape(B, S * L, 5)
+    assert (out["topk_idx"].cpu().numpy().reshape(B, S * L, 5) == top_ref)[valid].all(-1).mean() > 0.97
+    eng.close()
+
+
 def test_exact_mode_topk_ties_masked_rows_and_chunks():
     """tf.nn.top_k's order on the materialised rows: equal values in index order (duplicated items give bitwise equal logits), masked rows
     0..k-1, and a row count that spans several logits chunks with a ragged last one."""
