@@ -221,6 +221,26 @@ def test_gradient_exchange_dense_and_row_sparse(tmp_path):
             _check_exchange(d, want_sparse)
 
 
+def test_gradient_exchange_on_four_ranks(tmp_path):
+    """The same exchange at world 4 (the driver's scaling runs are 2, 4 and 8 ranks): dense and row-sparse item table, then the RCCL branches
+    (reduce-scatter + all-gather: 1632 floats divide by 4) -- every rank ends with the sum over the four shards, bit-identical replicas, the
+    global user count 3 + 4 + 5 + 6."""
+    for tag, frac, as_rccl in (("dense", 0.0, False), ("sparse", 2.0, False), ("rccl_sparse", 2.0, True)):
+        d = tmp_path / tag
+        d.mkdir()
+        mp.spawn(_exchange_worker, args=(4, _free_port(), str(d), frac, 6 * 2 * 5, as_rccl, "rs_ag", 96), nprocs=4, join=True)
+        before = [np.load(d / f"before{r}.npy") for r in range(4)]
+        after = [np.load(d / f"after{r}.npy") for r in range(4)]
+        users, sparse = np.load(d / "meta.npy")
+        assert sparse == (1.0 if frac > 1 else 0.0) and users == 3 + 4 + 5 + 6
+        for r in range(1, 4):
+            assert np.array_equal(after[0], after[r])
+        np.testing.assert_allclose(after[0], sum(before), rtol=1e-6, atol=1e-6)
+        if as_rccl:
+            calls = open(d / "calls.txt").read().split()
+            assert calls.count("reduce_scatter_tensor") == 1 and calls.count("all_gather_into_tensor") == 1 + 3 and "all_gather" not in calls
+
+
 def test_gradient_exchange_rccl_branches_over_host_tensors(tmp_path):
     """The branches taken when dist.get_backend() == "nccl" (RCCL), run here over gloo on host tensors: reduce_scatter_tensor +
     all_gather_into_tensor on the scoring segment when its size divides by the world size (N = 96: 2 N E + N = 1632 floats), the plain
