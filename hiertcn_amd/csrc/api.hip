@@ -119,11 +119,18 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
   if (cfg->item_num < 2) return fail(HIERTCN_ERR_INVALID, "item_num must be >= 2 (row 0 is the null id)");
   if (E < 32 || (E & 31) || E > 1024)
     return fail(HIERTCN_ERR_INVALID, "emb_dim %d unsupported: widths are multiples of 32 (one MFMA tile), zero-pad other widths on the host", E);
-  const bool low_gru = cfg->hier && cfg->low_type == 1;
-  if (cfg->low_type != 0 && !low_gru) return fail(HIERTCN_ERR_INVALID, "low_type %d: 0 (tcn) or, for hier models, 1 (gru)", cfg->low_type);
+  // low_type 1: the GRU stack of model_gru.py:33-55 as the low level of model_hier (HierGRU, model_hier.py:67-68) or, with hier = 0, as the single-level
+  // model_gru of model.py:66-67 (the embedded ids feed the stack directly: model_gru.py:46 on one-hot rows IS the embedding lookup)
+  const bool low_gru = cfg->low_type == 1;
+  if (cfg->low_type != 0 && !low_gru) return fail(HIERTCN_ERR_INVALID, "low_type %d: 0 (tcn) or 1 (gru)", cfg->low_type);
   if (low_gru) {
     if (!(cfg->hidden_dim == 64 || cfg->hidden_dim == 128 || cfg->hidden_dim == 256 || cfg->hidden_dim == 512))
       return fail(HIERTCN_ERR_INVALID, "HierGRU: hidden_dim %d feeds the scoring kernel, which is built for 64, 128, 256, 512", cfg->hidden_dim);
+    if (!cfg->hier) {
+      if (!(E == 64 || E == 128 || E == 256 || E == 512))
+        return fail(HIERTCN_ERR_INVALID, "model_gru: emb_dim %d: the GRU cells' input width is one of 64, 128, 256, 512", E);
+      if (cfg->num_layer < 1 || cfg->num_layer > HIERTCN_MAX_LAYERS) return fail(HIERTCN_ERR_INVALID, "num_layer out of range");
+    }
     // the TemporalConvNet fields do not apply: normalise them so that the shared checks / sizes below see one "block" of H channels
     cfg_local.n_blocks = 1; cfg_local.channels[0] = cfg->hidden_dim; cfg_local.kernel_size = 1;
   }
@@ -165,8 +172,8 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
   m.NP = (cfg->item_num + 63) & ~63;
   m.E = E;
   m.hier = cfg->hier ? 1 : 0;
-  m.H = m.hier ? cfg->hidden_dim : 0;
-  m.nl = m.hier ? cfg->num_layer : 0;
+  m.H = (m.hier || low_gru) ? cfg->hidden_dim : 0;   // (single-level model_gru: the stack's own width and depth; there is no across-session GRU)
+  m.nl = (m.hier || low_gru) ? cfg->num_layer : 0;
   m.HT = m.H * m.nl;
   m.K = cfg->kernel_size;
   m.n_blocks = cfg->n_blocks;
@@ -209,7 +216,12 @@ int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
       ALLOC_OR_FAIL(m.gru_bg[l], (size_t)2 * m.H);
       ALLOC_OR_FAIL(m.gru_wc[l], (size_t)(in + m.H) * m.H);
       ALLOC_OR_FAIL(m.gru_bc[l], (size_t)m.H);
-      if (low_gru) {
+    }
+  }
+  if (low_gru) {
+    for (int l = 0; l < m.nl; l++) {
+      const int in = (l == 0) ? E : m.H;
+      {
         ALLOC_OR_FAIL(m.lgru_wg[l], (size_t)(in + m.H) * 2 * m.H);
         ALLOC_OR_FAIL(m.lgru_bg[l], (size_t)2 * m.H);
         ALLOC_OR_FAIL(m.lgru_wc[l], (size_t)(in + m.H) * m.H);
@@ -316,7 +328,12 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
       HIP_TRY(launch_copy_pad_f32(w->gru_gate_bias[l], m.gru_bg[l], 2 * m.H, 2 * m.H, 0.f, st));
       HIP_TRY(launch_transpose_f32(w->gru_cand_kernel[l], m.gru_wc[l], in + m.H, m.H, st));
       HIP_TRY(launch_copy_pad_f32(w->gru_cand_bias[l], m.gru_bc[l], m.H, m.H, 0.f, st));
-      if (m.low_gru) {
+    }
+  }
+  if (m.low_gru) {   // the GRU stack of model_gru.py:33-45 (HierGRU's low level, or the single-level model_gru)
+    for (int l = 0; l < m.nl; l++) {
+      const int in = (l == 0) ? E : m.H;
+      {
         if (!w->low_gate_kernel[l] || !w->low_gate_bias[l] || !w->low_cand_kernel[l] || !w->low_cand_bias[l])
           return fail(HIERTCN_ERR_INVALID, "HierGRU: low-level GRU layer %d weights missing", l);
         HIP_TRY(launch_transpose_f32(w->low_gate_kernel[l], m.lgru_wg[l], in + m.H, 2 * m.H, st));

@@ -231,12 +231,17 @@ static hipError_t launch_exact_low_gru(const ModelDev& m, const ExactDev& x, con
   b.keep_all = 0;
   b.hidden32 = hidden;
   b.persist = n_sess <= 1024 ? reinterpret_cast<float*>(take(low_gru_persist_floats(m, n_sess, L) * 4)) : nullptr;
-  XGemm g = {};
-  g.A = x.emb; g.lda = m.E; g.ids = ids; g.n_tab = m.N;
-  g.Wt = x.projT; g.taps = 1; g.Cin = m.E; g.M = R; g.N = m.E;
-  g.seq_init = sproj; g.Lseq = L;
-  g.out = b.uf; g.ldo = m.E; g.epi = XEPI_LINEAR;
-  hipError_t e = launch_xgemm(g, st);
+  hipError_t e;
+  if (!m.hier) {   // single-level model_gru: the embedded ids are the stack's input (model_gru.py:46 on one-hot rows = the lookup)
+    e = launch_xembed_rows(x.emb, ids, R, m.E, m.N, b.uf, st);
+  } else {
+    XGemm g = {};
+    g.A = x.emb; g.lda = m.E; g.ids = ids; g.n_tab = m.N;
+    g.Wt = x.projT; g.taps = 1; g.Cin = m.E; g.M = R; g.N = m.E;
+    g.seq_init = sproj; g.Lseq = L;
+    g.out = b.uf; g.ldo = m.E; g.epi = XEPI_LINEAR;
+    e = launch_xgemm(g, st);
+  }
   if (e != hipSuccess) return e;
   return launch_low_gru_bufs(m, ids, sproj, n_sess, L, nullptr, b, st);
 }

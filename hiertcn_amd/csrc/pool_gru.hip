@@ -547,6 +547,14 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
   if (b.hidden32) {   // exact numerics mode: b.uf already holds the fp32 projection (exact.hip)
     hipLaunchKernelGGL(k_len_f32, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.uf, n_sess, L, E, b.seq_len);
     if ((e = hipGetLastError()) != hipSuccess) return e;
+  } else if (!m.hier) {
+    // single-level model_gru (model.py:66-67): model_gru.py:46's 'emb' dense on one-hot rows IS the embedding lookup -- the gathered rows feed the stack
+    if ((e = launch_embed_rows(m, x, R, b.u16, st)) != hipSuccess) return e;
+    if (!b.keep_all && lgru_tile_applies(m, n_sess) && (E % 8) == 0)
+      hipLaunchKernelGGL(k_len_u16, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.seq_len);
+    else
+      hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, b.u16, n_sess, L, E, b.uf, b.seq_len);
+    if ((e = hipGetLastError()) != hipSuccess) return e;
   } else {
     if ((e = launch_embed_rows(m, x, R, b.a_emb, st)) != hipSuccess) return e;
     {  // 'emb' projection of [e, state] (model_gru.py:46), rounded to the 16-bit storage type like the TCN's input

@@ -55,7 +55,7 @@ size_t train_layout(const ModelDev& m, TrainCtx& t) {
       seg(t.res_bias[i], (size_t)m.C[i]);
     }
   }
-  for (int l = 0; l < m.nl; l++) {
+  for (int l = 0; l < m.nl && m.hier; l++) {   // the across-session GRU (model_hier.py:36-37); the single-level model_gru has none
     const int in = (l == 0) ? m.E : m.H;
     seg(t.wg[l], (size_t)(in + m.H) * 2 * m.H);
     seg(t.bg[l], (size_t)2 * m.H);
@@ -105,8 +105,10 @@ hipError_t train_enable(ModelDev& m, TrainCtx& t) {
     if (t.resT[i].n) m.res_bias[i] = M + t.res_bias[i].off;
   }
   for (int l = 0; l < m.nl; l++) {
-    m.gru_wg[l] = M + t.wg[l].off; m.gru_bg[l] = M + t.bg[l].off;
-    m.gru_wc[l] = M + t.wc[l].off; m.gru_bc[l] = M + t.bc[l].off;
+    if (m.hier) {
+      m.gru_wg[l] = M + t.wg[l].off; m.gru_bg[l] = M + t.bg[l].off;
+      m.gru_wc[l] = M + t.wc[l].off; m.gru_bc[l] = M + t.bc[l].off;
+    }
     if (m.low_gru) {
       m.lgru_wg[l] = M + t.lwg[l].off; m.lgru_bg[l] = M + t.lbg[l].off;
       m.lgru_wc[l] = M + t.lwc[l].off; m.lgru_bc[l] = M + t.lbc[l].off;
@@ -569,7 +571,12 @@ hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weig
       if ((e = cp(d->gru_gate_bias[l], t.bg[l], (size_t)2 * H)) != hipSuccess) return e;
       if ((e = tr(d->gru_cand_kernel[l], A + t.wc[l].off, H, K)) != hipSuccess) return e;
       if ((e = cp(d->gru_cand_bias[l], t.bc[l], (size_t)H)) != hipSuccess) return e;
-      if (m.low_gru) {
+    }
+  }
+  if (m.low_gru) {
+    for (int l = 0; l < m.nl; l++) {
+      const int K = ((l == 0) ? E : H) + H;
+      {
         if ((e = tr(d->low_gate_kernel[l], A + t.lwg[l].off, 2 * H, K)) != hipSuccess) return e;
         if ((e = cp(d->low_gate_bias[l], t.lbg[l], (size_t)2 * H)) != hipSuccess) return e;
         if ((e = tr(d->low_cand_kernel[l], A + t.lwc[l].off, H, K)) != hipSuccess) return e;
@@ -900,8 +907,8 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   if (do_begin && F) {
     // ---- forward on the masters, everything kept in fp32 (model_hier.py:39-93 as exact.hip computes it) ----
     const ExactDev xv = fp32_master_view(m, t);
-    if (!m.hier) {   // single-level model_tcn (model.py:71-73): block 0 reads the embedded ids
-      T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, F32(w.f_act[0]), st));
+    if (!m.hier) {   // single-level model_tcn (model.py:71-73): block 0 reads the embedded ids; model_gru (:66-67): the GRU stack does (lb.uf)
+      T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, m.low_gru ? F32(w.lg_uf) : F32(w.f_act[0]), st));
     } else {
     T_HIP(launch_xsession_pool(m, xv, y, n_sess, L, pooled, st));
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
@@ -1308,7 +1315,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     float* tmp = da; da = dprev; dprev = tmp;
   }
   if (!m.hier) {
-    // single-level model_tcn (model.py:56-57,71-73): block 0 reads the embedded ids directly
+    // single-level model_tcn / model_gru (model.py:56-57,66-67,71-73): block 0 / the GRU stack reads the embedded ids directly
     hipLaunchKernelGGL(k_scatter_add_rows, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, G + t.emb.off, x, da, R, E, m.N);
     T_HIP(hipGetLastError());
 #undef F32

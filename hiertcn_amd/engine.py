@@ -72,7 +72,8 @@ def config_from_args(args, hier: bool = True, train: bool = False) -> _lib.Confi
     for i, c in enumerate(ch):
         cfg.channels[i] = c
     cfg.hier = 1 if hier else 0
-    low = getattr(args, "model_low_type", "tcn") if hier else "tcn"
+    # hier: the low level of model_hier (model_hier.py:62-69); single level: model.py:66-73 dispatches on model_type ('gru': model_gru, else model_tcn)
+    low = getattr(args, "model_low_type", "tcn") if hier else ("gru" if getattr(args, "model_type", "tcn") == "gru" else "tcn")
     if low not in ("tcn", "gru"):
         raise HierTCNError(f"model_low_type {low!r}: 'tcn' (HierTCN) and 'gru' (HierGRU) are built")
     cfg.low_type = 1 if low == "gru" else 0
@@ -114,10 +115,11 @@ class Engine:
         self._args_for_shapes = args
         self.N = int(self.cfg.item_num)
         self.E = int(self.cfg.emb_dim)
-        self.H = int(self.cfg.hidden_dim) if hier else 0
-        self.nl = int(self.cfg.num_layer) if hier else 0
-        self.HT = self.H * self.nl
         self.low_gru = bool(self.cfg.low_type == 1)
+        self.H = int(self.cfg.hidden_dim) if (hier or self.low_gru) else 0      # (single-level model_gru: the stack's width / depth)
+        self.nl = int(self.cfg.num_layer) if (hier or self.low_gru) else 0
+        self.HT = self.H * self.nl if hier else 0                                # the carried state of model_hier; single-level models carry none
+        self.kind = "hier" if hier else ("gru" if self.low_gru else "tcn")      # scope of the TF variable names (model.py:66-88)
         self.C = self.H if self.low_gru else int(self.cfg.channels[self.cfg.n_blocks - 1])
         self._h = C.c_void_p()
         with torch.cuda.device(self.device):
@@ -194,7 +196,7 @@ class Engine:
     def set_weights(self, params: Dict[str, "np.ndarray | torch.Tensor"], root: Optional[str] = None):
         """params: TF-named tensors in the reference layout; numpy or torch, any
         float dtype; uploaded as fp32 and converted on the device by hiertcn_set_weights."""
-        root = root or ("hier" if self.hier else "tcn")
+        root = root or self.kind
         tcn = (f"{root}/gru" if self.low_gru else f"{root}/tcn") if self.hier else root
         keep = []
 
@@ -238,12 +240,15 @@ class Engine:
                 w.gru_gate_bias[l] = dev(f"{pre}/gates/bias", (2 * H,))
                 w.gru_cand_kernel[l] = dev(f"{pre}/candidate/kernel", (inp + H, H))
                 w.gru_cand_bias[l] = dev(f"{pre}/candidate/bias", (H,))
-                if self.low_gru:   # dynamic_rnn's scope 'rnn' under model_gru's 'gru' (model_gru.py:47)
-                    lo = f"{tcn}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
-                    w.low_gate_kernel[l] = dev(f"{lo}/gates/kernel", (inp + H, 2 * H))
-                    w.low_gate_bias[l] = dev(f"{lo}/gates/bias", (2 * H,))
-                    w.low_cand_kernel[l] = dev(f"{lo}/candidate/kernel", (inp + H, H))
-                    w.low_cand_bias[l] = dev(f"{lo}/candidate/bias", (H,))
+                inp = H
+        if self.low_gru:   # dynamic_rnn's scope 'rnn' under model_gru's 'gru' (model_gru.py:47)
+            inp = E
+            for l in range(self.nl):
+                lo = f"{tcn}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+                w.low_gate_kernel[l] = dev(f"{lo}/gates/kernel", (inp + H, 2 * H))
+                w.low_gate_bias[l] = dev(f"{lo}/gates/bias", (2 * H,))
+                w.low_cand_kernel[l] = dev(f"{lo}/candidate/kernel", (inp + H, H))
+                w.low_cand_bias[l] = dev(f"{lo}/candidate/bias", (H,))
                 inp = H
         with torch.cuda.device(self.device):
             self._ck(self.lib.hiertcn_set_weights(self._h, C.byref(w), self._stream()))
@@ -527,12 +532,12 @@ class Engine:
     def export(self, which: str = "weights", root: Optional[str] = None) -> Dict[str, np.ndarray]:
         """Masters ('weights') or gradients ('grads') as {TF variable name: fp32 ndarray in the reference layout}."""
         from .params import param_shapes
-        kind = "hier" if self.hier else "tcn"
+        kind = self.kind
         root = root or kind
         shapes = param_shapes(self._args_for_shapes, kind)
         bufs = {k: torch.zeros(v, dtype=torch.float32, device=self.device) for k, v in shapes.items()}
         w = _lib.Weights()
-        tcn = ("hier/gru" if self.low_gru else "hier/tcn") if self.hier else "tcn"
+        tcn = ("hier/gru" if self.low_gru else "hier/tcn") if self.hier else kind
         g = lambda k: bufs[k].data_ptr()  # noqa: E731
         w.emb_kernel = g(f"{kind}/emb/kernel")
         if self.hier:
@@ -544,9 +549,10 @@ class Engine:
                 w.res_kernel[i], w.res_bias[i] = g(f"{pre}/dense/kernel"), g(f"{pre}/dense/bias")
         w.out_kernel, w.out_bias = g(f"{tcn}/dense/kernel"), g(f"{tcn}/dense/bias")
         for l in range(self.nl):
-            pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
-            w.gru_gate_kernel[l], w.gru_gate_bias[l] = g(f"{pre}/gates/kernel"), g(f"{pre}/gates/bias")
-            w.gru_cand_kernel[l], w.gru_cand_bias[l] = g(f"{pre}/candidate/kernel"), g(f"{pre}/candidate/bias")
+            if self.hier:
+                pre = f"hier/multi_rnn_cell/cell_{l}/gru_cell"
+                w.gru_gate_kernel[l], w.gru_gate_bias[l] = g(f"{pre}/gates/kernel"), g(f"{pre}/gates/bias")
+                w.gru_cand_kernel[l], w.gru_cand_bias[l] = g(f"{pre}/candidate/kernel"), g(f"{pre}/candidate/bias")
             if self.low_gru:
                 lo = f"{tcn}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
                 w.low_gate_kernel[l], w.low_gate_bias[l] = g(f"{lo}/gates/kernel"), g(f"{lo}/gates/bias")

@@ -317,32 +317,40 @@ class HierTCNModel:
 
 
 class TcnModel:
-    """The single-level model (model.py:56-57,71-73; run with --model_type tcn): ids [B, T] ->
-    embedding (tcn/emb/kernel) -> TemporalConvNet -> scoring, no carried state.  Widths that are not a
-    multiple of 32 (BASELINE.json config 1: d = 100) are zero-padded on upload (params.pad_widths)."""
+    """The single-level models (model.py:56-57,66-73): ids [B, T] -> embedding (<scope>/emb/kernel) -> low level -> scoring, no carried state.
+    KIND 'tcn' (run with --model_type tcn): TemporalConvNet; widths that are not a multiple of 32 (BASELINE.json config 1: d = 100) are zero-padded
+    on upload (params.pad_widths).  KIND 'gru' (GruModel below, --model_type gru): the GRU stack of model_gru.py:33-55."""
+    KIND = "tcn"
 
-    def __init__(self, args, params: Optional[dict] = None, name: str = "tcn", seed: int = 2, train: Optional[bool] = None):
+    def _to_kind(self, params: dict) -> dict:
+        K, n = self.KIND, self.name
+        return {(K + k[len(n):] if k.startswith(n + "/") else k): v for k, v in params.items()}
+
+    def __init__(self, args, params: Optional[dict] = None, name: Optional[str] = None, seed: int = 2, train: Optional[bool] = None):
         from .params import pad_widths
-        self.args, self.name, self.hier = args, name, False
+        K = self.KIND
+        self.args, self.name, self.hier = args, (name or K), False
         self.trainable = bool(getattr(args, "train", False)) if train is None else bool(train)
-        self._params = params if params is not None else init_params(args, seed, "tcn")
-        renamed = {("tcn" + k[len(name):] if k.startswith(name + "/") else k): v for k, v in self._params.items()}
-        self._dev_args, dev_params = pad_widths(args, renamed, "tcn")
-        # width-padded models (d = 100 -> 128) train as they are: the padded channels stay exactly zero (params.unpad_widths)
+        self._params = params if params is not None else init_params(args, seed, K)
+        self._dev_args, dev_params = pad_widths(args, self._to_kind(self._params), K)
+        if K == "gru":   # (Engine picks the single-level low level from args.model_type, as model.py:66-73 does)
+            self._dev_args.model_type = "gru"
+        # width-padded models (d = 100 -> 128; model_gru's hidden_dim 200 -> 256) train as they are: the padded channels stay exactly zero (params.unpad_widths)
         self._padded = (self._dev_args.emb_dim != int(getattr(args, "emb_dim", 128)) or
-                        list(self._dev_args.tcn_channel) != [int(c) for c in args.tcn_channel])
+                        list(self._dev_args.tcn_channel) != [int(c) for c in args.tcn_channel] or
+                        int(self._dev_args.hidden_dim) != int(args.hidden_dim))
         self.engine = Engine(self._dev_args, hier=False, train=self.trainable)
-        self.engine.set_weights(dev_params, root="tcn")
+        self.engine.set_weights(dev_params, root=K)
 
     @property
     def params(self) -> dict:
         if self.trainable:
+            K = self.KIND
             dev = self.engine.export("weights", root=self.name)
             if self._padded:
                 from .params import unpad_widths
-                tcn_named = {("tcn" + k[len(self.name):] if k.startswith(self.name + "/") else k): v for k, v in dev.items()}
-                cut = unpad_widths(self.args, tcn_named, "tcn")
-                dev = {(self.name + k[3:] if k.startswith("tcn/") else k): v for k, v in cut.items()}
+                cut = unpad_widths(self.args, self._to_kind(dev), K)
+                dev = {(self.name + k[len(K):] if k.startswith(K + "/") else k): v for k, v in cut.items()}
             self._params = dev
         return self._params
 
@@ -353,8 +361,7 @@ class TcnModel:
     def set_parameters(self, params: dict):
         from .params import pad_widths
         self._params = params
-        renamed = {("tcn" + k[len(self.name):] if k.startswith(self.name + "/") else k): v for k, v in params.items()}
-        self.engine.set_weights(pad_widths(self.args, renamed, "tcn")[1], root="tcn")
+        self.engine.set_weights(pad_widths(self.args, self._to_kind(params), self.KIND)[1], root=self.KIND)
 
     def eval_step(self, x, y, want_pred: bool = False):
         """One sess.run of evaluate_nn's fetch list (run_nn_xing.py:43-47): x, y [B, T] ids."""
@@ -406,11 +413,18 @@ class TcnModel:
         return dict(loss=m["loss"], user_count=m["user_count"])
 
 
+class GruModel(TcnModel):
+    """The single-level model_gru (model.py:66-67 -> model_gru.py:16-63; run with --model_type gru): ids [B, T] -> embedding (gru/emb/kernel; the
+    'emb' dense of model_gru.py:46 on one-hot rows) -> MultiRNNCell of GRUCells under dynamic_rnn from the zero state, sequence_length = the count of
+    non-null input steps (:51, :109-118) -> scoring dense (:57).  hidden_dim is zero-padded to the next kernel width (args.py:306-308 sets 200)."""
+    KIND = "gru"
+
+
 def get_scope(args, name: str):
     """tf.variable_scope(name, reuse=tf.AUTO_REUSE) (model_hier.py:28, model_tcn.py:26): the first
     use of a scope creates its variables (glorot / zeros / gate-bias 1.0), later uses share them."""
     if name not in _SCOPES:
-        _SCOPES[name] = HierTCNModel(args, None, name) if name.startswith("hier") else TcnModel(args, None, name)
+        _SCOPES[name] = HierTCNModel(args, None, name) if name.startswith("hier") else (GruModel if name.startswith("gru") else TcnModel)(args, None, name)
     return _SCOPES[name]
 
 

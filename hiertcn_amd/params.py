@@ -42,6 +42,21 @@ def param_shapes(args, model: str = "hier") -> Dict[str, tuple]:
         s["hier/gru/dense/kernel"] = (H, N)
         s["hier/gru/dense/bias"] = (N,)
         return s
+    if model == "gru":
+        # single-level model_gru (model.py:66-67 -> model_gru.py:16-63 under scope 'gru'): 'emb' dense on the one-hot input = the item table,
+        # the GRU stack under dynamic_rnn's scope 'rnn' [TF-sem], the scoring dense on the top layer's outputs
+        s["gru/emb/kernel"] = (N, E)
+        inp = E
+        for l in range(nl):
+            pre = f"gru/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+            s[f"{pre}/gates/kernel"] = (inp + H, 2 * H)
+            s[f"{pre}/gates/bias"] = (2 * H,)
+            s[f"{pre}/candidate/kernel"] = (inp + H, H)
+            s[f"{pre}/candidate/bias"] = (H,)
+            inp = H
+        s["gru/dense/kernel"] = (H, N)
+        s["gru/dense/bias"] = (N,)
+        return s
     if model == "hier":
         root = "hier/tcn"
         s["hier/emb/kernel"] = (N, E)
@@ -100,6 +115,9 @@ def pad_widths(args, params: Dict[str, np.ndarray], model: str = "hier", multipl
     (sigmoid(0) = 0.5), choose a multiple of 32."""
     import copy
 
+    if model == "gru":
+        return _pad_gru(args, params)
+
     def up(c):
         return -(-int(c) // multiple) * multiple
 
@@ -126,11 +144,73 @@ def pad_widths(args, params: Dict[str, np.ndarray], model: str = "hier", multipl
     return a, out
 
 
+GRU_WIDTHS = (64, 128, 256, 512)   # what the scoring kernels, which read the stack's output rows, are built for
+
+
+def _gru_index(shape0, in0, H0, in1, H1, kernel_cols):
+    """index arrays that place a [in0 + H0, kernel_cols * H0] GRU kernel inside its [in1 + H1, kernel_cols * H1] padded form: input rows first,
+    then the state rows; the columns in blocks of H (gates: r | u, customed_gru_cell.py:324)."""
+    rows = np.concatenate([np.arange(in0), in1 + np.arange(H0)])
+    cols = np.concatenate([b * H1 + np.arange(H0) for b in range(kernel_cols)])
+    return rows, cols
+
+
+def _pad_gru(args, params):
+    """Single-level model_gru (model.py:66-67; args.py:306-308 sets hidden_dim = 200 for it): zero-pad the GRU width up to the next width the
+    kernels are built for.  A padded unit stays exactly zero: its state starts at zero (dynamic_rnn's zero state, model_gru.py:47-53), its
+    candidate is tanh(0) = 0, so h' = u * 0 + (1 - u) * 0 whatever its gates are; its rows of the next layer's kernels and of the scoring
+    kernel are zero, so no logit changes and no gradient reaches a padded entry (zero gradients leave Adam's update at exactly zero)."""
+    import copy
+    a = copy.copy(args)
+    H0, nl, E = int(args.hidden_dim), int(args.num_layer), int(getattr(args, "emb_dim", 128))
+    H1 = next((w for w in GRU_WIDTHS if w >= H0), None)
+    if H1 is None:
+        raise ValueError(f"hidden_dim {H0}: the GRU stack is built for widths up to {GRU_WIDTHS[-1]}")
+    a.hidden_dim = H1
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in param_shapes(a, "gru").items():
+        src = np.asarray(params[name], dtype=np.float32)
+        dst = np.zeros(shape, np.float32)
+        l = int(name.split("/cell_")[1].split("/")[0]) if "/cell_" in name else 0
+        in0 = E if l == 0 else H0
+        in1 = E if l == 0 else H1
+        if name.endswith("gates/kernel") or name.endswith("candidate/kernel"):
+            r, c = _gru_index(src.shape[0], in0, H0, in1, H1, 2 if "gates" in name else 1)
+            dst[np.ix_(r, c)] = src
+        elif name.endswith("gates/bias"):
+            dst[np.concatenate([np.arange(H0), H1 + np.arange(H0)])] = src
+        else:   # item table, candidate bias, scoring kernel [H, N] / bias: leading corner
+            dst[tuple(slice(0, n) for n in src.shape)] = src
+        out[name] = dst
+    return a, out
+
+
+def _unpad_gru(args, padded):
+    H0, E = int(args.hidden_dim), int(getattr(args, "emb_dim", 128))
+    out: Dict[str, np.ndarray] = {}
+    for name, shape in param_shapes(args, "gru").items():
+        src = np.asarray(padded[name])
+        H1 = src.shape[-1] // 2 if name.endswith("gates/kernel") or name.endswith("gates/bias") else (src.shape[-1] if "gru_cell" in name else src.shape[0])
+        l = int(name.split("/cell_")[1].split("/")[0]) if "/cell_" in name else 0
+        in0 = E if l == 0 else H0
+        in1 = E if l == 0 else H1
+        if name.endswith("gates/kernel") or name.endswith("candidate/kernel"):
+            r, c = _gru_index(shape[0], in0, H0, in1, H1, 2 if "gates" in name else 1)
+            out[name] = np.ascontiguousarray(src[np.ix_(r, c)])
+        elif name.endswith("gates/bias"):
+            out[name] = np.ascontiguousarray(src[np.concatenate([np.arange(H0), H1 + np.arange(H0)])])
+        else:
+            out[name] = np.ascontiguousarray(src[tuple(slice(0, n) for n in shape)])
+    return out
+
+
 def unpad_widths(args, padded: Dict[str, np.ndarray], model: str = "hier") -> Dict[str, np.ndarray]:
     """Inverse of pad_widths: cut the tensors of a width-padded model back to the shapes of `args` (what a checkpoint holds).  The cut
     entries are exactly zero for a model that was created by pad_widths and trained on the device: a zero-padded channel has zero
     activations, so every gradient into its weights and every gradient flowing back through it is exactly zero, and Adam on a
     zero gradient with zero moments is a zero update."""
+    if model == "gru":
+        return _unpad_gru(args, padded)
     E0 = int(getattr(args, "emb_dim", 128))
     out: Dict[str, np.ndarray] = {}
     for name, shape in param_shapes(args, model).items():

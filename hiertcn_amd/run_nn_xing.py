@@ -59,9 +59,10 @@ def evaluate_nn(args, loader, sess, prefix="test", warm_start=None):
 def run_nn(args, loader_train, loader_validate, loader_test, warm_start=None, sess=None):
     """run_nn_xing.py:101-192: same epoch / lr / save / test cadence as run_hier, no carried state."""
     from . import checkpoint
-    from .model import TcnModel
+    from .model import GruModel, TcnModel
 
-    model = sess if sess is not None else TcnModel(args)
+    # model.py:66-73: model_type 'gru' builds model_gru, 'tcn' model_tcn -- same loop, same fetches
+    model = sess if sess is not None else (GruModel if getattr(args, "model_type", "tcn") == "gru" else TcnModel)(args)
     epoch = 0
     if args.load:
         fname = args.load_path + str(args.load_epoch) + ".ckpt"

@@ -3,7 +3,7 @@
     python -m hiertcn_amd.run_xing --model_type hier --model_low_type tcn [flags of args.py]
 
 uniquify the log directory, build the three loaders from dataset/interactions.csv, dispatch on
-model_type.  Only the hot-path models are built: 'hier' (model_low_type 'tcn' = HierTCN and 'gru' = HierGRU), 'tcn', and the
+model_type.  Only the hot-path models are built: 'hier' (model_low_type 'tcn' = HierTCN and 'gru' = HierGRU), 'tcn', 'gru' (single level), and the
 mixture-output models 'tcn_gmm' / 'gru_gmm' (evaluation flow: run_gmm_xing.py).
 """
 from __future__ import annotations
@@ -37,7 +37,7 @@ def main(argv=None):
     Loader = Dataloader_hier_model_xing if hier else Dataloader_single_level_model_xing
     splits = ("train", "train", "train") if args.warm_start else ("train", "validate", "test")  # :20-35
     loader_train, loader_validate, loader_test = (Loader(args, s, rank=rank, world=world) for s in splits)
-    if args.model_type == "tcn":
+    if args.model_type in ("tcn", "gru"):   # model.py:66-73: the single-level models, one loop (run_nn_xing.py)
         from .run_nn_xing import run_nn
         return run_nn(args, loader_train, loader_validate, loader_test)
     if args.model_type == "hier":
@@ -46,7 +46,7 @@ def main(argv=None):
     if args.model_type in ("tcn_gmm", "gru_gmm"):   # model.py:74-77
         from .run_gmm_xing import run_gmm
         return run_gmm(args, loader_train, loader_validate, loader_test)
-    raise NotImplementedError(f"model_type {args.model_type!r}: 'hier', 'tcn', 'tcn_gmm' and 'gru_gmm' are built (SURVEY.md 8)")
+    raise NotImplementedError(f"model_type {args.model_type!r}: 'hier', 'tcn', 'gru', 'tcn_gmm' and 'gru_gmm' are built (SURVEY.md 8)")
 
 
 if __name__ == "__main__":

@@ -68,15 +68,18 @@ enum hiertcn_status {
 typedef struct {
   int32_t item_num;                      /* N, args.item_num (row 0 = null id)            */
   int32_t emb_dim;                       /* E = C0: 'emb' units                            */
-  int32_t hidden_dim;                    /* H, args.hidden_dim (ignored when hier == 0)    */
+  int32_t hidden_dim;                    /* H, args.hidden_dim (ignored when hier == 0 and low_type == 0) */
   int32_t num_layer;                     /* nl, args.num_layer                             */
   int32_t kernel_size;                   /* K, args.kernel_size                            */
   int32_t n_blocks;                      /* len(args.tcn_channel)                          */
   int32_t channels[HIERTCN_MAX_BLOCKS];  /* args.tcn_channel                               */
-  int32_t hier;                          /* 1: model_hier low level; 0: single-level model_tcn */
-  int32_t low_type;                      /* args.model_low_type (hier only): 0 'tcn' = HierTCN; 1 'gru' = HierGRU, the reference's
+  int32_t hier;                          /* 1: model_hier low level; 0: single-level model_tcn / model_gru (model.py:66-73) */
+  int32_t low_type;                      /* hier == 1: args.model_low_type -- 0 'tcn' = HierTCN; 1 'gru' = HierGRU, the reference's
                                           * default (args.py:40; model_hier.py:67-68 -> model_gru.py:16-63): n_blocks / channels /
-                                          * kernel_size are ignored, the scoring layer reads hidden_dim channels */
+                                          * kernel_size are ignored, the scoring layer reads hidden_dim channels.
+                                          * hier == 0: 0 = model_tcn; 1 = the single-level model_gru (args.model_type 'gru', model.py:66-67):
+                                          * the embedded ids feed the same GRU stack directly (model_gru.py:46 on one-hot rows is the
+                                          * embedding lookup), zero initial state, sequence_length = the count of non-null input steps */
 } hiertcn_config_t;
 
 /* Device pointers to fp32 tensors in the REFERENCE's variable layout:
@@ -106,8 +109,9 @@ typedef struct {
   const float* gru_gate_bias[HIERTCN_MAX_LAYERS];
   const float* gru_cand_kernel[HIERTCN_MAX_LAYERS];
   const float* gru_cand_bias[HIERTCN_MAX_LAYERS];
-  /* HierGRU only (low_type == 1): hier/gru/rnn/multi_rnn_cell/cell_{l}/gru_cell/{gates,candidate}/{kernel,bias};
-   * proj_kernel is then hier/gru/emb/kernel, out_kernel / out_bias hier/gru/dense/{kernel [H][N], bias} */
+  /* low_type == 1 only: hier/gru/rnn/multi_rnn_cell/cell_{l}/gru_cell/{gates,candidate}/{kernel,bias};
+   * proj_kernel is then hier/gru/emb/kernel, out_kernel / out_bias hier/gru/dense/{kernel [H][N], bias}
+   * (single-level model_gru: gru/rnn/..., emb_kernel = gru/emb/kernel, out_kernel / out_bias = gru/dense/{kernel, bias}, no proj_kernel) */
   const float* low_gate_kernel[HIERTCN_MAX_LAYERS];
   const float* low_gate_bias[HIERTCN_MAX_LAYERS];
   const float* low_cand_kernel[HIERTCN_MAX_LAYERS];

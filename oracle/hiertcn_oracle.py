@@ -147,6 +147,20 @@ def init_params(args, seed=2, model="hier", emb_dim=None):
         p["hier/gru/dense/kernel"] = _glorot(rng, (H, N), H, N)
         p["hier/gru/dense/bias"] = np.zeros(N, np.float32)
         return p
+    if model == "gru":
+        # single-level model_gru (model.py:66-67; model_gru.py:16-63 under scope 'gru'): the 'emb' dense on one-hot rows is the item table
+        p["gru/emb/kernel"] = _glorot(rng, (N, E), N, E)
+        inp = E
+        for l in range(nl):
+            pre = f"gru/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+            p[f"{pre}/gates/kernel"] = _glorot(rng, (inp + H, 2 * H), inp + H, 2 * H)
+            p[f"{pre}/gates/bias"] = np.ones(2 * H, np.float32)
+            p[f"{pre}/candidate/kernel"] = _glorot(rng, (inp + H, H), inp + H, H)
+            p[f"{pre}/candidate/bias"] = np.zeros(H, np.float32)
+            inp = H
+        p["gru/dense/kernel"] = _glorot(rng, (H, N), H, N)
+        p["gru/dense/bias"] = np.zeros(N, np.float32)
+        return p
     if model == "hier":
         root = "hier/tcn"
         p["hier/emb/kernel"] = _glorot(rng, (N, E), N, E)
@@ -313,7 +327,12 @@ def model_gru_low(args, xs, params, root="hier/gru", num: Numerics = EXACT64, re
     carried through unchanged; scoring dense on the outputs (:57)."""
     dt = num.dtype
     H, nl = int(args.hidden_dim), int(args.num_layer)
-    u = num.act(dense(xs.astype(dt), params[f"{root}/emb/kernel"]))
+    xs = np.asarray(xs)
+    if np.issubdtype(xs.dtype, np.integer):
+        # single-level model_gru (model.py:56,66-67): x = one_hot(id) * sign(id), so the 'emb' dense (:46) is the embedding lookup with row 0 -> 0
+        u = num.act(embed_ids(xs, params[f"{root}/emb/kernel"], dt))
+    else:
+        u = num.act(dense(xs.astype(dt), params[f"{root}/emb/kernel"]))
     length = seq_length(u)
     B, L, _ = u.shape
     state = np.zeros((B, H * nl), dt)
@@ -327,6 +346,14 @@ def model_gru_low(args, xs, params, root="hier/gru", num: Numerics = EXACT64, re
     if return_hidden:
         return outs
     return dense(outs, params[f"{root}/dense/kernel"], params[f"{root}/dense/bias"])
+
+
+def model_gru(args, x_ids, params, name="gru", num: Numerics = EXACT64, return_hidden=False):
+    """The single-level model_gru as model.py:66-67 builds it on XING (model_gru.py:16-63, scope 'gru'): integer ids [B, T] -> logits
+    [B, T, N].  dynamic_rnn starts from the zero state with sequence_length = length(embedded x) (:47-53, :109-118): the COUNT of steps whose
+    id is not null, used as a prefix length -- a sequence that opens with the loader's null step (data_loader.py: x is y shifted right) is cut
+    one step short and its last real step outputs zeros (logits = the dense bias)."""
+    return model_gru_low(args, np.asarray(x_ids).astype(np.int64), params, name, num, return_hidden)
 
 
 def session_mean_pool(y_ids, params, dtype=np.float64):
