@@ -1,5 +1,5 @@
 """Pieces shared by the hier and single-level run loops: the epoch accumulator behind
-`results.txt`, the scalar event log that stands in for the TensorBoard FileWriter, and the
+`results.txt`, the scalar log (TensorBoard event files + `scalars.jsonl`) in the place of tf.summary.FileWriter, and the
 learning-rate schedule.
 
 Reference: run_hier_xing.py:96-106,152-201 / run_nn_xing.py:20-27,50-95 (the six running sums, the
@@ -76,20 +76,86 @@ class EpochMeter:
             f.write("{} {}, {} {}\n".format(t[4], m[t[4]], t[5], m[t[5]]))
 
 
+# ---- TensorBoard event files (what tf.summary.FileWriter writes, run_hier_xing.py:233-235,311-345), without TensorFlow ------------------------------
+# A file is a sequence of TFRecords -- uint64 length, masked CRC-32C of those 8 bytes, the payload, masked CRC-32C of the payload -- whose payloads
+# are serialised `Event` protos: {1: wall_time double, 2: step int64, 3: file_version string | 5: Summary {1: repeated Value {1: tag, 2: simple_value float}}}.
+_CRC32C_TABLE = []
+
+
+def crc32c(data: bytes) -> int:
+    """CRC-32C (Castagnoli, reflected polynomial 0x82F63B78); crc32c(b"123456789") == 0xE3069283."""
+    if not _CRC32C_TABLE:
+        for i in range(256):
+            c = i
+            for _ in range(8):
+                c = (c >> 1) ^ 0x82F63B78 if c & 1 else c >> 1
+            _CRC32C_TABLE.append(c)
+    c = 0xFFFFFFFF
+    for byte in data:
+        c = _CRC32C_TABLE[(c ^ byte) & 0xFF] ^ (c >> 8)
+    return c ^ 0xFFFFFFFF
+
+
+def _masked_crc(data: bytes) -> int:
+    c = crc32c(data)
+    return ((((c >> 15) | (c << 17)) & 0xFFFFFFFF) + 0xA282EAD8) & 0xFFFFFFFF
+
+
+def _varint(n: int) -> bytes:
+    n &= (1 << 64) - 1
+    out = bytearray()
+    while True:
+        b7 = n & 0x7F
+        n >>= 7
+        out.append(b7 | (0x80 if n else 0))
+        if not n:
+            return bytes(out)
+
+
+def _ld(field: int, payload: bytes) -> bytes:   # length-delimited field
+    return _varint((field << 3) | 2) + _varint(len(payload)) + payload
+
+
+def tf_event(wall_time: float, step: int = 0, scalars: Dict[str, float] = None, file_version: str = None) -> bytes:
+    import struct
+    ev = b"\x09" + struct.pack("<d", float(wall_time)) + b"\x10" + _varint(int(step))
+    if file_version is not None:
+        ev += _ld(3, file_version.encode())
+    if scalars is not None:
+        summary = b"".join(_ld(1, _ld(1, str(tag).encode()) + b"\x15" + struct.pack("<f", float(v))) for tag, v in scalars.items())
+        ev += _ld(5, summary)
+    return ev
+
+
+def tf_record(payload: bytes) -> bytes:
+    import struct
+    head = struct.pack("<Q", len(payload))
+    return head + struct.pack("<I", _masked_crc(head)) + payload + struct.pack("<I", _masked_crc(payload))
+
+
 class ScalarLog:
-    """One directory per split, like tf.summary.FileWriter(args.log_path + 'train/'): scalars are
-    appended to `scalars.jsonl` as {"step", "tag", "value", "wall"}.  Creating it creates the
-    directory, which is what makes `<log_path>/<prefix>/results.txt` writable in the reference."""
+    """One directory per split, like tf.summary.FileWriter(args.log_path + 'train/') (run_hier_xing.py:233-235): `add_summary(summary, step)` appends
+    the scalars to a TensorBoard event file `events.out.tfevents.<time>.<host>` (the format above: TensorBoard reads the directory as it reads the
+    reference's) and to `scalars.jsonl` as {"step", "tag", "value", "wall"} (greppable).  Creating it creates the directory, which is what makes
+    `<log_path>/<prefix>/results.txt` writable in the reference."""
 
     def __init__(self, logdir: str):
+        import socket
         self.logdir = logdir
         os.makedirs(logdir, exist_ok=True)
         self._path = os.path.join(logdir, "scalars.jsonl")
+        now = time.time()
+        self._events = os.path.join(logdir, "events.out.tfevents.%010d.%s" % (int(now), socket.gethostname()))
+        with open(self._events, "ab") as f:
+            f.write(tf_record(tf_event(now, 0, file_version="brain.Event:2")))
 
     def add_summary(self, summary: Dict[str, float], step: int):
+        now = time.time()
         with open(self._path, "a") as f:
             for tag, value in summary.items():
-                f.write(json.dumps({"step": int(step), "tag": tag, "value": float(value), "wall": time.time()}) + "\n")
+                f.write(json.dumps({"step": int(step), "tag": tag, "value": float(value), "wall": now}) + "\n")
+        with open(self._events, "ab") as f:
+            f.write(tf_record(tf_event(now, int(step), scalars=summary)))
 
 
 def scheduled_lr(args, epoch: int):

@@ -167,3 +167,54 @@ def test_run_xing_dispatches_the_mixture_models_and_refuses_training(tmp_path):
         run_gmm(a, None, None, None, sess=fake)
     a.train, a.validate, a.test, a.load = False, False, True, False
     assert run_gmm(a, None, None, Loader(2), sess=fake) is fake
+
+
+def test_scalar_log_writes_a_tensorboard_event_file(tmp_path):
+    """run_hier_xing.py:233-235,311-345 write tf.Summary scalars through tf.summary.FileWriter.  ScalarLog writes the same file format without
+    TensorFlow: TFRecord framing (length, masked CRC-32C of the length, payload, masked CRC-32C of the payload) around serialised Event protos.  Checked
+    here with an independent reader: CRC-32C against its published check value, every record's two checksums, and the payloads parsed by
+    google.protobuf against message types declared with event.proto / summary.proto's field numbers."""
+    import struct
+    from google.protobuf import descriptor_pb2, descriptor_pool, message_factory
+    from hiertcn_amd.run_common import ScalarLog, crc32c
+    assert crc32c(b"123456789") == 0xE3069283 and crc32c(b"") == 0
+    log = ScalarLog(str(tmp_path) + "/train/")
+    log.add_summary({"loss_epoch": 6.25, "recall10_epoch_mean": 0.125}, 3)
+    log.add_summary({"loss_epoch": 5.5}, 4)
+    files = [f for f in os.listdir(log.logdir) if f.startswith("events.out.tfevents.")]
+    assert len(files) == 1 and os.path.exists(log.logdir + "/scalars.jsonl")
+    raw = open(os.path.join(log.logdir, files[0]), "rb").read()
+    fd = descriptor_pb2.FileDescriptorProto(name="hiertcn_test_event.proto", package="hiertcn_test", syntax="proto3")
+    val = fd.message_type.add(name="Value")
+    val.field.add(name="tag", number=1, type=9, label=1)
+    val.field.add(name="simple_value", number=2, type=2, label=1)
+    summ = fd.message_type.add(name="Summary")
+    summ.field.add(name="value", number=1, type=11, label=3, type_name=".hiertcn_test.Value")
+    evd = fd.message_type.add(name="Event")
+    evd.field.add(name="wall_time", number=1, type=1, label=1)
+    evd.field.add(name="step", number=2, type=3, label=1)
+    evd.field.add(name="file_version", number=3, type=9, label=1)
+    evd.field.add(name="summary", number=5, type=11, label=1, type_name=".hiertcn_test.Summary")
+    pool = descriptor_pool.DescriptorPool()
+    pool.Add(fd)
+    Event = message_factory.GetMessageClass(pool.FindMessageTypeByName("hiertcn_test.Event"))
+
+    def unmask(m):
+        r = (m - 0xA282EAD8) & 0xFFFFFFFF
+        return ((r >> 17) | (r << 15)) & 0xFFFFFFFF
+
+    events, off = [], 0
+    while off < len(raw):
+        (n,) = struct.unpack_from("<Q", raw, off)
+        assert unmask(struct.unpack_from("<I", raw, off + 8)[0]) == crc32c(raw[off:off + 8])
+        payload = raw[off + 12:off + 12 + n]
+        assert unmask(struct.unpack_from("<I", raw, off + 12 + n)[0]) == crc32c(payload)
+        e = Event()
+        e.ParseFromString(payload)
+        events.append(e)
+        off += 16 + n
+    assert off == len(raw) and len(events) == 3
+    assert events[0].file_version == "brain.Event:2" and events[0].wall_time > 1e9
+    assert events[1].step == 3 and [(v.tag, v.simple_value) for v in events[1].summary.value] == [("loss_epoch", 6.25), ("recall10_epoch_mean", 0.125)]
+    assert events[2].step == 4 and [(v.tag, v.simple_value) for v in events[2].summary.value] == [("loss_epoch", 5.5)]
+
