@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 10
+ABI_VERSION = 11
 N_STRUCTS = 6
 PRECISION_STORAGE16, PRECISION_FP32, PRECISION_SPLIT16 = 0, 1, 2
 
@@ -139,6 +139,7 @@ SYMBOLS = {
     "hiertcn_train_step_finish": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
                                              C.c_size_t, C.c_void_p]),
     "hiertcn_count_users": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_set_score_ids": (C.c_int, [C.c_void_p, C.c_void_p]),
     "hiertcn_train_segment": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]),
     "hiertcn_grad_rows_workspace_bytes": (C.c_size_t, [C.c_void_p]),
     "hiertcn_grad_rows_list": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p,

@@ -64,6 +64,7 @@ struct hiertcn_ctx {
   TrainCtx train;
   ExactDev x;        // fp32 copies of the 16-bit tensors (hiertcn_set_precision)
   int precision;
+  const int32_t* score_ids = nullptr;   // one-shot (hiertcn_set_score_ids): the next evaluation / training step scores against these ids
   // timing hook
   bool timing;
   std::vector<hipEvent_t> ev_begin, ev_end;
@@ -653,6 +654,10 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   if (int rc = check_topk(h, &so)) return rc;
   const int64_t n_sessions = (int64_t)B * S;
   const int64_t R = n_sessions * L;
+  // warm-start evaluation (model.py:102-103, hiertcn_set_score_ids): targets / masks / loss / metrics from the one-shot score ids, the session mean-pool from y_ids
+  const int32_t* y_pool = y_ids;
+  if (h->score_ids) y_ids = h->score_ids;
+  h->score_ids = nullptr;
   // scan first (it never reads the low level's output: model_hier.py:83-93), then every
   // (user, session) low-level problem is independent.
   // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): the outputs are zeroed, the rows that do carry a target listed, and
@@ -666,11 +671,11 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   }
   bool compacted = false;
   if (hier) {
-    if (exact) HIP_TRY(launch_xsession_pool(h->m, h->x, y_ids, n_sessions, L, pooled, st));
-    else if (session_pool_compact_applies(R)) {   // small batches: the row list rides on the pooling launch (it depends on the ids alone)
+    if (exact) HIP_TRY(launch_xsession_pool(h->m, h->x, y_pool, n_sessions, L, pooled, st));
+    else if (session_pool_compact_applies(R) && y_pool == y_ids) {   // small batches: the row list rides on the pooling launch (it depends on the ids alone)
       HIP_TRY(launch_session_pool_compact(h->m, y_ids, n_sessions, L, pooled, row_map, n_valid, so.rank, so.ce, so.target, st));
       compacted = true;
-    } else HIP_TRY(launch_session_pool(h->m, y_ids, n_sessions, L, pooled, st));
+    } else HIP_TRY(launch_session_pool(h->m, y_pool, n_sessions, L, pooled, st));
     HIP_TRY(launch_gru_scan(h->m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, reinterpret_cast<float*>(ws + w.gru), st));
   }
   if (exact && !split16) {   // fp32 end to end: every row is scored on materialised logits; rows without a target come out as 0 / 0 / 0..k-1 there
@@ -744,8 +749,10 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
   if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
+  const int32_t* ys = h->score_ids;
+  h->score_ids = nullptr;
   if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, state_in, B, S, L, workspace, state_out, metrics8, h->metric_scratch,
-                             reinterpret_cast<hipStream_t>(stream)) != 0)
+                             reinterpret_cast<hipStream_t>(stream), TRAIN_BEGIN | TRAIN_FINISH, nullptr, ys) != 0)
     return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
   return HIERTCN_OK;
 }
@@ -761,7 +768,7 @@ int hiertcn_train_step_begin(hiertcn_handle_t h, const int32_t* x_ids, const int
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
   if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, state_in, B, S, L, workspace, state_out, metrics8, h->metric_scratch,
-                             reinterpret_cast<hipStream_t>(stream), TRAIN_BEGIN, users_global) != 0)
+                             reinterpret_cast<hipStream_t>(stream), TRAIN_BEGIN, users_global, h->score_ids) != 0)   // (kept for the matching finish)
     return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
   return HIERTCN_OK;
 }
@@ -773,9 +780,17 @@ int hiertcn_train_step_finish(hiertcn_handle_t h, const int32_t* x_ids, const in
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (h->m.hier && !mask) return fail(HIERTCN_ERR_INVALID, "mask is required for hier models");
   if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
+  const int32_t* ys = h->score_ids;
+  h->score_ids = nullptr;
   if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, nullptr, B, S, L, workspace, nullptr, nullptr, h->metric_scratch,
-                             reinterpret_cast<hipStream_t>(stream), TRAIN_FINISH, nullptr) != 0)
+                             reinterpret_cast<hipStream_t>(stream), TRAIN_FINISH, nullptr, ys) != 0)
     return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
+  return HIERTCN_OK;
+}
+
+int hiertcn_set_score_ids(hiertcn_handle_t h, const int32_t* y_score_ids) {
+  if (!h) return fail(HIERTCN_ERR_INVALID, "null handle");
+  h->score_ids = y_score_ids;
   return HIERTCN_OK;
 }
 

@@ -43,7 +43,9 @@ size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L);
 #define TRAIN_FINISH 2   // the rest of the backward pass
 int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y, const float* mask, const float* state_in, int B,
                            int S, int L, void* ws, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st,
-                           int phases = TRAIN_BEGIN | TRAIN_FINISH, const float* users_global = nullptr);
+                           int phases = TRAIN_BEGIN | TRAIN_FINISH, const float* users_global = nullptr, const int32_t* y_score = nullptr);
+// y_score (optional, hiertcn_set_score_ids): the ids the LOSS sees -- y with the steps that do not count set to 0 (model.py:102-103, mask_y *= mask_warmstart) --
+// while the session mean-pool (model_hier.py:83-85) and its backward keep reading y
 // data-parallel helpers: lanes with a target -> users[0]; the item table's row-sparse gradient exchange
 hipError_t train_count_users(const int32_t* y, int B, int T, float* act_scratch, float* users, hipStream_t st);
 size_t train_rows_workspace_bytes(const ModelDev& m);

@@ -876,9 +876,11 @@ size_t train_workspace_bytes(const ModelDev& m, int B, int S, int L) { return tr
 // caller starts their collective there), TRAIN_FINISH = the rest of the backward pass; both = the whole step.
 // users_global (device, optional): the user count of the GLOBAL batch (all ranks) that normalises the loss (model.py:113-117);
 // null = this batch's own count.
-int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y, const float* mask, const float* state_in, int B,
+int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, const int32_t* y_pool, const float* mask, const float* state_in, int B,
                            int S, int L, void* wsp, float* state_out, double* metrics8, double* metric_scratch, hipStream_t st, int phases,
-                           const float* users_global) {
+                           const float* users_global, const int32_t* y_score) {
+  // y: what the scoring layer, the loss, the metrics and the row weights read (train.h); y_pool: what the session mean-pool reads (model_hier.py:83-85)
+  const int32_t* y = y_score ? y_score : y_pool;
   const bool do_begin = (phases & TRAIN_BEGIN) != 0, do_finish = (phases & TRAIN_FINISH) != 0;
   if (!t.enabled) return tfail("training is not enabled on this handle (hiertcn_train_enable before hiertcn_set_weights)");
   const TrainWs w = train_ws(m, B, S, L);
@@ -910,7 +912,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     if (!m.hier) {   // single-level model_tcn (model.py:71-73): block 0 reads the embedded ids; model_gru (:66-67): the GRU stack does (lb.uf)
       T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, m.low_gru ? F32(w.lg_uf) : F32(w.f_act[0]), st));
     } else {
-    T_HIP(launch_xsession_pool(m, xv, y, n_sess, L, pooled, st));
+    T_HIP(launch_xsession_pool(m, xv, y_pool, n_sess, L, pooled, st));
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
     T_HIP(launch_xembed_rows(xv.emb, x, R, E, m.N, F32(w.f_emb), st));
     }
@@ -940,7 +942,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   if (do_begin && !F) {
   if (!m.low_gru && !fused_fw) T_HIP(launch_embed_rows(m, x, R, a_emb, st));
   if (m.hier) {
-    T_HIP(launch_session_pool(m, y, n_sess, L, pooled, st));
+    T_HIP(launch_session_pool(m, y_pool, n_sess, L, pooled, st));
     T_HIP(launch_gru_scan(m, pooled, mask, state_in, B, S, sproj, state_out, nullptr, hist, st, gsave));
     if (!m.low_gru && !fused_fw) {
       LayerArgs a = {};
@@ -1474,7 +1476,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
   }
   // ================= session mean-pool + 'emb' bias (model_hier.py:83-85) ================================
   T_HIP(colsum_f32(dpooled, n_sess, E, E, G + t.emb_bias.off, st));
-  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)n_sess), dim3(256), 0, st, G + t.emb.off, y, dpooled, n_sess, L, E, m.N);
+  hipLaunchKernelGGL(k_pool_bwd, dim3((unsigned)n_sess), dim3(256), 0, st, G + t.emb.off, y_pool, dpooled, n_sess, L, E, m.N);
   T_HIP(hipGetLastError());
 #undef F32
 #undef BF

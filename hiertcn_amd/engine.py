@@ -353,10 +353,22 @@ class Engine:
             self._ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._ws
 
-    def forward_eval(self, x_ids, y_ids, mask, state_in, want_rows=False, state_out=None, metrics8=None, topk: int = 0):
+    def set_score_ids(self, y_score: Optional[torch.Tensor]):
+        """hiertcn_set_score_ids: the NEXT evaluation / training step of this handle scores against y_score [B, S, L] int32 (= y_ids with the steps
+        that do not count set to 0: model.py:102-103, mask_y *= mask_warmstart) while the session mean-pool keeps reading that call's y_ids."""
+        if y_score is not None:
+            _req(y_score, torch.int32, "y_score")
+        self._score_keep = y_score           # (alive until the step that consumes it has been enqueued and the next one replaces it)
+        self._ck(self.lib.hiertcn_set_score_ids(self._h, _ptr(y_score)))
+
+    def forward_eval(self, x_ids, y_ids, mask, state_in, want_rows=False, state_out=None, metrics8=None, topk: int = 0, y_score=None):
         """One evaluation step on a packed batch: x_ids, y_ids [B,S,L] int32; mask [B,S] fp32;
-        state_in [B,H*nl] fp32.  Returns dict(state, metrics8 (device, 8 doubles)[, rank, ce][, topk_idx, topk_val])."""
+        state_in [B,H*nl] fp32.  Returns dict(state, metrics8 (device, 8 doubles)[, rank, ce][, topk_idx, topk_val]).
+        y_score (optional, [B,S,L] int32): warm-start evaluation -- see set_score_ids."""
         B, S, L = x_ids.shape
+        if y_score is not None:
+            _req(y_score, torch.int32, "y_score", (B, S, L))
+            self.set_score_ids(y_score)
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
         if self.hier:
@@ -398,10 +410,13 @@ class Engine:
         return EvalGraph(self, B, S, L)
 
     # -- training (hiertcn.h "training step") ------------------------------------------------------
-    def train_forward_backward(self, x_ids, y_ids, mask=None, state_in=None, state_out=None, metrics8=None):
+    def train_forward_backward(self, x_ids, y_ids, mask=None, state_in=None, state_out=None, metrics8=None, y_score=None):
         """Forward + loss + gradients of every variable (into the handle's gradient arena).
-        Returns dict(state, metrics8).  Single-level handles: x_ids / y_ids [B, 1, T], no mask / state."""
+        Returns dict(state, metrics8).  Single-level handles: x_ids / y_ids [B, 1, T], no mask / state.  y_score: see set_score_ids."""
         B, S, L = x_ids.shape
+        if y_score is not None:
+            _req(y_score, torch.int32, "y_score", (B, S, L))
+            self.set_score_ids(y_score)
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
         if self.hier:
@@ -428,10 +443,14 @@ class Engine:
             self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         return self._train_ws
 
-    def train_step_begin(self, x_ids, y_ids, mask=None, state_in=None, state_out=None, metrics8=None, users_global=None):
+    def train_step_begin(self, x_ids, y_ids, mask=None, state_in=None, state_out=None, metrics8=None, users_global=None, y_score=None):
         """Forward + loss + backward of the scoring layer; behind it the gradients of out_kernel / out_bias are final.
-        users_global: device float32 [1], the lanes-with-a-target count of the GLOBAL batch (or None: this batch's own)."""
+        users_global: device float32 [1], the lanes-with-a-target count of the GLOBAL batch (or None: this batch's own).
+        y_score: see set_score_ids (it holds for the matching train_step_finish too)."""
         B, S, L = x_ids.shape
+        if y_score is not None:
+            _req(y_score, torch.int32, "y_score", (B, S, L))
+            self.set_score_ids(y_score)
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
         if self.hier:

@@ -47,6 +47,23 @@ def pack_slots(x_list: Sequence, y_list: Sequence, mask_list: Sequence):
     return x, y, mask, lens
 
 
+def warm_score_ids(y: np.ndarray, lens, mask_warmstart):
+    """y [B, S, Lmax] (pack_slots) and the warm-start feed [B, sum L_i] in the concat order of y_id (run_hier_xing.py:116,125-129) -> the ids the
+    loss and the metrics see: y where the mask is set, 0 elsewhere (model.py:102-103).  None in, None out."""
+    if mask_warmstart is None:
+        return None
+    mw = np.asarray(mask_warmstart) > 0
+    B, S, Lmax = y.shape
+    if mw.shape != (B, int(sum(lens))):
+        raise ValueError(f"mask_warmstart {mw.shape}: expected {(B, int(sum(lens)))} (one entry per step of y_id)")
+    out = np.zeros_like(y)
+    off = 0
+    for i, l in enumerate(lens):
+        out[:, i, :l] = y[:, i, :l] * mw[:, off:off + l]
+        off += l
+    return out
+
+
 class PendingEval:
     """One evaluation batch in flight (HierTCNModel.eval_step_packed_async): result() waits for ITS read-backs only and builds the dict
     eval_step_packed returns (without "state": the carried state stays on the device until eval_end)."""
@@ -158,24 +175,27 @@ class HierTCNModel:
         self.engine.set_weights(params, root=self.name)
 
     # one sess.run of the evaluation fetch list (run_hier_xing.py:145-149) ------------------------
-    def eval_step(self, x_list, y_list, mask_list, state_np, want_pred: bool = False):
-        """Slot lists as the loader emits them (S arrays [B, L_i]) -> the fetch list."""
+    def eval_step(self, x_list, y_list, mask_list, state_np, want_pred: bool = False, mask_warmstart=None):
+        """Slot lists as the loader emits them (S arrays [B, L_i]) -> the fetch list.  mask_warmstart (optional, [B, sum L_i] in the concat order
+        of y_id): the feed of model.py:40 -- `mask_y *= mask_warmstart` (:102-103): the steps it zeroes count neither in the loss nor in the metrics."""
         x, y, mask, lens = pack_slots(x_list, y_list, mask_list)
-        return self.eval_step_packed(x, y, mask, lens, state_np, want_pred)
+        return self.eval_step_packed(x, y, mask, lens, state_np, want_pred, y_score=warm_score_ids(y, lens, mask_warmstart))
 
-    def eval_step_packed(self, x, y, mask, lens, state_np, want_pred: bool = False):
+    def eval_step_packed(self, x, y, mask, lens, state_np, want_pred: bool = False, y_score=None):
         """x, y int32 [B, S, Lmax]; mask float32 [B, S]; lens = the slot widths L_i.  Per-step
-        outputs come back in the reference's concat order [B, sum L_i] (model_hier.py:79)."""
+        outputs come back in the reference's concat order [B, sum L_i] (model_hier.py:79).
+        y_score (optional): y with the steps a warm-start mask drops set to 0 (warm_score_ids)."""
         eng = self.engine
         B, S, Lmax = x.shape
         dev = eng.device
         xd, yd, md = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, y, mask))
         st = torch.as_tensor(np.asarray(state_np, dtype=np.float32)).to(dev).contiguous()
-        out = eng.forward_eval(xd, yd, md, st, want_rows=True)
+        ysd = None if y_score is None else torch.from_numpy(np.ascontiguousarray(y_score, dtype=np.int32)).to(dev)
+        out = eng.forward_eval(xd, yd, md, st, want_rows=True, y_score=ysd)
         m = metrics_dict(out["metrics8"])
         cols = np.concatenate([i * Lmax + np.arange(l) for i, l in enumerate(lens)])
         rank = out["rank"].cpu().numpy()[:, cols].astype(np.float32)
-        mask_y = (y.reshape(B, S * Lmax)[:, cols] > 0).astype(np.float32)
+        mask_y = ((y if y_score is None else y_score).reshape(B, S * Lmax)[:, cols] > 0).astype(np.float32)   # (the fetch follows model.py:103)
         res = dict(loss=m["loss"], state=out["state"].cpu().numpy(), ranks_float_mean_user=m["rank_frac"],
                    ranks_float=rank / float(eng.N), mask_y=mask_y, reciprocal_ranks_float_mean_user=m["mrr"],
                    recall1_mean_user=m["recall1"], recall5_mean_user=m["recall5"], recall10_mean_user=m["recall10"],
@@ -274,25 +294,27 @@ class HierTCNModel:
         ev.record()
         return PendingTrain(m8_h, ev)
 
-    def train_step(self, x_list, y_list, mask_list, state_np, lr):
+    def train_step(self, x_list, y_list, mask_list, state_np, lr, mask_warmstart=None):
         """One sess.run([train_op, loss, state]) of run_hier_xing.py:301: forward, masked lane-mean cross
         entropy (model.py:102-117), gradients of every variable, [RCCL all-reduce of the gradient arena
-        when a process group is up], TF-form Adam (model.py:139-141).  Returns dict(loss, state)."""
+        when a process group is up], TF-form Adam (model.py:139-141).  Returns dict(loss, state).
+        mask_warmstart: as in eval_step (run_hier_xing.py:286-289 feeds the events at or before the warm-start time)."""
         if not self.trainable:
             raise RuntimeError("this model was created without training state (args.train = False)")
-        x, y, mask, _lens = pack_slots(x_list, y_list, mask_list)
-        return self.train_step_packed(x, y, mask, state_np, lr)
+        x, y, mask, lens = pack_slots(x_list, y_list, mask_list)
+        return self.train_step_packed(x, y, mask, state_np, lr, y_score=warm_score_ids(y, lens, mask_warmstart))
 
-    def train_step_packed(self, x, y, mask, state_np, lr):
+    def train_step_packed(self, x, y, mask, state_np, lr, y_score=None):
         eng = self.engine
         dev = eng.device
         xd, yd, md = (torch.from_numpy(np.ascontiguousarray(v)).to(dev) for v in (x, y, mask))
         st = torch.as_tensor(np.asarray(state_np, dtype=np.float32)).to(dev).contiguous()
-        out = self.train_step_device(xd, yd, md, st, lr)
+        ysd = None if y_score is None else torch.from_numpy(np.ascontiguousarray(y_score, dtype=np.int32)).to(dev)
+        out = self.train_step_device(xd, yd, md, st, lr, y_score=ysd)
         m = metrics_dict(out["metrics8"])
         return dict(loss=m["loss"], state=out["state"].cpu().numpy(), user_count=m["user_count"])
 
-    def train_step_device(self, xd, yd, md, st, lr, state_out=None, metrics8=None):
+    def train_step_device(self, xd, yd, md, st, lr, state_out=None, metrics8=None, y_score=None):
         """The step on device tensors, nothing read back: [global user count ->] forward + loss + scoring-layer backward ->
         [collective of the scoring layer's gradient, overlapped with] the rest of the backward -> [the other collectives] ->
         TF-form Adam.  `metrics8` comes back summed over ranks (its loss is the global batch's, model.py:116-117)."""
@@ -306,8 +328,8 @@ class HierTCNModel:
                      else int(a.batch_size) * int(getattr(a, "max_seq_len", 500)))
             self._exchange = GradientExchange(eng, ids_bound=max(bound, 1))
         ex = self._exchange
-        users = ex.global_users(yd)
-        out = eng.train_step_begin(xd, yd, md, st, state_out=state_out, metrics8=metrics8, users_global=users)
+        users = ex.global_users(yd if y_score is None else y_score)      # lanes with a SCORED target (model.py:112-113 on the warm-start-masked mask_y)
+        out = eng.train_step_begin(xd, yd, md, st, state_out=state_out, metrics8=metrics8, users_global=users, y_score=y_score)
         ex.after_scoring()
         eng.train_step_finish(xd, yd, md)
         ex.after_backward(xd, yd if self.hier else None)
@@ -363,10 +385,13 @@ class TcnModel:
         self._params = params
         self.engine.set_weights(pad_widths(self.args, self._to_kind(params), self.KIND)[1], root=self.KIND)
 
-    def eval_step(self, x, y, want_pred: bool = False):
-        """One sess.run of evaluate_nn's fetch list (run_nn_xing.py:43-47): x, y [B, T] ids."""
+    def eval_step(self, x, y, want_pred: bool = False, mask_warmstart=None):
+        """One sess.run of evaluate_nn's fetch list (run_nn_xing.py:43-47): x, y [B, T] ids.  mask_warmstart [B, T] (model.py:40,102-103): the
+        targets it zeroes are not scored -- a single-level model reads y nowhere else, so the mask is applied to the ids."""
         eng = self.engine
         xi, yi = _to_ids(x), _to_ids(y)
+        if mask_warmstart is not None:
+            yi = (yi * (np.asarray(mask_warmstart) > 0)).astype(yi.dtype)
         B, T = xi.shape
         xd = torch.from_numpy(np.ascontiguousarray(xi)).to(eng.device).view(B, 1, T)
         yd = torch.from_numpy(np.ascontiguousarray(yi)).to(eng.device).view(B, 1, T)
@@ -399,12 +424,14 @@ class TcnModel:
         ev.record()
         return PendingEvalNN(rank_h, m8_h, ev, yi, eng.N)
 
-    def train_step(self, x, y, lr):
+    def train_step(self, x, y, lr, mask_warmstart=None):
         """One sess.run([train_op, loss]) of run_nn_xing.py: forward, loss, gradients, [collectives], TF-form Adam."""
         if not self.trainable:
             raise RuntimeError("this model was created without training state (args.train = False)")
         eng = self.engine
         xi, yi = _to_ids(x), _to_ids(y)
+        if mask_warmstart is not None:
+            yi = (yi * (np.asarray(mask_warmstart) > 0)).astype(yi.dtype)
         B, T = xi.shape
         xd = torch.from_numpy(np.ascontiguousarray(xi)).to(eng.device).view(B, 1, T)
         yd = torch.from_numpy(np.ascontiguousarray(yi)).to(eng.device).view(B, 1, T)

@@ -13,6 +13,8 @@ import os
 import time
 from typing import Dict, Optional
 
+import numpy as np
+
 # (key in a step's result dict, tag written to results.txt / the event log)
 SCALARS = (("loss", "loss_epoch"), ("ranks_float_mean_user", "ranks_float_epoch_mean"),
            ("reciprocal_ranks_float_mean_user", "reciprocal_ranks_float_epoch_mean"),
@@ -156,6 +158,19 @@ class ScalarLog:
                 f.write(json.dumps({"step": int(step), "tag": tag, "value": float(value), "wall": now}) + "\n")
         with open(self._events, "ab") as f:
             f.write(tf_record(tf_event(now, int(step), scalars=summary)))
+
+
+WARM_START_TIME = 1445617130   # run_hier_xing.py:128,288 / run_nn_xing.py:40,150: the XING timestamp that splits a user's events into "before" and "after"
+
+
+def warm_start_mask(info, train: bool) -> np.ndarray:
+    """The `mask_warmstart` feed of a warm-start run (args.warm_start; model.py:40,102-103).  info: the loader's per-event rows aligned with y --
+    a list of S arrays [B, L_i, 5] (hier loader; concatenated along the steps as run_hier_xing.py:117 does) or one array [B, T, 5]; column 3 is
+    the event's timestamp (data_prepare.load_xing).  Evaluation counts the events AFTER the time (run_hier_xing.py:128, run_nn_xing.py:40),
+    training the real events at or before it (:288 / :150: `<= T` and `> 0`, padding has timestamp 0).  -> float32 [B, sum L_i]."""
+    ts = (np.concatenate([np.asarray(i) for i in info], axis=1) if isinstance(info, (list, tuple)) else np.asarray(info))[:, :, 3]
+    m = (ts <= WARM_START_TIME) & (ts > 0) if train else ts > WARM_START_TIME
+    return m.astype(np.float32)
 
 
 def scheduled_lr(args, epoch: int):

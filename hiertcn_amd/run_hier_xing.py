@@ -16,7 +16,7 @@ from typing import Sequence
 
 import numpy as np
 
-from .run_common import EpochMeter, ScalarLog, scheduled_lr
+from .run_common import EpochMeter, ScalarLog, scheduled_lr, warm_start_mask
 
 
 def ranks_analysis(ranks_float_np, batch_x_list: Sequence, batch_mask_y, ranks_temp, ranks_temp_count):
@@ -36,8 +36,9 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
     """-> (summary, summary_val, time_load, time_run, state_np), the tuple of run_hier_xing.py:207.
     `sess` is the model handle.  `summary` is a dict tag -> value (the reference builds a
     tf.Summary with the same tags, :189-196); `summary_val` is the last batch's step dict."""
-    if warm_start if warm_start is not None else getattr(args, "warm_start", False):
-        raise NotImplementedError("warm-start masks (model.py:102-103) are outside the hot path")
+    # warm-start runs (args.warm_start, run_hier_xing.py:125-129): only the events after WARM_START_TIME count; the mask comes from the loader's
+    # info rows, so those runs take the slot-list batches (get_batch) one blocking step at a time
+    warm = bool(warm_start if warm_start is not None else getattr(args, "warm_start", False))
     model = sess
     time_load = time_run = 0.0
     from .distributed import is_main
@@ -45,7 +46,7 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
     ranks_temp = np.zeros(args.max_activity_len + 1)
     ranks_temp_count = np.zeros(args.max_activity_len + 1)
     step = None
-    packed = hasattr(loader, "get_packed_batch") and hasattr(model, "eval_step_packed")
+    packed = hasattr(loader, "get_packed_batch") and hasattr(model, "eval_step_packed") and not warm
     pre = None
     if packed and int(getattr(args, "load_worker_num", 0) or 0) > 0:
         # the packer runs ahead on a background thread (args.load_worker_num > 0, the reference's loader-worker flag, args.py:75):
@@ -94,9 +95,12 @@ def evaluate_hier(args, loader, state_np, sess, y_slice_np=None, topic_state_np=
             step = model.eval_step_packed(x, y, mask, widths, state_np)
             slot_shapes = [np.empty((0, w)) for w in widths]
         else:
-            batch_x_list, batch_y_list, batch_mask_list, _info = loader.get_batch()
+            batch_x_list, batch_y_list, batch_mask_list, batch_info_list = loader.get_batch()
             t2 = time.time()
-            step = model.eval_step(batch_x_list, batch_y_list, batch_mask_list, state_np)
+            if warm:
+                step = model.eval_step(batch_x_list, batch_y_list, batch_mask_list, state_np, mask_warmstart=warm_start_mask(batch_info_list, train=False))
+            else:
+                step = model.eval_step(batch_x_list, batch_y_list, batch_mask_list, state_np)
             slot_shapes = batch_x_list
         state_np = step["state"]  # :147 -- carried into the next batch
         health.after_batch()
@@ -169,6 +173,7 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
 
     from .distributed import barrier, is_main
     model = sess if sess is not None else HierTCNModel(args)
+    warm = bool(warm_start if warm_start is not None else getattr(args, "warm_start", False))   # :286-289: train on the events up to WARM_START_TIME
     epoch = 0
     if args.load:  # :220-229
         fname = args.load_path + str(args.load_epoch) + ".ckpt"
@@ -200,7 +205,7 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
             lr = scheduled_lr(args, epoch)
             training_loss_epoch = 0.0
             if (hasattr(loader_train, "get_packed_batch") and hasattr(model, "train_step_packed_async") and not os.environ.get("HIERTCN_TRAIN_SERIAL")
-                    and args.epoch_batches_train > 0):
+                    and args.epoch_batches_train > 0 and not warm):
                 # the device is left running (model.py, PendingTrain): the carried state goes device to device, a step's loss is read one step later
                 model.train_begin(state_np)
                 pending = None
@@ -216,8 +221,11 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
                 state_np = model.train_end()
             else:
               for _ in range(args.epoch_batches_train):  # :275
-                batch_x_list, batch_y_list, batch_mask_list, _info = loader_train.get_batch()
-                out = model.train_step(batch_x_list, batch_y_list, batch_mask_list, state_np, lr)
+                batch_x_list, batch_y_list, batch_mask_list, batch_info_list = loader_train.get_batch()
+                if warm:
+                    out = model.train_step(batch_x_list, batch_y_list, batch_mask_list, state_np, lr, mask_warmstart=warm_start_mask(batch_info_list, train=True))
+                else:
+                    out = model.train_step(batch_x_list, batch_y_list, batch_mask_list, state_np, lr)
                 state_np = out["state"]
                 training_loss_epoch += float(out["loss"])
             _check_persistent_health(model, "training epoch %d" % epoch)   # (the training step runs persistent launches too: scan, its backward, lgru_pipe)
@@ -234,10 +242,10 @@ def run_hier(args, loader_train, loader_validate, loader_test, warm_start=None, 
                 barrier()
         if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:  # :324
             if args.validate:
-                summary, _, _, _, state_np_validate = evaluate_hier(args, loader_validate, state_np_validate, model, prefix="validate")
+                summary, _, _, _, state_np_validate = evaluate_hier(args, loader_validate, state_np_validate, model, prefix="validate", warm_start=warm)
                 validate_writer.add_summary(summary, epoch)
             if args.test:
-                summary, _, t_load, t_run, state_np_test = evaluate_hier(args, loader_test, state_np_test, model, prefix="test")
+                summary, _, t_load, t_run, state_np_test = evaluate_hier(args, loader_test, state_np_test, model, prefix="test", warm_start=warm)
                 test_writer.add_summary(summary, epoch)
                 print("Step {}: test load {:.2f}s, test run {:.2f}s, {}".format(epoch, t_load, t_run, args.name))
             if not args.train:

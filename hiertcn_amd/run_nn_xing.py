@@ -7,19 +7,18 @@ from __future__ import annotations
 import os
 import time
 
-from .run_common import EpochMeter, ScalarLog, scheduled_lr
+from .run_common import EpochMeter, ScalarLog, scheduled_lr, warm_start_mask
 
 
 def evaluate_nn(args, loader, sess, prefix="test", warm_start=None):
     """-> (summary, summary_val, time_load, time_run), the tuple of run_nn_xing.py:98."""
-    if warm_start if warm_start is not None else getattr(args, "warm_start", False):
-        raise NotImplementedError("warm-start masks (model.py:102-103) are outside the hot path")
+    warm = bool(warm_start if warm_start is not None else getattr(args, "warm_start", False))   # run_nn_xing.py:38-41: only the events after WARM_START_TIME count
     model = sess
     time_load = time_run = 0.0
     from .distributed import is_main
     meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) and is_main() else None, final_header=False)
     step = None
-    pipelined = hasattr(model, "eval_step_async") and not os.environ.get("HIERTCN_EVAL_SERIAL")
+    pipelined = hasattr(model, "eval_step_async") and not os.environ.get("HIERTCN_EVAL_SERIAL") and not warm
     if pipelined:   # the device is left running: batch i is enqueued before the host turns to batch i - 1's ranks and metrics (run_hier_xing.py)
         pending = None
         while True:
@@ -43,9 +42,9 @@ def evaluate_nn(args, loader, sess, prefix="test", warm_start=None):
         time_run += time.time() - t2
     while not pipelined:  # :31
         t1 = time.time()
-        batch_x, batch_y, _info = loader.get_batch()
+        batch_x, batch_y, info = loader.get_batch()
         t2 = time.time()
-        step = model.eval_step(batch_x, batch_y)
+        step = model.eval_step(batch_x, batch_y, mask_warmstart=warm_start_mask(info, train=False)) if warm else model.eval_step(batch_x, batch_y)
         meter.add(step)
         t3 = time.time()
         time_load += t2 - t1
@@ -63,6 +62,7 @@ def run_nn(args, loader_train, loader_validate, loader_test, warm_start=None, se
 
     # model.py:66-73: model_type 'gru' builds model_gru, 'tcn' model_tcn -- same loop, same fetches
     model = sess if sess is not None else (GruModel if getattr(args, "model_type", "tcn") == "gru" else TcnModel)(args)
+    warm = bool(warm_start if warm_start is not None else getattr(args, "warm_start", False))   # :148-151: train on the events up to WARM_START_TIME
     epoch = 0
     if args.load:
         fname = args.load_path + str(args.load_epoch) + ".ckpt"
@@ -85,8 +85,9 @@ def run_nn(args, loader_train, loader_validate, loader_test, warm_start=None, se
             lr = scheduled_lr(args, epoch)
             training_loss_epoch = 0.0
             for _ in range(args.epoch_batches_train):
-                batch_x, batch_y, _info = loader_train.get_batch()
-                training_loss_epoch += float(model.train_step(batch_x, batch_y, lr)["loss"])
+                batch_x, batch_y, info = loader_train.get_batch()
+                out = model.train_step(batch_x, batch_y, lr, mask_warmstart=warm_start_mask(info, train=True)) if warm else model.train_step(batch_x, batch_y, lr)
+                training_loss_epoch += float(out["loss"])
             training_loss_epoch /= args.epoch_batches_train
             train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
             if args.save and epoch % args.save_epoch == 0 and epoch != 0:
@@ -97,10 +98,10 @@ def run_nn(args, loader_train, loader_validate, loader_test, warm_start=None, se
                 barrier()
         if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:
             if args.validate:
-                summary, _, _, _ = evaluate_nn(args, loader_validate, model, prefix="validate")
+                summary, _, _, _ = evaluate_nn(args, loader_validate, model, prefix="validate", warm_start=warm)
                 validate_writer.add_summary(summary, epoch)
             if args.test:
-                summary, _, t_load, t_run = evaluate_nn(args, loader_test, model, prefix="test")
+                summary, _, t_load, t_run = evaluate_nn(args, loader_test, model, prefix="test", warm_start=warm)
                 test_writer.add_summary(summary, epoch)
                 print("Step {}: test load {:.2f}s, test run {:.2f}s, {}".format(epoch, t_load, t_run, args.name))
             if not args.train:

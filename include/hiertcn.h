@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 10
+#define HIERTCN_ABI_VERSION 11
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -321,6 +321,13 @@ int hiertcn_train_step_begin(hiertcn_handle_t h, const int32_t* x_ids, const int
 int hiertcn_train_step_finish(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, int32_t B, int32_t S,
                               int32_t L, void* workspace, size_t workspace_bytes, void* stream);
 int hiertcn_count_users(hiertcn_handle_t h, const int32_t* y_ids, int32_t B, int32_t T, float* users, void* stream);
+/* Warm-start runs (ABI 11; args.warm_start: model.py:40,102-103 `mask_y *= mask_warmstart`, fed at run_hier_xing.py:125-129,286-289 and
+ * run_nn_xing.py:38-41,148-151 from the events' timestamps).  y_score_ids [B][S][L] = y_ids with the steps that do not count set to 0.
+ * ONE-SHOT: the next hiertcn_forward_eval, hiertcn_train_forward_backward or hiertcn_train_step_begin + _finish pair of this handle takes
+ * its targets, masks, loss, ranks, metrics and row weights from y_score_ids, while the session mean-pool of model_hier.py:83-85 (and its
+ * backward) keeps reading the y_ids passed to that call; the pointer must stay valid until that call's work has run.  NULL clears it.
+ * (hiertcn_count_users for such a step takes y_score_ids too: a lane counts when it has a SCORED target.) */
+int hiertcn_set_score_ids(hiertcn_handle_t h, const int32_t* y_score_ids);
 int hiertcn_train_segment(hiertcn_handle_t h, int32_t which, size_t* offset, size_t* count);
 size_t hiertcn_grad_rows_workspace_bytes(hiertcn_handle_t h);
 int hiertcn_grad_rows_list(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, int64_t n_ids, int32_t* ids_out, int64_t cap,

@@ -52,9 +52,11 @@ class OracleSession:
     def __init__(self, args, params, num=None):
         self.args, self.params, self.num = args, params, num or O.EXACT64
 
-    def eval_step(self, x_list, y_list, mask_list, state_np):
+    def eval_step(self, x_list, y_list, mask_list, state_np, mask_warmstart=None):
         pred, state = O.model_hier(self.args, x_list, y_list, mask_list, np.asarray(state_np, np.float64), self.params, self.num)
         y_id = np.concatenate([np.asarray(v).astype(np.int64) for v in y_list], axis=1)
+        if mask_warmstart is not None:   # model.py:102-103: mask_y = sign(y_id) * mask_warmstart -- the model above still pooled the unmasked y_list
+            y_id = y_id * (np.asarray(mask_warmstart) > 0)
         m = O.masked_loss_and_metrics(pred, y_id, int(self.args.item_num))
         return dict(loss=float(m["loss"]), state=state, ranks_float_mean_user=float(m["rank_frac"]),
                     ranks_float=m["ranks_float"], mask_y=(y_id > 0).astype(np.float64),

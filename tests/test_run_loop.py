@@ -218,3 +218,56 @@ def test_scalar_log_writes_a_tensorboard_event_file(tmp_path):
     assert events[1].step == 3 and [(v.tag, v.simple_value) for v in events[1].summary.value] == [("loss_epoch", 6.25), ("recall10_epoch_mean", 0.125)]
     assert events[2].step == 4 and [(v.tag, v.simple_value) for v in events[2].summary.value] == [("loss_epoch", 5.5)]
 
+
+def test_warm_start_masks_and_evaluate_hier(tmp_path, data, monkeypatch):
+    """args.warm_start (args.py:10-11): model.py:102-103 multiplies mask_y by the fed `mask_warmstart`, which run_hier_xing.py builds from the events'
+    timestamps -- evaluation: after 1445617130 (:128), training: real events at or before it (:288).  The masked steps drop out of the loss and of every
+    metric; the model itself (the session mean-pool over ALL targets, the carried state) is untouched."""
+    from hiertcn_amd import run_common
+    from hiertcn_amd.model import pack_slots, warm_score_ids
+    from hiertcn_amd.run_common import warm_start_mask
+    assert run_common.WARM_START_TIME == 1445617130                  # run_hier_xing.py:128,288
+    # the reference's time leaves 4.9 % of the synthetic file's events "after": with 4 lanes most batches would have no scored user at all, and such
+    # a batch is 0 / 0 = NaN in the reference's graph (model.py:113,117) and here alike.  8 lanes and the 30 % quantile keep every batch populated.
+    WARM_START_TIME = float(np.quantile(data[1][:, 3], 0.3))
+    monkeypatch.setattr(run_common, "WARM_START_TIME", WARM_START_TIME)
+    args = _args(tmp_path, data)
+    args.batch_size = 8
+    params = make_params(args)
+    sess = OracleSession(args, params)
+    os.makedirs(args.log_path + "test/")
+    os.makedirs(args.log_path + "plain/")
+    st0 = np.zeros((8, 16))
+    warm, _, _, _, st_w = evaluate_hier(args, Dataloader_hier_model_xing(args, "train", data=data), st0, sess, prefix="test", warm_start=True)
+    plain, _, _, _, st_p = evaluate_hier(args, Dataloader_hier_model_xing(args, "train", data=data), st0, sess, prefix="plain")
+    np.testing.assert_array_equal(st_w, st_p)                      # the mask never reaches the model
+    assert warm["loss_epoch"] != plain["loss_epoch"]
+    # independent replay
+    ld = Dataloader_hier_model_xing(args, "train", data=data)
+    state, sums, n, n_eval, n_train, n_real = np.zeros((8, 16)), np.zeros(2), 0, 0, 0, 0
+    while True:
+        xl, yl, ml, il = ld.get_batch()
+        ts = np.concatenate(il, axis=1)[:, :, 3]
+        y_id = np.concatenate(yl, axis=1).astype(np.int64)
+        me, mt = warm_start_mask(il, train=False), warm_start_mask(il, train=True)
+        assert np.array_equal(me > 0, ts > WARM_START_TIME) and np.array_equal(mt > 0, (ts <= WARM_START_TIME) & (ts > 0))
+        assert not (me * mt).any() and np.array_equal((me + mt) > 0, y_id > 0)       # the two masks split the real events
+        n_eval, n_train, n_real = n_eval + int(me.sum()), n_train + int(mt.sum()), n_real + int((y_id > 0).sum())
+        pred, state = O.model_hier(args, xl, yl, ml, state, params)
+        m = O.masked_loss_and_metrics(pred, y_id * (me > 0), int(args.item_num))
+        assert np.isfinite(m["loss"])
+        sums += [m["loss"], m["recall10"]]
+        n += 1
+        x, y, _, lens = pack_slots(xl, yl, ml)
+        ys = warm_score_ids(y, lens, me)
+        assert ys.shape == y.shape and np.array_equal(ys > 0, (y > 0) & (ys == y)) and int((ys > 0).sum()) == int(me.sum())
+        if ld.done:
+            break
+    assert n_eval > 0 and n_train > 0 and n_eval + n_train == n_real
+    assert warm["loss_epoch"] == pytest.approx(sums[0] / n, rel=1e-12) and warm["recall10_epoch_mean"] == pytest.approx(sums[1] / n, rel=1e-12)
+    with pytest.raises(ValueError):
+        warm_score_ids(y, lens, me[:, :-1])
+    # a batch in which no lane has a scored step: user_count = 0 -> 0 / 0, as in the reference's graph
+    none = O.masked_loss_and_metrics(pred, y_id * 0, int(args.item_num))
+    assert np.isnan(none["loss"])
+
