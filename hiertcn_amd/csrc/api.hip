@@ -632,6 +632,8 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
                          int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out,
                          double* metrics8, const hiertcn_score_out_t* score_out, void* stream) {
   CHECK_READY(h);
+  const int32_t* score_ids = h->score_ids;   // one-shot (hiertcn_set_score_ids): consumed by THIS call whether it succeeds or not
+  h->score_ids = nullptr;
   const bool hier = h->m.hier != 0;
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
@@ -656,8 +658,7 @@ int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t
   const int64_t R = n_sessions * L;
   // warm-start evaluation (model.py:102-103, hiertcn_set_score_ids): targets / masks / loss / metrics from the one-shot score ids, the session mean-pool from y_ids
   const int32_t* y_pool = y_ids;
-  if (h->score_ids) y_ids = h->score_ids;
-  h->score_ids = nullptr;
+  if (score_ids) y_ids = score_ids;
   // scan first (it never reads the low level's output: model_hier.py:83-93), then every
   // (user, session) low-level problem is independent.
   // Padded steps (y == 0) have rank 0 / loss 0 by definition (model.py:105): the outputs are zeroed, the rows that do carry a target listed, and
@@ -743,14 +744,14 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
                                    int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out,
                                    double* metrics8, void* stream) {
   CHECK_READY(h);
+  const int32_t* ys = h->score_ids;   // one-shot (hiertcn_set_score_ids): consumed by THIS call whether it succeeds or not
+  h->score_ids = nullptr;
   if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (h->m.hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
   if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
-  const int32_t* ys = h->score_ids;
-  h->score_ids = nullptr;
   if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, state_in, B, S, L, workspace, state_out, metrics8, h->metric_scratch,
                              reinterpret_cast<hipStream_t>(stream), TRAIN_BEGIN | TRAIN_FINISH, nullptr, ys) != 0)
     return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
@@ -776,12 +777,12 @@ int hiertcn_train_step_begin(hiertcn_handle_t h, const int32_t* x_ids, const int
 int hiertcn_train_step_finish(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, int32_t B, int32_t S,
                               int32_t L, void* workspace, size_t workspace_bytes, void* stream) {
   CHECK_READY(h);
+  const int32_t* ys = h->score_ids;   // (set before the matching begin; consumed here whether the call succeeds or not)
+  h->score_ids = nullptr;
   if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (h->m.hier && !mask) return fail(HIERTCN_ERR_INVALID, "mask is required for hier models");
   if (workspace_bytes < train_workspace_bytes(h->m, B, S, L)) return fail(HIERTCN_ERR_WORKSPACE, "train workspace too small");
-  const int32_t* ys = h->score_ids;
-  h->score_ids = nullptr;
   if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, nullptr, B, S, L, workspace, nullptr, nullptr, h->metric_scratch,
                              reinterpret_cast<hipStream_t>(stream), TRAIN_FINISH, nullptr, ys) != 0)
     return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
