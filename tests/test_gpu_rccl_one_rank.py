@@ -87,10 +87,14 @@ def test_training_step_through_a_one_rank_rccl_group_equals_the_step_without_a_g
     one, two = np.load(tmp_path / "plain.npz"), np.load(tmp_path / (tag + ".npz"))
     assert str(two["table"]) == table and str(two["dense_taken"]) == taken       # the branch that was meant to run, ran -- over RCCL
     assert str(one["table"]) == "" and str(one["dense_taken"]) == "None"          # ... and the reference step entered no collective
-    assert np.array_equal(one["m8"], two["m8"])
+    # The two steps run in two PROCESSES: a one-rank collective is the identity, so what may differ is what differs between any two runs of the
+    # step -- fp32 atomics in a few reductions and the scoring kernels' item-walk start reorder sums (scripts/soak_refbatch.py: "gradients within
+    # 1e-5").  Most runs are bitwise equal; the bound below is the soak's.
+    np.testing.assert_allclose(one["m8"], two["m8"], rtol=1e-6, atol=0)
     n = 0
     for k in one.files:
         if k[:2] in ("g:", "w:"):
-            assert np.array_equal(one[k], two[k]), k
+            d, ref = np.linalg.norm(one[k].astype(np.float64) - two[k]), np.linalg.norm(one[k].astype(np.float64))
+            assert d <= 1e-5 * max(ref, 1e-30), (k, d, ref)
             n += 1
     assert n > 20
