@@ -20,7 +20,10 @@ struct GruBwdEpi {
 };
 hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, const GruBwdEpi& ep, hipStream_t st);
 int gemm32_skinny_max_rows();
-hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st);
+// scratch (optional): partial tiles of a reduction sliced over blockIdx.z where the output has few tiles and K is long -- the fp32 training mode's
+// d hidden [R][C] = d logits [R][NP] . Wo^T [NP][C] is 50-100 tiles behind a reduction of 20,800 (gemm32_tn's slicing, summed in slice order)
+hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st,
+                     float* scratch = nullptr, size_t scratch_floats = 0);
 //   TN: C[N1][N2] (ldc) = beta C + sum_{m < Mred} A[m][N1] (lda) . B[m][N2] (ldb); scratch (optional): partial tiles of the row slices
 hipError_t gemm32_tn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int N1, int N2, int Mred, float beta,
                      float* scratch, size_t scratch_floats, hipStream_t st);

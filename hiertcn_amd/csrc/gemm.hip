@@ -370,7 +370,8 @@ __global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, co
 // even at 4096, the tiled form ahead from 8192).  tune.skinny_max_rows (hiertcn_set_tuning) overrides.
 int gemm32_skinny_max_rows() { return tune_now().skinny_max_rows; }
 
-hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st) {
+hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, float* C, int64_t ldc, int M, int N, int K, float beta, hipStream_t st,
+                     float* scratch, size_t scratch_floats) {
   if ((K & 3) || (N & 3) || (lda & 3) || (ldb & 3)) return hipErrorInvalidValue;   // 16-byte loads along k (A) and n (B)
   if (M > 0 && M <= gemm32_skinny_max_rows() && N > 0) {
     G32 g;
@@ -380,7 +381,7 @@ hipError_t gemm32_nn(const float* A, int64_t lda, const float* B, int64_t ldb, f
     hipLaunchKernelGGL(k_gemm32_nn_skinny<0>, dim3((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32)), dim3(SK_THREADS), 0, st, g, ep);
     return hipGetLastError();
   }
-  return run32<false, true>(A, lda, B, ldb, C, ldc, M, N, K, beta, nullptr, 0, st);
+  return run32<false, true>(A, lda, B, ldb, C, ldc, M, N, K, beta, scratch, scratch_floats, st);
 }
 
 // C-less products of a GRU cell's backward (M <= 64 rows): mode 1: [M][K] = dac[M][H] . wc[H][K] with k_gru_bwd_b's arithmetic as the epilogue (ep.dcat_c

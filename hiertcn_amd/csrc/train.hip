@@ -1025,7 +1025,7 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
       T_HIP(hipGetLastError());
       T_HIP(gemm32_tn(Z, ldz, hc32, CL, G + t.outT.off, CL, m.NP, CL, (int)rc, r0 == 0 ? 0.f : 1.f, F32(w.splitk), w.splitk_floats, st));
       T_HIP(colsum_f32(Z, rc, ldz, m.NP, G + t.out_bias.off, st));
-      T_HIP(gemm32_nn(Z, ldz, xv.outT, CL, dH + r0 * CL, CL, (int)rc, CL, m.NP, 0.f, st));
+      T_HIP(gemm32_nn(Z, ldz, xv.outT, CL, dH + r0 * CL, CL, (int)rc, CL, m.NP, 0.f, st, F32(w.splitk), w.splitk_floats));   // (few output tiles, K = NP: sliced)
     }
     if (metrics8) T_HIP(launch_metrics_scratch(m, so.rank, so.ce, y, B, S * L, metrics8, metric_scratch, st));
   }
