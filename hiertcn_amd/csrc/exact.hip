@@ -322,18 +322,28 @@ __global__ __launch_bounds__(256) void k_xrow_stats(const float* __restrict__ lo
   // ONE pass over the row (it is read from HBM: a chunk of materialised logits does not fit any cache): count, running maximum and the sum
   // of exponentials relative to the running maximum (rescaled when the maximum moves), per thread; then the threads' (max, sum) pairs are
   // merged at the row maximum.  The sum is carried in fp64: N fp32 terms would put ~1e-6 of rounding into ce, this keeps it at the logit error.
+  // (eight strided elements per trip: eight loads in flight, ONE test of the running maximum and one fp64 add per eight terms -- the per-element
+  //  form, a load + a data-dependent branch + an fp64 update each, ran at 1.4 TB/s: 0.65 ms per 768-row chunk of a 300,000-item catalogue)
   float mx = -INFINITY;
   double s = 0.0;
   int cnt = 0;
-  for (int n = threadIdx.x; n < N; n += 256) {
-    const float v = z[n];
-    cnt += v > tz ? 1 : 0;
-    if (v > mx) {
-      s = s * (double)expf(mx - v) + 1.0;   // (mx = -inf at the first element: exp(-inf) = 0)
-      mx = v;
-    } else {
-      s += (double)expf(v - mx);
+  for (int n0 = threadIdx.x; n0 < N; n0 += 8 * 256) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; j++) v[j] = (n0 + 256 * j < N) ? z[n0 + 256 * j] : -INFINITY;   // (-inf: counts nothing, adds exp(-inf) = 0)
+    float m8 = v[0];
+#pragma unroll
+    for (int j = 1; j < 8; j++) m8 = fmaxf(m8, v[j]);
+#pragma unroll
+    for (int j = 0; j < 8; j++) cnt += v[j] > tz ? 1 : 0;
+    if (m8 > mx) {
+      s *= (double)expf(mx - m8);           // (mx = -inf on the first trip: exp(-inf) = 0 and s = 0)
+      mx = m8;
     }
+    float p = 0.f;                          // eight terms <= 1 each: an fp32 partial sum carries ~1e-7 of its own size into the fp64 total
+#pragma unroll
+    for (int j = 0; j < 8; j++) p += expf(v[j] - mx);
+    s += (double)p;
   }
   const float row_max = xblock_max(mx, shf);
   s *= (double)expf(mx - row_max);           // a thread that saw no element has mx = -inf, s = 0: 0 * 0
