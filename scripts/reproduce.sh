@@ -65,3 +65,7 @@ echo "== parity against the exact oracle on unrounded fp32 weights"; python3 tes
 echo "== ids starting in host memory"; python3 scripts/h2d_bench.py 2>&1 | tail -3
 echo "== repeated full-size launches agree (ranks, target logits bitwise; ce to 5e-5)"; python3 scripts/soak_score.py 2>&1 | grep mismatching
 echo "== evaluation batch and training step against the number of lanes (DESIGN 4.9, profiles/r4_lane_sweep.txt)"; bash scripts/lane_sweep.sh 2>&1 | grep -v amdgpu.ids
+echo "== fp32 TRAINING mode at the reference's batch (32 x 10 x 20, XING catalogue): HierTCN d = 256, HierGRU d = 128"
+python3 scripts/fp32_train_bench.py 30 2>&1 | tail -1; LOW=gru D=128 python3 scripts/fp32_train_bench.py 30 2>&1 | tail -1
+echo "== single-level models at the reference's defaults (model_gru: hidden 200 -> 256; model_tcn: six blocks), 32 users x T = 200"
+python3 scripts/single_level_bench.py 2>&1 | grep single-level
