@@ -23,7 +23,7 @@ typedef float f32x16x __attribute__((ext_vector_type(16)));
 #define XK 32
 #define XP 36
 
-__global__ __launch_bounds__(256) void k_xgemm(const XGemm g) {
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) void k_xgemm(const XGemm g) {   // (three workgroups per CU: <= 170 registers; four would spill 74)
   __shared__ float As[XT * XP];
   __shared__ float Bs[XT * XP];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -53,17 +53,25 @@ __global__ __launch_bounds__(256) void k_xgemm(const XGemm g) {
   const int kchunks = g.Cin / XK;
   const int n_it = g.taps * kchunks;
   float4 ra[4], rb[4];
+  // the staged rows' addresses are derived ONCE PER TAP (row index, causal shift, 64-bit row offset, the bounds tests) and advanced by one chunk per
+  // trip: re-derived per load they were ~240 vector instructions per 32-deep chunk beside its 64 MFMAs (3.7 VALU per MFMA, profiles/r5_xgemm_pmc.json)
+  const float* pa[4];
+  const float* pb[4];
   auto fetch = [&](int it) {
     const int j = it / kchunks, kc = it - j * kchunks;
-    const int sh = (g.taps - 1 - j) * g.dil;
+    if (kc == 0) {
+      const int sh = (g.taps - 1 - j) * g.dil;
+#pragma unroll
+      for (int p = 0; p < 4; p++) {
+        pa[p] = (a_src[p] >= 0 && (g.ids || a_t[p] - sh >= 0)) ? g.A + (a_src[p] - (g.ids ? 0 : sh)) * g.lda + ldc4 : nullptr;
+        const int gn = n0 + ldrow + 32 * p;
+        pb[p] = gn < g.N ? g.Wt + ((int64_t)j * g.N + gn) * g.Cin + ldc4 : nullptr;
+      }
+    }
 #pragma unroll
     for (int p = 0; p < 4; p++) {
-      ra[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (a_src[p] >= 0 && (g.ids || a_t[p] - sh >= 0))
-        ra[p] = *reinterpret_cast<const float4*>(g.A + (a_src[p] - (g.ids ? 0 : sh)) * g.lda + kc * XK + ldc4);
-      const int gn = n0 + ldrow + 32 * p;
-      rb[p] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (gn < g.N) rb[p] = *reinterpret_cast<const float4*>(g.Wt + ((int64_t)j * g.N + gn) * g.Cin + kc * XK + ldc4);
+      ra[p] = pa[p] ? *reinterpret_cast<const float4*>(pa[p] + kc * XK) : make_float4(0.f, 0.f, 0.f, 0.f);
+      rb[p] = pb[p] ? *reinterpret_cast<const float4*>(pb[p] + kc * XK) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
   };
   f32x16x acc[2][2];
