@@ -108,27 +108,40 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 3))) voi
 #undef XSTEP
     }
   }
-  // epilogue: D[row = m][col = n]; lane holds column lr of 16 rows per tile
+  // epilogue: D[row = m][col = n]; lane holds column lr of 16 rows per tile.  Row-major over the lane's 32 rows: one 64-bit row offset (and, for the
+  // projection, one 32-bit division for the sequence's row of seq_init) per ROW, the two columns' stores behind it -- the column-major form derived
+  // them per element behind per-element branches: ~10,000 instructions per wave and tile, 20 us of every tile's 34 at K = 256
+  // (scripts/xgemm_k_sweep.py: 0.36 ms + 3.5 us K per 768 x 300,000 chunk whatever the row stride)
+  int nn[2];
+  float bn[2];
 #pragma unroll
   for (int j = 0; j < 2; j++) {
-    const int n = n0 + 64 * wn + 32 * j + lr;
-    if (n >= g.N) continue;
-    const float bn = g.bias ? g.bias[n] : 0.f;
+    nn[j] = n0 + 64 * wn + 32 * j + lr;
+    bn[j] = (g.bias && nn[j] < g.N) ? g.bias[nn[j]] : 0.f;
+  }
+  const bool block = g.epi == XEPI_BLOCK;
 #pragma unroll
-    for (int i = 0; i < 2; i++) {
+  for (int i = 0; i < 2; i++) {
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int64_t m = m0 + 64 * wm + 32 * i + acc_row(q, lh);
-        if (m >= g.M) continue;
+    for (int q = 0; q < 16; q++) {
+      const int64_t m = m0 + 64 * wm + 32 * i + acc_row(q, lh);
+      if (m >= g.M) continue;
+      float* orow = g.out + m * g.ldo;
+      const float* srow = g.seq_init ? g.seq_init + (int64_t)((int)m / g.Lseq) * g.N : nullptr;   // (m < 65535 x 128 rows per launch: launch_xgemm)
+      float* o2row = (block && g.out2) ? g.out2 + m * g.ldo : nullptr;
+      const float* rrow = block ? g.res + m * g.ldres : nullptr;
+#pragma unroll
+      for (int j = 0; j < 2; j++) {
+        if (nn[j] >= g.N) continue;
         float v = acc[i][j][q];
-        if (g.seq_init) v += g.seq_init[(m / g.Lseq) * (int64_t)g.N + n];
-        v += bn;
-        if (g.epi == XEPI_BLOCK) {   // customized_tcn_cell.py:117-126: relu(relu(conv1(x)) + res(x)), dropout rate 0
+        if (srow) v += srow[nn[j]];
+        v += bn[j];
+        if (block) {   // customized_tcn_cell.py:117-126: relu(relu(conv1(x)) + res(x)), dropout rate 0
           v = fmaxf(v, 0.f);
-          if (g.out2) g.out2[m * g.ldo + n] = v;
-          v = fmaxf(v + g.res[m * g.ldres + n], 0.f);
+          if (o2row) o2row[nn[j]] = v;
+          v = fmaxf(v + rrow[nn[j]], 0.f);
         }
-        g.out[m * g.ldo + n] = v;
+        orow[nn[j]] = v;
       }
     }
   }
