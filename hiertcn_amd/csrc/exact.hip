@@ -423,11 +423,13 @@ __global__ __launch_bounds__(256) void k_xrow_topk(const float* __restrict__ log
   }
 }
 
+// rows of materialised logits per chunk: 2 GiB of scratch, at most 8192 rows.  (1 GiB / 4096 until round 5: the GEMM's rate grows with the number of
+// tile rounds of a launch -- scripts/xgemm_tile_sweep.py: 78 TFLOP/s at 3 rounds of the chip, 92 at 18 (768 rows x 300,000 items), 102 at 37.)
 int64_t exact_chunk_rows(int N) {
-  int64_t rows = ((int64_t)1 << 30) / ((int64_t)N * 4);
+  int64_t rows = ((int64_t)2 << 30) / ((int64_t)N * 4);
   rows &= ~(int64_t)127;
   if (rows < 128) rows = 128;
-  if (rows > 4096) rows = 4096;
+  if (rows > 8192) rows = 8192;
   return rows;
 }
 

@@ -161,7 +161,7 @@ int hiertcn_set_weights(hiertcn_handle_t h, const hiertcn_weights_t* w, void* st
  * product of the backward an exact-fp32 GEMM; gradients agree with fp64 autograd on the unrounded weights to ~1e-6.  model_hier with low_type 0 (TemporalConvNet) or 1 (the GRU stack) and single-level model_tcn.
  * FP32 keeps ONE logits scratch per handle: calls of a handle in that mode must not overlap on different streams (SPLIT16 and STORAGE16 have no such state).
  * The first switch to a mode must precede hiertcn_set_weights (it allocates the weight copies that set_weights fills -- for FP32 also a logits
- * scratch of <= 1 GiB owned by the handle); after that the modes may be switched back and forth between calls. */
+ * scratch of <= 2 GiB owned by the handle); after that the modes may be switched back and forth between calls. */
 #define HIERTCN_PRECISION_STORAGE16 0
 #define HIERTCN_PRECISION_FP32 1
 #define HIERTCN_PRECISION_SPLIT16 2

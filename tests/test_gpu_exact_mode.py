@@ -271,7 +271,7 @@ def test_exact_mode_topk_ties_masked_rows_and_chunks():
     Wo[:, [5, 6, 300]] *= 30                       # ... near the top of many rows
     eng = Engine(args, hier=True, dtype="fp32")
     eng.set_weights(p)
-    R = 4096 + 4096 + 37
+    R = 8192 + 8192 + 37                           # (csrc/exact.hip exact_chunk_rows: at most 8192 rows per chunk -- two full chunks and a ragged one)
     rng = np.random.default_rng(0)
     hid = torch.as_tensor(rng.standard_normal((R, d)).astype(np.float32)).to("cuda:0")
     y = rng.integers(1, N, R).astype(np.int32)
