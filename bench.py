@@ -747,7 +747,11 @@ def main():
         return out
 
     # N > 1: the secondary legs below run collectives that no hardware run has exercised at more than one rank.  A rank stuck in one would take the
-    # headline line with it, so a watchdog on EVERY rank prints the line as it stands (rank 0) and ends the process if they have not finished in time.
+    # headline line with it, so a watchdog on EVERY rank prints the line as it stands (rank 0) and ends the process if they have not finished in
+    # time -- with a NON-ZERO status (3): a run whose secondary legs never finished is not a clean run, whatever the line says (it says
+    # `secondary_legs.error`).  The other ranks hold their exit back a little: under torch.distributed.run the first non-zero exit makes the
+    # launcher end every rank, and rank 0 must have flushed its line by then.  (No re-exec, no retry from here: a process that has touched
+    # the GPU is never replaced; a caller that wants another attempt starts a fresh one.)
     watchdog = None
     if world > 1:
         import threading
@@ -756,9 +760,13 @@ def main():
         def _expired():
             if rank == 0:
                 o = make_out()
-                o["secondary_legs"] = {"error": f"not finished after {limit:.0f} s: line printed by the watchdog, process ended"}
+                o["secondary_legs"] = {"error": f"not finished after {limit:.0f} s: line printed by the watchdog, process ended with status 3"}
                 print(json.dumps(o), flush=True)
-            os._exit(0)
+                sys.stderr.write(f"bench.py: the secondary legs did not finish within {limit:.0f} s; exiting with status 3 after the partial line\n")
+                sys.stderr.flush()
+            else:
+                time.sleep(10.0)
+            os._exit(3)
         watchdog = threading.Timer(limit, _expired)
         watchdog.daemon = True
         watchdog.start()

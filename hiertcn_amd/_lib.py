@@ -86,7 +86,7 @@ ENV_TUNING = {
     "HIERTCN_SGRAD_DYN_MAX_BLOCKS": ("sgrad_dyn_max_blocks", int),
     "HIERTCN_SGRAD0_MIN_STAGES": ("sgrad0_min_stages", int),
     "HIERTCN_TCN_GS2_MAX": ("tcn_gs2_max_sessions", lambda v: -1 if int(v) <= 0 else int(v)),
-    "HIERTCN_LGRU_DEFER_MAX_GIB": ("lgru_defer_max_gib", int),
+    "HIERTCN_LGRU_DEFER_MAX_GIB": ("lgru_defer_max_gib", lambda v: -1 if int(v) <= 0 else int(v)),   # <= 0: never defer (0 in the struct = the default)
     "HIERTCN_TRAIN_FP32_CHUNK_MIB": ("train_fp32_chunk_mib", int),
 }
 

@@ -34,7 +34,7 @@ LIB_F16 = os.path.join(HERE, "libhiertcn_gfx950_f16.so")
 
 
 LIB_TESTHOOKS = os.path.join(HERE, "libhiertcn_gfx950_testhooks.so")
-TESTHOOK_SOURCES = ("gru_persist.hip", "lgru_pipe.hip")   # the sources that hold a fault-injection switch
+TESTHOOK_SOURCES = ("gru_persist.hip", "lgru_pipe.hip", "api.hip")   # the sources that hold a fault-injection switch / a test probe
 
 
 # libhiertcn_gfx950_ablation.so: the bfloat16 library PLUS every superseded kernel and A/B switch (-DHIERTCN_ABLATION=1): the previous forms of the

@@ -37,8 +37,10 @@ static const hiertcn_tuning_t* default_tuning() {
   static const hiertcn_tuning_t d = [] { hiertcn_tuning_t t; tuning_defaults(&t); return t; }();
   return &d;
 }
-static thread_local const hiertcn_tuning_t* g_tune = nullptr;   // the handle whose API call this thread is in (ON_DEVICE)
+static thread_local const hiertcn_tuning_t* g_tune = nullptr;   // set only INSIDE an API call (TuneScope); null between calls
 const hiertcn_tuning_t& tune_now() { return g_tune ? *g_tune : *default_tuning(); }
+TuneScope::TuneScope(const hiertcn_tuning_t* t) : prev(g_tune) { g_tune = t; }
+TuneScope::~TuneScope() { g_tune = prev; }
 
 static int fail(int code, const char* fmt, ...) {
   va_list ap;
@@ -97,7 +99,7 @@ struct DeviceGuard {
 };
 #define ON_DEVICE(h)                                                                       \
   DeviceGuard guard_((h)->device);                                                         \
-  g_tune = &(h)->m.tune;                                                                   \
+  TuneScope tune_(&(h)->m.tune);                                                           \
   if (!guard_.ok) return fail(HIERTCN_ERR_HIP, "cannot switch to the handle's device %d", (h)->device)
 
 extern "C" {
@@ -111,6 +113,9 @@ int hiertcn_storage_dtype(void) {
 #endif
 }
 const char* hiertcn_last_error(void) { return g_err; }
+#ifdef HIERTCN_TEST_HOOKS   // libhiertcn_gfx950_testhooks.so only: 1 while this thread is inside a TuneScope (never, seen from a caller between calls)
+int hiertcn_test_tune_in_scope(void) { return g_tune != nullptr; }
+#endif
 
 int hiertcn_create(hiertcn_handle_t* out, const hiertcn_config_t* cfg_in) {
   if (!out || !cfg_in) return fail(HIERTCN_ERR_INVALID, "null argument");
@@ -443,9 +448,11 @@ int hiertcn_set_tuning(hiertcn_handle_t h, const hiertcn_tuning_t* in) {
   THRESH(lgru_wide_max_launches, 1, 64);
   THRESH(sgrad_dyn_max_blocks, 1, 1 << 20);
   THRESH(sgrad0_min_stages, 1, 1 << 20);
-  THRESH(lgru_defer_max_gib, 1, 256);
   THRESH(train_fp32_chunk_mib, 1, 1 << 20);
 #undef THRESH
+  if (t.lgru_defer_max_gib == 0) t.lgru_defer_max_gib = d.lgru_defer_max_gib;
+  if (t.lgru_defer_max_gib < -1 || t.lgru_defer_max_gib > 256)
+    return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: lgru_defer_max_gib = %d: -1 (never defer), 0 (the default) or 1 .. 256 GiB", t.lgru_defer_max_gib);
   if (t.tcn_gs2_max_sessions == 0) t.tcn_gs2_max_sessions = d.tcn_gs2_max_sessions;
   if (t.tcn_gs2_max_sessions < -1) return fail(HIERTCN_ERR_INVALID, "hiertcn_set_tuning: tcn_gs2_max_sessions = %d: -1 (never), 0 (the default) or a session count", t.tcn_gs2_max_sessions);
   for (int32_t r : t.reserved)
@@ -477,6 +484,14 @@ int hiertcn_struct_sizes(size_t out[HIERTCN_N_STRUCTS]) {
     if (!(h)->weights_set) return fail(HIERTCN_ERR_STATE, "hiertcn_set_weights has not been called"); \
   } while (0);                                                                \
   ON_DEVICE(h)
+// The one-shot score ids (hiertcn_set_score_ids) are consumed by the step they were armed for WHETHER IT SUCCEEDS OR NOT -- a failed state / device
+// check included: take them before anything can return.
+static const int32_t* take_score_ids(hiertcn_ctx* h) {
+  if (!h) return nullptr;
+  const int32_t* ids = h->score_ids;
+  h->score_ids = nullptr;
+  return ids;
+}
 #define IS_EXACT(h) ((h)->precision != HIERTCN_PRECISION_STORAGE16)   /* fp32 hidden rows, fp32 low level: the FP32 and the SPLIT16 mode */
 #define IS_SPLIT(h) ((h)->precision == HIERTCN_PRECISION_SPLIT16)
 
@@ -631,9 +646,8 @@ size_t hiertcn_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, int32_t
 int hiertcn_forward_eval(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
                          int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out,
                          double* metrics8, const hiertcn_score_out_t* score_out, void* stream) {
+  const int32_t* score_ids = take_score_ids(h);   // one-shot (hiertcn_set_score_ids): consumed by THIS call whether it succeeds or not
   CHECK_READY(h);
-  const int32_t* score_ids = h->score_ids;   // one-shot (hiertcn_set_score_ids): consumed by THIS call whether it succeeds or not
-  h->score_ids = nullptr;
   const bool hier = h->m.hier != 0;
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
@@ -743,9 +757,8 @@ size_t hiertcn_train_workspace_bytes(hiertcn_handle_t h, int32_t B, int32_t S, i
 int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
                                    int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out,
                                    double* metrics8, void* stream) {
+  const int32_t* ys = take_score_ids(h);   // one-shot (hiertcn_set_score_ids): consumed by THIS call whether it succeeds or not
   CHECK_READY(h);
-  const int32_t* ys = h->score_ids;   // one-shot (hiertcn_set_score_ids): consumed by THIS call whether it succeeds or not
-  h->score_ids = nullptr;
   if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (h->m.hier && (!mask || !state_in || !state_out)) return fail(HIERTCN_ERR_INVALID, "mask / state_in / state_out are required for hier models");
@@ -761,6 +774,12 @@ int hiertcn_train_forward_backward(hiertcn_handle_t h, const int32_t* x_ids, con
 int hiertcn_train_step_begin(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in,
                              int32_t B, int32_t S, int32_t L, void* workspace, size_t workspace_bytes, float* state_out, double* metrics8,
                              const float* users_global, void* stream) {
+  // the ids armed for this step stay on the handle for the matching hiertcn_train_step_finish -- but only when this call succeeds: a begin that
+  // fails (a state / argument / workspace check or a launch error) drops them, so that they cannot reach an unrelated later step
+  struct DropOnFailure {
+    hiertcn_ctx* h; const int32_t* ids; bool keep = false;
+    ~DropOnFailure() { if (h && keep) h->score_ids = ids; }
+  } armed{h, take_score_ids(h)};
   CHECK_READY(h);
   if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
@@ -769,16 +788,16 @@ int hiertcn_train_step_begin(hiertcn_handle_t h, const int32_t* x_ids, const int
   if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return fail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
   if ((B + 3) / 4 > HIERTCN_METRIC_BLOCKS_MAX) return fail(HIERTCN_ERR_INVALID, "too many lanes in one call");
   if (train_forward_backward(h->m, h->train, x_ids, y_ids, mask, state_in, B, S, L, workspace, state_out, metrics8, h->metric_scratch,
-                             reinterpret_cast<hipStream_t>(stream), TRAIN_BEGIN, users_global, h->score_ids) != 0)   // (kept for the matching finish)
+                             reinterpret_cast<hipStream_t>(stream), TRAIN_BEGIN, users_global, armed.ids) != 0)
     return fail(HIERTCN_ERR_HIP, "%s", train_last_error());
+  armed.keep = true;   // (kept for the matching finish)
   return HIERTCN_OK;
 }
 
 int hiertcn_train_step_finish(hiertcn_handle_t h, const int32_t* x_ids, const int32_t* y_ids, const float* mask, int32_t B, int32_t S,
                               int32_t L, void* workspace, size_t workspace_bytes, void* stream) {
+  const int32_t* ys = take_score_ids(h);   // (set before the matching begin; consumed here whether the call succeeds or not)
   CHECK_READY(h);
-  const int32_t* ys = h->score_ids;   // (set before the matching begin; consumed here whether the call succeeds or not)
-  h->score_ids = nullptr;
   if (!h->train.enabled) return fail(HIERTCN_ERR_STATE, "training is not enabled on this handle");
   if (!x_ids || !y_ids || !workspace || B < 1 || S < 1 || L < 1) return fail(HIERTCN_ERR_INVALID, "bad argument");
   if (h->m.hier && !mask) return fail(HIERTCN_ERR_INVALID, "mask is required for hier models");

@@ -102,8 +102,18 @@ struct ModelDev {
 };
 #define XW_PACE_SLOTS 64                    // position slots per XCD class (32 workgroups are resident per XCD at one per CU)
 #define XW_PACE_INTS (XW_PACE_SLOTS + 32)   // + a line of its own for the ticket counter
-// the tuning of the handle whose API call this thread is in (api.hip sets it on entry): for the few launch helpers that take no ModelDev
+// the tuning of the handle whose API call this thread is in: for the few launch helpers that take no ModelDev (launch_gemm in pool_gru.hip,
+// gemm32_skinny_max_rows).  Every entry point that can reach them opens a TuneScope -- hiertcn_* through ON_DEVICE with the handle's tuning,
+// hiertcn_gmm_* with nullptr (= the defaults) -- which restores the previous pointer when the call returns: nothing points into a handle
+// between calls, so a destroyed handle cannot be read and one handle's thresholds never steer another's launches.
 const hiertcn_tuning_t& tune_now();
+struct TuneScope {
+  const hiertcn_tuning_t* prev;
+  explicit TuneScope(const hiertcn_tuning_t* t);
+  ~TuneScope();
+  TuneScope(const TuneScope&) = delete;
+  TuneScope& operator=(const TuneScope&) = delete;
+};
 void tuning_defaults(hiertcn_tuning_t* t);
 // A/B alternatives of superseded kernels exist in the ablation build only (hiertcn_amd/build.py, HIERTCN_ABLATION=1): there, and only there, the
 // old environment switches are looked up

@@ -502,7 +502,8 @@ size_t hiertcn_gmm_forward_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, in
 
 #define G_READY(g)                                                                       \
   if (!(g)) return gfail(HIERTCN_ERR_INVALID, "null handle");                            \
-  if (!(g)->weights_set) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_set_weights has not been called")
+  if (!(g)->weights_set) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_set_weights has not been called");   \
+  TuneScope tune_(nullptr)   /* the mixture handle has no tuning of its own: the defaults, never another handle's (common.h) */
 
 int hiertcn_gmm_forward(hiertcn_gmm_handle_t g, const int32_t* x_ids, int64_t B, int32_t T, uint16_t* hidden, void* workspace,
                         size_t workspace_bytes, void* stream) {

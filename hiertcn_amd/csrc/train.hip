@@ -681,6 +681,7 @@ struct TrainWs {
 // ~870 lanes x 10 slots x 20 steps (d = 256) fell back to the per-cell launch chain: 27.1 ms per training step at 1024 lanes against 20.0 (2048: 44.2 -> 36.3;
 // d = 128, 2048: 26.9 -> 17.0).  tune.lgru_defer_max_gib overrides.
 static bool lgru_deferred_wgrad(const ModelDev& m, size_t M, int L) {
+  if (m.tune.lgru_defer_max_gib < 0) return false;   // -1: never defer (the per-cell weight-gradient launches)
   const size_t gib = (size_t)m.tune.lgru_defer_max_gib;
   return (size_t)m.nl * L * M * 3 * m.H * 4 <= (gib << 30) && !ABL_ENV("HIERTCN_LGRU_WGRAD_PER_CELL");
 }

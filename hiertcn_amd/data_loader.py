@@ -210,7 +210,7 @@ class Dataloader_hier_model_xing:
             self._walk_c = None
 
     def __del__(self):  # pragma: no cover
-        for pre in getattr(self, "_prefetchers", []):   # no background thread inside pk_pop when the queues are freed
+        for pre in list(getattr(self, "_prefetchers", ())):   # no background thread inside pk_pop when the queues are freed
             pre.close()
         if getattr(self, "_pk", None) is not None and self._pk.value:
             self._pk_lib.pk_destroy(self._pk)
@@ -359,6 +359,23 @@ class Dataloader_hier_model_xing:
         return x, y, mask, [int(v) for v in slot_len]
 
 
+import atexit as _atexit
+import weakref as _weakref
+
+_LIVE_PREFETCHERS = _weakref.WeakSet()   # every running Prefetcher: one exit hook stops their threads before the interpreter tears down
+
+
+def _close_live_prefetchers():
+    for pre in list(_LIVE_PREFETCHERS):
+        try:
+            pre.close()
+        except Exception:  # noqa: BLE001  (interpreter exit)
+            pass
+
+
+_atexit.register(_close_live_prefetchers)
+
+
 class Prefetcher:
     """Runs a batch source (`loader.get_packed_batch`, `loader.get_batch`) on a background thread, `depth` batches ahead, so that
     packing batch i+1 overlaps the GPU work on batch i (the packers are NumPy array passes that release the GIL for most of their
@@ -371,26 +388,43 @@ class Prefetcher:
     def __init__(self, source, depth: int = 2, owner=None):
         import queue
         import threading
+        weakref = _weakref
         self._q = queue.Queue(maxsize=max(1, int(depth)))
         self._stop = threading.Event()
-        self._source, self._owner = source, owner
+        self._source = source
+        # the owner (a loader whose C packer the thread calls into) is held WEAKLY: a prefetcher must not keep its loader -- and the loader's
+        # queues -- alive, and the loader's list of prefetchers holds this object weakly in turn (no cycle, nothing pinned for the process's life)
+        self._owner = weakref.ref(owner) if owner is not None else None
+        if owner is not None and getattr(source, "__self__", None) is owner:
+            self._source = weakref.WeakMethod(source)          # (a bound method of the owner would hold it strongly)
         self.done = False
         self._t = threading.Thread(target=self._run, daemon=True)
-        # the thread calls into the owner's C packer: it is stopped and joined before that packer is destroyed (owner.__del__) and before the
-        # interpreter tears down (a daemon thread inside pk_pop while pk_destroy frees the queues would read freed memory)
+        # the thread is stopped and joined before the owner's packer is destroyed (owner.__del__ -> close) and before the interpreter tears down
+        # (ONE module-level atexit hook over the live prefetchers: a daemon thread inside pk_pop while pk_destroy frees the queues would read
+        # freed memory)
         if owner is not None:
             try:
-                owner.__dict__.setdefault("_prefetchers", []).append(self)
+                owner.__dict__.setdefault("_prefetchers", weakref.WeakSet()).add(self)
             except AttributeError:
                 pass
-        import atexit
-        atexit.register(self.close)
+        _LIVE_PREFETCHERS.add(self)
         self._t.start()
+
+    def _call_source(self):
+        src = self._source
+        if isinstance(src, _weakref.WeakMethod):
+            src = src()
+            if src is None:
+                raise RuntimeError("Prefetcher: the loader it reads from has been collected")
+        return src()
 
     def _run(self):
         while not self._stop.is_set():
             try:
-                item = (self._source(), bool(getattr(self._owner, "done", False)), None)
+                batch = self._call_source()
+                owner = self._owner() if self._owner is not None else None
+                item = (batch, bool(getattr(owner, "done", False)), None)
+                del owner
             except Exception as e:  # noqa: BLE001  (re-raised in the consumer)
                 item = (None, False, e)
             while not self._stop.is_set():
@@ -410,6 +444,28 @@ class Prefetcher:
         return batch
 
     def close(self):
+        """Stops and joins the thread, drops the batches still queued and leaves every registry (idempotent)."""
+        import threading
         self._stop.set()
-        if self._t.is_alive():
+        if self._t.is_alive() and threading.current_thread() is not self._t:   # (the loader's last reference may die on the thread itself)
             self._t.join(timeout=5.0)
+        try:
+            while True:
+                self._q.get_nowait()
+        except Exception:  # queue.Empty
+            pass
+        _LIVE_PREFETCHERS.discard(self)
+        owner = self._owner() if self._owner is not None else None
+        if owner is not None:
+            try:
+                owner.__dict__.get("_prefetchers", set()).discard(self)
+                if owner.__dict__.get("_prefetcher") is self:
+                    owner.__dict__.pop("_prefetcher")
+            except AttributeError:
+                pass
+
+    def __del__(self):  # pragma: no cover
+        try:
+            self._stop.set()
+        except Exception:  # noqa: BLE001
+            pass

@@ -14,6 +14,35 @@ import torch.distributed as dist
 
 
 _FORCE = False   # init_from_env(force_group=True): run every collective even at world size 1 (a one-rank RCCL communicator)
+_SHARED_DEVICE = False   # init_from_env found two ranks on one GPU: the persistent (co-resident) launches are switched off on every handle
+
+# what a shared device changes in hiertcn_tuning_t (include/hiertcn.h): no launch that waits on other workgroups -- the across-session scan (its
+# training form and its backward follow gru_scan_persistent) and the HierGRU low level run as launch chains
+SHARED_DEVICE_TUNING = {"gru_scan_persistent": 0, "lgru_persistent": 0}
+
+
+def shared_device() -> bool:
+    """True once init_from_env has seen two ranks of the job on one GPU.  Engine.__init__ consults it (an Engine created AFTER the decision
+    starts with SHARED_DEVICE_TUNING), and init_from_env applies the same fields to every Engine already alive, so the order of
+    `Engine(...)` and `init_from_env(...)` does not matter."""
+    return _SHARED_DEVICE
+
+
+def _mark_shared_device():
+    global _SHARED_DEVICE
+    _SHARED_DEVICE = True
+    try:
+        from . import engine as _engine
+    except Exception:  # noqa: BLE001  (no library / no GPU: there is no live handle to retune)
+        return
+    from ._lib import tuning_from_env
+    fields = {k: v for k, v in SHARED_DEVICE_TUNING.items() if k not in tuning_from_env()}   # (an explicit HIERTCN_* switch outranks the guard, as in Engine.__init__)
+    for eng in list(getattr(_engine, "_LIVE_ENGINES", ())):
+        try:
+            if fields:
+                eng.set_tuning(**fields)
+        except Exception:  # noqa: BLE001  (a closed handle)
+            pass
 
 
 def _active() -> bool:
@@ -66,8 +95,7 @@ def init_from_env(backend: str | None = None, device: torch.device | None = None
         dist.all_gather_object(idents, device_ident(device))
         shared = world > torch.cuda.device_count() * max(1, len({i.split("|")[0] for i in idents})) or len(set(idents)) < world
         if shared:
-            os.environ.setdefault("HIERTCN_GRU_CHAIN", "1")
-            os.environ.setdefault("HIERTCN_LGRU_CHAIN", "1")
+            _mark_shared_device()
     return rank, world, local_rank
 
 

@@ -13,8 +13,12 @@ from typing import Dict, Optional
 import numpy as np
 import torch
 
+import weakref
+
 from . import _lib
 from ._lib import HierTCNError, check
+
+_LIVE_ENGINES = weakref.WeakSet()   # every open Engine: distributed.init_from_env retunes them when it finds ranks sharing a GPU
 
 METRIC_KEYS = ("loss", "recall1", "recall5", "recall10", "mrr", "rank_frac", "user_count", "valid_steps")
 
@@ -135,10 +139,17 @@ class Engine:
         self._gru_ws: Optional[torch.Tensor] = None
         self._tcn_ws: Optional[torch.Tensor] = None
         self._weights_set = False
-        t = _lib.tuning_from_env()
+        # order of precedence, lowest first: a device shared between ranks (distributed.init_from_env's decision, whenever it is taken: live
+        # engines are retuned there) < the HIERTCN_* environment switches < the `tuning` argument
+        t = {}
+        from . import distributed as _dist
+        if _dist.shared_device():
+            t.update(_dist.SHARED_DEVICE_TUNING)
+        t.update(_lib.tuning_from_env())
         t.update(tuning or {})
         if t:
             self.set_tuning(**t)
+        _LIVE_ENGINES.add(self)
 
     # ---------------------------------------------------------------------------------------
     def get_tuning(self) -> dict:
@@ -167,6 +178,7 @@ class Engine:
         if getattr(self, "_h", None) is not None and self._h.value:
             self.lib.hiertcn_destroy(self._h)
             self._h = C.c_void_p()
+            _LIVE_ENGINES.discard(self)
 
     def __del__(self):  # pragma: no cover
         try:
@@ -361,6 +373,22 @@ class Engine:
         self._score_keep = y_score           # (alive until the step that consumes it has been enqueued and the next one replaces it)
         self._ck(self.lib.hiertcn_set_score_ids(self._h, _ptr(y_score)))
 
+    def _armed(self, y_score, call):
+        """Runs the C call of a step with the one-shot score ids armed IMMEDIATELY before it -- behind every argument check and workspace
+        allocation of the Python side -- and disarmed again if anything raises, so that an exception never leaves ids behind for an unrelated
+        later step (the library consumes them in the call itself, successful or not; a failed hiertcn_train_step_begin drops them too)."""
+        if y_score is None:
+            return call()
+        self.set_score_ids(y_score)
+        try:
+            return call()
+        except BaseException:
+            try:
+                self.set_score_ids(None)
+            except Exception:  # noqa: BLE001  (the original error is the one to report)
+                pass
+            raise
+
     def forward_eval(self, x_ids, y_ids, mask, state_in, want_rows=False, state_out=None, metrics8=None, topk: int = 0, y_score=None):
         """One evaluation step on a packed batch: x_ids, y_ids [B,S,L] int32; mask [B,S] fp32;
         state_in [B,H*nl] fp32.  Returns dict(state, metrics8 (device, 8 doubles)[, rank, ce][, topk_idx, topk_val]).
@@ -368,7 +396,6 @@ class Engine:
         B, S, L = x_ids.shape
         if y_score is not None:
             _req(y_score, torch.int32, "y_score", (B, S, L))
-            self.set_score_ids(y_score)
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
         if self.hier:
@@ -397,9 +424,9 @@ class Engine:
             if topk > 0:
                 out["topk_idx"] = ti.view(B, S * L, topk)
                 out["topk_val"] = tv.view(B, S * L, topk)
-        self._ck(self.lib.hiertcn_forward_eval(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
-                                            _ptr(ws), ws.numel(), _ptr(state_out), _ptr(metrics8),
-                                            C.byref(so) if so is not None else None, self._stream()))
+        self._armed(y_score, lambda: self._ck(self.lib.hiertcn_forward_eval(
+            self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L, _ptr(ws), ws.numel(), _ptr(state_out), _ptr(metrics8),
+            C.byref(so) if so is not None else None, self._stream())))
         return out
 
     # -- hipGraph replay of the evaluation step (launch-bound at the reference's batch sizes) ------------------------
@@ -416,7 +443,6 @@ class Engine:
         B, S, L = x_ids.shape
         if y_score is not None:
             _req(y_score, torch.int32, "y_score", (B, S, L))
-            self.set_score_ids(y_score)
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
         if self.hier:
@@ -431,9 +457,9 @@ class Engine:
             self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
         if metrics8 is None:
             metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
-        self._ck(self.lib.hiertcn_train_forward_backward(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L,
-                                                      _ptr(self._train_ws), self._train_ws.numel(), _ptr(state_out), _ptr(metrics8),
-                                                      self._stream()))
+        self._armed(y_score, lambda: self._ck(self.lib.hiertcn_train_forward_backward(
+            self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L, _ptr(self._train_ws), self._train_ws.numel(), _ptr(state_out),
+            _ptr(metrics8), self._stream())))
         return dict(state=state_out, metrics8=metrics8)
 
     # -- the step in two halves + helpers for data-parallel runs (hiertcn.h "data-parallel training") ---------------------
@@ -450,7 +476,6 @@ class Engine:
         B, S, L = x_ids.shape
         if y_score is not None:
             _req(y_score, torch.int32, "y_score", (B, S, L))
-            self.set_score_ids(y_score)
         _req(x_ids, torch.int32, "x_ids", (B, S, L))
         _req(y_ids, torch.int32, "y_ids", (B, S, L))
         if self.hier:
@@ -465,15 +490,20 @@ class Engine:
         ws = self._train_ws_for(B, S, L)
         if metrics8 is None:
             metrics8 = torch.empty(8, dtype=torch.float64, device=self.device)
-        self._ck(self.lib.hiertcn_train_step_begin(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L, _ptr(ws),
-                                                ws.numel(), _ptr(state_out), _ptr(metrics8), _ptr(users_global), self._stream()))
+        self._armed(y_score, lambda: self._ck(self.lib.hiertcn_train_step_begin(
+            self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask), _ptr(state_in), B, S, L, _ptr(ws), ws.numel(), _ptr(state_out), _ptr(metrics8),
+            _ptr(users_global), self._stream())))   # (on success the ids stay armed for the matching train_step_finish)
         return dict(state=state_out, metrics8=metrics8)
 
     def train_step_finish(self, x_ids, y_ids, mask=None):
         B, S, L = x_ids.shape
-        ws = self._train_ws_for(B, S, L)
-        self._ck(self.lib.hiertcn_train_step_finish(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask if self.hier else None), B, S, L,
-                                                 _ptr(ws), ws.numel(), self._stream()))
+        try:
+            ws = self._train_ws_for(B, S, L)
+            self._ck(self.lib.hiertcn_train_step_finish(self._h, _ptr(x_ids), _ptr(y_ids), _ptr(mask if self.hier else None), B, S, L,
+                                                     _ptr(ws), ws.numel(), self._stream()))
+        except BaseException:
+            self.lib.hiertcn_set_score_ids(self._h, None)   # whatever the matching begin armed must not reach an unrelated later step
+            raise
 
     def count_users(self, y_ids: torch.Tensor) -> torch.Tensor:
         """-> device float32 [1]: lanes of y [B, ...] with at least one target (model.py:113)."""

@@ -200,7 +200,7 @@ typedef struct {
   int32_t sgrad_dyn_max_blocks;       /* row blocks up to which the scoring backward deals its grid on the device (default 1024)            */
   int32_t sgrad0_min_stages;          /* catalogue stages per part of the scoring backward's forward split (default 64)                     */
   int32_t tcn_gs2_max_sessions;       /* sessions up to which the fused TCN kernel runs two sessions per workgroup (default 512; -1 never)  */
-  int32_t lgru_defer_max_gib;         /* GiB of records up to which HierGRU's weight gradients are deferred to one GEMM (default 8)         */
+  int32_t lgru_defer_max_gib;         /* GiB of records up to which HierGRU's weight gradients are deferred to one GEMM (default 8; -1 never) */
   int32_t train_fp32_chunk_mib;       /* fp32 training mode: MiB of materialised fp32 logits per row chunk of the scoring layer (default 8192)   */
   int32_t reserved[10];               /* zero                                                                                               */
 } hiertcn_tuning_t;
@@ -326,6 +326,8 @@ int hiertcn_count_users(hiertcn_handle_t h, const int32_t* y_ids, int32_t B, int
  * ONE-SHOT: the next hiertcn_forward_eval, hiertcn_train_forward_backward or hiertcn_train_step_begin + _finish pair of this handle takes
  * its targets, masks, loss, ranks, metrics and row weights from y_score_ids, while the session mean-pool of model_hier.py:83-85 (and its
  * backward) keeps reading the y_ids passed to that call; the pointer must stay valid until that call's work has run.  NULL clears it.
+ * The ids are consumed by that call WHETHER IT SUCCEEDS OR NOT (a failed state check included); a hiertcn_train_step_begin that returns an
+ * error drops them instead of keeping them for a finish that will not come: no error path leaves ids armed for an unrelated later step.
  * (hiertcn_count_users for such a step takes y_score_ids too: a lane counts when it has a SCORED target.) */
 int hiertcn_set_score_ids(hiertcn_handle_t h, const int32_t* y_score_ids);
 int hiertcn_train_segment(hiertcn_handle_t h, int32_t which, size_t* offset, size_t* count);

@@ -138,3 +138,44 @@ def test_native_packer_equals_the_numpy_packer(B, S, L, shuffle):
                 assert np.array_equal(va, vb) and va.dtype == vb.dtype
             else:
                 assert va == vb
+
+
+def test_prefetcher_order_and_lifecycle(fx, data):
+    """Prefetcher: the source's batches in order; nothing pins a prefetcher, its queue or its loader for the life of the process:
+    close() leaves every registry, and a loader dropped WITHOUT close() takes its prefetcher's thread with it."""
+    import gc
+    import time
+    import weakref
+
+    from hiertcn_amd.data_loader import _LIVE_PREFETCHERS, Prefetcher
+
+    B, S, max_act = [int(v) for v in fx["meta"][:3]]
+    args = hier_tcn_args(batch_size=B, max_session_num=S, max_activity_len=max_act)
+    want_ld = Dataloader_hier_model_xing(args, "train", data=data)
+    want = [want_ld.get_packed_batch() for _ in range(4)]
+    live0 = len(_LIVE_PREFETCHERS)
+    ld = Dataloader_hier_model_xing(args, "train", data=data)
+    pre = ld._prefetcher = Prefetcher(ld.get_packed_batch, depth=2, owner=ld)
+    for w in want:
+        got = pre.get()
+        for a, b in zip(got[:3], w[:3]):
+            np.testing.assert_array_equal(a, b)
+    assert len(_LIVE_PREFETCHERS) == live0 + 1 and pre in ld._prefetchers
+    thread = pre._t
+    pre.close()
+    pre.close()                                              # idempotent
+    assert not thread.is_alive() and pre._q.empty()
+    assert len(_LIVE_PREFETCHERS) == live0 and pre not in ld._prefetchers and "_prefetcher" not in ld.__dict__
+    # a second prefetcher on the same loader, then the loader is dropped without close()
+    pre2 = ld._prefetcher = Prefetcher(ld.get_packed_batch, depth=2, owner=ld)
+    pre2.get()
+    t2, wl, wp = pre2._t, weakref.ref(ld), weakref.ref(pre2)
+    del ld, pre2, pre
+    for _ in range(50):
+        gc.collect()
+        if not t2.is_alive() and wl() is None and wp() is None:
+            break
+        time.sleep(0.1)
+    assert wl() is None, "the prefetcher (or its thread) kept the loader alive"
+    assert not t2.is_alive() and wp() is None
+    assert len(_LIVE_PREFETCHERS) == live0

@@ -56,7 +56,19 @@ def _worker(rank, world, port, out_dir, tag, sparse_fraction):
     import torch.distributed as dist
     from hiertcn_amd.distributed import init_from_env
     torch.cuda.set_device(0)
+    # the shared-GPU guard: two ranks on one device -> no launch that waits on co-resident workgroups, on a handle created BEFORE
+    # init_from_env took the decision as well as on the ones created after it
+    from hiertcn_amd import distributed as hd
+    from hiertcn_amd.engine import Engine
+    early = Engine(small_args(N=N, d=D, H=H, S=S, L=L, B=B), hier=True)
+    assert early.get_tuning()["gru_scan_persistent"] == -1 and not hd.shared_device()
     init_from_env("gloo")
+    assert hd.shared_device()
+    late = Engine(small_args(N=N, d=D, H=H, S=S, L=L, B=B), hier=True)
+    for e in (early, late):
+        t = e.get_tuning()
+        assert t["gru_scan_persistent"] == 0 and t["lgru_persistent"] == 0, t
+        e.close()
     first, count = (0, 5) if rank == 0 else (5, 4)      # uneven shards: 5 + 4 lanes
     _run(rank, world, first, count, out_dir, tag)
     dist.barrier()

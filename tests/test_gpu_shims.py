@@ -86,3 +86,21 @@ def test_model_tcn_single_level_like_model_py():
     assert abs(loss - ref["loss"]) < 1e-3 and abs(float(rf) - ref["rank_frac"]) < 5e-3
     assert np.abs(pred.materialize().cpu().numpy() - z).max() < 1e-3
     M.reset_scopes()
+
+
+def test_the_tuning_of_a_call_in_progress_never_outlives_the_call():
+    """csrc/common.h TuneScope.  tests/tools/tune_scope_probe.py runs against the test-hooks build (the only one that exports the
+    probe symbol) in a process of its own; the shipped libraries do not export it."""
+    import os
+    import subprocess
+    import sys
+
+    from hiertcn_amd.build import LIB, LIB_F16, LIB_TESTHOOKS
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    assert os.path.exists(LIB_TESTHOOKS), "python -m hiertcn_amd.build (or __graft_entry__.build()) builds the test-hooks library"
+    env = dict(os.environ, HIERTCN_LIB=LIB_TESTHOOKS)
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "tune_scope_probe.py")], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    assert "tune_scope_probe ok" in r.stdout
+    for path in (LIB, LIB_F16):
+        assert b"hiertcn_test_tune_in_scope" not in open(path, "rb").read(), path

@@ -179,6 +179,61 @@ def test_training_step_with_score_ids_in_the_16_bit_mode_and_two_halves():
     eng.close()
 
 
+def test_a_failed_step_never_leaves_score_ids_armed():
+    """the one-shot ids are armed immediately before the C call, behind every check of the Python side, and any failure --
+    a Python-side shape check, a rejected argument inside the library, a failed hiertcn_train_step_begin, a finish that raises -- leaves
+    nothing behind: the next plain step is scored against its own targets."""
+    import ctypes as C
+
+    from hiertcn_amd.engine import Engine, HierTCNError, metrics_dict
+    args, p, x, y, ys, mask, st0 = _case("tcn", d=64, H=64, N=900, seed=5)
+    B, S, L = x.shape
+    eng = Engine(args, hier=True, train=True)
+    eng.set_weights(p)
+    X, Y, YS, M, ST = dev(x), dev(y), dev(ys), dev(mask), dev(st0)
+    plain = metrics_dict(eng.forward_eval(X, Y, M, ST)["metrics8"])
+    masked = metrics_dict(eng.forward_eval(X, Y, M, ST, y_score=YS)["metrics8"])
+    assert masked["valid_steps"] < plain["valid_steps"]
+    full_steps = plain["valid_steps"]
+
+    def next_plain_eval_is_plain(where):
+        got = metrics_dict(eng.forward_eval(X, Y, M, ST)["metrics8"])
+        assert got["valid_steps"] == full_steps and abs(got["loss"] - plain["loss"]) <= 1e-6 * abs(plain["loss"]), (where, got, plain)
+
+    # (1) Python-side checks fail AFTER y_score itself was accepted: evaluation, training, the first half of a step
+    bad_state = ST[:, :-1].contiguous()
+    for name, call in (("forward_eval", lambda: eng.forward_eval(X, Y, M, bad_state, y_score=YS)),
+                       ("train_forward_backward", lambda: eng.train_forward_backward(X, Y, M, bad_state, y_score=YS)),
+                       ("train_step_begin", lambda: eng.train_step_begin(X, Y, M, bad_state, y_score=YS))):
+        with pytest.raises(HierTCNError):
+            call()
+        next_plain_eval_is_plain(name + " / python check")
+    # (2) the library rejects the call with the ids armed: consumed all the same (forward_eval, train_forward_backward), dropped (begin)
+    lib, h = eng.lib, eng._h
+    for name, call in (
+            ("hiertcn_forward_eval", lambda: lib.hiertcn_forward_eval(h, None, None, None, None, B, S, L, None, 0, None, None, None, None)),
+            ("hiertcn_train_forward_backward", lambda: lib.hiertcn_train_forward_backward(h, None, None, None, None, B, S, L, None, 0, None, None, None)),
+            ("hiertcn_train_step_begin", lambda: lib.hiertcn_train_step_begin(h, None, None, None, None, B, S, L, None, 0, None, None, None, None))):
+        eng.set_score_ids(YS)
+        assert call() != 0
+        next_plain_eval_is_plain(name + " / library check")
+    # (3) a begin that succeeded keeps them for ITS finish; a finish that fails consumes them
+    eng.train_step_begin(X, Y, M, ST, y_score=YS)
+    assert lib.hiertcn_train_step_finish(h, None, None, None, B, S, L, None, 0, None) != 0
+    next_plain_eval_is_plain("failed finish")
+    # (4) and the ordinary pair still carries them from begin to finish
+    a = eng.train_forward_backward(X, Y, M, ST, y_score=YS)
+    ga = eng.export("grads")
+    eng.train_step_begin(X, Y, M, ST, y_score=YS)
+    eng.train_step_finish(X, Y, M)
+    gb = eng.export("grads")
+    for k in ga:
+        assert np.linalg.norm(ga[k] - gb[k]) <= 1e-5 * max(np.linalg.norm(ga[k]), 1e-30), k
+    assert metrics_dict(a["metrics8"])["valid_steps"] == masked["valid_steps"]
+    next_plain_eval_is_plain("after an ordinary pair")
+    eng.close()
+
+
 def test_run_hier_and_run_nn_in_the_warm_start_protocol(tmp_path, monkeypatch):
     """`run_xing --warm_start` (run_xing.py:20-35: all three loaders on the 'train' users; training counts the events up to the warm-start time,
     evaluation the later ones): evaluate_hier on the device against the oracle session, then run_hier trains and the warm-start test loss falls;
