@@ -11,7 +11,7 @@ LIB_PATH = os.path.join(HERE, "libhiertcn_gfx950.so")
 MAX_BLOCKS = 8
 MAX_LAYERS = 4
 MAX_TOPK = 16
-ABI_VERSION = 11
+ABI_VERSION = 12
 N_STRUCTS = 6
 PRECISION_STORAGE16, PRECISION_FP32, PRECISION_SPLIT16 = 0, 1, 2
 
@@ -168,6 +168,15 @@ SYMBOLS = {
                                     C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
     "hiertcn_gmm_head_means": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_void_p, C.c_void_p]),
     "hiertcn_gmm_lane_loss": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]),
+    "hiertcn_gmm_train_enable": (C.c_int, [C.c_void_p, C.POINTER(GmmWeights), C.c_void_p]),
+    "hiertcn_gmm_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
+    "hiertcn_gmm_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
+                                          C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hiertcn_gmm_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "hiertcn_gmm_adam_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hiertcn_gmm_train_sync": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "hiertcn_gmm_train_copy": (C.c_int, [C.c_void_p, C.c_int32, C.c_int32, C.POINTER(GmmWeights), C.c_void_p]),
+    "hiertcn_gmm_train_arena": (C.c_int, [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
     "hiertcn_timing_enable": (C.c_int, [C.c_void_p, C.c_int32]),
     "hiertcn_timing_read": (C.c_int, [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.c_int32]),
     "hiertcn_persistent_health": (C.c_int, [C.c_void_p, C.POINTER(C.c_int32)]),

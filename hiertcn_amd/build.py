@@ -11,7 +11,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "build")
 LIB = os.path.join(HERE, "libhiertcn_gfx950.so")
-SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "score_x3w.hip", "lgru_tile.hip", "lgru_pipe.hip", "lgru_wide.hip"]
+SOURCES = ["api.hip", "prep.hip", "pool_gru.hip", "gru_persist.hip", "tcn.hip", "tcn_layers.hip", "score.hip", "score_bwd.hip", "metrics.hip", "train.hip", "gmm.hip", "gmm_train.hip", "gmm_gram.hip", "exact.hip", "gemm.hip", "gru_x3.hip", "score_x3.hip", "score_x3w.hip", "lgru_tile.hip", "lgru_pipe.hip", "lgru_wide.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wall", "-Wno-unused-function", "-Wno-pass-failed", "-Wno-shift-negative-value",
          "-fno-gpu-rdc", "-D__HIP_PLATFORM_AMD__"]
 
@@ -87,7 +87,7 @@ NO_NAN_SOURCES = ("score.hip", "score_x3.hip", "score_x3w.hip")
 
 
 def _headers():
-    return [os.path.join(CSRC, h) for h in ("common.h", "train.h", "exact.h", "gemm.h", "score_geom.h", "score_lists.h", "score_x3.h")] + [
+    return [os.path.join(CSRC, h) for h in ("common.h", "train.h", "exact.h", "gemm.h", "gmm.h", "score_geom.h", "score_lists.h", "score_x3.h")] + [
         os.path.join(HERE, "..", "include", "hiertcn.h")]
 
 

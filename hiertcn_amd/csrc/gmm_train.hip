@@ -1,0 +1,735 @@
+// Training step of the mixture-output model (BASELINE.json configs[4]; model_tcn_gmm.py:27-44 + the likelihood losses of loss.py:247-257 under
+// model.py:111-117's lane mean and model.py:135-141's Adam).  C-ABI: hiertcn_gmm_train_* / hiertcn_gmm_adam_* in include/hiertcn.h (ABI 12).
+//
+// The reference never trains these models on XING (calc_loss_gmm has no caller and model.py:105-132 cannot build the graph), so
+// the step is defined by the build's own decode (oracle/gmm_oracle.py) and checked against fp64 autograd of that decode (tests/test_gpu_gmm_train.py).
+//
+// Everything is fp32 on the masters (the fp32 training mode's recipe, train.hip): exact-fp32 MFMA GEMMs (gemm.hip, exact.hip), nothing rounded to
+// 16 bits.  What makes the step cheap is the same algebra as the forward's Gram form (gmm_gram.hip): for a one-hot target
+//     d2_m = |y - mu_m|^2 = h^T G_m h + 2 h.v_m + |b_m|^2 - 2 mu_m[y] + 1,     G_m = W_m W_m^T [C x C],  v_m = W_m b_m,
+// so neither the [rows, M D] means nor their gradient are ever formed.  With g_rm = d loss / d d2_m * 2 per (row, mixture):
+//     d h_r      = sum_m g_rm (G_m h_r + v_m - W_m[:, y_r]) + W_pi d a_r
+//     d W_m^T    = W_m^T S_m + b_m s_m^T - scatter(y_r <- g_rm h_r),       S_m = sum_r g_rm h_r h_r^T [C x C],  s_m = sum_r g_rm h_r
+//     d b_m      = W_m^T s_m + (sum_r g_rm) b_m - scatter(y_r <- g_rm)
+// i.e. per mixture two [rows x C x C] products, one [C x D x C] product (G_m) and one [D x C x C] product (d W_m^T) instead of two
+// [rows x D x C] ones: at the reference's batch (6,400 rows, D = 20,778, C = 256, M = 5) 0.14 TFLOP instead of 0.7, and no 2.7 GB matrix.
+// The trunk is model_tcn_gmm's: block 0 reads one-hot rows, so its conv taps and its Dense residual are row GATHERS of [K + 1][N][C0] tables in
+// the forward and row SCATTER-ADDS in the backward; blocks 1.. are train.hip's fp32 TemporalBlock forward / backward.
+//
+// Built for: trunk 0 (the TemporalConvNet on ids), a fixed scale (args.sigma set), loss modes gmm_prob and gmm_prob_max.  The GRU trunk, the dense-row
+// trunks of model_hier's mixture low levels and a learned scale evaluate only (hiertcn_gmm_train_enable refuses them).
+#include <math.h>
+#include <string.h>
+
+#include "exact.h"
+#include "gemm.h"
+#include "gmm.h"
+#include "train.h"
+
+#define GT_MP 16   // the prior logits' gradient is kept [rows][16] (num_mixture <= 16; the fp32 GEMM wants multiples of 4)
+
+struct GSeg {
+  size_t off = 0, n = 0;   // floats, inside each arena
+};
+
+struct GmmTrain {
+  float* arena = nullptr;   // [4][total], REFERENCE (TF) layouts: master | grad | m | v -- a checkpoint is a copy, Adam is elementwise
+  size_t total = 0;
+  GSeg conv[HIERTCN_MAX_BLOCKS], conv_b[HIERTCN_MAX_BLOCKS], res[HIERTCN_MAX_BLOCKS], res_b[HIERTCN_MAX_BLOCKS], head_w, head_b;
+  int64_t step = 0;         // Adam time step
+  bool stale = false;       // the handle's evaluation tables (gmm.hip) are older than the masters: hiertcn_gmm_train_sync
+  // compute-layout copies of the masters, re-derived at the start of every step, and the gradients in the same layouts
+  float* work = nullptr;    // one allocation behind everything below
+  float* convT[HIERTCN_MAX_BLOCKS] = {};    // [K][Cout][Cin], blocks >= 1
+  float* resT[HIERTCN_MAX_BLOCKS] = {};     // [Cout][Cin]
+  float* dconvT[HIERTCN_MAX_BLOCKS] = {};
+  float* dresT[HIERTCN_MAX_BLOCKS] = {};
+  float *Wt = nullptr, *bt = nullptr, *pw = nullptr, *pb = nullptr;         // [M][DP][C] item-major (pad rows zero), [M][DP], [GT_MP][C], [GT_MP]
+  float *dWt = nullptr, *dbt = nullptr, *dpw = nullptr, *dpb = nullptr;
+  float *Gm = nullptr, *vm = nullptr, *cm = nullptr, *Sm = nullptr, *sm = nullptr, *gs = nullptr;   // [M][C][C], [M][C], [M], [M][C][C], [M][C], [M]
+  float* splitk = nullptr;
+  size_t splitk_floats = 0;
+  float* master() const { return arena; }
+  float* grad() const { return arena + total; }
+  float* mom1() const { return arena + 2 * total; }
+  float* mom2() const { return arena + 3 * total; }
+};
+
+void gmm_train_destroy(GmmTrain* t) {
+  if (!t) return;
+  if (t->arena) (void)hipFree(t->arena);
+  if (t->work) (void)hipFree(t->work);
+  delete t;
+}
+
+static size_t up64(size_t n) { return (n + 63) & ~(size_t)63; }
+
+// ---- layout transposes between the reference's tensors and the compute layouts --------------------------------------------------------------
+// dst[j * ld_dst + i] = src[i * ld_src + j]   (i < rows, j < cols), 32 x 32 tiles through LDS: both sides coalesced whatever the strides
+__global__ __launch_bounds__(256) void k_gt_transpose(const float* __restrict__ src, int64_t ld_src, float* __restrict__ dst, int64_t ld_dst, int rows,
+                                                      int cols) {
+  __shared__ float tile[32][33];
+  const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+  for (int k = ty; k < 32; k += 8) {
+    const int i = i0 + k, j = j0 + tx;
+    tile[k][tx] = (i < rows && j < cols) ? src[(int64_t)i * ld_src + j] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int j = j0 + k, i = i0 + tx;
+    if (i < rows && j < cols) dst[(int64_t)j * ld_dst + i] = tile[tx][k];
+  }
+}
+static hipError_t gt_transpose(const float* src, int64_t ld_src, float* dst, int64_t ld_dst, int rows, int cols, hipStream_t st) {
+  hipLaunchKernelGGL(k_gt_transpose, dim3((unsigned)((cols + 31) / 32), (unsigned)((rows + 31) / 32)), dim3(256), 0, st, src, ld_src, dst, ld_dst, rows, cols);
+  return hipGetLastError();
+}
+
+// ---- block 0 on ids, fp32: a0 = relu(relu(b + sum_j W_j[id[t - s_j]]) + Wr[id[t]] + br), c0 = relu(conv) kept for the backward --------------------
+// (customized_tcn_cell.py:46-49,102-106,120-127 on one_hot(id) * sign(id), model.py:56-61: a one-hot row times a kernel is that kernel's row)
+__global__ __launch_bounds__(256) void k_gt_block0(const float* __restrict__ conv, const float* __restrict__ res, const float* __restrict__ b0,
+                                                   const float* __restrict__ br0, const int32_t* __restrict__ ids, int64_t R, int T, int N, int C0, int K,
+                                                   float* __restrict__ a0, float* __restrict__ c0) {
+  const int ch = C0 >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch) * 4;
+  const int t = (int)(r % T);
+  float4 acc = *reinterpret_cast<const float4*>(b0 + c), rs = *reinterpret_cast<const float4*>(br0 + c);
+  for (int j = 0; j < K; j++) {
+    const int s = K - 1 - j;                 // tap j reads id[t - (K-1-j)] (dilation 1)
+    if (t - s < 0) continue;                 // causal left padding: zeros
+    const int id = ids[r - s];
+    if (id <= 0 || id >= N) continue;        // null / out-of-range id: an all-zero one-hot row
+    const float4 v = *reinterpret_cast<const float4*>(conv + ((int64_t)j * N + id) * C0 + c);
+    acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+  }
+  const int id = ids[r];
+  if (id > 0 && id < N) {
+    const float4 v = *reinterpret_cast<const float4*>(res + (int64_t)id * C0 + c);
+    rs.x += v.x; rs.y += v.y; rs.z += v.z; rs.w += v.w;
+  }
+  const float4 cc = make_float4(fmaxf(acc.x, 0.f), fmaxf(acc.y, 0.f), fmaxf(acc.z, 0.f), fmaxf(acc.w, 0.f));
+  *reinterpret_cast<float4*>(c0 + r * C0 + c) = cc;
+  *reinterpret_cast<float4*>(a0 + r * C0 + c) = make_float4(fmaxf(cc.x + rs.x, 0.f), fmaxf(cc.y + rs.y, 0.f), fmaxf(cc.z + rs.z, 0.f), fmaxf(cc.w + rs.w, 0.f));
+}
+// its backward: the rows the forward gathered receive ds (residual table) / dc (tap tables) -- scatter-adds into the [K][N][C0] and [N][C0] gradients
+__global__ __launch_bounds__(256) void k_gt_block0_bwd(const float* __restrict__ ds, const float* __restrict__ dc, const int32_t* __restrict__ ids, int64_t R,
+                                                       int T, int N, int C0, int K, float* __restrict__ dconv, float* __restrict__ dres) {
+  const int ch = C0 >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch) * 4;
+  const int t = (int)(r % T);
+  const float4 g = *reinterpret_cast<const float4*>(dc + r * C0 + c);
+  if (g.x != 0.f || g.y != 0.f || g.z != 0.f || g.w != 0.f)
+    for (int j = 0; j < K; j++) {
+      const int s = K - 1 - j;
+      if (t - s < 0) continue;
+      const int id = ids[r - s];
+      if (id <= 0 || id >= N) continue;
+      float* d = dconv + ((int64_t)j * N + id) * C0 + c;
+      atomicAdd(d, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+    }
+  const int id = ids[r];
+  if (id > 0 && id < N) {
+    const float4 q = *reinterpret_cast<const float4*>(ds + r * C0 + c);
+    float* d = dres + (int64_t)id * C0 + c;
+    if (q.x != 0.f) atomicAdd(d, q.x);
+    if (q.y != 0.f) atomicAdd(d + 1, q.y);
+    if (q.z != 0.f) atomicAdd(d + 2, q.z);
+    if (q.w != 0.f) atomicAdd(d + 3, q.w);
+  }
+}
+
+// ---- head ------------------------------------------------------------------------------------------------------------------------------------------
+// vm[m][c] += sum_d Wt[m][d][c] bt[m][d] over this block's slice of d;  cm[m] += sum_d bt[m][d]^2   (outputs zeroed by the caller)
+__global__ __launch_bounds__(256) void k_gt_vc(const float* __restrict__ Wt, const float* __restrict__ bt, int DP, int C, int dslice,
+                                               float* __restrict__ vm, float* __restrict__ cm) {
+  const int m = blockIdx.y;
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  const int q = threadIdx.x >> 6;
+  const int d0 = blockIdx.z * dslice, d1 = (d0 + dslice < DP) ? d0 + dslice : DP;
+  const float* W = Wt + (size_t)m * DP * C;
+  const float* b = bt + (size_t)m * DP;
+  float acc = 0.f, sq = 0.f;
+  for (int d = d0 + q; d < d1; d += 4) {
+    const float bd = b[d];
+    if (c < C) acc = fmaf(W[(size_t)d * C + c], bd, acc);
+    sq = fmaf(bd, bd, sq);
+  }
+  __shared__ float red[4][64];
+  red[q][threadIdx.x & 63] = acc;
+  __syncthreads();
+  if (q == 0 && c < C) atomicAdd(vm + (size_t)m * C + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(cm + m, sq);   // (each of the 4 d-quarters of this block once)
+}
+
+struct HeadRows {
+  const float* H;        // [R][C] hidden rows
+  const float* X;        // [M][R][C] = H . G_m
+  const float* Wt;       // [M][DP][C]
+  const float* bt;       // [M][DP]
+  const float* pw;       // [GT_MP][C]
+  const float* pb;       // [GT_MP]
+  const float* vm;       // [M][C]
+  const float* cm;       // [M]
+  const int32_t* y;      // [R]
+  const float* act;      // [B] valid steps per lane
+  const float* users;    // [1]
+  int64_t R;
+  int T, C, M, D, DP, mode;
+  float inv_s2;          // 1 / sigma^2
+  double cst_over_D;     // (-D log sigma - D/2 log 2 pi) / D
+  float* loss;           // [R] per-step loss (0 on rows without a target), unweighted: what hiertcn_gmm_loss returns
+  float* dH;             // [R][C]
+  float* GH;             // [M][R][C] = g_rm h_r
+  float* gv;             // [M][R]    = g_rm
+  float* dA;             // [R][GT_MP] = d loss / d prior logits
+};
+// one wave per row: the M (prior logit, h^T G h, h.v, mu[y]) dot products, the loss, its gradient w.r.t. the row
+template <int CPL>   // channels per lane = C / 64
+__global__ __launch_bounds__(256) void k_gt_head_rows(const HeadRows a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const int C = a.C, M = a.M;
+  const int yy = a.y[r];
+  const bool valid = yy > 0 && yy < a.D;
+  float h[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; k++) h[k] = a.H[r * C + lane + 64 * k];
+  float pl[16], d2[16];
+  for (int m = 0; m < M; m++) {
+    const float* xr = a.X + ((size_t)m * a.R + r) * C;
+    const float* wy = a.Wt + ((size_t)m * a.DP + (valid ? yy : 0)) * C;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      const int c = lane + 64 * k;
+      s0 = fmaf(h[k], a.pw[(size_t)m * C + c], s0);
+      s1 = fmaf(h[k], xr[c], s1);
+      s2 = fmaf(h[k], a.vm[(size_t)m * C + c], s2);
+      s3 = fmaf(h[k], wy[c], s3);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); s2 += __shfl_xor(s2, off); s3 += __shfl_xor(s3, off);
+    }
+    pl[m] = s0 + a.pb[m];
+    const float sq = s1 + 2.f * s2 + a.cm[m];                                        // |mu_m|^2
+    const float tg = valid ? s3 + a.bt[(size_t)m * a.DP + yy] : 0.f;                 // mu_m[y]
+    d2[m] = sq - 2.f * tg + 1.f;
+  }
+  // log pi = log_softmax(prior logits)
+  float mx = -INFINITY;
+  for (int m = 0; m < M; m++) mx = fmaxf(mx, pl[m]);
+  float se = 0.f;
+  for (int m = 0; m < M; m++) se += expf(pl[m] - mx);
+  const float lse_pi = mx + logf(se);
+  const float u = a.users[0];
+  const float w = (valid && u > 0.f) ? 1.0f / ((a.act[r / a.T] + 1e-6f) * u) : 0.f;   // d (batch loss) / d loss_r (model.py:111-117)
+  const float invD = 1.0f / (float)a.D;
+  float gpi[16], g[16];   // d L / d log pi_m;  2 d L / d d2_m
+  float loss = 0.f;
+  if (a.mode == 0) {      // gmm_prob (loss.py:248): -log_prob / D, log_prob = LSE_m(log pi_m - d2_m / (2 sigma^2)) + cst
+    float z[16], zmax = -INFINITY;
+    for (int m = 0; m < M; m++) { z[m] = (pl[m] - lse_pi) - 0.5f * a.inv_s2 * d2[m]; zmax = fmaxf(zmax, z[m]); }
+    float s = 0.f;
+    for (int m = 0; m < M; m++) { z[m] = expf(z[m] - zmax); s += z[m]; }
+    loss = (float)(-((double)(zmax + logf(s)) * (double)invD + a.cst_over_D));
+    for (int m = 0; m < M; m++) {
+      const float rho = z[m] / s;
+      gpi[m] = -w * rho * invD;
+      g[m] = w * rho * a.inv_s2 * invD;
+    }
+  } else {                // gmm_prob_max (loss.py:249-257): -max_m (log pi_m + mvn_m / D); the gradient goes to the (first) arg max
+    float best = -INFINITY;
+    int mb = 0;
+    for (int m = 0; m < M; m++) {
+      const float v = (pl[m] - lse_pi) - 0.5f * a.inv_s2 * d2[m] * invD;
+      if (v > best) { best = v; mb = m; }
+    }
+    loss = (float)(-((double)best + a.cst_over_D));
+    for (int m = 0; m < M; m++) { gpi[m] = (m == mb) ? -w : 0.f; g[m] = (m == mb) ? w * a.inv_s2 * invD : 0.f; }
+  }
+  if (!valid) loss = 0.f;
+  float gsum = 0.f;
+  for (int m = 0; m < M; m++) gsum += gpi[m];
+  float da[16];
+  for (int m = 0; m < M; m++) da[m] = gpi[m] - expf(pl[m] - lse_pi) * gsum;      // log_softmax backward
+  // d h = sum_m g_m (G_m h + v_m - W_m[:, y]) + sum_j da_j pi_w[j];   GH_m = g_m h
+  float dh[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; k++) dh[k] = 0.f;
+  for (int m = 0; m < M; m++) {
+    const float* xr = a.X + ((size_t)m * a.R + r) * C;
+    const float* wy = a.Wt + ((size_t)m * a.DP + (valid ? yy : 0)) * C;
+    float* gh = a.GH + ((size_t)m * a.R + r) * C;
+#pragma unroll
+    for (int k = 0; k < CPL; k++) {
+      const int c = lane + 64 * k;
+      dh[k] += g[m] * (xr[c] + a.vm[(size_t)m * C + c] - wy[c]) + da[m] * a.pw[(size_t)m * C + c];
+      gh[c] = g[m] * h[k];
+    }
+  }
+#pragma unroll
+  for (int k = 0; k < CPL; k++) a.dH[r * C + lane + 64 * k] = dh[k];
+  if (lane == 0) {
+    a.loss[r] = loss;
+    for (int m = 0; m < M; m++) a.gv[(size_t)m * a.R + r] = g[m];
+  }
+  if (lane < GT_MP) a.dA[r * GT_MP + lane] = lane < M ? da[lane] : 0.f;
+}
+
+// dWt[m][d][:] += bt[m][d] s_m[:];  dbt[m][d] = Wt[m][d] . s_m + gs[m] bt[m][d]   -- one wave per (m, d) row, d < D
+__global__ __launch_bounds__(256) void k_gt_head_fix(const float* __restrict__ Wt, const float* __restrict__ bt, const float* __restrict__ sm,
+                                                     const float* __restrict__ gs, int M, int D, int DP, int C, float* __restrict__ dWt,
+                                                     float* __restrict__ dbt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= (int64_t)M * D) return;
+  const int m = (int)(row / D), d = (int)(row - (int64_t)m * D);
+  const size_t o = ((size_t)m * DP + d) * C;
+  const float bd = bt[(size_t)m * DP + d];
+  float dot = 0.f;
+  for (int c = lane; c < C; c += 64) {
+    const float s = sm[(size_t)m * C + c];
+    dot = fmaf(Wt[o + c], s, dot);
+    dWt[o + c] += bd * s;
+  }
+  for (int off = 32; off > 0; off >>= 1) dot += __shfl_xor(dot, off);
+  if (lane == 0) dbt[(size_t)m * DP + d] = dot + gs[m] * bd;
+}
+// the target column of every row: dWt[m][y_r][:] -= g_rm h_r, dbt[m][y_r] -= g_rm   (GH holds g_rm h_r)
+__global__ __launch_bounds__(256) void k_gt_head_scatter(const float* __restrict__ GH, const float* __restrict__ gv, const int32_t* __restrict__ y, int64_t R,
+                                                         int M, int D, int DP, int C, float* __restrict__ dWt, float* __restrict__ dbt) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= R) return;
+  const int yy = y[r];
+  if (yy <= 0 || yy >= D) return;
+  for (int m = 0; m < M; m++) {
+    const float g = gv[(size_t)m * R + r];
+    if (g == 0.f) continue;
+    const float* gh = GH + ((size_t)m * R + r) * C;
+    float* dst = dWt + ((size_t)m * DP + yy) * C;
+    for (int c = lane; c < C; c += 64) atomicAdd(dst + c, -gh[c]);
+    if (lane == 0) atomicAdd(dbt + (size_t)m * DP + yy, -g);
+  }
+}
+// gs[m] = sum_r gv[m][r]   (one workgroup per mixture, fixed-order tree)
+__global__ __launch_bounds__(256) void k_gt_rowsum(const float* __restrict__ gv, int64_t R, float* __restrict__ gs) {
+  __shared__ float red[256];
+  const float* v = gv + (size_t)blockIdx.x * R;
+  float acc = 0.f;
+  for (int64_t r = threadIdx.x; r < R; r += 256) acc += v[r];
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if ((int)threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) gs[blockIdx.x] = red[0];
+}
+// head gradients from the compute layouts into the reference layout: dW[c][m] = dpw[m][c], db[m] = dpb[m], db[M + m D + d] = dbt[m][d]
+__global__ void k_gt_head_small(const float* __restrict__ dpw, const float* __restrict__ dpb, const float* __restrict__ dbt, int M, int D, int DP, int C,
+                                int64_t n_out, float* __restrict__ dW, float* __restrict__ db) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (int64_t)M * C) {
+    const int m = (int)(i / C), c = (int)(i - (int64_t)m * C);
+    dW[(int64_t)c * n_out + m] = dpw[(size_t)m * C + c];
+  }
+  if (i < M) db[i] = dpb[i];
+  if (i < (int64_t)M * D) {
+    const int m = (int)(i / D), d = (int)(i - (int64_t)m * D);
+    db[M + i] = dbt[(size_t)m * DP + d];
+  }
+}
+
+// ---- the handle's training state -------------------------------------------------------------------------------------------------------------------
+static void gt_layout(const hiertcn_gmm_ctx* g, GmmTrain* t) {
+  size_t off = 0;
+  auto seg = [&](GSeg& s, size_t n) { s.off = off; s.n = n; off += up64(n); };
+  const int K = g->K;
+  for (int i = 0, cin = g->N; i < g->nb; cin = g->cfg.channels[i], i++) {
+    const int cout = g->cfg.channels[i];
+    seg(t->conv[i], (size_t)K * cin * cout);
+    seg(t->conv_b[i], cout);
+    if (cin != cout) { seg(t->res[i], (size_t)cin * cout); seg(t->res_b[i], cout); }
+  }
+  const size_t n_out = (size_t)g->M * (1 + (size_t)g->D);
+  seg(t->head_w, (size_t)g->Clast * n_out);
+  seg(t->head_b, n_out);
+  t->total = off;
+}
+
+static int cmax_of(const hiertcn_gmm_ctx* g) {
+  int w = 0;
+  for (int i = 0; i < g->nb; i++) w = g->cfg.channels[i] > w ? g->cfg.channels[i] : w;
+  return w;
+}
+
+struct GtWs {
+  size_t act[HIERTCN_MAX_BLOCKS], cact[HIERTCN_MAX_BLOCKS], resb, X, GH, dA, gv, loss, dH, bufA, bufB, ds, dc, sh, lane_act, users, total;
+};
+static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
+  GtWs w;
+  memset(&w, 0, sizeof(w));
+  const size_t R = (size_t)B * T;
+  size_t off = 0;
+  auto take = [&](size_t floats) { const size_t o = off; off += ((floats * 4) + 255) & ~(size_t)255; return o; };
+  for (int i = 0; i < g->nb; i++) { w.act[i] = take(R * g->cfg.channels[i]); w.cact[i] = take(R * g->cfg.channels[i]); }
+  const size_t cm = (size_t)cmax_of(g), C = (size_t)g->Clast;
+  w.resb = take(R * cm);
+  w.X = take((size_t)g->M * R * C);
+  w.GH = take((size_t)g->M * R * C);
+  w.dA = take(R * GT_MP);
+  w.gv = take((size_t)g->M * R);
+  w.loss = take(R);
+  w.dH = take(R * cm);
+  w.bufA = take(R * cm);
+  w.bufB = take(R * cm);
+  w.ds = take(R * cm);
+  w.dc = take(R * cm);
+  w.sh = take(R * cm);
+  w.lane_act = take((size_t)B);
+  w.users = take(64);
+  w.total = off;
+  return w;
+}
+
+#define GT_READY(g)                                                                                                    \
+  if (!(g)) return gfail(HIERTCN_ERR_INVALID, "null handle");                                                          \
+  if (!(g)->train) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_train_enable has not been called on this handle");     \
+  TuneScope tune_(nullptr)
+
+static void master_ptrs(const hiertcn_gmm_ctx* g, const GmmTrain* t, const float* base, hiertcn_gmm_weights_t* w) {
+  memset(w, 0, sizeof(*w));
+  for (int i = 0; i < g->nb; i++) {
+    w->conv_kernel[i] = base + t->conv[i].off;
+    w->conv_bias[i] = base + t->conv_b[i].off;
+    if (t->res[i].n) { w->res_kernel[i] = base + t->res[i].off; w->res_bias[i] = base + t->res_b[i].off; }
+  }
+  w->head_weights = base + t->head_w.off;
+  w->head_biases = base + t->head_b.off;
+}
+
+// compute-layout copies of the masters (start of a step): conv / residual kernels of blocks >= 1 output-major, the head item-major
+static int gt_refresh(hiertcn_gmm_ctx* g, hipStream_t st) {
+  GmmTrain* t = g->train;
+  const float* P = t->master();
+  const int K = g->K, C = g->Clast, M = g->M, D = g->D, DP = g->DP;
+  for (int i = 1, cin = g->C0; i < g->nb; cin = g->cfg.channels[i], i++) {
+    const int cout = g->cfg.channels[i];
+    for (int j = 0; j < K; j++)
+      G_HIP(gt_transpose(P + t->conv[i].off + (size_t)j * cin * cout, cout, t->convT[i] + (size_t)j * cin * cout, cin, cin, cout, st));
+    if (t->res[i].n) G_HIP(gt_transpose(P + t->res[i].off, cout, t->resT[i], cin, cin, cout, st));
+  }
+  const int64_t n_out = (int64_t)M * (1 + (int64_t)D);
+  const float* W = P + t->head_w.off;
+  const float* b = P + t->head_b.off;
+  for (int m = 0; m < M; m++) {
+    G_HIP(gt_transpose(W + M + (int64_t)m * D, n_out, t->Wt + (size_t)m * DP * C, C, C, D, st));   // Wt[m][d][c] = W[c][M + m D + d]
+    G_HIP(hipMemcpyAsync(t->bt + (size_t)m * DP, b + M + (size_t)m * D, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
+  }
+  G_HIP(gt_transpose(W, n_out, t->pw, C, C, M, st));                                               // pw[m][c] = W[c][m]
+  G_HIP(hipMemcpyAsync(t->pb, b, (size_t)M * 4, hipMemcpyDeviceToDevice, st));
+  return HIERTCN_OK;
+}
+
+extern "C" {
+
+int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream) {
+  if (!g || !w) return gfail(HIERTCN_ERR_INVALID, "null argument");
+  if (g->train) return gfail(HIERTCN_ERR_STATE, "training is already enabled on this handle");
+  if (g->trunk != 0)
+    return gfail(HIERTCN_ERR_INVALID, "the training step is built for the TemporalConvNet trunk on ids (trunk 0: model_tcn_gmm); trunk %d evaluates only", g->trunk);
+  if (g->learned) return gfail(HIERTCN_ERR_INVALID, "the training step is built for a fixed scale (args.sigma set); a learned scale evaluates only");
+  if (g->M > GT_MP) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: the training step takes up to 16 mixtures", g->M);
+  if (g->Clast != 64 && g->Clast != 128 && g->Clast != 256 && g->Clast != 512) return gfail(HIERTCN_ERR_INVALID, "last width %d: 64, 128, 256, 512", g->Clast);
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  TuneScope tune_(nullptr);
+  if (!w->head_weights || !w->head_biases) return gfail(HIERTCN_ERR_INVALID, "the head (fully_connected weights / biases) is required");
+  for (int i = 0, cin = g->N; i < g->nb; cin = g->cfg.channels[i], i++) {
+    if (!w->conv_kernel[i] || !w->conv_bias[i]) return gfail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
+    if ((cin != g->cfg.channels[i]) != (w->res_kernel[i] != nullptr && w->res_bias[i] != nullptr))
+      return gfail(HIERTCN_ERR_INVALID, "block %d: a Dense residual (kernel and bias) exists exactly when Cin != Cout", i);
+  }
+  GmmTrain* t = new GmmTrain();
+  gt_layout(g, t);
+  hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->arena), 4 * t->total * sizeof(float));
+  if (e != hipSuccess) { gmm_train_destroy(t); return gfail(HIERTCN_ERR_HIP, "hipMalloc of the training arenas (%zu MB) failed: %s", 4 * t->total * 4 >> 20, hipGetErrorString(e)); }
+  // working set
+  const size_t C = (size_t)g->Clast, M = (size_t)g->M, DP = (size_t)g->DP;
+  size_t off = 0;
+  auto take = [&](size_t floats) { const size_t o = off; off += up64(floats); return o; };
+  size_t o_convT[HIERTCN_MAX_BLOCKS] = {}, o_resT[HIERTCN_MAX_BLOCKS] = {}, o_dconvT[HIERTCN_MAX_BLOCKS] = {}, o_dresT[HIERTCN_MAX_BLOCKS] = {};
+  for (int i = 1; i < g->nb; i++) {
+    o_convT[i] = take(t->conv[i].n); o_dconvT[i] = take(t->conv[i].n);
+    if (t->res[i].n) { o_resT[i] = take(t->res[i].n); o_dresT[i] = take(t->res[i].n); }
+  }
+  const size_t o_Wt = take(M * DP * C), o_bt = take(M * DP), o_pw = take(GT_MP * C), o_pb = take(GT_MP);
+  const size_t o_dWt = take(M * DP * C), o_dbt = take(M * DP), o_dpw = take(GT_MP * C), o_dpb = take(GT_MP);
+  const size_t o_Gm = take(M * C * C), o_vm = take(M * C), o_cm = take(64), o_Sm = take(M * C * C), o_sm = take(M * C), o_gs = take(64);
+  size_t sk = 128 * C * C;
+  if (sk > ((size_t)16 << 20)) sk = (size_t)16 << 20;
+  const size_t o_sk = take(sk);
+  e = hipMalloc(reinterpret_cast<void**>(&t->work), off * sizeof(float));
+  if (e != hipSuccess) { gmm_train_destroy(t); return gfail(HIERTCN_ERR_HIP, "hipMalloc of the training work set (%zu MB) failed: %s", off * 4 >> 20, hipGetErrorString(e)); }
+  for (int i = 1; i < g->nb; i++) {
+    t->convT[i] = t->work + o_convT[i]; t->dconvT[i] = t->work + o_dconvT[i];
+    if (t->res[i].n) { t->resT[i] = t->work + o_resT[i]; t->dresT[i] = t->work + o_dresT[i]; }
+  }
+  t->Wt = t->work + o_Wt; t->bt = t->work + o_bt; t->pw = t->work + o_pw; t->pb = t->work + o_pb;
+  t->dWt = t->work + o_dWt; t->dbt = t->work + o_dbt; t->dpw = t->work + o_dpw; t->dpb = t->work + o_dpb;
+  t->Gm = t->work + o_Gm; t->vm = t->work + o_vm; t->cm = t->work + o_cm; t->Sm = t->work + o_Sm; t->sm = t->work + o_sm; t->gs = t->work + o_gs;
+  t->splitk = t->work + o_sk; t->splitk_floats = sk;
+  hipError_t e2 = hipMemsetAsync(t->work, 0, off * sizeof(float), st);   // (the pad rows d >= D of the item-major tables stay zero for good)
+  if (e2 == hipSuccess) e2 = hipMemsetAsync(t->arena, 0, 4 * t->total * sizeof(float), st);
+  if (e2 != hipSuccess) { gmm_train_destroy(t); return gfail(HIERTCN_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e2)); }
+  g->train = t;
+  // masters <- the caller's tensors (reference layouts: plain copies)
+  hiertcn_gmm_weights_t dst;
+  master_ptrs(g, t, t->master(), &dst);
+  for (int i = 0; i < g->nb; i++) {
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.conv_kernel[i]), w->conv_kernel[i], t->conv[i].n * 4, hipMemcpyDeviceToDevice, st));
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.conv_bias[i]), w->conv_bias[i], t->conv_b[i].n * 4, hipMemcpyDeviceToDevice, st));
+    if (t->res[i].n) {
+      G_HIP(hipMemcpyAsync(const_cast<float*>(dst.res_kernel[i]), w->res_kernel[i], t->res[i].n * 4, hipMemcpyDeviceToDevice, st));
+      G_HIP(hipMemcpyAsync(const_cast<float*>(dst.res_bias[i]), w->res_bias[i], t->res_b[i].n * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_weights), w->head_weights, t->head_w.n * 4, hipMemcpyDeviceToDevice, st));
+  G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_biases), w->head_biases, t->head_b.n * 4, hipMemcpyDeviceToDevice, st));
+  t->step = 0;
+  t->stale = true;
+  return HIERTCN_OK;
+}
+
+size_t hiertcn_gmm_train_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T) {
+  if (!g || B < 1 || T < 1) return 0;
+  return gt_ws(g, B, T).total;
+}
+
+int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, int64_t B, int32_t T, int32_t mode,
+                           const float* users_global, void* workspace, size_t workspace_bytes, double* out2, float* loss_rows, void* stream) {
+  GT_READY(g);
+  if (!x_ids || !y_ids || !workspace || B < 1 || T < 1 || T > 4096 || B > (int64_t)1 << 22) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  if (mode != 0 && mode != 1) return gfail(HIERTCN_ERR_INVALID, "mode %d: 0 (gmm_prob) or 1 (gmm_prob_max)", mode);
+  const GtWs w = gt_ws(g, B, T);
+  if (workspace_bytes < w.total) return gfail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.total);
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return gfail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
+  if ((int64_t)B * T > (int64_t)1 << 30) return gfail(HIERTCN_ERR_INVALID, "too many rows in one step");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  GmmTrain* t = g->train;
+  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+#define F32(o) reinterpret_cast<float*>(ws + (o))
+  const int64_t R = B * T;
+  const int K = g->K, C = g->Clast, M = g->M, D = g->D, DP = g->DP, N = g->N, C0 = g->C0, nb = g->nb;
+  const float* P = t->master();
+  float* G = t->grad();
+  if (int rc = gt_refresh(g, st)) return rc;
+  G_HIP(hipMemsetAsync(G, 0, t->total * sizeof(float), st));
+
+  // ================= forward on the masters =================================================================================================
+  hipLaunchKernelGGL(k_gt_block0, dim3((unsigned)((R * (C0 >> 2) + 255) / 256)), dim3(256), 0, st, P + t->conv[0].off, P + t->res[0].off, P + t->conv_b[0].off,
+                     P + t->res_b[0].off, x_ids, R, T, N, C0, K, F32(w.act[0]), F32(w.cact[0]));
+  G_HIP(hipGetLastError());
+  for (int i = 1, cin = C0; i < nb; cin = g->cfg.channels[i], i++) {
+    const int cout = g->cfg.channels[i];
+    const float* res = F32(w.act[i - 1]);
+    int64_t ldres = cin;
+    if (cin != cout) {   // customized_tcn_cell.py:102-106: a biased Dense on the residual path
+      XGemm r = {};
+      r.A = F32(w.act[i - 1]); r.lda = cin; r.Wt = t->resT[i]; r.taps = 1; r.Cin = cin; r.M = R; r.N = cout; r.bias = P + t->res_b[i].off;
+      r.out = F32(w.resb); r.ldo = cout; r.epi = XEPI_LINEAR;
+      G_HIP(launch_xgemm(r, st));
+      res = F32(w.resb); ldres = cout;
+    }
+    XGemm x = {};
+    x.A = F32(w.act[i - 1]); x.lda = cin; x.Wt = t->convT[i]; x.taps = K; x.dil = 1 << i; x.L = T; x.Cin = cin; x.M = R; x.N = cout;
+    x.bias = P + t->conv_b[i].off; x.res = res; x.ldres = ldres; x.out = F32(w.act[i]); x.out2 = F32(w.cact[i]); x.ldo = cout; x.epi = XEPI_BLOCK;
+    G_HIP(launch_xgemm(x, st));
+  }
+  const float* H = F32(w.act[nb - 1]);
+
+  // ================= head: G_m, v_m, |b_m|^2 from the masters; X_m = H G_m; the row-wise kernel ==============================================
+  G_HIP(hipMemsetAsync(t->vm, 0, (size_t)M * C * 4, st));
+  G_HIP(hipMemsetAsync(t->cm, 0, 64 * 4, st));
+  for (int m = 0; m < M; m++)
+    G_HIP(gemm32_tn(t->Wt + (size_t)m * DP * C, C, t->Wt + (size_t)m * DP * C, C, t->Gm + (size_t)m * C * C, C, C, C, DP, 0.f, t->splitk, t->splitk_floats, st));
+  {
+    const int dslice = 1024;
+    hipLaunchKernelGGL(k_gt_vc, dim3((unsigned)((C + 63) / 64), (unsigned)M, (unsigned)((DP + dslice - 1) / dslice)), dim3(256), 0, st, t->Wt, t->bt, DP, C, dslice,
+                       t->vm, t->cm);
+    G_HIP(hipGetLastError());
+  }
+  for (int m = 0; m < M; m++)
+    G_HIP(gemm32_nn(H, C, t->Gm + (size_t)m * C * C, C, F32(w.X) + (size_t)m * R * C, C, (int)R, C, C, 0.f, st));
+  G_HIP(train_lane_act(y_ids, (int)B, T, F32(w.lane_act), F32(w.users), st));
+  float* loss = loss_rows ? loss_rows : F32(w.loss);
+  {
+    HeadRows a;
+    a.H = H; a.X = F32(w.X); a.Wt = t->Wt; a.bt = t->bt; a.pw = t->pw; a.pb = t->pb; a.vm = t->vm; a.cm = t->cm; a.y = y_ids;
+    a.act = F32(w.lane_act); a.users = users_global ? users_global : F32(w.users);
+    a.R = R; a.T = T; a.C = C; a.M = M; a.D = D; a.DP = DP; a.mode = mode;
+    const double sg = (double)g->cfg.sigma;
+    a.inv_s2 = (float)(1.0 / (sg * sg));
+    a.cst_over_D = (-(double)D * log(sg) - 0.5 * (double)D * log(2.0 * M_PI)) / (double)D;
+    a.loss = loss; a.dH = F32(w.dH); a.GH = F32(w.GH); a.gv = F32(w.gv); a.dA = F32(w.dA);
+    const dim3 grid((unsigned)((R + 3) / 4));
+    if (C == 64) hipLaunchKernelGGL(k_gt_head_rows<1>, grid, dim3(256), 0, st, a);
+    else if (C == 128) hipLaunchKernelGGL(k_gt_head_rows<2>, grid, dim3(256), 0, st, a);
+    else if (C == 256) hipLaunchKernelGGL(k_gt_head_rows<4>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_gt_head_rows<8>, grid, dim3(256), 0, st, a);
+    G_HIP(hipGetLastError());
+  }
+  if (out2) {
+    if (int rc = hiertcn_gmm_lane_loss(g, loss, y_ids, (int32_t)B, T, out2, stream)) return rc;
+  }
+
+  // ================= head backward ==============================================================================================================
+  G_HIP(hipMemsetAsync(t->sm, 0, (size_t)M * C * 4, st));
+  for (int m = 0; m < M; m++) {
+    const float* GHm = F32(w.GH) + (size_t)m * R * C;
+    G_HIP(gemm32_tn(GHm, C, H, C, t->Sm + (size_t)m * C * C, C, C, C, (int)R, 0.f, t->splitk, t->splitk_floats, st));   // S_m = sum_r g_rm h_r h_r^T
+    G_HIP(train_colsum_f32(GHm, R, C, C, t->sm + (size_t)m * C, st));                                                     // s_m = sum_r g_rm h_r
+    G_HIP(gemm32_nn(t->Wt + (size_t)m * DP * C, C, t->Sm + (size_t)m * C * C, C, t->dWt + (size_t)m * DP * C, C, DP, C, C, 0.f, st));   // W_m^T S_m
+  }
+  hipLaunchKernelGGL(k_gt_rowsum, dim3((unsigned)M), dim3(256), 0, st, F32(w.gv), R, t->gs);
+  hipLaunchKernelGGL(k_gt_head_fix, dim3((unsigned)(((int64_t)M * D + 3) / 4)), dim3(256), 0, st, t->Wt, t->bt, t->sm, t->gs, M, D, DP, C, t->dWt, t->dbt);
+  hipLaunchKernelGGL(k_gt_head_scatter, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, F32(w.GH), F32(w.gv), y_ids, R, M, D, DP, C, t->dWt, t->dbt);
+  G_HIP(hipGetLastError());
+  // prior: d pi_w[m][:] = sum_r dA[r][m] h_r, d pi_b[m] = sum_r dA[r][m]
+  G_HIP(gemm32_tn(F32(w.dA), GT_MP, H, C, t->dpw, C, GT_MP, C, (int)R, 0.f, t->splitk, t->splitk_floats, st));
+  G_HIP(hipMemsetAsync(t->dpb, 0, GT_MP * 4, st));
+  G_HIP(train_colsum_f32(F32(w.dA), R, GT_MP, GT_MP, t->dpb, st));
+  // ... into the reference layout [C][M (1 + D)] / [M (1 + D)]
+  const int64_t n_out = (int64_t)M * (1 + (int64_t)D);
+  float* dW = G + t->head_w.off;
+  float* db = G + t->head_b.off;
+  for (int m = 0; m < M; m++) G_HIP(gt_transpose(t->dWt + (size_t)m * DP * C, C, dW + M + (int64_t)m * D, n_out, D, C, st));
+  {
+    const int64_t n = (int64_t)M * (D > C ? D : C);
+    hipLaunchKernelGGL(k_gt_head_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t->dpw, t->dpb, t->dbt, M, D, DP, C, n_out, dW, db);
+    G_HIP(hipGetLastError());
+  }
+
+  // ================= TemporalBlocks, last to first (train.hip's fp32 recipe) ===========================================================================
+  float* da = F32(w.dH);
+  float* dprev = F32(w.bufA);
+  float* spare = F32(w.bufB);
+  float* ds = F32(w.ds);
+  float* dc = F32(w.dc);
+  float* sh = F32(w.sh);
+  for (int i = nb - 1; i >= 1; i--) {
+    const int cin = g->cfg.channels[i - 1], cout = g->cfg.channels[i];
+    const float* a_in = F32(w.act[i - 1]);
+    const int dil = 1 << i;
+    const int64_t nOut = R * cout;
+    G_HIP(train_block_bwd_f32(da, F32(w.act[i]), F32(w.cact[i]), nOut, ds, dc, st));
+    G_HIP(train_colsum_f32(dc, R, cout, cout, G + t->conv_b[i].off, st));
+    if (t->res[i].n) {
+      G_HIP(train_colsum_f32(ds, R, cout, cout, G + t->res_b[i].off, st));
+      G_HIP(gemm32_tn(ds, cout, a_in, cin, t->dresT[i], cin, cout, cin, (int)R, 0.f, t->splitk, t->splitk_floats, st));   // d resT[Cout][Cin] = ds^T . a_in
+      G_HIP(gemm32_nn(ds, cout, t->resT[i], cin, dprev, cin, (int)R, cin, cout, 0.f, st));                                   // d a_in = ds . resT
+      G_HIP(gt_transpose(t->dresT[i], cin, G + t->res[i].off, cout, cout, cin, st));                                         // -> [Cin][Cout]
+    } else {
+      G_HIP(hipMemcpyAsync(dprev, ds, (size_t)nOut * 4, hipMemcpyDeviceToDevice, st));   // identity residual
+    }
+    for (int j = 0; j < K; j++) {   // tap j reads a_in[t - s_j], s_j = (K-1-j) dil (customized_tcn_cell.py:46-49)
+      const int sj = (K - 1 - j) * dil;
+      float* dWj = t->dconvT[i] + (size_t)j * cout * cin;
+      if (sj >= T) { G_HIP(hipMemsetAsync(dWj, 0, (size_t)cout * cin * 4, st)); continue; }   // the tap only ever saw the zero padding
+      const float* a_sh = a_in;
+      const float* dc_sh = dc;
+      if (sj > 0) { G_HIP(train_shift_rows_f32(a_in, R, cin, T, sj, sh, st)); a_sh = sh; }
+      G_HIP(gemm32_tn(dc, cout, a_sh, cin, dWj, cin, cout, cin, (int)R, 0.f, t->splitk, t->splitk_floats, st));   // d W_j[Cout][Cin] = sum_t dc[t]^T . a_in[t - s_j]
+      if (sj > 0) { G_HIP(train_shift_rows_f32(dc, R, cout, T, -sj, sh, st)); dc_sh = sh; }
+      G_HIP(gemm32_nn(dc_sh, cout, t->convT[i] + (size_t)j * cout * cin, cin, dprev, cin, (int)R, cin, cout, 1.f, st));   // d a_in[tau] += dc[tau + s_j] . W_j
+      G_HIP(gt_transpose(dWj, cin, G + t->conv[i].off + (size_t)j * cin * cout, cout, cout, cin, st));                   // -> [Cin][Cout]
+    }
+    float* tmp = da; da = dprev; dprev = (tmp == F32(w.dH)) ? spare : tmp;
+  }
+  // block 0: pointwise part, bias sums, then the row scatter-adds into the gathered tables
+  {
+    const int64_t nOut = R * C0;
+    G_HIP(train_block_bwd_f32(da, F32(w.act[0]), F32(w.cact[0]), nOut, ds, dc, st));
+    G_HIP(train_colsum_f32(dc, R, C0, C0, G + t->conv_b[0].off, st));
+    G_HIP(train_colsum_f32(ds, R, C0, C0, G + t->res_b[0].off, st));
+    hipLaunchKernelGGL(k_gt_block0_bwd, dim3((unsigned)((R * (C0 >> 2) + 255) / 256)), dim3(256), 0, st, ds, dc, x_ids, R, T, N, C0, K, G + t->conv[0].off,
+                       G + t->res[0].off);
+    G_HIP(hipGetLastError());
+  }
+#undef F32
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_adam_step(hiertcn_gmm_handle_t g, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
+  GT_READY(g);
+  GmmTrain* t = g->train;
+  t->step += 1;
+  G_HIP(train_adam_flat(t->master(), t->grad(), t->mom1(), t->mom2(), t->total, lr, beta1, beta2, eps, grad_scale, t->step, reinterpret_cast<hipStream_t>(stream)));
+  t->stale = true;
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_adam_time(hiertcn_gmm_handle_t g, int64_t* get, const int64_t* set) {
+  GT_READY(g);
+  if (set) {
+    if (*set < 0) return gfail(HIERTCN_ERR_INVALID, "the Adam time step cannot be negative");
+    g->train->step = *set;
+  }
+  if (get) *get = g->train->step;
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_train_sync(hiertcn_gmm_handle_t g, void* stream) {
+  GT_READY(g);
+  GmmTrain* t = g->train;
+  if (!t->stale && g->weights_set) return HIERTCN_OK;
+  hiertcn_gmm_weights_t w;
+  master_ptrs(g, t, t->master(), &w);
+  if (int rc = hiertcn_gmm_set_weights(g, &w, stream)) return rc;
+  t->stale = false;
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_train_copy(hiertcn_gmm_handle_t g, int32_t which, int32_t to_handle, const hiertcn_gmm_weights_t* bufs, void* stream) {
+  GT_READY(g);
+  if (!bufs || which < 0 || which > 3) return gfail(HIERTCN_ERR_INVALID, "which: 0 masters, 1 gradients, 2 / 3 the Adam moments");
+  GmmTrain* t = g->train;
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  hiertcn_gmm_weights_t a;
+  master_ptrs(g, t, t->arena + (size_t)which * t->total, &a);
+  auto cp = [&](const float* arena_ptr, const float* user_ptr, size_t n) -> hipError_t {
+    if (!n) return hipSuccess;
+    if (!user_ptr) return hipErrorInvalidValue;
+    return to_handle ? hipMemcpyAsync(const_cast<float*>(arena_ptr), user_ptr, n * 4, hipMemcpyDeviceToDevice, st)
+                     : hipMemcpyAsync(const_cast<float*>(user_ptr), arena_ptr, n * 4, hipMemcpyDeviceToDevice, st);
+  };
+  for (int i = 0; i < g->nb; i++) {
+    G_HIP(cp(a.conv_kernel[i], bufs->conv_kernel[i], t->conv[i].n));
+    G_HIP(cp(a.conv_bias[i], bufs->conv_bias[i], t->conv_b[i].n));
+    G_HIP(cp(a.res_kernel[i], bufs->res_kernel[i], t->res[i].n));
+    G_HIP(cp(a.res_bias[i], bufs->res_bias[i], t->res_b[i].n));
+  }
+  G_HIP(cp(a.head_weights, bufs->head_weights, t->head_w.n));
+  G_HIP(cp(a.head_biases, bufs->head_biases, t->head_b.n));
+  if (to_handle && which == 0) t->stale = true;
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_train_arena(hiertcn_gmm_handle_t g, int32_t which, float** ptr, size_t* count) {
+  GT_READY(g);
+  if (which < 0 || which > 3 || !ptr || !count) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  *ptr = g->train->arena + (size_t)which * g->train->total;
+  *count = g->train->total;
+  return HIERTCN_OK;
+}
+
+}  // extern "C"

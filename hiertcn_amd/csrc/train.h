@@ -58,3 +58,13 @@ hipError_t train_rows_op(const ModelDev& m, const TrainCtx& t, int op, const int
 hipError_t train_adam(const ModelDev& m, TrainCtx& t, float lr, float beta1, float beta2, float eps, float grad_scale, hipStream_t st);
 // which = 0: masters, 1: gradients -> fp32 tensors in the reference layouts (device destinations)
 hipError_t train_export(const ModelDev& m, const TrainCtx& t, const hiertcn_weights_t* dst, int which, hipStream_t st);
+
+// pieces of the fp32 training step shared with the mixture model's (gmm_train.hip): TemporalBlock pointwise backward (ds = da [out > 0], dc = ds [c > 0]),
+// row shifts inside sequences of L rows, column sums (ACCUMULATED into `out`: zero it first), lane activity + user count (model.py:112-113),
+// TF-form Adam on flat arenas at time step `step` (>= 1)
+hipError_t train_block_bwd_f32(const float* da, const float* aout, const float* cact, int64_t n, float* ds, float* dc, hipStream_t st);
+hipError_t train_shift_rows_f32(const float* src, int64_t R, int C, int L, int shift, float* dst, hipStream_t st);
+hipError_t train_colsum_f32(const float* src, int64_t rows, int64_t ld, int cols, float* out, hipStream_t st);
+hipError_t train_lane_act(const int32_t* y, int B, int T, float* act, float* users, hipStream_t st);
+hipError_t train_adam_flat(float* p, const float* g, float* m1, float* m2, size_t n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                           int64_t step, hipStream_t st);

@@ -1483,3 +1483,26 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
 #undef BF
   return 0;
 }
+
+// ---- small pieces of the fp32 training step that the mixture model's training step (gmm_train.hip) composes as well -------------------------
+hipError_t train_block_bwd_f32(const float* da, const float* aout, const float* cact, int64_t n, float* ds, float* dc, hipStream_t st) {
+  hipLaunchKernelGGL(k_block_bwd_f32, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, da, aout, cact, n, ds, dc);
+  return hipGetLastError();
+}
+hipError_t train_shift_rows_f32(const float* src, int64_t R, int C, int L, int shift, float* dst, hipStream_t st) { return shift_rows_f32(src, R, C, L, shift, dst, st); }
+hipError_t train_colsum_f32(const float* src, int64_t rows, int64_t ld, int cols, float* out, hipStream_t st) { return colsum_f32(src, rows, ld, cols, out, st); }
+hipError_t train_lane_act(const int32_t* y, int B, int T, float* act, float* users, hipStream_t st) {
+  hipError_t e = hipMemsetAsync(users, 0, sizeof(float), st);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(k_lane_act, dim3(B), dim3(256), 0, st, y, T, act, users);
+  return hipGetLastError();
+}
+hipError_t train_adam_flat(float* p, const float* g, float* m1, float* m2, size_t n, float lr, float beta1, float beta2, float eps, float grad_scale,
+                           int64_t step, hipStream_t st) {
+  const double tt = (double)step;
+  const float lr_t = (float)(lr * sqrt(1.0 - pow((double)beta2, tt)) / (1.0 - pow((double)beta1, tt)));
+  size_t blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m1, m2, n, lr_t, beta1, beta2, eps, grad_scale);
+  return hipGetLastError();
+}

@@ -74,6 +74,10 @@ class GruGmmModel(TcnGmmModel):
         self._upload(self.params)
         self._ws = None
 
+    def enable_training(self):
+        raise NotImplementedError("model_gru_gmm trains nowhere in this build: the training step of the mixture models (csrc/gmm_train.hip) is built "
+                                  "for the TemporalConvNet trunk of model_tcn_gmm; the GRU trunk on one-hot rows evaluates only (DESIGN.md 7)")
+
     def _upload(self, params):
         keep = []
 

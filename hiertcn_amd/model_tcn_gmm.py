@@ -112,6 +112,7 @@ class TcnGmmModel:
     def forward(self, ids: torch.Tensor) -> torch.Tensor:
         """ids int32 [B, T] -> last TCN activations [B*T, C] (storage type)."""
         B, T = ids.shape
+        self.sync()
         hidden = torch.empty((B * T, self.C), dtype=torch.bfloat16, device=self.device)
         need = int(self.lib.hiertcn_gmm_forward_workspace_bytes(self._h, B, T))
         if self._ws is None or self._ws.numel() < need:
@@ -124,6 +125,7 @@ class TcnGmmModel:
     def loss_rows(self, hidden: torch.Tensor, y_ids: torch.Tensor, mode: str = "gmm_prob", parts: bool = False):
         """-> loss [R] (0 where y == 0) [, |mu_m|^2 [M, R] (learned scale: sum_d mu_d^2 exp(-2 s_d)), mu_m[y] [M, R], prior logits [R, M]]."""
         R = hidden.shape[0]
+        self.sync()
         y = y_ids.reshape(-1).contiguous()
         loss = torch.empty(R, dtype=torch.float32, device=self.device)
         sq = torch.empty((self.M, R), dtype=torch.float32, device=self.device) if parts else None
@@ -150,6 +152,125 @@ class TcnGmmModel:
         _ck(self.lib.hiertcn_gmm_lane_loss(self._h, C.c_void_p(rows.data_ptr()), C.c_void_p(yd.data_ptr()), B, T, C.c_void_p(out2.data_ptr()),
                                            C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
         return dict(sums=out2, loss_rows=rows.view(B, T))
+
+    # -- training (include/hiertcn.h "training step of the mixture-output model", csrc/gmm_train.hip) -----------------------------------------
+    MODES = {"gmm_prob": 0, "gmm_prob_max": 1}
+
+    def _weights_struct(self, bufs: Dict[str, torch.Tensor]):
+        w = _lib.GmmWeights()
+        p = lambda k: bufs[k].data_ptr()  # noqa: E731
+        for i in range(len(self.args.tcn_channel)):
+            pre = f"{self.name}/temporal_conv_net/tblock_{i}"
+            w.conv_kernel[i], w.conv_bias[i] = p(f"{pre}/conv1/kernel"), p(f"{pre}/conv1/bias")
+            if f"{pre}/dense/kernel" in bufs:
+                w.res_kernel[i], w.res_bias[i] = p(f"{pre}/dense/kernel"), p(f"{pre}/dense/bias")
+        w.head_weights, w.head_biases = p(f"{self.name}/fully_connected/weights"), p(f"{self.name}/fully_connected/biases")
+        return w
+
+    def enable_training(self):
+        """fp32 masters (filled from self.params), gradients and Adam moments on the device: hiertcn_gmm_train_enable.  The model of
+        model_tcn_gmm.py on ids with a fixed scale; anything else raises (the library refuses: evaluation only)."""
+        if getattr(self, "_training", False):
+            return
+        bufs = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device).contiguous() for k, v in self.params.items()}
+        w = self._weights_struct(bufs)
+        _ck(self.lib.hiertcn_gmm_train_enable(self._h, C.byref(w), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        torch.cuda.current_stream().synchronize()
+        self._training = True
+        self._train_ws = None
+        self._stale = False
+
+    def train_forward_backward(self, x_ids: torch.Tensor, y_ids: torch.Tensor, mode: Optional[str] = None, users_global: Optional[torch.Tensor] = None,
+                               want_rows: bool = False) -> dict:
+        """ids [B, T] int32 on the device -> the gradients of every variable of the batch's lane-mean mixture loss (model.py:111-117 on args.loss)
+        in the handle's gradient arena; returns dict(sums = device doubles [sum of lane means, users][, loss_rows [B, T]])."""
+        if not getattr(self, "_training", False):
+            raise HierTCNError("enable_training() first")
+        mode = mode or getattr(self.args, "loss", "gmm_prob")
+        if mode not in self.MODES:
+            raise NotImplementedError(f"args.loss={mode!r}: the mixture models train on 'gmm_prob' or 'gmm_prob_max' (loss.py:247-257)")
+        for t, name in ((x_ids, "x_ids"), (y_ids, "y_ids")):
+            if t.dtype != torch.int32 or not t.is_cuda or not t.is_contiguous() or t.dim() != 2:
+                raise HierTCNError(f"{name}: a contiguous int32 device tensor [B, T]")
+        if x_ids.shape != y_ids.shape:
+            raise HierTCNError("x_ids and y_ids differ in shape")
+        B, T = x_ids.shape
+        need = int(self.lib.hiertcn_gmm_train_workspace_bytes(self._h, B, T))
+        if self._train_ws is None or self._train_ws.numel() < need:
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out2 = torch.empty(2, dtype=torch.float64, device=self.device)
+        rows = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_rows else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _ck(self.lib.hiertcn_gmm_train_step(self._h, p(x_ids), p(y_ids), B, T, self.MODES[mode], p(users_global), p(self._train_ws),
+                                            self._train_ws.numel(), p(out2), p(rows), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        out = dict(sums=out2)
+        if want_rows:
+            out["loss_rows"] = rows
+        return out
+
+    def adam_step(self, lr: float, beta1: float = 0.9, beta2: float = 0.999, eps: float = 1e-8, grad_scale: float = 1.0):
+        """TF-form Adam (model.py:139) on the masters; the evaluation tables are re-derived lazily (sync) before the next evaluation."""
+        _ck(self.lib.hiertcn_gmm_adam_step(self._h, float(lr), float(beta1), float(beta2), float(eps), float(grad_scale),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        self._stale = True
+
+    def sync(self):
+        """Evaluation tables <- masters (hiertcn_gmm_train_sync) where an optimizer step has run since the last one."""
+        if getattr(self, "_training", False) and getattr(self, "_stale", False):
+            _ck(self.lib.hiertcn_gmm_train_sync(self._h, C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+            self._stale = False
+
+    def train_step(self, x, y, lr: float, mode: Optional[str] = None) -> dict:
+        """One optimizer step of the run loop (run_gmm_xing.run_gmm): ids x, y [B, T] (host or device) -> forward + backward + the data-parallel
+        gradient sum (distributed.py: global user count in the loss normaliser, one all-reduce of the flat gradient arena) + Adam."""
+        from . import distributed as hd
+        ids = torch.as_tensor(np.ascontiguousarray(np.asarray(x).astype(np.int32))).to(self.device) if not isinstance(x, torch.Tensor) else x
+        yd = torch.as_tensor(np.ascontiguousarray(np.asarray(y).astype(np.int32))).to(self.device) if not isinstance(y, torch.Tensor) else y
+        users = None
+        if hd._is_dist():
+            users = (yd > 0).any(dim=1).sum().to(torch.float32).reshape(1)
+            hd._sum_async(users).wait()
+        out = self.train_forward_backward(ids, yd, mode, users_global=users)
+        if hd._is_dist():
+            hd._sum_async(self.arena(1)).wait()
+            hd.all_reduce_metrics(out["sums"])
+        self.adam_step(lr)
+        return out
+
+    def arena(self, which: int) -> torch.Tensor:
+        """The flat fp32 arena `which` (0 masters, 1 gradients, 2 / 3 Adam moments) as a torch view (no copy)."""
+        ptr, n = C.c_void_p(), C.c_size_t()
+        _ck(self.lib.hiertcn_gmm_train_arena(self._h, int(which), C.byref(ptr), C.byref(n)), self.lib)
+
+        class _Raw:
+            __cuda_array_interface__ = {"shape": (int(n.value),), "typestr": "<f4", "data": (int(ptr.value), False), "version": 2}
+
+        return torch.as_tensor(_Raw(), device=self.device)
+
+    def export(self, which: str = "weights") -> Dict[str, np.ndarray]:
+        """Masters ('weights'), gradients ('grads') or Adam moments ('m', 'v') as {TF variable name: fp32 ndarray in the reference layout}."""
+        k = {"weights": 0, "grads": 1, "m": 2, "v": 3}[which]
+        bufs = {name: torch.zeros(np.asarray(v).shape, dtype=torch.float32, device=self.device) for name, v in self.params.items()}
+        w = self._weights_struct(bufs)
+        _ck(self.lib.hiertcn_gmm_train_copy(self._h, k, 0, C.byref(w), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        torch.cuda.current_stream().synchronize()
+        return {name: t.cpu().numpy() for name, t in bufs.items()}
+
+    def restore(self, which: str, tensors: Dict[str, np.ndarray]):
+        """The reverse of export (checkpoint restore: masters and Adam moments)."""
+        k = {"weights": 0, "grads": 1, "m": 2, "v": 3}[which]
+        bufs = {name: torch.as_tensor(np.asarray(tensors[name], dtype=np.float32)).to(self.device).contiguous() for name in self.params}
+        w = self._weights_struct(bufs)
+        _ck(self.lib.hiertcn_gmm_train_copy(self._h, k, 1, C.byref(w), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        torch.cuda.current_stream().synchronize()
+        if k == 0:
+            self._stale = True
+
+    def adam_time(self, set_to: Optional[int] = None) -> int:
+        get = C.c_int64(0)
+        st = C.c_int64(int(set_to)) if set_to is not None else None
+        _ck(self.lib.hiertcn_gmm_adam_time(self._h, C.byref(get), C.byref(st) if st is not None else None), self.lib)
+        return int(get.value)
 
     def head_means(self, hidden: torch.Tensor, m: int) -> torch.Tensor:
         """parity/debug: mu_m [R, D] fp32 materialised (learned scale: m in [M, 2M) materialises the log-scales s_{m-M})."""

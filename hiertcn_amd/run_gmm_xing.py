@@ -5,7 +5,9 @@ the likelihood loss args.loss in {gmm_prob, gmm_prob_max} (loss.py:247-257) -- a
 What the reference itself does with these models on XING cannot be run: its graph feeds the [B, T, M (1 + D)] head output to calc_loss /
 calc_metric_fast against the [B, T, item_num] one-hot targets (model.py:105-132), whose last dimensions differ, and calc_loss_gmm has no
 caller.  This loop therefore reports the mixture loss only; the rank metrics of results.txt do not exist for a density model and are
-written as nan.  Evaluation only: the head has no backward pass.
+written as nan.  Training (--train): model_tcn_gmm with a fixed scale steps through csrc/gmm_train.hip (the gradient of this loop's own
+loss: the decode is the build's, so is its derivative -- checked against fp64 autograd, tests/test_gpu_gmm_train.py); model_gru_gmm, the
+mixture low levels of model_hier and a learned scale evaluate only and say so.
 """
 from __future__ import annotations
 
@@ -43,11 +45,12 @@ def evaluate_gmm(args, loader, sess, prefix="test"):
 
 
 def run_gmm(args, loader_train, loader_validate, loader_test, sess=None):
-    """run_nn's cadence (run_nn_xing.py:101-192) for --model_type tcn_gmm / gru_gmm, evaluation flow."""
+    """run_nn's cadence (run_nn_xing.py:101-192) for --model_type tcn_gmm / gru_gmm: per epoch args.epoch_batches_train optimizer steps at the
+    scheduled learning rate (run_hier_xing.py:265-269), a checkpoint every args.save_epoch, validation / test every args.test_epoch -- or one
+    evaluation pass with the evaluation flags (args.py:193).  Training is built for model_tcn_gmm with a fixed scale (csrc/gmm_train.hip); the
+    other mixture models evaluate and raise on --train."""
     from . import checkpoint
-    if getattr(args, "train", False):
-        raise NotImplementedError("training of the mixture-output models is not built (no backward pass for csrc/gmm.hip): run with the "
-                                  "evaluation flags (args.py:193)")
+    from .run_common import scheduled_lr
     if sess is None:
         if args.model_type == "tcn_gmm":
             from .model_tcn_gmm import TcnGmmModel
@@ -56,25 +59,54 @@ def run_gmm(args, loader_train, loader_validate, loader_test, sess=None):
             from .model_gru_gmm import GruGmmModel
             sess = GruGmmModel(args, None, "rnn_gmm")
     model = sess
+    epoch = 0
     if args.load:
         fname = args.load_path + str(args.load_epoch) + ".ckpt"
         try:
             params = checkpoint.load(fname)
         except FileNotFoundError:
-            print("No ckpt found: {}, evaluating the initial weights".format(fname))
+            print("No ckpt found: {}, {}".format(fname, "train from scratch" if args.train else "evaluating the initial weights"))
         else:
             model.params = params
             model._upload(params)
             print("Model restored: {}".format(fname))
-    from .distributed import is_main, rank_world
+            epoch = args.load_epoch + 1
+    if getattr(args, "train", False):
+        model.enable_training()      # (raises for the models / options the training step is not built for)
+    from .distributed import barrier, is_main, rank_world
     log = args.log_path if is_main() else args.log_path + "rank{}/".format(rank_world()[0])
+    train_writer = ScalarLog(log + "train/") if args.train else None
     validate_writer = ScalarLog(log + "validate/")
     test_writer = ScalarLog(log + "test/")
-    if args.validate:
-        summary, _, _ = evaluate_gmm(args, loader_validate, model, prefix="validate")
-        validate_writer.add_summary({"loss_epoch": summary["loss_epoch"]}, 0)
-    if args.test:
-        summary, t_load, t_run = evaluate_gmm(args, loader_test, model, prefix="test")
-        test_writer.add_summary({"loss_epoch": summary["loss_epoch"]}, 0)
-        print("Step 0: test load {:.2f}s, test run {:.2f}s, {}".format(t_load, t_run, args.name))
+    while epoch <= args.epoch_max:
+        if args.train:
+            lr = scheduled_lr(args, epoch)
+            sums = []
+            for _ in range(args.epoch_batches_train):
+                batch_x, batch_y, _info = loader_train.get_batch()
+                sums.append(model.train_step(batch_x, batch_y, lr)["sums"])
+            import torch
+            s = torch.stack(sums).cpu().numpy()                      # one read-back per epoch: the steps themselves never wait for the host
+            training_loss_epoch = float((s[:, 0] / s[:, 1]).mean())
+            train_writer.add_summary({"loss_epoch": training_loss_epoch}, epoch)
+            if args.save and epoch % args.save_epoch == 0 and epoch != 0:
+                fname = args.save_path + str(epoch) + ".ckpt"
+                if is_main():
+                    model.params = model.export("weights")
+                    checkpoint.save(fname, model.params)
+                    print("Model saved in path: %s" % fname)
+                barrier()
+        if (epoch % args.test_epoch == 0 and epoch != 0) or not args.train:
+            if args.validate:
+                summary, _, _ = evaluate_gmm(args, loader_validate, model, prefix="validate")
+                validate_writer.add_summary({"loss_epoch": summary["loss_epoch"]}, epoch)
+            if args.test:
+                summary, t_load, t_run = evaluate_gmm(args, loader_test, model, prefix="test")
+                test_writer.add_summary({"loss_epoch": summary["loss_epoch"]}, epoch)
+                print("Step {}: test load {:.2f}s, test run {:.2f}s, {}".format(epoch, t_load, t_run, args.name))
+            if not args.train:
+                break
+        epoch += 1
+    if args.train:
+        model.params = model.export("weights")
     return model

@@ -48,7 +48,7 @@
 extern "C" {
 #endif
 
-#define HIERTCN_ABI_VERSION 11
+#define HIERTCN_ABI_VERSION 12
 #define HIERTCN_MAX_BLOCKS 8
 #define HIERTCN_MAX_LAYERS 4
 #define HIERTCN_MAX_TOPK 16
@@ -422,6 +422,34 @@ int hiertcn_gmm_head_means(hiertcn_gmm_handle_t g, const uint16_t* hidden, int64
 /* model.py:111-117 applied to the per-step mixture loss [B][T] (mask = sign(y), per-lane mean over valid steps + 1e-6): out2 (device, 2
  * doubles) = [sum over lanes of the lane means, number of lanes with a target] -- ready for a cross-rank sum; batch loss = out2[0] / out2[1]. */
 int hiertcn_gmm_lane_loss(hiertcn_gmm_handle_t g, const float* loss, const int32_t* y_ids, int32_t B, int32_t T, double* out2, void* stream);
+
+/* ---- training step of the mixture-output model (ABI 12; model.py:135-141 on the lane-mean mixture loss of model.py:111-117 + loss.py:247-257).
+ * The reference itself cannot train these models on XING (its graph does not build): the step differentiates the decode
+ * documented above, and is checked against fp64 autograd of that decode.  Built for trunk 0 (model_tcn_gmm: the TemporalConvNet on ids), a fixed
+ * scale (cfg.sigma > 0), loss modes 0 / 1; the GRU trunk, the dense-row trunks and a learned scale evaluate only (train_enable returns an error).
+ * Everything is fp32 on master copies kept in the REFERENCE's layouts (a checkpoint is a copy; Adam is elementwise); no [rows][M D] matrix is
+ * formed in either direction -- the head's backward is linear algebra on the hidden rows through G_m = W_m W_m^T (csrc/gmm_train.hip).
+ *   hiertcn_gmm_train_enable          allocates masters / gradients / the two Adam moments, fills the masters from `w` (hiertcn_gmm_set_weights'
+ *                                     tensors), zeroes the moments and the time step.
+ *   hiertcn_gmm_train_step            x_ids, y_ids [B][T] -> gradients of every variable of  loss = (1 / users) sum_b (sum_t l_bt [y_bt > 0]) /
+ *                                     (act_b + 1e-6)  (users_global: device float [1], the lanes-with-a-target count of the GLOBAL batch in a
+ *                                     data-parallel run, or NULL: this batch's own); out2 as hiertcn_gmm_lane_loss; loss_rows [B*T] optional.
+ *   hiertcn_gmm_adam_step             TF-form Adam on the masters (grad_scale multiplies the gradients first); hiertcn_gmm_adam_time reads / sets t.
+ *   hiertcn_gmm_train_sync            re-derives the evaluation tables of hiertcn_gmm_forward / hiertcn_gmm_loss from the masters (what
+ *                                     hiertcn_gmm_set_weights does; synchronises the stream): call it before evaluating a handle that has stepped.
+ *   hiertcn_gmm_train_copy            which = 0 masters, 1 gradients, 2 / 3 Adam moments; to_handle = 0: into the caller's fp32 device buffers
+ *                                     `bufs` (reference layouts -- they are WRITTEN despite the const), 1: from them (checkpoint restore).
+ *   hiertcn_gmm_train_arena           the flat arena `which` (device pointer, floats): a data-parallel run all-reduces arena 1 between
+ *                                     hiertcn_gmm_train_step and hiertcn_gmm_adam_step.                                                        */
+int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream);
+size_t hiertcn_gmm_train_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T);
+int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, int64_t B, int32_t T, int32_t mode,
+                           const float* users_global, void* workspace, size_t workspace_bytes, double* out2, float* loss_rows, void* stream);
+int hiertcn_gmm_adam_step(hiertcn_gmm_handle_t g, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream);
+int hiertcn_gmm_adam_time(hiertcn_gmm_handle_t g, int64_t* get, const int64_t* set);
+int hiertcn_gmm_train_sync(hiertcn_gmm_handle_t g, void* stream);
+int hiertcn_gmm_train_copy(hiertcn_gmm_handle_t g, int32_t which, int32_t to_handle, const hiertcn_gmm_weights_t* bufs, void* stream);
+int hiertcn_gmm_train_arena(hiertcn_gmm_handle_t g, int32_t which, float** ptr, size_t* count);
 
 /* Measurement hook for bench.py: average duration in milliseconds of the scoring kernel over the
  * launches made since the last reset, measured with HIP events recorded on the launch stream.

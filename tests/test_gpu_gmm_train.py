@@ -1,0 +1,233 @@
+"""-m gpu: the TRAINING step of the mixture-output model (csrc/gmm_train.hip, C-ABI 12; model.py:135-141 on the lane-mean mixture loss of
+model.py:111-117 + loss.py:247-257).  The reference cannot train these models on XING (its graph does not build: SURVEY.md 8(f) 4), so the
+step is pinned the way the fp32 training mode is: every gradient against fp64 AUTOGRAD of an independent torch formulation that MATERIALISES
+what the device never forms -- the one-hot inputs' row products as gathers, pred = h . W + b [B, T, M (1 + D)], the decode of
+oracle/gmm_oracle.py, |y - mu_m|^2 over all D outputs -- whose forward is itself checked against the NumPy oracle; then an Adam trajectory
+against an fp64 TF-form Adam, and the evaluation path of the same handle after hiertcn_gmm_train_sync."""
+import numpy as np
+import pytest
+
+from hiertcn_amd.args import make_args
+from oracle import gmm_oracle as G
+
+torch = pytest.importorskip("torch")
+pytestmark = pytest.mark.gpu
+
+dev = lambda v: torch.as_tensor(np.ascontiguousarray(v)).to("cuda:0")  # noqa: E731
+
+
+def _args(N, M, channels, K, loss="gmm_prob", sigma=0.1):
+    return make_args([], model_type="tcn_gmm", item_num=N, output_dim=N, num_mixture=M, sigma=sigma, loss=loss, tcn_channel=list(channels),
+                     kernel_size=K, adjust=False)
+
+
+def _batch(rng, N, B, T):
+    ids = rng.integers(1, N, (B, T + 1))
+    lens = rng.integers(2, T + 1, B)
+    ids = ids * (np.arange(T + 1)[None, :] <= lens[:, None])           # right padding with the null id
+    x, y = ids[:, :-1].astype(np.int32), ids[:, 1:].astype(np.int32)
+    x[:, 0] = 0                                                          # a sequence starts from the null id (data_loader.py:246-261)
+    y[B - 1] = 0                                                         # a lane without any target: no user of this batch (model.py:112-113)
+    return x, y
+
+
+def _params(a, seed):
+    p = G.init_params(a, seed=seed)
+    rng = np.random.default_rng(seed + 100)
+    for k in p:   # non-zero biases so that a dropped or misplaced bias term shows in the gradients
+        if k.endswith("bias") or k.endswith("biases"):
+            p[k] = (0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    return p
+
+
+def torch_loss(a, P, x, y, mode, scope="tcn_gmm"):
+    """fp64, materialising: -> (batch loss, loss rows [B, T]).  P: {TF name: float64 tensor (requires_grad)}."""
+    xt, yt = torch.as_tensor(x.astype(np.int64)), torch.as_tensor(y.astype(np.int64))
+    B, T = xt.shape
+    K, M, D = int(a.kernel_size), int(a.num_mixture), int(a.output_dim)
+    sigma = float(a.sigma)
+    pre = f"{scope}/temporal_conv_net/tblock_0"
+    W0, b0, Wr, br = P[f"{pre}/conv1/kernel"], P[f"{pre}/conv1/bias"], P[f"{pre}/dense/kernel"], P[f"{pre}/dense/bias"]
+    live_x = (xt > 0).to(torch.float64)[..., None]
+    c = b0.expand(B, T, -1).clone()
+    for j in range(K):
+        s = K - 1 - j
+        rows = W0[j][xt] * live_x                                      # a one-hot row times the kernel = its row; the null id is an all-zero row
+        c = c + (torch.nn.functional.pad(rows, (0, 0, s, 0))[:, :T] if s else rows)
+    act = torch.relu(torch.relu(c) + Wr[xt] * live_x + br)
+    for i in range(1, len(a.tcn_channel)):
+        pre = f"{scope}/temporal_conv_net/tblock_{i}"
+        W, b = P[f"{pre}/conv1/kernel"], P[f"{pre}/conv1/bias"]      # [K, Cin, Cout]
+        dil = 2 ** i
+        c = b.expand(B, T, -1).clone()
+        for j in range(K):
+            s = (K - 1 - j) * dil
+            if s >= T:
+                continue
+            z = act @ W[j]
+            c = c + (torch.nn.functional.pad(z, (0, 0, s, 0))[:, :T] if s else z)
+        res = act @ P[f"{pre}/dense/kernel"] + P[f"{pre}/dense/bias"] if f"{pre}/dense/kernel" in P else act
+        act = torch.relu(torch.relu(c) + res)
+    pred = act @ P[f"{scope}/fully_connected/weights"] + P[f"{scope}/fully_connected/biases"]      # [B, T, M (1 + D)]: what the device never forms
+    log_pi = torch.log_softmax(pred[..., :M], -1)
+    mu = pred[..., M:M + M * D].reshape(B, T, M, D)
+    yoh = torch.nn.functional.one_hot(yt, D).to(torch.float64) * (yt > 0)[..., None]
+    d2 = ((yoh[:, :, None, :] - mu) ** 2).sum(-1)
+    mvn = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+    if mode == "gmm_prob":
+        rows = -torch.logsumexp(log_pi + mvn, -1) / D
+    else:
+        rows = -(log_pi + mvn / D).max(-1).values
+    mask = (yt > 0).to(torch.float64)
+    cnt = mask.sum(1)
+    users = (cnt > 0).sum()
+    loss = ((rows * mask).sum(1) / (cnt + 1e-6)).sum() / users
+    return loss, rows * mask
+
+
+CASES = [
+    # N (= D), M, channels, K, B, T
+    (303, 3, (64, 64), 3, 5, 9),          # D not a multiple of 4 (pad rows / unaligned head columns), identity residual in block 1
+    (500, 5, (64, 128), 5, 4, 12),        # Dense residual in block 1 (Cin != Cout)
+    (1201, 2, (128,), 2, 6, 7),           # one block: the hidden rows are block 0's output
+    (777, 4, (64, 64, 128), 3, 3, 20),    # three blocks, dilation 4 reaches past short sequences
+    (20_778, 5, (256, 256), 5, 3, 11),    # the XING catalogue at the reference's widths
+]
+
+
+@pytest.mark.parametrize("mode", ["gmm_prob", "gmm_prob_max"])
+@pytest.mark.parametrize("N,M,channels,K,B,T", CASES)
+def test_every_gradient_against_fp64_autograd(N, M, channels, K, B, T, mode):
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    a = _args(N, M, channels, K, loss=mode)
+    p = _params(a, seed=N % 97)
+    rng = np.random.default_rng(N + M + len(channels))
+    x, y = _batch(rng, N, B, T)
+    # reference: fp64 autograd of the materialising formulation, whose forward agrees with the NumPy oracle
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in p.items()}
+    loss_ref, rows_ref = torch_loss(a, P, x, y, mode)
+    loss_ref.backward()
+    pred = G.model_tcn_gmm(a, x, {k: np.asarray(v, np.float64) for k, v in p.items()})
+    want_rows = G.calc_loss_gmm_ids(pred, y, a) * (y > 0)
+    assert np.abs(rows_ref.detach().numpy() - want_rows).max() < 1e-9 * max(1.0, np.abs(want_rows).max())
+    # device
+    model = TcnGmmModel(a, p)
+    model.enable_training()
+    out = model.train_forward_backward(dev(x), dev(y), mode, want_rows=True)
+    sums = out["sums"].cpu().numpy()
+    rows = out["loss_rows"].cpu().numpy()
+    live = y > 0
+    assert not rows[~live].any()
+    assert np.abs(rows - want_rows)[live].max() < 2e-6 * max(1.0, np.abs(want_rows).max()), np.abs(rows - want_rows)[live].max()
+    assert sums[1] == B - 1 and abs(sums[0] / sums[1] - float(loss_ref.detach())) < 2e-6 * max(1.0, abs(float(loss_ref.detach())))
+    grads = model.export("grads")
+    worst = {}
+    for k, t in P.items():
+        ref = t.grad.numpy()
+        got = grads[k].astype(np.float64)
+        assert got.shape == ref.shape, k
+        err = np.linalg.norm(got - ref) / max(np.linalg.norm(ref), 1e-30)
+        worst[k] = err
+        assert np.linalg.norm(ref) > 0, k                                                  # (every variable takes part)
+        assert err < 2e-5, (k, err)
+        assert np.abs(got - ref).max() < 1e-4 * max(np.abs(ref).max(), 1e-30), (k, np.abs(got - ref).max(), np.abs(ref).max())
+    # rows of the gathered tables no id of the batch touched have an exactly zero gradient (scatter-adds only where the forward gathered)
+    untouched = np.setdiff1d(np.arange(N), np.unique(x))
+    assert not grads["tcn_gmm/temporal_conv_net/tblock_0/dense/kernel"][untouched].any()
+    assert not grads["tcn_gmm/temporal_conv_net/tblock_0/conv1/kernel"][:, untouched].any()
+    # the weights are what was handed in; a second call overwrites (does not accumulate) the gradients
+    w = model.export("weights")
+    for k in p:
+        assert np.array_equal(w[k], np.asarray(p[k], np.float32)), k
+    model.train_forward_backward(dev(x), dev(y), mode)
+    again = model.export("grads")
+    for k in grads:
+        assert np.abs(again[k] - grads[k]).max() <= 1e-5 * max(np.abs(grads[k]).max(), 1e-30), k   # (fp32 atomics reorder sums)
+    model.close()
+
+
+def _adam_fp64(p, g, m, v, t, lr, b1=0.9, b2=0.999, eps=1e-8):
+    lr_t = lr * np.sqrt(1 - b2 ** t) / (1 - b1 ** t)            # TF-1.x AdamOptimizer (model.py:139)
+    for k in p:
+        m[k] = b1 * m[k] + (1 - b1) * g[k]
+        v[k] = b2 * v[k] + (1 - b2) * g[k] ** 2
+        p[k] = p[k] - lr_t * m[k] / (np.sqrt(v[k]) + eps)
+
+
+def test_adam_trajectory_against_fp64_and_evaluation_after_sync():
+    """Six optimizer steps: the loss trajectory and the final weights follow an fp64 run (autograd + TF-form Adam) of the same model; the
+    evaluation path of the same handle then scores the UPDATED weights (hiertcn_gmm_train_sync), exactly as a fresh handle created from the
+    exported weights does; Adam moments and time step survive an export / restore round trip into a new handle."""
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    N, M, channels, K, B, T = 900, 3, (64, 64), 3, 6, 10
+    a = _args(N, M, channels, K)
+    p = _params(a, seed=5)
+    rng = np.random.default_rng(11)
+    batches = [_batch(rng, N, B, T) for _ in range(6)]
+    lr = 2e-3
+    ref = {k: np.asarray(v, np.float64).copy() for k, v in p.items()}
+    m1 = {k: np.zeros_like(v) for k, v in ref.items()}
+    m2 = {k: np.zeros_like(v) for k, v in ref.items()}
+    want = []
+    for t, (x, y) in enumerate(batches, 1):
+        P = {k: torch.tensor(v, requires_grad=True) for k, v in ref.items()}
+        loss, _ = torch_loss(a, P, x, y, "gmm_prob")
+        loss.backward()
+        want.append(float(loss.detach()))
+        _adam_fp64(ref, {k: P[k].grad.numpy() for k in ref}, m1, m2, t, lr)
+    model = TcnGmmModel(a, p)
+    model.enable_training()
+    before = model.eval_step(*batches[0])["sums"].cpu().numpy()
+    got = []
+    for x, y in batches:
+        s = model.train_step(x, y, lr)["sums"].cpu().numpy()
+        got.append(s[0] / s[1])
+    assert np.abs(np.array(got) - np.array(want)).max() < 5e-6 * max(1.0, np.abs(want).max()), (got, want)
+    assert model.adam_time() == 6
+    w = model.export("weights")
+    for k in ref:
+        assert np.abs(w[k] - ref[k]).max() < 2e-5 * max(np.abs(ref[k]).max(), 1.0), (k, np.abs(w[k] - ref[k]).max())
+    # evaluation of the stepped handle == a fresh handle on the exported weights; and it moved
+    after = model.eval_step(*batches[0])["sums"].cpu().numpy()
+    fresh = TcnGmmModel(a, w)
+    want_after = fresh.eval_step(*batches[0])["sums"].cpu().numpy()
+    assert np.array_equal(after, want_after)
+    assert abs(after[0] - before[0]) > 1e-6
+    # checkpoint round trip: weights + moments + time step into the fresh handle, one more step on both -> the same weights
+    fresh.enable_training()
+    for which in ("m", "v"):
+        fresh.restore(which, model.export(which))
+    fresh.adam_time(model.adam_time())
+    x, y = _batch(rng, N, B, T)
+    model.train_step(x, y, lr)
+    fresh.train_step(x, y, lr)
+    wa, wb = model.export("weights"), fresh.export("weights")
+    for k in wa:
+        assert np.abs(wa[k] - wb[k]).max() <= 1e-6 * max(np.abs(wa[k]).max(), 1e-30), k
+    model.close()
+    fresh.close()
+
+
+def test_what_is_not_built_says_so():
+    from hiertcn_amd._lib import HierTCNError
+    from hiertcn_amd.model_gru_gmm import GruGmmModel
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    a = _args(300, 2, (64,), 3)
+    m = TcnGmmModel(a, _params(a, 1))
+    with pytest.raises(HierTCNError):
+        m.train_forward_backward(dev(np.zeros((2, 3), np.int32)), dev(np.zeros((2, 3), np.int32)))      # enable_training() first
+    m.enable_training()
+    with pytest.raises(NotImplementedError):
+        m.train_forward_backward(dev(np.zeros((2, 3), np.int32)), dev(np.zeros((2, 3), np.int32)), mode="gmm_prob_hinge")
+    m.close()
+    al = _args(300, 2, (64,), 3)
+    al.sigma = None                                                                                        # a learned scale: evaluation only
+    ml = TcnGmmModel(al, None)
+    with pytest.raises(HierTCNError, match="fixed scale"):
+        ml.enable_training()
+    ml.close()
+    ag = make_args([], model_type="gru_gmm", item_num=300, output_dim=300, num_mixture=2, sigma=0.1, loss="gmm_prob", hidden_dim=64, num_layer=1, adjust=False)
+    mg = GruGmmModel(ag, None)
+    with pytest.raises(NotImplementedError):
+        mg.enable_training()
+    mg.close()

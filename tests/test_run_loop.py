@@ -1,6 +1,7 @@
 """run_hier / evaluate_hier control flow (run_hier_xing.py:83-207,210-350) on the synthetic XING
 CSV, with the CPU oracle as the model handle: batching, state carry, mean-of-means aggregation,
 results.txt text, eval-once-when-not-training."""
+import json
 import os
 import re
 
@@ -127,8 +128,9 @@ def test_checkpoint_roundtrip_with_carried_state(tmp_path, data):
 
 
 def test_run_xing_dispatches_the_mixture_models_and_refuses_training(tmp_path):
-    """model.py:74-77: --model_type tcn_gmm / gru_gmm reach run_gmm_xing.run_gmm (evaluation flow over a model handle with eval_step -> 'sums');
-    training of these models is not built and says so."""
+    """model.py:74-77: --model_type tcn_gmm / gru_gmm reach run_gmm_xing.run_gmm: the evaluation flow over a model handle with eval_step ->
+    'sums', and (round 6) run_nn's training cadence over enable_training / train_step / export; a model whose training step is not built
+    raises from enable_training and the loop lets that through."""
     import numpy as np
     import pytest
     import torch
@@ -162,9 +164,39 @@ def test_run_xing_dispatches_the_mixture_models_and_refuses_training(tmp_path):
     m, _, _ = evaluate_gmm(a, Loader(3), fake, prefix="test")
     assert fake.calls == 3 and abs(m["loss_epoch"] - 2.5 * (1 + 2 + 3) / 3) < 1e-12      # mean over batches of the per-batch lane means
     assert np.isnan(m["recall10_epoch_mean"])
-    a.train = True
-    with pytest.raises(NotImplementedError, match="training of the mixture-output models"):
-        run_gmm(a, None, None, None, sess=fake)
+    a.train, a.validate, a.test, a.load, a.save = True, False, True, False, False
+    a.epoch_max, a.epoch_batches_train, a.test_epoch, a.lr_schedule, a.learning_rate = 2, 3, 2, False, 0.5
+
+    class Refuses(FakeGmm):
+        def enable_training(self):
+            raise NotImplementedError("model_gru_gmm trains nowhere in this build")
+
+    with pytest.raises(NotImplementedError, match="trains nowhere"):
+        run_gmm(a, Loader(10 ** 9), None, Loader(2), sess=Refuses())
+
+    class Trains(FakeGmm):
+        enabled, steps, lrs = False, 0, []
+
+        def enable_training(self):
+            self.enabled = True
+
+        def train_step(self, x, y, lr):
+            assert self.enabled
+            self.steps += 1
+            self.lrs.append(lr)
+            return dict(sums=torch.tensor([4.0 / self.steps, 2.0], dtype=torch.float64))
+
+        def export(self, which):
+            return {"w": np.full(1, self.steps, np.float32)}
+
+    tr = Trains()
+    assert run_gmm(a, Loader(10 ** 9), None, Loader(2), sess=tr) is tr
+    assert tr.steps == 3 * 3 and set(tr.lrs) == {0.5}                    # epochs 0, 1, 2 x epoch_batches_train steps (run_nn_xing.py:147-153)
+    assert tr.calls == 2                                                    # one test pass, at epoch 2 (test_epoch 2; epoch 0 never evaluates)
+    assert tr.params["w"][0] == 9                                           # the weights the loop hands back are the trained ones
+    lines = open(a.log_path + "train/scalars.jsonl").read().splitlines()
+    assert len(lines) == 3 and json.loads(lines[0])["tag"] == "loss_epoch"
+    assert abs(json.loads(lines[0])["value"] - np.mean([2.0 / k for k in (1, 2, 3)])) < 1e-12
     a.train, a.validate, a.test, a.load = False, False, True, False
     assert run_gmm(a, None, None, Loader(2), sess=fake) is fake
 
