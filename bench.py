@@ -225,10 +225,35 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     torch.cuda.synchronize()
     ms["learned_scale"] = (time.perf_counter() - t0) / reps * 1e3
     model.close()
+    # the TRAINING step of model_tcn_gmm (csrc/gmm_train.hip, C-ABI 12) at the reference's batch: 32 lanes (args.py:19) x 200 steps of the
+    # single-level loader = 6,400 rows, the XING catalogue, d = 256, 5 mixtures: forward + backward of every variable + Adam, ids resident
+    tB, tT = 32, 200
+    rng = np.random.default_rng(5)
+    ids = rng.integers(1, n_out, (tB, tT + 1))
+    ids = ids * (np.arange(tT + 1)[None, :] <= rng.integers(2, tT + 1, tB)[:, None])
+    tx = torch.as_tensor(np.ascontiguousarray(ids[:, :-1].astype(np.int32))).cuda()
+    ty = torch.as_tensor(np.ascontiguousarray(ids[:, 1:].astype(np.int32))).cuda()
+    tm = TcnGmmModel(ga, init_params(ga, 3))
+    tm.enable_training()
+    tl = []
+    for _ in range(3):
+        tl.append(tm.train_step(tx, ty, 1e-3)["sums"])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):
+        tl.append(tm.train_step(tx, ty, 1e-3)["sums"])
+    torch.cuda.synchronize()
+    train_ms = (time.perf_counter() - t0) / 10 * 1e3
+    tl = torch.stack(tl).cpu().numpy()
+    tm.close()
     diff = float((losses["gram"] - losses["table_pass"]).abs().max())
     flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
-    return {"training": "not built: the mixture models evaluate (forward, gmm_prob / gmm_prob_max, lane loss, run loop); no backward of hiertcn_gmm_loss / the head / "
-                        "the one-hot trunk exists, `run_xing --model_type tcn_gmm --train` refuses (the reference's calc_loss_gmm, loss.py:225-292, has no caller either)",
+    return {"training": {"what": "one optimizer step of model_tcn_gmm (fixed scale, gmm_prob): fp32 forward on the masters + backward of every variable + TF-form "
+                                 "Adam (csrc/gmm_train.hip: the head's backward through G_m = W_m W_m^T, no [rows][M D] matrix; block 0's one-hot rows as "
+                                 "scatter-adds), 32 lanes x 200 steps = 6,400 rows, ids resident; model_gru_gmm / a learned scale / the mixture low "
+                                 "levels of model_hier evaluate only",
+                         "rows": tB * tT, "ms_per_step": round(train_ms, 3), "rows_per_s": round(tB * tT / train_ms * 1e3),
+                         "loss_first_last": [round(float(tl[0, 0] / tl[0, 1]), 5), round(float(tl[-1, 0] / tl[-1, 1]), 5)]},
             "what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
                     "bf16 parts, + one row-wise kernel for prior / linear terms / target mean + finish); ms_table_pass: M passes of "
                     "k_score_pipe<256,21,...> (sum-of-squares epilogue) over the [D, C] mean tables + prior + finish; ms_learned_scale: args.sigma None, M passes of "

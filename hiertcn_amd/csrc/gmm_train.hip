@@ -146,13 +146,15 @@ __global__ __launch_bounds__(256) void k_gt_block0_bwd(const float* __restrict__
 }
 
 // ---- head ------------------------------------------------------------------------------------------------------------------------------------------
-// vm[m][c] += sum_d Wt[m][d][c] bt[m][d] over this block's slice of d;  cm[m] += sum_d bt[m][d]^2   (outputs zeroed by the caller)
-__global__ __launch_bounds__(256) void k_gt_vc(const float* __restrict__ Wt, const float* __restrict__ bt, int DP, int C, int dslice,
-                                               float* __restrict__ vm, float* __restrict__ cm) {
-  const int m = blockIdx.y;
+// v_m = W_m b_m and |b_m|^2 in two fixed-order stages (no atomics: these enter the FORWARD, where 1 / (2 sigma^2) = 50 multiplies every last-bit
+// difference of d2_m before the soft-max over the mixtures -- the loss and the responsibilities are then repeatable run to run):
+//   part[m][z][c] = sum_{d in slice z} Wt[m][d][c] bt[m][d],  part[m][z][C] = sum_{d in slice z} bt[m][d]^2;   then the slices in order
+__global__ __launch_bounds__(256) void k_gt_vc_part(const float* __restrict__ Wt, const float* __restrict__ bt, int DP, int C, int dslice,
+                                                    float* __restrict__ part) {
+  const int m = blockIdx.y, z = blockIdx.z, nz = gridDim.z;
   const int c = blockIdx.x * 64 + (threadIdx.x & 63);
   const int q = threadIdx.x >> 6;
-  const int d0 = blockIdx.z * dslice, d1 = (d0 + dslice < DP) ? d0 + dslice : DP;
+  const int d0 = z * dslice, d1 = (d0 + dslice < DP) ? d0 + dslice : DP;
   const float* W = Wt + (size_t)m * DP * C;
   const float* b = bt + (size_t)m * DP;
   float acc = 0.f, sq = 0.f;
@@ -161,11 +163,22 @@ __global__ __launch_bounds__(256) void k_gt_vc(const float* __restrict__ Wt, con
     if (c < C) acc = fmaf(W[(size_t)d * C + c], bd, acc);
     sq = fmaf(bd, bd, sq);
   }
-  __shared__ float red[4][64];
+  __shared__ float red[4][64], rsq[4];
   red[q][threadIdx.x & 63] = acc;
+  if ((threadIdx.x & 63) == 0) rsq[q] = sq;
   __syncthreads();
-  if (q == 0 && c < C) atomicAdd(vm + (size_t)m * C + c, red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x]);
-  if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) atomicAdd(cm + m, sq);   // (each of the 4 d-quarters of this block once)
+  float* out = part + ((size_t)m * nz + z) * (C + 1);
+  if (q == 0 && c < C) out[c] = (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]);
+  if (blockIdx.x == 0 && threadIdx.x == 0) out[C] = (rsq[0] + rsq[1]) + (rsq[2] + rsq[3]);
+}
+__global__ void k_gt_vc_sum(const float* __restrict__ part, int nz, int C, float* __restrict__ vm, float* __restrict__ cm) {
+  const int m = blockIdx.y;
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c > C) return;
+  float acc = 0.f;
+  for (int z = 0; z < nz; z++) acc += part[((size_t)m * nz + z) * (C + 1) + c];
+  if (c < C) vm[(size_t)m * C + c] = acc;
+  else cm[m] = acc;
 }
 
 struct HeadRows {
@@ -558,14 +571,13 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
   const float* H = F32(w.act[nb - 1]);
 
   // ================= head: G_m, v_m, |b_m|^2 from the masters; X_m = H G_m; the row-wise kernel ==============================================
-  G_HIP(hipMemsetAsync(t->vm, 0, (size_t)M * C * 4, st));
-  G_HIP(hipMemsetAsync(t->cm, 0, 64 * 4, st));
   for (int m = 0; m < M; m++)
     G_HIP(gemm32_tn(t->Wt + (size_t)m * DP * C, C, t->Wt + (size_t)m * DP * C, C, t->Gm + (size_t)m * C * C, C, C, C, DP, 0.f, t->splitk, t->splitk_floats, st));
   {
-    const int dslice = 1024;
-    hipLaunchKernelGGL(k_gt_vc, dim3((unsigned)((C + 63) / 64), (unsigned)M, (unsigned)((DP + dslice - 1) / dslice)), dim3(256), 0, st, t->Wt, t->bt, DP, C, dslice,
-                       t->vm, t->cm);
+    const int dslice = 1024, nz = (DP + dslice - 1) / dslice;   // (the partials live in the split-K scratch: M nz (C + 1) floats, free between the products)
+    if ((size_t)M * nz * (C + 1) > t->splitk_floats) return gfail(HIERTCN_ERR_INVALID, "output_dim %d too large for the v_m partials", D);
+    hipLaunchKernelGGL(k_gt_vc_part, dim3((unsigned)((C + 63) / 64), (unsigned)M, (unsigned)nz), dim3(256), 0, st, t->Wt, t->bt, DP, C, dslice, t->splitk);
+    hipLaunchKernelGGL(k_gt_vc_sum, dim3((unsigned)((C + 1 + 255) / 256), (unsigned)M), dim3(256), 0, st, t->splitk, nz, C, t->vm, t->cm);
     G_HIP(hipGetLastError());
   }
   for (int m = 0; m < M; m++)

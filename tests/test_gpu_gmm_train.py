@@ -231,3 +231,112 @@ def test_what_is_not_built_says_so():
     with pytest.raises(NotImplementedError):
         mg.enable_training()
     mg.close()
+
+
+def test_run_gmm_trains_on_the_synthetic_xing_file_and_the_checkpoint_resumes(tmp_path):
+    """`run_xing --model_type tcn_gmm --train` = run_gmm in run_nn's cadence: epochs of optimizer steps at the scheduled learning rate, a
+    checkpoint at save_epoch, evaluation at test_epoch.  The test loss falls; the checkpoint holds the trained weights under the reference's
+    variable names and a second run restores it and evaluates to the same number."""
+    import os
+
+    from hiertcn_amd import checkpoint
+    from hiertcn_amd.data_loader import Dataloader_single_level_model_xing
+    from hiertcn_amd.data_prepare import load_xing
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    from hiertcn_amd.run_gmm_xing import evaluate_gmm, run_gmm
+    data = load_xing(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interactions_synth.csv"))
+    N = int(data[1][:, 1].max()) + 1
+    a = _args(N, 3, (64, 64), 3)
+    a.batch_size = 6
+    a.name = "gmm_train_test"
+    a.log_path, a.save_path, a.load_path = str(tmp_path) + "/log/", str(tmp_path) + "/model/", str(tmp_path) + "/model/"
+    os.makedirs(a.save_path)
+    os.makedirs(a.log_path + "before/")
+    a.train, a.validate, a.test, a.load, a.save = True, False, True, False, True
+    a.epoch_max, a.epoch_batches_train, a.test_epoch, a.save_epoch, a.lr_schedule, a.learning_rate = 2, 12, 2, 2, False, 2e-3
+    mk = lambda split: Dataloader_single_level_model_xing(a, split, data=data)  # noqa: E731
+    p0 = G.init_params(a, seed=3)
+    model = TcnGmmModel(a, p0)
+    before, _, _ = evaluate_gmm(a, mk("test"), model, prefix="before")
+    run_gmm(a, mk("train"), mk("validate"), mk("test"), sess=model)
+    assert model.adam_time() == 3 * 12
+    after, _, _ = evaluate_gmm(a, mk("test"), model, prefix="before")
+    assert after["loss_epoch"] < before["loss_epoch"] - 1e-3, (before["loss_epoch"], after["loss_epoch"])
+    saved = checkpoint.load(a.save_path + "2.ckpt")
+    assert set(saved) == set(p0)
+    w = model.export("weights")
+    for k in p0:
+        assert saved[k].shape == p0[k].shape and np.array_equal(saved[k], w[k]), k
+        assert not np.array_equal(saved[k], p0[k]), k                                    # every variable moved
+    scalars = open(a.log_path + "train/scalars.jsonl").read().splitlines()
+    assert len(scalars) == 3
+    model.close()
+    # a second run: restore epoch 2 and evaluate only
+    b = _args(N, 3, (64, 64), 3)
+    b.batch_size, b.name = 6, "gmm_train_test"
+    b.log_path, b.save_path, b.load_path = str(tmp_path) + "/log2/", a.save_path, a.save_path
+    b.train, b.validate, b.test, b.load, b.load_epoch, b.save = False, False, True, True, 2, False
+    m2 = run_gmm(b, None, None, mk("test"))
+    again, _, _ = evaluate_gmm(a, mk("test"), m2, prefix="before")
+    assert abs(again["loss_epoch"] - after["loss_epoch"]) < 1e-9 * max(1.0, abs(after["loss_epoch"]))
+    m2.close()
+
+
+# ---- data parallel: two ranks on ONE GPU over gloo == one rank on the concatenated batch (model.py:135-141 on the global batch) ---------------------
+def _dp_case():
+    N, M, channels, K, B, T = 700, 3, (64, 64), 3, 7, 9
+    a = _args(N, M, channels, K)
+    p = _params(a, seed=9)
+    x, y = _batch(np.random.default_rng(21), N, B, T)
+    return a, p, x, y
+
+
+def _dp_worker(rank, world, port, out_dir):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    from hiertcn_amd.distributed import init_from_env
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    torch.cuda.set_device(0)
+    init_from_env("gloo")
+    a, p, x, y = _dp_case()
+    sl = slice(0, 4) if rank == 0 else slice(4, 7)                      # uneven shards: 4 + 3 lanes (the last one has no target)
+    m = TcnGmmModel(a, p)
+    m.enable_training()
+    out = m.train_step(x[sl], y[sl], 1e-2)
+    torch.cuda.synchronize()
+    if rank == 0:
+        np.savez(os.path.join(out_dir, "dp.npz"), sums=out["sums"].cpu().numpy(), **{"g:" + k: v for k, v in m.export("grads").items()},
+                 **{"w:" + k: v for k, v in m.export("weights").items()})
+    m.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from hiertcn_amd.model_tcn_gmm import TcnGmmModel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    dp = np.load(str(tmp_path / "dp.npz"))
+    a, p, x, y = _dp_case()
+    m = TcnGmmModel(a, p)
+    m.enable_training()
+    out = m.train_step(x, y, 1e-2)
+    sums = out["sums"].cpu().numpy()
+    g, w = m.export("grads"), m.export("weights")
+    assert dp["sums"][1] == sums[1] == 6                                                         # users of the GLOBAL batch
+    assert abs(dp["sums"][0] - sums[0]) < 1e-6 * abs(sums[0])
+    for k in g:
+        assert np.linalg.norm(dp["g:" + k] - g[k]) <= 2e-6 * max(np.linalg.norm(g[k]), 1e-30), k   # the summed shard gradients = the batch gradient
+        # ... and so is the Adam update: a first step moves every weight by ~lr (m / sqrt(v) = g / |g|), and where |g| is of the order of
+        # Adam's epsilon (3e-7 behind the first step's bias correction) the quotient magnifies the last-bit differences of the summed gradients
+        # (the scale of the gradients is what the line above checks -- Adam's first step does not see it): 1e-3 of the step
+        assert np.abs(dp["w:" + k] - w[k]).max() <= 1e-3 * 1e-2, k
+    m.close()
