@@ -246,13 +246,30 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     train_ms = (time.perf_counter() - t0) / 10 * 1e3
     tl = torch.stack(tl).cpu().numpy()
     tm.close()
+    # ... and of model_gru_gmm (the GRU stack on the same one-hot rows: 2 layers, backward through the 200 steps)
+    from hiertcn_amd.model_gru_gmm import GruGmmModel, init_params as gru_init
+    gg = make_args([], model_type="gru_gmm", item_num=n_out, output_dim=n_out, num_mixture=n_mix, sigma=0.1, loss="gmm_prob", hidden_dim=dim, num_layer=2,
+                   adjust=False)
+    gm = GruGmmModel(gg, gru_init(gg, 3))
+    gm.enable_training()
+    for _ in range(2):
+        gm.train_step(tx, ty, 1e-3)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        gm.train_step(tx, ty, 1e-3)
+    torch.cuda.synchronize()
+    train_ms_gru = (time.perf_counter() - t0) / 5 * 1e3
+    gm.close()
     diff = float((losses["gram"] - losses["table_pass"]).abs().max())
     flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
     return {"training": {"what": "one optimizer step of model_tcn_gmm (fixed scale, gmm_prob): fp32 forward on the masters + backward of every variable + TF-form "
                                  "Adam (csrc/gmm_train.hip: the head's backward through G_m = W_m W_m^T, no [rows][M D] matrix; block 0's one-hot rows as "
-                                 "scatter-adds), 32 lanes x 200 steps = 6,400 rows, ids resident; model_gru_gmm / a learned scale / the mixture low "
-                                 "levels of model_hier evaluate only",
+                                 "scatter-adds), 32 lanes x 200 steps = 6,400 rows, ids resident; ms_per_step_gru_gmm: the same step of model_gru_gmm "
+                                 "(2-layer GRU stack on the one-hot rows, backward through the 200 steps as a launch chain); a learned scale / the "
+                                 "mixture low levels of model_hier evaluate only",
                          "rows": tB * tT, "ms_per_step": round(train_ms, 3), "rows_per_s": round(tB * tT / train_ms * 1e3),
+                         "ms_per_step_gru_gmm": round(train_ms_gru, 3),
                          "loss_first_last": [round(float(tl[0, 0] / tl[0, 1]), 5), round(float(tl[-1, 0] / tl[-1, 1]), 5)]},
             "what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
                     "bf16 parts, + one row-wise kernel for prior / linear terms / target mean + finish); ms_table_pass: M passes of "

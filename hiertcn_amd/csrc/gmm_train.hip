@@ -16,8 +16,13 @@
 // The trunk is model_tcn_gmm's: block 0 reads one-hot rows, so its conv taps and its Dense residual are row GATHERS of [K + 1][N][C0] tables in
 // the forward and row SCATTER-ADDS in the backward; blocks 1.. are train.hip's fp32 TemporalBlock forward / backward.
 //
-// Built for: trunk 0 (the TemporalConvNet on ids), a fixed scale (args.sigma set), loss modes gmm_prob and gmm_prob_max.  The GRU trunk, the dense-row
-// trunks of model_hier's mixture low levels and a learned scale evaluate only (hiertcn_gmm_train_enable refuses them).
+// model_gru_gmm's trunk (trunk 1, model_gru_gmm.py:33-48) is the GRU stack on the same one-hot rows: the forward keeps every cell's record
+// (pool_gru.hip: launch_onehot_gru_records), the backward runs through the T steps with train.hip's cell pieces (two exact-fp32 products + three
+// pointwise launches per cell), the weight gradients of all T x nl cells follow as one product per layer and operand, and layer 0's input half -- a
+// gathered table row in the forward -- takes its gradient as a row scatter-add.
+//
+// Built for: trunks 0 and 1 (the models on ids), a fixed scale (args.sigma set), loss modes gmm_prob and gmm_prob_max.  The dense-row trunks of
+// model_hier's mixture low levels and a learned scale evaluate only (hiertcn_gmm_train_enable refuses them).
 #include <math.h>
 #include <string.h>
 
@@ -36,6 +41,7 @@ struct GmmTrain {
   float* arena = nullptr;   // [4][total], REFERENCE (TF) layouts: master | grad | m | v -- a checkpoint is a copy, Adam is elementwise
   size_t total = 0;
   GSeg conv[HIERTCN_MAX_BLOCKS], conv_b[HIERTCN_MAX_BLOCKS], res[HIERTCN_MAX_BLOCKS], res_b[HIERTCN_MAX_BLOCKS], head_w, head_b;
+  GSeg gk[HIERTCN_MAX_LAYERS], gb[HIERTCN_MAX_LAYERS], ck[HIERTCN_MAX_LAYERS], cb[HIERTCN_MAX_LAYERS];   // trunk 1: gate / candidate kernel [in + H][2H | H], bias
   int64_t step = 0;         // Adam time step
   bool stale = false;       // the handle's evaluation tables (gmm.hip) are older than the masters: hiertcn_gmm_train_sync
   // compute-layout copies of the masters, re-derived at the start of every step, and the gradients in the same layouts
@@ -44,6 +50,10 @@ struct GmmTrain {
   float* resT[HIERTCN_MAX_BLOCKS] = {};     // [Cout][Cin]
   float* dconvT[HIERTCN_MAX_BLOCKS] = {};
   float* dresT[HIERTCN_MAX_BLOCKS] = {};
+  float* wg[HIERTCN_MAX_LAYERS] = {};       // trunk 1, output-major: layer 0 [2H][H] (the state half; the input half is the master's rows), layers >= 1 [2H][2H]
+  float* wc[HIERTCN_MAX_LAYERS] = {};       // layer 0 [H][H], layers >= 1 [H][2H]
+  float* dwg[HIERTCN_MAX_LAYERS] = {};
+  float* dwc[HIERTCN_MAX_LAYERS] = {};
   float *Wt = nullptr, *bt = nullptr, *pw = nullptr, *pb = nullptr;         // [M][DP][C] item-major (pad rows zero), [M][DP], [GT_MP][C], [GT_MP]
   float *dWt = nullptr, *dbt = nullptr, *dpw = nullptr, *dpb = nullptr;
   float *Gm = nullptr, *vm = nullptr, *cm = nullptr, *Sm = nullptr, *sm = nullptr, *gs = nullptr;   // [M][C][C], [M][C], [M], [M][C][C], [M][C], [M]
@@ -143,6 +153,37 @@ __global__ __launch_bounds__(256) void k_gt_block0_bwd(const float* __restrict__
     if (q.z != 0.f) atomicAdd(d + 2, q.z);
     if (q.w != 0.f) atomicAdd(d + 3, q.w);
   }
+}
+
+// trunk 1, layer 0: the input half of [x, h] . W on a one-hot row is the table row W[id] (model_gru_gmm.py:33-48 on one_hot(id) * sign(id)); its gradient is a
+// scatter-add of the cell's pre-activation gradients into that row.  dac [L][M][H] (candidate), dag [L][M][2H] (gates); rows (t, m); zero where a row was inactive.
+__global__ __launch_bounds__(256) void k_gt_gru_in_scatter(const float* __restrict__ dac, const float* __restrict__ dag, const int32_t* __restrict__ ids, int M,
+                                                           int L, int N, int H, float* __restrict__ dgk, float* __restrict__ dck) {
+  const int ch = H >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)L * M * ch) return;
+  const int64_t row = i / ch;                  // (t, m)
+  const int c = (int)(i - row * ch) * 4;
+  const int t = (int)(row / M), m = (int)(row - (int64_t)t * M);
+  const int id = ids[(int64_t)m * L + t];
+  if (id <= 0 || id >= N) return;
+  const float4 a = *reinterpret_cast<const float4*>(dac + row * H + c);
+  const float4 g0 = *reinterpret_cast<const float4*>(dag + row * 2 * H + c);
+  const float4 g1 = *reinterpret_cast<const float4*>(dag + row * 2 * H + H + c);
+  float* dc = dck + (int64_t)id * H + c;
+  float* dg = dgk + (int64_t)id * 2 * H + c;
+  if (a.x != 0.f) atomicAdd(dc, a.x);
+  if (a.y != 0.f) atomicAdd(dc + 1, a.y);
+  if (a.z != 0.f) atomicAdd(dc + 2, a.z);
+  if (a.w != 0.f) atomicAdd(dc + 3, a.w);
+  if (g0.x != 0.f) atomicAdd(dg, g0.x);
+  if (g0.y != 0.f) atomicAdd(dg + 1, g0.y);
+  if (g0.z != 0.f) atomicAdd(dg + 2, g0.z);
+  if (g0.w != 0.f) atomicAdd(dg + 3, g0.w);
+  if (g1.x != 0.f) atomicAdd(dg + H, g1.x);
+  if (g1.y != 0.f) atomicAdd(dg + H + 1, g1.y);
+  if (g1.z != 0.f) atomicAdd(dg + H + 2, g1.z);
+  if (g1.w != 0.f) atomicAdd(dg + H + 3, g1.w);
 }
 
 // ---- head ------------------------------------------------------------------------------------------------------------------------------------------
@@ -368,6 +409,10 @@ static void gt_layout(const hiertcn_gmm_ctx* g, GmmTrain* t) {
   size_t off = 0;
   auto seg = [&](GSeg& s, size_t n) { s.off = off; s.n = n; off += up64(n); };
   const int K = g->K;
+  for (int l = 0; l < g->nl; l++) {   // trunk 1 (nb == 0): rnn.GRUCell layouts, in = item_num for layer 0 and H above
+    const size_t in = (l == 0) ? (size_t)g->N : (size_t)g->H, H = (size_t)g->H;
+    seg(t->gk[l], (in + H) * 2 * H); seg(t->gb[l], 2 * H); seg(t->ck[l], (in + H) * H); seg(t->cb[l], H);
+  }
   for (int i = 0, cin = g->N; i < g->nb; cin = g->cfg.channels[i], i++) {
     const int cout = g->cfg.channels[i];
     seg(t->conv[i], (size_t)K * cin * cout);
@@ -388,6 +433,8 @@ static int cmax_of(const hiertcn_gmm_ctx* g) {
 
 struct GtWs {
   size_t act[HIERTCN_MAX_BLOCKS], cact[HIERTCN_MAX_BLOCKS], resb, X, GH, dA, gv, loss, dH, bufA, bufB, ds, dc, sh, lane_act, users, total;
+  // trunk 1 (GRU stack on one-hot rows): the forward's records and the backward-through-time's buffers
+  size_t hid, seq_len, states, recs, dac_all, dag_all, dcar[2], dhpart, dcat_c, dcat_g, din_up;
 };
 static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
   GtWs w;
@@ -395,22 +442,39 @@ static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
   const size_t R = (size_t)B * T;
   size_t off = 0;
   auto take = [&](size_t floats) { const size_t o = off; off += ((floats * 4) + 255) & ~(size_t)255; return o; };
-  for (int i = 0; i < g->nb; i++) { w.act[i] = take(R * g->cfg.channels[i]); w.cact[i] = take(R * g->cfg.channels[i]); }
-  const size_t cm = (size_t)cmax_of(g), C = (size_t)g->Clast;
-  w.resb = take(R * cm);
+  const size_t C = (size_t)g->Clast;
+  const size_t cm = g->trunk == 1 ? C : (size_t)cmax_of(g);
   w.X = take((size_t)g->M * R * C);
   w.GH = take((size_t)g->M * R * C);
   w.dA = take(R * GT_MP);
   w.gv = take((size_t)g->M * R);
   w.loss = take(R);
   w.dH = take(R * cm);
-  w.bufA = take(R * cm);
-  w.bufB = take(R * cm);
-  w.ds = take(R * cm);
-  w.dc = take(R * cm);
-  w.sh = take(R * cm);
   w.lane_act = take((size_t)B);
   w.users = take(64);
+  if (g->trunk == 1) {
+    const size_t H = (size_t)g->H, HT = H * g->nl, M = (size_t)B, L = (size_t)T, nl = (size_t)g->nl;
+    w.hid = take(R * H);
+    w.seq_len = take(M);
+    w.states = take((L + 1) * M * HT);
+    w.recs = take(L * nl * M * 5 * H);
+    w.dac_all = take(nl * L * M * H);
+    w.dag_all = take(nl * L * M * 2 * H);
+    w.dcar[0] = take(M * HT);
+    w.dcar[1] = take(M * HT);
+    w.dhpart = take(M * H);
+    w.dcat_c = take(M * 2 * H);
+    w.dcat_g = take(M * 2 * H);
+    w.din_up = take(M * H);
+  } else {
+    for (int i = 0; i < g->nb; i++) { w.act[i] = take(R * g->cfg.channels[i]); w.cact[i] = take(R * g->cfg.channels[i]); }
+    w.resb = take(R * cm);
+    w.bufA = take(R * cm);
+    w.bufB = take(R * cm);
+    w.ds = take(R * cm);
+    w.dc = take(R * cm);
+    w.sh = take(R * cm);
+  }
   w.total = off;
   return w;
 }
@@ -427,6 +491,10 @@ static void master_ptrs(const hiertcn_gmm_ctx* g, const GmmTrain* t, const float
     w->conv_bias[i] = base + t->conv_b[i].off;
     if (t->res[i].n) { w->res_kernel[i] = base + t->res[i].off; w->res_bias[i] = base + t->res_b[i].off; }
   }
+  for (int l = 0; l < g->nl; l++) {
+    w->gru_gate_kernel[l] = base + t->gk[l].off; w->gru_gate_bias[l] = base + t->gb[l].off;
+    w->gru_cand_kernel[l] = base + t->ck[l].off; w->gru_cand_bias[l] = base + t->cb[l].off;
+  }
   w->head_weights = base + t->head_w.off;
   w->head_biases = base + t->head_b.off;
 }
@@ -441,6 +509,12 @@ static int gt_refresh(hiertcn_gmm_ctx* g, hipStream_t st) {
     for (int j = 0; j < K; j++)
       G_HIP(gt_transpose(P + t->conv[i].off + (size_t)j * cin * cout, cout, t->convT[i] + (size_t)j * cin * cout, cin, cin, cout, st));
     if (t->res[i].n) G_HIP(gt_transpose(P + t->res[i].off, cout, t->resT[i], cin, cin, cout, st));
+  }
+  for (int l = 0; l < g->nl; l++) {   // trunk 1: the state half of layer 0 / the whole kernels above, output-major (the cells' B operand)
+    const int H = g->H, in_tf = (l == 0) ? g->N : H, Kc = (l == 0) ? H : 2 * H;
+    const size_t skip = (l == 0) ? (size_t)in_tf : 0;   // layer 0: rows [N, N + H) only -- the input half stays where it is (item-major rows of the master)
+    G_HIP(gt_transpose(P + t->gk[l].off + skip * 2 * H, 2 * H, t->wg[l], Kc, Kc, 2 * H, st));
+    G_HIP(gt_transpose(P + t->ck[l].off + skip * H, H, t->wc[l], Kc, Kc, H, st));
   }
   const int64_t n_out = (int64_t)M * (1 + (int64_t)D);
   const float* W = P + t->head_w.off;
@@ -459,14 +533,18 @@ extern "C" {
 int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream) {
   if (!g || !w) return gfail(HIERTCN_ERR_INVALID, "null argument");
   if (g->train) return gfail(HIERTCN_ERR_STATE, "training is already enabled on this handle");
-  if (g->trunk != 0)
-    return gfail(HIERTCN_ERR_INVALID, "the training step is built for the TemporalConvNet trunk on ids (trunk 0: model_tcn_gmm); trunk %d evaluates only", g->trunk);
+  if (g->trunk != 0 && g->trunk != 1)
+    return gfail(HIERTCN_ERR_INVALID, "the training step is built for the models on ids (trunk 0: model_tcn_gmm, trunk 1: model_gru_gmm); trunk %d -- a mixture low level "
+                 "of model_hier -- evaluates only", g->trunk);
   if (g->learned) return gfail(HIERTCN_ERR_INVALID, "the training step is built for a fixed scale (args.sigma set); a learned scale evaluates only");
   if (g->M > GT_MP) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: the training step takes up to 16 mixtures", g->M);
   if (g->Clast != 64 && g->Clast != 128 && g->Clast != 256 && g->Clast != 512) return gfail(HIERTCN_ERR_INVALID, "last width %d: 64, 128, 256, 512", g->Clast);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   TuneScope tune_(nullptr);
   if (!w->head_weights || !w->head_biases) return gfail(HIERTCN_ERR_INVALID, "the head (fully_connected weights / biases) is required");
+  for (int l = 0; l < g->nl; l++)
+    if (!w->gru_gate_kernel[l] || !w->gru_gate_bias[l] || !w->gru_cand_kernel[l] || !w->gru_cand_bias[l])
+      return gfail(HIERTCN_ERR_INVALID, "GRU layer %d: gate / candidate kernel and bias are required", l);
   for (int i = 0, cin = g->N; i < g->nb; cin = g->cfg.channels[i], i++) {
     if (!w->conv_kernel[i] || !w->conv_bias[i]) return gfail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
     if ((cin != g->cfg.channels[i]) != (w->res_kernel[i] != nullptr && w->res_bias[i] != nullptr))
@@ -485,6 +563,11 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
     o_convT[i] = take(t->conv[i].n); o_dconvT[i] = take(t->conv[i].n);
     if (t->res[i].n) { o_resT[i] = take(t->res[i].n); o_dresT[i] = take(t->res[i].n); }
   }
+  size_t o_wg[HIERTCN_MAX_LAYERS] = {}, o_wc[HIERTCN_MAX_LAYERS] = {}, o_dwg[HIERTCN_MAX_LAYERS] = {}, o_dwc[HIERTCN_MAX_LAYERS] = {};
+  for (int l = 0; l < g->nl; l++) {
+    const size_t H = (size_t)g->H, Kc = (l == 0) ? H : 2 * H;
+    o_wg[l] = take(2 * H * Kc); o_dwg[l] = take(2 * H * Kc); o_wc[l] = take(H * Kc); o_dwc[l] = take(H * Kc);
+  }
   const size_t o_Wt = take(M * DP * C), o_bt = take(M * DP), o_pw = take(GT_MP * C), o_pb = take(GT_MP);
   const size_t o_dWt = take(M * DP * C), o_dbt = take(M * DP), o_dpw = take(GT_MP * C), o_dpb = take(GT_MP);
   const size_t o_Gm = take(M * C * C), o_vm = take(M * C), o_cm = take(64), o_Sm = take(M * C * C), o_sm = take(M * C), o_gs = take(64);
@@ -497,6 +580,7 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
     t->convT[i] = t->work + o_convT[i]; t->dconvT[i] = t->work + o_dconvT[i];
     if (t->res[i].n) { t->resT[i] = t->work + o_resT[i]; t->dresT[i] = t->work + o_dresT[i]; }
   }
+  for (int l = 0; l < g->nl; l++) { t->wg[l] = t->work + o_wg[l]; t->dwg[l] = t->work + o_dwg[l]; t->wc[l] = t->work + o_wc[l]; t->dwc[l] = t->work + o_dwc[l]; }
   t->Wt = t->work + o_Wt; t->bt = t->work + o_bt; t->pw = t->work + o_pw; t->pb = t->work + o_pb;
   t->dWt = t->work + o_dWt; t->dbt = t->work + o_dbt; t->dpw = t->work + o_dpw; t->dpb = t->work + o_dpb;
   t->Gm = t->work + o_Gm; t->vm = t->work + o_vm; t->cm = t->work + o_cm; t->Sm = t->work + o_Sm; t->sm = t->work + o_sm; t->gs = t->work + o_gs;
@@ -515,6 +599,12 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
       G_HIP(hipMemcpyAsync(const_cast<float*>(dst.res_kernel[i]), w->res_kernel[i], t->res[i].n * 4, hipMemcpyDeviceToDevice, st));
       G_HIP(hipMemcpyAsync(const_cast<float*>(dst.res_bias[i]), w->res_bias[i], t->res_b[i].n * 4, hipMemcpyDeviceToDevice, st));
     }
+  }
+  for (int l = 0; l < g->nl; l++) {
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.gru_gate_kernel[l]), w->gru_gate_kernel[l], t->gk[l].n * 4, hipMemcpyDeviceToDevice, st));
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.gru_gate_bias[l]), w->gru_gate_bias[l], t->gb[l].n * 4, hipMemcpyDeviceToDevice, st));
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.gru_cand_kernel[l]), w->gru_cand_kernel[l], t->ck[l].n * 4, hipMemcpyDeviceToDevice, st));
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.gru_cand_bias[l]), w->gru_cand_bias[l], t->cb[l].n * 4, hipMemcpyDeviceToDevice, st));
   }
   G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_weights), w->head_weights, t->head_w.n * 4, hipMemcpyDeviceToDevice, st));
   G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_biases), w->head_biases, t->head_b.n * 4, hipMemcpyDeviceToDevice, st));
@@ -549,6 +639,17 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
   G_HIP(hipMemsetAsync(G, 0, t->total * sizeof(float), st));
 
   // ================= forward on the masters =================================================================================================
+  const float* H = nullptr;
+  OneHotGru og;
+  memset(&og, 0, sizeof(og));
+  if (g->trunk == 1) {
+    // model_gru_gmm.py:33-48: MultiRNNCell of GRUCells under dynamic_rnn on the one-hot rows, from a zero state; every record kept for the backward
+    og.N = N; og.H = g->H; og.nl = g->nl;
+    og.in_g = P + t->gk[0].off; og.in_c = P + t->ck[0].off;     // rows [0, N) of the masters' layer-0 kernels: the input half, item-major as it is
+    for (int l = 0; l < g->nl; l++) { og.wg[l] = t->wg[l]; og.bg[l] = P + t->gb[l].off; og.wc[l] = t->wc[l]; og.bc[l] = P + t->cb[l].off; }
+    G_HIP(launch_onehot_gru_records(og, x_ids, B, T, F32(w.hid), reinterpret_cast<int32_t*>(ws + w.seq_len), F32(w.states), F32(w.recs), st));
+    H = F32(w.hid);
+  } else {
   hipLaunchKernelGGL(k_gt_block0, dim3((unsigned)((R * (C0 >> 2) + 255) / 256)), dim3(256), 0, st, P + t->conv[0].off, P + t->res[0].off, P + t->conv_b[0].off,
                      P + t->res_b[0].off, x_ids, R, T, N, C0, K, F32(w.act[0]), F32(w.cact[0]));
   G_HIP(hipGetLastError());
@@ -568,8 +669,8 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     x.bias = P + t->conv_b[i].off; x.res = res; x.ldres = ldres; x.out = F32(w.act[i]); x.out2 = F32(w.cact[i]); x.ldo = cout; x.epi = XEPI_BLOCK;
     G_HIP(launch_xgemm(x, st));
   }
-  const float* H = F32(w.act[nb - 1]);
-
+  H = F32(w.act[nb - 1]);
+  }
   // ================= head: G_m, v_m, |b_m|^2 from the masters; X_m = H G_m; the row-wise kernel ==============================================
   for (int m = 0; m < M; m++)
     G_HIP(gemm32_tn(t->Wt + (size_t)m * DP * C, C, t->Wt + (size_t)m * DP * C, C, t->Gm + (size_t)m * C * C, C, C, C, DP, 0.f, t->splitk, t->splitk_floats, st));
@@ -631,6 +732,71 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     G_HIP(hipGetLastError());
   }
 
+  if (g->trunk == 1) {
+    // ================= backward through time of the GRU stack (customed_gru_cell.py:323-337 differentiated; train.hip's cell chain) =============
+    const int Hh = g->H, HT = g->H * g->nl, nl = g->nl, Mb = (int)B, L = T;
+    const size_t cell = (size_t)Mb * 5 * Hh;
+    const int32_t* seq_len = reinterpret_cast<const int32_t*>(ws + w.seq_len);
+    const float* states = F32(w.states);
+    const float* recs = F32(w.recs);
+    float* dac_all = F32(w.dac_all);
+    float* dag_all = F32(w.dag_all);
+    float* lcar = F32(w.dcar[0]);
+    float* lnext = F32(w.dcar[1]);
+    float* dhpart = F32(w.dhpart);
+    float* dcat_c = F32(w.dcat_c);
+    float* dcat_g = F32(w.dcat_g);
+    float* din_up = F32(w.din_up);
+    const float* dHid = F32(w.dH);
+    G_HIP(hipMemsetAsync(lcar, 0, (size_t)Mb * HT * 4, st));   // the final state is dropped (model_gru_gmm.py:47: outputs only)
+    for (int tt = L - 1; tt >= 0; tt--) {
+      for (int l = nl - 1; l >= 0; l--) {
+        const int in = (l == 0) ? 0 : Hh;            // layer 0's input half is the gathered table row: no dense input operand
+        const int Kc = in + Hh;
+        const float* rec = recs + ((size_t)tt * nl + l) * cell;
+        const float* gates = rec;
+        const float* cand = rec + (size_t)Mb * 3 * Hh;
+        const float* hold = states + (size_t)tt * Mb * HT + (size_t)l * Hh;   // row stride HT
+        const float* dout = (l == nl - 1) ? dHid + (size_t)tt * Hh : din_up;
+        const int64_t ld_dout = (l == nl - 1) ? (int64_t)L * Hh : Hh;
+        float* dac = dac_all + ((size_t)l * L + tt) * Mb * Hh;
+        float* dag = dag_all + ((size_t)l * L + tt) * Mb * 2 * Hh;
+        G_HIP(train_lgru_bwd_a(lcar + (size_t)l * Hh, HT, dout, ld_dout, seq_len, tt, hold, HT, gates, cand, Mb, Hh, dac, dag, dhpart, st));
+        G_HIP(gemm32_nn(dac, Hh, t->wc[l], Kc, dcat_c, Kc, Mb, Kc, Hh, 0.f, st));            // d [in | r*h] = dac . wc
+        G_HIP(train_gru_bwd_b(dcat_c, Kc, in, hold, HT, gates, Mb, Hh, dag, dhpart, st));
+        G_HIP(gemm32_nn(dag, 2 * Hh, t->wg[l], Kc, dcat_g, Kc, Mb, Kc, 2 * Hh, 0.f, st));    // d [in | h] = dag . wg
+        G_HIP(train_lgru_bwd_c(dcat_c, dcat_g, Kc, in, dhpart, Mb, Hh, din_up, Hh, lnext + (size_t)l * Hh, HT, lcar + (size_t)l * Hh, seq_len, tt, st));
+      }
+      float* tmp = lcar; lcar = lnext; lnext = tmp;
+    }
+    // weight gradients of all L * nl cells: one product per layer and operand over the L * M rows (rows (t, m): slab t, session m)
+    const int LM = L * Mb;
+    for (int l = 0; l < nl; l++) {
+      const int in = (l == 0) ? 0 : Hh, Kc = in + Hh;
+      const float* dac = dac_all + (size_t)l * L * Mb * Hh;
+      const float* dag = dag_all + (size_t)l * L * Mb * 2 * Hh;
+      const int64_t rss = (int64_t)((size_t)nl * cell);   // the same record of the next step
+      const float* rh = recs + (size_t)l * cell + (size_t)Mb * 2 * Hh;
+      const float* hold = states + (size_t)l * Hh;        // states 0 .. L-1: contiguous rows (t, m) of HT floats
+      if (l > 0) {
+        const float* inp = recs + (size_t)(l - 1) * cell + (size_t)Mb * 4 * Hh;
+        G_HIP(gemm32_tn_slabs(dac, Hh, 0, 0, inp, Hh, Mb, rss, t->dwc[l], Kc, Hh, in, LM, 0.f, t->splitk, t->splitk_floats, st));
+        G_HIP(gemm32_tn_slabs(dag, 2 * Hh, 0, 0, inp, Hh, Mb, rss, t->dwg[l], Kc, 2 * Hh, in, LM, 0.f, t->splitk, t->splitk_floats, st));
+      }
+      G_HIP(gemm32_tn_slabs(dac, Hh, 0, 0, rh, Hh, Mb, rss, t->dwc[l] + in, Kc, Hh, Hh, LM, 0.f, t->splitk, t->splitk_floats, st));
+      G_HIP(gemm32_tn_slabs(dag, 2 * Hh, 0, 0, hold, HT, 0, 0, t->dwg[l] + in, Kc, 2 * Hh, Hh, LM, 0.f, t->splitk, t->splitk_floats, st));
+      G_HIP(train_colsum_f32(dac, LM, Hh, Hh, G + t->cb[l].off, st));
+      G_HIP(train_colsum_f32(dag, LM, 2 * Hh, 2 * Hh, G + t->gb[l].off, st));
+      // -> the reference layout [in_tf + H][2H | H]: rows behind the input half (layer 0: behind the N table rows)
+      const size_t skip = (l == 0) ? (size_t)N : 0;
+      G_HIP(gt_transpose(t->dwg[l], Kc, G + t->gk[l].off + skip * 2 * Hh, 2 * Hh, 2 * Hh, Kc, st));
+      G_HIP(gt_transpose(t->dwc[l], Kc, G + t->ck[l].off + skip * Hh, Hh, Hh, Kc, st));
+    }
+    // layer 0's input half: the table rows the forward gathered receive the cells' pre-activation gradients
+    hipLaunchKernelGGL(k_gt_gru_in_scatter, dim3((unsigned)(((int64_t)LM * (Hh >> 2) + 255) / 256)), dim3(256), 0, st, dac_all, dag_all, x_ids, Mb, L, N, Hh,
+                       G + t->gk[0].off, G + t->ck[0].off);
+    G_HIP(hipGetLastError());
+  } else {
   // ================= TemporalBlocks, last to first (train.hip's fp32 recipe) ===========================================================================
   float* da = F32(w.dH);
   float* dprev = F32(w.bufA);
@@ -676,6 +842,7 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     hipLaunchKernelGGL(k_gt_block0_bwd, dim3((unsigned)((R * (C0 >> 2) + 255) / 256)), dim3(256), 0, st, ds, dc, x_ids, R, T, N, C0, K, G + t->conv[0].off,
                        G + t->res[0].off);
     G_HIP(hipGetLastError());
+  }
   }
 #undef F32
   return HIERTCN_OK;
@@ -729,6 +896,12 @@ int hiertcn_gmm_train_copy(hiertcn_gmm_handle_t g, int32_t which, int32_t to_han
     G_HIP(cp(a.conv_bias[i], bufs->conv_bias[i], t->conv_b[i].n));
     G_HIP(cp(a.res_kernel[i], bufs->res_kernel[i], t->res[i].n));
     G_HIP(cp(a.res_bias[i], bufs->res_bias[i], t->res_b[i].n));
+  }
+  for (int l = 0; l < g->nl; l++) {
+    G_HIP(cp(a.gru_gate_kernel[l], bufs->gru_gate_kernel[l], t->gk[l].n));
+    G_HIP(cp(a.gru_gate_bias[l], bufs->gru_gate_bias[l], t->gb[l].n));
+    G_HIP(cp(a.gru_cand_kernel[l], bufs->gru_cand_kernel[l], t->ck[l].n));
+    G_HIP(cp(a.gru_cand_bias[l], bufs->gru_cand_bias[l], t->cb[l].n));
   }
   G_HIP(cp(a.head_weights, bufs->head_weights, t->head_w.n));
   G_HIP(cp(a.head_biases, bufs->head_biases, t->head_b.n));

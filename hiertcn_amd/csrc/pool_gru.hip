@@ -797,3 +797,50 @@ static hipError_t gru_rows_cells(const OneHotGru& w, const int32_t* x, const flo
   }
   return hipSuccess;
 }
+
+// The same cells with EVERY record kept, fp32 output rows and the masters' fp32 kernels as they are (gmm_train.hip: the training step of model_gru_gmm):
+//   states [L + 1][M][HT] (slot 0 = the zero state), recs [L][nl][gates 2H | r*h H | cand H | out H per session], hidden32 [M * L][H] rows (session, t)
+hipError_t launch_onehot_gru_records(const OneHotGru& w, const int32_t* x, int64_t n_sess, int L, float* hidden32, int32_t* seq_len, float* states, float* recs,
+                                     hipStream_t st) {
+  if (n_sess <= 0) return hipSuccess;
+  const int H = w.H, HT = w.H * w.nl;
+  const size_t cell = (size_t)n_sess * 5 * H;
+  hipLaunchKernelGGL(k_count_ids, dim3((unsigned)((n_sess + 255) / 256)), dim3(256), 0, st, x, n_sess, L, w.N, seq_len);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state
+  for (int t = 0; t < L; t++) {
+    const float* s_old = states + (size_t)t * n_sess * HT;
+    float* s_new = states + (size_t)(t + 1) * n_sess * HT;
+    for (int l = 0; l < w.nl; l++) {
+      float* rec = recs + ((size_t)t * w.nl + l) * cell;
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      const float* hold = s_old + (size_t)l * H;
+      float* gates = rec;
+      float* rh = rec + (size_t)n_sess * 2 * H;
+      g.M = (int)n_sess; g.H = H;
+      if (l == 0) {
+        g.A1 = nullptr; g.lda1 = 0; g.K1 = 0;
+        g.add_tab = w.in_g; g.add_ld = 2 * H; g.add_n = w.N; g.add_ids = x + t; g.add_ids_ld = L;
+      } else {
+        g.A1 = recs + ((size_t)t * w.nl + l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H;
+      }
+      g.A2 = hold; g.lda2 = HT; g.K2 = H;
+      g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
+      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
+      g.A2 = rh; g.lda2 = H;
+      g.Wt = w.wc[l]; g.bias = w.bc[l]; g.N = H;
+      if (l == 0) { g.add_tab = w.in_c; g.add_ld = H; }
+      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
+      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
+      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
+      g.gates = gates; g.ldg = 2 * H;
+      g.seq_len = seq_len; g.tstep = t;
+      if (l == w.nl - 1) { g.hid_out32 = hidden32 + (size_t)t * H; g.ldho = (int64_t)L * H; }
+      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
+}

@@ -68,3 +68,13 @@ hipError_t train_colsum_f32(const float* src, int64_t rows, int64_t ld, int cols
 hipError_t train_lane_act(const int32_t* y, int B, int T, float* act, float* users, hipStream_t st);
 hipError_t train_adam_flat(float* p, const float* g, float* m1, float* m2, size_t n, float lr, float beta1, float beta2, float eps, float grad_scale,
                            int64_t step, hipStream_t st);
+// pointwise pieces of a GRU cell's backward under dynamic_rnn's sequence_length (model_gru.py:47-53; customed_gru_cell.py:323-337 differentiated):
+//   a: d = active ? dcar + dout : 0;  dac = d (1-u) (1-c^2);  dag[:, H:] = d (h - c) u (1-u);  dhpart = d u
+//   b: drh = dcat_c[:, in:];  dag[:, :H] = drh h r (1-r);  dhpart += drh r
+//   c: d input = dcat_c[:, :in] + dcat_g[:, :in];  d old state = active ? dhpart + dcat_g[:, in:] : dcar
+hipError_t train_lgru_bwd_a(const float* dcar, int ldd, const float* dout, int64_t ld_dout, const int32_t* seq_len, int tstep, const float* h, int ldh,
+                            const float* gates, const float* cand, int M, int H, float* dac, float* dag, float* dhpart, hipStream_t st);
+hipError_t train_gru_bwd_b(const float* dcat_c, int K, int in, const float* h, int ldh, const float* gates, int M, int H, float* dag, float* dhpart,
+                           hipStream_t st);
+hipError_t train_lgru_bwd_c(const float* dcat_c, const float* dcat_g, int K, int in, const float* dhpart, int M, int H, float* dst_in, int64_t ldi, float* dst_h,
+                            int ldo, const float* dcar, const int32_t* seq_len, int tstep, hipStream_t st);

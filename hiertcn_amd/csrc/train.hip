@@ -1506,3 +1506,22 @@ hipError_t train_adam_flat(float* p, const float* g, float* m1, float* m2, size_
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m1, m2, n, lr_t, beta1, beta2, eps, grad_scale);
   return hipGetLastError();
 }
+// the pointwise pieces of a GRU cell's backward under dynamic_rnn's sequence_length (k_lgru_bwd_a / k_gru_bwd_b / k_lgru_bwd_c above)
+hipError_t train_lgru_bwd_a(const float* dcar, int ldd, const float* dout, int64_t ld_dout, const int32_t* seq_len, int tstep, const float* h, int ldh,
+                            const float* gates, const float* cand, int M, int H, float* dac, float* dag, float* dhpart, hipStream_t st) {
+  hipLaunchKernelGGL(k_lgru_bwd_a, dim3((unsigned)(((int64_t)M * H + 255) / 256)), dim3(256), 0, st, dcar, ldd, dout, ld_dout, seq_len, tstep, h, ldh, gates, cand,
+                     M, H, dac, dag, dhpart);
+  return hipGetLastError();
+}
+hipError_t train_gru_bwd_b(const float* dcat_c, int K, int in, const float* h, int ldh, const float* gates, int M, int H, float* dag, float* dhpart,
+                           hipStream_t st) {
+  hipLaunchKernelGGL(k_gru_bwd_b, dim3((unsigned)(((int64_t)M * H + 255) / 256)), dim3(256), 0, st, dcat_c, K, in, h, ldh, gates, M, H, dag, dhpart);
+  return hipGetLastError();
+}
+hipError_t train_lgru_bwd_c(const float* dcat_c, const float* dcat_g, int K, int in, const float* dhpart, int M, int H, float* dst_in, int64_t ldi, float* dst_h,
+                            int ldo, const float* dcar, const int32_t* seq_len, int tstep, hipStream_t st) {
+  const int Wd = in > H ? in : H;
+  hipLaunchKernelGGL(k_lgru_bwd_c, dim3((unsigned)(((int64_t)M * Wd + 255) / 256)), dim3(256), 0, st, dcat_c, dcat_g, K, in, dhpart, M, H, dst_in, ldi, dst_h, ldo,
+                     dcar, seq_len, tstep);
+  return hipGetLastError();
+}

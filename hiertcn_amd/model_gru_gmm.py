@@ -74,9 +74,16 @@ class GruGmmModel(TcnGmmModel):
         self._upload(self.params)
         self._ws = None
 
-    def enable_training(self):
-        raise NotImplementedError("model_gru_gmm trains nowhere in this build: the training step of the mixture models (csrc/gmm_train.hip) is built "
-                                  "for the TemporalConvNet trunk of model_tcn_gmm; the GRU trunk on one-hot rows evaluates only (DESIGN.md 7)")
+    def _weights_struct(self, bufs):
+        """hiertcn_gmm_weights_t over {TF name: device tensor} (training: masters in / gradients, moments out -- TcnGmmModel.export / restore)."""
+        w = _lib.GmmWeights()
+        p = lambda k: bufs[k].data_ptr()  # noqa: E731
+        for l in range(self.nl):
+            pre = f"{self.name}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+            w.gru_gate_kernel[l], w.gru_gate_bias[l] = p(f"{pre}/gates/kernel"), p(f"{pre}/gates/bias")
+            w.gru_cand_kernel[l], w.gru_cand_bias[l] = p(f"{pre}/candidate/kernel"), p(f"{pre}/candidate/bias")
+        w.head_weights, w.head_biases = p(f"{self.name}/fully_connected/weights"), p(f"{self.name}/fully_connected/biases")
+        return w
 
     def _upload(self, params):
         keep = []

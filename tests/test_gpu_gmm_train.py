@@ -210,7 +210,6 @@ def test_adam_trajectory_against_fp64_and_evaluation_after_sync():
 
 def test_what_is_not_built_says_so():
     from hiertcn_amd._lib import HierTCNError
-    from hiertcn_amd.model_gru_gmm import GruGmmModel
     from hiertcn_amd.model_tcn_gmm import TcnGmmModel
     a = _args(300, 2, (64,), 3)
     m = TcnGmmModel(a, _params(a, 1))
@@ -226,11 +225,20 @@ def test_what_is_not_built_says_so():
     with pytest.raises(HierTCNError, match="fixed scale"):
         ml.enable_training()
     ml.close()
-    ag = make_args([], model_type="gru_gmm", item_num=300, output_dim=300, num_mixture=2, sigma=0.1, loss="gmm_prob", hidden_dim=64, num_layer=1, adjust=False)
-    mg = GruGmmModel(ag, None)
-    with pytest.raises(NotImplementedError):
-        mg.enable_training()
-    mg.close()
+    # the mixture low levels of model_hier (dense input rows: trunks 2 / 3) evaluate only: the library refuses
+    import ctypes as C
+
+    from hiertcn_amd import _lib
+    lib = _lib.load()
+    cfg = _lib.GmmConfig(item_num=300, output_dim=300, num_mixture=2, kernel_size=3, n_blocks=1, sigma=0.1, trunk=2, input_dim=64)
+    cfg.channels[0] = 64
+    h = C.c_void_p()
+    assert lib.hiertcn_gmm_create(C.byref(h), C.byref(cfg)) == 0
+    w = _lib.GmmWeights()
+    one = torch.zeros(8, device="cuda")
+    w.head_weights = w.head_biases = one.data_ptr()
+    assert lib.hiertcn_gmm_train_enable(h, C.byref(w), None) != 0 and b"evaluates only" in lib.hiertcn_gmm_last_error()
+    lib.hiertcn_gmm_destroy(h)
 
 
 def test_run_gmm_trains_on_the_synthetic_xing_file_and_the_checkpoint_resumes(tmp_path):
@@ -340,3 +348,92 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
         # (the scale of the gradients is what the line above checks -- Adam's first step does not see it): 1e-3 of the step
         assert np.abs(dp["w:" + k] - w[k]).max() <= 1e-3 * 1e-2, k
     m.close()
+
+
+# ---- model_gru_gmm: the GRU stack on one-hot rows (model_gru_gmm.py:33-48) under the same head -----------------------------------------------------
+def _gru_args(N, M, H, nl, loss="gmm_prob"):
+    return make_args([], model_type="gru_gmm", item_num=N, output_dim=N, num_mixture=M, sigma=0.1, loss=loss, hidden_dim=H, num_layer=nl, adjust=False)
+
+
+def torch_gru_loss(a, P, x, y, mode, scope="rnn_gmm"):
+    """fp64: the cells of customed_gru_cell.py:323-337 on MATERIALISED one-hot rows under dynamic_rnn's sequence_length (the count of non-zero
+    rows, a prefix length: past it the state is carried and the output row is zero), then the same head / decode / losses as torch_loss."""
+    xt, yt = torch.as_tensor(x.astype(np.int64)), torch.as_tensor(y.astype(np.int64))
+    B, T = xt.shape
+    N, H, nl, M, D = int(a.item_num), int(a.hidden_dim), int(a.num_layer), int(a.num_mixture), int(a.output_dim)
+    sigma = float(a.sigma)
+    onehot = torch.nn.functional.one_hot(xt, N).to(torch.float64) * (xt > 0)[..., None]
+    length = (xt > 0).sum(1)
+    state = [torch.zeros(B, H, dtype=torch.float64) for _ in range(nl)]
+    outs = []
+    for t in range(T):
+        active = (t < length)[:, None]
+        inp = onehot[:, t]
+        for l in range(nl):
+            pre = f"{scope}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+            gates = torch.sigmoid(torch.cat([inp, state[l]], 1) @ P[f"{pre}/gates/kernel"] + P[f"{pre}/gates/bias"])
+            r, u = gates[:, :H], gates[:, H:]
+            c = torch.tanh(torch.cat([inp, r * state[l]], 1) @ P[f"{pre}/candidate/kernel"] + P[f"{pre}/candidate/bias"])
+            new = u * state[l] + (1 - u) * c
+            state[l] = torch.where(active, new, state[l])
+            inp = new
+        outs.append(torch.where(active, inp, torch.zeros_like(inp)))
+    act = torch.stack(outs, 1)
+    pred = act @ P[f"{scope}/fully_connected/weights"] + P[f"{scope}/fully_connected/biases"]
+    log_pi = torch.log_softmax(pred[..., :M], -1)
+    mu = pred[..., M:M + M * D].reshape(B, T, M, D)
+    yoh = torch.nn.functional.one_hot(yt, D).to(torch.float64) * (yt > 0)[..., None]
+    d2 = ((yoh[:, :, None, :] - mu) ** 2).sum(-1)
+    mvn = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+    rows = -torch.logsumexp(log_pi + mvn, -1) / D if mode == "gmm_prob" else -(log_pi + mvn / D).max(-1).values
+    mask = (yt > 0).to(torch.float64)
+    cnt = mask.sum(1)
+    loss = ((rows * mask).sum(1) / (cnt + 1e-6)).sum() / (cnt > 0).sum()
+    return loss, rows * mask
+
+
+@pytest.mark.parametrize("mode", ["gmm_prob", "gmm_prob_max"])
+@pytest.mark.parametrize("N,M,H,nl,B,T", [(303, 3, 64, 1, 5, 9), (500, 2, 64, 2, 6, 12), (900, 4, 128, 2, 4, 15), (20_778, 5, 256, 2, 3, 7)])
+def test_gru_trunk_every_gradient_against_fp64_autograd(N, M, H, nl, B, T, mode):
+    from hiertcn_amd.model_gru_gmm import GruGmmModel
+    a = _gru_args(N, M, H, nl, loss=mode)
+    p = G.init_params_gru(a, seed=N % 89)
+    rng = np.random.default_rng(N + H)
+    for k in p:
+        if k.endswith("biases") or k.endswith("candidate/bias"):
+            p[k] = (0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    x, y = _batch(rng, N, B, T)
+    x[1, 3:] = 0                                     # a short sequence: steps past its length carry the state, emit zero rows, take no gradient
+    x[2, 2] = 0                                      # a null id INSIDE a sequence: sequence_length is a count, used as a prefix length [TF-sem]
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in p.items()}
+    loss_ref, rows_ref = torch_gru_loss(a, P, x, y, mode)
+    loss_ref.backward()
+    pred = G.model_gru_gmm(a, x, {k: np.asarray(v, np.float64) for k, v in p.items()})
+    want_rows = G.calc_loss_gmm_ids(pred, y, a) * (y > 0)
+    assert np.abs(rows_ref.detach().numpy() - want_rows).max() < 1e-9 * max(1.0, np.abs(want_rows).max())
+    model = GruGmmModel(a, p)
+    model.enable_training()
+    out = model.train_forward_backward(dev(x), dev(y), mode, want_rows=True)
+    rows = out["loss_rows"].cpu().numpy()
+    sums = out["sums"].cpu().numpy()
+    live = y > 0
+    assert np.abs(rows - want_rows)[live].max() < 3e-6 * max(1.0, np.abs(want_rows).max()), np.abs(rows - want_rows)[live].max()
+    assert abs(sums[0] / sums[1] - float(loss_ref.detach())) < 3e-6 * max(1.0, abs(float(loss_ref.detach())))
+    grads = model.export("grads")
+    for k, t in P.items():
+        ref = t.grad.numpy()
+        got = grads[k].astype(np.float64)
+        assert got.shape == ref.shape and np.linalg.norm(ref) > 0, k
+        err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert err < 3e-5, (k, err)
+    untouched = np.setdiff1d(np.arange(N), np.unique(x))
+    assert not grads["rnn_gmm/rnn/multi_rnn_cell/cell_0/gru_cell/gates/kernel"][untouched].any()
+    assert not grads["rnn_gmm/rnn/multi_rnn_cell/cell_0/gru_cell/candidate/kernel"][untouched].any()
+    # one optimizer step, then the evaluation path of the same handle == a fresh handle on the exported weights
+    model.adam_step(1e-3)
+    w = model.export("weights")
+    got_eval = model.eval_step(x, y)["sums"].cpu().numpy()
+    fresh = GruGmmModel(a, w)
+    assert np.array_equal(got_eval, fresh.eval_step(x, y)["sums"].cpu().numpy())
+    model.close()
+    fresh.close()
