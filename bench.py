@@ -260,6 +260,19 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
         gm.train_step(tx, ty, 1e-3)
     torch.cuda.synchronize()
     train_ms_gru = (time.perf_counter() - t0) / 5 * 1e3
+    train_ms_gru_graph = None
+    try:   # the same step with its forward + backward replayed as ONE hipGraph (the launch chain's host cost removed)
+        gr = gm.capture_train_graph(tB, tT)
+        for _ in range(2):
+            gr.step(tx, ty, 1e-3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            gr.step(tx, ty, 1e-3)
+        torch.cuda.synchronize()
+        train_ms_gru_graph = round((time.perf_counter() - t0) / 5 * 1e3, 3)
+    except Exception as e:  # noqa: BLE001  (a secondary figure)
+        train_ms_gru_graph = repr(e)[:200]
     gm.close()
     diff = float((losses["gram"] - losses["table_pass"]).abs().max())
     flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
@@ -269,7 +282,7 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
                                  "(2-layer GRU stack on the one-hot rows, backward through the 200 steps as a launch chain); a learned scale / the "
                                  "mixture low levels of model_hier evaluate only",
                          "rows": tB * tT, "ms_per_step": round(train_ms, 3), "rows_per_s": round(tB * tT / train_ms * 1e3),
-                         "ms_per_step_gru_gmm": round(train_ms_gru, 3),
+                         "ms_per_step_gru_gmm": round(train_ms_gru, 3), "ms_per_step_gru_gmm_hipgraph": train_ms_gru_graph,
                          "loss_first_last": [round(float(tl[0, 0] / tl[0, 1]), 5), round(float(tl[-1, 0] / tl[-1, 1]), 5)]},
             "what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
                     "bf16 parts, + one row-wise kernel for prior / linear terms / target mean + finish); ms_table_pass: M passes of "

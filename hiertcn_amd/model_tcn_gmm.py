@@ -181,7 +181,7 @@ class TcnGmmModel:
         self._stale = False
 
     def train_forward_backward(self, x_ids: torch.Tensor, y_ids: torch.Tensor, mode: Optional[str] = None, users_global: Optional[torch.Tensor] = None,
-                               want_rows: bool = False) -> dict:
+                               want_rows: bool = False, sums_out: Optional[torch.Tensor] = None) -> dict:
         """ids [B, T] int32 on the device -> the gradients of every variable of the batch's lane-mean mixture loss (model.py:111-117 on args.loss)
         in the handle's gradient arena; returns dict(sums = device doubles [sum of lane means, users][, loss_rows [B, T]])."""
         if not getattr(self, "_training", False):
@@ -198,7 +198,7 @@ class TcnGmmModel:
         need = int(self.lib.hiertcn_gmm_train_workspace_bytes(self._h, B, T))
         if self._train_ws is None or self._train_ws.numel() < need:
             self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
-        out2 = torch.empty(2, dtype=torch.float64, device=self.device)
+        out2 = sums_out if sums_out is not None else torch.empty(2, dtype=torch.float64, device=self.device)
         rows = torch.empty((B, T), dtype=torch.float32, device=self.device) if want_rows else None
         p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
         _ck(self.lib.hiertcn_gmm_train_step(self._h, p(x_ids), p(y_ids), B, T, self.MODES[mode], p(users_global), p(self._train_ws),
@@ -236,6 +236,12 @@ class TcnGmmModel:
             hd.all_reduce_metrics(out["sums"])
         self.adam_step(lr)
         return out
+
+    def capture_train_graph(self, B: int, T: int, mode: Optional[str] = None) -> "GmmTrainGraph":
+        """The forward + backward of one batch shape as a replayable hipGraph (torch.cuda.CUDAGraph on ROCm): model_gru_gmm's step is a chain of
+        ~2,800 small launches at T = 200 (seven per cell), whose host cost the replay removes.  Adam stays outside (its bias-corrected rate is a
+        host scalar that changes every step): GmmTrainGraph.step = copy ids -> replay -> adam_step."""
+        return GmmTrainGraph(self, B, T, mode)
 
     def arena(self, which: int) -> torch.Tensor:
         """The flat fp32 arena `which` (0 masters, 1 gradients, 2 / 3 Adam moments) as a torch view (no copy)."""
@@ -279,6 +285,35 @@ class TcnGmmModel:
         _ck(self.lib.hiertcn_gmm_head_means(self._h, C.c_void_p(hidden.data_ptr()), R, int(m), C.c_void_p(out.data_ptr()),
                                             C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
         return out
+
+
+class GmmTrainGraph:
+    """Static-shape training step (forward + backward into the gradient arena) as a replayable graph.  Buffers: x, y int32 [B, T]; sums fp64 [2]."""
+
+    def __init__(self, model: "TcnGmmModel", B: int, T: int, mode: Optional[str] = None):
+        model.enable_training()
+        self.model, self.mode = model, mode or getattr(model.args, "loss", "gmm_prob")
+        dev = model.device
+        self.x = torch.zeros((B, T), dtype=torch.int32, device=dev)
+        self.y = torch.zeros((B, T), dtype=torch.int32, device=dev)
+        self.sums = torch.zeros(2, dtype=torch.float64, device=dev)
+        side = torch.cuda.Stream(device=dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):   # warm-up outside the capture (the workspace is allocated here)
+            for _ in range(2):
+                model.train_forward_backward(self.x, self.y, self.mode, sums_out=self.sums)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            model.train_forward_backward(self.x, self.y, self.mode, sums_out=self.sums)
+
+    def step(self, x_ids: torch.Tensor, y_ids: torch.Tensor, lr: float) -> dict:
+        self.x.copy_(x_ids, non_blocking=True)
+        self.y.copy_(y_ids, non_blocking=True)
+        self.graph.replay()
+        self.model.adam_step(lr)
+        return dict(sums=self.sums)
 
 
 class GmmHead:

@@ -437,3 +437,28 @@ def test_gru_trunk_every_gradient_against_fp64_autograd(N, M, H, nl, B, T, mode)
     assert np.array_equal(got_eval, fresh.eval_step(x, y)["sums"].cpu().numpy())
     model.close()
     fresh.close()
+
+
+def test_training_step_replayed_as_a_hipgraph_equals_the_launch_chain():
+    """GmmTrainGraph: forward + backward of one batch shape captured once and replayed -- same gradients, same Adam trajectory as the plain calls."""
+    from hiertcn_amd.model_gru_gmm import GruGmmModel
+    N, M, H, nl, B, T = 600, 3, 64, 2, 5, 14
+    a = _gru_args(N, M, H, nl)
+    p = G.init_params_gru(a, seed=4)
+    rng = np.random.default_rng(8)
+    batches = [_batch(rng, N, B, T) for _ in range(3)]
+    plain, graph = GruGmmModel(a, p), GruGmmModel(a, p)
+    plain.enable_training()
+    gr = graph.capture_train_graph(B, T)
+    for x, y in batches:
+        s1 = plain.train_step(x, y, 1e-3)["sums"].cpu().numpy()
+        s2 = gr.step(dev(x), dev(y), 1e-3)["sums"].cpu().numpy()
+        assert np.array_equal(s1, s2)
+    g1, g2 = plain.export("grads"), graph.export("grads")
+    w1, w2 = plain.export("weights"), graph.export("weights")
+    for k in g1:
+        assert np.abs(g1[k] - g2[k]).max() <= 1e-5 * max(np.abs(g1[k]).max(), 1e-30), k     # (fp32 atomics reorder sums)
+        assert np.abs(w1[k] - w2[k]).max() <= 1e-3 * 1e-3, k
+    assert graph.adam_time() == 3
+    plain.close()
+    graph.close()
