@@ -236,12 +236,18 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     tm = TcnGmmModel(ga, init_params(ga, 3))
     tm.enable_training()
     tl = []
+
+    def step_local(model):   # forward + backward + Adam on THIS rank alone (this leg runs on rank 0 only: no collective may be entered here)
+        out = model.train_forward_backward(tx, ty)
+        model.adam_step(1e-3)
+        return out["sums"]
+
     for _ in range(3):
-        tl.append(tm.train_step(tx, ty, 1e-3)["sums"])
+        tl.append(step_local(tm))
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(10):
-        tl.append(tm.train_step(tx, ty, 1e-3)["sums"])
+        tl.append(step_local(tm))
     torch.cuda.synchronize()
     train_ms = (time.perf_counter() - t0) / 10 * 1e3
     tl = torch.stack(tl).cpu().numpy()
@@ -253,11 +259,11 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     gm = GruGmmModel(gg, gru_init(gg, 3))
     gm.enable_training()
     for _ in range(2):
-        gm.train_step(tx, ty, 1e-3)
+        step_local(gm)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(5):
-        gm.train_step(tx, ty, 1e-3)
+        step_local(gm)
     torch.cuda.synchronize()
     train_ms_gru = (time.perf_counter() - t0) / 5 * 1e3
     train_ms_gru_graph = None
