@@ -462,3 +462,42 @@ def test_training_step_replayed_as_a_hipgraph_equals_the_launch_chain():
     assert graph.adam_time() == 3
     plain.close()
     graph.close()
+
+
+@pytest.mark.parametrize("seed", range(8))
+def test_fuzzed_shapes_against_fp64_autograd(seed):
+    """Random model / batch shapes for both trunks (widths 64 .. 256 per block, 1 .. 4 blocks or 1 .. 3 GRU layers, kernel sizes 1 .. 6, catalogues that
+    are no multiple of anything, sequences shorter than the receptive field, lanes without targets): loss rows and every gradient vs fp64 autograd."""
+    rng = np.random.default_rng(1000 + seed)
+    N = int(rng.integers(130, 2600))
+    M = int(rng.integers(1, 7))
+    B, T = int(rng.integers(1, 9)), int(rng.integers(2, 40))
+    mode = ["gmm_prob", "gmm_prob_max"][seed % 2]
+    x, y = _batch(rng, N, max(B, 2), T)
+    if seed % 2 == 0:
+        from hiertcn_amd.model_tcn_gmm import TcnGmmModel as Model
+        channels = tuple(int(c) for c in rng.choice([64, 128, 256], int(rng.integers(1, 5))))
+        a = _args(N, M, channels, int(rng.integers(1, 7)), loss=mode)
+        p = _params(a, seed)
+        ref_loss = torch_loss
+    else:
+        from hiertcn_amd.model_gru_gmm import GruGmmModel as Model
+        a = _gru_args(N, M, int(rng.choice([64, 128, 256])), int(rng.integers(1, 4)), loss=mode)
+        p = G.init_params_gru(a, seed=seed)
+        ref_loss = torch_gru_loss
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in p.items()}
+    loss_ref, rows_ref = ref_loss(a, P, x, y, mode)
+    loss_ref.backward()
+    model = Model(a, p)
+    model.enable_training()
+    out = model.train_forward_backward(dev(x), dev(y), mode, want_rows=True)
+    rows = out["loss_rows"].cpu().numpy()
+    want = rows_ref.detach().numpy()
+    assert np.abs(rows - want).max() < 5e-6 * max(1.0, np.abs(want).max()), (a.tcn_channel if seed % 2 == 0 else (a.hidden_dim, a.num_layer), np.abs(rows - want).max())
+    grads = model.export("grads")
+    for k, t in P.items():
+        ref = t.grad.numpy()
+        nr = np.linalg.norm(ref)
+        err = np.linalg.norm(grads[k].astype(np.float64) - ref) / max(nr, 1e-30)
+        assert err < 5e-5 or nr < 1e-12, (k, err, nr)
+    model.close()
