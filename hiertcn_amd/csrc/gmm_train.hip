@@ -21,8 +21,12 @@
 // pointwise launches per cell), the weight gradients of all T x nl cells follow as one product per layer and operand, and layer 0's input half -- a
 // gathered table row in the forward -- takes its gradient as a row scatter-add.
 //
-// Built for: trunks 0 and 1 (the models on ids), a fixed scale (args.sigma set), loss modes gmm_prob and gmm_prob_max.  The dense-row trunks of
-// model_hier's mixture low levels and a learned scale evaluate only (hiertcn_gmm_train_enable refuses them).
+// A LEARNED scale (args.sigma None: M (1 + 2 D) outputs, sigma_d = exp(s_d)) has no such identity -- sum_d mu_d^2 exp(-2 s_d) is no quadratic form of the
+// hidden row -- so that variant materialises mu and s per mixture ([2 M][rows][D] fp32, 5.3 GB at the reference's batch), forms their gradients in place
+// and takes three exact-fp32 products per table (k_gtl_rows / k_gtl_grad below).
+//
+// Built for: trunks 0 and 1 (the models on ids), both scale variants, loss modes gmm_prob and gmm_prob_max.  The dense-row trunks (the mixture low levels of
+// model_hier) evaluate only (hiertcn_gmm_train_enable refuses them).
 #include <math.h>
 #include <string.h>
 
@@ -390,18 +394,134 @@ __global__ __launch_bounds__(256) void k_gt_rowsum(const float* __restrict__ gv,
   if (threadIdx.x == 0) gs[blockIdx.x] = red[0];
 }
 // head gradients from the compute layouts into the reference layout: dW[c][m] = dpw[m][c], db[m] = dpb[m], db[M + m D + d] = dbt[m][d]
-__global__ void k_gt_head_small(const float* __restrict__ dpw, const float* __restrict__ dpb, const float* __restrict__ dbt, int M, int D, int DP, int C,
-                                int64_t n_out, float* __restrict__ dW, float* __restrict__ db) {
+__global__ void k_gt_head_small(const float* __restrict__ dpw, const float* __restrict__ dpb, const float* __restrict__ dbt, int M, int Tn, int D, int DP, int C,
+                                int64_t n_out, float* __restrict__ dW, float* __restrict__ db) {   // Tn tables: M mean blocks (+ M log-scale blocks)
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < (int64_t)M * C) {
     const int m = (int)(i / C), c = (int)(i - (int64_t)m * C);
     dW[(int64_t)c * n_out + m] = dpw[(size_t)m * C + c];
   }
   if (i < M) db[i] = dpb[i];
-  if (i < (int64_t)M * D) {
+  if (i < (int64_t)Tn * D) {
     const int m = (int)(i / D), d = (int)(i - (int64_t)m * D);
     db[M + i] = dbt[(size_t)m * DP + d];
   }
+}
+
+// ---- a learned scale (args.sigma None: head outputs M (1 + 2 D), sigma_d = exp(s_d); the decode of oracle/gmm_oracle.py) ---------------------------------
+//   log N_m(y) = -1/2 [ Q_m + (1 - 2 mu_m[y]) exp(-2 s_m[y]) ] - sum_d s_d - D/2 log 2 pi,   Q_m = sum_d mu_d^2 exp(-2 s_d)
+// Q_m is no quadratic form of the hidden row, so this path MATERIALISES mu and s (MUS: [2 M][R][DP] fp32: 5.3 GB at the reference's 6,400 rows) with
+// exact-fp32 products, turns them into their gradients in place and pushes those through three more products per table.
+struct LearnedRows {
+  const float* H; const float* MUS; const float* pw; const float* pb; const int32_t* y; const float* act; const float* users;
+  int64_t R;
+  int T, C, M, D, DP, mode;
+  double cst_over_D;     // (-D/2 log 2 pi) / D
+  float* loss; float* gl; float* dA; float* dH;
+};
+// pass 1, one wave per row: Q_m and sum_d s_d over the D outputs, the target's mean and log-scale, the loss, gl_m = d L / d log N_m, d prior logits, and
+// dH initialised with the prior's share  sum_j da_j pi_w[j]
+template <int CPL>
+__global__ __launch_bounds__(256) void k_gtl_rows(const LearnedRows a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= a.R) return;
+  const int C = a.C, M = a.M, D = a.D;
+  const int yy = a.y[r];
+  const bool valid = yy > 0 && yy < D;
+  float h[CPL];
+#pragma unroll
+  for (int k = 0; k < CPL; k++) h[k] = a.H[r * C + lane + 64 * k];
+  float pl[16], lp[16];
+  for (int m = 0; m < M; m++) {
+    const float* mu = a.MUS + ((size_t)m * a.R + r) * a.DP;
+    const float* sc = a.MUS + ((size_t)(M + m) * a.R + r) * a.DP;
+    float q = 0.f, ss = 0.f, s0 = 0.f;
+    for (int d = lane; d < D; d += 64) {
+      const float u = mu[d], sv = sc[d];
+      q = fmaf(u * u, expf(-2.f * sv), q);
+      ss += sv;
+    }
+#pragma unroll
+    for (int k = 0; k < CPL; k++) s0 = fmaf(h[k], a.pw[(size_t)m * C + lane + 64 * k], s0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { q += __shfl_xor(q, off); ss += __shfl_xor(ss, off); s0 += __shfl_xor(s0, off); }
+    pl[m] = s0 + a.pb[m];
+    const float tg = valid ? mu[yy] : 0.f, sy = valid ? sc[yy] : 0.f;
+    lp[m] = -0.5f * (q + (valid ? (1.f - 2.f * tg) * expf(-2.f * sy) : 0.f)) - ss;      // log N_m(y) - cst
+  }
+  float mx = -INFINITY;
+  for (int m = 0; m < M; m++) mx = fmaxf(mx, pl[m]);
+  float se = 0.f;
+  for (int m = 0; m < M; m++) se += expf(pl[m] - mx);
+  const float lse_pi = mx + logf(se);
+  const float u = a.users[0];
+  const float w = (valid && u > 0.f) ? 1.0f / ((a.act[r / a.T] + 1e-6f) * u) : 0.f;
+  const float invD = 1.0f / (float)D;
+  float gpi[16], gl[16];
+  float loss = 0.f;
+  if (a.mode == 0) {
+    float z[16], zmax = -INFINITY;
+    for (int m = 0; m < M; m++) { z[m] = (pl[m] - lse_pi) + lp[m]; zmax = fmaxf(zmax, z[m]); }
+    float s = 0.f;
+    for (int m = 0; m < M; m++) { z[m] = expf(z[m] - zmax); s += z[m]; }
+    loss = (float)(-((double)(zmax + logf(s)) * (double)invD + a.cst_over_D));
+    for (int m = 0; m < M; m++) { const float rho = z[m] / s; gpi[m] = -w * rho * invD; gl[m] = -w * rho * invD; }
+  } else {
+    float best = -INFINITY;
+    int mb = 0;
+    for (int m = 0; m < M; m++) {
+      const float v = (pl[m] - lse_pi) + lp[m] * invD;
+      if (v > best) { best = v; mb = m; }
+    }
+    loss = (float)(-((double)best + a.cst_over_D));
+    for (int m = 0; m < M; m++) { gpi[m] = (m == mb) ? -w : 0.f; gl[m] = (m == mb) ? -w * invD : 0.f; }
+  }
+  if (!valid) loss = 0.f;
+  float gsum = 0.f;
+  for (int m = 0; m < M; m++) gsum += gpi[m];
+  float da[16];
+  for (int m = 0; m < M; m++) da[m] = gpi[m] - expf(pl[m] - lse_pi) * gsum;
+#pragma unroll
+  for (int k = 0; k < CPL; k++) {
+    const int c = lane + 64 * k;
+    float acc = 0.f;
+    for (int m = 0; m < M; m++) acc = fmaf(da[m], a.pw[(size_t)m * C + c], acc);
+    a.dH[r * C + c] = acc;
+  }
+  if (lane == 0) {
+    a.loss[r] = loss;
+    for (int m = 0; m < M; m++) a.gl[(size_t)m * a.R + r] = gl[m];
+  }
+  if (lane < GT_MP) a.dA[r * GT_MP + lane] = lane < M ? da[lane] : 0.f;
+}
+// pass 2, in place: mu <- d L / d mu = gl (y_d - mu_d) e^{-2 s_d};  s <- d L / d s = gl ((y_d - mu_d)^2 e^{-2 s_d} - 1);  0 in the pad columns d >= D
+__global__ __launch_bounds__(256) void k_gtl_grad(float* __restrict__ MUS, const float* __restrict__ gl, const int32_t* __restrict__ y, int64_t R, int M, int D,
+                                                  int DP) {
+  const int d4 = DP >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (int64_t)M * R * d4) return;
+  const int64_t mr = i / d4;
+  const int d0 = (int)(i - mr * d4) * 4;
+  const int m = (int)(mr / R);
+  const int64_t r = mr - (int64_t)m * R;
+  const float g = gl[mr];
+  const int yy = y[r];
+  float* pm = MUS + (size_t)mr * DP + d0;
+  float* ps = MUS + ((size_t)(M + m) * R + r) * DP + d0;
+  float4 u = *reinterpret_cast<float4*>(pm), sv = *reinterpret_cast<float4*>(ps);
+  float uo[4] = {u.x, u.y, u.z, u.w}, so[4] = {sv.x, sv.y, sv.z, sv.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int d = d0 + j;
+    if (d >= D || g == 0.f) { uo[j] = 0.f; so[j] = 0.f; continue; }
+    const float e = expf(-2.f * so[j]);
+    const float diff = ((d == yy) ? 1.f : 0.f) - uo[j];
+    uo[j] = g * diff * e;
+    so[j] = g * (diff * diff * e - 1.f);
+  }
+  *reinterpret_cast<float4*>(pm) = make_float4(uo[0], uo[1], uo[2], uo[3]);
+  *reinterpret_cast<float4*>(ps) = make_float4(so[0], so[1], so[2], so[3]);
 }
 
 // ---- the handle's training state -------------------------------------------------------------------------------------------------------------------
@@ -419,7 +539,7 @@ static void gt_layout(const hiertcn_gmm_ctx* g, GmmTrain* t) {
     seg(t->conv_b[i], cout);
     if (cin != cout) { seg(t->res[i], (size_t)cin * cout); seg(t->res_b[i], cout); }
   }
-  const size_t n_out = (size_t)g->M * (1 + (size_t)g->D);
+  const size_t n_out = (size_t)g->M * (1 + (g->learned ? 2 : 1) * (size_t)g->D);   // a learned scale: M (1 + 2 D) outputs (model_tcn_gmm.py:39-40)
   seg(t->head_w, (size_t)g->Clast * n_out);
   seg(t->head_b, n_out);
   t->total = off;
@@ -435,6 +555,7 @@ struct GtWs {
   size_t act[HIERTCN_MAX_BLOCKS], cact[HIERTCN_MAX_BLOCKS], resb, X, GH, dA, gv, loss, dH, bufA, bufB, ds, dc, sh, lane_act, users, total;
   // trunk 1 (GRU stack on one-hot rows): the forward's records and the backward-through-time's buffers
   size_t hid, seq_len, states, recs, dac_all, dag_all, dcar[2], dhpart, dcat_c, dcat_g, din_up;
+  size_t MUS;   // a learned scale: the materialised means and log-scales, [2 M][R][DP] fp32 (then, in place, their gradients)
 };
 static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
   GtWs w;
@@ -444,8 +565,12 @@ static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
   auto take = [&](size_t floats) { const size_t o = off; off += ((floats * 4) + 255) & ~(size_t)255; return o; };
   const size_t C = (size_t)g->Clast;
   const size_t cm = g->trunk == 1 ? C : (size_t)cmax_of(g);
-  w.X = take((size_t)g->M * R * C);
-  w.GH = take((size_t)g->M * R * C);
+  if (g->learned) {
+    w.MUS = take((size_t)2 * g->M * R * g->DP);
+  } else {
+    w.X = take((size_t)g->M * R * C);
+    w.GH = take((size_t)g->M * R * C);
+  }
   w.dA = take(R * GT_MP);
   w.gv = take((size_t)g->M * R);
   w.loss = take(R);
@@ -516,10 +641,11 @@ static int gt_refresh(hiertcn_gmm_ctx* g, hipStream_t st) {
     G_HIP(gt_transpose(P + t->gk[l].off + skip * 2 * H, 2 * H, t->wg[l], Kc, Kc, 2 * H, st));
     G_HIP(gt_transpose(P + t->ck[l].off + skip * H, H, t->wc[l], Kc, Kc, H, st));
   }
-  const int64_t n_out = (int64_t)M * (1 + (int64_t)D);
+  const int Tn = g->learned ? 2 * M : M;   // item-major tables: the M mean blocks, then (learned scale) the M log-scale blocks
+  const int64_t n_out = (int64_t)M + (int64_t)Tn * D;
   const float* W = P + t->head_w.off;
   const float* b = P + t->head_b.off;
-  for (int m = 0; m < M; m++) {
+  for (int m = 0; m < Tn; m++) {
     G_HIP(gt_transpose(W + M + (int64_t)m * D, n_out, t->Wt + (size_t)m * DP * C, C, C, D, st));   // Wt[m][d][c] = W[c][M + m D + d]
     G_HIP(hipMemcpyAsync(t->bt + (size_t)m * DP, b + M + (size_t)m * D, (size_t)D * 4, hipMemcpyDeviceToDevice, st));
   }
@@ -536,7 +662,6 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   if (g->trunk != 0 && g->trunk != 1)
     return gfail(HIERTCN_ERR_INVALID, "the training step is built for the models on ids (trunk 0: model_tcn_gmm, trunk 1: model_gru_gmm); trunk %d -- a mixture low level "
                  "of model_hier -- evaluates only", g->trunk);
-  if (g->learned) return gfail(HIERTCN_ERR_INVALID, "the training step is built for a fixed scale (args.sigma set); a learned scale evaluates only");
   if (g->M > GT_MP) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: the training step takes up to 16 mixtures", g->M);
   if (g->Clast != 64 && g->Clast != 128 && g->Clast != 256 && g->Clast != 512) return gfail(HIERTCN_ERR_INVALID, "last width %d: 64, 128, 256, 512", g->Clast);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -568,8 +693,9 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
     const size_t H = (size_t)g->H, Kc = (l == 0) ? H : 2 * H;
     o_wg[l] = take(2 * H * Kc); o_dwg[l] = take(2 * H * Kc); o_wc[l] = take(H * Kc); o_dwc[l] = take(H * Kc);
   }
-  const size_t o_Wt = take(M * DP * C), o_bt = take(M * DP), o_pw = take(GT_MP * C), o_pb = take(GT_MP);
-  const size_t o_dWt = take(M * DP * C), o_dbt = take(M * DP), o_dpw = take(GT_MP * C), o_dpb = take(GT_MP);
+  const size_t Tn = g->learned ? 2 * M : M;
+  const size_t o_Wt = take(Tn * DP * C), o_bt = take(Tn * DP), o_pw = take(GT_MP * C), o_pb = take(GT_MP);
+  const size_t o_dWt = take(Tn * DP * C), o_dbt = take(Tn * DP), o_dpw = take(GT_MP * C), o_dpb = take(GT_MP);
   const size_t o_Gm = take(M * C * C), o_vm = take(M * C), o_cm = take(64), o_Sm = take(M * C * C), o_sm = take(M * C), o_gs = take(64);
   size_t sk = 128 * C * C;
   if (sk > ((size_t)16 << 20)) sk = (size_t)16 << 20;
@@ -671,6 +797,38 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
   }
   H = F32(w.act[nb - 1]);
   }
+  G_HIP(train_lane_act(y_ids, (int)B, T, F32(w.lane_act), F32(w.users), st));
+  float* loss = loss_rows ? loss_rows : F32(w.loss);
+  const int Tn = g->learned ? 2 * M : M;
+  if (g->learned) {
+    // ================= head with a learned scale: mu and s materialised, the loss row-wise, their gradients in place, three products per table ====
+    float* MUS = F32(w.MUS);
+    for (int tb = 0; tb < Tn; tb++) {
+      XGemm x = {};
+      x.A = H; x.lda = C; x.Wt = t->Wt + (size_t)tb * DP * C; x.taps = 1; x.Cin = C; x.M = R; x.N = DP; x.bias = t->bt + (size_t)tb * DP;
+      x.out = MUS + (size_t)tb * R * DP; x.ldo = DP; x.epi = XEPI_LINEAR;
+      G_HIP(launch_xgemm(x, st));
+    }
+    LearnedRows a;
+    a.H = H; a.MUS = MUS; a.pw = t->pw; a.pb = t->pb; a.y = y_ids; a.act = F32(w.lane_act); a.users = users_global ? users_global : F32(w.users);
+    a.R = R; a.T = T; a.C = C; a.M = M; a.D = D; a.DP = DP; a.mode = mode;
+    a.cst_over_D = (-0.5 * (double)D * log(2.0 * M_PI)) / (double)D;
+    a.loss = loss; a.gl = F32(w.gv); a.dA = F32(w.dA); a.dH = F32(w.dH);
+    const dim3 grid((unsigned)((R + 3) / 4));
+    if (C == 64) hipLaunchKernelGGL(k_gtl_rows<1>, grid, dim3(256), 0, st, a);
+    else if (C == 128) hipLaunchKernelGGL(k_gtl_rows<2>, grid, dim3(256), 0, st, a);
+    else if (C == 256) hipLaunchKernelGGL(k_gtl_rows<4>, grid, dim3(256), 0, st, a);
+    else hipLaunchKernelGGL(k_gtl_rows<8>, grid, dim3(256), 0, st, a);
+    hipLaunchKernelGGL(k_gtl_grad, dim3((unsigned)(((int64_t)M * R * (DP >> 2) + 255) / 256)), dim3(256), 0, st, MUS, F32(w.gv), y_ids, R, M, D, DP);
+    G_HIP(hipGetLastError());
+    G_HIP(hipMemsetAsync(t->dbt, 0, (size_t)Tn * DP * 4, st));
+    for (int tb = 0; tb < Tn; tb++) {
+      const float* dT = MUS + (size_t)tb * R * DP;            // d mu_m (tb < M) or d s_m: [R][DP]
+      G_HIP(gemm32_tn(dT, DP, H, C, t->dWt + (size_t)tb * DP * C, C, DP, C, (int)R, 0.f, t->splitk, t->splitk_floats, st));             // d table^T [DP][C] = dT^T . H
+      G_HIP(train_colsum_f32(dT, R, DP, DP, t->dbt + (size_t)tb * DP, st));
+      G_HIP(gemm32_nn(dT, DP, t->Wt + (size_t)tb * DP * C, C, F32(w.dH), C, (int)R, C, DP, 1.f, st, t->splitk, t->splitk_floats));      // d h += dT . table^T
+    }
+  } else {
   // ================= head: G_m, v_m, |b_m|^2 from the masters; X_m = H G_m; the row-wise kernel ==============================================
   for (int m = 0; m < M; m++)
     G_HIP(gemm32_tn(t->Wt + (size_t)m * DP * C, C, t->Wt + (size_t)m * DP * C, C, t->Gm + (size_t)m * C * C, C, C, C, DP, 0.f, t->splitk, t->splitk_floats, st));
@@ -683,8 +841,6 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
   }
   for (int m = 0; m < M; m++)
     G_HIP(gemm32_nn(H, C, t->Gm + (size_t)m * C * C, C, F32(w.X) + (size_t)m * R * C, C, (int)R, C, C, 0.f, st));
-  G_HIP(train_lane_act(y_ids, (int)B, T, F32(w.lane_act), F32(w.users), st));
-  float* loss = loss_rows ? loss_rows : F32(w.loss);
   {
     HeadRows a;
     a.H = H; a.X = F32(w.X); a.Wt = t->Wt; a.bt = t->bt; a.pw = t->pw; a.pb = t->pb; a.vm = t->vm; a.cm = t->cm; a.y = y_ids;
@@ -701,9 +857,6 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     else hipLaunchKernelGGL(k_gt_head_rows<8>, grid, dim3(256), 0, st, a);
     G_HIP(hipGetLastError());
   }
-  if (out2) {
-    if (int rc = hiertcn_gmm_lane_loss(g, loss, y_ids, (int32_t)B, T, out2, stream)) return rc;
-  }
 
   // ================= head backward ==============================================================================================================
   G_HIP(hipMemsetAsync(t->sm, 0, (size_t)M * C * 4, st));
@@ -717,18 +870,22 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
   hipLaunchKernelGGL(k_gt_head_fix, dim3((unsigned)(((int64_t)M * D + 3) / 4)), dim3(256), 0, st, t->Wt, t->bt, t->sm, t->gs, M, D, DP, C, t->dWt, t->dbt);
   hipLaunchKernelGGL(k_gt_head_scatter, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, F32(w.GH), F32(w.gv), y_ids, R, M, D, DP, C, t->dWt, t->dbt);
   G_HIP(hipGetLastError());
+  }
+  if (out2) {
+    if (int rc = hiertcn_gmm_lane_loss(g, loss, y_ids, (int32_t)B, T, out2, stream)) return rc;
+  }
   // prior: d pi_w[m][:] = sum_r dA[r][m] h_r, d pi_b[m] = sum_r dA[r][m]
   G_HIP(gemm32_tn(F32(w.dA), GT_MP, H, C, t->dpw, C, GT_MP, C, (int)R, 0.f, t->splitk, t->splitk_floats, st));
   G_HIP(hipMemsetAsync(t->dpb, 0, GT_MP * 4, st));
   G_HIP(train_colsum_f32(F32(w.dA), R, GT_MP, GT_MP, t->dpb, st));
   // ... into the reference layout [C][M (1 + D)] / [M (1 + D)]
-  const int64_t n_out = (int64_t)M * (1 + (int64_t)D);
+  const int64_t n_out = (int64_t)M + (int64_t)Tn * D;
   float* dW = G + t->head_w.off;
   float* db = G + t->head_b.off;
-  for (int m = 0; m < M; m++) G_HIP(gt_transpose(t->dWt + (size_t)m * DP * C, C, dW + M + (int64_t)m * D, n_out, D, C, st));
+  for (int m = 0; m < Tn; m++) G_HIP(gt_transpose(t->dWt + (size_t)m * DP * C, C, dW + M + (int64_t)m * D, n_out, D, C, st));
   {
-    const int64_t n = (int64_t)M * (D > C ? D : C);
-    hipLaunchKernelGGL(k_gt_head_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t->dpw, t->dpb, t->dbt, M, D, DP, C, n_out, dW, db);
+    const int64_t n = (int64_t)Tn * (D > C ? D : C);
+    hipLaunchKernelGGL(k_gt_head_small, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, t->dpw, t->dpb, t->dbt, M, Tn, D, DP, C, n_out, dW, db);
     G_HIP(hipGetLastError());
   }
 

@@ -5,9 +5,9 @@ the likelihood loss args.loss in {gmm_prob, gmm_prob_max} (loss.py:247-257) -- a
 What the reference itself does with these models on XING cannot be run: its graph feeds the [B, T, M (1 + D)] head output to calc_loss /
 calc_metric_fast against the [B, T, item_num] one-hot targets (model.py:105-132), whose last dimensions differ, and calc_loss_gmm has no
 caller.  This loop therefore reports the mixture loss only; the rank metrics of results.txt do not exist for a density model and are
-written as nan.  Training (--train): model_tcn_gmm and model_gru_gmm with a fixed scale step through csrc/gmm_train.hip (the gradient of this
-loop's own loss: the decode is the build's, so is its derivative -- checked against fp64 autograd, tests/test_gpu_gmm_train.py); the
-mixture low levels of model_hier and a learned scale evaluate only and say so.
+written as nan.  Training (--train): model_tcn_gmm and model_gru_gmm (fixed or learned scale) step through csrc/gmm_train.hip (the gradient of
+this loop's own loss: the decode is the build's, so is its derivative -- checked against fp64 autograd, tests/test_gpu_gmm_train.py); the
+mixture low levels of model_hier evaluate only and say so.
 """
 from __future__ import annotations
 
@@ -47,8 +47,8 @@ def evaluate_gmm(args, loader, sess, prefix="test"):
 def run_gmm(args, loader_train, loader_validate, loader_test, sess=None):
     """run_nn's cadence (run_nn_xing.py:101-192) for --model_type tcn_gmm / gru_gmm: per epoch args.epoch_batches_train optimizer steps at the
     scheduled learning rate (run_hier_xing.py:265-269), a checkpoint every args.save_epoch, validation / test every args.test_epoch -- or one
-    evaluation pass with the evaluation flags (args.py:193).  Training is built for model_tcn_gmm / model_gru_gmm with a fixed scale
-    (csrc/gmm_train.hip); a learned scale raises on --train."""
+    evaluation pass with the evaluation flags (args.py:193).  Training is built for model_tcn_gmm / model_gru_gmm
+    (csrc/gmm_train.hip)."""
     from . import checkpoint
     from .run_common import scheduled_lr
     if sess is None:

@@ -426,10 +426,13 @@ int hiertcn_gmm_lane_loss(hiertcn_gmm_handle_t g, const float* loss, const int32
 /* ---- training step of the mixture-output model (ABI 12; model.py:135-141 on the lane-mean mixture loss of model.py:111-117 + loss.py:247-257).
  * The reference itself cannot train these models on XING (its graph does not build): the step differentiates the decode
  * documented above, and is checked against fp64 autograd of that decode.  Built for the models on ids -- trunk 0 (model_tcn_gmm: the
- * TemporalConvNet) and trunk 1 (model_gru_gmm: the GRU stack, backward through time over its T steps) --, a fixed scale (cfg.sigma > 0), loss
- * modes 0 / 1; the dense-row trunks (the mixture low levels of model_hier) and a learned scale evaluate only (train_enable returns an error).
- * Everything is fp32 on master copies kept in the REFERENCE's layouts (a checkpoint is a copy; Adam is elementwise); no [rows][M D] matrix is
- * formed in either direction -- the head's backward is linear algebra on the hidden rows through G_m = W_m W_m^T (csrc/gmm_train.hip).
+ * TemporalConvNet) and trunk 1 (model_gru_gmm: the GRU stack, backward through time over its T steps) --, a fixed scale (cfg.sigma > 0) or a
+ * learned one (cfg.sigma = 0), loss modes 0 / 1; the dense-row trunks (the mixture low levels of model_hier) evaluate only (train_enable returns
+ * an error).
+ * Everything is fp32 on master copies kept in the REFERENCE's layouts (a checkpoint is a copy; Adam is elementwise).  With a fixed scale no
+ * [rows][M D] matrix is formed in either direction -- the head's backward is linear algebra on the hidden rows through G_m = W_m W_m^T
+ * (csrc/gmm_train.hip); a learned scale materialises the means and log-scales ([2 M][rows][D] fp32 in the workspace: size it with
+ * hiertcn_gmm_train_workspace_bytes) and differentiates them in place.
  *   hiertcn_gmm_train_enable          allocates masters / gradients / the two Adam moments, fills the masters from `w` (hiertcn_gmm_set_weights'
  *                                     tensors), zeroes the moments and the time step.
  *   hiertcn_gmm_train_step            x_ids, y_ids [B][T] -> gradients of every variable of  loss = (1 / users) sum_b (sum_t l_bt [y_bt > 0]) /

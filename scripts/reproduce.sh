@@ -69,3 +69,5 @@ echo "== fp32 TRAINING mode at the reference's batch (32 x 10 x 20, XING catalog
 python3 scripts/fp32_train_bench.py 30 2>&1 | tail -1; LOW=gru D=128 python3 scripts/fp32_train_bench.py 30 2>&1 | tail -1
 echo "== single-level models at the reference's defaults (model_gru: hidden 200 -> 256; model_tcn: six blocks), 32 users x T = 200"
 python3 scripts/single_level_bench.py 2>&1 | grep single-level
+echo "== mixture models' TRAINING step (csrc/gmm_train.hip): 32 lanes x 200 steps, XING catalogue, d = 256, 5 mixtures: model_tcn_gmm, model_gru_gmm, model_tcn_gmm with a learned scale"
+python3 scripts/gmm_train_bench.py tcn 20 2>&1 | tail -1; python3 scripts/gmm_train_bench.py gru 5 2>&1 | tail -1; python3 scripts/gmm_train_bench.py tcn 5 learned 2>&1 | tail -1

@@ -40,12 +40,29 @@ def _params(a, seed):
     return p
 
 
+def _mix_rows(a, pred, yt, mode):
+    """The decode of oracle/gmm_oracle.py and the two likelihood losses on a MATERIALISED head output pred [B, T, n_out] (torch, fp64): fixed scale
+    (args.sigma) or a learned one (args.sigma None: the third block of outputs as log-scales, sigma_d = exp(s_d)) -> loss rows [B, T] (unmasked)."""
+    M, D = int(a.num_mixture), int(a.output_dim)
+    B, T = yt.shape
+    log_pi = torch.log_softmax(pred[..., :M], -1)
+    mu = pred[..., M:M + M * D].reshape(B, T, M, D)
+    yoh = torch.nn.functional.one_hot(yt, D).to(torch.float64) * (yt > 0)[..., None]
+    if getattr(a, "sigma", 0.1):
+        sigma = float(a.sigma)
+        d2 = ((yoh[:, :, None, :] - mu) ** 2).sum(-1)
+        mvn = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
+    else:
+        sc = pred[..., M + M * D:M + 2 * M * D].reshape(B, T, M, D)
+        mvn = -0.5 * (((yoh[:, :, None, :] - mu) * torch.exp(-sc)) ** 2).sum(-1) - sc.sum(-1) - 0.5 * D * np.log(2 * np.pi)
+    return -torch.logsumexp(log_pi + mvn, -1) / D if mode == "gmm_prob" else -(log_pi + mvn / D).max(-1).values
+
+
 def torch_loss(a, P, x, y, mode, scope="tcn_gmm"):
     """fp64, materialising: -> (batch loss, loss rows [B, T]).  P: {TF name: float64 tensor (requires_grad)}."""
     xt, yt = torch.as_tensor(x.astype(np.int64)), torch.as_tensor(y.astype(np.int64))
     B, T = xt.shape
-    K, M, D = int(a.kernel_size), int(a.num_mixture), int(a.output_dim)
-    sigma = float(a.sigma)
+    K = int(a.kernel_size)
     pre = f"{scope}/temporal_conv_net/tblock_0"
     W0, b0, Wr, br = P[f"{pre}/conv1/kernel"], P[f"{pre}/conv1/bias"], P[f"{pre}/dense/kernel"], P[f"{pre}/dense/bias"]
     live_x = (xt > 0).to(torch.float64)[..., None]
@@ -69,15 +86,7 @@ def torch_loss(a, P, x, y, mode, scope="tcn_gmm"):
         res = act @ P[f"{pre}/dense/kernel"] + P[f"{pre}/dense/bias"] if f"{pre}/dense/kernel" in P else act
         act = torch.relu(torch.relu(c) + res)
     pred = act @ P[f"{scope}/fully_connected/weights"] + P[f"{scope}/fully_connected/biases"]      # [B, T, M (1 + D)]: what the device never forms
-    log_pi = torch.log_softmax(pred[..., :M], -1)
-    mu = pred[..., M:M + M * D].reshape(B, T, M, D)
-    yoh = torch.nn.functional.one_hot(yt, D).to(torch.float64) * (yt > 0)[..., None]
-    d2 = ((yoh[:, :, None, :] - mu) ** 2).sum(-1)
-    mvn = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
-    if mode == "gmm_prob":
-        rows = -torch.logsumexp(log_pi + mvn, -1) / D
-    else:
-        rows = -(log_pi + mvn / D).max(-1).values
+    rows = _mix_rows(a, pred, yt, mode)
     mask = (yt > 0).to(torch.float64)
     cnt = mask.sum(1)
     users = (cnt > 0).sum()
@@ -219,12 +228,6 @@ def test_what_is_not_built_says_so():
     with pytest.raises(NotImplementedError):
         m.train_forward_backward(dev(np.zeros((2, 3), np.int32)), dev(np.zeros((2, 3), np.int32)), mode="gmm_prob_hinge")
     m.close()
-    al = _args(300, 2, (64,), 3)
-    al.sigma = None                                                                                        # a learned scale: evaluation only
-    ml = TcnGmmModel(al, None)
-    with pytest.raises(HierTCNError, match="fixed scale"):
-        ml.enable_training()
-    ml.close()
     # the mixture low levels of model_hier (dense input rows: trunks 2 / 3) evaluate only: the library refuses
     import ctypes as C
 
@@ -360,8 +363,7 @@ def torch_gru_loss(a, P, x, y, mode, scope="rnn_gmm"):
     rows, a prefix length: past it the state is carried and the output row is zero), then the same head / decode / losses as torch_loss."""
     xt, yt = torch.as_tensor(x.astype(np.int64)), torch.as_tensor(y.astype(np.int64))
     B, T = xt.shape
-    N, H, nl, M, D = int(a.item_num), int(a.hidden_dim), int(a.num_layer), int(a.num_mixture), int(a.output_dim)
-    sigma = float(a.sigma)
+    N, H, nl = int(a.item_num), int(a.hidden_dim), int(a.num_layer)
     onehot = torch.nn.functional.one_hot(xt, N).to(torch.float64) * (xt > 0)[..., None]
     length = (xt > 0).sum(1)
     state = [torch.zeros(B, H, dtype=torch.float64) for _ in range(nl)]
@@ -380,12 +382,7 @@ def torch_gru_loss(a, P, x, y, mode, scope="rnn_gmm"):
         outs.append(torch.where(active, inp, torch.zeros_like(inp)))
     act = torch.stack(outs, 1)
     pred = act @ P[f"{scope}/fully_connected/weights"] + P[f"{scope}/fully_connected/biases"]
-    log_pi = torch.log_softmax(pred[..., :M], -1)
-    mu = pred[..., M:M + M * D].reshape(B, T, M, D)
-    yoh = torch.nn.functional.one_hot(yt, D).to(torch.float64) * (yt > 0)[..., None]
-    d2 = ((yoh[:, :, None, :] - mu) ** 2).sum(-1)
-    mvn = -0.5 * d2 / sigma ** 2 - D * np.log(sigma) - 0.5 * D * np.log(2 * np.pi)
-    rows = -torch.logsumexp(log_pi + mvn, -1) / D if mode == "gmm_prob" else -(log_pi + mvn / D).max(-1).values
+    rows = _mix_rows(a, pred, yt, mode)
     mask = (yt > 0).to(torch.float64)
     cnt = mask.sum(1)
     loss = ((rows * mask).sum(1) / (cnt + 1e-6)).sum() / (cnt > 0).sum()
@@ -501,3 +498,53 @@ def test_fuzzed_shapes_against_fp64_autograd(seed):
         err = np.linalg.norm(grads[k].astype(np.float64) - ref) / max(nr, 1e-30)
         assert err < 5e-5 or nr < 1e-12, (k, err, nr)
     model.close()
+
+
+@pytest.mark.parametrize("mode", ["gmm_prob", "gmm_prob_max"])
+@pytest.mark.parametrize("trunk,N,M,width,depth,B,T", [("tcn", 303, 3, 64, 2, 5, 9), ("tcn", 1201, 2, 128, 1, 4, 13), ("gru", 500, 4, 64, 2, 4, 11),
+                                                       ("tcn", 20_778, 5, 256, 2, 2, 6)])
+def test_learned_scale_every_gradient_against_fp64_autograd(trunk, N, M, width, depth, B, T, mode):
+    """args.sigma None (`--sigma none`): M (1 + 2 D) head outputs, sigma_d = exp(s_d).  sum_d mu_d^2 e^{-2 s_d} is no quadratic form of the hidden
+    row: the device materialises mu and s with exact-fp32 products and differentiates them in place."""
+    rng = np.random.default_rng(N + M)
+    x, y = _batch(rng, N, B, T)
+    if trunk == "tcn":
+        from hiertcn_amd.model_tcn_gmm import TcnGmmModel as Model
+        a = _args(N, M, (width,) * depth, 3, loss=mode)
+        a.sigma = None
+        p = _params(a, seed=N % 89)
+        ref_loss, oracle_pred = torch_loss, G.model_tcn_gmm
+    else:
+        from hiertcn_amd.model_gru_gmm import GruGmmModel as Model
+        a = _gru_args(N, M, width, depth, loss=mode)
+        a.sigma = None
+        p = G.init_params_gru(a, seed=N % 89)
+        ref_loss, oracle_pred = torch_gru_loss, G.model_gru_gmm
+    assert p[[k for k in p if k.endswith("fully_connected/weights")][0]].shape[1] == M * (1 + 2 * N)
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in p.items()}
+    loss_ref, rows_ref = ref_loss(a, P, x, y, mode)
+    loss_ref.backward()
+    pred = oracle_pred(a, x, {k: np.asarray(v, np.float64) for k, v in p.items()})
+    want_rows = G.calc_loss_gmm_ids(pred, y, a) * (y > 0)
+    assert np.abs(rows_ref.detach().numpy() - want_rows).max() < 1e-9 * max(1.0, np.abs(want_rows).max())
+    model = Model(a, p)
+    model.enable_training()
+    out = model.train_forward_backward(dev(x), dev(y), mode, want_rows=True)
+    rows = out["loss_rows"].cpu().numpy()
+    live = y > 0
+    assert not rows[~live].any()
+    assert np.abs(rows - want_rows)[live].max() < 5e-6 * max(1.0, np.abs(want_rows).max()), np.abs(rows - want_rows)[live].max()
+    sums = out["sums"].cpu().numpy()
+    assert abs(sums[0] / sums[1] - float(loss_ref.detach())) < 5e-6 * max(1.0, abs(float(loss_ref.detach())))
+    grads = model.export("grads")
+    for k, t in P.items():
+        ref = t.grad.numpy()
+        err = np.linalg.norm(grads[k].astype(np.float64) - ref) / max(np.linalg.norm(ref), 1e-30)
+        assert np.linalg.norm(ref) > 0 and err < 5e-5, (k, err)
+    # a step, then the evaluation path of the same handle == a fresh handle on the exported weights
+    model.adam_step(1e-3)
+    w = model.export("weights")
+    fresh = Model(a, w)
+    assert np.array_equal(model.eval_step(x, y)["sums"].cpu().numpy(), fresh.eval_step(x, y)["sums"].cpu().numpy())
+    model.close()
+    fresh.close()
