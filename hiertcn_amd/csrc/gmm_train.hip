@@ -60,7 +60,7 @@ struct GmmTrain {
   float* dwc[HIERTCN_MAX_LAYERS] = {};
   float *Wt = nullptr, *bt = nullptr, *pw = nullptr, *pb = nullptr;         // [M][DP][C] item-major (pad rows zero), [M][DP], [GT_MP][C], [GT_MP]
   float *dWt = nullptr, *dbt = nullptr, *dpw = nullptr, *dpb = nullptr;
-  float *Gm = nullptr, *vm = nullptr, *cm = nullptr, *Sm = nullptr, *sm = nullptr, *gs = nullptr;   // [M][C][C], [M][C], [M], [M][C][C], [M][C], [M]
+  float *Gm = nullptr, *vm = nullptr, *cm = nullptr, *Sm = nullptr, *sm = nullptr, *gs = nullptr;   // [C][M C] (G_m side by side), [M][C], [M], [M C][C] (S_m stacked), [M][C], [M]
   float* splitk = nullptr;
   size_t splitk_floats = 0;
   float* master() const { return arena; }
@@ -228,7 +228,7 @@ __global__ void k_gt_vc_sum(const float* __restrict__ part, int nz, int C, float
 
 struct HeadRows {
   const float* H;        // [R][C] hidden rows
-  const float* X;        // [M][R][C] = H . G_m
+  const float* X;        // [R][M C]: columns [m C, (m + 1) C) = H . G_m  (ONE product H . [G_1 | ... | G_M])
   const float* Wt;       // [M][DP][C]
   const float* bt;       // [M][DP]
   const float* pw;       // [GT_MP][C]
@@ -244,7 +244,7 @@ struct HeadRows {
   double cst_over_D;     // (-D log sigma - D/2 log 2 pi) / D
   float* loss;           // [R] per-step loss (0 on rows without a target), unweighted: what hiertcn_gmm_loss returns
   float* dH;             // [R][C]
-  float* GH;             // [M][R][C] = g_rm h_r
+  float* GH;             // [R][M C]: columns [m C, (m + 1) C) = g_rm h_r  (so that S = GH^T . H is ONE product, [M C][C])
   float* gv;             // [M][R]    = g_rm
   float* dA;             // [R][GT_MP] = d loss / d prior logits
 };
@@ -262,7 +262,7 @@ __global__ __launch_bounds__(256) void k_gt_head_rows(const HeadRows a) {
   for (int k = 0; k < CPL; k++) h[k] = a.H[r * C + lane + 64 * k];
   float pl[16], d2[16];
   for (int m = 0; m < M; m++) {
-    const float* xr = a.X + ((size_t)m * a.R + r) * C;
+    const float* xr = a.X + ((size_t)r * M + m) * C;
     const float* wy = a.Wt + ((size_t)m * a.DP + (valid ? yy : 0)) * C;
     float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
 #pragma unroll
@@ -324,9 +324,9 @@ __global__ __launch_bounds__(256) void k_gt_head_rows(const HeadRows a) {
 #pragma unroll
   for (int k = 0; k < CPL; k++) dh[k] = 0.f;
   for (int m = 0; m < M; m++) {
-    const float* xr = a.X + ((size_t)m * a.R + r) * C;
+    const float* xr = a.X + ((size_t)r * M + m) * C;
     const float* wy = a.Wt + ((size_t)m * a.DP + (valid ? yy : 0)) * C;
-    float* gh = a.GH + ((size_t)m * a.R + r) * C;
+    float* gh = a.GH + ((size_t)r * M + m) * C;
 #pragma unroll
     for (int k = 0; k < CPL; k++) {
       const int c = lane + 64 * k;
@@ -373,7 +373,7 @@ __global__ __launch_bounds__(256) void k_gt_head_scatter(const float* __restrict
   for (int m = 0; m < M; m++) {
     const float g = gv[(size_t)m * R + r];
     if (g == 0.f) continue;
-    const float* gh = GH + ((size_t)m * R + r) * C;
+    const float* gh = GH + ((size_t)r * M + m) * C;
     float* dst = dWt + ((size_t)m * DP + yy) * C;
     for (int c = lane; c < C; c += 64) atomicAdd(dst + c, -gh[c]);
     if (lane == 0) atomicAdd(dbt + (size_t)m * DP + yy, -g);
@@ -830,8 +830,8 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     }
   } else {
   // ================= head: G_m, v_m, |b_m|^2 from the masters; X_m = H G_m; the row-wise kernel ==============================================
-  for (int m = 0; m < M; m++)
-    G_HIP(gemm32_tn(t->Wt + (size_t)m * DP * C, C, t->Wt + (size_t)m * DP * C, C, t->Gm + (size_t)m * C * C, C, C, C, DP, 0.f, t->splitk, t->splitk_floats, st));
+  for (int m = 0; m < M; m++)   // G_m into columns [m C, (m + 1) C) of Gcat [C][M C]
+    G_HIP(gemm32_tn(t->Wt + (size_t)m * DP * C, C, t->Wt + (size_t)m * DP * C, C, t->Gm + (size_t)m * C, (int64_t)M * C, C, C, DP, 0.f, t->splitk, t->splitk_floats, st));
   {
     const int dslice = 1024, nz = (DP + dslice - 1) / dslice;   // (the partials live in the split-K scratch: M nz (C + 1) floats, free between the products)
     if ((size_t)M * nz * (C + 1) > t->splitk_floats) return gfail(HIERTCN_ERR_INVALID, "output_dim %d too large for the v_m partials", D);
@@ -839,8 +839,7 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     hipLaunchKernelGGL(k_gt_vc_sum, dim3((unsigned)((C + 1 + 255) / 256), (unsigned)M), dim3(256), 0, st, t->splitk, nz, C, t->vm, t->cm);
     G_HIP(hipGetLastError());
   }
-  for (int m = 0; m < M; m++)
-    G_HIP(gemm32_nn(H, C, t->Gm + (size_t)m * C * C, C, F32(w.X) + (size_t)m * R * C, C, (int)R, C, C, 0.f, st));
+  G_HIP(gemm32_nn(H, C, t->Gm, (int64_t)M * C, F32(w.X), (int64_t)M * C, (int)R, M * C, C, 0.f, st));   // X = H . [G_1 | ... | G_M]
   {
     HeadRows a;
     a.H = H; a.X = F32(w.X); a.Wt = t->Wt; a.bt = t->bt; a.pw = t->pw; a.pb = t->pb; a.vm = t->vm; a.cm = t->cm; a.y = y_ids;
@@ -860,12 +859,10 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
 
   // ================= head backward ==============================================================================================================
   G_HIP(hipMemsetAsync(t->sm, 0, (size_t)M * C * 4, st));
-  for (int m = 0; m < M; m++) {
-    const float* GHm = F32(w.GH) + (size_t)m * R * C;
-    G_HIP(gemm32_tn(GHm, C, H, C, t->Sm + (size_t)m * C * C, C, C, C, (int)R, 0.f, t->splitk, t->splitk_floats, st));   // S_m = sum_r g_rm h_r h_r^T
-    G_HIP(train_colsum_f32(GHm, R, C, C, t->sm + (size_t)m * C, st));                                                     // s_m = sum_r g_rm h_r
+  G_HIP(gemm32_tn(F32(w.GH), (int64_t)M * C, H, C, t->Sm, C, M * C, C, (int)R, 0.f, t->splitk, t->splitk_floats, st));   // S [M C][C]: rows [m C, (m + 1) C) = S_m = sum_r g_rm h_r h_r^T
+  G_HIP(train_colsum_f32(F32(w.GH), R, (int64_t)M * C, M * C, t->sm, st));                                               // s_m = sum_r g_rm h_r
+  for (int m = 0; m < M; m++)
     G_HIP(gemm32_nn(t->Wt + (size_t)m * DP * C, C, t->Sm + (size_t)m * C * C, C, t->dWt + (size_t)m * DP * C, C, DP, C, C, 0.f, st));   // W_m^T S_m
-  }
   hipLaunchKernelGGL(k_gt_rowsum, dim3((unsigned)M), dim3(256), 0, st, F32(w.gv), R, t->gs);
   hipLaunchKernelGGL(k_gt_head_fix, dim3((unsigned)(((int64_t)M * D + 3) / 4)), dim3(256), 0, st, t->Wt, t->bt, t->sm, t->gs, M, D, DP, C, t->dWt, t->dbt);
   hipLaunchKernelGGL(k_gt_head_scatter, dim3((unsigned)((R + 3) / 4)), dim3(256), 0, st, F32(w.GH), F32(w.gv), y_ids, R, M, D, DP, C, t->dWt, t->dbt);
