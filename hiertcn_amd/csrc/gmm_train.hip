@@ -159,6 +159,27 @@ __global__ __launch_bounds__(256) void k_gt_block0_bwd(const float* __restrict__
   }
 }
 
+// trunk 1, first pointwise step of a cell's backward under dynamic_rnn's sequence_length (train.hip's k_lgru_bwd_a) in the form the FUSED products
+// of gemm.hip need (gemm32_nn_gru_bwd: the other two pointwise steps ride on the two products' epilogues, three launches per cell instead of five):
+// an inactive row (t >= sequence_length) neither produced an output nor moved its state -- its dac / dag rows are zero, and its carried state
+// gradient passes through as dhpart, which the second product's epilogue then writes out unchanged (0 . W + dhpart).
+__global__ void k_gt_gru_bwd_a(const float* __restrict__ dcar, int ldd, const float* __restrict__ dout, int64_t ld_dout, const int32_t* __restrict__ seq_len,
+                               int tstep, const float* __restrict__ h, int ldh, const float* __restrict__ gates, const float* __restrict__ cand, int M, int H,
+                               float* __restrict__ dac, float* __restrict__ dag, float* __restrict__ dhpart) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * H) return;
+  const int64_t b = i / H;
+  const int k = (int)(i - b * H);
+  const bool active = tstep < seq_len[b];
+  const float car = dcar[b * ldd + k];
+  const float d = active ? car + dout[b * ld_dout + k] : 0.f;
+  const float u = gates[b * 2 * H + H + k], c = cand[i], hv = h[b * ldh + k];
+  dac[i] = d * (1.f - u) * (1.f - c * c);
+  dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  dag[b * 2 * H + k] = 0.f;                      // (the r half is written by the first product's epilogue for every row; zero here in case M exceeds a tile edge)
+  dhpart[i] = active ? d * u : car;
+}
+
 // trunk 1, layer 0: the input half of [x, h] . W on a one-hot row is the table row W[id] (model_gru_gmm.py:33-48 on one_hot(id) * sign(id)); its gradient is a
 // scatter-add of the cell's pre-activation gradients into that row.  dac [L][M][H] (candidate), dag [L][M][2H] (gates); rows (t, m); zero where a row was inactive.
 __global__ __launch_bounds__(256) void k_gt_gru_in_scatter(const float* __restrict__ dac, const float* __restrict__ dag, const int32_t* __restrict__ ids, int M,
@@ -715,6 +736,7 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   if (e2 == hipSuccess) e2 = hipMemsetAsync(t->arena, 0, 4 * t->total * sizeof(float), st);
   if (e2 != hipSuccess) { gmm_train_destroy(t); return gfail(HIERTCN_ERR_HIP, "hipMemsetAsync failed: %s", hipGetErrorString(e2)); }
   g->train = t;
+  auto fill = [&]() -> int {
   // masters <- the caller's tensors (reference layouts: plain copies)
   hiertcn_gmm_weights_t dst;
   master_ptrs(g, t, t->master(), &dst);
@@ -734,6 +756,13 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   }
   G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_weights), w->head_weights, t->head_w.n * 4, hipMemcpyDeviceToDevice, st));
   G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_biases), w->head_biases, t->head_b.n * 4, hipMemcpyDeviceToDevice, st));
+    return HIERTCN_OK;
+  };
+  if (int rc = fill()) {   // a handle with half-filled masters must not look like one that trains
+    gmm_train_destroy(t);
+    g->train = nullptr;
+    return rc;
+  }
   t->step = 0;
   t->stale = true;
   return HIERTCN_OK;
@@ -903,6 +932,7 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     float* din_up = F32(w.din_up);
     const float* dHid = F32(w.dH);
     G_HIP(hipMemsetAsync(lcar, 0, (size_t)Mb * HT * 4, st));   // the final state is dropped (model_gru_gmm.py:47: outputs only)
+    const bool fused = Mb <= gemm32_skinny_max_rows();
     for (int tt = L - 1; tt >= 0; tt--) {
       for (int l = nl - 1; l >= 0; l--) {
         const int in = (l == 0) ? 0 : Hh;            // layer 0's input half is the gathered table row: no dense input operand
@@ -915,6 +945,19 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
         const int64_t ld_dout = (l == nl - 1) ? (int64_t)L * Hh : Hh;
         float* dac = dac_all + ((size_t)l * L + tt) * Mb * Hh;
         float* dag = dag_all + ((size_t)l * L + tt) * Mb * 2 * Hh;
+        if (fused) {   // three launches per cell: the pointwise steps b and c ride on the two products' epilogues (gemm.hip, gemm32_nn_gru_bwd)
+          hipLaunchKernelGGL(k_gt_gru_bwd_a, dim3((unsigned)(((int64_t)Mb * Hh + 255) / 256)), dim3(256), 0, st, lcar + (size_t)l * Hh, HT, dout, ld_dout, seq_len, tt,
+                             hold, HT, gates, cand, Mb, Hh, dac, dag, dhpart);
+          G_HIP(hipGetLastError());
+          GruBwdEpi ep;
+          memset(&ep, 0, sizeof(ep));
+          ep.in = in; ep.H = Hh; ep.K = Kc;
+          ep.gates = gates; ep.h = hold; ep.ldh = HT; ep.dag = dag; ep.dhpart = dhpart; ep.dcat_c = dcat_c;
+          ep.dst_in = din_up; ep.ldi = Hh; ep.dst_h = lnext + (size_t)l * Hh; ep.ldo = HT;
+          G_HIP(gemm32_nn_gru_bwd(1, dac, Hh, t->wc[l], Kc, Mb, Kc, Hh, ep, st));           // d [in | r*h] = dac . wc, then step b
+          G_HIP(gemm32_nn_gru_bwd(2, dag, 2 * Hh, t->wg[l], Kc, Mb, Kc, 2 * Hh, ep, st));    // d [in | h] = dag . wg, then step c
+          continue;
+        }
         G_HIP(train_lgru_bwd_a(lcar + (size_t)l * Hh, HT, dout, ld_dout, seq_len, tt, hold, HT, gates, cand, Mb, Hh, dac, dag, dhpart, st));
         G_HIP(gemm32_nn(dac, Hh, t->wc[l], Kc, dcat_c, Kc, Mb, Kc, Hh, 0.f, st));            // d [in | r*h] = dac . wc
         G_HIP(train_gru_bwd_b(dcat_c, Kc, in, hold, HT, gates, Mb, Hh, dag, dhpart, st));
