@@ -168,8 +168,8 @@ class TcnGmmModel:
         return w
 
     def enable_training(self):
-        """fp32 masters (filled from self.params), gradients and Adam moments on the device: hiertcn_gmm_train_enable.  The model of
-        model_tcn_gmm.py on ids with a fixed scale; anything else raises (the library refuses: evaluation only)."""
+        """fp32 masters (filled from self.params), gradients and Adam moments on the device: hiertcn_gmm_train_enable.  The models on ids
+        (model_tcn_gmm, model_gru_gmm), fixed or learned scale; the mixture low levels of model_hier raise (the library refuses them)."""
         if getattr(self, "_training", False):
             return
         bufs = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device).contiguous() for k, v in self.params.items()}

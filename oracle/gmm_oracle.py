@@ -17,7 +17,8 @@ PARITY UNPINNED, twice over:
       with a shape mismatch.  The decode used here is the build's own, documented choice:
           pi    = softmax(pred[..., :M])                                  (class prior of each Gaussian, loss.py:236)
           mu    = pred[..., M : M + M*D] reshaped [M, D], mixture-major   (loss.py:237)
-          sigma = args.sigma (a scalar, the reference default 0.1, args.py:70-71); a learned sigma (args.sigma None) is not built
+          sigma = args.sigma (a scalar, the reference default 0.1, args.py:70-71), or with a learned scale (args.sigma None) sigma_d = exp(s_d), s = the
+                  third block of M*D outputs, mixture-major (decode_scale below)
           gmm   = Mixture(Categorical(pi), [MultivariateNormalDiag(mu_m, sigma * 1)]) [TF-sem: tf.contrib.distributions]:
                   log_prob(y) = logsumexp_m( log pi_m + mvn_m.log_prob(y) ),
                   mvn.log_prob(y) = -1/2 sum_d ((y_d - mu_d) / sigma)^2 - D log(sigma) - D/2 log(2 pi).
