@@ -167,19 +167,24 @@ def _pad_gru(args, params):
     if H1 is None:
         raise ValueError(f"hidden_dim {H0}: the GRU stack is built for widths up to {GRU_WIDTHS[-1]}")
     a.hidden_dim = H1
+    # the 'emb' width too, up to the stack's width (model_gru.py:46 hard-codes 128 against hidden_dim 200 -> 256): with E == H the session-tile /
+    # layer-pipelined kernels of the HierGRU low level apply (lgru_tile.hip, lgru_wide.hip: one launch for all T steps instead of 2 T nl), and the
+    # padded columns are exactly zero -- zero table columns against zero kernel rows: no logit changes, no gradient reaches them
+    E1 = H1 if E < H1 else E
+    a.emb_dim = E1
     out: Dict[str, np.ndarray] = {}
     for name, shape in param_shapes(a, "gru").items():
         src = np.asarray(params[name], dtype=np.float32)
         dst = np.zeros(shape, np.float32)
         l = int(name.split("/cell_")[1].split("/")[0]) if "/cell_" in name else 0
         in0 = E if l == 0 else H0
-        in1 = E if l == 0 else H1
+        in1 = E1 if l == 0 else H1
         if name.endswith("gates/kernel") or name.endswith("candidate/kernel"):
             r, c = _gru_index(src.shape[0], in0, H0, in1, H1, 2 if "gates" in name else 1)
             dst[np.ix_(r, c)] = src
         elif name.endswith("gates/bias"):
             dst[np.concatenate([np.arange(H0), H1 + np.arange(H0)])] = src
-        else:   # item table, candidate bias, scoring kernel [H, N] / bias: leading corner
+        else:   # item table (columns E .. E1 zero), candidate bias, scoring kernel [H, N] / bias: leading corner
             dst[tuple(slice(0, n) for n in src.shape)] = src
         out[name] = dst
     return a, out
@@ -187,13 +192,14 @@ def _pad_gru(args, params):
 
 def _unpad_gru(args, padded):
     H0, E = int(args.hidden_dim), int(getattr(args, "emb_dim", 128))
+    E1 = int(np.asarray(padded["gru/emb/kernel"]).shape[1])   # the padded 'emb' width (_pad_gru)
     out: Dict[str, np.ndarray] = {}
     for name, shape in param_shapes(args, "gru").items():
         src = np.asarray(padded[name])
         H1 = src.shape[-1] // 2 if name.endswith("gates/kernel") or name.endswith("gates/bias") else (src.shape[-1] if "gru_cell" in name else src.shape[0])
         l = int(name.split("/cell_")[1].split("/")[0]) if "/cell_" in name else 0
         in0 = E if l == 0 else H0
-        in1 = E if l == 0 else H1
+        in1 = E1 if l == 0 else H1
         if name.endswith("gates/kernel") or name.endswith("candidate/kernel"):
             r, c = _gru_index(shape[0], in0, H0, in1, H1, 2 if "gates" in name else 1)
             out[name] = np.ascontiguousarray(src[np.ix_(r, c)])
