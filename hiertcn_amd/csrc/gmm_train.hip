@@ -1048,8 +1048,8 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
 int hiertcn_gmm_adam_step(hiertcn_gmm_handle_t g, float lr, float beta1, float beta2, float eps, float grad_scale, void* stream) {
   GT_READY(g);
   GmmTrain* t = g->train;
-  t->step += 1;
-  G_HIP(train_adam_flat(t->master(), t->grad(), t->mom1(), t->mom2(), t->total, lr, beta1, beta2, eps, grad_scale, t->step, reinterpret_cast<hipStream_t>(stream)));
+  G_HIP(train_adam_flat(t->master(), t->grad(), t->mom1(), t->mom2(), t->total, lr, beta1, beta2, eps, grad_scale, t->step + 1, reinterpret_cast<hipStream_t>(stream)));
+  t->step += 1;          // (only a step that was enqueued counts)
   t->stale = true;
   return HIERTCN_OK;
 }
