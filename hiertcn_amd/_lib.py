@@ -49,7 +49,11 @@ class GmmWeights(C.Structure):
                 ("res_kernel", C.c_void_p * MAX_BLOCKS), ("res_bias", C.c_void_p * MAX_BLOCKS),
                 ("head_weights", C.c_void_p), ("head_biases", C.c_void_p),
                 ("gru_gate_kernel", C.c_void_p * MAX_LAYERS), ("gru_gate_bias", C.c_void_p * MAX_LAYERS),
-                ("gru_cand_kernel", C.c_void_p * MAX_LAYERS), ("gru_cand_bias", C.c_void_p * MAX_LAYERS)]
+                ("gru_cand_kernel", C.c_void_p * MAX_LAYERS), ("gru_cand_bias", C.c_void_p * MAX_LAYERS),
+                # training of trunk 2 as model_hier's low level only: the high level's variables (hiertcn_gmm_train_step_hier)
+                ("hl_emb_kernel", C.c_void_p), ("hl_emb_bias", C.c_void_p),
+                ("hl_gate_kernel", C.c_void_p * MAX_LAYERS), ("hl_gate_bias", C.c_void_p * MAX_LAYERS),
+                ("hl_cand_kernel", C.c_void_p * MAX_LAYERS), ("hl_cand_bias", C.c_void_p * MAX_LAYERS)]
 
 
 TUNING_FIELDS = ("gru_scan_persistent", "gru_scan_persistent_train", "gru_bptt_persistent", "gru_bptt_fused", "lgru_persistent", "lgru_pipe", "lgru_tile",
@@ -172,6 +176,9 @@ SYMBOLS = {
     "hiertcn_gmm_train_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32]),
     "hiertcn_gmm_train_step": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_size_t,
                                           C.c_void_p, C.c_void_p, C.c_void_p]),
+    "hiertcn_gmm_train_hier_workspace_bytes": (C.c_size_t, [C.c_void_p, C.c_int64, C.c_int32, C.c_int32]),
+    "hiertcn_gmm_train_step_hier": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_int32, C.c_void_p,
+                                               C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]),
     "hiertcn_gmm_adam_step": (C.c_int, [C.c_void_p, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "hiertcn_gmm_adam_time": (C.c_int, [C.c_void_p, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hiertcn_gmm_train_sync": (C.c_int, [C.c_void_p, C.c_void_p]),

@@ -25,8 +25,14 @@
 // hidden row -- so that variant materialises mu and s per mixture ([2 M][rows][D] fp32, 5.3 GB at the reference's batch), forms their gradients in place
 // and takes three exact-fp32 products per table (k_gtl_rows / k_gtl_grad below).
 //
-// Built for: trunks 0 and 1 (the models on ids), both scale variants, loss modes gmm_prob and gmm_prob_max.  The dense-row trunks (the mixture low levels of
-// model_hier) evaluate only (hiertcn_gmm_train_enable refuses them).
+// model_hier with the tcn_gmm low level (model_hier.py:39-93 around trunk 2) trains as ONE step on this handle (hiertcn_gmm_train_step_hier): the handle
+// then also keeps the HIGH level's masters (item table, emb bias, across-session cells), runs session mean-pool -> across-session scan with every record
+// kept (pool_gru.hip's launch_gru_scan on a view of the masters) -> the [e, state] rows -> the step above with block 0 as an ordinary TemporalBlock on
+// those rows -> and sends the rows' gradient back: the item table's rows by scatter-add, the states through the S slots (three launches per cell, the
+// user-boundary mask in the first), the pool.
+//
+// Built for: trunks 0 and 1 (the models on ids) and trunk 2 together with the high level, both scale variants, loss modes gmm_prob and gmm_prob_max.
+// Trunk 3 (model_hier with the gru_gmm low level) evaluates only (hiertcn_gmm_train_enable refuses it).
 #include <math.h>
 #include <string.h>
 
@@ -46,6 +52,13 @@ struct GmmTrain {
   size_t total = 0;
   GSeg conv[HIERTCN_MAX_BLOCKS], conv_b[HIERTCN_MAX_BLOCKS], res[HIERTCN_MAX_BLOCKS], res_b[HIERTCN_MAX_BLOCKS], head_w, head_b;
   GSeg gk[HIERTCN_MAX_LAYERS], gb[HIERTCN_MAX_LAYERS], ck[HIERTCN_MAX_LAYERS], cb[HIERTCN_MAX_LAYERS];   // trunk 1: gate / candidate kernel [in + H][2H | H], bias
+  // trunk 2 as model_hier's low level: the HIGH level trains with it (hE = 0: a handle that trains on dense rows it is handed is not built)
+  int hE = 0, hH = 0, hnl = 0, hN = 0;      // emb width, across-session GRU width / layers, item table rows
+  GSeg hemb, hemb_b, hgk[HIERTCN_MAX_LAYERS], hgb[HIERTCN_MAX_LAYERS], hck[HIERTCN_MAX_LAYERS], hcb[HIERTCN_MAX_LAYERS];
+  float* hwg[HIERTCN_MAX_LAYERS] = {};      // across-session cells, output-major [2H][in + H] / [H][in + H] (the scan's B operands), and their gradients
+  float* hwc[HIERTCN_MAX_LAYERS] = {};
+  float* dhwg[HIERTCN_MAX_LAYERS] = {};
+  float* dhwc[HIERTCN_MAX_LAYERS] = {};
   int64_t step = 0;         // Adam time step
   bool stale = false;       // the handle's evaluation tables (gmm.hip) are older than the masters: hiertcn_gmm_train_sync
   // compute-layout copies of the masters, re-derived at the start of every step, and the gradients in the same layouts
@@ -209,6 +222,94 @@ __global__ __launch_bounds__(256) void k_gt_gru_in_scatter(const float* __restri
   if (g1.y != 0.f) atomicAdd(dg + H + 1, g1.y);
   if (g1.z != 0.f) atomicAdd(dg + H + 2, g1.z);
   if (g1.w != 0.f) atomicAdd(dg + H + 3, g1.w);
+}
+
+// ---- model_hier around the dense-row trunk (model_hier.py:39-93 with model_low_type 'tcn_gmm'): the rows, and the pieces of its backward ------------------
+// rows[(b, s, t)] = [ emb[x_bst] (zeros for the null id) | state before slot s of user b ]   (model_hier.py:50,54-55); hist [B][S + 1][HT]
+__global__ __launch_bounds__(256) void k_gt_hier_rows(const float* __restrict__ emb, const int32_t* __restrict__ x, const float* __restrict__ hist, int64_t R,
+                                                      int S, int L, int E, int HT, int N, float* __restrict__ rows) {
+  const int W = E + HT, ch = W >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= R * ch) return;
+  const int64_t r = i / ch;
+  const int c = (int)(i - r * ch) * 4;
+  float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < E) {
+    const int id = x[r];
+    if (id > 0 && id < N) v = *reinterpret_cast<const float4*>(emb + (int64_t)id * E + c);
+  } else {
+    const int64_t bs = r / L, b = bs / S, sl = bs - b * S;
+    v = *reinterpret_cast<const float4*>(hist + (b * (S + 1) + sl) * HT + (c - E));
+  }
+  *reinterpret_cast<float4*>(rows + r * W + c) = v;
+}
+// backward of the rows: the item table's rows take d rows[:, :E] (scatter-add); d (state before slot s) = sum_t d rows[(b, s, t), E:] -> dsb [B][S + 1][HT]
+// (slot S stays zero: the state behind the last slot reaches no row)
+__global__ __launch_bounds__(256) void k_gt_hier_rows_bwd(const float* __restrict__ drows, const int32_t* __restrict__ x, int64_t n_sess, int S, int L, int E,
+                                                          int HT, int N, float* __restrict__ demb, float* __restrict__ dsb) {
+  const int W = E + HT, ch = W >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_sess * ch) return;
+  const int64_t bs = i / ch;
+  const int c = (int)(i - bs * ch) * 4;
+  if (c < E) {
+    for (int t = 0; t < L; t++) {
+      const int64_t r = bs * L + t;
+      const int id = x[r];
+      if (id <= 0 || id >= N) continue;
+      const float4 g = *reinterpret_cast<const float4*>(drows + r * W + c);
+      float* d = demb + (int64_t)id * E + c;
+      if (g.x != 0.f) atomicAdd(d, g.x);
+      if (g.y != 0.f) atomicAdd(d + 1, g.y);
+      if (g.z != 0.f) atomicAdd(d + 2, g.z);
+      if (g.w != 0.f) atomicAdd(d + 3, g.w);
+    }
+  } else {
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int t = 0; t < L; t++) {
+      const float4 g = *reinterpret_cast<const float4*>(drows + (bs * L + t) * W + c);
+      acc.x += g.x; acc.y += g.y; acc.z += g.z; acc.w += g.w;
+    }
+    const int64_t b = bs / S, sl = bs - b * S;
+    *reinterpret_cast<float4*>(dsb + (b * (S + 1) + sl) * HT + (c - E)) = acc;
+  }
+}
+// first pointwise step of an across-session cell's backward (customed_gru_cell.py:323-337 differentiated; model_hier.py:93's mask): the gradient of the
+// cell's unmasked output is (carried from slot s + 1 + what slot s + 1's rows sent to the state they read) * mask[s] + what the layer above sent down
+__global__ void k_gt_hl_bwd_a(const float* __restrict__ dcar, int ldc, const float* __restrict__ dsb_next, int64_t ld_dsb, const float* __restrict__ mask, int ldm,
+                              const float* __restrict__ din_up, const float* __restrict__ h, int64_t ldh, const float* __restrict__ gates,
+                              const float* __restrict__ cand, int B, int H, float* __restrict__ dac, float* __restrict__ dag, float* __restrict__ dhpart) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)B * H) return;
+  const int64_t b = i / H;
+  const int k = (int)(i - b * H);
+  const float d = (dcar[b * ldc + k] + dsb_next[b * ld_dsb + k]) * mask[b * ldm] + (din_up ? din_up[i] : 0.f);
+  const float u = gates[b * 2 * H + H + k], c = cand[i], hv = h[b * ldh + k];
+  dac[i] = d * (1.f - u) * (1.f - c * c);
+  dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  dag[b * 2 * H + k] = 0.f;
+  dhpart[i] = d * u;
+}
+// backward of the session mean-pool + bias (model_hier.py:83-85): d emb[y_t] += d pooled / cnt for the session's cnt targets (the bias: column sums)
+__global__ __launch_bounds__(256) void k_gt_pool_bwd(const float* __restrict__ dpooled, const int32_t* __restrict__ y, int64_t n_sess, int L, int E, int N,
+                                                     float* __restrict__ demb) {
+  const int ch = E >> 2;
+  const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n_sess * ch) return;
+  const int64_t bs = i / ch;
+  const int c = (int)(i - bs * ch) * 4;
+  int cnt = 0;
+  for (int t = 0; t < L; t++) { const int id = y[bs * L + t]; cnt += (id > 0 && id < N) ? 1 : 0; }
+  if (cnt == 0) return;
+  float4 g = *reinterpret_cast<const float4*>(dpooled + bs * E + c);
+  const float inv = 1.0f / (float)cnt;
+  g.x *= inv; g.y *= inv; g.z *= inv; g.w *= inv;
+  for (int t = 0; t < L; t++) {
+    const int id = y[bs * L + t];
+    if (id <= 0 || id >= N) continue;
+    float* d = demb + (int64_t)id * E + c;
+    atomicAdd(d, g.x); atomicAdd(d + 1, g.y); atomicAdd(d + 2, g.z); atomicAdd(d + 3, g.w);
+  }
 }
 
 // ---- head ------------------------------------------------------------------------------------------------------------------------------------------
@@ -554,7 +655,7 @@ static void gt_layout(const hiertcn_gmm_ctx* g, GmmTrain* t) {
     const size_t in = (l == 0) ? (size_t)g->N : (size_t)g->H, H = (size_t)g->H;
     seg(t->gk[l], (in + H) * 2 * H); seg(t->gb[l], 2 * H); seg(t->ck[l], (in + H) * H); seg(t->cb[l], H);
   }
-  for (int i = 0, cin = g->N; i < g->nb; cin = g->cfg.channels[i], i++) {
+  for (int i = 0, cin = (g->trunk == 2 ? g->cfg.input_dim : g->N); i < g->nb; cin = g->cfg.channels[i], i++) {
     const int cout = g->cfg.channels[i];
     seg(t->conv[i], (size_t)K * cin * cout);
     seg(t->conv_b[i], cout);
@@ -563,6 +664,14 @@ static void gt_layout(const hiertcn_gmm_ctx* g, GmmTrain* t) {
   const size_t n_out = (size_t)g->M * (1 + (g->learned ? 2 : 1) * (size_t)g->D);   // a learned scale: M (1 + 2 D) outputs (model_tcn_gmm.py:39-40)
   seg(t->head_w, (size_t)g->Clast * n_out);
   seg(t->head_b, n_out);
+  if (t->hE) {   // hier/emb/{kernel,bias}, hier/multi_rnn_cell/cell_l/gru_cell/...
+    seg(t->hemb, (size_t)t->hN * t->hE);
+    seg(t->hemb_b, t->hE);
+    for (int l = 0; l < t->hnl; l++) {
+      const size_t in = (l == 0) ? (size_t)t->hE : (size_t)t->hH, H = (size_t)t->hH;
+      seg(t->hgk[l], (in + H) * 2 * H); seg(t->hgb[l], 2 * H); seg(t->hck[l], (in + H) * H); seg(t->hcb[l], H);
+    }
+  }
   t->total = off;
 }
 
@@ -585,7 +694,8 @@ static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
   size_t off = 0;
   auto take = [&](size_t floats) { const size_t o = off; off += ((floats * 4) + 255) & ~(size_t)255; return o; };
   const size_t C = (size_t)g->Clast;
-  const size_t cm = g->trunk == 1 ? C : (size_t)cmax_of(g);
+  size_t cm = g->trunk == 1 ? C : (size_t)cmax_of(g);
+  if (g->trunk == 2 && (size_t)g->cfg.input_dim > cm) cm = (size_t)g->cfg.input_dim;   // (block 0's shifted input rows)
   if (g->learned) {
     w.MUS = take((size_t)2 * g->M * R * g->DP);
   } else {
@@ -643,6 +753,13 @@ static void master_ptrs(const hiertcn_gmm_ctx* g, const GmmTrain* t, const float
   }
   w->head_weights = base + t->head_w.off;
   w->head_biases = base + t->head_b.off;
+  if (t->hE) {
+    w->hl_emb_kernel = base + t->hemb.off; w->hl_emb_bias = base + t->hemb_b.off;
+    for (int l = 0; l < t->hnl; l++) {
+      w->hl_gate_kernel[l] = base + t->hgk[l].off; w->hl_gate_bias[l] = base + t->hgb[l].off;
+      w->hl_cand_kernel[l] = base + t->hck[l].off; w->hl_cand_bias[l] = base + t->hcb[l].off;
+    }
+  }
 }
 
 // compute-layout copies of the masters (start of a step): conv / residual kernels of blocks >= 1 output-major, the head item-major
@@ -650,11 +767,17 @@ static int gt_refresh(hiertcn_gmm_ctx* g, hipStream_t st) {
   GmmTrain* t = g->train;
   const float* P = t->master();
   const int K = g->K, C = g->Clast, M = g->M, D = g->D, DP = g->DP;
-  for (int i = 1, cin = g->C0; i < g->nb; cin = g->cfg.channels[i], i++) {
+  const int b0 = g->trunk == 2 ? 0 : 1;   // dense input rows: block 0 is an ordinary TemporalBlock with Cin = input_dim
+  for (int i = b0, cin = (b0 ? g->C0 : g->cfg.input_dim); i < g->nb; cin = g->cfg.channels[i], i++) {
     const int cout = g->cfg.channels[i];
     for (int j = 0; j < K; j++)
       G_HIP(gt_transpose(P + t->conv[i].off + (size_t)j * cin * cout, cout, t->convT[i] + (size_t)j * cin * cout, cin, cin, cout, st));
     if (t->res[i].n) G_HIP(gt_transpose(P + t->res[i].off, cout, t->resT[i], cin, cin, cout, st));
+  }
+  for (int l = 0; l < t->hnl; l++) {   // the across-session cells, output-major
+    const int H = t->hH, Kc = ((l == 0) ? t->hE : H) + H;
+    G_HIP(gt_transpose(P + t->hgk[l].off, 2 * H, t->hwg[l], Kc, Kc, 2 * H, st));
+    G_HIP(gt_transpose(P + t->hck[l].off, H, t->hwc[l], Kc, Kc, H, st));
   }
   for (int l = 0; l < g->nl; l++) {   // trunk 1: the state half of layer 0 / the whole kernels above, output-major (the cells' B operand)
     const int H = g->H, in_tf = (l == 0) ? g->N : H, Kc = (l == 0) ? H : 2 * H;
@@ -680,9 +803,21 @@ extern "C" {
 int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream) {
   if (!g || !w) return gfail(HIERTCN_ERR_INVALID, "null argument");
   if (g->train) return gfail(HIERTCN_ERR_STATE, "training is already enabled on this handle");
-  if (g->trunk != 0 && g->trunk != 1)
-    return gfail(HIERTCN_ERR_INVALID, "the training step is built for the models on ids (trunk 0: model_tcn_gmm, trunk 1: model_gru_gmm); trunk %d -- a mixture low level "
-                 "of model_hier -- evaluates only", g->trunk);
+  if (g->trunk == 3)
+    return gfail(HIERTCN_ERR_INVALID, "the training step is built for the models on ids (trunks 0, 1) and for model_hier with the tcn_gmm low level (trunk 2); trunk 3 -- "
+                 "model_hier with the gru_gmm low level -- evaluates only");
+  int hE = 0;
+  if (g->trunk == 2) {   // model_hier.py:39-93 around the dense-row trunk: the high level (item table, emb bias, across-session cells) trains with it
+    const int H = g->cfg.hidden_dim, nl = g->cfg.num_layer;
+    if (H < 32 || (H & 31) || H > 1024 || nl < 1 || nl > HIERTCN_MAX_LAYERS || g->cfg.item_num < 2)
+      return gfail(HIERTCN_ERR_INVALID, "training trunk 2 as model_hier's low level: cfg.hidden_dim (a multiple of 32), cfg.num_layer and cfg.item_num describe the high level");
+    hE = g->cfg.input_dim - H * nl;
+    if (hE < 32 || (hE & 31)) return gfail(HIERTCN_ERR_INVALID, "input_dim %d - hidden_dim %d x num_layer %d = emb width %d: a multiple of 32", g->cfg.input_dim, H, nl, hE);
+    if (!w->hl_emb_kernel || !w->hl_emb_bias) return gfail(HIERTCN_ERR_INVALID, "training trunk 2: hl_emb_kernel / hl_emb_bias (hier/emb/{kernel,bias}) are required");
+    for (int l = 0; l < nl; l++)
+      if (!w->hl_gate_kernel[l] || !w->hl_gate_bias[l] || !w->hl_cand_kernel[l] || !w->hl_cand_bias[l])
+        return gfail(HIERTCN_ERR_INVALID, "training trunk 2: the across-session cell %d (hl_gate / hl_cand kernel and bias) is required", l);
+  }
   if (g->M > GT_MP) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: the training step takes up to 16 mixtures", g->M);
   if (g->Clast != 64 && g->Clast != 128 && g->Clast != 256 && g->Clast != 512) return gfail(HIERTCN_ERR_INVALID, "last width %d: 64, 128, 256, 512", g->Clast);
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
@@ -691,12 +826,13 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   for (int l = 0; l < g->nl; l++)
     if (!w->gru_gate_kernel[l] || !w->gru_gate_bias[l] || !w->gru_cand_kernel[l] || !w->gru_cand_bias[l])
       return gfail(HIERTCN_ERR_INVALID, "GRU layer %d: gate / candidate kernel and bias are required", l);
-  for (int i = 0, cin = g->N; i < g->nb; cin = g->cfg.channels[i], i++) {
+  for (int i = 0, cin = (g->trunk == 2 ? g->cfg.input_dim : g->N); i < g->nb; cin = g->cfg.channels[i], i++) {
     if (!w->conv_kernel[i] || !w->conv_bias[i]) return gfail(HIERTCN_ERR_INVALID, "conv_kernel[%d]/conv_bias[%d] missing", i, i);
     if ((cin != g->cfg.channels[i]) != (w->res_kernel[i] != nullptr && w->res_bias[i] != nullptr))
       return gfail(HIERTCN_ERR_INVALID, "block %d: a Dense residual (kernel and bias) exists exactly when Cin != Cout", i);
   }
   GmmTrain* t = new GmmTrain();
+  if (hE) { t->hE = hE; t->hH = g->cfg.hidden_dim; t->hnl = g->cfg.num_layer; t->hN = g->cfg.item_num; }
   gt_layout(g, t);
   hipError_t e = hipMalloc(reinterpret_cast<void**>(&t->arena), 4 * t->total * sizeof(float));
   if (e != hipSuccess) { gmm_train_destroy(t); return gfail(HIERTCN_ERR_HIP, "hipMalloc of the training arenas (%zu MB) failed: %s", 4 * t->total * 4 >> 20, hipGetErrorString(e)); }
@@ -705,9 +841,14 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   size_t off = 0;
   auto take = [&](size_t floats) { const size_t o = off; off += up64(floats); return o; };
   size_t o_convT[HIERTCN_MAX_BLOCKS] = {}, o_resT[HIERTCN_MAX_BLOCKS] = {}, o_dconvT[HIERTCN_MAX_BLOCKS] = {}, o_dresT[HIERTCN_MAX_BLOCKS] = {};
-  for (int i = 1; i < g->nb; i++) {
+  const int blk0 = g->trunk == 2 ? 0 : 1;
+  for (int i = blk0; i < g->nb; i++) {
     o_convT[i] = take(t->conv[i].n); o_dconvT[i] = take(t->conv[i].n);
     if (t->res[i].n) { o_resT[i] = take(t->res[i].n); o_dresT[i] = take(t->res[i].n); }
+  }
+  size_t o_hwg[HIERTCN_MAX_LAYERS] = {}, o_hwc[HIERTCN_MAX_LAYERS] = {}, o_dhwg[HIERTCN_MAX_LAYERS] = {}, o_dhwc[HIERTCN_MAX_LAYERS] = {};
+  for (int l = 0; l < t->hnl; l++) {
+    o_hwg[l] = take(t->hgk[l].n); o_dhwg[l] = take(t->hgk[l].n); o_hwc[l] = take(t->hck[l].n); o_dhwc[l] = take(t->hck[l].n);
   }
   size_t o_wg[HIERTCN_MAX_LAYERS] = {}, o_wc[HIERTCN_MAX_LAYERS] = {}, o_dwg[HIERTCN_MAX_LAYERS] = {}, o_dwc[HIERTCN_MAX_LAYERS] = {};
   for (int l = 0; l < g->nl; l++) {
@@ -723,10 +864,11 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   const size_t o_sk = take(sk);
   e = hipMalloc(reinterpret_cast<void**>(&t->work), off * sizeof(float));
   if (e != hipSuccess) { gmm_train_destroy(t); return gfail(HIERTCN_ERR_HIP, "hipMalloc of the training work set (%zu MB) failed: %s", off * 4 >> 20, hipGetErrorString(e)); }
-  for (int i = 1; i < g->nb; i++) {
+  for (int i = blk0; i < g->nb; i++) {
     t->convT[i] = t->work + o_convT[i]; t->dconvT[i] = t->work + o_dconvT[i];
     if (t->res[i].n) { t->resT[i] = t->work + o_resT[i]; t->dresT[i] = t->work + o_dresT[i]; }
   }
+  for (int l = 0; l < t->hnl; l++) { t->hwg[l] = t->work + o_hwg[l]; t->dhwg[l] = t->work + o_dhwg[l]; t->hwc[l] = t->work + o_hwc[l]; t->dhwc[l] = t->work + o_dhwc[l]; }
   for (int l = 0; l < g->nl; l++) { t->wg[l] = t->work + o_wg[l]; t->dwg[l] = t->work + o_dwg[l]; t->wc[l] = t->work + o_wc[l]; t->dwc[l] = t->work + o_dwc[l]; }
   t->Wt = t->work + o_Wt; t->bt = t->work + o_bt; t->pw = t->work + o_pw; t->pb = t->work + o_pb;
   t->dWt = t->work + o_dWt; t->dbt = t->work + o_dbt; t->dpw = t->work + o_dpw; t->dpb = t->work + o_dpb;
@@ -756,6 +898,16 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   }
   G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_weights), w->head_weights, t->head_w.n * 4, hipMemcpyDeviceToDevice, st));
   G_HIP(hipMemcpyAsync(const_cast<float*>(dst.head_biases), w->head_biases, t->head_b.n * 4, hipMemcpyDeviceToDevice, st));
+  if (t->hE) {
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.hl_emb_kernel), w->hl_emb_kernel, t->hemb.n * 4, hipMemcpyDeviceToDevice, st));
+    G_HIP(hipMemcpyAsync(const_cast<float*>(dst.hl_emb_bias), w->hl_emb_bias, t->hemb_b.n * 4, hipMemcpyDeviceToDevice, st));
+    for (int l = 0; l < t->hnl; l++) {
+      G_HIP(hipMemcpyAsync(const_cast<float*>(dst.hl_gate_kernel[l]), w->hl_gate_kernel[l], t->hgk[l].n * 4, hipMemcpyDeviceToDevice, st));
+      G_HIP(hipMemcpyAsync(const_cast<float*>(dst.hl_gate_bias[l]), w->hl_gate_bias[l], t->hgb[l].n * 4, hipMemcpyDeviceToDevice, st));
+      G_HIP(hipMemcpyAsync(const_cast<float*>(dst.hl_cand_kernel[l]), w->hl_cand_kernel[l], t->hck[l].n * 4, hipMemcpyDeviceToDevice, st));
+      G_HIP(hipMemcpyAsync(const_cast<float*>(dst.hl_cand_bias[l]), w->hl_cand_bias[l], t->hcb[l].n * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
     return HIERTCN_OK;
   };
   if (int rc = fill()) {   // a handle with half-filled masters must not look like one that trains
@@ -773,25 +925,19 @@ size_t hiertcn_gmm_train_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int3
   return gt_ws(g, B, T).total;
 }
 
-int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, int64_t B, int32_t T, int32_t mode,
-                           const float* users_global, void* workspace, size_t workspace_bytes, double* out2, float* loss_rows, void* stream) {
-  GT_READY(g);
-  if (!x_ids || !y_ids || !workspace || B < 1 || T < 1 || T > 4096 || B > (int64_t)1 << 22) return gfail(HIERTCN_ERR_INVALID, "bad argument");
-  if (mode != 0 && mode != 1) return gfail(HIERTCN_ERR_INVALID, "mode %d: 0 (gmm_prob) or 1 (gmm_prob_max)", mode);
-  const GtWs w = gt_ws(g, B, T);
-  if (workspace_bytes < w.total) return gfail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.total);
-  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return gfail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
-  if ((int64_t)B * T > (int64_t)1 << 30) return gfail(HIERTCN_ERR_INVALID, "too many rows in one step");
+// The step behind hiertcn_gmm_train_step (x_ids: B sequences of T steps, lanes = sequences) and hiertcn_gmm_train_step_hier (rows_in: the dense
+// [e, state] rows of B * S sessions of L steps, lanes = users with S * L steps each; d_rows receives the gradient of those rows).  The caller has
+// refreshed the compute-layout copies and zeroed the gradient arena.
+static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* rows_in, const int32_t* y_ids, int64_t B, int32_t T, int64_t lanes, int32_t Tlane,
+                        int32_t mode, const float* users_global, unsigned char* ws, const GtWs& w, double* out2, float* loss_rows, float* d_rows, void* stream) {
   hipStream_t st = reinterpret_cast<hipStream_t>(stream);
   GmmTrain* t = g->train;
-  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
 #define F32(o) reinterpret_cast<float*>(ws + (o))
   const int64_t R = B * T;
   const int K = g->K, C = g->Clast, M = g->M, D = g->D, DP = g->DP, N = g->N, C0 = g->C0, nb = g->nb;
   const float* P = t->master();
   float* G = t->grad();
-  if (int rc = gt_refresh(g, st)) return rc;
-  G_HIP(hipMemsetAsync(G, 0, t->total * sizeof(float), st));
+  const int b0 = g->trunk == 2 ? 0 : 1;   // dense input rows: block 0 is an ordinary TemporalBlock on rows_in
 
   // ================= forward on the masters =================================================================================================
   const float* H = nullptr;
@@ -805,28 +951,31 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     G_HIP(launch_onehot_gru_records(og, x_ids, B, T, F32(w.hid), reinterpret_cast<int32_t*>(ws + w.seq_len), F32(w.states), F32(w.recs), st));
     H = F32(w.hid);
   } else {
-  hipLaunchKernelGGL(k_gt_block0, dim3((unsigned)((R * (C0 >> 2) + 255) / 256)), dim3(256), 0, st, P + t->conv[0].off, P + t->res[0].off, P + t->conv_b[0].off,
-                     P + t->res_b[0].off, x_ids, R, T, N, C0, K, F32(w.act[0]), F32(w.cact[0]));
-  G_HIP(hipGetLastError());
-  for (int i = 1, cin = C0; i < nb; cin = g->cfg.channels[i], i++) {
+  if (b0) {
+    hipLaunchKernelGGL(k_gt_block0, dim3((unsigned)((R * (C0 >> 2) + 255) / 256)), dim3(256), 0, st, P + t->conv[0].off, P + t->res[0].off, P + t->conv_b[0].off,
+                       P + t->res_b[0].off, x_ids, R, T, N, C0, K, F32(w.act[0]), F32(w.cact[0]));
+    G_HIP(hipGetLastError());
+  }
+  for (int i = b0, cin = (b0 ? C0 : g->cfg.input_dim); i < nb; cin = g->cfg.channels[i], i++) {
     const int cout = g->cfg.channels[i];
-    const float* res = F32(w.act[i - 1]);
+    const float* a_prev = (i == 0) ? rows_in : F32(w.act[i - 1]);
+    const float* res = a_prev;
     int64_t ldres = cin;
     if (cin != cout) {   // customized_tcn_cell.py:102-106: a biased Dense on the residual path
       XGemm r = {};
-      r.A = F32(w.act[i - 1]); r.lda = cin; r.Wt = t->resT[i]; r.taps = 1; r.Cin = cin; r.M = R; r.N = cout; r.bias = P + t->res_b[i].off;
+      r.A = a_prev; r.lda = cin; r.Wt = t->resT[i]; r.taps = 1; r.Cin = cin; r.M = R; r.N = cout; r.bias = P + t->res_b[i].off;
       r.out = F32(w.resb); r.ldo = cout; r.epi = XEPI_LINEAR;
       G_HIP(launch_xgemm(r, st));
       res = F32(w.resb); ldres = cout;
     }
     XGemm x = {};
-    x.A = F32(w.act[i - 1]); x.lda = cin; x.Wt = t->convT[i]; x.taps = K; x.dil = 1 << i; x.L = T; x.Cin = cin; x.M = R; x.N = cout;
+    x.A = a_prev; x.lda = cin; x.Wt = t->convT[i]; x.taps = K; x.dil = 1 << i; x.L = T; x.Cin = cin; x.M = R; x.N = cout;
     x.bias = P + t->conv_b[i].off; x.res = res; x.ldres = ldres; x.out = F32(w.act[i]); x.out2 = F32(w.cact[i]); x.ldo = cout; x.epi = XEPI_BLOCK;
     G_HIP(launch_xgemm(x, st));
   }
   H = F32(w.act[nb - 1]);
   }
-  G_HIP(train_lane_act(y_ids, (int)B, T, F32(w.lane_act), F32(w.users), st));
+  G_HIP(train_lane_act(y_ids, (int)lanes, Tlane, F32(w.lane_act), F32(w.users), st));
   float* loss = loss_rows ? loss_rows : F32(w.loss);
   const int Tn = g->learned ? 2 * M : M;
   if (g->learned) {
@@ -840,7 +989,7 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     }
     LearnedRows a;
     a.H = H; a.MUS = MUS; a.pw = t->pw; a.pb = t->pb; a.y = y_ids; a.act = F32(w.lane_act); a.users = users_global ? users_global : F32(w.users);
-    a.R = R; a.T = T; a.C = C; a.M = M; a.D = D; a.DP = DP; a.mode = mode;
+    a.R = R; a.T = Tlane; a.C = C; a.M = M; a.D = D; a.DP = DP; a.mode = mode;
     a.cst_over_D = (-0.5 * (double)D * log(2.0 * M_PI)) / (double)D;
     a.loss = loss; a.gl = F32(w.gv); a.dA = F32(w.dA); a.dH = F32(w.dH);
     const dim3 grid((unsigned)((R + 3) / 4));
@@ -873,7 +1022,7 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     HeadRows a;
     a.H = H; a.X = F32(w.X); a.Wt = t->Wt; a.bt = t->bt; a.pw = t->pw; a.pb = t->pb; a.vm = t->vm; a.cm = t->cm; a.y = y_ids;
     a.act = F32(w.lane_act); a.users = users_global ? users_global : F32(w.users);
-    a.R = R; a.T = T; a.C = C; a.M = M; a.D = D; a.DP = DP; a.mode = mode;
+    a.R = R; a.T = Tlane; a.C = C; a.M = M; a.D = D; a.DP = DP; a.mode = mode;
     const double sg = (double)g->cfg.sigma;
     a.inv_s2 = (float)(1.0 / (sg * sg));
     a.cst_over_D = (-(double)D * log(sg) - 0.5 * (double)D * log(2.0 * M_PI)) / (double)D;
@@ -898,7 +1047,7 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
   G_HIP(hipGetLastError());
   }
   if (out2) {
-    if (int rc = hiertcn_gmm_lane_loss(g, loss, y_ids, (int32_t)B, T, out2, stream)) return rc;
+    if (int rc = hiertcn_gmm_lane_loss(g, loss, y_ids, (int32_t)lanes, Tlane, out2, stream)) return rc;
   }
   // prior: d pi_w[m][:] = sum_r dA[r][m] h_r, d pi_b[m] = sum_r dA[r][m]
   G_HIP(gemm32_tn(F32(w.dA), GT_MP, H, C, t->dpw, C, GT_MP, C, (int)R, 0.f, t->splitk, t->splitk_floats, st));
@@ -1001,9 +1150,10 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
   float* ds = F32(w.ds);
   float* dc = F32(w.dc);
   float* sh = F32(w.sh);
-  for (int i = nb - 1; i >= 1; i--) {
-    const int cin = g->cfg.channels[i - 1], cout = g->cfg.channels[i];
-    const float* a_in = F32(w.act[i - 1]);
+  for (int i = nb - 1; i >= b0; i--) {
+    const int cin = (i == 0) ? g->cfg.input_dim : g->cfg.channels[i - 1], cout = g->cfg.channels[i];
+    const float* a_in = (i == 0) ? rows_in : F32(w.act[i - 1]);
+    if (i == 0) dprev = d_rows;   // the gradient of the dense input rows goes straight to the caller's buffer
     const int dil = 1 << i;
     const int64_t nOut = R * cout;
     G_HIP(train_block_bwd_f32(da, F32(w.act[i]), F32(w.cact[i]), nOut, ds, dc, st));
@@ -1030,8 +1180,8 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     }
     float* tmp = da; da = dprev; dprev = (tmp == F32(w.dH)) ? spare : tmp;
   }
-  // block 0: pointwise part, bias sums, then the row scatter-adds into the gathered tables
-  {
+  // block 0 on ids: pointwise part, bias sums, then the row scatter-adds into the gathered tables
+  if (b0) {
     const int64_t nOut = R * C0;
     G_HIP(train_block_bwd_f32(da, F32(w.act[0]), F32(w.cact[0]), nOut, ds, dc, st));
     G_HIP(train_colsum_f32(dc, R, C0, C0, G + t->conv_b[0].off, st));
@@ -1041,6 +1191,181 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
     G_HIP(hipGetLastError());
   }
   }
+#undef F32
+  return HIERTCN_OK;
+}
+
+int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, int64_t B, int32_t T, int32_t mode,
+                           const float* users_global, void* workspace, size_t workspace_bytes, double* out2, float* loss_rows, void* stream) {
+  GT_READY(g);
+  if (g->trunk != 0 && g->trunk != 1) return gfail(HIERTCN_ERR_STATE, "this handle reads dense rows (trunk %d): hiertcn_gmm_train_step_hier", g->trunk);
+  if (!x_ids || !y_ids || !workspace || B < 1 || T < 1 || T > 4096 || B > (int64_t)1 << 22) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  if (mode != 0 && mode != 1) return gfail(HIERTCN_ERR_INVALID, "mode %d: 0 (gmm_prob) or 1 (gmm_prob_max)", mode);
+  const GtWs w = gt_ws(g, B, T);
+  if (workspace_bytes < w.total) return gfail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, w.total);
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return gfail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
+  if ((int64_t)B * T > (int64_t)1 << 30) return gfail(HIERTCN_ERR_INVALID, "too many rows in one step");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  if (int rc = gt_refresh(g, st)) return rc;
+  G_HIP(hipMemsetAsync(g->train->grad(), 0, g->train->total * sizeof(float), st));
+  return gt_step_core(g, x_ids, nullptr, y_ids, B, T, B, T, mode, users_global, reinterpret_cast<unsigned char*>(workspace), w, out2, loss_rows, nullptr, stream);
+}
+
+// ---- model_hier with the tcn_gmm low level (model_hier.py:39-93; trunk 2): session mean-pool -> across-session scan (every record kept) -> [e, state] rows
+// -> the step above on those rows -> the rows' gradient back into the item table and the states -> backward through the S slots -> the pool's backward.
+// Extra workspace behind the trunk's: the high level's buffers.
+struct GtHierWs {
+  size_t pooled, scan, save, rows, drows, dsb, dpooled, dac_all, dag_all, dcar[2], dhpart, dcat_c, din_up, total;
+};
+static GtHierWs gt_hier_ws(const GmmTrain* t, int64_t B, int S, int L, size_t base) {
+  GtHierWs w;
+  memset(&w, 0, sizeof(w));
+  size_t off = base;
+  auto take = [&](size_t floats) { const size_t o = off; off += ((floats * 4) + 255) & ~(size_t)255; return o; };
+  const size_t E = (size_t)t->hE, H = (size_t)t->hH, nl = (size_t)t->hnl, HT = H * nl, W = E + HT, Bz = (size_t)B, R = Bz * S * L;
+  w.pooled = take(Bz * S * E);
+  w.scan = take(Bz * (S + 1) * HT + nl * Bz * 5 * H);       // launch_gru_scan's own: the state history [B][S + 1][HT] first (pool_gru.hip: gru_workspace_bytes)
+  w.save = take((size_t)S * nl * Bz * 5 * H);               // per (slot, layer): gates | r*h | candidate | unmasked output
+  w.rows = take(R * W);
+  w.drows = take(R * W);
+  w.dsb = take(Bz * (S + 1) * HT);
+  w.dpooled = take(Bz * S * E);
+  w.dac_all = take(nl * S * Bz * H);
+  w.dag_all = take(nl * S * Bz * 2 * H);
+  w.dcar[0] = take(Bz * HT);
+  w.dcar[1] = take(Bz * HT);
+  w.dhpart = take(Bz * H);
+  w.dcat_c = take(Bz * (W > 2 * H ? W : 2 * H));
+  w.din_up = take(Bz * H);
+  w.total = off;
+  return w;
+}
+
+size_t hiertcn_gmm_train_hier_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t S, int32_t L) {
+  if (!g || !g->train || !g->train->hE || B < 1 || S < 1 || L < 1) return 0;
+  return gt_hier_ws(g->train, B, S, L, gt_ws(g, B * S, L).total).total;
+}
+
+int hiertcn_gmm_train_step_hier(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in, int64_t B, int32_t S,
+                                int32_t L, int32_t mode, const float* users_global, void* workspace, size_t workspace_bytes, float* state_out, double* out2,
+                                float* loss_rows, void* stream) {
+  GT_READY(g);
+  GmmTrain* t = g->train;
+  if (g->trunk != 2 || !t->hE) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_train_step_hier is the step of trunk 2 enabled with the high level's variables");
+  if (!x_ids || !y_ids || !mask || !state_in || !state_out || !workspace || B < 1 || S < 1 || L < 1 || L > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
+  if (mode != 0 && mode != 1) return gfail(HIERTCN_ERR_INVALID, "mode %d: 0 (gmm_prob) or 1 (gmm_prob_max)", mode);
+  if (B > gemm32_skinny_max_rows()) return gfail(HIERTCN_ERR_INVALID, "%lld lanes: the across-session backward takes up to %d per step", (long long)B, gemm32_skinny_max_rows());
+  if ((int64_t)B * S * L > (int64_t)1 << 30) return gfail(HIERTCN_ERR_INVALID, "too many rows in one step");
+  const int64_t n_sess = B * S, R = n_sess * L;
+  const GtWs w = gt_ws(g, n_sess, L);
+  const GtHierWs hw = gt_hier_ws(t, B, S, L, w.total);
+  if (workspace_bytes < hw.total) return gfail(HIERTCN_ERR_WORKSPACE, "workspace %zu < required %zu bytes", workspace_bytes, hw.total);
+  if ((reinterpret_cast<uintptr_t>(workspace) & 255) != 0) return gfail(HIERTCN_ERR_INVALID, "workspace must be 256-byte aligned");
+  hipStream_t st = reinterpret_cast<hipStream_t>(stream);
+  unsigned char* ws = reinterpret_cast<unsigned char*>(workspace);
+#define F32(o) reinterpret_cast<float*>(ws + (o))
+  const int E = t->hE, H = t->hH, nl = t->hnl, HT = H * nl, W = E + HT, N = t->hN, Bi = (int)B;
+  const float* P = t->master();
+  float* G = t->grad();
+  if (int rc = gt_refresh(g, st)) return rc;
+  G_HIP(hipMemsetAsync(G, 0, t->total * sizeof(float), st));
+
+  // ---- forward of the high level on the masters: the reference's slot loop, restructured as everywhere in this library: the scan consumes the mean
+  // TARGET embeddings only, so it runs first for all slots and every (user, slot) is then an independent low-level problem
+  ModelDev md;
+  memset(static_cast<void*>(&md), 0, sizeof(md));
+  tuning_defaults(&md.tune);
+  md.tune.gru_scan_persistent = 0;           // (the persistent launch needs the main handle's LDS images: the chain of exact-fp32 cell products here)
+  md.hier = 1; md.N = N; md.E = E; md.H = H; md.nl = nl; md.HT = HT;
+  md.emb_bias = const_cast<float*>(P + t->hemb_b.off);
+  for (int l = 0; l < nl; l++) {
+    md.gru_wg[l] = t->hwg[l]; md.gru_bg[l] = const_cast<float*>(P + t->hgb[l].off);
+    md.gru_wc[l] = t->hwc[l]; md.gru_bc[l] = const_cast<float*>(P + t->hcb[l].off);
+  }
+  ExactDev xd;
+  memset(&xd, 0, sizeof(xd));
+  xd.emb = const_cast<float*>(P + t->hemb.off);
+  float* pooled = F32(hw.pooled);
+  float* hist = F32(hw.scan);                 // [B][S + 1][HT]
+  float* save = F32(hw.save);
+  G_HIP(launch_xsession_pool(md, xd, y_ids, n_sess, L, pooled, st));
+  G_HIP(launch_gru_scan(md, pooled, mask, state_in, Bi, S, nullptr, state_out, nullptr, hist, st, save));
+  hipLaunchKernelGGL(k_gt_hier_rows, dim3((unsigned)((R * (W >> 2) + 255) / 256)), dim3(256), 0, st, xd.emb, x_ids, hist, R, S, L, E, HT, N, F32(hw.rows));
+  G_HIP(hipGetLastError());
+
+  // ---- the low level + head, forward and backward, on those rows (lanes = users, S * L steps each)
+  if (int rc = gt_step_core(g, nullptr, F32(hw.rows), y_ids, n_sess, L, B, S * L, mode, users_global, ws, w, out2, loss_rows, F32(hw.drows), stream)) return rc;
+
+  // ---- the rows' gradient: item-table rows (scatter-add) and the states the rows read
+  float* dsb = F32(hw.dsb);
+  G_HIP(hipMemsetAsync(dsb, 0, (size_t)B * (S + 1) * HT * 4, st));
+  hipLaunchKernelGGL(k_gt_hier_rows_bwd, dim3((unsigned)((n_sess * (W >> 2) + 255) / 256)), dim3(256), 0, st, F32(hw.drows), x_ids, n_sess, S, L, E, HT, N,
+                     G + t->hemb.off, dsb);
+  G_HIP(hipGetLastError());
+
+  // ---- backward through the S slots (customed_gru_cell.py:323-337 differentiated, model_hier.py:91-93): three launches per cell
+  const size_t cell = (size_t)B * 5 * H;
+  const int64_t hs = (int64_t)(S + 1) * HT;      // row stride of the state history / of dsb
+  float* dcar = F32(hw.dcar[0]);
+  float* dnext = F32(hw.dcar[1]);
+  float* dpooled = F32(hw.dpooled);
+  float* dhpart = F32(hw.dhpart);
+  float* dcat_c = F32(hw.dcat_c);
+  float* din_up = F32(hw.din_up);
+  float* dac_all = F32(hw.dac_all);
+  float* dag_all = F32(hw.dag_all);
+  G_HIP(hipMemsetAsync(dcar, 0, (size_t)B * HT * 4, st));     // the state behind the last slot is an output, not part of the loss
+  for (int sl = S - 1; sl >= 0; sl--) {
+    for (int l = nl - 1; l >= 0; l--) {
+      const int in = (l == 0) ? E : H, Kc = in + H;
+      const float* rec = save + ((size_t)sl * nl + l) * cell;
+      const float* gates = rec;
+      const float* cand = rec + (size_t)B * 3 * H;
+      const float* hold = hist + (size_t)sl * HT + (size_t)l * H;        // row stride hs
+      float* dac = dac_all + ((size_t)l * S + sl) * B * H;
+      float* dag = dag_all + ((size_t)l * S + sl) * B * 2 * H;
+      hipLaunchKernelGGL(k_gt_hl_bwd_a, dim3((unsigned)(((int64_t)B * H + 255) / 256)), dim3(256), 0, st, dcar + (size_t)l * H, HT,
+                         dsb + (size_t)(sl + 1) * HT + (size_t)l * H, hs, mask + sl, S, (l == nl - 1) ? nullptr : din_up, hold, hs, gates, cand, Bi, H, dac, dag, dhpart);
+      G_HIP(hipGetLastError());
+      GruBwdEpi ep;
+      memset(&ep, 0, sizeof(ep));
+      ep.in = in; ep.H = H; ep.K = Kc;
+      ep.gates = gates; ep.h = hold; ep.ldh = (int)hs; ep.dag = dag; ep.dhpart = dhpart; ep.dcat_c = dcat_c;
+      ep.dst_in = (l == 0) ? dpooled + (size_t)sl * E : din_up; ep.ldi = (l == 0) ? S * E : H;
+      ep.dst_h = dnext + (size_t)l * H; ep.ldo = HT;
+      G_HIP(gemm32_nn_gru_bwd(1, dac, H, t->hwc[l], Kc, Bi, Kc, H, ep, st));
+      G_HIP(gemm32_nn_gru_bwd(2, dag, 2 * H, t->hwg[l], Kc, Bi, Kc, 2 * H, ep, st));
+    }
+    float* tmp = dcar; dcar = dnext; dnext = tmp;
+  }
+  // weight gradients of all S * nl cells: one product per layer and operand over the S * B rows (rows (slot, user))
+  const int SB = S * Bi;
+  for (int l = 0; l < nl; l++) {
+    const int in = (l == 0) ? E : H, Kc = in + H;
+    const float* dac = dac_all + (size_t)l * S * B * H;
+    const float* dag = dag_all + (size_t)l * S * B * 2 * H;
+    const int64_t rss = (int64_t)((size_t)nl * cell);
+    const float* rh = save + (size_t)l * cell + (size_t)B * 2 * H;
+    const float* hold = hist + (size_t)l * H;
+    if (l == 0) {   // input = pooled[b][slot]: row (slot, b) at slot * E + b * (S * E)
+      G_HIP(gemm32_tn_slabs(dac, H, 0, 0, pooled, (int64_t)S * E, Bi, E, t->dhwc[l], Kc, H, in, SB, 0.f, t->splitk, t->splitk_floats, st));
+      G_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, pooled, (int64_t)S * E, Bi, E, t->dhwg[l], Kc, 2 * H, in, SB, 0.f, t->splitk, t->splitk_floats, st));
+    } else {
+      const float* inp = save + (size_t)(l - 1) * cell + (size_t)B * 4 * H;
+      G_HIP(gemm32_tn_slabs(dac, H, 0, 0, inp, H, Bi, rss, t->dhwc[l], Kc, H, in, SB, 0.f, t->splitk, t->splitk_floats, st));
+      G_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, inp, H, Bi, rss, t->dhwg[l], Kc, 2 * H, in, SB, 0.f, t->splitk, t->splitk_floats, st));
+    }
+    G_HIP(gemm32_tn_slabs(dac, H, 0, 0, rh, H, Bi, rss, t->dhwc[l] + in, Kc, H, H, SB, 0.f, t->splitk, t->splitk_floats, st));
+    G_HIP(gemm32_tn_slabs(dag, 2 * H, 0, 0, hold, hs, Bi, HT, t->dhwg[l] + in, Kc, 2 * H, H, SB, 0.f, t->splitk, t->splitk_floats, st));
+    G_HIP(train_colsum_f32(dac, SB, H, H, G + t->hcb[l].off, st));
+    G_HIP(train_colsum_f32(dag, SB, 2 * H, 2 * H, G + t->hgb[l].off, st));
+    G_HIP(gt_transpose(t->dhwg[l], Kc, G + t->hgk[l].off, 2 * H, 2 * H, Kc, st));   // -> the reference layout [in + H][2H]
+    G_HIP(gt_transpose(t->dhwc[l], Kc, G + t->hck[l].off, H, H, Kc, st));
+  }
+  // ---- session mean-pool + bias
+  hipLaunchKernelGGL(k_gt_pool_bwd, dim3((unsigned)((n_sess * (E >> 2) + 255) / 256)), dim3(256), 0, st, dpooled, y_ids, n_sess, L, E, N, G + t->hemb.off);
+  G_HIP(hipGetLastError());
+  G_HIP(train_colsum_f32(dpooled, n_sess, E, E, G + t->hemb_b.off, st));
 #undef F32
   return HIERTCN_OK;
 }
@@ -1102,6 +1427,16 @@ int hiertcn_gmm_train_copy(hiertcn_gmm_handle_t g, int32_t which, int32_t to_han
   }
   G_HIP(cp(a.head_weights, bufs->head_weights, t->head_w.n));
   G_HIP(cp(a.head_biases, bufs->head_biases, t->head_b.n));
+  if (t->hE) {
+    G_HIP(cp(a.hl_emb_kernel, bufs->hl_emb_kernel, t->hemb.n));
+    G_HIP(cp(a.hl_emb_bias, bufs->hl_emb_bias, t->hemb_b.n));
+    for (int l = 0; l < t->hnl; l++) {
+      G_HIP(cp(a.hl_gate_kernel[l], bufs->hl_gate_kernel[l], t->hgk[l].n));
+      G_HIP(cp(a.hl_gate_bias[l], bufs->hl_gate_bias[l], t->hgb[l].n));
+      G_HIP(cp(a.hl_cand_kernel[l], bufs->hl_cand_kernel[l], t->hck[l].n));
+      G_HIP(cp(a.hl_cand_bias[l], bufs->hl_cand_bias[l], t->hcb[l].n));
+    }
+  }
   if (to_handle && which == 0) t->stale = true;
   return HIERTCN_OK;
 }

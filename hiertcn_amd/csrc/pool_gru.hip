@@ -434,7 +434,7 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
       i = j;
     }
   }
-  {  // state half of the input projection for every slot at once: [B*(S+1), HT] x [HT, E]
+  if (sproj) {  // state half of the input projection for every slot at once: [B*(S+1), HT] x [HT, E]  (null: a caller without that projection, gmm_train.hip)
     GemmArgs g;
     memset(&g, 0, sizeof(g));
     g.M = B * (S + 1); g.N = E; g.A1 = hist; g.lda1 = HT; g.K1 = HT; g.K2 = 0;

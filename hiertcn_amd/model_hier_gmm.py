@@ -15,6 +15,9 @@ What the reference does with `pred` afterwards cannot be run (it feeds the [B, T
 model_low_type 'gru_gmm' (model_hier.py:68-69 -> model_gru_gmm.py:33-54) is the same with trunk 3: the MultiRNNCell of GRUCells under dynamic_rnn on
 the x_slice rows (sequence_length = the count of rows that are not all-zero), variables hier/rnn_gmm/rnn/multi_rnn_cell/cell_l/gru_cell/... and
 hier/rnn_gmm/fully_connected/{weights,biases} (model_gru_gmm's default scope name 'rnn_gmm' under 'hier').
+Training (round 6): with the 'tcn_gmm' low level the WHOLE model -- item table, emb bias, across-session cells, TemporalConvNet, head -- trains as one
+step on the mixture handle (csrc/gmm_train.hip, hiertcn_gmm_train_step_hier; HierGmmModel.enable_training / train_step_hier); evaluation afterwards
+re-uploads the high level into the main handle (sync).  The 'gru_gmm' low level evaluates only.
 """
 from __future__ import annotations
 
@@ -109,13 +112,16 @@ class HierGmmModel(TcnGmmModel):
                 ep[k] = v
         self.engine = Engine(sa, hier=True)
         self.engine.set_weights(ep)
+        self._engine_params = ep     # (the main handle's own, never-run low level keeps these initial values when sync() re-uploads the high level)
         if self.low == "gru_gmm":
             cfg = _lib.GmmConfig(item_num=0, output_dim=self.D, num_mixture=self.M, kernel_size=1, n_blocks=0,
                                  sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=3, hidden_dim=int(args.hidden_dim),
                                  num_layer=int(args.num_layer), input_dim=self.E + self.HT)
         else:
-            cfg = _lib.GmmConfig(item_num=0, output_dim=self.D, num_mixture=self.M, kernel_size=int(args.kernel_size), n_blocks=len(ch),
-                                 sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=2, input_dim=self.E + self.HT)
+            # (item_num / hidden_dim / num_layer: ignored by the evaluation of trunk 2, they describe the HIGH level to hiertcn_gmm_train_enable)
+            cfg = _lib.GmmConfig(item_num=self.N, output_dim=self.D, num_mixture=self.M, kernel_size=int(args.kernel_size), n_blocks=len(ch),
+                                 sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=2, hidden_dim=int(args.hidden_dim),
+                                 num_layer=int(args.num_layer), input_dim=self.E + self.HT)
             for i, c in enumerate(ch):
                 cfg.channels[i] = c
         cfg.table_pass = 1 if os.environ.get("HIERTCN_GMM_TABLE_PASS") else 0   # A/B runs, tests: never the Gram form (read here, once; the library reads no environment)
@@ -153,6 +159,91 @@ class HierGmmModel(TcnGmmModel):
         _ck(self.lib.hiertcn_gmm_set_weights(self._h, C.byref(w), C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
         torch.cuda.current_stream().synchronize()
 
+    # -- training (csrc/gmm_train.hip, hiertcn_gmm_train_step_hier): model_hier with the tcn_gmm low level as ONE step on the mixture handle ------------
+    def _weights_struct(self, bufs):
+        root = f"{self.name}/tcn_gmm"
+        w = _lib.GmmWeights()
+        p = lambda k: bufs[k].data_ptr()  # noqa: E731
+        for i in range(len(self.args.tcn_channel)):
+            pre = f"{root}/temporal_conv_net/tblock_{i}"
+            w.conv_kernel[i], w.conv_bias[i] = p(f"{pre}/conv1/kernel"), p(f"{pre}/conv1/bias")
+            if f"{pre}/dense/kernel" in bufs:
+                w.res_kernel[i], w.res_bias[i] = p(f"{pre}/dense/kernel"), p(f"{pre}/dense/bias")
+        w.head_weights, w.head_biases = p(f"{root}/fully_connected/weights"), p(f"{root}/fully_connected/biases")
+        w.hl_emb_kernel, w.hl_emb_bias = p(f"{self.name}/emb/kernel"), p(f"{self.name}/emb/bias")
+        for l in range(int(self.args.num_layer)):
+            pre = f"{self.name}/multi_rnn_cell/cell_{l}/gru_cell"
+            w.hl_gate_kernel[l], w.hl_gate_bias[l] = p(f"{pre}/gates/kernel"), p(f"{pre}/gates/bias")
+            w.hl_cand_kernel[l], w.hl_cand_bias[l] = p(f"{pre}/candidate/kernel"), p(f"{pre}/candidate/bias")
+        return w
+
+    def enable_training(self):
+        if self.low != "tcn_gmm":
+            raise NotImplementedError("model_hier with model_low_type 'gru_gmm' evaluates only: the training step of the mixture low levels is built for 'tcn_gmm' "
+                                      "(csrc/gmm_train.hip, hiertcn_gmm_train_step_hier)")
+        super().enable_training()
+
+    def train_forward_backward(self, *a, **k):   # (TcnGmmModel's id-input step does not apply to this trunk)
+        raise HierTCNError("HierGmmModel trains through train_forward_backward_hier / train_step_hier (ids [B, S, L], mask, state)")
+
+    def train_forward_backward_hier(self, xd: torch.Tensor, yd: torch.Tensor, md: torch.Tensor, st: torch.Tensor, mode: Optional[str] = None,
+                                    users_global: Optional[torch.Tensor] = None, want_rows: bool = False) -> dict:
+        """packed ids xd, yd [B, S, L] int32, mask md [B, S] fp32, carried state st [B, HT] fp32 (all on the device) -> the gradients of EVERY variable of
+        model_hier + model_tcn_gmm (item table, emb bias, across-session cells, TemporalConvNet, head) in the handle's gradient arena;
+        returns dict(sums = [sum of lane means, users], state = the carried state behind the last slot[, loss_rows [B, S * L]])."""
+        if not getattr(self, "_training", False):
+            raise HierTCNError("enable_training() first")
+        mode = mode or getattr(self.args, "loss", "gmm_prob")
+        if mode not in self.MODES:
+            raise NotImplementedError(f"args.loss={mode!r}: the mixture models train on 'gmm_prob' or 'gmm_prob_max' (loss.py:247-257)")
+        B, S, L = xd.shape
+        for t, name, dt, shape in ((xd, "x_ids", torch.int32, (B, S, L)), (yd, "y_ids", torch.int32, (B, S, L)), (md, "mask", torch.float32, (B, S)),
+                                   (st, "state", torch.float32, (B, self.HT))):
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous() or tuple(t.shape) != shape:
+                raise HierTCNError(f"{name}: a contiguous {dt} device tensor {shape}")
+        need = int(self.lib.hiertcn_gmm_train_hier_workspace_bytes(self._h, B, S, L))
+        if self._train_ws is None or self._train_ws.numel() < need:
+            self._train_ws = torch.empty(need, dtype=torch.uint8, device=self.device)
+        out2 = torch.empty(2, dtype=torch.float64, device=self.device)
+        state_out = torch.empty((B, self.HT), dtype=torch.float32, device=self.device)
+        rows = torch.empty((B, S * L), dtype=torch.float32, device=self.device) if want_rows else None
+        p = lambda t: C.c_void_p(t.data_ptr()) if t is not None else None  # noqa: E731
+        _ck(self.lib.hiertcn_gmm_train_step_hier(self._h, p(xd), p(yd), p(md), p(st), B, S, L, self.MODES[mode], p(users_global), p(self._train_ws),
+                                                 self._train_ws.numel(), p(state_out), p(out2), p(rows), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+            self.lib)
+        out = dict(sums=out2, state=state_out)
+        if want_rows:
+            out["loss_rows"] = rows
+        return out
+
+    def train_step_hier(self, xd, yd, md, st, lr: float, mode: Optional[str] = None) -> dict:
+        """One optimizer step (run_hier_xing.py:275-301 with the mixture low level): forward + backward + [data parallel: global user count in the loss
+        normaliser, one all-reduce of the flat gradient arena] + TF-form Adam."""
+        from . import distributed as hd
+        users = None
+        if hd._is_dist():
+            users = (yd.reshape(yd.shape[0], -1) > 0).any(dim=1).sum().to(torch.float32).reshape(1)
+            hd._sum_async(users).wait()
+        out = self.train_forward_backward_hier(xd, yd, md, st, mode, users_global=users)
+        if hd._is_dist():
+            hd._sum_async(self.arena(1)).wait()
+            hd.all_reduce_metrics(out["sums"])
+        self.adam_step(lr)
+        return out
+
+    def sync(self):
+        """Evaluation reads the 16-bit tables of BOTH handles: the mixture handle's (hiertcn_gmm_train_sync) and the main handle's item table / emb bias /
+        across-session cells, which the training step keeps as masters on the mixture handle."""
+        if getattr(self, "_training", False) and getattr(self, "_stale", False):
+            super().sync()
+            w = self.export("weights")
+            self.params = w
+            ep = dict(self._engine_params)
+            for k, v in w.items():
+                if k.startswith(f"{self.name}/emb/") or k.startswith(f"{self.name}/multi_rnn_cell/"):
+                    ep[k] = v
+            self.engine.set_weights(ep)
+
     def forward_rows(self, rows: torch.Tensor, n_seq: int, L: int) -> torch.Tensor:
         """rows [n_seq*L, E + HT] (storage type) -> last TCN activations [n_seq*L, C]."""
         hidden = torch.empty((n_seq * L, self.C), dtype=torch.bfloat16, device=self.device)
@@ -169,6 +260,7 @@ class HierGmmModel(TcnGmmModel):
 
     def forward_hier(self, xd: torch.Tensor, yd: torch.Tensor, md: torch.Tensor, st: torch.Tensor):
         """packed ids xd, yd [B, S, L] int32, mask md [B, S] fp32, state st [B, HT] fp32 -> (hidden [B*S*L, C], state_out [B, HT])."""
+        self.sync()
         eng = self.engine
         B, S, L = xd.shape
         pooled = eng.session_pool(yd.view(B * S, L)).view(B, S, -1)

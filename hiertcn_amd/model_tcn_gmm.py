@@ -169,7 +169,8 @@ class TcnGmmModel:
 
     def enable_training(self):
         """fp32 masters (filled from self.params), gradients and Adam moments on the device: hiertcn_gmm_train_enable.  The models on ids
-        (model_tcn_gmm, model_gru_gmm), fixed or learned scale; the mixture low levels of model_hier raise (the library refuses them)."""
+        (model_tcn_gmm, model_gru_gmm) and model_hier with the tcn_gmm low level (HierGmmModel), fixed or learned scale; model_hier's gru_gmm low
+        level raises (the library refuses it)."""
         if getattr(self, "_training", False):
             return
         bufs = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device).contiguous() for k, v in self.params.items()}

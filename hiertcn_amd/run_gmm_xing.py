@@ -6,8 +6,8 @@ What the reference itself does with these models on XING cannot be run: its grap
 calc_metric_fast against the [B, T, item_num] one-hot targets (model.py:105-132), whose last dimensions differ, and calc_loss_gmm has no
 caller.  This loop therefore reports the mixture loss only; the rank metrics of results.txt do not exist for a density model and are
 written as nan.  Training (--train): model_tcn_gmm and model_gru_gmm (fixed or learned scale) step through csrc/gmm_train.hip (the gradient of
-this loop's own loss: the decode is the build's, so is its derivative -- checked against fp64 autograd, tests/test_gpu_gmm_train.py); the
-mixture low levels of model_hier evaluate only and say so.
+this loop's own loss: the decode is the build's, so is its derivative -- checked against fp64 autograd, tests/test_gpu_gmm_train.py).  (The
+mixture low levels of model_hier have no run loop -- the reference's run_hier cannot build their graph: HierGmmModel.train_step_hier.)
 """
 from __future__ import annotations
 

@@ -228,13 +228,21 @@ def test_what_is_not_built_says_so():
     with pytest.raises(NotImplementedError):
         m.train_forward_backward(dev(np.zeros((2, 3), np.int32)), dev(np.zeros((2, 3), np.int32)), mode="gmm_prob_hinge")
     m.close()
-    # the mixture low levels of model_hier (dense input rows: trunks 2 / 3) evaluate only: the library refuses
+    # model_hier's gru_gmm low level (trunk 3) evaluates only, and trunk 2 trains only together with the high level's variables: the library says so
     import ctypes as C
 
     from hiertcn_amd import _lib
     lib = _lib.load()
-    cfg = _lib.GmmConfig(item_num=300, output_dim=300, num_mixture=2, kernel_size=3, n_blocks=1, sigma=0.1, trunk=2, input_dim=64)
+    cfg = _lib.GmmConfig(item_num=300, output_dim=300, num_mixture=2, kernel_size=3, n_blocks=1, sigma=0.1, trunk=2, input_dim=128, hidden_dim=32, num_layer=2)
     cfg.channels[0] = 64
+    h2 = C.c_void_p()
+    assert lib.hiertcn_gmm_create(C.byref(h2), C.byref(cfg)) == 0
+    w2 = _lib.GmmWeights()
+    one = torch.zeros(8, device="cuda")
+    w2.head_weights = w2.head_biases = one.data_ptr()
+    assert lib.hiertcn_gmm_train_enable(h2, C.byref(w2), None) != 0 and b"hl_emb_kernel" in lib.hiertcn_gmm_last_error()
+    lib.hiertcn_gmm_destroy(h2)
+    cfg = _lib.GmmConfig(item_num=300, output_dim=300, num_mixture=2, sigma=0.1, trunk=3, input_dim=64, hidden_dim=64, num_layer=1)
     h = C.c_void_p()
     assert lib.hiertcn_gmm_create(C.byref(h), C.byref(cfg)) == 0
     w = _lib.GmmWeights()
@@ -549,3 +557,154 @@ def test_learned_scale_every_gradient_against_fp64_autograd(trunk, N, M, width, 
     assert np.array_equal(model.eval_step(x, y)["sums"].cpu().numpy(), fresh.eval_step(x, y)["sums"].cpu().numpy())
     model.close()
     fresh.close()
+
+
+# ---- model_hier with the tcn_gmm low level (model_hier.py:39-93 around model_tcn_gmm): the whole model trains as one step ---------------------------
+def torch_hier_loss(a, P, x, y, mask, st0, mode, scope="hier"):
+    """fp64: the reference's slot loop, literally -- per slot the [emb(x), carried state] rows into the TemporalConvNet (block 0 an ordinary block on
+    them) and the head, then the high level (mean target embedding + bias -> MultiRNNCell -> state * mask) -- and the lane-mean mixture loss over the
+    concatenated slots.  -> (loss, loss rows [B, S * L], final state)."""
+    xt, yt = torch.as_tensor(x.astype(np.int64)), torch.as_tensor(y.astype(np.int64))
+    mk = torch.as_tensor(mask.astype(np.float64))
+    B, S, L = xt.shape
+    E, H, nl, K = int(a.emb_dim), int(a.hidden_dim), int(a.num_layer), int(a.kernel_size)
+    emb, eb = P[f"{scope}/emb/kernel"], P[f"{scope}/emb/bias"]
+    state = torch.as_tensor(st0.astype(np.float64))
+    preds = []
+    root = f"{scope}/tcn_gmm"
+    for s in range(S):
+        xe = emb[xt[:, s]] * (xt[:, s] > 0).to(torch.float64)[..., None]
+        act = torch.cat([xe, state[:, None, :].expand(B, L, H * nl)], -1)
+        for i in range(len(a.tcn_channel)):
+            pre = f"{root}/temporal_conv_net/tblock_{i}"
+            Wc, bc = P[f"{pre}/conv1/kernel"], P[f"{pre}/conv1/bias"]
+            dil = 2 ** i
+            c = bc.expand(B, L, -1).clone()
+            for j in range(K):
+                sh = (K - 1 - j) * dil
+                if sh >= L:
+                    continue
+                z = act @ Wc[j]
+                c = c + (torch.nn.functional.pad(z, (0, 0, sh, 0))[:, :L] if sh else z)
+            res = act @ P[f"{pre}/dense/kernel"] + P[f"{pre}/dense/bias"] if f"{pre}/dense/kernel" in P else act
+            act = torch.relu(torch.relu(c) + res)
+        preds.append(act @ P[f"{root}/fully_connected/weights"] + P[f"{root}/fully_connected/biases"])
+        ys = yt[:, s]
+        valid = (ys > 0).to(torch.float64)
+        inp = (emb[ys] * valid[..., None]).sum(1) / valid.sum(1, keepdim=True) + eb
+        new = []
+        for l in range(nl):
+            pre = f"{scope}/multi_rnn_cell/cell_{l}/gru_cell"
+            h = state[:, l * H:(l + 1) * H]
+            gates = torch.sigmoid(torch.cat([inp, h], 1) @ P[f"{pre}/gates/kernel"] + P[f"{pre}/gates/bias"])
+            r, u = gates[:, :H], gates[:, H:]
+            cnd = torch.tanh(torch.cat([inp, r * h], 1) @ P[f"{pre}/candidate/kernel"] + P[f"{pre}/candidate/bias"])
+            hn = u * h + (1 - u) * cnd
+            new.append(hn)
+            inp = hn
+        state = torch.cat(new, 1) * mk[:, s:s + 1]
+    pred = torch.cat(preds, 1)                                   # [B, S * L, n_out]
+    yy = yt.reshape(B, S * L)
+    rows = _mix_rows(a, pred, yy, mode)
+    m = (yy > 0).to(torch.float64)
+    cnt = m.sum(1)
+    loss = ((rows * m).sum(1) / (cnt + 1e-6)).sum() / (cnt > 0).sum()
+    return loss, rows * m, state
+
+
+@pytest.mark.parametrize("mode", ["gmm_prob", "gmm_prob_max"])
+@pytest.mark.parametrize("N,E,H,nl,M,channels,K,B,S,L", [(900, 64, 32, 2, 3, (64, 128), 3, 5, 4, 7), (500, 64, 64, 1, 2, (128,), 2, 3, 5, 6),
+                                                         (1500, 128, 64, 2, 4, (128, 128), 5, 6, 3, 12)])
+def test_hier_low_level_every_gradient_against_fp64_autograd(N, E, H, nl, M, channels, K, B, S, L, mode):
+    from hiertcn_amd import model_hier_gmm as HG
+    from hiertcn_amd.args import hier_tcn_args
+    from tests.gpu_common import as_lists, make_batch
+    a = hier_tcn_args(item_num=N, output_dim=N, emb_dim=E, hidden_dim=H, num_layer=nl, tcn_channel=list(channels), kernel_size=K, num_mixture=M,
+                      model_low_type="tcn_gmm", loss=mode, sigma=0.1)
+    p = G.init_params_hier(a, seed=N % 83)
+    rng = np.random.default_rng(N + E)
+    for k in p:
+        if (k.endswith("/bias") and "gates" not in k) or k.endswith("biases"):
+            p[k] = (p[k] + 0.05 * rng.standard_normal(p[k].shape)).astype(np.float32)
+    x, y, mask = make_batch(rng, B, S, L, N)
+    mask[0, 1] = 0.0                                             # a user boundary inside the batch: the state restarts from zero behind it
+    st0 = (0.3 * rng.standard_normal((B, H * nl))).astype(np.float32)
+    P = {k: torch.tensor(np.asarray(v, np.float64), requires_grad=True) for k, v in p.items()}
+    loss_ref, rows_ref, st_ref = torch_hier_loss(a, P, x, y, mask, st0, mode)
+    loss_ref.backward()
+    # the torch formulation's forward against the NumPy oracle of the same model
+    xl, yl, ml = as_lists(x, y, mask)
+    pred_o, st_o = G.model_hier_tcn_gmm(a, xl, yl, ml, st0, {k: np.asarray(v, np.float64) for k, v in p.items()})
+    yy = y.reshape(B, S * L)
+    want_rows = G.calc_loss_gmm_ids(pred_o, yy, a) * (yy > 0)
+    assert np.abs(rows_ref.detach().numpy() - want_rows).max() < 1e-9 * max(1.0, np.abs(want_rows).max())
+    assert np.abs(st_ref.detach().numpy() - st_o).max() < 1e-12
+    model = HG.HierGmmModel(a, p, "hier")
+    model.enable_training()
+    out = model.train_forward_backward_hier(dev(x), dev(y), dev(mask), dev(st0), mode, want_rows=True)
+    rows = out["loss_rows"].cpu().numpy()
+    live = yy > 0
+    assert not rows[~live].any()
+    assert np.abs(rows - want_rows)[live].max() < 5e-6 * max(1.0, np.abs(want_rows).max()), np.abs(rows - want_rows)[live].max()
+    np.testing.assert_allclose(out["state"].cpu().numpy(), st_o, atol=2e-6, rtol=0)
+    sums = out["sums"].cpu().numpy()
+    assert abs(sums[0] / sums[1] - float(loss_ref.detach())) < 5e-6 * max(1.0, abs(float(loss_ref.detach())))
+    grads = model.export("grads")
+    assert set(grads) == set(P)
+    for k, t in P.items():
+        ref = t.grad.numpy()
+        got = grads[k].astype(np.float64)
+        assert got.shape == ref.shape and np.linalg.norm(ref) > 0, k
+        err = np.linalg.norm(got - ref) / np.linalg.norm(ref)
+        assert err < 5e-5, (k, err)
+    # one optimizer step; evaluation (main handle: pool / scan / rows; mixture handle: trunk + head) then sees the updated weights of BOTH handles
+    from hiertcn_amd.model_hier import model_hier  # noqa: F401
+    before = model.forward_hier(dev(x), dev(y), dev(mask), dev(st0))[1].cpu().numpy()
+    model.adam_step(1e-2)
+    after_h, after_state = model.forward_hier(dev(x), dev(y), dev(mask), dev(st0))
+    fresh = HG.HierGmmModel(a, model.export("weights"), "hier")
+    fresh_h, fresh_state = fresh.forward_hier(dev(x), dev(y), dev(mask), dev(st0))
+    assert torch.equal(after_h, fresh_h) and torch.equal(after_state, fresh_state)
+    assert np.abs(after_state.cpu().numpy() - before).max() > 1e-5                       # the across-session cells moved
+    model.close()
+    fresh.close()
+
+
+def test_hier_low_level_adam_trajectory_and_what_is_refused():
+    from hiertcn_amd import model_hier_gmm as HG
+    from hiertcn_amd.args import hier_tcn_args
+    from tests.gpu_common import make_batch
+    N, E, H, nl, M, B, S, L = 700, 64, 32, 2, 3, 4, 3, 6
+    a = hier_tcn_args(item_num=N, output_dim=N, emb_dim=E, hidden_dim=H, num_layer=nl, tcn_channel=[64, 64], kernel_size=3, num_mixture=M,
+                      model_low_type="tcn_gmm", loss="gmm_prob", sigma=0.1)
+    p = G.init_params_hier(a, seed=6)
+    rng = np.random.default_rng(2)
+    batches = [make_batch(rng, B, S, L, N) for _ in range(5)]
+    lr = 2e-3
+    ref = {k: np.asarray(v, np.float64).copy() for k, v in p.items()}
+    m1 = {k: np.zeros_like(v) for k, v in ref.items()}
+    m2 = {k: np.zeros_like(v) for k, v in ref.items()}
+    st_ref = np.zeros((B, H * nl))
+    model = HG.HierGmmModel(a, p, "hier")
+    model.enable_training()
+    st_dev = torch.zeros((B, H * nl), device="cuda")
+    for t, (x, y, mask) in enumerate(batches, 1):
+        P = {k: torch.tensor(v, requires_grad=True) for k, v in ref.items()}
+        loss, _, st_new = torch_hier_loss(a, P, x, y, mask, st_ref, "gmm_prob")
+        loss.backward()
+        _adam_fp64(ref, {k: P[k].grad.numpy() for k in ref}, m1, m2, t, lr)
+        st_ref = st_new.detach().numpy()                                                   # the carried state is re-fed as data (run_hier_xing.py:291,301)
+        out = model.train_step_hier(dev(x), dev(y), dev(mask), st_dev, lr)
+        st_dev = out["state"]
+        s = out["sums"].cpu().numpy()
+        assert abs(s[0] / s[1] - float(loss.detach())) < 1e-5 * max(1.0, abs(float(loss.detach()))), t
+        np.testing.assert_allclose(st_dev.cpu().numpy(), st_ref, atol=5e-5, rtol=0)
+    w = model.export("weights")
+    for k in ref:
+        assert np.abs(w[k] - ref[k]).max() < 5e-5 * max(np.abs(ref[k]).max(), 1.0), (k, np.abs(w[k] - ref[k]).max())
+    model.close()
+    ag = hier_tcn_args(item_num=N, output_dim=N, emb_dim=E, hidden_dim=64, num_layer=1, num_mixture=M, model_low_type="gru_gmm", loss="gmm_prob", sigma=0.1)
+    mg = HG.HierGmmModel(ag, None, "hier")
+    with pytest.raises(NotImplementedError, match="gru_gmm"):
+        mg.enable_training()
+    mg.close()
