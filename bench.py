@@ -285,8 +285,8 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     return {"training": {"what": "one optimizer step of model_tcn_gmm (fixed scale, gmm_prob): fp32 forward on the masters + backward of every variable + TF-form "
                                  "Adam (csrc/gmm_train.hip: the head's backward through G_m = W_m W_m^T, no [rows][M D] matrix; block 0's one-hot rows as "
                                  "scatter-adds), 32 lanes x 200 steps = 6,400 rows, ids resident; ms_per_step_gru_gmm: the same step of model_gru_gmm "
-                                 "(2-layer GRU stack on the one-hot rows, backward through the 200 steps as a launch chain); model_hier's gru_gmm low level "
-                                 "evaluates only",
+                                 "(2-layer GRU stack on the one-hot rows, backward through the 200 steps as a launch chain); model_hier with a mixture low level trains through "
+                                 "hiertcn_gmm_train_step_hier (tests/test_gpu_gmm_train.py)",
                          "rows": tB * tT, "ms_per_step": round(train_ms, 3), "rows_per_s": round(tB * tT / train_ms * 1e3),
                          "ms_per_step_gru_gmm": round(train_ms_gru, 3), "ms_per_step_gru_gmm_hipgraph": train_ms_gru_graph,
                          "loss_first_last": [round(float(tl[0, 0] / tl[0, 1]), 5), round(float(tl[-1, 0] / tl[-1, 1]), 5)]},

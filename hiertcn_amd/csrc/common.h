@@ -251,6 +251,8 @@ hipError_t launch_onehot_gru(const OneHotGru& w, const int32_t* x, int64_t n_ses
 // ... with every record kept and fp32 output rows (the training step of model_gru_gmm, gmm_train.hip): states [L + 1][M][H nl], recs [L][nl][M 5 H]
 hipError_t launch_onehot_gru_records(const OneHotGru& w, const int32_t* x, int64_t n_sess, int L, float* hidden32, int32_t* seq_len, float* states, float* recs,
                                      hipStream_t st);
+hipError_t launch_rows_gru_records(const OneHotGru& w, const float* rows, int in_dim, int64_t n_sess, int L, float* hidden32, int32_t* seq_len, float* states,
+                                   float* recs, hipStream_t st);   // ... on dense fp32 rows [n_sess * L][in_dim]: wg[0] / wc[0] the full kernels
 hipError_t launch_low_gru(const ModelDev& m, const int32_t* x, const float* sproj, int64_t n_sess, int L, uint16_t* hidden, void* workspace,
                           hipStream_t st);
 size_t tcn_workspace_bytes(const ModelDev& m, int64_t n_sessions, int L);

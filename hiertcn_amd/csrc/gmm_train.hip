@@ -25,14 +25,14 @@
 // hidden row -- so that variant materialises mu and s per mixture ([2 M][rows][D] fp32, 5.3 GB at the reference's batch), forms their gradients in place
 // and takes three exact-fp32 products per table (k_gtl_rows / k_gtl_grad below).
 //
-// model_hier with the tcn_gmm low level (model_hier.py:39-93 around trunk 2) trains as ONE step on this handle (hiertcn_gmm_train_step_hier): the handle
+// model_hier with a mixture low level (model_hier.py:39-93 around trunk 2 = tcn_gmm or trunk 3 = gru_gmm) trains as ONE step on this handle (hiertcn_gmm_train_step_hier): the handle
 // then also keeps the HIGH level's masters (item table, emb bias, across-session cells), runs session mean-pool -> across-session scan with every record
 // kept (pool_gru.hip's launch_gru_scan on a view of the masters) -> the [e, state] rows -> the step above with block 0 as an ordinary TemporalBlock on
-// those rows -> and sends the rows' gradient back: the item table's rows by scatter-add, the states through the S slots (three launches per cell, the
+// those rows (or the GRU stack with a dense layer-0 input: launch_rows_gru_records) -> and sends the rows' gradient back: the item table's rows by scatter-add, the states through the S slots (three launches per cell, the
 // user-boundary mask in the first), the pool.
 //
-// Built for: trunks 0 and 1 (the models on ids) and trunk 2 together with the high level, both scale variants, loss modes gmm_prob and gmm_prob_max.
-// Trunk 3 (model_hier with the gru_gmm low level) evaluates only (hiertcn_gmm_train_enable refuses it).
+// Built for: trunks 0 and 1 (the models on ids) and trunks 2 and 3 together with the high level, both scale variants, loss modes gmm_prob and gmm_prob_max:
+// every mixture model the reference's model.py:74-77 / model_hier.py:64-69 dispatch to.
 #include <math.h>
 #include <string.h>
 
@@ -651,8 +651,8 @@ static void gt_layout(const hiertcn_gmm_ctx* g, GmmTrain* t) {
   size_t off = 0;
   auto seg = [&](GSeg& s, size_t n) { s.off = off; s.n = n; off += up64(n); };
   const int K = g->K;
-  for (int l = 0; l < g->nl; l++) {   // trunk 1 (nb == 0): rnn.GRUCell layouts, in = item_num for layer 0 and H above
-    const size_t in = (l == 0) ? (size_t)g->N : (size_t)g->H, H = (size_t)g->H;
+  for (int l = 0; l < g->nl; l++) {   // trunks 1 / 3 (nb == 0): rnn.GRUCell layouts, in = item_num (one-hot rows) or input_dim (dense rows) for layer 0, H above
+    const size_t in = (l == 0) ? (g->trunk == 3 ? (size_t)g->cfg.input_dim : (size_t)g->N) : (size_t)g->H, H = (size_t)g->H;
     seg(t->gk[l], (in + H) * 2 * H); seg(t->gb[l], 2 * H); seg(t->ck[l], (in + H) * H); seg(t->cb[l], H);
   }
   for (int i = 0, cin = (g->trunk == 2 ? g->cfg.input_dim : g->N); i < g->nb; cin = g->cfg.channels[i], i++) {
@@ -694,7 +694,8 @@ static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
   size_t off = 0;
   auto take = [&](size_t floats) { const size_t o = off; off += ((floats * 4) + 255) & ~(size_t)255; return o; };
   const size_t C = (size_t)g->Clast;
-  size_t cm = g->trunk == 1 ? C : (size_t)cmax_of(g);
+  const bool gru = g->trunk == 1 || g->trunk == 3;
+  size_t cm = gru ? C : (size_t)cmax_of(g);
   if (g->trunk == 2 && (size_t)g->cfg.input_dim > cm) cm = (size_t)g->cfg.input_dim;   // (block 0's shifted input rows)
   if (g->learned) {
     w.MUS = take((size_t)2 * g->M * R * g->DP);
@@ -708,8 +709,9 @@ static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
   w.dH = take(R * cm);
   w.lane_act = take((size_t)B);
   w.users = take(64);
-  if (g->trunk == 1) {
+  if (gru) {
     const size_t H = (size_t)g->H, HT = H * g->nl, M = (size_t)B, L = (size_t)T, nl = (size_t)g->nl;
+    const size_t Kmax = (g->trunk == 3 && (size_t)g->cfg.input_dim + H > 2 * H) ? (size_t)g->cfg.input_dim + H : 2 * H;
     w.hid = take(R * H);
     w.seq_len = take(M);
     w.states = take((L + 1) * M * HT);
@@ -719,8 +721,8 @@ static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
     w.dcar[0] = take(M * HT);
     w.dcar[1] = take(M * HT);
     w.dhpart = take(M * H);
-    w.dcat_c = take(M * 2 * H);
-    w.dcat_g = take(M * 2 * H);
+    w.dcat_c = take(M * Kmax);
+    w.dcat_g = take(M * Kmax);
     w.din_up = take(M * H);
   } else {
     for (int i = 0; i < g->nb; i++) { w.act[i] = take(R * g->cfg.channels[i]); w.cact[i] = take(R * g->cfg.channels[i]); }
@@ -779,9 +781,10 @@ static int gt_refresh(hiertcn_gmm_ctx* g, hipStream_t st) {
     G_HIP(gt_transpose(P + t->hgk[l].off, 2 * H, t->hwg[l], Kc, Kc, 2 * H, st));
     G_HIP(gt_transpose(P + t->hck[l].off, H, t->hwc[l], Kc, Kc, H, st));
   }
-  for (int l = 0; l < g->nl; l++) {   // trunk 1: the state half of layer 0 / the whole kernels above, output-major (the cells' B operand)
-    const int H = g->H, in_tf = (l == 0) ? g->N : H, Kc = (l == 0) ? H : 2 * H;
-    const size_t skip = (l == 0) ? (size_t)in_tf : 0;   // layer 0: rows [N, N + H) only -- the input half stays where it is (item-major rows of the master)
+  for (int l = 0; l < g->nl; l++) {   // trunk 1: the state half of layer 0 / the whole kernels above, output-major (the cells' B operand); trunk 3: whole kernels
+    const int H = g->H, in_tf = (l == 0) ? g->N : H;
+    const int Kc = (l == 0) ? (g->trunk == 3 ? g->cfg.input_dim + H : H) : 2 * H;
+    const size_t skip = (l == 0 && g->trunk == 1) ? (size_t)in_tf : 0;   // one-hot input: rows [N, N + H) only -- the input half stays where it is (item-major rows of the master)
     G_HIP(gt_transpose(P + t->gk[l].off + skip * 2 * H, 2 * H, t->wg[l], Kc, Kc, 2 * H, st));
     G_HIP(gt_transpose(P + t->ck[l].off + skip * H, H, t->wc[l], Kc, Kc, H, st));
   }
@@ -803,20 +806,18 @@ extern "C" {
 int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t* w, void* stream) {
   if (!g || !w) return gfail(HIERTCN_ERR_INVALID, "null argument");
   if (g->train) return gfail(HIERTCN_ERR_STATE, "training is already enabled on this handle");
-  if (g->trunk == 3)
-    return gfail(HIERTCN_ERR_INVALID, "the training step is built for the models on ids (trunks 0, 1) and for model_hier with the tcn_gmm low level (trunk 2); trunk 3 -- "
-                 "model_hier with the gru_gmm low level -- evaluates only");
   int hE = 0;
-  if (g->trunk == 2) {   // model_hier.py:39-93 around the dense-row trunk: the high level (item table, emb bias, across-session cells) trains with it
+  if (g->trunk == 2 || g->trunk == 3) {   // model_hier.py:39-93 around the dense-row trunk: the high level (item table, emb bias, across-session cells) trains with it
     const int H = g->cfg.hidden_dim, nl = g->cfg.num_layer;
     if (H < 32 || (H & 31) || H > 1024 || nl < 1 || nl > HIERTCN_MAX_LAYERS || g->cfg.item_num < 2)
-      return gfail(HIERTCN_ERR_INVALID, "training trunk 2 as model_hier's low level: cfg.hidden_dim (a multiple of 32), cfg.num_layer and cfg.item_num describe the high level");
+      return gfail(HIERTCN_ERR_INVALID, "training a dense-row trunk as model_hier's low level: cfg.hidden_dim (a multiple of 32), cfg.num_layer and cfg.item_num describe the high level");
     hE = g->cfg.input_dim - H * nl;
     if (hE < 32 || (hE & 31)) return gfail(HIERTCN_ERR_INVALID, "input_dim %d - hidden_dim %d x num_layer %d = emb width %d: a multiple of 32", g->cfg.input_dim, H, nl, hE);
-    if (!w->hl_emb_kernel || !w->hl_emb_bias) return gfail(HIERTCN_ERR_INVALID, "training trunk 2: hl_emb_kernel / hl_emb_bias (hier/emb/{kernel,bias}) are required");
+    if (!w->hl_emb_kernel || !w->hl_emb_bias)
+      return gfail(HIERTCN_ERR_INVALID, "training a dense-row trunk means training model_hier around it: hl_emb_kernel / hl_emb_bias (hier/emb/{kernel,bias}) are required");
     for (int l = 0; l < nl; l++)
       if (!w->hl_gate_kernel[l] || !w->hl_gate_bias[l] || !w->hl_cand_kernel[l] || !w->hl_cand_bias[l])
-        return gfail(HIERTCN_ERR_INVALID, "training trunk 2: the across-session cell %d (hl_gate / hl_cand kernel and bias) is required", l);
+        return gfail(HIERTCN_ERR_INVALID, "training a dense-row trunk: the across-session cell %d (hl_gate / hl_cand kernel and bias) is required", l);
   }
   if (g->M > GT_MP) return gfail(HIERTCN_ERR_INVALID, "num_mixture %d: the training step takes up to 16 mixtures", g->M);
   if (g->Clast != 64 && g->Clast != 128 && g->Clast != 256 && g->Clast != 512) return gfail(HIERTCN_ERR_INVALID, "last width %d: 64, 128, 256, 512", g->Clast);
@@ -852,7 +853,7 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
   }
   size_t o_wg[HIERTCN_MAX_LAYERS] = {}, o_wc[HIERTCN_MAX_LAYERS] = {}, o_dwg[HIERTCN_MAX_LAYERS] = {}, o_dwc[HIERTCN_MAX_LAYERS] = {};
   for (int l = 0; l < g->nl; l++) {
-    const size_t H = (size_t)g->H, Kc = (l == 0) ? H : 2 * H;
+    const size_t H = (size_t)g->H, Kc = (l == 0) ? (g->trunk == 3 ? (size_t)g->cfg.input_dim + H : H) : 2 * H;
     o_wg[l] = take(2 * H * Kc); o_dwg[l] = take(2 * H * Kc); o_wc[l] = take(H * Kc); o_dwc[l] = take(H * Kc);
   }
   const size_t Tn = g->learned ? 2 * M : M;
@@ -943,12 +944,16 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
   const float* H = nullptr;
   OneHotGru og;
   memset(&og, 0, sizeof(og));
-  if (g->trunk == 1) {
-    // model_gru_gmm.py:33-48: MultiRNNCell of GRUCells under dynamic_rnn on the one-hot rows, from a zero state; every record kept for the backward
+  const bool gru_trunk = g->trunk == 1 || g->trunk == 3;
+  const int in0 = g->trunk == 3 ? g->cfg.input_dim : 0;   // layer 0's dense input width (one-hot rows: none -- the input half is a gathered table row)
+  if (gru_trunk) {
+    // model_gru_gmm.py:33-48: MultiRNNCell of GRUCells under dynamic_rnn on the one-hot rows (trunk 1) or on the dense [e, state] rows of model_hier
+    // (trunk 3, model_hier.py:68-69), from a zero state; every record kept for the backward
     og.N = N; og.H = g->H; og.nl = g->nl;
-    og.in_g = P + t->gk[0].off; og.in_c = P + t->ck[0].off;     // rows [0, N) of the masters' layer-0 kernels: the input half, item-major as it is
+    og.in_g = P + t->gk[0].off; og.in_c = P + t->ck[0].off;     // (trunk 1) rows [0, N) of the masters' layer-0 kernels: the input half, item-major as it is
     for (int l = 0; l < g->nl; l++) { og.wg[l] = t->wg[l]; og.bg[l] = P + t->gb[l].off; og.wc[l] = t->wc[l]; og.bc[l] = P + t->cb[l].off; }
-    G_HIP(launch_onehot_gru_records(og, x_ids, B, T, F32(w.hid), reinterpret_cast<int32_t*>(ws + w.seq_len), F32(w.states), F32(w.recs), st));
+    if (g->trunk == 1) G_HIP(launch_onehot_gru_records(og, x_ids, B, T, F32(w.hid), reinterpret_cast<int32_t*>(ws + w.seq_len), F32(w.states), F32(w.recs), st));
+    else G_HIP(launch_rows_gru_records(og, rows_in, in0, B, T, F32(w.hid), reinterpret_cast<int32_t*>(ws + w.seq_len), F32(w.states), F32(w.recs), st));
     H = F32(w.hid);
   } else {
   if (b0) {
@@ -1064,7 +1069,7 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
     G_HIP(hipGetLastError());
   }
 
-  if (g->trunk == 1) {
+  if (gru_trunk) {
     // ================= backward through time of the GRU stack (customed_gru_cell.py:323-337 differentiated; train.hip's cell chain) =============
     const int Hh = g->H, HT = g->H * g->nl, nl = g->nl, Mb = (int)B, L = T;
     const size_t cell = (size_t)Mb * 5 * Hh;
@@ -1084,8 +1089,10 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
     const bool fused = Mb <= gemm32_skinny_max_rows();
     for (int tt = L - 1; tt >= 0; tt--) {
       for (int l = nl - 1; l >= 0; l--) {
-        const int in = (l == 0) ? 0 : Hh;            // layer 0's input half is the gathered table row: no dense input operand
+        const int in = (l == 0) ? in0 : Hh;          // one-hot rows: layer 0's input half is the gathered table row, no dense input operand
         const int Kc = in + Hh;
+        float* d_in = (l == 0) ? (in0 ? d_rows + (size_t)tt * in0 : din_up) : din_up;     // dense rows: the gradient of step tt's input rows
+        const int64_t ld_d_in = (l == 0 && in0) ? (int64_t)L * in0 : Hh;
         const float* rec = recs + ((size_t)tt * nl + l) * cell;
         const float* gates = rec;
         const float* cand = rec + (size_t)Mb * 3 * Hh;
@@ -1102,7 +1109,7 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
           memset(&ep, 0, sizeof(ep));
           ep.in = in; ep.H = Hh; ep.K = Kc;
           ep.gates = gates; ep.h = hold; ep.ldh = HT; ep.dag = dag; ep.dhpart = dhpart; ep.dcat_c = dcat_c;
-          ep.dst_in = din_up; ep.ldi = Hh; ep.dst_h = lnext + (size_t)l * Hh; ep.ldo = HT;
+          ep.dst_in = d_in; ep.ldi = (int)ld_d_in; ep.dst_h = lnext + (size_t)l * Hh; ep.ldo = HT;
           G_HIP(gemm32_nn_gru_bwd(1, dac, Hh, t->wc[l], Kc, Mb, Kc, Hh, ep, st));           // d [in | r*h] = dac . wc, then step b
           G_HIP(gemm32_nn_gru_bwd(2, dag, 2 * Hh, t->wg[l], Kc, Mb, Kc, 2 * Hh, ep, st));    // d [in | h] = dag . wg, then step c
           continue;
@@ -1111,14 +1118,14 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
         G_HIP(gemm32_nn(dac, Hh, t->wc[l], Kc, dcat_c, Kc, Mb, Kc, Hh, 0.f, st));            // d [in | r*h] = dac . wc
         G_HIP(train_gru_bwd_b(dcat_c, Kc, in, hold, HT, gates, Mb, Hh, dag, dhpart, st));
         G_HIP(gemm32_nn(dag, 2 * Hh, t->wg[l], Kc, dcat_g, Kc, Mb, Kc, 2 * Hh, 0.f, st));    // d [in | h] = dag . wg
-        G_HIP(train_lgru_bwd_c(dcat_c, dcat_g, Kc, in, dhpart, Mb, Hh, din_up, Hh, lnext + (size_t)l * Hh, HT, lcar + (size_t)l * Hh, seq_len, tt, st));
+        G_HIP(train_lgru_bwd_c(dcat_c, dcat_g, Kc, in, dhpart, Mb, Hh, d_in, ld_d_in, lnext + (size_t)l * Hh, HT, lcar + (size_t)l * Hh, seq_len, tt, st));
       }
       float* tmp = lcar; lcar = lnext; lnext = tmp;
     }
     // weight gradients of all L * nl cells: one product per layer and operand over the L * M rows (rows (t, m): slab t, session m)
     const int LM = L * Mb;
     for (int l = 0; l < nl; l++) {
-      const int in = (l == 0) ? 0 : Hh, Kc = in + Hh;
+      const int in = (l == 0) ? in0 : Hh, Kc = in + Hh;
       const float* dac = dac_all + (size_t)l * L * Mb * Hh;
       const float* dag = dag_all + (size_t)l * L * Mb * 2 * Hh;
       const int64_t rss = (int64_t)((size_t)nl * cell);   // the same record of the next step
@@ -1128,20 +1135,24 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
         const float* inp = recs + (size_t)(l - 1) * cell + (size_t)Mb * 4 * Hh;
         G_HIP(gemm32_tn_slabs(dac, Hh, 0, 0, inp, Hh, Mb, rss, t->dwc[l], Kc, Hh, in, LM, 0.f, t->splitk, t->splitk_floats, st));
         G_HIP(gemm32_tn_slabs(dag, 2 * Hh, 0, 0, inp, Hh, Mb, rss, t->dwg[l], Kc, 2 * Hh, in, LM, 0.f, t->splitk, t->splitk_floats, st));
+      } else if (in0) {   // dense input rows: row (t, m) of the operand at t * in0 + m * (L * in0)
+        G_HIP(gemm32_tn_slabs(dac, Hh, 0, 0, rows_in, (int64_t)L * in0, Mb, in0, t->dwc[l], Kc, Hh, in, LM, 0.f, t->splitk, t->splitk_floats, st));
+        G_HIP(gemm32_tn_slabs(dag, 2 * Hh, 0, 0, rows_in, (int64_t)L * in0, Mb, in0, t->dwg[l], Kc, 2 * Hh, in, LM, 0.f, t->splitk, t->splitk_floats, st));
       }
       G_HIP(gemm32_tn_slabs(dac, Hh, 0, 0, rh, Hh, Mb, rss, t->dwc[l] + in, Kc, Hh, Hh, LM, 0.f, t->splitk, t->splitk_floats, st));
       G_HIP(gemm32_tn_slabs(dag, 2 * Hh, 0, 0, hold, HT, 0, 0, t->dwg[l] + in, Kc, 2 * Hh, Hh, LM, 0.f, t->splitk, t->splitk_floats, st));
       G_HIP(train_colsum_f32(dac, LM, Hh, Hh, G + t->cb[l].off, st));
       G_HIP(train_colsum_f32(dag, LM, 2 * Hh, 2 * Hh, G + t->gb[l].off, st));
       // -> the reference layout [in_tf + H][2H | H]: rows behind the input half (layer 0: behind the N table rows)
-      const size_t skip = (l == 0) ? (size_t)N : 0;
+      const size_t skip = (l == 0 && g->trunk == 1) ? (size_t)N : 0;
       G_HIP(gt_transpose(t->dwg[l], Kc, G + t->gk[l].off + skip * 2 * Hh, 2 * Hh, 2 * Hh, Kc, st));
       G_HIP(gt_transpose(t->dwc[l], Kc, G + t->ck[l].off + skip * Hh, Hh, Hh, Kc, st));
     }
-    // layer 0's input half: the table rows the forward gathered receive the cells' pre-activation gradients
-    hipLaunchKernelGGL(k_gt_gru_in_scatter, dim3((unsigned)(((int64_t)LM * (Hh >> 2) + 255) / 256)), dim3(256), 0, st, dac_all, dag_all, x_ids, Mb, L, N, Hh,
-                       G + t->gk[0].off, G + t->ck[0].off);
-    G_HIP(hipGetLastError());
+    if (g->trunk == 1) {   // layer 0's input half: the table rows the forward gathered receive the cells' pre-activation gradients
+      hipLaunchKernelGGL(k_gt_gru_in_scatter, dim3((unsigned)(((int64_t)LM * (Hh >> 2) + 255) / 256)), dim3(256), 0, st, dac_all, dag_all, x_ids, Mb, L, N, Hh,
+                         G + t->gk[0].off, G + t->ck[0].off);
+      G_HIP(hipGetLastError());
+    }
   } else {
   // ================= TemporalBlocks, last to first (train.hip's fp32 recipe) ===========================================================================
   float* da = F32(w.dH);
@@ -1251,7 +1262,7 @@ int hiertcn_gmm_train_step_hier(hiertcn_gmm_handle_t g, const int32_t* x_ids, co
                                 float* loss_rows, void* stream) {
   GT_READY(g);
   GmmTrain* t = g->train;
-  if (g->trunk != 2 || !t->hE) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_train_step_hier is the step of trunk 2 enabled with the high level's variables");
+  if ((g->trunk != 2 && g->trunk != 3) || !t->hE) return gfail(HIERTCN_ERR_STATE, "hiertcn_gmm_train_step_hier is the step of a dense-row trunk (2, 3) enabled with the high level's variables");
   if (!x_ids || !y_ids || !mask || !state_in || !state_out || !workspace || B < 1 || S < 1 || L < 1 || L > 4096) return gfail(HIERTCN_ERR_INVALID, "bad argument");
   if (mode != 0 && mode != 1) return gfail(HIERTCN_ERR_INVALID, "mode %d: 0 (gmm_prob) or 1 (gmm_prob_max)", mode);
   if (B > gemm32_skinny_max_rows()) return gfail(HIERTCN_ERR_INVALID, "%lld lanes: the across-session backward takes up to %d per step", (long long)B, gemm32_skinny_max_rows());

@@ -844,3 +844,59 @@ hipError_t launch_onehot_gru_records(const OneHotGru& w, const int32_t* x, int64
   }
   return hipSuccess;
 }
+
+// ... and on DENSE fp32 rows of width in_dim (model_hier.py:68-69: model_gru_gmm as the low level reads the [e_t, state] rows; gmm_train.hip: the training step
+// of that model): w.wg[0] [2H][in_dim + H] / w.wc[0] [H][in_dim + H] are the full kernels; sequence_length = the count of rows that are not all-zero
+__global__ __launch_bounds__(256) void k_len_rows_f32(const float* __restrict__ rows, int64_t n_sess, int L, int W, int32_t* __restrict__ seq_len) {
+  const int lane = threadIdx.x & 63;
+  const int64_t sess = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (sess >= n_sess) return;
+  int cnt = 0;
+  for (int t = 0; t < L; t++) {
+    const float* r = rows + (sess * L + t) * W;
+    int nz = 0;
+    for (int c = lane; c < W; c += 64) nz |= (r[c] != 0.f) ? 1 : 0;
+    nz = __any(nz);
+    cnt += nz ? 1 : 0;
+  }
+  if (lane == 0) seq_len[sess] = cnt;
+}
+hipError_t launch_rows_gru_records(const OneHotGru& w, const float* rows, int in_dim, int64_t n_sess, int L, float* hidden32, int32_t* seq_len, float* states,
+                                   float* recs, hipStream_t st) {
+  if (n_sess <= 0) return hipSuccess;
+  const int H = w.H, HT = w.H * w.nl;
+  const size_t cell = (size_t)n_sess * 5 * H;
+  hipLaunchKernelGGL(k_len_rows_f32, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, rows, n_sess, L, in_dim, seq_len);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  if ((e = hipMemsetAsync(states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state
+  for (int t = 0; t < L; t++) {
+    const float* s_old = states + (size_t)t * n_sess * HT;
+    float* s_new = states + (size_t)(t + 1) * n_sess * HT;
+    for (int l = 0; l < w.nl; l++) {
+      float* rec = recs + ((size_t)t * w.nl + l) * cell;
+      GemmArgs g;
+      memset(&g, 0, sizeof(g));
+      const float* hold = s_old + (size_t)l * H;
+      float* gates = rec;
+      float* rh = rec + (size_t)n_sess * 2 * H;
+      g.M = (int)n_sess; g.H = H;
+      if (l == 0) { g.A1 = rows + (size_t)t * in_dim; g.lda1 = L * in_dim; g.K1 = in_dim; }
+      else { g.A1 = recs + ((size_t)t * w.nl + l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H; }
+      g.A2 = hold; g.lda2 = HT; g.K2 = H;
+      g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
+      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
+      g.A2 = rh; g.lda2 = H;
+      g.Wt = w.wc[l]; g.bias = w.bc[l]; g.N = H;
+      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
+      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
+      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
+      g.gates = gates; g.ldg = 2 * H;
+      g.seq_len = seq_len; g.tstep = t;
+      if (l == w.nl - 1) { g.hid_out32 = hidden32 + (size_t)t * H; g.ldho = (int64_t)L * H; }
+      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    }
+  }
+  return hipSuccess;
+}

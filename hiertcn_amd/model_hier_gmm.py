@@ -15,9 +15,9 @@ What the reference does with `pred` afterwards cannot be run (it feeds the [B, T
 model_low_type 'gru_gmm' (model_hier.py:68-69 -> model_gru_gmm.py:33-54) is the same with trunk 3: the MultiRNNCell of GRUCells under dynamic_rnn on
 the x_slice rows (sequence_length = the count of rows that are not all-zero), variables hier/rnn_gmm/rnn/multi_rnn_cell/cell_l/gru_cell/... and
 hier/rnn_gmm/fully_connected/{weights,biases} (model_gru_gmm's default scope name 'rnn_gmm' under 'hier').
-Training (round 6): with the 'tcn_gmm' low level the WHOLE model -- item table, emb bias, across-session cells, TemporalConvNet, head -- trains as one
+Training (round 6): the WHOLE model -- item table, emb bias, across-session cells, the low level (TemporalConvNet or GRU stack), head -- trains as one
 step on the mixture handle (csrc/gmm_train.hip, hiertcn_gmm_train_step_hier; HierGmmModel.enable_training / train_step_hier); evaluation afterwards
-re-uploads the high level into the main handle (sync).  The 'gru_gmm' low level evaluates only.
+re-uploads the high level into the main handle (sync).
 """
 from __future__ import annotations
 
@@ -114,7 +114,7 @@ class HierGmmModel(TcnGmmModel):
         self.engine.set_weights(ep)
         self._engine_params = ep     # (the main handle's own, never-run low level keeps these initial values when sync() re-uploads the high level)
         if self.low == "gru_gmm":
-            cfg = _lib.GmmConfig(item_num=0, output_dim=self.D, num_mixture=self.M, kernel_size=1, n_blocks=0,
+            cfg = _lib.GmmConfig(item_num=self.N, output_dim=self.D, num_mixture=self.M, kernel_size=1, n_blocks=0,   # (item_num: the high level's table, training only)
                                  sigma=float(args.sigma) if getattr(args, "sigma", 0.1) else 0.0, trunk=3, hidden_dim=int(args.hidden_dim),
                                  num_layer=int(args.num_layer), input_dim=self.E + self.HT)
         else:
@@ -161,10 +161,14 @@ class HierGmmModel(TcnGmmModel):
 
     # -- training (csrc/gmm_train.hip, hiertcn_gmm_train_step_hier): model_hier with the tcn_gmm low level as ONE step on the mixture handle ------------
     def _weights_struct(self, bufs):
-        root = f"{self.name}/tcn_gmm"
+        root = f"{self.name}/rnn_gmm" if self.low == "gru_gmm" else f"{self.name}/tcn_gmm"
         w = _lib.GmmWeights()
         p = lambda k: bufs[k].data_ptr()  # noqa: E731
-        for i in range(len(self.args.tcn_channel)):
+        for l in range(int(self.args.num_layer) if self.low == "gru_gmm" else 0):
+            pre = f"{root}/rnn/multi_rnn_cell/cell_{l}/gru_cell"
+            w.gru_gate_kernel[l], w.gru_gate_bias[l] = p(f"{pre}/gates/kernel"), p(f"{pre}/gates/bias")
+            w.gru_cand_kernel[l], w.gru_cand_bias[l] = p(f"{pre}/candidate/kernel"), p(f"{pre}/candidate/bias")
+        for i in range(0 if self.low == "gru_gmm" else len(self.args.tcn_channel)):
             pre = f"{root}/temporal_conv_net/tblock_{i}"
             w.conv_kernel[i], w.conv_bias[i] = p(f"{pre}/conv1/kernel"), p(f"{pre}/conv1/bias")
             if f"{pre}/dense/kernel" in bufs:
@@ -176,12 +180,6 @@ class HierGmmModel(TcnGmmModel):
             w.hl_gate_kernel[l], w.hl_gate_bias[l] = p(f"{pre}/gates/kernel"), p(f"{pre}/gates/bias")
             w.hl_cand_kernel[l], w.hl_cand_bias[l] = p(f"{pre}/candidate/kernel"), p(f"{pre}/candidate/bias")
         return w
-
-    def enable_training(self):
-        if self.low != "tcn_gmm":
-            raise NotImplementedError("model_hier with model_low_type 'gru_gmm' evaluates only: the training step of the mixture low levels is built for 'tcn_gmm' "
-                                      "(csrc/gmm_train.hip, hiertcn_gmm_train_step_hier)")
-        super().enable_training()
 
     def train_forward_backward(self, *a, **k):   # (TcnGmmModel's id-input step does not apply to this trunk)
         raise HierTCNError("HierGmmModel trains through train_forward_backward_hier / train_step_hier (ids [B, S, L], mask, state)")

@@ -169,8 +169,7 @@ class TcnGmmModel:
 
     def enable_training(self):
         """fp32 masters (filled from self.params), gradients and Adam moments on the device: hiertcn_gmm_train_enable.  The models on ids
-        (model_tcn_gmm, model_gru_gmm) and model_hier with the tcn_gmm low level (HierGmmModel), fixed or learned scale; model_hier's gru_gmm low
-        level raises (the library refuses it)."""
+        (model_tcn_gmm, model_gru_gmm) and model_hier with either as its low level (HierGmmModel), fixed or learned scale."""
         if getattr(self, "_training", False):
             return
         bufs = {k: torch.as_tensor(np.asarray(v, dtype=np.float32)).to(self.device).contiguous() for k, v in self.params.items()}

@@ -437,8 +437,8 @@ int hiertcn_gmm_lane_loss(hiertcn_gmm_handle_t g, const float* loss, const int32
  * The reference itself cannot train these models on XING (its graph does not build): the step differentiates the decode
  * documented above, and is checked against fp64 autograd of that decode.  Built for the models on ids -- trunk 0 (model_tcn_gmm: the
  * TemporalConvNet) and trunk 1 (model_gru_gmm: the GRU stack, backward through time over its T steps) --, a fixed scale (cfg.sigma > 0) or a
- * learned one (cfg.sigma = 0), loss modes 0 / 1 -- and for trunk 2 as the low level of model_hier, together with the high level (below); trunk 3 (the
- * gru_gmm low level of model_hier) evaluates only (train_enable returns an error).
+ * learned one (cfg.sigma = 0), loss modes 0 / 1 -- and for the dense-row trunks 2 / 3 as the low level of model_hier, together with the high level
+ * (below).
  * Everything is fp32 on master copies kept in the REFERENCE's layouts (a checkpoint is a copy; Adam is elementwise).  With a fixed scale no
  * [rows][M D] matrix is formed in either direction -- the head's backward is linear algebra on the hidden rows through G_m = W_m W_m^T
  * (csrc/gmm_train.hip); a learned scale materialises the means and log-scales ([2 M][rows][D] fp32 in the workspace: size it with
@@ -459,12 +459,12 @@ int hiertcn_gmm_train_enable(hiertcn_gmm_handle_t g, const hiertcn_gmm_weights_t
 size_t hiertcn_gmm_train_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t T);
 int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, int64_t B, int32_t T, int32_t mode,
                            const float* users_global, void* workspace, size_t workspace_bytes, double* out2, float* loss_rows, void* stream);
-/* model_hier with model_low_type 'tcn_gmm' (model_hier.py:39-93 around trunk 2) trains as ONE step on the mixture handle: enabled with the high level's
+/* model_hier with model_low_type 'tcn_gmm' / 'gru_gmm' (model_hier.py:39-93 around trunk 2 / 3) trains as ONE step on the mixture handle: enabled with the high level's
  * variables (hiertcn_gmm_weights_t.hl_*; cfg.item_num / hidden_dim / num_layer describe them, emb width = input_dim - hidden_dim * num_layer), the step runs
- * session mean-pool -> across-session scan -> [e, state] rows -> TemporalConvNet -> head -> loss and all of its backward (the rows' gradient into the item
+ * session mean-pool -> across-session scan -> [e, state] rows -> TemporalConvNet or GRU stack -> head -> loss and all of its backward (the rows' gradient into the item
  * table and the states, backward through the S slots with the user-boundary mask, the pool), x_ids / y_ids [B][S][L], mask [B][S], state_in / state_out
  * [B][hidden_dim * num_layer]; lanes = users (B <= 4096 per step).  Evaluation keeps using the main handle for the high level: after training, export
- * the hl_* masters (hiertcn_gmm_train_copy) into it (hiertcn_set_weights).  Trunk 3 (the gru_gmm low level) evaluates only. */
+ * the hl_* masters (hiertcn_gmm_train_copy) into it (hiertcn_set_weights). */
 size_t hiertcn_gmm_train_hier_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t S, int32_t L);
 int hiertcn_gmm_train_step_hier(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in, int64_t B, int32_t S,
                                 int32_t L, int32_t mode, const float* users_global, void* workspace, size_t workspace_bytes, float* state_out, double* out2,
