@@ -242,6 +242,38 @@ class HierGmmModel(TcnGmmModel):
                     ep[k] = v
             self.engine.set_weights(ep)
 
+    def set_parameters(self, params: dict):
+        """Checkpoint restore (run_gmm_xing.run_hier_gmm): every variable into BOTH handles (and into the masters when training is enabled)."""
+        missing = set(self.params) - set(params)
+        if missing:
+            raise HierTCNError(f"checkpoint lacks {sorted(missing)[:3]} ... ({len(missing)} variables)")
+        self.params = {k: np.asarray(params[k], dtype=np.float32) for k in self.params}
+        self._upload(self.params)
+        ep = dict(self._engine_params)
+        for k, v in self.params.items():
+            if k.startswith(f"{self.name}/emb/") or k.startswith(f"{self.name}/multi_rnn_cell/"):
+                ep[k] = v
+        self.engine.set_weights(ep)
+        self._engine_params = ep
+        if getattr(self, "_training", False):
+            self.restore("weights", self.params)
+            self._stale = False     # (both handles' evaluation tables were just written from the same values)
+
+    def eval_step_hier(self, xd: torch.Tensor, yd: torch.Tensor, md: torch.Tensor, st: torch.Tensor, mode: Optional[str] = None) -> dict:
+        """One evaluation batch of the run loop (run_gmm_xing.evaluate_hier_gmm): packed ids [B, S, L], mask, carried state -> dict(sums = device
+        doubles [sum of lane means, users] of the masked lane-mean mixture loss over the concatenated slots (model.py:111-117), state [B, HT])."""
+        mode = mode or getattr(self.args, "loss", "gmm_prob")
+        if mode not in self.MODES:
+            raise NotImplementedError(f"args.loss={mode!r}: the mixture low level evaluates 'gmm_prob' or 'gmm_prob_max' (loss.py:247-257)")
+        B, S, L = xd.shape
+        hidden, state_out = self.forward_hier(xd, yd, md, st)
+        yy = yd.view(B, S * L)
+        rows = self.loss_rows(hidden, yy, mode)
+        out2 = torch.empty(2, dtype=torch.float64, device=self.device)
+        _ck(self.lib.hiertcn_gmm_lane_loss(self._h, C.c_void_p(rows.data_ptr()), C.c_void_p(yy.data_ptr()), B, S * L, C.c_void_p(out2.data_ptr()),
+                                           C.c_void_p(torch.cuda.current_stream().cuda_stream)), self.lib)
+        return dict(sums=out2, state=state_out)
+
     def forward_rows(self, rows: torch.Tensor, n_seq: int, L: int) -> torch.Tensor:
         """rows [n_seq*L, E + HT] (storage type) -> last TCN activations [n_seq*L, C]."""
         hidden = torch.empty((n_seq * L, self.C), dtype=torch.bfloat16, device=self.device)

@@ -3,8 +3,8 @@
     python -m hiertcn_amd.run_xing --model_type hier --model_low_type tcn [flags of args.py]
 
 uniquify the log directory, build the three loaders from dataset/interactions.csv, dispatch on
-model_type.  Only the hot-path models are built: 'hier' (model_low_type 'tcn' = HierTCN and 'gru' = HierGRU), 'tcn', 'gru' (single level), and the
-mixture-output models 'tcn_gmm' / 'gru_gmm' (evaluation flow: run_gmm_xing.py).
+model_type.  Only the hot-path models are built: 'hier' (model_low_type 'tcn' = HierTCN, 'gru' = HierGRU, 'tcn_gmm' / 'gru_gmm' = a mixture low
+level), 'tcn', 'gru' (single level), and the mixture-output models 'tcn_gmm' / 'gru_gmm' (run_gmm_xing.py).
 """
 from __future__ import annotations
 
@@ -40,6 +40,9 @@ def main(argv=None):
     if args.model_type in ("tcn", "gru"):   # model.py:66-73: the single-level models, one loop (run_nn_xing.py)
         from .run_nn_xing import run_nn
         return run_nn(args, loader_train, loader_validate, loader_test)
+    if args.model_type == "hier" and args.model_low_type in ("tcn_gmm", "gru_gmm"):   # model_hier.py:64-65,68-69
+        from .run_gmm_xing import run_hier_gmm
+        return run_hier_gmm(args, loader_train, loader_validate, loader_test)
     if args.model_type == "hier":
         from .run_hier_xing import run_hier
         return run_hier(args, loader_train, loader_validate, loader_test)

@@ -301,6 +301,61 @@ def test_run_gmm_trains_on_the_synthetic_xing_file_and_the_checkpoint_resumes(tm
     m2.close()
 
 
+@pytest.mark.parametrize("low", ["tcn_gmm", "gru_gmm"])
+def test_run_hier_gmm_trains_on_the_synthetic_xing_file_and_the_checkpoint_resumes(tmp_path, low):
+    """`run_xing --model_type hier --model_low_type tcn_gmm | gru_gmm --train` = run_hier_gmm in run_hier's cadence (run_hier_xing.py:210-350): the
+    hierarchical loader, one carried state per loader, both levels stepping together.  The test loss falls, every variable of BOTH levels moves,
+    the checkpoint holds them under the reference's names, and a second run restores it and evaluates to the same number."""
+    import os
+
+    from hiertcn_amd import checkpoint
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.data_loader import Dataloader_hier_model_xing
+    from hiertcn_amd.data_prepare import load_xing
+    from hiertcn_amd.model_hier_gmm import HierGmmModel
+    from hiertcn_amd.run_gmm_xing import evaluate_hier_gmm, run_hier_gmm
+    data = load_xing(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "interactions_synth.csv"))
+    N = int(data[1][:, 1].max()) + 1
+
+    def mkargs(log):
+        a = hier_tcn_args(item_num=N, output_dim=N, emb_dim=64, hidden_dim=64, num_layer=2, tcn_channel=[64, 64], kernel_size=3, num_mixture=3,
+                          model_low_type=low, loss="gmm_prob", sigma=0.1, batch_size=4, max_session_num=3, max_activity_len=6)
+        a.name = "hier_gmm_train_test"
+        a.log_path, a.save_path, a.load_path = str(tmp_path) + log, str(tmp_path) + "/model/", str(tmp_path) + "/model/"
+        return a
+
+    a = mkargs("/log/")
+    os.makedirs(a.save_path)
+    os.makedirs(a.log_path + "before/")
+    a.train, a.validate, a.test, a.load, a.save = True, False, True, False, True
+    a.epoch_max, a.epoch_batches_train, a.test_epoch, a.save_epoch, a.lr_schedule, a.learning_rate = 2, 10, 2, 2, False, 2e-3
+    mk = lambda split: Dataloader_hier_model_xing(a, split, data=data)  # noqa: E731
+    model = HierGmmModel(a, None, "hier")
+    p0 = {k: np.array(v) for k, v in model.params.items()}
+    zero = lambda: torch.zeros((4, 128), dtype=torch.float32, device="cuda")  # noqa: E731
+    before, _, _, _ = evaluate_hier_gmm(a, mk("test"), zero(), model, prefix="before")
+    run_hier_gmm(a, mk("train"), mk("validate"), mk("test"), sess=model)
+    assert model.adam_time() == 3 * 10
+    after, _, _, st_after = evaluate_hier_gmm(a, mk("test"), zero(), model, prefix="before")
+    assert after["loss_epoch"] < before["loss_epoch"] - 1e-3, (before["loss_epoch"], after["loss_epoch"])
+    assert float(st_after.abs().max()) > 0                                               # the state is carried, not re-zeroed, between batches
+    saved = checkpoint.load(a.save_path + "2.ckpt")
+    assert set(saved) == set(p0) and any(k.startswith("hier/multi_rnn_cell/") for k in saved) and "hier/emb/kernel" in saved
+    w = model.export("weights")
+    for k in p0:
+        assert saved[k].shape == p0[k].shape and np.array_equal(saved[k], w[k]), k
+        assert not np.array_equal(saved[k], p0[k]), k                                    # every variable of both levels moved
+    assert len(open(a.log_path + "train/scalars.jsonl").read().splitlines()) == 3
+    model.close()
+    # a second run: restore epoch 2 and evaluate only
+    b = mkargs("/log2/")
+    b.train, b.validate, b.test, b.load, b.load_epoch, b.save = False, False, True, True, 2, False
+    m2 = run_hier_gmm(b, None, None, mk("test"))
+    again, _, _, _ = evaluate_hier_gmm(a, mk("test"), zero(), m2, prefix="before")
+    assert abs(again["loss_epoch"] - after["loss_epoch"]) < 1e-9 * max(1.0, abs(after["loss_epoch"]))
+    m2.close()
+
+
 # ---- data parallel: two ranks on ONE GPU over gloo == one rank on the concatenated batch (model.py:135-141 on the global batch) ---------------------
 def _dp_case():
     N, M, channels, K, B, T = 700, 3, (64, 64), 3, 7, 9
