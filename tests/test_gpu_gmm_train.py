@@ -696,12 +696,25 @@ def torch_hier_loss(a, P, x, y, mask, st0, mode, scope="hier", kinks=None):
                                                              ("tcn_gmm", 1500, 128, 64, 2, 4, (128, 128), 5, 6, 3, 12),
                                                              ("gru_gmm", 900, 64, 64, 2, 3, (64,), 3, 5, 4, 7), ("gru_gmm", 600, 64, 128, 1, 2, (64,), 3, 4, 3, 9)])
 def test_hier_low_level_every_gradient_against_fp64_autograd(low, N, E, H, nl, M, channels, K, B, S, L, mode):
+    _hier_gradient_case(low, N, E, H, nl, M, channels, K, B, S, L, mode, 0.1)
+
+
+@pytest.mark.parametrize("mode", ["gmm_prob", "gmm_prob_max"])
+@pytest.mark.parametrize("low,N,E,H,nl,M,channels,K,B,S,L", [("tcn_gmm", 700, 64, 32, 2, 3, (64, 64), 3, 4, 3, 6), ("gru_gmm", 400, 64, 64, 1, 2, (64,), 3, 3, 4, 5)])
+def test_hier_low_level_with_a_learned_scale_every_gradient_against_fp64_autograd(low, N, E, H, nl, M, channels, K, B, S, L, mode):
+    """--sigma none under model_hier: the materialising head (M (1 + 2 D) outputs) behind the [e, state] rows of either mixture low level."""
+    _hier_gradient_case(low, N, E, H, nl, M, channels, K, B, S, L, mode, None)
+
+
+def _hier_gradient_case(low, N, E, H, nl, M, channels, K, B, S, L, mode, sigma):
     from hiertcn_amd import model_hier_gmm as HG
     from hiertcn_amd.args import hier_tcn_args
     from tests.gpu_common import as_lists, make_batch
     a = hier_tcn_args(item_num=N, output_dim=N, emb_dim=E, hidden_dim=H, num_layer=nl, tcn_channel=list(channels), kernel_size=K, num_mixture=M,
                       model_low_type=low, loss=mode, sigma=0.1)
+    a.sigma = sigma
     p = HG.init_params(a, seed=N % 83) if low == "gru_gmm" else G.init_params_hier(a, seed=N % 83)
+    assert p[[k for k in p if k.endswith("fully_connected/weights")][0]].shape[1] == M * (1 + (1 if sigma else 2) * N)
     rng = np.random.default_rng(N + E)
     for k in p:
         if (k.endswith("/bias") and "gates" not in k) or k.endswith("biases"):
