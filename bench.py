@@ -280,15 +280,51 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     except Exception as e:  # noqa: BLE001  (a secondary figure)
         train_ms_gru_graph = repr(e)[:200]
     gm.close()
+    # ... and of model_hier with a mixture low level at the reference's batch (32 lanes x 10 sessions x 20 steps; emb 128, 2 x 128 across-session cells)
+    hier_ms = {}
+    try:
+        from hiertcn_amd.args import hier_tcn_args
+        from hiertcn_amd.model_hier_gmm import HierGmmModel
+        hB, hS, hL = 32, 10, 20
+        hg = torch.Generator(device="cpu").manual_seed(7)
+        hy = torch.randint(1, n_out, (hB, hS, hL), generator=hg, dtype=torch.int32).cuda()
+        hx = torch.zeros_like(hy)
+        hx[:, :, 1:] = hy[:, :, :-1]
+        hm = torch.ones((hB, hS), dtype=torch.float32, device="cuda")
+        for low in ("tcn_gmm", "gru_gmm"):
+            ha = hier_tcn_args(item_num=n_out, output_dim=n_out, emb_dim=128, hidden_dim=128, num_layer=2, tcn_channel=[128, 128], kernel_size=5,
+                               num_mixture=n_mix, model_low_type=low, loss="gmm_prob", sigma=0.1)
+            hmod = HierGmmModel(ha, None, "hier")
+            hmod.enable_training()
+            hst = torch.zeros((hB, 256), dtype=torch.float32, device="cuda")
+
+            def hstep(hst):
+                out = hmod.train_forward_backward_hier(hx, hy, hm, hst, "gmm_prob")     # (the local step: no collective on rank 0 alone)
+                hmod.adam_step(1e-3)
+                return out["state"]
+
+            for _ in range(3):
+                hst = hstep(hst)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(10):
+                hst = hstep(hst)
+            torch.cuda.synchronize()
+            hier_ms[low] = round((time.perf_counter() - t0) / 10 * 1e3, 3)
+            hmod.close()
+    except Exception as e:  # noqa: BLE001  (a secondary figure)
+        hier_ms["error"] = repr(e)[:200]
     diff = float((losses["gram"] - losses["table_pass"]).abs().max())
     flop = 2.0 * rows * dim * ((n_out + 63) // 64 * 64) * n_mix
     return {"training": {"what": "one optimizer step of model_tcn_gmm (fixed scale, gmm_prob): fp32 forward on the masters + backward of every variable + TF-form "
                                  "Adam (csrc/gmm_train.hip: the head's backward through G_m = W_m W_m^T, no [rows][M D] matrix; block 0's one-hot rows as "
                                  "scatter-adds), 32 lanes x 200 steps = 6,400 rows, ids resident; ms_per_step_gru_gmm: the same step of model_gru_gmm "
-                                 "(2-layer GRU stack on the one-hot rows, backward through the 200 steps as a launch chain); model_hier with a mixture low level trains through "
-                                 "hiertcn_gmm_train_step_hier (tests/test_gpu_gmm_train.py)",
+                                 "(2-layer GRU stack on the one-hot rows, backward through the 200 steps as a launch chain); ms_per_step_hier: model_hier with the mixture "
+                                 "model as its low level (hiertcn_gmm_train_step_hier: both levels in one step) at 32 lanes x 10 sessions x 20 steps, emb 128, "
+                                 "2 x 128 across-session cells, tcn_gmm = TemporalConvNet [128, 128] K = 5, gru_gmm = 2 GRU layers of 128",
                          "rows": tB * tT, "ms_per_step": round(train_ms, 3), "rows_per_s": round(tB * tT / train_ms * 1e3),
                          "ms_per_step_gru_gmm": round(train_ms_gru, 3), "ms_per_step_gru_gmm_hipgraph": train_ms_gru_graph,
+                         "ms_per_step_hier": hier_ms,
                          "loss_first_last": [round(float(tl[0, 0] / tl[0, 1]), 5), round(float(tl[-1, 0] / tl[-1, 1]), 5)]},
             "what": "hiertcn_gmm_loss (gmm_prob) on random hidden rows.  ms: the Gram form (k_gmm_quad: h^T G_m h on the bf16 MFMA with G_m in three "
                     "bf16 parts, + one row-wise kernel for prior / linear terms / target mean + finish); ms_table_pass: M passes of "
