@@ -104,6 +104,21 @@ def test_ranks_analysis_matches_loop_definition():
     np.testing.assert_allclose(got_n, want_n)
 
 
+def test_ranks_analysis_matches_the_references_own_function_on_captured_vectors():
+    """tests/golden/run_loop_fixtures.npz: inputs and outputs of the reference's ranks_analysis (run_hier_xing.py:11-31) executed in the build
+    container (make_run_loop_fixtures.py) -- ragged slot widths, width-1 slots, accumulators that are non-zero at entry."""
+    import os
+    fx = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "run_loop_fixtures.npz"))
+    assert int(fx["n_cases"]) >= 6
+    for c in range(int(fx["n_cases"])):
+        widths = [int(w) for w in fx[f"c{c}_widths"]]
+        B = fx[f"c{c}_ranks_float"].shape[0]
+        acc, cnt = ranks_analysis(fx[f"c{c}_ranks_float"], [np.zeros((B, w)) for w in widths], fx[f"c{c}_mask_y"], fx[f"c{c}_acc_in"].copy(),
+                                  fx[f"c{c}_cnt_in"].copy())
+        np.testing.assert_allclose(acc, fx[f"c{c}_acc_out"], rtol=1e-13, atol=0)      # (a different summation order: column sums first)
+        np.testing.assert_array_equal(cnt, fx[f"c{c}_cnt_out"])
+
+
 def test_run_hier_eval_only_runs_once_and_keeps_per_loader_state(tmp_path, data):
     args = _args(tmp_path, data)
     args.train, args.validate, args.test = False, True, True
