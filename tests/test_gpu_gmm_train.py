@@ -416,6 +416,74 @@ def test_two_ranks_equal_one_rank_on_the_concatenated_batch(tmp_path):
     m.close()
 
 
+def _dp_hier_case(low):
+    from hiertcn_amd import model_hier_gmm as HG
+    from hiertcn_amd.args import hier_tcn_args
+    from tests.gpu_common import make_batch
+    N, B, S, L = 600, 6, 3, 7
+    a = hier_tcn_args(item_num=N, output_dim=N, emb_dim=64, hidden_dim=64, num_layer=2, tcn_channel=[64, 64], kernel_size=3, num_mixture=3,
+                      model_low_type=low, loss="gmm_prob", sigma=0.1)
+    p = HG.init_params(a, seed=5)
+    rng = np.random.default_rng(33)
+    x, y, mask = make_batch(rng, B, S, L, N)     # (every session holds an event, as the loader's do: an empty one is the reference's 0 / 0, model_hier.py:84)
+    st0 = (0.3 * rng.standard_normal((B, 128))).astype(np.float32)
+    return a, p, x, y, mask, st0
+
+
+def _dp_hier_worker(rank, world, port, out_dir, low):
+    import os
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    import torch.distributed as dist
+
+    from hiertcn_amd.distributed import init_from_env
+    from hiertcn_amd.model_hier_gmm import HierGmmModel
+    torch.cuda.set_device(0)
+    init_from_env("gloo")
+    a, p, x, y, mask, st0 = _dp_hier_case(low)
+    sl = slice(0, 4) if rank == 0 else slice(4, 6)                      # uneven shards of the lanes: 4 + 2
+    m = HierGmmModel(a, p, "hier")
+    m.enable_training()
+    out = m.train_step_hier(dev(x[sl]), dev(y[sl]), dev(mask[sl]), dev(st0[sl]), 1e-2)
+    torch.cuda.synchronize()
+    np.savez(os.path.join(out_dir, f"dp{rank}.npz"), sums=out["sums"].cpu().numpy(), state=out["state"].cpu().numpy(),
+             **{"g:" + k: v for k, v in m.export("grads").items()}, **{"w:" + k: v for k, v in m.export("weights").items()})
+    m.close()
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("low", ["tcn_gmm", "gru_gmm"])
+def test_hier_two_ranks_equal_one_rank_on_all_lanes(tmp_path, low):
+    """HierGmmModel.train_step_hier under torch.distributed (gloo, two ranks on this one GPU): lanes sharded 4 + 2, the GLOBAL user count in the
+    loss normaliser, one all-reduce of the flat gradient arena -> both ranks hold the gradient and the Adam update of the whole batch."""
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from hiertcn_amd.model_hier_gmm import HierGmmModel
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    mp.spawn(_dp_hier_worker, args=(2, port, str(tmp_path), low), nprocs=2, join=True)
+    d0, d1 = np.load(str(tmp_path / "dp0.npz")), np.load(str(tmp_path / "dp1.npz"))
+    a, p, x, y, mask, st0 = _dp_hier_case(low)
+    m = HierGmmModel(a, p, "hier")
+    m.enable_training()
+    out = m.train_step_hier(dev(x), dev(y), dev(mask), dev(st0), 1e-2)
+    sums = out["sums"].cpu().numpy()
+    g, w = m.export("grads"), m.export("weights")
+    assert d0["sums"][1] == d1["sums"][1] == sums[1] == 6                                         # users of the GLOBAL batch
+    assert abs(d0["sums"][0] - sums[0]) < 1e-6 * abs(sums[0])
+    np.testing.assert_allclose(np.concatenate([d0["state"], d1["state"]]), out["state"].cpu().numpy(), atol=1e-6, rtol=0)   # each rank carries ITS lanes
+    for k in g:
+        assert np.array_equal(d0["g:" + k], d1["g:" + k]) and np.array_equal(d0["w:" + k], d1["w:" + k]), (
+            k, np.abs(d0["g:" + k] - d1["g:" + k]).max(), np.abs(d0["w:" + k] - d1["w:" + k]).max(), np.abs(d0["g:" + k]).max())   # replicas stay identical
+        assert np.linalg.norm(d0["g:" + k] - g[k]) <= 5e-6 * max(np.linalg.norm(g[k]), 1e-30), (k, np.linalg.norm(d0["g:" + k] - g[k]) / np.linalg.norm(g[k]))
+        # (Adam's first step divides g by |g| + eps: where |g| ~ eps the last bits of the summed gradients are magnified -- see the single-level test)
+        assert np.abs(d0["w:" + k] - w[k]).max() <= 3e-3 * 1e-2, (k, np.abs(d0["w:" + k] - w[k]).max())
+    m.close()
+
+
 # ---- model_gru_gmm: the GRU stack on one-hot rows (model_gru_gmm.py:33-48) under the same head -----------------------------------------------------
 def _gru_args(N, M, H, nl, loss="gmm_prob"):
     return make_args([], model_type="gru_gmm", item_num=N, output_dim=N, num_mixture=M, sigma=0.1, loss=loss, hidden_dim=H, num_layer=nl, adjust=False)
