@@ -762,7 +762,10 @@ def torch_hier_loss(a, P, x, y, mask, st0, mode, scope="hier", kinks=None):
 @pytest.mark.parametrize("mode", ["gmm_prob", "gmm_prob_max"])
 @pytest.mark.parametrize("low,N,E,H,nl,M,channels,K,B,S,L", [("tcn_gmm", 900, 64, 32, 2, 3, (64, 128), 3, 5, 4, 7), ("tcn_gmm", 500, 64, 64, 1, 2, (128,), 2, 3, 5, 6),
                                                              ("tcn_gmm", 1500, 128, 64, 2, 4, (128, 128), 5, 6, 3, 12),
-                                                             ("gru_gmm", 900, 64, 64, 2, 3, (64,), 3, 5, 4, 7), ("gru_gmm", 600, 64, 128, 1, 2, (64,), 3, 4, 3, 9)])
+                                                             ("gru_gmm", 900, 64, 64, 2, 3, (64,), 3, 5, 4, 7), ("gru_gmm", 600, 64, 128, 1, 2, (64,), 3, 4, 3, 9),
+                                                             # the reference's defaults (args.py: emb 128, hidden 128 x 2, [128, 128] K = 5, 5 mixtures, the XING catalogue)
+                                                             ("tcn_gmm", 20_778, 128, 128, 2, 5, (128, 128), 5, 4, 3, 20),
+                                                             ("gru_gmm", 20_778, 128, 128, 2, 5, (128,), 5, 4, 3, 20)])
 def test_hier_low_level_every_gradient_against_fp64_autograd(low, N, E, H, nl, M, channels, K, B, S, L, mode):
     _hier_gradient_case(low, N, E, H, nl, M, channels, K, B, S, L, mode, 0.1)
 
