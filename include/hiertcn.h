@@ -403,7 +403,7 @@ typedef struct {
   const float* gru_gate_bias[HIERTCN_MAX_LAYERS];
   const float* gru_cand_kernel[HIERTCN_MAX_LAYERS];
   const float* gru_cand_bias[HIERTCN_MAX_LAYERS];
-  /* TRAINING of trunk 2 as the low level of model_hier (hiertcn_gmm_train_step_hier, ABI 12) only -- the HIGH level's variables, which the step
+  /* TRAINING of trunk 2 / 3 as the low level of model_hier (hiertcn_gmm_train_step_hier, ABI 12) only -- the HIGH level's variables, which the step
    * differentiates too: hier/emb/kernel [item_num][E] and hier/emb/bias [E] (E = input_dim - hidden_dim * num_layer), and the across-session cells
    * hier/multi_rnn_cell/cell_l/gru_cell/{gates,candidate}/{kernel,bias} in the rnn.GRUCell layouts (in_0 = E, in_l = hidden_dim).  Ignored (may be
    * NULL) everywhere else: evaluation takes the high level from the main handle (hiertcn_session_pool, hiertcn_gru_scan, hiertcn_embed_concat). */
@@ -463,7 +463,8 @@ int hiertcn_gmm_train_step(hiertcn_gmm_handle_t g, const int32_t* x_ids, const i
  * variables (hiertcn_gmm_weights_t.hl_*; cfg.item_num / hidden_dim / num_layer describe them, emb width = input_dim - hidden_dim * num_layer), the step runs
  * session mean-pool -> across-session scan -> [e, state] rows -> TemporalConvNet or GRU stack -> head -> loss and all of its backward (the rows' gradient into the item
  * table and the states, backward through the S slots with the user-boundary mask, the pool), x_ids / y_ids [B][S][L], mask [B][S], state_in / state_out
- * [B][hidden_dim * num_layer]; lanes = users (B <= 4096 per step).  Evaluation keeps using the main handle for the high level: after training, export
+ * [B][hidden_dim * num_layer]; lanes = users (B <= 4096 per step).  Every session holds at least one id > 0 (the loader's do): an empty one is the
+ * reference's 0 / 0 (model_hier.py:84) -- a NaN state, and NaN gradients behind it.  Evaluation keeps using the main handle for the high level: after training, export
  * the hl_* masters (hiertcn_gmm_train_copy) into it (hiertcn_set_weights). */
 size_t hiertcn_gmm_train_hier_workspace_bytes(hiertcn_gmm_handle_t g, int64_t B, int32_t S, int32_t L);
 int hiertcn_gmm_train_step_hier(hiertcn_gmm_handle_t g, const int32_t* x_ids, const int32_t* y_ids, const float* mask, const float* state_in, int64_t B, int32_t S,
