@@ -26,20 +26,28 @@ def evaluate_gmm(args, loader, sess, prefix="test"):
     time_load = time_run = 0.0
     meter = EpochMeter(args.log_path + prefix + "/results.txt" if getattr(args, "log_path", None) and is_main() else None, final_header=False)
     nan = float("nan")
+
+    def add(sums):
+        s = [float(v) for v in sums.cpu()]
+        step = {k: nan for k, _ in SCALARS}
+        step["loss"] = s[0] / s[1] if s[1] > 0 else nan
+        meter.add(step)
+
+    pending = None
     while True:
         t1 = time.time()
         batch_x, batch_y, _info = loader.get_batch()
         t2 = time.time()
         sums = model.eval_step(batch_x, batch_y)["sums"]
-        s = [float(v) for v in sums.cpu()]
-        step = {k: nan for k, _ in SCALARS}
-        step["loss"] = s[0] / s[1] if s[1] > 0 else nan
-        meter.add(step)
+        if pending is not None:       # a batch's two doubles are read while the next one runs
+            add(pending)
+        pending = sums
         t3 = time.time()
         time_load += t2 - t1
         time_run += t3 - t2
         if loader.done:
             break
+    add(pending)
     # data-parallel evaluation: every rank walked its own shard of the users -- shards may differ in their number of batches, so there is
     # no collective inside the loop (a rank that finished early would leave the others waiting in it); the epoch value is the mean over
     # the batches of all ranks, pooled once here exactly as evaluate_hier / evaluate_nn pool theirs (EpochMeter.finish)
