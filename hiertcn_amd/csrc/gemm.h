@@ -19,6 +19,8 @@ struct GruBwdEpi {
   float* na_dac; float* na_dag; float* na_dhpart;
 };
 hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float* B, int64_t ldb, int M, int N, int K, const GruBwdEpi& ep, hipStream_t st);
+struct GruBwdProd { const float* A; int64_t lda; const float* B; int64_t ldb; int M, N, K; GruBwdEpi ep; };
+hipError_t gemm32_nn_gru_bwd_n(int mode, const GruBwdProd* pr, int n, hipStream_t st);   // n = 1 or 2 independent products as one launch
 int gemm32_skinny_max_rows();
 // scratch (optional): partial tiles of a reduction sliced over blockIdx.z where the output has few tiles and K is long -- the fp32 training mode's
 // d hidden [R][C] = d logits [R][NP] . Wo^T [NP][C] is 50-100 tiles behind a reduction of 20,800 (gemm32_tn's slicing, summed in slice order)

@@ -231,9 +231,7 @@ static hipError_t run32(const float* A, int64_t lda, const float* B, int64_t ldb
 // half the round trips.  (The sum over k is split in four: results differ from the tiled kernel's in the last bit.)
 #define SK_THREADS 512
 template <int EPI>
-__global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, const GruBwdEpi ep) {
-  __shared__ float As[32 * SK_PA];
-  __shared__ float Bs[SK_K * SK_PB];   // (>= 4 x 32 x 64 floats: the partial tiles of the final reduction)
+__device__ __forceinline__ void sk_body(const G32& g, const GruBwdEpi& ep, float* As, float* Bs) {
   const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
   const int wave = wv & 1, wk = wv >> 1;
   const int lr = lane & 31, lh = lane >> 5;
@@ -364,6 +362,24 @@ __global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, co
   }
 }
 
+template <int EPI>
+__global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny(const G32 g, const GruBwdEpi ep) {
+  __shared__ float As[32 * SK_PA];
+  __shared__ float Bs[SK_K * SK_PB];   // (>= 4 x 32 x 64 floats: the partial tiles of the final reduction)
+  sk_body<EPI>(g, ep, As, Bs);
+}
+// up to two independent products of one launch (blockIdx.z): the cells of one anti-diagonal of a GRU stack's backward through time (gmm_train.hip) --
+// their N may differ (layer 0 of a stack on one-hot rows has no dense input half): the grid covers the wider one
+struct SkPair { G32 g[2]; GruBwdEpi ep[2]; };
+template <int EPI>
+__global__ __launch_bounds__(SK_THREADS) void k_gemm32_nn_skinny_pair(const SkPair p) {
+  __shared__ float As[32 * SK_PA];
+  __shared__ float Bs[SK_K * SK_PB];
+  const G32& g = p.g[blockIdx.z];
+  if ((int)blockIdx.x * 64 >= g.N || (int)blockIdx.y * 32 >= g.M) return;   // (uniform per workgroup)
+  sk_body<EPI>(g, p.ep[blockIdx.z], As, Bs);
+}
+
 // rows up to which the skinny kernel (32-row tiles, the reduction split over a workgroup's waves) takes an nn product instead of the tiled one, and the
 // scan's backward its fused three-launch cells (train.hip).  Round 4: 64 -> 4096 -- the tiled kernel's 33 us per [128 x 512] . [512 x 256] product was
 // 1.4 ms of a 3.6 ms training step at 128 lanes (2.5 ms now; 256 / 512 / 1024 / 2048 lanes: 5.3 -> 4.0, 8.5 -> 7.2, 13.6 -> 12.2, 23.8 -> 22.9 ms;
@@ -394,6 +410,28 @@ hipError_t gemm32_nn_gru_bwd(int mode, const float* A, int64_t lda, const float*
   const dim3 grid((unsigned)((N + 63) / 64), (unsigned)((M + 31) / 32));
   if (mode == 1) hipLaunchKernelGGL(k_gemm32_nn_skinny<1>, grid, dim3(SK_THREADS), 0, st, g, ep);
   else hipLaunchKernelGGL(k_gemm32_nn_skinny<2>, grid, dim3(SK_THREADS), 0, st, g, ep);
+  return hipGetLastError();
+}
+
+// n = 1 or 2 such products as ONE launch (GruBwdProd: the arguments of gemm32_nn_gru_bwd)
+hipError_t gemm32_nn_gru_bwd_n(int mode, const GruBwdProd* pr, int n, hipStream_t st) {
+  if (n < 1 || n > 2) return hipErrorInvalidValue;
+  if (n == 1) return gemm32_nn_gru_bwd(mode, pr[0].A, pr[0].lda, pr[0].B, pr[0].ldb, pr[0].M, pr[0].N, pr[0].K, pr[0].ep, st);
+  SkPair p;
+  int maxN = 0, maxM = 0;
+  for (int i = 0; i < 2; i++) {
+    const GruBwdProd& q = pr[i];
+    if ((q.K & 3) || (q.N & 3) || (q.lda & 3) || (q.ldb & 3) || q.M <= 0 || q.M > gemm32_skinny_max_rows() || q.N != q.ep.in + q.ep.H) return hipErrorInvalidValue;
+    G32& g = p.g[i];
+    g.A = q.A; g.lda = q.lda; g.B = q.B; g.ldb = q.ldb; g.C = const_cast<float*>(q.ep.dcat_c); g.ldc = q.ep.K; g.M = q.M; g.N = q.N; g.K = q.K; g.beta = 0.f;
+    g.k_per_split = q.K; g.parts = nullptr; g.a_div = g.b_div = 0; g.a_ss = g.b_ss = 0;
+    p.ep[i] = q.ep;
+    maxN = q.N > maxN ? q.N : maxN;
+    maxM = q.M > maxM ? q.M : maxM;
+  }
+  const dim3 grid((unsigned)((maxN + 63) / 64), (unsigned)((maxM + 31) / 32), 2);
+  if (mode == 1) hipLaunchKernelGGL(k_gemm32_nn_skinny_pair<1>, grid, dim3(SK_THREADS), 0, st, p);
+  else hipLaunchKernelGGL(k_gemm32_nn_skinny_pair<2>, grid, dim3(SK_THREADS), 0, st, p);
   return hipGetLastError();
 }
 

@@ -176,21 +176,25 @@ __global__ __launch_bounds__(256) void k_gt_block0_bwd(const float* __restrict__
 // of gemm.hip need (gemm32_nn_gru_bwd: the other two pointwise steps ride on the two products' epilogues, three launches per cell instead of five):
 // an inactive row (t >= sequence_length) neither produced an output nor moved its state -- its dac / dag rows are zero, and its carried state
 // gradient passes through as dhpart, which the second product's epilogue then writes out unchanged (0 . W + dhpart).
-__global__ void k_gt_gru_bwd_a(const float* __restrict__ dcar, int ldd, const float* __restrict__ dout, int64_t ld_dout, const int32_t* __restrict__ seq_len,
-                               int tstep, const float* __restrict__ h, int ldh, const float* __restrict__ gates, const float* __restrict__ cand, int M, int H,
-                               float* __restrict__ dac, float* __restrict__ dag, float* __restrict__ dhpart) {
+struct GtBwdA {
+  const float* dcar; int ldd; const float* dout; int64_t ld_dout; int tstep; const float* h; int ldh; const float* gates; const float* cand;
+  float* dac; float* dag; float* dhpart;
+};
+struct GtBwdAPair { GtBwdA a[2]; };   // the cells of one anti-diagonal of the backward through time: blockIdx.y
+__global__ void k_gt_gru_bwd_a(const GtBwdAPair p, const int32_t* __restrict__ seq_len, int M, int H) {
+  const GtBwdA& a = p.a[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)M * H) return;
   const int64_t b = i / H;
   const int k = (int)(i - b * H);
-  const bool active = tstep < seq_len[b];
-  const float car = dcar[b * ldd + k];
-  const float d = active ? car + dout[b * ld_dout + k] : 0.f;
-  const float u = gates[b * 2 * H + H + k], c = cand[i], hv = h[b * ldh + k];
-  dac[i] = d * (1.f - u) * (1.f - c * c);
-  dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
-  dag[b * 2 * H + k] = 0.f;                      // (the r half is written by the first product's epilogue for every row; zero here in case M exceeds a tile edge)
-  dhpart[i] = active ? d * u : car;
+  const bool active = a.tstep < seq_len[b];
+  const float car = a.dcar[b * a.ldd + k];
+  const float d = active ? car + a.dout[b * a.ld_dout + k] : 0.f;
+  const float u = a.gates[b * 2 * H + H + k], c = a.cand[i], hv = a.h[b * a.ldh + k];
+  a.dac[i] = d * (1.f - u) * (1.f - c * c);
+  a.dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  a.dag[b * 2 * H + k] = 0.f;                    // (the r half is written by the first product's epilogue for every row; zero here in case M exceeds a tile edge)
+  a.dhpart[i] = active ? d * u : car;
 }
 
 // trunk 1, layer 0: the input half of [x, h] . W on a one-hot row is the table row W[id] (model_gru_gmm.py:33-48 on one_hot(id) * sign(id)); its gradient is a
@@ -276,19 +280,23 @@ __global__ __launch_bounds__(256) void k_gt_hier_rows_bwd(const float* __restric
 }
 // first pointwise step of an across-session cell's backward (customed_gru_cell.py:323-337 differentiated; model_hier.py:93's mask): the gradient of the
 // cell's unmasked output is (carried from slot s + 1 + what slot s + 1's rows sent to the state they read) * mask[s] + what the layer above sent down
-__global__ void k_gt_hl_bwd_a(const float* __restrict__ dcar, int ldc, const float* __restrict__ dsb_next, int64_t ld_dsb, const float* __restrict__ mask, int ldm,
-                              const float* __restrict__ din_up, const float* __restrict__ h, int64_t ldh, const float* __restrict__ gates,
-                              const float* __restrict__ cand, int B, int H, float* __restrict__ dac, float* __restrict__ dag, float* __restrict__ dhpart) {
+struct GtHlBwdA {
+  const float* dcar; int ldc; const float* dsb_next; int64_t ld_dsb; const float* mask; int ldm; const float* din_up; const float* h; int64_t ldh;
+  const float* gates; const float* cand; float* dac; float* dag; float* dhpart;
+};
+struct GtHlBwdAPair { GtHlBwdA a[2]; };   // the cells of one anti-diagonal (slot, layer): blockIdx.y
+__global__ void k_gt_hl_bwd_a(const GtHlBwdAPair p, int B, int H) {
+  const GtHlBwdA& a = p.a[blockIdx.y];
   const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (int64_t)B * H) return;
   const int64_t b = i / H;
   const int k = (int)(i - b * H);
-  const float d = (dcar[b * ldc + k] + dsb_next[b * ld_dsb + k]) * mask[b * ldm] + (din_up ? din_up[i] : 0.f);
-  const float u = gates[b * 2 * H + H + k], c = cand[i], hv = h[b * ldh + k];
-  dac[i] = d * (1.f - u) * (1.f - c * c);
-  dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
-  dag[b * 2 * H + k] = 0.f;
-  dhpart[i] = d * u;
+  const float d = (a.dcar[b * a.ldc + k] + a.dsb_next[b * a.ld_dsb + k]) * a.mask[b * a.ldm] + (a.din_up ? a.din_up[i] : 0.f);
+  const float u = a.gates[b * 2 * H + H + k], c = a.cand[i], hv = a.h[b * a.ldh + k];
+  a.dac[i] = d * (1.f - u) * (1.f - c * c);
+  a.dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  a.dag[b * 2 * H + k] = 0.f;
+  a.dhpart[i] = d * u;
 }
 // backward of the session mean-pool + bias (model_hier.py:83-85): d emb[y_t] += d pooled / cnt for the session's cnt targets (the bias: column sums)
 __global__ __launch_bounds__(256) void k_gt_pool_bwd(const float* __restrict__ dpooled, const int32_t* __restrict__ y, int64_t n_sess, int L, int E, int N,
@@ -720,10 +728,10 @@ static GtWs gt_ws(const hiertcn_gmm_ctx* g, int64_t B, int T) {
     w.dag_all = take(nl * L * M * 2 * H);
     w.dcar[0] = take(M * HT);
     w.dcar[1] = take(M * HT);
-    w.dhpart = take(M * H);
-    w.dcat_c = take(M * Kmax);
+    w.dhpart = take(nl * M * H);      // (per layer: the cells of one anti-diagonal of the backward run in one launch)
+    w.dcat_c = take(nl * M * Kmax);
     w.dcat_g = take(M * Kmax);
-    w.din_up = take(M * H);
+    w.din_up = take(nl * M * H);
   } else {
     for (int i = 0; i < g->nb; i++) { w.act[i] = take(R * g->cfg.channels[i]); w.cact[i] = take(R * g->cfg.channels[i]); }
     w.resb = take(R * cm);
@@ -1087,7 +1095,59 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
     const float* dHid = F32(w.dH);
     G_HIP(hipMemsetAsync(lcar, 0, (size_t)Mb * HT * 4, st));   // the final state is dropped (model_gru_gmm.py:47: outputs only)
     const bool fused = Mb <= gemm32_skinny_max_rows();
-    for (int tt = L - 1; tt >= 0; tt--) {
+    const size_t Kmax_ws = (g->trunk == 3 && (size_t)in0 + Hh > 2 * (size_t)Hh) ? (size_t)in0 + Hh : 2 * (size_t)Hh;   // (gt_ws' pitch of the per-layer scratch)
+    if (fused) {
+      // Wavefront over (step, layer), last to first: cell (tt, l) needs (tt + 1, l) [the carried state gradient] and (tt, l + 1) [its output's gradient]
+      // only, so the cells with tt + l = const are independent and go out together -- three launches per anti-diagonal (the pointwise step, the two
+      // products with the other two pointwise steps as epilogues: gemm32_nn_gru_bwd_n), 3 (L + nl - 1) dependent launches instead of 3 L nl.  The carried
+      // gradient alternates between two [M][HT] buffers by the parity of tt (cell (tt, l) reads slot (tt + 1) & 1, writes slot tt & 1, columns of layer l).
+      float* car[2] = {F32(w.dcar[0]), F32(w.dcar[1])};
+      G_HIP(hipMemsetAsync(car[1], 0, (size_t)Mb * HT * 4, st));
+      for (int tau = 0; tau < L + nl - 1; tau++) {
+        GtBwdAPair pa;
+        GruBwdProd p1[HIERTCN_MAX_LAYERS], p2[HIERTCN_MAX_LAYERS];
+        GtBwdA aa[HIERTCN_MAX_LAYERS];
+        int n = 0;
+        for (int l = nl - 1; l >= 0; l--) {
+          const int tt = (L - 1) - (tau - (nl - 1 - l));
+          if (tt < 0 || tt >= L) continue;
+          const int in = (l == 0) ? in0 : Hh, Kc = in + Hh;
+          float* din_l = din_up + (size_t)l * Mb * Hh;                              // written by layer l (its input's gradient), read by layer l - 1
+          float* d_in = (l == 0) ? (in0 ? d_rows + (size_t)tt * in0 : din_l) : din_l;
+          const int64_t ld_d_in = (l == 0 && in0) ? (int64_t)L * in0 : Hh;
+          const float* rec = recs + ((size_t)tt * nl + l) * cell;
+          const float* gates = rec;
+          const float* cand = rec + (size_t)Mb * 3 * Hh;
+          const float* hold = states + (size_t)tt * Mb * HT + (size_t)l * Hh;   // row stride HT
+          float* dac = dac_all + ((size_t)l * L + tt) * Mb * Hh;
+          float* dag = dag_all + ((size_t)l * L + tt) * Mb * 2 * Hh;
+          float* dhp = dhpart + (size_t)l * Mb * Hh;
+          float* dcc = dcat_c + (size_t)l * Mb * Kmax_ws;
+          GtBwdA& a = aa[n];
+          a.dcar = car[(tt + 1) & 1] + (size_t)l * Hh; a.ldd = HT;
+          a.dout = (l == nl - 1) ? dHid + (size_t)tt * Hh : din_up + (size_t)(l + 1) * Mb * Hh;
+          a.ld_dout = (l == nl - 1) ? (int64_t)L * Hh : Hh;
+          a.tstep = tt; a.h = hold; a.ldh = HT; a.gates = gates; a.cand = cand; a.dac = dac; a.dag = dag; a.dhpart = dhp;
+          GruBwdEpi ep;
+          memset(&ep, 0, sizeof(ep));
+          ep.in = in; ep.H = Hh; ep.K = Kc;
+          ep.gates = gates; ep.h = hold; ep.ldh = HT; ep.dag = dag; ep.dhpart = dhp; ep.dcat_c = dcc;
+          ep.dst_in = d_in; ep.ldi = (int)ld_d_in; ep.dst_h = car[tt & 1] + (size_t)l * Hh; ep.ldo = HT;
+          p1[n].A = dac; p1[n].lda = Hh; p1[n].B = t->wc[l]; p1[n].ldb = Kc; p1[n].M = Mb; p1[n].N = Kc; p1[n].K = Hh; p1[n].ep = ep;          // d [in | r*h] = dac . wc, then step b
+          p2[n].A = dag; p2[n].lda = 2 * Hh; p2[n].B = t->wg[l]; p2[n].ldb = Kc; p2[n].M = Mb; p2[n].N = Kc; p2[n].K = 2 * Hh; p2[n].ep = ep;    // d [in | h] = dag . wg, then step c
+          n++;
+        }
+        for (int i = 0; i < n; i += 2) {
+          const int k = (n - i) > 1 ? 2 : 1;
+          pa.a[0] = aa[i]; pa.a[1] = aa[i + k - 1];
+          hipLaunchKernelGGL(k_gt_gru_bwd_a, dim3((unsigned)(((int64_t)Mb * Hh + 255) / 256), k), dim3(256), 0, st, pa, seq_len, Mb, Hh);
+          G_HIP(hipGetLastError());
+        }
+        for (int i = 0; i < n; i += 2) G_HIP(gemm32_nn_gru_bwd_n(1, p1 + i, (n - i) > 1 ? 2 : 1, st));
+        for (int i = 0; i < n; i += 2) G_HIP(gemm32_nn_gru_bwd_n(2, p2 + i, (n - i) > 1 ? 2 : 1, st));
+      }
+    }
+    for (int tt = L - 1; tt >= 0 && !fused; tt--) {   // more lanes than the skinny products take: the five-launch cells, one after the other
       for (int l = nl - 1; l >= 0; l--) {
         const int in = (l == 0) ? in0 : Hh;          // one-hot rows: layer 0's input half is the gathered table row, no dense input operand
         const int Kc = in + Hh;
@@ -1101,19 +1161,6 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
         const int64_t ld_dout = (l == nl - 1) ? (int64_t)L * Hh : Hh;
         float* dac = dac_all + ((size_t)l * L + tt) * Mb * Hh;
         float* dag = dag_all + ((size_t)l * L + tt) * Mb * 2 * Hh;
-        if (fused) {   // three launches per cell: the pointwise steps b and c ride on the two products' epilogues (gemm.hip, gemm32_nn_gru_bwd)
-          hipLaunchKernelGGL(k_gt_gru_bwd_a, dim3((unsigned)(((int64_t)Mb * Hh + 255) / 256)), dim3(256), 0, st, lcar + (size_t)l * Hh, HT, dout, ld_dout, seq_len, tt,
-                             hold, HT, gates, cand, Mb, Hh, dac, dag, dhpart);
-          G_HIP(hipGetLastError());
-          GruBwdEpi ep;
-          memset(&ep, 0, sizeof(ep));
-          ep.in = in; ep.H = Hh; ep.K = Kc;
-          ep.gates = gates; ep.h = hold; ep.ldh = HT; ep.dag = dag; ep.dhpart = dhpart; ep.dcat_c = dcat_c;
-          ep.dst_in = d_in; ep.ldi = (int)ld_d_in; ep.dst_h = lnext + (size_t)l * Hh; ep.ldo = HT;
-          G_HIP(gemm32_nn_gru_bwd(1, dac, Hh, t->wc[l], Kc, Mb, Kc, Hh, ep, st));           // d [in | r*h] = dac . wc, then step b
-          G_HIP(gemm32_nn_gru_bwd(2, dag, 2 * Hh, t->wg[l], Kc, Mb, Kc, 2 * Hh, ep, st));    // d [in | h] = dag . wg, then step c
-          continue;
-        }
         G_HIP(train_lgru_bwd_a(lcar + (size_t)l * Hh, HT, dout, ld_dout, seq_len, tt, hold, HT, gates, cand, Mb, Hh, dac, dag, dhpart, st));
         G_HIP(gemm32_nn(dac, Hh, t->wc[l], Kc, dcat_c, Kc, Mb, Kc, Hh, 0.f, st));            // d [in | r*h] = dac . wc
         G_HIP(train_gru_bwd_b(dcat_c, Kc, in, hold, HT, gates, Mb, Hh, dag, dhpart, st));
@@ -1245,9 +1292,9 @@ static GtHierWs gt_hier_ws(const GmmTrain* t, int64_t B, int S, int L, size_t ba
   w.dag_all = take(nl * S * Bz * 2 * H);
   w.dcar[0] = take(Bz * HT);
   w.dcar[1] = take(Bz * HT);
-  w.dhpart = take(Bz * H);
-  w.dcat_c = take(Bz * (W > 2 * H ? W : 2 * H));
-  w.din_up = take(Bz * H);
+  w.dhpart = take(nl * Bz * H);     // (per layer: the cells of one anti-diagonal of the backward run in one launch)
+  w.dcat_c = take(nl * Bz * (W > 2 * H ? W : 2 * H));
+  w.din_up = take(nl * Bz * H);
   w.total = off;
   return w;
 }
@@ -1326,8 +1373,18 @@ int hiertcn_gmm_train_step_hier(hiertcn_gmm_handle_t g, const int32_t* x_ids, co
   float* dac_all = F32(hw.dac_all);
   float* dag_all = F32(hw.dag_all);
   G_HIP(hipMemsetAsync(dcar, 0, (size_t)B * HT * 4, st));     // the state behind the last slot is an output, not part of the loss
-  for (int sl = S - 1; sl >= 0; sl--) {
+  G_HIP(hipMemsetAsync(dnext, 0, (size_t)B * HT * 4, st));
+  // wavefront over (slot, layer), last to first, as the low-level stack's (gt_step_core): cell (sl, l) needs (sl + 1, l) and (sl, l + 1) only; the carried
+  // gradient alternates between the two buffers by the slot's parity; 3 (S + nl - 1) dependent launches instead of 3 S nl
+  float* car[2] = {dcar, dnext};
+  const size_t pitch_c = (size_t)B * ((size_t)W > 2 * (size_t)H ? (size_t)W : 2 * (size_t)H);
+  for (int tau = 0; tau < S + nl - 1; tau++) {
+    GtHlBwdA aa[HIERTCN_MAX_LAYERS];
+    GruBwdProd p1[HIERTCN_MAX_LAYERS], p2[HIERTCN_MAX_LAYERS];
+    int n = 0;
     for (int l = nl - 1; l >= 0; l--) {
+      const int sl = (S - 1) - (tau - (nl - 1 - l));
+      if (sl < 0 || sl >= S) continue;
       const int in = (l == 0) ? E : H, Kc = in + H;
       const float* rec = save + ((size_t)sl * nl + l) * cell;
       const float* gates = rec;
@@ -1335,19 +1392,31 @@ int hiertcn_gmm_train_step_hier(hiertcn_gmm_handle_t g, const int32_t* x_ids, co
       const float* hold = hist + (size_t)sl * HT + (size_t)l * H;        // row stride hs
       float* dac = dac_all + ((size_t)l * S + sl) * B * H;
       float* dag = dag_all + ((size_t)l * S + sl) * B * 2 * H;
-      hipLaunchKernelGGL(k_gt_hl_bwd_a, dim3((unsigned)(((int64_t)B * H + 255) / 256)), dim3(256), 0, st, dcar + (size_t)l * H, HT,
-                         dsb + (size_t)(sl + 1) * HT + (size_t)l * H, hs, mask + sl, S, (l == nl - 1) ? nullptr : din_up, hold, hs, gates, cand, Bi, H, dac, dag, dhpart);
-      G_HIP(hipGetLastError());
+      float* dhp = dhpart + (size_t)l * B * H;
+      GtHlBwdA& a = aa[n];
+      a.dcar = car[(sl + 1) & 1] + (size_t)l * H; a.ldc = HT;
+      a.dsb_next = dsb + (size_t)(sl + 1) * HT + (size_t)l * H; a.ld_dsb = hs; a.mask = mask + sl; a.ldm = S;
+      a.din_up = (l == nl - 1) ? nullptr : din_up + (size_t)(l + 1) * B * H;   // (written by layer l + 1: its input's gradient)
+      a.h = hold; a.ldh = hs; a.gates = gates; a.cand = cand; a.dac = dac; a.dag = dag; a.dhpart = dhp;
       GruBwdEpi ep;
       memset(&ep, 0, sizeof(ep));
       ep.in = in; ep.H = H; ep.K = Kc;
-      ep.gates = gates; ep.h = hold; ep.ldh = (int)hs; ep.dag = dag; ep.dhpart = dhpart; ep.dcat_c = dcat_c;
-      ep.dst_in = (l == 0) ? dpooled + (size_t)sl * E : din_up; ep.ldi = (l == 0) ? S * E : H;
-      ep.dst_h = dnext + (size_t)l * H; ep.ldo = HT;
-      G_HIP(gemm32_nn_gru_bwd(1, dac, H, t->hwc[l], Kc, Bi, Kc, H, ep, st));
-      G_HIP(gemm32_nn_gru_bwd(2, dag, 2 * H, t->hwg[l], Kc, Bi, Kc, 2 * H, ep, st));
+      ep.gates = gates; ep.h = hold; ep.ldh = (int)hs; ep.dag = dag; ep.dhpart = dhp; ep.dcat_c = dcat_c + (size_t)l * pitch_c;
+      ep.dst_in = (l == 0) ? dpooled + (size_t)sl * E : din_up + (size_t)l * B * H; ep.ldi = (l == 0) ? S * E : H;
+      ep.dst_h = car[sl & 1] + (size_t)l * H; ep.ldo = HT;
+      p1[n].A = dac; p1[n].lda = H; p1[n].B = t->hwc[l]; p1[n].ldb = Kc; p1[n].M = Bi; p1[n].N = Kc; p1[n].K = H; p1[n].ep = ep;
+      p2[n].A = dag; p2[n].lda = 2 * H; p2[n].B = t->hwg[l]; p2[n].ldb = Kc; p2[n].M = Bi; p2[n].N = Kc; p2[n].K = 2 * H; p2[n].ep = ep;
+      n++;
     }
-    float* tmp = dcar; dcar = dnext; dnext = tmp;
+    for (int i = 0; i < n; i += 2) {
+      const int k = (n - i) > 1 ? 2 : 1;
+      GtHlBwdAPair pa;
+      pa.a[0] = aa[i]; pa.a[1] = aa[i + k - 1];
+      hipLaunchKernelGGL(k_gt_hl_bwd_a, dim3((unsigned)(((int64_t)B * H + 255) / 256), k), dim3(256), 0, st, pa, Bi, H);
+      G_HIP(hipGetLastError());
+    }
+    for (int i = 0; i < n; i += 2) G_HIP(gemm32_nn_gru_bwd_n(1, p1 + i, (n - i) > 1 ? 2 : 1, st));
+    for (int i = 0; i < n; i += 2) G_HIP(gemm32_nn_gru_bwd_n(2, p2 + i, (n - i) > 1 ? 2 : 1, st));
   }
   // weight gradients of all S * nl cells: one product per layer and operand over the S * B rows (rows (slot, user))
   const int SB = S * Bi;

@@ -798,6 +798,28 @@ static hipError_t gru_rows_cells(const OneHotGru& w, const int32_t* x, const flo
   return hipSuccess;
 }
 
+// (step, layer) wavefront of a records-keeping GRU stack: every cell has its own record and state slot, so the cells of one anti-diagonal share nothing;
+// they go out two per launch (k_gemm_f32 takes a pair of GEMMs with one (M, N); their K and input kind may differ -- each block reads its own arguments)
+template <class CellArgs>
+static hipError_t records_wavefront(int nl, int L, CellArgs&& cell_args, hipStream_t st) {
+  hipError_t e;
+  for (int tau = 0; tau < L + nl - 1; tau++) {
+    GemmArgs gg[HIERTCN_MAX_LAYERS], gc[HIERTCN_MAX_LAYERS];
+    int n = 0;
+    for (int l = 0; l < nl; l++) {
+      const int t = tau - l;
+      if (t < 0 || t >= L) continue;
+      cell_args(t, l, gg[n], gc[n]);
+      n++;
+    }
+    for (int i = 0; i < n; i += 2)
+      if ((e = launch_gemm<EPI_GATES>(gg + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
+    for (int i = 0; i < n; i += 2)
+      if ((e = launch_gemm<EPI_CAND>(gc + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // The same cells with EVERY record kept, fp32 output rows and the masters' fp32 kernels as they are (gmm_train.hip: the training step of model_gru_gmm):
 //   states [L + 1][M][HT] (slot 0 = the zero state), recs [L][nl][gates 2H | r*h H | cand H | out H per session], hidden32 [M * L][H] rows (session, t)
 hipError_t launch_onehot_gru_records(const OneHotGru& w, const int32_t* x, int64_t n_sess, int L, float* hidden32, int32_t* seq_len, float* states, float* recs,
@@ -809,40 +831,38 @@ hipError_t launch_onehot_gru_records(const OneHotGru& w, const int32_t* x, int64
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state
-  for (int t = 0; t < L; t++) {
+  // wavefront over (step, layer) as in launch_gru_scan: cell (t, l) needs (t, l - 1) and (t - 1, l) only, so the cells with t + l = tau go out as ONE grouped
+  // launch per GEMM kind -- 2 (L + nl - 1) dependent launches instead of 2 L nl (the chain is bound by the device's dependent-launch latency)
+  auto cell_args = [&](int t, int l, GemmArgs& g, GemmArgs& gc) {
     const float* s_old = states + (size_t)t * n_sess * HT;
     float* s_new = states + (size_t)(t + 1) * n_sess * HT;
-    for (int l = 0; l < w.nl; l++) {
-      float* rec = recs + ((size_t)t * w.nl + l) * cell;
-      GemmArgs g;
-      memset(&g, 0, sizeof(g));
-      const float* hold = s_old + (size_t)l * H;
-      float* gates = rec;
-      float* rh = rec + (size_t)n_sess * 2 * H;
-      g.M = (int)n_sess; g.H = H;
-      if (l == 0) {
-        g.A1 = nullptr; g.lda1 = 0; g.K1 = 0;
-        g.add_tab = w.in_g; g.add_ld = 2 * H; g.add_n = w.N; g.add_ids = x + t; g.add_ids_ld = L;
-      } else {
-        g.A1 = recs + ((size_t)t * w.nl + l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H;
-      }
-      g.A2 = hold; g.lda2 = HT; g.K2 = H;
-      g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
-      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
-      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
-      g.A2 = rh; g.lda2 = H;
-      g.Wt = w.wc[l]; g.bias = w.bc[l]; g.N = H;
-      if (l == 0) { g.add_tab = w.in_c; g.add_ld = H; }
-      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
-      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
-      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
-      g.gates = gates; g.ldg = 2 * H;
-      g.seq_len = seq_len; g.tstep = t;
-      if (l == w.nl - 1) { g.hid_out32 = hidden32 + (size_t)t * H; g.ldho = (int64_t)L * H; }
-      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    float* rec = recs + ((size_t)t * w.nl + l) * cell;
+    memset(&g, 0, sizeof(g));
+    const float* hold = s_old + (size_t)l * H;
+    float* gates = rec;
+    float* rh = rec + (size_t)n_sess * 2 * H;
+    g.M = (int)n_sess; g.H = H;
+    if (l == 0) {
+      g.A1 = nullptr; g.lda1 = 0; g.K1 = 0;
+      g.add_tab = w.in_g; g.add_ld = 2 * H; g.add_n = w.N; g.add_ids = x + t; g.add_ids_ld = L;
+    } else {
+      g.A1 = recs + ((size_t)t * w.nl + l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H;
     }
-  }
-  return hipSuccess;
+    g.A2 = hold; g.lda2 = HT; g.K2 = H;
+    g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
+    g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+    gc = g;
+    gc.A2 = rh; gc.lda2 = H;
+    gc.Wt = w.wc[l]; gc.bias = w.bc[l]; gc.N = H;
+    if (l == 0) { gc.add_tab = w.in_c; gc.add_ld = H; }
+    gc.cand_out = rec + (size_t)n_sess * 3 * H; gc.ldc = H;
+    gc.out = rec + (size_t)n_sess * 4 * H; gc.ldo = H;
+    gc.out2 = s_new + (size_t)l * H; gc.ldo2 = HT;
+    gc.gates = gates; gc.ldg = 2 * H;
+    gc.seq_len = seq_len; gc.tstep = t;
+    if (l == w.nl - 1) { gc.hid_out32 = hidden32 + (size_t)t * H; gc.ldho = (int64_t)L * H; }
+  };
+  return records_wavefront(w.nl, L, cell_args, st);
 }
 
 // ... and on DENSE fp32 rows of width in_dim (model_hier.py:68-69: model_gru_gmm as the low level reads the [e_t, state] rows; gmm_train.hip: the training step
@@ -870,33 +890,29 @@ hipError_t launch_rows_gru_records(const OneHotGru& w, const float* rows, int in
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) return e;
   if ((e = hipMemsetAsync(states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state
-  for (int t = 0; t < L; t++) {
+  auto cell_args = [&](int t, int l, GemmArgs& g, GemmArgs& gc) {   // (the wavefront of launch_onehot_gru_records)
     const float* s_old = states + (size_t)t * n_sess * HT;
     float* s_new = states + (size_t)(t + 1) * n_sess * HT;
-    for (int l = 0; l < w.nl; l++) {
-      float* rec = recs + ((size_t)t * w.nl + l) * cell;
-      GemmArgs g;
-      memset(&g, 0, sizeof(g));
-      const float* hold = s_old + (size_t)l * H;
-      float* gates = rec;
-      float* rh = rec + (size_t)n_sess * 2 * H;
-      g.M = (int)n_sess; g.H = H;
-      if (l == 0) { g.A1 = rows + (size_t)t * in_dim; g.lda1 = L * in_dim; g.K1 = in_dim; }
-      else { g.A1 = recs + ((size_t)t * w.nl + l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H; }
-      g.A2 = hold; g.lda2 = HT; g.K2 = H;
-      g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
-      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
-      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
-      g.A2 = rh; g.lda2 = H;
-      g.Wt = w.wc[l]; g.bias = w.bc[l]; g.N = H;
-      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
-      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
-      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
-      g.gates = gates; g.ldg = 2 * H;
-      g.seq_len = seq_len; g.tstep = t;
-      if (l == w.nl - 1) { g.hid_out32 = hidden32 + (size_t)t * H; g.ldho = (int64_t)L * H; }
-      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
-    }
-  }
-  return hipSuccess;
+    float* rec = recs + ((size_t)t * w.nl + l) * cell;
+    memset(&g, 0, sizeof(g));
+    const float* hold = s_old + (size_t)l * H;
+    float* gates = rec;
+    float* rh = rec + (size_t)n_sess * 2 * H;
+    g.M = (int)n_sess; g.H = H;
+    if (l == 0) { g.A1 = rows + (size_t)t * in_dim; g.lda1 = L * in_dim; g.K1 = in_dim; }
+    else { g.A1 = recs + ((size_t)t * w.nl + l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H; }
+    g.A2 = hold; g.lda2 = HT; g.K2 = H;
+    g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
+    g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+    gc = g;
+    gc.A2 = rh; gc.lda2 = H;
+    gc.Wt = w.wc[l]; gc.bias = w.bc[l]; gc.N = H;
+    gc.cand_out = rec + (size_t)n_sess * 3 * H; gc.ldc = H;
+    gc.out = rec + (size_t)n_sess * 4 * H; gc.ldo = H;
+    gc.out2 = s_new + (size_t)l * H; gc.ldo2 = HT;
+    gc.gates = gates; gc.ldg = 2 * H;
+    gc.seq_len = seq_len; gc.tstep = t;
+    if (l == w.nl - 1) { gc.hid_out32 = hidden32 + (size_t)t * H; gc.ldho = (int64_t)L * H; }
+  };
+  return records_wavefront(w.nl, L, cell_args, st);
 }
