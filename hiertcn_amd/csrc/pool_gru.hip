@@ -520,6 +520,28 @@ __global__ __launch_bounds__(256) void k_len_f32(const float* __restrict__ uf, i
 }
 
 // split-operand cells: state hi / lo ping-pong [2][2][M][HT] + per layer r*h hi / lo and output hi / lo [nl][4][M][H]
+// (step, layer) wavefront of a records-keeping GRU stack: every cell has its own record and state slot, so the cells of one anti-diagonal share nothing;
+// they go out two per launch (k_gemm_f32 takes a pair of GEMMs with one (M, N); their K and input kind may differ -- each block reads its own arguments)
+template <class CellArgs>
+static hipError_t records_wavefront(int nl, int L, CellArgs&& cell_args, hipStream_t st) {
+  hipError_t e;
+  for (int tau = 0; tau < L + nl - 1; tau++) {
+    GemmArgs gg[HIERTCN_MAX_LAYERS], gc[HIERTCN_MAX_LAYERS];
+    int n = 0;
+    for (int l = 0; l < nl; l++) {
+      const int t = tau - l;
+      if (t < 0 || t >= L) continue;
+      cell_args(t, l, gg[n], gc[n]);
+      n++;
+    }
+    for (int i = 0; i < n; i += 2)
+      if ((e = launch_gemm<EPI_GATES>(gg + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
+    for (int i = 0; i < n; i += 2)
+      if ((e = launch_gemm<EPI_CAND>(gc + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 size_t low_gru_x3_elems(const ModelDev& m, int64_t n_sess) { return (size_t)10 * n_sess * m.HT; }   // states 2 x 2, r*h 2, outputs 2 x 2 (hi, lo each)
 
 size_t low_gru_workspace_bytes(const ModelDev& m, int64_t n_sess, int L) {
@@ -635,40 +657,46 @@ hipError_t launch_low_gru_bufs(const ModelDev& m, const int32_t* x, const float*
     }
     return hipSuccess;
   }
-  for (int t = 0; t < L; t++) {
+  auto cell_args = [&](int t, int l, GemmArgs& g, GemmArgs& gc) {
     const float* s_old = b.states + (size_t)(t % b.n_states) * n_sess * HT;
     float* s_new = b.states + (size_t)((t + 1) % b.n_states) * n_sess * HT;
-    for (int l = 0; l < m.nl; l++) {
-      float* rec = b.rec + (b.keep_all ? ((size_t)t * m.nl + l) : (size_t)l) * cell;
-      const float* below = (l == 0) ? nullptr : b.rec + (b.keep_all ? ((size_t)t * m.nl + l - 1) : (size_t)(l - 1)) * cell + (size_t)n_sess * 4 * H;
-      GemmArgs g;
-      memset(&g, 0, sizeof(g));
-      const float* in = (l == 0) ? b.uf + (size_t)t * E : below;
-      const int ldin = (l == 0) ? L * E : H;
-      const int in_dim = (l == 0) ? E : H;
-      const float* hold = s_old + (size_t)l * H;
-      float* gates = rec;
-      float* rh = rec + (size_t)n_sess * 2 * H;
-      g.M = (int)n_sess; g.H = H;
-      g.A1 = in; g.lda1 = ldin; g.K1 = in_dim;
-      g.A2 = hold; g.lda2 = HT; g.K2 = H;
-      g.Wt = m.lgru_wg[l]; g.bias = m.lgru_bg[l]; g.N = 2 * H;
-      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
-      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
-      g.A2 = rh; g.lda2 = H;
-      g.Wt = m.lgru_wc[l]; g.bias = m.lgru_bc[l]; g.N = H;
-      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
-      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
-      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
-      g.gates = gates; g.ldg = 2 * H;
-      g.seq_len = b.seq_len; g.tstep = t;
-      if (l == m.nl - 1) {
-        g.ldho = (int64_t)L * H;
-        if (b.hidden32) g.hid_out32 = b.hidden32 + (size_t)t * H; else g.hid_out = hidden + (size_t)t * H;
-      }
-      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    float* rec = b.rec + (b.keep_all ? ((size_t)t * m.nl + l) : (size_t)l) * cell;
+    const float* below = (l == 0) ? nullptr : b.rec + (b.keep_all ? ((size_t)t * m.nl + l - 1) : (size_t)(l - 1)) * cell + (size_t)n_sess * 4 * H;
+    memset(&g, 0, sizeof(g));
+    const float* in = (l == 0) ? b.uf + (size_t)t * E : below;
+    const int ldin = (l == 0) ? L * E : H;
+    const int in_dim = (l == 0) ? E : H;
+    const float* hold = s_old + (size_t)l * H;
+    float* gates = rec;
+    float* rh = rec + (size_t)n_sess * 2 * H;
+    g.M = (int)n_sess; g.H = H;
+    g.A1 = in; g.lda1 = ldin; g.K1 = in_dim;
+    g.A2 = hold; g.lda2 = HT; g.K2 = H;
+    g.Wt = m.lgru_wg[l]; g.bias = m.lgru_bg[l]; g.N = 2 * H;
+    g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+    gc = g;
+    gc.A2 = rh; gc.lda2 = H;
+    gc.Wt = m.lgru_wc[l]; gc.bias = m.lgru_bc[l]; gc.N = H;
+    gc.cand_out = rec + (size_t)n_sess * 3 * H; gc.ldc = H;
+    gc.out = rec + (size_t)n_sess * 4 * H; gc.ldo = H;
+    gc.out2 = s_new + (size_t)l * H; gc.ldo2 = HT;
+    gc.gates = gates; gc.ldg = 2 * H;
+    gc.seq_len = b.seq_len; gc.tstep = t;
+    if (l == m.nl - 1) {
+      gc.ldho = (int64_t)L * H;
+      if (b.hidden32) gc.hid_out32 = b.hidden32 + (size_t)t * H; else gc.hid_out = hidden + (size_t)t * H;
     }
-  }
+  };
+  // every record kept (the fp32 training mode) and a state slot per step: the cells of an anti-diagonal share nothing -- the (step, layer) wavefront,
+  // two cells per launch (records_wavefront); otherwise the layers share one record each and the cells go one after the other
+  if (b.keep_all && b.n_states > L) return records_wavefront(m.nl, L, cell_args, st);
+  for (int t = 0; t < L; t++)
+    for (int l = 0; l < m.nl; l++) {
+      GemmArgs g, gc;
+      cell_args(t, l, g, gc);
+      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
+      if ((e = launch_gemm<EPI_CAND>(gc, st)) != hipSuccess) return e;
+    }
   return hipSuccess;
 }
 
@@ -794,28 +822,6 @@ static hipError_t gru_rows_cells(const OneHotGru& w, const int32_t* x, const flo
       if (l == w.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
       if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
     }
-  }
-  return hipSuccess;
-}
-
-// (step, layer) wavefront of a records-keeping GRU stack: every cell has its own record and state slot, so the cells of one anti-diagonal share nothing;
-// they go out two per launch (k_gemm_f32 takes a pair of GEMMs with one (M, N); their K and input kind may differ -- each block reads its own arguments)
-template <class CellArgs>
-static hipError_t records_wavefront(int nl, int L, CellArgs&& cell_args, hipStream_t st) {
-  hipError_t e;
-  for (int tau = 0; tau < L + nl - 1; tau++) {
-    GemmArgs gg[HIERTCN_MAX_LAYERS], gc[HIERTCN_MAX_LAYERS];
-    int n = 0;
-    for (int l = 0; l < nl; l++) {
-      const int t = tau - l;
-      if (t < 0 || t >= L) continue;
-      cell_args(t, l, gg[n], gc[n]);
-      n++;
-    }
-    for (int i = 0; i < n; i += 2)
-      if ((e = launch_gemm<EPI_GATES>(gg + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
-    for (int i = 0; i < n; i += 2)
-      if ((e = launch_gemm<EPI_CAND>(gc + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
   }
   return hipSuccess;
 }
