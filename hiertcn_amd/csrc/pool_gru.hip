@@ -742,7 +742,7 @@ __global__ __launch_bounds__(256) void k_count_ids(const int32_t* __restrict__ x
 
 size_t onehot_gru_workspace_bytes(int H, int nl, int64_t n_sess) {
   auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
-  return al((size_t)n_sess * 4) + al((size_t)2 * n_sess * H * nl * 4) + al((size_t)nl * n_sess * 5 * H * 4);
+  return al((size_t)n_sess * 4) + al((size_t)2 * n_sess * H * nl * 4) + al((size_t)2 * nl * n_sess * 5 * H * 4);   // (records by the step's parity: gru_rows_cells)
 }
 // ... on DENSE rows of width in_dim (model_hier.py:68-69: model_gru_gmm as the low level reads the [e_t, state] rows): + the rows as fp32
 size_t rows_gru_workspace_bytes(int H, int nl, int in_dim, int64_t n_sess, int L) {
@@ -758,7 +758,7 @@ hipError_t launch_rows_gru(const OneHotGru& w, const uint16_t* rows16, int in_di
   unsigned char* p = reinterpret_cast<unsigned char*>(workspace);
   int32_t* seq_len = reinterpret_cast<int32_t*>(p); p += al((size_t)n_sess * 4);
   float* states = reinterpret_cast<float*>(p);      p += al((size_t)2 * n_sess * w.H * w.nl * 4);
-  float* recs = reinterpret_cast<float*>(p);        p += al((size_t)w.nl * n_sess * 5 * w.H * 4);
+  float* recs = reinterpret_cast<float*>(p);        p += al((size_t)2 * w.nl * n_sess * 5 * w.H * 4);
   float* rows = reinterpret_cast<float*>(p);
   // the rows as fp32 (the GEMM operand) and dynamic_rnn's sequence_length = the count of rows that are not all-zero (model_gru_gmm.py:57-67)
   hipLaunchKernelGGL(k_rows_f32_and_len, dim3((unsigned)((n_sess + 3) / 4)), dim3(256), 0, st, rows16, n_sess, L, in_dim, rows, seq_len);
@@ -788,42 +788,40 @@ static hipError_t gru_rows_cells(const OneHotGru& w, const int32_t* x, const flo
   const size_t cell = (size_t)n_sess * 5 * H;   // gates [M][2H] | r*h [M][H] | cand [M][H] | out [M][H]
   hipError_t e;
   if ((e = hipMemsetAsync(states, 0, (size_t)n_sess * HT * 4, st)) != hipSuccess) return e;   // zero_state
-  for (int t = 0; t < L; t++) {
+  // (step, layer) wavefront, two cells per launch (records_wavefront): the layers' records alternate between two sets by the step's parity, so that cell
+  // (t + 1, l - 1) does not overwrite the output row cell (t, l) is reading in the same launch; the states alternate likewise (columns of one layer each)
+  auto cell_args = [&](int t, int l, GemmArgs& g, GemmArgs& gc) {
     const float* s_old = states + (size_t)(t & 1) * n_sess * HT;
     float* s_new = states + (size_t)((t + 1) & 1) * n_sess * HT;
-    for (int l = 0; l < w.nl; l++) {
-      float* rec = recs + (size_t)l * cell;
-      GemmArgs g;
-      memset(&g, 0, sizeof(g));
-      const float* hold = s_old + (size_t)l * H;
-      float* gates = rec;
-      float* rh = rec + (size_t)n_sess * 2 * H;
-      g.M = (int)n_sess; g.H = H;
-      if (l == 0 && rows) {
-        g.A1 = rows + (size_t)t * in_dim; g.lda1 = L * in_dim; g.K1 = in_dim;
-      } else if (l == 0) {
-        g.A1 = nullptr; g.lda1 = 0; g.K1 = 0;
-        g.add_tab = w.in_g; g.add_ld = 2 * H; g.add_n = w.N; g.add_ids = x + t; g.add_ids_ld = L;
-      } else {
-        g.A1 = recs + (size_t)(l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H;
-      }
-      g.A2 = hold; g.lda2 = HT; g.K2 = H;
-      g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
-      g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
-      if ((e = launch_gemm<EPI_GATES>(g, st)) != hipSuccess) return e;
-      g.A2 = rh; g.lda2 = H;
-      g.Wt = w.wc[l]; g.bias = w.bc[l]; g.N = H;
-      if (l == 0 && !rows) { g.add_tab = w.in_c; g.add_ld = H; }
-      g.cand_out = rec + (size_t)n_sess * 3 * H; g.ldc = H;
-      g.out = rec + (size_t)n_sess * 4 * H; g.ldo = H;
-      g.out2 = s_new + (size_t)l * H; g.ldo2 = HT;
-      g.gates = gates; g.ldg = 2 * H;
-      g.seq_len = seq_len; g.tstep = t;
-      if (l == w.nl - 1) { g.hid_out = hidden + (size_t)t * H; g.ldho = (int64_t)L * H; }
-      if ((e = launch_gemm<EPI_CAND>(g, st)) != hipSuccess) return e;
+    float* rec = recs + ((size_t)(t & 1) * w.nl + l) * cell;
+    memset(&g, 0, sizeof(g));
+    const float* hold = s_old + (size_t)l * H;
+    float* gates = rec;
+    float* rh = rec + (size_t)n_sess * 2 * H;
+    g.M = (int)n_sess; g.H = H;
+    if (l == 0 && rows) {
+      g.A1 = rows + (size_t)t * in_dim; g.lda1 = L * in_dim; g.K1 = in_dim;
+    } else if (l == 0) {
+      g.A1 = nullptr; g.lda1 = 0; g.K1 = 0;
+      g.add_tab = w.in_g; g.add_ld = 2 * H; g.add_n = w.N; g.add_ids = x + t; g.add_ids_ld = L;
+    } else {
+      g.A1 = recs + ((size_t)(t & 1) * w.nl + l - 1) * cell + (size_t)n_sess * 4 * H; g.lda1 = H; g.K1 = H;
     }
-  }
-  return hipSuccess;
+    g.A2 = hold; g.lda2 = HT; g.K2 = H;
+    g.Wt = w.wg[l]; g.bias = w.bg[l]; g.N = 2 * H;
+    g.out = gates; g.ldo = 2 * H; g.out2 = rh; g.ldo2 = H; g.h = hold; g.ldh = HT;
+    gc = g;
+    gc.A2 = rh; gc.lda2 = H;
+    gc.Wt = w.wc[l]; gc.bias = w.bc[l]; gc.N = H;
+    if (l == 0 && !rows) { gc.add_tab = w.in_c; gc.add_ld = H; }
+    gc.cand_out = rec + (size_t)n_sess * 3 * H; gc.ldc = H;
+    gc.out = rec + (size_t)n_sess * 4 * H; gc.ldo = H;
+    gc.out2 = s_new + (size_t)l * H; gc.ldo2 = HT;
+    gc.gates = gates; gc.ldg = 2 * H;
+    gc.seq_len = seq_len; gc.tstep = t;
+    if (l == w.nl - 1) { gc.hid_out = hidden + (size_t)t * H; gc.ldho = (int64_t)L * H; }
+  };
+  return records_wavefront(w.nl, L, cell_args, st);
 }
 
 // The same cells with EVERY record kept, fp32 output rows and the masters' fp32 kernels as they are (gmm_train.hip: the training step of model_gru_gmm):
