@@ -381,7 +381,7 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
   } else if ((e = copy_rows(state_in, HT, hist, hs, B, HT, st)) != hipSuccess) return e;
   // Wavefront over (slot, layer): cell (s, l) needs (s, l-1) and (s-1, l) only, so the cells with s + l = tau are independent -- layer 1
   // of slot s runs beside layer 0 of slot s + 1.  The critical path is S + nl - 1 cells instead of S * nl, and the independent cells of
-  // a step go out as ONE grouped launch per GEMM kind when they have one shape (layers >= 1 all do; layer 0 too when E == H): 2 (S + 1)
+  // a step go out as ONE grouped launch per GEMM kind (two cells each): 2 (S + 1)
   // dependent launches instead of 4 S for the reference's two layers -- the scan is latency-bound at the reference's batch sizes (§4.5).
   auto cell_args = [&](int s, int l, GemmArgs& gg, GemmArgs& gc) {
     memset(&gg, 0, sizeof(gg));
@@ -420,19 +420,11 @@ hipError_t launch_gru_scan(const ModelDev& m, const float* pooled, const float* 
       cell_args(s, l, gg[n], gc[n]);
       n++;
     }
-    // group cells of one shape (K1 may differ between layer 0 and the others when E != H: then they go out separately)
-    for (int i = 0; i < n;) {
-      int j = i + 1;
-      if (j < n && gg[j].K1 == gg[i].K1) j++;   // at most two per launch
-      if ((e = launch_gemm<EPI_GATES>(gg + i, j - i, st)) != hipSuccess) return e;
-      i = j;
-    }
-    for (int i = 0; i < n;) {
-      int j = i + 1;
-      if (j < n && gc[j].K1 == gc[i].K1) j++;
-      if ((e = launch_gemm<EPI_CAND>(gc + i, j - i, st)) != hipSuccess) return e;
-      i = j;
-    }
+    // two cells per launch: one (M, N) -- their reduction lengths may differ (layer 0 reads E inputs, the others H): every block reads its own arguments
+    for (int i = 0; i < n; i += 2)
+      if ((e = launch_gemm<EPI_GATES>(gg + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
+    for (int i = 0; i < n; i += 2)
+      if ((e = launch_gemm<EPI_CAND>(gc + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
   }
   if (sproj) {  // state half of the input projection for every slot at once: [B*(S+1), HT] x [HT, E]  (null: a caller without that projection, gmm_train.hip)
     GemmArgs g;
