@@ -319,7 +319,7 @@ def gmm_leg(rows=614_400, n_out=20_778, n_mix=5, dim=256, reps=5):
     return {"training": {"what": "one optimizer step of model_tcn_gmm (fixed scale, gmm_prob): fp32 forward on the masters + backward of every variable + TF-form "
                                  "Adam (csrc/gmm_train.hip: the head's backward through G_m = W_m W_m^T, no [rows][M D] matrix; block 0's one-hot rows as "
                                  "scatter-adds), 32 lanes x 200 steps = 6,400 rows, ids resident; ms_per_step_gru_gmm: the same step of model_gru_gmm "
-                                 "(2-layer GRU stack on the one-hot rows, backward through the 200 steps as a launch chain); ms_per_step_hier: model_hier with the mixture "
+                                 "(2-layer GRU stack on the one-hot rows, forward and backward through the 200 steps as a (step, layer) wavefront of launches); ms_per_step_hier: model_hier with the mixture "
                                  "model as its low level (hiertcn_gmm_train_step_hier: both levels in one step) at 32 lanes x 10 sessions x 20 steps, emb 128, "
                                  "2 x 128 across-session cells, tcn_gmm = TemporalConvNet [128, 128] K = 5, gru_gmm = 2 GRU layers of 128",
                          "rows": tB * tT, "ms_per_step": round(train_ms, 3), "rows_per_s": round(tB * tT / train_ms * 1e3),

@@ -239,7 +239,7 @@ class TcnGmmModel:
 
     def capture_train_graph(self, B: int, T: int, mode: Optional[str] = None) -> "GmmTrainGraph":
         """The forward + backward of one batch shape as a replayable hipGraph (torch.cuda.CUDAGraph on ROCm): model_gru_gmm's step is a chain of
-        ~2,800 small launches at T = 200 (seven per cell), whose host cost the replay removes.  Adam stays outside (its bias-corrected rate is a
+        ~1,000 small launches at T = 200 (five per anti-diagonal of the (step, layer) wavefront), whose host cost the replay removes (measured: no gain -- the kernels' own ~10 us each bound the chain).  Adam stays outside (its bias-corrected rate is a
         host scalar that changes every step): GmmTrainGraph.step = copy ids -> replay -> adam_step."""
         return GmmTrainGraph(self, B, T, mode)
 
