@@ -318,3 +318,62 @@ def test_warm_start_masks_and_evaluate_hier(tmp_path, data, monkeypatch):
     none = O.masked_loss_and_metrics(pred, y_id * 0, int(args.item_num))
     assert np.isnan(none["loss"])
 
+
+
+def test_run_hier_gmm_keeps_one_carried_state_per_loader_and_run_hiers_cadence(tmp_path):
+    """run_gmm_xing.run_hier_gmm / evaluate_hier_gmm over a fake model handle (no GPU): run_hier's cadence (run_hier_xing.py:261-349) -- per epoch
+    epoch_batches_train steps at the scheduled rate, each fed the state the PREVIOUS step returned (:301), one state per loader surviving across
+    evaluations and epochs (:241-243,332,343), evaluation every test_epoch, a checkpoint every save_epoch."""
+    import torch
+    from hiertcn_amd import checkpoint
+    from hiertcn_amd.args import hier_tcn_args
+    from hiertcn_amd.run_gmm_xing import run_hier_gmm
+
+    class Fake:
+        device = torch.device("cpu")
+        params = {"hier/emb/kernel": np.zeros((3, 2), np.float32)}
+
+        def __init__(self):
+            self.train_states, self.eval_states, self.lrs, self.enabled = [], [], [], False
+
+        def enable_training(self):
+            self.enabled = True
+
+        def train_step_hier(self, xd, yd, md, st, lr):
+            assert self.enabled and xd.dtype == torch.int32 and md.dtype == torch.float32
+            self.train_states.append(float(st[0, 0]))
+            self.lrs.append(lr)
+            return dict(state=st + 1.0, sums=torch.tensor([3.0, 2.0], dtype=torch.float64))
+
+        def eval_step_hier(self, xd, yd, md, st):
+            self.eval_states.append(float(st[0, 0]))
+            return dict(state=st + 100.0, sums=torch.tensor([5.0, 2.0], dtype=torch.float64))
+
+        def export(self, which):
+            return {"hier/emb/kernel": np.full((3, 2), float(len(self.train_states)), np.float32)}
+
+    class Loader:
+        def __init__(self, n):
+            self.n, self.i, self.done = n, 0, False
+
+        def get_packed_batch(self):
+            self.i += 1
+            self.done = self.i % self.n == 0
+            z = np.ones((4, 2, 3), np.int32)
+            return z, z, np.ones((4, 2), np.float32), [3, 3]
+
+    a = hier_tcn_args(item_num=50, emb_dim=64, hidden_dim=64, num_layer=2, batch_size=4, model_low_type="tcn_gmm", loss="gmm_prob")
+    a.log_path, a.save_path, a.load_path, a.name = str(tmp_path) + "/log/", str(tmp_path) + "/model/", str(tmp_path) + "/model/", "t"
+    os.makedirs(a.save_path)
+    a.train, a.validate, a.test, a.load, a.save = True, False, True, False, True
+    a.epoch_max, a.epoch_batches_train, a.test_epoch, a.save_epoch, a.lr_schedule, a.learning_rate = 2, 3, 1, 2, False, 0.5
+    fake = Fake()
+    run_hier_gmm(a, Loader(10 ** 9), None, Loader(2), sess=fake)
+    assert fake.train_states == [float(i) for i in range(9)]            # 3 epochs x 3 steps, the state handed on from step to step and epoch to epoch
+    assert fake.lrs == [0.5] * 9
+    assert fake.eval_states == [0.0, 100.0, 200.0, 300.0]               # epochs 1 and 2 (not 0), two batches each: the test loader's own state, carried across evaluations
+    saved = checkpoint.load(a.save_path + "2.ckpt")
+    assert float(saved["hier/emb/kernel"][0, 0]) == 9.0                 # written after epoch 2's steps
+    assert not os.path.exists(a.save_path + "1.ckpt")
+    lines = open(a.log_path + "test/scalars.jsonl").read().splitlines()
+    assert len(lines) == 2 and all(abs(__import__("json").loads(l)["value"] - 2.5) < 1e-12 for l in lines)
