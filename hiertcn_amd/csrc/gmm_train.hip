@@ -172,31 +172,6 @@ __global__ __launch_bounds__(256) void k_gt_block0_bwd(const float* __restrict__
   }
 }
 
-// trunk 1, first pointwise step of a cell's backward under dynamic_rnn's sequence_length (train.hip's k_lgru_bwd_a) in the form the FUSED products
-// of gemm.hip need (gemm32_nn_gru_bwd: the other two pointwise steps ride on the two products' epilogues, three launches per cell instead of five):
-// an inactive row (t >= sequence_length) neither produced an output nor moved its state -- its dac / dag rows are zero, and its carried state
-// gradient passes through as dhpart, which the second product's epilogue then writes out unchanged (0 . W + dhpart).
-struct GtBwdA {
-  const float* dcar; int ldd; const float* dout; int64_t ld_dout; int tstep; const float* h; int ldh; const float* gates; const float* cand;
-  float* dac; float* dag; float* dhpart;
-};
-struct GtBwdAPair { GtBwdA a[2]; };   // the cells of one anti-diagonal of the backward through time: blockIdx.y
-__global__ void k_gt_gru_bwd_a(const GtBwdAPair p, const int32_t* __restrict__ seq_len, int M, int H) {
-  const GtBwdA& a = p.a[blockIdx.y];
-  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (int64_t)M * H) return;
-  const int64_t b = i / H;
-  const int k = (int)(i - b * H);
-  const bool active = a.tstep < seq_len[b];
-  const float car = a.dcar[b * a.ldd + k];
-  const float d = active ? car + a.dout[b * a.ld_dout + k] : 0.f;
-  const float u = a.gates[b * 2 * H + H + k], c = a.cand[i], hv = a.h[b * a.ldh + k];
-  a.dac[i] = d * (1.f - u) * (1.f - c * c);
-  a.dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
-  a.dag[b * 2 * H + k] = 0.f;                    // (the r half is written by the first product's epilogue for every row; zero here in case M exceeds a tile edge)
-  a.dhpart[i] = active ? d * u : car;
-}
-
 // trunk 1, layer 0: the input half of [x, h] . W on a one-hot row is the table row W[id] (model_gru_gmm.py:33-48 on one_hot(id) * sign(id)); its gradient is a
 // scatter-add of the cell's pre-activation gradients into that row.  dac [L][M][H] (candidate), dag [L][M][2H] (gates); rows (t, m); zero where a row was inactive.
 __global__ __launch_bounds__(256) void k_gt_gru_in_scatter(const float* __restrict__ dac, const float* __restrict__ dag, const int32_t* __restrict__ ids, int M,
@@ -1096,56 +1071,18 @@ static int gt_step_core(hiertcn_gmm_ctx* g, const int32_t* x_ids, const float* r
     G_HIP(hipMemsetAsync(lcar, 0, (size_t)Mb * HT * 4, st));   // the final state is dropped (model_gru_gmm.py:47: outputs only)
     const bool fused = Mb <= gemm32_skinny_max_rows();
     const size_t Kmax_ws = (g->trunk == 3 && (size_t)in0 + Hh > 2 * (size_t)Hh) ? (size_t)in0 + Hh : 2 * (size_t)Hh;   // (gt_ws' pitch of the per-layer scratch)
-    if (fused) {
-      // Wavefront over (step, layer), last to first: cell (tt, l) needs (tt + 1, l) [the carried state gradient] and (tt, l + 1) [its output's gradient]
-      // only, so the cells with tt + l = const are independent and go out together -- three launches per anti-diagonal (the pointwise step, the two
-      // products with the other two pointwise steps as epilogues: gemm32_nn_gru_bwd_n), 3 (L + nl - 1) dependent launches instead of 3 L nl.  The carried
-      // gradient alternates between two [M][HT] buffers by the parity of tt (cell (tt, l) reads slot (tt + 1) & 1, writes slot tt & 1, columns of layer l).
-      float* car[2] = {F32(w.dcar[0]), F32(w.dcar[1])};
-      G_HIP(hipMemsetAsync(car[1], 0, (size_t)Mb * HT * 4, st));
-      for (int tau = 0; tau < L + nl - 1; tau++) {
-        GtBwdAPair pa;
-        GruBwdProd p1[HIERTCN_MAX_LAYERS], p2[HIERTCN_MAX_LAYERS];
-        GtBwdA aa[HIERTCN_MAX_LAYERS];
-        int n = 0;
-        for (int l = nl - 1; l >= 0; l--) {
-          const int tt = (L - 1) - (tau - (nl - 1 - l));
-          if (tt < 0 || tt >= L) continue;
-          const int in = (l == 0) ? in0 : Hh, Kc = in + Hh;
-          float* din_l = din_up + (size_t)l * Mb * Hh;                              // written by layer l (its input's gradient), read by layer l - 1
-          float* d_in = (l == 0) ? (in0 ? d_rows + (size_t)tt * in0 : din_l) : din_l;
-          const int64_t ld_d_in = (l == 0 && in0) ? (int64_t)L * in0 : Hh;
-          const float* rec = recs + ((size_t)tt * nl + l) * cell;
-          const float* gates = rec;
-          const float* cand = rec + (size_t)Mb * 3 * Hh;
-          const float* hold = states + (size_t)tt * Mb * HT + (size_t)l * Hh;   // row stride HT
-          float* dac = dac_all + ((size_t)l * L + tt) * Mb * Hh;
-          float* dag = dag_all + ((size_t)l * L + tt) * Mb * 2 * Hh;
-          float* dhp = dhpart + (size_t)l * Mb * Hh;
-          float* dcc = dcat_c + (size_t)l * Mb * Kmax_ws;
-          GtBwdA& a = aa[n];
-          a.dcar = car[(tt + 1) & 1] + (size_t)l * Hh; a.ldd = HT;
-          a.dout = (l == nl - 1) ? dHid + (size_t)tt * Hh : din_up + (size_t)(l + 1) * Mb * Hh;
-          a.ld_dout = (l == nl - 1) ? (int64_t)L * Hh : Hh;
-          a.tstep = tt; a.h = hold; a.ldh = HT; a.gates = gates; a.cand = cand; a.dac = dac; a.dag = dag; a.dhpart = dhp;
-          GruBwdEpi ep;
-          memset(&ep, 0, sizeof(ep));
-          ep.in = in; ep.H = Hh; ep.K = Kc;
-          ep.gates = gates; ep.h = hold; ep.ldh = HT; ep.dag = dag; ep.dhpart = dhp; ep.dcat_c = dcc;
-          ep.dst_in = d_in; ep.ldi = (int)ld_d_in; ep.dst_h = car[tt & 1] + (size_t)l * Hh; ep.ldo = HT;
-          p1[n].A = dac; p1[n].lda = Hh; p1[n].B = t->wc[l]; p1[n].ldb = Kc; p1[n].M = Mb; p1[n].N = Kc; p1[n].K = Hh; p1[n].ep = ep;          // d [in | r*h] = dac . wc, then step b
-          p2[n].A = dag; p2[n].lda = 2 * Hh; p2[n].B = t->wg[l]; p2[n].ldb = Kc; p2[n].M = Mb; p2[n].N = Kc; p2[n].K = 2 * Hh; p2[n].ep = ep;    // d [in | h] = dag . wg, then step c
-          n++;
-        }
-        for (int i = 0; i < n; i += 2) {
-          const int k = (n - i) > 1 ? 2 : 1;
-          pa.a[0] = aa[i]; pa.a[1] = aa[i + k - 1];
-          hipLaunchKernelGGL(k_gt_gru_bwd_a, dim3((unsigned)(((int64_t)Mb * Hh + 255) / 256), k), dim3(256), 0, st, pa, seq_len, Mb, Hh);
-          G_HIP(hipGetLastError());
-        }
-        for (int i = 0; i < n; i += 2) G_HIP(gemm32_nn_gru_bwd_n(1, p1 + i, (n - i) > 1 ? 2 : 1, st));
-        for (int i = 0; i < n; i += 2) G_HIP(gemm32_nn_gru_bwd_n(2, p2 + i, (n - i) > 1 ? 2 : 1, st));
-      }
+    if (fused) {   // the (step, layer) wavefront with fused epilogues (train.hip, train_lgru_bptt_wavefront): 3 (L + nl - 1) dependent launches instead of 3 L nl
+      LgruBptt bp;
+      memset(&bp, 0, sizeof(bp));
+      bp.nl = nl; bp.L = L; bp.M = Mb; bp.H = Hh; bp.in0 = in0;
+      for (int l = 0; l < nl; l++) { bp.wc[l] = t->wc[l]; bp.wg[l] = t->wg[l]; }
+      bp.seq_len = seq_len; bp.states = states; bp.recs = recs;
+      bp.d_out = dHid; bp.ld_d_out = (int64_t)L * Hh;
+      bp.d_in0 = d_rows; bp.ld_d_in0 = (int64_t)L * in0;
+      bp.dac_all = dac_all; bp.dag_all = dag_all;
+      bp.car[0] = F32(w.dcar[0]); bp.car[1] = F32(w.dcar[1]); bp.dhpart = dhpart; bp.din_up = din_up;
+      bp.dcat_c = dcat_c; bp.dcat_pitch = (size_t)Mb * Kmax_ws;
+      G_HIP(train_lgru_bptt_wavefront(bp, st));
     }
     for (int tt = L - 1; tt >= 0 && !fused; tt--) {   // more lanes than the skinny products take: the five-launch cells, one after the other
       for (int l = nl - 1; l >= 0; l--) {

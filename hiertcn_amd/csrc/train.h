@@ -78,3 +78,24 @@ hipError_t train_gru_bwd_b(const float* dcat_c, int K, int in, const float* h, i
                            hipStream_t st);
 hipError_t train_lgru_bwd_c(const float* dcat_c, const float* dcat_g, int K, int in, const float* dhpart, int M, int H, float* dst_in, int64_t ldi, float* dst_h,
                             int ldo, const float* dcar, const int32_t* seq_len, int tstep, hipStream_t st);
+
+// Backward through time of a GRU stack under dynamic_rnn's sequence_length as a (step, layer) WAVEFRONT (train.hip): cell (t, l) needs (t + 1, l) [the carried
+// state gradient] and (t, l + 1) [its output's gradient] only, so the cells with t + l = const share their launches, two cells each -- one pointwise step and the
+// two skinny fp32 products whose epilogues carry the other two pointwise steps (gemm32_nn_gru_bwd_n): 3 (L + nl - 1) dependent launches instead of 5 L nl.
+// M <= gemm32_skinny_max_rows().  Every cell's pre-activation gradients are kept (dac_all [nl][L][M][H], dag_all [nl][L][M][2H]) for the weight gradients behind.
+struct LgruBptt {
+  int nl, L, M, H;
+  int in0;                                   // layer 0's dense input width (0: a one-hot input -- no dense input half)
+  const float* wc[HIERTCN_MAX_LAYERS];       // [H][in_l + H]  (output-major candidate kernels)
+  const float* wg[HIERTCN_MAX_LAYERS];       // [2H][in_l + H]
+  const int32_t* seq_len;
+  const float* states;                       // [L + 1][M][H nl]: the state before step t
+  const float* recs;                         // [L][nl][gates 2H | r*h H | cand H | out H per row]
+  const float* d_out; int64_t ld_d_out;      // the top layer's output gradient: row m of step t at d_out + t * H + m * ld_d_out
+  float* d_in0; int64_t ld_d_in0;            // gradient of layer 0's dense input rows (row m of step t at d_in0 + t * in0 + m * ld_d_in0); unused when in0 == 0
+  float* dac_all; float* dag_all;
+  float* car[2];                             // [M][H nl] each: the carried state gradient by the step's parity (both are overwritten)
+  float* dhpart; float* din_up;              // [nl][M][H] each
+  float* dcat_c; size_t dcat_pitch;          // [nl][dcat_pitch] floats, dcat_pitch >= M * max_l (in_l + H)
+};
+hipError_t train_lgru_bptt_wavefront(const LgruBptt& b, hipStream_t st);

@@ -792,8 +792,8 @@ static TrainWs train_ws(const ModelDev& m, int B, int S, int L) {
     w.lg_bwd = take(lgru_wide_bwd_bytes(m, (int64_t)M, L));
     w.lg_dcar[0] = take(M * HT * 4); w.lg_dcar[1] = take(M * HT * 4);
     const size_t cells = lgru_deferred_wgrad(m, M, L) ? (size_t)m.nl * L : 1;
-    w.lg_dac = take(cells * M * H * 4); w.lg_dag = take(cells * M * 2 * H * 4); w.lg_dhpart = take(M * H * 4);
-    w.lg_dcat_c = take(M * Kmax * 4); w.lg_dcat_g = take(M * Kmax * 4); w.lg_din_up = take(M * H * 4);
+    w.lg_dac = take(cells * M * H * 4); w.lg_dag = take(cells * M * 2 * H * 4); w.lg_dhpart = take((size_t)m.nl * M * H * 4);   // (per layer: train_lgru_bptt_wavefront)
+    w.lg_dcat_c = take((size_t)m.nl * M * Kmax * 4); w.lg_dcat_g = take(M * Kmax * 4); w.lg_din_up = take((size_t)m.nl * M * H * 4);
   }
   if (m.train_fp32) {
     for (int i = 0; i <= m.n_blocks; i++) w.f_act[i] = take(R * C * 4);
@@ -1166,7 +1166,23 @@ int train_forward_backward(const ModelDev& m, TrainCtx& t, const int32_t* x, con
     if (tile_bwd && lgru_wide_bwd_applies(m, (int64_t)M) && lgru_wide_bwd_bytes(m, (int64_t)M, L) > 0)   // H = 128 / 256: HB workgroups per (tile, layer), weights in registers, layers pipelined
       T_HIP(launch_lgru_wide_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, ws + w.lg_bwd, st));
     else if (tile_bwd) T_HIP(launch_lgru_tile_bwd(m, dH, lb.seq_len, lst, lrec, (int64_t)M, L, du, dac_all, dag_all, st));
-    for (int tt = L - 1; tt >= 0 && !tile_bwd; tt--) {
+    // the launch chain (the fp32 mode; batches the one-launch forms do not take): with every cell's pre-activation gradients kept and few enough rows for the
+    // skinny products, the (step, layer) wavefront with fused epilogues -- 3 (L + nl - 1) dependent launches; otherwise five launches per cell, one after the other
+    const bool wave_bwd = !tile_bwd && deferred && M <= gemm32_skinny_max_rows();
+    if (wave_bwd) {
+      LgruBptt bp;
+      memset(&bp, 0, sizeof(bp));
+      bp.nl = m.nl; bp.L = L; bp.M = M; bp.H = H; bp.in0 = E;
+      for (int l = 0; l < m.nl; l++) { bp.wc[l] = m.lgru_wc[l]; bp.wg[l] = m.lgru_wg[l]; }
+      bp.seq_len = lb.seq_len; bp.states = lst; bp.recs = lrec;
+      bp.d_out = dH; bp.ld_d_out = (int64_t)L * H;
+      bp.d_in0 = du; bp.ld_d_in0 = (int64_t)L * E;
+      bp.dac_all = dac_all; bp.dag_all = dag_all;
+      bp.car[0] = lcar; bp.car[1] = lnext; bp.dhpart = dhpart; bp.din_up = din_up;
+      bp.dcat_c = dcat_c; bp.dcat_pitch = (size_t)M * ((size_t)(E > H ? E : H) + H);
+      T_HIP(train_lgru_bptt_wavefront(bp, st));
+    }
+    for (int tt = L - 1; tt >= 0 && !tile_bwd && !wave_bwd; tt--) {
       for (int l = m.nl - 1; l >= 0; l--) {
         const int in = (l == 0) ? E : H;
         const int K = in + H;
@@ -1506,6 +1522,86 @@ hipError_t train_adam_flat(float* p, const float* g, float* m1, float* m2, size_
   hipLaunchKernelGGL(k_adam, dim3((unsigned)blocks), dim3(256), 0, st, p, g, m1, m2, n, lr_t, beta1, beta2, eps, grad_scale);
   return hipGetLastError();
 }
+// first pointwise step of a cell's backward under dynamic_rnn's sequence_length (k_lgru_bwd_a) in the form the FUSED products of gemm.hip need: an inactive
+// row (t >= sequence_length) neither produced an output nor moved its state -- its dac / dag rows are zero, and its carried state gradient passes through as
+// dhpart, which the second product's epilogue then writes out unchanged (0 . W + dhpart).  Up to two cells per launch (blockIdx.y).
+struct LgruBwdA {
+  const float* dcar; int ldd; const float* dout; int64_t ld_dout; int tstep; const float* h; int ldh; const float* gates; const float* cand;
+  float* dac; float* dag; float* dhpart;
+};
+struct LgruBwdAPair { LgruBwdA a[2]; };
+__global__ void k_lgru_bwd_a_fused(const LgruBwdAPair p, const int32_t* __restrict__ seq_len, int M, int H) {
+  const LgruBwdA& a = p.a[blockIdx.y];
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (int64_t)M * H) return;
+  const int64_t b = i / H;
+  const int k = (int)(i - b * H);
+  const bool active = a.tstep < seq_len[b];
+  const float car = a.dcar[b * a.ldd + k];
+  const float d = active ? car + a.dout[b * a.ld_dout + k] : 0.f;
+  const float u = a.gates[b * 2 * H + H + k], c = a.cand[i], hv = a.h[b * a.ldh + k];
+  a.dac[i] = d * (1.f - u) * (1.f - c * c);
+  a.dag[b * 2 * H + H + k] = d * (hv - c) * u * (1.f - u);
+  a.dag[b * 2 * H + k] = 0.f;                    // (the r half is written by the first product's epilogue for every row; zero here in case M exceeds a tile edge)
+  a.dhpart[i] = active ? d * u : car;
+}
+
+hipError_t train_lgru_bptt_wavefront(const LgruBptt& b, hipStream_t st) {
+  const int nl = b.nl, L = b.L, M = b.M, H = b.H, HT = b.H * b.nl;
+  if (M <= 0 || M > gemm32_skinny_max_rows() || nl < 1 || nl > HIERTCN_MAX_LAYERS) return hipErrorInvalidValue;
+  const size_t cell = (size_t)M * 5 * H;
+  hipError_t e;
+  // the carried gradient alternates between two buffers by the parity of t: cell (t, l) reads slot (t + 1) & 1, writes slot t & 1, columns of layer l; the
+  // final state is dropped (model_gru.py:47 / model_gru_gmm.py:47: outputs only), so both start from zero
+  for (int i = 0; i < 2; i++)
+    if ((e = hipMemsetAsync(b.car[i], 0, (size_t)M * HT * 4, st)) != hipSuccess) return e;
+  for (int tau = 0; tau < L + nl - 1; tau++) {
+    GruBwdProd p1[HIERTCN_MAX_LAYERS], p2[HIERTCN_MAX_LAYERS];
+    LgruBwdA aa[HIERTCN_MAX_LAYERS];
+    int n = 0;
+    for (int l = nl - 1; l >= 0; l--) {
+      const int tt = (L - 1) - (tau - (nl - 1 - l));
+      if (tt < 0 || tt >= L) continue;
+      const int in = (l == 0) ? b.in0 : H, Kc = in + H;
+      float* din_l = b.din_up + (size_t)l * M * H;                               // written by layer l (its input's gradient), read by layer l - 1
+      float* d_in = (l == 0 && b.in0) ? b.d_in0 + (size_t)tt * b.in0 : din_l;
+      const int64_t ld_d_in = (l == 0 && b.in0) ? b.ld_d_in0 : H;
+      const float* rec = b.recs + ((size_t)tt * nl + l) * cell;
+      const float* gates = rec;
+      const float* cand = rec + (size_t)M * 3 * H;
+      const float* hold = b.states + (size_t)tt * M * HT + (size_t)l * H;       // row stride HT
+      float* dac = b.dac_all + ((size_t)l * L + tt) * M * H;
+      float* dag = b.dag_all + ((size_t)l * L + tt) * M * 2 * H;
+      float* dhp = b.dhpart + (size_t)l * M * H;
+      LgruBwdA& a = aa[n];
+      a.dcar = b.car[(tt + 1) & 1] + (size_t)l * H; a.ldd = HT;
+      a.dout = (l == nl - 1) ? b.d_out + (size_t)tt * H : b.din_up + (size_t)(l + 1) * M * H;
+      a.ld_dout = (l == nl - 1) ? b.ld_d_out : H;
+      a.tstep = tt; a.h = hold; a.ldh = HT; a.gates = gates; a.cand = cand; a.dac = dac; a.dag = dag; a.dhpart = dhp;
+      GruBwdEpi ep;
+      memset(&ep, 0, sizeof(ep));
+      ep.in = in; ep.H = H; ep.K = Kc;
+      ep.gates = gates; ep.h = hold; ep.ldh = HT; ep.dag = dag; ep.dhpart = dhp; ep.dcat_c = b.dcat_c + (size_t)l * b.dcat_pitch;
+      ep.dst_in = d_in; ep.ldi = (int)ld_d_in; ep.dst_h = b.car[tt & 1] + (size_t)l * H; ep.ldo = HT;
+      p1[n].A = dac; p1[n].lda = H; p1[n].B = b.wc[l]; p1[n].ldb = Kc; p1[n].M = M; p1[n].N = Kc; p1[n].K = H; p1[n].ep = ep;            // d [in | r*h] = dac . wc, then step b
+      p2[n].A = dag; p2[n].lda = 2 * H; p2[n].B = b.wg[l]; p2[n].ldb = Kc; p2[n].M = M; p2[n].N = Kc; p2[n].K = 2 * H; p2[n].ep = ep;    // d [in | h] = dag . wg, then step c
+      n++;
+    }
+    for (int i = 0; i < n; i += 2) {
+      const int k = (n - i) > 1 ? 2 : 1;
+      LgruBwdAPair pa;
+      pa.a[0] = aa[i]; pa.a[1] = aa[i + k - 1];
+      hipLaunchKernelGGL(k_lgru_bwd_a_fused, dim3((unsigned)(((int64_t)M * H + 255) / 256), k), dim3(256), 0, st, pa, b.seq_len, M, H);
+      if ((e = hipGetLastError()) != hipSuccess) return e;
+    }
+    for (int i = 0; i < n; i += 2)
+      if ((e = gemm32_nn_gru_bwd_n(1, p1 + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
+    for (int i = 0; i < n; i += 2)
+      if ((e = gemm32_nn_gru_bwd_n(2, p2 + i, (n - i) > 1 ? 2 : 1, st)) != hipSuccess) return e;
+  }
+  return hipSuccess;
+}
+
 // the pointwise pieces of a GRU cell's backward under dynamic_rnn's sequence_length (k_lgru_bwd_a / k_gru_bwd_b / k_lgru_bwd_c above)
 hipError_t train_lgru_bwd_a(const float* dcar, int ldd, const float* dout, int64_t ld_dout, const int32_t* seq_len, int tstep, const float* h, int ldh,
                             const float* gates, const float* cand, int M, int H, float* dac, float* dag, float* dhpart, hipStream_t st) {
