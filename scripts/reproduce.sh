@@ -72,3 +72,4 @@ python3 scripts/single_level_bench.py 2>&1 | grep single-level
 echo "== mixture models' TRAINING step (csrc/gmm_train.hip): 32 lanes x 200 steps, XING catalogue, d = 256, 5 mixtures: model_tcn_gmm, model_gru_gmm, model_tcn_gmm with a learned scale"
 python3 scripts/gmm_train_bench.py tcn 20 2>&1 | tail -1; python3 scripts/gmm_train_bench.py gru 5 2>&1 | tail -1; python3 scripts/gmm_train_bench.py tcn 5 learned 2>&1 | tail -1
 echo "== soak of the mixture training step (repeatable forward, two handles on one trajectory, evaluation after sync)"; python3 scripts/soak_gmm_train.py tcn 20 50 2>&1 | grep -v amdgpu.ids | tail -4
+echo "== ... and of model_hier's step with a mixture low level (the state carried from step to step)"; for l in tcn_gmm gru_gmm; do python3 scripts/soak_hier_gmm_train.py $l 20 50 2>&1 | grep -v amdgpu.ids | tail -4 | head -3; done
