@@ -522,7 +522,8 @@ def torch_gru_loss(a, P, x, y, mode, scope="rnn_gmm"):
 
 @pytest.mark.parametrize("mode", ["gmm_prob", "gmm_prob_max"])
 @pytest.mark.parametrize("N,M,H,nl,B,T", [(303, 3, 64, 1, 5, 9), (500, 2, 64, 2, 6, 12), (900, 4, 128, 2, 4, 15), (20_778, 5, 256, 2, 3, 7),
-                                         (300, 2, 64, 2, 4100, 3)])   # (more lanes than the skinny products take: the five-launch cells of the backward)
+                                         (300, 2, 64, 2, 4100, 3),    # (more lanes than the skinny products take: the five-launch cells of the backward)
+                                         (350, 2, 64, 3, 4, 10), (280, 2, 64, 4, 3, 6)])   # three / four layers: anti-diagonals of the wavefront with an odd cell, two pairs
 def test_gru_trunk_every_gradient_against_fp64_autograd(N, M, H, nl, B, T, mode):
     from hiertcn_amd.model_gru_gmm import GruGmmModel
     a = _gru_args(N, M, H, nl, loss=mode)
