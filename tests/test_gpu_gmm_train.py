@@ -766,7 +766,9 @@ def torch_hier_loss(a, P, x, y, mask, st0, mode, scope="hier", kinks=None):
                                                              ("gru_gmm", 900, 64, 64, 2, 3, (64,), 3, 5, 4, 7), ("gru_gmm", 600, 64, 128, 1, 2, (64,), 3, 4, 3, 9),
                                                              # the reference's defaults (args.py: emb 128, hidden 128 x 2, [128, 128] K = 5, 5 mixtures, the XING catalogue)
                                                              ("tcn_gmm", 20_778, 128, 128, 2, 5, (128, 128), 5, 4, 3, 20),
-                                                             ("gru_gmm", 20_778, 128, 128, 2, 5, (128,), 5, 4, 3, 20)])
+                                                             ("gru_gmm", 20_778, 128, 128, 2, 5, (128,), 5, 4, 3, 20),
+                                                             # three layers at both levels: anti-diagonals of the two wavefronts with an odd cell
+                                                             ("gru_gmm", 450, 64, 64, 3, 2, (64,), 3, 3, 4, 5), ("tcn_gmm", 450, 64, 32, 3, 2, (64, 64), 3, 3, 4, 5)])
 def test_hier_low_level_every_gradient_against_fp64_autograd(low, N, E, H, nl, M, channels, K, B, S, L, mode):
     _hier_gradient_case(low, N, E, H, nl, M, channels, K, B, S, L, mode, 0.1)
 
