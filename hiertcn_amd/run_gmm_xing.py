@@ -144,6 +144,10 @@ def evaluate_hier_gmm(args, loader, state, sess, prefix="test"):
         step["loss"] = s[0] / s[1] if s[1] > 0 else nan
         meter.add(step)
 
+    # the high level runs on the main handle, whose across-session scan is a persistent launch at these batch sizes: its health word is polled where
+    # evaluate_hier polls it (every 20 batches, without a synchronisation) and read once at the end -- a timed-out launch never reports metrics
+    from .run_hier_xing import _HealthWatch, _check_persistent_health
+    health = _HealthWatch(model, "evaluation epoch '%s'" % prefix)
     pending = None
     while True:
         t1 = time.time()
@@ -152,6 +156,7 @@ def evaluate_hier_gmm(args, loader, state, sess, prefix="test"):
         xd, yd, md = _dev_batch(model, x, y, mask)
         out = model.eval_step_hier(xd, yd, md, state)
         state = out["state"]
+        health.after_batch()
         if pending is not None:
             add(pending)
         pending = out["sums"]
@@ -161,6 +166,7 @@ def evaluate_hier_gmm(args, loader, state, sess, prefix="test"):
         if loader.done:
             break
     add(pending)
+    _check_persistent_health(model, "evaluation epoch '%s'" % prefix)
     return meter.finish(), time_load, time_run, state
 
 
