@@ -150,16 +150,19 @@ def test_pipelined_loops_equal_the_blocking_ones(tmp_path):
     assert losses[0][-1] < losses[0][0]
 
 
-def test_a_timed_out_persistent_launch_stops_the_epoch_within_twenty_batches(tmp_path):
-    """run_hier_xing.py's health watch: evaluate_hier over 60 batches against the test-hooks library, the scan of batch 3 timing out -- the loop raises
-    at the first check behind it (batches 20-22), not at the end of the epoch, and the handle works again afterwards (tests/tools/health_watch_probe.py)."""
+@pytest.mark.parametrize("loop", ["hier", "gmm"])
+def test_a_timed_out_persistent_launch_stops_the_epoch_within_twenty_batches(tmp_path, loop):
+    """run_hier_xing.py's health watch: evaluate_hier (and run_gmm_xing.evaluate_hier_gmm, which shares it) over 60 batches against the test-hooks library,
+    the scan of batch 3 timing out -- the loop raises at the first check behind it (batches 20-22), not at the end of the epoch, and the handle works again
+    afterwards (tests/tools/health_watch_probe.py)."""
     import subprocess
     import sys
     from hiertcn_amd.build import LIB_TESTHOOKS
     root = os.path.dirname(HERE)
     env = dict(os.environ, HIERTCN_LIB=LIB_TESTHOOKS)
     env.pop("HIERTCN_EVAL_SERIAL", None)
-    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "health_watch_probe.py"), str(tmp_path)], env=env, capture_output=True, text=True,
+    r = subprocess.run([sys.executable, os.path.join(root, "tests", "tools", "health_watch_probe.py"), str(tmp_path)] + (["gmm"] if loop == "gmm" else []), env=env,
+                       capture_output=True, text=True,
                        timeout=600)
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("HEALTH_WATCH_PROBE")]
     assert r.returncode == 0 and len(lines) == 2, (r.stdout[-1500:], r.stderr[-1500:])

@@ -46,6 +46,43 @@ class Sixty:
         return self.i >= self.n
 
 
+if len(sys.argv) > 2 and sys.argv[2] == "gmm":
+    # the same watch in run_gmm_xing.evaluate_hier_gmm (model_hier with a mixture low level: the high level's scan runs on the MAIN handle, persistent)
+    import torch
+
+    from hiertcn_amd.model_hier_gmm import HierGmmModel
+    from hiertcn_amd.run_gmm_xing import evaluate_hier_gmm
+    args.model_low_type, args.loss, args.num_mixture, args.sigma, args.output_dim, args.kernel_size = "tcn_gmm", "gmm_prob", 3, 0.1, n_items, 3
+    gm = HierGmmModel(args, None, "hier")
+    assert gm.engine.get_tuning()["gru_scan_persistent"] == -1
+    calls = {"n": 0, "bad": 3}
+    step = gm.eval_step_hier
+
+    def faulty_step(*a, **k):
+        calls["n"] += 1
+        if calls["n"] == calls["bad"]:
+            os.environ["HIERTCN_GRU_TEST_MISSING_WG"] = "1"
+        try:
+            return step(*a, **k)
+        finally:
+            os.environ.pop("HIERTCN_GRU_TEST_MISSING_WG", None)
+
+    gm.eval_step_hier = faulty_step
+    zero = lambda: torch.zeros((4, 128), dtype=torch.float32, device="cuda")  # noqa: E731
+    ld = Sixty()
+    try:
+        evaluate_hier_gmm(args, ld, zero(), gm, prefix="test")
+    except RuntimeError as e:
+        m = re.search(r"by batch (\d+)", str(e))
+        assert m and "timed out" in str(e), str(e)
+        print("HEALTH_WATCH_PROBE", int(m.group(1)), ld.i)
+        calls["bad"] = -1
+        evaluate_hier_gmm(args, Sixty(n=25), zero(), gm, prefix="test")
+        print("HEALTH_WATCH_PROBE recovered")
+        sys.exit(0)
+    print("HEALTH_WATCH_PROBE no exception after", ld.i, "batches")
+    sys.exit(1)
+
 model = HierTCNModel(args, make_params(args))
 assert model.engine.get_tuning()["gru_scan_persistent"] == -1
 # the fault switch of the test-hooks build is looked up when the scan is LAUNCHED: up for the launch of batch 3 alone
